@@ -1,0 +1,420 @@
+// ref_driver.cc — TEST INFRASTRUCTURE (oracle/_ref build only).
+//
+// Thin extern "C" driver over the REFERENCE's own classes, compiled against the
+// reference headers/sources where they lie under /root/reference/src (see
+// oracle/Makefile).  It contains no algorithm: each ref_* function copies its
+// dense arguments into the reference's Matrix/CuMatrix (HAVE_CUDA undefined ->
+// CPU branch), calls the reference function named in its comment, and copies
+// the result back.  Signatures mirror the ko_* functions of kaldi_oracle.h so
+// the same Python wrappers can drive both.
+//
+// Used by tests/golden/make_golden.py (in the build container) to generate the
+// golden vectors, by tests/test_oracle_vs_ref.py, and (optionally) as bench.py's
+// cpu_baseline kind "reference" for the nnet2 forward / GMM part.
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cudamatrix/cu-math.h"
+#include "cudamatrix/cu-matrix-lib.h"
+#include "gmm/diag-gmm.h"
+#include "matrix/matrix-lib.h"
+#include "nnet2/nnet-component.h"
+#include "nnet2/nnet-nnet.h"
+
+#include "kaldi_oracle.h"  // KoComponent
+
+using namespace kaldi;
+using namespace kaldi::nnet2;
+
+namespace {
+
+Matrix<BaseFloat> In(const float *p, int rows, int cols, int stride) {
+  Matrix<BaseFloat> m(rows, cols, kUndefined);
+  for (int r = 0; r < rows; r++)
+    memcpy(m.RowData(r), p + static_cast<size_t>(r) * stride,
+           sizeof(float) * cols);
+  return m;
+}
+void Out(const MatrixBase<BaseFloat> &m, float *p, int stride) {
+  for (int r = 0; r < m.NumRows(); r++)
+    memcpy(p + static_cast<size_t>(r) * stride, m.RowData(r),
+           sizeof(float) * m.NumCols());
+}
+Vector<BaseFloat> InV(const float *p, int dim) {
+  Vector<BaseFloat> v(dim, kUndefined);
+  memcpy(v.Data(), p, sizeof(float) * dim);
+  return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+// MatrixBase::AddMatMat matrix/kaldi-matrix.cc:160-175 via CuMatrix CPU branch
+// cudamatrix/cu-matrix.cc:977-981.
+void ref_add_mat_mat(float alpha, const float *A, int a_rows, int a_cols,
+                     int a_stride, int transA, const float *B, int b_rows,
+                     int b_cols, int b_stride, int transB, float beta, float *C,
+                     int c_rows, int c_cols, int c_stride) {
+  CuMatrix<BaseFloat> a(In(A, a_rows, a_cols, a_stride)),
+      b(In(B, b_rows, b_cols, b_stride)), c(In(C, c_rows, c_cols, c_stride));
+  c.AddMatMat(alpha, a, transA ? kTrans : kNoTrans, b,
+              transB ? kTrans : kNoTrans, beta);
+  Out(c.Mat(), C, c_stride);
+}
+
+// cu-matrix.cc:1251-1271
+void ref_softmax_per_row(const float *src, int rows, int cols, int src_stride,
+                         float *dst, int dst_stride) {
+  CuMatrix<BaseFloat> s(In(src, rows, cols, src_stride)), d(rows, cols);
+  d.ApplySoftMaxPerRow(s);
+  Out(d.Mat(), dst, dst_stride);
+}
+
+// cu-matrix.cc:1274-1295
+void ref_log_softmax_per_row(const float *src, int rows, int cols,
+                             int src_stride, float *dst, int dst_stride) {
+  CuMatrix<BaseFloat> s(In(src, rows, cols, src_stride)), d(rows, cols);
+  d.ApplyLogSoftMaxPerRow(s);
+  Out(d.Mat(), dst, dst_stride);
+}
+
+// cu-matrix.cc:1965-1990
+void ref_copy_rows(float *dst, int rows, int cols, int dst_stride,
+                   const float *src, int src_rows, int src_stride,
+                   const int32_t *indices) {
+  CuMatrix<BaseFloat> s(In(src, src_rows, cols, src_stride)),
+      d(In(dst, rows, cols, dst_stride));
+  std::vector<int32> idx(indices, indices + rows);
+  d.CopyRows(s, idx);
+  Out(d.Mat(), dst, dst_stride);
+}
+
+// cudamatrix/cu-math.cc:130-165
+void ref_splice(const float *src, int rows, int cols, int src_stride,
+                const int32_t *frame_offsets, int n_offsets, float *tgt,
+                int tgt_stride) {
+  CuMatrix<BaseFloat> s(In(src, rows, cols, src_stride)),
+      t(rows, cols * n_offsets);
+  std::vector<int32> off(frame_offsets, frame_offsets + n_offsets);
+  CuArray<int32> cu_off(off);
+  cu::Splice(s, cu_off, &t);
+  Out(t.Mat(), tgt, tgt_stride);
+}
+
+// cu-matrix.cc:1147-1164
+void ref_group_pnorm(const float *src, int rows, int src_cols, int src_stride,
+                     float power, float *dst, int dst_cols, int dst_stride) {
+  CuMatrix<BaseFloat> s(In(src, rows, src_cols, src_stride)), d(rows, dst_cols);
+  d.GroupPnorm(s, power);
+  Out(d.Mat(), dst, dst_stride);
+}
+
+// NormalizeComponent::Propagate nnet2/nnet-component.cc:576-588
+void ref_normalize(const float *src, int rows, int cols, int src_stride,
+                   float *dst, int dst_stride) {
+  CuMatrix<BaseFloat> s(In(src, rows, cols, src_stride)), d(rows, cols);
+  NormalizeComponent comp(cols);
+  ChunkInfo info(cols, 1, 0, rows - 1);
+  comp.Propagate(info, info, s, &d);
+  Out(d.Mat(), dst, dst_stride);
+}
+
+// cu-vector.cc:517-580 AddDiagMat2
+void ref_add_diag_mat2(float alpha, const float *M, int rows, int cols,
+                       int stride, float beta, float *v) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  CuVector<BaseFloat> vec(InV(v, rows));
+  vec.AddDiagMat2(alpha, m, kNoTrans, beta);
+  Vector<BaseFloat> host(rows);
+  vec.CopyToVec(&host);
+  memcpy(v, host.Data(), sizeof(float) * rows);
+}
+
+void ref_mul_rows_vec(float *M, int rows, int cols, int stride, const float *s) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  CuVector<BaseFloat> v(InV(s, rows));
+  m.MulRowsVec(v);
+  Out(m.Mat(), M, stride);
+}
+
+void ref_mul_cols_vec(float *M, int rows, int cols, int stride, const float *s) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  CuVector<BaseFloat> v(InV(s, cols));
+  m.MulColsVec(v);
+  Out(m.Mat(), M, stride);
+}
+
+void ref_copy_rows_from_vec(float *M, int rows, int cols, int stride,
+                            const float *v) {
+  CuMatrix<BaseFloat> m(rows, cols);
+  CuVector<BaseFloat> vec(InV(v, cols));
+  m.CopyRowsFromVec(vec);
+  Out(m.Mat(), M, stride);
+}
+
+void ref_add_vec_to_rows(float alpha, const float *v, float beta, float *M,
+                         int rows, int cols, int stride) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  CuVector<BaseFloat> vec(InV(v, cols));
+  m.AddVecToRows(alpha, vec, beta);
+  Out(m.Mat(), M, stride);
+}
+
+void ref_apply_floor(float *M, int rows, int cols, int stride, float f) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  m.ApplyFloor(f);
+  Out(m.Mat(), M, stride);
+}
+void ref_apply_log(float *M, int rows, int cols, int stride) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  m.ApplyLog();
+  Out(m.Mat(), M, stride);
+}
+void ref_apply_exp(float *M, int rows, int cols, int stride) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  m.ApplyExp();
+  Out(m.Mat(), M, stride);
+}
+void ref_apply_pow(float *M, int rows, int cols, int stride, float power) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  m.ApplyPow(power);
+  Out(m.Mat(), M, stride);
+}
+void ref_scale(float *M, int rows, int cols, int stride, float alpha) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  m.Scale(alpha);
+  Out(m.Mat(), M, stride);
+}
+
+// cu-matrix.cc:1994-2028
+void ref_sum_column_ranges(float *dst, int rows, int dst_cols, int dst_stride,
+                           const float *src, int src_cols, int src_stride,
+                           const int32_t *ranges) {
+  CuMatrix<BaseFloat> s(In(src, rows, src_cols, src_stride)), d(rows, dst_cols);
+  std::vector<Int32Pair> idx(dst_cols);
+  for (int i = 0; i < dst_cols; i++) {
+    idx[i].first = ranges[2 * i];
+    idx[i].second = ranges[2 * i + 1];
+  }
+  CuArray<Int32Pair> cu_idx(idx);
+  d.SumColumnRanges(s, cu_idx);
+  Out(d.Mat(), dst, dst_stride);
+}
+
+// cu-matrix.cc:2327-...
+void ref_matrix_lookup(const float *M, int rows, int cols, int stride,
+                       const int32_t *row_col_pairs, int n, float *out) {
+  CuMatrix<BaseFloat> m(In(M, rows, cols, stride));
+  std::vector<Int32Pair> idx(n);
+  for (int i = 0; i < n; i++) {
+    idx[i].first = row_col_pairs[2 * i];
+    idx[i].second = row_col_pairs[2 * i + 1];
+  }
+  std::vector<BaseFloat> o;
+  m.Lookup(idx, &o);
+  memcpy(out, o.data(), sizeof(float) * n);
+}
+
+// ---- nnet2 -------------------------------------------------------------------
+static Nnet *BuildNnet(const KoComponent *comps, int n_comps) {
+  std::vector<Component *> cs;
+  for (int i = 0; i < n_comps; i++) {
+    const KoComponent &k = comps[i];
+    switch (k.type) {
+      case KO_SPLICE: {
+        SpliceComponent *c = new SpliceComponent();
+        c->Init(k.input_dim,
+                std::vector<int32>(k.context, k.context + k.n_context),
+                k.const_dim);
+        cs.push_back(c);
+        break;
+      }
+      case KO_FIXED_AFFINE: {
+        Matrix<BaseFloat> m(k.output_dim, k.input_dim + 1);
+        for (int r = 0; r < k.output_dim; r++) {
+          memcpy(m.RowData(r), k.linear + static_cast<size_t>(r) * k.input_dim,
+                 sizeof(float) * k.input_dim);
+          m(r, k.input_dim) = k.bias[r];
+        }
+        FixedAffineComponent *c = new FixedAffineComponent();
+        c->Init(CuMatrix<BaseFloat>(m));
+        cs.push_back(c);
+        break;
+      }
+      case KO_AFFINE: {
+        CuMatrix<BaseFloat> lin(In(k.linear, k.output_dim, k.input_dim,
+                                   k.input_dim));
+        CuVector<BaseFloat> b(InV(k.bias, k.output_dim));
+        cs.push_back(new AffineComponent(lin, b, 0.001));
+        break;
+      }
+      case KO_PNORM:
+        cs.push_back(new PnormComponent(k.input_dim, k.output_dim, k.p));
+        break;
+      case KO_NORMALIZE:
+        cs.push_back(new NormalizeComponent(k.input_dim));
+        break;
+      case KO_SOFTMAX:
+        cs.push_back(new SoftmaxComponent(k.input_dim));
+        break;
+      case KO_SUM_GROUP: {
+        SumGroupComponent *c = new SumGroupComponent();
+        c->Init(std::vector<int32>(k.sizes, k.sizes + k.n_sizes));
+        cs.push_back(c);
+        break;
+      }
+      case KO_FIXED_SCALE: {
+        FixedScaleComponent *c = new FixedScaleComponent();
+        c->Init(CuVector<BaseFloat>(InV(k.bias, k.input_dim)));
+        cs.push_back(c);
+        break;
+      }
+      case KO_FIXED_BIAS: {
+        FixedBiasComponent *c = new FixedBiasComponent();
+        c->Init(CuVector<BaseFloat>(InV(k.bias, k.input_dim)));
+        cs.push_back(c);
+        break;
+      }
+      default:
+        return NULL;
+    }
+  }
+  Nnet *nnet = new Nnet();
+  nnet->Init(&cs);
+  return nnet;
+}
+
+int ref_nnet_left_context(const KoComponent *comps, int n) {
+  Nnet *nnet = BuildNnet(comps, n);
+  int ans = nnet->LeftContext();
+  delete nnet;
+  return ans;
+}
+int ref_nnet_right_context(const KoComponent *comps, int n) {
+  Nnet *nnet = BuildNnet(comps, n);
+  int ans = nnet->RightContext();
+  delete nnet;
+  return ans;
+}
+
+// The reference's NnetComputer (nnet2/nnet-compute.cc:63-108) cannot be
+// compiled here (it includes hmm/posterior.h -> fst/fst-decl.h, OpenFst absent),
+// so this driver performs its two steps with the reference's own pieces:
+// the edge-frame padding by Matrix row copies (:75-89), Nnet::ComputeChunkInfo
+// (reference code, nnet-nnet.cc:65-112) and a loop of the reference's
+// Component::Propagate (nnet-component.h:197-215) — :94-108.
+int ref_nnet_forward(const KoComponent *comps, int n_comps, const float *feats,
+                     int T, int feat_stride, int pad_input, float *out,
+                     int out_stride) {
+  Nnet *nnet = BuildNnet(comps, n_comps);
+  if (!nnet) return -8;
+  int dim = nnet->InputDim();
+  int left = pad_input ? nnet->LeftContext() : 0,
+      right = pad_input ? nnet->RightContext() : 0;
+  int num_rows = left + T + right;
+  std::vector<ChunkInfo> chunk_info;
+  nnet->ComputeChunkInfo(num_rows, 1, &chunk_info);
+  CuMatrix<BaseFloat> input_feats(In(feats, T, dim, feat_stride));
+  CuMatrix<BaseFloat> input(num_rows, dim);
+  input.Range(left, T, 0, dim).CopyFromMat(input_feats);
+  for (int i = 0; i < left; i++) input.Row(i).CopyFromVec(input_feats.Row(0));
+  for (int i = 0; i < right; i++)
+    input.Row(num_rows - i - 1).CopyFromVec(input_feats.Row(T - 1));
+  CuMatrix<BaseFloat> cur(input), next;
+  for (int c = 0; c < nnet->NumComponents(); c++) {
+    nnet->GetComponent(c).Propagate(chunk_info[c], chunk_info[c + 1], cur, &next);
+    cur.Swap(&next);
+    next.Resize(0, 0);
+  }
+  int rows = cur.NumRows();
+  Out(cur.Mat(), out, out_stride);
+  delete nnet;
+  return rows;
+}
+
+// nnet2/decodable-am-nnet.h:39-73 (header cannot be included: it pulls
+// hmm/transition-model.h -> OpenFst); the five CuMatrix calls of its ctor are
+// issued here on the reference's CuMatrix.
+int ref_decodable_am_nnet(const KoComponent *comps, int n_comps,
+                          const float *priors, float prob_scale,
+                          const float *feats, int T, int feat_stride,
+                          float *log_probs, int out_stride) {
+  int n = comps[n_comps - 1].output_dim;
+  Matrix<BaseFloat> tmp(T, n);
+  int rows = ref_nnet_forward(comps, n_comps, feats, T, feat_stride, 1,
+                              tmp.Data(), tmp.Stride());
+  if (rows < 0) return rows;
+  CuMatrix<BaseFloat> lp(tmp);
+  lp.ApplyFloor(1.0e-20);
+  lp.ApplyLog();
+  CuVector<BaseFloat> priors_v(InV(priors, n));
+  priors_v.ApplyLog();
+  lp.AddVecToRows(-1.0, priors_v);
+  lp.Scale(prob_scale);
+  Out(lp.Mat(), log_probs, out_stride);
+  return rows;
+}
+
+// ---- DiagGmm -------------------------------------------------------------------
+// The model is given in its natural parameters (weights, means, vars); the
+// reference derives inv_vars / means_invvars / gconsts itself
+// (DiagGmm::SetInvVarsAndMeans + ComputeGconsts, gmm/diag-gmm.cc:114-152) and
+// they are exported so the restatement and the HIP kernels consume the same
+// stored parameters the reference would read from a model file.
+static void FillGmm(DiagGmm *gmm, const float *weights, const float *means,
+                    const float *vars, int num_mix, int dim) {
+  gmm->Resize(num_mix, dim);
+  gmm->SetWeights(InV(weights, num_mix));
+  Matrix<BaseFloat> inv_vars(In(vars, num_mix, dim, dim));
+  inv_vars.InvertElements();
+  gmm->SetInvVarsAndMeans(inv_vars, In(means, num_mix, dim, dim));
+}
+
+int ref_diag_gmm_build(const float *weights, const float *means,
+                       const float *vars, int num_mix, int dim, float *gconsts,
+                       float *means_invvars, float *inv_vars) {
+  DiagGmm gmm;
+  FillGmm(&gmm, weights, means, vars, num_mix, dim);
+  int bad = gmm.ComputeGconsts();
+  memcpy(gconsts, gmm.gconsts().Data(), sizeof(float) * num_mix);
+  Out(gmm.means_invvars(), means_invvars, dim);
+  Out(gmm.inv_vars(), inv_vars, dim);
+  return bad;
+}
+
+// DiagGmm::LogLikelihoods(const MatrixBase&, Matrix*) gmm/diag-gmm.cc:546-562
+void ref_diag_gmm_loglikes(const float *weights, const float *means,
+                           const float *vars, int num_mix, int dim,
+                           const float *data, int T, int data_stride,
+                           float *loglikes, int ll_stride) {
+  DiagGmm gmm;
+  FillGmm(&gmm, weights, means, vars, num_mix, dim);
+  gmm.ComputeGconsts();
+  Matrix<BaseFloat> d(In(data, T, dim, data_stride)), ll;
+  gmm.LogLikelihoods(d, &ll);
+  Out(ll, loglikes, ll_stride);
+}
+
+// Per-frame DiagGmm::LogLikelihood(VectorBase) diag-gmm.cc:517-526 (vector
+// LogLikelihoods :528-543 + LogSumExp()).
+void ref_diag_gmm_loglike_per_frame(const float *weights, const float *means,
+                                    const float *vars, int num_mix, int dim,
+                                    const float *data, int T, int data_stride,
+                                    float *out) {
+  DiagGmm gmm;
+  FillGmm(&gmm, weights, means, vars, num_mix, dim);
+  gmm.ComputeGconsts();
+  Matrix<BaseFloat> d(In(data, T, dim, data_stride));
+  for (int t = 0; t < T; t++) out[t] = gmm.LogLikelihood(d.Row(t));
+}
+
+// VectorBase::LogSumExp matrix/kaldi-vector.cc:745-763
+float ref_log_sum_exp(const float *v, int dim, float prune) {
+  Vector<BaseFloat> vec(InV(v, dim));
+  return vec.LogSumExp(prune);
+}
+
+}  // extern "C"
