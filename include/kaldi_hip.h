@@ -1,0 +1,339 @@
+/* kaldi_hip.h — C-ABI of libkaldi_hip.so: the MI355X (gfx950) implementation of
+ * Kaldi's acoustic-scoring + lattice-decoding hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no torch / C++
+ * types.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference's src/).  Unless stated otherwise pointers
+ * are DEVICE pointers, matrices are row-major float32 described by KhMatrixDim
+ * (the reference's MatrixDim, cudamatrix/cu-matrixdim.h:49-53, stride in
+ * elements), work is enqueued on the library's current HIP stream
+ * (kh_set_stream) and — like the reference, whose CU_SAFE_CALL synchronises
+ * after every call (cudamatrix/cu-common.h:37-44) — results are visible to the
+ * host after kh_synchronize() or any kh_* call documented as synchronous.
+ *
+ * Error convention: functions return 0 on success and a negative KH_E* code on
+ * failure; kh_last_error() returns the message.  The C++ host layer
+ * (old-kaldi-git_amd/host/) turns a failure into std::runtime_error exactly as
+ * KALDI_ERR does (base/kaldi-error.cc:143,179-182).  There is NO CPU fallback
+ * in this library: if no gfx950 device is usable every compute call fails.
+ */
+#ifndef KALDI_HIP_H_
+#define KALDI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KH_OK 0
+#define KH_EINVAL (-1)  /* dimension / argument violation (KALDI_ASSERT) */
+#define KH_EDEVICE (-2) /* HIP runtime failure (CU_SAFE_CALL) */
+#define KH_ENOMEM (-3)
+#define KH_ESTATE (-4)   /* call sequence violation */
+#define KH_ECAPACITY (-5) /* a decoder arena overflowed; see message */
+
+/* cudamatrix/cu-matrixdim.h:49-53 */
+typedef struct KhMatrixDim {
+  int32_t rows;
+  int32_t cols;
+  int32_t stride;
+} KhMatrixDim;
+
+/* ------------------------------------------------------------------ runtime
+ * Replaces CuDevice (cudamatrix/cu-device.h:41-143, cu-device.cc). */
+const char *kh_last_error(void);
+/* cudaGetDeviceCount in SelectGpuId, cu-device.cc:93-192. */
+int kh_device_count(void);
+/* CuDevice::SelectGpuId with an explicit ordinal (needed for
+ * one-process-per-GPU sharding).  ordinal < 0: keep the current device. */
+int kh_select_gpu(int ordinal);
+/* CuDevice::Enabled() cu-device.h:87 */
+int kh_enabled(void);
+/* CuDevice::DeviceGetName / GetFreeMemory cu-device.cc:391-397,195-225 */
+int kh_device_name(char *buf, size_t len);
+int kh_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all
+ * subsequent launches; NULL = the library's own stream. */
+int kh_set_stream(void *hip_stream);
+void *kh_get_stream(void);
+int kh_synchronize(void);
+/* CuDevice::Malloc / MallocPitch / Free cu-device.cc:530-555.  Served from a
+ * caching pool (the reference allocates on every Resize).  Pitch is a multiple
+ * of 256 bytes. */
+void *kh_malloc(size_t bytes);
+void *kh_malloc_pitch(size_t row_bytes, size_t num_rows, size_t *pitch_bytes);
+int kh_free(void *ptr);
+int kh_pool_release(void); /* return cached blocks to the driver */
+/* cudaMemcpy2D H2D / D2H / D2D in CuMatrix::CopyFromMat / CopyToMat / Swap
+ * cu-matrix.cc:112-147,197-231,283-307,387-412.  Synchronous. kind: 0 H2D,
+ * 1 D2H, 2 D2D. Pitches and width in bytes. */
+int kh_memcpy_2d(void *dst, size_t dst_pitch, const void *src, size_t src_pitch,
+                 size_t width_bytes, size_t height, int kind);
+int kh_memset(void *dst, int value, size_t bytes);
+
+/* ------------------------------------------------------------------ a1
+ * CuMatrixBase::AddMatMat cu-matrix.cc:947-982 (cublas_gemm
+ * cublas-wrappers.h:28-33): C = alpha*op(A)*op(B) + beta*C, FP32 MFMA.
+ * transX != 0 means kTrans.  dA/dB describe A/B as stored. */
+int kh_add_mat_mat(float alpha, const float *A, KhMatrixDim dA, int transA,
+                   const float *B, KhMatrixDim dB, int transB, float beta,
+                   float *C, KhMatrixDim dC);
+/* Fused affine layer: C = A * W^T + bias (row broadcast).  Equals
+ * CopyRowsFromVec + AddMatMat(beta=1) (AffineComponent::Propagate
+ * nnet2/nnet-component.cc:1221-1223) and AddMatMat(beta=0) + AddVecToRows
+ * (FixedAffineComponent::Propagate :3340-3342). */
+int kh_affine(const float *A, KhMatrixDim dA, const float *W, KhMatrixDim dW,
+              const float *bias, float *C, KhMatrixDim dC);
+
+/* ------------------------------------------------------------------ a2
+ * cudaF_softmax_reduce / CuMatrixBase::ApplySoftMaxPerRow cu-matrix.cc:1251-1271.
+ * d describes y; x has stride src_stride. */
+int kh_softmax_per_row(float *y, const float *x, KhMatrixDim d, int src_stride);
+/* cudaF_log_softmax_reduce / ApplyLogSoftMaxPerRow cu-matrix.cc:1274-1295 */
+int kh_log_softmax_per_row(float *y, const float *x, KhMatrixDim d,
+                           int src_stride);
+
+/* ------------------------------------------------------------------ a3
+ * cudaF_copy_rows / CuMatrixBase::CopyRows cu-matrix.cc:1965-1990:
+ * dst[i,:] = idx[i] < 0 ? 0 : src[idx[i],:].  indices is a DEVICE array of
+ * dst_dim.rows int32. */
+int kh_copy_rows(float *dst, KhMatrixDim dst_dim, const float *src,
+                 int src_stride, const int32_t *indices);
+
+/* ------------------------------------------------------------------ a4
+ * cudaF_splice / cu::Splice cudamatrix/cu-math.cc:130-165:
+ * y[r, k*D + c] = x[clamp(r + off[k], 0, R-1), c].  frame_offsets: DEVICE int32. */
+int kh_splice(float *y, KhMatrixDim d_out, const float *x, KhMatrixDim d_in,
+              const int32_t *frame_offsets, int n_offsets);
+
+/* ------------------------------------------------------------------ a5
+ * cudaF_group_pnorm / CuMatrixBase::GroupPnorm cu-matrix.cc:1147-1164.
+ * d describes y (rows x cols); x has cols*group_size columns. */
+int kh_group_pnorm(float *y, const float *x, KhMatrixDim d, int src_stride,
+                   int group_size, float power);
+
+/* ------------------------------------------------------------------ a6
+ * NormalizeComponent::Propagate nnet2/nnet-component.cc:576-588 fused:
+ * y = x / sqrt(max(mean(x^2), 2^-66)).  */
+int kh_normalize(float *y, const float *x, KhMatrixDim d, int src_stride);
+/* cudaF_add_diag_mat_mat via CuVectorBase::AddDiagMat2 cu-vector.cc:517-580
+ * (kNoTrans): v[i] = beta*v[i] + alpha * sum_j M[i,j]^2 */
+int kh_add_diag_mat2(float alpha, const float *M, KhMatrixDim d, float beta,
+                     float *v);
+/* cudaF_mul_rows_vec / MulRowsVec cu-matrix.cc:693-713 */
+int kh_mul_rows_vec(float *M, KhMatrixDim d, const float *scale);
+/* cudaF_mul_cols_vec / MulColsVec cu-matrix.cc:668 */
+int kh_mul_cols_vec(float *M, KhMatrixDim d, const float *scale);
+
+/* ------------------------------------------------------------------ a7 */
+/* cudaF_copy_rows_from_vec / CopyRowsFromVec cu-matrix.cc:1673-1745 */
+int kh_copy_rows_from_vec(float *M, KhMatrixDim d, const float *v);
+/* cudaF_add_vec_to_rows / AddVecToRows cu-matrix.cc:916-939 */
+int kh_add_vec_to_rows(float alpha, const float *v, float beta, float *M,
+                       KhMatrixDim d);
+/* cudaF_apply_floor :1845, _apply_log :600, _apply_exp, _apply_pow, _scale :579 */
+int kh_apply_floor(float *M, KhMatrixDim d, float floor_val);
+int kh_apply_log(float *M, KhMatrixDim d);
+int kh_apply_exp(float *M, KhMatrixDim d);
+int kh_apply_pow(float *M, KhMatrixDim d, float power);
+int kh_scale(float *M, KhMatrixDim d, float alpha);
+/* cudaF_sum_column_ranges / SumColumnRanges cu-matrix.cc:1994-2028; ranges:
+ * DEVICE array of 2*d.cols int32 ([start,end) per output column). */
+int kh_sum_column_ranges(float *y, KhMatrixDim d, const float *x,
+                         KhMatrixDim d_src, const int32_t *ranges);
+/* cudaF_matrix_lookup / CuMatrixBase::Lookup cu-matrix.cc:2327: out[k] =
+ * M[pairs[2k], pairs[2k+1]]; pairs/out DEVICE arrays. */
+int kh_matrix_lookup(const float *M, KhMatrixDim d, const int32_t *pairs, int n,
+                     float *out);
+/* DecodableAmNnet epilogue decodable-am-nnet.h:60-69 fused:
+ * M = (log(max(M, 1e-20)) - log_priors[c]) * prob_scale */
+int kh_log_prior_scale(float *M, KhMatrixDim d, const float *log_priors,
+                       float prob_scale);
+
+/* ------------------------------------------------------------------ a8
+ * nnet2 forward: Nnet + NnetComputer + DecodableAmNnet
+ * (nnet2/nnet-nnet.h, nnet2/nnet-compute.cc:63-108,159-166,
+ * nnet2/decodable-am-nnet.h:37-98, online-nnet2-decodable.cc:81-142). */
+enum KhComponentType {
+  KH_SPLICE = 1,
+  KH_FIXED_AFFINE = 2,
+  KH_AFFINE = 3,
+  KH_PNORM = 4,
+  KH_NORMALIZE = 5,
+  KH_SOFTMAX = 6,
+  KH_SUM_GROUP = 7,
+  KH_FIXED_SCALE = 8,
+  KH_FIXED_BIAS = 9
+};
+/* HOST-side description of one component; parameters are HOST pointers and are
+ * copied to the device by kh_nnet_add_component. */
+typedef struct KhComponentDesc {
+  int32_t type;
+  int32_t input_dim;
+  int32_t output_dim;
+  const float *linear;    /* [output_dim x input_dim] row-major */
+  const float *bias;      /* [output_dim]; scales/bias for FixedScale/FixedBias */
+  const int32_t *context; /* splice context */
+  int32_t n_context;
+  int32_t const_dim;
+  float p;
+  const int32_t *sizes; /* sum-group sizes */
+  int32_t n_sizes;
+} KhComponentDesc;
+
+typedef struct KhNnet KhNnet;
+KhNnet *kh_nnet_create(void);
+void kh_nnet_destroy(KhNnet *nnet);
+int kh_nnet_add_component(KhNnet *nnet, const KhComponentDesc *desc);
+int kh_nnet_set_priors(KhNnet *nnet, const float *priors_host, int n);
+int kh_nnet_num_components(const KhNnet *nnet);
+int kh_nnet_input_dim(const KhNnet *nnet);
+int kh_nnet_output_dim(const KhNnet *nnet);
+int kh_nnet_left_context(const KhNnet *nnet);  /* Nnet::LeftContext nnet-nnet.cc:45 */
+int kh_nnet_right_context(const KhNnet *nnet); /* Nnet::RightContext :55 */
+/* NnetComputation over a BATCH of utterances stacked by rows.
+ * feats: [utt_row_offsets[n_utts] x input_dim]; utterance u owns rows
+ * [utt_row_offsets[u], utt_row_offsets[u+1]) (HOST array, n_utts+1).
+ * pad_input != 0: each utterance is padded by edge-frame duplication
+ * (nnet-compute.cc:75-89) so it yields as many output rows as input rows and
+ * out uses the same row offsets; pad_input == 0: utterance u yields
+ * T_u - left - right rows, packed in order (out_row_offsets_host, if non-NULL,
+ * receives n_utts+1 offsets).
+ * epilogue: 0 = raw network output (NnetComputation); 1 = DecodableAmNnet's
+ * floor, log, minus log prior, times prob_scale (requires kh_nnet_set_priors). */
+int kh_nnet_compute(KhNnet *nnet, const float *feats, int feat_stride,
+                    const int32_t *utt_row_offsets_host, int n_utts,
+                    int pad_input, int epilogue, float prob_scale, float *out,
+                    int out_stride, int32_t *out_row_offsets_host);
+
+/* ------------------------------------------------------------------ a9
+ * DiagGmm (gmm/diag-gmm.h:83-135). */
+/* DiagGmm::ComputeGconsts gmm/diag-gmm.cc:114-152 — HOST arrays (model-load
+ * time, as in the reference).  Returns number of bad gconsts (>= 0). */
+int kh_gmm_compute_gconsts(const float *weights, const float *means_invvars,
+                           const float *inv_vars, int num_mix, int dim,
+                           float *gconsts);
+/* DiagGmm::LogLikelihoods(const MatrixBase&, Matrix*) diag-gmm.cc:546-562:
+ * loglikes[T x num_mix]. */
+int kh_diag_gmm_loglikes(const float *data, KhMatrixDim d_data,
+                         const float *gconsts, const float *means_invvars,
+                         const float *inv_vars, int num_mix, float *loglikes,
+                         int ll_stride);
+/* Frame x pdf matrix (gmm-compute-likes.cc:70-77; DecodableAmDiagGmmUnmapped::
+ * LogLikelihoodZeroBased decodable-am-diag-gmm.cc:28-71 for every (t,pdf)):
+ * out[t,j] = LogSumExp_{m in pdf j}(loglike[t,m], prune), LogSumExp as
+ * matrix/kaldi-vector.cc:745-763.  All pdfs' Gaussians concatenated;
+ * pdf_offsets: DEVICE int32 [num_pdfs+1]. */
+int kh_am_gmm_loglikes(const float *data, KhMatrixDim d_data,
+                       const float *gconsts, const float *means_invvars,
+                       const float *inv_vars, const int32_t *pdf_offsets,
+                       int num_pdfs, int num_mix, float log_sum_exp_prune,
+                       float *out, int out_stride);
+
+/* ------------------------------------------------------------------ a10-a14
+ * LatticeFasterDecoder (decoder/lattice-faster-decoder.{h,cc}) over a
+ * device-resident HCLG, decoding a batch of utterances per call. */
+typedef struct KhFst KhFst;
+/* fst::Fst<StdArc> as read by ReadFstKaldi (nnet-latgen-faster.cc:108):
+ * HOST CSR arrays; arc_offsets has num_states+1 entries; final[s] = +inf for
+ * non-final states (TropicalWeight::Zero()). */
+KhFst *kh_fst_create(int32_t num_states, int32_t start,
+                     const int64_t *arc_offsets, const int32_t *ilabel,
+                     const int32_t *olabel, const float *weight,
+                     const int32_t *nextstate, const float *final_cost);
+void kh_fst_destroy(KhFst *fst);
+int64_t kh_fst_num_arcs(const KhFst *fst);
+
+/* LatticeFasterDecoderConfig lattice-faster-decoder.h:40-95 (same defaults). */
+typedef struct KhDecoderConfig {
+  float beam;             /* 16.0 */
+  int32_t max_active;     /* INT32_MAX */
+  int32_t min_active;     /* 200 */
+  float lattice_beam;     /* 10.0 */
+  int32_t prune_interval; /* 25 */
+  float beam_delta;       /* 0.5 */
+  float hash_ratio;       /* 2.0 (sizes the device token table) */
+  float prune_scale;      /* 0.1 */
+} KhDecoderConfig;
+void kh_decoder_config_default(KhDecoderConfig *cfg);
+
+typedef struct KhDecoder KhDecoder;
+/* max_batch: utterances decoded concurrently per kh_decoder_decode call
+ * (one workgroup each).  max_frames: longest utterance.  max_tokens_per_frame /
+ * arena sizes derive from max_active; see DESIGN.md "Decoder memory". */
+KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg,
+                             int max_batch, int max_frames);
+void kh_decoder_destroy(KhDecoder *dec);
+/* LatticeFasterDecoder::Decode (lattice-faster-decoder.cc:77-95) for a batch:
+ * loglikes is what DecodableAmNnet::LogLikelihood / DecodableMatrixScaledMapped
+ * (decoder/decodable-matrix.h:33-84) would return: row t of utterance u at
+ * utt_row_offsets[u] + t, column tid2pdf[ilabel] (tid2pdf: DEVICE int32 LUT
+ * indexed by transition-id, TransitionModel::TransitionIdToPdf
+ * hmm/transition-model.h:312; NULL = identity minus one, ilabel-1).
+ * Includes FinalizeDecoding.  Synchronous. */
+int kh_decoder_decode(KhDecoder *dec, const float *loglikes, int ll_stride,
+                      const int32_t *utt_row_offsets_host, int n_utts,
+                      const int32_t *tid2pdf);
+/* Per-utterance statistics of the last kh_decoder_decode call. */
+typedef struct KhDecodeStats {
+  int32_t num_frames;
+  int32_t reached_final;      /* ReachedFinal() lattice-faster-decoder.h:143 */
+  float final_relative_cost;  /* FinalRelativeCost() */
+  float final_best_cost;
+  int32_t num_tokens;         /* surviving tokens (lattice states) */
+  int32_t num_links;          /* surviving forward links (lattice arcs) */
+  int64_t arcs_expanded;      /* emitting+epsilon arcs visited (roofline unit) */
+  int64_t tokens_created;
+  int32_t status;             /* 0 ok; KH_ECAPACITY if an arena overflowed */
+  int32_t max_tokens_frame;
+} KhDecodeStats;
+int kh_decoder_get_stats(const KhDecoder *dec, int utt, KhDecodeStats *stats);
+/* GetRawLattice (lattice-faster-decoder.cc:109-191), use_final_probs = true,
+ * in canonical form: states are the surviving tokens sorted by
+ * (frame, hclg_state); arcs sorted by (src, ilabel, olabel, dst, graph, ac).
+ * HOST output arrays sized from kh_decoder_get_stats (num_tokens/num_links):
+ *   state_frame[num_tokens], state_hclg[num_tokens], state_final[num_tokens]
+ *   (LatticeWeight(final,0) value1; +inf = not final),
+ *   arc_src/arc_dst/arc_ilabel/arc_olabel[num_links], arc_graph/arc_acoustic
+ *   (acoustic_cost - cost_offset[frame], :172). Any pointer may be NULL. */
+int kh_decoder_get_raw_lattice(const KhDecoder *dec, int utt,
+                               int32_t *state_frame, int32_t *state_hclg,
+                               float *state_final, int32_t *arc_src,
+                               int32_t *arc_dst, int32_t *arc_ilabel,
+                               int32_t *arc_olabel, float *arc_graph,
+                               float *arc_acoustic);
+/* GetBestPath (lattice-faster-decoder.cc:99-105) + GetLinearSymbolSequence as
+ * DecodeUtteranceLatticeFaster uses it (decoder-wrappers.cc:232-246):
+ * alignment = ilabels != 0 along the best path, words = olabels != 0.
+ * Returns lengths via *n_ali / *n_words (buffers of capacity cap_*), the total
+ * weight as (graph, acoustic). */
+int kh_decoder_get_best_path(const KhDecoder *dec, int utt, int32_t *alignment,
+                             int cap_ali, int32_t *n_ali, int32_t *words,
+                             int cap_words, int32_t *n_words,
+                             float *graph_cost, float *acoustic_cost);
+
+/* ------------------------------------------------------------------ a15
+ * Lattice forward-backward (lat/lattice-functions.cc:36-67,272-354) for a batch
+ * of top-sorted lattices given as HOST CSR (state s owns arcs
+ * [arc_offsets[s], arc_offsets[s+1])); lattices are concatenated, lattice l
+ * owns states [lat_state_offsets[l], lat_state_offsets[l+1]) and its arcs'
+ * nextstate values are lattice-local.  Arc weight = (graph, acoustic)
+ * LatticeWeight (fstext/lattice-weight.h:47), final = value1+value2 sum
+ * (+inf = Zero).  Outputs (HOST): per-arc posterior (float), per-lattice total
+ * log-prob (double, tot_backward_prob) and acoustic_like_sum (double), per-state
+ * time (LatticeStateTimes).  */
+int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_offsets,
+                                const int64_t *arc_offsets,
+                                const int32_t *arc_ilabel,
+                                const int32_t *arc_nextstate,
+                                const float *arc_graph, const float *arc_acoustic,
+                                const float *state_final, float *arc_post,
+                                double *tot_like, double *acoustic_like_sum,
+                                int32_t *state_times);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KALDI_HIP_H_ */

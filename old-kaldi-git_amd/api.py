@@ -1,0 +1,320 @@
+"""Python host-side mirror of the reference's operator interface for the hot path.
+
+Same names / argument meaning / error behaviour as the reference classes
+(`CuMatrixBase` methods of cudamatrix/cu-matrix.h, `cu::Splice`, `DiagGmm`,
+`nnet2::Nnet` + `NnetComputation` + `DecodableAmNnet`, `LatticeFasterDecoder`,
+`LatticeForwardBackward`), implemented by calling the C-ABI of libkaldi_hip.so.
+torch is used only as the owner of device memory (tensors -> data_ptr()) and of
+the HIP stream; no computation is done by torch and there is no fallback: every
+function raises KhError (the KALDI_ERR equivalent) if the library call fails.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import KhMatrixDim, KhComponentDesc, KhDecoderConfig, KhDecodeStats, check, KhError
+
+kTrans, kNoTrans = 1, 0
+
+TYPE_BY_NAME = {
+    "splice": 1, "fixed_affine": 2, "affine": 3, "pnorm": 4, "normalize": 5,
+    "softmax": 6, "sum_group": 7, "fixed_scale": 8, "fixed_bias": 9,
+}
+
+
+def lib():
+    return capi.load()
+
+
+def use_torch_stream():
+    """Enqueue library work on torch's current HIP stream (ordering with tensor
+    creation / copies done by torch)."""
+    check(lib().kh_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def select_gpu(ordinal):
+    """CuDevice::SelectGpuId with explicit ordinal (cu-device.cc:93-192)."""
+    check(lib().kh_select_gpu(int(ordinal)))
+    torch.cuda.set_device(int(ordinal))
+    use_torch_stream()
+
+
+def _dim(t):
+    assert t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda
+    assert t.stride(1) == 1 or t.shape[1] <= 1
+    return KhMatrixDim(t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _dev_i32(a, device):
+    if isinstance(a, torch.Tensor):
+        assert a.dtype == torch.int32 and a.is_cuda
+        return a
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=device)
+
+
+# ---------------------------------------------------------------- CuMatrix ops
+def add_mat_mat(Cm, alpha, A, transA, B, transB, beta):
+    """CuMatrixBase::AddMatMat (cu-matrix.cc:947-982): C = alpha op(A) op(B) + beta C."""
+    check(lib().kh_add_mat_mat(alpha, _p(A), _dim(A), int(transA), _p(B), _dim(B), int(transB), beta, _p(Cm), _dim(Cm)))
+    return Cm
+
+
+def affine(out, A, W, bias):
+    check(lib().kh_affine(_p(A), _dim(A), _p(W), _dim(W), _p(bias), _p(out), _dim(out)))
+    return out
+
+
+def apply_softmax_per_row(dst, src):
+    """CuMatrixBase::ApplySoftMaxPerRow (cu-matrix.cc:1251-1271)."""
+    assert dst.shape == src.shape  # KALDI_ASSERT(SameDim(*this, src))
+    check(lib().kh_softmax_per_row(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    return dst
+
+
+def apply_log_softmax_per_row(dst, src):
+    assert dst.shape == src.shape
+    check(lib().kh_log_softmax_per_row(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    return dst
+
+
+def copy_rows(dst, src, indices):
+    """CuMatrixBase::CopyRows (cu-matrix.cc:1965-1990)."""
+    idx = _dev_i32(indices, dst.device)
+    if dst.shape[1] != src.shape[1] or dst.shape[0] != idx.numel():
+        raise KhError("CopyRows: dimension mismatch")
+    check(lib().kh_copy_rows(_p(dst), _dim(dst), _p(src), _dim(src).stride, _p(idx)))
+    return dst
+
+
+def splice(src, frame_offsets, tgt):
+    """cu::Splice (cudamatrix/cu-math.cc:130-165)."""
+    off = _dev_i32(frame_offsets, src.device)
+    check(lib().kh_splice(_p(tgt), _dim(tgt), _p(src), _dim(src), _p(off), off.numel()))
+    return tgt
+
+
+def group_pnorm(dst, src, power):
+    """CuMatrixBase::GroupPnorm (cu-matrix.cc:1147-1164)."""
+    if src.shape[1] % dst.shape[1] != 0 or src.shape[0] != dst.shape[0]:
+        raise KhError("GroupPnorm: dimension mismatch")
+    check(lib().kh_group_pnorm(_p(dst), _p(src), _dim(dst), _dim(src).stride, src.shape[1] // dst.shape[1], power))
+    return dst
+
+
+def normalize(dst, src):
+    """NormalizeComponent::Propagate (nnet2/nnet-component.cc:576-588)."""
+    assert dst.shape == src.shape
+    check(lib().kh_normalize(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    return dst
+
+
+def add_diag_mat2(v, alpha, M, beta):
+    """CuVectorBase::AddDiagMat2 kNoTrans (cu-vector.cc:517-580)."""
+    assert v.numel() == M.shape[0]
+    check(lib().kh_add_diag_mat2(alpha, _p(M), _dim(M), beta, _p(v)))
+    return v
+
+
+def mul_rows_vec(M, s):
+    assert s.numel() == M.shape[0]
+    check(lib().kh_mul_rows_vec(_p(M), _dim(M), _p(s)))
+    return M
+
+
+def mul_cols_vec(M, s):
+    assert s.numel() == M.shape[1]
+    check(lib().kh_mul_cols_vec(_p(M), _dim(M), _p(s)))
+    return M
+
+
+def copy_rows_from_vec(M, v):
+    assert v.numel() == M.shape[1]
+    check(lib().kh_copy_rows_from_vec(_p(M), _dim(M), _p(v)))
+    return M
+
+
+def add_vec_to_rows(M, alpha, v, beta=1.0):
+    assert v.numel() == M.shape[1]
+    check(lib().kh_add_vec_to_rows(alpha, _p(v), beta, _p(M), _dim(M)))
+    return M
+
+
+def apply_floor(M, f):
+    check(lib().kh_apply_floor(_p(M), _dim(M), f))
+    return M
+
+
+def apply_log(M):
+    check(lib().kh_apply_log(_p(M), _dim(M)))
+    return M
+
+
+def apply_exp(M):
+    check(lib().kh_apply_exp(_p(M), _dim(M)))
+    return M
+
+
+def apply_pow(M, p):
+    check(lib().kh_apply_pow(_p(M), _dim(M), p))
+    return M
+
+
+def scale(M, a):
+    check(lib().kh_scale(_p(M), _dim(M), a))
+    return M
+
+
+def sum_column_ranges(dst, src, ranges):
+    """CuMatrixBase::SumColumnRanges (cu-matrix.cc:1994-2028)."""
+    r = _dev_i32(ranges, dst.device)
+    assert r.numel() == 2 * dst.shape[1]
+    check(lib().kh_sum_column_ranges(_p(dst), _dim(dst), _p(src), _dim(src), _p(r)))
+    return dst
+
+
+def lookup(M, pairs):
+    """CuMatrixBase::Lookup (cu-matrix.cc:2327)."""
+    pr = _dev_i32(pairs, M.device)
+    n = pr.numel() // 2
+    out = torch.empty(n, dtype=torch.float32, device=M.device)
+    check(lib().kh_matrix_lookup(_p(M), _dim(M), _p(pr), n, _p(out)))
+    return out
+
+
+# ---------------------------------------------------------------- nnet2
+class Nnet:
+    """nnet2::Nnet (forward only) + NnetComputation + DecodableAmNnet epilogue."""
+
+    def __init__(self, components, priors=None):
+        self._h = C.c_void_p(lib().kh_nnet_create())
+        self._keep = []
+        for comp in components:
+            d = KhComponentDesc()
+            d.type = TYPE_BY_NAME[comp["type"]]
+            d.input_dim, d.output_dim = int(comp["input_dim"]), int(comp["output_dim"])
+            keep = []
+            if "linear" in comp:
+                w = np.ascontiguousarray(comp["linear"], np.float32)
+                keep.append(w)
+                d.linear = w.ctypes.data_as(capi.c_float_p)
+            if "bias" in comp:
+                b = np.ascontiguousarray(comp["bias"], np.float32)
+                keep.append(b)
+                d.bias = b.ctypes.data_as(capi.c_float_p)
+            if "context" in comp:
+                ctx = np.ascontiguousarray(comp["context"], np.int32)
+                keep.append(ctx)
+                d.context = ctx.ctypes.data_as(capi.c_int32_p)
+                d.n_context = len(ctx)
+                d.const_dim = int(comp.get("const_dim", 0))
+            d.p = float(comp.get("p", 2.0))
+            if "sizes" in comp:
+                sz = np.ascontiguousarray(comp["sizes"], np.int32)
+                keep.append(sz)
+                d.sizes = sz.ctypes.data_as(capi.c_int32_p)
+                d.n_sizes = len(sz)
+            check(lib().kh_nnet_add_component(self._h, C.byref(d)))
+        if priors is not None:
+            pr = np.ascontiguousarray(priors, np.float32)
+            check(lib().kh_nnet_set_priors(self._h, pr.ctypes.data_as(capi.c_float_p), len(pr)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kh_nnet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def input_dim(self):
+        return lib().kh_nnet_input_dim(self._h)
+
+    def output_dim(self):
+        return lib().kh_nnet_output_dim(self._h)
+
+    def left_context(self):
+        return lib().kh_nnet_left_context(self._h)
+
+    def right_context(self):
+        return lib().kh_nnet_right_context(self._h)
+
+    def compute(self, feats, utt_row_offsets=None, pad_input=True, epilogue=False, prob_scale=1.0, out=None):
+        """NnetComputation (nnet-compute.cc:159-166) for a batch stacked by rows;
+        epilogue=True adds DecodableAmNnet's floor/log/-logprior/scale."""
+        T = feats.shape[0]
+        if utt_row_offsets is None:
+            utt_row_offsets = [0, T]
+        off = np.ascontiguousarray(utt_row_offsets, np.int32)
+        n_utts = len(off) - 1
+        L, R = self.left_context(), self.right_context()
+        rows = int(off[-1] - off[0]) if pad_input else int(off[-1] - off[0]) - n_utts * (L + R)
+        if rows <= 0:
+            raise KhError("Nnet.compute: no output rows")
+        if out is None:
+            od = self.output_dim()
+            stride = (od + 3) // 4 * 4
+            out = torch.empty((rows, stride), dtype=torch.float32, device=feats.device)[:, :od]
+        out_off = np.zeros(n_utts + 1, np.int32)
+        check(lib().kh_nnet_compute(self._h, _p(feats), _dim(feats).stride,
+                                    off.ctypes.data_as(capi.c_int32_p), n_utts, int(pad_input),
+                                    int(epilogue), float(prob_scale), _p(out), _dim(out).stride,
+                                    out_off.ctypes.data_as(capi.c_int32_p)))
+        return out, out_off
+
+
+# ---------------------------------------------------------------- DiagGmm
+def gmm_compute_gconsts(weights, means_invvars, inv_vars):
+    """DiagGmm::ComputeGconsts (gmm/diag-gmm.cc:114-152); host arrays."""
+    w = np.ascontiguousarray(weights, np.float32)
+    mi = np.ascontiguousarray(means_invvars, np.float32)
+    iv = np.ascontiguousarray(inv_vars, np.float32)
+    g = np.empty(len(w), np.float32)
+    fp = capi.c_float_p
+    rc = lib().kh_gmm_compute_gconsts(w.ctypes.data_as(fp), mi.ctypes.data_as(fp), iv.ctypes.data_as(fp),
+                                      mi.shape[0], mi.shape[1], g.ctypes.data_as(fp))
+    if rc < 0:
+        check(rc)
+    return g, rc
+
+
+class AmDiagGmm:
+    """All pdfs' DiagGmm parameters concatenated, resident on the device
+    (AmDiagGmm gmm/am-diag-gmm.h; scoring as DecodableAmDiagGmmUnmapped)."""
+
+    def __init__(self, gconsts, means_invvars, inv_vars, pdf_offsets, device="cuda"):
+        self.gconsts = torch.as_tensor(np.ascontiguousarray(gconsts, np.float32), device=device)
+        self.means_invvars = torch.as_tensor(np.ascontiguousarray(means_invvars, np.float32), device=device)
+        self.inv_vars = torch.as_tensor(np.ascontiguousarray(inv_vars, np.float32), device=device)
+        self.pdf_offsets = torch.as_tensor(np.ascontiguousarray(pdf_offsets, np.int32), device=device)
+        self.num_mix = self.means_invvars.shape[0]
+        self.dim = self.means_invvars.shape[1]
+        self.num_pdfs = self.pdf_offsets.numel() - 1
+
+    def log_likelihoods(self, data, out=None):
+        """DiagGmm::LogLikelihoods(Matrix) (diag-gmm.cc:546-562) over ALL Gaussians: T x M."""
+        if data.shape[0] == 0:
+            raise KhError("KALDI_ASSERT: data.NumRows() != 0")
+        if data.shape[1] != self.dim:
+            raise KhError("DiagGmm::ComponentLogLikelihood, dimension mismatch %d vs. %d" % (data.shape[1], self.dim))
+        if out is None:
+            out = torch.empty((data.shape[0], self.num_mix), dtype=torch.float32, device=data.device)
+        check(lib().kh_diag_gmm_loglikes(_p(data), _dim(data), _p(self.gconsts), _p(self.means_invvars),
+                                         _p(self.inv_vars), self.num_mix, _p(out), _dim(out).stride))
+        return out
+
+    def pdf_log_likelihoods(self, data, log_sum_exp_prune=-1.0, out=None):
+        """frame x pdf matrix (gmm-compute-likes.cc:70-77)."""
+        if data.shape[1] != self.dim:
+            raise KhError("Dim mismatch: data dim = %d vs. model dim = %d" % (data.shape[1], self.dim))
+        if out is None:
+            out = torch.empty((data.shape[0], self.num_pdfs), dtype=torch.float32, device=data.device)
+        check(lib().kh_am_gmm_loglikes(_p(data), _dim(data), _p(self.gconsts), _p(self.means_invvars),
+                                       _p(self.inv_vars), _p(self.pdf_offsets), self.num_pdfs, self.num_mix,
+                                       float(log_sum_exp_prune), _p(out), _dim(out).stride))
+        return out

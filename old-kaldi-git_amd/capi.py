@@ -1,0 +1,145 @@
+"""ctypes declarations for include/kaldi_hip.h (libkaldi_hip.so).
+
+The library is the product; this module only declares its C-ABI.  Loading fails
+loudly if the shared object is missing — there is no fallback path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkaldi_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_double_p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class KhMatrixDim(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("stride", C.c_int32)]
+
+
+class KhComponentDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("input_dim", C.c_int32), ("output_dim", C.c_int32),
+        ("linear", c_float_p), ("bias", c_float_p),
+        ("context", c_int32_p), ("n_context", C.c_int32), ("const_dim", C.c_int32),
+        ("p", C.c_float), ("sizes", c_int32_p), ("n_sizes", C.c_int32),
+    ]
+
+
+class KhDecoderConfig(C.Structure):
+    _fields_ = [
+        ("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
+        ("lattice_beam", C.c_float), ("prune_interval", C.c_int32),
+        ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("prune_scale", C.c_float),
+    ]
+
+
+class KhDecodeStats(C.Structure):
+    _fields_ = [
+        ("num_frames", C.c_int32), ("reached_final", C.c_int32),
+        ("final_relative_cost", C.c_float), ("final_best_cost", C.c_float),
+        ("num_tokens", C.c_int32), ("num_links", C.c_int32),
+        ("arcs_expanded", C.c_int64), ("tokens_created", C.c_int64),
+        ("status", C.c_int32), ("max_tokens_frame", C.c_int32),
+    ]
+
+
+D = KhMatrixDim
+f, i32, i64 = C.c_float, C.c_int32, C.c_int64
+
+# name -> (restype, argtypes).  Must list EVERY symbol include/kaldi_hip.h declares
+# (tests/test_abi.py checks this against the header).
+SIGNATURES = {
+    "kh_last_error": (C.c_char_p, []),
+    "kh_device_count": (C.c_int, []),
+    "kh_select_gpu": (C.c_int, [C.c_int]),
+    "kh_enabled": (C.c_int, []),
+    "kh_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "kh_mem_info": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "kh_set_stream": (C.c_int, [vp]),
+    "kh_get_stream": (vp, []),
+    "kh_synchronize": (C.c_int, []),
+    "kh_malloc": (vp, [C.c_size_t]),
+    "kh_malloc_pitch": (vp, [C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "kh_free": (C.c_int, [vp]),
+    "kh_pool_release": (C.c_int, []),
+    "kh_memcpy_2d": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
+    "kh_memset": (C.c_int, [vp, C.c_int, C.c_size_t]),
+    "kh_add_mat_mat": (C.c_int, [f, vp, D, C.c_int, vp, D, C.c_int, f, vp, D]),
+    "kh_affine": (C.c_int, [vp, D, vp, D, vp, vp, D]),
+    "kh_softmax_per_row": (C.c_int, [vp, vp, D, C.c_int]),
+    "kh_log_softmax_per_row": (C.c_int, [vp, vp, D, C.c_int]),
+    "kh_copy_rows": (C.c_int, [vp, D, vp, C.c_int, vp]),
+    "kh_splice": (C.c_int, [vp, D, vp, D, vp, C.c_int]),
+    "kh_group_pnorm": (C.c_int, [vp, vp, D, C.c_int, C.c_int, f]),
+    "kh_normalize": (C.c_int, [vp, vp, D, C.c_int]),
+    "kh_add_diag_mat2": (C.c_int, [f, vp, D, f, vp]),
+    "kh_mul_rows_vec": (C.c_int, [vp, D, vp]),
+    "kh_mul_cols_vec": (C.c_int, [vp, D, vp]),
+    "kh_copy_rows_from_vec": (C.c_int, [vp, D, vp]),
+    "kh_add_vec_to_rows": (C.c_int, [f, vp, f, vp, D]),
+    "kh_apply_floor": (C.c_int, [vp, D, f]),
+    "kh_apply_log": (C.c_int, [vp, D]),
+    "kh_apply_exp": (C.c_int, [vp, D]),
+    "kh_apply_pow": (C.c_int, [vp, D, f]),
+    "kh_scale": (C.c_int, [vp, D, f]),
+    "kh_sum_column_ranges": (C.c_int, [vp, D, vp, D, vp]),
+    "kh_matrix_lookup": (C.c_int, [vp, D, vp, C.c_int, vp]),
+    "kh_log_prior_scale": (C.c_int, [vp, D, vp, f]),
+    "kh_nnet_create": (vp, []),
+    "kh_nnet_destroy": (None, [vp]),
+    "kh_nnet_add_component": (C.c_int, [vp, C.POINTER(KhComponentDesc)]),
+    "kh_nnet_set_priors": (C.c_int, [vp, c_float_p, C.c_int]),
+    "kh_nnet_num_components": (C.c_int, [vp]),
+    "kh_nnet_input_dim": (C.c_int, [vp]),
+    "kh_nnet_output_dim": (C.c_int, [vp]),
+    "kh_nnet_left_context": (C.c_int, [vp]),
+    "kh_nnet_right_context": (C.c_int, [vp]),
+    "kh_nnet_compute": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, C.c_int, C.c_int, f, vp, C.c_int, c_int32_p]),
+    "kh_gmm_compute_gconsts": (C.c_int, [c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]),
+    "kh_diag_gmm_loglikes": (C.c_int, [vp, D, vp, vp, vp, C.c_int, vp, C.c_int]),
+    "kh_am_gmm_loglikes": (C.c_int, [vp, D, vp, vp, vp, vp, C.c_int, C.c_int, f, vp, C.c_int]),
+    "kh_fst_create": (vp, [i32, i32, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_float_p]),
+    "kh_fst_destroy": (None, [vp]),
+    "kh_fst_num_arcs": (i64, [vp]),
+    "kh_decoder_config_default": (None, [C.POINTER(KhDecoderConfig)]),
+    "kh_decoder_create": (vp, [vp, C.POINTER(KhDecoderConfig), C.c_int, C.c_int]),
+    "kh_decoder_destroy": (None, [vp]),
+    "kh_decoder_decode": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, vp]),
+    "kh_decoder_get_stats": (C.c_int, [vp, C.c_int, C.POINTER(KhDecodeStats)]),
+    "kh_decoder_get_raw_lattice": (C.c_int, [vp, C.c_int, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p]),
+    "kh_decoder_get_best_path": (C.c_int, [vp, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p, c_float_p, c_float_p]),
+    "kh_lattice_forward_backward": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p, c_int32_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libkaldi_hip.so and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libkaldi_hip.so not found at %s — build it with `python __graft_entry__.py` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class KhError(RuntimeError):
+    """KALDI_ERR equivalent (base/kaldi-error.cc:143,179-182 throws std::runtime_error)."""
+
+
+def check(rc):
+    if rc != 0:
+        raise KhError("libkaldi_hip error %d: %s" % (rc, load().kh_last_error().decode()))

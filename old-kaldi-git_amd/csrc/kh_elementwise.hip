@@ -1,0 +1,525 @@
+// kh_elementwise.hip — HBM-bound CuMatrix primitives of the nnet2 forward path
+// (SURVEY.md §8 rows a2-a7), written for gfx950: 64-wide waves, column index on
+// the lane (coalesced rows — the reference's _copy_rows/_sum_column_ranges map
+// x->row, cu-matrix.cc:1979-1982, i.e. uncoalesced), wave shuffles + LDS for the
+// per-row reductions, one HBM read and one write per element.
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float BlockMax(float v, float *red) {
+  v = kh_wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; i++) r = fmaxf(r, red[i]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float BlockSum(float v, float *red) {
+  v = kh_wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; i++) r += red[i];
+  __syncthreads();
+  return r;
+}
+
+// ---- a2 softmax / log-softmax: one workgroup per row, row cached in LDS -------
+// (reference: _softmax_reduce cu-kernels.cu:1624-1688 re-reads the row from
+// global memory in each of its three passes.)
+constexpr int kSoftmaxLdsFloats = 12288;  // 48 KiB: 3 blocks/CU
+
+template <bool LOG>
+__global__ void __launch_bounds__(kBlock)
+SoftmaxKernel(float *__restrict__ y, const float *__restrict__ x, int cols,
+              int y_stride, int x_stride) {
+  __shared__ float cache[kSoftmaxLdsFloats];
+  __shared__ float red[kBlock / 64];
+  const int r = blockIdx.x;
+  const float *xr = x + static_cast<size_t>(r) * x_stride;
+  float *yr = y + static_cast<size_t>(r) * y_stride;
+  const bool cached = cols <= kSoftmaxLdsFloats;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += kBlock) {
+    float v = xr[c];
+    if (cached) cache[c] = v;
+    m = fmaxf(m, v);
+  }
+  m = BlockMax(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += kBlock) {
+    float v = (cached ? cache[c] : xr[c]) - m;
+    float e = expf(v);
+    if (cached) cache[c] = LOG ? v : e;
+    s += e;
+  }
+  s = BlockSum(s, red);
+  if (LOG) {
+    const float ls = -1.0f * logf(s);
+    for (int c = threadIdx.x; c < cols; c += kBlock)
+      yr[c] = (cached ? cache[c] : (xr[c] - m)) + ls;
+  } else {
+    const float inv = 1.0f / s;
+    for (int c = threadIdx.x; c < cols; c += kBlock)
+      yr[c] = (cached ? cache[c] : expf(xr[c] - m)) * inv;
+  }
+}
+
+// small rows: one wave per row, 4 rows per workgroup
+template <bool LOG>
+__global__ void __launch_bounds__(kBlock)
+SoftmaxWaveKernel(float *__restrict__ y, const float *__restrict__ x, int rows,
+                  int cols, int y_stride, int x_stride) {
+  const int r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *xr = x + static_cast<size_t>(r) * x_stride;
+  float *yr = y + static_cast<size_t>(r) * y_stride;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+  m = kh_wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += expf(xr[c] - m);
+  s = kh_wave_sum(s);
+  if (LOG) {
+    const float ls = -1.0f * logf(s);
+    for (int c = lane; c < cols; c += 64) yr[c] = (xr[c] - m) + ls;
+  } else {
+    const float inv = 1.0f / s;
+    for (int c = lane; c < cols; c += 64) yr[c] = expf(xr[c] - m) * inv;
+  }
+}
+
+// ---- generic 2-D element-wise launch: column on the lane ----------------------
+struct Dim2 {
+  int rows, cols, stride;
+};
+
+template <class F>
+__global__ void __launch_bounds__(kBlock) Map2D(Dim2 d, F f) {
+  // grid-stride over rows; blockDim = (64 | 256 over columns)
+  const int cpb = blockDim.x;
+  for (int r = blockIdx.y; r < d.rows; r += gridDim.y)
+    for (int c = blockIdx.x * cpb + threadIdx.x; c < d.cols; c += gridDim.x * cpb)
+      f(r, c);
+}
+
+template <class F>
+int LaunchMap2D(int rows, int cols, F f) {
+  if (rows <= 0 || cols <= 0) return KH_OK;
+  const int bx = cols >= 256 ? 256 : 64;
+  dim3 block(bx);
+  int gx = DivUp(cols, bx);
+  if (gx > 64) gx = 64;
+  int gy = rows;
+  const int max_blocks = NumCUs() * 16;
+  if (static_cast<int64_t>(gx) * gy > max_blocks) gy = max_blocks / gx > 0 ? max_blocks / gx : 1;
+  if (gy > 65535) gy = 65535;
+  dim3 grid(gx, gy);
+  Dim2 d{rows, cols, 0};
+  hipLaunchKernelGGL(Map2D<F>, grid, block, 0, Stream(), d, f);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+// ---- a5 group p-norm ---------------------------------------------------------------
+template <int MODE>  // 0: p==2, 1: p==1, 2: generic
+__global__ void __launch_bounds__(kBlock)
+GroupPnormKernel(float *__restrict__ y, const float *__restrict__ x, int rows,
+                 int cols, int y_stride, int x_stride, int group, float p) {
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float *xr = x + static_cast<size_t>(r) * x_stride;
+    for (int c = blockIdx.x * kBlock + threadIdx.x; c < cols;
+         c += gridDim.x * kBlock) {
+      const float *g = xr + c * group;
+      float out;
+      if (MODE == 0) {
+        float s = 0.f;
+        for (int j = 0; j < group; j++) s += g[j] * g[j];
+        out = sqrtf(s);
+      } else if (MODE == 1) {
+        float s = 0.f;
+        for (int j = 0; j < group; j++) s += fabsf(g[j]);
+        out = s;
+      } else {
+        // VectorBase::Norm generic branch kaldi-vector.cc:526-544 (double pow,
+        // float store), with the overflow rescue by max-abs rescaling.
+        float s = 0.f, mx = 0.f;
+        bool ok = true;
+        for (int j = 0; j < group; j++) {
+          float a = fabsf(g[j]);
+          mx = fmaxf(mx, a);
+          float t = static_cast<float>(pow(static_cast<double>(a), static_cast<double>(p)));
+          if (isinf(t)) ok = false;
+          s += t;
+        }
+        const double ip = static_cast<double>(static_cast<float>(1.0 / p));
+        if (ok) {
+          out = static_cast<float>(pow(static_cast<double>(s), ip));
+        } else {
+          const float sc = 1.0f / mx;
+          float s2 = 0.f;
+          for (int j = 0; j < group; j++) {
+            float a = fabsf(g[j] * sc);
+            s2 += static_cast<float>(pow(static_cast<double>(a), static_cast<double>(p)));
+          }
+          out = static_cast<float>(pow(static_cast<double>(s2), ip)) * mx;
+        }
+      }
+      y[static_cast<size_t>(r) * y_stride + c] = out;
+    }
+  }
+}
+
+// ---- a6 normalize: one wave per row (cols ~ 350..2000) -----------------------------
+__global__ void __launch_bounds__(kBlock)
+NormalizeKernel(float *__restrict__ y, const float *__restrict__ x, int rows,
+                int cols, int y_stride, int x_stride, float alpha, float floor_v) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < rows;
+       r += gridDim.x * (kBlock / 64)) {
+    const float *xr = x + static_cast<size_t>(r) * x_stride;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+      float v = xr[c];
+      s += v * v;
+    }
+    s = kh_wave_sum(s);
+    float n = alpha * s;              // AddDiagMat2(1/cols, in, kNoTrans, 0.0)
+    if (n < floor_v) n = floor_v;     // ApplyFloor(kNormFloor)
+    // ApplyPow(-0.5): the reference's generic branch is a double pow().
+    const float sc = static_cast<float>(1.0 / sqrt(static_cast<double>(n)));
+    float *yr = y + static_cast<size_t>(r) * y_stride;
+    for (int c = lane; c < cols; c += 64) yr[c] = xr[c] * sc;  // MulRowsVec
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+AddDiagMat2Kernel(float alpha, const float *__restrict__ M, int rows, int cols,
+                  int stride, float beta, float *__restrict__ v) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); r < rows;
+       r += gridDim.x * (kBlock / 64)) {
+    const float *xr = M + static_cast<size_t>(r) * stride;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += xr[c] * xr[c];
+    s = kh_wave_sum(s);
+    if (lane == 0) v[r] = (beta == 0.f ? 0.f : beta * v[r]) + alpha * s;
+  }
+}
+
+// ---- a7 sum column ranges: one wave per output row chunk ---------------------------
+__global__ void __launch_bounds__(kBlock)
+SumColumnRangesKernel(float *__restrict__ y, const float *__restrict__ x, int rows,
+                      int cols, int y_stride, int x_stride,
+                      const int32_t *__restrict__ ranges) {
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float *xr = x + static_cast<size_t>(r) * x_stride;
+    for (int c = blockIdx.x * kBlock + threadIdx.x; c < cols;
+         c += gridDim.x * kBlock) {
+      const int s = ranges[2 * c], e = ranges[2 * c + 1];
+      float sum = 0.f;
+      for (int j = s; j < e; j++) sum += xr[j];
+      y[static_cast<size_t>(r) * y_stride + c] = sum;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+LookupKernel(const float *__restrict__ M, int rows, int cols, int stride,
+             const int32_t *__restrict__ pairs, int n, float *__restrict__ out) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+    const int r = pairs[2 * k], c = pairs[2 * k + 1];
+    out[k] = (r >= 0 && r < rows && c >= 0 && c < cols)
+                 ? M[static_cast<size_t>(r) * stride + c]
+                 : __int_as_float(0x7fc00000);
+  }
+}
+
+dim3 RowColGrid(int rows, int cols) {
+  int gx = DivUp(cols, kBlock);
+  if (gx > 32) gx = 32;
+  int gy = rows;
+  const int cap = NumCUs() * 16 / gx;
+  if (gy > cap) gy = cap > 0 ? cap : 1;
+  return dim3(gx, gy);
+}
+
+bool DimOk(const KhMatrixDim &d) {
+  return d.rows >= 0 && d.cols >= 0 && d.stride >= d.cols;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kh_softmax_per_row(float *y, const float *x, KhMatrixDim d, int src_stride) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && src_stride >= d.cols && y && x);
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  if (d.cols <= 1024) {
+    hipLaunchKernelGGL(SoftmaxWaveKernel<false>, dim3(DivUp(d.rows, kBlock / 64)),
+                       dim3(kBlock), 0, Stream(), y, x, d.rows, d.cols, d.stride,
+                       src_stride);
+  } else {
+    hipLaunchKernelGGL(SoftmaxKernel<false>, dim3(d.rows), dim3(kBlock), 0,
+                       Stream(), y, x, d.cols, d.stride, src_stride);
+  }
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_log_softmax_per_row(float *y, const float *x, KhMatrixDim d,
+                           int src_stride) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && src_stride >= d.cols && y && x);
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  if (d.cols <= 1024) {
+    hipLaunchKernelGGL(SoftmaxWaveKernel<true>, dim3(DivUp(d.rows, kBlock / 64)),
+                       dim3(kBlock), 0, Stream(), y, x, d.rows, d.cols, d.stride,
+                       src_stride);
+  } else {
+    hipLaunchKernelGGL(SoftmaxKernel<true>, dim3(d.rows), dim3(kBlock), 0,
+                       Stream(), y, x, d.cols, d.stride, src_stride);
+  }
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_copy_rows(float *dst, KhMatrixDim dd, const float *src, int src_stride,
+                 const int32_t *indices) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(dd) && src_stride >= dd.cols && dst && src && indices);
+  const int ds = dd.stride;
+  return LaunchMap2D(dd.rows, dd.cols, [=] __device__(int r, int c) {
+    const int idx = indices[r];
+    dst[static_cast<size_t>(r) * ds + c] =
+        idx < 0 ? 0.f : src[static_cast<size_t>(idx) * src_stride + c];
+  });
+}
+
+int kh_splice(float *y, KhMatrixDim d_out, const float *x, KhMatrixDim d_in,
+              const int32_t *frame_offsets, int n_offsets) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d_out) && DimOk(d_in) && y && x && frame_offsets);
+  KH_CHECK_ARG(d_in.cols * n_offsets == d_out.cols && d_in.rows == d_out.rows);
+  const int D = d_in.cols, R = d_in.rows, os = d_out.stride, is = d_in.stride;
+  // 2-D over (row, offset-block): the column within a block stays on the lane,
+  // so no per-element divide/modulo (cf. _splice cu-kernels.cu:1764-1775).
+  return LaunchMap2D(d_out.rows * n_offsets, D, [=] __device__(int rk, int c) {
+    const int r = rk / n_offsets, k = rk - r * n_offsets;
+    int sr = r + frame_offsets[k];
+    sr = sr < 0 ? 0 : (sr >= R ? R - 1 : sr);
+    y[static_cast<size_t>(r) * os + k * D + c] = x[static_cast<size_t>(sr) * is + c];
+  });
+}
+
+int kh_group_pnorm(float *y, const float *x, KhMatrixDim d, int src_stride,
+                   int group_size, float power) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && group_size > 0 && y && x &&
+               src_stride >= d.cols * group_size && power >= 0.0f);
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  dim3 grid = RowColGrid(d.rows, d.cols);
+  if (power == 2.0f)
+    hipLaunchKernelGGL(GroupPnormKernel<0>, grid, dim3(kBlock), 0, Stream(), y, x,
+                       d.rows, d.cols, d.stride, src_stride, group_size, power);
+  else if (power == 1.0f)
+    hipLaunchKernelGGL(GroupPnormKernel<1>, grid, dim3(kBlock), 0, Stream(), y, x,
+                       d.rows, d.cols, d.stride, src_stride, group_size, power);
+  else
+    hipLaunchKernelGGL(GroupPnormKernel<2>, grid, dim3(kBlock), 0, Stream(), y, x,
+                       d.rows, d.cols, d.stride, src_stride, group_size, power);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_normalize(float *y, const float *x, KhMatrixDim d, int src_stride) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && src_stride >= d.cols && y && x);
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  const float alpha = static_cast<float>(1.0 / d.cols);
+  const float floor_v = 1.3552527156068805e-20f;  // 2^-66, nnet-component.cc:571
+  int g = DivUp(d.rows, kBlock / 64);
+  if (g > NumCUs() * 8) g = NumCUs() * 8;
+  hipLaunchKernelGGL(NormalizeKernel, dim3(g), dim3(kBlock), 0, Stream(), y, x,
+                     d.rows, d.cols, d.stride, src_stride, alpha, floor_v);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_add_diag_mat2(float alpha, const float *M, KhMatrixDim d, float beta,
+                     float *v) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && v);
+  if (d.rows == 0) return KH_OK;
+  int g = DivUp(d.rows, kBlock / 64);
+  if (g > NumCUs() * 8) g = NumCUs() * 8;
+  hipLaunchKernelGGL(AddDiagMat2Kernel, dim3(g), dim3(kBlock), 0, Stream(), alpha,
+                     M, d.rows, d.cols, d.stride, beta, v);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_mul_rows_vec(float *M, KhMatrixDim d, const float *scale) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && scale);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    M[static_cast<size_t>(r) * s + c] *= scale[r];
+  });
+}
+
+int kh_mul_cols_vec(float *M, KhMatrixDim d, const float *scale) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && scale);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    M[static_cast<size_t>(r) * s + c] *= scale[c];
+  });
+}
+
+int kh_copy_rows_from_vec(float *M, KhMatrixDim d, const float *v) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && v);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    M[static_cast<size_t>(r) * s + c] = v[c];
+  });
+}
+
+int kh_add_vec_to_rows(float alpha, const float *v, float beta, float *M,
+                       KhMatrixDim d) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && v);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    float *p = M + static_cast<size_t>(r) * s + c;
+    const float cur = (beta != 1.0f) ? beta * *p : *p;
+    *p = cur + alpha * v[c];
+  });
+}
+
+int kh_apply_floor(float *M, KhMatrixDim d, float floor_val) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    float *p = M + static_cast<size_t>(r) * s + c;
+    if (*p < floor_val) *p = floor_val;
+  });
+}
+
+int kh_apply_log(float *M, KhMatrixDim d) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    float *p = M + static_cast<size_t>(r) * s + c;
+    *p = logf(*p);
+  });
+}
+
+int kh_apply_exp(float *M, KhMatrixDim d) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    float *p = M + static_cast<size_t>(r) * s + c;
+    *p = expf(*p);
+  });
+}
+
+int kh_apply_pow(float *M, KhMatrixDim d, float power) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M);
+  if (power == 1.0f) return KH_OK;
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    float *p = M + static_cast<size_t>(r) * s + c;
+    const float x = *p;
+    float o;
+    if (power == 2.0f) o = x * x;
+    else if (power == 0.5f) o = sqrtf(x);
+    else o = static_cast<float>(pow(static_cast<double>(x), static_cast<double>(power)));
+    *p = o;
+  });
+}
+
+int kh_scale(float *M, KhMatrixDim d, float alpha) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    M[static_cast<size_t>(r) * s + c] *= alpha;
+  });
+}
+
+int kh_sum_column_ranges(float *y, KhMatrixDim d, const float *x,
+                         KhMatrixDim d_src, const int32_t *ranges) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && DimOk(d_src) && d.rows == d_src.rows && y && x && ranges);
+  if (d.rows == 0 || d.cols == 0) return KH_OK;
+  hipLaunchKernelGGL(SumColumnRangesKernel, RowColGrid(d.rows, d.cols),
+                     dim3(kBlock), 0, Stream(), y, x, d.rows, d.cols, d.stride,
+                     d_src.stride, ranges);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_matrix_lookup(const float *M, KhMatrixDim d, const int32_t *pairs, int n,
+                     float *out) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && (n == 0 || (pairs && out)) && n >= 0);
+  if (n == 0) return KH_OK;
+  int g = DivUp(n, kBlock);
+  if (g > NumCUs() * 8) g = NumCUs() * 8;
+  hipLaunchKernelGGL(LookupKernel, dim3(g), dim3(kBlock), 0, Stream(), M, d.rows,
+                     d.cols, d.stride, pairs, n, out);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+int kh_log_prior_scale(float *M, KhMatrixDim d, const float *log_priors,
+                       float prob_scale) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(DimOk(d) && M && log_priors);
+  const int s = d.stride;
+  return LaunchMap2D(d.rows, d.cols, [=] __device__(int r, int c) {
+    float *p = M + static_cast<size_t>(r) * s + c;
+    float v = *p;
+    if (v < 1.0e-20f) v = 1.0e-20f;           // ApplyFloor(1.0e-20)
+    v = logf(v);                               // ApplyLog()
+    v = v + (-1.0f) * log_priors[c];           // AddVecToRows(-1.0, log priors)
+    *p = v * prob_scale;                       // Scale(prob_scale)
+  });
+}
+
+}  // extern "C"

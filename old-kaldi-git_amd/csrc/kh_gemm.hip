@@ -1,0 +1,260 @@
+// kh_gemm.hip — CuMatrixBase::AddMatMat (cudamatrix/cu-matrix.cc:947-982, which
+// calls cuBLAS sgemm through cublas-wrappers.h:28-33) as a hand-written FP32
+// MFMA GEMM for gfx950.
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is exact f32 — each output element is one
+// k-ordered fmaf chain (guide §3 "FP32-input MFMA").  K is never split across
+// accumulators or workgroups, so the result is bit-identical to
+//     acc = 0; for k in 0..K-1: acc = fmaf(a[i,k], b[k,j], acc)
+// which is what the CPU oracle computes; the epilogue is
+//     c = beta == 0 ? alpha*acc : fl(beta*c) + fl(alpha*acc).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each
+// wave 64x64 = 2x2 MFMA 32x32 tiles -> 64 accumulator VGPRs), BK = 16,
+// double-buffered LDS filled from registers (global loads for tile t+1 are
+// issued before the MFMAs of tile t).  LDS image is [k][m] (+4 pad) so a wave's
+// operand fetch (lanes 0-31: k, lanes 32-63: k+1, consecutive m) is a
+// conflict-free ds_read_b32.  Workgroup ids are remapped so each XCD (own L2)
+// gets a contiguous run of tiles that share an A row panel.
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4;
+constexpr int kThreads = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float *A;  // element (i,k) at A[i*a_si + k*a_sk]
+  const float *B;  // element (j,k) at B[j*b_sj + k*b_sk]
+  float *C;
+  const float *bias;  // optional [N]
+  int M, N, K;
+  long a_si, a_sk, b_sj, b_sk;
+  int c_stride;
+  float alpha, beta;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int XcdRemap(int bid, int nwg) {
+  const int cpx = nwg >> 3, rem = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  return xcd < rem ? xcd * (cpx + 1) + local
+                   : rem * (cpx + 1) + (xcd - rem) * cpx + local;
+}
+
+// Loads 4 consecutive-k elements of one row of an operand tile.
+template <bool VEC>
+__device__ __forceinline__ float4 LoadRow4(const float *base, long s_row, long s_k,
+                                           int row, int k, int rows, int K) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < rows) {
+    if (VEC) {
+      const float *p = base + row * s_row + k;
+      if (k + 3 < K) {
+        v = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (k < K) v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+      }
+    } else {
+      const float *p = base + row * s_row + k * s_k;
+      if (k < K) v.x = p[0];
+      if (k + 1 < K) v.y = p[s_k];
+      if (k + 2 < K) v.z = p[2 * s_k];
+      if (k + 3 < K) v.w = p[3 * s_k];
+    }
+  }
+  return v;
+}
+
+template <bool VEC_A, bool VEC_B>
+__global__ void __launch_bounds__(kThreads, 2) GemmKernel(GemmArgs g) {
+  __shared__ float As[2][BK][LDT];
+  __shared__ float Bs[2][BK][LDT];
+
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int tile = XcdRemap(blockIdx.x, nwg);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = t >> 2;        // 0..63
+  const int lk = (t & 3) << 2;    // 0,4,8,12
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int rowsA = g.M - m0, rowsB = g.N - n0;
+  const float *Ab = g.A + static_cast<long>(m0) * g.a_si;
+  const float *Bb = g.B + static_cast<long>(n0) * g.b_sj;
+
+  float4 ra[2], rb[2];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      ra[i] = LoadRow4<VEC_A>(Ab, g.a_si, g.a_sk, lrow + 64 * i, k0 + lk, rowsA, g.K);
+      rb[i] = LoadRow4<VEC_B>(Bb, g.b_sj, g.b_sk, lrow + 64 * i, k0 + lk, rowsB, g.K);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int m = lrow + 64 * i;
+      As[buf][lk + 0][m] = ra[i].x;
+      As[buf][lk + 1][m] = ra[i].y;
+      As[buf][lk + 2][m] = ra[i].z;
+      As[buf][lk + 3][m] = ra[i].w;
+      Bs[buf][lk + 0][m] = rb[i].x;
+      Bs[buf][lk + 1][m] = rb[i].y;
+      Bs[buf][lk + 2][m] = rb[i].z;
+      Bs[buf][lk + 3][m] = rb[i].w;
+    }
+  };
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int kk = lane >> 5, l31 = lane & 31;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      const int k = 2 * s + kk;
+      float a0 = As[buf][k][wm * 64 + l31];
+      float a1 = As[buf][k][wm * 64 + 32 + l31];
+      float b0 = Bs[buf][k][wn * 64 + l31];
+      float b1 = Bs[buf][k][wn * 64 + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile(buf ^ 1);  // the other buffer was last read in iteration kt-1
+      __syncthreads();
+    }
+  }
+
+  // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row >= g.M) continue;
+        float *cp = g.C + static_cast<size_t>(row) * g.c_stride + col;
+        const float a = acc[i][j][r];
+        float out;
+        if (g.bias) {
+          out = a + bv;
+        } else {
+          const float prod = g.alpha * a;
+          out = (g.beta == 0.f) ? prod : (g.beta * *cp + prod);
+        }
+        *cp = out;
+      }
+    }
+  }
+}
+
+int LaunchGemm(GemmArgs g) {
+  if (g.M == 0 || g.N == 0) return KH_OK;
+  g.tiles_m = DivUp(g.M, BM);
+  g.tiles_n = DivUp(g.N, BN);
+  const int nwg = g.tiles_m * g.tiles_n;
+  const bool va = g.a_sk == 1 && (g.a_si % 4 == 0) &&
+                  (reinterpret_cast<uintptr_t>(g.A) % 16 == 0);
+  const bool vb = g.b_sk == 1 && (g.b_sj % 4 == 0) &&
+                  (reinterpret_cast<uintptr_t>(g.B) % 16 == 0);
+  dim3 grid(nwg), block(kThreads);
+  if (va && vb)
+    hipLaunchKernelGGL((GemmKernel<true, true>), grid, block, 0, Stream(), g);
+  else if (va)
+    hipLaunchKernelGGL((GemmKernel<true, false>), grid, block, 0, Stream(), g);
+  else if (vb)
+    hipLaunchKernelGGL((GemmKernel<false, true>), grid, block, 0, Stream(), g);
+  else
+    hipLaunchKernelGGL((GemmKernel<false, false>), grid, block, 0, Stream(), g);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kh_add_mat_mat(float alpha, const float *A, KhMatrixDim dA, int transA,
+                   const float *B, KhMatrixDim dB, int transB, float beta,
+                   float *C, KhMatrixDim dC) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(A && B && C);
+  KH_CHECK_ARG(dA.stride >= dA.cols && dB.stride >= dB.cols && dC.stride >= dC.cols);
+  const int m = transA ? dA.cols : dA.rows, k = transA ? dA.rows : dA.cols;
+  const int n = transB ? dB.rows : dB.cols, kb = transB ? dB.cols : dB.rows;
+  // KALDI_ASSERT of cu-matrix.cc:959-967
+  KH_CHECK_ARG(m == dC.rows && n == dC.cols && k == kb);
+  GemmArgs g;
+  g.A = A;
+  g.B = B;
+  g.C = C;
+  g.bias = nullptr;
+  g.M = m;
+  g.N = n;
+  g.K = k;
+  g.a_si = transA ? 1 : dA.stride;
+  g.a_sk = transA ? dA.stride : 1;
+  g.b_sj = transB ? dB.stride : 1;
+  g.b_sk = transB ? 1 : dB.stride;
+  g.c_stride = dC.stride;
+  g.alpha = alpha;
+  g.beta = beta;
+  return LaunchGemm(g);
+}
+
+int kh_affine(const float *A, KhMatrixDim dA, const float *W, KhMatrixDim dW,
+              const float *bias, float *C, KhMatrixDim dC) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(A && W && C && bias);
+  KH_CHECK_ARG(dA.cols == dW.cols && dC.rows == dA.rows && dC.cols == dW.rows);
+  KH_CHECK_ARG(dA.stride >= dA.cols && dW.stride >= dW.cols && dC.stride >= dC.cols);
+  GemmArgs g;
+  g.A = A;
+  g.B = W;
+  g.C = C;
+  g.bias = bias;
+  g.M = dA.rows;
+  g.N = dW.rows;
+  g.K = dA.cols;
+  g.a_si = dA.stride;
+  g.a_sk = 1;
+  g.b_sj = dW.stride;
+  g.b_sk = 1;
+  g.c_stride = dC.stride;
+  g.alpha = 1.f;
+  g.beta = 0.f;
+  return LaunchGemm(g);
+}
+
+}  // extern "C"

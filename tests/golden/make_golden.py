@@ -1,0 +1,160 @@
+"""Generate golden input/output vectors from the REFERENCE's own CPU code.
+
+Runs only in the build container (needs /root/reference): it loads
+oracle/_ref/libkaldi_ref.so — the reference's base/matrix/cudamatrix(CPU
+branch)/gmm/nnet2 sources compiled where they lie by oracle/Makefile — feeds it
+seeded inputs, and stores inputs + the reference's outputs as small .npz
+fixtures next to this script.  The fixtures are data only; nothing from
+/root/reference travels.
+
+    python tests/golden/make_golden.py
+
+Cases follow SURVEY.md §8c and the reference's own unit tests
+(cudamatrix/cu-matrix-test.cc: AddMatMat :1038-1066, Softmax :1559-1587,
+CopyRows :379-402 with -1 indices, GroupPnorm :246, SumColumnRanges :442,
+Lookup :2011; cu-math-test.cc Splice; gmm/diag-gmm-test.cc:93-188;
+nnet2/nnet-compute-test.cc:28-80).
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import binding  # noqa: E402
+
+workloads = importlib.import_module("old-kaldi-git_amd.workloads")
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def main():
+    binding.build(ref=True)
+    ref = binding.OracleLib("ref")
+    rng = np.random.default_rng(20151001)
+    f32 = np.float32
+
+    # ---- a1 AddMatMat: NN/NT/TN/TT, alpha/beta in {0, 0.5, 1}, odd sizes
+    cases = {}
+    i = 0
+    for (m, n, k) in [(37, 23, 50), (70, 40, 90), (1, 7, 3), (65, 129, 17)]:
+        for tA in (0, 1):
+            for tB in (0, 1):
+                alpha = [1.0, 0.5, 1.0, 0.5][i % 4]
+                beta = [0.0, 1.0, 0.5, 0.0][(i // 2) % 4]
+                A = rng.standard_normal((k, m) if tA else (m, k)).astype(f32)
+                B = rng.standard_normal((n, k) if tB else (k, n)).astype(f32)
+                Cm = rng.standard_normal((m, n)).astype(f32)
+                out = ref.add_mat_mat(alpha, A, tA, B, tB, beta, Cm)
+                cases["c%d_A" % i], cases["c%d_B" % i], cases["c%d_C" % i] = A, B, Cm
+                cases["c%d_out" % i] = out
+                cases["c%d_par" % i] = np.array([alpha, beta, tA, tB], f32)
+                i += 1
+    cases["n"] = np.array(i)
+    save("add_mat_mat", **cases)
+
+    # ---- a2 softmax / log-softmax: cols 1, 10, 256, 257, 3000; randn*5 and +-80 extremes
+    cases = {}
+    for j, cols in enumerate([1, 10, 59, 256, 257, 3000]):
+        X = (rng.standard_normal((7, cols)) * 5).astype(f32)
+        if cols > 1:
+            X[0, 0], X[0, 1] = 80.0, -80.0
+            X[1, :] = -80.0
+        cases["x%d" % j] = X
+        cases["soft%d" % j] = ref.softmax_per_row(X)
+        cases["logsoft%d" % j] = ref.log_softmax_per_row(X)
+    cases["n"] = np.array(6)
+    save("softmax", **cases)
+
+    # ---- a3 CopyRows with -1; a4 Splice with clamping
+    src = rng.standard_normal((40, 33)).astype(f32)
+    idx = rng.integers(-1, 40, 55).astype(np.int32)
+    idx[:3] = [-1, 0, 39]
+    save("copy_rows", src=src, idx=idx, out=ref.copy_rows(src, idx))
+    offs = np.array([-5, -2, 0, 1, 5], np.int32)
+    save("splice", src=src, offsets=offs, out=ref.splice(src, offs))
+
+    # ---- a5 GroupPnorm p in {1, 2, 3, 0.5}, and overflow rescue for p=3
+    X = rng.standard_normal((19, 60)).astype(f32)
+    Xbig = X.copy()
+    Xbig[0, :10] *= 1e20  # x^2 overflows float -> +inf out of the p == 2 branch
+    cases = dict(x=X, xbig=Xbig)
+    for p in (1.0, 2.0, 3.0, 0.5):
+        cases["p%g" % p] = ref.group_pnorm(X, 10, p)
+    # (p = 3 on such input trips KALDI_ASSERT(tmp != HUGE_VAL), kaldi-vector.cc:533,
+    # before the rescue branch :535-543 can run, so no fixture exists for it.)
+    cases["big_p2"] = ref.group_pnorm(Xbig, 10, 2.0)
+    save("group_pnorm", **cases)
+
+    # ---- a6 Normalize incl. all-zero row; AddDiagMat2; MulRowsVec / MulColsVec
+    X = rng.standard_normal((23, 35)).astype(f32)
+    X[4, :] = 0.0
+    X[5, :] *= 1e-12
+    v = rng.standard_normal(23).astype(f32)
+    s = rng.standard_normal(35).astype(f32)
+    save("normalize", x=X, out=ref.normalize(X), v=v,
+         diag2=ref.add_diag_mat2(0.7, X, 0.3, v),
+         mul_rows=ref.mul_rows_vec(X, v), mul_cols=ref.mul_cols_vec(X, s), s=s)
+
+    # ---- a7 element-wise + SumColumnRanges + Lookup
+    X = (rng.standard_normal((17, 40)) * 3).astype(f32)
+    P = np.abs(X) + f32(1e-3)
+    b = rng.standard_normal(40).astype(f32)
+    sizes = np.array([3, 1, 7, 2, 10, 5, 4, 8], np.int32)
+    ends = np.cumsum(sizes)
+    ranges = np.stack([ends - sizes, ends], 1).astype(np.int32).ravel()
+    pairs = np.stack([rng.integers(0, 17, 29), rng.integers(0, 40, 29)], 1).astype(np.int32).ravel()
+    save("elementwise", x=X, p=P, b=b,
+         copy_rows_from_vec=ref.copy_rows_from_vec(5, b),
+         add_vec_to_rows=ref.add_vec_to_rows(-1.0, b, 1.0, X),
+         add_vec_to_rows_beta=ref.add_vec_to_rows(0.5, b, 0.25, X),
+         floor=ref.apply_floor(X, 0.5), log=ref.apply_log(P), exp=ref.apply_exp(X),
+         pow_half=ref.apply_pow(P, 0.5), pow_2=ref.apply_pow(X, 2.0), pow_m05=ref.apply_pow(P, -0.5),
+         scale=ref.scale(X, 0.1), ranges=ranges, sum_ranges=ref.sum_column_ranges(X, ranges),
+         pairs=pairs, lookup=ref.matrix_lookup(X, pairs))
+
+    # ---- a8 nnet2 forward: random p-norm net (with mix-up SumGroup and const part)
+    net, priors = workloads.tiny_net(np.random.default_rng(7), n_pdf=40)
+    feats = rng.standard_normal((37, 13)).astype(f32)
+    flat = {}
+    for ci, comp in enumerate(net):
+        for key, val in comp.items():
+            if isinstance(val, np.ndarray):
+                flat["c%d_%s" % (ci, key)] = val
+    save("nnet_tiny", feats=feats, priors=priors,
+         out_pad=ref.nnet_forward(net, feats, True), out_nopad=ref.nnet_forward(net, feats, False),
+         logprobs=ref.decodable_am_nnet(net, priors, 0.1, feats),
+         context=np.array(ref.nnet_context(net), np.int32), **flat)
+
+    # ---- a9 DiagGmm: M in {1, 7, 32}, D in {13, 39, 40}; zero-weight component
+    cases = {}
+    for gi, (M, D) in enumerate([(1, 13), (7, 39), (32, 40)]):
+        w = rng.dirichlet(np.ones(M)).astype(f32)
+        if M == 7:
+            w[3] = 0.0
+            w /= w.sum()
+        m = rng.standard_normal((M, D)).astype(f32)
+        v = np.exp(rng.standard_normal((M, D)) * 0.5).astype(f32)
+        data = rng.standard_normal((11, D)).astype(f32)
+        g, mi, iv, bad = ref.ref_diag_gmm_build(w, m, v)
+        ll = ref.ref_diag_gmm_loglikes(w, m, v, data)
+        per_frame = ref.ref_diag_gmm_loglike_per_frame(w, m, v, data)
+        lse_prune5 = np.array([ref.log_sum_exp(ll[t], 5.0) for t in range(len(data))], f32)
+        lse = np.array([ref.log_sum_exp(ll[t], -1.0) for t in range(len(data))], f32)
+        for k, a in dict(w=w, m=m, v=v, data=data, g=g, mi=mi, iv=iv, bad=np.array(bad), ll=ll,
+                         per_frame=per_frame, lse=lse, lse_prune5=lse_prune5).items():
+            cases["g%d_%s" % (gi, k)] = a
+    cases["n"] = np.array(3)
+    save("diag_gmm", **cases)
+
+
+if __name__ == "__main__":
+    main()
