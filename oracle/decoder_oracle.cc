@@ -1,0 +1,899 @@
+// decoder_oracle.cc — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement of LatticeFasterDecoder.  Follows
+//   decoder/lattice-faster-decoder.{h,cc}   (token passing, pruning, lattice)
+//   util/hash-list.h, util/hash-list-inl.h  (HashList: list order + buckets)
+//   decoder/decoder-wrappers.cc:197-293     (what is taken from the decoder)
+//   fstext/lattice-weight.h:295-340         (LatticeWeight Compare/Plus/Times)
+// function by function; each function cites its lines.
+//
+// PARITY UNPINNED by the reference's own tests: src/decoder has no unit tests and
+// the reference decoder cannot be compiled here (it includes fst/fstlib.h;
+// OpenFst 1.3.4 is fetched by tools/Makefile:6 and is absent).  It is pinned by
+// tests/test_decoder_oracle.py instead: brute-force enumeration of all paths
+// on small graphs, invariants the reference asserts, and cross-checks between
+// the two modes below.
+//
+// Two modes:
+//  mode 0 "reference": reproduces the reference's iteration order exactly —
+//     HashList bucket/list order (hash-list-inl.h:125-147, 45-58), the running
+//     next_cutoff of ProcessEmitting (lattice-faster-decoder.cc:731-733), the
+//     LIFO worklist of ProcessNonemitting (:766-811), per-token/per-link
+//     new/delete, and the delta-tolerant Gauss-Seidel sweeps of
+//     PruneForwardLinks (:296-343).  This is what bench.py times as the CPU
+//     baseline.
+//  mode 1 "canonical": the same algorithm with the three places where the
+//     reference's RESULT depends on that (arbitrary) iteration order resolved
+//     order-independently — what a parallel implementation can reproduce:
+//       (E) ProcessEmitting accepts an arc iff tot_cost <= the FINAL next_cutoff
+//           (the reference tests against the running value, which only ever
+//           decreases towards the same final value);
+//       (B) ties for the best token go to the smallest state id;
+//       (P) PruneForwardLinks / PruneForwardLinksFinal iterate extra_costs to the
+//           exact fixed point before excising links (the reference stops when a
+//           sweep changes nothing by more than delta and excises during sweeps).
+//     DESIGN.md "Decoder parity" discusses why, and tests quantify the
+//     difference between the modes.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "decoder_oracle.h"
+
+namespace {
+
+typedef int32_t StateId;
+typedef int32_t Label;
+typedef float BaseFloat;
+const BaseFloat kInf = std::numeric_limits<BaseFloat>::infinity();
+
+// lattice-faster-decoder.h:211-266
+struct Token;
+struct ForwardLink {
+  Token *next_tok;
+  Label ilabel, olabel;
+  BaseFloat graph_cost, acoustic_cost;
+  ForwardLink *next;
+  ForwardLink(Token *nt, Label il, Label ol, BaseFloat g, BaseFloat a, ForwardLink *n)
+      : next_tok(nt), ilabel(il), olabel(ol), graph_cost(g), acoustic_cost(a), next(n) {}
+};
+struct Token {
+  BaseFloat tot_cost, extra_cost;
+  ForwardLink *links;
+  Token *next;
+  StateId state;  // not in the reference: kept so the lattice can be canonicalised
+  Token(BaseFloat t, BaseFloat e, ForwardLink *l, Token *n, StateId s)
+      : tot_cost(t), extra_cost(e), links(l), next(n), state(s) {}
+  void DeleteForwardLinks() {
+    ForwardLink *l = links, *m;
+    while (l != NULL) {
+      m = l->next;
+      delete l;
+      l = m;
+    }
+    links = NULL;
+  }
+};
+struct TokenList {
+  Token *toks;
+  bool must_prune_forward_links, must_prune_tokens;
+  TokenList() : toks(NULL), must_prune_forward_links(true), must_prune_tokens(true) {}
+};
+
+// util/hash-list.h:48-135, hash-list-inl.h.  Same list order: buckets chained in
+// order of first occupation, elements appended inside their bucket.
+class HashList {
+ public:
+  struct Elem {
+    StateId key;
+    Token *val;
+    Elem *tail;
+  };
+  HashList() : list_head_(NULL), bucket_list_tail_(static_cast<size_t>(-1)), hash_size_(0), freed_head_(NULL) {}
+  ~HashList() {
+    for (size_t i = 0; i < allocated_.size(); i++) delete[] allocated_[i];
+  }
+  void SetSize(size_t size) {  // hash-list-inl.h:37-42
+    hash_size_ = size;
+    if (size > buckets_.size()) buckets_.resize(size, HashBucket(0, NULL));
+  }
+  size_t Size() const { return hash_size_; }
+  Elem *Clear() {  // :45-58
+    for (size_t cur = bucket_list_tail_; cur != static_cast<size_t>(-1); cur = buckets_[cur].prev_bucket)
+      buckets_[cur].last_elem = NULL;
+    bucket_list_tail_ = static_cast<size_t>(-1);
+    Elem *ans = list_head_;
+    list_head_ = NULL;
+    return ans;
+  }
+  const Elem *GetList() const { return list_head_; }
+  void Delete(Elem *e) {  // :66-69
+    e->tail = freed_head_;
+    freed_head_ = e;
+  }
+  Elem *Find(StateId key) {  // :72-85
+    size_t index = static_cast<size_t>(key) % hash_size_;
+    HashBucket &bucket = buckets_[index];
+    if (bucket.last_elem == NULL) return NULL;
+    Elem *head = (bucket.prev_bucket == static_cast<size_t>(-1) ? list_head_ : buckets_[bucket.prev_bucket].last_elem->tail),
+         *tail = bucket.last_elem->tail;
+    for (Elem *e = head; e != tail; e = e->tail)
+      if (e->key == key) return e;
+    return NULL;
+  }
+  void Insert(StateId key, Token *val) {  // :118-147
+    size_t index = static_cast<size_t>(key) % hash_size_;
+    HashBucket &bucket = buckets_[index];
+    Elem *elem = New();
+    elem->key = key;
+    elem->val = val;
+    if (bucket.last_elem == NULL) {
+      if (bucket_list_tail_ == static_cast<size_t>(-1)) {
+        list_head_ = elem;
+      } else {
+        buckets_[bucket_list_tail_].last_elem->tail = elem;
+      }
+      elem->tail = NULL;
+      bucket.last_elem = elem;
+      bucket.prev_bucket = bucket_list_tail_;
+      bucket_list_tail_ = index;
+    } else {
+      elem->tail = bucket.last_elem->tail;
+      bucket.last_elem->tail = elem;
+      bucket.last_elem = elem;
+    }
+  }
+
+ private:
+  struct HashBucket {
+    size_t prev_bucket;
+    Elem *last_elem;
+    HashBucket(size_t i, Elem *e) : prev_bucket(i), last_elem(e) {}
+  };
+  Elem *New() {  // :87-101
+    if (!freed_head_) {
+      const size_t n = 1024;  // allocate_block_size_ hash-list.h:129
+      Elem *tmp = new Elem[n];
+      for (size_t i = 0; i + 1 < n; i++) tmp[i].tail = tmp + i + 1;
+      tmp[n - 1].tail = NULL;
+      freed_head_ = tmp;
+      allocated_.push_back(tmp);
+    }
+    Elem *ans = freed_head_;
+    freed_head_ = freed_head_->tail;
+    return ans;
+  }
+  Elem *list_head_;
+  size_t bucket_list_tail_;
+  size_t hash_size_;
+  std::vector<HashBucket> buckets_;
+  Elem *freed_head_;
+  std::vector<Elem *> allocated_;
+};
+typedef HashList::Elem Elem;
+
+struct LatWeight {  // LatticeWeightTpl<float>, fstext/lattice-weight.h:47
+  float v1, v2;
+};
+// fstext/lattice-weight.h:297-312
+inline int Compare(const LatWeight &w1, const LatWeight &w2) {
+  float f1 = w1.v1 + w1.v2, f2 = w2.v1 + w2.v2;
+  if (f1 < f2) return 1;
+  else if (f1 > f2) return -1;
+  else if (w1.v1 < w2.v1) return 1;
+  else if (w1.v1 > w2.v1) return -1;
+  else return 0;
+}
+
+class Decoder {
+ public:
+  Decoder(const KoFst &fst, const KoDecoderConfig &cfg, int mode)
+      : fst_(fst), config_(cfg), mode_(mode), num_toks_(0), warned_(false),
+        decoding_finalized_(false), final_relative_cost_(kInf), final_best_cost_(kInf),
+        ll_(NULL), ll_stride_(0), num_frames_(0), tid2pdf_(NULL), arcs_expanded_(0),
+        tokens_created_(0), max_tokens_frame_(0) {
+    toks_.SetSize(1000);  // lattice-faster-decoder.cc:37
+  }
+  ~Decoder() {
+    DeleteElems(toks_.Clear());
+    ClearActiveTokens();
+  }
+
+  // DecodableMatrixScaledMapped::LogLikelihood decoder/decodable-matrix.h:56-59 /
+  // DecodableAmNnet::LogLikelihood nnet2/decodable-am-nnet.h:77-80 (already scaled).
+  inline BaseFloat LogLikelihood(int32_t frame, Label tid) const {
+    int32_t pdf = tid2pdf_ ? tid2pdf_[tid] : tid - 1;
+    return ll_[static_cast<size_t>(frame) * ll_stride_ + pdf];
+  }
+
+  // lattice-faster-decoder.cc:77-95
+  bool Decode(const float *loglikes, int T, int ll_stride, const int32_t *tid2pdf) {
+    ll_ = loglikes;
+    ll_stride_ = ll_stride;
+    num_frames_ = T;
+    tid2pdf_ = tid2pdf;
+    InitDecoding();
+    while (NumFramesDecoded() < num_frames_) {  // !IsLastFrame(NumFramesDecoded()-1)
+      if (NumFramesDecoded() % config_.prune_interval == 0)
+        PruneActiveTokens(config_.lattice_beam * config_.prune_scale);
+      BaseFloat cost_cutoff = ProcessEmitting();
+      ProcessNonemitting(cost_cutoff);
+    }
+    FinalizeDecoding();
+    return !active_toks_.empty() && active_toks_.back().toks != NULL;
+  }
+
+  inline int32_t NumFramesDecoded() const { return static_cast<int32_t>(active_toks_.size()) - 1; }
+
+  // ---- results --------------------------------------------------------------------
+  struct CanonLattice {
+    std::vector<int32_t> state_frame, state_hclg;
+    std::vector<float> state_final;
+    std::vector<int32_t> arc_src, arc_dst, arc_il, arc_ol;
+    std::vector<float> arc_g, arc_a;
+  };
+
+  // GetRawLattice lattice-faster-decoder.cc:109-191 (use_final_probs = true, after
+  // FinalizeDecoding), emitted in canonical order instead of TopSortTokens order.
+  bool GetRawLattice(CanonLattice *lat) const {
+    int32_t num_frames = static_cast<int32_t>(active_toks_.size()) - 1;
+    struct Key { int32_t f, s; Token *t; };
+    std::vector<Key> keys;
+    for (int32_t f = 0; f <= num_frames; f++) {
+      if (active_toks_[f].toks == NULL) return false;  // :137-141
+      for (Token *tok = active_toks_[f].toks; tok != NULL; tok = tok->next)
+        keys.push_back(Key{f, tok->state, tok});
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+      return a.f != b.f ? a.f < b.f : a.s < b.s;
+    });
+    std::unordered_map<Token *, int32_t> tok_map;
+    tok_map.reserve(keys.size() * 2);
+    for (size_t i = 0; i < keys.size(); i++) tok_map[keys[i].t] = static_cast<int32_t>(i);
+    const size_t n = keys.size();
+    lat->state_frame.resize(n);
+    lat->state_hclg.resize(n);
+    lat->state_final.assign(n, kInf);
+    struct A { int32_t src, il, ol, dst; float g, a; };
+    std::vector<A> arcs;
+    for (size_t i = 0; i < n; i++) {
+      Token *tok = keys[i].t;
+      int32_t f = keys[i].f;
+      lat->state_frame[i] = f;
+      lat->state_hclg[i] = keys[i].s;
+      for (ForwardLink *l = tok->links; l != NULL; l = l->next) {
+        BaseFloat cost_offset = 0.0;
+        if (l->ilabel != 0) cost_offset = cost_offsets_[f];  // :168-171
+        arcs.push_back(A{static_cast<int32_t>(i), l->ilabel, l->olabel, tok_map.at(l->next_tok),
+                         l->graph_cost, l->acoustic_cost - cost_offset});  // :172-174
+      }
+      if (f == num_frames) {  // :177-186
+        if (!final_costs_.empty()) {
+          std::unordered_map<Token *, BaseFloat>::const_iterator it = final_costs_.find(tok);
+          if (it != final_costs_.end()) lat->state_final[i] = it->second;
+        } else {
+          lat->state_final[i] = 0.0f;  // LatticeWeight::One()
+        }
+      }
+    }
+    std::sort(arcs.begin(), arcs.end(), [](const A &x, const A &y) {
+      if (x.src != y.src) return x.src < y.src;
+      if (x.il != y.il) return x.il < y.il;
+      if (x.ol != y.ol) return x.ol < y.ol;
+      if (x.dst != y.dst) return x.dst < y.dst;
+      if (x.g != y.g) return x.g < y.g;
+      return x.a < y.a;
+    });
+    const size_t m = arcs.size();
+    lat->arc_src.resize(m); lat->arc_dst.resize(m); lat->arc_il.resize(m);
+    lat->arc_ol.resize(m); lat->arc_g.resize(m); lat->arc_a.resize(m);
+    for (size_t j = 0; j < m; j++) {
+      lat->arc_src[j] = arcs[j].src; lat->arc_dst[j] = arcs[j].dst;
+      lat->arc_il[j] = arcs[j].il; lat->arc_ol[j] = arcs[j].ol;
+      lat->arc_g[j] = arcs[j].g; lat->arc_a[j] = arcs[j].a;
+    }
+    return n > 0;
+  }
+
+  bool ReachedFinal() const { return final_relative_cost_ != kInf; }  // .h:143-145
+  BaseFloat final_relative_cost() const { return final_relative_cost_; }
+  BaseFloat final_best_cost() const { return final_best_cost_; }
+  int32_t num_toks() const { return num_toks_; }
+  int64_t arcs_expanded() const { return arcs_expanded_; }
+  int64_t tokens_created() const { return tokens_created_; }
+  int32_t max_tokens_frame() const { return max_tokens_frame_; }
+
+ private:
+  // lattice-faster-decoder.cc:55-72
+  void InitDecoding() {
+    DeleteElems(toks_.Clear());
+    cost_offsets_.clear();
+    ClearActiveTokens();
+    warned_ = false;
+    num_toks_ = 0;
+    decoding_finalized_ = false;
+    final_costs_.clear();
+    StateId start_state = fst_.start;
+    active_toks_.resize(1);
+    Token *start_tok = new Token(0.0, 0.0, NULL, NULL, start_state);
+    active_toks_[0].toks = start_tok;
+    toks_.Insert(start_state, start_tok);
+    num_toks_++;
+    tokens_created_++;
+    ProcessNonemitting(config_.beam);
+  }
+
+  // :219-225
+  void PossiblyResizeHash(size_t num_toks) {
+    size_t new_sz = static_cast<size_t>(static_cast<BaseFloat>(num_toks) * config_.hash_ratio);
+    if (new_sz > toks_.Size()) toks_.SetSize(new_sz);
+  }
+
+  // :232-268
+  inline Token *FindOrAddToken(StateId state, int32_t frame_plus_one, BaseFloat tot_cost, bool *changed) {
+    Token *&toks = active_toks_[frame_plus_one].toks;
+    Elem *e_found = toks_.Find(state);
+    if (e_found == NULL) {
+      const BaseFloat extra_cost = 0.0;
+      Token *new_tok = new Token(tot_cost, extra_cost, NULL, toks, state);
+      toks = new_tok;
+      num_toks_++;
+      tokens_created_++;
+      toks_.Insert(state, new_tok);
+      if (changed) *changed = true;
+      return new_tok;
+    } else {
+      Token *tok = e_found->val;
+      if (tok->tot_cost > tot_cost) {
+        tok->tot_cost = tot_cost;
+        if (changed) *changed = true;
+      } else {
+        if (changed) *changed = false;
+      }
+      return tok;
+    }
+  }
+
+  // One sweep of :300-333 over the frame's token list.  excise: delete links with
+  // link_extra_cost > lattice_beam (reference does this during every sweep).
+  // Returns max |new - old| style flag via *changed (> delta).
+  // Shared by both modes.
+  inline void SweepToken(Token *tok, bool excise, BaseFloat init_extra, bool *links_pruned,
+                         BaseFloat *tok_extra_out) {
+    ForwardLink *link, *prev_link = NULL;
+    BaseFloat tok_extra_cost = init_extra;
+    for (link = tok->links; link != NULL;) {
+      Token *next_tok = link->next_tok;
+      BaseFloat link_extra_cost = next_tok->extra_cost +
+          ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost);  // :309-311
+      if (link_extra_cost > config_.lattice_beam) {  // :315
+        if (excise) {
+          ForwardLink *next_link = link->next;
+          if (prev_link != NULL) prev_link->next = next_link;
+          else tok->links = next_link;
+          delete link;
+          link = next_link;
+          if (links_pruned) *links_pruned = true;
+        } else {
+          prev_link = link;
+          link = link->next;
+        }
+      } else {
+        if (link_extra_cost < 0.0) link_extra_cost = 0.0;  // :324-328
+        if (link_extra_cost < tok_extra_cost) tok_extra_cost = link_extra_cost;
+        prev_link = link;
+        link = link->next;
+      }
+    }
+    *tok_extra_out = tok_extra_cost;
+  }
+
+  // :273-344
+  void PruneForwardLinks(int32_t frame_plus_one, bool *extra_costs_changed, bool *links_pruned, BaseFloat delta) {
+    *extra_costs_changed = false;
+    *links_pruned = false;
+    if (mode_ == 0) {
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next) {
+          BaseFloat tok_extra_cost;
+          SweepToken(tok, true, kInf, links_pruned, &tok_extra_cost);
+          if (std::fabs(tok_extra_cost - tok->extra_cost) > delta) changed = true;  // :334
+          tok->extra_cost = tok_extra_cost;
+        }
+        if (changed) *extra_costs_changed = true;
+      }
+    } else {
+      // canonical (P): exact fixed point first, then one excising sweep.
+      std::vector<BaseFloat> entry;
+      for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next)
+        entry.push_back(tok->extra_cost);
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next) {
+          BaseFloat e;
+          SweepToken(tok, false, kInf, NULL, &e);
+          if (!(e == tok->extra_cost)) changed = true;
+          tok->extra_cost = e;
+        }
+      }
+      size_t i = 0;
+      for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next, i++) {
+        BaseFloat e;
+        SweepToken(tok, true, kInf, links_pruned, &e);  // values are final: e == extra_cost
+        if (std::fabs(tok->extra_cost - entry[i]) > delta) *extra_costs_changed = true;
+      }
+    }
+  }
+
+  // :349-431
+  void PruneForwardLinksFinal() {
+    int32_t frame_plus_one = static_cast<int32_t>(active_toks_.size()) - 1;
+    ComputeFinalCosts(&final_costs_, &final_relative_cost_, &final_best_cost_);
+    decoding_finalized_ = true;
+    DeleteElems(toks_.Clear());
+    bool changed = true;
+    BaseFloat delta = 1.0e-05;
+    while (changed) {
+      changed = false;
+      for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next) {
+        BaseFloat final_cost;
+        if (final_costs_.empty()) {
+          final_cost = 0.0;
+        } else {
+          std::unordered_map<Token *, BaseFloat>::const_iterator it = final_costs_.find(tok);
+          final_cost = it != final_costs_.end() ? it->second : kInf;
+        }
+        BaseFloat init = tok->tot_cost + final_cost - final_best_cost_;  // :385
+        BaseFloat tok_extra_cost;
+        SweepToken(tok, mode_ == 0, init, NULL, &tok_extra_cost);
+        if (tok_extra_cost > config_.lattice_beam) tok_extra_cost = kInf;  // :416-417
+        if (mode_ == 0) {
+          // ApproxEqual(a, b, delta) base/kaldi-math.h: |a-b| <= delta*(|a|+|b|)
+          BaseFloat a = tok->extra_cost, b = tok_extra_cost;
+          bool approx = (a == b) || (std::fabs(a - b) <= delta * (std::fabs(a) + std::fabs(b)));
+          if (!approx) changed = true;  // :420-421
+        } else {
+          if (!(tok_extra_cost == tok->extra_cost)) changed = true;
+        }
+        tok->extra_cost = tok_extra_cost;
+      }
+    }
+    if (mode_ != 0) {  // canonical (P): excise with the converged values
+      for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next) {
+        BaseFloat e;
+        SweepToken(tok, true, kInf, NULL, &e);
+      }
+    }
+  }
+
+  // :450-469
+  void PruneTokensForFrame(int32_t frame_plus_one) {
+    Token *&toks = active_toks_[frame_plus_one].toks;
+    Token *tok, *next_tok, *prev_tok = NULL;
+    for (tok = toks; tok != NULL; tok = next_tok) {
+      next_tok = tok->next;
+      if (tok->extra_cost == kInf) {
+        if (prev_tok != NULL) prev_tok->next = tok->next;
+        else toks = tok->next;
+        // the reference leaks nothing here because pruned tokens have no links
+        tok->DeleteForwardLinks();
+        delete tok;
+        num_toks_--;
+      } else {
+        prev_tok = tok;
+      }
+    }
+  }
+
+  // :476-503
+  void PruneActiveTokens(BaseFloat delta) {
+    int32_t cur_frame_plus_one = NumFramesDecoded();
+    for (int32_t f = cur_frame_plus_one - 1; f >= 0; f--) {
+      if (active_toks_[f].must_prune_forward_links) {
+        bool extra_costs_changed = false, links_pruned = false;
+        PruneForwardLinks(f, &extra_costs_changed, &links_pruned, delta);
+        if (extra_costs_changed && f > 0) active_toks_[f - 1].must_prune_forward_links = true;
+        if (links_pruned) active_toks_[f].must_prune_tokens = true;
+        active_toks_[f].must_prune_forward_links = false;
+      }
+      if (f + 1 < cur_frame_plus_one && active_toks_[f + 1].must_prune_tokens) {
+        PruneTokensForFrame(f + 1);
+        active_toks_[f + 1].must_prune_tokens = false;
+      }
+    }
+  }
+
+  // :505-545
+  void ComputeFinalCosts(std::unordered_map<Token *, BaseFloat> *final_costs,
+                         BaseFloat *final_relative_cost, BaseFloat *final_best_cost) {
+    if (final_costs != NULL) final_costs->clear();
+    const Elem *final_toks = toks_.GetList();
+    BaseFloat best_cost = kInf, best_cost_with_final = kInf;
+    while (final_toks != NULL) {
+      StateId state = final_toks->key;
+      Token *tok = final_toks->val;
+      const Elem *next = final_toks->tail;
+      BaseFloat final_cost = fst_.final_cost[state];
+      BaseFloat cost = tok->tot_cost, cost_with_final = cost + final_cost;
+      best_cost = std::min(cost, best_cost);
+      best_cost_with_final = std::min(cost_with_final, best_cost_with_final);
+      if (final_costs != NULL && final_cost != kInf) (*final_costs)[tok] = final_cost;
+      final_toks = next;
+    }
+    if (final_relative_cost != NULL) {
+      if (best_cost == kInf && best_cost_with_final == kInf) *final_relative_cost = kInf;
+      else *final_relative_cost = best_cost_with_final - best_cost;
+    }
+    if (final_best_cost != NULL) {
+      if (best_cost_with_final != kInf) *final_best_cost = best_cost_with_final;
+      else *final_best_cost = best_cost;
+    }
+  }
+
+  // :573-588
+  void FinalizeDecoding() {
+    int32_t final_frame_plus_one = NumFramesDecoded();
+    PruneForwardLinksFinal();
+    for (int32_t f = final_frame_plus_one - 1; f >= 0; f--) {
+      bool b1, b2;
+      BaseFloat dontcare = 0.0;
+      PruneForwardLinks(f, &b1, &b2, dontcare);
+      PruneTokensForFrame(f + 1);
+    }
+    PruneTokensForFrame(0);
+  }
+
+  // :591-658
+  BaseFloat GetCutoff(Elem *list_head, size_t *tok_count, BaseFloat *adaptive_beam, Elem **best_elem) {
+    BaseFloat best_weight = kInf;
+    size_t count = 0;
+    if (config_.max_active == std::numeric_limits<int32_t>::max() && config_.min_active == 0) {
+      for (Elem *e = list_head; e != NULL; e = e->tail, count++) {
+        BaseFloat w = e->val->tot_cost;
+        if (Better(w, e, best_weight, best_elem ? *best_elem : NULL)) {
+          best_weight = w;
+          if (best_elem) *best_elem = e;
+        }
+      }
+      if (tok_count != NULL) *tok_count = count;
+      if (adaptive_beam != NULL) *adaptive_beam = config_.beam;
+      return best_weight + config_.beam;
+    } else {
+      tmp_array_.clear();
+      for (Elem *e = list_head; e != NULL; e = e->tail, count++) {
+        BaseFloat w = e->val->tot_cost;
+        tmp_array_.push_back(w);
+        if (Better(w, e, best_weight, best_elem ? *best_elem : NULL)) {
+          best_weight = w;
+          if (best_elem) *best_elem = e;
+        }
+      }
+      if (tok_count != NULL) *tok_count = count;
+      BaseFloat beam_cutoff = best_weight + config_.beam, min_active_cutoff = kInf, max_active_cutoff = kInf;
+      if (tmp_array_.size() > static_cast<size_t>(config_.max_active)) {
+        std::nth_element(tmp_array_.begin(), tmp_array_.begin() + config_.max_active, tmp_array_.end());
+        max_active_cutoff = tmp_array_[config_.max_active];
+      }
+      if (max_active_cutoff < beam_cutoff) {
+        if (adaptive_beam) *adaptive_beam = max_active_cutoff - best_weight + config_.beam_delta;
+        return max_active_cutoff;
+      }
+      if (tmp_array_.size() > static_cast<size_t>(config_.min_active)) {
+        if (config_.min_active == 0) min_active_cutoff = best_weight;
+        else {
+          std::nth_element(tmp_array_.begin(), tmp_array_.begin() + config_.min_active,
+                           tmp_array_.size() > static_cast<size_t>(config_.max_active)
+                               ? tmp_array_.begin() + config_.max_active : tmp_array_.end());
+          min_active_cutoff = tmp_array_[config_.min_active];
+        }
+      }
+      if (min_active_cutoff > beam_cutoff) {
+        if (adaptive_beam) *adaptive_beam = min_active_cutoff - best_weight + config_.beam_delta;
+        return min_active_cutoff;
+      } else {
+        *adaptive_beam = config_.beam;
+        return beam_cutoff;
+      }
+    }
+  }
+  // reference: strict '<' keeps the first minimum in list order (:599,:611);
+  // canonical (B): ties go to the smallest state id.
+  inline bool Better(BaseFloat w, Elem *e, BaseFloat best_w, Elem *best_e) const {
+    if (w < best_w) return true;
+    if (mode_ != 0 && w == best_w && best_e != NULL && e->key < best_e->key) return true;
+    return false;
+  }
+
+  // :660-750
+  BaseFloat ProcessEmitting() {
+    int32_t frame = static_cast<int32_t>(active_toks_.size()) - 1;
+    active_toks_.resize(active_toks_.size() + 1);
+    Elem *final_toks = toks_.Clear();
+    Elem *best_elem = NULL;
+    BaseFloat adaptive_beam;
+    size_t tok_cnt;
+    BaseFloat cur_cutoff = GetCutoff(final_toks, &tok_cnt, &adaptive_beam, &best_elem);
+    if (static_cast<int32_t>(tok_cnt) > max_tokens_frame_) max_tokens_frame_ = static_cast<int32_t>(tok_cnt);
+    PossiblyResizeHash(tok_cnt);
+    BaseFloat next_cutoff = kInf;
+    BaseFloat cost_offset = 0.0;
+    if (best_elem) {  // :688-705
+      StateId state = best_elem->key;
+      Token *tok = best_elem->val;
+      cost_offset = -tok->tot_cost;
+      for (int64_t a = fst_.arc_offsets[state]; a < fst_.arc_offsets[state + 1]; a++) {
+        if (fst_.ilabel[a] != 0) {
+          // arc.weight = Times(arc.weight, Weight(cost_offset - loglike)); TropicalWeight Times = +
+          BaseFloat w = fst_.weight[a] + (cost_offset - LogLikelihood(frame, fst_.ilabel[a]));
+          BaseFloat new_weight = w + tok->tot_cost;
+          if (new_weight + adaptive_beam < next_cutoff) next_cutoff = new_weight + adaptive_beam;
+        }
+      }
+    }
+    cost_offsets_.resize(frame + 1, 0.0);
+    cost_offsets_[frame] = cost_offset;
+
+    if (mode_ != 0) {
+      // canonical (E): the running cutoff of the loop below only decreases, to
+      // min(estimate, min over ALL emitting arcs of tot_cost + adaptive_beam)
+      // (a rejected arc has tot_cost > cutoff so it cannot lower it).  Compute that
+      // final value first; then accept against it.
+      for (Elem *e = final_toks; e != NULL; e = e->tail) {
+        Token *tok = e->val;
+        if (tok->tot_cost <= cur_cutoff) {
+          StateId state = e->key;
+          for (int64_t a = fst_.arc_offsets[state]; a < fst_.arc_offsets[state + 1]; a++) {
+            if (fst_.ilabel[a] != 0) {
+              BaseFloat ac_cost = cost_offset - LogLikelihood(frame, fst_.ilabel[a]),
+                        graph_cost = fst_.weight[a], cur_cost = tok->tot_cost,
+                        tot_cost = cur_cost + ac_cost + graph_cost;
+              if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+            }
+          }
+        }
+      }
+    }
+
+    for (Elem *e = final_toks, *e_tail; e != NULL; e = e_tail) {  // :716-748
+      StateId state = e->key;
+      Token *tok = e->val;
+      if (tok->tot_cost <= cur_cutoff) {
+        for (int64_t a = fst_.arc_offsets[state]; a < fst_.arc_offsets[state + 1]; a++) {
+          if (fst_.ilabel[a] != 0) {
+            arcs_expanded_++;
+            BaseFloat ac_cost = cost_offset - LogLikelihood(frame, fst_.ilabel[a]),
+                      graph_cost = fst_.weight[a], cur_cost = tok->tot_cost,
+                      tot_cost = cur_cost + ac_cost + graph_cost;
+            if (tot_cost > next_cutoff) continue;
+            else if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+            Token *next_tok = FindOrAddToken(fst_.nextstate[a], frame + 1, tot_cost, NULL);
+            tok->links = new ForwardLink(next_tok, fst_.ilabel[a], fst_.olabel[a], graph_cost, ac_cost, tok->links);
+          }
+        }
+      }
+      e_tail = e->tail;
+      toks_.Delete(e);
+    }
+    return next_cutoff;
+  }
+
+  // :752-812
+  void ProcessNonemitting(BaseFloat cutoff) {
+    int32_t frame = static_cast<int32_t>(active_toks_.size()) - 2;
+    for (const Elem *e = toks_.GetList(); e != NULL; e = e->tail) queue_.push_back(e->key);
+    while (!queue_.empty()) {
+      StateId state = queue_.back();
+      queue_.pop_back();
+      Token *tok = toks_.Find(state)->val;
+      BaseFloat cur_cost = tok->tot_cost;
+      if (cur_cost > cutoff) continue;
+      tok->DeleteForwardLinks();
+      tok->links = NULL;
+      for (int64_t a = fst_.arc_offsets[state]; a < fst_.arc_offsets[state + 1]; a++) {
+        if (fst_.ilabel[a] == 0) {
+          arcs_expanded_++;
+          BaseFloat graph_cost = fst_.weight[a], tot_cost = cur_cost + graph_cost;
+          if (tot_cost < cutoff) {
+            bool changed;
+            Token *new_tok = FindOrAddToken(fst_.nextstate[a], frame + 1, tot_cost, &changed);
+            tok->links = new ForwardLink(new_tok, 0, fst_.olabel[a], graph_cost, 0, tok->links);
+            if (changed) queue_.push_back(fst_.nextstate[a]);
+          }
+        }
+      }
+    }
+  }
+
+  void DeleteElems(Elem *list) {  // :815-820
+    for (Elem *e = list, *e_tail; e != NULL; e = e_tail) {
+      e_tail = e->tail;
+      toks_.Delete(e);
+    }
+  }
+  void ClearActiveTokens() {  // :822-837
+    for (size_t i = 0; i < active_toks_.size(); i++) {
+      for (Token *tok = active_toks_[i].toks; tok != NULL;) {
+        tok->DeleteForwardLinks();
+        Token *next_tok = tok->next;
+        delete tok;
+        num_toks_--;
+        tok = next_tok;
+      }
+    }
+    active_toks_.clear();
+  }
+
+  HashList toks_;
+  std::vector<TokenList> active_toks_;
+  std::vector<StateId> queue_;
+  std::vector<BaseFloat> tmp_array_;
+  const KoFst fst_;
+  KoDecoderConfig config_;
+  int mode_;
+  int32_t num_toks_;
+  bool warned_;
+  bool decoding_finalized_;
+  std::vector<BaseFloat> cost_offsets_;
+  std::unordered_map<Token *, BaseFloat> final_costs_;
+  BaseFloat final_relative_cost_, final_best_cost_;
+  const float *ll_;
+  int ll_stride_, num_frames_;
+  const int32_t *tid2pdf_;
+  int64_t arcs_expanded_, tokens_created_;
+  int32_t max_tokens_frame_;
+};
+
+struct Handle {
+  Decoder *dec;
+  Decoder::CanonLattice lat;
+  bool have_lat;
+};
+
+}  // namespace
+
+// Best path over a canonical lattice: fst::ShortestPath(raw_lat, n=1) +
+// GetLinearSymbolSequence as used by GetBestPath (lattice-faster-decoder.cc:99-105)
+// and DecodeUtteranceLatticeFaster (decoder-wrappers.cc:232-246).  OpenFst's
+// single-shortest-path relaxes "if (nd != Plus(nd, w))" in queue order, so exact
+// ties are resolved by its state numbering (arbitrary in the reference, see
+// GetRawLattice's unordered_map).  Canonical rule used here and by the product:
+// strictly better weight (Compare == 1) wins; on an exact tie the smaller
+// canonical arc index wins; on a tie between final states the smaller state index.
+extern "C" int ko_lattice_best_path(int n_states, int n_arcs, const int32_t *arc_src, const int32_t *arc_dst,
+                                    const int32_t *arc_il, const int32_t *arc_ol, const float *arc_g,
+                                    const float *arc_a, const float *state_final, int32_t *ali, int cap_ali,
+                                    int32_t *n_ali, int32_t *words, int cap_words, int32_t *n_words,
+                                    float *graph_cost, float *acoustic_cost) {
+  if (n_states <= 0) return -1;
+  std::vector<LatWeight> d(n_states, LatWeight{kInf, kInf});
+  std::vector<int32_t> parent(n_states, -1);
+  d[0] = LatWeight{0.f, 0.f};  // start = state 0 = (frame 0, start) token
+  // arcs are sorted by src; sources are ordered by (frame, hclg state) so
+  // emitting arcs always go forward, epsilon arcs may go backward in index:
+  // iterate to the fixed point.
+  bool changed = true;
+  int guard = 0;
+  while (changed && guard++ < n_states + 2) {
+    changed = false;
+    for (int j = 0; j < n_arcs; j++) {
+      const LatWeight &sd = d[arc_src[j]];
+      if (sd.v1 == kInf) continue;
+      LatWeight w{sd.v1 + arc_g[j], sd.v2 + arc_a[j]};
+      LatWeight &nd = d[arc_dst[j]];
+      int c = (nd.v1 == kInf && nd.v2 == kInf) ? 1 : Compare(w, nd);
+      if (c == 1 || (c == 0 && parent[arc_dst[j]] > j)) {
+        if (!(c == 0 && parent[arc_dst[j]] == j)) {
+          nd = w;
+          parent[arc_dst[j]] = j;
+          changed = true;
+        }
+      }
+    }
+  }
+  LatWeight best{kInf, kInf};
+  int best_state = -1;
+  for (int s = 0; s < n_states; s++) {
+    if (state_final[s] == kInf || d[s].v1 == kInf) continue;
+    LatWeight w{d[s].v1 + state_final[s], d[s].v2 + 0.0f};
+    if (best_state < 0 || Compare(w, best) == 1) {
+      best = w;
+      best_state = s;
+    }
+  }
+  if (best_state < 0) return -2;
+  std::vector<int32_t> path;
+  for (int s = best_state; parent[s] >= 0; s = arc_src[parent[s]]) path.push_back(parent[s]);
+  std::reverse(path.begin(), path.end());
+  int na = 0, nw = 0;
+  for (size_t i = 0; i < path.size(); i++) {
+    int j = path[i];
+    if (arc_il[j] != 0) { if (na < cap_ali) ali[na] = arc_il[j]; na++; }
+    if (arc_ol[j] != 0) { if (nw < cap_words) words[nw] = arc_ol[j]; nw++; }
+  }
+  *n_ali = na;
+  *n_words = nw;
+  *graph_cost = best.v1;
+  *acoustic_cost = best.v2;
+  return 0;
+}
+
+extern "C" {
+
+void *ko_decoder_create(const KoFst *fst, const KoDecoderConfig *cfg, int mode) {
+  Handle *h = new Handle();
+  h->dec = new Decoder(*fst, *cfg, mode);
+  h->have_lat = false;
+  return h;
+}
+
+void ko_decoder_destroy(void *hp) {
+  Handle *h = static_cast<Handle *>(hp);
+  if (!h) return;
+  delete h->dec;
+  delete h;
+}
+
+int ko_decoder_decode(void *hp, const float *loglikes, int T, int ll_stride, const int32_t *tid2pdf) {
+  Handle *h = static_cast<Handle *>(hp);
+  h->have_lat = false;
+  return h->dec->Decode(loglikes, T, ll_stride, tid2pdf) ? 1 : 0;
+}
+
+int ko_decoder_get_stats(void *hp, KoDecodeStats *st) {
+  Handle *h = static_cast<Handle *>(hp);
+  if (!h->have_lat) h->have_lat = h->dec->GetRawLattice(&h->lat);
+  st->num_frames = h->dec->NumFramesDecoded();
+  st->reached_final = h->dec->ReachedFinal() ? 1 : 0;
+  st->final_relative_cost = h->dec->final_relative_cost();
+  st->final_best_cost = h->dec->final_best_cost();
+  st->num_tokens = h->have_lat ? static_cast<int32_t>(h->lat.state_frame.size()) : 0;
+  st->num_links = h->have_lat ? static_cast<int32_t>(h->lat.arc_src.size()) : 0;
+  st->arcs_expanded = h->dec->arcs_expanded();
+  st->tokens_created = h->dec->tokens_created();
+  st->status = 0;
+  st->max_tokens_frame = h->dec->max_tokens_frame();
+  return 0;
+}
+
+int ko_decoder_get_raw_lattice(void *hp, int32_t *state_frame, int32_t *state_hclg, float *state_final,
+                               int32_t *arc_src, int32_t *arc_dst, int32_t *arc_il, int32_t *arc_ol,
+                               float *arc_g, float *arc_a) {
+  Handle *h = static_cast<Handle *>(hp);
+  if (!h->have_lat) h->have_lat = h->dec->GetRawLattice(&h->lat);
+  if (!h->have_lat) return -1;
+  const Decoder::CanonLattice &L = h->lat;
+  size_t n = L.state_frame.size(), m = L.arc_src.size();
+  if (state_frame) memcpy(state_frame, L.state_frame.data(), 4 * n);
+  if (state_hclg) memcpy(state_hclg, L.state_hclg.data(), 4 * n);
+  if (state_final) memcpy(state_final, L.state_final.data(), 4 * n);
+  if (arc_src) memcpy(arc_src, L.arc_src.data(), 4 * m);
+  if (arc_dst) memcpy(arc_dst, L.arc_dst.data(), 4 * m);
+  if (arc_il) memcpy(arc_il, L.arc_il.data(), 4 * m);
+  if (arc_ol) memcpy(arc_ol, L.arc_ol.data(), 4 * m);
+  if (arc_g) memcpy(arc_g, L.arc_g.data(), 4 * m);
+  if (arc_a) memcpy(arc_a, L.arc_a.data(), 4 * m);
+  return 0;
+}
+
+int ko_decoder_get_best_path(void *hp, int32_t *ali, int cap_ali, int32_t *n_ali, int32_t *words, int cap_words,
+                             int32_t *n_words, float *graph_cost, float *acoustic_cost) {
+  Handle *h = static_cast<Handle *>(hp);
+  if (!h->have_lat) h->have_lat = h->dec->GetRawLattice(&h->lat);
+  if (!h->have_lat) return -1;
+  const Decoder::CanonLattice &L = h->lat;
+  return ko_lattice_best_path(static_cast<int>(L.state_frame.size()), static_cast<int>(L.arc_src.size()),
+                              L.arc_src.data(), L.arc_dst.data(), L.arc_il.data(), L.arc_ol.data(),
+                              L.arc_g.data(), L.arc_a.data(), L.state_final.data(), ali, cap_ali, n_ali, words,
+                              cap_words, n_words, graph_cost, acoustic_cost);
+}
+
+}  // extern "C"

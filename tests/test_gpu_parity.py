@@ -49,8 +49,20 @@ def test_gemm_dimension_mismatch_raises(api, gpu):
 @pytest.mark.parametrize("rows,cols", [(3, 12000), (50, 5800), (10, 13000), (1, 1), (257, 64)])
 def test_softmax_vs_oracle(gpu, oracle, rng, rows, cols):
     X = (rng.standard_normal((rows, cols)) * 5).astype(np.float32)
-    cases.close(gpu.softmax_per_row(X), oracle.softmax_per_row(X), atol=1e-30)
-    cases.close(gpu.log_softmax_per_row(X), oracle.log_softmax_per_row(X), atol=1e-5)
+    # The reference accumulates the row sum sequentially in float32
+    # (kaldi-vector.cc:842-844), whose rounding error grows ~sqrt(cols)*eps; the
+    # kernel's tree sum does not.  1e-5 (the reference's own test tolerance,
+    # cu-matrix-test.cc:1585, rows <= 60 wide) holds for short rows; wide rows
+    # get 5e-5 relative — still inside north_star's 1e-4 on log-likelihoods.
+    rtol = 1e-5 if cols <= 1024 else 5e-5
+    got, want = gpu.softmax_per_row(X), oracle.softmax_per_row(X)
+    cases.close(got, want, rtol=rtol, atol=1e-30)
+    # and the kernel is at least as close to the exact (float64) softmax
+    x64 = X.astype(np.float64)
+    e = np.exp(x64 - x64.max(1, keepdims=True))
+    truth = e / e.sum(1, keepdims=True)
+    assert np.abs(got / truth - 1).max() <= max(np.abs(want / truth - 1).max(), 2e-6)
+    cases.close(gpu.log_softmax_per_row(X), oracle.log_softmax_per_row(X), rtol=rtol, atol=5e-5)
 
 
 def test_pnorm_normalize_sumgroup_large(gpu, oracle, rng):
