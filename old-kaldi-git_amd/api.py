@@ -318,3 +318,120 @@ class AmDiagGmm:
                                        _p(self.inv_vars), _p(self.pdf_offsets), self.num_pdfs, self.num_mix,
                                        float(log_sum_exp_prune), _p(out), _dim(out).stride))
         return out
+
+
+# ---------------------------------------------------------------- decoder
+def decoder_config(beam=16.0, max_active=2147483647, min_active=200, lattice_beam=10.0,
+                   prune_interval=25, beam_delta=0.5, hash_ratio=2.0, prune_scale=0.1):
+    """LatticeFasterDecoderConfig with the reference's defaults
+    (decoder/lattice-faster-decoder.h:58-66)."""
+    return dict(beam=beam, max_active=max_active, min_active=min_active, lattice_beam=lattice_beam,
+                prune_interval=prune_interval, beam_delta=beam_delta, hash_ratio=hash_ratio,
+                prune_scale=prune_scale)
+
+
+class Fst:
+    """fst::Fst<StdArc> (HCLG) resident on the device as CSR."""
+
+    def __init__(self, graph):
+        off = np.ascontiguousarray(graph["arc_offsets"], np.int64)
+        il = np.ascontiguousarray(graph["ilabel"], np.int32)
+        ol = np.ascontiguousarray(graph["olabel"], np.int32)
+        w = np.ascontiguousarray(graph["weight"], np.float32)
+        ns = np.ascontiguousarray(graph["nextstate"], np.int32)
+        fin = np.ascontiguousarray(graph["final"], np.float32)
+        h = lib().kh_fst_create(int(graph["num_states"]), int(graph["start"]),
+                                off.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(capi.c_int32_p),
+                                ol.ctypes.data_as(capi.c_int32_p), w.ctypes.data_as(capi.c_float_p),
+                                ns.ctypes.data_as(capi.c_int32_p), fin.ctypes.data_as(capi.c_float_p))
+        if not h:
+            raise KhError(lib().kh_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.tid2pdf = None
+        if graph.get("tid2pdf") is not None:
+            self.tid2pdf = torch.as_tensor(np.ascontiguousarray(graph["tid2pdf"], np.int32), device="cuda")
+
+    def num_arcs(self):
+        return lib().kh_fst_num_arcs(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kh_fst_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class LatticeFasterDecoder:
+    """decoder/lattice-faster-decoder.h:96-413 for a batch of utterances.
+
+    decode(loglikes, utt_row_offsets) == Decode(&decodable) per utterance with a
+    DecodableMatrixScaledMapped-style decodable (decoder/decodable-matrix.h:33-84):
+    loglikes[t, tid2pdf[ilabel]] already scaled."""
+
+    def __init__(self, fst, config=None, max_batch=256, max_frames=4096):
+        self.fst = fst
+        cfg = decoder_config() if config is None else config
+        self.cfg = KhDecoderConfig(**cfg)
+        h = lib().kh_decoder_create(fst._h, C.byref(self.cfg), int(max_batch), int(max_frames))
+        if not h:
+            raise KhError(lib().kh_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n_utts = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kh_decoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def decode(self, loglikes, utt_row_offsets=None):
+        if utt_row_offsets is None:
+            utt_row_offsets = [0, loglikes.shape[0]]
+        off = np.ascontiguousarray(utt_row_offsets, np.int32)
+        self.n_utts = len(off) - 1
+        self._T = np.diff(off)
+        t2p = _p(self.fst.tid2pdf) if self.fst.tid2pdf is not None else None
+        self._ll = loglikes  # keep alive
+        check(lib().kh_decoder_decode(self._h, _p(loglikes), _dim(loglikes).stride,
+                                      off.ctypes.data_as(capi.c_int32_p), self.n_utts, t2p))
+
+    def stats(self, utt=0):
+        st = KhDecodeStats()
+        check(lib().kh_decoder_get_stats(self._h, int(utt), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in KhDecodeStats._fields_}
+
+    def reached_final(self, utt=0):
+        return bool(self.stats(utt)["reached_final"])
+
+    def get_raw_lattice(self, utt=0):
+        """GetRawLattice (lattice-faster-decoder.cc:109-191), canonical form."""
+        st = self.stats(utt)
+        n, m = st["num_tokens"], st["num_links"]
+        L = dict(state_frame=np.empty(n, np.int32), state_hclg=np.empty(n, np.int32),
+                 state_final=np.empty(n, np.float32), arc_src=np.empty(m, np.int32),
+                 arc_dst=np.empty(m, np.int32), arc_il=np.empty(m, np.int32), arc_ol=np.empty(m, np.int32),
+                 arc_g=np.empty(m, np.float32), arc_a=np.empty(m, np.float32))
+        ip, fp = capi.c_int32_p, capi.c_float_p
+        check(lib().kh_decoder_get_raw_lattice(
+            self._h, int(utt), L["state_frame"].ctypes.data_as(ip), L["state_hclg"].ctypes.data_as(ip),
+            L["state_final"].ctypes.data_as(fp), L["arc_src"].ctypes.data_as(ip), L["arc_dst"].ctypes.data_as(ip),
+            L["arc_il"].ctypes.data_as(ip), L["arc_ol"].ctypes.data_as(ip), L["arc_g"].ctypes.data_as(fp),
+            L["arc_a"].ctypes.data_as(fp)))
+        return L
+
+    def get_best_path(self, utt=0):
+        """GetBestPath + GetLinearSymbolSequence (decoder-wrappers.cc:232-246)."""
+        cap = int(self._T[utt]) + 16
+        capw = 4 * cap + 64
+        ali, words = np.empty(cap, np.int32), np.empty(capw, np.int32)
+        na, nw = C.c_int32(), C.c_int32()
+        g, a = C.c_float(), C.c_float()
+        check(lib().kh_decoder_get_best_path(self._h, int(utt), ali.ctypes.data_as(capi.c_int32_p), cap, C.byref(na),
+                                             words.ctypes.data_as(capi.c_int32_p), capw, C.byref(nw),
+                                             C.byref(g), C.byref(a)))
+        return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
+                    graph_cost=g.value, acoustic_cost=a.value)

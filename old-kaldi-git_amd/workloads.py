@@ -108,33 +108,38 @@ def gmm_inv_params(am):
 # transition-ids mapped to pdfs.
 # --------------------------------------------------------------------------
 def make_graph(rng, num_states, mean_degree=2.5, eps_frac=0.15, num_tids=None, num_pdfs=100,
-               num_words=1000, final_frac=0.02, weight_max=10.0, locality=None):
+               num_words=1000, final_frac=0.02, weight_max=10.0, locality=None, start_degree=12):
+    """Random HCLG-like graph in CSR form.  State 0 is the start state and gets
+    `start_degree` emitting arcs; about half of the states carry an emitting
+    self-loop (HMM self-transitions); `eps_frac` of the remaining arcs are
+    input-epsilon arcs that only go to higher state ids (acyclic, as
+    LatticeFasterDecoder requires: TopSortTokens asserts on epsilon loops,
+    lattice-faster-decoder.cc:904-905)."""
     if num_tids is None:
         num_tids = 2 * num_pdfs
     deg = rng.geometric(1.0 / mean_degree, size=num_states).astype(np.int64)
     deg = np.minimum(deg, 64)
+    deg[0] = max(int(deg[0]), start_degree)
     offsets = np.zeros(num_states + 1, np.int64)
     offsets[1:] = np.cumsum(deg)
     A = int(offsets[-1])
     src = np.repeat(np.arange(num_states, dtype=np.int64), deg)
-    is_eps = rng.random(A) < eps_frac
-    # epsilon arcs: strictly forward (acyclic); emitting arcs: anywhere (or local)
+    first = np.zeros(A, bool)
+    first[offsets[:-1]] = True
     if locality is None:
         nxt = rng.integers(0, num_states, A)
     else:
         nxt = (src + rng.integers(-locality, locality + 1, A)) % num_states
+    # self-loops on the first arc of ~half the states (never on the start state)
+    selfloop = first & (rng.random(A) < 0.5) & (src != 0)
+    nxt = np.where(selfloop, src, nxt)
+    # epsilon arcs: not the first arc of a state, strictly forward
     fwd = src + 1 + rng.integers(0, max(1, num_states // 50), A)
-    can_eps = fwd < num_states
-    is_eps &= can_eps
+    is_eps = (rng.random(A) < eps_frac) & ~first & (fwd < num_states) & (src != 0)
     nxt = np.where(is_eps, fwd, nxt)
-    # every state keeps a self-loop-ish emitting arc as its first arc so tokens survive
-    first = offsets[:-1]
-    is_eps[first] = False
-    nxt[first] = np.where(rng.random(num_states) < 0.5, np.arange(num_states), nxt[first])
     ilabel = np.where(is_eps, 0, rng.integers(1, num_tids + 1, A)).astype(np.int32)
     olabel = np.where(rng.random(A) < 0.1, rng.integers(1, num_words + 1, A), 0).astype(np.int32)
     weight = (rng.random(A) * weight_max).astype(np.float32)
-    # round weights to a 1/64 grid like -log probs stored in text FSTs do not; keep full floats
     final = np.full(num_states, np.inf, np.float32)
     fin = rng.random(num_states) < final_frac
     final[fin] = (rng.random(int(fin.sum())) * 5.0).astype(np.float32)

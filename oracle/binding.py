@@ -313,3 +313,161 @@ class OracleLib:
 
 def have_ref():
     return os.path.exists(REF_SO)
+
+
+# ----------------------------------------------------------------------------
+# decoder / lattice oracle (decoder_oracle.cc, lattice_oracle.cc)
+# ----------------------------------------------------------------------------
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class KoFst(C.Structure):
+    _fields_ = [("num_states", C.c_int32), ("start", C.c_int32), ("arc_offsets", c_int64_p),
+                ("ilabel", c_int_p), ("olabel", c_int_p), ("weight", c_float_p),
+                ("nextstate", c_int_p), ("final_cost", c_float_p)]
+
+
+class KoDecoderConfig(C.Structure):
+    _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
+                ("lattice_beam", C.c_float), ("prune_interval", C.c_int32), ("beam_delta", C.c_float),
+                ("hash_ratio", C.c_float), ("prune_scale", C.c_float)]
+
+
+class KoDecodeStats(C.Structure):
+    _fields_ = [("num_frames", C.c_int32), ("reached_final", C.c_int32),
+                ("final_relative_cost", C.c_float), ("final_best_cost", C.c_float),
+                ("num_tokens", C.c_int32), ("num_links", C.c_int32),
+                ("arcs_expanded", C.c_int64), ("tokens_created", C.c_int64),
+                ("status", C.c_int32), ("max_tokens_frame", C.c_int32)]
+
+
+def decoder_config(beam=16.0, max_active=2147483647, min_active=200, lattice_beam=10.0,
+                   prune_interval=25, beam_delta=0.5, hash_ratio=2.0, prune_scale=0.1):
+    """LatticeFasterDecoderConfig defaults (lattice-faster-decoder.h:58-66)."""
+    return dict(beam=beam, max_active=max_active, min_active=min_active, lattice_beam=lattice_beam,
+                prune_interval=prune_interval, beam_delta=beam_delta, hash_ratio=hash_ratio,
+                prune_scale=prune_scale)
+
+
+def pack_fst(graph):
+    keep = dict(
+        off=np.ascontiguousarray(graph["arc_offsets"], np.int64),
+        il=_i32(graph["ilabel"]), ol=_i32(graph["olabel"]), w=_f32(graph["weight"]),
+        ns=_i32(graph["nextstate"]), fin=_f32(graph["final"]))
+    f = KoFst(int(graph["num_states"]), int(graph["start"]), keep["off"].ctypes.data_as(c_int64_p),
+              _ip(keep["il"]), _ip(keep["ol"]), _fp(keep["w"]), _ip(keep["ns"]), _fp(keep["fin"]))
+    return f, keep
+
+
+class Lattice(dict):
+    """Canonical raw lattice: states sorted by (frame, hclg state), arcs sorted."""
+
+    def key(self):
+        return tuple(self[k].tobytes() for k in ("state_frame", "state_hclg", "state_final", "arc_src",
+                                                  "arc_dst", "arc_il", "arc_ol", "arc_g", "arc_a"))
+
+
+class DecoderOracle:
+    """LatticeFasterDecoder restatement; mode 'reference' or 'canonical'."""
+
+    def __init__(self, graph, config=None, mode="canonical"):
+        self.lib = C.CDLL(ORACLE_SO)
+        self.lib.ko_decoder_create.restype = C.c_void_p
+        self.lib.ko_decoder_create.argtypes = [C.POINTER(KoFst), C.POINTER(KoDecoderConfig), C.c_int]
+        self.lib.ko_decoder_destroy.argtypes = [C.c_void_p]
+        self.lib.ko_decoder_decode.argtypes = [C.c_void_p, c_float_p, C.c_int, C.c_int, c_int_p]
+        self.lib.ko_decoder_get_stats.argtypes = [C.c_void_p, C.POINTER(KoDecodeStats)]
+        self.lib.ko_decoder_get_raw_lattice.argtypes = [C.c_void_p] + [c_int_p, c_int_p, c_float_p, c_int_p, c_int_p, c_int_p, c_int_p, c_float_p, c_float_p]
+        self.lib.ko_decoder_get_best_path.argtypes = [C.c_void_p, c_int_p, C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_float_p, c_float_p]
+        self.fst, self._keep = pack_fst(graph)
+        cfg = decoder_config() if config is None else config
+        self.cfg = KoDecoderConfig(**cfg)
+        self.tid2pdf = _i32(graph["tid2pdf"]) if graph.get("tid2pdf") is not None else None
+        self.h = C.c_void_p(self.lib.ko_decoder_create(C.byref(self.fst), C.byref(self.cfg), {"reference": 0, "canonical": 3, "canonical_emit_only": 1, "canonical_prune_only": 2}[mode]))
+
+    def __del__(self):
+        try:
+            self.lib.ko_decoder_destroy(self.h)
+        except Exception:
+            pass
+
+    def decode(self, loglikes):
+        ll = _f32(loglikes)
+        self._ll = ll
+        t2p = _ip(self.tid2pdf) if self.tid2pdf is not None else None
+        return bool(self.lib.ko_decoder_decode(self.h, _fp(ll), ll.shape[0], ll.shape[1], t2p))
+
+    def stats(self):
+        st = KoDecodeStats()
+        self.lib.ko_decoder_get_stats(self.h, C.byref(st))
+        return {k: getattr(st, k) for k, _ in KoDecodeStats._fields_}
+
+    def raw_lattice(self):
+        st = self.stats()
+        n, m = st["num_tokens"], st["num_links"]
+        L = Lattice(state_frame=np.empty(n, np.int32), state_hclg=np.empty(n, np.int32),
+                    state_final=np.empty(n, np.float32), arc_src=np.empty(m, np.int32),
+                    arc_dst=np.empty(m, np.int32), arc_il=np.empty(m, np.int32), arc_ol=np.empty(m, np.int32),
+                    arc_g=np.empty(m, np.float32), arc_a=np.empty(m, np.float32))
+        rc = self.lib.ko_decoder_get_raw_lattice(
+            self.h, _ip(L["state_frame"]), _ip(L["state_hclg"]), _fp(L["state_final"]), _ip(L["arc_src"]),
+            _ip(L["arc_dst"]), _ip(L["arc_il"]), _ip(L["arc_ol"]), _fp(L["arc_g"]), _fp(L["arc_a"]))
+        if rc != 0:
+            raise RuntimeError("no lattice")
+        return L
+
+    def best_path(self):
+        cap = self.stats()["num_frames"] + 16
+        capw = 4 * cap + 64
+        ali, words = np.empty(cap, np.int32), np.empty(capw, np.int32)
+        na, nw = C.c_int32(), C.c_int32()
+        g, a = C.c_float(), C.c_float()
+        rc = self.lib.ko_decoder_get_best_path(self.h, _ip(ali), cap, C.byref(na), _ip(words), capw, C.byref(nw), C.byref(g), C.byref(a))
+        if rc != 0:
+            raise RuntimeError("no best path (rc=%d)" % rc)
+        return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(), graph_cost=g.value, acoustic_cost=a.value)
+
+
+def lattice_csr(L):
+    """Canonical lattice -> (top-sorted CSR) for forward-backward.  Canonical state
+    order is (frame, hclg state); epsilon arcs may point backwards in that order, so
+    states are re-sorted topologically (by frame, then epsilon depth)."""
+    n = len(L["state_frame"])
+    depth = np.zeros(n, np.int64)
+    eps = L["arc_il"] == 0
+    for _ in range(n + 1):
+        nd = depth.copy()
+        np.maximum.at(nd, L["arc_dst"][eps], depth[L["arc_src"][eps]] + 1)
+        if np.array_equal(nd, depth):
+            break
+        depth = nd
+    order = np.lexsort((L["state_hclg"], depth, L["state_frame"]))
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    src, dst = rank[L["arc_src"]], rank[L["arc_dst"]]
+    perm = np.lexsort((np.arange(len(src)), src))
+    counts = np.bincount(src, minlength=n)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(counts)
+    return dict(n_states=n, arc_offsets=off, arc_ilabel=L["arc_il"][perm].astype(np.int32),
+                arc_nextstate=dst[perm].astype(np.int32), arc_graph=L["arc_g"][perm].astype(np.float32),
+                arc_acoustic=L["arc_a"][perm].astype(np.float32),
+                state_final=L["state_final"][order].astype(np.float32), perm=perm, order=order)
+
+
+def lattice_forward_backward(csr):
+    """ko_lattice_forward_backward on one CSR lattice."""
+    lib = C.CDLL(ORACLE_SO)
+    fn = lib.ko_lattice_forward_backward
+    fn.restype = C.c_double
+    n = csr["n_states"]
+    m = len(csr["arc_ilabel"])
+    post = np.empty(m, np.float32)
+    times = np.empty(n, np.int32)
+    ac = C.c_double()
+    fwd = C.c_double()
+    off = np.ascontiguousarray(csr["arc_offsets"], np.int64)
+    tot = fn(C.c_int(n), off.ctypes.data_as(c_int64_p), _ip(_i32(csr["arc_ilabel"])), _ip(_i32(csr["arc_nextstate"])),
+             _fp(_f32(csr["arc_graph"])), _fp(_f32(csr["arc_acoustic"])), _fp(_f32(csr["state_final"])),
+             _fp(post), C.byref(ac), _ip(times), C.byref(fwd))
+    return dict(arc_post=post, tot_like=tot, tot_forward=fwd.value, acoustic_like_sum=ac.value, state_times=times)

@@ -22,7 +22,8 @@
 //     new/delete, and the delta-tolerant Gauss-Seidel sweeps of
 //     PruneForwardLinks (:296-343).  This is what bench.py times as the CPU
 //     baseline.
-//  mode 1 "canonical": the same algorithm with the three places where the
+//  mode 3 "canonical" (bit 1 = (E)+(B), bit 2 = (P); the bits can be set
+//     separately to attribute differences): the same algorithm with the three places where the
 //     reference's RESULT depends on that (arbitrary) iteration order resolved
 //     order-independently — what a parallel implementation can reproduce:
 //       (E) ProcessEmitting accepts an arc iff tot_cost <= the FINAL next_cutoff
@@ -189,6 +190,14 @@ inline int Compare(const LatWeight &w1, const LatWeight &w2) {
   else if (w1.v1 < w2.v1) return 1;
   else if (w1.v1 > w2.v1) return -1;
   else return 0;
+}
+
+// base/kaldi-math.h:256-264
+inline bool ApproxEqual(float a, float b, float relative_tolerance) {
+  if (a == b) return true;  // handles infinities
+  float diff = std::abs(a - b);
+  if (diff == kInf || diff != diff) return false;  // diff is +inf or nan
+  return (diff <= relative_tolerance * (std::abs(a) + std::abs(b)));
 }
 
 class Decoder {
@@ -398,7 +407,7 @@ class Decoder {
   void PruneForwardLinks(int32_t frame_plus_one, bool *extra_costs_changed, bool *links_pruned, BaseFloat delta) {
     *extra_costs_changed = false;
     *links_pruned = false;
-    if (mode_ == 0) {
+    if (!(mode_ & 2)) {
       bool changed = true;
       while (changed) {
         changed = false;
@@ -454,20 +463,17 @@ class Decoder {
         }
         BaseFloat init = tok->tot_cost + final_cost - final_best_cost_;  // :385
         BaseFloat tok_extra_cost;
-        SweepToken(tok, mode_ == 0, init, NULL, &tok_extra_cost);
+        SweepToken(tok, !(mode_ & 2), init, NULL, &tok_extra_cost);
         if (tok_extra_cost > config_.lattice_beam) tok_extra_cost = kInf;  // :416-417
-        if (mode_ == 0) {
-          // ApproxEqual(a, b, delta) base/kaldi-math.h: |a-b| <= delta*(|a|+|b|)
-          BaseFloat a = tok->extra_cost, b = tok_extra_cost;
-          bool approx = (a == b) || (std::fabs(a - b) <= delta * (std::fabs(a) + std::fabs(b)));
-          if (!approx) changed = true;  // :420-421
+        if (!(mode_ & 2)) {
+          if (!ApproxEqual(tok->extra_cost, tok_extra_cost, delta)) changed = true;  // :420-421
         } else {
           if (!(tok_extra_cost == tok->extra_cost)) changed = true;
         }
         tok->extra_cost = tok_extra_cost;
       }
     }
-    if (mode_ != 0) {  // canonical (P): excise with the converged values
+    if (mode_ & 2) {  // canonical (P): excise with the converged values
       for (Token *tok = active_toks_[frame_plus_one].toks; tok != NULL; tok = tok->next) {
         BaseFloat e;
         SweepToken(tok, true, kInf, NULL, &e);
@@ -609,7 +615,7 @@ class Decoder {
   // canonical (B): ties go to the smallest state id.
   inline bool Better(BaseFloat w, Elem *e, BaseFloat best_w, Elem *best_e) const {
     if (w < best_w) return true;
-    if (mode_ != 0 && w == best_w && best_e != NULL && e->key < best_e->key) return true;
+    if ((mode_ & 1) && w == best_w && best_e != NULL && e->key < best_e->key) return true;
     return false;
   }
 
@@ -642,7 +648,7 @@ class Decoder {
     cost_offsets_.resize(frame + 1, 0.0);
     cost_offsets_[frame] = cost_offset;
 
-    if (mode_ != 0) {
+    if (mode_ & 1) {
       // canonical (E): the running cutoff of the loop below only decreases, to
       // min(estimate, min over ALL emitting arcs of tot_cost + adaptive_beam)
       // (a rejected arc has tot_cost > cutoff so it cannot lower it).  Compute that

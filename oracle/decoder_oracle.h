@@ -44,7 +44,8 @@ typedef struct KoDecodeStats {
   int32_t max_tokens_frame;
 } KoDecodeStats;
 
-/* mode 0: reference iteration order; mode 1: canonical (order-independent). */
+/* mode 0: reference iteration order; mode 3: canonical (order-independent);
+ * bit 1 = canonical emitting cutoff + best-token tie rule, bit 2 = canonical pruning. */
 void *ko_decoder_create(const KoFst *fst, const KoDecoderConfig *cfg, int mode);
 void ko_decoder_destroy(void *dec);
 int ko_decoder_decode(void *dec, const float *loglikes, int T, int ll_stride, const int32_t *tid2pdf);
