@@ -435,3 +435,60 @@ class LatticeFasterDecoder:
                                              C.byref(g), C.byref(a)))
         return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
                     graph_cost=g.value, acoustic_cost=a.value)
+
+
+# ---------------------------------------------------------------- lattice forward-backward
+def lattice_forward_backward(lats):
+    """LatticeForwardBackward (lat/lattice-functions.cc:272-354) for a batch of
+    top-sorted lattices.  Each lattice is a dict with n_states, arc_offsets (int64,
+    n_states+1), arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final.
+    Returns per lattice: dict(arc_post, tot_like, acoustic_like_sum, state_times, post)
+    where post is the Posterior: per frame a sorted list of (transition-id, weight)
+    merged as MergePairVectorSumming does (:351-352)."""
+    n = len(lats)
+    soff = np.zeros(n + 1, np.int32)
+    for i, L in enumerate(lats):
+        soff[i + 1] = soff[i] + L["n_states"]
+    aoff = [np.zeros(1, np.int64)]
+    base = 0
+    for L in lats:
+        o = np.asarray(L["arc_offsets"], np.int64)
+        aoff.append(o[1:] + base)
+        base += int(o[-1])
+    aoff = np.ascontiguousarray(np.concatenate(aoff))
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(L[k], dt) for L in lats]))
+    il, ns = cat("arc_ilabel", np.int32), cat("arc_nextstate", np.int32)
+    g, a, fin = cat("arc_graph", np.float32), cat("arc_acoustic", np.float32), cat("state_final", np.float32)
+    post = np.empty(len(il), np.float32)
+    tot, ac = np.empty(n, np.float64), np.empty(n, np.float64)
+    times = np.empty(int(soff[-1]), np.int32)
+    ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
+    check(lib().kh_lattice_forward_backward(
+        n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip),
+        ns.ctypes.data_as(ip), g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp),
+        post.ctypes.data_as(fp), tot.ctypes.data_as(dp), ac.ctypes.data_as(dp), times.ctypes.data_as(ip)))
+    out = []
+    for i, L in enumerate(lats):
+        a0, a1 = int(aoff[soff[i]]), int(aoff[soff[i + 1]])
+        t = times[soff[i]:soff[i + 1]]
+        ap = post[a0:a1]
+        # Posterior: (*post)[state_times[s]].push_back((tid, posterior)) for tid != 0
+        src = np.repeat(np.arange(L["n_states"]), np.diff(np.asarray(L["arc_offsets"], np.int64)))
+        tid = il[a0:a1]
+        frames = {}
+        for s, ti, p in zip(src[tid != 0], tid[tid != 0], ap[tid != 0]):
+            frames.setdefault(int(t[s]), {}).setdefault(int(ti), []).append(np.float32(p))
+        max_time = int(t.max()) if len(t) else 0
+        posterior = []
+        for fr in range(max_time):
+            ent = []
+            for ti in sorted(frames.get(fr, {})):
+                acc = np.float32(0.0)
+                for p in frames[fr][ti]:
+                    acc = np.float32(acc + p)
+                if acc != 0.0:
+                    ent.append((ti, float(acc)))
+            posterior.append(ent)
+        out.append(dict(arc_post=ap.copy(), tot_like=float(tot[i]), acoustic_like_sum=float(ac[i]),
+                        state_times=t.copy(), post=posterior))
+    return out

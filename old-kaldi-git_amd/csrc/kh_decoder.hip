@@ -69,39 +69,48 @@ __host__ __device__ __forceinline__ float Dec(uint32_t e) {
 }
 
 // Per-utterance arenas and parameters (device-resident array of these).
+//
+// Tokens and links live in one append-only arena each, in frame order:
+//   tokens: frame 0, frame 1, ...          links: eps(0), emit(0), eps(1), emit(1), ...
+// Every prune_interval frames the tail of both arenas — the "window" = all frames
+// since the compaction before the previous one — is compacted in place (sliding
+// the survivors down).  Frames older than the window have been compacted twice
+// (the second time >= prune_interval frames behind the frontier, i.e. already
+// thinned to lattice density) and never move again.
 struct Utt {
   // inputs
   const float *ll;   // first row of this utterance's log-likelihood matrix
   int32_t ll_stride, T;
-  // token arenas: index space [0, tokC_cap) = compact, [tokC_cap, tokC_cap + tokR_cap) = raw
-  int32_t tokC_cap, tokR_cap;
-  int32_t *tok_state;
-  uint32_t *tok_cost;
+  // token arena
+  int32_t tok_cap;
+  int32_t *tok_state;    // HCLG state, -1 = pruned token
+  uint32_t *tok_cost;    // Enc(tot_cost); free slots hold Enc(+inf)
   float *tok_extra;
   int32_t *tok_eps_b, *tok_eps_n, *tok_emit_b, *tok_emit_n;
-  // link arenas, same split
-  int32_t linkC_cap, linkR_cap;
-  int32_t *link_dst, *link_il, *link_ol;
+  // link arena
+  int32_t link_cap;
+  int32_t *link_dst, *link_il, *link_ol;   // dst: token index, -1 = excised
   float *link_g, *link_a;
-  float *link_tot;       // raw only: [linkR_cap]
+  float *link_tot;       // candidate tot_cost of the frame being expanded [link_frame_cap]
   // per-frame bookkeeping
-  int32_t *frame_b;      // [T+2]: first token of frame f
-  int32_t *frame_e;      // [T+2]: one past the last token of frame f
+  int32_t *frame_b, *frame_e;      // [T+2] token range of frame f
+  int32_t *feps_b, *feps_e;        // [T+2] link range of eps(f)
+  int32_t *femit_b, *femit_e;      // [T+2] link range of emit(f)
   float *cost_offset;    // [T+1]
   uint8_t *must_links;   // [T+2] must_prune_forward_links
   uint8_t *must_toks;    // [T+2] must_prune_tokens
-  // raw-frame temporaries (indexed by token - tokC_cap)
-  int32_t *tmp_slot;     // hash slot of the token (current frame)
-  int32_t *tmp_i;        // compaction remap
-  int32_t *tmp_dirty;    // nonemitting worklist flags; invariant: all zero outside ProcessNonemitting
-  float *tmp_f0, *tmp_f1;  // prune: entry extra, emit-link base (indexed by token - frame_b, capacity tok_frame_cap)
-  int32_t tok_frame_cap;
+  // temporaries
+  int32_t *tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
+  int32_t *tmp_dirty;    // [tok_frame_cap] nonemitting worklist flags; all zero outside ProcessNonemitting
+  float *tmp_f0, *tmp_f1;  // [tok_frame_cap] prune: entry extra, emit-link base (i - frame begin)
+  int32_t *tmp_remap;    // [window_cap] compaction remap (i - window begin)
+  int32_t tok_frame_cap, link_frame_cap, window_cap;
   // hash
   unsigned long long *hash;
   uint32_t hash_mask;
   // outputs
   KhDecodeStats *stats;
-  int32_t *counters;     // [8]: tokC_end, linkC_end, ...
+  int32_t *counters;     // [8]: tok_end, link_end
 };
 
 struct Params {
@@ -125,7 +134,8 @@ struct Shared {
   float bcast_f[8];
   unsigned int hist[256];
   // running state (owned by thread 0, read after barriers)
-  int tokC_end, tokR_end, linkC_end, linkR_end;
+  int tok_end, link_end;
+  int front_b;  // first token of the frame under construction (frontier)
   int status;
   long long arcs_expanded, tokens_created;
   int max_tokens_frame;
@@ -249,8 +259,8 @@ __device__ __forceinline__ uint32_t HashState(int32_t s) {
 // `state` in the frame under construction, creating it if needed (cost slot is
 // pre-filled with +inf: arena invariant), or -1 if the raw arena is full.
 // Entry: low 32 bits = state + 1 (0 = empty), high 32 bits = token + 1 (0 = pending).
-__device__ int FindOrAdd(const Utt &u, int32_t state, int *tokR_end /*LDS counter*/,
-                         int tok_limit) {
+__device__ int FindOrAdd(const Utt &u, int32_t state, int *tok_end /*LDS counter*/,
+                         int tok_limit, int front_b) {
   uint32_t slot = HashState(state) & u.hash_mask;
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
   for (int probes = 0; probes < (1 << 30); probes++) {
@@ -259,7 +269,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, int *tokR_end /*LDS counte
       const unsigned long long old = atomicCAS(&u.hash[slot], kEmpty, want_key);
       if (old == kEmpty) {
         // we own the slot: allocate the token, publish it
-        const int idx = atomicAdd(tokR_end, 1);
+        const int idx = atomicAdd(tok_end, 1);
         if (idx >= tok_limit) {
           // arena full: publish an invalid token so waiters terminate
           atomicExch(&u.hash[slot], want_key | (0xFFFFFFFFull << 32));
@@ -269,7 +279,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, int *tokR_end /*LDS counte
         u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
         u.tok_eps_n[idx] = 0;
         u.tok_emit_n[idx] = 0;
-        u.tmp_slot[idx - u.tokC_cap] = static_cast<int32_t>(slot);
+        u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot);
         atomicExch(&u.hash[slot], want_key | (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32));
         return idx;
       }
@@ -355,20 +365,21 @@ __device__ __forceinline__ float LogLike(const Utt &u, const Params &p, int fram
 }
 
 // ProcessNonemitting :752-812 on the tokens of the frame under construction
-// ([fb, sh.tokR_end)), then generation of the epsilon links with the converged
-// costs.  Returns false on arena overflow.
-__device__ bool ProcessNonemitting(const Utt &u, const Params &p, int fb, float cutoff, Shared &sh) {
-  const int tok_limit = min(u.tokC_cap + u.tokR_cap, fb + u.tok_frame_cap);
+// ([sh.front_b, sh.tok_end)), then generation of the epsilon links with the
+// converged costs.  Returns false on arena overflow.
+__device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, float cutoff, Shared &sh) {
+  const int fb = sh.front_b;
+  const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff
   bool first = true;
   long long my_arcs = 0;
   for (;;) {
-    const int fe = sh.tokR_end;  // tokens existing at the start of the round
+    const int fe = sh.tok_end;  // tokens existing at the start of the round
     __syncthreads();
     bool any = false;
     for (int i = fb + threadIdx.x; i < fe; i += NT) {
       int dirty = 1;
-      if (!first) dirty = atomicExch(&u.tmp_dirty[i - u.tokC_cap], 0);
+      if (!first) dirty = atomicExch(&u.tmp_dirty[i - fb], 0);
       if (!dirty) continue;
       const float cur_cost = Dec(__hip_atomic_load(&u.tok_cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (cur_cost > cutoff) continue;  // :779
@@ -379,24 +390,25 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int fb, float 
         my_arcs++;
         const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
         if (tot_cost < cutoff) {  // :794
-          const int dst = FindOrAdd(u, arc.w, &sh.tokR_end, tok_limit);
-          if (dst < 0) { sh.status = KH_ECAPACITY; continue; }
+          const int dst = FindOrAdd(u, arc.w, &sh.tok_end, tok_limit, fb);
+          if (dst < 0) { sh.status = 1; continue; }
           const uint32_t enc = Enc(tot_cost);
           const uint32_t old = atomicMin(&u.tok_cost[dst], enc);
           if (enc < old) {  // "changed": new or cheaper -> (re)process dst
-            atomicExch(&u.tmp_dirty[dst - u.tokC_cap], 1);
+            atomicExch(&u.tmp_dirty[dst - fb], 1);
             any = true;
           }
         }
       }
     }
     first = false;
-    if (!BlockAny(any, sh)) break;
+    const bool more = BlockAny(any, sh);
     if (sh.status != 0) return false;
+    if (!more) break;
   }
-  if (sh.status != 0) return false;
   // ---- epsilon links: {(tok, arc): cost[tok] <= cutoff, cost[tok] + w < cutoff}
-  const int fe = sh.tokR_end;
+  const int fe = sh.tok_end;
+  const int blk_b = sh.link_end;
   for (int base = fb; base < fe; base += NT) {
     const int i = base + threadIdx.x;
     int cnt = 0, ab = 0, ae = 0;
@@ -415,9 +427,9 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int fb, float 
     }
     int total;
     const int off = BlockExScan(cnt, &total, sh);
-    const int lbase = sh.linkR_end;
-    if (lbase + total > u.linkC_cap + u.linkR_cap) {
-      if (threadIdx.x == 0) sh.status = KH_ECAPACITY;
+    const int lbase = sh.link_end;
+    if (lbase + total > u.link_cap) {
+      if (threadIdx.x == 0) sh.status = 2;
       __syncthreads();
       return false;
     }
@@ -430,7 +442,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int fb, float 
           const int4 arc = p.n_arcs[a];
           const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
           if (tot_cost < cutoff) {
-            const int dst = FindOrAdd(u, arc.w, &sh.tokR_end, tok_limit);  // exists already
+            const int dst = FindOrAdd(u, arc.w, &sh.tok_end, tok_limit, fb);  // exists already
             u.link_dst[l] = dst;
             u.link_il[l] = 0;
             u.link_ol[l] = arc.y;
@@ -442,27 +454,32 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int fb, float 
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) sh.linkR_end = lbase + total;
+    if (threadIdx.x == 0) sh.link_end = lbase + total;
     __syncthreads();
   }
-  sh.arcs_expanded += 0;  // (accumulated below by thread 0)
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) sh.arcs_expanded += tot_arcs;
+  if (threadIdx.x == 0) {
+    sh.arcs_expanded += tot_arcs;
+    u.feps_b[frame] = blk_b;
+    u.feps_e[frame] = sh.link_end;
+  }
   __syncthreads();
   return true;
 }
 
-// Clears the hash entries of the tokens [fb, fe) (they were inserted this frame).
+// Clears the hash entries of the frontier tokens [fb, fe) (inserted this frame).
 __device__ void ClearHash(const Utt &u, int fb, int fe) {
-  for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - u.tokC_cap]] = kEmpty;
+  for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb]] = kEmpty;
   __syncthreads();
 }
 
 // ProcessEmitting :660-750 for frame `frame` (tokens [b, e) -> new tokens appended
-// at sh.tokR_end).  Returns next_cutoff through *next_cutoff; false on overflow.
+// at sh.tok_end, which becomes the new frontier sh.front_b).  Returns next_cutoff
+// through *next_cutoff_out; false on overflow.
 __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b, int e,
                                 float *next_cutoff_out, Shared &sh) {
-  const int tok_limit = min(u.tokC_cap + u.tokR_cap, sh.tokR_end + u.tok_frame_cap);
+  const int nb = sh.tok_end;  // first token of frame + 1
+  const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   const Cutoff c = GetCutoff(u, p, b, e, sh);
   if (threadIdx.x == 0 && c.count > sh.max_tokens_frame) sh.max_tokens_frame = c.count;
   const float inf = INFINITY;
@@ -486,7 +503,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 
   // ---- pass 1: expand every token under cur_cutoff; write candidate links with
   // their tot_cost; reduce min(tot_cost + adaptive_beam).
-  const int link_frame_b = sh.linkR_end;
+  const int link_frame_b = sh.link_end;
   long long my_arcs = 0;
   for (int base = b; base < e; base += NT) {
     const int i = base + threadIdx.x;
@@ -502,9 +519,9 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     }
     int total;
     const int off = BlockExScan(cnt, &total, sh);
-    const int lbase = sh.linkR_end;
-    if (lbase + total > u.linkC_cap + u.linkR_cap) {
-      if (threadIdx.x == 0) sh.status = KH_ECAPACITY;
+    const int lbase = sh.link_end;
+    if (lbase + total > u.link_cap || lbase + total - link_frame_b > u.link_frame_cap) {
+      if (threadIdx.x == 0) sh.status = (lbase + total > u.link_cap) ? 2 : 3;
       __syncthreads();
       return false;
     }
@@ -522,27 +539,33 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         u.link_ol[l] = arc.y;
         u.link_g[l] = graph_cost;
         u.link_a[l] = ac_cost;
-        u.link_tot[l - u.linkC_cap] = tot_cost;
+        u.link_tot[l - link_frame_b] = tot_cost;
         est = fminf(est, tot_cost + c.adaptive_beam);
       }
       my_arcs += cnt;
     }
     __syncthreads();
-    if (threadIdx.x == 0) sh.linkR_end = lbase + total;
+    if (threadIdx.x == 0) sh.link_end = lbase + total;
     __syncthreads();
   }
   // final next_cutoff: the value the reference's running cutoff converges to
   const float next_cutoff = BlockMinF(est, sh);
-  const int link_frame_e = sh.linkR_end;
+  const int link_frame_e = sh.link_end;
+  if (threadIdx.x == 0) {
+    u.femit_b[frame] = link_frame_b;
+    u.femit_e[frame] = link_frame_e;
+    sh.front_b = nb;
+  }
+  __syncthreads();
 
   // ---- pass 2: accept (canonical rule E: tot_cost <= final next_cutoff),
   // FindOrAddToken + cost min; rejected candidates become dead links.
   for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-    const float tot_cost = u.link_tot[l - u.linkC_cap];
+    const float tot_cost = u.link_tot[l - link_frame_b];
     int dst = -1;
     if (!(tot_cost > next_cutoff)) {  // :731 "if (tot_cost > next_cutoff) continue"
-      dst = FindOrAdd(u, u.link_dst[l], &sh.tokR_end, tok_limit);
-      if (dst < 0) sh.status = KH_ECAPACITY;
+      dst = FindOrAdd(u, u.link_dst[l], &sh.tok_end, tok_limit, nb);
+      if (dst < 0) sh.status = 1;
       else atomicMin(&u.tok_cost[dst], Enc(tot_cost));
     }
     u.link_dst[l] = dst;
@@ -674,99 +697,130 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
   __syncthreads();
 }
 
-// Moves the survivors of the raw arenas into the compact arenas and resets the
-// raw arenas.  f0 = frontier frame of the previous compaction (its tokens are in
-// C already, its emitting links are in R); cur = current frontier.
-__device__ bool Compact(const Utt &u, int f0, int cur, Shared &sh) {
-  const int tokR_b = u.tokC_cap;
-  // (1) tokens of frames f0+1 .. cur
-  for (int f = f0 + 1; f <= cur; f++) {
+// In-place sliding compaction of the window [w_lo, cur]: survivors of the token
+// arena tail and of the link arena tail move down, token indices stored in links
+// are rewritten through tmp_remap (frame w_lo - 1 keeps its place but its emitting
+// links point into the window, so their dst fields are rewritten too).
+__device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
+  if (w_lo < 0) w_lo = 0;
+  const int win_b = u.frame_b[w_lo];
+  const int old_tok_end = sh.tok_end;
+  if (old_tok_end - win_b > u.window_cap) {
+    if (threadIdx.x == 0) sh.status = 4;
+    __syncthreads();
+    return false;
+  }
+  // (a) tokens
+  if (threadIdx.x == 0) sh.tok_end = win_b;
+  __syncthreads();
+  for (int f = w_lo; f <= cur; f++) {
     const int b = u.frame_b[f], e = u.frame_e[f];
-    const int new_b = sh.tokC_end;
+    const int new_b = sh.tok_end;
     for (int base = b; base < e; base += NT) {
       const int i = base + threadIdx.x;
-      const int alive = (i < e && u.tok_state[i] >= 0) ? 1 : 0;
-      int total;
-      const int off = BlockExScan(alive, &total, sh);
-      const int dbase = sh.tokC_end;
-      if (dbase + total > u.tokC_cap) {
-        if (threadIdx.x == 0) sh.status = KH_ECAPACITY;
-        __syncthreads();
-        return false;
+      int st = -1, eb = 0, en = 0, mb = 0, mn = 0;
+      uint32_t co = kEncInf;
+      float ex = 0.f;
+      if (i < e) {
+        st = u.tok_state[i]; co = u.tok_cost[i]; ex = u.tok_extra[i];
+        eb = u.tok_eps_b[i]; en = u.tok_eps_n[i]; mb = u.tok_emit_b[i]; mn = u.tok_emit_n[i];
       }
+      const int alive = st >= 0 ? 1 : 0;
+      int total;
+      const int off = BlockExScan(alive, &total, sh);  // barriers: all reads of the chunk are done
+      const int dbase = sh.tok_end;
       if (i < e) {
         int ni = -1;
         if (alive) {
           ni = dbase + off;
-          u.tok_state[ni] = u.tok_state[i];
-          u.tok_cost[ni] = u.tok_cost[i];
-          u.tok_extra[ni] = u.tok_extra[i];
-          u.tok_eps_b[ni] = u.tok_eps_b[i];
-          u.tok_eps_n[ni] = u.tok_eps_n[i];
-          u.tok_emit_b[ni] = u.tok_emit_b[i];
-          u.tok_emit_n[ni] = f < cur ? u.tok_emit_n[i] : 0;
+          u.tok_state[ni] = st; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
+          u.tok_eps_b[ni] = eb; u.tok_eps_n[ni] = en; u.tok_emit_b[ni] = mb; u.tok_emit_n[ni] = mn;
         }
-        u.tmp_i[i - tokR_b] = ni;  // remap
-        u.tok_cost[i] = kEncInf;   // arena invariant: free raw slots hold +inf
+        u.tmp_remap[i - win_b] = ni;
       }
       __syncthreads();
-      if (threadIdx.x == 0) sh.tokC_end = dbase + total;
+      if (threadIdx.x == 0) sh.tok_end = dbase + total;
       __syncthreads();
     }
     if (threadIdx.x == 0) {
       u.frame_b[f] = new_b;
-      u.frame_e[f] = sh.tokC_end;
+      u.frame_e[f] = sh.tok_end;
     }
     __syncthreads();
   }
-  // (2) links: emitting links of f0.., epsilon links of f0+1.. (tokens at their new place)
-  for (int f = (f0 < 0 ? 0 : f0); f <= cur; f++) {
-    const int b = u.frame_b[f], e = u.frame_e[f];
-    for (int kind = 0; kind < 2; kind++) {  // 0: epsilon, 1: emitting
-      if (kind == 0 && f == f0) continue;   // already compact
-      if (kind == 1 && f == cur) continue;  // not created yet
-      for (int base = b; base < e; base += NT) {
-        const int i = base + threadIdx.x;
-        int cnt = 0, lbeg = 0, n = 0;
-        if (i < e && u.tok_state[i] >= 0) {
-          lbeg = kind ? u.tok_emit_b[i] : u.tok_eps_b[i];
-          n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
-          for (int l = lbeg; l < lbeg + n; l++)
-            if (u.link_dst[l] >= 0) cnt++;
-        }
-        int total;
-        const int off = BlockExScan(cnt, &total, sh);
-        const int dbase = sh.linkC_end;
-        if (dbase + total > u.linkC_cap) {
-          if (threadIdx.x == 0) sh.status = KH_ECAPACITY;
-          __syncthreads();
-          return false;
-        }
-        if (i < e && u.tok_state[i] >= 0) {
-          int d = dbase + off;
-          for (int l = lbeg; l < lbeg + n; l++) {
-            const int dst = u.link_dst[l];
-            if (dst < 0) continue;
-            u.link_dst[d] = dst >= tokR_b ? u.tmp_i[dst - tokR_b] : dst;
-            u.link_il[d] = u.link_il[l];
-            u.link_ol[d] = u.link_ol[l];
-            u.link_g[d] = u.link_g[l];
-            u.link_a[d] = u.link_a[l];
-            d++;
-          }
-          if (kind) { u.tok_emit_b[i] = dbase + off; u.tok_emit_n[i] = cnt; }
-          else { u.tok_eps_b[i] = dbase + off; u.tok_eps_n[i] = cnt; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) sh.linkC_end = dbase + total;
-        __syncthreads();
-      }
+  const int new_tok_end = sh.tok_end;
+  // arena invariant: free slots hold +inf
+  for (int i = new_tok_end + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
+  // (b) emitting links of frame w_lo - 1 point into the window: rewrite in place
+  if (w_lo > 0) {
+    for (int l = u.femit_b[w_lo - 1] + threadIdx.x; l < u.femit_e[w_lo - 1]; l += NT) {
+      const int dst = u.link_dst[l];
+      if (dst >= win_b) u.link_dst[l] = u.tmp_remap[dst - win_b];
     }
   }
-  if (threadIdx.x == 0) {
-    sh.tokR_end = u.tokC_cap;
-    sh.linkR_end = u.linkC_cap;
+  __syncthreads();
+  // (c) links, block by block in arena order: eps(f), emit(f)
+  if (threadIdx.x == 0) sh.link_end = u.feps_b[w_lo];
+  __syncthreads();
+  for (int f = w_lo; f <= cur; f++) {
+    for (int kind = 0; kind < 2; kind++) {  // 0: epsilon, 1: emitting
+      if (kind == 1 && f == cur) continue;  // not created yet
+      const int blk_b = kind ? u.femit_b[f] : u.feps_b[f];
+      const int blk_e = kind ? u.femit_e[f] : u.feps_e[f];
+      const int new_blk_b = sh.link_end;
+      // per-token new link ranges (tokens already sit at their new index)
+      {
+        const int b = u.frame_b[f], e = u.frame_e[f];
+        int running = new_blk_b;
+        for (int base = b; base < e; base += NT) {
+          const int i = base + threadIdx.x;
+          int cnt = 0;
+          if (i < e) {
+            const int lbeg = kind ? u.tok_emit_b[i] : u.tok_eps_b[i];
+            const int n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
+            for (int l = lbeg; l < lbeg + n; l++)
+              if (u.link_dst[l] >= 0) cnt++;
+          }
+          int total;
+          const int off = BlockExScan(cnt, &total, sh);
+          if (i < e) {
+            if (kind) { u.tok_emit_b[i] = running + off; u.tok_emit_n[i] = cnt; }
+            else { u.tok_eps_b[i] = running + off; u.tok_eps_n[i] = cnt; }
+          }
+          running += total;
+        }
+      }
+      __syncthreads();
+      // flat move of the block's slots
+      for (int base = blk_b; base < blk_e; base += NT) {
+        const int l = base + threadIdx.x;
+        int dst = -1, il = 0, ol = 0;
+        float g = 0.f, a = 0.f;
+        if (l < blk_e) {
+          dst = u.link_dst[l];
+          if (dst >= 0) { il = u.link_il[l]; ol = u.link_ol[l]; g = u.link_g[l]; a = u.link_a[l]; }
+        }
+        const int alive = dst >= 0 ? 1 : 0;
+        int total;
+        const int off = BlockExScan(alive, &total, sh);
+        const int dbase = sh.link_end;
+        if (alive) {
+          const int d = dbase + off;
+          u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
+          u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh.link_end = dbase + total;
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = sh.link_end; }
+        else { u.feps_b[f] = new_blk_b; u.feps_e[f] = sh.link_end; }
+      }
+      __syncthreads();
+    }
   }
+  if (threadIdx.x == 0) sh.front_b = u.frame_b[cur];
   __syncthreads();
   return true;
 }
@@ -776,10 +830,9 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
   const Utt u = utts[blockIdx.x];
   const float inf = INFINITY;
   if (threadIdx.x == 0) {
-    sh.tokC_end = 0;
-    sh.linkC_end = 0;
-    sh.tokR_end = u.tokC_cap;
-    sh.linkR_end = u.linkC_cap;
+    sh.tok_end = 0;
+    sh.link_end = 0;
+    sh.front_b = 0;
     sh.status = 0;
     sh.arcs_expanded = 0;
     sh.tokens_created = 0;
@@ -793,37 +846,38 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
 
   // ---- InitDecoding :55-72
   if (threadIdx.x == 0) {
-    const int idx = FindOrAdd(u, p.start, &sh.tokR_end, u.tokC_cap + u.tokR_cap);
+    const int idx = FindOrAdd(u, p.start, &sh.tok_end, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
     u.frame_b[0] = idx;
   }
   __syncthreads();
-  bool ok = ProcessNonemitting(u, p, u.tokC_cap, p.beam, sh);
-  int fb = u.tokC_cap;           // first token of the frontier frame
-  int fe = sh.tokR_end;
+  bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
+  int fb = 0;                    // token range of the frontier frame
+  int fe = sh.tok_end;
   if (threadIdx.x == 0) { u.frame_e[0] = fe; sh.tokens_created += fe - fb; }
-  ClearHash(u, fb, fe);
-  int last_compact = -1;          // frontier of the previous compaction
+  if (ok) ClearHash(u, fb, fe);
+  // Compaction window: everything younger than 2 * max(prune_interval, 25) frames
+  // (frames leave it only once they are >= 25 frames behind the frontier, i.e.
+  // thinned to lattice density by the backward pruning).
+  const int win_frames = 2 * (p.prune_interval > 25 ? p.prune_interval : 25);
 
   // ---- Decode :77-95
   int t = 0;
   for (; ok && t < u.T; t++) {
     if (t % p.prune_interval == 0 && t > 0) {
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
-      ok = Compact(u, last_compact, t, sh);
+      ok = Compact(u, t - win_frames, t, sh);
       if (!ok) break;
-      last_compact = t;
       fb = u.frame_b[t];
       fe = u.frame_e[t];
     }
     float next_cutoff;
-    const int nb = sh.tokR_end;  // new frame's tokens start here
     ok = ProcessEmitting(u, p, t, fb, fe, &next_cutoff, sh);
     if (!ok) break;
-    ok = ProcessNonemitting(u, p, nb, next_cutoff, sh);
+    ok = ProcessNonemitting(u, p, t + 1, next_cutoff, sh);
     if (!ok) break;
-    fb = nb;
-    fe = sh.tokR_end;
+    fb = sh.front_b;
+    fe = sh.tok_end;
     if (threadIdx.x == 0) {
       u.frame_b[t + 1] = fb;
       u.frame_e[t + 1] = fe;
@@ -863,7 +917,8 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
       PruneTokensForFrame(u, u.frame_b[f + 1], u.frame_e[f + 1]);
     }
     PruneTokensForFrame(u, u.frame_b[0], u.frame_e[0]);
-    ok = Compact(u, last_compact, last, sh);
+    // final compaction of the window so the export below copies little
+    ok = Compact(u, last - win_frames, last, sh);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -871,11 +926,11 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
     st.tokens_created = sh.tokens_created;
     st.status = sh.status;
     st.max_tokens_frame = sh.max_tokens_frame;
-    st.num_tokens = sh.tokC_end;   // slots used in C (dead ones included; host filters)
-    st.num_links = sh.linkC_end;
+    st.num_tokens = sh.tok_end;   // arena slots in use (pruned ones included; host filters)
+    st.num_links = sh.link_end;
     *u.stats = st;
-    u.counters[0] = sh.tokC_end;
-    u.counters[1] = sh.linkC_end;
+    u.counters[0] = sh.tok_end;
+    u.counters[1] = sh.link_end;
   }
 }
 
@@ -933,13 +988,18 @@ void CarveUtt(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, i
               float hash_ratio) {
   u.T = T;
   u.tok_frame_cap = tok_frame_cap;
-  const int frames_raw = prune_interval + 2;
-  u.tokR_cap = tok_frame_cap * std::min(frames_raw, T + 2);
-  u.linkR_cap = link_frame_cap * std::min(frames_raw, T + 2);
-  u.tokC_cap = std::max(65536, 192 * (T + 2)) + tok_frame_cap;
-  u.linkC_cap = std::max(131072, 384 * (T + 2)) + link_frame_cap;
-  const size_t nt = static_cast<size_t>(u.tokC_cap) + u.tokR_cap;
-  const size_t nl = static_cast<size_t>(u.linkC_cap) + u.linkR_cap;
+  u.link_frame_cap = link_frame_cap;
+  // window: two pruning intervals + frontier; stable part: lattice density
+  const long long win_frames = std::min<long long>(2ll * std::max(prune_interval, 25) + prune_interval + 3, T + 2);
+  long long per_frame = 256;
+  if (const char *e = getenv("KH_DECODER_STABLE_TOKENS_PER_FRAME")) per_frame = atoll(e);
+  const long long stable_tok = std::max<long long>(65536, per_frame * (T + 2));
+  const long long tok_cap = stable_tok + win_frames * tok_frame_cap;
+  const long long link_cap = 3 * stable_tok + win_frames * link_frame_cap;
+  u.window_cap = static_cast<int32_t>(std::min<long long>(tok_cap, 0x7fffffff));
+  u.tok_cap = static_cast<int32_t>(std::min<long long>(tok_cap, 0x7fffffff));
+  u.link_cap = static_cast<int32_t>(std::min<long long>(link_cap, 0x7fffffff));
+  const size_t nt = u.tok_cap, nl = u.link_cap;
   u.tok_state = c.Take<int32_t>(nt);
   u.tok_cost = c.Take<uint32_t>(nt);
   u.tok_extra = c.Take<float>(nt);
@@ -947,24 +1007,26 @@ void CarveUtt(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, i
   u.tok_eps_n = c.Take<int32_t>(nt);
   u.tok_emit_b = c.Take<int32_t>(nt);
   u.tok_emit_n = c.Take<int32_t>(nt);
+  u.tmp_remap = c.Take<int32_t>(nt);
   u.link_dst = c.Take<int32_t>(nl);
   u.link_il = c.Take<int32_t>(nl);
   u.link_ol = c.Take<int32_t>(nl);
   u.link_g = c.Take<float>(nl);
   u.link_a = c.Take<float>(nl);
-  u.link_tot = c.Take<float>(u.linkR_cap);
+  u.link_tot = c.Take<float>(link_frame_cap);
   u.frame_b = c.Take<int32_t>(T + 2);
   u.frame_e = c.Take<int32_t>(T + 2);
+  u.feps_b = c.Take<int32_t>(T + 2);
+  u.feps_e = c.Take<int32_t>(T + 2);
+  u.femit_b = c.Take<int32_t>(T + 2);
+  u.femit_e = c.Take<int32_t>(T + 2);
   u.cost_offset = c.Take<float>(T + 1);
   u.must_links = c.Take<uint8_t>(T + 2);
   u.must_toks = c.Take<uint8_t>(T + 2);
-  u.tmp_slot = c.Take<int32_t>(u.tokR_cap);
-  u.tmp_i = c.Take<int32_t>(u.tokR_cap);
-  u.tmp_dirty = c.Take<int32_t>(u.tokR_cap);
-  // prune temporaries are indexed by (token - frame begin): a frame never holds
-  // more than tokR_cap tokens
-  u.tmp_f0 = c.Take<float>(u.tokR_cap);
-  u.tmp_f1 = c.Take<float>(u.tokR_cap);
+  u.tmp_slot = c.Take<int32_t>(tok_frame_cap);
+  u.tmp_dirty = c.Take<int32_t>(tok_frame_cap);
+  u.tmp_f0 = c.Take<float>(tok_frame_cap);
+  u.tmp_f1 = c.Take<float>(tok_frame_cap);
   size_t hs = 1;
   while (hs < static_cast<size_t>(hash_ratio * tok_frame_cap)) hs <<= 1;
   u.hash_mask = static_cast<uint32_t>(hs - 1);
@@ -979,7 +1041,7 @@ int BuildLattice(KhDecoder *d, int ui) {
   const Utt &u = d->h_utts[ui];
   const KhDecodeStats &st = d->h_stats[ui];
   if (st.status != 0) {
-    SetError("utterance %d: decoder arena overflow (status %d); raise capacities", ui, st.status);
+    SetError("utterance %d: decoder arena overflow (code %d); raise capacities", ui, st.status);
     return KH_ECAPACITY;
   }
   const int nt = st.num_tokens, nl = st.num_links, T = u.T;
@@ -1264,10 +1326,9 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   // arena invariants: raw token costs = +inf, hash empty
   for (int i = 0; i < n_utts; i++) {
     Utt &u = d->h_utts[i];
-    const size_t nt = static_cast<size_t>(u.tokC_cap) + u.tokR_cap;
-    hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, u.tok_cost, nt, kEncInf);
+    hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
     KH_HIP(hipMemsetAsync(u.hash, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
-    KH_HIP(hipMemsetAsync(u.tmp_dirty, 0, sizeof(int32_t) * u.tokR_cap, st));
+    KH_HIP(hipMemsetAsync(u.tmp_dirty, 0, sizeof(int32_t) * u.tok_frame_cap, st));
   }
   KH_HIP(hipMemcpyAsync(d->d_utts, d->h_utts.data(), sizeof(Utt) * n_utts, hipMemcpyHostToDevice, st));
   Params p;
@@ -1294,9 +1355,15 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   KH_HIP(hipStreamSynchronize(st));
   for (int i = 0; i < n_utts; i++) {
     if (d->h_stats[i].status != 0) {
-      SetError("kh_decoder_decode: utterance %d overflowed a decoder arena (tokens/frame cap %d, "
-               "links/frame cap %d); set KH_DECODER_TOKENS_PER_FRAME / KH_DECODER_LINKS_PER_FRAME",
-               i, d->tok_frame_cap, d->link_frame_cap);
+      static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena",
+                                   "links-per-frame cap", "compaction window", "?"};
+      const KhDecodeStats &hs = d->h_stats[i];
+      SetError("kh_decoder_decode: utterance %d overflowed the %s at frame %d (tokens/frame cap %d, "
+               "links/frame cap %d, token arena %d/%d, link arena %d/%d); set "
+               "KH_DECODER_TOKENS_PER_FRAME / KH_DECODER_LINKS_PER_FRAME",
+               i, what[std::min(std::max(hs.status, 0), 5)], hs.num_frames, d->tok_frame_cap,
+               d->link_frame_cap, hs.num_tokens, d->h_utts[i].tok_cap, hs.num_links,
+               d->h_utts[i].link_cap);
       return KH_ECAPACITY;
     }
   }
