@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec decoded + real-time factor, LibriSpeech-shaped
+nnet2 decode (BASELINE.json config 4) on N MI355X of one node.
+
+A "step" = one pass of the hot path over one per-GPU shard of utterances, inputs
+already resident in HBM:  nnet2 forward of every frame (Splice -> FixedAffine ->
+4 x (Affine, Pnorm, Normalize) -> Affine -> Softmax -> SumGroup, then
+DecodableAmNnet's floor/log/-log prior/x acwt)  ->  LatticeFasterDecoder over the
+whole shard (beam 15, max-active 7000, min-active 200, lattice-beam 8, acwt 0.1:
+steps/nnet2/decode.sh:14-20)  ->  raw lattice + best path of every utterance
+(what DecodeUtteranceLatticeFaster takes from the decoder,
+decoder-wrappers.cc:232-262; lattice determinization is outside SURVEY.md §8).
+
+Workload ("librispeech_nnet_a_synthetic"): no corpus or trained model is
+available offline, so everything is seeded synthetic data of the reference
+recipe's shape: nnet_a 140 -> 700 -> 4x(3500/350) ->
+12000 -> 5800 pdfs with random weights, a random HCLG-like graph with 10 M
+states / ~25 M arcs, and a per-GPU shard of 328 utterances (1/8 of
+test-clean's 2620) with a LibriSpeech-like length distribution.  Multi-GPU =
+utterance sharding (weak scaling: every rank decodes its own 328-utterance
+shard); the only collective is the final all-reduce of {frames, utterances,
+tot_like} (nnet-latgen-faster.cc:100-101,133-135) over RCCL.
+
+RTF = elapsed * 100 / frames (nnet-latgen-faster.cc:179-182).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "old-kaldi-git_amd"
+
+ACWT = 0.1
+DECODE_CFG = dict(beam=15.0, max_active=7000, min_active=200, lattice_beam=8.0)
+
+
+def build_workload(seed, rank, n_utts, graph_states, small=False):
+    workloads = importlib.import_module(PKG + ".workloads")
+    rng = np.random.default_rng(seed)           # model + graph: identical on every rank
+    if small:
+        net, priors = workloads.make_pnorm_net(rng, feat_dim=40, splice=2, const_dim=10, pnorm_in=400,
+                                               pnorm_out=40, n_hidden=2, n_mix=600, n_pdf=300, final_scale=2.0)
+    else:
+        net, priors = workloads.librispeech_nnet_a(rng, final_scale=2.0)
+    n_pdf = net[-1]["output_dim"]
+    g = workloads.make_hclg_like(rng, graph_states, n_pdf)
+    urng = np.random.default_rng(seed * 1000 + 17 + rank)   # this rank's utterances
+    if small:
+        lens = urng.integers(40, 120, n_utts)
+    else:
+        lens = workloads.utterance_lengths(urng, n_utts)
+    lens = np.sort(lens)[::-1].copy()            # longest first
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = urng.standard_normal((int(off[-1]), net[0]["input_dim"])).astype(np.float32)
+    return net, priors, g, feats, off
+
+
+def forward_all(api, torch, nnet, feats_d, off, loglikes, max_rows):
+    """nnet forward in groups of utterances (bounds the activation buffers)."""
+    u0 = 0
+    n = len(off) - 1
+    while u0 < n:
+        u1 = u0 + 1
+        while u1 < n and off[u1 + 1] - off[u0] <= max_rows:
+            u1 += 1
+        sub = (off[u0:u1 + 1] - off[u0]).astype(np.int32)
+        nnet.compute(feats_d[off[u0]:off[u1]], sub, True, epilogue=True, prob_scale=ACWT,
+                     out=loglikes[off[u0]:off[u1]])
+        u0 = u1
+
+
+def cpu_baseline(net, priors, g, feats, off, budget_frames):
+    """The reference CPU path on a bounded sample of the same workload, 1 thread:
+    nnet2 forward through the reference's own compiled CPU code when oracle/_ref
+    exists (cblas_sgemm as in the reference), else the restatement; decoding by
+    the restatement in reference-iteration-order mode (the reference decoder cannot
+    be compiled here).  Returns (frames_per_sec, description)."""
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    from oracle import binding
+    fwd = binding.OracleLib("ref") if binding.have_ref() else binding.OracleLib("ko")
+    # utterances closest to the median length until the frame budget is reached (the
+    # shortest ones would over-weight the cheap first frames of every utterance)
+    lens = np.diff(off)
+    order = np.argsort(np.abs(lens - np.median(lens)), kind="stable")
+    sample, tot = [], 0
+    for u in order:
+        T = int(off[u + 1] - off[u])
+        if sample and tot + T > budget_frames:
+            break
+        sample.append(int(u))
+        tot += T
+    dec = binding.DecoderOracle(g, binding.decoder_config(**DECODE_CFG), "reference")
+    t0 = time.perf_counter()
+    t_fwd = 0.0
+    for u in sample:
+        x = feats[off[u]:off[u + 1]]
+        a = time.perf_counter()
+        ll = fwd.decodable_am_nnet(net, priors, ACWT, x)
+        t_fwd += time.perf_counter() - a
+        dec.decode(ll)
+        dec.best_path()
+        dec.raw_lattice()
+    el = time.perf_counter() - t0
+    desc = ("%d median-length utterances of the rank-0 shard (%d frames): nnet2 forward via %s, "
+            "LatticeFasterDecoder restatement in reference iteration order, 1 thread; "
+            "forward %.1f s + decode %.1f s" %
+            (len(sample), tot, "compiled reference (oracle/_ref, OpenBLAS sgemm)" if fwd.kind == "ref" else "restatement",
+             t_fwd, el - t_fwd))
+    return tot / el, desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--utts", type=int, default=328, help="utterances per GPU (1/8 of test-clean)")
+    ap.add_argument("--graph-states", type=int, default=10_000_000)
+    ap.add_argument("--small", action="store_true", help="tiny model/graph for a quick functional run")
+    ap.add_argument("--cpu-frames", type=int, default=1500, help="frame budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    api = importlib.import_module(PKG + ".api")
+    api.select_gpu(local_rank)                   # CuDevice::SelectGpuId(ordinal)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.small:
+        args.graph_states = min(args.graph_states, 200_000)
+    net, priors, g, feats, off = build_workload(3456, rank, args.utts, args.graph_states, args.small)
+    n_utts = len(off) - 1
+    frames = int(off[-1])
+    n_pdf = net[-1]["output_dim"]
+
+    nnet = api.Nnet(net, priors)
+    fst = api.Fst(g)
+    dec = api.LatticeFasterDecoder(fst, api.decoder_config(**DECODE_CFG), max_batch=n_utts,
+                                   max_frames=int(np.diff(off).max()))
+    feats_d = torch.from_numpy(feats).cuda()     # inputs resident in HBM before the timed region
+    stride = (n_pdf + 3) // 4 * 4
+    loglikes = torch.empty((frames, stride), dtype=torch.float32, device="cuda")[:, :n_pdf]
+
+    stats = {}
+
+    def step():
+        forward_all(api, torch, nnet, feats_d, off, loglikes, max_rows=60000)
+        dec.decode(loglikes, off)
+        tot_like, n_ok = 0.0, 0
+        arcs = toks = 0
+        for u in range(n_utts):
+            bp = dec.get_best_path(u)            # GetBestPath + lattice export (host part)
+            tot_like += -(bp["graph_cost"] + bp["acoustic_cost"])
+            n_ok += 1
+            st = dec.counters(u)
+            arcs += st["arcs_expanded"]
+            toks += st["tokens_created"]
+        stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, kernel_ms=dec.last_kernel_ms())
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(stats["kernel_ms"])
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    # max over ranks + the final scalar reduction (tot frames / like / utterances)
+    red = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(frames), stats["tot_like"], float(stats["n_ok"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(red.item())
+    total_frames = float(tot[0].item())
+
+    if rank == 0:
+        fps = total_frames * args.steps / elapsed
+        # roofline of the dominant kernel (DecodeKernel): algorithmic bytes per launch =
+        # 60 B per expanded arc + 16 B per created token / measured duration
+        alg_bytes = stats["arcs"] * 60.0 + stats["toks"] * 16.0
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "frames/sec decoded (nnet2 forward + LatticeFasterDecoder); RTF = 100/value_per_gpu",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": elapsed * 100.0 / (total_frames * args.steps) * world,
+            "config": {"workload": "librispeech_nnet_a_synthetic" + ("_small" if args.small else ""),
+                       "utts_per_gpu": n_utts, "frames_per_gpu": frames, "graph_states": int(g["num_states"]),
+                       "graph_arcs": int(g["arc_offsets"][-1]), "nnet": "140-700-4x(3500/350)-12000-5800" if not args.small else "small",
+                       "decoder": DECODE_CFG, "acwt": ACWT, "parallelism": "utterance-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "DecodeKernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "arcs_expanded_per_launch": stats["arcs"], "tokens_created_per_launch": stats["toks"]},
+            "loglike_per_frame": stats["tot_like"] / frames,
+        }
+        if not args.no_cpu_baseline:
+            v, desc = cpu_baseline(net, priors, g, feats, off, args.cpu_frames)
+            out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port", "sample": desc}
+            out["speedup_vs_cpu_1thread_per_gpu"] = fps / world / v
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -290,6 +290,13 @@ typedef struct KhDecodeStats {
   int32_t max_tokens_frame;
 } KhDecodeStats;
 int kh_decoder_get_stats(const KhDecoder *dec, int utt, KhDecodeStats *stats);
+/* Same counters without building the lattice (num_tokens / num_links are then the
+ * arena slots in use).  Measurement aid, no reference counterpart. */
+int kh_decoder_get_counters(const KhDecoder *dec, int utt, KhDecodeStats *stats);
+/* Duration of the decode kernel of the last kh_decoder_decode call, from HIP
+ * events recorded on the launch stream (measurement aid; the reference wraps
+ * every CuMatrix op in a Timer, cu-device.cc:384-389). */
+int kh_decoder_last_kernel_ms(const KhDecoder *dec, float *ms);
 /* GetRawLattice (lattice-faster-decoder.cc:109-191), use_final_probs = true,
  * in canonical form: states are the surviving tokens sorted by
  * (frame, hclg_state); arcs sorted by (src, ilabel, olabel, dst, graph, ac).

@@ -404,6 +404,16 @@ class LatticeFasterDecoder:
         check(lib().kh_decoder_get_stats(self._h, int(utt), C.byref(st)))
         return {k: getattr(st, k) for k, _ in KhDecodeStats._fields_}
 
+    def counters(self, utt=0):
+        st = KhDecodeStats()
+        check(lib().kh_decoder_get_counters(self._h, int(utt), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in KhDecodeStats._fields_}
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib().kh_decoder_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
     def reached_final(self, utt=0):
         return bool(self.stats(utt)["reached_final"])
 

@@ -958,6 +958,8 @@ struct KhDecoder {
   std::vector<KhDecodeStats> h_stats;
   std::vector<int32_t> h_T;
   int n_utts = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_kernel_ms = 0.f;
   // canonical lattices, built lazily per utterance
   struct Lat {
     bool built = false;
@@ -1348,11 +1350,18 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   p.max_active = d->cfg.max_active;
   p.min_active = d->cfg.min_active;
   p.prune_interval = d->cfg.prune_interval;
+  if (!d->ev0) {
+    KH_HIP(hipEventCreate(&d->ev0));
+    KH_HIP(hipEventCreate(&d->ev1));
+  }
+  KH_HIP(hipEventRecord(d->ev0, st));
   hipLaunchKernelGGL(DecodeKernel, dim3(n_utts), dim3(NT), 0, st, d->d_utts, p);
   KH_LAUNCH_CHECK();
+  KH_HIP(hipEventRecord(d->ev1, st));
   KH_HIP(hipMemcpyAsync(d->h_stats.data(), d->d_stats, sizeof(KhDecodeStats) * n_utts,
                         hipMemcpyDeviceToHost, st));
   KH_HIP(hipStreamSynchronize(st));
+  KH_HIP(hipEventElapsedTime(&d->last_kernel_ms, d->ev0, d->ev1));
   for (int i = 0; i < n_utts; i++) {
     if (d->h_stats[i].status != 0) {
       static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena",
@@ -1367,6 +1376,19 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       return KH_ECAPACITY;
     }
   }
+  return KH_OK;
+}
+
+int kh_decoder_last_kernel_ms(const KhDecoder *d, float *ms) {
+  KH_CHECK_ARG(d && ms);
+  *ms = d->last_kernel_ms;
+  return KH_OK;
+}
+
+// Raw per-utterance counters of the last decode (no lattice export).
+int kh_decoder_get_counters(const KhDecoder *d, int utt, KhDecodeStats *stats) {
+  KH_CHECK_ARG(d && stats && utt >= 0 && utt < d->n_utts);
+  *stats = d->h_stats[utt];
   return KH_OK;
 }
 

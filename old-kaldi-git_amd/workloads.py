@@ -47,7 +47,7 @@ def make_pnorm_net(rng, feat_dim, splice, const_dim, pnorm_in, pnorm_out, n_hidd
     return net, priors.astype(np.float32)
 
 
-def librispeech_nnet_a(rng, final_scale=4.0):
+def librispeech_nnet_a(rng, final_scale=2.0):
     """cfg 4: 40-dim hires MFCC + 100-dim iVector (const), splice +-7 -> 700,
     p-norm 3500->350 x4, mix-up 12000, ~5800 pdfs
     (egs/librispeech/s5/local/online/run_nnet2.sh; SURVEY.md §8 header)."""
@@ -148,6 +148,28 @@ def make_graph(rng, num_states, mean_degree=2.5, eps_frac=0.15, num_tids=None, n
     return dict(num_states=num_states, start=0, arc_offsets=offsets.astype(np.int64),
                 ilabel=ilabel, olabel=olabel, weight=weight, nextstate=nxt.astype(np.int32),
                 final=final, tid2pdf=tid2pdf)
+
+
+def make_hclg_like(rng, num_states, num_pdfs, self_loop_floor=0.5, **kw):
+    """make_graph with HCLG-like arc costs: HMM-transition-sized costs U[0, 1.5) on
+    ordinary arcs, self-loops no cheaper than `self_loop_floor` (a -log
+    self-transition probability is never ~0; without the floor a random graph grows
+    zero-cost self-loop attractors and the active-token population collapses),
+    LM-sized costs U[2, 10) on word-emitting (olabel != 0) arcs.  With this graph
+    and the decode.sh options (beam 15, max-active 7000) the search stays in the
+    max-active-bound regime (~10 k tokens, ~18 k arcs per frame), which puts the
+    single-thread CPU reference path at RTF ~0.9 — the order of the reference's
+    published 1.62 on 2015 hardware (src/doc/online_decoding.dox:288-304)."""
+    g = make_graph(rng, num_states, num_pdfs=num_pdfs, weight_max=1.0, **kw)
+    A = len(g["ilabel"])
+    src = np.repeat(np.arange(num_states), np.diff(g["arc_offsets"]))
+    selfloop = g["nextstate"] == src
+    has_o = g["olabel"] != 0
+    w = rng.random(A) * 1.5
+    w = np.where(selfloop, self_loop_floor + rng.random(A) * (1.5 - self_loop_floor), w)
+    w = np.where(has_o & ~selfloop, 2.0 + rng.random(A) * 8.0, w)
+    g["weight"] = w.astype(np.float32)
+    return g
 
 
 def utterance_lengths(rng, n_utts, mean=740, max_len=3500, min_len=100):

@@ -18,10 +18,7 @@ LAT_KEYS = ("state_frame", "state_hclg", "state_final", "arc_src", "arc_dst", "a
 
 
 def graph_like_hclg(rng, n_states, n_pdfs, **kw):
-    g = workloads.make_graph(rng, n_states, num_pdfs=n_pdfs, weight_max=1.0, **kw)
-    has_o = g["olabel"] != 0
-    g["weight"] = np.where(has_o, 2.0 + rng.random(len(has_o)) * 8, rng.random(len(has_o)) * 1.5).astype(np.float32)
-    return g
+    return workloads.make_hclg_like(rng, n_states, n_pdfs, **kw)
 
 
 def assert_same_lattice(got, want):
