@@ -49,6 +49,7 @@ struct KhFst {
   int4 *e_arcs = nullptr;    // {ilabel, olabel, weight bits, nextstate}
   int4 *n_arcs = nullptr;    // {0, olabel, weight bits, nextstate}
   float *final_cost = nullptr;
+  std::vector<float> final_host;  // host copy for lattice export
   int32_t max_ilabel = 0;
 };
 
@@ -1072,15 +1073,10 @@ int BuildLattice(KhDecoder *d, int ui) {
   // final costs of the last frame
   std::vector<float> fin_host;
   {
-    // fetch final costs for the last frame's states only
     const int b = fbv[T], e = fev[T];
-    fin_host.assign(e - b, 0.f);
-    for (int i = b; i < e; i++) {
-      float fc = std::numeric_limits<float>::infinity();
-      if (tstate[i] >= 0)
-        KH_HIP(hipMemcpy(&fc, d->fst->final_cost + tstate[i], sizeof(float), hipMemcpyDeviceToHost));
-      fin_host[i - b] = fc;
-    }
+    fin_host.assign(e - b, std::numeric_limits<float>::infinity());
+    for (int i = b; i < e; i++)
+      if (tstate[i] >= 0) fin_host[i - b] = d->fst->final_host[tstate[i]];
   }
   struct Key { int32_t f, s, idx; };
   std::vector<Key> keys;
@@ -1201,6 +1197,7 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
   f->num_emit = static_cast<int64_t>(e_arcs.size());
   f->num_eps = static_cast<int64_t>(n_arcs.size());
   f->max_ilabel = max_il;
+  f->final_host.assign(final_cost, final_cost + num_states);
   auto up = [&](void **dst, const void *src, size_t bytes) -> bool {
     *dst = PoolMalloc(bytes ? bytes : 16);
     if (!*dst) return false;
