@@ -50,6 +50,20 @@ def build(force=False, verbose=False, jobs=8):
     return LIB
 
 
+def build_host_test():
+    """Compile tests/cpp/host_api_test.cc (plain g++, host only) against the library."""
+    build()
+    root = os.path.normpath(os.path.join(HERE, ".."))
+    src = os.path.join(root, "tests", "cpp", "host_api_test.cc")
+    exe = os.path.join(HERE, "build", "host_api_test")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    hdr = os.path.join(HERE, "host", "kaldi-hip.h")
+    if (not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB))):
+        subprocess.check_call(["g++", "-std=c++14", "-O1", src, "-o", exe, LIB, "-Wl,-rpath," + HERE,
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
 def _wait(procs):
     while procs:
         src, p = procs.pop(0)

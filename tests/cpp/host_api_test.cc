@@ -1,0 +1,137 @@
+// host_api_test.cc — exercises the C++ host layer (old-kaldi-git_amd/host/kaldi-hip.h)
+// the way the reference's cudamatrix/cu-matrix-test.cc exercises CuMatrix:
+// random shapes, CPU loops as the check (UnitTestCuMatrixAddMatMat :1038-1066,
+// UnitTestCuSoftmax :1559-1587, UnitTestCuMatrixCopyRows :379-402 with -1 indices,
+// UnitTestCuMatrixGroupPnorm :246, UnitTestCuMatrixSumColumnRanges :442,
+// UnitTestCuMatrixLookup :2011, cu-math-test.cc Splice), plus a tiny decode.
+// Needs a GPU; built by __graft_entry__.build(), run by tests/test_gpu_cpp_host.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../old-kaldi-git_amd/host/kaldi-hip.h"
+
+using namespace kaldi;
+
+static float Rnd() { return static_cast<float>(rand()) / RAND_MAX * 2.f - 1.f; }
+static std::vector<float> RandMat(int r, int c, float s = 1.f) {
+  std::vector<float> m(static_cast<size_t>(r) * c);
+  for (size_t i = 0; i < m.size(); i++) m[i] = Rnd() * s;
+  return m;
+}
+#define CHECK(cond) do { if (!(cond)) { printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); exit(1); } } while (0)
+static void Near(float a, float b, float rel, float abs_tol = 1e-6f) {
+  if (!(std::fabs(a - b) <= abs_tol + rel * std::fabs(b))) { printf("FAIL %g vs %g\n", a, b); exit(1); }
+}
+
+static void TestAddMatMat() {
+  const int m = 200, k = 100, n = 190;
+  std::vector<float> A = RandMat(m, k), B = RandMat(n, k), C0 = RandMat(m, n);
+  CuMatrix a, b, c;
+  a.CopyFromMat(A.data(), m, k, k); b.CopyFromMat(B.data(), n, k, k); c.CopyFromMat(C0.data(), m, n, n);
+  c.AddMatMat(0.5f, a, kNoTrans, b, kTrans, 0.25f);
+  std::vector<float> out(m * n);
+  c.CopyToMat(out.data(), n);
+  for (int i = 0; i < m; i += 7)
+    for (int j = 0; j < n; j += 5) {
+      double s = 0;
+      for (int p = 0; p < k; p++) s += static_cast<double>(A[i * k + p]) * B[j * k + p];
+      Near(out[i * n + j], static_cast<float>(0.5 * s + 0.25 * C0[i * n + j]), 1e-4f, 1e-4f);
+    }
+  bool threw = false;
+  try { c.AddMatMat(1.f, a, kNoTrans, b, kNoTrans, 0.f); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw);  // dimension mismatch -> KALDI_ASSERT -> exception
+}
+
+static void TestSoftmaxPnormCopyRows() {
+  const int r = 37, c = 60;
+  std::vector<float> X = RandMat(r, c, 5.f);
+  CuMatrix x, y(r, c);
+  x.CopyFromMat(X.data(), r, c, c);
+  y.ApplySoftMaxPerRow(x);
+  std::vector<float> out(r * c);
+  y.CopyToMat(out.data(), c);
+  for (int i = 0; i < r; i++) {
+    double mx = -1e30, s = 0;
+    for (int j = 0; j < c; j++) mx = std::max<double>(mx, X[i * c + j]);
+    for (int j = 0; j < c; j++) s += std::exp(X[i * c + j] - mx);
+    for (int j = 0; j < c; j++) Near(out[i * c + j], static_cast<float>(std::exp(X[i * c + j] - mx) / s), 1e-5f, 1e-9f);
+  }
+  CuMatrix p(r, c / 10);
+  p.GroupPnorm(x, 2.0f);
+  std::vector<float> po(r * (c / 10));
+  p.CopyToMat(po.data(), c / 10);
+  for (int i = 0; i < r; i++)
+    for (int g = 0; g < c / 10; g++) {
+      double s = 0;
+      for (int j = 0; j < 10; j++) s += static_cast<double>(X[i * c + g * 10 + j]) * X[i * c + g * 10 + j];
+      Near(po[i * (c / 10) + g], static_cast<float>(std::sqrt(s)), 1e-5f);
+    }
+  std::vector<int32> idx(50);
+  for (int i = 0; i < 50; i++) idx[i] = (rand() % (r + 1)) - 1;
+  CuMatrix d(50, c);
+  d.CopyRows(x, idx);
+  std::vector<float> dout(50 * c);
+  d.CopyToMat(dout.data(), c);
+  for (int i = 0; i < 50; i++)
+    for (int j = 0; j < c; j++) CHECK(dout[i * c + j] == (idx[i] < 0 ? 0.f : X[idx[i] * c + j]));
+  std::vector<int32> offs = {-3, 0, 2};
+  CuMatrix sp(r, c * 3);
+  cu::Splice(x, offs, &sp);
+  std::vector<float> so(r * c * 3);
+  sp.CopyToMat(so.data(), c * 3);
+  for (int i = 0; i < r; i++)
+    for (int o = 0; o < 3; o++) {
+      int ri = std::min(std::max(i + offs[o], 0), r - 1);
+      for (int j = 0; j < c; j++) CHECK(so[i * c * 3 + o * c + j] == X[ri * c + j]);
+    }
+  std::vector<int32> pairs = {0, 0, 3, 7, r - 1, c - 1};
+  std::vector<float> lk;
+  x.Lookup(pairs, &lk);
+  CHECK(lk.size() == 3 && lk[0] == X[0] && lk[1] == X[3 * c + 7] && lk[2] == X[(r - 1) * c + c - 1]);
+}
+
+static void TestDecoder() {
+  // 3-state left-to-right graph: 0 -(1:10/0.5)-> 1 -(2:0/0.25)-> 2(final 0.1), self loops tid 3 on 1
+  std::vector<int64_t> off = {0, 1, 3, 3};
+  std::vector<int32> il = {1, 3, 2}, ol = {10, 0, 0}, ns = {1, 1, 2};
+  std::vector<float> w = {0.5f, 0.75f, 0.25f}, fin = {INFINITY, INFINITY, 0.1f};
+  KhFst *fst = kh_fst_create(3, 0, off.data(), il.data(), ol.data(), w.data(), ns.data(), fin.data());
+  CHECK(fst != NULL);
+  LatticeFasterDecoderConfig cfg;
+  LatticeFasterDecoder dec(fst, cfg, 1, 8);
+  // 3 frames, 3 pdfs (tid - 1): choose loglikes so the path 1,3,2 wins
+  std::vector<float> ll = {0.f, -5.f, -5.f, -5.f, -5.f, 0.f, -5.f, 0.f, -5.f};
+  CuMatrix L;
+  L.CopyFromMat(ll.data(), 3, 3, 3);
+  std::vector<int32> offs = {0, 3};
+  CHECK(dec.Decode(L.Data(), L.Stride(), offs, NULL));
+  CHECK(dec.ReachedFinal(0));
+  std::vector<int32> ali, words;
+  float g, a;
+  CHECK(dec.GetBestPath(0, &ali, &words, &g, &a));
+  CHECK(ali.size() == 3 && ali[0] == 1 && ali[1] == 3 && ali[2] == 2);
+  CHECK(words.size() == 1 && words[0] == 10);
+  Near(g, 0.5f + 0.75f + 0.25f + 0.1f, 1e-6f);
+  Near(a, 0.f, 1e-6f, 1e-6f);
+  RawLattice lat;
+  CHECK(dec.GetRawLattice(0, &lat));
+  CHECK(lat.state_frame.size() == 4 && lat.arc_src.size() == 3);
+  kh_fst_destroy(fst);
+}
+
+int main() {
+  try {
+    CuDevice::Instantiate().SelectGpuId("yes");
+    printf("device: %s\n", CuDevice::Instantiate().DeviceGetName().c_str());
+    TestAddMatMat();
+    TestSoftmaxPnormCopyRows();
+    TestDecoder();
+  } catch (const std::exception &e) {
+    printf("FAIL exception: %s\n", e.what());
+    return 1;
+  }
+  printf("host_api_test: all tests passed\n");
+  return 0;
+}
