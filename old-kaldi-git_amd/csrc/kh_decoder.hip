@@ -69,6 +69,20 @@ __host__ __device__ __forceinline__ float Dec(uint32_t e) {
   return __builtin_bit_cast(float, u);
 }
 
+// Token costs are updated with L2 atomics (atomicMin), which do not refresh this
+// CU's vector L1: a plain load could return a stale L1 copy of the line (e.g. one
+// fetched while reading the previous frame's tokens that share it).  Every read
+// of tok_cost therefore goes to L2 (sc1 load).
+__device__ __forceinline__ float LoadExtra(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void StoreExtra(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t LoadCostEnc(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Per-utterance arenas and parameters (device-resident array of these).
 //
 // Tokens and links live in one append-only arena each, in frame order:
@@ -109,9 +123,7 @@ struct Utt {
   // hash
   unsigned long long *hash;
   uint32_t hash_mask;
-  // outputs
-  KhDecodeStats *stats;
-  int32_t *counters;     // [8]: tok_end, link_end
+  long long *phase_cycles;  // [16] diagnostic (KH_DECODER_PROFILE=1), else nullptr
 };
 
 struct Params {
@@ -140,7 +152,20 @@ struct Shared {
   int status;
   long long arcs_expanded, tokens_created;
   int max_tokens_frame;
+  long long t_last;
+  long long phase[16];
+  int tok_hw;  // highest token slot dirtied by this slot's utterances so far
 };
+
+// Diagnostic phase timer: thread 0 charges the shader cycles since the previous
+// stamp to `ph`.  Only active when the host passed a phase_cycles buffer.
+__device__ __forceinline__ void Stamp(const Utt &u, Shared &sh, int ph) {
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh.phase[ph] += now - sh.t_last;
+    sh.t_last = now;
+  }
+}
 
 __device__ __forceinline__ int BlockExScan(int v, int *total, Shared &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -227,7 +252,7 @@ __device__ uint32_t RadixSelect(const uint32_t *__restrict__ keys, int b, int e,
     for (int i = threadIdx.x; i < 256; i += NT) sh.hist[i] = 0;
     __syncthreads();
     for (int i = b + threadIdx.x; i < e; i += NT) {
-      const uint32_t key = keys[i];
+      const uint32_t key = LoadCostEnc(&keys[i]);
       if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -312,7 +337,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Shared 
   for (int i = b + threadIdx.x; i < e; i += NT) {
     // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
     const unsigned long long key =
-        (static_cast<unsigned long long>(u.tok_cost[i]) << 32) | static_cast<uint32_t>(u.tok_state[i]);
+        (static_cast<unsigned long long>(LoadCostEnc(&u.tok_cost[i])) << 32) | static_cast<uint32_t>(u.tok_state[i]);
     best = key < best ? key : best;
   }
   best = BlockMinU64(best, sh);
@@ -382,7 +407,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
       int dirty = 1;
       if (!first) dirty = atomicExch(&u.tmp_dirty[i - fb], 0);
       if (!dirty) continue;
-      const float cur_cost = Dec(__hip_atomic_load(&u.tok_cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
       if (cur_cost > cutoff) continue;  // :779
       const int32_t s = u.tok_state[i];
       const int ab = p.n_off[s], ae = p.n_off[s + 1];
@@ -407,6 +432,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     if (sh.status != 0) return false;
     if (!more) break;
   }
+  Stamp(u, sh, 3);
   // ---- epsilon links: {(tok, arc): cost[tok] <= cutoff, cost[tok] + w < cutoff}
   const int fe = sh.tok_end;
   const int blk_b = sh.link_end;
@@ -415,7 +441,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     int cnt = 0, ab = 0, ae = 0;
     float cur_cost = 0.f;
     if (i < fe) {
-      cur_cost = Dec(u.tok_cost[i]);
+      cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
       if (cur_cost <= cutoff) {
         const int32_t s = u.tok_state[i];
         ab = p.n_off[s];
@@ -465,6 +491,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     u.feps_e[frame] = sh.link_end;
   }
   __syncthreads();
+  Stamp(u, sh, 4);
   return true;
 }
 
@@ -481,7 +508,9 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
                                 float *next_cutoff_out, Shared &sh) {
   const int nb = sh.tok_end;  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
+  Stamp(u, sh, 15);
   const Cutoff c = GetCutoff(u, p, b, e, sh);
+  Stamp(u, sh, 0);
   if (threadIdx.x == 0 && c.count > sh.max_tokens_frame) sh.max_tokens_frame = c.count;
   const float inf = INFINITY;
   float cost_offset = 0.0f;
@@ -511,7 +540,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     int cnt = 0, ab = 0;
     float cur_cost = 0.f;
     if (i < e) {
-      cur_cost = Dec(u.tok_cost[i]);
+      cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
       if (cur_cost <= c.cur_cutoff) {  // :719
         const int32_t s = u.tok_state[i];
         ab = p.e_off[s];
@@ -551,6 +580,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   }
   // final next_cutoff: the value the reference's running cutoff converges to
   const float next_cutoff = BlockMinF(est, sh);
+  Stamp(u, sh, 1);
   const int link_frame_e = sh.link_end;
   if (threadIdx.x == 0) {
     u.femit_b[frame] = link_frame_b;
@@ -575,14 +605,15 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
   if (threadIdx.x == 0) sh.arcs_expanded += tot_arcs;
   __syncthreads();
+  Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
   return sh.status == 0;
 }
 
 // link_extra_cost of :309-311 for link l of token `tok`
 __device__ __forceinline__ float LinkExtra(const Utt &u, float tok_cost, int l, int dst) {
-  const float next_extra = __hip_atomic_load(&u.tok_extra[dst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return next_extra + ((tok_cost + u.link_a[l] + u.link_g[l]) - Dec(u.tok_cost[dst]));
+  const float next_extra = LoadExtra(&u.tok_extra[dst]);
+  return next_extra + ((tok_cost + u.link_a[l] + u.link_g[l]) - Dec(LoadCostEnc(&u.tok_cost[dst])));
 }
 
 // PruneForwardLinks :273-344 (canonical rule P: exact fixed point, then excise)
@@ -595,8 +626,8 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
   // pass 0: entry values; contribution of the emitting links (fixed during the iteration)
   for (int i = b + threadIdx.x; i < e; i += NT) {
     if (u.tok_state[i] < 0) continue;
-    u.tmp_f0[i - b] = u.tok_extra[i];
-    const float tc = Dec(u.tok_cost[i]);
+    u.tmp_f0[i - b] = LoadExtra(&u.tok_extra[i]);
+    const float tc = Dec(LoadCostEnc(&u.tok_cost[i]));
     float base = inf;
     if (final_frame) {
       float final_cost = 0.0f;
@@ -620,7 +651,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
     bool changed = false;
     for (int i = b + threadIdx.x; i < e; i += NT) {
       if (u.tok_state[i] < 0) continue;
-      const float tc = Dec(u.tok_cost[i]);
+      const float tc = Dec(LoadCostEnc(&u.tok_cost[i]));
       float v = u.tmp_f1[i - b];
       const int lbeg = u.tok_eps_b[i], n = u.tok_eps_n[i];
       for (int l = lbeg; l < lbeg + n; l++) {
@@ -632,9 +663,9 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
         v = fminf(v, lec);
       }
       if (final_frame && v > lb) v = inf;  // :416-417
-      const float old = u.tok_extra[i];
+      const float old = LoadExtra(&u.tok_extra[i]);
       if (!(v == old)) {
-        __hip_atomic_store(&u.tok_extra[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        StoreExtra(&u.tok_extra[i], v);
         changed = true;
       }
     }
@@ -644,7 +675,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
   bool ch = false, pr = false;
   for (int i = b + threadIdx.x; i < e; i += NT) {
     if (u.tok_state[i] < 0) continue;
-    const float tc = Dec(u.tok_cost[i]);
+    const float tc = Dec(LoadCostEnc(&u.tok_cost[i]));
     for (int pass = 0; pass < 2; pass++) {
       const int lbeg = pass ? u.tok_eps_b[i] : u.tok_emit_b[i];
       const int n = pass ? u.tok_eps_n[i] : u.tok_emit_n[i];
@@ -658,7 +689,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
         }
       }
     }
-    if (fabsf(u.tok_extra[i] - u.tmp_f0[i - b]) > delta) ch = true;  // :334
+    if (fabsf(LoadExtra(&u.tok_extra[i]) - u.tmp_f0[i - b]) > delta) ch = true;  // :334
   }
   *extra_costs_changed = BlockAny(ch, sh);
   *links_pruned = BlockAny(pr, sh);
@@ -667,7 +698,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
 // PruneTokensForFrame :450-469
 __device__ void PruneTokensForFrame(const Utt &u, int b, int e) {
   for (int i = b + threadIdx.x; i < e; i += NT)
-    if (u.tok_state[i] >= 0 && u.tok_extra[i] == INFINITY) u.tok_state[i] = -1;
+    if (u.tok_state[i] >= 0 && LoadExtra(&u.tok_extra[i]) == INFINITY) u.tok_state[i] = -1;
   __syncthreads();
 }
 
@@ -723,7 +754,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
       uint32_t co = kEncInf;
       float ex = 0.f;
       if (i < e) {
-        st = u.tok_state[i]; co = u.tok_cost[i]; ex = u.tok_extra[i];
+        st = u.tok_state[i]; co = LoadCostEnc(&u.tok_cost[i]); ex = LoadExtra(&u.tok_extra[i]);
         eb = u.tok_eps_b[i]; en = u.tok_eps_n[i]; mb = u.tok_emit_b[i]; mn = u.tok_emit_n[i];
       }
       const int alive = st >= 0 ? 1 : 0;
@@ -826,9 +857,9 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
   return true;
 }
 
-__global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts, Params p) {
-  __shared__ Shared sh;
-  const Utt u = utts[blockIdx.x];
+// One utterance: InitDecoding, Decode, FinalizeDecoding.  Leaves the surviving
+// tokens/links in the slot's arenas ([0, sh.tok_end) / [0, sh.link_end)).
+__device__ bool DecodeOne(const Utt &u, const Params &p, Shared &sh, KhDecodeStats *st_out) {
   const float inf = INFINITY;
   if (threadIdx.x == 0) {
     sh.tok_end = 0;
@@ -855,7 +886,7 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
   bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
   int fb = 0;                    // token range of the frontier frame
   int fe = sh.tok_end;
-  if (threadIdx.x == 0) { u.frame_e[0] = fe; sh.tokens_created += fe - fb; }
+  if (threadIdx.x == 0) { u.frame_e[0] = fe; sh.tokens_created += fe - fb; if (fe > sh.tok_hw) sh.tok_hw = fe; }
   if (ok) ClearHash(u, fb, fe);
   // Compaction window: everything younger than 2 * max(prune_interval, 25) frames
   // (frames leave it only once they are >= 25 frames behind the frontier, i.e.
@@ -866,8 +897,11 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
   int t = 0;
   for (; ok && t < u.T; t++) {
     if (t % p.prune_interval == 0 && t > 0) {
+      Stamp(u, sh, 15);
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
+      Stamp(u, sh, 6);
       ok = Compact(u, t - win_frames, t, sh);
+      Stamp(u, sh, 7);
       if (!ok) break;
       fb = u.frame_b[t];
       fe = u.frame_e[t];
@@ -883,8 +917,11 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
       u.frame_b[t + 1] = fb;
       u.frame_e[t + 1] = fe;
       sh.tokens_created += fe - fb;
+      if (fe > sh.tok_hw) sh.tok_hw = fe;
     }
+    Stamp(u, sh, 15);
     ClearHash(u, fb, fe);
+    Stamp(u, sh, 5);
   }
 
   KhDecodeStats st;
@@ -899,7 +936,7 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
     const int last = u.T;
     float best_cost = inf, best_with_final = inf;
     for (int i = fb + threadIdx.x; i < fe; i += NT) {
-      const float cost = Dec(u.tok_cost[i]);
+      const float cost = Dec(LoadCostEnc(&u.tok_cost[i]));
       const float final_cost = p.final_cost[u.tok_state[i]];
       best_cost = fminf(best_cost, cost);
       best_with_final = fminf(best_with_final, cost + final_cost);
@@ -920,20 +957,175 @@ __global__ void __launch_bounds__(NT) DecodeKernel(const Utt *__restrict__ utts,
     PruneTokensForFrame(u, u.frame_b[0], u.frame_e[0]);
     // final compaction of the window so the export below copies little
     ok = Compact(u, last - win_frames, last, sh);
+    Stamp(u, sh, 8);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    st.arcs_expanded = sh.arcs_expanded;
-    st.tokens_created = sh.tokens_created;
-    st.status = sh.status;
-    st.max_tokens_frame = sh.max_tokens_frame;
-    st.num_tokens = sh.tok_end;   // arena slots in use (pruned ones included; host filters)
-    st.num_links = sh.link_end;
-    *u.stats = st;
-    u.counters[0] = sh.tok_end;
-    u.counters[1] = sh.link_end;
-  }
+  st.arcs_expanded = sh.arcs_expanded;
+  st.tokens_created = sh.tokens_created;
+  st.status = sh.status;
+  st.max_tokens_frame = sh.max_tokens_frame;
+  st.num_tokens = sh.tok_end;   // arena slots in use (pruned ones included)
+  st.num_links = sh.link_end;
+  *st_out = st;
+  __syncthreads();
+  return ok && sh.status == 0;
 }
+
+// Per-utterance inputs / outputs of the batch and the lattice pool the finished
+// utterances are exported to (so that the slot's arenas can be reused).
+struct UttIn {
+  const float *ll;
+  int32_t T, pad;
+};
+struct UttOut {
+  KhDecodeStats stats;
+  long long tok_off, link_off;  // position in the pool
+  int32_t n_tok, n_link;
+};
+struct Pool {
+  int32_t *t_frame, *t_state;                 // per exported token
+  int32_t *l_src, *l_dst, *l_il, *l_ol;       // per exported link (indices relative to the utterance)
+  float *l_g, *l_a;                           // graph cost, acoustic cost - cost_offset[frame]
+  long long tok_cap, link_cap;
+  unsigned long long *used;                   // [0] tokens, [1] links, [2] utterance queue head
+};
+
+// GetRawLattice :109-191 device half: survivors -> pool (frame, state) / (src, dst, labels, costs).
+__device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Shared &sh) {
+  const int tok_end = sh.tok_end, T = u.T;
+  // pass A: alive tokens -> dense indices (tmp_remap), count
+  if (threadIdx.x == 0) sh.bcast_i[3] = 0;
+  __syncthreads();
+  for (int base = 0; base < tok_end; base += NT) {
+    const int i = base + threadIdx.x;
+    const int alive = (i < tok_end && u.tok_state[i] >= 0) ? 1 : 0;
+    int total;
+    const int off = BlockExScan(alive, &total, sh);
+    const int run = sh.bcast_i[3];
+    if (i < tok_end) u.tmp_remap[i] = alive ? run + off : -1;
+    __syncthreads();
+    if (threadIdx.x == 0) sh.bcast_i[3] = run + total;
+    __syncthreads();
+  }
+  const int n_tok = sh.bcast_i[3];
+  // pass B: count alive links per alive token -> link offsets (kept in tok_extra bits)
+  __syncthreads();
+  if (threadIdx.x == 0) sh.bcast_i[3] = 0;
+  __syncthreads();
+  for (int base = 0; base < tok_end; base += NT) {
+    const int i = base + threadIdx.x;
+    int cnt = 0;
+    if (i < tok_end && u.tok_state[i] >= 0) {
+      for (int kind = 0; kind < 2; kind++) {
+        const int lb = kind ? u.tok_emit_b[i] : u.tok_eps_b[i], n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
+        for (int l = lb; l < lb + n; l++)
+          if (u.link_dst[l] >= 0) cnt++;
+      }
+    }
+    int total;
+    const int off = BlockExScan(cnt, &total, sh);
+    const int run = sh.bcast_i[3];
+    if (i < tok_end) u.tok_extra[i] = __int_as_float(run + off);  // extra_cost is dead after finalisation
+    __syncthreads();
+    if (threadIdx.x == 0) sh.bcast_i[3] = run + total;
+    __syncthreads();
+  }
+  const int n_link = sh.bcast_i[3];
+  // allocate in the pool
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long tb = atomicAdd(&pool.used[0], static_cast<unsigned long long>(n_tok));
+    const unsigned long long lb = atomicAdd(&pool.used[1], static_cast<unsigned long long>(n_link));
+    out->tok_off = static_cast<long long>(tb);
+    out->link_off = static_cast<long long>(lb);
+    out->n_tok = n_tok;
+    out->n_link = n_link;
+    const bool fits = tb + n_tok <= static_cast<unsigned long long>(pool.tok_cap) &&
+                      lb + n_link <= static_cast<unsigned long long>(pool.link_cap);
+    if (!fits) { sh.status = 6; out->stats.status = 6; }
+    sh.wmin[0] = tb;
+    sh.wmin[1] = lb;
+    sh.flag = fits ? 1 : 0;
+  }
+  __syncthreads();
+  const long long tb = static_cast<long long>(sh.wmin[0]), lbase = static_cast<long long>(sh.wmin[1]);
+  const bool fits = sh.flag != 0;
+  __syncthreads();
+  if (!fits) return;
+  // pass C: write
+  for (int i = threadIdx.x; i < tok_end; i += NT) {
+    const int ni = u.tmp_remap[i];
+    if (ni < 0) continue;
+    // frame of token i: largest f with frame_b[f] <= i (frames are contiguous and ordered)
+    int lo = 0, hi = T;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (u.frame_b[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    // skip empty frames that share the same begin
+    while (lo < T && u.frame_e[lo] <= i) lo++;
+    const int f = lo;
+    pool.t_frame[tb + ni] = f;
+    pool.t_state[tb + ni] = u.tok_state[i];
+    long long d = lbase + __float_as_int(u.tok_extra[i]);
+    const float coff = f < T ? u.cost_offset[f] : 0.0f;
+    for (int kind = 1; kind >= 0; kind--) {
+      const int lb2 = kind ? u.tok_emit_b[i] : u.tok_eps_b[i], n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
+      for (int l = lb2; l < lb2 + n; l++) {
+        const int dst = u.link_dst[l];
+        if (dst < 0) continue;
+        const int il = u.link_il[l];
+        pool.l_src[d] = ni;
+        pool.l_dst[d] = u.tmp_remap[dst];
+        pool.l_il[d] = il;
+        pool.l_ol[d] = u.link_ol[l];
+        pool.l_g[d] = u.link_g[l];
+        pool.l_a[d] = il != 0 ? u.link_a[l] - coff : u.link_a[l];  // :168-174
+        d++;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Persistent workgroups: each owns one slot (arena set) and pulls utterances from
+// a queue (the host orders them longest-first) until it is empty.
+__global__ void __launch_bounds__(NT)
+DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut *__restrict__ out,
+             int n_utts, Pool pool, Params p, long long *__restrict__ phase_cycles) {
+  __shared__ Shared sh;
+  Utt u = slots[blockIdx.x];
+  u.phase_cycles = phase_cycles ? phase_cycles + 16 * blockIdx.x : nullptr;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) sh.phase[i] = 0;
+    sh.t_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh.tok_hw = 0;
+  }
+  __syncthreads();
+  for (;;) {
+    if (threadIdx.x == 0) sh.bcast_i[3] = static_cast<int>(atomicAdd(&pool.used[2], 1ull));
+    __syncthreads();
+    const int ui = sh.bcast_i[3];
+    __syncthreads();
+    if (ui >= n_utts) break;
+    u.ll = in[ui].ll;
+    u.T = in[ui].T;
+    // restore the arena invariants left dirty by the previous utterance of this slot
+    const int hw = sh.tok_hw;
+    for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
+    for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+    __syncthreads();
+    KhDecodeStats st;
+    DecodeOne(u, p, sh, &st);
+    if (threadIdx.x == 0) out[ui].stats = st;
+    __syncthreads();
+    if (st.status == 0) ExportLattice(u, pool, &out[ui], sh);
+    Stamp(u, sh, 9);
+  }
+  if (threadIdx.x == 0 && u.phase_cycles != nullptr)
+    for (int i = 0; i < 16; i++) u.phase_cycles[i] = sh.phase[i];
+}
+
 
 __global__ void FillU32(uint32_t *p, size_t n, uint32_t v) {
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
@@ -949,15 +1141,30 @@ struct KhDecoder {
   KhDecoderConfig cfg;
   int max_batch = 0, max_frames = 0;
   int tok_frame_cap = 0, link_frame_cap = 0;
-  // one big device slab per kind, carved per utterance at decode time
+  int max_slots = 0;
+  // slot arenas (one set per persistent workgroup)
   void *slab = nullptr;
   size_t slab_bytes = 0;
-  Utt *d_utts = nullptr;
-  KhDecodeStats *d_stats = nullptr;
-  int32_t *d_counters = nullptr;
-  std::vector<Utt> h_utts;
-  std::vector<KhDecodeStats> h_stats;
+  int slab_slots = 0, slab_T = 0;
+  std::vector<Utt> h_slots;
+  Utt *d_slots = nullptr;
+  UttIn *d_in = nullptr;
+  UttOut *d_out = nullptr;
+  unsigned long long *d_used = nullptr;
+  long long *d_phase = nullptr;
+  // lattice pool
+  void *pool_slab = nullptr;
+  size_t pool_bytes = 0;
+  Pool pool;
+  struct HostPool {
+    std::vector<int32_t> t_frame, t_state, l_src, l_dst, l_il, l_ol;
+    std::vector<float> l_g, l_a;
+  };
+  std::vector<HostPool> rounds;     // one per launch (re-launches only after a pool overflow)
+  std::vector<int32_t> h_round;     // utterance -> round holding its lattice
+  std::vector<UttOut> h_out;
   std::vector<int32_t> h_T;
+  std::vector<int32_t> order;  // queue position -> utterance
   int n_utts = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_kernel_ms = 0.f;
@@ -987,12 +1194,14 @@ struct Carver {
   }
 };
 
-void CarveUtt(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, int prune_interval,
-              float hash_ratio) {
+// Arena set of one slot, sized for utterances of up to T frames.
+void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, int prune_interval,
+               float hash_ratio) {
   u.T = T;
   u.tok_frame_cap = tok_frame_cap;
   u.link_frame_cap = link_frame_cap;
-  // window: two pruning intervals + frontier; stable part: lattice density
+  // window: 2 * max(prune_interval, 25) frames + one interval of new frames + frontier;
+  // stable part: lattice density
   const long long win_frames = std::min<long long>(2ll * std::max(prune_interval, 25) + prune_interval + 3, T + 2);
   long long per_frame = 256;
   if (const char *e = getenv("KH_DECODER_STABLE_TOKENS_PER_FRAME")) per_frame = atoll(e);
@@ -1034,90 +1243,57 @@ void CarveUtt(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, i
   while (hs < static_cast<size_t>(hash_ratio * tok_frame_cap)) hs <<= 1;
   u.hash_mask = static_cast<uint32_t>(hs - 1);
   u.hash = c.Take<unsigned long long>(hs);
+  u.ll = nullptr;
+  u.ll_stride = 0;
+  u.phase_cycles = nullptr;
 }
 
-// canonical lattice from the compact arenas of one utterance (GetRawLattice
+// canonical lattice of one utterance from the host copy of the pool (GetRawLattice
 // :109-191 with use_final_probs = true after FinalizeDecoding)
 int BuildLattice(KhDecoder *d, int ui) {
   KhDecoder::Lat &L = d->lats[ui];
   if (L.built) return KH_OK;
-  const Utt &u = d->h_utts[ui];
-  const KhDecodeStats &st = d->h_stats[ui];
+  const UttOut &o = d->h_out[ui];
+  const KhDecodeStats &st = o.stats;
   if (st.status != 0) {
-    SetError("utterance %d: decoder arena overflow (code %d); raise capacities", ui, st.status);
+    SetError("utterance %d: decoder capacity overflow (code %d)", ui, st.status);
     return KH_ECAPACITY;
   }
-  const int nt = st.num_tokens, nl = st.num_links, T = u.T;
-  std::vector<int32_t> tstate(nt), eps_b(nt), eps_n(nt), emit_b(nt), emit_n(nt), fbv(T + 2), fev(T + 2);
-  std::vector<uint32_t> tcost(nt);
-  std::vector<int32_t> ldst(nl), lil(nl), lol(nl);
-  std::vector<float> lg(nl), la(nl), coff(T + 1);
-  hipStream_t s = Stream();
-#define D2H(dst, src, n, type) KH_HIP(hipMemcpyAsync(dst.data(), src, sizeof(type) * (n), hipMemcpyDeviceToHost, s))
-  D2H(tstate, u.tok_state, nt, int32_t);
-  D2H(tcost, u.tok_cost, nt, uint32_t);
-  D2H(eps_b, u.tok_eps_b, nt, int32_t);
-  D2H(eps_n, u.tok_eps_n, nt, int32_t);
-  D2H(emit_b, u.tok_emit_b, nt, int32_t);
-  D2H(emit_n, u.tok_emit_n, nt, int32_t);
-  D2H(fbv, u.frame_b, T + 2, int32_t);
-  D2H(fev, u.frame_e, T + 2, int32_t);
-  D2H(ldst, u.link_dst, nl, int32_t);
-  D2H(lil, u.link_il, nl, int32_t);
-  D2H(lol, u.link_ol, nl, int32_t);
-  D2H(lg, u.link_g, nl, float);
-  D2H(la, u.link_a, nl, float);
-  D2H(coff, u.cost_offset, T + 1, float);
-#undef D2H
-  KH_HIP(hipStreamSynchronize(s));
-  // final costs of the last frame
-  std::vector<float> fin_host;
-  {
-    const int b = fbv[T], e = fev[T];
-    fin_host.assign(e - b, std::numeric_limits<float>::infinity());
-    for (int i = b; i < e; i++)
-      if (tstate[i] >= 0) fin_host[i - b] = d->fst->final_host[tstate[i]];
-  }
-  struct Key { int32_t f, s, idx; };
-  std::vector<Key> keys;
-  keys.reserve(nt);
-  for (int f = 0; f <= T; f++)
-    for (int i = fbv[f]; i < fev[f]; i++)
-      if (tstate[i] >= 0) keys.push_back(Key{f, tstate[i], i});
-  std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-    return a.f != b.f ? a.f < b.f : a.s < b.s;
+  const int T = d->h_T[ui];
+  const size_t n = o.n_tok, m = o.n_link;
+  const KhDecoder::HostPool &hp = d->rounds[d->h_round[ui]];
+  const int32_t *tf = hp.t_frame.data() + o.tok_off, *ts = hp.t_state.data() + o.tok_off;
+  std::vector<int32_t> ord(n);
+  for (size_t k = 0; k < n; k++) ord[k] = static_cast<int32_t>(k);
+  std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+    return tf[a] != tf[b] ? tf[a] < tf[b] : ts[a] < ts[b];
   });
-  std::vector<int32_t> newidx(nt, -1);
-  for (size_t k = 0; k < keys.size(); k++) newidx[keys[k].idx] = static_cast<int32_t>(k);
-  const size_t n = keys.size();
+  std::vector<int32_t> newidx(n);
+  for (size_t k = 0; k < n; k++) newidx[ord[k]] = static_cast<int32_t>(k);
+  const float inf = std::numeric_limits<float>::infinity();
   L.state_frame.resize(n);
   L.state_hclg.resize(n);
-  L.state_final.assign(n, std::numeric_limits<float>::infinity());
-  struct A { int32_t src, il, ol, dst; float g, a; };
-  std::vector<A> arcs;
+  L.state_final.assign(n, inf);
   const bool have_final = st.reached_final != 0;
   for (size_t k = 0; k < n; k++) {
-    const int i = keys[k].idx, f = keys[k].f;
-    L.state_frame[k] = f;
-    L.state_hclg[k] = keys[k].s;
-    for (int pass = 0; pass < 2; pass++) {
-      const int lb = pass ? eps_b[i] : emit_b[i], ln = pass ? eps_n[i] : emit_n[i];
-      for (int l = lb; l < lb + ln; l++) {
-        if (ldst[l] < 0) continue;
-        float cost_offset = 0.0f;
-        if (lil[l] != 0) cost_offset = coff[f];  // :168-171
-        arcs.push_back(A{static_cast<int32_t>(k), lil[l], lol[l], newidx[ldst[l]], lg[l], la[l] - cost_offset});
-      }
-    }
-    if (f == T) {  // :177-186
+    const int32_t i = ord[k];
+    L.state_frame[k] = tf[i];
+    L.state_hclg[k] = ts[i];
+    if (tf[i] == T) {  // :177-186
       if (have_final) {
-        const float fc = fin_host[i - fbv[T]];
-        if (fc != std::numeric_limits<float>::infinity()) L.state_final[k] = fc;
+        const float fc = d->fst->final_host[ts[i]];
+        if (fc != inf) L.state_final[k] = fc;
       } else {
         L.state_final[k] = 0.0f;
       }
     }
   }
+  struct A { int32_t src, il, ol, dst; float g, a; };
+  std::vector<A> arcs(m);
+  const int32_t *ls = hp.l_src.data() + o.link_off, *ld = hp.l_dst.data() + o.link_off,
+                *li = hp.l_il.data() + o.link_off, *lo = hp.l_ol.data() + o.link_off;
+  const float *lg = hp.l_g.data() + o.link_off, *la = hp.l_a.data() + o.link_off;
+  for (size_t j = 0; j < m; j++) arcs[j] = A{newidx[ls[j]], li[j], lo[j], newidx[ld[j]], lg[j], la[j]};
   std::sort(arcs.begin(), arcs.end(), [](const A &x, const A &y) {
     if (x.src != y.src) return x.src < y.src;
     if (x.il != y.il) return x.il < y.il;
@@ -1126,7 +1302,6 @@ int BuildLattice(KhDecoder *d, int ui) {
     if (x.g != y.g) return x.g < y.g;
     return x.a < y.a;
   });
-  const size_t m = arcs.size();
   L.arc_src.resize(m); L.arc_dst.resize(m); L.arc_il.resize(m);
   L.arc_ol.resize(m); L.arc_g.resize(m); L.arc_a.resize(m);
   for (size_t j = 0; j < m; j++) {
@@ -1270,15 +1445,20 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
   long long lf = 3 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
   d->link_frame_cap = static_cast<int>(lf);
+  d->max_slots = NumCUs();  // one persistent 1024-thread workgroup per CU
+  if (const char *e = getenv("KH_DECODER_SLOTS")) d->max_slots = std::max(1, atoi(e));
   return d;
 }
 
 void kh_decoder_destroy(KhDecoder *d) {
   if (!d) return;
   PoolFree(d->slab);
-  PoolFree(d->d_utts);
-  PoolFree(d->d_stats);
-  PoolFree(d->d_counters);
+  PoolFree(d->pool_slab);
+  PoolFree(d->d_slots);
+  PoolFree(d->d_in);
+  PoolFree(d->d_out);
+  PoolFree(d->d_used);
+  PoolFree(d->d_phase);
   delete d;
 }
 
@@ -1289,47 +1469,71 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   KH_CHECK_ARG(d && loglikes && utt_off && n_utts > 0 && n_utts <= d->max_batch && ll_stride > 0);
   hipStream_t st = Stream();
   d->n_utts = n_utts;
-  d->h_utts.assign(n_utts, Utt());
-  d->h_stats.assign(n_utts, KhDecodeStats());
   d->lats.assign(n_utts, KhDecoder::Lat());
-  // size pass
-  Carver sizer{nullptr};
+  d->h_T.resize(n_utts);
+  int T_max = 0;
+  long long tot_frames = 0;
   for (int i = 0; i < n_utts; i++) {
     const int T = utt_off[i + 1] - utt_off[i];
     KH_CHECK_ARG(T > 0 && T <= d->max_frames);
-    Utt tmp;
-    CarveUtt(sizer, tmp, T, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio);
+    d->h_T[i] = T;
+    T_max = std::max(T_max, T);
+    tot_frames += T;
   }
-  if (sizer.off > d->slab_bytes) {
+  // ---- slot arenas
+  const int n_slots = std::min(n_utts, d->max_slots);
+  if (n_slots > d->slab_slots || T_max > d->slab_T) {
+    Carver sizer{nullptr};
+    for (int i = 0; i < n_slots; i++) {
+      Utt tmp;
+      CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio);
+    }
     PoolFree(d->slab);
     d->slab = PoolMalloc(sizer.off);
-    if (!d->slab) { d->slab_bytes = 0; return KH_ENOMEM; }
+    if (!d->slab) { d->slab_bytes = 0; d->slab_slots = 0; return KH_ENOMEM; }
     d->slab_bytes = sizer.off;
+    d->slab_slots = n_slots;
+    d->slab_T = T_max;
+    d->h_slots.assign(n_slots, Utt());
+    Carver carver{static_cast<char *>(d->slab)};
+    for (int i = 0; i < n_slots; i++)
+      CarveSlot(carver, d->h_slots[i], T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval,
+                d->cfg.hash_ratio);
+    // arena invariants for the first utterance of every slot (later ones are
+    // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
+    for (int i = 0; i < n_slots; i++) {
+      Utt &u = d->h_slots[i];
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
+      KH_HIP(hipMemsetAsync(u.hash, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
+      KH_HIP(hipMemsetAsync(u.tmp_dirty, 0, sizeof(int32_t) * u.tok_frame_cap, st));
+    }
+    PoolFree(d->d_slots);
+    d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
+    if (!d->d_slots) return KH_ENOMEM;
+  } else {
+    // slots were left with dirty token costs by the previous call: refill
+    for (int i = 0; i < n_slots; i++) {
+      Utt &u = d->h_slots[i];
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
+    }
   }
-  if (!d->d_utts) {
-    d->d_utts = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * d->max_batch));
-    d->d_stats = static_cast<KhDecodeStats *>(PoolMalloc(sizeof(KhDecodeStats) * d->max_batch));
-    d->d_counters = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * 8 * d->max_batch));
-    if (!d->d_utts || !d->d_stats || !d->d_counters) return KH_ENOMEM;
+  for (int i = 0; i < n_slots; i++) d->h_slots[i].ll_stride = ll_stride;
+  KH_HIP(hipMemcpyAsync(d->d_slots, d->h_slots.data(), sizeof(Utt) * n_slots, hipMemcpyHostToDevice, st));
+  if (!d->d_in) {
+    d->d_in = static_cast<UttIn *>(PoolMalloc(sizeof(UttIn) * d->max_batch));
+    d->d_out = static_cast<UttOut *>(PoolMalloc(sizeof(UttOut) * d->max_batch));
+    d->d_used = static_cast<unsigned long long *>(PoolMalloc(sizeof(unsigned long long) * 4));
+    if (!d->d_in || !d->d_out || !d->d_used) return KH_ENOMEM;
+    if (getenv("KH_DECODER_PROFILE")) {
+      d->d_phase = static_cast<long long *>(PoolMalloc(sizeof(long long) * 16 * d->max_slots));
+      if (!d->d_phase) return KH_ENOMEM;
+    }
   }
-  Carver carver{static_cast<char *>(d->slab)};
-  for (int i = 0; i < n_utts; i++) {
-    Utt &u = d->h_utts[i];
-    CarveUtt(carver, u, utt_off[i + 1] - utt_off[i], d->tok_frame_cap, d->link_frame_cap,
-             d->cfg.prune_interval, d->cfg.hash_ratio);
-    u.ll = loglikes + static_cast<size_t>(utt_off[i]) * ll_stride;
-    u.ll_stride = ll_stride;
-    u.stats = d->d_stats + i;
-    u.counters = d->d_counters + 8 * i;
-  }
-  // arena invariants: raw token costs = +inf, hash empty
-  for (int i = 0; i < n_utts; i++) {
-    Utt &u = d->h_utts[i];
-    hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
-    KH_HIP(hipMemsetAsync(u.hash, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
-    KH_HIP(hipMemsetAsync(u.tmp_dirty, 0, sizeof(int32_t) * u.tok_frame_cap, st));
-  }
-  KH_HIP(hipMemcpyAsync(d->d_utts, d->h_utts.data(), sizeof(Utt) * n_utts, hipMemcpyHostToDevice, st));
+  // ---- queue order: longest first (greedy LPT over the persistent workgroups)
+  d->order.resize(n_utts);
+  for (int i = 0; i < n_utts; i++) d->order[i] = i;
+  std::stable_sort(d->order.begin(), d->order.end(),
+                   [&](int a, int b) { return d->h_T[a] > d->h_T[b]; });
   Params p;
   p.e_off = d->fst->e_off;
   p.n_off = d->fst->n_off;
@@ -1351,27 +1555,144 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     KH_HIP(hipEventCreate(&d->ev0));
     KH_HIP(hipEventCreate(&d->ev1));
   }
-  KH_HIP(hipEventRecord(d->ev0, st));
-  hipLaunchKernelGGL(DecodeKernel, dim3(n_utts), dim3(NT), 0, st, d->d_utts, p);
-  KH_LAUNCH_CHECK();
-  KH_HIP(hipEventRecord(d->ev1, st));
-  KH_HIP(hipMemcpyAsync(d->h_stats.data(), d->d_stats, sizeof(KhDecodeStats) * n_utts,
-                        hipMemcpyDeviceToHost, st));
-  KH_HIP(hipStreamSynchronize(st));
-  KH_HIP(hipEventElapsedTime(&d->last_kernel_ms, d->ev0, d->ev1));
-  for (int i = 0; i < n_utts; i++) {
-    if (d->h_stats[i].status != 0) {
-      static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena",
-                                   "links-per-frame cap", "compaction window", "?"};
-      const KhDecodeStats &hs = d->h_stats[i];
-      SetError("kh_decoder_decode: utterance %d overflowed the %s at frame %d (tokens/frame cap %d, "
-               "links/frame cap %d, token arena %d/%d, link arena %d/%d); set "
-               "KH_DECODER_TOKENS_PER_FRAME / KH_DECODER_LINKS_PER_FRAME",
-               i, what[std::min(std::max(hs.status, 0), 5)], hs.num_frames, d->tok_frame_cap,
-               d->link_frame_cap, hs.num_tokens, d->h_utts[i].tok_cap, hs.num_links,
-               d->h_utts[i].link_cap);
+  d->h_out.assign(n_utts, UttOut());
+  d->h_round.assign(n_utts, 0);
+  d->rounds.clear();
+  d->last_kernel_ms = 0.f;
+  long long tok_per_frame = 160, link_per_frame = 240;
+  if (const char *e = getenv("KH_DECODER_POOL_TOKENS_PER_FRAME")) {
+    tok_per_frame = atoll(e);
+    link_per_frame = tok_per_frame * 3 / 2;
+  }
+  std::vector<int> pending(d->order);
+  // The lattice pool is sized from an estimate; an utterance whose lattice does not
+  // fit reports its exact size and is decoded again in a second launch with a pool
+  // of exactly the needed size (rare: the estimate is ~1.5x the density measured on
+  // the recipe's options).
+  long long need_tok = 0, need_link = 0;
+  for (int round = 0; !pending.empty(); round++) {
+    if (round > 3) {
+      SetError("kh_decoder_decode: lattice pool still too small after %d launches", round);
       return KH_ECAPACITY;
     }
+    const int np = static_cast<int>(pending.size());
+    long long frames = 0;
+    for (int ui : pending) frames += d->h_T[ui];
+    const long long pool_tok = round == 0 ? frames * tok_per_frame + 65536 : need_tok + 1024;
+    const long long pool_link = round == 0 ? frames * link_per_frame + 131072 : need_link + 1024;
+    {
+      Carver sizer{nullptr};
+      sizer.Take<int32_t>(pool_tok); sizer.Take<int32_t>(pool_tok);
+      for (int k = 0; k < 4; k++) sizer.Take<int32_t>(pool_link);
+      sizer.Take<float>(pool_link); sizer.Take<float>(pool_link);
+      if (sizer.off > d->pool_bytes) {
+        PoolFree(d->pool_slab);
+        d->pool_slab = PoolMalloc(sizer.off);
+        if (!d->pool_slab) { d->pool_bytes = 0; return KH_ENOMEM; }
+        d->pool_bytes = sizer.off;
+      }
+      Carver c{static_cast<char *>(d->pool_slab)};
+      d->pool.t_frame = c.Take<int32_t>(pool_tok);
+      d->pool.t_state = c.Take<int32_t>(pool_tok);
+      d->pool.l_src = c.Take<int32_t>(pool_link);
+      d->pool.l_dst = c.Take<int32_t>(pool_link);
+      d->pool.l_il = c.Take<int32_t>(pool_link);
+      d->pool.l_ol = c.Take<int32_t>(pool_link);
+      d->pool.l_g = c.Take<float>(pool_link);
+      d->pool.l_a = c.Take<float>(pool_link);
+      d->pool.tok_cap = pool_tok;
+      d->pool.link_cap = pool_link;
+      d->pool.used = d->d_used;
+    }
+    std::vector<UttIn> h_in(np);
+    for (int q = 0; q < np; q++) {
+      const int ui = pending[q];
+      h_in[q].ll = loglikes + static_cast<size_t>(utt_off[ui]) * ll_stride;
+      h_in[q].T = d->h_T[ui];
+      h_in[q].pad = 0;
+    }
+    KH_HIP(hipMemcpyAsync(d->d_in, h_in.data(), sizeof(UttIn) * np, hipMemcpyHostToDevice, st));
+    KH_HIP(hipMemsetAsync(d->d_used, 0, sizeof(unsigned long long) * 4, st));
+    if (round > 0)
+      for (int i = 0; i < n_slots; i++)
+        hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, d->h_slots[i].tok_cost,
+                           static_cast<size_t>(d->h_slots[i].tok_cap), kEncInf);
+    const int grid = std::min(np, n_slots);
+    KH_HIP(hipEventRecord(d->ev0, st));
+    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), 0, st, d->d_slots, d->d_in, d->d_out, np, d->pool, p,
+                       d->d_phase);
+    KH_LAUNCH_CHECK();
+    KH_HIP(hipEventRecord(d->ev1, st));
+    std::vector<UttOut> q_out(np);
+    unsigned long long used[4] = {0, 0, 0, 0};
+    KH_HIP(hipMemcpyAsync(q_out.data(), d->d_out, sizeof(UttOut) * np, hipMemcpyDeviceToHost, st));
+    KH_HIP(hipMemcpyAsync(used, d->d_used, sizeof(used), hipMemcpyDeviceToHost, st));
+    std::vector<long long> h_phase;
+    if (d->d_phase) {
+      h_phase.resize(16 * static_cast<size_t>(grid));
+      KH_HIP(hipMemcpyAsync(h_phase.data(), d->d_phase, sizeof(long long) * 16 * grid, hipMemcpyDeviceToHost, st));
+    }
+    KH_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    KH_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    d->last_kernel_ms += ms;
+    if (d->d_phase) {
+      static const char *names[16] = {"cutoff", "emit_pass1", "emit_pass2", "eps_closure", "eps_links", "clear_hash",
+                                      "prune", "compact", "finalize", "export", "", "", "", "", "", "other"};
+      long long tot[16] = {0};
+      long long all = 0;
+      for (int i = 0; i < grid; i++)
+        for (int k = 0; k < 16; k++) { tot[k] += h_phase[16 * i + k]; all += h_phase[16 * i + k]; }
+      fprintf(stderr, "[kh_decoder profile] launch %d: %d utterances, kernel %.1f ms, %d slots; share of shader cycles:",
+              round, np, ms, grid);
+      for (int k = 0; k < 16; k++)
+        if (tot[k]) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
+      fprintf(stderr, "\n");
+    }
+    std::vector<int> next;
+    need_tok = need_link = 0;
+    for (int q = 0; q < np; q++) {
+      const int ui = pending[q];
+      const KhDecodeStats &hs = q_out[q].stats;
+      if (hs.status == 6) {  // lattice did not fit in the pool: exact size is known now
+        next.push_back(ui);
+        need_tok += q_out[q].n_tok;
+        need_link += q_out[q].n_link;
+        continue;
+      }
+      if (hs.status != 0) {
+        static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena", "links-per-frame cap",
+                                     "compaction window", "?", "lattice pool"};
+        SetError("kh_decoder_decode: utterance %d overflowed the %s at frame %d (tokens/frame cap %d, "
+                 "links/frame cap %d, arena slots in use: tokens %d/%d, links %d/%d); see "
+                 "KH_DECODER_TOKENS_PER_FRAME / KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME",
+                 ui, what[std::min(std::max(hs.status, 0), 6)], hs.num_frames, d->tok_frame_cap, d->link_frame_cap,
+                 hs.num_tokens, d->h_slots[0].tok_cap, hs.num_links, d->h_slots[0].link_cap);
+        return KH_ECAPACITY;
+      }
+      d->h_out[ui] = q_out[q];
+      d->h_round[ui] = round;
+    }
+    // ---- one D2H per pool array for the launch (the lattices the reference would
+    // build on the host in GetRawLattice)
+    d->rounds.emplace_back();
+    KhDecoder::HostPool &hp = d->rounds.back();
+    const size_t ut = std::min<unsigned long long>(used[0], pool_tok), ul = std::min<unsigned long long>(used[1], pool_link);
+    hp.t_frame.resize(ut); hp.t_state.resize(ut);
+    hp.l_src.resize(ul); hp.l_dst.resize(ul); hp.l_il.resize(ul); hp.l_ol.resize(ul);
+    hp.l_g.resize(ul); hp.l_a.resize(ul);
+#define D2H(dst, src, n, type) if (n) KH_HIP(hipMemcpyAsync(dst.data(), src, sizeof(type) * (n), hipMemcpyDeviceToHost, st))
+    D2H(hp.t_frame, d->pool.t_frame, ut, int32_t);
+    D2H(hp.t_state, d->pool.t_state, ut, int32_t);
+    D2H(hp.l_src, d->pool.l_src, ul, int32_t);
+    D2H(hp.l_dst, d->pool.l_dst, ul, int32_t);
+    D2H(hp.l_il, d->pool.l_il, ul, int32_t);
+    D2H(hp.l_ol, d->pool.l_ol, ul, int32_t);
+    D2H(hp.l_g, d->pool.l_g, ul, float);
+    D2H(hp.l_a, d->pool.l_a, ul, float);
+#undef D2H
+    KH_HIP(hipStreamSynchronize(st));
+    pending.swap(next);
   }
   return KH_OK;
 }
@@ -1385,7 +1706,7 @@ int kh_decoder_last_kernel_ms(const KhDecoder *d, float *ms) {
 // Raw per-utterance counters of the last decode (no lattice export).
 int kh_decoder_get_counters(const KhDecoder *d, int utt, KhDecodeStats *stats) {
   KH_CHECK_ARG(d && stats && utt >= 0 && utt < d->n_utts);
-  *stats = d->h_stats[utt];
+  *stats = d->h_out[utt].stats;
   return KH_OK;
 }
 
@@ -1394,7 +1715,7 @@ int kh_decoder_get_stats(const KhDecoder *dc, int utt, KhDecodeStats *stats) {
   KH_CHECK_ARG(d && stats && utt >= 0 && utt < d->n_utts);
   int rc = BuildLattice(d, utt);
   if (rc) return rc;
-  *stats = d->h_stats[utt];
+  *stats = d->h_out[utt].stats;
   stats->num_tokens = static_cast<int32_t>(d->lats[utt].state_frame.size());
   stats->num_links = static_cast<int32_t>(d->lats[utt].arc_src.size());
   return KH_OK;

@@ -122,3 +122,37 @@ def test_config_check_rejects_bad_options(api):
         api.LatticeFasterDecoder(fst, api.decoder_config(beam=-1.0))
     with pytest.raises(api.KhError):
         api.LatticeFasterDecoder(fst, api.decoder_config(prune_scale=1.5))
+
+
+def test_repeated_decodes_are_deterministic(api):
+    """Regression: L2 atomics (atomicMin on token costs) do not refresh the CU's own
+    vector L1, so plain loads of those words could return stale lines; every read of
+    an atomically-updated word must go to L2.  Dense frames (every state active)
+    made the stale reads frequent."""
+    rng = np.random.default_rng(2)
+    g = graph_like_hclg(rng, 20000, 200)
+    lls = [workloads.make_loglikes(rng, T, 200) for T in (75, 130)]
+    cfg = api.decoder_config(beam=9.0, lattice_beam=6.0)
+    want = []
+    for x in lls:
+        oc = B.DecoderOracle(g, cfg, "canonical")
+        assert oc.decode(x)
+        want.append(oc.raw_lattice())
+    fst = api.Fst(g)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
+    ll = torch.from_numpy(np.concatenate(lls, 0)).cuda()
+    for _ in range(6):
+        dec = api.LatticeFasterDecoder(fst, cfg, max_batch=2, max_frames=130)
+        dec.decode(ll, off)
+        for u in range(2):
+            assert_same_lattice(dec.get_raw_lattice(u), want[u])
+
+
+def test_more_utterances_than_slots(api, monkeypatch):
+    """Persistent workgroups pull utterances from a queue: 9 utterances on 2 slots
+    (arena reuse between utterances) must give the same lattices as one per slot."""
+    monkeypatch.setenv("KH_DECODER_SLOTS", "2")
+    rng = np.random.default_rng(12)
+    g = graph_like_hclg(rng, 30000, 300)
+    lls = [workloads.make_loglikes(rng, int(T), 300) for T in rng.integers(5, 90, 9)]
+    run_case(api, g, lls, api.decoder_config(beam=13.0, max_active=1500, min_active=100, lattice_beam=7.0))
