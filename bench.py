@@ -15,11 +15,11 @@ Workload ("librispeech_nnet_a_synthetic"): no corpus or trained model is
 available offline, so everything is seeded synthetic data of the reference
 recipe's shape: nnet_a 140 -> 700 -> 4x(3500/350) ->
 12000 -> 5800 pdfs with random weights, a random HCLG-like graph with 10 M
-states / ~25 M arcs, and a per-GPU shard of 328 utterances (1/8 of
-test-clean's 2620) with a LibriSpeech-like length distribution.  Multi-GPU =
-utterance sharding (weak scaling: every rank decodes its own 328-utterance
-shard); the only collective is the final all-reduce of {frames, utterances,
-tot_like} (nnet-latgen-faster.cc:100-101,133-135) over RCCL.
+states / ~25 M arcs, and per GPU a test-clean-sized set of 2620 utterances
+(~1.94 M frames, LibriSpeech-like length distribution).  Multi-GPU = utterance
+sharding (weak scaling: every rank decodes its own 2620-utterance set); the only
+collective is the final all-reduce of {frames, utterances, tot_like}
+(nnet-latgen-faster.cc:100-101,133-135) over RCCL.
 
 RTF = elapsed * 100 / frames (nnet-latgen-faster.cc:179-182).
 """
@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=328, help="utterances per GPU (1/8 of test-clean)")
+    ap.add_argument("--utts", type=int, default=2620, help="utterances per GPU (test-clean has 2620)")
     ap.add_argument("--graph-states", type=int, default=10_000_000)
     ap.add_argument("--small", action="store_true", help="tiny model/graph for a quick functional run")
     ap.add_argument("--cpu-frames", type=int, default=1500, help="frame budget of the CPU baseline sample")

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkaldi_hip.so")
+LIB_PATH = os.environ.get("KH_LIB_OVERRIDE") or os.path.join(HERE, "libkaldi_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
