@@ -157,16 +157,34 @@ struct Params {
 // kernel communicates between waves partly through L2 (atomics, sc1 loads/stores
 // of words that atomics update), so a store issued before the barrier must have
 // reached L2 before another wave's L2 read after it: s_waitcnt vmcnt(0) first.
+#ifdef KH_BARRIER_CHECK
+__device__ int g_bar_cnt[256 * 16];
+__device__ int g_bar_misaligned[4];
+#endif
 __device__ __forceinline__ void KhSync() {
+#ifdef KH_BARRIER_CHECK
+  const int w_ = threadIdx.x >> 6;
+  int *bc_ = g_bar_cnt + blockIdx.x * 16;
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&bc_[w_], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef KH_BARRIER_CHECK
+  {
+    const int n_ = __hip_atomic_load(&bc_[w_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v_ = __hip_atomic_load(&bc_[(w_ + 1) & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v_ != n_ && v_ != n_ + 1) {
+      if (atomicAdd(&g_bar_misaligned[0], 1) == 0) { g_bar_misaligned[1] = n_; g_bar_misaligned[2] = v_; g_bar_misaligned[3] = w_; }
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- block helpers
 struct Shared {
-  int wsum[NW];
+  int wsum[2][NW];                 // BlockExScan, double buffered
+  unsigned long long wred[2][NW];  // block reductions, double buffered
+  int orbuf[4];                    // BlockOr / BlockAny, 4 rotating slots
   unsigned long long wmin[NW];
-  float wminf[NW];
   int flag;
   int bcast_i[4];
   float bcast_f[8];
@@ -182,17 +200,30 @@ struct Shared {
   int tok_hw;  // highest token slot dirtied by this slot's utterances so far
 };
 
+// Per-thread view of the workgroup state: the LDS block plus the (uniform)
+// rotation counters of the barrier-light block primitives below.
+typedef __attribute__((address_space(3))) Shared LdsShared;
+struct Blk {
+  LdsShared *p;
+  int k_or, k_red, k_scan;
+  __device__ __forceinline__ LdsShared *operator->() const { return p; }
+};
+
 // Diagnostic phase timer: thread 0 charges the shader cycles since the previous
 // stamp to `ph`.  Only active when the host passed a phase_cycles buffer.
-__device__ __forceinline__ void Stamp(const Utt &u, Shared &sh, int ph) {
+__device__ __forceinline__ void Stamp(const Utt &u, Blk &sh, int ph) {
   if (u.phase_cycles != nullptr && threadIdx.x == 0) {
     const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
-    sh.phase[ph] += now - sh.t_last;
-    sh.t_last = now;
+    sh->phase[ph] += now - sh->t_last;
+    sh->t_last = now;
   }
 }
 
-__device__ __forceinline__ int BlockExScan(int v, int *total, Shared &sh) {
+// Block primitives with ONE barrier each.  Every primitive writes its per-wave
+// partials into a buffer selected by a per-thread call counter (uniform across the
+// workgroup) and reads all partials after the barrier; a buffer is rewritten two
+// calls later, i.e. behind at least one more barrier than its last read.
+__device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -200,101 +231,98 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Shared &sh) {
     int n = __shfl_up(inc, o, 64);
     if (lane >= o) inc += n;
   }
-  if (lane == 63) sh.wsum[w] = inc;
+  const int buf = (sh.k_scan++) & 1;
+  if (lane == 63) sh->wsum[buf][w] = inc;
   KhSync();
-  if (w == 0) {
-    int s = lane < NW ? sh.wsum[lane] : 0;
-    int si = s;
+  int before = 0, all = 0;
 #pragma unroll
-    for (int o = 1; o < NW; o <<= 1) {
-      int n = __shfl_up(si, o, 64);
-      if (lane >= o) si += n;
-    }
-    if (lane < NW) sh.wsum[lane] = si - s;  // exclusive wave offsets
-    if (lane == NW - 1) sh.bcast_i[0] = si;
+  for (int i = 0; i < NW; i++) {
+    const int t = sh->wsum[buf][i];
+    before += i < w ? t : 0;
+    all += t;
   }
-  KhSync();
-  const int res = sh.wsum[w] + inc - v;
-  *total = sh.bcast_i[0];
-  KhSync();
-  return res;
+  *total = all;
+  return before + inc - v;
 }
 
-__device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, Shared &sh) {
+__device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, Blk &sh) {
+  const int buf = (sh.k_red++) & 1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     unsigned long long n = __shfl_xor(v, o, 64);
     v = n < v ? n : v;
   }
-  if ((threadIdx.x & 63) == 0) sh.wmin[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) sh->wred[buf][threadIdx.x >> 6] = v;
   KhSync();
-  unsigned long long r = sh.wmin[0];
+  unsigned long long r = sh->wred[buf][0];
 #pragma unroll
-  for (int i = 1; i < NW; i++) r = sh.wmin[i] < r ? sh.wmin[i] : r;
-  KhSync();
+  for (int i = 1; i < NW; i++) r = sh->wred[buf][i] < r ? sh->wred[buf][i] : r;
   return r;
 }
 
-__device__ __forceinline__ float BlockMinF(float v, Shared &sh) {
+__device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
+  const int buf = (sh.k_red++) & 1;
   v = kh_wave_min(v);
-  if ((threadIdx.x & 63) == 0) sh.wminf[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) sh->wred[buf][threadIdx.x >> 6] = __float_as_uint(v);
   KhSync();
-  float r = sh.wminf[0];
+  float r = __uint_as_float(static_cast<uint32_t>(sh->wred[buf][0]));
 #pragma unroll
-  for (int i = 1; i < NW; i++) r = fminf(r, sh.wminf[i]);
-  KhSync();
+  for (int i = 1; i < NW; i++) r = fminf(r, __uint_as_float(static_cast<uint32_t>(sh->wred[buf][i])));
   return r;
 }
 
-__device__ __forceinline__ bool BlockAny(bool p, Shared &sh) {
-  if (threadIdx.x == 0) sh.flag = 0;
-  KhSync();
-  if (__any(p) && (threadIdx.x & 63) == 0) sh.flag = 1;  // benign same-value race
-  KhSync();
-  const bool r = sh.flag != 0;
-  KhSync();
-  return r;
-}
-
-__device__ __forceinline__ long long BlockSumLL(long long v, Shared &sh) {
+__device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
+  const int buf = (sh.k_red++) & 1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63) == 0) sh.wmin[threadIdx.x >> 6] = static_cast<unsigned long long>(v);
+  if ((threadIdx.x & 63) == 0) sh->wred[buf][threadIdx.x >> 6] = static_cast<unsigned long long>(v);
   KhSync();
   long long r = 0;
 #pragma unroll
-  for (int i = 0; i < NW; i++) r += static_cast<long long>(sh.wmin[i]);
-  KhSync();
+  for (int i = 0; i < NW; i++) r += static_cast<long long>(sh->wred[buf][i]);
   return r;
 }
+
+// OR over the workgroup.  Slot k is reset two calls ahead (by thread 0, before the
+// barrier of call n it clears the slot of call n + 2): its previous use (call n - 2)
+// was fully read before every thread reached the barrier of call n - 1.
+__device__ __forceinline__ int BlockOr(int bits, Blk &sh) {
+  const int k = (sh.k_or++) & 3;
+  if (threadIdx.x == 0) sh->orbuf[(k + 2) & 3] = 0;
+  if (bits) __hip_atomic_fetch_or(&sh->orbuf[k], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  KhSync();
+  return sh->orbuf[k];
+}
+
+__device__ __forceinline__ bool BlockAny(bool p, Blk &sh) { return BlockOr(p ? 1 : 0, sh) != 0; }
 
 // Exact k-th smallest (0-based) of the cost images tok_cost[b..e): what
 // std::nth_element yields at position k (GetCutoff :621-626,:633-640).
 __device__ uint32_t RadixSelect(GP(const uint32_t) keys, int b, int e, int k,
-                                Shared &sh) {
+                                Blk &sh) {
   uint32_t prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = threadIdx.x; i < 256; i += NT) sh.hist[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += NT) sh->hist[i] = 0;
     KhSync();
     for (int i = b + threadIdx.x; i < e; i += NT) {
       const uint32_t key = LoadCostEnc(&keys[i]);
-      if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+      if ((key & mask) == prefix) __hip_atomic_fetch_add(&sh->hist[(key >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     KhSync();
     if (threadIdx.x == 0) {
       int acc = 0, bin = 0;
       for (; bin < 256; bin++) {
-        const int c = static_cast<int>(sh.hist[bin]);
+        const int c = static_cast<int>(sh->hist[bin]);
         if (acc + c > k) break;
         acc += c;
       }
-      sh.bcast_i[1] = bin;
-      sh.bcast_i[2] = k - acc;
+      sh->bcast_i[1] = bin;
+      sh->bcast_i[2] = k - acc;
     }
     KhSync();
-    prefix |= static_cast<uint32_t>(sh.bcast_i[1]) << shift;
+    prefix |= static_cast<uint32_t>(sh->bcast_i[1]) << shift;
     mask |= 255u << shift;
-    k = sh.bcast_i[2];
+    k = sh->bcast_i[2];
     KhSync();
   }
   return prefix;
@@ -310,7 +338,7 @@ __device__ __forceinline__ uint32_t HashState(int32_t s) {
 // `state` in the frame under construction, creating it if needed (cost slot is
 // pre-filled with +inf: arena invariant), or -1 if the raw arena is full.
 // Entry: low 32 bits = state + 1 (0 = empty), high 32 bits = token + 1 (0 = pending).
-__device__ int FindOrAdd(const Utt &u, int32_t state, int *tok_end /*LDS counter*/,
+__device__ int FindOrAdd(const Utt &u, int32_t state, __attribute__((address_space(3))) int *tok_end /*LDS counter*/,
                          int tok_limit, int front_b) {
   uint32_t slot = HashState(state) & u.hash_mask;
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
@@ -322,7 +350,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, int *tok_end /*LDS counter
                                            __HIP_MEMORY_SCOPE_AGENT);  // old <- previous value
       if (old == kEmpty) {
         // we own the slot: allocate the token, publish it
-        const int idx = atomicAdd(tok_end, 1);
+        const int idx = __hip_atomic_fetch_add(tok_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (idx >= tok_limit) {
           // arena full: publish an invalid token so waiters terminate
           __hip_atomic_exchange(&u.hash[slot], want_key | (0xFFFFFFFFull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -357,7 +385,7 @@ struct Cutoff {
 };
 
 // GetCutoff :591-658 over the tokens [b, e) of the current frame.
-__device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Shared &sh) {
+__device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh) {
   Cutoff c;
   const int n = e - b;
   c.count = n;
@@ -419,16 +447,16 @@ __device__ __forceinline__ float LogLike(const Utt &u, const Params &p, int fram
 }
 
 // ProcessNonemitting :752-812 on the tokens of the frame under construction
-// ([sh.front_b, sh.tok_end)), then generation of the epsilon links with the
+// ([sh->front_b, sh->tok_end)), then generation of the epsilon links with the
 // converged costs.  Returns false on arena overflow.
-__device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, float cutoff, Shared &sh) {
-  const int fb = sh.front_b;
+__device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, float cutoff, Blk &sh) {
+  const int fb = sh->front_b;
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff
   bool first = true;
   long long my_arcs = 0;
   for (;;) {
-    const int fe = sh.tok_end;  // tokens existing at the start of the round
+    const int fe = sh->tok_end;  // tokens existing at the start of the round
     KhSync();
     bool any = false;
     for (int i = fb + threadIdx.x; i < fe; i += NT) {
@@ -444,8 +472,8 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         my_arcs++;
         const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
         if (tot_cost < cutoff) {  // :794
-          const int dst = FindOrAdd(u, arc.w, &sh.tok_end, tok_limit, fb);
-          if (dst < 0) { sh.status = 1; continue; }
+          const int dst = FindOrAdd(u, arc.w, &sh->tok_end, tok_limit, fb);
+          if (dst < 0) { sh->status = 1; continue; }
           const uint32_t enc = Enc(tot_cost);
           const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (enc < old) {  // "changed": new or cheaper -> (re)process dst
@@ -456,14 +484,15 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
       }
     }
     first = false;
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
     const bool more = BlockAny(any, sh);
-    if (sh.status != 0) return false;
+    if (sh->status != 0) return false;
     if (!more) break;
   }
   Stamp(u, sh, 3);
   // ---- epsilon links: {(tok, arc): cost[tok] <= cutoff, cost[tok] + w < cutoff}
-  const int fe = sh.tok_end;
-  const int blk_b = sh.link_end;
+  const int fe = sh->tok_end;
+  const int blk_b = sh->link_end;
   for (int base = fb; base < fe; base += NT) {
     const int i = base + threadIdx.x;
     int cnt = 0, ab = 0, ae = 0;
@@ -482,9 +511,9 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     }
     int total;
     const int off = BlockExScan(cnt, &total, sh);
-    const int lbase = sh.link_end;
+    const int lbase = sh->link_end;
     if (lbase + total > u.link_cap) {
-      if (threadIdx.x == 0) sh.status = 2;
+      if (threadIdx.x == 0) sh->status = 2;
       KhSync();
       return false;
     }
@@ -497,7 +526,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
           const KhInt4 arc = p.n_arcs[a];
           const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
           if (tot_cost < cutoff) {
-            const int dst = FindOrAdd(u, arc.w, &sh.tok_end, tok_limit, fb);  // exists already
+            const int dst = FindOrAdd(u, arc.w, &sh->tok_end, tok_limit, fb);  // exists already
             u.link_dst[l] = dst;
             u.link_il[l] = 0;
             u.link_ol[l] = arc.y;
@@ -509,14 +538,14 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
       }
     }
     KhSync();
-    if (threadIdx.x == 0) sh.link_end = lbase + total;
+    if (threadIdx.x == 0) sh->link_end = lbase + total;
     KhSync();
   }
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
   if (threadIdx.x == 0) {
-    sh.arcs_expanded += tot_arcs;
+    sh->arcs_expanded += tot_arcs;
     u.feps_b[frame] = blk_b;
-    u.feps_e[frame] = sh.link_end;
+    u.feps_e[frame] = sh->link_end;
   }
   KhSync();
   Stamp(u, sh, 4);
@@ -530,16 +559,16 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
 }
 
 // ProcessEmitting :660-750 for frame `frame` (tokens [b, e) -> new tokens appended
-// at sh.tok_end, which becomes the new frontier sh.front_b).  Returns next_cutoff
+// at sh->tok_end, which becomes the new frontier sh->front_b).  Returns next_cutoff
 // through *next_cutoff_out; false on overflow.
 __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b, int e,
-                                float *next_cutoff_out, Shared &sh) {
-  const int nb = sh.tok_end;  // first token of frame + 1
+                                float *next_cutoff_out, Blk &sh) {
+  const int nb = sh->tok_end;  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff(u, p, b, e, sh);
   Stamp(u, sh, 0);
-  if (threadIdx.x == 0 && c.count > sh.max_tokens_frame) sh.max_tokens_frame = c.count;
+  if (threadIdx.x == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
   const float inf = INFINITY;
   float cost_offset = 0.0f;
   float est = inf;
@@ -561,7 +590,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 
   // ---- pass 1: expand every token under cur_cutoff; write candidate links with
   // their tot_cost; reduce min(tot_cost + adaptive_beam).
-  const int link_frame_b = sh.link_end;
+  const int link_frame_b = sh->link_end;
   long long my_arcs = 0;
   for (int base = b; base < e; base += NT) {
     const int i = base + threadIdx.x;
@@ -577,9 +606,9 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     }
     int total;
     const int off = BlockExScan(cnt, &total, sh);
-    const int lbase = sh.link_end;
+    const int lbase = sh->link_end;
     if (lbase + total > u.link_cap || lbase + total - link_frame_b > u.link_frame_cap) {
-      if (threadIdx.x == 0) sh.status = (lbase + total > u.link_cap) ? 2 : 3;
+      if (threadIdx.x == 0) sh->status = (lbase + total > u.link_cap) ? 2 : 3;
       KhSync();
       return false;
     }
@@ -603,17 +632,17 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       my_arcs += cnt;
     }
     KhSync();
-    if (threadIdx.x == 0) sh.link_end = lbase + total;
+    if (threadIdx.x == 0) sh->link_end = lbase + total;
     KhSync();
   }
   // final next_cutoff: the value the reference's running cutoff converges to
   const float next_cutoff = BlockMinF(est, sh);
   Stamp(u, sh, 1);
-  const int link_frame_e = sh.link_end;
+  const int link_frame_e = sh->link_end;
   if (threadIdx.x == 0) {
     u.femit_b[frame] = link_frame_b;
     u.femit_e[frame] = link_frame_e;
-    sh.front_b = nb;
+    sh->front_b = nb;
   }
   KhSync();
 
@@ -623,19 +652,19 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     const float tot_cost = u.link_tot[l - link_frame_b];
     int dst = -1;
     if (!(tot_cost > next_cutoff)) {  // :731 "if (tot_cost > next_cutoff) continue"
-      dst = FindOrAdd(u, u.link_dst[l], &sh.tok_end, tok_limit, nb);
-      if (dst < 0) sh.status = 1;
+      dst = FindOrAdd(u, u.link_dst[l], &sh->tok_end, tok_limit, nb);
+      if (dst < 0) sh->status = 1;
       else __hip_atomic_fetch_min(&u.tok_cost[dst], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     u.link_dst[l] = dst;
   }
   KhSync();
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) sh.arcs_expanded += tot_arcs;
+  if (threadIdx.x == 0) sh->arcs_expanded += tot_arcs;
   KhSync();
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
-  return sh.status == 0;
+  return sh->status == 0;
 }
 
 // link_extra_cost of :309-311 for link l of token `tok`
@@ -652,29 +681,12 @@ __device__ __forceinline__ float LinkExtra(const Utt &u, float tok_cost, int l, 
 #ifndef KH_PRUNE_EARLY_EXCISE
 #define KH_PRUNE_EARLY_EXCISE 1
 #endif
-__device__ __forceinline__ int BlockOr(int bits, Shared &sh) {
-#ifdef KH_BLOCKOR_VIA_ANY
-  int r = 0;
-  if (BlockAny((bits & 1) != 0, sh)) r |= 1;
-  if (BlockAny((bits & 2) != 0, sh)) r |= 2;
-  if (BlockAny((bits & 4) != 0, sh)) r |= 4;
-  return r;
-#else
-  if (threadIdx.x == 0) sh.flag = 0;
-  KhSync();
-  if (bits) atomicOr(&sh.flag, bits);
-  KhSync();
-  const int r = sh.flag;
-  KhSync();
-  return r;
-#endif
-}
-
 __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, float delta,
                                   bool final_frame, bool have_final, float final_best_cost,
-                                  bool *extra_costs_changed, bool *links_pruned, Shared &sh) {
+                                  bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY;
   const float lb = p.lattice_beam;
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; }
   // Pass 0.  A link to the NEXT frame sees final extra_costs there, so its
   // link_extra_cost — hence whether it is excised (:315) — is final at first
   // sight: emitting links are visited exactly once.  Tokens without epsilon links
@@ -740,6 +752,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, f
           changed = true;
         }
       }
+      if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
       if (!BlockAny(changed, sh)) break;
     }
     // excise epsilon links with the converged values; change flags vs entry values
@@ -791,7 +804,8 @@ __device__ __forceinline__ void StoreFlag(P p, uint8_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Shared &sh) {
+__device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Blk &sh) {
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[12] += 1;
   for (int f = cur - 1; f >= 0; f--) {
     const bool ml = LoadFlag(&u.must_links[f]);
     const bool mt = (f + 1 < cur) && LoadFlag(&u.must_toks[f + 1]);
@@ -821,21 +835,22 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
 // arena tail and of the link arena tail move down, token indices stored in links
 // are rewritten through tmp_remap (frame w_lo - 1 keeps its place but its emitting
 // links point into the window, so their dst fields are rewritten too).
-__device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
+__device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   if (w_lo < 0) w_lo = 0;
   const int win_b = u.frame_b[w_lo];
-  const int old_tok_end = sh.tok_end;
+  const int old_tok_end = sh->tok_end;
   if (old_tok_end - win_b > u.window_cap) {
-    if (threadIdx.x == 0) sh.status = 4;
+    if (threadIdx.x == 0) sh->status = 4;
     KhSync();
     return false;
   }
   // (a) tokens
-  if (threadIdx.x == 0) sh.tok_end = win_b;
+  KhSync();  // every thread has read old_tok_end
+  if (threadIdx.x == 0) sh->tok_end = win_b;
   KhSync();
   for (int f = w_lo; f <= cur; f++) {
     const int b = u.frame_b[f], e = u.frame_e[f];
-    const int new_b = sh.tok_end;
+    const int new_b = sh->tok_end;
     for (int base = b; base < e; base += NT) {
       const int i = base + threadIdx.x;
       int st = -1, eb = 0, en = 0, mb = 0, mn = 0;
@@ -848,7 +863,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
       const int alive = st >= 0 ? 1 : 0;
       int total;
       const int off = BlockExScan(alive, &total, sh);  // barriers: all reads of the chunk are done
-      const int dbase = sh.tok_end;
+      const int dbase = sh->tok_end;
       if (i < e) {
         int ni = -1;
         if (alive) {
@@ -859,16 +874,16 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
         u.tmp_remap[i - win_b] = ni;
       }
       KhSync();
-      if (threadIdx.x == 0) sh.tok_end = dbase + total;
+      if (threadIdx.x == 0) sh->tok_end = dbase + total;
       KhSync();
     }
     if (threadIdx.x == 0) {
       u.frame_b[f] = new_b;
-      u.frame_e[f] = sh.tok_end;
+      u.frame_e[f] = sh->tok_end;
     }
     KhSync();
   }
-  const int new_tok_end = sh.tok_end;
+  const int new_tok_end = sh->tok_end;
   // arena invariant: free slots hold +inf
   for (int i = new_tok_end + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
   // (b) emitting links of frame w_lo - 1 point into the window: rewrite in place
@@ -880,14 +895,14 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
   }
   KhSync();
   // (c) links, block by block in arena order: eps(f), emit(f)
-  if (threadIdx.x == 0) sh.link_end = u.feps_b[w_lo];
+  if (threadIdx.x == 0) sh->link_end = u.feps_b[w_lo];
   KhSync();
   for (int f = w_lo; f <= cur; f++) {
     for (int kind = 0; kind < 2; kind++) {  // 0: epsilon, 1: emitting
       if (kind == 1 && f == cur) continue;  // not created yet
       const int blk_b = kind ? u.femit_b[f] : u.feps_b[f];
       const int blk_e = kind ? u.femit_e[f] : u.feps_e[f];
-      const int new_blk_b = sh.link_end;
+      const int new_blk_b = sh->link_end;
       // per-token new link ranges (tokens already sit at their new index)
       {
         const int b = u.frame_b[f], e = u.frame_e[f];
@@ -923,40 +938,40 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Shared &sh) {
         const int alive = dst >= 0 ? 1 : 0;
         int total;
         const int off = BlockExScan(alive, &total, sh);
-        const int dbase = sh.link_end;
+        const int dbase = sh->link_end;
         if (alive) {
           const int d = dbase + off;
           u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
           u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
         }
         KhSync();
-        if (threadIdx.x == 0) sh.link_end = dbase + total;
+        if (threadIdx.x == 0) sh->link_end = dbase + total;
         KhSync();
       }
       if (threadIdx.x == 0) {
-        if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = sh.link_end; }
-        else { u.feps_b[f] = new_blk_b; u.feps_e[f] = sh.link_end; }
+        if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = sh->link_end; }
+        else { u.feps_b[f] = new_blk_b; u.feps_e[f] = sh->link_end; }
       }
       KhSync();
     }
   }
-  if (threadIdx.x == 0) sh.front_b = u.frame_b[cur];
+  if (threadIdx.x == 0) sh->front_b = u.frame_b[cur];
   KhSync();
   return true;
 }
 
 // One utterance: InitDecoding, Decode, FinalizeDecoding.  Leaves the surviving
-// tokens/links in the slot's arenas ([0, sh.tok_end) / [0, sh.link_end)).
-__device__ bool DecodeOne(const Utt &u, const Params &p, Shared &sh, KhDecodeStats *st_out) {
+// tokens/links in the slot's arenas ([0, sh->tok_end) / [0, sh->link_end)).
+__device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats *st_out) {
   const float inf = INFINITY;
   if (threadIdx.x == 0) {
-    sh.tok_end = 0;
-    sh.link_end = 0;
-    sh.front_b = 0;
-    sh.status = 0;
-    sh.arcs_expanded = 0;
-    sh.tokens_created = 0;
-    sh.max_tokens_frame = 0;
+    sh->tok_end = 0;
+    sh->link_end = 0;
+    sh->front_b = 0;
+    sh->status = 0;
+    sh->arcs_expanded = 0;
+    sh->tokens_created = 0;
+    sh->max_tokens_frame = 0;
   }
   for (int f = threadIdx.x; f < u.T + 2; f += NT) {
     u.must_links[f] = 1;  // TokenList(): must_prune_forward_links(true), must_prune_tokens(true)
@@ -966,15 +981,15 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Shared &sh, KhDecodeSta
 
   // ---- InitDecoding :55-72
   if (threadIdx.x == 0) {
-    const int idx = FindOrAdd(u, p.start, &sh.tok_end, u.tok_cap, 0);
+    const int idx = FindOrAdd(u, p.start, &sh->tok_end, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
     u.frame_b[0] = idx;
   }
   KhSync();
   bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
   int fb = 0;                    // token range of the frontier frame
-  int fe = sh.tok_end;
-  if (threadIdx.x == 0) { u.frame_e[0] = fe; sh.tokens_created += fe - fb; if (fe > sh.tok_hw) sh.tok_hw = fe; }
+  int fe = sh->tok_end;
+  if (threadIdx.x == 0) { u.frame_e[0] = fe; sh->tokens_created += fe - fb; if (fe > sh->tok_hw) sh->tok_hw = fe; }
   if (ok) ClearHash(u, fb, fe);
   // Compaction window: everything younger than 2 * max(prune_interval, 25) frames
   // (frames leave it only once they are >= 25 frames behind the frontier, i.e.
@@ -999,13 +1014,13 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Shared &sh, KhDecodeSta
     if (!ok) break;
     ok = ProcessNonemitting(u, p, t + 1, next_cutoff, sh);
     if (!ok) break;
-    fb = sh.front_b;
-    fe = sh.tok_end;
+    fb = sh->front_b;
+    fe = sh->tok_end;
     if (threadIdx.x == 0) {
       u.frame_b[t + 1] = fb;
       u.frame_e[t + 1] = fe;
-      sh.tokens_created += fe - fb;
-      if (fe > sh.tok_hw) sh.tok_hw = fe;
+      sh->tokens_created += fe - fb;
+      if (fe > sh->tok_hw) sh->tok_hw = fe;
     }
     Stamp(u, sh, 15);
     ClearHash(u, fb, fe);
@@ -1048,15 +1063,15 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Shared &sh, KhDecodeSta
     Stamp(u, sh, 8);
   }
   KhSync();
-  st.arcs_expanded = sh.arcs_expanded;
-  st.tokens_created = sh.tokens_created;
-  st.status = sh.status;
-  st.max_tokens_frame = sh.max_tokens_frame;
-  st.num_tokens = sh.tok_end;   // arena slots in use (pruned ones included)
-  st.num_links = sh.link_end;
+  st.arcs_expanded = sh->arcs_expanded;
+  st.tokens_created = sh->tokens_created;
+  st.status = sh->status;
+  st.max_tokens_frame = sh->max_tokens_frame;
+  st.num_tokens = sh->tok_end;   // arena slots in use (pruned ones included)
+  st.num_links = sh->link_end;
   *st_out = st;
   KhSync();
-  return ok && sh.status == 0;
+  return ok && sh->status == 0;
 }
 
 // Per-utterance inputs / outputs of the batch and the lattice pool the finished
@@ -1079,26 +1094,26 @@ struct Pool {
 };
 
 // GetRawLattice :109-191 device half: survivors -> pool (frame, state) / (src, dst, labels, costs).
-__device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Shared &sh) {
-  const int tok_end = sh.tok_end, T = u.T;
+__device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &sh) {
+  const int tok_end = sh->tok_end, T = u.T;
   // pass A: alive tokens -> dense indices (tmp_remap), count
-  if (threadIdx.x == 0) sh.bcast_i[3] = 0;
+  if (threadIdx.x == 0) sh->bcast_i[3] = 0;
   KhSync();
   for (int base = 0; base < tok_end; base += NT) {
     const int i = base + threadIdx.x;
     const int alive = (i < tok_end && u.tok_state[i] >= 0) ? 1 : 0;
     int total;
     const int off = BlockExScan(alive, &total, sh);
-    const int run = sh.bcast_i[3];
+    const int run = sh->bcast_i[3];
     if (i < tok_end) u.tmp_remap[i] = alive ? run + off : -1;
     KhSync();
-    if (threadIdx.x == 0) sh.bcast_i[3] = run + total;
+    if (threadIdx.x == 0) sh->bcast_i[3] = run + total;
     KhSync();
   }
-  const int n_tok = sh.bcast_i[3];
+  const int n_tok = sh->bcast_i[3];
   // pass B: count alive links per alive token -> link offsets (kept in tok_extra bits)
   KhSync();
-  if (threadIdx.x == 0) sh.bcast_i[3] = 0;
+  if (threadIdx.x == 0) sh->bcast_i[3] = 0;
   KhSync();
   for (int base = 0; base < tok_end; base += NT) {
     const int i = base + threadIdx.x;
@@ -1112,13 +1127,13 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Share
     }
     int total;
     const int off = BlockExScan(cnt, &total, sh);
-    const int run = sh.bcast_i[3];
+    const int run = sh->bcast_i[3];
     if (i < tok_end) u.tok_extra[i] = __int_as_float(run + off);  // extra_cost is dead after finalisation
     KhSync();
-    if (threadIdx.x == 0) sh.bcast_i[3] = run + total;
+    if (threadIdx.x == 0) sh->bcast_i[3] = run + total;
     KhSync();
   }
-  const int n_link = sh.bcast_i[3];
+  const int n_link = sh->bcast_i[3];
   // allocate in the pool
   KhSync();
   if (threadIdx.x == 0) {
@@ -1130,14 +1145,14 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Share
     out->n_link = n_link;
     const bool fits = tb + n_tok <= static_cast<unsigned long long>(pool.tok_cap) &&
                       lb + n_link <= static_cast<unsigned long long>(pool.link_cap);
-    if (!fits) { sh.status = 6; out->stats.status = 6; }
-    sh.wmin[0] = tb;
-    sh.wmin[1] = lb;
-    sh.flag = fits ? 1 : 0;
+    if (!fits) { sh->status = 6; out->stats.status = 6; }
+    sh->wmin[0] = tb;
+    sh->wmin[1] = lb;
+    sh->flag = fits ? 1 : 0;
   }
   KhSync();
-  const long long tb = static_cast<long long>(sh.wmin[0]), lbase = static_cast<long long>(sh.wmin[1]);
-  const bool fits = sh.flag != 0;
+  const long long tb = static_cast<long long>(sh->wmin[0]), lbase = static_cast<long long>(sh->wmin[1]);
+  const bool fits = sh->flag != 0;
   KhSync();
   if (!fits) return;
   // pass C: write
@@ -1181,25 +1196,38 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Share
 __global__ void __launch_bounds__(NT)
 DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut *__restrict__ out,
              int n_utts, Pool pool, Params p, GP(long long) phase_cycles) {
-  __shared__ Shared sh;
+  __shared__ Shared shm;
+  Blk sh;
+  sh.p = (LdsShared *)&shm;
+  sh.k_or = 0;
+  sh.k_red = 0;
+  sh.k_scan = 0;
   Utt u = slots[blockIdx.x];
   u.phase_cycles = phase_cycles ? phase_cycles + 16 * blockIdx.x : (GP(long long))nullptr;
   if (threadIdx.x == 0) {
-    for (int i = 0; i < 16; i++) sh.phase[i] = 0;
-    sh.t_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
-    sh.tok_hw = 0;
+    for (int i = 0; i < 16; i++) sh->phase[i] = 0;
+    sh->t_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh->tok_hw = 0;
+    for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
+#ifdef KH_BARRIER_CHECK
+    for (int i = 0; i < 16; i++) __hip_atomic_store(&g_bar_cnt[blockIdx.x * 16 + i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   }
+#ifdef KH_BARRIER_CHECK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#endif
   KhSync();
   for (;;) {
-    if (threadIdx.x == 0) sh.bcast_i[3] = static_cast<int>(__hip_atomic_fetch_add(&pool.used[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (threadIdx.x == 0) sh->bcast_i[3] = static_cast<int>(__hip_atomic_fetch_add(&pool.used[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     KhSync();
-    const int ui = sh.bcast_i[3];
+    const int ui = sh->bcast_i[3];
     KhSync();
     if (ui >= n_utts) break;
     u.ll = in[ui].ll;
     u.T = in[ui].T;
     // restore the arena invariants left dirty by the previous utterance of this slot
-    const int hw = sh.tok_hw;
+    const int hw = sh->tok_hw;
     for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
     KhSync();
@@ -1211,7 +1239,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     Stamp(u, sh, 9);
   }
   if (threadIdx.x == 0 && u.phase_cycles != nullptr)
-    for (int i = 0; i < 16; i++) u.phase_cycles[i] = sh.phase[i];
+    for (int i = 0; i < 16; i++) u.phase_cycles[i] = sh->phase[i];
 }
 
 
@@ -1724,6 +1752,15 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     float ms = 0.f;
     KH_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
     d->last_kernel_ms += ms;
+#ifdef KH_BARRIER_CHECK
+    {
+      int h[4];
+      KH_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bar_misaligned), sizeof(h)));
+      fprintf(stderr, "[kh barrier check] mismatches=%d first: n=%d neighbour=%d wave=%d\n", h[0], h[1], h[2], h[3]);
+      int z[4] = {0, 0, 0, 0};
+      KH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bar_misaligned), z, sizeof(z)));
+    }
+#endif
     if (d->d_phase) {
       static const char *names[16] = {"cutoff", "emit_pass1", "emit_pass2", "eps_closure", "eps_links", "clear_hash",
                                       "prune", "compact", "finalize", "export", "", "", "", "", "", "other"};
@@ -1733,9 +1770,13 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
         for (int k = 0; k < 16; k++) { tot[k] += h_phase[16 * i + k]; all += h_phase[16 * i + k]; }
       fprintf(stderr, "[kh_decoder profile] launch %d: %d utterances, kernel %.1f ms, %d slots; share of shader cycles:",
               round, np, ms, grid);
+      all -= tot[10] + tot[11] + tot[12] + tot[13] + tot[14];
       for (int k = 0; k < 16; k++)
-        if (tot[k]) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
-      fprintf(stderr, "\n");
+        if (tot[k] && (k < 10 || k == 15)) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
+      fprintf(stderr, "\n[kh_decoder profile] PruneActiveTokens calls %lld, frames pruned %lld (%.1f per call), tokens scanned "
+              "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
+              tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
+              tot[10] ? double(tot[14]) / tot[10] : 0.0, tot[13]);
     }
     std::vector<int> next;
     need_tok = need_link = 0;
