@@ -159,9 +159,17 @@ def main():
 
     stats = {}
 
+    verbose = bool(os.environ.get("BENCH_VERBOSE"))
+
     def step():
+        t = [time.perf_counter()]
         forward_all(api, torch, nnet, feats_d, off, loglikes, max_rows=60000)
+        if verbose:
+            torch.cuda.synchronize(); api.synchronize(); t.append(time.perf_counter())
         dec.decode(loglikes, off)
+        t.append(time.perf_counter())
+        dec.prepare()                            # raw lattices + best paths, host threads
+        t.append(time.perf_counter())
         tot_like, n_ok = 0.0, 0
         arcs = toks = 0
         for u in range(n_utts):
@@ -171,7 +179,12 @@ def main():
             st = dec.counters(u)
             arcs += st["arcs_expanded"]
             toks += st["tokens_created"]
+        t.append(time.perf_counter())
         stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, kernel_ms=dec.last_kernel_ms())
+        if verbose and rank == 0:
+            d = np.diff(t) * 1e3
+            print("[bench] forward %.0f ms, decode() %.0f ms (kernel %.0f), prepare %.0f ms, fetch %.0f ms"
+                  % (d[0], d[1], stats["kernel_ms"], d[2], d[3]), file=sys.stderr)
 
     def sync():
         torch.cuda.synchronize()

@@ -320,6 +320,12 @@ int kh_decoder_get_best_path(const KhDecoder *dec, int utt, int32_t *alignment,
                              int cap_ali, int32_t *n_ali, int32_t *words,
                              int cap_words, int32_t *n_words,
                              float *graph_cost, float *acoustic_cost);
+/* Host post-pass of the whole batch on num_threads host threads (<= 0: all
+ * cores): GetRawLattice + GetBestPath of every utterance, i.e. what
+ * DecodeUtteranceLatticeFaster (decoder-wrappers.cc:215-262) does one utterance
+ * at a time after Decode().  The per-utterance getters above then return the
+ * cached results.  Optional: the getters compute on demand otherwise. */
+int kh_decoder_prepare(KhDecoder *dec, int num_threads);
 
 /* ------------------------------------------------------------------ a15
  * Lattice forward-backward (lat/lattice-functions.cc:36-67,272-354) for a batch

@@ -34,6 +34,11 @@ def use_torch_stream():
     check(lib().kh_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
+def synchronize():
+    """Wait for the library's stream (CU_SAFE_CALL's cudaThreadSynchronize, cu-common.h:37-44)."""
+    check(lib().kh_synchronize())
+
+
 def select_gpu(ordinal):
     """CuDevice::SelectGpuId with explicit ordinal (cu-device.cc:93-192)."""
     check(lib().kh_select_gpu(int(ordinal)))
@@ -432,6 +437,11 @@ class LatticeFasterDecoder:
             L["arc_il"].ctypes.data_as(ip), L["arc_ol"].ctypes.data_as(ip), L["arc_g"].ctypes.data_as(fp),
             L["arc_a"].ctypes.data_as(fp)))
         return L
+
+    def prepare(self, num_threads=0):
+        """GetRawLattice + GetBestPath of every utterance of the batch on host
+        threads (decoder-wrappers.cc:215-262 per utterance); 0 = all cores."""
+        check(lib().kh_decoder_prepare(self._h, int(num_threads)))
 
     def get_best_path(self, utt=0):
         """GetBestPath + GetLinearSymbolSequence (decoder-wrappers.cc:232-246)."""

@@ -114,6 +114,7 @@ SIGNATURES = {
     "kh_decoder_last_kernel_ms": (C.c_int, [vp, c_float_p]),
     "kh_decoder_get_raw_lattice": (C.c_int, [vp, C.c_int, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p]),
     "kh_decoder_get_best_path": (C.c_int, [vp, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p, c_float_p, c_float_p]),
+    "kh_decoder_prepare": (C.c_int, [vp, C.c_int]),
     "kh_lattice_forward_backward": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p, c_int32_p]),
 }
 

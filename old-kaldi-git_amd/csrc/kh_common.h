@@ -46,6 +46,7 @@ hipStream_t Stream();
 // caching allocator (kh_runtime.hip)
 void *PoolMalloc(size_t bytes);
 int PoolFree(void *p);
+size_t PoolCachedBytes();  // freed blocks the pool still holds (given back to HIP when an allocation fails)
 
 inline int DivUp(int a, int b) { return (a + b - 1) / b; }
 inline int64_t DivUp64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -34,6 +34,10 @@
 #include <cmath>
 #include <limits>
 #include <numeric>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "kh_common.h"
@@ -55,7 +59,10 @@ struct KhFst {
 
 namespace {
 
-constexpr int NT = 1024;           // threads per workgroup (one utterance)
+#ifndef KH_NT
+#define KH_NT 1024
+#endif
+constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
 constexpr uint32_t kEncInf = 0xFF800000u;  // Enc(+inf)
 constexpr unsigned long long kEmpty = 0ull;
@@ -171,7 +178,7 @@ __device__ __forceinline__ void KhSync() {
   __syncthreads();
 #ifdef KH_BARRIER_CHECK
   {
-    const int n_ = __hip_atomic_load(&bc_[w_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v_ = __hip_atomic_load(&bc_[(w_ + 1) & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n_ = __hip_atomic_load(&bc_[w_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v_ = __hip_atomic_load(&bc_[(w_ + 1) & (NW - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v_ != n_ && v_ != n_ + 1) {
       if (atomicAdd(&g_bar_misaligned[0], 1) == 0) { g_bar_misaligned[1] = n_; g_bar_misaligned[2] = v_; g_bar_misaligned[3] = w_; }
     }
@@ -1193,7 +1200,13 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &
 
 // Persistent workgroups: each owns one slot (arena set) and pulls utterances from
 // a queue (the host orders them longest-first) until it is empty.
+#ifndef KH_WG_PER_CU
+#define KH_WG_PER_CU 2   // two 1024-thread workgroups per CU (<= 64 VGPRs): more loads in flight
+#endif
 __global__ void __launch_bounds__(NT)
+#if KH_WG_PER_CU > 1
+__attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
+#endif
 DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut *__restrict__ out,
              int n_utts, Pool pool, Params p, GP(long long) phase_cycles) {
   __shared__ Shared shm;
@@ -1284,6 +1297,7 @@ struct KhDecoder {
   int n_utts = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_kernel_ms = 0.f;
+  int slot_limit = std::numeric_limits<int>::max();  // slots that fit in memory (found by a failed allocation)
   // canonical lattices, built lazily per utterance
   struct Lat {
     bool built = false;
@@ -1291,6 +1305,10 @@ struct KhDecoder {
     std::vector<float> state_final;
     std::vector<int32_t> arc_src, arc_dst, arc_il, arc_ol;
     std::vector<float> arc_g, arc_a;
+    // best path (GetBestPath), cached
+    int bp_rc = 1;  // 1 = not computed yet
+    std::vector<int32_t> bp_ali, bp_words;
+    float bp_graph = 0.f, bp_acoustic = 0.f;
   };
   std::vector<Lat> lats;
 };
@@ -1439,6 +1457,68 @@ inline int Compare(const LatWeight &w1, const LatWeight &w2) {
   else return 0;
 }
 
+// Best path of utterance `utt` on its canonical lattice, cached in the Lat.
+int ComputeBestPath(KhDecoder *d, int utt) {
+  int rc = BuildLattice(d, utt);
+  if (rc) return rc;
+  KhDecoder::Lat &L = d->lats[utt];
+  if (L.bp_rc != 1) {
+    if (L.bp_rc != KH_OK) SetError("GetBestPath: no best path for utterance %d", utt);
+    return L.bp_rc;
+  }
+  const int ns = static_cast<int>(L.state_frame.size()), na = static_cast<int>(L.arc_src.size());
+  if (ns == 0) {
+    SetError("GetBestPath: empty lattice for utterance %d", utt);
+    return L.bp_rc = KH_ESTATE;
+  }
+  const float inf = std::numeric_limits<float>::infinity();
+  std::vector<LatWeight> dist(ns, LatWeight{inf, inf});
+  std::vector<int32_t> parent(ns, -1);
+  dist[0] = LatWeight{0.f, 0.f};
+  bool changed = true;
+  for (int guard = 0; changed && guard < ns + 2; guard++) {
+    changed = false;
+    for (int j = 0; j < na; j++) {
+      const LatWeight sd = dist[L.arc_src[j]];
+      if (sd.v1 == inf) continue;
+      const LatWeight w{sd.v1 + L.arc_g[j], sd.v2 + L.arc_a[j]};
+      LatWeight &nd = dist[L.arc_dst[j]];
+      const int c = (nd.v1 == inf && nd.v2 == inf) ? 1 : Compare(w, nd);
+      if (c == 1 || (c == 0 && parent[L.arc_dst[j]] > j)) {
+        nd = w;
+        parent[L.arc_dst[j]] = j;
+        changed = true;
+      }
+    }
+  }
+  LatWeight best{inf, inf};
+  int best_state = -1;
+  for (int s = 0; s < ns; s++) {
+    if (L.state_final[s] == inf || dist[s].v1 == inf) continue;
+    const LatWeight w{dist[s].v1 + L.state_final[s], dist[s].v2 + 0.0f};
+    if (best_state < 0 || Compare(w, best) == 1) {
+      best = w;
+      best_state = s;
+    }
+  }
+  if (best_state < 0) {
+    SetError("GetBestPath: no final state reachable for utterance %d", utt);
+    return L.bp_rc = KH_ESTATE;
+  }
+  std::vector<int32_t> path;
+  for (int s = best_state; parent[s] >= 0; s = L.arc_src[parent[s]]) path.push_back(parent[s]);
+  std::reverse(path.begin(), path.end());
+  L.bp_ali.clear();
+  L.bp_words.clear();
+  for (int j : path) {
+    if (L.arc_il[j] != 0) L.bp_ali.push_back(L.arc_il[j]);
+    if (L.arc_ol[j] != 0) L.bp_words.push_back(L.arc_ol[j]);
+  }
+  L.bp_graph = best.v1;
+  L.bp_acoustic = best.v2;
+  return L.bp_rc = KH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1561,7 +1641,7 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
   long long lf = 3 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
   d->link_frame_cap = static_cast<int>(lf);
-  d->max_slots = NumCUs();  // one persistent 1024-thread workgroup per CU
+  d->max_slots = NumCUs() * (1024 / NT) * KH_WG_PER_CU;  // persistent workgroups: 1024 threads per CU
   if (const char *e = getenv("KH_DECODER_SLOTS")) d->max_slots = std::max(1, atoi(e));
   return d;
 }
@@ -1597,16 +1677,39 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     tot_frames += T;
   }
   // ---- slot arenas
-  const int n_slots = std::min(n_utts, d->max_slots);
+  int n_slots = std::min(n_utts, d->max_slots);
+  if (T_max <= d->slab_T) n_slots = std::min(n_slots, d->slot_limit);  // an earlier batch found that more do not fit
   if (n_slots > d->slab_slots || T_max > d->slab_T) {
-    Carver sizer{nullptr};
-    for (int i = 0; i < n_slots; i++) {
-      Utt tmp;
-      CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio);
-    }
     PoolFree(d->slab);
-    d->slab = PoolMalloc(sizer.off);
+    d->slab = nullptr;
+    size_t slab_bytes = 0;
+    // leave room for the lattice pool and the caller: all but 16 GB of what is free
+    // (blocks cached by the library's own pool count as free: PoolMalloc returns
+    // them to HIP when an allocation fails)
+    size_t free_b = 0, total_b = 0;
+    KH_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += PoolCachedBytes();
+    const size_t budget = free_b > (16ull << 30) ? free_b - (16ull << 30) : free_b / 2;
+    const int want_slots = n_slots;
+    for (;; n_slots = (n_slots + 1) / 2) {
+      Carver sizer{nullptr};
+      for (int i = 0; i < n_slots; i++) {
+        Utt tmp;
+        CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio);
+      }
+      slab_bytes = sizer.off;
+      if (slab_bytes <= budget || n_slots == 1) {
+        d->slab = PoolMalloc(slab_bytes);
+        if (d->slab || n_slots == 1) break;
+      }
+    }
     if (!d->slab) { d->slab_bytes = 0; d->slab_slots = 0; return KH_ENOMEM; }
+    if (getenv("KH_DECODER_PROFILE"))
+      fprintf(stderr, "[kh_decoder profile] arenas: %d slots (wanted %d) x %.1f MB = %.1f GB; device memory free %.1f GB of %.1f GB\n",
+              n_slots, want_slots, slab_bytes / 1e6 / n_slots, slab_bytes / 1e9, free_b / 1e9, total_b / 1e9);
+    d->slot_limit = n_slots < want_slots ? n_slots : std::numeric_limits<int>::max();
+    Carver sizer{nullptr};
+    sizer.off = slab_bytes;
     d->slab_bytes = sizer.off;
     d->slab_slots = n_slots;
     d->slab_T = T_max;
@@ -1882,60 +1985,50 @@ int kh_decoder_get_best_path(const KhDecoder *dc, int utt, int32_t *alignment, i
                              float *graph_cost, float *acoustic_cost) {
   KhDecoder *d = const_cast<KhDecoder *>(dc);
   KH_CHECK_ARG(d && utt >= 0 && utt < d->n_utts && n_ali && n_words && graph_cost && acoustic_cost);
-  int rc = BuildLattice(d, utt);
+  int rc = ComputeBestPath(d, utt);
   if (rc) return rc;
   const KhDecoder::Lat &L = d->lats[utt];
-  const int ns = static_cast<int>(L.state_frame.size()), na = static_cast<int>(L.arc_src.size());
-  if (ns == 0) {
-    SetError("GetBestPath: empty lattice for utterance %d", utt);
-    return KH_ESTATE;
-  }
-  const float inf = std::numeric_limits<float>::infinity();
-  std::vector<LatWeight> dist(ns, LatWeight{inf, inf});
-  std::vector<int32_t> parent(ns, -1);
-  dist[0] = LatWeight{0.f, 0.f};
-  bool changed = true;
-  for (int guard = 0; changed && guard < ns + 2; guard++) {
-    changed = false;
-    for (int j = 0; j < na; j++) {
-      const LatWeight sd = dist[L.arc_src[j]];
-      if (sd.v1 == inf) continue;
-      const LatWeight w{sd.v1 + L.arc_g[j], sd.v2 + L.arc_a[j]};
-      LatWeight &nd = dist[L.arc_dst[j]];
-      const int c = (nd.v1 == inf && nd.v2 == inf) ? 1 : Compare(w, nd);
-      if (c == 1 || (c == 0 && parent[L.arc_dst[j]] > j)) {
-        nd = w;
-        parent[L.arc_dst[j]] = j;
-        changed = true;
-      }
-    }
-  }
-  LatWeight best{inf, inf};
-  int best_state = -1;
-  for (int s = 0; s < ns; s++) {
-    if (L.state_final[s] == inf || dist[s].v1 == inf) continue;
-    const LatWeight w{dist[s].v1 + L.state_final[s], dist[s].v2 + 0.0f};
-    if (best_state < 0 || Compare(w, best) == 1) {
-      best = w;
-      best_state = s;
-    }
-  }
-  if (best_state < 0) {
-    SetError("GetBestPath: no final state reachable for utterance %d", utt);
-    return KH_ESTATE;
-  }
-  std::vector<int32_t> path;
-  for (int s = best_state; parent[s] >= 0; s = L.arc_src[parent[s]]) path.push_back(parent[s]);
-  std::reverse(path.begin(), path.end());
-  int a = 0, w = 0;
-  for (int j : path) {
-    if (L.arc_il[j] != 0) { if (alignment && a < cap_ali) alignment[a] = L.arc_il[j]; a++; }
-    if (L.arc_ol[j] != 0) { if (words && w < cap_words) words[w] = L.arc_ol[j]; w++; }
-  }
+  const int a = static_cast<int>(L.bp_ali.size()), w = static_cast<int>(L.bp_words.size());
+  if (alignment) memcpy(alignment, L.bp_ali.data(), sizeof(int32_t) * std::min(a, std::max(cap_ali, 0)));
+  if (words) memcpy(words, L.bp_words.data(), sizeof(int32_t) * std::min(w, std::max(cap_words, 0)));
   *n_ali = a;
   *n_words = w;
-  *graph_cost = best.v1;
-  *acoustic_cost = best.v2;
+  *graph_cost = L.bp_graph;
+  *acoustic_cost = L.bp_acoustic;
+  return KH_OK;
+}
+
+// Host post-pass of a batch in parallel: GetRawLattice + GetBestPath of every
+// utterance (what DecodeUtteranceLatticeFaster does per utterance after Decode(),
+// decoder-wrappers.cc:215-262), on num_threads host threads (<= 0: all cores).
+int kh_decoder_prepare(KhDecoder *d, int num_threads) {
+  KH_CHECK_ARG(d);
+  const int n = d->n_utts;
+  if (n <= 0) return KH_OK;
+  int nt = num_threads > 0 ? num_threads : static_cast<int>(std::thread::hardware_concurrency());
+  nt = std::max(1, std::min(nt, n));
+  std::atomic<int> next(0), first_rc(0);
+  std::mutex mu;
+  std::string first_err;
+  auto work = [&]() {
+    for (;;) {
+      const int ui = next.fetch_add(1);
+      if (ui >= n) break;
+      const int rc = ComputeBestPath(d, ui);
+      if (rc != KH_OK) {
+        std::lock_guard<std::mutex> l(mu);
+        if (first_rc.load() == 0) { first_rc = rc; first_err = LastError(); }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < nt; i++) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+  if (first_rc.load() != 0) {
+    SetError("%s", first_err.c_str());
+    return first_rc.load();
+  }
   return KH_OK;
 }
 

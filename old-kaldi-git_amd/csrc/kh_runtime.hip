@@ -97,10 +97,12 @@ void *PoolMalloc(size_t bytes) {
   if (EnsureDevice() != KH_OK) return nullptr;
   size_t sz = RoundSize(bytes);
   std::lock_guard<std::mutex> l(g_mu);
-  auto it = g_pool.free_blocks.find(sz);
+  // best fit: the smallest cached block of at least sz, wasting at most 25 %
+  auto it = g_pool.free_blocks.lower_bound(sz);
   void *p = nullptr;
-  if (it != g_pool.free_blocks.end()) {
+  if (it != g_pool.free_blocks.end() && it->first <= sz + sz / 4) {
     p = it->second;
+    sz = it->first;
     g_pool.free_blocks.erase(it);
     g_pool.cached_bytes -= sz;
   } else {
@@ -113,8 +115,10 @@ void *PoolMalloc(size_t bytes) {
       e = hipMalloc(&p, sz);
       if (e != hipSuccess) {
         SetError("hipMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+        (void)hipGetLastError();
         return nullptr;
       }
+      (void)hipGetLastError();  // the first failure is sticky: clear it
     }
   }
   g_pool.live[p] = sz;
@@ -134,6 +138,11 @@ int PoolFree(void *p) {
   g_pool.free_blocks.emplace(sz, p);
   g_pool.cached_bytes += sz;
   return KH_OK;
+}
+
+size_t PoolCachedBytes() {
+  std::lock_guard<std::mutex> l(g_mu);
+  return g_pool.cached_bytes;
 }
 
 }  // namespace kh

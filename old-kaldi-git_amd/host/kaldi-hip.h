@@ -321,6 +321,9 @@ class LatticeFasterDecoder {
                               static_cast<int>(utt_row_offsets.size()) - 1, tid2pdf));
     return true;
   }
+  /// Raw lattices + best paths of the whole batch on host threads (0 = all cores);
+  /// optional, the per-utterance getters compute on demand otherwise.
+  void Prepare(int num_threads = 0) { KhCheck(kh_decoder_prepare(dec_, num_threads)); }
   bool ReachedFinal(int utt) const {
     KhDecodeStats st;
     KhCheck(kh_decoder_get_stats(dec_, utt, &st));

@@ -156,3 +156,24 @@ def test_more_utterances_than_slots(api, monkeypatch):
     g = graph_like_hclg(rng, 30000, 300)
     lls = [workloads.make_loglikes(rng, int(T), 300) for T in rng.integers(5, 90, 9)]
     run_case(api, g, lls, api.decoder_config(beam=13.0, max_active=1500, min_active=100, lattice_beam=7.0))
+
+
+def test_prepare_on_host_threads_matches_on_demand(api):
+    """kh_decoder_prepare builds every lattice and best path on host threads; the
+    results must equal the ones the getters compute on demand."""
+    rng = np.random.default_rng(21)
+    g = graph_like_hclg(rng, 20000, 200)
+    lls = [workloads.make_loglikes(rng, int(T), 200) for T in rng.integers(3, 70, 12)]
+    cfg = api.decoder_config(beam=11.0, max_active=1200, min_active=100, lattice_beam=6.0)
+    fst = api.Fst(g)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
+    ll = torch.from_numpy(np.concatenate(lls, 0)).cuda()
+    a = api.LatticeFasterDecoder(fst, cfg, max_batch=len(lls), max_frames=70)
+    a.decode(ll, off)
+    b = api.LatticeFasterDecoder(fst, cfg, max_batch=len(lls), max_frames=70)
+    b.decode(ll, off)
+    b.prepare(num_threads=4)
+    b.prepare()  # idempotent
+    for u in range(len(lls)):
+        assert_same_lattice(a.get_raw_lattice(u), b.get_raw_lattice(u))
+        assert_same_best_path(a.get_best_path(u), b.get_best_path(u))
