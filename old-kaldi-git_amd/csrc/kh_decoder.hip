@@ -64,6 +64,8 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
+constexpr int NPH = 24;            // diagnostic counters per slot
+constexpr int PU = 1;              // token / link slots a lane keeps in flight per round of a sweep (measured: 1 beats 2, 4, 8 - the sweeps are bound by the CU's address pipeline, not by latency, and more slots spill)
 constexpr uint32_t kEncInf = 0xFF800000u;  // Enc(+inf)
 constexpr unsigned long long kEmpty = 0ull;
 
@@ -126,6 +128,7 @@ struct Utt {
   // link arena
   int32_t link_cap;
   GP(int32_t) link_dst; GP(int32_t) link_il; GP(int32_t) link_ol;   // dst: token index, -1 = excised
+  GP(int32_t) link_src;     // owning token (links are also walked link-parallel)
   GP(float) link_g; GP(float) link_a;
   GP(float) link_tot;       // candidate tot_cost of the frame being expanded [link_frame_cap]
   // per-frame bookkeeping
@@ -138,7 +141,8 @@ struct Utt {
   // temporaries
   GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
   GP(int32_t) tmp_dirty;    // [tok_frame_cap] nonemitting worklist flags; all zero outside ProcessNonemitting
-  GP(float) tmp_f0; GP(float) tmp_f1;  // [tok_frame_cap] prune: entry extra, emit-link base (i - frame begin)
+  GP(float) tmp_f0;         // [tok_frame_cap] prune: extra_cost on entry (i - frame begin)
+  GP(uint32_t) tmp_acc0; GP(uint32_t) tmp_acc1;  // [tok_frame_cap] prune: Enc(min link_extra_cost) over emitting / epsilon links
   GP(int32_t) tmp_remap;    // [window_cap] compaction remap (i - window begin)
   int32_t tok_frame_cap, link_frame_cap, window_cap;
   // hash
@@ -151,7 +155,7 @@ struct Params {
   GP(const int32_t) e_off; GP(const int32_t) n_off;
   GP(const KhInt4) e_arcs; GP(const KhInt4) n_arcs;
   GP(const float) final_cost;
-  int32_t start, num_states;
+  int32_t start, num_states, num_emit, num_eps;
   GP(const int32_t) tid2pdf;
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
@@ -164,6 +168,12 @@ struct Params {
 // kernel communicates between waves partly through L2 (atomics, sc1 loads/stores
 // of words that atomics update), so a store issued before the barrier must have
 // reached L2 before another wave's L2 read after it: s_waitcnt vmcnt(0) first.
+#ifdef KH_BOUNDS_CHECK
+__device__ int g_oob[8];
+#define KH_BOUND(code, v, lo, hi) do { if ((v) < (lo) || (v) >= (hi)) { if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = (code); g_oob[2] = (int)(v); g_oob[3] = (int)(lo); g_oob[4] = (int)(hi); g_oob[5] = threadIdx.x; } (v) = (lo); } } while (0)
+#else
+#define KH_BOUND(code, v, lo, hi) do {} while (0)
+#endif
 #ifdef KH_BARRIER_CHECK
 __device__ int g_bar_cnt[256 * 16];
 __device__ int g_bar_misaligned[4];
@@ -189,6 +199,7 @@ __device__ __forceinline__ void KhSync() {
 // ---------------------------------------------------------------- block helpers
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
+  int wsumk[2][PU][NW];            // BlockExScanK, double buffered
   unsigned long long wred[2][NW];  // block reductions, double buffered
   int orbuf[4];                    // BlockOr / BlockAny, 4 rotating slots
   unsigned long long wmin[NW];
@@ -203,7 +214,7 @@ struct Shared {
   long long arcs_expanded, tokens_created;
   int max_tokens_frame;
   long long t_last;
-  long long phase[16];
+  long long phase[NPH];
   int tok_hw;  // highest token slot dirtied by this slot's utterances so far
 };
 
@@ -250,6 +261,39 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   }
   *total = all;
   return before + inc - v;
+}
+
+// Exclusive scan of PU * NT items laid out slice-major (item (k, t) = slice k,
+// thread t): one barrier for all slices.
+__device__ __forceinline__ void BlockExScanK(const int (&v)[PU], int (&off)[PU], int *total, Blk &sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int buf = (sh.k_scan++) & 1;
+  int inc[PU];
+#pragma unroll
+  for (int k = 0; k < PU; k++) {
+    inc[k] = v[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int n = __shfl_up(inc[k], o, 64);
+      if (lane >= o) inc[k] += n;
+    }
+    if (lane == 63) sh->wsumk[buf][k][w] = inc[k];
+  }
+  KhSync();
+  int run = 0;
+#pragma unroll
+  for (int k = 0; k < PU; k++) {
+    int before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const int t = sh->wsumk[buf][k][i];
+      before += i < w ? t : 0;
+      all += t;
+    }
+    off[k] = run + before + inc[k] - v[k];
+    run += all;
+  }
+  *total = run;
 }
 
 __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, Blk &sh) {
@@ -385,6 +429,76 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, __attribute__((address_spa
   return -1;
 }
 
+// Lookup of a state that is known to be in the hash (its token exists).
+__device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigned long long first_probe, uint32_t slot) {
+  const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
+  unsigned long long ent = first_probe;
+  for (int probes = 0; probes < (1 << 30); probes++) {
+    if ((ent & 0xFFFFFFFFull) == want_key) {
+      const uint32_t hi = static_cast<uint32_t>(ent >> 32);
+      if (hi != 0) return hi == 0xFFFFFFFFu ? -1 : static_cast<int>(hi - 1u);
+    } else {
+      slot = (slot + 1) & u.hash_mask;
+    }
+    ent = __hip_atomic_load(&u.hash[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return -1;
+}
+
+// First half of an expansion sweep over the tokens [b, e): every token whose cost
+// is <= cutoff gets one link slot per arc of its HCLG state (arc ranges `off`),
+// appended at link slot `lrun` on in token order; the slots are seeded with
+// (link_src = token, link_dst = arc index) for the link-parallel second half.
+// tok_b / tok_n receive the token's slot range.  Returns the new end of the link
+// arena, or -1 on overflow (sh->status set).
+__device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, float cutoff, int lrun,
+                            int frame_cap, GP(int32_t) tok_b, GP(int32_t) tok_n, long long *arcs, Blk &sh) {
+  const int lrun0 = lrun;
+  for (int base = b; base < e; base += NT * PU) {
+    int i[PU], st[PU];
+    uint32_t co[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      i[k] = base + k * NT + threadIdx.x;
+      const int ic = min(i[k], e - 1);
+      co[k] = LoadCostEnc(&u.tok_cost[ic]);
+      st[k] = u.tok_state[ic];
+      KH_BOUND(1, st[k], 0, 0x7ffffff0);
+    }
+    int ab[PU], cnt[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      ab[k] = off[st[k]];
+      cnt[k] = off[st[k] + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < PU; k++) cnt[k] = (i[k] < e && Dec(co[k]) <= cutoff) ? cnt[k] - ab[k] : 0;
+    int loff[PU], total;
+    BlockExScanK(cnt, loff, &total, sh);
+    if (lrun + total > u.link_cap || lrun + total - lrun0 > frame_cap) {
+      if (threadIdx.x == 0) sh->status = (lrun + total > u.link_cap) ? 2 : 3;
+      KhSync();
+      return -1;
+    }
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      if (i[k] >= e) continue;
+      int l0 = lrun + loff[k];
+      KH_BOUND(2, l0, 0, u.link_cap - cnt[k] + 1);
+      tok_b[i[k]] = l0;
+      tok_n[i[k]] = cnt[k];
+      for (int j = 0; j < cnt[k]; j++) {
+        u.link_src[l0 + j] = i[k];
+        u.link_dst[l0 + j] = ab[k] + j;
+      }
+      *arcs += cnt[k];
+    }
+    lrun += total;
+  }
+  KhSync();  // the seeds are visible to the link sweep
+  return lrun;
+}
+
 // ---------------------------------------------------------------- frame steps
 struct Cutoff {
   float cur_cutoff, adaptive_beam, best_cost;
@@ -498,56 +612,55 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   }
   Stamp(u, sh, 3);
   // ---- epsilon links: {(tok, arc): cost[tok] <= cutoff, cost[tok] + w < cutoff}
+  // One slot per epsilon arc of every token under the cutoff; the slots whose
+  // tot_cost is not under the cutoff stay dead (dst = -1) until the compaction.
   const int fe = sh->tok_end;
   const int blk_b = sh->link_end;
-  for (int base = fb; base < fe; base += NT) {
-    const int i = base + threadIdx.x;
-    int cnt = 0, ab = 0, ae = 0;
-    float cur_cost = 0.f;
-    if (i < fe) {
-      cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
-      if (cur_cost <= cutoff) {
-        const int32_t s = u.tok_state[i];
-        ab = p.n_off[s];
-        ae = p.n_off[s + 1];
-        for (int a = ab; a < ae; a++) {
-          const float tot_cost = cur_cost + __int_as_float(p.n_arcs[a].z);
-          if (tot_cost < cutoff) cnt++;
-        }
-      }
+  long long seeded = 0;
+  const int blk_e = ExpandTokens(u, p.n_off, fb, fe, cutoff, blk_b, u.link_frame_cap, u.tok_eps_b, u.tok_eps_n, &seeded, sh);
+  if (blk_e < 0) return false;
+  for (int base = blk_b + threadIdx.x; base < blk_e; base += NT * PU) {
+    int l[PU], src[PU], ai[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      l[k] = min(base + k * NT, blk_e - 1);
+      src[k] = u.link_src[l[k]];
+      ai[k] = u.link_dst[l[k]];
+      // a lane past the end re-reads the last slot, which its owner may already have
+      // rewritten: only the loaded values of in-range lanes are seeds
+      if (base + k * NT >= blk_e) { src[k] = fb; ai[k] = 0; }
+      KH_BOUND(3, src[k], 0, u.tok_cap);
+      KH_BOUND(4, ai[k], 0, p.num_eps);
     }
-    int total;
-    const int off = BlockExScan(cnt, &total, sh);
-    const int lbase = sh->link_end;
-    if (lbase + total > u.link_cap) {
-      if (threadIdx.x == 0) sh->status = 2;
-      KhSync();
-      return false;
+    KhInt4 arc[PU];
+    uint32_t co[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      arc[k] = p.n_arcs[ai[k]];
+      co[k] = LoadCostEnc(&u.tok_cost[src[k]]);
     }
-    if (i < fe) {
-      u.tok_eps_b[i] = lbase + off;
-      u.tok_eps_n[i] = cnt;
-      int l = lbase + off;
-      if (cnt > 0) {
-        for (int a = ab; a < ae; a++) {
-          const KhInt4 arc = p.n_arcs[a];
-          const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
-          if (tot_cost < cutoff) {
-            const int dst = FindOrAdd(u, arc.w, &sh->tok_end, tok_limit, fb);  // exists already
-            u.link_dst[l] = dst;
-            u.link_il[l] = 0;
-            u.link_ol[l] = arc.y;
-            u.link_g[l] = graph_cost;
-            u.link_a[l] = 0.0f;
-            l++;
-          }
-        }
-      }
+    bool live[PU];
+    uint32_t slot[PU];
+    unsigned long long ent[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      const float tot_cost = Dec(co[k]) + __int_as_float(arc[k].z);
+      live[k] = base + k * NT < blk_e && tot_cost < cutoff;
+      slot[k] = HashState(arc[k].w) & u.hash_mask;
+      ent[k] = __hip_atomic_load(&u.hash[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    KhSync();
-    if (threadIdx.x == 0) sh->link_end = lbase + total;
-    KhSync();
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      if (base + k * NT >= blk_e) continue;
+      u.link_dst[l[k]] = live[k] ? FindExisting(u, arc[k].w, ent[k], slot[k]) : -1;  // the token exists already
+      u.link_il[l[k]] = 0;
+      u.link_ol[l[k]] = arc[k].y;
+      u.link_g[l[k]] = __int_as_float(arc[k].z);
+      u.link_a[l[k]] = 0.0f;
+    }
   }
+  KhSync();
+  if (threadIdx.x == 0) sh->link_end = blk_e;
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
   if (threadIdx.x == 0) {
     sh->arcs_expanded += tot_arcs;
@@ -595,60 +708,60 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   }
   if (threadIdx.x == 0) u.cost_offset[frame] = cost_offset;  // :710-711
 
-  // ---- pass 1: expand every token under cur_cutoff; write candidate links with
-  // their tot_cost; reduce min(tot_cost + adaptive_beam).
+  // ---- pass 1: one candidate link per emitting arc of every token under
+  // cur_cutoff (token sweep + scan), then a link sweep that fetches the arcs and
+  // the acoustic scores, writes the links with their tot_cost and reduces
+  // min(tot_cost + adaptive_beam).
   const int link_frame_b = sh->link_end;
   long long my_arcs = 0;
-  for (int base = b; base < e; base += NT) {
-    const int i = base + threadIdx.x;
-    int cnt = 0, ab = 0;
-    float cur_cost = 0.f;
-    if (i < e) {
-      cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
-      if (cur_cost <= c.cur_cutoff) {  // :719
-        const int32_t s = u.tok_state[i];
-        ab = p.e_off[s];
-        cnt = p.e_off[s + 1] - ab;
-      }
+  const int link_frame_e = ExpandTokens(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, u.tok_emit_b,
+                                        u.tok_emit_n, &my_arcs, sh);
+  if (link_frame_e < 0) return false;
+  for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * PU) {
+    int l[PU], src[PU], ai[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      l[k] = min(base + k * NT, link_frame_e - 1);
+      src[k] = u.link_src[l[k]];
+      ai[k] = u.link_dst[l[k]];
+      if (base + k * NT >= link_frame_e) { src[k] = b; ai[k] = 0; }  // see ProcessNonemitting
+      KH_BOUND(5, src[k], 0, u.tok_cap);
+      KH_BOUND(6, ai[k], 0, p.num_emit);
     }
-    int total;
-    const int off = BlockExScan(cnt, &total, sh);
-    const int lbase = sh->link_end;
-    if (lbase + total > u.link_cap || lbase + total - link_frame_b > u.link_frame_cap) {
-      if (threadIdx.x == 0) sh->status = (lbase + total > u.link_cap) ? 2 : 3;
-      KhSync();
-      return false;
+    KhInt4 arc[PU];
+    uint32_t co[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      arc[k] = p.e_arcs[ai[k]];
+      co[k] = LoadCostEnc(&u.tok_cost[src[k]]);
     }
-    if (i < e) {
-      u.tok_emit_b[i] = lbase + off;
-      u.tok_emit_n[i] = cnt;
-      int l = lbase + off;
-      for (int a = ab; a < ab + cnt; a++, l++) {
-        const KhInt4 arc = p.e_arcs[a];
-        const float ac_cost = cost_offset - LogLike(u, p, frame, arc.x),
-                    graph_cost = __int_as_float(arc.z),
-                    tot_cost = cur_cost + ac_cost + graph_cost;  // :726-730
-        u.link_dst[l] = arc.w;  // HCLG next state for now; token index after pass 2
-        u.link_il[l] = arc.x;
-        u.link_ol[l] = arc.y;
-        u.link_g[l] = graph_cost;
-        u.link_a[l] = ac_cost;
-        u.link_tot[l - link_frame_b] = tot_cost;
-        est = fminf(est, tot_cost + c.adaptive_beam);
-      }
-      my_arcs += cnt;
+    int32_t pdf[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) { pdf[k] = p.tid2pdf ? p.tid2pdf[arc[k].x] : arc[k].x - 1; KH_BOUND(7, pdf[k], 0, u.ll_stride); }
+    float like[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) like[k] = u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf[k]];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      if (base + k * NT >= link_frame_e) continue;
+      const float ac_cost = cost_offset - like[k], graph_cost = __int_as_float(arc[k].z),
+                  tot_cost = Dec(co[k]) + ac_cost + graph_cost;  // :726-730
+      u.link_dst[l[k]] = arc[k].w;  // HCLG next state for now; token index after pass 2
+      u.link_il[l[k]] = arc[k].x;
+      u.link_ol[l[k]] = arc[k].y;
+      u.link_g[l[k]] = graph_cost;
+      u.link_a[l[k]] = ac_cost;
+      u.link_tot[l[k] - link_frame_b] = tot_cost;
+      est = fminf(est, tot_cost + c.adaptive_beam);
     }
-    KhSync();
-    if (threadIdx.x == 0) sh->link_end = lbase + total;
-    KhSync();
   }
   // final next_cutoff: the value the reference's running cutoff converges to
   const float next_cutoff = BlockMinF(est, sh);
   Stamp(u, sh, 1);
-  const int link_frame_e = sh->link_end;
   if (threadIdx.x == 0) {
     u.femit_b[frame] = link_frame_b;
     u.femit_e[frame] = link_frame_e;
+    sh->link_end = link_frame_e;
     sh->front_b = nb;
   }
   KhSync();
@@ -674,122 +787,140 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   return sh->status == 0;
 }
 
-// link_extra_cost of :309-311 for link l of token `tok`
-__device__ __forceinline__ float LinkExtra(const Utt &u, float tok_cost, int l, int dst) {
-  const float next_extra = LoadExtra(&u.tok_extra[dst]);
-  return next_extra + ((tok_cost + u.link_a[l] + u.link_g[l]) - Dec(LoadCostEnc(&u.tok_cost[dst])));
+// ---------------------------------------------------------------- pruning
+// PruneForwardLinks walks LINKS, not tokens: one lane per link slot (coalesced,
+// branch-free loads, PU slots per lane in flight), the per-token minimum of
+// link_extra_cost (:309-323) is an atomicMin on the order-preserving image Enc().
+
+// One pass over the link slots [lo, hi).  link_extra_cost (:309-311) of every
+// live link with the extra_costs currently stored; kExcise: links over the
+// lattice beam are excised (:315); kAccum: the others are min-ed into
+// acc[src - b].  Returns 2 if this lane excised a link.
+template <bool kAccum, bool kExcise>
+__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, GP(uint32_t) acc) {
+  int flags = 0;
+  for (int base = lo + threadIdx.x; base < hi; base += NT * PU) {
+    int l[PU], dst[PU], src[PU];
+    float a[PU], g[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      l[k] = min(base + k * NT, hi - 1);  // clamped: the tail repeats the last slot
+      dst[k] = u.link_dst[l[k]];
+      src[k] = u.link_src[l[k]];
+      a[k] = u.link_a[l[k]];
+      g[k] = u.link_g[l[k]];
+      KH_BOUND(8, src[k], 0, u.tok_cap);
+      KH_BOUND(9, dst[k], -1, u.tok_cap);
+    }
+    uint32_t cs[PU], cd[PU];
+    float ex[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      const int d = dst[k] >= 0 ? dst[k] : src[k];  // any valid token for an excised slot
+      cs[k] = LoadCostEnc(&u.tok_cost[src[k]]);
+      cd[k] = LoadCostEnc(&u.tok_cost[d]);
+      ex[k] = LoadExtra(&u.tok_extra[d]);
+    }
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      if (base + k * NT >= hi || dst[k] < 0) continue;
+      float lec = ex[k] + ((Dec(cs[k]) + a[k] + g[k]) - Dec(cd[k]));  // :309-311
+      if (lec > lb) {  // :315 excise
+        if (kExcise) { u.link_dst[l[k]] = -1; flags |= 2; }
+        continue;
+      }
+      if (kAccum) {
+        if (lec < 0.0f) lec = 0.0f;  // :319-320
+        __hip_atomic_fetch_min(&acc[src[k] - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  return flags;
 }
 
 // PruneForwardLinks :273-344 (canonical rule P: exact fixed point, then excise)
-// for the tokens [b, e) of frame f.  final_frame: PruneForwardLinksFinal :349-431.
-#ifndef KH_PRUNE_EARLY_FINALIZE
-#define KH_PRUNE_EARLY_FINALIZE 1
-#endif
-#ifndef KH_PRUNE_EARLY_EXCISE
-#define KH_PRUNE_EARLY_EXCISE 1
-#endif
-__device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, float delta,
-                                  bool final_frame, bool have_final, float final_best_cost,
-                                  bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
+// for frame f = tokens [b, e), emitting links [mb, me), epsilon links [nb, ne).
+// final_frame: PruneForwardLinksFinal :349-431.  [tb, te): tokens of frame f + 1
+// to run PruneTokensForFrame :450-469 on in the same sweep (tb == te: none).
+__device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne,
+                                  float delta, bool final_frame, bool have_final, float final_best_cost,
+                                  int tb, int te, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY;
   const float lb = p.lattice_beam;
   if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; }
-  // Pass 0.  A link to the NEXT frame sees final extra_costs there, so its
-  // link_extra_cost — hence whether it is excised (:315) — is final at first
-  // sight: emitting links are visited exactly once.  Tokens without epsilon links
-  // are finished in this pass; the others keep their partial minimum in tmp_f1.
-  int flags = 0;  // 1: extra_cost changed by more than delta; 2: link excised; 4: epsilon tokens present
-  for (int i = b + threadIdx.x; i < e; i += NT) {
-    const int st = u.tok_state[i];
-    if (st < 0) continue;
-    const int lbeg = u.tok_emit_b[i], n = u.tok_emit_n[i], en = u.tok_eps_n[i];
-    const float entry = LoadExtra(&u.tok_extra[i]);
-    const float tc = Dec(LoadCostEnc(&u.tok_cost[i]));
-    float base = inf;
-    if (final_frame) {
-      float final_cost = 0.0f;
-      if (have_final) final_cost = p.final_cost[st];
-      base = tc + final_cost - final_best_cost;  // :385
+  // P0 (tokens): remember the entry extra_cost, start the two accumulators.
+  for (int base = b + threadIdx.x; base < e; base += NT * PU) {
+    int i[PU], st[PU];
+    float entry[PU];
+    uint32_t co[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      i[k] = min(base + k * NT, e - 1);
+      st[k] = u.tok_state[i[k]];
+      entry[k] = LoadExtra(&u.tok_extra[i[k]]);
+      co[k] = final_frame ? LoadCostEnc(&u.tok_cost[i[k]]) : 0u;
     }
-    for (int l = lbeg; l < lbeg + n; l++) {
-      const int dst = u.link_dst[l];
-      if (dst < 0) continue;
-      float lec = LinkExtra(u, tc, l, dst);
-      if (lec > lb) {  // :315 excise
-        if (KH_PRUNE_EARLY_EXCISE) { u.link_dst[l] = -1; flags |= 2; }
-        continue;
-      }
-      if (lec < 0.0f) lec = 0.0f;
-      base = fminf(base, lec);
-    }
-    if (en == 0 && KH_PRUNE_EARLY_FINALIZE) {
-      float v = base;
-      if (final_frame && v > lb) v = inf;  // :416-417
-      if (!(v == entry)) StoreExtra(&u.tok_extra[i], v);
-      if (fabsf(v - entry) > delta) flags |= 1;  // :334
-    } else {
-      u.tmp_f0[i - b] = entry;
-      u.tmp_f1[i - b] = base;
-      flags |= 4;
+    float fc[PU];
+#pragma unroll
+    for (int k = 0; k < PU; k++) fc[k] = (final_frame && have_final && st[k] >= 0) ? p.final_cost[st[k]] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < PU; k++) {
+      if (base + k * NT >= e) continue;
+      float base_v = inf;
+      if (final_frame) base_v = Dec(co[k]) + fc[k] - final_best_cost;  // :385
+      u.tmp_f0[i[k] - b] = entry[k];
+      u.tmp_acc0[i[k] - b] = Enc(base_v);
+      u.tmp_acc1[i[k] - b] = kEncInf;
     }
   }
-  int all = BlockOr(flags, sh);
-  if (all & 4) {
-    // iterate the epsilon part to the exact fixed point (canonical rule P)
-    for (;;) {
-      bool changed = false;
-      for (int i = b + threadIdx.x; i < e; i += NT) {
-        if (u.tok_state[i] < 0) continue;
-        const int lbeg = u.tok_eps_b[i], n = u.tok_eps_n[i];
-        if (n == 0 && KH_PRUNE_EARLY_FINALIZE) continue;
-        const float tc = Dec(LoadCostEnc(&u.tok_cost[i]));
-        float v = u.tmp_f1[i - b];
-        for (int l = lbeg; l < lbeg + n; l++) {
-          const int dst = u.link_dst[l];
-          if (dst < 0) continue;
-          float lec = LinkExtra(u, tc, l, dst);
-          if (lec > lb) continue;
-          if (lec < 0.0f) lec = 0.0f;
-          v = fminf(v, lec);
-        }
+  // PruneTokensForFrame(f + 1): its extra_costs are final, nothing below reads its states
+  for (int i = tb + threadIdx.x; i < te; i += NT)
+    if (u.tok_state[i] >= 0 && LoadExtra(&u.tok_extra[i]) == inf) u.tok_state[i] = -1;
+  KhSync();
+  // P1 (emitting links): a link to the NEXT frame sees final extra_costs there, so
+  // its link_extra_cost - hence whether it is excised - is final at first sight.
+  int flags = PruneLinkPass<true, true>(u, mb, me, b, lb, u.tmp_acc0);
+  // Epsilon links stay inside the frame: Jacobi iteration to the exact fixed point
+  // (unique: the epsilon links of a frame form a DAG), then excise.
+  bool changed_by_delta = false;
+  for (;;) {
+    if (ne > nb) PruneLinkPass<true, false>(u, nb, ne, b, lb, u.tmp_acc1);
+    KhSync();
+    bool changed = false;
+    changed_by_delta = false;
+    for (int base = b + threadIdx.x; base < e; base += NT * PU) {
+      int i[PU], st[PU];
+      uint32_t a0[PU], a1[PU];
+      float old[PU], entry[PU];
+#pragma unroll
+      for (int k = 0; k < PU; k++) {
+        i[k] = min(base + k * NT, e - 1);
+        st[k] = u.tok_state[i[k]];
+        a0[k] = LoadCostEnc(&u.tmp_acc0[i[k] - b]);
+        a1[k] = LoadCostEnc(&u.tmp_acc1[i[k] - b]);
+        old[k] = LoadExtra(&u.tok_extra[i[k]]);
+        entry[k] = u.tmp_f0[i[k] - b];
+      }
+#pragma unroll
+      for (int k = 0; k < PU; k++) {
+        if (base + k * NT >= e || st[k] < 0) continue;
+        float v = Dec(a0[k] < a1[k] ? a0[k] : a1[k]);
         if (final_frame && v > lb) v = inf;  // :416-417
-        const float old = LoadExtra(&u.tok_extra[i]);
-        if (!(v == old)) {
-          StoreExtra(&u.tok_extra[i], v);
+        if (!(v == old[k])) {
+          StoreExtra(&u.tok_extra[i[k]], v);
           changed = true;
         }
+        if (fabsf(v - entry[k]) > delta) changed_by_delta = true;  // :334
+        if (a1[k] != kEncInf) u.tmp_acc1[i[k] - b] = kEncInf;
       }
-      if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
-      if (!BlockAny(changed, sh)) break;
     }
-    // excise epsilon links with the converged values; change flags vs entry values
-    flags = 0;
-    for (int i = b + threadIdx.x; i < e; i += NT) {
-      if (u.tok_state[i] < 0) continue;
-      const int lbeg = u.tok_eps_b[i], n = u.tok_eps_n[i];
-      if (n == 0 && KH_PRUNE_EARLY_FINALIZE) continue;
-      const float tc = Dec(LoadCostEnc(&u.tok_cost[i]));
-      for (int l = lbeg; l < lbeg + n; l++) {
-        const int dst = u.link_dst[l];
-        if (dst < 0) continue;
-        const float lec = LinkExtra(u, tc, l, dst);
-        if (lec > lb) {  // :315 excise
-          u.link_dst[l] = -1;
-          flags |= 2;
-        }
-      }
-      if (!KH_PRUNE_EARLY_EXCISE) {
-        const int mb = u.tok_emit_b[i], mn = u.tok_emit_n[i];
-        for (int l = mb; l < mb + mn; l++) {
-          const int dst = u.link_dst[l];
-          if (dst < 0) continue;
-          if (LinkExtra(u, tc, l, dst) > lb) { u.link_dst[l] = -1; flags |= 2; }
-        }
-      }
-      if (fabsf(LoadExtra(&u.tok_extra[i]) - u.tmp_f0[i - b]) > delta) flags |= 1;  // :334
-    }
-    all |= BlockOr(flags, sh);
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
+    if (ne == nb) break;  // no epsilon links: one sweep is exact
+    if (!BlockAny(changed, sh)) break;
   }
+  if (ne > nb) flags |= PruneLinkPass<false, true>(u, nb, ne, b, lb, u.tmp_acc1);
+  if (changed_by_delta) flags |= 1;
+  const int all = BlockOr(flags, sh);
   *extra_costs_changed = (all & 1) != 0;
   *links_pruned = (all & 2) != 0;
 }
@@ -820,20 +951,28 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     // pass (all frames visited by earlier passes were cleared), so once a frame
     // has nothing to do the reference's remaining iterations are no-ops.
     if (!ml && !mt) break;
+    long long t0 = 0;
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (ml) {
       bool ec, lp;
-      PruneForwardLinks(u, p, u.frame_b[f], u.frame_e[f], delta, false, false, 0.f, &ec, &lp, sh);
+      PruneForwardLinks(u, p, u.frame_b[f], u.frame_e[f], u.femit_b[f], u.femit_e[f], u.feps_b[f], u.feps_e[f],
+                        delta, false, false, 0.f, mt ? u.frame_b[f + 1] : 0, mt ? u.frame_e[f + 1] : 0, &ec, &lp, sh);
       if (threadIdx.x == 0) {
         if (ec && f > 0) StoreFlag(&u.must_links[f - 1], 1);
         if (lp) StoreFlag(&u.must_toks[f], 1);
         StoreFlag(&u.must_links[f], 0);
+        if (mt) StoreFlag(&u.must_toks[f + 1], 0);
       }
-    }
-    if (mt) {
+    } else {  // mt
       PruneTokensForFrame(u, u.frame_b[f + 1], u.frame_e[f + 1]);
       if (threadIdx.x == 0) StoreFlag(&u.must_toks[f + 1], 0);
     }
     KhSync();
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+      const int thick = (u.frame_e[f] - u.frame_b[f] > NT) ? 1 : 0;
+      sh->phase[16 + thick] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - t0;
+      sh->phase[18 + thick] += 1;
+    }
   }
   KhSync();
 }
@@ -936,11 +1075,11 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
       // flat move of the block's slots
       for (int base = blk_b; base < blk_e; base += NT) {
         const int l = base + threadIdx.x;
-        int dst = -1, il = 0, ol = 0;
+        int dst = -1, src = 0, il = 0, ol = 0;
         float g = 0.f, a = 0.f;
         if (l < blk_e) {
           dst = u.link_dst[l];
-          if (dst >= 0) { il = u.link_il[l]; ol = u.link_ol[l]; g = u.link_g[l]; a = u.link_a[l]; }
+          if (dst >= 0) { src = u.link_src[l]; il = u.link_il[l]; ol = u.link_ol[l]; g = u.link_g[l]; a = u.link_a[l]; }
         }
         const int alive = dst >= 0 ? 1 : 0;
         int total;
@@ -949,6 +1088,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
         if (alive) {
           const int d = dbase + off;
           u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
+          u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
           u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
         }
         KhSync();
@@ -1059,11 +1199,11 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
     const float final_best_cost = have_final ? best_with_final : best_cost;
     st.final_best_cost = final_best_cost;
     bool b1, b2;
-    PruneForwardLinks(u, p, fb, fe, 0.0f, true, have_final, final_best_cost, &b1, &b2, sh);
-    for (int f = last - 1; f >= 0; f--) {
-      PruneForwardLinks(u, p, u.frame_b[f], u.frame_e[f], 0.0f, false, false, 0.f, &b1, &b2, sh);
-      PruneTokensForFrame(u, u.frame_b[f + 1], u.frame_e[f + 1]);
-    }
+    PruneForwardLinks(u, p, fb, fe, 0, 0, u.feps_b[last], u.feps_e[last], 0.0f, true, have_final, final_best_cost,
+                      0, 0, &b1, &b2, sh);
+    for (int f = last - 1; f >= 0; f--)
+      PruneForwardLinks(u, p, u.frame_b[f], u.frame_e[f], u.femit_b[f], u.femit_e[f], u.feps_b[f], u.feps_e[f],
+                        0.0f, false, false, 0.f, u.frame_b[f + 1], u.frame_e[f + 1], &b1, &b2, sh);
     PruneTokensForFrame(u, u.frame_b[0], u.frame_e[0]);
     // final compaction of the window so the export below copies little
     ok = Compact(u, last - win_frames, last, sh);
@@ -1216,9 +1356,9 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
   sh.k_red = 0;
   sh.k_scan = 0;
   Utt u = slots[blockIdx.x];
-  u.phase_cycles = phase_cycles ? phase_cycles + 16 * blockIdx.x : (GP(long long))nullptr;
+  u.phase_cycles = phase_cycles ? phase_cycles + NPH * blockIdx.x : (GP(long long))nullptr;
   if (threadIdx.x == 0) {
-    for (int i = 0; i < 16; i++) sh->phase[i] = 0;
+    for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
     sh->t_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->tok_hw = 0;
     for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
@@ -1252,7 +1392,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     Stamp(u, sh, 9);
   }
   if (threadIdx.x == 0 && u.phase_cycles != nullptr)
-    for (int i = 0; i < 16; i++) u.phase_cycles[i] = sh->phase[i];
+    for (int i = 0; i < NPH; i++) u.phase_cycles[i] = sh->phase[i];
 }
 
 
@@ -1355,6 +1495,7 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tok_emit_n = c.Take<int32_t>(nt);
   u.tmp_remap = c.Take<int32_t>(nt);
   u.link_dst = c.Take<int32_t>(nl);
+  u.link_src = c.Take<int32_t>(nl);
   u.link_il = c.Take<int32_t>(nl);
   u.link_ol = c.Take<int32_t>(nl);
   u.link_g = c.Take<float>(nl);
@@ -1372,7 +1513,8 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tmp_slot = c.Take<int32_t>(tok_frame_cap);
   u.tmp_dirty = c.Take<int32_t>(tok_frame_cap);
   u.tmp_f0 = c.Take<float>(tok_frame_cap);
-  u.tmp_f1 = c.Take<float>(tok_frame_cap);
+  u.tmp_acc0 = c.Take<uint32_t>(tok_frame_cap);
+  u.tmp_acc1 = c.Take<uint32_t>(tok_frame_cap);
   size_t hs = 1;
   while (hs < static_cast<size_t>(hash_ratio * tok_frame_cap)) hs <<= 1;
   u.hash_mask = static_cast<uint32_t>(hs - 1);
@@ -1744,7 +1886,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     d->d_used = static_cast<unsigned long long *>(PoolMalloc(sizeof(unsigned long long) * 4));
     if (!d->d_in || !d->d_out || !d->d_used) return KH_ENOMEM;
     if (getenv("KH_DECODER_PROFILE")) {
-      d->d_phase = static_cast<long long *>(PoolMalloc(sizeof(long long) * 16 * d->max_slots));
+      d->d_phase = static_cast<long long *>(PoolMalloc(sizeof(long long) * NPH * d->max_slots));
       if (!d->d_phase) return KH_ENOMEM;
     }
   }
@@ -1761,6 +1903,8 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   p.final_cost = (GP(const float))d->fst->final_cost;
   p.start = d->fst->start;
   p.num_states = d->fst->num_states;
+  p.num_emit = static_cast<int32_t>(d->fst->num_emit);
+  p.num_eps = static_cast<int32_t>(d->fst->num_eps);
   p.tid2pdf = (GP(const int32_t))tid2pdf;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
@@ -1848,13 +1992,22 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     KH_HIP(hipMemcpyAsync(used, d->d_used, sizeof(used), hipMemcpyDeviceToHost, st));
     std::vector<long long> h_phase;
     if (d->d_phase) {
-      h_phase.resize(16 * static_cast<size_t>(grid));
-      KH_HIP(hipMemcpyAsync(h_phase.data(), d->d_phase, sizeof(long long) * 16 * grid, hipMemcpyDeviceToHost, st));
+      h_phase.resize(NPH * static_cast<size_t>(grid));
+      KH_HIP(hipMemcpyAsync(h_phase.data(), d->d_phase, sizeof(long long) * NPH * grid, hipMemcpyDeviceToHost, st));
     }
     KH_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     KH_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
     d->last_kernel_ms += ms;
+#ifdef KH_BOUNDS_CHECK
+    {
+      int h[8];
+      KH_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_oob), sizeof(h)));
+      fprintf(stderr, "[kh bounds check] violations=%d first: code=%d v=%d lo=%d hi=%d thread=%d\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+      int z[8] = {0};
+      KH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_oob), z, sizeof(z)));
+    }
+#endif
 #ifdef KH_BARRIER_CHECK
     {
       int h[4];
@@ -1867,10 +2020,13 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     if (d->d_phase) {
       static const char *names[16] = {"cutoff", "emit_pass1", "emit_pass2", "eps_closure", "eps_links", "clear_hash",
                                       "prune", "compact", "finalize", "export", "", "", "", "", "", "other"};
-      long long tot[16] = {0};
+      long long tot[NPH] = {0};
       long long all = 0;
       for (int i = 0; i < grid; i++)
-        for (int k = 0; k < 16; k++) { tot[k] += h_phase[16 * i + k]; all += h_phase[16 * i + k]; }
+        for (int k = 0; k < NPH; k++) {
+          tot[k] += h_phase[NPH * i + k];
+          if (k < 16) all += h_phase[NPH * i + k];
+        }
       fprintf(stderr, "[kh_decoder profile] launch %d: %d utterances, kernel %.1f ms, %d slots; share of shader cycles:",
               round, np, ms, grid);
       all -= tot[10] + tot[11] + tot[12] + tot[13] + tot[14];
@@ -1880,6 +2036,10 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
               "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
               tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
               tot[10] ? double(tot[14]) / tot[10] : 0.0, tot[13]);
+      fprintf(stderr, "[kh_decoder profile] prune by frame size: <=1024 tokens: %lld visits, %.1f%% of prune cycles (%.0f cycles each); "
+              "larger: %lld visits, %.1f%% (%.0f cycles each)\n",
+              tot[18], tot[6] ? 100.0 * tot[16] / tot[6] : 0.0, tot[18] ? double(tot[16]) / tot[18] : 0.0,
+              tot[19], tot[6] ? 100.0 * tot[17] / tot[6] : 0.0, tot[19] ? double(tot[17]) / tot[19] : 0.0);
     }
     std::vector<int> next;
     need_tok = need_link = 0;
