@@ -54,6 +54,7 @@ struct KhFst {
   int4 *n_arcs = nullptr;    // {0, olabel, weight bits, nextstate}
   float *final_cost = nullptr;
   std::vector<float> final_host;  // host copy for lattice export
+  int start_has_eps = 0;
   int32_t max_ilabel = 0;
 };
 
@@ -65,6 +66,9 @@ namespace {
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
 constexpr int NPH = 24;            // diagnostic counters per slot
+// Arc records carry, in bit 30 of the next state, whether that state has epsilon
+// arcs: a token knows it at creation without touching the graph again.
+constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x3fffffff;
 constexpr int PU = 1;              // token / link slots a lane keeps in flight per round of a sweep (measured: 1 beats 2, 4, 8 - the sweeps are bound by the CU's address pipeline, not by latency, and more slots spill)
 constexpr uint32_t kEncInf = 0xFF800000u;  // Enc(+inf)
 constexpr unsigned long long kEmpty = 0ull;
@@ -140,7 +144,8 @@ struct Utt {
   GP(uint8_t) must_toks;    // [T+2] must_prune_tokens
   // temporaries
   GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
-  GP(int32_t) tmp_dirty;    // [tok_frame_cap] nonemitting worklist flags; all zero outside ProcessNonemitting
+  GP(int32_t) tmp_dirty;    // [tok_frame_cap] 1 = queued in a nonemitting work list; all zero outside ProcessNonemitting
+  GP(int32_t) tmp_work0; GP(int32_t) tmp_work1;  // [tok_frame_cap] nonemitting work lists (token indices), double buffered
   GP(float) tmp_f0;         // [tok_frame_cap] prune: extra_cost on entry (i - frame begin)
   GP(uint32_t) tmp_acc0; GP(uint32_t) tmp_acc1;  // [tok_frame_cap] prune: Enc(min link_extra_cost) over emitting / epsilon links
   GP(int32_t) tmp_remap;    // [window_cap] compaction remap (i - window begin)
@@ -155,7 +160,7 @@ struct Params {
   GP(const int32_t) e_off; GP(const int32_t) n_off;
   GP(const KhInt4) e_arcs; GP(const KhInt4) n_arcs;
   GP(const float) final_cost;
-  int32_t start, num_states, num_emit, num_eps;
+  int32_t start, num_states, num_emit, num_eps, start_has_eps;
   GP(const int32_t) tid2pdf;
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
@@ -200,6 +205,7 @@ __device__ __forceinline__ void KhSync() {
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
   int wsumk[2][PU][NW];            // BlockExScanK, double buffered
+  int wl_n[3];                     // nonemitting work-list lengths, rotating
   unsigned long long wred[2][NW];  // block reductions, double buffered
   int orbuf[4];                    // BlockOr / BlockAny, 4 rotating slots
   unsigned long long wmin[NW];
@@ -389,7 +395,7 @@ __device__ __forceinline__ uint32_t HashState(int32_t s) {
 // `state` in the frame under construction, creating it if needed (cost slot is
 // pre-filled with +inf: arena invariant), or -1 if the raw arena is full.
 // Entry: low 32 bits = state + 1 (0 = empty), high 32 bits = token + 1 (0 = pending).
-__device__ int FindOrAdd(const Utt &u, int32_t state, __attribute__((address_space(3))) int *tok_end /*LDS counter*/,
+__device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute__((address_space(3))) int *tok_end /*LDS counter*/,
                          int tok_limit, int front_b) {
   uint32_t slot = HashState(state) & u.hash_mask;
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
@@ -409,7 +415,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, __attribute__((address_spa
         }
         u.tok_state[idx] = state;
         u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
-        u.tok_eps_n[idx] = 0;
+        u.tok_eps_n[idx] = has_eps ? -1 : 0;  // -1: epsilon arcs not expanded yet
         u.tok_emit_n[idx] = 0;
         u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot);
         __hip_atomic_exchange(&u.hash[slot], want_key | (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32),
@@ -451,6 +457,7 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
 // (link_src = token, link_dst = arc index) for the link-parallel second half.
 // tok_b / tok_n receive the token's slot range.  Returns the new end of the link
 // arena, or -1 on overflow (sh->status set).
+template <bool kEps>
 __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, float cutoff, int lrun,
                             int frame_cap, GP(int32_t) tok_b, GP(int32_t) tok_n, long long *arcs, Blk &sh) {
   const int lrun0 = lrun;
@@ -468,11 +475,15 @@ __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, f
     int ab[PU], cnt[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
-      ab[k] = off[st[k]];
-      cnt[k] = off[st[k] + 1];
+      bool need = i[k] < e && Dec(co[k]) <= cutoff;
+      if (kEps) need = need && tok_n[min(i[k], e - 1)] != 0;  // FindOrAdd left -1 iff the state has epsilon arcs
+      ab[k] = 0;
+      cnt[k] = 0;
+      if (need) {
+        ab[k] = off[st[k]];
+        cnt[k] = off[st[k] + 1] - ab[k];
+      }
     }
-#pragma unroll
-    for (int k = 0; k < PU; k++) cnt[k] = (i[k] < e && Dec(co[k]) <= cutoff) ? cnt[k] - ab[k] : 0;
     int loff[PU], total;
     BlockExScanK(cnt, loff, &total, sh);
     if (lrun + total > u.link_cap || lrun + total - lrun0 > frame_cap) {
@@ -573,17 +584,22 @@ __device__ __forceinline__ float LogLike(const Utt &u, const Params &p, int fram
 __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, float cutoff, Blk &sh) {
   const int fb = sh->front_b;
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
-  // ---- cost fixed point: min-plus closure under the cutoff
-  bool first = true;
+  // ---- cost fixed point: min-plus closure under the cutoff, driven by work lists.
+  // List 0 (length wl_n[0]) holds the tokens with epsilon arcs that the emitting
+  // pass created; processing a token may lower the cost of others, which are
+  // queued (once: tmp_dirty) for the next round.
   long long my_arcs = 0;
-  for (;;) {
-    const int fe = sh->tok_end;  // tokens existing at the start of the round
-    KhSync();
-    bool any = false;
-    for (int i = fb + threadIdx.x; i < fe; i += NT) {
-      int dirty = 1;
-      if (!first) dirty = __hip_atomic_exchange(&u.tmp_dirty[i - fb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!dirty) continue;
+  for (int r = 0;; r++) {
+    const int n = sh->wl_n[r % 3];
+    if (threadIdx.x == 0) sh->wl_n[(r + 2) % 3] = 0;  // last read one barrier ago, next pushed to one barrier ahead
+    if (n == 0) break;
+    GP(const int32_t) cur = (r & 1) ? u.tmp_work1 : u.tmp_work0;
+    GP(int32_t) nxt = (r & 1) ? u.tmp_work0 : u.tmp_work1;
+    auto nxt_n = &sh->wl_n[(r + 1) % 3];
+    for (int q = threadIdx.x; q < n; q += NT) {
+      const int i = cur[q];
+      // leave the queue BEFORE reading the cost: a later improvement queues the token again
+      (void)__hip_atomic_exchange(&u.tmp_dirty[i - fb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
       if (cur_cost > cutoff) continue;  // :779
       const int32_t s = u.tok_state[i];
@@ -593,23 +609,26 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         my_arcs++;
         const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
         if (tot_cost < cutoff) {  // :794
-          const int dst = FindOrAdd(u, arc.w, &sh->tok_end, tok_limit, fb);
+          const bool he = (arc.w & kHasEps) != 0;
+          const int dst = FindOrAdd(u, arc.w & kStateMask, he, &sh->tok_end, tok_limit, fb);
           if (dst < 0) { sh->status = 1; continue; }
           const uint32_t enc = Enc(tot_cost);
-          const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (enc < old) {  // "changed": new or cheaper -> (re)process dst
-            __hip_atomic_exchange(&u.tmp_dirty[dst - fb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            any = true;
+          if (he) {
+            const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (enc < old &&  // "changed": new or cheaper -> (re)process dst
+                __hip_atomic_exchange(&u.tmp_dirty[dst - fb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+              nxt[__hip_atomic_fetch_add(nxt_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = dst;
+          } else {
+            (void)__hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
     }
-    first = false;
     if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
-    const bool more = BlockAny(any, sh);
+    KhSync();
     if (sh->status != 0) return false;
-    if (!more) break;
   }
+  KhSync();
   Stamp(u, sh, 3);
   // ---- epsilon links: {(tok, arc): cost[tok] <= cutoff, cost[tok] + w < cutoff}
   // One slot per epsilon arc of every token under the cutoff; the slots whose
@@ -617,7 +636,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   const int fe = sh->tok_end;
   const int blk_b = sh->link_end;
   long long seeded = 0;
-  const int blk_e = ExpandTokens(u, p.n_off, fb, fe, cutoff, blk_b, u.link_frame_cap, u.tok_eps_b, u.tok_eps_n, &seeded, sh);
+  const int blk_e = ExpandTokens<true>(u, p.n_off, fb, fe, cutoff, blk_b, u.link_frame_cap, u.tok_eps_b, u.tok_eps_n, &seeded, sh);
   if (blk_e < 0) return false;
   for (int base = blk_b + threadIdx.x; base < blk_e; base += NT * PU) {
     int l[PU], src[PU], ai[PU];
@@ -646,13 +665,13 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     for (int k = 0; k < PU; k++) {
       const float tot_cost = Dec(co[k]) + __int_as_float(arc[k].z);
       live[k] = base + k * NT < blk_e && tot_cost < cutoff;
-      slot[k] = HashState(arc[k].w) & u.hash_mask;
+      slot[k] = HashState(arc[k].w & kStateMask) & u.hash_mask;
       ent[k] = __hip_atomic_load(&u.hash[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       if (base + k * NT >= blk_e) continue;
-      u.link_dst[l[k]] = live[k] ? FindExisting(u, arc[k].w, ent[k], slot[k]) : -1;  // the token exists already
+      u.link_dst[l[k]] = live[k] ? FindExisting(u, arc[k].w & kStateMask, ent[k], slot[k]) : -1;  // the token exists already
       u.link_il[l[k]] = 0;
       u.link_ol[l[k]] = arc[k].y;
       u.link_g[l[k]] = __int_as_float(arc[k].z);
@@ -685,6 +704,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
                                 float *next_cutoff_out, Blk &sh) {
   const int nb = sh->tok_end;  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }  // pass 2 fills list 0 (barriers in between)
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff(u, p, b, e, sh);
   Stamp(u, sh, 0);
@@ -714,7 +734,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // min(tot_cost + adaptive_beam).
   const int link_frame_b = sh->link_end;
   long long my_arcs = 0;
-  const int link_frame_e = ExpandTokens(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, u.tok_emit_b,
+  const int link_frame_e = ExpandTokens<false>(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, u.tok_emit_b,
                                         u.tok_emit_n, &my_arcs, sh);
   if (link_frame_e < 0) return false;
   for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * PU) {
@@ -772,9 +792,20 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     const float tot_cost = u.link_tot[l - link_frame_b];
     int dst = -1;
     if (!(tot_cost > next_cutoff)) {  // :731 "if (tot_cost > next_cutoff) continue"
-      dst = FindOrAdd(u, u.link_dst[l], &sh->tok_end, tok_limit, nb);
-      if (dst < 0) sh->status = 1;
-      else __hip_atomic_fetch_min(&u.tok_cost[dst], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t ns = u.link_dst[l];
+      const bool he = (ns & kHasEps) != 0;
+      dst = FindOrAdd(u, ns & kStateMask, he, &sh->tok_end, tok_limit, nb);
+      if (dst < 0) {
+        sh->status = 1;
+      } else if (he) {
+        // queue the token for the nonemitting closure the first time its cost drops
+        const uint32_t enc = Enc(tot_cost);
+        const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (enc < old && __hip_atomic_exchange(&u.tmp_dirty[dst - nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+          u.tmp_work0[__hip_atomic_fetch_add(&sh->wl_n[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = dst;
+      } else {
+        (void)__hip_atomic_fetch_min(&u.tok_cost[dst], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     u.link_dst[l] = dst;
   }
@@ -1128,9 +1159,16 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
 
   // ---- InitDecoding :55-72
   if (threadIdx.x == 0) {
-    const int idx = FindOrAdd(u, p.start, &sh->tok_end, u.tok_cap, 0);
+    const int idx = FindOrAdd(u, p.start, p.start_has_eps != 0, &sh->tok_end, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
     u.frame_b[0] = idx;
+    sh->wl_n[0] = 0;
+    sh->wl_n[1] = 0;
+    if (p.start_has_eps) {
+      u.tmp_dirty[0] = 1;
+      u.tmp_work0[0] = idx;
+      sh->wl_n[0] = 1;
+    }
   }
   KhSync();
   bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
@@ -1512,6 +1550,8 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.must_toks = c.Take<uint8_t>(T + 2);
   u.tmp_slot = c.Take<int32_t>(tok_frame_cap);
   u.tmp_dirty = c.Take<int32_t>(tok_frame_cap);
+  u.tmp_work0 = c.Take<int32_t>(tok_frame_cap);
+  u.tmp_work1 = c.Take<int32_t>(tok_frame_cap);
   u.tmp_f0 = c.Take<float>(tok_frame_cap);
   u.tmp_acc0 = c.Take<uint32_t>(tok_frame_cap);
   u.tmp_acc1 = c.Take<uint32_t>(tok_frame_cap);
@@ -1679,6 +1719,14 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
     SetError("kh_fst_create: %lld arcs exceed int32 indexing", static_cast<long long>(na));
     return nullptr;
   }
+  if (num_states > kStateMask) {
+    SetError("kh_fst_create: %d states exceed the 30-bit state ids of the arc records", num_states);
+    return nullptr;
+  }
+  std::vector<uint8_t> has_eps(num_states, 0);
+  for (int32_t s = 0; s < num_states; s++)
+    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
+      if (ilabel[a] == 0) { has_eps[s] = 1; break; }
   std::vector<int32_t> e_off(num_states + 1), n_off(num_states + 1);
   std::vector<int4> e_arcs, n_arcs;
   e_arcs.reserve(na);
@@ -1693,11 +1741,12 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
       }
       int wbits;
       memcpy(&wbits, &weight[a], 4);
+      const int32_t ns = nextstate[a] | (has_eps[nextstate[a]] ? kHasEps : 0);
       if (ilabel[a] != 0) {
-        e_arcs.push_back(make_int4(ilabel[a], olabel[a], wbits, nextstate[a]));
+        e_arcs.push_back(make_int4(ilabel[a], olabel[a], wbits, ns));
         max_il = std::max(max_il, ilabel[a]);
       } else {
-        n_arcs.push_back(make_int4(0, olabel[a], wbits, nextstate[a]));
+        n_arcs.push_back(make_int4(0, olabel[a], wbits, ns));
       }
     }
   }
@@ -1711,6 +1760,7 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
   f->num_eps = static_cast<int64_t>(n_arcs.size());
   f->max_ilabel = max_il;
   f->final_host.assign(final_cost, final_cost + num_states);
+  f->start_has_eps = has_eps[start];
   auto up = [&](void **dst, const void *src, size_t bytes) -> bool {
     *dst = PoolMalloc(bytes ? bytes : 16);
     if (!*dst) return false;
@@ -1905,6 +1955,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   p.num_states = d->fst->num_states;
   p.num_emit = static_cast<int32_t>(d->fst->num_emit);
   p.num_eps = static_cast<int32_t>(d->fst->num_eps);
+  p.start_has_eps = d->fst->start_has_eps;
   p.tid2pdf = (GP(const int32_t))tid2pdf;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
