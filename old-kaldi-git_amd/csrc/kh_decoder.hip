@@ -128,7 +128,6 @@ struct Utt {
   GP(int32_t) tok_state;    // HCLG state, -1 = pruned token
   GP(uint32_t) tok_cost;    // Enc(tot_cost); free slots hold Enc(+inf)
   GP(float) tok_extra;
-  GP(int32_t) tok_eps_b; GP(int32_t) tok_eps_n; GP(int32_t) tok_emit_b; GP(int32_t) tok_emit_n;
   // link arena
   int32_t link_cap;
   GP(int32_t) link_dst; GP(int32_t) link_il; GP(int32_t) link_ol;   // dst: token index, -1 = excised
@@ -143,7 +142,7 @@ struct Utt {
   GP(uint8_t) must_links;   // [T+2] must_prune_forward_links
   GP(uint8_t) must_toks;    // [T+2] must_prune_tokens
   // temporaries
-  GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
+  GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin); sign bit: its state has epsilon arcs
   GP(int32_t) tmp_dirty;    // [tok_frame_cap] 1 = queued in a nonemitting work list; all zero outside ProcessNonemitting
   GP(int32_t) tmp_work0; GP(int32_t) tmp_work1;  // [tok_frame_cap] nonemitting work lists (token indices), double buffered
   GP(float) tmp_f0;         // [tok_frame_cap] prune: extra_cost on entry (i - frame begin)
@@ -415,9 +414,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute_
         }
         u.tok_state[idx] = state;
         u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
-        u.tok_eps_n[idx] = has_eps ? -1 : 0;  // -1: epsilon arcs not expanded yet
-        u.tok_emit_n[idx] = 0;
-        u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot);
+        u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot | (has_eps ? 0x80000000u : 0u));
         __hip_atomic_exchange(&u.hash[slot], want_key | (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32),
                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return idx;
@@ -455,11 +452,10 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
 // is <= cutoff gets one link slot per arc of its HCLG state (arc ranges `off`),
 // appended at link slot `lrun` on in token order; the slots are seeded with
 // (link_src = token, link_dst = arc index) for the link-parallel second half.
-// tok_b / tok_n receive the token's slot range.  Returns the new end of the link
-// arena, or -1 on overflow (sh->status set).
+// Returns the new end of the link arena, or -1 on overflow (sh->status set).
 template <bool kEps>
 __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, float cutoff, int lrun,
-                            int frame_cap, GP(int32_t) tok_b, GP(int32_t) tok_n, long long *arcs, Blk &sh) {
+                            int frame_cap, long long *arcs, Blk &sh) {
   const int lrun0 = lrun;
   for (int base = b; base < e; base += NT * PU) {
     int i[PU], st[PU];
@@ -476,7 +472,7 @@ __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, f
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       bool need = i[k] < e && Dec(co[k]) <= cutoff;
-      if (kEps) need = need && tok_n[min(i[k], e - 1)] != 0;  // FindOrAdd left -1 iff the state has epsilon arcs
+      if (kEps) need = need && u.tmp_slot[min(i[k], e - 1) - b] < 0;  // sign bit: the state has epsilon arcs
       ab[k] = 0;
       cnt[k] = 0;
       if (need) {
@@ -496,8 +492,6 @@ __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, f
       if (i[k] >= e) continue;
       int l0 = lrun + loff[k];
       KH_BOUND(2, l0, 0, u.link_cap - cnt[k] + 1);
-      tok_b[i[k]] = l0;
-      tok_n[i[k]] = cnt[k];
       for (int j = 0; j < cnt[k]; j++) {
         u.link_src[l0 + j] = i[k];
         u.link_dst[l0 + j] = ab[k] + j;
@@ -636,7 +630,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   const int fe = sh->tok_end;
   const int blk_b = sh->link_end;
   long long seeded = 0;
-  const int blk_e = ExpandTokens<true>(u, p.n_off, fb, fe, cutoff, blk_b, u.link_frame_cap, u.tok_eps_b, u.tok_eps_n, &seeded, sh);
+  const int blk_e = ExpandTokens<true>(u, p.n_off, fb, fe, cutoff, blk_b, u.link_frame_cap, &seeded, sh);
   if (blk_e < 0) return false;
   for (int base = blk_b + threadIdx.x; base < blk_e; base += NT * PU) {
     int l[PU], src[PU], ai[PU];
@@ -693,7 +687,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
 
 // Clears the hash entries of the frontier tokens [fb, fe) (inserted this frame).
 __device__ void ClearHash(const Utt &u, int fb, int fe) {
-  for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb]] = kEmpty;
+  for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb] & 0x7fffffff] = kEmpty;
   KhSync();
 }
 
@@ -734,8 +728,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // min(tot_cost + adaptive_beam).
   const int link_frame_b = sh->link_end;
   long long my_arcs = 0;
-  const int link_frame_e = ExpandTokens<false>(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, u.tok_emit_b,
-                                        u.tok_emit_n, &my_arcs, sh);
+  const int link_frame_e = ExpandTokens<false>(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh);
   if (link_frame_e < 0) return false;
   for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * PU) {
     int l[PU], src[PU], ai[PU];
@@ -1011,58 +1004,51 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
 // In-place sliding compaction of the window [w_lo, cur]: survivors of the token
 // arena tail and of the link arena tail move down, token indices stored in links
 // are rewritten through tmp_remap (frame w_lo - 1 keeps its place but its emitting
-// links point into the window, so their dst fields are rewritten too).
+// links point into the window, so their dst fields are rewritten too).  A chunk's
+// slots are all read before the barrier of its scan and written at or below their
+// old position after it, so one barrier per chunk orders the slide.
 __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   if (w_lo < 0) w_lo = 0;
   const int win_b = u.frame_b[w_lo];
   const int old_tok_end = sh->tok_end;
+  const int old_link_b = u.feps_b[w_lo];
   if (old_tok_end - win_b > u.window_cap) {
     if (threadIdx.x == 0) sh->status = 4;
     KhSync();
     return false;
   }
+  KhSync();  // every thread has read the old ends
   // (a) tokens
-  KhSync();  // every thread has read old_tok_end
-  if (threadIdx.x == 0) sh->tok_end = win_b;
-  KhSync();
+  int tend = win_b;  // running end of the compacted tokens (uniform)
   for (int f = w_lo; f <= cur; f++) {
     const int b = u.frame_b[f], e = u.frame_e[f];
-    const int new_b = sh->tok_end;
+    const int new_b = tend;
     for (int base = b; base < e; base += NT) {
       const int i = base + threadIdx.x;
-      int st = -1, eb = 0, en = 0, mb = 0, mn = 0;
+      int st = -1;
       uint32_t co = kEncInf;
       float ex = 0.f;
-      if (i < e) {
-        st = u.tok_state[i]; co = LoadCostEnc(&u.tok_cost[i]); ex = LoadExtra(&u.tok_extra[i]);
-        eb = u.tok_eps_b[i]; en = u.tok_eps_n[i]; mb = u.tok_emit_b[i]; mn = u.tok_emit_n[i];
-      }
+      if (i < e) { st = u.tok_state[i]; co = LoadCostEnc(&u.tok_cost[i]); ex = LoadExtra(&u.tok_extra[i]); }
       const int alive = st >= 0 ? 1 : 0;
       int total;
-      const int off = BlockExScan(alive, &total, sh);  // barriers: all reads of the chunk are done
-      const int dbase = sh->tok_end;
+      const int off = BlockExScan(alive, &total, sh);
       if (i < e) {
         int ni = -1;
         if (alive) {
-          ni = dbase + off;
+          ni = tend + off;
           u.tok_state[ni] = st; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
-          u.tok_eps_b[ni] = eb; u.tok_eps_n[ni] = en; u.tok_emit_b[ni] = mb; u.tok_emit_n[ni] = mn;
         }
         u.tmp_remap[i - win_b] = ni;
       }
-      KhSync();
-      if (threadIdx.x == 0) sh->tok_end = dbase + total;
-      KhSync();
+      tend += total;
     }
-    if (threadIdx.x == 0) {
-      u.frame_b[f] = new_b;
-      u.frame_e[f] = sh->tok_end;
-    }
-    KhSync();
+    // (an empty frame has no barrier above: a lane that reads these after the update
+    // sees another empty range)
+    if (threadIdx.x == 0) { u.frame_b[f] = new_b; u.frame_e[f] = tend; }
   }
-  const int new_tok_end = sh->tok_end;
+  KhSync();
   // arena invariant: free slots hold +inf
-  for (int i = new_tok_end + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
+  for (int i = tend + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
   // (b) emitting links of frame w_lo - 1 point into the window: rewrite in place
   if (w_lo > 0) {
     for (int l = u.femit_b[w_lo - 1] + threadIdx.x; l < u.femit_e[w_lo - 1]; l += NT) {
@@ -1070,40 +1056,14 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
       if (dst >= win_b) u.link_dst[l] = u.tmp_remap[dst - win_b];
     }
   }
-  KhSync();
   // (c) links, block by block in arena order: eps(f), emit(f)
-  if (threadIdx.x == 0) sh->link_end = u.feps_b[w_lo];
-  KhSync();
+  int lend = old_link_b;  // running end of the compacted links (uniform)
   for (int f = w_lo; f <= cur; f++) {
     for (int kind = 0; kind < 2; kind++) {  // 0: epsilon, 1: emitting
       if (kind == 1 && f == cur) continue;  // not created yet
       const int blk_b = kind ? u.femit_b[f] : u.feps_b[f];
       const int blk_e = kind ? u.femit_e[f] : u.feps_e[f];
-      const int new_blk_b = sh->link_end;
-      // per-token new link ranges (tokens already sit at their new index)
-      {
-        const int b = u.frame_b[f], e = u.frame_e[f];
-        int running = new_blk_b;
-        for (int base = b; base < e; base += NT) {
-          const int i = base + threadIdx.x;
-          int cnt = 0;
-          if (i < e) {
-            const int lbeg = kind ? u.tok_emit_b[i] : u.tok_eps_b[i];
-            const int n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
-            for (int l = lbeg; l < lbeg + n; l++)
-              if (u.link_dst[l] >= 0) cnt++;
-          }
-          int total;
-          const int off = BlockExScan(cnt, &total, sh);
-          if (i < e) {
-            if (kind) { u.tok_emit_b[i] = running + off; u.tok_emit_n[i] = cnt; }
-            else { u.tok_eps_b[i] = running + off; u.tok_eps_n[i] = cnt; }
-          }
-          running += total;
-        }
-      }
-      KhSync();
-      // flat move of the block's slots
+      const int new_blk_b = lend;
       for (int base = blk_b; base < blk_e; base += NT) {
         const int l = base + threadIdx.x;
         int dst = -1, src = 0, il = 0, ol = 0;
@@ -1115,25 +1075,25 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
         const int alive = dst >= 0 ? 1 : 0;
         int total;
         const int off = BlockExScan(alive, &total, sh);
-        const int dbase = sh->link_end;
         if (alive) {
-          const int d = dbase + off;
+          const int d = lend + off;
           u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
           u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
           u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
         }
-        KhSync();
-        if (threadIdx.x == 0) sh->link_end = dbase + total;
-        KhSync();
+        lend += total;
       }
       if (threadIdx.x == 0) {
-        if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = sh->link_end; }
-        else { u.feps_b[f] = new_blk_b; u.feps_e[f] = sh->link_end; }
+        if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = lend; }
+        else { u.feps_b[f] = new_blk_b; u.feps_e[f] = lend; }
       }
-      KhSync();
     }
   }
-  if (threadIdx.x == 0) sh->front_b = u.frame_b[cur];
+  if (threadIdx.x == 0) {
+    sh->tok_end = tend;
+    sh->link_end = lend;
+    sh->front_b = u.frame_b[cur];
+  }
   KhSync();
   return true;
 }
@@ -1278,49 +1238,39 @@ struct Pool {
   GP(unsigned long long) used;                // [0] tokens, [1] links, [2] utterance queue head
 };
 
+// Frame of token i: the f with frame_b[f] <= i < frame_e[f] (frames are contiguous
+// and ordered; empty frames share their begin with the next one).
+__device__ __forceinline__ int FrameOfToken(const Utt &u, int i, int T) {
+  int lo = 0, hi = T;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (u.frame_b[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  while (lo < T && u.frame_e[lo] <= i) lo++;
+  return lo;
+}
+
 // GetRawLattice :109-191 device half: survivors -> pool (frame, state) / (src, dst, labels, costs).
 __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &sh) {
-  const int tok_end = sh->tok_end, T = u.T;
-  // pass A: alive tokens -> dense indices (tmp_remap), count
-  if (threadIdx.x == 0) sh->bcast_i[3] = 0;
-  KhSync();
+  const int tok_end = sh->tok_end, link_end = sh->link_end, T = u.T;
+  // pass A: alive tokens -> dense indices (tmp_remap)
+  int n_tok = 0;
   for (int base = 0; base < tok_end; base += NT) {
     const int i = base + threadIdx.x;
     const int alive = (i < tok_end && u.tok_state[i] >= 0) ? 1 : 0;
     int total;
     const int off = BlockExScan(alive, &total, sh);
-    const int run = sh->bcast_i[3];
-    if (i < tok_end) u.tmp_remap[i] = alive ? run + off : -1;
-    KhSync();
-    if (threadIdx.x == 0) sh->bcast_i[3] = run + total;
-    KhSync();
+    if (i < tok_end) u.tmp_remap[i] = alive ? n_tok + off : -1;
+    n_tok += total;
   }
-  const int n_tok = sh->bcast_i[3];
-  // pass B: count alive links per alive token -> link offsets (kept in tok_extra bits)
-  KhSync();
-  if (threadIdx.x == 0) sh->bcast_i[3] = 0;
-  KhSync();
-  for (int base = 0; base < tok_end; base += NT) {
-    const int i = base + threadIdx.x;
-    int cnt = 0;
-    if (i < tok_end && u.tok_state[i] >= 0) {
-      for (int kind = 0; kind < 2; kind++) {
-        const int lb = kind ? u.tok_emit_b[i] : u.tok_eps_b[i], n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
-        for (int l = lb; l < lb + n; l++)
-          if (u.link_dst[l] >= 0) cnt++;
-      }
-    }
-    int total;
-    const int off = BlockExScan(cnt, &total, sh);
-    const int run = sh->bcast_i[3];
-    if (i < tok_end) u.tok_extra[i] = __int_as_float(run + off);  // extra_cost is dead after finalisation
-    KhSync();
-    if (threadIdx.x == 0) sh->bcast_i[3] = run + total;
-    KhSync();
+  // pass B: alive links -> dense positions, kept in link_src's dead... count only
+  int n_link = 0;
+  {
+    int mine = 0;
+    for (int l = threadIdx.x; l < link_end; l += NT) mine += u.link_dst[l] >= 0 ? 1 : 0;
+    n_link = static_cast<int>(BlockSumLL(mine, sh));
   }
-  const int n_link = sh->bcast_i[3];
   // allocate in the pool
-  KhSync();
   if (threadIdx.x == 0) {
     const unsigned long long tb = __hip_atomic_fetch_add(&pool.used[0], static_cast<unsigned long long>(n_tok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long lb = __hip_atomic_fetch_add(&pool.used[1], static_cast<unsigned long long>(n_link), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1340,38 +1290,37 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &
   const bool fits = sh->flag != 0;
   KhSync();
   if (!fits) return;
-  // pass C: write
+  // pass C: tokens
   for (int i = threadIdx.x; i < tok_end; i += NT) {
     const int ni = u.tmp_remap[i];
     if (ni < 0) continue;
-    // frame of token i: largest f with frame_b[f] <= i (frames are contiguous and ordered)
-    int lo = 0, hi = T;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (u.frame_b[mid] <= i) lo = mid; else hi = mid - 1;
-    }
-    // skip empty frames that share the same begin
-    while (lo < T && u.frame_e[lo] <= i) lo++;
-    const int f = lo;
-    pool.t_frame[tb + ni] = f;
+    pool.t_frame[tb + ni] = FrameOfToken(u, i, T);
     pool.t_state[tb + ni] = u.tok_state[i];
-    long long d = lbase + __float_as_int(u.tok_extra[i]);
-    const float coff = f < T ? u.cost_offset[f] : 0.0f;
-    for (int kind = 1; kind >= 0; kind--) {
-      const int lb2 = kind ? u.tok_emit_b[i] : u.tok_eps_b[i], n = kind ? u.tok_emit_n[i] : u.tok_eps_n[i];
-      for (int l = lb2; l < lb2 + n; l++) {
-        const int dst = u.link_dst[l];
-        if (dst < 0) continue;
-        const int il = u.link_il[l];
-        pool.l_src[d] = ni;
-        pool.l_dst[d] = u.tmp_remap[dst];
-        pool.l_il[d] = il;
-        pool.l_ol[d] = u.link_ol[l];
-        pool.l_g[d] = u.link_g[l];
-        pool.l_a[d] = il != 0 ? u.link_a[l] - coff : u.link_a[l];  // :168-174
-        d++;
+  }
+  // pass D: links, in arena order
+  int lrun = 0;
+  for (int base = 0; base < link_end; base += NT) {
+    const int l = base + threadIdx.x;
+    const int dst = l < link_end ? u.link_dst[l] : -1;
+    const int alive = dst >= 0 ? 1 : 0;
+    int total;
+    const int off = BlockExScan(alive, &total, sh);
+    if (alive) {
+      const long long d = lbase + lrun + off;
+      const int src = u.link_src[l], il = u.link_il[l];
+      float a = u.link_a[l];
+      if (il != 0) {  // :168-174 the acoustic cost without the frame's cost_offset
+        const int f = FrameOfToken(u, src, T);
+        a -= f < T ? u.cost_offset[f] : 0.0f;
       }
+      pool.l_src[d] = u.tmp_remap[src];
+      pool.l_dst[d] = u.tmp_remap[dst];
+      pool.l_il[d] = il;
+      pool.l_ol[d] = u.link_ol[l];
+      pool.l_g[d] = u.link_g[l];
+      pool.l_a[d] = a;
     }
+    lrun += total;
   }
   KhSync();
 }
@@ -1527,10 +1476,6 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tok_state = c.Take<int32_t>(nt);
   u.tok_cost = c.Take<uint32_t>(nt);
   u.tok_extra = c.Take<float>(nt);
-  u.tok_eps_b = c.Take<int32_t>(nt);
-  u.tok_eps_n = c.Take<int32_t>(nt);
-  u.tok_emit_b = c.Take<int32_t>(nt);
-  u.tok_emit_n = c.Take<int32_t>(nt);
   u.tmp_remap = c.Take<int32_t>(nt);
   u.link_dst = c.Take<int32_t>(nl);
   u.link_src = c.Take<int32_t>(nl);
