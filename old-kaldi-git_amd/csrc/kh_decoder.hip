@@ -160,6 +160,7 @@ struct Params {
   GP(const KhInt4) e_arcs; GP(const KhInt4) n_arcs;
   GP(const float) final_cost;
   int32_t start, num_states, num_emit, num_eps, start_has_eps;
+  int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
   GP(const int32_t) tid2pdf;
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
@@ -204,7 +205,8 @@ __device__ __forceinline__ void KhSync() {
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
   int wsumk[2][PU][NW];            // BlockExScanK, double buffered
-  int wl_n[3];                     // nonemitting work-list lengths, rotating
+  int wl_n[3];                     // nonemitting work-list lengths, rotating ([0] also: prune's epsilon-token list)
+  int pr_moved;                    // PruneForwardLinks: tokens whose extra_cost moved by more than delta
   unsigned long long wred[2][NW];  // block reductions, double buffered
   int orbuf[4];                    // BlockOr / BlockAny, 4 rotating slots
   unsigned long long wmin[NW];
@@ -228,6 +230,7 @@ struct Shared {
 typedef __attribute__((address_space(3))) Shared LdsShared;
 struct Blk {
   LdsShared *p;
+  __attribute__((address_space(3))) float *ll_row;  // the frame's log-likelihood row staged in LDS (ll_cols > 0)
   int k_or, k_red, k_scan;
   __device__ __forceinline__ LdsShared *operator->() const { return p; }
 };
@@ -567,8 +570,9 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   return c;
 }
 
-__device__ __forceinline__ float LogLike(const Utt &u, const Params &p, int frame, int32_t tid) {
+__device__ __forceinline__ float LogLike(const Utt &u, const Params &p, const Blk &sh, int frame, int32_t tid) {
   const int32_t pdf = p.tid2pdf ? p.tid2pdf[tid] : tid - 1;
+  if (p.ll_cols > 0) return sh.ll_row[pdf];
   return u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
 }
 
@@ -665,11 +669,16 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       if (base + k * NT >= blk_e) continue;
-      u.link_dst[l[k]] = live[k] ? FindExisting(u, arc[k].w & kStateMask, ent[k], slot[k]) : -1;  // the token exists already
+      const int dst = live[k] ? FindExisting(u, arc[k].w & kStateMask, ent[k], slot[k]) : -1;  // the token exists already
+      const float g = __int_as_float(arc[k].z);
+      u.link_dst[l[k]] = dst;
       u.link_il[l[k]] = 0;
       u.link_ol[l[k]] = arc[k].y;
-      u.link_g[l[k]] = __int_as_float(arc[k].z);
-      u.link_a[l[k]] = 0.0f;
+      u.link_g[l[k]] = g;
+      // The acoustic cost of an epsilon link is 0; its field holds the constant part of
+      // link_extra_cost (:309-311) instead, (cost[src] + 0 + g) - cost[dst]: both costs
+      // are final once the closure has converged.
+      u.link_a[l[k]] = dst >= 0 ? (Dec(co[k]) + 0.0f + g) - Dec(LoadCostEnc(&u.tok_cost[dst])) : 0.0f;
     }
   }
   KhSync();
@@ -699,6 +708,9 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   const int nb = sh->tok_end;  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }  // pass 2 fills list 0 (barriers in between)
+  // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
+  // against the last readers of the previous row and the first readers of this one)
+  for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff(u, p, b, e, sh);
   Stamp(u, sh, 0);
@@ -715,7 +727,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     const int ab = p.e_off[s], ae = p.e_off[s + 1];
     for (int a = ab + threadIdx.x; a < ae; a += NT) {
       const KhInt4 arc = p.e_arcs[a];
-      const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, frame, arc.x));
+      const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
       const float new_weight = w + tot;
       est = fminf(est, new_weight + c.adaptive_beam);
     }
@@ -753,7 +765,8 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     for (int k = 0; k < PU; k++) { pdf[k] = p.tid2pdf ? p.tid2pdf[arc[k].x] : arc[k].x - 1; KH_BOUND(7, pdf[k], 0, u.ll_stride); }
     float like[PU];
 #pragma unroll
-    for (int k = 0; k < PU; k++) like[k] = u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf[k]];
+    for (int k = 0; k < PU; k++)
+      like[k] = p.ll_cols > 0 ? sh.ll_row[pdf[k]] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf[k]];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       if (base + k * NT >= link_frame_e) continue;
@@ -820,8 +833,9 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 // live link with the extra_costs currently stored; kExcise: links over the
 // lattice beam are excised (:315); kAccum: the others are min-ed into
 // acc[src - b].  Returns 2 if this lane excised a link.
-template <bool kAccum, bool kExcise>
-__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, GP(uint32_t) acc) {
+template <bool kEps, bool kAccum, bool kExcise, bool kList = false>
+__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, GP(uint32_t) acc,
+                                             __attribute__((address_space(3))) int *list_n = nullptr) {
   int flags = 0;
   for (int base = lo + threadIdx.x; base < hi; base += NT * PU) {
     int l[PU], dst[PU], src[PU];
@@ -832,23 +846,27 @@ __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b
       dst[k] = u.link_dst[l[k]];
       src[k] = u.link_src[l[k]];
       a[k] = u.link_a[l[k]];
-      g[k] = u.link_g[l[k]];
-      KH_BOUND(8, src[k], 0, u.tok_cap);
-      KH_BOUND(9, dst[k], -1, u.tok_cap);
+      g[k] = kEps ? 0.0f : u.link_g[l[k]];
     }
     uint32_t cs[PU], cd[PU];
     float ex[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       const int d = dst[k] >= 0 ? dst[k] : src[k];  // any valid token for an excised slot
-      cs[k] = LoadCostEnc(&u.tok_cost[src[k]]);
-      cd[k] = LoadCostEnc(&u.tok_cost[d]);
+      if (!kEps) {
+        cs[k] = LoadCostEnc(&u.tok_cost[src[k]]);
+        cd[k] = LoadCostEnc(&u.tok_cost[d]);
+      }
       ex[k] = LoadExtra(&u.tok_extra[d]);
     }
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       if (base + k * NT >= hi || dst[k] < 0) continue;
-      float lec = ex[k] + ((Dec(cs[k]) + a[k] + g[k]) - Dec(cd[k]));  // :309-311
+      if (kList &&  // list (once) the tokens that own live epsilon links
+          __hip_atomic_exchange(&u.tmp_dirty[src[k] - b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        u.tmp_work0[__hip_atomic_fetch_add(list_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = src[k];
+      // :309-311; for an epsilon link the parenthesis was evaluated when it was created
+      float lec = kEps ? ex[k] + a[k] : ex[k] + ((Dec(cs[k]) + a[k] + g[k]) - Dec(cd[k]));
       if (lec > lb) {  // :315 excise
         if (kExcise) { u.link_dst[l[k]] = -1; flags |= 2; }
         continue;
@@ -872,16 +890,20 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   const float inf = INFINITY;
   const float lb = p.lattice_beam;
   if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; }
-  // P0 (tokens): remember the entry extra_cost, start the two accumulators.
+  long long tp = 0;
+  const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0 && e - b > NT;
+  if (prof) tp = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#define KH_PRUNE_STAMP(k) do { if (prof) { const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tp; tp = now_; } } while (0)
+  // P0 (tokens): start the accumulator of the emitting links.  (tmp_acc1, the one of
+  // the epsilon links, is +inf for every token outside this function.)
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->pr_moved = 0; }
   for (int base = b + threadIdx.x; base < e; base += NT * PU) {
     int i[PU], st[PU];
-    float entry[PU];
     uint32_t co[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       i[k] = min(base + k * NT, e - 1);
-      st[k] = u.tok_state[i[k]];
-      entry[k] = LoadExtra(&u.tok_extra[i[k]]);
+      st[k] = final_frame ? u.tok_state[i[k]] : 0;
       co[k] = final_frame ? LoadCostEnc(&u.tok_cost[i[k]]) : 0u;
     }
     float fc[PU];
@@ -892,59 +914,75 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
       if (base + k * NT >= e) continue;
       float base_v = inf;
       if (final_frame) base_v = Dec(co[k]) + fc[k] - final_best_cost;  // :385
-      u.tmp_f0[i[k] - b] = entry[k];
       u.tmp_acc0[i[k] - b] = Enc(base_v);
-      u.tmp_acc1[i[k] - b] = kEncInf;
     }
   }
   // PruneTokensForFrame(f + 1): its extra_costs are final, nothing below reads its states
   for (int i = tb + threadIdx.x; i < te; i += NT)
     if (u.tok_state[i] >= 0 && LoadExtra(&u.tok_extra[i]) == inf) u.tok_state[i] = -1;
   KhSync();
+  KH_PRUNE_STAMP(20);
   // P1 (emitting links): a link to the NEXT frame sees final extra_costs there, so
   // its link_extra_cost - hence whether it is excised - is final at first sight.
-  int flags = PruneLinkPass<true, true>(u, mb, me, b, lb, u.tmp_acc0);
+  int flags = PruneLinkPass<false, true, true>(u, mb, me, b, lb, u.tmp_acc0);
   // Epsilon links stay inside the frame: Jacobi iteration to the exact fixed point
-  // (unique: the epsilon links of a frame form a DAG), then excise.
-  bool changed_by_delta = false;
-  for (;;) {
-    if (ne > nb) PruneLinkPass<true, false>(u, nb, ne, b, lb, u.tmp_acc1);
+  // (unique: the epsilon links of a frame form a DAG), then excise.  The first sweep
+  // visits every token and records its entry extra_cost; the later ones only the
+  // tokens that own live epsilon links (listed by the first epsilon pass).
+  int n_moved = 0;
+  auto settle = [&](int i, uint32_t a0, uint32_t a1, int st, float old, float entry, bool &changed) {
+    if (st < 0) return;
+    float v = Dec(a1 < a0 ? a1 : a0);
+    if (final_frame && v > lb) v = inf;  // :416-417
+    if (!(v == old)) {
+      StoreExtra(&u.tok_extra[i], v);
+      changed = true;
+    }
+    // :334 on the converged values: net count of tokens whose extra_cost moved by more than delta
+    n_moved += (fabsf(v - entry) > delta ? 1 : 0) - (fabsf(old - entry) > delta ? 1 : 0);
+    if (a1 != kEncInf) u.tmp_acc1[i - b] = kEncInf;
+  };
+  for (int iter = 0;; iter++) {
+    if (ne > nb) {
+      if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, u.tmp_acc1, &sh->wl_n[0]);
+      else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, u.tmp_acc1);
+    }
     KhSync();
+    if (iter == 0) KH_PRUNE_STAMP(21);
     bool changed = false;
-    changed_by_delta = false;
-    for (int base = b + threadIdx.x; base < e; base += NT * PU) {
-      int i[PU], st[PU];
-      uint32_t a0[PU], a1[PU];
-      float old[PU], entry[PU];
-#pragma unroll
-      for (int k = 0; k < PU; k++) {
-        i[k] = min(base + k * NT, e - 1);
-        st[k] = u.tok_state[i[k]];
-        a0[k] = LoadCostEnc(&u.tmp_acc0[i[k] - b]);
-        a1[k] = LoadCostEnc(&u.tmp_acc1[i[k] - b]);
-        old[k] = LoadExtra(&u.tok_extra[i[k]]);
-        entry[k] = u.tmp_f0[i[k] - b];
+    if (iter == 0) {
+      for (int i = b + threadIdx.x; i < e; i += NT) {
+        const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
+        const int st = u.tok_state[i];
+        const float old = LoadExtra(&u.tok_extra[i]);
+        u.tmp_f0[i - b] = old;
+        settle(i, a0, a1, st, old, old, changed);
       }
-#pragma unroll
-      for (int k = 0; k < PU; k++) {
-        if (base + k * NT >= e || st[k] < 0) continue;
-        float v = Dec(a0[k] < a1[k] ? a0[k] : a1[k]);
-        if (final_frame && v > lb) v = inf;  // :416-417
-        if (!(v == old[k])) {
-          StoreExtra(&u.tok_extra[i[k]], v);
-          changed = true;
-        }
-        if (fabsf(v - entry[k]) > delta) changed_by_delta = true;  // :334
-        if (a1[k] != kEncInf) u.tmp_acc1[i[k] - b] = kEncInf;
+    } else {
+      const int n_list = sh->wl_n[0];
+      for (int q = threadIdx.x; q < n_list; q += NT) {
+        const int i = u.tmp_work0[q];
+        const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
+        const int st = u.tok_state[i];
+        const float old = LoadExtra(&u.tok_extra[i]), entry = u.tmp_f0[i - b];
+        settle(i, a0, a1, st, old, entry, changed);
       }
     }
     if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
     if (ne == nb) break;  // no epsilon links: one sweep is exact
     if (!BlockAny(changed, sh)) break;
   }
-  if (ne > nb) flags |= PruneLinkPass<false, true>(u, nb, ne, b, lb, u.tmp_acc1);
-  if (changed_by_delta) flags |= 1;
-  const int all = BlockOr(flags, sh);
+  if (ne > nb) {  // leave tmp_dirty all zero
+    const int n_list = sh->wl_n[0];
+    for (int q = threadIdx.x; q < n_list; q += NT) u.tmp_dirty[u.tmp_work0[q] - b] = 0;
+  }
+  if (n_moved != 0) __hip_atomic_fetch_add(&sh->pr_moved, n_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  KH_PRUNE_STAMP(22);
+  if (ne > nb) flags |= PruneLinkPass<true, false, true>(u, nb, ne, b, lb, u.tmp_acc1);
+  int all = BlockOr(flags, sh);
+  if (sh->pr_moved > 0) all |= 1;
+  KH_PRUNE_STAMP(23);
+#undef KH_PRUNE_STAMP
   *extra_costs_changed = (all & 1) != 0;
   *links_pruned = (all & 2) != 0;
 }
@@ -1308,7 +1346,7 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &
     if (alive) {
       const long long d = lbase + lrun + off;
       const int src = u.link_src[l], il = u.link_il[l];
-      float a = u.link_a[l];
+      float a = il != 0 ? u.link_a[l] : 0.0f;  // (an epsilon link's field holds its extra-cost constant)
       if (il != 0) {  // :168-174 the acoustic cost without the frame's cost_offset
         const int f = FrameOfToken(u, src, T);
         a -= f < T ? u.cost_offset[f] : 0.0f;
@@ -1337,8 +1375,10 @@ __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER
 DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut *__restrict__ out,
              int n_utts, Pool pool, Params p, GP(long long) phase_cycles) {
   __shared__ Shared shm;
+  extern __shared__ float dyn_ll_row[];
   Blk sh;
   sh.p = (LdsShared *)&shm;
+  sh.ll_row = (__attribute__((address_space(3))) float *)dyn_ll_row;
   sh.k_or = 0;
   sh.k_red = 0;
   sh.k_scan = 0;
@@ -1370,6 +1410,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     const int hw = sh->tok_hw;
     for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+    for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) u.tmp_acc1[i] = kEncInf;
     KhSync();
     KhDecodeStats st;
     DecodeOne(u, p, sh, &st);
@@ -1901,6 +1942,9 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   p.num_emit = static_cast<int32_t>(d->fst->num_emit);
   p.num_eps = static_cast<int32_t>(d->fst->num_eps);
   p.start_has_eps = d->fst->start_has_eps;
+  // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
+  p.ll_cols = ll_stride <= 12288 ? ll_stride : 0;
+  if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.tid2pdf = (GP(const int32_t))tid2pdf;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
@@ -1978,7 +2022,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
                            static_cast<size_t>(d->h_slots[i].tok_cap), kEncInf);
     const int grid = std::min(np, n_slots);
     KH_HIP(hipEventRecord(d->ev0, st));
-    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), 0, st, d->d_slots, d->d_in, d->d_out, np, d->pool, p,
+    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), sizeof(float) * p.ll_cols, st, d->d_slots, d->d_in, d->d_out, np, d->pool, p,
                        (GP(long long))d->d_phase);
     KH_LAUNCH_CHECK();
     KH_HIP(hipEventRecord(d->ev1, st));
@@ -2036,6 +2080,10 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
               "larger: %lld visits, %.1f%% (%.0f cycles each)\n",
               tot[18], tot[6] ? 100.0 * tot[16] / tot[6] : 0.0, tot[18] ? double(tot[16]) / tot[18] : 0.0,
               tot[19], tot[6] ? 100.0 * tot[17] / tot[6] : 0.0, tot[19] ? double(tot[17]) / tot[19] : 0.0);
+      fprintf(stderr, "[kh_decoder profile] PruneForwardLinks on frames > %d tokens, share of prune cycles: token init %.1f%%, "
+              "emitting links + first epsilon sweep %.1f%%, token sweeps + later epsilon sweeps %.1f%%, excise + flags %.1f%%\n",
+              NT, tot[6] ? 100.0 * tot[20] / tot[6] : 0.0, tot[6] ? 100.0 * tot[21] / tot[6] : 0.0,
+              tot[6] ? 100.0 * tot[22] / tot[6] : 0.0, tot[6] ? 100.0 * tot[23] / tot[6] : 0.0);
     }
     std::vector<int> next;
     need_tok = need_link = 0;
