@@ -852,12 +852,14 @@ __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b
     float ex[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
-      const int d = dst[k] >= 0 ? dst[k] : src[k];  // any valid token for an excised slot
+      cs[k] = cd[k] = 0u;
+      ex[k] = 0.0f;
+      if (dst[k] < 0) continue;  // excised slot: no gathers
       if (!kEps) {
         cs[k] = LoadCostEnc(&u.tok_cost[src[k]]);
-        cd[k] = LoadCostEnc(&u.tok_cost[d]);
+        cd[k] = LoadCostEnc(&u.tok_cost[dst[k]]);
       }
-      ex[k] = LoadExtra(&u.tok_extra[d]);
+      ex[k] = LoadExtra(&u.tok_extra[dst[k]]);
     }
 #pragma unroll
     for (int k = 0; k < PU; k++) {
@@ -1080,8 +1082,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
       }
       tend += total;
     }
-    // (an empty frame has no barrier above: a lane that reads these after the update
-    // sees another empty range)
+    KhSync();  // every lane has read the old range (an empty frame has no barrier above)
     if (threadIdx.x == 0) { u.frame_b[f] = new_b; u.frame_e[f] = tend; }
   }
   KhSync();
@@ -1121,6 +1122,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
         }
         lend += total;
       }
+      KhSync();  // every lane has read the old range (an empty block has no barrier above)
       if (threadIdx.x == 0) {
         if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = lend; }
         else { u.feps_b[f] = new_blk_b; u.feps_e[f] = lend; }
