@@ -116,6 +116,27 @@ def cpu_baseline(net, priors, g, feats, off, budget_frames):
     return tot / el, desc
 
 
+def measured_traffic(args, n_utts, world):
+    """HBM bytes per DecodeKernel launch from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, tools/collect_profiles.sh):
+    counters cannot be read inside this process.  Only quoted for the workload they
+    were measured on (the default one, 1 GPU); FETCH_SIZE + WRITE_SIZE are in KB and
+    taken as reported (MI355X guide: FETCH_SIZE is exact for 64-B requests and halves
+    wide coalesced reads, so this is a lower bound)."""
+    if args.small or args.utts != 2620 or args.graph_states != 10_000_000 or world != 1:
+        return None
+    tot = 0.0
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_%s.txt" % name)
+        try:
+            with open(path) as f:
+                fields = f.readline().strip().split(",")
+            tot += float(fields[2]) * 1024.0
+        except (OSError, IndexError, ValueError):
+            return None
+    return tot
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,7 +251,7 @@ def main():
                        "graph_arcs": int(g["arc_offsets"][-1]), "nnet": "140-700-4x(3500/350)-12000-5800" if not args.small else "small",
                        "decoder": DECODE_CFG, "acwt": ACWT, "parallelism": "utterance-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": measured_traffic(args, n_utts, world),
                          "kernel": "DecodeKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "arcs_expanded_per_launch": stats["arcs"], "tokens_created_per_launch": stats["toks"]},

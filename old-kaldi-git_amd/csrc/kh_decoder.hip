@@ -696,7 +696,12 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
 
 // Clears the hash entries of the frontier tokens [fb, fe) (inserted this frame).
 __device__ void ClearHash(const Utt &u, int fb, int fe) {
-  for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb] & 0x7fffffff] = kEmpty;
+  if (2 * (fe - fb) > static_cast<int>(u.hash_mask >> 2)) {
+    // many entries: stream over the whole table (coalesced) instead of one scattered store per token
+    for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+  } else {
+    for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb] & 0x7fffffff] = kEmpty;
+  }
   KhSync();
 }
 
@@ -1439,7 +1444,7 @@ struct KhDecoder {
   const KhFst *fst = nullptr;
   KhDecoderConfig cfg;
   int max_batch = 0, max_frames = 0;
-  int tok_frame_cap = 0, link_frame_cap = 0;
+  int tok_frame_cap = 0, link_frame_cap = 0, expected_tokens = 0;
   int max_slots = 0;
   // slot arenas (one set per persistent workgroup)
   void *slab = nullptr;
@@ -1500,7 +1505,7 @@ struct Carver {
 
 // Arena set of one slot, sized for utterances of up to T frames.
 void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, int prune_interval,
-               float hash_ratio) {
+               float hash_ratio, int expected_tokens) {
   u.T = T;
   u.tok_frame_cap = tok_frame_cap;
   u.link_frame_cap = link_frame_cap;
@@ -1543,8 +1548,11 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tmp_f0 = c.Take<float>(tok_frame_cap);
   u.tmp_acc0 = c.Take<uint32_t>(tok_frame_cap);
   u.tmp_acc1 = c.Take<uint32_t>(tok_frame_cap);
+  // hash_ratio x the tokens a frame is expected to hold (lattice-faster-decoder.cc:193-199
+  // resizes to hash_ratio x the previous frame's count); never fewer entries than a
+  // frame may hold.  A smaller table keeps more of it in L2.
   size_t hs = 1;
-  while (hs < static_cast<size_t>(hash_ratio * tok_frame_cap)) hs <<= 1;
+  while (hs < static_cast<size_t>(hash_ratio * expected_tokens) || hs <= static_cast<size_t>(tok_frame_cap)) hs <<= 1;
   u.hash_mask = static_cast<uint32_t>(hs - 1);
   u.hash = c.Take<unsigned long long>(hs);
   u.ll = (GP(const float))nullptr;
@@ -1818,6 +1826,9 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
                      : std::min<long long>(65536, 3ll * cfg->max_active + 4096);
   if (const char *e = getenv("KH_DECODER_TOKENS_PER_FRAME")) tf = atoll(e);
   d->tok_frame_cap = static_cast<int>(tf);
+  // tokens a frame is sized for in the hash (hash_ratio x this many entries)
+  d->expected_tokens = d->tok_frame_cap;
+  if (const char *e = getenv("KH_DECODER_HASH_TOKENS")) d->expected_tokens = atoi(e);
   long long lf = 3 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
   d->link_frame_cap = static_cast<int>(lf);
@@ -1875,7 +1886,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       Carver sizer{nullptr};
       for (int i = 0; i < n_slots; i++) {
         Utt tmp;
-        CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio);
+        CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio, d->expected_tokens);
       }
       slab_bytes = sizer.off;
       if (slab_bytes <= budget || n_slots == 1) {
@@ -1897,7 +1908,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     Carver carver{static_cast<char *>(d->slab)};
     for (int i = 0; i < n_slots; i++)
       CarveSlot(carver, d->h_slots[i], T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval,
-                d->cfg.hash_ratio);
+                d->cfg.hash_ratio, d->expected_tokens);
     // arena invariants for the first utterance of every slot (later ones are
     // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
     for (int i = 0; i < n_slots; i++) {

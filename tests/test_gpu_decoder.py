@@ -177,3 +177,14 @@ def test_prepare_on_host_threads_matches_on_demand(api):
     for u in range(len(lls)):
         assert_same_lattice(a.get_raw_lattice(u), b.get_raw_lattice(u))
         assert_same_best_path(a.get_best_path(u), b.get_best_path(u))
+
+
+def test_long_utterances_sparse_epsilons(api, monkeypatch):
+    """Many prune/compaction cycles (T up to 330 = 13 intervals) on a graph whose
+    frames mostly have NO epsilon links (empty link blocks), two slots shared by six
+    utterances: exercises the sliding compaction's block bookkeeping."""
+    monkeypatch.setenv("KH_DECODER_SLOTS", "2")
+    rng = np.random.default_rng(33)
+    g = graph_like_hclg(rng, 40000, 300, eps_frac=0.01)
+    lls = [workloads.make_loglikes(rng, int(T), 300) for T in (330, 41, 257, 26, 180, 75)]
+    run_case(api, g, lls, api.decoder_config(beam=12.0, max_active=1200, min_active=100, lattice_beam=6.0))
