@@ -327,6 +327,48 @@ int kh_decoder_get_best_path(const KhDecoder *dec, int utt, int32_t *alignment,
  * cached results.  Optional: the getters compute on demand otherwise. */
 int kh_decoder_prepare(KhDecoder *dec, int num_threads);
 
+/* ------------------------------------------------------------------ (f)1
+ * LatticeFasterOnlineDecoder (decoder/lattice-faster-online-decoder.h:44-200) for
+ * num_streams concurrent utterances, advanced a chunk of frames at a time (what
+ * online2/ feeds from DecodableNnet2Online).  The search, its pruning schedule
+ * (every prune_interval frames, :762-764) and therefore the lattice are those of
+ * kh_decoder_decode on the concatenated chunks.  A stream is an index in
+ * [0, num_streams); every call takes a list of DISTINCT streams and processes them
+ * in one kernel launch (one workgroup per stream). */
+typedef struct KhOnlineDecoder KhOnlineDecoder;
+KhOnlineDecoder *kh_online_decoder_create(const KhFst *hclg, const KhDecoderConfig *config,
+                                          int num_streams, int max_frames);
+void kh_online_decoder_destroy(KhOnlineDecoder *dec);
+/* InitDecoding() :160 (.cc:55-72). */
+int kh_online_decoder_init_decoding(KhOnlineDecoder *dec, const int32_t *streams, int n);
+/* AdvanceDecoding(decodable, max_num_frames) :166 (.cc:747-769): stream streams[i]
+ * decodes the next num_frames[i] frames; loglikes[i] = device matrix of their
+ * acoustic_scale * log-likelihoods (num_frames[i] rows of ll_stride floats, whole
+ * rows allocated), the rows a Decodable would return for frames NumFramesDecoded()...;
+ * tid2pdf as in kh_decoder_decode. */
+int kh_online_decoder_advance(KhOnlineDecoder *dec, const int32_t *streams, int n,
+                              const float *const *loglikes, int ll_stride,
+                              const int32_t *num_frames, const int32_t *tid2pdf);
+/* NumFramesDecoded() :194. */
+int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream, int32_t *num_frames);
+/* FinalizeDecoding() :180 (.cc:775-790). */
+int kh_online_decoder_finalize(KhOnlineDecoder *dec, const int32_t *streams, int n);
+/* GetRawLattice(ofst, use_final_probs) :143 (.cc:143-233), GetBestPath :107 and the
+ * counters, valid at any point after the first frame: before FinalizeDecoding the
+ * lattice holds every token not yet pruned and, with use_final_probs, the final
+ * costs computed on the fly (.cc:160-165).  use_final_probs == 0 after
+ * FinalizeDecoding is an error as in the reference (.cc:156-158).  Layout as
+ * kh_decoder_get_raw_lattice / kh_decoder_get_best_path (sizes via get_stats). */
+int kh_online_decoder_get_stats(KhOnlineDecoder *dec, int stream, int use_final_probs, KhDecodeStats *stats);
+int kh_online_decoder_get_raw_lattice(KhOnlineDecoder *dec, int stream, int use_final_probs,
+                                      int32_t *state_frame, int32_t *state_hclg, float *state_final,
+                                      int32_t *arc_src, int32_t *arc_dst, int32_t *arc_ilabel,
+                                      int32_t *arc_olabel, float *arc_graph, float *arc_acoustic);
+int kh_online_decoder_get_best_path(KhOnlineDecoder *dec, int stream, int use_final_probs,
+                                    int32_t *alignment, int cap_ali, int32_t *n_ali, int32_t *words,
+                                    int cap_words, int32_t *n_words, float *graph_cost,
+                                    float *acoustic_cost);
+
 /* ------------------------------------------------------------------ a15
  * Lattice forward-backward (lat/lattice-functions.cc:36-67,272-354) for a batch
  * of top-sorted lattices given as HOST CSR (state s owns arcs

@@ -457,6 +457,95 @@ class LatticeFasterDecoder:
                     graph_cost=g.value, acoustic_cost=a.value)
 
 
+class LatticeFasterOnlineDecoder:
+    """decoder/lattice-faster-online-decoder.h:44-200 for num_streams concurrent
+    utterances: InitDecoding / AdvanceDecoding (a chunk of frames at a time) /
+    FinalizeDecoding, GetRawLattice and GetBestPath at any point.  The scaled
+    log-likelihood chunks are what DecodableNnet2Online would serve for the next
+    frames (rows [t, t + n) of the utterance's matrix)."""
+
+    def __init__(self, fst, config=None, num_streams=1, max_frames=4096):
+        self.fst = fst
+        cfg = decoder_config() if config is None else config
+        self.cfg = KhDecoderConfig(**cfg)
+        self.num_streams = int(num_streams)
+        h = lib().kh_online_decoder_create(fst._h, C.byref(self.cfg), self.num_streams, int(max_frames))
+        if not h:
+            raise KhError(lib().kh_last_error().decode())
+        self._h = C.c_void_p(h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kh_online_decoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _streams(streams):
+        a = np.ascontiguousarray(streams, np.int32).reshape(-1)
+        return a, a.ctypes.data_as(capi.c_int32_p), len(a)
+
+    def init_decoding(self, streams):
+        a, ptr, n = self._streams(streams)
+        check(lib().kh_online_decoder_init_decoding(self._h, ptr, n))
+
+    def advance_decoding(self, streams, chunks):
+        """chunks[i]: 2-D float32 device tensor, the next rows of stream streams[i]
+        (all with the same row stride)."""
+        a, ptr, n = self._streams(streams)
+        assert len(chunks) == n
+        strides = {int(_dim(c).stride) for c in chunks if c.shape[0] > 0}
+        assert len(strides) <= 1, "chunks of one call must share their row stride"
+        stride = strides.pop() if strides else 1
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(c.data_ptr()) if c.shape[0] > 0 else None for c in chunks])
+        nf = np.ascontiguousarray([c.shape[0] for c in chunks], np.int32)
+        t2p = _p(self.fst.tid2pdf) if self.fst.tid2pdf is not None else None
+        self._keep = chunks
+        check(lib().kh_online_decoder_advance(self._h, ptr, n, ptrs, stride, nf.ctypes.data_as(capi.c_int32_p), t2p))
+
+    def num_frames_decoded(self, stream=0):
+        n = C.c_int32()
+        check(lib().kh_online_decoder_num_frames_decoded(self._h, int(stream), C.byref(n)))
+        return n.value
+
+    def finalize_decoding(self, streams):
+        a, ptr, n = self._streams(streams)
+        check(lib().kh_online_decoder_finalize(self._h, ptr, n))
+
+    def stats(self, stream=0, use_final_probs=True):
+        st = KhDecodeStats()
+        check(lib().kh_online_decoder_get_stats(self._h, int(stream), int(bool(use_final_probs)), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in KhDecodeStats._fields_}
+
+    def get_raw_lattice(self, stream=0, use_final_probs=True):
+        st = self.stats(stream, use_final_probs)
+        n, m = st["num_tokens"], st["num_links"]
+        L = dict(state_frame=np.empty(n, np.int32), state_hclg=np.empty(n, np.int32),
+                 state_final=np.empty(n, np.float32), arc_src=np.empty(m, np.int32),
+                 arc_dst=np.empty(m, np.int32), arc_il=np.empty(m, np.int32), arc_ol=np.empty(m, np.int32),
+                 arc_g=np.empty(m, np.float32), arc_a=np.empty(m, np.float32))
+        i32 = lambda k: L[k].ctypes.data_as(capi.c_int32_p)
+        f32 = lambda k: L[k].ctypes.data_as(capi.c_float_p)
+        check(lib().kh_online_decoder_get_raw_lattice(
+            self._h, int(stream), int(bool(use_final_probs)), i32("state_frame"), i32("state_hclg"),
+            f32("state_final"), i32("arc_src"), i32("arc_dst"), i32("arc_il"), i32("arc_ol"), f32("arc_g"), f32("arc_a")))
+        return L
+
+    def get_best_path(self, stream=0, use_final_probs=True):
+        cap = self.num_frames_decoded(stream) + 16
+        capw = 4 * cap + 64
+        ali, words = np.empty(cap, np.int32), np.empty(capw, np.int32)
+        na, nw = C.c_int32(), C.c_int32()
+        g, a = C.c_float(), C.c_float()
+        check(lib().kh_online_decoder_get_best_path(
+            self._h, int(stream), int(bool(use_final_probs)), ali.ctypes.data_as(capi.c_int32_p), cap, C.byref(na),
+            words.ctypes.data_as(capi.c_int32_p), capw, C.byref(nw), C.byref(g), C.byref(a)))
+        return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
+                    graph_cost=g.value, acoustic_cost=a.value)
+
+
 # ---------------------------------------------------------------- lattice forward-backward
 def lattice_forward_backward(lats):
     """LatticeForwardBackward (lat/lattice-functions.cc:272-354) for a batch of

@@ -115,6 +115,15 @@ SIGNATURES = {
     "kh_decoder_get_raw_lattice": (C.c_int, [vp, C.c_int, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p]),
     "kh_decoder_get_best_path": (C.c_int, [vp, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p, c_float_p, c_float_p]),
     "kh_decoder_prepare": (C.c_int, [vp, C.c_int]),
+    "kh_online_decoder_create": (vp, [vp, C.POINTER(KhDecoderConfig), C.c_int, C.c_int]),
+    "kh_online_decoder_destroy": (None, [vp]),
+    "kh_online_decoder_init_decoding": (C.c_int, [vp, c_int32_p, C.c_int]),
+    "kh_online_decoder_advance": (C.c_int, [vp, c_int32_p, C.c_int, C.POINTER(vp), C.c_int, c_int32_p, vp]),
+    "kh_online_decoder_num_frames_decoded": (C.c_int, [vp, C.c_int, c_int32_p]),
+    "kh_online_decoder_finalize": (C.c_int, [vp, c_int32_p, C.c_int]),
+    "kh_online_decoder_get_stats": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(KhDecodeStats)]),
+    "kh_online_decoder_get_raw_lattice": (C.c_int, [vp, C.c_int, C.c_int, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p]),
+    "kh_online_decoder_get_best_path": (C.c_int, [vp, C.c_int, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p, c_float_p, c_float_p]),
     "kh_lattice_forward_backward": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p, c_int32_p]),
 }
 

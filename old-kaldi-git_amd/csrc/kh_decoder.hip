@@ -1143,10 +1143,19 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   return true;
 }
 
-// One utterance: InitDecoding, Decode, FinalizeDecoding.  Leaves the surviving
-// tokens/links in the slot's arenas ([0, sh->tok_end) / [0, sh->link_end)).
-__device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats *st_out) {
-  const float inf = INFINITY;
+// Frontier of a decoding run (uniform over the workgroup): frames decoded so far and
+// the token range of the newest frame.
+struct Run {
+  int t, fb, fe;
+};
+
+// Compaction window: everything younger than 2 * max(prune_interval, 25) frames
+// (frames leave it only once they are >= 25 frames behind the frontier, i.e.
+// thinned to lattice density by the backward pruning).
+__device__ __forceinline__ int WindowFrames(const Params &p) { return 2 * (p.prune_interval > 25 ? p.prune_interval : 25); }
+
+// InitDecoding :55-72 on a slot whose arenas hold their invariants.
+__device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   if (threadIdx.x == 0) {
     sh->tok_end = 0;
     sh->link_end = 0;
@@ -1161,8 +1170,6 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
     u.must_toks[f] = 1;
   }
   KhSync();
-
-  // ---- InitDecoding :55-72
   if (threadIdx.x == 0) {
     const int idx = FindOrAdd(u, p.start, p.start_has_eps != 0, &sh->tok_end, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
@@ -1176,19 +1183,26 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
     }
   }
   KhSync();
-  bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
-  int fb = 0;                    // token range of the frontier frame
-  int fe = sh->tok_end;
-  if (threadIdx.x == 0) { u.frame_e[0] = fe; sh->tokens_created += fe - fb; if (fe > sh->tok_hw) sh->tok_hw = fe; }
-  if (ok) ClearHash(u, fb, fe);
-  // Compaction window: everything younger than 2 * max(prune_interval, 25) frames
-  // (frames leave it only once they are >= 25 frames behind the frontier, i.e.
-  // thinned to lattice density by the backward pruning).
-  const int win_frames = 2 * (p.prune_interval > 25 ? p.prune_interval : 25);
+  const bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
+  run->t = 0;
+  run->fb = 0;  // token range of the frontier frame
+  run->fe = sh->tok_end;
+  if (threadIdx.x == 0) {
+    u.frame_e[0] = run->fe;
+    sh->tokens_created += run->fe - run->fb;
+    if (run->fe > sh->tok_hw) sh->tok_hw = run->fe;
+  }
+  if (ok) ClearHash(u, run->fb, run->fe);
+  return ok;
+}
 
-  // ---- Decode :77-95
-  int t = 0;
-  for (; ok && t < u.T; t++) {
+// Decode :77-95 / AdvanceDecoding (lattice-faster-online-decoder.cc:747-769): frames
+// [run->t, t_end).  u.ll is addressed by absolute frame.
+__device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, int t_end) {
+  const int win_frames = WindowFrames(p);
+  bool ok = true;
+  int t = run->t, fb = run->fb, fe = run->fe;
+  for (; ok && t < t_end; t++) {
     if (t % p.prune_interval == 0 && t > 0) {
       Stamp(u, sh, 15);
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
@@ -1216,17 +1230,27 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
     ClearHash(u, fb, fe);
     Stamp(u, sh, 5);
   }
+  run->t = t;
+  run->fb = fb;
+  run->fe = fe;
+  return ok;
+}
 
+// FinalizeDecoding :573-588 (ComputeFinalCosts :505-545 first) after run->t frames,
+// then the counters of the utterance.  Leaves the surviving tokens/links in the
+// slot's arenas ([0, sh->tok_end) / [0, sh->link_end)).
+__device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run &run, bool ok, KhDecodeStats *st_out) {
+  const float inf = INFINITY;
+  const int fb = run.fb, fe = run.fe;
   KhDecodeStats st;
-  st.num_frames = t;
+  st.num_frames = run.t;
   st.reached_final = 0;
   st.final_relative_cost = inf;
   st.final_best_cost = inf;
   st.num_tokens = 0;
   st.num_links = 0;
   if (ok) {
-    // ---- FinalizeDecoding :573-588.  ComputeFinalCosts :505-545 first.
-    const int last = u.T;
+    const int last = run.t;
     float best_cost = inf, best_with_final = inf;
     for (int i = fb + threadIdx.x; i < fe; i += NT) {
       const float cost = Dec(LoadCostEnc(&u.tok_cost[i]));
@@ -1249,7 +1273,7 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
                         0.0f, false, false, 0.f, u.frame_b[f + 1], u.frame_e[f + 1], &b1, &b2, sh);
     PruneTokensForFrame(u, u.frame_b[0], u.frame_e[0]);
     // final compaction of the window so the export below copies little
-    ok = Compact(u, last - win_frames, last, sh);
+    ok = Compact(u, last - WindowFrames(p), last, sh);
     Stamp(u, sh, 8);
   }
   KhSync();
@@ -1262,6 +1286,14 @@ __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats 
   *st_out = st;
   KhSync();
   return ok && sh->status == 0;
+}
+
+// One utterance: InitDecoding, Decode, FinalizeDecoding.
+__device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats *st_out) {
+  Run run;
+  bool ok = DecodeInit(u, p, sh, &run);
+  if (ok) ok = DecodeFrames(u, p, sh, &run, u.T);
+  return DecodeFinalize(u, p, sh, run, ok, st_out);
 }
 
 // Per-utterance inputs / outputs of the batch and the lattice pool the finished
@@ -1431,6 +1463,113 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
 }
 
 
+// ---------------------------------------------------------------- online decoding
+// LatticeFasterOnlineDecoder (decoder/lattice-faster-online-decoder.{h,cc}): the
+// same search, advanced a chunk of frames at a time.  A stream keeps its slot for
+// the whole utterance; between launches the workgroup's LDS scalars live in
+// SlotState.  One workgroup per job.
+struct SlotState {
+  int32_t tok_end, link_end, front_b, status, max_tokens_frame, tok_hw;
+  int32_t t, fb, fe;          // Run
+  int32_t ok, finalized;
+  long long arcs_expanded, tokens_created;
+  KhDecodeStats stats;        // valid once finalized
+};
+enum { kJobInit = 0, kJobAdvance = 1, kJobFinalize = 2, kJobExport = 3 };
+struct Job {
+  int32_t slot, op;
+  GP(const float) ll;         // kJobAdvance: matrix addressed by ABSOLUTE frame (chunk pointer - t * stride)
+  int32_t ll_stride, n_frames;
+};
+
+__device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
+  if (threadIdx.x == 0) {
+    sh->tok_end = S.tok_end; sh->link_end = S.link_end; sh->front_b = S.front_b; sh->status = S.status;
+    sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw;
+    sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created;
+  }
+  run->t = S.t; run->fb = S.fb; run->fe = S.fe;
+  KhSync();
+}
+__device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
+  KhSync();
+  if (threadIdx.x == 0) {
+    S->tok_end = sh->tok_end; S->link_end = sh->link_end; S->front_b = sh->front_b; S->status = sh->status;
+    S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw;
+    S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created;
+    S->t = run.t; S->fb = run.fb; S->fe = run.fe;
+    S->ok = (ok && sh->status == 0) ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+#if KH_WG_PER_CU > 1
+__attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
+#endif
+OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, const Job *__restrict__ jobs,
+             UttOut *__restrict__ out, Pool pool, Params p) {
+  __shared__ Shared shm;
+  extern __shared__ float dyn_ll_row[];
+  Blk sh;
+  sh.p = (LdsShared *)&shm;
+  sh.ll_row = (__attribute__((address_space(3))) float *)dyn_ll_row;
+  sh.k_or = 0;
+  sh.k_red = 0;
+  sh.k_scan = 0;
+  const Job job = jobs[blockIdx.x];
+  Utt u = slots[job.slot];
+  SlotState *S = &states[job.slot];
+  u.phase_cycles = (GP(long long))nullptr;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
+    for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
+  }
+  KhSync();
+  Run run;
+  if (job.op == kJobInit) {
+    // arena invariants (a previous utterance of this stream may have left them dirty)
+    const int hw = S->tok_hw;
+    KhSync();
+    for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
+    for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+    for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
+    if (threadIdx.x == 0) sh->tok_hw = 0;
+    KhSync();
+    const bool ok = DecodeInit(u, p, sh, &run);
+    SaveState(S, sh, run, ok);
+    if (threadIdx.x == 0) S->finalized = 0;
+  } else if (job.op == kJobAdvance) {
+    LoadState(*S, sh, &run);
+    u.ll = job.ll;
+    u.ll_stride = job.ll_stride;
+    bool ok = S->ok != 0;
+    if (ok) ok = DecodeFrames(u, p, sh, &run, run.t + job.n_frames);
+    SaveState(S, sh, run, ok);
+  } else if (job.op == kJobFinalize) {
+    LoadState(*S, sh, &run);
+    KhDecodeStats st;
+    const bool ok = DecodeFinalize(u, p, sh, run, S->ok != 0, &st);
+    SaveState(S, sh, run, ok);
+    if (threadIdx.x == 0) { S->finalized = 1; S->stats = st; }
+  } else {  // kJobExport: non-destructive snapshot of the current lattice
+    LoadState(*S, sh, &run);
+    u.T = run.t;
+    if (threadIdx.x == 0) {
+      KhDecodeStats st = S->stats;
+      if (!S->finalized) {
+        st.num_frames = run.t; st.reached_final = 0; st.final_relative_cost = INFINITY; st.final_best_cost = INFINITY;
+        st.arcs_expanded = sh->arcs_expanded; st.tokens_created = sh->tokens_created;
+        st.max_tokens_frame = sh->max_tokens_frame; st.num_tokens = sh->tok_end; st.num_links = sh->link_end;
+      }
+      st.status = sh->status;
+      out[blockIdx.x].stats = st;
+    }
+    KhSync();
+    ExportLattice(u, pool, &out[blockIdx.x], sh);
+  }
+}
+
+
 __global__ void FillU32(uint32_t *p, size_t n, uint32_t v) {
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -1486,6 +1625,18 @@ struct KhDecoder {
     float bp_graph = 0.f, bp_acoustic = 0.f;
   };
   std::vector<Lat> lats;
+};
+
+// LatticeFasterOnlineDecoder for num_streams concurrent utterances: stream i owns
+// slot i of `base` for the whole utterance.
+struct KhOnlineDecoder {
+  KhDecoder *base = nullptr;
+  int num_streams = 0, max_frames = 0;
+  SlotState *d_states = nullptr;
+  Job *d_jobs = nullptr;
+  std::vector<int32_t> frames;       // NumFramesDecoded() per stream
+  std::vector<char> inited, finalized;
+  std::vector<long long> lat_key;    // what base->lats[stream] was built from (-1: nothing)
 };
 
 namespace {
@@ -1697,6 +1848,150 @@ int ComputeBestPath(KhDecoder *d, int utt) {
   return L.bp_rc = KH_OK;
 }
 
+// Arena slab of the decoder: n_want slots sized for utterances of up to T_max frames
+// (fewer if they do not fit in free memory); establishes the arena invariants.
+int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slots_out) {
+  int n_slots = n_want;
+  if (T_max <= d->slab_T) n_slots = std::min(n_slots, d->slot_limit);  // an earlier batch found that more do not fit
+  if (n_slots > d->slab_slots || T_max > d->slab_T) {
+    PoolFree(d->slab);
+    d->slab = nullptr;
+    size_t slab_bytes = 0;
+    // leave room for the lattice pool and the caller: all but 16 GB of what is free
+    // (blocks cached by the library's own pool count as free: PoolMalloc returns
+    // them to HIP when an allocation fails)
+    size_t free_b = 0, total_b = 0;
+    KH_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += PoolCachedBytes();
+    const size_t budget = free_b > (16ull << 30) ? free_b - (16ull << 30) : free_b / 2;
+    const int want_slots = n_slots;
+    for (;; n_slots = (n_slots + 1) / 2) {
+      Carver sizer{nullptr};
+      for (int i = 0; i < n_slots; i++) {
+        Utt tmp;
+        CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio, d->expected_tokens);
+      }
+      slab_bytes = sizer.off;
+      if (slab_bytes <= budget || n_slots == 1) {
+        d->slab = PoolMalloc(slab_bytes);
+        if (d->slab || n_slots == 1) break;
+      }
+    }
+    if (!d->slab) { d->slab_bytes = 0; d->slab_slots = 0; return KH_ENOMEM; }
+    if (getenv("KH_DECODER_PROFILE"))
+      fprintf(stderr, "[kh_decoder profile] arenas: %d slots (wanted %d) x %.1f MB = %.1f GB; device memory free %.1f GB of %.1f GB\n",
+              n_slots, want_slots, slab_bytes / 1e6 / n_slots, slab_bytes / 1e9, free_b / 1e9, total_b / 1e9);
+    d->slot_limit = n_slots < want_slots ? n_slots : std::numeric_limits<int>::max();
+    Carver sizer{nullptr};
+    sizer.off = slab_bytes;
+    d->slab_bytes = sizer.off;
+    d->slab_slots = n_slots;
+    d->slab_T = T_max;
+    d->h_slots.assign(n_slots, Utt());
+    Carver carver{static_cast<char *>(d->slab)};
+    for (int i = 0; i < n_slots; i++)
+      CarveSlot(carver, d->h_slots[i], T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval,
+                d->cfg.hash_ratio, d->expected_tokens);
+    // arena invariants for the first utterance of every slot (later ones are
+    // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
+    for (int i = 0; i < n_slots; i++) {
+      Utt &u = d->h_slots[i];
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
+      KH_HIP(hipMemsetAsync((void *)(unsigned long long *)u.hash, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
+      KH_HIP(hipMemsetAsync((void *)(int32_t *)u.tmp_dirty, 0, sizeof(int32_t) * u.tok_frame_cap, st));
+    }
+    PoolFree(d->d_slots);
+    d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
+    if (!d->d_slots) return KH_ENOMEM;
+  } else {
+    // slots were left with dirty token costs by the previous call: refill
+    for (int i = 0; i < n_slots; i++) {
+      Utt &u = d->h_slots[i];
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
+    }
+  }
+  *n_slots_out = n_slots;
+  return KH_OK;
+}
+
+void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *tid2pdf) {
+  Params &p = *pp;
+  p.e_off = (GP(const int32_t))d->fst->e_off;
+  p.n_off = (GP(const int32_t))d->fst->n_off;
+  p.e_arcs = (GP(const KhInt4))d->fst->e_arcs;
+  p.n_arcs = (GP(const KhInt4))d->fst->n_arcs;
+  p.final_cost = (GP(const float))d->fst->final_cost;
+  p.start = d->fst->start;
+  p.num_states = d->fst->num_states;
+  p.num_emit = static_cast<int32_t>(d->fst->num_emit);
+  p.num_eps = static_cast<int32_t>(d->fst->num_eps);
+  p.start_has_eps = d->fst->start_has_eps;
+  // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
+  p.ll_cols = ll_stride <= 12288 ? ll_stride : 0;
+  if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
+  p.tid2pdf = (GP(const int32_t))tid2pdf;
+  p.max_tid = d->fst->max_ilabel;
+  p.beam = d->cfg.beam;
+  p.lattice_beam = d->cfg.lattice_beam;
+  p.beam_delta = d->cfg.beam_delta;
+  p.prune_scale = d->cfg.prune_scale;
+  p.max_active = d->cfg.max_active;
+  p.min_active = d->cfg.min_active;
+  p.prune_interval = d->cfg.prune_interval;
+}
+
+// Lattice pool of pool_tok tokens / pool_link links (grown on demand).
+int EnsurePool(KhDecoder *d, long long pool_tok, long long pool_link) {
+    {
+      Carver sizer{nullptr};
+      sizer.Take<int32_t>(pool_tok); sizer.Take<int32_t>(pool_tok);
+      for (int k = 0; k < 4; k++) sizer.Take<int32_t>(pool_link);
+      sizer.Take<float>(pool_link); sizer.Take<float>(pool_link);
+      if (sizer.off > d->pool_bytes) {
+        PoolFree(d->pool_slab);
+        d->pool_slab = PoolMalloc(sizer.off);
+        if (!d->pool_slab) { d->pool_bytes = 0; return KH_ENOMEM; }
+        d->pool_bytes = sizer.off;
+      }
+      Carver c{static_cast<char *>(d->pool_slab)};
+      d->pool.t_frame = c.Take<int32_t>(pool_tok);
+      d->pool.t_state = c.Take<int32_t>(pool_tok);
+      d->pool.l_src = c.Take<int32_t>(pool_link);
+      d->pool.l_dst = c.Take<int32_t>(pool_link);
+      d->pool.l_il = c.Take<int32_t>(pool_link);
+      d->pool.l_ol = c.Take<int32_t>(pool_link);
+      d->pool.l_g = c.Take<float>(pool_link);
+      d->pool.l_a = c.Take<float>(pool_link);
+      d->pool.tok_cap = pool_tok;
+      d->pool.link_cap = pool_link;
+      d->pool.used = (GP(unsigned long long))d->d_used;
+    }
+  return KH_OK;
+}
+
+// One D2H per pool array (the lattices the reference would build on the host in
+// GetRawLattice) into a new HostPool.
+int FetchPool(KhDecoder *d, const unsigned long long *used, long long pool_tok, long long pool_link, hipStream_t st) {
+    d->rounds.emplace_back();
+    KhDecoder::HostPool &hp = d->rounds.back();
+    const size_t ut = std::min<unsigned long long>(used[0], pool_tok), ul = std::min<unsigned long long>(used[1], pool_link);
+    hp.t_frame.resize(ut); hp.t_state.resize(ut);
+    hp.l_src.resize(ul); hp.l_dst.resize(ul); hp.l_il.resize(ul); hp.l_ol.resize(ul);
+    hp.l_g.resize(ul); hp.l_a.resize(ul);
+#define D2H(dst, src, n, type) if (n) KH_HIP(hipMemcpyAsync(dst.data(), src, sizeof(type) * (n), hipMemcpyDeviceToHost, st))
+    D2H(hp.t_frame, (int32_t *)d->pool.t_frame, ut, int32_t);
+    D2H(hp.t_state, (int32_t *)d->pool.t_state, ut, int32_t);
+    D2H(hp.l_src, (int32_t *)d->pool.l_src, ul, int32_t);
+    D2H(hp.l_dst, (int32_t *)d->pool.l_dst, ul, int32_t);
+    D2H(hp.l_il, (int32_t *)d->pool.l_il, ul, int32_t);
+    D2H(hp.l_ol, (int32_t *)d->pool.l_ol, ul, int32_t);
+    D2H(hp.l_g, (float *)d->pool.l_g, ul, float);
+    D2H(hp.l_a, (float *)d->pool.l_a, ul, float);
+#undef D2H
+    KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1832,7 +2127,7 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
   long long lf = 3 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
   d->link_frame_cap = static_cast<int>(lf);
-  d->max_slots = NumCUs() * (1024 / NT) * KH_WG_PER_CU;  // persistent workgroups: 1024 threads per CU
+  d->max_slots = NumCUs() * (NT >= 1024 ? 1 : 1024 / NT) * KH_WG_PER_CU;  // persistent workgroups
   if (const char *e = getenv("KH_DECODER_SLOTS")) d->max_slots = std::max(1, atoi(e));
   return d;
 }
@@ -1868,65 +2163,9 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     tot_frames += T;
   }
   // ---- slot arenas
-  int n_slots = std::min(n_utts, d->max_slots);
-  if (T_max <= d->slab_T) n_slots = std::min(n_slots, d->slot_limit);  // an earlier batch found that more do not fit
-  if (n_slots > d->slab_slots || T_max > d->slab_T) {
-    PoolFree(d->slab);
-    d->slab = nullptr;
-    size_t slab_bytes = 0;
-    // leave room for the lattice pool and the caller: all but 16 GB of what is free
-    // (blocks cached by the library's own pool count as free: PoolMalloc returns
-    // them to HIP when an allocation fails)
-    size_t free_b = 0, total_b = 0;
-    KH_HIP(hipMemGetInfo(&free_b, &total_b));
-    free_b += PoolCachedBytes();
-    const size_t budget = free_b > (16ull << 30) ? free_b - (16ull << 30) : free_b / 2;
-    const int want_slots = n_slots;
-    for (;; n_slots = (n_slots + 1) / 2) {
-      Carver sizer{nullptr};
-      for (int i = 0; i < n_slots; i++) {
-        Utt tmp;
-        CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio, d->expected_tokens);
-      }
-      slab_bytes = sizer.off;
-      if (slab_bytes <= budget || n_slots == 1) {
-        d->slab = PoolMalloc(slab_bytes);
-        if (d->slab || n_slots == 1) break;
-      }
-    }
-    if (!d->slab) { d->slab_bytes = 0; d->slab_slots = 0; return KH_ENOMEM; }
-    if (getenv("KH_DECODER_PROFILE"))
-      fprintf(stderr, "[kh_decoder profile] arenas: %d slots (wanted %d) x %.1f MB = %.1f GB; device memory free %.1f GB of %.1f GB\n",
-              n_slots, want_slots, slab_bytes / 1e6 / n_slots, slab_bytes / 1e9, free_b / 1e9, total_b / 1e9);
-    d->slot_limit = n_slots < want_slots ? n_slots : std::numeric_limits<int>::max();
-    Carver sizer{nullptr};
-    sizer.off = slab_bytes;
-    d->slab_bytes = sizer.off;
-    d->slab_slots = n_slots;
-    d->slab_T = T_max;
-    d->h_slots.assign(n_slots, Utt());
-    Carver carver{static_cast<char *>(d->slab)};
-    for (int i = 0; i < n_slots; i++)
-      CarveSlot(carver, d->h_slots[i], T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval,
-                d->cfg.hash_ratio, d->expected_tokens);
-    // arena invariants for the first utterance of every slot (later ones are
-    // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
-    for (int i = 0; i < n_slots; i++) {
-      Utt &u = d->h_slots[i];
-      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
-      KH_HIP(hipMemsetAsync((void *)(unsigned long long *)u.hash, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
-      KH_HIP(hipMemsetAsync((void *)(int32_t *)u.tmp_dirty, 0, sizeof(int32_t) * u.tok_frame_cap, st));
-    }
-    PoolFree(d->d_slots);
-    d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
-    if (!d->d_slots) return KH_ENOMEM;
-  } else {
-    // slots were left with dirty token costs by the previous call: refill
-    for (int i = 0; i < n_slots; i++) {
-      Utt &u = d->h_slots[i];
-      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
-    }
-  }
+  int n_slots = 0;
+  rc = EnsureSlots(d, std::min(n_utts, d->max_slots), T_max, st, &n_slots);
+  if (rc) return rc;
   for (int i = 0; i < n_slots; i++) d->h_slots[i].ll_stride = ll_stride;
   KH_HIP(hipMemcpyAsync(d->d_slots, d->h_slots.data(), sizeof(Utt) * n_slots, hipMemcpyHostToDevice, st));
   if (!d->d_in) {
@@ -1945,28 +2184,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   std::stable_sort(d->order.begin(), d->order.end(),
                    [&](int a, int b) { return d->h_T[a] > d->h_T[b]; });
   Params p;
-  p.e_off = (GP(const int32_t))d->fst->e_off;
-  p.n_off = (GP(const int32_t))d->fst->n_off;
-  p.e_arcs = (GP(const KhInt4))d->fst->e_arcs;
-  p.n_arcs = (GP(const KhInt4))d->fst->n_arcs;
-  p.final_cost = (GP(const float))d->fst->final_cost;
-  p.start = d->fst->start;
-  p.num_states = d->fst->num_states;
-  p.num_emit = static_cast<int32_t>(d->fst->num_emit);
-  p.num_eps = static_cast<int32_t>(d->fst->num_eps);
-  p.start_has_eps = d->fst->start_has_eps;
-  // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
-  p.ll_cols = ll_stride <= 12288 ? ll_stride : 0;
-  if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
-  p.tid2pdf = (GP(const int32_t))tid2pdf;
-  p.max_tid = d->fst->max_ilabel;
-  p.beam = d->cfg.beam;
-  p.lattice_beam = d->cfg.lattice_beam;
-  p.beam_delta = d->cfg.beam_delta;
-  p.prune_scale = d->cfg.prune_scale;
-  p.max_active = d->cfg.max_active;
-  p.min_active = d->cfg.min_active;
-  p.prune_interval = d->cfg.prune_interval;
+  FillParams(d, &p, ll_stride, tid2pdf);
   if (!d->ev0) {
     KH_HIP(hipEventCreate(&d->ev0));
     KH_HIP(hipEventCreate(&d->ev1));
@@ -1996,30 +2214,8 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     for (int ui : pending) frames += d->h_T[ui];
     const long long pool_tok = round == 0 ? frames * tok_per_frame + 65536 : need_tok + 1024;
     const long long pool_link = round == 0 ? frames * link_per_frame + 131072 : need_link + 1024;
-    {
-      Carver sizer{nullptr};
-      sizer.Take<int32_t>(pool_tok); sizer.Take<int32_t>(pool_tok);
-      for (int k = 0; k < 4; k++) sizer.Take<int32_t>(pool_link);
-      sizer.Take<float>(pool_link); sizer.Take<float>(pool_link);
-      if (sizer.off > d->pool_bytes) {
-        PoolFree(d->pool_slab);
-        d->pool_slab = PoolMalloc(sizer.off);
-        if (!d->pool_slab) { d->pool_bytes = 0; return KH_ENOMEM; }
-        d->pool_bytes = sizer.off;
-      }
-      Carver c{static_cast<char *>(d->pool_slab)};
-      d->pool.t_frame = c.Take<int32_t>(pool_tok);
-      d->pool.t_state = c.Take<int32_t>(pool_tok);
-      d->pool.l_src = c.Take<int32_t>(pool_link);
-      d->pool.l_dst = c.Take<int32_t>(pool_link);
-      d->pool.l_il = c.Take<int32_t>(pool_link);
-      d->pool.l_ol = c.Take<int32_t>(pool_link);
-      d->pool.l_g = c.Take<float>(pool_link);
-      d->pool.l_a = c.Take<float>(pool_link);
-      d->pool.tok_cap = pool_tok;
-      d->pool.link_cap = pool_link;
-      d->pool.used = (GP(unsigned long long))d->d_used;
-    }
+    rc = EnsurePool(d, pool_tok, pool_link);
+    if (rc) return rc;
     std::vector<UttIn> h_in(np);
     for (int q = 0; q < np; q++) {
       const int ui = pending[q];
@@ -2122,25 +2318,8 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       d->h_out[ui] = q_out[q];
       d->h_round[ui] = round;
     }
-    // ---- one D2H per pool array for the launch (the lattices the reference would
-    // build on the host in GetRawLattice)
-    d->rounds.emplace_back();
-    KhDecoder::HostPool &hp = d->rounds.back();
-    const size_t ut = std::min<unsigned long long>(used[0], pool_tok), ul = std::min<unsigned long long>(used[1], pool_link);
-    hp.t_frame.resize(ut); hp.t_state.resize(ut);
-    hp.l_src.resize(ul); hp.l_dst.resize(ul); hp.l_il.resize(ul); hp.l_ol.resize(ul);
-    hp.l_g.resize(ul); hp.l_a.resize(ul);
-#define D2H(dst, src, n, type) if (n) KH_HIP(hipMemcpyAsync(dst.data(), src, sizeof(type) * (n), hipMemcpyDeviceToHost, st))
-    D2H(hp.t_frame, (int32_t *)d->pool.t_frame, ut, int32_t);
-    D2H(hp.t_state, (int32_t *)d->pool.t_state, ut, int32_t);
-    D2H(hp.l_src, (int32_t *)d->pool.l_src, ul, int32_t);
-    D2H(hp.l_dst, (int32_t *)d->pool.l_dst, ul, int32_t);
-    D2H(hp.l_il, (int32_t *)d->pool.l_il, ul, int32_t);
-    D2H(hp.l_ol, (int32_t *)d->pool.l_ol, ul, int32_t);
-    D2H(hp.l_g, (float *)d->pool.l_g, ul, float);
-    D2H(hp.l_a, (float *)d->pool.l_a, ul, float);
-#undef D2H
-    KH_HIP(hipStreamSynchronize(st));
+    rc = FetchPool(d, used, pool_tok, pool_link, st);
+    if (rc) return rc;
     pending.swap(next);
   }
   return KH_OK;
@@ -2247,6 +2426,296 @@ int kh_decoder_prepare(KhDecoder *d, int num_threads) {
     return first_rc.load();
   }
   return KH_OK;
+}
+
+
+// ================================================================ online decoding
+KhOnlineDecoder *kh_online_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int num_streams,
+                                          int max_frames) {
+  KhDecoder *b = kh_decoder_create(fst, cfg, num_streams, max_frames);
+  if (!b) return nullptr;
+  KhOnlineDecoder *o = new KhOnlineDecoder();
+  o->base = b;
+  o->num_streams = num_streams;
+  o->max_frames = max_frames;
+  hipStream_t st = Stream();
+  int n_slots = 0;
+  int rc = EnsureSlots(b, num_streams, max_frames, st, &n_slots);
+  if (rc == KH_OK && n_slots < num_streams) {
+    SetError("kh_online_decoder_create: only %d of %d streams fit in device memory", n_slots, num_streams);
+    rc = KH_ENOMEM;
+  }
+  if (rc == KH_OK) {
+    o->d_states = static_cast<SlotState *>(PoolMalloc(sizeof(SlotState) * num_streams));
+    o->d_jobs = static_cast<Job *>(PoolMalloc(sizeof(Job) * num_streams));
+    b->d_out = static_cast<UttOut *>(PoolMalloc(sizeof(UttOut) * num_streams));
+    b->d_used = static_cast<unsigned long long *>(PoolMalloc(sizeof(unsigned long long) * 4));
+    if (!o->d_states || !o->d_jobs || !b->d_out || !b->d_used) rc = KH_ENOMEM;
+  }
+  if (rc == KH_OK && hipMemsetAsync(o->d_states, 0, sizeof(SlotState) * num_streams, st) != hipSuccess) rc = KH_EDEVICE;
+  if (rc == KH_OK && hipMemcpyAsync(b->d_slots, b->h_slots.data(), sizeof(Utt) * num_streams, hipMemcpyHostToDevice, st) != hipSuccess) rc = KH_EDEVICE;
+  if (rc == KH_OK && hipStreamSynchronize(st) != hipSuccess) rc = KH_EDEVICE;
+  if (rc != KH_OK) {
+    kh_online_decoder_destroy(o);
+    return nullptr;
+  }
+  b->n_utts = num_streams;
+  b->lats.assign(num_streams, KhDecoder::Lat());
+  b->h_out.assign(num_streams, UttOut());
+  b->h_T.assign(num_streams, 0);
+  b->h_round.assign(num_streams, 0);
+  o->frames.assign(num_streams, 0);
+  o->inited.assign(num_streams, 0);
+  o->finalized.assign(num_streams, 0);
+  o->lat_key.assign(num_streams, -1);
+  return o;
+}
+
+void kh_online_decoder_destroy(KhOnlineDecoder *o) {
+  if (!o) return;
+  PoolFree(o->d_states);
+  PoolFree(o->d_jobs);
+  kh_decoder_destroy(o->base);
+  delete o;
+}
+
+static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_stride, const int32_t *tid2pdf) {
+  KhDecoder *b = o->base;
+  hipStream_t st = Stream();
+  Params p;
+  FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
+  if (ll_stride <= 0) p.ll_cols = 0;
+  KH_HIP(hipMemcpyAsync(o->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(OnlineKernel, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), sizeof(float) * p.ll_cols, st,
+                     b->d_slots, o->d_states, o->d_jobs, b->d_out, b->pool, p);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+// kernel status of the listed streams -> error
+static int CheckStreams(KhOnlineDecoder *o, const int32_t *streams, int n, const char *what) {
+  hipStream_t st = Stream();
+  std::vector<SlotState> hs(o->num_streams);
+  KH_HIP(hipMemcpyAsync(hs.data(), o->d_states, sizeof(SlotState) * o->num_streams, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; i++) {
+    const SlotState &S = hs[streams[i]];
+    if (!S.ok) {
+      SetError("%s: stream %d overflowed a decoder arena (code %d) at frame %d; see KH_DECODER_TOKENS_PER_FRAME / "
+               "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME", what, streams[i], S.status, S.t);
+      return KH_ECAPACITY;
+    }
+    o->frames[streams[i]] = S.t;
+  }
+  return KH_OK;
+}
+
+static bool DistinctStreams(const KhOnlineDecoder *o, const int32_t *streams, int n) {
+  std::vector<char> seen(o->num_streams, 0);
+  for (int i = 0; i < n; i++) {
+    if (streams[i] < 0 || streams[i] >= o->num_streams || seen[streams[i]]) return false;
+    seen[streams[i]] = 1;
+  }
+  return true;
+}
+
+// InitDecoding (lattice-faster-online-decoder.cc:55-72) of the listed streams.
+int kh_online_decoder_init_decoding(KhOnlineDecoder *o, const int32_t *streams, int n) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o && streams && n > 0 && n <= o->num_streams && DistinctStreams(o, streams, n));
+  std::vector<Job> jobs(n);
+  for (int i = 0; i < n; i++) {
+    jobs[i].slot = streams[i];
+    jobs[i].op = kJobInit;
+    jobs[i].ll = (GP(const float))nullptr;
+    jobs[i].ll_stride = 0;
+    jobs[i].n_frames = 0;
+    o->inited[streams[i]] = 1;
+    o->finalized[streams[i]] = 0;
+    o->lat_key[streams[i]] = -1;
+  }
+  rc = LaunchJobs(o, jobs, 0, nullptr);
+  if (rc) return rc;
+  return CheckStreams(o, streams, n, "kh_online_decoder_init_decoding");
+}
+
+// AdvanceDecoding (:747-769): stream streams[i] decodes the next num_frames[i] frames,
+// whose scaled log-likelihoods are the rows of loglikes[i] (device, row stride
+// ll_stride, full rows allocated).
+int kh_online_decoder_advance(KhOnlineDecoder *o, const int32_t *streams, int n, const float *const *loglikes,
+                              int ll_stride, const int32_t *num_frames, const int32_t *tid2pdf) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o && streams && loglikes && num_frames && n > 0 && n <= o->num_streams && ll_stride > 0 &&
+               DistinctStreams(o, streams, n));
+  std::vector<Job> jobs;
+  for (int i = 0; i < n; i++) {
+    const int sidx = streams[i];
+    if (!o->inited[sidx] || o->finalized[sidx]) {
+      SetError("kh_online_decoder_advance: stream %d: call InitDecoding() first, and not after FinalizeDecoding() "
+               "(lattice-faster-online-decoder.cc:749-750)", sidx);
+      return KH_ESTATE;
+    }
+    KH_CHECK_ARG(num_frames[i] >= 0 && o->frames[sidx] + num_frames[i] <= o->max_frames);
+    if (num_frames[i] == 0) continue;
+    KH_CHECK_ARG(loglikes[i] != nullptr);
+    Job j;
+    j.slot = sidx;
+    j.op = kJobAdvance;
+    // the kernel addresses the matrix by absolute frame
+    j.ll = (GP(const float))(loglikes[i] - static_cast<ptrdiff_t>(o->frames[sidx]) * ll_stride);
+    j.ll_stride = ll_stride;
+    j.n_frames = num_frames[i];
+    jobs.push_back(j);
+    o->lat_key[sidx] = -1;
+  }
+  if (jobs.empty()) return KH_OK;
+  rc = LaunchJobs(o, jobs, ll_stride, tid2pdf);
+  if (rc) return rc;
+  return CheckStreams(o, streams, n, "kh_online_decoder_advance");
+}
+
+int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *o, int stream, int32_t *num_frames) {
+  KH_CHECK_ARG(o && num_frames && stream >= 0 && stream < o->num_streams);
+  *num_frames = o->frames[stream];
+  return KH_OK;
+}
+
+// FinalizeDecoding (:775-790) of the listed streams.
+int kh_online_decoder_finalize(KhOnlineDecoder *o, const int32_t *streams, int n) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o && streams && n > 0 && n <= o->num_streams && DistinctStreams(o, streams, n));
+  std::vector<Job> jobs(n);
+  for (int i = 0; i < n; i++) {
+    const int sidx = streams[i];
+    if (!o->inited[sidx] || o->finalized[sidx]) {
+      SetError("kh_online_decoder_finalize: stream %d is not in a decoding run", sidx);
+      return KH_ESTATE;
+    }
+    jobs[i].slot = sidx;
+    jobs[i].op = kJobFinalize;
+    jobs[i].ll = (GP(const float))nullptr;
+    jobs[i].ll_stride = 0;
+    jobs[i].n_frames = 0;
+    o->finalized[sidx] = 1;
+    o->lat_key[sidx] = -1;
+  }
+  rc = LaunchJobs(o, jobs, 0, nullptr);
+  if (rc) return rc;
+  return CheckStreams(o, streams, n, "kh_online_decoder_finalize");
+}
+
+// Snapshot of a stream's raw lattice into base->lats[stream] (GetRawLattice,
+// lattice-faster-online-decoder.cc:143-233: before FinalizeDecoding the final costs are
+// computed on the fly when use_final_probs is set, :160-165).
+static int SnapshotLattice(KhOnlineDecoder *o, int stream, int use_final_probs) {
+  KhDecoder *b = o->base;
+  KH_CHECK_ARG(stream >= 0 && stream < o->num_streams);
+  if (!o->inited[stream]) {
+    SetError("stream %d: InitDecoding() has not been called", stream);
+    return KH_ESTATE;
+  }
+  if (o->finalized[stream] && !use_final_probs) {
+    SetError("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false "
+             "(lattice-faster-online-decoder.cc:156-158)");
+    return KH_ESTATE;
+  }
+  if (o->frames[stream] <= 0) {
+    SetError("stream %d: no frames decoded yet (lattice-faster-online-decoder.cc:171)", stream);
+    return KH_ESTATE;
+  }
+  const long long key = (static_cast<long long>(o->frames[stream]) << 2) | (use_final_probs ? 2 : 0) | (o->finalized[stream] ? 1 : 0);
+  if (o->lat_key[stream] == key) return KH_OK;
+  hipStream_t st = Stream();
+  long long pool_tok = 65536 + 512ll * o->frames[stream], pool_link = 131072 + 1024ll * o->frames[stream];
+  UttOut q;
+  for (int attempt = 0;; attempt++) {
+    int rc = EnsurePool(b, pool_tok, pool_link);
+    if (rc) return rc;
+    KH_HIP(hipMemsetAsync(b->d_used, 0, sizeof(unsigned long long) * 4, st));
+    std::vector<Job> jobs(1);
+    jobs[0].slot = stream;
+    jobs[0].op = kJobExport;
+    jobs[0].ll = (GP(const float))nullptr;
+    jobs[0].ll_stride = 0;
+    jobs[0].n_frames = 0;
+    rc = LaunchJobs(o, jobs, 0, nullptr);
+    if (rc) return rc;
+    unsigned long long used[4] = {0, 0, 0, 0};
+    KH_HIP(hipMemcpyAsync(&q, b->d_out, sizeof(UttOut), hipMemcpyDeviceToHost, st));
+    KH_HIP(hipMemcpyAsync(used, b->d_used, sizeof(used), hipMemcpyDeviceToHost, st));
+    KH_HIP(hipStreamSynchronize(st));
+    if (q.stats.status == 6 && attempt == 0) {  // pool too small: the exact size is known now
+      pool_tok = q.n_tok + 1024;
+      pool_link = q.n_link + 1024;
+      continue;
+    }
+    if (q.stats.status != 0) {
+      SetError("stream %d: decoder capacity overflow (code %d)", stream, q.stats.status);
+      return KH_ECAPACITY;
+    }
+    b->rounds.clear();
+    rc = FetchPool(b, used, pool_tok, pool_link, st);
+    if (rc) return rc;
+    break;
+  }
+  b->h_round[stream] = 0;
+  b->h_T[stream] = o->frames[stream];
+  KhDecoder::HostPool &hp = b->rounds[0];
+  if (!o->finalized[stream]) {
+    // ComputeFinalCosts :309 (:860-900) on the current last frame
+    const float inf = std::numeric_limits<float>::infinity();
+    bool any_final = false;
+    float best = inf, best_final = inf;
+    (void)best; (void)best_final;
+    if (use_final_probs)
+      for (int k = 0; k < q.n_tok; k++)
+        if (hp.t_frame[q.tok_off + k] == o->frames[stream] && b->fst->final_host[hp.t_state[q.tok_off + k]] != inf) any_final = true;
+    q.stats.reached_final = any_final ? 1 : 0;
+  }
+  b->h_out[stream] = q;
+  b->lats[stream] = KhDecoder::Lat();
+  int rc = BuildLattice(b, stream);
+  b->rounds.clear();
+  if (rc) return rc;
+  o->lat_key[stream] = key;
+  return KH_OK;
+}
+
+int kh_online_decoder_get_stats(KhOnlineDecoder *o, int stream, int use_final_probs, KhDecodeStats *stats) {
+  KH_CHECK_ARG(o && stats);
+  int rc = SnapshotLattice(o, stream, use_final_probs);
+  if (rc) return rc;
+  *stats = o->base->h_out[stream].stats;
+  stats->num_tokens = static_cast<int32_t>(o->base->lats[stream].state_frame.size());
+  stats->num_links = static_cast<int32_t>(o->base->lats[stream].arc_src.size());
+  return KH_OK;
+}
+
+int kh_online_decoder_get_raw_lattice(KhOnlineDecoder *o, int stream, int use_final_probs, int32_t *state_frame,
+                                      int32_t *state_hclg, float *state_final, int32_t *arc_src, int32_t *arc_dst,
+                                      int32_t *arc_ilabel, int32_t *arc_olabel, float *arc_graph,
+                                      float *arc_acoustic) {
+  KH_CHECK_ARG(o);
+  int rc = SnapshotLattice(o, stream, use_final_probs);
+  if (rc) return rc;
+  return kh_decoder_get_raw_lattice(o->base, stream, state_frame, state_hclg, state_final, arc_src, arc_dst,
+                                    arc_ilabel, arc_olabel, arc_graph, arc_acoustic);
+}
+
+// GetBestPath (:107-108): the reference traces token backpointers (BestPathEnd /
+// TraceBackBestPath); here it is the shortest path of the same raw lattice, which
+// TestGetBestPath (:113) checks to be equivalent.
+int kh_online_decoder_get_best_path(KhOnlineDecoder *o, int stream, int use_final_probs, int32_t *alignment,
+                                    int cap_ali, int32_t *n_ali, int32_t *words, int cap_words, int32_t *n_words,
+                                    float *graph_cost, float *acoustic_cost) {
+  KH_CHECK_ARG(o);
+  int rc = SnapshotLattice(o, stream, use_final_probs);
+  if (rc) return rc;
+  return kh_decoder_get_best_path(o->base, stream, alignment, cap_ali, n_ali, words, cap_words, n_words, graph_cost,
+                                  acoustic_cost);
 }
 
 }  // extern "C"

@@ -368,5 +368,67 @@ class LatticeFasterDecoder {
   KhDecoder *dec_;
 };
 
+/// decoder/lattice-faster-online-decoder.h:44-200 for num_streams concurrent
+/// utterances (stream = index).  AdvanceDecoding takes, per stream, the device matrix
+/// of the next frames' scaled log-likelihoods (what DecodableNnet2Online serves).
+class LatticeFasterOnlineDecoder {
+ public:
+  LatticeFasterOnlineDecoder(KhFst *fst, const LatticeFasterDecoderConfig &config, int num_streams, int max_frames)
+      : dec_(NULL) {
+    KhDecoderConfig c = config.ToC();
+    dec_ = kh_online_decoder_create(fst, &c, num_streams, max_frames);
+    if (!dec_) KhCheck(KH_EINVAL);
+  }
+  ~LatticeFasterOnlineDecoder() { kh_online_decoder_destroy(dec_); }
+  void InitDecoding(const std::vector<int32> &streams) {
+    KhCheck(kh_online_decoder_init_decoding(dec_, streams.data(), static_cast<int>(streams.size())));
+  }
+  /// loglikes[i]: device pointer to num_frames[i] rows of `stride` floats for streams[i].
+  void AdvanceDecoding(const std::vector<int32> &streams, const std::vector<const BaseFloat *> &loglikes, int32 stride,
+                       const std::vector<int32> &num_frames, const int32 *tid2pdf) {
+    KhCheck(kh_online_decoder_advance(dec_, streams.data(), static_cast<int>(streams.size()), loglikes.data(), stride,
+                                      num_frames.data(), tid2pdf));
+  }
+  void FinalizeDecoding(const std::vector<int32> &streams) {
+    KhCheck(kh_online_decoder_finalize(dec_, streams.data(), static_cast<int>(streams.size())));
+  }
+  int32 NumFramesDecoded(int stream) const {
+    int32 n = 0;
+    KhCheck(kh_online_decoder_num_frames_decoded(dec_, stream, &n));
+    return n;
+  }
+  bool GetRawLattice(int stream, RawLattice *lat, bool use_final_probs = true) const {
+    KhDecodeStats st;
+    KhCheck(kh_online_decoder_get_stats(dec_, stream, use_final_probs, &st));
+    const size_t n = st.num_tokens, m = st.num_links;
+    lat->state_frame.resize(n); lat->state_hclg.resize(n); lat->state_final.resize(n);
+    lat->arc_src.resize(m); lat->arc_dst.resize(m); lat->arc_ilabel.resize(m); lat->arc_olabel.resize(m);
+    lat->arc_graph.resize(m); lat->arc_acoustic.resize(m);
+    KhCheck(kh_online_decoder_get_raw_lattice(dec_, stream, use_final_probs, lat->state_frame.data(),
+                                              lat->state_hclg.data(), lat->state_final.data(), lat->arc_src.data(),
+                                              lat->arc_dst.data(), lat->arc_ilabel.data(), lat->arc_olabel.data(),
+                                              lat->arc_graph.data(), lat->arc_acoustic.data()));
+    return n > 0;
+  }
+  bool GetBestPath(int stream, std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost,
+                   BaseFloat *acoustic_cost, bool use_final_probs = true) const {
+    const int32 T = NumFramesDecoded(stream);
+    alignment->resize(T + 16);
+    words->resize(4 * T + 64);
+    int32 na = 0, nw = 0;
+    KhCheck(kh_online_decoder_get_best_path(dec_, stream, use_final_probs, alignment->data(),
+                                            static_cast<int>(alignment->size()), &na, words->data(),
+                                            static_cast<int>(words->size()), &nw, graph_cost, acoustic_cost));
+    alignment->resize(na);
+    words->resize(nw);
+    return true;
+  }
+
+ private:
+  LatticeFasterOnlineDecoder(const LatticeFasterOnlineDecoder &);
+  LatticeFasterOnlineDecoder &operator=(const LatticeFasterOnlineDecoder &);
+  KhOnlineDecoder *dec_;
+};
+
 }  // namespace kaldi
 #endif  // KALDI_HIP_HOST_H_

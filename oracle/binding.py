@@ -397,6 +397,31 @@ class DecoderOracle:
         t2p = _ip(self.tid2pdf) if self.tid2pdf is not None else None
         return bool(self.lib.ko_decoder_decode(self.h, _fp(ll), ll.shape[0], ll.shape[1], t2p))
 
+    # LatticeFasterOnlineDecoder call sequence (lattice-faster-online-decoder.cc)
+    def begin(self, loglikes):
+        """InitDecoding over a decodable that has all rows of `loglikes` ready."""
+        ll = _f32(loglikes)
+        self._ll = ll
+        t2p = _ip(self.tid2pdf) if self.tid2pdf is not None else None
+        self.lib.ko_decoder_begin.argtypes = [C.c_void_p, c_float_p, C.c_int, C.c_int, c_int_p]
+        self.lib.ko_decoder_begin(self.h, _fp(ll), ll.shape[0], ll.shape[1], t2p)
+
+    def advance(self, max_num_frames=-1):
+        """AdvanceDecoding(decodable, max_num_frames); returns NumFramesDecoded()."""
+        self.lib.ko_decoder_advance.argtypes = [C.c_void_p, C.c_int]
+        return int(self.lib.ko_decoder_advance(self.h, int(max_num_frames)))
+
+    def finalize(self):
+        self.lib.ko_decoder_finalize.argtypes = [C.c_void_p]
+        self.lib.ko_decoder_finalize(self.h)
+
+    def snapshot(self, use_final_probs=True):
+        """GetRawLattice(use_final_probs) at the current point; the getters below then
+        describe that lattice."""
+        self.lib.ko_decoder_snapshot.argtypes = [C.c_void_p, C.c_int]
+        if self.lib.ko_decoder_snapshot(self.h, int(bool(use_final_probs))) != 0:
+            raise RuntimeError("no lattice")
+
     def stats(self):
         st = KoDecodeStats()
         self.lib.ko_decoder_get_stats(self.h, C.byref(st))

@@ -238,6 +238,29 @@ class Decoder {
     return !active_toks_.empty() && active_toks_.back().toks != NULL;
   }
 
+  // LatticeFasterOnlineDecoder::InitDecoding / AdvanceDecoding / FinalizeDecoding
+  // (decoder/lattice-faster-online-decoder.cc:55-72,747-769,775-790): the same search
+  // advanced a chunk at a time over a decodable with num_frames_ready frames.
+  void Begin(const float *loglikes, int num_frames_ready, int ll_stride, const int32_t *tid2pdf) {
+    ll_ = loglikes;
+    ll_stride_ = ll_stride;
+    num_frames_ = num_frames_ready;
+    tid2pdf_ = tid2pdf;
+    InitDecoding();
+  }
+  void Advance(int max_num_frames) {
+    int32_t target = num_frames_;
+    if (max_num_frames >= 0) target = std::min(target, NumFramesDecoded() + max_num_frames);
+    while (NumFramesDecoded() < target) {
+      if (NumFramesDecoded() % config_.prune_interval == 0)
+        PruneActiveTokens(config_.lattice_beam * config_.prune_scale);
+      BaseFloat cost_cutoff = ProcessEmitting();
+      ProcessNonemitting(cost_cutoff);
+    }
+  }
+  void Finish() { FinalizeDecoding(); }
+  bool finalized() const { return decoding_finalized_; }
+
   inline int32_t NumFramesDecoded() const { return static_cast<int32_t>(active_toks_.size()) - 1; }
 
   // ---- results --------------------------------------------------------------------
@@ -250,7 +273,13 @@ class Decoder {
 
   // GetRawLattice lattice-faster-decoder.cc:109-191 (use_final_probs = true, after
   // FinalizeDecoding), emitted in canonical order instead of TopSortTokens order.
-  bool GetRawLattice(CanonLattice *lat) const {
+  bool GetRawLattice(CanonLattice *lat, bool use_final_probs = true) {
+    // lattice-faster-online-decoder.cc:156-165 (same in lattice-faster-decoder.cc:115-126)
+    if (decoding_finalized_ && !use_final_probs) return false;
+    std::unordered_map<Token *, BaseFloat> final_costs_local;
+    if (!decoding_finalized_ && use_final_probs) ComputeFinalCosts(&final_costs_local, NULL, NULL);
+    const std::unordered_map<Token *, BaseFloat> &final_costs_ =
+        decoding_finalized_ ? this->final_costs_ : final_costs_local;
     int32_t num_frames = static_cast<int32_t>(active_toks_.size()) - 1;
     struct Key { int32_t f, s; Token *t; };
     std::vector<Key> keys;
@@ -852,6 +881,34 @@ int ko_decoder_decode(void *hp, const float *loglikes, int T, int ll_stride, con
   Handle *h = static_cast<Handle *>(hp);
   h->have_lat = false;
   return h->dec->Decode(loglikes, T, ll_stride, tid2pdf) ? 1 : 0;
+}
+
+int ko_decoder_begin(void *hp, const float *loglikes, int num_frames_ready, int ll_stride, const int32_t *tid2pdf) {
+  Handle *h = static_cast<Handle *>(hp);
+  h->have_lat = false;
+  h->dec->Begin(loglikes, num_frames_ready, ll_stride, tid2pdf);
+  return 0;
+}
+
+int ko_decoder_advance(void *hp, int max_num_frames) {
+  Handle *h = static_cast<Handle *>(hp);
+  h->have_lat = false;
+  h->dec->Advance(max_num_frames);
+  return h->dec->NumFramesDecoded();
+}
+
+int ko_decoder_finalize(void *hp) {
+  Handle *h = static_cast<Handle *>(hp);
+  h->have_lat = false;
+  h->dec->Finish();
+  return 0;
+}
+
+// Snapshot for the getters below: GetRawLattice(ofst, use_final_probs) at the current point.
+int ko_decoder_snapshot(void *hp, int use_final_probs) {
+  Handle *h = static_cast<Handle *>(hp);
+  h->have_lat = h->dec->GetRawLattice(&h->lat, use_final_probs != 0);
+  return h->have_lat ? 0 : -1;
 }
 
 int ko_decoder_get_stats(void *hp, KoDecodeStats *st) {

@@ -49,6 +49,14 @@ typedef struct KoDecodeStats {
 void *ko_decoder_create(const KoFst *fst, const KoDecoderConfig *cfg, int mode);
 void ko_decoder_destroy(void *dec);
 int ko_decoder_decode(void *dec, const float *loglikes, int T, int ll_stride, const int32_t *tid2pdf);
+/* LatticeFasterOnlineDecoder call sequence (lattice-faster-online-decoder.cc:55-72,
+ * 747-769,775-790): begin = InitDecoding over a decodable with num_frames_ready rows,
+ * advance(max_num_frames) returns NumFramesDecoded(), finalize = FinalizeDecoding,
+ * snapshot = GetRawLattice(use_final_probs) at the current point for the getters. */
+int ko_decoder_begin(void *dec, const float *loglikes, int num_frames_ready, int ll_stride, const int32_t *tid2pdf);
+int ko_decoder_advance(void *dec, int max_num_frames);
+int ko_decoder_finalize(void *dec);
+int ko_decoder_snapshot(void *dec, int use_final_probs);
 int ko_decoder_get_stats(void *dec, KoDecodeStats *st);
 int ko_decoder_get_raw_lattice(void *dec, int32_t *state_frame, int32_t *state_hclg, float *state_final,
                                int32_t *arc_src, int32_t *arc_dst, int32_t *arc_il, int32_t *arc_ol,

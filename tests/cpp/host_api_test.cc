@@ -118,6 +118,28 @@ static void TestDecoder() {
   RawLattice lat;
   CHECK(dec.GetRawLattice(0, &lat));
   CHECK(lat.state_frame.size() == 4 && lat.arc_src.size() == 3);
+  // the same utterance through the online call sequence, one frame + two frames
+  LatticeFasterOnlineDecoder online(fst, cfg, 2, 8);
+  std::vector<int32> s1(1, 1);
+  online.InitDecoding(s1);
+  std::vector<const BaseFloat *> rows(1, L.Data());
+  std::vector<int32> nf(1, 1);
+  online.AdvanceDecoding(s1, rows, L.Stride(), nf, NULL);
+  CHECK(online.NumFramesDecoded(1) == 1);
+  RawLattice partial;
+  CHECK(online.GetRawLattice(1, &partial, false));
+  CHECK(partial.state_frame.back() == 1 && partial.state_final.back() == 0.f);
+  rows[0] = L.Data() + L.Stride();
+  nf[0] = 2;
+  online.AdvanceDecoding(s1, rows, L.Stride(), nf, NULL);
+  online.FinalizeDecoding(s1);
+  std::vector<int32> ali2, words2;
+  float g2, a2;
+  CHECK(online.GetBestPath(1, &ali2, &words2, &g2, &a2));
+  CHECK(ali2 == ali && words2 == words && g2 == g && a2 == a);
+  RawLattice lat2;
+  CHECK(online.GetRawLattice(1, &lat2));
+  CHECK(lat2.state_frame == lat.state_frame && lat2.arc_src == lat.arc_src && lat2.arc_graph == lat.arc_graph);
   kh_fst_destroy(fst);
 }
 
