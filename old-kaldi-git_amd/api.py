@@ -273,6 +273,94 @@ class Nnet:
         return out, out_off
 
 
+class DecodableNnet2Online:
+    """nnet2/online-nnet2-decodable.{h,cc} for num_streams concurrent utterances: the
+    feature rows of a stream arrive in chunks (the OnlineFeatureInterface side:
+    accept_features / input_finished), NumFramesReady() follows :75-89, and compute()
+    is ComputeForFrame (:91-143) for a list of streams at once — one gather of the
+    context-padded input rows (first / last frame duplicated past the edges when
+    pad_input), one NnetComputation(pad_input=false) over all of them, the
+    floor / log / -log prior / acoustic scale epilogue."""
+
+    def __init__(self, nnet, num_streams, max_frames, acoustic_scale=0.1, pad_input=True, max_nnet_batch_size=256,
+                 device="cuda"):
+        assert max_nnet_batch_size > 0  # :40
+        self.nnet, self.scale, self.pad_input, self.max_batch = nnet, float(acoustic_scale), bool(pad_input), int(max_nnet_batch_size)
+        self.num_streams, self.max_frames = int(num_streams), int(max_frames)
+        self.L, self.R = nnet.left_context(), nnet.right_context()
+        dim = nnet.input_dim()
+        stride = (dim + 3) // 4 * 4
+        self._feats = torch.empty((self.num_streams * self.max_frames, stride), dtype=torch.float32, device=device)[:, :dim]
+        self._n = [0] * self.num_streams
+        self._finished = [False] * self.num_streams
+
+    def reset(self, streams):
+        for s in streams:
+            self._n[s], self._finished[s] = 0, False
+
+    def accept_features(self, stream, feats, input_finished=False):
+        """Append rows (host array or device tensor) to the stream's features."""
+        assert not self._finished[stream], "input already finished"
+        x = feats if torch.is_tensor(feats) else torch.from_numpy(np.ascontiguousarray(feats, np.float32))
+        k = x.shape[0]
+        if self._n[stream] + k > self.max_frames:
+            raise KhError("DecodableNnet2Online: more than max_frames=%d feature frames" % self.max_frames)
+        if k:
+            b = stream * self.max_frames + self._n[stream]
+            self._feats[b:b + k].copy_(x)
+        self._n[stream] += k
+        self._finished[stream] = bool(input_finished)
+
+    def num_frames_ready(self, stream):
+        """NumFramesReady() :75-89."""
+        ready = self._n[stream]
+        if ready == 0:
+            return 0
+        if self.pad_input:
+            return ready if self._finished[stream] else max(0, ready - self.R)
+        return max(0, ready - self.R - self.L)
+
+    def is_last_frame(self, stream, frame):
+        """IsLastFrame() :67-73."""
+        last = self._n[stream] - 1 if self._finished[stream] else None
+        if last is None:
+            return False
+        return frame == last if self.pad_input else frame + self.L + self.R == last
+
+    def compute(self, streams, frames):
+        """Scaled log-likelihoods of frames [frames[i], frames[i] + n_i) of streams[i],
+        n_i = min(NumFramesReady - frames[i], max_nnet_batch_size) (ComputeForFrame).
+        Returns one device matrix per stream (0 rows if nothing is ready)."""
+        idx, off, n_out = [], [0], []
+        for s, f in zip(streams, frames):
+            ready = self._n[s]
+            n = max(0, min(self.num_frames_ready(s) - f, self.max_batch))
+            n_out.append(n)
+            if n == 0:
+                continue
+            begin = f - self.L if self.pad_input else f          # :103-107
+            t = np.arange(begin, begin + n + self.L + self.R)
+            t = np.clip(t, 0, ready - 1)                            # :118-124 (only ever clips when pad_input)
+            idx.append(s * self.max_frames + t)
+            off.append(off[-1] + len(t))
+        od = self.nnet.output_dim()
+        if not idx:
+            return [torch.empty((0, od), dtype=torch.float32, device=self._feats.device) for _ in streams]
+        idx = np.concatenate(idx).astype(np.int32)
+        stride = self._feats.stride(0)
+        x = torch.empty((len(idx), stride), dtype=torch.float32, device=self._feats.device)[:, :self._feats.shape[1]]
+        copy_rows(x, self._feats, idx)
+        out, out_off = self.nnet.compute(x, off, pad_input=False, epilogue=True, prob_scale=self.scale)
+        res, k = [], 0
+        for n in n_out:
+            if n == 0:
+                res.append(out[0:0])
+            else:
+                res.append(out[int(out_off[k]):int(out_off[k]) + n])
+                k += 1
+        return res
+
+
 # ---------------------------------------------------------------- DiagGmm
 def gmm_compute_gconsts(weights, means_invvars, inv_vars):
     """DiagGmm::ComputeGconsts (gmm/diag-gmm.cc:114-152); host arrays."""

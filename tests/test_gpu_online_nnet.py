@@ -1,0 +1,94 @@
+"""DecodableNnet2Online (nnet2/online-nnet2-decodable.{h,cc}) on the GPU: the scaled
+log-likelihoods served chunk by chunk are the rows DecodableAmNnet computes for the
+whole utterance (bit-identical: every output row is an independent k-ordered chain),
+and features -> lattice through the online call sequence equals the offline pipeline."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_decoder import assert_same_best_path, assert_same_lattice
+
+pytestmark = pytest.mark.gpu
+workloads = importlib.import_module("old-kaldi-git_amd.workloads")
+
+
+def _setup(api, rng, n_pdf=40):
+    comps, priors = workloads.tiny_net(rng, n_pdf=n_pdf)
+    return api.Nnet(comps, priors)
+
+
+@pytest.mark.parametrize("pad_input", [True, False])
+def test_chunked_loglikes_equal_whole_utterance(api, pad_input):
+    rng = np.random.default_rng(51)
+    nnet = _setup(api, rng)
+    L, R = nnet.left_context(), nnet.right_context()
+    Ts = [57, 9, 130]
+    feats = [rng.standard_normal((T, 13)).astype(np.float32) for T in Ts]
+    dec = api.DecodableNnet2Online(nnet, num_streams=3, max_frames=160, acoustic_scale=0.1, pad_input=pad_input,
+                                   max_nnet_batch_size=32)
+    got = [[] for _ in Ts]
+    fed, done = [0] * 3, [0] * 3
+    n_out = [T if pad_input else T - L - R for T in Ts]
+    while any(d < n for d, n in zip(done, n_out)):
+        for s in range(3):  # feature chunks arrive
+            if fed[s] < Ts[s]:
+                k = int(min(Ts[s] - fed[s], rng.integers(1, 30)))
+                dec.accept_features(s, feats[s][fed[s]:fed[s] + k], input_finished=fed[s] + k == Ts[s])
+                fed[s] += k
+        ready = [dec.num_frames_ready(s) for s in range(3)]
+        for s in range(3):
+            if fed[s] < Ts[s]:
+                assert ready[s] == max(0, fed[s] - R - (0 if pad_input else L))
+            else:
+                assert ready[s] == n_out[s]
+        act = [s for s in range(3) if done[s] < ready[s]]
+        outs = dec.compute(act, [done[s] for s in act])
+        for s, o in zip(act, outs):
+            assert 0 < o.shape[0] <= 32
+            got[s].append(o.cpu().numpy())
+            done[s] += o.shape[0]
+    for s, T in enumerate(Ts):
+        x = torch.from_numpy(feats[s]).cuda()
+        want, _ = nnet.compute(x, [0, T], pad_input=pad_input, epilogue=True, prob_scale=0.1)
+        want = want.cpu().numpy()
+        have = np.concatenate(got[s], 0)
+        assert have.shape == want.shape
+        assert np.array_equal(have.view(np.int32), want.view(np.int32))
+        assert dec.is_last_frame(s, n_out[s] - 1) and not dec.is_last_frame(s, n_out[s] - 2)
+
+
+def test_features_to_lattice_online_equals_offline(api):
+    rng = np.random.default_rng(52)
+    n_pdf = 40
+    nnet = _setup(api, rng, n_pdf)
+    g = workloads.make_hclg_like(rng, 5000, n_pdf)
+    cfg = api.decoder_config(beam=10.0, max_active=800, min_active=50, lattice_beam=5.0)
+    fst = api.Fst(g)
+    Ts = [75, 140]
+    feats = [rng.standard_normal((T, 13)).astype(np.float32) for T in Ts]
+    # offline: DecodableAmNnet + LatticeFasterDecoder
+    x = torch.from_numpy(np.concatenate(feats, 0)).cuda()
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+    ll, _ = nnet.compute(x, off, pad_input=True, epilogue=True, prob_scale=0.1)
+    offline = api.LatticeFasterDecoder(fst, cfg, max_batch=2, max_frames=max(Ts))
+    offline.decode(ll, off)
+    # online: chunks of 23 feature frames per stream
+    am = api.DecodableNnet2Online(nnet, num_streams=2, max_frames=160, acoustic_scale=0.1)
+    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=2, max_frames=160)
+    dec.init_decoding([0, 1])
+    fed = [0, 0]
+    while any(dec.num_frames_decoded(s) < Ts[s] for s in range(2)):
+        for s in range(2):
+            if fed[s] < Ts[s]:
+                k = min(23, Ts[s] - fed[s])
+                am.accept_features(s, feats[s][fed[s]:fed[s] + k], input_finished=fed[s] + k == Ts[s])
+                fed[s] += k
+        act = [s for s in range(2) if dec.num_frames_decoded(s) < am.num_frames_ready(s)]
+        chunks = am.compute(act, [dec.num_frames_decoded(s) for s in act])
+        dec.advance_decoding(act, chunks)                       # AdvanceDecoding(&decodable)
+    dec.finalize_decoding([0, 1])
+    for s in range(2):
+        assert_same_lattice(dec.get_raw_lattice(s), offline.get_raw_lattice(s))
+        assert_same_best_path(dec.get_best_path(s), offline.get_best_path(s))
