@@ -54,6 +54,15 @@ inline int64_t DivUp64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Number of CUs of the selected device (256 on MI355X).
 int NumCUs();
 
+// Fused tail of the nnet2 output layer (kh_elementwise.hip): SoftmaxComponent
+// (softmax + its 1e-20 floor, nnet-component.cc:929-943) -> SumGroupComponent, and
+// when log_priors != nullptr DecodableAmNnet's floor / log / -log prior / scale
+// (decodable-am-nnet.h:60-69), one pass over the logits.  Same operations in the same
+// order as the separate kernels.  Requires d_in.cols <= SoftmaxLdsCols().
+int FusedSoftmaxSumGroup(float *y, KhMatrixDim d_out, const float *x, KhMatrixDim d_in, const int32_t *ranges,
+                         const float *log_priors, float prob_scale);
+int SoftmaxLdsCols();
+
 }  // namespace kh
 
 // ---- device helpers --------------------------------------------------------------

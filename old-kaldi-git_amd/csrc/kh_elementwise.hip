@@ -73,6 +73,51 @@ SoftmaxKernel(float *__restrict__ y, const float *__restrict__ x, int cols,
   }
 }
 
+// Softmax (+1e-20 floor) -> sum over column ranges (-> floor, log, -log prior, scale):
+// the output layer of the nnet2 p-norm recipes in one pass, the row of probabilities
+// never leaves LDS.
+__global__ void __launch_bounds__(kBlock)
+SoftmaxSumGroupKernel(float *__restrict__ y, const float *__restrict__ x, int in_cols, int out_cols,
+                      int y_stride, int x_stride, const int32_t *__restrict__ ranges,
+                      const float *__restrict__ log_priors, float prob_scale) {
+  __shared__ float cache[kSoftmaxLdsFloats];
+  __shared__ float red[kBlock / 64];
+  const int r = blockIdx.x;
+  const float *xr = x + static_cast<size_t>(r) * x_stride;
+  float *yr = y + static_cast<size_t>(r) * y_stride;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < in_cols; c += kBlock) {
+    const float v = xr[c];
+    cache[c] = v;
+    m = fmaxf(m, v);
+  }
+  m = BlockMax(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < in_cols; c += kBlock) {
+    const float e = expf(cache[c] - m);
+    cache[c] = e;
+    s += e;
+  }
+  s = BlockSum(s, red);
+  const float inv = 1.0f / s;
+  for (int c = threadIdx.x; c < out_cols; c += kBlock) {
+    const int b = ranges[2 * c], e = ranges[2 * c + 1];
+    float sum = 0.f;
+    for (int j = b; j < e; j++) {
+      float p = cache[j] * inv;          // softmax
+      if (p < 1.0e-20f) p = 1.0e-20f;    // SoftmaxComponent::Propagate floor :942
+      sum += p;                          // SumGroupComponent
+    }
+    if (log_priors != nullptr) {
+      if (sum < 1.0e-20f) sum = 1.0e-20f;        // ApplyFloor(1.0e-20)
+      sum = logf(sum);                           // ApplyLog()
+      sum = sum + (-1.0f) * log_priors[c];       // AddVecToRows(-1.0, log priors)
+      sum = sum * prob_scale;                    // Scale(prob_scale)
+    }
+    yr[c] = sum;
+  }
+}
+
 // small rows: one wave per row, 4 rows per workgroup
 template <bool LOG>
 __global__ void __launch_bounds__(kBlock)
@@ -258,6 +303,21 @@ bool DimOk(const KhMatrixDim &d) {
 }
 
 }  // namespace
+
+namespace kh {
+int SoftmaxLdsCols() { return kSoftmaxLdsFloats; }
+int FusedSoftmaxSumGroup(float *y, KhMatrixDim d_out, const float *x, KhMatrixDim d_in, const int32_t *ranges,
+                         const float *log_priors, float prob_scale) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(d_out.rows == d_in.rows && d_in.cols <= kSoftmaxLdsFloats && d_out.cols > 0 && y && x && ranges);
+  if (d_out.rows == 0) return KH_OK;
+  hipLaunchKernelGGL(SoftmaxSumGroupKernel, dim3(d_out.rows), dim3(kBlock), 0, Stream(), y, x, d_in.cols, d_out.cols,
+                     d_out.stride, d_in.stride, ranges, log_priors, prob_scale);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+}  // namespace kh
 
 extern "C" {
 

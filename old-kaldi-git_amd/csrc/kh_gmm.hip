@@ -212,7 +212,7 @@ int kh_am_gmm_loglikes(const float *data, KhMatrixDim dd, const float *gconsts,
       break;
     }
   }
-  hipStreamSynchronize(Stream());  // scratch returns to the pool
+  KH_HIP(hipStreamSynchronize(Stream()));  // scratch returns to the pool
   PoolFree(scratch);
   return rc;
 }

@@ -504,6 +504,16 @@ int kh_nnet_compute(KhNnet *n, const float *feats, int feat_stride,
         rc = kh_normalize(dst, cur, dout, cur_stride);
         break;
       case KH_SOFTMAX:
+        if (i + 2 == nc && n->comps[i + 1].type == KH_SUM_GROUP && c.out <= SoftmaxLdsCols() &&
+            !getenv("KH_NNET_NO_FUSED_OUTPUT")) {
+          // output layer: softmax -> sum-group (-> epilogue) in one pass over the logits
+          const KhNnet::Comp &sg = n->comps[i + 1];
+          rc = FusedSoftmaxSumGroup(out, KhMatrixDim{offs[nc][n_utts], sg.out, out_stride}, cur, din, sg.ranges,
+                                    epilogue ? n->log_priors : nullptr, prob_scale);
+          if (rc) return rc;
+          KH_HIP(hipStreamSynchronize(st));
+          return KH_OK;
+        }
         rc = kh_softmax_per_row(dst, cur, dout, cur_stride);
         if (!rc) rc = kh_apply_floor(dst, dout, 1.0e-20f);  // :942
         break;
