@@ -142,9 +142,10 @@ struct Utt {
   GP(uint8_t) must_links;   // [T+2] must_prune_forward_links
   GP(uint8_t) must_toks;    // [T+2] must_prune_tokens
   // temporaries
-  GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin); sign bit: its state has epsilon arcs
+  GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
   GP(int32_t) tmp_dirty;    // [tok_frame_cap] 1 = queued in a nonemitting work list; all zero outside ProcessNonemitting
   GP(int32_t) tmp_work0; GP(int32_t) tmp_work1;  // [tok_frame_cap] nonemitting work lists (token indices), double buffered
+  GP(int32_t) tmp_epslist;  // [tok_frame_cap] the frontier's tokens whose state has epsilon arcs (each once, in creation order)
   GP(float) tmp_f0;         // [tok_frame_cap] prune: extra_cost on entry (i - frame begin)
   GP(uint32_t) tmp_acc0; GP(uint32_t) tmp_acc1;  // [tok_frame_cap] prune: Enc(min link_extra_cost) over emitting / epsilon links
   GP(int32_t) tmp_remap;    // [window_cap] compaction remap (i - window begin)
@@ -207,6 +208,7 @@ struct Shared {
   int wsumk[2][PU][NW];            // BlockExScanK, double buffered
   int wl_n[3];                     // nonemitting work-list lengths, rotating ([0] also: prune's epsilon-token list)
   int pr_moved;                    // PruneForwardLinks: tokens whose extra_cost moved by more than delta
+  int eps_n;                       // length of tmp_epslist
   unsigned long long wred[2][NW];  // block reductions, double buffered
   int orbuf[4];                    // BlockOr / BlockAny, 4 rotating slots
   unsigned long long wmin[NW];
@@ -368,21 +370,18 @@ __device__ uint32_t RadixSelect(GP(const uint32_t) keys, int b, int e, int k,
       if ((key & mask) == prefix) __hip_atomic_fetch_add(&sh->hist[(key >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     KhSync();
-    if (threadIdx.x == 0) {
-      int acc = 0, bin = 0;
-      for (; bin < 256; bin++) {
-        const int c = static_cast<int>(sh->hist[bin]);
-        if (acc + c > k) break;
-        acc += c;
-      }
-      sh->bcast_i[1] = bin;
-      sh->bcast_i[2] = k - acc;
+    // the bin that holds rank k: workgroup scan of the 256 counts (lane t owns bin t)
+    const int cnt = threadIdx.x < 256 ? static_cast<int>(sh->hist[threadIdx.x]) : 0;
+    int total;
+    const int before = BlockExScan(cnt, &total, sh);
+    if (threadIdx.x < 256 && before <= k && k < before + cnt) {
+      sh->bcast_i[1] = threadIdx.x;
+      sh->bcast_i[2] = k - before;
     }
     KhSync();
     prefix |= static_cast<uint32_t>(sh->bcast_i[1]) << shift;
     mask |= 255u << shift;
     k = sh->bcast_i[2];
-    KhSync();
   }
   return prefix;
 }
@@ -398,7 +397,7 @@ __device__ __forceinline__ uint32_t HashState(int32_t s) {
 // pre-filled with +inf: arena invariant), or -1 if the raw arena is full.
 // Entry: low 32 bits = state + 1 (0 = empty), high 32 bits = token + 1 (0 = pending).
 __device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute__((address_space(3))) int *tok_end /*LDS counter*/,
-                         int tok_limit, int front_b) {
+                         __attribute__((address_space(3))) int *eps_n /*LDS counter*/, int tok_limit, int front_b) {
   uint32_t slot = HashState(state) & u.hash_mask;
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
   for (int probes = 0; probes < (1 << 30); probes++) {
@@ -417,7 +416,8 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute_
         }
         u.tok_state[idx] = state;
         u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
-        u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot | (has_eps ? 0x80000000u : 0u));
+        u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot);
+        if (has_eps) u.tmp_epslist[__hip_atomic_fetch_add(eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
         __hip_atomic_exchange(&u.hash[slot], want_key | (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32),
                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return idx;
@@ -451,7 +451,8 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
   return -1;
 }
 
-// First half of an expansion sweep over the tokens [b, e): every token whose cost
+// First half of an expansion sweep over the tokens [b, e) (kEps: over entries [b, e) of
+// tmp_epslist, the tokens whose state has epsilon arcs): every token whose cost
 // is <= cutoff gets one link slot per arc of its HCLG state (arc ranges `off`),
 // appended at link slot `lrun` on in token order; the slots are seeded with
 // (link_src = token, link_dst = arc index) for the link-parallel second half.
@@ -463,10 +464,13 @@ __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, f
   for (int base = b; base < e; base += NT * PU) {
     int i[PU], st[PU];
     uint32_t co[PU];
+    bool in_range[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       i[k] = base + k * NT + threadIdx.x;
-      const int ic = min(i[k], e - 1);
+      in_range[k] = i[k] < e;
+      int ic = min(i[k], e - 1);
+      if (kEps) { ic = u.tmp_epslist[ic]; i[k] = ic; }  // [b, e) indexes the list of tokens with epsilon arcs
       co[k] = LoadCostEnc(&u.tok_cost[ic]);
       st[k] = u.tok_state[ic];
       KH_BOUND(1, st[k], 0, 0x7ffffff0);
@@ -474,8 +478,7 @@ __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, f
     int ab[PU], cnt[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
-      bool need = i[k] < e && Dec(co[k]) <= cutoff;
-      if (kEps) need = need && u.tmp_slot[min(i[k], e - 1) - b] < 0;  // sign bit: the state has epsilon arcs
+      const bool need = in_range[k] && Dec(co[k]) <= cutoff;
       ab[k] = 0;
       cnt[k] = 0;
       if (need) {
@@ -492,7 +495,7 @@ __device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, f
     }
 #pragma unroll
     for (int k = 0; k < PU; k++) {
-      if (i[k] >= e) continue;
+      if (!in_range[k]) continue;
       int l0 = lrun + loff[k];
       KH_BOUND(2, l0, 0, u.link_cap - cnt[k] + 1);
       for (int j = 0; j < cnt[k]; j++) {
@@ -519,12 +522,14 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   const int n = e - b;
   c.count = n;
   unsigned long long best = ~0ull;
+  int best_i = -1;
   for (int i = b + threadIdx.x; i < e; i += NT) {
     // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
     const unsigned long long key =
         (static_cast<unsigned long long>(LoadCostEnc(&u.tok_cost[i])) << 32) | static_cast<uint32_t>(u.tok_state[i]);
-    best = key < best ? key : best;
+    if (key < best) { best = key; best_i = i; }
   }
+  const unsigned long long mine = best;
   best = BlockMinU64(best, sh);
   const float inf = INFINITY;
   if (n == 0) {
@@ -535,13 +540,10 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
     return c;
   }
   c.best_cost = Dec(static_cast<uint32_t>(best >> 32));
-  // locate the best token's index
-  int found = 0x7fffffff;
-  const int32_t best_state = static_cast<int32_t>(static_cast<uint32_t>(best));
-  for (int i = b + threadIdx.x; i < e; i += NT)
-    if (u.tok_state[i] == best_state) found = i;
-  unsigned long long f64 = BlockMinU64(static_cast<unsigned long long>(static_cast<uint32_t>(found)), sh);
-  c.best_tok = static_cast<int>(f64);
+  // the lane that holds the winning key (states are unique within a frame) publishes its token
+  if (mine == best && best_i >= 0) sh->bcast_i[0] = best_i;
+  KhSync();
+  c.best_tok = sh->bcast_i[0];
   const float best_weight = c.best_cost;
   if (p.max_active == 0x7fffffff && p.min_active == 0) {
     c.adaptive_beam = p.beam;
@@ -608,7 +610,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
         if (tot_cost < cutoff) {  // :794
           const bool he = (arc.w & kHasEps) != 0;
-          const int dst = FindOrAdd(u, arc.w & kStateMask, he, &sh->tok_end, tok_limit, fb);
+          const int dst = FindOrAdd(u, arc.w & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, fb);
           if (dst < 0) { sh->status = 1; continue; }
           const uint32_t enc = Enc(tot_cost);
           if (he) {
@@ -634,7 +636,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   const int fe = sh->tok_end;
   const int blk_b = sh->link_end;
   long long seeded = 0;
-  const int blk_e = ExpandTokens<true>(u, p.n_off, fb, fe, cutoff, blk_b, u.link_frame_cap, &seeded, sh);
+  const int blk_e = ExpandTokens<true>(u, p.n_off, 0, sh->eps_n, cutoff, blk_b, u.link_frame_cap, &seeded, sh);
   if (blk_e < 0) return false;
   for (int base = blk_b + threadIdx.x; base < blk_e; base += NT * PU) {
     int l[PU], src[PU], ai[PU];
@@ -700,7 +702,7 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
     // many entries: stream over the whole table (coalesced) instead of one scattered store per token
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
   } else {
-    for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb] & 0x7fffffff] = kEmpty;
+    for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb]] = kEmpty;
   }
   KhSync();
 }
@@ -712,7 +714,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
                                 float *next_cutoff_out, Blk &sh) {
   const int nb = sh->tok_end;  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }  // pass 2 fills list 0 (barriers in between)
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }  // pass 2 fills list 0 (barriers in between)
   // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
   // against the last readers of the previous row and the first readers of this one)
   for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
@@ -805,7 +807,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     if (!(tot_cost > next_cutoff)) {  // :731 "if (tot_cost > next_cutoff) continue"
       const int32_t ns = u.link_dst[l];
       const bool he = (ns & kHasEps) != 0;
-      dst = FindOrAdd(u, ns & kStateMask, he, &sh->tok_end, tok_limit, nb);
+      dst = FindOrAdd(u, ns & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, nb);
       if (dst < 0) {
         sh->status = 1;
       } else if (he) {
@@ -1171,7 +1173,8 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   }
   KhSync();
   if (threadIdx.x == 0) {
-    const int idx = FindOrAdd(u, p.start, p.start_has_eps != 0, &sh->tok_end, u.tok_cap, 0);
+    sh->eps_n = 0;
+    const int idx = FindOrAdd(u, p.start, p.start_has_eps != 0, &sh->tok_end, &sh->eps_n, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
     u.frame_b[0] = idx;
     sh->wl_n[0] = 0;
@@ -1696,6 +1699,7 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tmp_dirty = c.Take<int32_t>(tok_frame_cap);
   u.tmp_work0 = c.Take<int32_t>(tok_frame_cap);
   u.tmp_work1 = c.Take<int32_t>(tok_frame_cap);
+  u.tmp_epslist = c.Take<int32_t>(tok_frame_cap);
   u.tmp_f0 = c.Take<float>(tok_frame_cap);
   u.tmp_acc0 = c.Take<uint32_t>(tok_frame_cap);
   u.tmp_acc1 = c.Take<uint32_t>(tok_frame_cap);
