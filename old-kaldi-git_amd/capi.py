@@ -141,6 +141,8 @@ def load():
             "(there is no CPU fallback)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("KH_LIB_OVERRIDE") and not hasattr(lib, name):
+            continue  # A/B runs against an older build of the library (tools/): it may predate a symbol
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -2131,7 +2131,7 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
   long long lf = 3 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
   d->link_frame_cap = static_cast<int>(lf);
-  d->max_slots = NumCUs() * (NT >= 1024 ? 1 : 1024 / NT) * KH_WG_PER_CU;  // persistent workgroups
+  d->max_slots = NumCUs() * KH_WG_PER_CU;  // persistent workgroups
   if (const char *e = getenv("KH_DECODER_SLOTS")) d->max_slots = std::max(1, atoi(e));
   return d;
 }
