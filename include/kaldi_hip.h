@@ -388,6 +388,51 @@ int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_offsets,
                                 double *tot_like, double *acoustic_like_sum,
                                 int32_t *state_times);
 
+/* ComputeLatticeAlphasAndBetas (lat/lattice-functions.cc:412-463) for a batch (same CSR
+ * layout as above): alpha / beta per state (log-semiring, or the tropical one when
+ * viterbi != 0: LogAddOrMax :395-410), tot[l] = 0.5 * (forward + backward total). */
+int kh_lattice_alphas_betas(int n_lats, const int32_t *lat_state_offsets,
+                            const int64_t *arc_offsets, const int32_t *arc_ilabel,
+                            const int32_t *arc_nextstate, const float *arc_graph,
+                            const float *arc_acoustic, const float *state_final,
+                            int viterbi, double *alpha, double *beta, double *tot);
+
+/* LatticeForwardBackwardMpeVariants (lat/lattice-functions.cc:740-919): criterion
+ * "smbr" (is_mpfe = 0) or "mpfe".  tid2phone / tid2pdf = TransitionIdToPhone /
+ * TransitionIdToPdf as arrays of num_tids + 1 entries indexed by transition-id;
+ * silence_phones sorted; num_ali = the numerator alignments concatenated
+ * (num_ali_offsets[n_lats + 1]; lattice l needs max_time(l) entries, :764).
+ * arc_post[a] = posterior_smbr of arc a (0 on epsilon arcs); the Posterior is
+ * post[state_times[src(a)]] += (ilabel, arc_post[a]) merged as MergePairVectorSumming
+ * (:916-917).  tot_forward_score[l] = the expected frame accuracy (:919).  Fails with
+ * KH_ESTATE when one of the reference's forward/backward checks fails (:808, :909). */
+int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_state_offsets,
+                                    const int64_t *arc_offsets, const int32_t *arc_ilabel,
+                                    const int32_t *arc_nextstate, const float *arc_graph,
+                                    const float *arc_acoustic, const float *state_final,
+                                    const int32_t *tid2phone, const int32_t *tid2pdf, int num_tids,
+                                    const int32_t *silence_phones, int n_sil, const int32_t *num_ali,
+                                    const int32_t *num_ali_offsets, int is_mpfe, int one_silence_class,
+                                    float *arc_post, double *tot_forward_score);
+
+/* RescoreLattice (lat/lattice-functions.cc:1307-1358) with a matrix decodable: every
+ * arc with a transition-id gets -loglikes[t][tid2pdf ? tid2pdf[tid] : tid - 1] added to
+ * its acoustic cost (host array, updated in place), t = LatticeStateTimes of its source
+ * state.  loglikes: DEVICE matrix, lattice l uses rows ll_row_offsets[l]...  Top-sorted
+ * input required (the reference sorts first). */
+int kh_rescore_lattice(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                       const int32_t *arc_ilabel, const int32_t *arc_nextstate, float *arc_acoustic,
+                       const float *loglikes, int ll_stride, const int32_t *ll_row_offsets,
+                       const int32_t *tid2pdf);
+
+/* CuMatrix::CompObjfAndDeriv (cudamatrix/cu-matrix.cc:1198-1248): the supervision
+ * labels (row, column, weight) as three host arrays, output / deriv DEVICE matrices of
+ * equal size: *tot_objf = sum w log output(r, c), *tot_weight = sum w,
+ * deriv(r, c) += w / output(r, c). */
+int kh_comp_objf_and_deriv(int n, const int32_t *rows, const int32_t *cols, const float *weights,
+                           const float *output, KhMatrixDim d_output, float *deriv, KhMatrixDim d_deriv,
+                           float *tot_objf, float *tot_weight);
+
 #ifdef __cplusplus
 }
 #endif

@@ -689,3 +689,195 @@ def lattice_forward_backward(lats):
         out.append(dict(arc_post=ap.copy(), tot_like=float(tot[i]), acoustic_like_sum=float(ac[i]),
                         state_times=t.copy(), post=posterior))
     return out
+
+
+def _cat_lattices(lats):
+    n = len(lats)
+    soff = np.zeros(n + 1, np.int32)
+    for i, L in enumerate(lats):
+        soff[i + 1] = soff[i] + L["n_states"]
+    aoff = [np.zeros(1, np.int64)]
+    base = 0
+    for L in lats:
+        o = np.asarray(L["arc_offsets"], np.int64)
+        aoff.append(o[1:] + base)
+        base += int(o[-1])
+    aoff = np.ascontiguousarray(np.concatenate(aoff))
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(L[k], dt) for L in lats]))
+    return (n, soff, aoff, cat("arc_ilabel", np.int32), cat("arc_nextstate", np.int32), cat("arc_graph", np.float32),
+            cat("arc_acoustic", np.float32), cat("state_final", np.float32))
+
+
+def _arc_posterior_to_post(L, times, tids, arc_post, max_time):
+    """(*post)[state_times[s]].push_back((tid, p)) for tid != 0, then MergePairVectorSumming
+    (util/stl-utils.h: sort by tid, sum equal keys in float, drop zeros)."""
+    src = np.repeat(np.arange(L["n_states"]), np.diff(np.asarray(L["arc_offsets"], np.int64)))
+    frames = {}
+    for s, ti, p in zip(src[tids != 0], tids[tids != 0], arc_post[tids != 0]):
+        frames.setdefault(int(times[s]), {}).setdefault(int(ti), []).append(np.float32(p))
+    posterior = []
+    for fr in range(max_time):
+        ent = []
+        for ti in sorted(frames.get(fr, {})):
+            acc = np.float32(0.0)
+            for p in frames[fr][ti]:
+                acc = np.float32(acc + p)
+            if acc != 0.0:
+                ent.append((ti, float(acc)))
+        posterior.append(ent)
+    return posterior
+
+
+def lattice_alphas_betas(lats, viterbi=False):
+    """ComputeLatticeAlphasAndBetas (lat/lattice-functions.cc:412-463) for a batch."""
+    n, soff, aoff, il, ns, g, a, fin = _cat_lattices(lats)
+    alpha, beta, tot = np.empty(int(soff[-1])), np.empty(int(soff[-1])), np.empty(n)
+    ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
+    check(lib().kh_lattice_alphas_betas(
+        n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
+        g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp), int(bool(viterbi)),
+        alpha.ctypes.data_as(dp), beta.ctypes.data_as(dp), tot.ctypes.data_as(dp)))
+    return [dict(alpha=alpha[soff[i]:soff[i + 1]].copy(), beta=beta[soff[i]:soff[i + 1]].copy(), tot=float(tot[i]))
+            for i in range(n)]
+
+
+def lattice_forward_backward_mpe(lats, tid2phone, tid2pdf, silence_phones, num_alis, criterion="smbr",
+                                 one_silence_class=False):
+    """LatticeForwardBackwardMpeVariants (lat/lattice-functions.cc:740-919) for a batch;
+    returns per lattice dict(arc_post, post, tot_forward_score)."""
+    if criterion not in ("smbr", "mpfe"):
+        raise KhError('criterion must be "mpfe" or "smbr" (lattice-functions.cc:753)')
+    n, soff, aoff, il, ns, g, a, fin = _cat_lattices(lats)
+    t2ph, t2pdf = np.ascontiguousarray(tid2phone, np.int32), np.ascontiguousarray(tid2pdf, np.int32)
+    sil = np.ascontiguousarray(sorted(silence_phones), np.int32)
+    ali_off = np.concatenate([[0], np.cumsum([len(x) for x in num_alis])]).astype(np.int32)
+    ali = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int32) for x in num_alis]) if len(num_alis) else [], np.int32)
+    post = np.empty(len(il), np.float32)
+    score = np.empty(n)
+    ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
+    check(lib().kh_lattice_forward_backward_mpe(
+        n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
+        g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp), t2ph.ctypes.data_as(ip),
+        t2pdf.ctypes.data_as(ip), len(t2ph) - 1, sil.ctypes.data_as(ip), len(sil), ali.ctypes.data_as(ip),
+        ali_off.ctypes.data_as(ip), int(criterion == "mpfe"), int(bool(one_silence_class)), post.ctypes.data_as(fp),
+        score.ctypes.data_as(dp)))
+    # state times for the Posterior (host, LatticeStateTimes :36-67)
+    out = []
+    for i, L in enumerate(lats):
+        a0, a1 = int(aoff[soff[i]]), int(aoff[soff[i + 1]])
+        times = lattice_state_times(L)
+        out.append(dict(arc_post=post[a0:a1].copy(), tot_forward_score=float(score[i]),
+                        post=_arc_posterior_to_post(L, times, il[a0:a1], post[a0:a1], len(num_alis[i]))))
+    return out
+
+
+def lattice_state_times(L):
+    """LatticeStateTimes (lat/lattice-functions.cc:36-67) of one top-sorted lattice."""
+    n = L["n_states"]
+    off = np.asarray(L["arc_offsets"], np.int64)
+    il, ns = np.asarray(L["arc_ilabel"]), np.asarray(L["arc_nextstate"])
+    times = np.full(n, -1, np.int32)
+    times[0] = 0
+    for s in range(n):
+        for a in range(off[s], off[s + 1]):
+            want = times[s] + (1 if il[a] != 0 else 0)
+            if times[ns[a]] == -1:
+                times[ns[a]] = want
+            elif times[ns[a]] != want:
+                raise KhError("LatticeStateTimes: inconsistent lattice")
+    return times
+
+
+def rescore_lattice(lats, loglikes, utt_row_offsets, tid2pdf=None):
+    """RescoreLattice (lat/lattice-functions.cc:1307-1358) for a batch: loglikes = device
+    matrix (rows of lattice i at utt_row_offsets[i]...).  Returns the new arc_acoustic arrays."""
+    n, soff, aoff, il, ns, g, a, fin = _cat_lattices(lats)
+    a = a.copy()
+    off = np.ascontiguousarray(utt_row_offsets, np.int32)
+    ip, fp = capi.c_int32_p, capi.c_float_p
+    check(lib().kh_rescore_lattice(n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip),
+                                   ns.ctypes.data_as(ip), a.ctypes.data_as(fp), _p(loglikes), _dim(loglikes).stride,
+                                   off.ctypes.data_as(ip), _p(tid2pdf) if tid2pdf is not None else None))
+    return [a[int(aoff[soff[i]]):int(aoff[soff[i + 1]])].copy() for i in range(n)]
+
+
+def comp_objf_and_deriv(deriv, sv_labels, output):
+    """CuMatrix::CompObjfAndDeriv (cu-matrix.cc:1198-1248): deriv.CompObjfAndDeriv(sv_labels,
+    output, &tot_objf, &tot_weight); sv_labels = [(row, column, weight), ...]."""
+    r = np.ascontiguousarray([x[0] for x in sv_labels], np.int32)
+    c = np.ascontiguousarray([x[1] for x in sv_labels], np.int32)
+    w = np.ascontiguousarray([x[2] for x in sv_labels], np.float32)
+    objf, wt = C.c_float(), C.c_float()
+    check(lib().kh_comp_objf_and_deriv(len(r), r.ctypes.data_as(capi.c_int32_p), c.ctypes.data_as(capi.c_int32_p),
+                                       w.ctypes.data_as(capi.c_float_p), _p(output), _dim(output), _p(deriv), _dim(deriv),
+                                       C.byref(objf), C.byref(wt)))
+    return objf.value, wt.value
+
+
+# ---- Posterior algebra of hmm/posterior.cc used by LatticeForwardBackwardMmi (host lists,
+# as in the reference).  A Posterior is a list over frames of [(id, weight), ...].
+def alignment_to_posterior(ali):
+    """AlignmentToPosterior hmm/posterior.cc:276-285."""
+    return [[(int(t), 1.0)] for t in ali]
+
+
+def scale_posterior(scale, post):
+    """ScalePosterior hmm/posterior.cc:204-218 (scale == 0 clears the frames)."""
+    if scale == 0.0:
+        return [[] for _ in post]
+    return [[(i, float(np.float32(np.float32(w) * np.float32(scale)))) for i, w in fr] for fr in post]
+
+
+def convert_posterior_to_pdfs(tid2pdf, post):
+    """ConvertPosteriorToPdfs hmm/posterior.cc:308-332 (entries of a frame in ascending pdf
+    order here; the reference's order is that of an unordered_map)."""
+    out = []
+    for fr in post:
+        acc = {}
+        for tid, w in fr:
+            pdf = int(tid2pdf[tid])
+            acc[pdf] = np.float32(acc[pdf] + np.float32(w)) if pdf in acc else np.float32(w)
+        out.append([(k, float(v)) for k, v in sorted(acc.items()) if v != 0.0])
+    return out
+
+
+def merge_posteriors(post1, post2, merge, drop_frames):
+    """MergePosteriors hmm/posterior.cc:244-274; returns (post, num_disjoint)."""
+    assert len(post1) == len(post2)
+    out, num_disjoint = [], 0
+    for a, b in zip(post1, post2):
+        fr = list(a) + list(b)
+        if merge:  # MergePairVectorSumming: sort on the id, sum equal ids, drop zeros
+            fr.sort(key=lambda x: x[0])
+            merged = []
+            for i, w in fr:
+                if merged and merged[-1][0] == i:
+                    merged[-1] = (i, float(np.float32(np.float32(merged[-1][1]) + np.float32(w))))
+                else:
+                    merged.append((i, float(np.float32(w))))
+            fr = [(i, w) for i, w in merged if w != 0.0]
+        else:
+            fr.sort()
+        if not ({i for i, _ in a} & {i for i, _ in b}):  # PosteriorEntriesAreDisjoint :220-241
+            num_disjoint += 1
+            if drop_frames:
+                fr = []
+        out.append(fr)
+    return out, num_disjoint
+
+
+def lattice_forward_backward_mmi(lats, tid2pdf, num_alis, drop_frames, convert_to_pdf_ids, cancel):
+    """LatticeForwardBackwardMmi (lat/lattice-functions.cc:1361-1396) for a batch: the
+    denominator forward-backward on the GPU, the posterior algebra on the host as in the
+    reference.  Returns per lattice dict(post, tot_like)."""
+    fb = lattice_forward_backward(lats)
+    out = []
+    for r, ali in zip(fb, num_alis):
+        den_post = scale_posterior(-1.0, r["post"])
+        num_post = alignment_to_posterior(ali)
+        if convert_to_pdf_ids:
+            num_post = convert_posterior_to_pdfs(tid2pdf, num_post)
+            den_post = convert_posterior_to_pdfs(tid2pdf, den_post)
+        post, _ = merge_posteriors(num_post, den_post, cancel, drop_frames)
+        out.append(dict(post=post, tot_like=r["tot_like"]))
+    return out

@@ -121,6 +121,206 @@ ForwardBackwardKernel(const LatDesc *__restrict__ lats, const int64_t *__restric
   }
 }
 
+// ComputeLatticeAlphasAndBetas :412-463 (LogAddOrMax :395-410): alpha, beta and the
+// forward total of every lattice.
+__global__ void __launch_bounds__(kThreads)
+AlphaBetaKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off,
+                const int32_t *__restrict__ arc_next, const float *__restrict__ arc_g,
+                const float *__restrict__ arc_a, const float *__restrict__ state_final,
+                const int32_t *__restrict__ level_off, const int32_t *__restrict__ level_states,
+                const int64_t *__restrict__ in_off, const int64_t *__restrict__ in_arc,
+                const int32_t *__restrict__ in_src, const int32_t *__restrict__ final_list,
+                double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ tot_forward,
+                int viterbi, double min_log_diff) {
+  const LatDesc L = lats[blockIdx.x];
+  const double kLogZero = -INFINITY;
+  double *al = alpha + L.state_b, *be = beta + L.state_b;
+  const float *fin = state_final + L.state_b;
+  const int32_t *lstates = level_states + L.state_b;
+  const int32_t *loff = level_off + L.level_b;
+  for (int lv = 0; lv < L.n_levels; lv++) {
+    for (int k = loff[lv] + threadIdx.x; k < loff[lv + 1]; k += kThreads) {
+      const int s = lstates[k];
+      double a = (s == 0) ? 0.0 : kLogZero;
+      for (int64_t j = in_off[L.state_b + s]; j < in_off[L.state_b + s + 1]; j++) {
+        const int64_t arc = in_arc[j];
+        const double v = al[in_src[j]] - static_cast<double>(arc_g[arc] + arc_a[arc]);
+        a = viterbi ? fmax(a, v) : LogAddD(a, v, min_log_diff);
+      }
+      al[s] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double tot = kLogZero;
+    for (int k = 0; k < L.n_final; k++) {
+      const int s = final_list[L.final_b + k];
+      const double final_like = al[s] - static_cast<double>(fin[s] + 0.0f);
+      tot = viterbi ? fmax(tot, final_like) : LogAddD(tot, final_like, min_log_diff);
+    }
+    tot_forward[blockIdx.x] = tot;
+  }
+  for (int lv = L.n_levels - 1; lv >= 0; lv--) {
+    for (int k = loff[lv] + threadIdx.x; k < loff[lv + 1]; k += kThreads) {
+      const int s = lstates[k];
+      double this_beta = -static_cast<double>(fin[s] + 0.0f);
+      for (int64_t arc = arc_off[L.state_b + s]; arc < arc_off[L.state_b + s + 1]; arc++) {
+        const double arc_beta = be[arc_next[arc]] - static_cast<double>(arc_g[arc] + arc_a[arc]);
+        this_beta = viterbi ? fmax(this_beta, arc_beta) : LogAddD(this_beta, arc_beta, min_log_diff);
+      }
+      be[s] = this_beta;
+    }
+    __syncthreads();
+  }
+}
+
+struct MpeArgs {
+  const int32_t *tid2phone, *tid2pdf, *sil, *num_ali, *ali_off, *times, *ilabel;
+  int n_sil, is_mpfe, one_silence_class;
+};
+
+// frame accuracy of an arc (:820-842)
+__device__ __forceinline__ double FrameAcc(const MpeArgs &m, int lat, int state_global, int64_t arc) {
+  const int il = m.ilabel[arc];
+  if (il == 0) return 0.0;
+  const int ref_tid = m.num_ali[m.ali_off[lat] + m.times[state_global]];
+  const int phone = m.tid2phone[il], ref_phone = m.tid2phone[ref_tid];
+  bool phone_is_sil = false, ref_is_sil = false;
+  for (int i = 0; i < m.n_sil; i++) {  // short sorted list
+    phone_is_sil |= m.sil[i] == phone;
+    ref_is_sil |= m.sil[i] == ref_phone;
+  }
+  const bool both_sil = phone_is_sil && ref_is_sil;
+  if (!m.is_mpfe) {
+    const int pdf = m.tid2pdf[il], ref_pdf = m.tid2pdf[ref_tid];
+    if (!m.one_silence_class) return (pdf == ref_pdf && !phone_is_sil) ? 1.0 : 0.0;
+    return (pdf == ref_pdf || both_sil) ? 1.0 : 0.0;
+  }
+  if (!m.one_silence_class) return (phone == ref_phone && !phone_is_sil) ? 1.0 : 0.0;
+  return (phone == ref_phone || both_sil) ? 1.0 : 0.0;
+}
+
+// LatticeForwardBackwardMpeVariants :740-919 after AlphaBetaKernel: the second forward
+// pass (alpha_smbr, expected accuracy) and the second backward pass (beta_smbr,
+// posterior_smbr per arc).  Sums run in the reference's order: a state adds its
+// incoming arcs by ascending (source, arc), its outgoing arcs by ascending arc.
+__global__ void __launch_bounds__(kThreads)
+MpeKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off,
+          const int32_t *__restrict__ arc_next, const float *__restrict__ arc_g,
+          const float *__restrict__ arc_a, const float *__restrict__ state_final,
+          const int32_t *__restrict__ level_off, const int32_t *__restrict__ level_states,
+          const int64_t *__restrict__ in_off, const int64_t *__restrict__ in_arc,
+          const int32_t *__restrict__ in_src, const int32_t *__restrict__ final_list,
+          const double *__restrict__ alpha, const double *__restrict__ beta,
+          const double *__restrict__ tot_forward, double *__restrict__ alpha_smbr,
+          double *__restrict__ beta_smbr, MpeArgs m, float *__restrict__ arc_post,
+          double *__restrict__ tot_score, double *__restrict__ tot_backward_score) {
+  __shared__ double s_score;
+  const LatDesc L = lats[blockIdx.x];
+  const double *al = alpha + L.state_b, *be = beta + L.state_b;
+  double *as = alpha_smbr + L.state_b, *bs = beta_smbr + L.state_b;
+  const float *fin = state_final + L.state_b;
+  const int32_t *lstates = level_states + L.state_b;
+  const int32_t *loff = level_off + L.level_b;
+  const double tot_forward_prob = tot_forward[blockIdx.x];
+  for (int lv = 0; lv < L.n_levels; lv++) {  // :813-846
+    for (int k = loff[lv] + threadIdx.x; k < loff[lv + 1]; k += kThreads) {
+      const int s = lstates[k];
+      double acc = 0.0;
+      for (int64_t j = in_off[L.state_b + s]; j < in_off[L.state_b + s + 1]; j++) {
+        const int64_t arc = in_arc[j];
+        const int src = in_src[j];
+        const double arc_like = -static_cast<double>(arc_g[arc] + arc_a[arc]);
+        const double frame_acc = FrameAcc(m, blockIdx.x, L.state_b + src, arc);
+        const double arc_scale = exp(al[src] + arc_like - al[s]);
+        acc += arc_scale * (as[src] + frame_acc);
+      }
+      as[s] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // :847-854
+    double score = 0.0;
+    for (int k = 0; k < L.n_final; k++) {
+      const int s = final_list[L.final_b + k];
+      const double final_like = al[s] - static_cast<double>(fin[s] + 0.0f);
+      score += exp(final_like - tot_forward_prob) * as[s];
+    }
+    s_score = score;
+    tot_score[blockIdx.x] = score;
+  }
+  __syncthreads();
+  const double tot_forward_score = s_score;
+  for (int lv = L.n_levels - 1; lv >= 0; lv--) {  // :857-903
+    for (int k = loff[lv] + threadIdx.x; k < loff[lv + 1]; k += kThreads) {
+      const int s = lstates[k];
+      double b = 0.0;
+      for (int64_t arc = arc_off[L.state_b + s]; arc < arc_off[L.state_b + s + 1]; arc++) {
+        const int nxt = arc_next[arc];
+        const double arc_like = -static_cast<double>(arc_g[arc] + arc_a[arc]), arc_beta = be[nxt] + arc_like;
+        const double frame_acc = FrameAcc(m, blockIdx.x, L.state_b + s, arc);
+        double arc_scale = exp(be[nxt] + arc_like - be[s]);
+        if (arc_scale != arc_scale) arc_scale = 0;  // KALDI_ISNAN :890
+        b += arc_scale * (bs[nxt] + frame_acc);
+        float post = 0.0f;
+        if (m.ilabel[arc] != 0) {
+          const double posterior = exp(al[s] + arc_beta - tot_forward_prob);
+          const double acc_diff = as[s] + frame_acc + bs[nxt] - tot_forward_score;
+          post = static_cast<float>(posterior * acc_diff);
+        }
+        arc_post[arc] = post;
+      }
+      bs[s] = b;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tot_backward_score[blockIdx.x] = bs[0];
+}
+
+// RescoreLattice :1307-1358: arcs with a transition-id get -log_like added to their
+// acoustic cost.  One lane per (state, its arcs).
+__global__ void RescoreKernel(int total_states, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ ilabel,
+                              const int32_t *__restrict__ times, const int32_t *__restrict__ state_lat,
+                              const int32_t *__restrict__ ll_row_off, float *__restrict__ arc_a,
+                              const float *__restrict__ loglikes, int ll_stride, const int32_t *__restrict__ tid2pdf) {
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < total_states; s += gridDim.x * blockDim.x) {
+    const int t = times[s];
+    if (t < 0) continue;
+    const float *row = loglikes + static_cast<size_t>(ll_row_off[state_lat[s]] + t) * ll_stride;
+    for (int64_t a = arc_off[s]; a < arc_off[s + 1]; a++) {
+      const int il = ilabel[a];
+      if (il != 0) arc_a[a] = -row[tid2pdf ? tid2pdf[il] : il - 1] + arc_a[a];  // :1349-1350
+    }
+  }
+}
+
+// CuMatrix::CompObjfAndDeriv cu-matrix.cc:1198-1248 (_cuda_comp_obj_deriv cu-kernels.cu:997-1035):
+// objf = sum w log(output(r, c)), weight = sum w, deriv(r, c) += w / output(r, c).
+// Duplicated (r, c) pairs are summed (atomicAdd; the reference's kernel races on them).
+__global__ void __launch_bounds__(kThreads)
+CompObjfKernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
+               const float *__restrict__ weights, const float *__restrict__ output, int out_stride,
+               float *__restrict__ deriv, int deriv_stride, double *__restrict__ sums) {
+  __shared__ double s_red[2][kThreads / 64];
+  double objf = 0.0, wsum = 0.0;
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    const float w = weights[i], p = output[static_cast<size_t>(rows[i]) * out_stride + cols[i]];
+    objf += static_cast<double>(w * logf(p));
+    wsum += static_cast<double>(w);
+    atomicAdd(&deriv[static_cast<size_t>(rows[i]) * deriv_stride + cols[i]], w / p);
+  }
+  objf = kh_wave_sum_d(objf);
+  wsum = kh_wave_sum_d(wsum);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = objf; s_red[1][threadIdx.x >> 6] = wsum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < kThreads / 64; i++) { a += s_red[0][i]; b += s_red[1][i]; }
+    atomicAdd(&sums[0], a);
+    atomicAdd(&sums[1], b);
+  }
+}
+
 template <class T>
 struct DevArr {
   T *p = nullptr;
@@ -139,6 +339,108 @@ struct DevArr {
 
 }  // namespace
 
+// Host preparation shared by the lattice sweeps: validation (top-sorted, consistent
+// state times), dependency levels, the incoming-arc CSR (ascending arc index per
+// destination), the list of final states; everything uploaded.
+struct LatBatch {
+  int n_lats = 0, total_states = 0;
+  int64_t total_arcs = 0;
+  std::vector<LatDesc> descs;
+  std::vector<int32_t> level_off, level_states, final_list, in_src, times;
+  std::vector<int64_t> in_off, in_arc;
+  DevArr<LatDesc> d_descs;
+  DevArr<int64_t> d_arc_off, d_in_off, d_in_arc;
+  DevArr<int32_t> d_next, d_ilabel, d_level_off, d_level_states, d_in_src, d_final_list, d_times;
+  DevArr<float> d_g, d_a, d_fin;
+
+  int Build(int n, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
+            const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic,
+            const float *state_final, hipStream_t st) {
+    n_lats = n;
+    total_states = lat_state_offsets[n_lats];
+    total_arcs = arc_offsets[total_states];
+    const float inf = std::numeric_limits<float>::infinity();
+    descs.resize(n_lats);
+    level_states.resize(total_states);
+    in_src.resize(total_arcs);
+    in_off.assign(static_cast<size_t>(total_states) + 1, 0);
+    in_arc.resize(total_arcs);
+    times.assign(total_states, -1);
+    for (int l = 0; l < n_lats; l++) {
+      const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
+      KH_CHECK_ARG(ns > 0);
+      LatDesc &d = descs[l];
+      d.state_b = sb;
+      d.n_states = ns;
+      d.arc_b = arc_offsets[sb];
+      std::vector<int32_t> level(ns, 0);
+      int max_level = 0;
+      // LatticeStateTimes :36-67 + level assignment + topological-order check
+      // ("Input lattice must be topologically sorted", :38-39,:285-286).
+      times[sb] = 0;
+      for (int s = 0; s < ns; s++) {
+        const int cur_time = times[sb + s];
+        for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
+          const int nxt = arc_nextstate[a];
+          if (nxt <= s || nxt >= ns) {
+            SetError("lattice %d: arc %lld (state %d -> %d): input lattice must be topologically sorted",
+                     l, static_cast<long long>(a), s, nxt);
+            return KH_EINVAL;
+          }
+          if (cur_time >= 0) {
+            const int want = cur_time + (arc_ilabel[a] != 0 ? 1 : 0);
+            if (times[sb + nxt] == -1) times[sb + nxt] = want;
+            else if (times[sb + nxt] != want) {
+              SetError("lattice %d: inconsistent state times at state %d (KALDI_ASSERT lattice-functions.cc:55,61)", l, nxt);
+              return KH_EINVAL;
+            }
+          }
+          level[nxt] = std::max(level[nxt], level[s] + 1);
+          in_off[static_cast<size_t>(sb) + nxt + 1]++;
+        }
+        max_level = std::max(max_level, level[s]);
+      }
+      d.n_levels = max_level + 1;
+      d.level_b = static_cast<int32_t>(level_off.size());
+      std::vector<int32_t> cnt(d.n_levels + 1, 0);
+      for (int s = 0; s < ns; s++) cnt[level[s] + 1]++;
+      for (int i = 0; i < d.n_levels; i++) cnt[i + 1] += cnt[i];
+      for (int i = 0; i <= d.n_levels; i++) level_off.push_back(cnt[i]);
+      std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+      for (int s = 0; s < ns; s++) level_states[sb + fill[level[s]]++] = s;
+      d.final_b = static_cast<int32_t>(final_list.size());
+      for (int s = 0; s < ns; s++)
+        if (state_final[sb + s] != inf) final_list.push_back(s);
+      d.n_final = static_cast<int32_t>(final_list.size()) - d.final_b;
+    }
+    for (size_t i = 0; i < static_cast<size_t>(total_states); i++) in_off[i + 1] += in_off[i];
+    {
+      std::vector<int64_t> fill(in_off.begin(), in_off.end() - 1);
+      for (int l = 0; l < n_lats; l++) {
+        const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
+        for (int s = 0; s < ns; s++)
+          for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
+            const int64_t pos = fill[static_cast<size_t>(sb) + arc_nextstate[a]]++;
+            in_arc[pos] = a;  // ascending arc index per destination
+            in_src[pos] = s;
+          }
+      }
+    }
+    std::vector<int64_t> h_arc_off(arc_offsets, arc_offsets + total_states + 1);
+    std::vector<int32_t> h_next(arc_nextstate, arc_nextstate + total_arcs), h_il(arc_ilabel, arc_ilabel + total_arcs);
+    std::vector<float> h_g(arc_graph, arc_graph + total_arcs), h_a(arc_acoustic, arc_acoustic + total_arcs),
+        h_fin(state_final, state_final + total_states);
+    int rc;
+#define UP(dev, host) do { rc = dev.Upload(host, st); if (rc) return rc; } while (0)
+    UP(d_descs, descs); UP(d_arc_off, h_arc_off); UP(d_next, h_next); UP(d_ilabel, h_il); UP(d_g, h_g); UP(d_a, h_a);
+    UP(d_fin, h_fin); UP(d_level_off, level_off); UP(d_level_states, level_states); UP(d_in_off, in_off);
+    UP(d_in_arc, in_arc); UP(d_in_src, in_src); UP(d_final_list, final_list); UP(d_times, times);
+#undef UP
+    KH_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope
+    return KH_OK;
+  }
+};
+
 extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_offsets,
                                            const int64_t *arc_offsets, const int32_t *arc_ilabel,
                                            const int32_t *arc_nextstate, const float *arc_graph,
@@ -149,97 +451,22 @@ extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_
   if (rc) return rc;
   KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate &&
                arc_graph && arc_acoustic && state_final);
-  const int total_states = lat_state_offsets[n_lats];
-  const int64_t total_arcs = arc_offsets[total_states];
-  const float inf = std::numeric_limits<float>::infinity();
-  std::vector<LatDesc> descs(n_lats);
-  std::vector<int32_t> level_off, level_states(total_states), final_list, in_src(total_arcs);
-  std::vector<int64_t> in_off(static_cast<size_t>(total_states) + 1, 0), in_arc(total_arcs);
-  std::vector<int32_t> times(total_states, -1);
-  for (int l = 0; l < n_lats; l++) {
-    const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
-    KH_CHECK_ARG(ns > 0);
-    LatDesc &d = descs[l];
-    d.state_b = sb;
-    d.n_states = ns;
-    d.arc_b = arc_offsets[sb];
-    std::vector<int32_t> level(ns, 0);
-    int max_level = 0;
-    // LatticeStateTimes :36-67 + level assignment + topological-order check
-    // ("Input lattice must be topologically sorted", :38-39,:285-286).
-    times[sb] = 0;
-    for (int s = 0; s < ns; s++) {
-      const int cur_time = times[sb + s];
-      for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
-        const int nxt = arc_nextstate[a];
-        if (nxt <= s || nxt >= ns) {
-          SetError("lattice %d: arc %lld (state %d -> %d): input lattice must be topologically sorted",
-                   l, static_cast<long long>(a), s, nxt);
-          return KH_EINVAL;
-        }
-        if (cur_time >= 0) {
-          const int want = cur_time + (arc_ilabel[a] != 0 ? 1 : 0);
-          if (times[sb + nxt] == -1) times[sb + nxt] = want;
-          else if (times[sb + nxt] != want) {
-            SetError("lattice %d: inconsistent state times at state %d (KALDI_ASSERT lattice-functions.cc:55,61)", l, nxt);
-            return KH_EINVAL;
-          }
-        }
-        level[nxt] = std::max(level[nxt], level[s] + 1);
-        in_off[static_cast<size_t>(sb) + nxt + 1]++;
-      }
-      max_level = std::max(max_level, level[s]);
-    }
-    d.n_levels = max_level + 1;
-    d.level_b = static_cast<int32_t>(level_off.size());
-    std::vector<int32_t> cnt(d.n_levels + 1, 0);
-    for (int s = 0; s < ns; s++) cnt[level[s] + 1]++;
-    for (int i = 0; i < d.n_levels; i++) cnt[i + 1] += cnt[i];
-    for (int i = 0; i <= d.n_levels; i++) level_off.push_back(cnt[i]);
-    std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
-    for (int s = 0; s < ns; s++) level_states[sb + fill[level[s]]++] = s;
-    d.final_b = static_cast<int32_t>(final_list.size());
-    for (int s = 0; s < ns; s++)
-      if (state_final[sb + s] != inf) final_list.push_back(s);
-    d.n_final = static_cast<int32_t>(final_list.size()) - d.final_b;
-  }
-  for (size_t i = 0; i < static_cast<size_t>(total_states); i++) in_off[i + 1] += in_off[i];
-  {
-    std::vector<int64_t> fill(in_off.begin(), in_off.end() - 1);
-    for (int l = 0; l < n_lats; l++) {
-      const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
-      for (int s = 0; s < ns; s++)
-        for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
-          const int64_t pos = fill[static_cast<size_t>(sb) + arc_nextstate[a]]++;
-          in_arc[pos] = a;  // ascending arc index per destination
-          in_src[pos] = s;
-        }
-    }
-  }
-  if (state_times) memcpy(state_times, times.data(), sizeof(int32_t) * total_states);
-
   hipStream_t st = Stream();
-  DevArr<LatDesc> d_descs;
-  DevArr<int64_t> d_arc_off, d_in_off, d_in_arc;
-  DevArr<int32_t> d_next, d_level_off, d_level_states, d_in_src, d_final_list;
-  DevArr<float> d_g, d_a, d_fin, d_post;
+  LatBatch B;
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
+  if (rc) return rc;
+  const int total_states = B.total_states;
+  const int64_t total_arcs = B.total_arcs;
+  if (state_times) memcpy(state_times, B.times.data(), sizeof(int32_t) * total_states);
+  DevArr<float> d_post;
   DevArr<double> d_alpha, d_beta, d_tot, d_ac;
-  std::vector<int64_t> h_arc_off(arc_offsets, arc_offsets + total_states + 1);
-  std::vector<int32_t> h_next(arc_nextstate, arc_nextstate + total_arcs);
-  std::vector<float> h_g(arc_graph, arc_graph + total_arcs), h_a(arc_acoustic, arc_acoustic + total_arcs),
-      h_fin(state_final, state_final + total_states);
-#define UP(dev, host) do { rc = dev.Upload(host, st); if (rc) return rc; } while (0)
-  UP(d_descs, descs); UP(d_arc_off, h_arc_off); UP(d_next, h_next); UP(d_g, h_g); UP(d_a, h_a);
-  UP(d_fin, h_fin); UP(d_level_off, level_off); UP(d_level_states, level_states); UP(d_in_off, in_off);
-  UP(d_in_arc, in_arc); UP(d_in_src, in_src); UP(d_final_list, final_list);
-#undef UP
   if (d_post.Alloc(total_arcs) || d_alpha.Alloc(total_states) || d_beta.Alloc(total_states) ||
       d_tot.Alloc(n_lats) || d_ac.Alloc(n_lats))
     return KH_ENOMEM;
   const double min_log_diff = log(DBL_EPSILON);  // kMinLogDiffDouble kaldi-math.h:120
-  hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, d_descs.p,
-                     d_arc_off.p, d_next.p, d_g.p, d_a.p, d_fin.p, d_level_off.p, d_level_states.p,
-                     d_in_off.p, d_in_arc.p, d_in_src.p, d_final_list.p, d_alpha.p, d_beta.p,
+  hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p,
+                     B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p,
+                     B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p, d_alpha.p, d_beta.p,
                      d_post.p, d_tot.p, d_ac.p, min_log_diff);
   KH_LAUNCH_CHECK();
   if (arc_post)
@@ -249,5 +476,208 @@ extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_
   if (acoustic_like_sum)
     KH_HIP(hipMemcpyAsync(acoustic_like_sum, d_ac.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
   KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+// base/kaldi-math.h ApproxEqual
+static bool ApproxEqualD(double a, double b, double tol) {
+  if (a == b) return true;
+  const double diff = std::fabs(a - b);
+  if (diff == std::numeric_limits<double>::infinity() || diff != diff) return false;
+  return diff <= tol * (std::fabs(a) + std::fabs(b));
+}
+
+static int RunAlphaBeta(const LatBatch &B, DevArr<double> &d_alpha, DevArr<double> &d_beta, DevArr<double> &d_tot,
+                        int viterbi, hipStream_t st) {
+  if (d_alpha.Alloc(B.total_states) || d_beta.Alloc(B.total_states) || d_tot.Alloc(B.n_lats)) return KH_ENOMEM;
+  hipLaunchKernelGGL(AlphaBetaKernel, dim3(B.n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_next.p,
+                     B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p,
+                     B.d_in_src.p, B.d_final_list.p, d_alpha.p, d_beta.p, d_tot.p, viterbi, log(DBL_EPSILON));
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
+extern "C" int kh_lattice_alphas_betas(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                                       const int32_t *arc_ilabel, const int32_t *arc_nextstate,
+                                       const float *arc_graph, const float *arc_acoustic, const float *state_final,
+                                       int viterbi, double *alpha, double *beta, double *tot) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_graph &&
+               arc_acoustic && state_final);
+  hipStream_t st = Stream();
+  LatBatch B;
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
+  if (rc) return rc;
+  DevArr<double> d_alpha, d_beta, d_tot;
+  rc = RunAlphaBeta(B, d_alpha, d_beta, d_tot, viterbi, st);
+  if (rc) return rc;
+  std::vector<double> h_beta(B.total_states), h_tot(n_lats);
+  if (alpha) KH_HIP(hipMemcpyAsync(alpha, d_alpha.p, sizeof(double) * B.total_states, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipMemcpyAsync(h_beta.data(), d_beta.p, sizeof(double) * B.total_states, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipMemcpyAsync(h_tot.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  if (beta) memcpy(beta, h_beta.data(), sizeof(double) * B.total_states);
+  if (tot)
+    for (int l = 0; l < n_lats; l++) tot[l] = 0.5 * (h_beta[lat_state_offsets[l]] + h_tot[l]);  // :462
+  return KH_OK;
+}
+
+extern "C" int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_state_offsets,
+                                               const int64_t *arc_offsets, const int32_t *arc_ilabel,
+                                               const int32_t *arc_nextstate, const float *arc_graph,
+                                               const float *arc_acoustic, const float *state_final,
+                                               const int32_t *tid2phone, const int32_t *tid2pdf, int num_tids,
+                                               const int32_t *silence_phones, int n_sil, const int32_t *num_ali,
+                                               const int32_t *num_ali_offsets, int is_mpfe, int one_silence_class,
+                                               float *arc_post, double *tot_forward_score) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_graph &&
+               arc_acoustic && state_final && tid2phone && tid2pdf && num_tids > 0 && n_sil >= 0 &&
+               (n_sil == 0 || silence_phones) && num_ali && num_ali_offsets);
+  hipStream_t st = Stream();
+  LatBatch B;
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
+  if (rc) return rc;
+  for (int64_t a = 0; a < B.total_arcs; a++) KH_CHECK_ARG(arc_ilabel[a] >= 0 && arc_ilabel[a] <= num_tids);
+  for (int l = 0; l < n_lats; l++) {  // max_time == num_ali.size() :764
+    int max_time = 0;
+    for (int s = lat_state_offsets[l]; s < lat_state_offsets[l + 1]; s++) max_time = std::max(max_time, B.times[s]);
+    if (max_time != num_ali_offsets[l + 1] - num_ali_offsets[l]) {
+      SetError("lattice %d: max_time %d != num_ali.size() %d (KALDI_ASSERT lattice-functions.cc:764)", l, max_time,
+               num_ali_offsets[l + 1] - num_ali_offsets[l]);
+      return KH_EINVAL;
+    }
+  }
+  const int n_ali = num_ali_offsets[n_lats];
+  for (int i = 0; i < n_ali; i++) KH_CHECK_ARG(num_ali[i] > 0 && num_ali[i] <= num_tids);
+  DevArr<double> d_alpha, d_beta, d_tot, d_as, d_bs, d_score, d_bscore;
+  DevArr<float> d_post;
+  DevArr<int32_t> d_t2ph, d_t2pdf, d_sil, d_ali, d_ali_off;
+  rc = RunAlphaBeta(B, d_alpha, d_beta, d_tot, 0, st);
+  if (rc) return rc;
+  std::vector<int32_t> h_t2ph(tid2phone, tid2phone + num_tids + 1), h_t2pdf(tid2pdf, tid2pdf + num_tids + 1),
+      h_sil(silence_phones, silence_phones + n_sil), h_ali(num_ali, num_ali + n_ali),
+      h_ali_off(num_ali_offsets, num_ali_offsets + n_lats + 1);
+  if ((rc = d_t2ph.Upload(h_t2ph, st)) || (rc = d_t2pdf.Upload(h_t2pdf, st)) || (rc = d_sil.Upload(h_sil, st)) ||
+      (rc = d_ali.Upload(h_ali, st)) || (rc = d_ali_off.Upload(h_ali_off, st)))
+    return rc;
+  if (d_as.Alloc(B.total_states) || d_bs.Alloc(B.total_states) || d_score.Alloc(n_lats) || d_bscore.Alloc(n_lats) ||
+      d_post.Alloc(B.total_arcs))
+    return KH_ENOMEM;
+  MpeArgs m;
+  m.tid2phone = d_t2ph.p; m.tid2pdf = d_t2pdf.p; m.sil = d_sil.p; m.num_ali = d_ali.p; m.ali_off = d_ali_off.p;
+  m.times = B.d_times.p; m.ilabel = B.d_ilabel.p; m.n_sil = n_sil; m.is_mpfe = is_mpfe; m.one_silence_class = one_silence_class;
+  hipLaunchKernelGGL(MpeKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_next.p, B.d_g.p,
+                     B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,
+                     B.d_final_list.p, d_alpha.p, d_beta.p, d_tot.p, d_as.p, d_bs.p, m, d_post.p, d_score.p, d_bscore.p);
+  KH_LAUNCH_CHECK();
+  std::vector<double> h_tot(n_lats), h_beta0(n_lats), h_score(n_lats), h_bscore(n_lats);
+  KH_HIP(hipMemcpyAsync(h_tot.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipMemcpyAsync(h_score.data(), d_score.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipMemcpyAsync(h_bscore.data(), d_bscore.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  for (int l = 0; l < n_lats; l++)
+    KH_HIP(hipMemcpyAsync(&h_beta0[l], d_beta.p + lat_state_offsets[l], sizeof(double), hipMemcpyDeviceToHost, st));
+  if (arc_post) KH_HIP(hipMemcpyAsync(arc_post, d_post.p, sizeof(float) * B.total_arcs, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  for (int l = 0; l < n_lats; l++) {
+    if (!ApproxEqualD(h_tot[l], h_beta0[l], 1e-6)) {  // :808-811
+      SetError("lattice %d: Total forward probability over lattice = %g, while total backward probability = %g", l,
+               h_tot[l], h_beta0[l]);
+      return KH_ESTATE;
+    }
+    if (!ApproxEqualD(h_score[l], h_bscore[l], 1e-4)) {  // :909-912
+      SetError("lattice %d: Total forward score over lattice = %g, while total backward score = %g", l, h_score[l],
+               h_bscore[l]);
+      return KH_ESTATE;
+    }
+    if (tot_forward_score) tot_forward_score[l] = h_score[l];
+  }
+  return KH_OK;
+}
+
+extern "C" int kh_rescore_lattice(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                                  const int32_t *arc_ilabel, const int32_t *arc_nextstate, float *arc_acoustic,
+                                  const float *loglikes, int ll_stride, const int32_t *ll_row_offsets,
+                                  const int32_t *tid2pdf) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_acoustic &&
+               loglikes && ll_stride > 0 && ll_row_offsets);
+  const int total_states = lat_state_offsets[n_lats];
+  const int64_t total_arcs = arc_offsets[total_states];
+  // LatticeStateTimes; states with t == utt_len have no transition-id arcs to rescore
+  std::vector<int32_t> times(total_states, -1), state_lat(total_states);
+  for (int l = 0; l < n_lats; l++) {
+    const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
+    int utt_len = 0;
+    times[sb] = 0;
+    for (int s = 0; s < ns; s++) {
+      state_lat[sb + s] = l;
+      for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
+        const int nxt = arc_nextstate[a];
+        KH_CHECK_ARG(nxt > s && nxt < ns);  // top-sorted (the reference sorts first, :1313-1318)
+        if (times[sb + s] >= 0) {
+          const int want = times[sb + s] + (arc_ilabel[a] != 0 ? 1 : 0);
+          if (times[sb + nxt] == -1) times[sb + nxt] = want;
+          utt_len = std::max(utt_len, want);
+        }
+      }
+    }
+    if (utt_len > ll_row_offsets[l + 1] - ll_row_offsets[l]) {
+      SetError("lattice %d: Features are too short for lattice: utt-len is %d (lattice-functions.cc:1337-1341)", l, utt_len);
+      return KH_EINVAL;
+    }
+    for (int s = 0; s < ns; s++)
+      if (times[sb + s] >= utt_len) times[sb + s] = -1;
+  }
+  hipStream_t st = Stream();
+  DevArr<int64_t> d_off;
+  DevArr<int32_t> d_il, d_times, d_lat, d_rows;
+  DevArr<float> d_a;
+  std::vector<int64_t> h_off(arc_offsets, arc_offsets + total_states + 1);
+  std::vector<int32_t> h_il(arc_ilabel, arc_ilabel + total_arcs), h_rows(ll_row_offsets, ll_row_offsets + n_lats + 1);
+  std::vector<float> h_a(arc_acoustic, arc_acoustic + total_arcs);
+  if ((rc = d_off.Upload(h_off, st)) || (rc = d_il.Upload(h_il, st)) || (rc = d_times.Upload(times, st)) ||
+      (rc = d_lat.Upload(state_lat, st)) || (rc = d_rows.Upload(h_rows, st)) || (rc = d_a.Upload(h_a, st)))
+    return rc;
+  hipLaunchKernelGGL(RescoreKernel, dim3(std::min(1024, (total_states + 255) / 256)), dim3(256), 0, st, total_states,
+                     d_off.p, d_il.p, d_times.p, d_lat.p, d_rows.p, d_a.p, loglikes, ll_stride, tid2pdf);
+  KH_LAUNCH_CHECK();
+  KH_HIP(hipMemcpyAsync(arc_acoustic, d_a.p, sizeof(float) * total_arcs, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+extern "C" int kh_comp_objf_and_deriv(int n, const int32_t *rows, const int32_t *cols, const float *weights,
+                                      const float *output, KhMatrixDim d_output, float *deriv, KhMatrixDim d_deriv,
+                                      float *tot_objf, float *tot_weight) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(n >= 0 && output && deriv && tot_objf && tot_weight && d_output.rows == d_deriv.rows &&
+               d_output.cols == d_deriv.cols && (n == 0 || (rows && cols && weights)));
+  *tot_objf = 0.0f;
+  *tot_weight = 0.0f;
+  if (n == 0) return KH_OK;  // "Empty supervision labels" :1214-1218
+  for (int i = 0; i < n; i++)  // :1202-1207
+    KH_CHECK_ARG(rows[i] >= 0 && rows[i] < d_deriv.rows && cols[i] >= 0 && cols[i] < d_deriv.cols);
+  hipStream_t st = Stream();
+  DevArr<int32_t> d_r, d_c;
+  DevArr<float> d_w;
+  DevArr<double> d_sums;
+  std::vector<int32_t> h_r(rows, rows + n), h_c(cols, cols + n);
+  std::vector<float> h_w(weights, weights + n);
+  if ((rc = d_r.Upload(h_r, st)) || (rc = d_c.Upload(h_c, st)) || (rc = d_w.Upload(h_w, st))) return rc;
+  if (d_sums.Alloc(2)) return KH_ENOMEM;
+  KH_HIP(hipMemsetAsync(d_sums.p, 0, sizeof(double) * 2, st));
+  hipLaunchKernelGGL(CompObjfKernel, dim3(std::min(256, (n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, n,
+                     d_r.p, d_c.p, d_w.p, output, d_output.stride, deriv, d_deriv.stride, d_sums.p);
+  KH_LAUNCH_CHECK();
+  double h[2];
+  KH_HIP(hipMemcpyAsync(h, d_sums.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  *tot_objf = static_cast<float>(h[0]);
+  *tot_weight = static_cast<float>(h[1]);
   return KH_OK;
 }

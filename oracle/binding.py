@@ -496,3 +496,67 @@ def lattice_forward_backward(csr):
              _fp(_f32(csr["arc_graph"])), _fp(_f32(csr["arc_acoustic"])), _fp(_f32(csr["state_final"])),
              _fp(post), C.byref(ac), _ip(times), C.byref(fwd))
     return dict(arc_post=post, tot_like=tot, tot_forward=fwd.value, acoustic_like_sum=ac.value, state_times=times)
+
+
+def _csr_args(csr):
+    off = np.ascontiguousarray(csr["arc_offsets"], np.int64)
+    keep = (off, _i32(csr["arc_ilabel"]), _i32(csr["arc_nextstate"]), _f32(csr["arc_graph"]),
+            _f32(csr["arc_acoustic"]), _f32(csr["state_final"]))
+    return keep
+
+
+def lattice_alphas_betas(csr, viterbi=False):
+    """ko_lattice_alphas_betas (ComputeLatticeAlphasAndBetas :412-463)."""
+    lib = C.CDLL(ORACLE_SO)
+    fn = lib.ko_lattice_alphas_betas
+    fn.restype = C.c_double
+    off, il, ns, g, a, fin = _csr_args(csr)
+    n = csr["n_states"]
+    alpha, beta = np.empty(n, np.float64), np.empty(n, np.float64)
+    tot = fn(C.c_int(n), off.ctypes.data_as(c_int64_p), _ip(ns), _fp(g), _fp(a), _fp(fin), C.c_int(int(viterbi)),
+             alpha.ctypes.data_as(C.POINTER(C.c_double)), beta.ctypes.data_as(C.POINTER(C.c_double)))
+    return dict(alpha=alpha, beta=beta, tot=tot)
+
+
+def lattice_forward_backward_mpe(csr, tid2phone, tid2pdf, silence_phones, num_ali, criterion="smbr",
+                                 one_silence_class=False):
+    """ko_lattice_forward_backward_mpe (LatticeForwardBackwardMpeVariants :740-919)."""
+    lib = C.CDLL(ORACLE_SO)
+    fn = lib.ko_lattice_forward_backward_mpe
+    fn.restype = C.c_int
+    off, il, ns, g, a, fin = _csr_args(csr)
+    t2ph, t2pdf, sil, ali = _i32(tid2phone), _i32(tid2pdf), _i32(sorted(silence_phones)), _i32(num_ali)
+    post = np.empty(len(il), np.float32)
+    score = C.c_double()
+    rc = fn(C.c_int(csr["n_states"]), off.ctypes.data_as(c_int64_p), _ip(il), _ip(ns), _fp(g), _fp(a), _fp(fin),
+            _ip(t2ph), _ip(t2pdf), _ip(sil), C.c_int(len(sil)), _ip(ali), C.c_int(len(ali)),
+            C.c_int(int(criterion == "mpfe")), C.c_int(int(one_silence_class)), _fp(post), C.byref(score))
+    if rc != 0:
+        raise RuntimeError("forward-backward check %d failed" % -rc)
+    return dict(arc_post=post, tot_forward_score=score.value)
+
+
+def rescore_lattice(csr, loglikes, tid2pdf=None):
+    """ko_rescore_lattice (RescoreLattice :1307-1358); returns the new acoustic costs."""
+    lib = C.CDLL(ORACLE_SO)
+    off, il, ns, g, a, fin = _csr_args(csr)
+    a = a.copy()
+    ll = _f32(loglikes)
+    t2p = _ip(_i32(tid2pdf)) if tid2pdf is not None else None
+    rc = lib.ko_rescore_lattice(C.c_int(csr["n_states"]), off.ctypes.data_as(c_int64_p), _ip(il), _ip(ns), _fp(a),
+                                _fp(ll), C.c_int(ll.shape[0]), C.c_int(ll.shape[1]), t2p)
+    if rc != 0:
+        raise RuntimeError("features are too short for the lattice")
+    return a
+
+
+def comp_objf_and_deriv(rows, cols, weights, output, deriv):
+    """ko_comp_objf_and_deriv (CuMatrix::CompObjfAndDeriv CPU branch); deriv is updated in place."""
+    lib = C.CDLL(ORACLE_SO)
+    r, c, w = _i32(rows), _i32(cols), _f32(weights)
+    out = _f32(output)
+    assert deriv.dtype == np.float32 and deriv.flags.c_contiguous
+    objf, wt = C.c_float(), C.c_float()
+    lib.ko_comp_objf_and_deriv(C.c_int(len(r)), _ip(r), _ip(c), _fp(w), _fp(out), C.c_int(out.shape[1]),
+                               _fp(deriv), C.c_int(deriv.shape[1]), C.byref(objf), C.byref(wt))
+    return objf.value, wt.value

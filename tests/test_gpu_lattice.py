@@ -53,3 +53,94 @@ def test_unsorted_lattice_is_rejected(api):
              arc_acoustic=np.zeros(2, np.float32), state_final=np.array([np.inf, 0], np.float32))
     with pytest.raises(api.KhError, match="topologically sorted"):
         api.lattice_forward_backward([L])
+
+
+def _trans(rng, n_tid=50, n_phone=6, n_pdf=9):
+    return (np.concatenate([[0], rng.integers(1, n_phone + 1, n_tid)]).astype(np.int32),
+            np.concatenate([[0], rng.integers(0, n_pdf, n_tid)]).astype(np.int32))
+
+
+@pytest.mark.parametrize("criterion,one_class", [("smbr", False), ("smbr", True), ("mpfe", False), ("mpfe", True)])
+def test_mpe_variants_batch(api, criterion, one_class):
+    """LatticeForwardBackwardMpeVariants (lat/lattice-functions.cc:740-919) vs the oracle."""
+    rng = np.random.default_rng(21)
+    lats = [random_lattice(rng, n_frames=int(rng.integers(3, 30)), width=5) for _ in range(9)]
+    t2ph, t2pdf = _trans(rng)
+    sil = [2, 5]
+    alis = [rng.integers(1, 50, int(B.lattice_forward_backward(L)["state_times"].max())).astype(np.int32) for L in lats]
+    outs = api.lattice_forward_backward_mpe(lats, t2ph, t2pdf, sil, alis, criterion, one_class)
+    for L, ali, got in zip(lats, alis, outs):
+        want = B.lattice_forward_backward_mpe(L, t2ph, t2pdf, sil, ali, criterion, one_class)
+        assert abs(got["tot_forward_score"] - want["tot_forward_score"]) < 1e-9 * max(1.0, abs(want["tot_forward_score"]))
+        assert np.abs(got["arc_post"] - want["arc_post"]).max() < 1e-6
+        assert len(got["post"]) == len(ali)
+        # the sMBR / MPFE posteriors of a frame sum to ~0 (sum_paths P (acc - E[acc]) = 0 per frame)
+        for ent in got["post"]:
+            assert abs(sum(w for _, w in ent)) < 1e-4
+    with pytest.raises(api.KhError, match="max_time"):
+        api.lattice_forward_backward_mpe(lats[:1], t2ph, t2pdf, sil, [alis[0][:-1]], criterion, one_class)
+
+
+@pytest.mark.parametrize("viterbi", [False, True])
+def test_alphas_and_betas(api, viterbi):
+    rng = np.random.default_rng(22)
+    lats = [random_lattice(rng, n_frames=int(rng.integers(3, 30)), width=5) for _ in range(7)]
+    for L, got in zip(lats, api.lattice_alphas_betas(lats, viterbi)):
+        want = B.lattice_alphas_betas(L, viterbi)
+        assert np.allclose(got["alpha"], want["alpha"], rtol=1e-12, atol=1e-9)
+        assert np.allclose(got["beta"], want["beta"], rtol=1e-12, atol=1e-9)
+        assert abs(got["tot"] - want["tot"]) < 1e-9
+        if viterbi:  # max / plus only: exact
+            assert np.array_equal(got["alpha"], want["alpha"]) and np.array_equal(got["beta"], want["beta"])
+
+
+def test_rescore_lattice_and_objf_deriv(api):
+    import torch
+    rng = np.random.default_rng(23)
+    lats = [random_lattice(rng, n_frames=int(T), width=4) for T in (4, 11, 7)]
+    rows = np.concatenate([[0], np.cumsum([5, 11, 9])]).astype(np.int32)   # lattice 0 and 2 have spare rows
+    ll = rng.standard_normal((int(rows[-1]), 60)).astype(np.float32)
+    got = api.rescore_lattice(lats, torch.from_numpy(ll).cuda(), rows)
+    for i, L in enumerate(lats):
+        want = B.rescore_lattice(L, ll[rows[i]:rows[i + 1]])
+        assert np.array_equal(got[i].view(np.int32), want.view(np.int32))
+    with pytest.raises(api.KhError, match="too short"):
+        api.rescore_lattice(lats[1:2], torch.from_numpy(ll).cuda(), np.array([0, 10], np.int32))
+    # CompObjfAndDeriv
+    out = (rng.random((40, 30)) + 0.05).astype(np.float32)
+    labels = [(int(rng.integers(0, 40)), int(rng.integers(0, 30)), float(rng.standard_normal())) for _ in range(500)]
+    deriv_h = np.zeros((40, 30), np.float32)
+    objf_w, wt_w = B.comp_objf_and_deriv([x[0] for x in labels], [x[1] for x in labels], [x[2] for x in labels], out, deriv_h)
+    deriv_d = torch.zeros((40, 32), dtype=torch.float32, device="cuda")[:, :30]
+    objf, wt = api.comp_objf_and_deriv(deriv_d, labels, torch.from_numpy(out).cuda())
+    assert abs(objf - objf_w) < 1e-3 * max(1.0, abs(objf_w)) and abs(wt - wt_w) < 1e-3
+    assert np.allclose(deriv_d.cpu().numpy(), deriv_h, rtol=1e-5, atol=1e-5)
+    assert api.comp_objf_and_deriv(deriv_d, [], torch.from_numpy(out).cuda()) == (0.0, 0.0)
+
+
+def test_mmi_posteriors(api):
+    """LatticeForwardBackwardMmi (:1361-1396): numerator alignment minus denominator
+    posteriors; with convert_to_pdf_ids + cancel every frame's weights sum to ~0."""
+    rng = np.random.default_rng(24)
+    lats = [random_lattice(rng, n_frames=int(T), width=4) for T in (6, 13)]
+    _, t2pdf = _trans(rng)
+    alis = [rng.integers(1, 50, T).astype(np.int32) for T in (6, 13)]
+    fb = api.lattice_forward_backward(lats)
+    for conv in (False, True):
+        for cancel in (False, True):
+            outs = api.lattice_forward_backward_mmi(lats, t2pdf, alis, drop_frames=False, convert_to_pdf_ids=conv, cancel=cancel)
+            for o, r, ali in zip(outs, fb, alis):
+                assert o["tot_like"] == r["tot_like"] and len(o["post"]) == len(ali)
+                for t, ent in enumerate(o["post"]):
+                    assert abs(sum(w for _, w in ent)) < 1e-4       # +1 numerator, -1 denominator mass
+                    ids = [i for i, _ in ent]
+                    if cancel:
+                        assert ids == sorted(set(ids))
+                    ref_id = int(t2pdf[ali[t]]) if conv else int(ali[t])
+                    assert ref_id in ids or cancel              # cancelled entries (exactly 0) are dropped
+    # drop_frames: frames where the numerator label is not in the denominator lattice are emptied
+    outs = api.lattice_forward_backward_mmi(lats, t2pdf, alis, drop_frames=True, convert_to_pdf_ids=False, cancel=True)
+    for o, r, ali in zip(outs, fb, alis):
+        for t, ent in enumerate(o["post"]):
+            in_den = int(ali[t]) in {i for i, _ in r["post"][t]}
+            assert (len(ent) > 0) == in_den or (in_den and len(ent) == 0 and len(r["post"][t]) == 1)

@@ -101,3 +101,105 @@ def test_forward_backward_on_decoder_lattice():
     # total likelihood >= best path likelihood
     assert out["tot_like"] >= -(bp["graph_cost"] + bp["acoustic_cost"]) - 1e-4
     assert out["state_times"].max() == 50
+
+
+def _trans(rng, n_tid=50, n_phone=6, n_pdf=9):
+    """TransitionIdToPhone / TransitionIdToPdf as arrays indexed by transition-id (0 unused)."""
+    return (np.concatenate([[0], rng.integers(1, n_phone + 1, n_tid)]).astype(np.int32),
+            np.concatenate([[0], rng.integers(0, n_pdf, n_tid)]).astype(np.int32))
+
+
+def _frame_acc(L, t2ph, t2pdf, sil, ali, times, a, src, criterion, one_class):
+    il = int(L["arc_ilabel"][a])
+    if il == 0:
+        return 0.0
+    t = int(times[src])
+    phone, ref_phone = int(t2ph[il]), int(t2ph[ali[t]])
+    p_sil, r_sil = phone in sil, ref_phone in sil
+    if criterion == "smbr":
+        same = int(t2pdf[il]) == int(t2pdf[ali[t]])
+    else:
+        same = phone == ref_phone
+    if not one_class:
+        return 1.0 if (same and not p_sil) else 0.0
+    return 1.0 if (same or (p_sil and r_sil)) else 0.0
+
+
+@pytest.mark.parametrize("criterion", ["smbr", "mpfe"])
+@pytest.mark.parametrize("one_class", [False, True])
+def test_mpe_variants_match_path_enumeration(criterion, one_class):
+    """posterior_smbr(arc) = sum over paths through the arc of P(path) * (acc(path) - E[acc]);
+    tot_forward_score = E[acc] (lat/lattice-functions.cc:740-919)."""
+    rng = np.random.default_rng(11)
+    L = random_lattice(rng, n_frames=5, width=3)
+    t2ph, t2pdf = _trans(rng)
+    sil = [1, 2]
+    ali = rng.integers(1, 50, 5).astype(np.int32)
+    fb = B.lattice_forward_backward(L)
+    times = fb["state_times"]
+    off = L["arc_offsets"]
+    src_of = np.repeat(np.arange(L["n_states"]), np.diff(off))
+    cost = (L["arc_graph"] + L["arc_acoustic"]).astype(np.float64)
+    paths = []
+    stack = [(0, 0.0, [])]
+    while stack:
+        s, c, path = stack.pop()
+        if np.isfinite(L["state_final"][s]):
+            paths.append((np.exp(-(c + float(L["state_final"][s]))), path))
+        for a in range(off[s], off[s + 1]):
+            stack.append((int(L["arc_nextstate"][a]), c + cost[a], path + [a]))
+    tot = sum(p for p, _ in paths)
+    acc = [sum(_frame_acc(L, t2ph, t2pdf, sil, ali, times, a, src_of[a], criterion, one_class) for a in path)
+           for _, path in paths]
+    e_acc = sum(p * x for (p, _), x in zip(paths, acc)) / tot
+    want = np.zeros(len(cost))
+    for (p, path), x in zip(paths, acc):
+        for a in path:
+            if L["arc_ilabel"][a] != 0:
+                want[a] += p / tot * (x - e_acc)
+    out = B.lattice_forward_backward_mpe(L, t2ph, t2pdf, sil, ali, criterion, one_class)
+    assert abs(out["tot_forward_score"] - e_acc) < 1e-9
+    assert np.abs(out["arc_post"] - want).max() < 1e-6
+
+
+def test_alphas_betas_and_viterbi():
+    rng = np.random.default_rng(12)
+    L = random_lattice(rng, n_frames=6, width=3)
+    fb = B.lattice_forward_backward(L)
+    ab = B.lattice_alphas_betas(L, viterbi=False)
+    assert abs(ab["tot"] - fb["tot_like"]) < 1e-9 and ab["alpha"][0] == 0.0 and abs(ab["beta"][0] - fb["tot_like"]) < 1e-9
+    vit = B.lattice_alphas_betas(L, viterbi=True)
+    # Viterbi total = minus the cost of the best path (enumeration)
+    _, logtot = brute_force(L)
+    best = -np.inf
+    off = L["arc_offsets"]
+    cost = (L["arc_graph"] + L["arc_acoustic"]).astype(np.float64)
+    stack = [(0, 0.0)]
+    while stack:
+        s, c = stack.pop()
+        if np.isfinite(L["state_final"][s]):
+            best = max(best, -(c + float(L["state_final"][s])))
+        for a in range(off[s], off[s + 1]):
+            stack.append((int(L["arc_nextstate"][a]), c + cost[a]))
+    assert abs(vit["tot"] - best) < 1e-9 and vit["tot"] <= logtot + 1e-12
+
+
+def test_rescore_lattice_and_objf_deriv():
+    rng = np.random.default_rng(13)
+    L = random_lattice(rng, n_frames=4, width=3)
+    ll = rng.standard_normal((4, 60)).astype(np.float32)
+    new_a = B.rescore_lattice(L, ll)
+    times = B.lattice_forward_backward(L)["state_times"]
+    src = np.repeat(np.arange(L["n_states"]), np.diff(L["arc_offsets"]))
+    for a in range(len(new_a)):
+        il = L["arc_ilabel"][a]
+        want = L["arc_acoustic"][a] if il == 0 else np.float32(-ll[times[src[a]], il - 1]) + L["arc_acoustic"][a]
+        assert new_a[a] == np.float32(want)
+    with pytest.raises(RuntimeError):
+        B.rescore_lattice(L, ll[:3])
+    out = (rng.random((5, 7)) + 0.05).astype(np.float32)
+    deriv = np.zeros((5, 7), np.float32)
+    rows, cols, w = [0, 3, 3, 4], [1, 2, 2, 6], [1.0, -0.5, 0.25, 2.0]
+    objf, wt = B.comp_objf_and_deriv(rows, cols, w, out, deriv)
+    assert abs(objf - sum(x * np.log(out[r, c]) for r, c, x in zip(rows, cols, w))) < 1e-5 and abs(wt - 2.75) < 1e-6
+    assert abs(deriv[3, 2] - (-0.5 + 0.25) / out[3, 2]) < 1e-5 and deriv.sum() != 0
