@@ -11,6 +11,11 @@
 //   kaldi::cu::Splice          cudamatrix/cu-math.h
 //   kaldi::LatticeFasterDecoderConfig / LatticeFasterDecoder
 //                              decoder/lattice-faster-decoder.h:40-205
+//   kaldi::LatticeFasterOnlineDecoder  decoder/lattice-faster-online-decoder.h:44-200
+//   kaldi::Nnet, NnetComputation       nnet2/nnet-nnet.h, nnet2/nnet-compute.cc:159-166
+//   kaldi::DiagGmm (likelihoods)       gmm/diag-gmm.h:83-135
+//   kaldi::LatticeForwardBackward, LatticeForwardBackwardMpeVariants
+//                              lat/lattice-functions.cc:272-354,740-919
 // Errors throw std::runtime_error exactly as KALDI_ERR does
 // (base/kaldi-error.cc:143,179-182); all operations are synchronous at the API
 // (results visible on return), like the reference's CU_SAFE_CALL
@@ -19,7 +24,9 @@
 #define KALDI_HIP_HOST_H_
 
 #include <cstdint>
+#include <cstdio>
 #include <limits>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -56,7 +63,7 @@ class CuDevice {
     KhCheck(kh_select_gpu(-1));
   }
   /// Explicit ordinal for one-process-per-GPU sharding.
-  void SelectGpuId(int32 ordinal) { KhCheck(kh_select_gpu(ordinal)); }
+  void SelectGpuId(int32 ordinal) { KhCheck(kh_select_gpu(ordinal)); active_gpu_id_ = ordinal; }
   bool Enabled() const { return kh_enabled() != 0; }
   std::string DeviceGetName() const {
     char buf[256];
@@ -74,9 +81,40 @@ class CuDevice {
     return p;
   }
   void Free(void *ptr) { KhCheck(kh_free(ptr)); }
+  /// ActiveGpuId() cu-device.h:67: -1 until a device is selected.
+  int32 ActiveGpuId() const { return Enabled() ? active_gpu_id_ : -1; }
+  /// GetFreeMemory(int64 *free, int64 *total) cu-device.cc:425-462
+  std::string GetFreeMemory(int64_t *free_b = NULL, int64_t *total_b = NULL) const {
+    size_t f = 0, t = 0;
+    KhCheck(kh_mem_info(&f, &t));
+    if (free_b) *free_b = static_cast<int64_t>(f);
+    if (total_b) *total_b = static_cast<int64_t>(t);
+    char buf[128];
+    snprintf(buf, sizeof(buf), "free:%lldM, used:%lldM, total:%lldM, free/total:%g", (long long)(f >> 20),
+             (long long)((t - f) >> 20), (long long)(t >> 20), t ? double(f) / double(t) : 0.0);
+    return buf;
+  }
+  void PrintMemoryUsage() const { fprintf(stderr, "Memory used: %s\n", GetFreeMemory().c_str()); }  // :465
+  void CheckGpuHealth() { KhCheck(kh_synchronize()); }                                              // :563
+  bool DoublePrecisionSupported() const { return true; }                                           // :407
+  void SetVerbose(bool verbose) { verbose_ = verbose; }
+  /// AccuProfile / PrintProfile / ResetProfile cu-device.cc:379-405
+  void AccuProfile(const std::string &key, double time) { profile_map_[key] += time; }
+  void PrintProfile() {
+    if (!verbose_ || !Enabled()) return;
+    fprintf(stderr, "-----\n[cudevice profile]\n");
+    for (std::map<std::string, double>::const_iterator it = profile_map_.begin(); it != profile_map_.end(); ++it)
+      fprintf(stderr, "%s\t%gs\n", it->first.c_str(), it->second);
+    fprintf(stderr, "-----\n");
+    PrintMemoryUsage();
+  }
+  void ResetProfile() { profile_map_.clear(); }
 
  private:
-  CuDevice() {}
+  CuDevice() : active_gpu_id_(0), verbose_(true) {}
+  int32 active_gpu_id_;
+  bool verbose_;
+  std::map<std::string, double> profile_map_;
 };
 
 // ---- CuArray cu-array.h:36-105 -------------------------------------------------------
@@ -252,6 +290,28 @@ class CuMatrix {
     KhCheck(kh_sum_column_ranges(data_, Dim(), src.data_, src.Dim(), r.Data()));
     Sync();
   }
+  /// this <- NormalizeComponent::Propagate(src) (nnet2/nnet-component.cc:576-588) in one kernel
+  void NormalizePerRow(const CuMatrix &src) {
+    KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
+    KhCheck(kh_normalize(data_, src.data_, Dim(), src.stride_));
+    Sync();
+  }
+  /// v.AddDiagMat2(alpha, *this, kNoTrans, beta) cu-vector.cc:517-580: v = beta v + alpha diag(M M^T)
+  void AddDiagMat2To(CuVector *v, BaseFloat alpha, BaseFloat beta) const {
+    KALDI_HIP_ASSERT(v->Dim() == num_rows_);
+    KhCheck(kh_add_diag_mat2(alpha, data_, Dim(), beta, v->Data()));
+    Sync();
+  }
+  /// CompObjfAndDeriv cu-matrix.cc:1198-1248 on *this = the derivative; labels = (row, column, weight)
+  struct MatrixElement { int32 row, column; BaseFloat weight; };
+  void CompObjfAndDeriv(const std::vector<MatrixElement> &sv_labels, const CuMatrix &output, BaseFloat *tot_objf,
+                        BaseFloat *tot_weight) {
+    std::vector<int32> r(sv_labels.size()), c(sv_labels.size());
+    std::vector<BaseFloat> w(sv_labels.size());
+    for (size_t i = 0; i < sv_labels.size(); i++) { r[i] = sv_labels[i].row; c[i] = sv_labels[i].column; w[i] = sv_labels[i].weight; }
+    KhCheck(kh_comp_objf_and_deriv(static_cast<int>(r.size()), r.data(), c.data(), w.data(), output.data_, output.Dim(),
+                                   data_, Dim(), tot_objf, tot_weight));
+  }
   void Lookup(const std::vector<int32> &row_col_pairs, std::vector<BaseFloat> *output) const {  // :2327
     const int n = static_cast<int>(row_col_pairs.size() / 2);
     output->resize(n);
@@ -280,6 +340,124 @@ inline void Splice(const CuMatrix &src, const std::vector<int32> &frame_offsets,
   KhCheck(kh_synchronize());
 }
 }  // namespace cu
+
+// ---- nnet2::Nnet (forward only) + NnetComputation + DecodableAmNnet ----------------------
+/// Components are described by KhComponentDesc (host parameter pointers, copied at Add).
+class Nnet {
+ public:
+  Nnet() : nnet_(kh_nnet_create()) { if (!nnet_) KhCheck(KH_ENOMEM); }
+  ~Nnet() { kh_nnet_destroy(nnet_); }
+  void AddComponent(const KhComponentDesc &desc) { KhCheck(kh_nnet_add_component(nnet_, &desc)); }
+  void SetPriors(const std::vector<BaseFloat> &priors) {  // AmNnet::SetPriors am-nnet.h
+    KhCheck(kh_nnet_set_priors(nnet_, priors.data(), static_cast<int>(priors.size())));
+  }
+  int32 NumComponents() const { return kh_nnet_num_components(nnet_); }
+  int32 InputDim() const { return kh_nnet_input_dim(nnet_); }
+  int32 OutputDim() const { return kh_nnet_output_dim(nnet_); }
+  int32 LeftContext() const { return kh_nnet_left_context(nnet_); }    // nnet-nnet.cc:45
+  int32 RightContext() const { return kh_nnet_right_context(nnet_); }  // :55
+  KhNnet *Handle() const { return nnet_; }
+
+ private:
+  Nnet(const Nnet &);
+  Nnet &operator=(const Nnet &);
+  KhNnet *nnet_;
+};
+
+/// NnetComputation(nnet, input, pad_input, &output) nnet2/nnet-compute.cc:159-166 for one
+/// utterance (utt_row_offsets = {0, T}) or a batch stacked by rows.
+inline void NnetComputation(const Nnet &nnet, const CuMatrix &input, bool pad_input, CuMatrix *output,
+                            const std::vector<int32> *utt_row_offsets = NULL) {
+  std::vector<int32> one;
+  if (!utt_row_offsets) { one.push_back(0); one.push_back(input.NumRows()); utt_row_offsets = &one; }
+  const int n_utts = static_cast<int>(utt_row_offsets->size()) - 1;
+  const int rows = pad_input ? input.NumRows() : input.NumRows() - n_utts * (nnet.LeftContext() + nnet.RightContext());
+  KALDI_HIP_ASSERT(rows > 0);
+  output->Resize(rows, nnet.OutputDim(), kUndefined);
+  KhCheck(kh_nnet_compute(nnet.Handle(), input.Data(), input.Stride(), utt_row_offsets->data(), n_utts, pad_input, 0,
+                          1.0f, output->Data(), output->Stride(), NULL));
+}
+
+/// DecodableAmNnet's matrix (nnet2/decodable-am-nnet.h:47-69): floor, log, -log prior, scale.
+inline void ComputeScaledLogLikes(const Nnet &nnet, const CuMatrix &feats, bool pad_input, BaseFloat prob_scale,
+                                  CuMatrix *log_probs, const std::vector<int32> *utt_row_offsets = NULL) {
+  std::vector<int32> one;
+  if (!utt_row_offsets) { one.push_back(0); one.push_back(feats.NumRows()); utt_row_offsets = &one; }
+  const int n_utts = static_cast<int>(utt_row_offsets->size()) - 1;
+  const int rows = pad_input ? feats.NumRows() : feats.NumRows() - n_utts * (nnet.LeftContext() + nnet.RightContext());
+  KALDI_HIP_ASSERT(rows > 0);
+  log_probs->Resize(rows, nnet.OutputDim(), kUndefined);
+  KhCheck(kh_nnet_compute(nnet.Handle(), feats.Data(), feats.Stride(), utt_row_offsets->data(), n_utts, pad_input, 1,
+                          prob_scale, log_probs->Data(), log_probs->Stride(), NULL));
+}
+
+// ---- DiagGmm gmm/diag-gmm.h:83-135 (likelihood side) -------------------------------------
+class DiagGmm {
+ public:
+  /// weights [M], means_invvars / inv_vars [M x D] row-major host arrays; ComputeGconsts :114-152
+  DiagGmm(const std::vector<BaseFloat> &weights, const std::vector<BaseFloat> &means_invvars,
+          const std::vector<BaseFloat> &inv_vars, int32 dim)
+      : num_mix_(static_cast<int32>(weights.size())), dim_(dim) {
+    std::vector<BaseFloat> g(num_mix_);
+    int bad = kh_gmm_compute_gconsts(weights.data(), means_invvars.data(), inv_vars.data(), num_mix_, dim, g.data());
+    if (bad < 0) KhCheck(bad);
+    gconsts_.CopyFromVec(g);
+    means_invvars_.CopyFromVec(means_invvars);  // packed [M x D], as the C-ABI takes them
+    inv_vars_.CopyFromVec(inv_vars);
+  }
+  int32 NumGauss() const { return num_mix_; }
+  int32 Dim() const { return dim_; }
+  /// LogLikelihoods(const MatrixBase &data, Matrix *loglikes) diag-gmm.cc:546-562
+  void LogLikelihoods(const CuMatrix &data, CuMatrix *loglikes) const {
+    KALDI_HIP_ASSERT(data.NumCols() == dim_);
+    loglikes->Resize(data.NumRows(), num_mix_, kUndefined);
+    KhCheck(kh_diag_gmm_loglikes(data.Data(), data.Dim(), gconsts_.Data(), means_invvars_.Data(), inv_vars_.Data(),
+                                 num_mix_, loglikes->Data(), loglikes->Stride()));
+    KhCheck(kh_synchronize());
+  }
+
+ private:
+  int32 num_mix_, dim_;
+  CuVector gconsts_, means_invvars_, inv_vars_;
+};
+
+// ---- lattice functions lat/lattice-functions.cc ---------------------------------------------
+/// A top-sorted Lattice flattened to CSR (state 0 = start): what ArcIterator yields.
+struct LatticeCsr {
+  std::vector<int64_t> arc_offsets;                       // num_states + 1
+  std::vector<int32> arc_ilabel, arc_nextstate;
+  std::vector<BaseFloat> arc_graph, arc_acoustic, state_final;  // final = +inf for non-final states
+  int32 NumStates() const { return static_cast<int32>(state_final.size()); }
+};
+/// LatticeForwardBackward :272-354: arc posteriors, returns tot_backward_prob.
+inline double LatticeForwardBackward(const LatticeCsr &lat, std::vector<BaseFloat> *arc_post,
+                                     double *acoustic_like_sum = NULL, std::vector<int32> *state_times = NULL) {
+  const int32 soff[2] = {0, lat.NumStates()};
+  arc_post->resize(lat.arc_ilabel.size());
+  if (state_times) state_times->resize(lat.NumStates());
+  double tot = 0.0;
+  KhCheck(kh_lattice_forward_backward(1, soff, lat.arc_offsets.data(), lat.arc_ilabel.data(), lat.arc_nextstate.data(),
+                                      lat.arc_graph.data(), lat.arc_acoustic.data(), lat.state_final.data(),
+                                      arc_post->data(), &tot, acoustic_like_sum, state_times ? state_times->data() : NULL));
+  return tot;
+}
+/// LatticeForwardBackwardMpeVariants :740-919; returns tot_forward_score.
+inline double LatticeForwardBackwardMpeVariants(const std::vector<int32> &tid2phone, const std::vector<int32> &tid2pdf,
+                                                const std::vector<int32> &silence_phones, const LatticeCsr &lat,
+                                                const std::vector<int32> &num_ali, const std::string &criterion,
+                                                bool one_silence_class, std::vector<BaseFloat> *arc_post) {
+  KALDI_HIP_ASSERT(criterion == "mpfe" || criterion == "smbr");
+  const int32 soff[2] = {0, lat.NumStates()}, aoff[2] = {0, static_cast<int32>(num_ali.size())};
+  arc_post->resize(lat.arc_ilabel.size());
+  double score = 0.0;
+  KhCheck(kh_lattice_forward_backward_mpe(1, soff, lat.arc_offsets.data(), lat.arc_ilabel.data(),
+                                          lat.arc_nextstate.data(), lat.arc_graph.data(), lat.arc_acoustic.data(),
+                                          lat.state_final.data(), tid2phone.data(), tid2pdf.data(),
+                                          static_cast<int>(tid2phone.size()) - 1, silence_phones.data(),
+                                          static_cast<int>(silence_phones.size()), num_ali.data(), aoff,
+                                          criterion == "mpfe", one_silence_class, arc_post->data(), &score));
+  return score;
+}
 
 // ---- LatticeFasterDecoder lattice-faster-decoder.h:40-205 ------------------------------
 struct LatticeFasterDecoderConfig {

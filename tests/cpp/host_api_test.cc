@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../old-kaldi-git_amd/host/kaldi-hip.h"
@@ -143,6 +145,73 @@ static void TestDecoder() {
   kh_fst_destroy(fst);
 }
 
+static void TestNnetGmmLattice() {
+  // 2-layer net: affine 3 -> 4, softmax; NnetComputation vs hand computation
+  Nnet nnet;
+  std::vector<float> W = {1, 0, 0,  0, 1, 0,  0, 0, 1,  1, 1, 1}, b = {0, 0, 0, -1};
+  KhComponentDesc a;
+  memset(&a, 0, sizeof(a));
+  a.type = KH_AFFINE; a.input_dim = 3; a.output_dim = 4; a.linear = W.data(); a.bias = b.data();
+  nnet.AddComponent(a);
+  CHECK(nnet.InputDim() == 3 && nnet.OutputDim() == 4 && nnet.LeftContext() == 0);
+  std::vector<float> x = {1, 2, 3,  0, 0, 0};
+  CuMatrix X, Y;
+  X.CopyFromMat(x.data(), 2, 3, 3);
+  NnetComputation(nnet, X, true, &Y);
+  std::vector<float> y(8);
+  Y.CopyToMat(y.data(), 4);
+  CHECK(y[0] == 1 && y[1] == 2 && y[2] == 3 && y[3] == 5 && y[7] == -1);
+  // DiagGmm: one Gaussian N(0, I) in 2 dims: loglike(x) = -log(2 pi) - 0.5 |x|^2
+  std::vector<float> w(1, 1.0f), mi(2, 0.0f), iv(2, 1.0f);
+  DiagGmm gmm(w, mi, iv, 2);
+  std::vector<float> d = {0, 0,  1, 2};
+  CuMatrix D, LL;
+  D.CopyFromMat(d.data(), 2, 2, 2);
+  gmm.LogLikelihoods(D, &LL);
+  std::vector<float> ll(2);
+  LL.CopyToMat(ll.data(), 1);
+  Near(ll[0], -1.8378770664f, 1e-5f);
+  Near(ll[1], -1.8378770664f - 2.5f, 1e-5f);
+  // lattice 0 -(1)-> 1 -(2)-> 3, 0 -(3)-> 2 -(2)-> 3: two paths with costs 1 and 2
+  LatticeCsr lat;
+  lat.arc_offsets = {0, 2, 3, 4, 4};
+  lat.arc_ilabel = {1, 3, 2, 2};
+  lat.arc_nextstate = {1, 2, 3, 3};
+  lat.arc_graph = {0.5f, 1.0f, 0.5f, 1.0f};
+  lat.arc_acoustic = {0, 0, 0, 0};
+  const float inf = std::numeric_limits<float>::infinity();
+  lat.state_final = {inf, inf, inf, 0.0f};
+  std::vector<float> post;
+  std::vector<int32> times;
+  double tot = LatticeForwardBackward(lat, &post, NULL, &times);
+  const double p1 = std::exp(-1.0), p2 = std::exp(-2.0);
+  Near(static_cast<float>(tot), static_cast<float>(std::log(p1 + p2)), 1e-6f);
+  Near(post[0], static_cast<float>(p1 / (p1 + p2)), 1e-6f);
+  CHECK(times[3] == 2);
+  // sMBR with the reference alignment {1, 2}: path 1 has accuracy 2, path 2 accuracy 1
+  std::vector<int32> t2ph = {0, 1, 1, 1}, t2pdf = {0, 0, 1, 2}, sil, ali = {1, 2};
+  std::vector<float> spost;
+  double score = LatticeForwardBackwardMpeVariants(t2ph, t2pdf, sil, lat, ali, "smbr", false, &spost);
+  Near(static_cast<float>(score), static_cast<float>((2 * p1 + 1 * p2) / (p1 + p2)), 1e-6f);
+  // CompObjfAndDeriv
+  CuMatrix out, deriv(1, 2);
+  std::vector<float> o = {0.25f, 0.75f};
+  out.CopyFromMat(o.data(), 1, 2, 2);
+  std::vector<CuMatrix::MatrixElement> lab(1);
+  lab[0].row = 0; lab[0].column = 1; lab[0].weight = 2.0f;
+  float objf, wt;
+  deriv.CompObjfAndDeriv(lab, out, &objf, &wt);
+  Near(objf, 2.0f * std::log(0.75f), 1e-6f);
+  Near(wt, 2.0f, 1e-6f);
+  std::vector<float> dv(2);
+  deriv.CopyToMat(dv.data(), 2);
+  Near(dv[1], 2.0f / 0.75f, 1e-6f);
+  CHECK(CuDevice::Instantiate().ActiveGpuId() >= 0 && CuDevice::Instantiate().DoublePrecisionSupported());
+  int64_t fr = 0, to = 0;
+  CuDevice::Instantiate().GetFreeMemory(&fr, &to);
+  CHECK(fr > 0 && to >= fr);
+}
+
 int main() {
   try {
     CuDevice::Instantiate().SelectGpuId("yes");
@@ -150,6 +219,7 @@ int main() {
     TestAddMatMat();
     TestSoftmaxPnormCopyRows();
     TestDecoder();
+    TestNnetGmmLattice();
   } catch (const std::exception &e) {
     printf("FAIL exception: %s\n", e.what());
     return 1;
