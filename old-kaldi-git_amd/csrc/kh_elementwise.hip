@@ -36,11 +36,13 @@ __device__ __forceinline__ float BlockSum(float v, float *red) {
 // (reference: _softmax_reduce cu-kernels.cu:1624-1688 re-reads the row from
 // global memory in each of its three passes.)
 constexpr int kSoftmaxLdsFloats = 12288;  // 48 KiB: 3 blocks/CU
+constexpr int kBigBlock = 1024;  // wide rows (> 4096 columns): two blocks of 1024 threads fill a CU
 
-template <bool LOG>
-__global__ void __launch_bounds__(kBlock)
+template <bool LOG, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 SoftmaxKernel(float *__restrict__ y, const float *__restrict__ x, int cols,
               int y_stride, int x_stride) {
+  constexpr int kBlock = BLOCK;  // (shadows the file-scope default inside this kernel)
   __shared__ float cache[kSoftmaxLdsFloats];
   __shared__ float red[kBlock / 64];
   const int r = blockIdx.x;
@@ -76,31 +78,32 @@ SoftmaxKernel(float *__restrict__ y, const float *__restrict__ x, int cols,
 // Softmax (+1e-20 floor) -> sum over column ranges (-> floor, log, -log prior, scale):
 // the output layer of the nnet2 p-norm recipes in one pass, the row of probabilities
 // never leaves LDS.
-__global__ void __launch_bounds__(kBlock)
+template <int BLOCK>  // the block size (= the partition of the row sums) SoftmaxKernel uses for this width
+__global__ void __launch_bounds__(BLOCK)
 SoftmaxSumGroupKernel(float *__restrict__ y, const float *__restrict__ x, int in_cols, int out_cols,
                       int y_stride, int x_stride, const int32_t *__restrict__ ranges,
                       const float *__restrict__ log_priors, float prob_scale) {
   __shared__ float cache[kSoftmaxLdsFloats];
-  __shared__ float red[kBlock / 64];
+  __shared__ float red[BLOCK / 64];
   const int r = blockIdx.x;
   const float *xr = x + static_cast<size_t>(r) * x_stride;
   float *yr = y + static_cast<size_t>(r) * y_stride;
   float m = -INFINITY;
-  for (int c = threadIdx.x; c < in_cols; c += kBlock) {
+  for (int c = threadIdx.x; c < in_cols; c += BLOCK) {
     const float v = xr[c];
     cache[c] = v;
     m = fmaxf(m, v);
   }
   m = BlockMax(m, red);
   float s = 0.f;
-  for (int c = threadIdx.x; c < in_cols; c += kBlock) {
+  for (int c = threadIdx.x; c < in_cols; c += BLOCK) {
     const float e = expf(cache[c] - m);
     cache[c] = e;
     s += e;
   }
   s = BlockSum(s, red);
   const float inv = 1.0f / s;
-  for (int c = threadIdx.x; c < out_cols; c += kBlock) {
+  for (int c = threadIdx.x; c < out_cols; c += BLOCK) {
     const int b = ranges[2 * c], e = ranges[2 * c + 1];
     float sum = 0.f;
     for (int j = b; j < e; j++) {
@@ -176,6 +179,28 @@ int LaunchMap2D(int rows, int cols, F f) {
 }
 
 // ---- a5 group p-norm ---------------------------------------------------------------
+constexpr int kPnormLdsFloats = 4096;  // 16 KiB: rows of up to 4096 inputs
+// p == 2, row staged in LDS: the row is read once, coalesced (the generic kernel below
+// has every lane walk its own group, 40-byte strides); same summation order per group.
+__global__ void __launch_bounds__(kBlock)
+GroupPnorm2RowKernel(float *__restrict__ y, const float *__restrict__ x, int rows, int cols, int y_stride,
+                     int x_stride, int group) {
+  __shared__ float row[kPnormLdsFloats];
+  const int in_cols = cols * group;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *xr = x + static_cast<size_t>(r) * x_stride;
+    for (int c = threadIdx.x; c < in_cols; c += kBlock) row[c] = xr[c];
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += kBlock) {
+      const float *g = row + c * group;
+      float s = 0.f;
+      for (int j = 0; j < group; j++) s += g[j] * g[j];
+      y[static_cast<size_t>(r) * y_stride + c] = sqrtf(s);
+    }
+    __syncthreads();
+  }
+}
+
 template <int MODE>  // 0: p==2, 1: p==1, 2: generic
 __global__ void __launch_bounds__(kBlock)
 GroupPnormKernel(float *__restrict__ y, const float *__restrict__ x, int rows,
@@ -312,8 +337,12 @@ int FusedSoftmaxSumGroup(float *y, KhMatrixDim d_out, const float *x, KhMatrixDi
   if (rc) return rc;
   KH_CHECK_ARG(d_out.rows == d_in.rows && d_in.cols <= kSoftmaxLdsFloats && d_out.cols > 0 && y && x && ranges);
   if (d_out.rows == 0) return KH_OK;
-  hipLaunchKernelGGL(SoftmaxSumGroupKernel, dim3(d_out.rows), dim3(kBlock), 0, Stream(), y, x, d_in.cols, d_out.cols,
-                     d_out.stride, d_in.stride, ranges, log_priors, prob_scale);
+  if (d_in.cols > 4096)
+    hipLaunchKernelGGL(SoftmaxSumGroupKernel<kBigBlock>, dim3(d_out.rows), dim3(kBigBlock), 0, Stream(), y, x, d_in.cols,
+                       d_out.cols, d_out.stride, d_in.stride, ranges, log_priors, prob_scale);
+  else
+    hipLaunchKernelGGL(SoftmaxSumGroupKernel<kBlock>, dim3(d_out.rows), dim3(kBlock), 0, Stream(), y, x, d_in.cols,
+                       d_out.cols, d_out.stride, d_in.stride, ranges, log_priors, prob_scale);
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -331,8 +360,12 @@ int kh_softmax_per_row(float *y, const float *x, KhMatrixDim d, int src_stride) 
                        dim3(kBlock), 0, Stream(), y, x, d.rows, d.cols, d.stride,
                        src_stride);
   } else {
-    hipLaunchKernelGGL(SoftmaxKernel<false>, dim3(d.rows), dim3(kBlock), 0,
-                       Stream(), y, x, d.cols, d.stride, src_stride);
+    if (d.cols > 4096)
+      hipLaunchKernelGGL((SoftmaxKernel<false, kBigBlock>), dim3(d.rows), dim3(kBigBlock), 0,
+                         Stream(), y, x, d.cols, d.stride, src_stride);
+    else
+      hipLaunchKernelGGL((SoftmaxKernel<false, kBlock>), dim3(d.rows), dim3(kBlock), 0,
+                         Stream(), y, x, d.cols, d.stride, src_stride);
   }
   KH_LAUNCH_CHECK();
   return KH_OK;
@@ -349,8 +382,12 @@ int kh_log_softmax_per_row(float *y, const float *x, KhMatrixDim d,
                        dim3(kBlock), 0, Stream(), y, x, d.rows, d.cols, d.stride,
                        src_stride);
   } else {
-    hipLaunchKernelGGL(SoftmaxKernel<true>, dim3(d.rows), dim3(kBlock), 0,
-                       Stream(), y, x, d.cols, d.stride, src_stride);
+    if (d.cols > 4096)
+      hipLaunchKernelGGL((SoftmaxKernel<true, kBigBlock>), dim3(d.rows), dim3(kBigBlock), 0,
+                         Stream(), y, x, d.cols, d.stride, src_stride);
+    else
+      hipLaunchKernelGGL((SoftmaxKernel<true, kBlock>), dim3(d.rows), dim3(kBlock), 0,
+                         Stream(), y, x, d.cols, d.stride, src_stride);
   }
   KH_LAUNCH_CHECK();
   return KH_OK;
@@ -394,7 +431,10 @@ int kh_group_pnorm(float *y, const float *x, KhMatrixDim d, int src_stride,
                src_stride >= d.cols * group_size && power >= 0.0f);
   if (d.rows == 0 || d.cols == 0) return KH_OK;
   dim3 grid = RowColGrid(d.rows, d.cols);
-  if (power == 2.0f)
+  if (power == 2.0f && d.cols * group_size <= kPnormLdsFloats && d.cols * group_size >= 512)
+    hipLaunchKernelGGL(GroupPnorm2RowKernel, dim3(std::min(d.rows, NumCUs() * 16)), dim3(kBlock), 0, Stream(), y, x,
+                       d.rows, d.cols, d.stride, src_stride, group_size);
+  else if (power == 2.0f)
     hipLaunchKernelGGL(GroupPnormKernel<0>, grid, dim3(kBlock), 0, Stream(), y, x,
                        d.rows, d.cols, d.stride, src_stride, group_size, power);
   else if (power == 1.0f)
