@@ -188,3 +188,12 @@ def test_long_utterances_sparse_epsilons(api, monkeypatch):
     g = graph_like_hclg(rng, 40000, 300, eps_frac=0.01)
     lls = [workloads.make_loglikes(rng, int(T), 300) for T in (330, 41, 257, 26, 180, 75)]
     run_case(api, g, lls, api.decoder_config(beam=12.0, max_active=1200, min_active=100, lattice_beam=6.0))
+
+
+def test_very_long_utterance(api):
+    """1500 frames = 60 prune/compaction cycles: the stable part of the arenas grows to
+    lattice density while the window keeps sliding; still bit-exact."""
+    rng = np.random.default_rng(44)
+    g = graph_like_hclg(rng, 50000, 400)
+    lls = [workloads.make_loglikes(rng, 1500, 400)]
+    run_case(api, g, lls, api.decoder_config(beam=11.0, max_active=900, min_active=100, lattice_beam=5.0))
