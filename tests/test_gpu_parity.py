@@ -133,6 +133,20 @@ def test_gmm_rm_tri1_shape(gpu, oracle):
         assert np.abs(a - b).max() < 1e-4  # north_star tolerance on frame log-likelihoods
 
 
+def test_gmm_full_rm_tri1_size_uses_the_gemm_path(gpu, oracle):
+    """cfg 2 at full size (1800 pdfs / 9000 Gaussians): large enough for the two-GEMM
+    formulation of DiagGmm::LogLikelihoods (diag-gmm.cc:546-562); still bit-exact."""
+    rng = np.random.default_rng(4321)
+    am = workloads.make_am_gmm(rng, num_pdfs=1800, tot_gauss=9000, dim=39)
+    mi, iv = workloads.gmm_inv_params(am)
+    g, _ = gpu.gmm_compute_gconsts(am["weights"], mi, iv)
+    data = rng.standard_normal((600, 39)).astype(np.float32)
+    cases.exact(gpu.diag_gmm_loglikes_stored(data, g, mi, iv), oracle.diag_gmm_loglikes_stored(data, g, mi, iv))
+    a = gpu.am_gmm_loglikes(data, g, mi, iv, am["pdf_offsets"], -1.0)
+    b = oracle.am_gmm_loglikes(data, g, mi, iv, am["pdf_offsets"], -1.0)
+    assert np.abs(a - b).max() < 1e-4
+
+
 @pytest.mark.gpu
 def test_fused_output_layer_equals_separate_kernels(api, monkeypatch):
     """softmax -> sum-group (-> DecodableAmNnet epilogue) in one kernel performs the
