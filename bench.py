@@ -241,7 +241,9 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "frames/sec decoded (nnet2 forward + LatticeFasterDecoder); RTF = 100/value_per_gpu",
+            # BASELINE.json's metric; value = frames/s of nnet2 forward + LatticeFasterDecoder, "rtf" = the
+            # real-time factor per GPU (10 ms frames: rtf = 100 / frames-per-second-per-GPU)
+            "metric": "frames/sec decoded + real-time factor, LibriSpeech nnet2 decode @1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
