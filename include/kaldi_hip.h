@@ -404,7 +404,8 @@ int kh_lattice_alphas_betas(int n_lats, const int32_t *lat_state_offsets,
  * (num_ali_offsets[n_lats + 1]; lattice l needs max_time(l) entries, :764).
  * arc_post[a] = posterior_smbr of arc a (0 on epsilon arcs); the Posterior is
  * post[state_times[src(a)]] += (ilabel, arc_post[a]) merged as MergePairVectorSumming
- * (:916-917).  tot_forward_score[l] = the expected frame accuracy (:919).  Fails with
+ * (:916-917).  tot_forward_score[l] = the expected frame accuracy (:919); state_times
+ * (optional) = LatticeStateTimes of every state.  Fails with
  * KH_ESTATE when one of the reference's forward/backward checks fails (:808, :909). */
 int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_state_offsets,
                                     const int64_t *arc_offsets, const int32_t *arc_ilabel,
@@ -413,7 +414,7 @@ int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_state_offsets
                                     const int32_t *tid2phone, const int32_t *tid2pdf, int num_tids,
                                     const int32_t *silence_phones, int n_sil, const int32_t *num_ali,
                                     const int32_t *num_ali_offsets, int is_mpfe, int one_silence_class,
-                                    float *arc_post, double *tot_forward_score);
+                                    float *arc_post, double *tot_forward_score, int32_t *state_times);
 
 /* RescoreLattice (lat/lattice-functions.cc:1307-1358) with a matrix decodable: every
  * arc with a transition-id gets -loglikes[t][tid2pdf ? tid2pdf[tid] : tid - 1] added to

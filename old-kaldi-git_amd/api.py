@@ -669,23 +669,8 @@ def lattice_forward_backward(lats):
         a0, a1 = int(aoff[soff[i]]), int(aoff[soff[i + 1]])
         t = times[soff[i]:soff[i + 1]]
         ap = post[a0:a1]
-        # Posterior: (*post)[state_times[s]].push_back((tid, posterior)) for tid != 0
-        src = np.repeat(np.arange(L["n_states"]), np.diff(np.asarray(L["arc_offsets"], np.int64)))
-        tid = il[a0:a1]
-        frames = {}
-        for s, ti, p in zip(src[tid != 0], tid[tid != 0], ap[tid != 0]):
-            frames.setdefault(int(t[s]), {}).setdefault(int(ti), []).append(np.float32(p))
         max_time = int(t.max()) if len(t) else 0
-        posterior = []
-        for fr in range(max_time):
-            ent = []
-            for ti in sorted(frames.get(fr, {})):
-                acc = np.float32(0.0)
-                for p in frames[fr][ti]:
-                    acc = np.float32(acc + p)
-                if acc != 0.0:
-                    ent.append((ti, float(acc)))
-            posterior.append(ent)
+        posterior = _arc_posterior_to_post(L, t, il[a0:a1], ap, max_time)
         out.append(dict(arc_post=ap.copy(), tot_like=float(tot[i]), acoustic_like_sum=float(ac[i]),
                         state_times=t.copy(), post=posterior))
     return out
@@ -710,22 +695,25 @@ def _cat_lattices(lats):
 
 def _arc_posterior_to_post(L, times, tids, arc_post, max_time):
     """(*post)[state_times[s]].push_back((tid, p)) for tid != 0, then MergePairVectorSumming
-    (util/stl-utils.h: sort by tid, sum equal keys in float, drop zeros)."""
+    (util/stl-utils.h: sort by tid, sum equal keys in float in their original order, drop
+    zeros).  Vectorised: stable sort by (frame, tid), sequential float32 sums (np.add.at)."""
     src = np.repeat(np.arange(L["n_states"]), np.diff(np.asarray(L["arc_offsets"], np.int64)))
-    frames = {}
-    for s, ti, p in zip(src[tids != 0], tids[tids != 0], arc_post[tids != 0]):
-        frames.setdefault(int(times[s]), {}).setdefault(int(ti), []).append(np.float32(p))
-    posterior = []
-    for fr in range(max_time):
-        ent = []
-        for ti in sorted(frames.get(fr, {})):
-            acc = np.float32(0.0)
-            for p in frames[fr][ti]:
-                acc = np.float32(acc + p)
-            if acc != 0.0:
-                ent.append((ti, float(acc)))
-        posterior.append(ent)
-    return posterior
+    m = tids != 0
+    fr, ti, p = times[src[m]].astype(np.int64), tids[m].astype(np.int64), arc_post[m].astype(np.float32)
+    key = fr * (int(ti.max()) + 1 if len(ti) else 1) + ti
+    order = np.argsort(key, kind="stable")
+    key, fr, ti, p = key[order], fr[order], ti[order], p[order]
+    first = np.ones(len(key), bool)
+    first[1:] = key[1:] != key[:-1]
+    grp = np.cumsum(first) - 1
+    acc = np.zeros(int(grp[-1]) + 1 if len(grp) else 0, np.float32)
+    np.add.at(acc, grp, p)                       # unbuffered: adds in array order
+    gfr, gti = fr[first], ti[first]
+    keep = acc != 0.0
+    gfr, gti, acc = gfr[keep], gti[keep], acc[keep]
+    bounds = np.searchsorted(gfr, np.arange(max_time + 1))
+    tl, wl = gti.tolist(), acc.tolist()
+    return [list(zip(tl[bounds[t]:bounds[t + 1]], wl[bounds[t]:bounds[t + 1]])) for t in range(max_time)]
 
 
 def lattice_alphas_betas(lats, viterbi=False):
@@ -754,18 +742,18 @@ def lattice_forward_backward_mpe(lats, tid2phone, tid2pdf, silence_phones, num_a
     ali = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int32) for x in num_alis]) if len(num_alis) else [], np.int32)
     post = np.empty(len(il), np.float32)
     score = np.empty(n)
+    all_times = np.empty(int(soff[-1]), np.int32)
     ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
     check(lib().kh_lattice_forward_backward_mpe(
         n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
         g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp), t2ph.ctypes.data_as(ip),
         t2pdf.ctypes.data_as(ip), len(t2ph) - 1, sil.ctypes.data_as(ip), len(sil), ali.ctypes.data_as(ip),
         ali_off.ctypes.data_as(ip), int(criterion == "mpfe"), int(bool(one_silence_class)), post.ctypes.data_as(fp),
-        score.ctypes.data_as(dp)))
-    # state times for the Posterior (host, LatticeStateTimes :36-67)
+        score.ctypes.data_as(dp), all_times.ctypes.data_as(ip)))
     out = []
     for i, L in enumerate(lats):
         a0, a1 = int(aoff[soff[i]]), int(aoff[soff[i + 1]])
-        times = lattice_state_times(L)
+        times = all_times[soff[i]:soff[i + 1]]
         out.append(dict(arc_post=post[a0:a1].copy(), tot_forward_score=float(score[i]),
                         post=_arc_posterior_to_post(L, times, il[a0:a1], post[a0:a1], len(num_alis[i]))))
     return out

@@ -530,7 +530,7 @@ extern "C" int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_st
                                                const int32_t *tid2phone, const int32_t *tid2pdf, int num_tids,
                                                const int32_t *silence_phones, int n_sil, const int32_t *num_ali,
                                                const int32_t *num_ali_offsets, int is_mpfe, int one_silence_class,
-                                               float *arc_post, double *tot_forward_score) {
+                                               float *arc_post, double *tot_forward_score, int32_t *state_times) {
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_graph &&
@@ -540,6 +540,7 @@ extern "C" int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_st
   LatBatch B;
   rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
   if (rc) return rc;
+  if (state_times) memcpy(state_times, B.times.data(), sizeof(int32_t) * B.total_states);
   for (int64_t a = 0; a < B.total_arcs; a++) KH_CHECK_ARG(arc_ilabel[a] >= 0 && arc_ilabel[a] <= num_tids);
   for (int l = 0; l < n_lats; l++) {  // max_time == num_ali.size() :764
     int max_time = 0;

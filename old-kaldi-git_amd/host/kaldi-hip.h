@@ -455,7 +455,7 @@ inline double LatticeForwardBackwardMpeVariants(const std::vector<int32> &tid2ph
                                           lat.state_final.data(), tid2phone.data(), tid2pdf.data(),
                                           static_cast<int>(tid2phone.size()) - 1, silence_phones.data(),
                                           static_cast<int>(silence_phones.size()), num_ali.data(), aoff,
-                                          criterion == "mpfe", one_silence_class, arc_post->data(), &score));
+                                          criterion == "mpfe", one_silence_class, arc_post->data(), &score, NULL));
   return score;
 }
 
