@@ -13,9 +13,13 @@
 // device's exp/log1p.  Arc posteriors are written per arc; the caller merges
 // them per (frame, transition-id) as MergePairVectorSumming does (:351-352).
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <functional>
 #include <limits>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "kh_common.h"
@@ -366,66 +370,99 @@ struct LatBatch {
     in_off.assign(static_cast<size_t>(total_states) + 1, 0);
     in_arc.resize(total_arcs);
     times.assign(total_states, -1);
-    for (int l = 0; l < n_lats; l++) {
+    // Per-lattice work on host threads (the lattices are independent); the shared arrays
+    // are stitched together by two serial prefix passes.
+    struct Local {
+      std::vector<int32_t> level_off, finals;
+      int n_levels = 0, rc = KH_OK;
+      std::string err;
+    };
+    std::vector<Local> loc(n_lats);
+    for (int l = 0; l < n_lats; l++) KH_CHECK_ARG(lat_state_offsets[l + 1] - lat_state_offsets[l] > 0);
+    auto for_each_lattice = [&](const std::function<void(int)> &fn) {
+      int nt = static_cast<int>(std::thread::hardware_concurrency());
+      nt = std::max(1, std::min(std::min(nt, 32), n_lats));
+      std::atomic<int> next(0);
+      auto work = [&]() { for (int l; (l = next.fetch_add(1)) < n_lats;) fn(l); };
+      std::vector<std::thread> th;
+      for (int i = 1; i < nt; i++) th.emplace_back(work);
+      work();
+      for (auto &t : th) t.join();
+    };
+    for_each_lattice([&](int l) {
       const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
-      KH_CHECK_ARG(ns > 0);
+      Local &L = loc[l];
       LatDesc &d = descs[l];
       d.state_b = sb;
       d.n_states = ns;
       d.arc_b = arc_offsets[sb];
       std::vector<int32_t> level(ns, 0);
       int max_level = 0;
+      char buf[256];
       // LatticeStateTimes :36-67 + level assignment + topological-order check
       // ("Input lattice must be topologically sorted", :38-39,:285-286).
       times[sb] = 0;
-      for (int s = 0; s < ns; s++) {
+      for (int s = 0; s < ns && L.rc == KH_OK; s++) {
         const int cur_time = times[sb + s];
         for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
           const int nxt = arc_nextstate[a];
           if (nxt <= s || nxt >= ns) {
-            SetError("lattice %d: arc %lld (state %d -> %d): input lattice must be topologically sorted",
+            snprintf(buf, sizeof(buf), "lattice %d: arc %lld (state %d -> %d): input lattice must be topologically sorted",
                      l, static_cast<long long>(a), s, nxt);
-            return KH_EINVAL;
+            L.err = buf;
+            L.rc = KH_EINVAL;
+            break;
           }
           if (cur_time >= 0) {
             const int want = cur_time + (arc_ilabel[a] != 0 ? 1 : 0);
             if (times[sb + nxt] == -1) times[sb + nxt] = want;
             else if (times[sb + nxt] != want) {
-              SetError("lattice %d: inconsistent state times at state %d (KALDI_ASSERT lattice-functions.cc:55,61)", l, nxt);
-              return KH_EINVAL;
+              snprintf(buf, sizeof(buf), "lattice %d: inconsistent state times at state %d (KALDI_ASSERT lattice-functions.cc:55,61)", l, nxt);
+              L.err = buf;
+              L.rc = KH_EINVAL;
+              break;
             }
           }
           level[nxt] = std::max(level[nxt], level[s] + 1);
-          in_off[static_cast<size_t>(sb) + nxt + 1]++;
+          in_off[static_cast<size_t>(sb) + nxt + 1]++;  // (indices of this lattice only)
         }
         max_level = std::max(max_level, level[s]);
       }
-      d.n_levels = max_level + 1;
-      d.level_b = static_cast<int32_t>(level_off.size());
-      std::vector<int32_t> cnt(d.n_levels + 1, 0);
+      if (L.rc != KH_OK) return;
+      L.n_levels = max_level + 1;
+      std::vector<int32_t> cnt(L.n_levels + 1, 0);
       for (int s = 0; s < ns; s++) cnt[level[s] + 1]++;
-      for (int i = 0; i < d.n_levels; i++) cnt[i + 1] += cnt[i];
-      for (int i = 0; i <= d.n_levels; i++) level_off.push_back(cnt[i]);
+      for (int i = 0; i < L.n_levels; i++) cnt[i + 1] += cnt[i];
+      L.level_off = cnt;
       std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
       for (int s = 0; s < ns; s++) level_states[sb + fill[level[s]]++] = s;
-      d.final_b = static_cast<int32_t>(final_list.size());
       for (int s = 0; s < ns; s++)
-        if (state_final[sb + s] != inf) final_list.push_back(s);
-      d.n_final = static_cast<int32_t>(final_list.size()) - d.final_b;
+        if (state_final[sb + s] != inf) L.finals.push_back(s);
+    });
+    for (int l = 0; l < n_lats; l++) {
+      if (loc[l].rc != KH_OK) {
+        SetError("%s", loc[l].err.c_str());
+        return loc[l].rc;
+      }
+      LatDesc &d = descs[l];
+      d.n_levels = loc[l].n_levels;
+      d.level_b = static_cast<int32_t>(level_off.size());
+      level_off.insert(level_off.end(), loc[l].level_off.begin(), loc[l].level_off.end());
+      d.final_b = static_cast<int32_t>(final_list.size());
+      final_list.insert(final_list.end(), loc[l].finals.begin(), loc[l].finals.end());
+      d.n_final = static_cast<int32_t>(loc[l].finals.size());
     }
     for (size_t i = 0; i < static_cast<size_t>(total_states); i++) in_off[i + 1] += in_off[i];
-    {
-      std::vector<int64_t> fill(in_off.begin(), in_off.end() - 1);
-      for (int l = 0; l < n_lats; l++) {
-        const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
-        for (int s = 0; s < ns; s++)
-          for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
-            const int64_t pos = fill[static_cast<size_t>(sb) + arc_nextstate[a]]++;
-            in_arc[pos] = a;  // ascending arc index per destination
-            in_src[pos] = s;
-          }
-      }
-    }
+    for_each_lattice([&](int l) {
+      const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
+      std::vector<int64_t> fill(in_off.begin() + sb, in_off.begin() + sb + ns);
+      for (int s = 0; s < ns; s++)
+        for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
+          const int64_t pos = fill[arc_nextstate[a]]++;
+          in_arc[pos] = a;  // ascending arc index per destination
+          in_src[pos] = s;
+        }
+    });
     std::vector<int64_t> h_arc_off(arc_offsets, arc_offsets + total_states + 1);
     std::vector<int32_t> h_next(arc_nextstate, arc_nextstate + total_arcs), h_il(arc_ilabel, arc_ilabel + total_arcs);
     std::vector<float> h_g(arc_graph, arc_graph + total_arcs), h_a(arc_acoustic, arc_acoustic + total_arcs),
