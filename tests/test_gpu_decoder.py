@@ -4,6 +4,7 @@ the CPU oracle in canonical mode — bit-exact raw lattice (states keyed by
 best path — and against the reference-order oracle (best path; lattice where the
 order-dependence of the reference cannot show, i.e. when max_active is not binding)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -40,7 +41,7 @@ def arc_set(L):
                    L["arc_il"].tolist(), L["arc_ol"].tolist(), L["arc_g"].tolist(), L["arc_a"].tolist()))
 
 
-def run_case(api, graph, lls, cfg, check_reference_lattice=False):
+def run_case(api, graph, lls, cfg, check_reference_lattice=False, check_reference_best_path=True, max_lattice_diff=0.10):
     fst = api.Fst(graph)
     dec = api.LatticeFasterDecoder(fst, cfg, max_batch=max(1, len(lls)), max_frames=max(len(x) for x in lls))
     off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
@@ -58,7 +59,8 @@ def run_case(api, graph, lls, cfg, check_reference_lattice=False):
         assert np.float32(so["final_relative_cost"]).tobytes() == np.float32(sg["final_relative_cost"]).tobytes()
         orf = B.DecoderOracle(graph, cfg, "reference")
         assert orf.decode(x)
-        assert_same_best_path(dec.get_best_path(u), orf.best_path())
+        if check_reference_best_path:
+            assert_same_best_path(dec.get_best_path(u), orf.best_path())
         # Against the reference-ORDER oracle the lattice can differ by the tokens that
         # only the reference's running cutoff lets through (DESIGN.md "Decoder
         # parity"); the reference's own decoder cross-check accepts 2 %
@@ -66,7 +68,7 @@ def run_case(api, graph, lls, cfg, check_reference_lattice=False):
         # --max-error-proportion=0.02).  Here: arc-set symmetric difference.
         ref_arcs, got_arcs = arc_set(orf.raw_lattice()), arc_set(got)
         diff = len(ref_arcs ^ got_arcs) / max(1, len(ref_arcs))
-        assert diff <= (0.0 if check_reference_lattice else 0.10), diff
+        assert diff <= (0.0 if check_reference_lattice else max_lattice_diff), diff
     return dec
 
 
@@ -197,3 +199,47 @@ def test_very_long_utterance(api):
     g = graph_like_hclg(rng, 50000, 400)
     lls = [workloads.make_loglikes(rng, 1500, 400)]
     run_case(api, g, lls, api.decoder_config(beam=11.0, max_active=900, min_active=100, lattice_beam=5.0))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "16"))))
+def test_random_configurations(api, seed, monkeypatch):
+    """Random graphs and LatticeFasterDecoderConfig values (tiny max_active, prune_interval
+    down to 1, lattice_beam below the beam_delta, epsilon-free and epsilon-heavy graphs,
+    one-frame utterances, more utterances than slots): bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_states = int(rng.choice([30, 300, 3000, 20000]))
+    n_pdf = int(rng.choice([5, 40, 200]))
+    g = graph_like_hclg(rng, n_states, n_pdf, eps_frac=float(rng.choice([0.0, 0.05, 0.2, 0.4])),
+                        final_frac=float(rng.choice([0.0, 0.05, 0.5])))
+    n_utt = int(rng.integers(1, 6))
+    lls = [workloads.make_loglikes(rng, int(T), n_pdf) for T in rng.integers(1, 130, n_utt)]
+    max_active = int(rng.choice([2, 5, 60, 800, 2147483647]))
+    # min_active >= max_active makes the reference call std::nth_element with nth beyond the
+    # range it passes (lattice-faster-decoder.cc:633-640): undefined there, not a parity case
+    min_active = int(rng.choice([m for m in (0, 1, 20, 300) if m < max_active]))
+    cfg = api.decoder_config(beam=float(rng.choice([2.0, 6.0, 11.0, 15.0])),
+                             max_active=max_active, min_active=min_active,
+                             lattice_beam=float(rng.choice([0.3, 2.0, 6.0, 10.0])),
+                             prune_interval=int(rng.choice([1, 2, 7, 25, 30])),
+                             beam_delta=float(rng.choice([0.1, 0.5])),
+                             prune_scale=float(rng.choice([0.05, 0.1, 0.5])))
+    if rng.random() < 0.5:
+        monkeypatch.setenv("KH_DECODER_SLOTS", str(int(rng.integers(1, 4))))
+    # Against the reference-ORDER oracle only where its order dependence is bounded: a
+    # max_active of a handful of tokens makes the running cutoff (DESIGN.md "Decoder
+    # parity") decide most of the search, best path included.
+    sane = max_active >= 800 and cfg["beam"] >= 6.0   # (beam 2: the running cutoff admits tokens that change the 1-best)
+    # (the arc-set distance to the reference-ORDER lattice is not asserted here: on the tiny
+    # lattices of these cases a handful of marginal arcs is a large fraction)
+    run_case(api, g, lls, cfg, check_reference_best_path=False, max_lattice_diff=10.0)
+    if sane:  # same 1-best as the reference-order search (costs to float rounding of its own cost offsets)
+        for u, x in enumerate(lls):
+            orf = B.DecoderOracle(g, cfg, "reference")
+            assert orf.decode(x)
+            want = orf.best_path()
+            fst = api.Fst(g)
+            dec = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=len(x))
+            dec.decode(torch.from_numpy(x).cuda())
+            got = dec.get_best_path(0)
+            assert np.array_equal(got["alignment"], want["alignment"]) and np.array_equal(got["words"], want["words"])
+            assert abs(got["graph_cost"] + got["acoustic_cost"] - want["graph_cost"] - want["acoustic_cost"]) < 1e-4
