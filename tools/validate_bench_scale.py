@@ -1,0 +1,45 @@
+"""One-off check at the benchmark's own scale: the bench.py workload (10 M-state graph,
+beam 15 / max-active 7000, real forward pass) decoded in one launch with more utterances
+than slots, and a sample of utterances — first and last in their slot's queue — compared
+bit-exactly with the canonical oracle on the SAME log-likelihood rows."""
+import importlib
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import bench
+from oracle import binding as B
+from test_gpu_decoder import assert_same_best_path, assert_same_lattice
+
+api = importlib.import_module("old-kaldi-git_amd.api")
+api.select_gpu(0)
+n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 700
+t0 = time.time()
+net, priors, g, feats, off = bench.build_workload(3456, 0, n_utts, 10_000_000)
+print("workload built in %.0f s: %d utterances, %d frames" % (time.time() - t0, n_utts, off[-1]))
+nnet = api.Nnet(net, priors)
+fst = api.Fst(g)
+cfg = api.decoder_config(**bench.DECODE_CFG)
+dec = api.LatticeFasterDecoder(fst, cfg, max_batch=n_utts, max_frames=int(np.diff(off).max()))
+n_pdf = net[-1]["output_dim"]
+ll = torch.empty((int(off[-1]), n_pdf), dtype=torch.float32, device="cuda")
+bench.forward_all(api, torch, nnet, torch.from_numpy(feats).cuda(), off, ll, max_rows=60000)
+dec.decode(ll, off)
+dec.prepare()
+lens = np.diff(off)
+sample = [0, 3, n_utts // 2, n_utts - 2, n_utts - 1, int(np.argmin(np.abs(lens - np.median(lens))))]
+for u in sample:
+    x = ll[off[u]:off[u + 1]].cpu().numpy()
+    t1 = time.time()
+    oc = B.DecoderOracle(g, cfg, "canonical")
+    assert oc.decode(x)
+    assert_same_lattice(dec.get_raw_lattice(u), oc.raw_lattice())
+    assert_same_best_path(dec.get_best_path(u), oc.best_path())
+    st = dec.stats(u)
+    print("utterance %d (%d frames, %d lattice states, %d arcs, max %d tokens/frame): bit-exact (oracle %.0f s)" %
+          (u, lens[u], st["num_tokens"], st["num_links"], st["max_tokens_frame"], time.time() - t1))
+print("OK")
