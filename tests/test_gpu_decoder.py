@@ -243,3 +243,30 @@ def test_random_configurations(api, seed, monkeypatch):
             got = dec.get_best_path(0)
             assert np.array_equal(got["alignment"], want["alignment"]) and np.array_equal(got["words"], want["words"])
             assert abs(got["graph_cost"] + got["acoustic_cost"] - want["graph_cost"] - want["acoustic_cost"]) < 1e-4
+
+
+def test_capacity_overflow_is_reported_not_hidden(api, monkeypatch):
+    """An arena that is too small ends the utterance with KH_ECAPACITY and a message naming
+    the knob — never a silent truncation; the same decoder works again with room."""
+    rng = np.random.default_rng(9)
+    g = graph_like_hclg(rng, 20000, 200)
+    x = workloads.make_loglikes(rng, 40, 200)
+    cfg = api.decoder_config(beam=9.0, lattice_beam=6.0)
+    fst = api.Fst(g)
+    monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", "64")
+    small = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=40)
+    with pytest.raises(api.KhError, match="KH_DECODER_TOKENS_PER_FRAME"):
+        small.decode(torch.from_numpy(x).cuda())
+    monkeypatch.delenv("KH_DECODER_TOKENS_PER_FRAME")
+    monkeypatch.setenv("KH_DECODER_POOL_TOKENS_PER_FRAME", "1")   # lattice pool far too small: exact-size retry
+    ok = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=40)
+    ok.decode(torch.from_numpy(x).cuda())
+    oc = B.DecoderOracle(g, cfg, "canonical")
+    assert oc.decode(x)
+    assert_same_lattice(ok.get_raw_lattice(0), oc.raw_lattice())
+    # online streams report the overflow from advance_decoding
+    monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", "64")
+    on = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=1, max_frames=40)
+    on.init_decoding([0])
+    with pytest.raises(api.KhError, match="overflowed"):
+        on.advance_decoding([0], [torch.from_numpy(x).cuda()])
