@@ -109,6 +109,46 @@ class OracleLib:
     def _fn(self, name):
         return getattr(self.lib, self.p + name)
 
+    # ---- feature front-end
+    def mfcc_compute(self, wave, samp_freq=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemph_coeff=0.97,
+                     remove_dc_offset=True, window_type="povey", num_bins=23, low_freq=20.0, high_freq=0.0,
+                     num_ceps=13, cepstral_lifter=22.0):
+        """Mfcc::Compute (feat/feature-mfcc.cc:96-184), dither 0, use_energy false, snip_edges true."""
+        w = _f32(wave).reshape(-1)
+        max_rows = len(w) // max(1, int(samp_freq * 0.001 * frame_shift_ms)) + 2
+        out = np.empty((max_rows, num_ceps), np.float32)
+        args = [_fp(w), C.c_int(len(w)), C.c_float(samp_freq), C.c_float(frame_length_ms), C.c_float(frame_shift_ms),
+                C.c_float(preemph_coeff), C.c_int(int(remove_dc_offset)), C.c_char_p(window_type.encode())]
+        if self.kind == "ref":
+            args.append(C.c_int(1))
+        args += [C.c_int(num_bins), C.c_float(low_freq), C.c_float(high_freq), C.c_int(num_ceps), C.c_float(cepstral_lifter),
+                 _fp(out), C.c_int(num_ceps), C.c_int(max_rows)]
+        rows = self._fn("mfcc_compute")(*args)
+        if rows < 0:
+            raise RuntimeError("mfcc_compute failed (%d)" % rows)
+        return out[:rows].copy()
+
+    def compute_deltas(self, feats, order=2, window=2):
+        """ComputeDeltas (feat/feature-functions.cc:361-372)."""
+        x = _f32(feats)
+        out = np.empty((x.shape[0], x.shape[1] * (order + 1)), np.float32)
+        self._fn("compute_deltas")(_fp(x), x.shape[0], x.shape[1], x.shape[1], int(order), int(window), _fp(out), out.shape[1])
+        return out
+
+    def acc_cmvn_stats(self, feats, stats=None):
+        """AccCmvnStats (transform/cmvn.cc:49-62); stats [2 x (dim + 1)] float64."""
+        x = _f32(feats)
+        st = np.zeros((2, x.shape[1] + 1)) if stats is None else np.ascontiguousarray(stats, np.float64).copy()
+        self._fn("acc_cmvn_stats")(_fp(x), x.shape[0], x.shape[1], x.shape[1], st.ctypes.data_as(C.POINTER(C.c_double)))
+        return st
+
+    def apply_cmvn(self, stats, var_norm, feats):
+        """ApplyCmvn (transform/cmvn.cc:64-113)."""
+        x = _f32(feats).copy()
+        st = np.ascontiguousarray(stats, np.float64)
+        self._fn("apply_cmvn")(st.ctypes.data_as(C.POINTER(C.c_double)), int(bool(var_norm)), _fp(x), x.shape[0], x.shape[1], x.shape[1])
+        return x
+
     # ---- a1
     def add_mat_mat(self, alpha, A, transA, B, transB, beta, Cm):
         A, B = _f32(A), _f32(B)

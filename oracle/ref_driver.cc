@@ -18,10 +18,13 @@
 
 #include "cudamatrix/cu-math.h"
 #include "cudamatrix/cu-matrix-lib.h"
+#include "feat/feature-functions.h"
+#include "feat/feature-mfcc.h"
 #include "gmm/diag-gmm.h"
 #include "matrix/matrix-lib.h"
 #include "nnet2/nnet-component.h"
 #include "nnet2/nnet-nnet.h"
+#include "transform/cmvn.h"
 
 #include "kaldi_oracle.h"  // KoComponent
 
@@ -415,6 +418,67 @@ void ref_diag_gmm_loglike_per_frame(const float *weights, const float *means,
 float ref_log_sum_exp(const float *v, int dim, float prune) {
   Vector<BaseFloat> vec(InV(v, dim));
   return vec.LogSumExp(prune);
+}
+
+
+// ---- feature front-end: Mfcc::Compute feat/feature-mfcc.cc:96-184,
+// ComputeDeltas feat/feature-functions.cc:361-372, AccCmvnStats / ApplyCmvn
+// transform/cmvn.cc:49-113.  dither is forced to 0 (the only random step).
+int ref_mfcc_compute(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
+                     float preemph_coeff, int remove_dc_offset, const char *window_type, int snip_edges,
+                     int num_bins, float low_freq, float high_freq, int num_ceps, float cepstral_lifter,
+                     float *out, int out_stride, int max_rows) {
+  MfccOptions opts;
+  opts.frame_opts.samp_freq = samp_freq;
+  opts.frame_opts.frame_length_ms = frame_length_ms;
+  opts.frame_opts.frame_shift_ms = frame_shift_ms;
+  opts.frame_opts.dither = 0.0;
+  opts.frame_opts.preemph_coeff = preemph_coeff;
+  opts.frame_opts.remove_dc_offset = remove_dc_offset != 0;
+  opts.frame_opts.window_type = window_type;
+  opts.frame_opts.snip_edges = snip_edges != 0;
+  opts.mel_opts.num_bins = num_bins;
+  opts.mel_opts.low_freq = low_freq;
+  opts.mel_opts.high_freq = high_freq;
+  opts.num_ceps = num_ceps;
+  opts.cepstral_lifter = cepstral_lifter;
+  opts.use_energy = false;
+  Mfcc mfcc(opts);
+  Vector<BaseFloat> w(n_samples);
+  memcpy(w.Data(), wave, sizeof(float) * n_samples);
+  Matrix<BaseFloat> feats;
+  mfcc.Compute(w, 1.0, &feats, NULL);
+  if (feats.NumRows() > max_rows) return -1;
+  if (feats.NumRows() > 0) Out(feats, out, out_stride);
+  return feats.NumRows();
+}
+
+void ref_compute_deltas(const float *in, int rows, int cols, int in_stride, int order, int window, float *out,
+                        int out_stride) {
+  DeltaFeaturesOptions opts(order, window);
+  Matrix<BaseFloat> input = In(in, rows, cols, in_stride), output;
+  ComputeDeltas(opts, input, &output);
+  Out(output, out, out_stride);
+}
+
+// stats: [2 x (cols + 1)] doubles, row-major, accumulated over the rows of feats
+void ref_acc_cmvn_stats(const float *feats, int rows, int cols, int stride, double *stats) {
+  Matrix<BaseFloat> f = In(feats, rows, cols, stride);
+  Matrix<double> st(2, cols + 1);
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c <= cols; c++) st(r, c) = stats[r * (cols + 1) + c];
+  AccCmvnStats(f, NULL, &st);
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c <= cols; c++) stats[r * (cols + 1) + c] = st(r, c);
+}
+
+void ref_apply_cmvn(const double *stats, int var_norm, float *feats, int rows, int cols, int stride) {
+  Matrix<double> st(2, cols + 1);
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c <= cols; c++) st(r, c) = stats[r * (cols + 1) + c];
+  Matrix<BaseFloat> f = In(feats, rows, cols, stride);
+  ApplyCmvn(st, var_norm != 0, &f);
+  Out(f, feats, stride);
 }
 
 }  // extern "C"

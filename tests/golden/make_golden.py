@@ -156,5 +156,30 @@ def main():
     save("diag_gmm", **cases)
 
 
+def make_features():
+    """Feature front-end vectors from the reference's own feat/ + transform/cmvn.cc
+    (oracle/_ref): MFCC of a synthetic 2 s waveform with the two recipe configurations,
+    deltas, CMVN statistics and normalised features."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from test_feature_oracle import MFCC_CONFIGS, wave
+    ref = binding.OracleLib("ref")
+    w = wave(7)
+    out = dict(wave=w)
+    for name, cfg in MFCC_CONFIGS.items():
+        out["mfcc_" + name] = ref.mfcc_compute(w, **cfg)
+    x = out["mfcc_mfcc13"]
+    out["deltas"] = ref.compute_deltas(x, 2, 2)
+    out["cmvn_stats"] = ref.acc_cmvn_stats(x)
+    out["cmn"] = ref.apply_cmvn(out["cmvn_stats"], False, x)
+    out["cmvn"] = ref.apply_cmvn(out["cmvn_stats"], True, x)
+    np.savez_compressed(os.path.join(os.path.dirname(__file__), "features.npz"), **out)
+    print("features.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "--features" in sys.argv:
+        make_features()
+    else:
+        main()
+        make_features()

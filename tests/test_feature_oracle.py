@@ -1,0 +1,69 @@
+"""Pins the feature front-end restatement (oracle/feature_oracle.cc) against the
+reference's own feat/ + transform/cmvn.cc code (oracle/_ref, built in this container) and
+against the committed golden vectors made from it (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as B
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "features.npz")
+MFCC_CONFIGS = {
+    # conf/mfcc.conf of the GMM recipes (egs/rm/s5/conf/mfcc.conf: --use-energy=false) at 16 kHz
+    "mfcc13": dict(num_bins=23, num_ceps=13, low_freq=20.0, high_freq=0.0),
+    # conf/mfcc_hires.conf (egs/librispeech/s5/conf/mfcc_hires.conf): 40 bins, 40 ceps, 40 .. -200 Hz
+    "hires40": dict(num_bins=40, num_ceps=40, low_freq=40.0, high_freq=-200.0),
+}
+
+
+def wave(seed, n=16000 * 2 + 137):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = 3000 * np.sin(2 * np.pi * 220 * t) + 1500 * np.sin(2 * np.pi * 1900 * t + 1.0) + 400 * rng.standard_normal(n)
+    return (x * (0.3 + 0.7 * np.abs(np.sin(2 * np.pi * 1.5 * t)))).astype(np.float32)
+
+
+def check_mfcc(got, want):
+    assert got.shape == want.shape
+    # the FFT of the reference is a float split-radix transform; the restatement evaluates
+    # the DFT in double: log-mel energies agree to a few 1e-5, cepstra to 1e-3 absolute
+    assert np.abs(got - want).max() < 2e-3, np.abs(got - want).max()
+    assert np.abs(got - want).mean() < 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(MFCC_CONFIGS))
+def test_golden_mfcc(name):
+    g = np.load(GOLDEN)
+    ko = B.OracleLib("ko")
+    check_mfcc(ko.mfcc_compute(g["wave"], **MFCC_CONFIGS[name]), g["mfcc_" + name])
+
+
+def test_golden_deltas_and_cmvn():
+    g = np.load(GOLDEN)
+    ko = B.OracleLib("ko")
+    d = ko.compute_deltas(g["mfcc_mfcc13"], 2, 2)
+    assert d.shape == g["deltas"].shape and np.abs(d - g["deltas"]).max() < 1e-5  # saxpy FMA vs mul+add
+    st = ko.acc_cmvn_stats(g["mfcc_mfcc13"])
+    assert np.allclose(st, g["cmvn_stats"], rtol=1e-12, atol=1e-9)
+    for vn, key in ((False, "cmn"), (True, "cmvn")):
+        y = ko.apply_cmvn(g["cmvn_stats"], vn, g["mfcc_mfcc13"])
+        assert np.array_equal(y.view(np.int32), g[key].view(np.int32))  # MulColsVec + AddVecToRows: bit-exact
+
+
+@pytest.mark.skipif(not B.have_ref(), reason="oracle/_ref is only built where /root/reference exists")
+def test_against_compiled_reference_on_fresh_input():
+    ko, ref = B.OracleLib("ko"), B.OracleLib("ref")
+    w = wave(99, 16000 + 55)
+    for name, cfg in MFCC_CONFIGS.items():
+        check_mfcc(ko.mfcc_compute(w, **cfg), ref.mfcc_compute(w, **cfg))
+    for wt in ("hamming", "hanning", "rectangular"):
+        check_mfcc(ko.mfcc_compute(w, window_type=wt, remove_dc_offset=False, preemph_coeff=0.0),
+                   ref.mfcc_compute(w, window_type=wt, remove_dc_offset=False, preemph_coeff=0.0))
+    x = ref.mfcc_compute(w)
+    for order, window in ((2, 2), (3, 1), (1, 3)):
+        assert np.abs(ko.compute_deltas(x, order, window) - ref.compute_deltas(x, order, window)).max() < 1e-5
+    st = ref.acc_cmvn_stats(x)
+    assert np.allclose(ko.acc_cmvn_stats(x), st, rtol=1e-12, atol=1e-9)
+    for vn in (False, True):
+        assert np.array_equal(ko.apply_cmvn(st, vn, x).view(np.int32), ref.apply_cmvn(st, vn, x).view(np.int32))
