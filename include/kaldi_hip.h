@@ -369,6 +369,33 @@ int kh_online_decoder_get_best_path(KhOnlineDecoder *dec, int stream, int use_fi
                                     int cap_words, int32_t *n_words, float *graph_cost,
                                     float *acoustic_cost);
 
+/* ------------------------------------------------------------------ (f)3
+ * Feature front-end, the step right before the path (feat/, transform/cmvn.cc).
+ * kh_mfcc_compute = Mfcc::ComputeInternal (feat/feature-mfcc.cc:119-184) with
+ * use_energy = false, dither = 0, snip_edges = true, for a waveform on the DEVICE.  The
+ * tables are the ones the reference's constructors build (HOST arrays): window =
+ * FeatureWindowFunction (feature-functions.cc:74-92, frame_length floats), mel_first /
+ * mel_off / mel_weights = MelBanks::bins_ (mel-computations.cc:33-152: first FFT bin,
+ * offsets into the concatenated weights), dct = the first num_ceps rows of
+ * ComputeDctMatrix (matrix-functions.cc:592-608, num_ceps x num_bins), lifter =
+ * ComputeLifterCoeffs (mel-computations.cc:248-254) or NULL.  padded = the power-of-two
+ * FFT size (<= 2048).  *num_frames = NumFrames (feature-functions.cc:29-48); out must
+ * hold that many rows of num_ceps floats. */
+int kh_mfcc_compute(const float *wave, int n_samples, int frame_shift, int frame_length, int padded,
+                    float preemph_coeff, int remove_dc_offset, const float *window_host, int num_bins,
+                    const int32_t *mel_first_host, const int32_t *mel_off_host,
+                    const float *mel_weights_host, int num_ceps, const float *dct_host,
+                    const float *lifter_host, float *out, int out_stride, int *num_frames);
+/* ComputeDeltas (feat/feature-functions.cc:361-372): scales of DeltaFeatures
+ * (:210-242) for orders 0..order back to back (HOST), their lengths in lens_host. */
+int kh_compute_deltas(const float *in, KhMatrixDim d_in, int order, const float *scales_host,
+                      const int32_t *lens_host, float *out, int out_stride);
+/* AccCmvnStats (transform/cmvn.cc:49-62, no weights): adds the sums of feats (DEVICE) to
+ * stats_host [2 x (cols + 1)] doubles (row 0: sum x and the count, row 1: sum x^2).
+ * ApplyCmvn (:64-113) is kh_mul_cols_vec + kh_add_vec_to_rows with the offset / scale
+ * vectors the caller derives from the stats as the reference does. */
+int kh_acc_cmvn_stats(const float *feats, KhMatrixDim d, double *stats_host);
+
 /* ------------------------------------------------------------------ a15
  * Lattice forward-backward (lat/lattice-functions.cc:36-67,272-354) for a batch
  * of top-sorted lattices given as HOST CSR (state s owns arcs

@@ -361,6 +361,159 @@ class DecodableNnet2Online:
         return res
 
 
+# ---------------------------------------------------------------- feature front-end
+class Mfcc:
+    """feat/feature-mfcc.h Mfcc with MfccOptions (use_energy = false, dither = 0,
+    snip_edges = true): the constructor builds the reference's tables (window function,
+    MelBanks, DCT rows, lifter) on the host, compute() runs the frames on the GPU."""
+
+    def __init__(self, samp_freq=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemph_coeff=0.97,
+                 remove_dc_offset=True, window_type="povey", num_bins=23, low_freq=20.0, high_freq=0.0, num_ceps=13,
+                 cepstral_lifter=22.0):
+        f32 = np.float32
+        self.frame_shift = int(f32(samp_freq) * f32(0.001) * f32(frame_shift_ms))      # WindowShift() feature-functions.h:119
+        self.frame_length = int(f32(samp_freq) * f32(0.001) * f32(frame_length_ms))    # WindowSize()
+        self.padded = 1 << int(np.ceil(np.log2(self.frame_length)))                    # PaddedWindowSize()
+        self.preemph, self.remove_dc = float(preemph_coeff), bool(remove_dc_offset)
+        self.num_bins, self.num_ceps = int(num_bins), int(num_ceps)
+        n = self.frame_length
+        i = np.arange(n, dtype=np.float32).astype(np.float64)
+        a = 2.0 * np.pi * i / (n - 1)
+        if window_type == "hanning":                                                    # FeatureWindowFunction :74-92
+            w = 0.5 - 0.5 * np.cos(a)
+        elif window_type == "hamming":
+            w = 0.54 - 0.46 * np.cos(a)
+        elif window_type == "povey":
+            w = np.power(0.5 - 0.5 * np.cos(a), 0.85)
+        elif window_type == "rectangular":
+            w = np.ones(n)
+        else:
+            raise KhError("Invalid window type " + window_type)
+        self.window = w.astype(np.float32)
+        # MelBanks (vtln_warp 1.0) mel-computations.cc:33-152, float arithmetic as there
+        mel = lambda fr: f32(1127.0) * np.log(f32(1.0) + np.asarray(fr, np.float32) / f32(700.0), dtype=np.float32)
+        nyquist = f32(0.5) * f32(samp_freq)
+        hf = f32(high_freq) if high_freq > 0.0 else nyquist + f32(high_freq)
+        lf = f32(low_freq)
+        if lf < 0.0 or lf >= nyquist or hf <= 0.0 or hf > nyquist or hf <= lf:
+            raise KhError("Bad values in options: low-freq %g and high-freq %g vs. nyquist %g" % (lf, hf, nyquist))
+        num_fft_bins = self.padded // 2
+        fft_bin_width = f32(samp_freq) / f32(self.padded)
+        mel_low, mel_high = mel(lf), mel(hf)
+        delta = (mel_high - mel_low) / f32(num_bins + 1)
+        mels = mel(fft_bin_width * np.arange(num_fft_bins, dtype=np.float32))
+        first, off, weights = [], [0], []
+        for b in range(num_bins):
+            left, center, right = mel_low + f32(b) * delta, mel_low + f32(b + 1) * delta, mel_low + f32(b + 2) * delta
+            idx = np.nonzero((mels > left) & (mels < right))[0]
+            if len(idx) == 0:
+                raise KhError("You may have set --num-mel-bins too large.")
+            m = mels[idx[0]:idx[-1] + 1]
+            wts = np.where(m <= center, (m - left) / (center - left), (right - m) / (right - center)).astype(np.float32)
+            wts[~((m > left) & (m < right))] = 0.0
+            first.append(int(idx[0]))
+            weights.append(wts)
+            off.append(off[-1] + len(wts))
+        self.mel_first = np.asarray(first, np.int32)
+        self.mel_off = np.asarray(off, np.int32)
+        self.mel_weights = np.concatenate(weights).astype(np.float32)
+        # ComputeDctMatrix matrix-functions.cc:592-608 (first num_ceps rows)
+        N = num_bins
+        dct = np.empty((num_ceps, N), np.float32)
+        dct[0] = f32(np.sqrt(1.0 / float(f32(N))))
+        norm = f32(np.sqrt(2.0 / float(f32(N))))
+        k = np.arange(1, num_ceps)[:, None]
+        nn = np.arange(N)[None, :]
+        dct[1:] = (float(norm) * np.cos(np.pi / N * (nn + 0.5) * k)).astype(np.float32)
+        self.dct = np.ascontiguousarray(dct)
+        self.lifter = None
+        if cepstral_lifter != 0.0:                                                      # mel-computations.cc:248-254
+            q = float(f32(cepstral_lifter))
+            self.lifter = (1.0 + 0.5 * q * np.sin(np.pi * np.arange(num_ceps) / q)).astype(np.float32)
+
+    def num_frames(self, n_samples):
+        """NumFrames feature-functions.cc:29-48 (snip_edges)."""
+        return 0 if n_samples < self.frame_length else 1 + (n_samples - self.frame_length) // self.frame_shift
+
+    def compute(self, wave):
+        """Mfcc::Compute(wave, 1.0, &output): wave = 1-D float32 device tensor."""
+        rows = self.num_frames(wave.numel())
+        stride = (self.num_ceps + 3) // 4 * 4
+        out = torch.empty((max(rows, 1), stride), dtype=torch.float32, device=wave.device)[:rows, :self.num_ceps]
+        nf = C.c_int32()
+        fp, ip = capi.c_float_p, capi.c_int32_p
+        check(lib().kh_mfcc_compute(
+            C.c_void_p(wave.data_ptr()), wave.numel(), self.frame_shift, self.frame_length, self.padded, self.preemph,
+            int(self.remove_dc), self.window.ctypes.data_as(fp), self.num_bins, self.mel_first.ctypes.data_as(ip),
+            self.mel_off.ctypes.data_as(ip), self.mel_weights.ctypes.data_as(fp), self.num_ceps,
+            self.dct.ctypes.data_as(fp), self.lifter.ctypes.data_as(fp) if self.lifter is not None else None,
+            C.c_void_p(out.data_ptr()) if rows else None, stride, C.byref(nf)))
+        assert nf.value == rows
+        return out
+
+
+def delta_scales(order, window):
+    """DeltaFeatures::DeltaFeatures feat/feature-functions.cc:210-242."""
+    scales = [np.ones(1, np.float32)]
+    for _ in range(order):
+        prev = scales[-1]
+        prev_offset = (len(prev) - 1) // 2
+        cur = np.zeros(len(prev) + 2 * window, np.float32)
+        normalizer = np.float32(0.0)
+        for j in range(-window, window + 1):
+            normalizer = np.float32(normalizer + np.float32(j * j))
+            for k in range(-prev_offset, prev_offset + 1):
+                cur[j + k + prev_offset + window] = np.float32(cur[j + k + prev_offset + window] + np.float32(j) * prev[k + prev_offset])
+        scales.append((cur * np.float32(1.0 / float(normalizer))).astype(np.float32))
+    return scales
+
+
+def compute_deltas(feats, order=2, window=2):
+    """ComputeDeltas (feat/feature-functions.cc:361-372): feats [T x D] device -> [T x D(order+1)]."""
+    if not (0 <= order < 1000 and 0 < window < 1000):
+        raise KhError("DeltaFeaturesOptions: bad order / window")
+    sc = delta_scales(order, window)
+    flat = np.ascontiguousarray(np.concatenate(sc), np.float32)
+    lens = np.ascontiguousarray([len(x) for x in sc], np.int32)
+    cols = feats.shape[1] * (order + 1)
+    stride = (cols + 3) // 4 * 4
+    out = torch.empty((feats.shape[0], stride), dtype=torch.float32, device=feats.device)[:, :cols]
+    check(lib().kh_compute_deltas(_p(feats), _dim(feats), int(order), flat.ctypes.data_as(capi.c_float_p),
+                                  lens.ctypes.data_as(capi.c_int32_p), _p(out), stride))
+    return out
+
+
+def acc_cmvn_stats(feats, stats=None):
+    """AccCmvnStats (transform/cmvn.cc:49-62): stats [2 x (dim + 1)] float64 on the host."""
+    st = np.zeros((2, feats.shape[1] + 1)) if stats is None else np.ascontiguousarray(stats, np.float64)
+    check(lib().kh_acc_cmvn_stats(_p(feats), _dim(feats), st.ctypes.data_as(capi.c_double_p)))
+    return st
+
+
+def apply_cmvn(stats, var_norm, feats):
+    """ApplyCmvn (transform/cmvn.cc:64-113), in place on the device matrix."""
+    dim = stats.shape[1] - 1
+    if stats.shape[0] not in (1, 2) or feats.shape[1] != dim:
+        raise KhError("Dim mismatch: cmvn %dx%d, feats %dx%d" % (stats.shape + tuple(feats.shape)))
+    if stats.shape[0] == 1 and var_norm:
+        raise KhError("You requested variance normalization but no variance stats are supplied.")
+    count = float(stats[0, dim])
+    if count < 1.0:
+        raise KhError("Insufficient stats for cepstral mean and variance normalization: count = %g" % count)
+    mean = stats[0, :dim] / count
+    if not var_norm:
+        scale, offset = np.ones(dim), -mean
+    else:
+        var = np.maximum(stats[1, :dim] / count - mean * mean, 1.0e-20)
+        scale = 1.0 / np.sqrt(var)
+        offset = -(mean * scale)
+    dev = feats.device
+    if var_norm:
+        mul_cols_vec(feats, torch.from_numpy(scale.astype(np.float32)).to(dev))
+    add_vec_to_rows(feats, 1.0, torch.from_numpy(offset.astype(np.float32)).to(dev))
+    return feats
+
+
 # ---------------------------------------------------------------- DiagGmm
 def gmm_compute_gconsts(weights, means_invvars, inv_vars):
     """DiagGmm::ComputeGconsts (gmm/diag-gmm.cc:114-152); host arrays."""

@@ -1,0 +1,245 @@
+// kh_features.hip — feature front-end on gfx950 (the step right
+// before the hot path).  Replaces, for a waveform resident on the device:
+//   Mfcc::ComputeInternal          feat/feature-mfcc.cc:119-184 (use_energy = false, dither = 0)
+//     ExtractWindow / Preemphasize feat/feature-functions.cc:61-70,98-167 (snip_edges = true)
+//     SplitRadixRealFft + ComputePowerSpectrum  matrix/srfft.cc, feature-functions.cc:186-207
+//     MelBanks::Compute            feat/mel-computations.cc:219-246
+//   ComputeDeltas                  feat/feature-functions.cc:244-267,361-372
+//   AccCmvnStats                   transform/cmvn.cc:30-62
+// The tables of the reference's constructors (window function, mel filter weights, DCT
+// rows, lifter) are built by the caller exactly as the reference builds them and passed in.
+// One workgroup per frame; the frame, its spectrum and the twiddle table live in LDS.  The
+// transform is the DFT itself (each lane owns a frequency bin): 512 x 257 FMAs per frame is
+// noise next to the acoustic model, and it needs no bit-reversal / butterfly stages.
+#include <cmath>
+#include <vector>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxPadded = 2048;
+
+__global__ void __launch_bounds__(kThreads)
+MfccKernel(const float *__restrict__ wave, int frame_shift, int frame_length, int padded, float preemph,
+           int remove_dc, const float *__restrict__ window, const float *__restrict__ cos_t,
+           const float *__restrict__ sin_t, int num_bins, const int32_t *__restrict__ mel_first,
+           const int32_t *__restrict__ mel_off, const float *__restrict__ mel_w, int num_ceps,
+           const float *__restrict__ dct, const float *__restrict__ lifter, float *__restrict__ out,
+           int out_stride) {
+  __shared__ float win[kMaxPadded];
+  __shared__ float ct[kMaxPadded], st[kMaxPadded];
+  __shared__ float power[kMaxPadded / 2 + 1];
+  __shared__ float mel[256];
+  __shared__ double red[kThreads / 64];
+  const int r = blockIdx.x;
+  const float *w0 = wave + static_cast<size_t>(frame_shift) * r;
+  // ExtractWindow: copy, remove DC (Sum() accumulates in double), pre-emphasis, window, zero pad
+  double part = 0.0;
+  for (int i = threadIdx.x; i < padded; i += kThreads) {
+    const float v = i < frame_length ? w0[i] : 0.0f;
+    win[i] = v;
+    part += v;
+    ct[i] = cos_t[i];
+    st[i] = sin_t[i];
+  }
+  if (remove_dc) {
+    part = kh_wave_sum_d(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    double sum = 0.0;
+    for (int i = 0; i < kThreads / 64; i++) sum += red[i];
+    const float c = -static_cast<float>(sum) / frame_length;
+    for (int i = threadIdx.x; i < frame_length; i += kThreads) win[i] += c;
+  }
+  __syncthreads();
+  // Preemphasize :61-67 reads the ORIGINAL neighbour (the loop runs from the end): two steps
+  float pre[kMaxPadded / kThreads];
+  int np = 0;
+  for (int i = threadIdx.x; i < frame_length; i += kThreads, np++)
+    pre[np] = preemph != 0.0f ? win[i] - preemph * win[i > 0 ? i - 1 : 0] : win[i];
+  __syncthreads();
+  np = 0;
+  for (int i = threadIdx.x; i < frame_length; i += kThreads, np++) win[i] = pre[np] * window[i];
+  __syncthreads();
+  // DFT bin k = sum_n x[n] e^{-2 pi i k n / N}; power spectrum (bins 0 .. N/2)
+  const int half = padded / 2;
+  for (int k = threadIdx.x; k <= half; k += kThreads) {
+    float re = 0.0f, im = 0.0f;
+    int idx = 0;  // (k * n) mod padded
+    for (int n = 0; n < padded; n++) {
+      const float x = win[n];
+      re += x * ct[idx];
+      im -= x * st[idx];
+      idx += k;
+      if (idx >= padded) idx -= padded;
+    }
+    power[k] = re * re + im * im;
+  }
+  __syncthreads();
+  // MelBanks::Compute, floor, log
+  for (int b = threadIdx.x; b < num_bins; b += kThreads) {
+    float e = 0.0f;
+    const int f0 = mel_first[b], o0 = mel_off[b], o1 = mel_off[b + 1];
+    for (int i = o0; i < o1; i++) e += mel_w[i] * power[f0 + (i - o0)];
+    if (e < 1.17549435e-38f) e = 1.17549435e-38f;  // numeric_limits<float>::min()
+    mel[b] = logf(e);
+  }
+  __syncthreads();
+  // this_mfcc = dct_matrix_ * mel_energies; MulElements(lifter_coeffs_)
+  for (int c = threadIdx.x; c < num_ceps; c += kThreads) {
+    float s = 0.0f;
+    for (int b = 0; b < num_bins; b++) s += dct[c * num_bins + b] * mel[b];
+    if (lifter != nullptr) s *= lifter[c];
+    out[static_cast<size_t>(r) * out_stride + c] = s;
+  }
+}
+
+// DeltaFeatures::Process :244-267 for every (frame, order, dim): column on the lane
+__global__ void DeltasKernel(const float *__restrict__ in, int rows, int cols, int in_stride, int order,
+                             const float *__restrict__ scales, const int32_t *__restrict__ lens,
+                             float *__restrict__ out, int out_stride) {
+  for (int t = blockIdx.y; t < rows; t += gridDim.y)
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols * (order + 1); c += gridDim.x * blockDim.x) {
+      const int i = c / cols, d = c - i * cols;
+      int pos = 0;
+      for (int j = 0; j < i; j++) pos += lens[j];
+      const int max_offset = (lens[i] - 1) / 2;
+      float acc = 0.0f;
+      for (int j = -max_offset; j <= max_offset; j++) {
+        int f = t + j;
+        f = f < 0 ? 0 : (f >= rows ? rows - 1 : f);
+        const float sc = scales[pos + j + max_offset];
+        if (sc != 0.0f) acc += sc * in[static_cast<size_t>(f) * in_stride + d];
+      }
+      out[static_cast<size_t>(t) * out_stride + c] = acc;
+    }
+}
+
+// AccCmvnStats: per column sum x and sum x*x (float products, double accumulation)
+__global__ void __launch_bounds__(kThreads)
+CmvnStatsKernel(const float *__restrict__ x, int rows, int cols, int stride, double *__restrict__ stats) {
+  const int d = blockIdx.x * kThreads + threadIdx.x;
+  if (d >= cols) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float v = x[static_cast<size_t>(r) * stride + d];
+    s1 += v;
+    s2 += v * v;
+  }
+  atomicAdd(&stats[d], s1);
+  atomicAdd(&stats[cols + 1 + d], s2);
+}
+
+template <class T>
+struct Dev {
+  T *p = nullptr;
+  ~Dev() { if (p) PoolFree(p); }
+  int Up(const T *h, size_t n, hipStream_t st) {
+    p = static_cast<T *>(PoolMalloc(sizeof(T) * (n ? n : 1)));
+    if (!p) return KH_ENOMEM;
+    if (n) KH_HIP(hipMemcpyAsync(p, h, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    return KH_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int kh_mfcc_compute(const float *wave, int n_samples, int frame_shift, int frame_length, int padded,
+                    float preemph_coeff, int remove_dc_offset, const float *window_host, int num_bins,
+                    const int32_t *mel_first_host, const int32_t *mel_off_host, const float *mel_weights_host,
+                    int num_ceps, const float *dct_host, const float *lifter_host, float *out, int out_stride,
+                    int *num_frames) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(wave && window_host && mel_first_host && mel_off_host && mel_weights_host && dct_host && num_frames &&
+               frame_shift > 0 && frame_length > 0 && padded >= frame_length && padded <= kMaxPadded &&
+               (padded & (padded - 1)) == 0 && num_bins >= 3 && num_bins <= 256 && num_ceps > 0 && num_ceps <= num_bins);
+  // NumFrames feature-functions.cc:29-48 (snip_edges)
+  const int rows = n_samples < frame_length ? 0 : 1 + (n_samples - frame_length) / frame_shift;
+  *num_frames = rows;
+  if (rows == 0) return KH_OK;
+  KH_CHECK_ARG(out && out_stride >= num_ceps);
+  for (int b = 0; b < num_bins; b++)
+    KH_CHECK_ARG(mel_first_host[b] >= 0 && mel_off_host[b + 1] >= mel_off_host[b] &&
+                 mel_first_host[b] + (mel_off_host[b + 1] - mel_off_host[b]) <= padded / 2 + 1);
+  std::vector<float> ct(padded), st_(padded);
+  for (int i = 0; i < padded; i++) {
+    const double a = 6.283185307179586476925286766559 * i / padded;
+    ct[i] = static_cast<float>(cos(a));
+    st_[i] = static_cast<float>(sin(a));
+  }
+  hipStream_t st = Stream();
+  Dev<float> d_win, d_ct, d_st, d_w, d_dct, d_lift;
+  Dev<int32_t> d_first, d_off;
+  if ((rc = d_win.Up(window_host, frame_length, st)) || (rc = d_ct.Up(ct.data(), padded, st)) ||
+      (rc = d_st.Up(st_.data(), padded, st)) || (rc = d_w.Up(mel_weights_host, mel_off_host[num_bins], st)) ||
+      (rc = d_dct.Up(dct_host, static_cast<size_t>(num_ceps) * num_bins, st)) ||
+      (rc = d_first.Up(mel_first_host, num_bins, st)) || (rc = d_off.Up(mel_off_host, num_bins + 1, st)))
+    return rc;
+  if (lifter_host && (rc = d_lift.Up(lifter_host, num_ceps, st))) return rc;
+  hipLaunchKernelGGL(MfccKernel, dim3(rows), dim3(kThreads), 0, st, wave, frame_shift, frame_length, padded,
+                     preemph_coeff, remove_dc_offset, d_win.p, d_ct.p, d_st.p, num_bins, d_first.p, d_off.p, d_w.p,
+                     num_ceps, d_dct.p, lifter_host ? d_lift.p : nullptr, out, out_stride);
+  KH_LAUNCH_CHECK();
+  KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+int kh_compute_deltas(const float *in, KhMatrixDim d_in, int order, const float *scales_host,
+                      const int32_t *lens_host, float *out, int out_stride) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(in && out && scales_host && lens_host && order >= 0 && order < 1000 && d_in.rows > 0 && d_in.cols > 0 &&
+               d_in.stride >= d_in.cols && out_stride >= d_in.cols * (order + 1));
+  size_t n = 0;
+  for (int i = 0; i <= order; i++) { KH_CHECK_ARG(lens_host[i] > 0 && (lens_host[i] & 1)); n += lens_host[i]; }
+  hipStream_t st = Stream();
+  Dev<float> d_sc;
+  Dev<int32_t> d_len;
+  if ((rc = d_sc.Up(scales_host, n, st)) || (rc = d_len.Up(lens_host, order + 1, st))) return rc;
+  const int out_cols = d_in.cols * (order + 1);
+  hipLaunchKernelGGL(DeltasKernel, dim3((out_cols + 63) / 64, std::min(d_in.rows, NumCUs() * 32)), dim3(64), 0, st, in,
+                     d_in.rows, d_in.cols, d_in.stride, order, d_sc.p, d_len.p, out, out_stride);
+  KH_LAUNCH_CHECK();
+  KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+int kh_acc_cmvn_stats(const float *feats, KhMatrixDim d, double *stats_host) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(feats && stats_host && d.rows >= 0 && d.cols > 0 && d.stride >= d.cols);
+  if (d.rows == 0) return KH_OK;
+  hipStream_t st = Stream();
+  const size_t n = 2 * (static_cast<size_t>(d.cols) + 1);
+  double *dev = static_cast<double *>(PoolMalloc(sizeof(double) * n));
+  if (!dev) return KH_ENOMEM;
+  hipError_t e = hipMemsetAsync(dev, 0, sizeof(double) * n, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(CmvnStatsKernel, dim3((d.cols + kThreads - 1) / kThreads, std::min(d.rows, 64)), dim3(kThreads), 0,
+                       st, feats, d.rows, d.cols, d.stride, dev);
+    e = hipGetLastError();
+  }
+  std::vector<double> h(n);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  PoolFree(dev);
+  if (e != hipSuccess) {
+    SetError("kh_acc_cmvn_stats: %s", hipGetErrorString(e));
+    return KH_EDEVICE;
+  }
+  for (int c = 0; c < d.cols; c++) {
+    stats_host[c] += h[c];
+    stats_host[d.cols + 1 + c] += h[d.cols + 1 + c];
+  }
+  stats_host[d.cols] += static_cast<double>(d.rows);  // the count (weight 1 per frame)
+  return KH_OK;
+}
+
+}  // extern "C"

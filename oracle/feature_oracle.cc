@@ -182,7 +182,8 @@ void ko_delta_scales(int order, int window, float *scales, int32_t *lens) {
       normalizer += j * j;
       for (int k = -prev_offset; k <= prev_offset; k++) cur[j + k + cur_offset] += static_cast<float>(j) * prev[k + prev_offset];
     }
-    for (size_t k = 0; k < cur.size(); k++) cur[k] *= 1.0 / normalizer;  // Scale(1.0 / normalizer): float * (float)(double)
+    const float inv = static_cast<float>(1.0 / normalizer);  // Scale(BaseFloat alpha): the double quotient becomes a float argument
+    for (size_t k = 0; k < cur.size(); k++) cur[k] = cur[k] * inv;
   }
   int pos = 0;
   for (int i = 0; i <= order; i++) {

@@ -1,0 +1,64 @@
+"""GPU parity of the feature front-end (MFCC, deltas, CMVN) through the C-ABI against the
+oracle restatement, which tests/test_feature_oracle.py pins to the reference's own code,
+and against the golden vectors made from that code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import binding as B
+from test_feature_oracle import GOLDEN, MFCC_CONFIGS, check_mfcc, wave
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(MFCC_CONFIGS))
+def test_mfcc_matches_golden_and_oracle(api, name):
+    g = np.load(GOLDEN)
+    mf = api.Mfcc(**MFCC_CONFIGS[name])
+    got = mf.compute(torch.from_numpy(g["wave"]).cuda()).cpu().numpy()
+    check_mfcc(got, g["mfcc_" + name])                       # the reference's own output
+    ko = B.OracleLib("ko")
+    w = wave(123, 16000 * 3 + 401)
+    want = ko.mfcc_compute(w, **MFCC_CONFIGS[name])
+    got = mf.compute(torch.from_numpy(w).cuda()).cpu().numpy()
+    assert got.shape == want.shape == (mf.num_frames(len(w)), MFCC_CONFIGS[name]["num_ceps"])
+    check_mfcc(got, want)
+
+
+def test_mfcc_options_and_edges(api):
+    ko = B.OracleLib("ko")
+    w = wave(5, 16000 + 333)
+    for kw in (dict(window_type="hamming", preemph_coeff=0.0), dict(window_type="hanning", remove_dc_offset=False),
+               dict(window_type="rectangular", cepstral_lifter=0.0), dict(frame_length_ms=20.0, frame_shift_ms=5.0)):
+        got = api.Mfcc(**kw).compute(torch.from_numpy(w).cuda()).cpu().numpy()
+        check_mfcc(got, ko.mfcc_compute(w, **kw))
+    mf = api.Mfcc()
+    assert mf.compute(torch.from_numpy(w[:399]).cuda()).shape[0] == 0       # shorter than one frame
+    assert mf.compute(torch.from_numpy(w[:400]).cuda()).shape[0] == 1
+    with pytest.raises(api.KhError):
+        api.Mfcc(window_type="triangular")
+    with pytest.raises(api.KhError):
+        api.Mfcc(low_freq=9000.0)
+
+
+def test_deltas_and_cmvn(api):
+    g = np.load(GOLDEN)
+    ko = B.OracleLib("ko")
+    x = g["mfcc_mfcc13"]
+    xd = torch.from_numpy(x).cuda()
+    for order, window in ((2, 2), (3, 1), (1, 3), (0, 2)):
+        got = api.compute_deltas(xd, order, window).cpu().numpy()
+        want = ko.compute_deltas(x, order, window)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))     # same products, same order
+    assert np.abs(api.compute_deltas(xd, 2, 2).cpu().numpy() - g["deltas"]).max() < 1e-5
+    st = api.acc_cmvn_stats(xd)
+    assert np.allclose(st, g["cmvn_stats"], rtol=1e-10, atol=1e-7)
+    st2 = api.acc_cmvn_stats(xd, st)                                         # accumulation over utterances
+    assert np.allclose(st2, 2 * g["cmvn_stats"], rtol=1e-10, atol=1e-7)
+    for vn, key in ((False, "cmn"), (True, "cmvn")):
+        y = api.apply_cmvn(g["cmvn_stats"], vn, xd.clone()).cpu().numpy()
+        assert np.array_equal(y.view(np.int32), g[key].view(np.int32))
+    with pytest.raises(api.KhError, match="Insufficient stats"):
+        api.apply_cmvn(np.zeros((2, 14)), True, xd.clone())
