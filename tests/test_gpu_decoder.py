@@ -270,3 +270,25 @@ def test_capacity_overflow_is_reported_not_hidden(api, monkeypatch):
     on.init_decoding([0])
     with pytest.raises(api.KhError, match="overflowed"):
         on.advance_decoding([0], [torch.from_numpy(x).cuda()])
+
+
+def test_decoder_object_reused_across_batches(api):
+    """One LatticeFasterDecoder object, successive Decode() batches of growing utterance
+    count and length (arena slab re-carved, slots refilled): every batch bit-exact."""
+    rng = np.random.default_rng(55)
+    g = graph_like_hclg(rng, 10000, 100)
+    cfg = api.decoder_config(beam=11.0, max_active=700, min_active=50, lattice_beam=5.0)
+    fst = api.Fst(g)
+    dec = api.LatticeFasterDecoder(fst, cfg, max_batch=8, max_frames=200)
+    for Ts in ((30,), (60, 45, 12), (20,), (200, 150, 7, 90, 33, 64, 180, 5)):
+        lls = [workloads.make_loglikes(rng, T, 100) for T in Ts]
+        off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+        dec.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
+        dec.prepare(2)
+        for u, x in enumerate(lls):
+            oc = B.DecoderOracle(g, cfg, "canonical")
+            assert oc.decode(x)
+            assert_same_lattice(dec.get_raw_lattice(u), oc.raw_lattice())
+            assert_same_best_path(dec.get_best_path(u), oc.best_path())
+    with pytest.raises(api.KhError):   # more utterances than max_batch
+        dec.decode(torch.zeros((90, 100), device="cuda"), np.arange(10, dtype=np.int32) * 10)
