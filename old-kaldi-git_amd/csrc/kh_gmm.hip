@@ -106,6 +106,35 @@ GmmPdfLseKernel(const float *__restrict__ ll, int T, int ll_stride,
   }
 }
 
+// Same, the row of per-Gaussian log-likelihoods staged in LDS first (read once, coalesced;
+// above, every lane walks its own pdf's Gaussians with 20-byte strides).
+constexpr int kLseLdsFloats = 12288;
+__global__ void __launch_bounds__(kThreads)
+GmmPdfLseRowKernel(const float *__restrict__ ll, int T, int ll_stride, int num_mix,
+                   const int32_t *__restrict__ pdf_offsets, int num_pdfs, float prune,
+                   float min_log_diff, float *__restrict__ out, int out_stride) {
+  __shared__ float row[kLseLdsFloats];
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    const float *src = ll + static_cast<size_t>(t) * ll_stride;
+    for (int m = threadIdx.x; m < num_mix; m += kThreads) row[m] = src[m];
+    __syncthreads();
+    for (int j = threadIdx.x; j < num_pdfs; j += kThreads) {
+      const int s = pdf_offsets[j], e = pdf_offsets[j + 1];
+      float mx = -INFINITY;
+      for (int m = s; m < e; m++) mx = fmaxf(mx, row[m]);
+      float cutoff = mx + min_log_diff;
+      if (prune > 0.0f && mx - prune > cutoff) cutoff = mx - prune;
+      double sum = 0.0;
+      for (int m = s; m < e; m++) {
+        const float f = row[m];
+        if (f >= cutoff) sum += static_cast<double>(expf(f - mx));
+      }
+      out[static_cast<size_t>(t) * out_stride + j] = static_cast<float>(static_cast<double>(mx) + log(sum));
+    }
+    __syncthreads();
+  }
+}
+
 template <int DP>
 int LaunchLoglikes(const float *data, KhMatrixDim dd, const float *g,
                    const float *mi, const float *iv, int M, float *out,
@@ -229,10 +258,15 @@ int kh_am_gmm_loglikes(const float *data, KhMatrixDim dd, const float *gconsts,
     int gy = rows;
     const int cap = NumCUs() * 16 / gx;
     if (gy > cap) gy = cap > 0 ? cap : 1;
-    hipLaunchKernelGGL(GmmPdfLseKernel, dim3(gx, gy), dim3(kThreads), 0, Stream(),
-                       scratch, rows, ll_stride, pdf_offsets, num_pdfs,
-                       log_sum_exp_prune, min_log_diff, out + r0 * out_stride,
-                       out_stride);
+    if (num_mix <= kLseLdsFloats && num_mix >= 1024)
+      hipLaunchKernelGGL(GmmPdfLseRowKernel, dim3(std::min(rows, NumCUs() * 12)), dim3(kThreads), 0, Stream(),
+                         scratch, rows, ll_stride, num_mix, pdf_offsets, num_pdfs, log_sum_exp_prune, min_log_diff,
+                         out + r0 * out_stride, out_stride);
+    else
+      hipLaunchKernelGGL(GmmPdfLseKernel, dim3(gx, gy), dim3(kThreads), 0, Stream(),
+                         scratch, rows, ll_stride, pdf_offsets, num_pdfs,
+                         log_sum_exp_prune, min_log_diff, out + r0 * out_stride,
+                         out_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       SetError("GmmPdfLseKernel launch failed: %s", hipGetErrorString(e));
