@@ -16,6 +16,8 @@
 //   kaldi::DiagGmm (likelihoods)       gmm/diag-gmm.h:83-135
 //   kaldi::LatticeForwardBackward, LatticeForwardBackwardMpeVariants
 //                              lat/lattice-functions.cc:272-354,740-919
+//   kaldi::Mfcc, ComputeDeltas, AccCmvnStats, ApplyCmvn
+//                              feat/feature-mfcc.h, feature-functions.cc:361-372, transform/cmvn.cc:49-113
 // Errors throw std::runtime_error exactly as KALDI_ERR does
 // (base/kaldi-error.cc:143,179-182); all operations are synchronous at the API
 // (results visible on return), like the reference's CU_SAFE_CALL
@@ -23,6 +25,7 @@
 #ifndef KALDI_HIP_HOST_H_
 #define KALDI_HIP_HOST_H_
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <limits>
@@ -457,6 +460,153 @@ inline double LatticeForwardBackwardMpeVariants(const std::vector<int32> &tid2ph
                                           static_cast<int>(silence_phones.size()), num_ali.data(), aoff,
                                           criterion == "mpfe", one_silence_class, arc_post->data(), &score, NULL));
   return score;
+}
+
+// ---- feature front-end feat/feature-mfcc.h, feature-functions.h, transform/cmvn.h ---------
+struct MfccOptions {  // feature-mfcc.h:37-78 + FrameExtractionOptions + MelBanksOptions (the supported subset)
+  BaseFloat samp_freq, frame_length_ms, frame_shift_ms, preemph_coeff;
+  bool remove_dc_offset;
+  std::string window_type;
+  int32 num_bins, num_ceps;
+  BaseFloat low_freq, high_freq, cepstral_lifter;
+  MfccOptions()
+      : samp_freq(16000), frame_length_ms(25.0), frame_shift_ms(10.0), preemph_coeff(0.97), remove_dc_offset(true),
+        window_type("povey"), num_bins(23), num_ceps(13), low_freq(20), high_freq(0), cepstral_lifter(22.0) {}
+};
+
+/// Mfcc (use_energy = false, dither = 0, snip_edges = true): the constructor builds the
+/// window function, the mel filters, the DCT rows and the lifter as the reference's does.
+class Mfcc {
+ public:
+  explicit Mfcc(const MfccOptions &opts) : opts_(opts) {
+    frame_shift_ = static_cast<int32>(opts.samp_freq * 0.001f * opts.frame_shift_ms);
+    frame_length_ = static_cast<int32>(opts.samp_freq * 0.001f * opts.frame_length_ms);
+    padded_ = 1;
+    while (padded_ < frame_length_) padded_ <<= 1;
+    const double two_pi = 6.283185307179586476925286766559, pi = 3.1415926535897932384626433832795;
+    window_.resize(frame_length_);
+    for (int32 i = 0; i < frame_length_; i++) {
+      const double a = two_pi * static_cast<BaseFloat>(i) / (frame_length_ - 1);
+      if (opts.window_type == "hanning") window_[i] = 0.5 - 0.5 * std::cos(a);
+      else if (opts.window_type == "hamming") window_[i] = 0.54 - 0.46 * std::cos(a);
+      else if (opts.window_type == "povey") window_[i] = std::pow(0.5 - 0.5 * std::cos(a), 0.85);
+      else if (opts.window_type == "rectangular") window_[i] = 1.0;
+      else throw std::runtime_error("Invalid window type " + opts.window_type);
+    }
+    const BaseFloat nyquist = 0.5f * opts.samp_freq;
+    const BaseFloat high = opts.high_freq > 0.0f ? opts.high_freq : nyquist + opts.high_freq;
+    if (opts.low_freq < 0.0f || opts.low_freq >= nyquist || high <= 0.0f || high > nyquist || high <= opts.low_freq)
+      throw std::runtime_error("Bad values in options: low-freq and high-freq vs. nyquist");
+    const int32 num_fft_bins = padded_ / 2;
+    const BaseFloat bin_width = opts.samp_freq / padded_;
+    const BaseFloat mel_low = MelScale(opts.low_freq), mel_high = MelScale(high);
+    const BaseFloat delta = (mel_high - mel_low) / (opts.num_bins + 1);
+    mel_off_.assign(1, 0);
+    for (int32 b = 0; b < opts.num_bins; b++) {
+      const BaseFloat left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+      int32 first = -1, last = -1;
+      std::vector<BaseFloat> w(num_fft_bins, 0.0f);
+      for (int32 i = 0; i < num_fft_bins; i++) {
+        const BaseFloat mel = MelScale(bin_width * i);
+        if (mel > left && mel < right) {
+          w[i] = mel <= center ? (mel - left) / (center - left) : (right - mel) / (right - center);
+          if (first < 0) first = i;
+          last = i;
+        }
+      }
+      if (first < 0) throw std::runtime_error("You may have set --num-mel-bins too large.");
+      mel_first_.push_back(first);
+      mel_weights_.insert(mel_weights_.end(), w.begin() + first, w.begin() + last + 1);
+      mel_off_.push_back(static_cast<int32>(mel_weights_.size()));
+    }
+    const int32 N = opts.num_bins;
+    dct_.resize(static_cast<size_t>(opts.num_ceps) * N);
+    BaseFloat norm = std::sqrt(1.0 / static_cast<BaseFloat>(N));
+    for (int32 n = 0; n < N; n++) dct_[n] = norm;
+    norm = std::sqrt(2.0 / static_cast<BaseFloat>(N));
+    for (int32 k = 1; k < opts.num_ceps; k++)
+      for (int32 n = 0; n < N; n++) dct_[static_cast<size_t>(k) * N + n] = norm * std::cos(pi / N * (n + 0.5) * k);
+    if (opts.cepstral_lifter != 0.0f) {
+      lifter_.resize(opts.num_ceps);
+      for (int32 i = 0; i < opts.num_ceps; i++)
+        lifter_[i] = 1.0 + 0.5 * opts.cepstral_lifter * std::sin(pi * i / opts.cepstral_lifter);
+    }
+  }
+  int32 Dim() const { return opts_.num_ceps; }
+  /// Mfcc::Compute(wave, 1.0, &output): wave = n_samples floats on the device
+  void Compute(const BaseFloat *wave_dev, int32 n_samples, CuMatrix *output) const {
+    const int32 rows = n_samples < frame_length_ ? 0 : 1 + (n_samples - frame_length_) / frame_shift_;
+    output->Resize(rows, opts_.num_ceps, kUndefined);
+    int32 got = 0;
+    KhCheck(kh_mfcc_compute(wave_dev, n_samples, frame_shift_, frame_length_, padded_, opts_.preemph_coeff,
+                            opts_.remove_dc_offset, window_.data(), opts_.num_bins, mel_first_.data(), mel_off_.data(),
+                            mel_weights_.data(), opts_.num_ceps, dct_.data(), lifter_.empty() ? NULL : lifter_.data(),
+                            output->Data(), output->Stride(), &got));
+    KALDI_HIP_ASSERT(got == rows);
+  }
+
+ private:
+  static BaseFloat MelScale(BaseFloat freq) { return 1127.0f * logf(1.0f + freq / 700.0f); }
+  MfccOptions opts_;
+  int32 frame_shift_, frame_length_, padded_;
+  std::vector<BaseFloat> window_, mel_weights_, dct_, lifter_;
+  std::vector<int32> mel_first_, mel_off_;
+};
+
+/// ComputeDeltas(DeltaFeaturesOptions(order, window), input, &output) feature-functions.cc:361-372
+inline void ComputeDeltas(int32 order, int32 window, const CuMatrix &input, CuMatrix *output) {
+  KALDI_HIP_ASSERT(order >= 0 && order < 1000 && window > 0 && window < 1000);
+  std::vector<std::vector<BaseFloat> > sc(order + 1);
+  sc[0].assign(1, 1.0f);
+  for (int32 i = 1; i <= order; i++) {
+    const std::vector<BaseFloat> &prev = sc[i - 1];
+    const int32 prev_offset = (static_cast<int32>(prev.size()) - 1) / 2;
+    std::vector<BaseFloat> &cur = sc[i];
+    cur.assign(prev.size() + 2 * window, 0.0f);
+    BaseFloat normalizer = 0.0f;
+    for (int32 j = -window; j <= window; j++) {
+      normalizer += j * j;
+      for (int32 k = -prev_offset; k <= prev_offset; k++) cur[j + k + prev_offset + window] += static_cast<BaseFloat>(j) * prev[k + prev_offset];
+    }
+    const BaseFloat inv = static_cast<BaseFloat>(1.0 / normalizer);
+    for (size_t k = 0; k < cur.size(); k++) cur[k] *= inv;
+  }
+  std::vector<BaseFloat> flat;
+  std::vector<int32> lens;
+  for (int32 i = 0; i <= order; i++) { lens.push_back(static_cast<int32>(sc[i].size())); flat.insert(flat.end(), sc[i].begin(), sc[i].end()); }
+  output->Resize(input.NumRows(), input.NumCols() * (order + 1), kUndefined);
+  KhCheck(kh_compute_deltas(input.Data(), input.Dim(), order, flat.data(), lens.data(), output->Data(), output->Stride()));
+}
+
+/// AccCmvnStats(feats, NULL, &stats) transform/cmvn.cc:49-62; stats = 2 x (dim + 1) doubles, row-major
+inline void AccCmvnStats(const CuMatrix &feats, std::vector<double> *stats) {
+  if (stats->empty()) stats->assign(2 * (feats.NumCols() + 1), 0.0);
+  KALDI_HIP_ASSERT(static_cast<int32>(stats->size()) == 2 * (feats.NumCols() + 1));
+  KhCheck(kh_acc_cmvn_stats(feats.Data(), feats.Dim(), stats->data()));
+}
+
+/// ApplyCmvn(stats, var_norm, &feats) transform/cmvn.cc:64-113
+inline void ApplyCmvn(const std::vector<double> &stats, bool var_norm, CuMatrix *feats) {
+  const int32 dim = feats->NumCols();
+  if (static_cast<int32>(stats.size()) != 2 * (dim + 1)) throw std::runtime_error("Dim mismatch: cmvn stats vs feats");
+  const double count = stats[dim];
+  if (count < 1.0) throw std::runtime_error("Insufficient stats for cepstral mean and variance normalization");
+  std::vector<BaseFloat> offset(dim), scale(dim);
+  for (int32 d = 0; d < dim; d++) {
+    const double mean = stats[d] / count;
+    double sc = 1.0, off = -mean;
+    if (var_norm) {
+      double var = stats[dim + 1 + d] / count - mean * mean;
+      if (var < 1.0e-20) var = 1.0e-20;
+      sc = 1.0 / std::sqrt(var);
+      off = -(mean * sc);
+    }
+    offset[d] = static_cast<BaseFloat>(off);
+    scale[d] = static_cast<BaseFloat>(sc);
+  }
+  if (var_norm) { CuVector s(scale); feats->MulColsVec(s); }
+  CuVector o(offset);
+  feats->AddVecToRows(1.0, o);
 }
 
 // ---- LatticeFasterDecoder lattice-faster-decoder.h:40-205 ------------------------------

@@ -212,7 +212,41 @@ static void TestNnetGmmLattice() {
   CHECK(fr > 0 && to >= fr);
 }
 
-int main() {
+// argv[1]: file written by tests/test_gpu_cpp_host.py: int32 n_samples, rows, cols; float wave[n];
+// float mfcc[rows*cols] (api.Mfcc, hires options); float cmvn_deltas[rows * 3 cols] (CMVN then deltas)
+static void TestFeatures(const char *path) {
+  FILE *f = fopen(path, "rb");
+  CHECK(f != NULL);
+  int32 hdr[3];
+  CHECK(fread(hdr, 4, 3, f) == 3);
+  const int n = hdr[0], rows = hdr[1], cols = hdr[2];
+  std::vector<float> wave(n), want(static_cast<size_t>(rows) * cols), want2(static_cast<size_t>(rows) * cols * 3);
+  CHECK(fread(wave.data(), 4, n, f) == static_cast<size_t>(n));
+  CHECK(fread(want.data(), 4, want.size(), f) == want.size());
+  CHECK(fread(want2.data(), 4, want2.size(), f) == want2.size());
+  fclose(f);
+  MfccOptions opts;
+  opts.num_bins = 40; opts.num_ceps = 40; opts.low_freq = 40; opts.high_freq = -200;
+  Mfcc mfcc(opts);
+  CuVector w(wave);
+  CuMatrix feats;
+  mfcc.Compute(w.Data(), n, &feats);
+  CHECK(feats.NumRows() == rows && feats.NumCols() == cols);
+  std::vector<float> got(want.size());
+  feats.CopyToMat(got.data(), cols);
+  for (size_t i = 0; i < got.size(); i++) Near(got[i], want[i], 1e-4f, 2e-4f);  // tables built in C++ vs numpy
+  std::vector<double> stats;
+  AccCmvnStats(feats, &stats);
+  ApplyCmvn(stats, true, &feats);
+  CuMatrix d;
+  ComputeDeltas(2, 2, feats, &d);
+  CHECK(d.NumCols() == 3 * cols);
+  std::vector<float> got2(want2.size());
+  d.CopyToMat(got2.data(), 3 * cols);
+  for (size_t i = 0; i < got2.size(); i++) Near(got2[i], want2[i], 1e-3f, 1e-3f);
+}
+
+int main(int argc, char **argv) {
   try {
     CuDevice::Instantiate().SelectGpuId("yes");
     printf("device: %s\n", CuDevice::Instantiate().DeviceGetName().c_str());
@@ -220,6 +254,7 @@ int main() {
     TestSoftmaxPnormCopyRows();
     TestDecoder();
     TestNnetGmmLattice();
+    if (argc > 1) TestFeatures(argv[1]);
   } catch (const std::exception &e) {
     printf("FAIL exception: %s\n", e.what());
     return 1;
