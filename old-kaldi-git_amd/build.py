@@ -20,7 +20,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "kaldi_hip.h")]
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -31,7 +31,7 @@ def build(force=False, verbose=False, jobs=8):
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
-    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "kaldi_hip.h")])
+    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")))
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)

@@ -35,6 +35,21 @@ def test_library_exports_every_declared_symbol(built):
     assert not missing, missing
 
 
+def seam_functions():
+    text = open(os.path.join(ROOT, "include", "cu_kernels_ansi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cudaF_[a-z0-9_]+|cublasSgemm|kh_cuda_seam_status)\s*\(", text)))
+
+
+def test_library_exports_the_reference_launcher_seam(built):
+    """include/cu_kernels_ansi_hip.h: the cu-kernels-ansi.h names of the hot subset."""
+    fns = seam_functions()
+    assert len(fns) == 20 and "cudaF_softmax_reduce" in fns and "cublasSgemm" in fns
+    lib = ctypes.CDLL(built)
+    missing = [f for f in fns if not hasattr(lib, f)]
+    assert not missing, missing
+
+
 def test_python_binding_covers_header(built):
     capi = pkg("capi")
     assert sorted(capi.SIGNATURES) == header_functions()
