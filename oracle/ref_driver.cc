@@ -21,10 +21,14 @@
 #include "feat/feature-functions.h"
 #include "feat/feature-mfcc.h"
 #include "gmm/diag-gmm.h"
+#include "hmm/hmm-topology.h"
 #include "matrix/matrix-lib.h"
 #include "nnet2/nnet-component.h"
+#include "nnet2/am-nnet.h"
 #include "nnet2/nnet-nnet.h"
 #include "transform/cmvn.h"
+#include "util/kaldi-io.h"
+#include "util/table-types.h"
 
 #include "kaldi_oracle.h"  // KoComponent
 
@@ -481,4 +485,164 @@ void ref_apply_cmvn(const double *stats, int var_norm, float *feats, int rows, i
   Out(f, feats, stride);
 }
 
+
+// ---- object / table / model I/O by the reference's own Write / Read -------------
+// (fixtures of tests/golden/kaldi_io/, tests/test_kaldi_io.py)
+
+// Matrix<float|double>::Write matrix/kaldi-matrix.cc:1155-1193 through Output (util/kaldi-io.cc)
+int ref_write_matrix(const char *path, const float *data, int rows, int cols, int binary, int as_double) {
+  try {
+    Output ko(path, binary != 0);
+    Matrix<BaseFloat> m(In(data, rows, cols, cols));
+    if (as_double) { Matrix<double> d(m); d.Write(ko.Stream(), binary != 0); }
+    else m.Write(ko.Stream(), binary != 0);
+    return ko.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+int ref_write_vector(const char *path, const float *data, int dim, int binary) {
+  try {
+    Output ko(path, binary != 0);
+    InV(data, dim).Write(ko.Stream(), binary != 0);
+    return ko.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// CompressedMatrix::Write matrix/compressed-matrix.cc:404-435 (format 1 "CM" or, for <= 8 rows, 2 "CM2")
+int ref_write_compressed_matrix(const char *path, const float *data, int rows, int cols) {
+  try {
+    Output ko(path, true);
+    CompressedMatrix cm(In(data, rows, cols, cols));
+    cm.Write(ko.Stream(), true);
+    return ko.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// and what the reference itself decompresses it to (CopyToMat :476-520)
+int ref_compress_roundtrip(const float *data, int rows, int cols, float *out) {
+  CompressedMatrix cm(In(data, rows, cols, cols));
+  Matrix<BaseFloat> m(rows, cols);
+  cm.CopyToMat(&m);
+  Out(m, out, cols);
+  return 0;
+}
+// WriteIntegerVector base/io-funcs-inl.h:195-224
+int ref_write_int_vector(const char *path, const int32_t *data, int n, int binary) {
+  try {
+    Output ko(path, binary != 0);
+    std::vector<int32> v(data, data + n);
+    WriteIntegerVector(ko.Stream(), binary != 0, v);
+    return ko.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// TableWriter<KaldiObjectHolder<Matrix>> util/kaldi-table-inl.h: utterance u = rows
+// [offsets[u], offsets[u+1]) of data, key "utt<u>"; compressed != 0: CompressedMatrixWriter
+int ref_write_matrix_table(const char *wspecifier, const float *data, int cols, const int32_t *offsets, int n_utts,
+                           int compressed) {
+  try {
+    BaseFloatMatrixWriter w;
+    CompressedMatrixWriter cw;
+    if (compressed) { if (!cw.Open(wspecifier)) return -1; }
+    else if (!w.Open(wspecifier)) return -1;
+    for (int u = 0; u < n_utts; u++) {
+      char key[32];
+      snprintf(key, sizeof(key), "utt%d", u);
+      Matrix<BaseFloat> m(In(data + static_cast<size_t>(offsets[u]) * cols, offsets[u + 1] - offsets[u], cols, cols));
+      if (compressed) cw.Write(key, CompressedMatrix(m));
+      else w.Write(key, m);
+    }
+    return (compressed ? cw.Close() : w.Close()) ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// SequentialTableReader over any rspecifier: total rows / cols / checksum of what the REFERENCE reads
+int ref_read_matrix_table(const char *rspecifier, int *n_utts, int *tot_rows, int *cols, double *sum,
+                          char *keys, int keys_cap) {
+  try {
+    SequentialBaseFloatMatrixReader r(rspecifier);
+    *n_utts = 0; *tot_rows = 0; *cols = 0; *sum = 0.0;
+    std::string all;
+    for (; !r.Done(); r.Next()) {
+      const Matrix<BaseFloat> &m = r.Value();
+      (*n_utts)++;
+      *tot_rows += m.NumRows();
+      *cols = m.NumCols();
+      *sum += m.Sum();
+      all += r.Key() + " ";
+    }
+    snprintf(keys, keys_cap, "%s", all.c_str());
+    return 0;
+  } catch (...) { return -1; }
+}
+// TableWriter<BasicVectorHolder<int32>> (alignments, word sequences) util/kaldi-holder-inl.h:191-224:
+// vector u = data[offsets[u], offsets[u+1]), key "utt<u>"
+int ref_write_int_vector_table(const char *wspecifier, const int32_t *data, const int32_t *offsets, int n_utts) {
+  try {
+    Int32VectorWriter w(wspecifier);
+    for (int u = 0; u < n_utts; u++) {
+      char key[32];
+      snprintf(key, sizeof(key), "utt%d", u);
+      w.Write(key, std::vector<int32>(data + offsets[u], data + offsets[u + 1]));
+    }
+    return w.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+int ref_read_int_vector_table(const char *rspecifier, int *n_utts, long long *sum) {
+  try {
+    SequentialInt32VectorReader r(rspecifier);
+    *n_utts = 0; *sum = 0;
+    for (; !r.Done(); r.Next()) {
+      (*n_utts)++;
+      for (size_t i = 0; i < r.Value().size(); i++) *sum += static_cast<long long>(r.Value()[i]) * (i + 1);
+    }
+    return 0;
+  } catch (...) { return -1; }
+}
+// AmNnet::Write nnet2/am-nnet.cc:31-37 (Nnet::Write nnet-nnet.cc:160-173 + priors).  affine_kind: the class
+// the KO_AFFINE layers are written as: 0 AffineComponent, 1 AffineComponentPreconditioned,
+// 2 AffineComponentPreconditionedOnline (nnet-component.cc:1288,1520,1829).  with_header: Output's "\0B".
+int ref_write_am_nnet(const char *path, const KoComponent *comps, int n_comps, const float *priors, int n_priors,
+                      int binary, int affine_kind, int with_header) {
+  try {
+    Nnet *nnet = BuildNnet(comps, n_comps);
+    if (!nnet) return -2;
+    if (affine_kind != 0) {
+      for (int c = 0; c < nnet->NumComponents(); c++) {
+        AffineComponent *ac = dynamic_cast<AffineComponent *>(&nnet->GetComponent(c));
+        if (!ac) continue;
+        Component *repl;
+        if (affine_kind == 2) {
+          repl = new AffineComponentPreconditionedOnline(*ac, 20, 40, 2, 2000.0, 4.0);
+        } else {
+          AffineComponentPreconditioned *p = new AffineComponentPreconditioned();
+          std::ostringstream args;
+          args << "learning-rate=0.002 input-dim=" << ac->InputDim() << " output-dim=" << ac->OutputDim()
+               << " alpha=3.5 max-change=7.0 param-stddev=0.1 bias-stddev=0.1";
+          p->InitFromString(args.str());
+          p->SetParams(Vector<BaseFloat>(ac->BiasParams()), Matrix<BaseFloat>(ac->LinearParams()));
+          repl = p;
+        }
+        nnet->SetComponent(c, repl);
+      }
+    }
+    AmNnet am(*nnet);
+    delete nnet;
+    if (n_priors > 0) am.SetPriors(InV(priors, n_priors));
+    if (with_header) {
+      Output ko(path, binary != 0);
+      am.Write(ko.Stream(), binary != 0);
+      return ko.Close() ? 0 : -1;
+    }
+    std::ofstream os(path, std::ios::binary);
+    am.Write(os, binary != 0);
+    return os.good() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// HmmTopology: Read (text) then Write hmm/hmm-topology.cc:39-196
+int ref_write_topology(const char *path, const char *topo_text, int binary) {
+  try {
+    std::istringstream is(topo_text);
+    HmmTopology topo;
+    topo.Read(is, false);
+    std::ofstream os(path, std::ios::binary);
+    topo.Write(os, binary != 0);
+    return os.good() ? 0 : -1;
+  } catch (...) { return -1; }
+}
 }  // extern "C"

@@ -177,9 +177,107 @@ def make_features():
     print("features.npz:", {k: v.shape for k, v in out.items()})
 
 
+TOPO_TEXT = """<Topology>
+<TopologyEntry>
+<ForPhones> 2 3 5 </ForPhones>
+<State> 0 <PdfClass> 0 <Transition> 0 0.75 <Transition> 1 0.25 </State>
+<State> 1 <PdfClass> 1 <Transition> 1 0.5 <Transition> 2 0.5 </State>
+<State> 2 <PdfClass> 2 <Transition> 2 0.6 <Transition> 3 0.4 </State>
+<State> 3 </State>
+</TopologyEntry>
+<TopologyEntry>
+<ForPhones> 1 </ForPhones>
+<State> 0 <PdfClass> 0 <Transition> 0 0.25 <Transition> 1 0.25 <Transition> 2 0.5 </State>
+<State> 1 <PdfClass> 1 <Transition> 1 0.5 <Transition> 2 0.5 </State>
+<State> 2 </State>
+</TopologyEntry>
+</Topology>
+"""
+
+
+def kaldi_io_net(rng):
+    """A small net with every component type the forward path reads."""
+    net, priors = workloads.make_pnorm_net(rng, feat_dim=6, splice=1, const_dim=2, pnorm_in=20, pnorm_out=4,
+                                           n_hidden=1, n_mix=12, n_pdf=5)
+    k = next(i for i, c in enumerate(net) if c["type"] == "normalize") + 1
+    net.insert(k, dict(type="fixed_scale", input_dim=4, output_dim=4, bias=rng.uniform(0.5, 2, 4).astype(np.float32)))
+    net.insert(k + 1, dict(type="fixed_bias", input_dim=4, output_dim=4, bias=rng.standard_normal(4).astype(np.float32)))
+    return net, priors
+
+
+def make_kaldi_io():
+    """Files written by the REFERENCE's own Write functions (oracle/_ref: Matrix / Vector /
+    CompressedMatrix / WriteIntegerVector / TableWriter / AmNnet / HmmTopology) + the arrays
+    that went in, for tests/test_kaldi_io.py.  Data only."""
+    import ctypes as C
+    out_dir = os.path.join(HERE, "kaldi_io")
+    os.makedirs(out_dir, exist_ok=True)
+    ref = binding.OracleLib("ref").lib
+    fp, ip = binding._fp, binding._ip
+    rng = np.random.default_rng(11)
+    M = (rng.standard_normal((5, 4)) * 10).astype(np.float32)
+    M[0, 0], M[1, 1], M[2, 2] = np.inf, -np.inf, 0.0
+    v = rng.standard_normal(7).astype(np.float32)
+    big = (rng.standard_normal((20, 7)) * 3).astype(np.float32)      # format 1 ("CM")
+    small = (rng.standard_normal((5, 7)) * 3).astype(np.float32)     # <= 8 rows: format 2 ("CM2")
+    iv = rng.integers(-5, 1000, 9).astype(np.int32)
+    cwd = os.getcwd()
+    os.chdir(out_dir)   # the script files then hold relative paths
+    try:
+        def b(x):
+            return x.encode()
+        assert ref.ref_write_matrix(b("mat_f.bin"), fp(M), 5, 4, 1, 0) == 0
+        assert ref.ref_write_matrix(b("mat_f.txt"), fp(M), 5, 4, 0, 0) == 0
+        assert ref.ref_write_matrix(b("mat_d.bin"), fp(M), 5, 4, 1, 1) == 0
+        assert ref.ref_write_matrix(b("mat_empty.txt"), fp(M), 0, 0, 0, 0) == 0
+        assert ref.ref_write_vector(b("vec.bin"), fp(v), 7, 1) == 0
+        assert ref.ref_write_vector(b("vec.txt"), fp(v), 7, 0) == 0
+        assert ref.ref_write_compressed_matrix(b("cm.bin"), fp(big), 20, 7) == 0
+        assert ref.ref_write_compressed_matrix(b("cm2.bin"), fp(small), 5, 7) == 0
+        big_rt, small_rt = np.zeros_like(big), np.zeros_like(small)
+        ref.ref_compress_roundtrip(fp(big), 20, 7, fp(big_rt))
+        ref.ref_compress_roundtrip(fp(small), 5, 7, fp(small_rt))
+        assert ref.ref_write_int_vector(b("ivec.bin"), ip(iv), 9, 1) == 0
+        assert ref.ref_write_int_vector(b("ivec.txt"), ip(iv), 9, 0) == 0
+        feats = rng.standard_normal((30, 6)).astype(np.float32)
+        off = np.asarray([0, 9, 10, 30], np.int32)
+        assert ref.ref_write_matrix_table(b("ark,scp:feats.ark,feats.scp"), fp(feats), 6, ip(off), 3, 0) == 0
+        assert ref.ref_write_matrix_table(b("ark,t:feats_t.ark"), fp(feats), 6, ip(off), 3, 0) == 0
+        assert ref.ref_write_matrix_table(b("ark:feats_cm.ark"), fp(feats), 6, ip(off), 3, 1) == 0
+        ali = rng.integers(1, 500, 14).astype(np.int32)
+        ali_off = np.asarray([0, 6, 6, 14], np.int32)     # the middle one is empty
+        assert ref.ref_write_int_vector_table(b("ark:ali.ark"), ip(ali), ip(ali_off), 3) == 0
+        assert ref.ref_write_int_vector_table(b("ark,t:ali_t.ark"), ip(ali), ip(ali_off), 3) == 0
+        feats_cm = np.zeros_like(feats)
+        for u in range(3):
+            a, e = off[u], off[u + 1]
+            blk = np.ascontiguousarray(feats[a:e])
+            rt = np.zeros_like(blk)
+            ref.ref_compress_roundtrip(fp(blk), int(e - a), 6, fp(rt))
+            feats_cm[a:e] = rt
+        net, priors = kaldi_io_net(np.random.default_rng(12))
+        arr, keep = binding.pack_components(net)
+        for kind in (0, 1, 2):
+            for binary in (1, 0):
+                name = "am_nnet_%s_%d" % ("bin" if binary else "txt", kind)
+                rc = ref.ref_write_am_nnet(b(name), arr, len(net), fp(priors), len(priors), binary, kind, 1)
+                assert rc == 0, (name, rc)
+        assert ref.ref_write_am_nnet(b("am_nnet_body_bin"), arr, len(net), fp(priors), len(priors), 1, 2, 0) == 0
+        assert ref.ref_write_topology(b("topo.bin"), b(TOPO_TEXT), 1) == 0
+        assert ref.ref_write_topology(b("topo.txt"), b(TOPO_TEXT), 0) == 0
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(out_dir, "expected.npz"), M=M, v=v, big=big, small=small, big_rt=big_rt,
+                        small_rt=small_rt, iv=iv, feats=feats, off=off, feats_cm=feats_cm, ali=ali, ali_off=ali_off)
+    print("kaldi_io:", sorted(os.listdir(out_dir)))
+
+
 if __name__ == "__main__":
     if "--features" in sys.argv:
         make_features()
+    elif "--kaldi-io" in sys.argv:
+        make_kaldi_io()
     else:
         main()
         make_features()
+        make_kaldi_io()
