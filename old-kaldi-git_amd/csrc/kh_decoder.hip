@@ -89,6 +89,29 @@ __host__ __device__ __forceinline__ float Dec(uint32_t e) {
 // dependable L1 bypass.  With the address space in the type every access below is
 // a global_* instruction.
 #define GP(T) __attribute__((address_space(1))) T *
+
+// A global array addressed with a 32-BIT UNSIGNED BYTE OFFSET: a[i] is
+// *(base + zext(uint32(i) * sizeof(T))), exactly the "SGPR base + 32-bit VGPR offset"
+// form of global_load / global_store / global_atomic.  With plain pointers and int
+// indices every access sign-extends and shifts to a 64-bit address in a VGPR pair of
+// its own (464 of the kernel's 579 loads did), which is what pushed the sweeps over
+// 64 VGPRs; here the six SoA arrays of a link sweep share ONE offset register.
+// Precondition (checked on the host): count * sizeof(T) < 4 GiB.
+template <class T>
+struct Arr {
+  GP(T) p;
+  Arr() = default;
+  __host__ __device__ Arr(GP(T) q) : p(q) {}
+  template <class U>
+  __host__ __device__ Arr(const Arr<U> &o) : p(o.p) {}
+  __device__ __forceinline__ __attribute__((address_space(1))) T &operator[](int i) const {
+    return *(GP(T))((__attribute__((address_space(1))) char *)p + static_cast<uint32_t>(i) * static_cast<uint32_t>(sizeof(T)));
+  }
+  __device__ __forceinline__ __attribute__((address_space(1))) T &operator[](uint32_t i) const {
+    return *(GP(T))((__attribute__((address_space(1))) char *)p + i * static_cast<uint32_t>(sizeof(T)));
+  }
+  __host__ __device__ operator GP(T)() const { return p; }
+};
 // 16-byte arc record as a native vector (HIP's int4 is a class; it cannot be
 // loaded through an address-space-qualified pointer)
 typedef int KhInt4 __attribute__((ext_vector_type(4)));
@@ -125,44 +148,44 @@ struct Utt {
   int32_t ll_stride, T;
   // token arena
   int32_t tok_cap;
-  GP(int32_t) tok_state;    // HCLG state, -1 = pruned token
-  GP(uint32_t) tok_cost;    // Enc(tot_cost); free slots hold Enc(+inf)
-  GP(float) tok_extra;
+  Arr<int32_t> tok_state;    // HCLG state, -1 = pruned token
+  Arr<uint32_t> tok_cost;    // Enc(tot_cost); free slots hold Enc(+inf)
+  Arr<float> tok_extra;
   // link arena
   int32_t link_cap;
-  GP(int32_t) link_dst; GP(int32_t) link_il; GP(int32_t) link_ol;   // dst: token index, -1 = excised
-  GP(int32_t) link_src;     // owning token (links are also walked link-parallel)
-  GP(float) link_g; GP(float) link_a;
-  GP(float) link_tot;       // candidate tot_cost of the frame being expanded [link_frame_cap]
+  Arr<int32_t> link_dst; Arr<int32_t> link_il; Arr<int32_t> link_ol;   // dst: token index, -1 = excised
+  Arr<int32_t> link_src;     // owning token (links are also walked link-parallel)
+  Arr<float> link_g; Arr<float> link_a;
+  Arr<float> link_tot;       // candidate tot_cost of the frame being expanded [link_frame_cap]
   // per-frame bookkeeping
-  GP(int32_t) frame_b; GP(int32_t) frame_e;      // [T+2] token range of frame f
-  GP(int32_t) feps_b; GP(int32_t) feps_e;        // [T+2] link range of eps(f)
-  GP(int32_t) femit_b; GP(int32_t) femit_e;      // [T+2] link range of emit(f)
-  GP(float) cost_offset;    // [T+1]
-  GP(uint8_t) must_links;   // [T+2] must_prune_forward_links
-  GP(uint8_t) must_toks;    // [T+2] must_prune_tokens
+  Arr<int32_t> frame_b; Arr<int32_t> frame_e;      // [T+2] token range of frame f
+  Arr<int32_t> feps_b; Arr<int32_t> feps_e;        // [T+2] link range of eps(f)
+  Arr<int32_t> femit_b; Arr<int32_t> femit_e;      // [T+2] link range of emit(f)
+  Arr<float> cost_offset;    // [T+1]
+  Arr<uint8_t> must_links;   // [T+2] must_prune_forward_links
+  Arr<uint8_t> must_toks;    // [T+2] must_prune_tokens
   // temporaries
-  GP(int32_t) tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
-  GP(int32_t) tmp_dirty;    // [tok_frame_cap] 1 = queued in a nonemitting work list; all zero outside ProcessNonemitting
-  GP(int32_t) tmp_work0; GP(int32_t) tmp_work1;  // [tok_frame_cap] nonemitting work lists (token indices), double buffered
-  GP(int32_t) tmp_epslist;  // [tok_frame_cap] the frontier's tokens whose state has epsilon arcs (each once, in creation order)
-  GP(float) tmp_f0;         // [tok_frame_cap] prune: extra_cost on entry (i - frame begin)
-  GP(uint32_t) tmp_acc0; GP(uint32_t) tmp_acc1;  // [tok_frame_cap] prune: Enc(min link_extra_cost) over emitting / epsilon links
-  GP(int32_t) tmp_remap;    // [window_cap] compaction remap (i - window begin)
+  Arr<int32_t> tmp_slot;     // [tok_frame_cap] hash slot of frontier token (i - frontier begin)
+  Arr<int32_t> tmp_dirty;    // [tok_frame_cap] 1 = queued in a nonemitting work list; all zero outside ProcessNonemitting
+  Arr<int32_t> tmp_work0; Arr<int32_t> tmp_work1;  // [tok_frame_cap] nonemitting work lists (token indices), double buffered
+  Arr<int32_t> tmp_epslist;  // [tok_frame_cap] the frontier's tokens whose state has epsilon arcs (each once, in creation order)
+  Arr<float> tmp_f0;         // [tok_frame_cap] prune: extra_cost on entry (i - frame begin)
+  Arr<uint32_t> tmp_acc0; Arr<uint32_t> tmp_acc1;  // [tok_frame_cap] prune: Enc(min link_extra_cost) over emitting / epsilon links
+  Arr<int32_t> tmp_remap;    // [window_cap] compaction remap (i - window begin)
   int32_t tok_frame_cap, link_frame_cap, window_cap;
   // hash
-  GP(unsigned long long) hash;
+  Arr<unsigned long long> hash;
   uint32_t hash_mask;
   GP(long long) phase_cycles;  // [16] diagnostic (KH_DECODER_PROFILE=1), else nullptr
 };
 
 struct Params {
-  GP(const int32_t) e_off; GP(const int32_t) n_off;
-  GP(const KhInt4) e_arcs; GP(const KhInt4) n_arcs;
-  GP(const float) final_cost;
+  Arr<const int32_t> e_off; Arr<const int32_t> n_off;
+  Arr<const KhInt4> e_arcs; Arr<const KhInt4> n_arcs;
+  Arr<const float> final_cost;
   int32_t start, num_states, num_emit, num_eps, start_has_eps;
   int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
-  GP(const int32_t) tid2pdf;
+  Arr<const int32_t> tid2pdf;
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
@@ -359,7 +382,7 @@ __device__ __forceinline__ bool BlockAny(bool p, Blk &sh) { return BlockOr(p ? 1
 
 // Exact k-th smallest (0-based) of the cost images tok_cost[b..e): what
 // std::nth_element yields at position k (GetCutoff :621-626,:633-640).
-__device__ uint32_t RadixSelect(GP(const uint32_t) keys, int b, int e, int k,
+__device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k,
                                 Blk &sh) {
   uint32_t prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
@@ -396,33 +419,38 @@ __device__ __forceinline__ uint32_t HashState(int32_t s) {
 // `state` in the frame under construction, creating it if needed (cost slot is
 // pre-filled with +inf: arena invariant), or -1 if the raw arena is full.
 // Entry: low 32 bits = state + 1 (0 = empty), high 32 bits = token + 1 (0 = pending).
+template <bool kQueue>
 __device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute__((address_space(3))) int *tok_end /*LDS counter*/,
                          __attribute__((address_space(3))) int *eps_n /*LDS counter*/, int tok_limit, int front_b) {
   uint32_t slot = HashState(state) & u.hash_mask;
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
   for (int probes = 0; probes < (1 << 30); probes++) {
-    unsigned long long ent = __hip_atomic_load(&u.hash[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE L2 round trip per probe: the compare-and-swap claims the slot if it is empty
+    // and otherwise returns its occupant (a failed CAS is an atomic load)
+    unsigned long long ent = kEmpty;
+    __hip_atomic_compare_exchange_strong(&u.hash[slot], &ent, want_key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);  // ent <- previous value
     if (ent == kEmpty) {
-      unsigned long long old = kEmpty;
-      __hip_atomic_compare_exchange_strong(&u.hash[slot], &old, want_key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);  // old <- previous value
-      if (old == kEmpty) {
-        // we own the slot: allocate the token, publish it
-        const int idx = __hip_atomic_fetch_add(tok_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (idx >= tok_limit) {
-          // arena full: publish an invalid token so waiters terminate
-          __hip_atomic_exchange(&u.hash[slot], want_key | (0xFFFFFFFFull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return -1;
-        }
-        u.tok_state[idx] = state;
-        u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
-        u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot);
-        if (has_eps) u.tmp_epslist[__hip_atomic_fetch_add(eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
-        __hip_atomic_exchange(&u.hash[slot], want_key | (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32),
-                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return idx;
+      // we own the slot: allocate the token, publish it
+      const int idx = __hip_atomic_fetch_add(tok_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (idx >= tok_limit) {
+        // arena full: publish an invalid token so waiters terminate
+        __hip_atomic_exchange(&u.hash[slot], want_key | (0xFFFFFFFFull << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
       }
-      ent = old;  // somebody else took it: fall through and inspect
+      u.tok_state[idx] = state;
+      u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
+      u.tmp_slot[idx - front_b] = static_cast<int32_t>(slot);
+      if (has_eps) {
+        u.tmp_epslist[__hip_atomic_fetch_add(eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+        // kQueue (emitting pass): the list of these tokens IS the first work list of the
+        // nonemitting closure — every one of them gets a finite cost from its creator —
+        // so it is marked queued here and the emitting pass needs no returning atomics
+        if (kQueue) u.tmp_dirty[idx - front_b] = 1;
+      }
+      __hip_atomic_exchange(&u.hash[slot], want_key | (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return idx;
     }
     if ((ent & 0xFFFFFFFFull) == want_key) {
       const uint32_t hi = static_cast<uint32_t>(ent >> 32);
@@ -458,7 +486,7 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
 // (link_src = token, link_dst = arc index) for the link-parallel second half.
 // Returns the new end of the link arena, or -1 on overflow (sh->status set).
 template <bool kEps>
-__device__ int ExpandTokens(const Utt &u, GP(const int32_t) off, int b, int e, float cutoff, int lrun,
+__device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
                             int frame_cap, long long *arcs, Blk &sh) {
   const int lrun0 = lrun;
   for (int base = b; base < e; base += NT * PU) {
@@ -585,16 +613,16 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   const int fb = sh->front_b;
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff, driven by work lists.
-  // List 0 (length wl_n[0]) holds the tokens with epsilon arcs that the emitting
-  // pass created; processing a token may lower the cost of others, which are
-  // queued (once: tmp_dirty) for the next round.
+  // List 0 = the first wl_n[0] entries of tmp_epslist: the tokens with epsilon arcs
+  // that the emitting pass created (marked queued at creation); processing a token may
+  // lower the cost of others, which are queued (once: tmp_dirty) for the next round.
   long long my_arcs = 0;
   for (int r = 0;; r++) {
     const int n = sh->wl_n[r % 3];
     if (threadIdx.x == 0) sh->wl_n[(r + 2) % 3] = 0;  // last read one barrier ago, next pushed to one barrier ahead
     if (n == 0) break;
-    GP(const int32_t) cur = (r & 1) ? u.tmp_work1 : u.tmp_work0;
-    GP(int32_t) nxt = (r & 1) ? u.tmp_work0 : u.tmp_work1;
+    const Arr<const int32_t> cur = r == 0 ? u.tmp_epslist : ((r & 1) ? u.tmp_work1 : u.tmp_work0);
+    const Arr<int32_t> nxt = (r & 1) ? u.tmp_work0 : u.tmp_work1;
     auto nxt_n = &sh->wl_n[(r + 1) % 3];
     for (int q = threadIdx.x; q < n; q += NT) {
       const int i = cur[q];
@@ -610,7 +638,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
         if (tot_cost < cutoff) {  // :794
           const bool he = (arc.w & kHasEps) != 0;
-          const int dst = FindOrAdd(u, arc.w & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, fb);
+          const int dst = FindOrAdd<false>(u, arc.w & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, fb);
           if (dst < 0) { sh->status = 1; continue; }
           const uint32_t enc = Enc(tot_cost);
           if (he) {
@@ -714,7 +742,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
                                 float *next_cutoff_out, Blk &sh) {
   const int nb = sh->tok_end;  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }  // pass 2 fills list 0 (barriers in between)
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
   // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
   // against the last readers of the previous row and the first readers of this one)
   for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
@@ -807,24 +835,18 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     if (!(tot_cost > next_cutoff)) {  // :731 "if (tot_cost > next_cutoff) continue"
       const int32_t ns = u.link_dst[l];
       const bool he = (ns & kHasEps) != 0;
-      dst = FindOrAdd(u, ns & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, nb);
-      if (dst < 0) {
-        sh->status = 1;
-      } else if (he) {
-        // queue the token for the nonemitting closure the first time its cost drops
-        const uint32_t enc = Enc(tot_cost);
-        const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (enc < old && __hip_atomic_exchange(&u.tmp_dirty[dst - nb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-          u.tmp_work0[__hip_atomic_fetch_add(&sh->wl_n[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = dst;
-      } else {
-        (void)__hip_atomic_fetch_min(&u.tok_cost[dst], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      dst = FindOrAdd<true>(u, ns & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, nb);
+      if (dst < 0) sh->status = 1;
+      else (void)__hip_atomic_fetch_min(&u.tok_cost[dst], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     u.link_dst[l] = dst;
   }
   KhSync();
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) sh->arcs_expanded += tot_arcs;
+  if (threadIdx.x == 0) {
+    sh->arcs_expanded += tot_arcs;
+    sh->wl_n[0] = sh->eps_n;  // the closure's first work list = the new tokens with epsilon arcs
+  }
   KhSync();
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
@@ -841,7 +863,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 // lattice beam are excised (:315); kAccum: the others are min-ed into
 // acc[src - b].  Returns 2 if this lane excised a link.
 template <bool kEps, bool kAccum, bool kExcise, bool kList = false>
-__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, GP(uint32_t) acc,
+__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, Arr<uint32_t> acc,
                                              __attribute__((address_space(3))) int *list_n = nullptr) {
   int flags = 0;
   for (int base = lo + threadIdx.x; base < hi; base += NT * PU) {
@@ -1174,16 +1196,11 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   KhSync();
   if (threadIdx.x == 0) {
     sh->eps_n = 0;
-    const int idx = FindOrAdd(u, p.start, p.start_has_eps != 0, &sh->tok_end, &sh->eps_n, u.tok_cap, 0);
+    const int idx = FindOrAdd<true>(u, p.start, p.start_has_eps != 0, &sh->tok_end, &sh->eps_n, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
     u.frame_b[0] = idx;
-    sh->wl_n[0] = 0;
+    sh->wl_n[0] = sh->eps_n;  // 1 if the start state has epsilon arcs: the closure's first work list
     sh->wl_n[1] = 0;
-    if (p.start_has_eps) {
-      u.tmp_dirty[0] = 1;
-      u.tmp_work0[0] = idx;
-      sh->wl_n[0] = 1;
-    }
   }
   KhSync();
   const bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
@@ -1900,9 +1917,9 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
     for (int i = 0; i < n_slots; i++) {
       Utt &u = d->h_slots[i];
-      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
-      KH_HIP(hipMemsetAsync((void *)(unsigned long long *)u.hash, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
-      KH_HIP(hipMemsetAsync((void *)(int32_t *)u.tmp_dirty, 0, sizeof(int32_t) * u.tok_frame_cap, st));
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost.p, static_cast<size_t>(u.tok_cap), kEncInf);
+      KH_HIP(hipMemsetAsync((void *)(unsigned long long *)u.hash.p, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
+      KH_HIP(hipMemsetAsync((void *)(int32_t *)u.tmp_dirty.p, 0, sizeof(int32_t) * u.tok_frame_cap, st));
     }
     PoolFree(d->d_slots);
     d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
@@ -1911,7 +1928,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     // slots were left with dirty token costs by the previous call: refill
     for (int i = 0; i < n_slots; i++) {
       Utt &u = d->h_slots[i];
-      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost, static_cast<size_t>(u.tok_cap), kEncInf);
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost.p, static_cast<size_t>(u.tok_cap), kEncInf);
     }
   }
   *n_slots_out = n_slots;
@@ -2231,7 +2248,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     KH_HIP(hipMemsetAsync(d->d_used, 0, sizeof(unsigned long long) * 4, st));
     if (round > 0)
       for (int i = 0; i < n_slots; i++)
-        hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)d->h_slots[i].tok_cost,
+        hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)d->h_slots[i].tok_cost.p,
                            static_cast<size_t>(d->h_slots[i].tok_cap), kEncInf);
     const int grid = std::min(np, n_slots);
     KH_HIP(hipEventRecord(d->ev0, st));
