@@ -225,6 +225,18 @@ __device__ __forceinline__ void KhSync() {
 #endif
 }
 
+// Workgroup-uniform values that reach a lane through LDS or a vector load sit in a
+// VGPR (the compiler cannot know they are uniform) and make every loop bound and branch
+// that depends on them a vector one.  Uni() moves such a value to an SGPR
+// (v_readfirstlane): only for values that are uniform BY CONSTRUCTION.
+__device__ __forceinline__ int Uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t Uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ __forceinline__ float Uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ unsigned long long Uni(unsigned long long v) {
+  return (static_cast<unsigned long long>(Uni(static_cast<uint32_t>(v >> 32))) << 32) | Uni(static_cast<uint32_t>(v));
+}
+__device__ __forceinline__ long long Uni(long long v) { return static_cast<long long>(Uni(static_cast<unsigned long long>(v))); }
+
 // ---------------------------------------------------------------- block helpers
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
@@ -238,7 +250,7 @@ struct Shared {
   int flag;
   int bcast_i[4];
   float bcast_f[8];
-  unsigned int hist[256];
+  unsigned int hist[1 << 11];       // RadixSelect digit histogram (kRadixBits)
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
   int front_b;  // first token of the frame under construction (frontier)
@@ -292,8 +304,8 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
     before += i < w ? t : 0;
     all += t;
   }
-  *total = all;
-  return before + inc - v;
+  *total = Uni(all);
+  return Uni(before) + inc - v;  // `before` is uniform over the wave
 }
 
 // Exclusive scan of PU * NT items laid out slice-major (item (k, t) = slice k,
@@ -323,8 +335,8 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[PU], int (&off)[PU],
       before += i < w ? t : 0;
       all += t;
     }
-    off[k] = run + before + inc[k] - v[k];
-    run += all;
+    off[k] = run + Uni(before) + inc[k] - v[k];
+    run += Uni(all);
   }
   *total = run;
 }
@@ -341,7 +353,7 @@ __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, 
   unsigned long long r = sh->wred[buf][0];
 #pragma unroll
   for (int i = 1; i < NW; i++) r = sh->wred[buf][i] < r ? sh->wred[buf][i] : r;
-  return r;
+  return Uni(r);
 }
 
 __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
@@ -352,7 +364,7 @@ __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
   float r = __uint_as_float(static_cast<uint32_t>(sh->wred[buf][0]));
 #pragma unroll
   for (int i = 1; i < NW; i++) r = fminf(r, __uint_as_float(static_cast<uint32_t>(sh->wred[buf][i])));
-  return r;
+  return Uni(r);
 }
 
 __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
@@ -364,7 +376,7 @@ __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
   long long r = 0;
 #pragma unroll
   for (int i = 0; i < NW; i++) r += static_cast<long long>(sh->wred[buf][i]);
-  return r;
+  return Uni(r);
 }
 
 // OR over the workgroup.  Slot k is reset two calls ahead (by thread 0, before the
@@ -375,36 +387,62 @@ __device__ __forceinline__ int BlockOr(int bits, Blk &sh) {
   if (threadIdx.x == 0) sh->orbuf[(k + 2) & 3] = 0;
   if (bits) __hip_atomic_fetch_or(&sh->orbuf[k], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   KhSync();
-  return sh->orbuf[k];
+  return Uni(sh->orbuf[k]);
 }
 
 __device__ __forceinline__ bool BlockAny(bool p, Blk &sh) { return BlockOr(p ? 1 : 0, sh) != 0; }
 
 // Exact k-th smallest (0-based) of the cost images tok_cost[b..e): what
-// std::nth_element yields at position k (GetCutoff :621-626,:633-640).
-__device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k,
+// std::nth_element yields at position k (GetCutoff :621-626,:633-640).  Radix select
+// over the bits in which the smallest and the largest key of the frame differ (the costs
+// of a frame lie within a beam of each other, so their images share the sign, the
+// exponent and the top mantissa bits: typically 18-21 bits remain), 11 bits per pass.
+constexpr int kRadixBits = 11;
+__device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k, uint32_t kmin, uint32_t kmax,
                                 Blk &sh) {
-  uint32_t prefix = 0, mask = 0;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    for (int i = threadIdx.x; i < 256; i += NT) sh->hist[i] = 0;
+  const uint32_t diff = kmin ^ kmax;
+  if (diff == 0) return kmin;
+  int remaining = 32 - __clz(static_cast<int>(diff));  // low bits that vary
+  uint32_t mask = remaining == 32 ? 0u : ~((1u << remaining) - 1u);
+  uint32_t prefix = kmin & mask;
+  int passes = (remaining + kRadixBits - 1) / kRadixBits;
+  constexpr int kPerLane = ((1 << kRadixBits) + NT - 1) / NT;  // bins a lane owns in the scan
+  for (; passes > 0; passes--) {
+    const int w = (remaining + passes - 1) / passes, shift = remaining - w;
+    const uint32_t dmask = (1u << w) - 1u;
+    const int bins = 1 << w;
+    for (int i = threadIdx.x; i < bins; i += NT) sh->hist[i] = 0;
     KhSync();
     for (int i = b + threadIdx.x; i < e; i += NT) {
       const uint32_t key = LoadCostEnc(&keys[i]);
-      if ((key & mask) == prefix) __hip_atomic_fetch_add(&sh->hist[(key >> shift) & 255u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((key & mask) == prefix) __hip_atomic_fetch_add(&sh->hist[(key >> shift) & dmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     KhSync();
-    // the bin that holds rank k: workgroup scan of the 256 counts (lane t owns bin t)
-    const int cnt = threadIdx.x < 256 ? static_cast<int>(sh->hist[threadIdx.x]) : 0;
+    // the bin that holds rank k: workgroup scan of the counts (lane t owns bins [t kPerLane, (t + 1) kPerLane))
+    int cnt[kPerLane], mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPerLane; j++) {
+      const int bin = threadIdx.x * kPerLane + j;
+      cnt[j] = bin < bins ? static_cast<int>(sh->hist[bin]) : 0;
+      mine += cnt[j];
+    }
     int total;
-    const int before = BlockExScan(cnt, &total, sh);
-    if (threadIdx.x < 256 && before <= k && k < before + cnt) {
-      sh->bcast_i[1] = threadIdx.x;
-      sh->bcast_i[2] = k - before;
+    int before = BlockExScan(mine, &total, sh);
+    if (before <= k && k < before + mine) {
+#pragma unroll
+      for (int j = 0; j < kPerLane; j++) {
+        if (before <= k && k < before + cnt[j]) {
+          sh->bcast_i[1] = threadIdx.x * kPerLane + j;
+          sh->bcast_i[2] = k - before;
+        }
+        before += cnt[j];
+      }
     }
     KhSync();
-    prefix |= static_cast<uint32_t>(sh->bcast_i[1]) << shift;
-    mask |= 255u << shift;
-    k = sh->bcast_i[2];
+    prefix |= static_cast<uint32_t>(Uni(sh->bcast_i[1])) << shift;
+    mask |= dmask << shift;
+    k = Uni(sh->bcast_i[2]);
+    remaining = shift;
   }
   return prefix;
 }
@@ -551,11 +589,13 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   c.count = n;
   unsigned long long best = ~0ull;
   int best_i = -1;
+  uint32_t kmax = 0;
   for (int i = b + threadIdx.x; i < e; i += NT) {
     // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
-    const unsigned long long key =
-        (static_cast<unsigned long long>(LoadCostEnc(&u.tok_cost[i])) << 32) | static_cast<uint32_t>(u.tok_state[i]);
+    const uint32_t enc = LoadCostEnc(&u.tok_cost[i]);
+    const unsigned long long key = (static_cast<unsigned long long>(enc) << 32) | static_cast<uint32_t>(u.tok_state[i]);
     if (key < best) { best = key; best_i = i; }
+    kmax = enc > kmax ? enc : kmax;
   }
   const unsigned long long mine = best;
   best = BlockMinU64(best, sh);
@@ -571,7 +611,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   // the lane that holds the winning key (states are unique within a frame) publishes its token
   if (mine == best && best_i >= 0) sh->bcast_i[0] = best_i;
   KhSync();
-  c.best_tok = sh->bcast_i[0];
+  c.best_tok = Uni(sh->bcast_i[0]);
   const float best_weight = c.best_cost;
   if (p.max_active == 0x7fffffff && p.min_active == 0) {
     c.adaptive_beam = p.beam;
@@ -580,7 +620,10 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   }
   const float beam_cutoff = best_weight + p.beam;
   float min_active_cutoff = inf, max_active_cutoff = inf;
-  if (n > p.max_active) max_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.max_active, sh));
+  // largest cost image of the frame (the smallest is the best cost): bounds the bits the selection looks at
+  kmax = ~static_cast<uint32_t>(BlockMinU64(static_cast<unsigned long long>(~kmax), sh));
+  const uint32_t kmin = static_cast<uint32_t>(best >> 32);
+  if (n > p.max_active) max_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.max_active, kmin, kmax, sh));
   if (max_active_cutoff < beam_cutoff) {
     c.adaptive_beam = max_active_cutoff - best_weight + p.beam_delta;
     c.cur_cutoff = max_active_cutoff;
@@ -588,7 +631,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   }
   if (n > p.min_active) {
     if (p.min_active == 0) min_active_cutoff = best_weight;
-    else min_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.min_active, sh));
+    else min_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.min_active, kmin, kmax, sh));
   }
   if (min_active_cutoff > beam_cutoff) {
     c.adaptive_beam = min_active_cutoff - best_weight + p.beam_delta;
@@ -610,7 +653,7 @@ __device__ __forceinline__ float LogLike(const Utt &u, const Params &p, const Bl
 // ([sh->front_b, sh->tok_end)), then generation of the epsilon links with the
 // converged costs.  Returns false on arena overflow.
 __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, float cutoff, Blk &sh) {
-  const int fb = sh->front_b;
+  const int fb = Uni(sh->front_b);
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff, driven by work lists.
   // List 0 = the first wl_n[0] entries of tmp_epslist: the tokens with epsilon arcs
@@ -618,7 +661,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   // lower the cost of others, which are queued (once: tmp_dirty) for the next round.
   long long my_arcs = 0;
   for (int r = 0;; r++) {
-    const int n = sh->wl_n[r % 3];
+    const int n = Uni(sh->wl_n[r % 3]);
     if (threadIdx.x == 0) sh->wl_n[(r + 2) % 3] = 0;  // last read one barrier ago, next pushed to one barrier ahead
     if (n == 0) break;
     const Arr<const int32_t> cur = r == 0 ? u.tmp_epslist : ((r & 1) ? u.tmp_work1 : u.tmp_work0);
@@ -654,17 +697,17 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     }
     if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
     KhSync();
-    if (sh->status != 0) return false;
+    if (Uni(sh->status) != 0) return false;
   }
   KhSync();
   Stamp(u, sh, 3);
   // ---- epsilon links: {(tok, arc): cost[tok] <= cutoff, cost[tok] + w < cutoff}
   // One slot per epsilon arc of every token under the cutoff; the slots whose
   // tot_cost is not under the cutoff stay dead (dst = -1) until the compaction.
-  const int fe = sh->tok_end;
-  const int blk_b = sh->link_end;
+  const int fe = Uni(sh->tok_end);
+  const int blk_b = Uni(sh->link_end);
   long long seeded = 0;
-  const int blk_e = ExpandTokens<true>(u, p.n_off, 0, sh->eps_n, cutoff, blk_b, u.link_frame_cap, &seeded, sh);
+  const int blk_e = ExpandTokens<true>(u, p.n_off, 0, Uni(sh->eps_n), cutoff, blk_b, u.link_frame_cap, &seeded, sh);
   if (blk_e < 0) return false;
   for (int base = blk_b + threadIdx.x; base < blk_e; base += NT * PU) {
     int l[PU], src[PU], ai[PU];
@@ -740,7 +783,7 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
 // through *next_cutoff_out; false on overflow.
 __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b, int e,
                                 float *next_cutoff_out, Blk &sh) {
-  const int nb = sh->tok_end;  // first token of frame + 1
+  const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
   // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
@@ -773,7 +816,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // cur_cutoff (token sweep + scan), then a link sweep that fetches the arcs and
   // the acoustic scores, writes the links with their tot_cost and reduces
   // min(tot_cost + adaptive_beam).
-  const int link_frame_b = sh->link_end;
+  const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
   const int link_frame_e = ExpandTokens<false>(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh);
   if (link_frame_e < 0) return false;
@@ -850,7 +893,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   KhSync();
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
-  return sh->status == 0;
+  return Uni(sh->status) == 0;
 }
 
 // ---------------------------------------------------------------- pruning
@@ -990,7 +1033,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
         settle(i, a0, a1, st, old, old, changed);
       }
     } else {
-      const int n_list = sh->wl_n[0];
+      const int n_list = Uni(sh->wl_n[0]);
       for (int q = threadIdx.x; q < n_list; q += NT) {
         const int i = u.tmp_work0[q];
         const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
@@ -1004,14 +1047,14 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     if (!BlockAny(changed, sh)) break;
   }
   if (ne > nb) {  // leave tmp_dirty all zero
-    const int n_list = sh->wl_n[0];
+    const int n_list = Uni(sh->wl_n[0]);
     for (int q = threadIdx.x; q < n_list; q += NT) u.tmp_dirty[u.tmp_work0[q] - b] = 0;
   }
   if (n_moved != 0) __hip_atomic_fetch_add(&sh->pr_moved, n_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   KH_PRUNE_STAMP(22);
   if (ne > nb) flags |= PruneLinkPass<true, false, true>(u, nb, ne, b, lb, u.tmp_acc1);
   int all = BlockOr(flags, sh);
-  if (sh->pr_moved > 0) all |= 1;
+  if (Uni(sh->pr_moved) > 0) all |= 1;
   KH_PRUNE_STAMP(23);
 #undef KH_PRUNE_STAMP
   *extra_costs_changed = (all & 1) != 0;
@@ -1038,8 +1081,8 @@ __device__ __forceinline__ void StoreFlag(P p, uint8_t v) {
 __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Blk &sh) {
   if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[12] += 1;
   for (int f = cur - 1; f >= 0; f--) {
-    const bool ml = LoadFlag(&u.must_links[f]);
-    const bool mt = (f + 1 < cur) && LoadFlag(&u.must_toks[f + 1]);
+    const bool ml = Uni(static_cast<int>(LoadFlag(&u.must_links[f]))) != 0;
+    const bool mt = (f + 1 < cur) && Uni(static_cast<int>(LoadFlag(&u.must_toks[f + 1]))) != 0;
     // Flags of older frames can only be raised by the frame above them in this
     // pass (all frames visited by earlier passes were cleared), so once a frame
     // has nothing to do the reference's remaining iterations are no-ops.
@@ -1048,8 +1091,8 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     if (u.phase_cycles != nullptr && threadIdx.x == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (ml) {
       bool ec, lp;
-      PruneForwardLinks(u, p, u.frame_b[f], u.frame_e[f], u.femit_b[f], u.femit_e[f], u.feps_b[f], u.feps_e[f],
-                        delta, false, false, 0.f, mt ? u.frame_b[f + 1] : 0, mt ? u.frame_e[f + 1] : 0, &ec, &lp, sh);
+      PruneForwardLinks(u, p, Uni(u.frame_b[f]), Uni(u.frame_e[f]), Uni(u.femit_b[f]), Uni(u.femit_e[f]), Uni(u.feps_b[f]), Uni(u.feps_e[f]),
+                        delta, false, false, 0.f, mt ? Uni(u.frame_b[f + 1]) : 0, mt ? Uni(u.frame_e[f + 1]) : 0, &ec, &lp, sh);
       if (threadIdx.x == 0) {
         if (ec && f > 0) StoreFlag(&u.must_links[f - 1], 1);
         if (lp) StoreFlag(&u.must_toks[f], 1);
@@ -1057,12 +1100,12 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
         if (mt) StoreFlag(&u.must_toks[f + 1], 0);
       }
     } else {  // mt
-      PruneTokensForFrame(u, u.frame_b[f + 1], u.frame_e[f + 1]);
+      PruneTokensForFrame(u, Uni(u.frame_b[f + 1]), Uni(u.frame_e[f + 1]));
       if (threadIdx.x == 0) StoreFlag(&u.must_toks[f + 1], 0);
     }
     KhSync();
     if (u.phase_cycles != nullptr && threadIdx.x == 0) {
-      const int thick = (u.frame_e[f] - u.frame_b[f] > NT) ? 1 : 0;
+      const int thick = (Uni(u.frame_e[f]) - Uni(u.frame_b[f]) > NT) ? 1 : 0;
       sh->phase[16 + thick] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - t0;
       sh->phase[18 + thick] += 1;
     }
@@ -1078,9 +1121,9 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
 // old position after it, so one barrier per chunk orders the slide.
 __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   if (w_lo < 0) w_lo = 0;
-  const int win_b = u.frame_b[w_lo];
-  const int old_tok_end = sh->tok_end;
-  const int old_link_b = u.feps_b[w_lo];
+  const int win_b = Uni(u.frame_b[w_lo]);
+  const int old_tok_end = Uni(sh->tok_end);
+  const int old_link_b = Uni(u.feps_b[w_lo]);
   if (old_tok_end - win_b > u.window_cap) {
     if (threadIdx.x == 0) sh->status = 4;
     KhSync();
@@ -1090,7 +1133,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   // (a) tokens
   int tend = win_b;  // running end of the compacted tokens (uniform)
   for (int f = w_lo; f <= cur; f++) {
-    const int b = u.frame_b[f], e = u.frame_e[f];
+    const int b = Uni(u.frame_b[f]), e = Uni(u.frame_e[f]);
     const int new_b = tend;
     for (int base = b; base < e; base += NT) {
       const int i = base + threadIdx.x;
@@ -1119,7 +1162,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   for (int i = tend + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
   // (b) emitting links of frame w_lo - 1 point into the window: rewrite in place
   if (w_lo > 0) {
-    for (int l = u.femit_b[w_lo - 1] + threadIdx.x; l < u.femit_e[w_lo - 1]; l += NT) {
+    for (int l = Uni(u.femit_b[w_lo - 1]) + threadIdx.x; l < Uni(u.femit_e[w_lo - 1]); l += NT) {
       const int dst = u.link_dst[l];
       if (dst >= win_b) u.link_dst[l] = u.tmp_remap[dst - win_b];
     }
@@ -1129,8 +1172,8 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   for (int f = w_lo; f <= cur; f++) {
     for (int kind = 0; kind < 2; kind++) {  // 0: epsilon, 1: emitting
       if (kind == 1 && f == cur) continue;  // not created yet
-      const int blk_b = kind ? u.femit_b[f] : u.feps_b[f];
-      const int blk_e = kind ? u.femit_e[f] : u.feps_e[f];
+      const int blk_b = kind ? Uni(u.femit_b[f]) : Uni(u.feps_b[f]);
+      const int blk_e = kind ? Uni(u.femit_e[f]) : Uni(u.feps_e[f]);
       const int new_blk_b = lend;
       for (int base = blk_b; base < blk_e; base += NT) {
         const int l = base + threadIdx.x;
@@ -1161,7 +1204,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   if (threadIdx.x == 0) {
     sh->tok_end = tend;
     sh->link_end = lend;
-    sh->front_b = u.frame_b[cur];
+    sh->front_b = Uni(u.frame_b[cur]);
   }
   KhSync();
   return true;
@@ -1206,7 +1249,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   const bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
   run->t = 0;
   run->fb = 0;  // token range of the frontier frame
-  run->fe = sh->tok_end;
+  run->fe = Uni(sh->tok_end);
   if (threadIdx.x == 0) {
     u.frame_e[0] = run->fe;
     sh->tokens_created += run->fe - run->fb;
@@ -1230,16 +1273,16 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       ok = Compact(u, t - win_frames, t, sh);
       Stamp(u, sh, 7);
       if (!ok) break;
-      fb = u.frame_b[t];
-      fe = u.frame_e[t];
+      fb = Uni(u.frame_b[t]);
+      fe = Uni(u.frame_e[t]);
     }
     float next_cutoff;
     ok = ProcessEmitting(u, p, t, fb, fe, &next_cutoff, sh);
     if (!ok) break;
     ok = ProcessNonemitting(u, p, t + 1, next_cutoff, sh);
     if (!ok) break;
-    fb = sh->front_b;
-    fe = sh->tok_end;
+    fb = Uni(sh->front_b);
+    fe = Uni(sh->tok_end);
     if (threadIdx.x == 0) {
       u.frame_b[t + 1] = fb;
       u.frame_e[t + 1] = fe;
@@ -1286,12 +1329,12 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
     const float final_best_cost = have_final ? best_with_final : best_cost;
     st.final_best_cost = final_best_cost;
     bool b1, b2;
-    PruneForwardLinks(u, p, fb, fe, 0, 0, u.feps_b[last], u.feps_e[last], 0.0f, true, have_final, final_best_cost,
+    PruneForwardLinks(u, p, fb, fe, 0, 0, Uni(u.feps_b[last]), Uni(u.feps_e[last]), 0.0f, true, have_final, final_best_cost,
                       0, 0, &b1, &b2, sh);
     for (int f = last - 1; f >= 0; f--)
-      PruneForwardLinks(u, p, u.frame_b[f], u.frame_e[f], u.femit_b[f], u.femit_e[f], u.feps_b[f], u.feps_e[f],
-                        0.0f, false, false, 0.f, u.frame_b[f + 1], u.frame_e[f + 1], &b1, &b2, sh);
-    PruneTokensForFrame(u, u.frame_b[0], u.frame_e[0]);
+      PruneForwardLinks(u, p, Uni(u.frame_b[f]), Uni(u.frame_e[f]), Uni(u.femit_b[f]), Uni(u.femit_e[f]), Uni(u.feps_b[f]), Uni(u.feps_e[f]),
+                        0.0f, false, false, 0.f, Uni(u.frame_b[f + 1]), Uni(u.frame_e[f + 1]), &b1, &b2, sh);
+    PruneTokensForFrame(u, Uni(u.frame_b[0]), Uni(u.frame_e[0]));
     // final compaction of the window so the export below copies little
     ok = Compact(u, last - WindowFrames(p), last, sh);
     Stamp(u, sh, 8);
@@ -1305,7 +1348,7 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
   st.num_links = sh->link_end;
   *st_out = st;
   KhSync();
-  return ok && sh->status == 0;
+  return ok && Uni(sh->status) == 0;
 }
 
 // One utterance: InitDecoding, Decode, FinalizeDecoding.
@@ -1349,7 +1392,7 @@ __device__ __forceinline__ int FrameOfToken(const Utt &u, int i, int T) {
 
 // GetRawLattice :109-191 device half: survivors -> pool (frame, state) / (src, dst, labels, costs).
 __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &sh) {
-  const int tok_end = sh->tok_end, link_end = sh->link_end, T = u.T;
+  const int tok_end = Uni(sh->tok_end), link_end = Uni(sh->link_end), T = u.T;
   // pass A: alive tokens -> dense indices (tmp_remap)
   int n_tok = 0;
   for (int base = 0; base < tok_end; base += NT) {
@@ -1460,7 +1503,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
   for (;;) {
     if (threadIdx.x == 0) sh->bcast_i[3] = static_cast<int>(__hip_atomic_fetch_add(&pool.used[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     KhSync();
-    const int ui = sh->bcast_i[3];
+    const int ui = Uni(sh->bcast_i[3]);
     KhSync();
     if (ui >= n_utts) break;
     u.ll = in[ui].ll;
