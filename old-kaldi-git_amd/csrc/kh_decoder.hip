@@ -65,10 +65,11 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 24;            // diagnostic counters per slot
+constexpr int NPH = 28;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x3fffffff;
+constexpr int KC = 4;              // chunks of NT slots the compaction moves per barrier when the slide has opened a gap
 constexpr int PU = 1;              // token / link slots a lane keeps in flight per round of a sweep (measured: 1 beats 2, 4, 8 - the sweeps are bound by the CU's address pipeline, not by latency, and more slots spill)
 constexpr uint32_t kEncInf = 0xFF800000u;  // Enc(+inf)
 constexpr unsigned long long kEmpty = 0ull;
@@ -240,7 +241,7 @@ __device__ __forceinline__ long long Uni(long long v) { return static_cast<long 
 // ---------------------------------------------------------------- block helpers
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
-  int wsumk[2][PU][NW];            // BlockExScanK, double buffered
+  int wsumk[2][PU > KC ? PU : KC][NW];  // BlockExScanK, double buffered
   int wl_n[3];                     // nonemitting work-list lengths, rotating ([0] also: prune's epsilon-token list)
   int pr_moved;                    // PruneForwardLinks: tokens whose extra_cost moved by more than delta
   int eps_n;                       // length of tmp_epslist
@@ -308,14 +309,15 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   return Uni(before) + inc - v;  // `before` is uniform over the wave
 }
 
-// Exclusive scan of PU * NT items laid out slice-major (item (k, t) = slice k,
+// Exclusive scan of K * NT items laid out slice-major (item (k, t) = slice k,
 // thread t): one barrier for all slices.
-__device__ __forceinline__ void BlockExScanK(const int (&v)[PU], int (&off)[PU], int *total, Blk &sh) {
+template <int K>
+__device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], int *total, Blk &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int buf = (sh.k_scan++) & 1;
-  int inc[PU];
+  int inc[K];
 #pragma unroll
-  for (int k = 0; k < PU; k++) {
+  for (int k = 0; k < K; k++) {
     inc[k] = v[k];
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -327,7 +329,7 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[PU], int (&off)[PU],
   KhSync();
   int run = 0;
 #pragma unroll
-  for (int k = 0; k < PU; k++) {
+  for (int k = 0; k < K; k++) {
     int before = 0, all = 0;
 #pragma unroll
     for (int i = 0; i < NW; i++) {
@@ -553,7 +555,7 @@ __device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, 
       }
     }
     int loff[PU], total;
-    BlockExScanK(cnt, loff, &total, sh);
+    BlockExScanK<PU>(cnt, loff, &total, sh);
     if (lrun + total > u.link_cap || lrun + total - lrun0 > frame_cap) {
       if (threadIdx.x == 0) sh->status = (lrun + total > u.link_cap) ? 2 : 3;
       KhSync();
@@ -936,9 +938,14 @@ __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       if (base + k * NT >= hi || dst[k] < 0) continue;
-      if (kList &&  // list (once) the tokens that own live epsilon links
-          __hip_atomic_exchange(&u.tmp_dirty[src[k] - b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-        u.tmp_work0[__hip_atomic_fetch_add(list_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = src[k];
+      if (kList) {
+        // list (once) the tokens that own live epsilon links; mark the tokens such links lead to
+        // (bit 1: a change of THEIR extra_cost is what makes another sweep necessary)
+        if ((__hip_atomic_fetch_or(&u.tmp_dirty[src[k] - b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) == 0)
+          u.tmp_work0[__hip_atomic_fetch_add(list_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = src[k];
+        (void)__hip_atomic_fetch_or(&u.tmp_dirty[dst[k] - b], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (kEps && kExcise) u.tmp_dirty[dst[k] - b] = 0;  // last pass over the epsilon links: leave tmp_dirty all zero
       // :309-311; for an epsilon link the parenthesis was evaluated when it was created
       float lec = kEps ? ex[k] + a[k] : ex[k] + ((Dec(cs[k]) + a[k] + g[k]) - Dec(cd[k]));
       if (lec > lb) {  // :315 excise
@@ -999,10 +1006,16 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   // P1 (emitting links): a link to the NEXT frame sees final extra_costs there, so
   // its link_extra_cost - hence whether it is excised - is final at first sight.
   int flags = PruneLinkPass<false, true, true>(u, mb, me, b, lb, u.tmp_acc0);
-  // Epsilon links stay inside the frame: Jacobi iteration to the exact fixed point
-  // (unique: the epsilon links of a frame form a DAG), then excise.  The first sweep
-  // visits every token and records its entry extra_cost; the later ones only the
-  // tokens that own live epsilon links (listed by the first epsilon pass).
+  KhSync();
+  KH_PRUNE_STAMP(21);
+  // Epsilon links stay inside the frame (a DAG): the exact fixed point of
+  //   extra[t] = min(emitting part, min over t's epsilon links of extra[dst] + const)
+  // is unique, so the order of evaluation is free.  T0 gives every token its emitting part
+  // (final for the tokens without epsilon links); then each round = one sweep over the
+  // epsilon links with the current extra_costs + one over the tokens that own them (listed
+  // by the first sweep).  A further round is needed only if a token that some epsilon link
+  // LEADS TO has changed (marked by the first sweep): rounds = depth of the DAG, no
+  // verification round and no round on the stale extra_costs of the previous visit.
   int n_moved = 0;
   auto settle = [&](int i, uint32_t a0, uint32_t a1, int st, float old, float entry, bool &changed) {
     if (st < 0) return;
@@ -1016,37 +1029,37 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     n_moved += (fabsf(v - entry) > delta ? 1 : 0) - (fabsf(old - entry) > delta ? 1 : 0);
     if (a1 != kEncInf) u.tmp_acc1[i - b] = kEncInf;
   };
-  for (int iter = 0;; iter++) {
-    if (ne > nb) {
+  for (int i = b + threadIdx.x; i < e; i += NT) {  // T0 (tmp_acc1 is +inf for every token here)
+    const uint32_t a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
+    const int st = u.tok_state[i];
+    const float old = LoadExtra(&u.tok_extra[i]);
+    u.tmp_f0[i - b] = old;
+    bool changed = false;
+    settle(i, a0, kEncInf, st, old, old, changed);
+  }
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
+  if (ne > nb) {
+    for (int iter = 0;; iter++) {
+      KhSync();  // the extra_costs of the previous token sweep are in place
       if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, u.tmp_acc1, &sh->wl_n[0]);
       else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, u.tmp_acc1);
-    }
-    KhSync();
-    if (iter == 0) KH_PRUNE_STAMP(21);
-    bool changed = false;
-    if (iter == 0) {
-      for (int i = b + threadIdx.x; i < e; i += NT) {
-        const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
-        const int st = u.tok_state[i];
-        const float old = LoadExtra(&u.tok_extra[i]);
-        u.tmp_f0[i - b] = old;
-        settle(i, a0, a1, st, old, old, changed);
-      }
-    } else {
+      KhSync();
+      bool again = false;
       const int n_list = Uni(sh->wl_n[0]);
       for (int q = threadIdx.x; q < n_list; q += NT) {
         const int i = u.tmp_work0[q];
         const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
         const int st = u.tok_state[i];
         const float old = LoadExtra(&u.tok_extra[i]), entry = u.tmp_f0[i - b];
+        bool changed = false;
         settle(i, a0, a1, st, old, entry, changed);
+        // (L2 read: the marks were set by atomics, which do not refresh this CU's L1)
+        if (changed && (__hip_atomic_load(&u.tmp_dirty[i - b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0) again = true;
       }
+      if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
+      if (!BlockAny(again, sh)) break;
     }
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
-    if (ne == nb) break;  // no epsilon links: one sweep is exact
-    if (!BlockAny(changed, sh)) break;
-  }
-  if (ne > nb) {  // leave tmp_dirty all zero
+    // bit 0 of the listed owners (bit 1 of the destinations is cleared by the excise pass below)
     const int n_list = Uni(sh->wl_n[0]);
     for (int q = threadIdx.x; q < n_list; q += NT) u.tmp_dirty[u.tmp_work0[q] - b] = 0;
   }
@@ -1130,12 +1143,49 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
     return false;
   }
   KhSync();  // every thread has read the old ends
+  long long tc = 0;
+  const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0;
+  if (prof) tc = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#define KH_COMPACT_STAMP(k) do { if (prof) { const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tc; tc = now_; } } while (0)
   // (a) tokens
   int tend = win_b;  // running end of the compacted tokens (uniform)
   for (int f = w_lo; f <= cur; f++) {
     const int b = Uni(u.frame_b[f]), e = Uni(u.frame_e[f]);
     const int new_b = tend;
-    for (int base = b; base < e; base += NT) {
+    // Up to KC chunks per barrier: only the liveness of the slots is read before the scan, the
+    // survivors' fields after it.  That is safe when none of the group's destinations
+    // [tend, tend + survivors) reaches into the group itself, which a group of at most
+    // (gap / NT) chunks guarantees (gap = base - tend, opened by the slots already dropped).
+    for (int base = b; base < e;) {
+      const int kk = min(KC, (base - tend) / NT);
+      if (kk >= 2) {
+        int st[KC], alive[KC], off[KC];
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+          const int i = base + k * NT + threadIdx.x;
+          st[k] = (k < kk && i < e) ? u.tok_state[i] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < KC; k++) alive[k] = st[k] >= 0 ? 1 : 0;
+        int total;
+        BlockExScanK<KC>(alive, off, &total, sh);
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+          const int i = base + k * NT + threadIdx.x;
+          if (k >= kk || i >= e) continue;
+          int ni = -1;
+          if (alive[k]) {
+            ni = tend + off[k];
+            const uint32_t co = LoadCostEnc(&u.tok_cost[i]);
+            const float ex = LoadExtra(&u.tok_extra[i]);
+            u.tok_state[ni] = st[k]; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
+          }
+          u.tmp_remap[i - win_b] = ni;
+        }
+        tend += total;
+        base += kk * NT;
+        continue;
+      }
       const int i = base + threadIdx.x;
       int st = -1;
       uint32_t co = kEncInf;
@@ -1153,11 +1203,13 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
         u.tmp_remap[i - win_b] = ni;
       }
       tend += total;
+      base += NT;
     }
-    KhSync();  // every lane has read the old range (an empty frame has no barrier above)
+    if (b == e) KhSync();  // every lane has read the old range: a non-empty frame passed a scan barrier since, an empty one has none
     if (threadIdx.x == 0) { u.frame_b[f] = new_b; u.frame_e[f] = tend; }
   }
   KhSync();
+  KH_COMPACT_STAMP(24);
   // arena invariant: free slots hold +inf
   for (int i = tend + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
   // (b) emitting links of frame w_lo - 1 point into the window: rewrite in place
@@ -1167,6 +1219,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
       if (dst >= win_b) u.link_dst[l] = u.tmp_remap[dst - win_b];
     }
   }
+  KH_COMPACT_STAMP(25);
   // (c) links, block by block in arena order: eps(f), emit(f)
   int lend = old_link_b;  // running end of the compacted links (uniform)
   for (int f = w_lo; f <= cur; f++) {
@@ -1175,7 +1228,33 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
       const int blk_b = kind ? Uni(u.femit_b[f]) : Uni(u.feps_b[f]);
       const int blk_e = kind ? Uni(u.femit_e[f]) : Uni(u.feps_e[f]);
       const int new_blk_b = lend;
-      for (int base = blk_b; base < blk_e; base += NT) {
+      for (int base = blk_b; base < blk_e;) {
+        const int kk = min(KC, (base - lend) / NT);  // see the tokens above
+        if (kk >= 2) {
+          int dst[KC], alive[KC], off[KC];
+#pragma unroll
+          for (int k = 0; k < KC; k++) {
+            const int l = base + k * NT + threadIdx.x;
+            dst[k] = (k < kk && l < blk_e) ? u.link_dst[l] : -1;
+          }
+#pragma unroll
+          for (int k = 0; k < KC; k++) alive[k] = dst[k] >= 0 ? 1 : 0;
+          int total;
+          BlockExScanK<KC>(alive, off, &total, sh);
+#pragma unroll
+          for (int k = 0; k < KC; k++) {
+            if (!alive[k]) continue;
+            const int l = base + k * NT + threadIdx.x, d = lend + off[k];
+            const int src = u.link_src[l], il = u.link_il[l], ol = u.link_ol[l];
+            const float g = u.link_g[l], a = u.link_a[l];
+            u.link_dst[d] = dst[k] >= win_b ? u.tmp_remap[dst[k] - win_b] : dst[k];
+            u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
+            u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
+          }
+          lend += total;
+          base += kk * NT;
+          continue;
+        }
         const int l = base + threadIdx.x;
         int dst = -1, src = 0, il = 0, ol = 0;
         float g = 0.f, a = 0.f;
@@ -1193,8 +1272,9 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
           u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
         }
         lend += total;
+        base += NT;
       }
-      KhSync();  // every lane has read the old range (an empty block has no barrier above)
+      if (blk_b == blk_e) KhSync();  // as for the frames above
       if (threadIdx.x == 0) {
         if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = lend; }
         else { u.feps_b[f] = new_blk_b; u.feps_e[f] = lend; }
@@ -1207,6 +1287,8 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
     sh->front_b = Uni(u.frame_b[cur]);
   }
   KhSync();
+  KH_COMPACT_STAMP(26);
+#undef KH_COMPACT_STAMP
   return true;
 }
 
@@ -2354,9 +2436,11 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
               tot[18], tot[6] ? 100.0 * tot[16] / tot[6] : 0.0, tot[18] ? double(tot[16]) / tot[18] : 0.0,
               tot[19], tot[6] ? 100.0 * tot[17] / tot[6] : 0.0, tot[19] ? double(tot[17]) / tot[19] : 0.0);
       fprintf(stderr, "[kh_decoder profile] PruneForwardLinks on frames > %d tokens, share of prune cycles: token init %.1f%%, "
-              "emitting links + first epsilon sweep %.1f%%, token sweeps + later epsilon sweeps %.1f%%, excise + flags %.1f%%\n",
+              "emitting links %.1f%%, token + epsilon sweeps %.1f%%, excise + flags %.1f%%\n",
               NT, tot[6] ? 100.0 * tot[20] / tot[6] : 0.0, tot[6] ? 100.0 * tot[21] / tot[6] : 0.0,
               tot[6] ? 100.0 * tot[22] / tot[6] : 0.0, tot[6] ? 100.0 * tot[23] / tot[6] : 0.0);
+      fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
+              tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);
     }
     std::vector<int> next;
     need_tok = need_link = 0;
