@@ -69,6 +69,7 @@ constexpr int NPH = 28;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x3fffffff;
+constexpr int EU = 2;              // chunks of NT tokens ExpandTokens scans per barrier (2: -1 %; 4 spills)
 constexpr int KC = 4;              // chunks of NT slots the compaction moves per barrier when the slide has opened a gap
 constexpr int PU = 1;              // token / link slots a lane keeps in flight per round of a sweep (measured: 1 beats 2, 4, 8 - the sweeps are bound by the CU's address pipeline, not by latency, and more slots spill)
 constexpr uint32_t kEncInf = 0xFF800000u;  // Enc(+inf)
@@ -241,7 +242,7 @@ __device__ __forceinline__ long long Uni(long long v) { return static_cast<long 
 // ---------------------------------------------------------------- block helpers
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
-  int wsumk[2][PU > KC ? PU : KC][NW];  // BlockExScanK, double buffered
+  int wsumk[2][(PU > KC ? PU : KC) > EU ? (PU > KC ? PU : KC) : EU][NW];  // BlockExScanK, double buffered
   int wl_n[3];                     // nonemitting work-list lengths, rotating ([0] also: prune's epsilon-token list)
   int pr_moved;                    // PruneForwardLinks: tokens whose extra_cost moved by more than delta
   int eps_n;                       // length of tmp_epslist
@@ -529,12 +530,12 @@ template <bool kEps>
 __device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
                             int frame_cap, long long *arcs, Blk &sh) {
   const int lrun0 = lrun;
-  for (int base = b; base < e; base += NT * PU) {
-    int i[PU], st[PU];
-    uint32_t co[PU];
-    bool in_range[PU];
+  for (int base = b; base < e; base += NT * EU) {
+    int i[EU], st[EU];
+    uint32_t co[EU];
+    bool in_range[EU];
 #pragma unroll
-    for (int k = 0; k < PU; k++) {
+    for (int k = 0; k < EU; k++) {
       i[k] = base + k * NT + threadIdx.x;
       in_range[k] = i[k] < e;
       int ic = min(i[k], e - 1);
@@ -543,9 +544,9 @@ __device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, 
       st[k] = u.tok_state[ic];
       KH_BOUND(1, st[k], 0, 0x7ffffff0);
     }
-    int ab[PU], cnt[PU];
+    int ab[EU], cnt[EU];
 #pragma unroll
-    for (int k = 0; k < PU; k++) {
+    for (int k = 0; k < EU; k++) {
       const bool need = in_range[k] && Dec(co[k]) <= cutoff;
       ab[k] = 0;
       cnt[k] = 0;
@@ -554,15 +555,15 @@ __device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, 
         cnt[k] = off[st[k] + 1] - ab[k];
       }
     }
-    int loff[PU], total;
-    BlockExScanK<PU>(cnt, loff, &total, sh);
+    int loff[EU], total;
+    BlockExScanK<EU>(cnt, loff, &total, sh);
     if (lrun + total > u.link_cap || lrun + total - lrun0 > frame_cap) {
       if (threadIdx.x == 0) sh->status = (lrun + total > u.link_cap) ? 2 : 3;
       KhSync();
       return -1;
     }
 #pragma unroll
-    for (int k = 0; k < PU; k++) {
+    for (int k = 0; k < EU; k++) {
       if (!in_range[k]) continue;
       int l0 = lrun + loff[k];
       KH_BOUND(2, l0, 0, u.link_cap - cnt[k] + 1);

@@ -1,14 +1,13 @@
 #!/bin/bash
 # Round profile bundle; run on the GPU box from the repo root:
 #   tools/collect_profiles.sh gpurun_out/profiles_rNN rNN
-# 1. bench line (default workload), decoder phase shares
-# 2. rocprofv3 --kernel-trace --stats of the same command
-# 3. PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE of DecodeKernel
+# 1. rocprofv3 --kernel-trace --stats of the bench command
+# 2. PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE of DecodeKernel
+# 3. bench line (default workload) + decoder phase shares, with the traffic of (2)
 out=${1:-gpurun_out/profiles}; tag=${2:-r01}
 mkdir -p "$out"
 export TMPDIR=/tmp
 T=${PROFILE_TIMEOUT:-420}
-KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout $T python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_decoder_phases.txt"
 timeout -k 10 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2> "$out/kt.log"
 f=$(find "$out/kt" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/${tag}_bench_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -16,5 +15,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find "$out/pmc_$c" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools/pmc_summarize.py "$f" DecodeKernel > "$out/${tag}_pmc_$c.txt"
 done
+# the bench line LAST: its roofline.traffic reads the PMC summaries of THIS build
+cp "$out/${tag}_pmc_FETCH_SIZE.txt" "$out/${tag}_pmc_WRITE_SIZE.txt" profiles/ 2>/dev/null
+KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout $T python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_decoder_phases.txt"
 rm -rf "$out/kt" "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE
 ls -la "$out"
