@@ -78,7 +78,10 @@ static int SelectLocked(int ordinal) {
     g_own_stream = nullptr;  // belongs to the other device; leak on purpose
   }
   if (!g_own_stream)
-    KH_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking));
+    // A BLOCKING stream: it orders itself against the legacy default stream, where a host
+    // framework that owns the device buffers (torch) enqueues its asynchronous fills and
+    // copies - the synchronous semantics the reference's callers expect.
+    KH_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamDefault));
   g_device = ordinal;
   g_selected = true;
   return KH_OK;
