@@ -31,29 +31,45 @@ import numpy as np
 
 
 class Stream:
-    """Byte stream with peek (std::istream as io-funcs uses it)."""
+    """Byte stream with an exact peek (std::istream as io-funcs uses it): own look-ahead
+    buffer, since io.BufferedReader.peek(n) may return fewer than n bytes."""
 
     def __init__(self, f):
-        self.f = f if hasattr(f, "peek") else io.BufferedReader(f)
+        self.f = f
+        self.buf = b""
+        self.pos = 0          # bytes consumed since construction
+        try:
+            self.base = f.tell()
+        except (OSError, AttributeError, io.UnsupportedOperation):
+            self.base = 0
+
+    def _fill(self, n):
+        while len(self.buf) < n:
+            chunk = self.f.read(max(n - len(self.buf), 1 << 16))
+            if not chunk:
+                break
+            self.buf += chunk
 
     def peek(self, n=1):
-        b = self.f.peek(n)[:n]
-        return b
+        self._fill(n)
+        return self.buf[:n]
 
     def get(self, n=1):
-        b = self.f.read(n)
-        if len(b) != n:
+        self._fill(n)
+        if len(self.buf) < n:
             raise EOFError("unexpected end of Kaldi stream")
-        return b
+        out, self.buf = self.buf[:n], self.buf[n:]
+        self.pos += n
+        return out
 
     def tell(self):
-        return self.f.tell()
+        return self.base + self.pos
 
     def skip_ws(self):
         while True:
             b = self.peek()
             if b and b in b" \t\n\r":
-                self.f.read(1)
+                self.get()
             else:
                 return
 
