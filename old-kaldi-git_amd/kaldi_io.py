@@ -11,12 +11,13 @@ Host-side, numpy only — the formats are byte layouts, not compute.  Restated f
   util/kaldi-table-inl.h, util/kaldi-holder-inl.h              ark / scp tables
   nnet2/nnet-nnet.cc:160-189, am-nnet.cc:31-42, nnet-component.cc (Read of every
       component the forward path supports)
+  gmm/am-diag-gmm.cc:147-176, gmm/diag-gmm.cc:705-756   AmDiagGmm / DiagGmm
   hmm/hmm-topology.cc:39-196, hmm/transition-model.cc:72-98,274-320
   lat/kaldi-lattice.cc:394-430        lattice text / binary (OpenFst VectorFst) I/O
 
 Pinned (tests/test_kaldi_io.py, fixtures written by the REFERENCE's own Write functions
 compiled in oracle/_ref): matrices, vectors, compressed matrices, integer vectors, ark/scp
-tables, Nnet / AmNnet in binary and text mode, HmmTopology.  PARITY UNPINNED (the
+tables, Nnet / AmNnet and AmDiagGmm in binary and text mode, HmmTopology.  PARITY UNPINNED (the
 reference's code for them needs OpenFst 1.3.4, absent here): TransitionModel's wrapper
 tokens, the OpenFst binary FST layout (HCLG read, lattice write) and FstPrinter's text
 lattice layout — restated from the reference's call sites and OpenFst's published format.
@@ -707,6 +708,60 @@ def read_transition_model(s, binary):
     if len(tid2pdf) != len(log_probs):
         raise ValueError("TransitionModel: %d transition-ids but %d log-probs" % (len(tid2pdf) - 1, len(log_probs)))
     return dict(topo=topo, triples=triples, log_probs=log_probs.astype(np.float32), tid2pdf=np.asarray(tid2pdf, np.int32))
+
+
+def read_diag_gmm(s, binary):
+    """DiagGmm::Read (gmm/diag-gmm.cc:728-756).  The stored gconsts are read and dropped, as the
+    reference recomputes them ("safer option than trusting the read gconsts")."""
+    tok = read_token(s, binary)
+    if tok not in ("<DiagGMMBegin>", "<DiagGMM>"):
+        raise ValueError("Expected <DiagGMM>, got " + tok)
+    tok = read_token(s, binary)
+    if tok == "<GCONSTS>":
+        read_vector(s, binary)
+        expect_token(s, binary, "<WEIGHTS>")
+    elif tok != "<WEIGHTS>":
+        raise ValueError("DiagGmm::Read, expected <WEIGHTS> or <GCONSTS>, got " + tok)
+    weights = read_vector(s, binary).astype(np.float32)
+    expect_token(s, binary, "<MEANS_INVVARS>")
+    means_invvars = read_matrix(s, binary).astype(np.float32)
+    expect_token(s, binary, "<INV_VARS>")
+    inv_vars = read_matrix(s, binary).astype(np.float32)
+    tok = read_token(s, binary)
+    if tok not in ("<DiagGMMEnd>", "</DiagGMM>"):
+        raise ValueError("Expected </DiagGMM>, got " + tok)
+    return weights, means_invvars, inv_vars
+
+
+def read_am_diag_gmm(s, binary):
+    """AmDiagGmm::Read (gmm/am-diag-gmm.cc:147-161) -> the concatenated arrays api.AmDiagGmm takes:
+    dict(weights [M], means_invvars [M, D], inv_vars [M, D], pdf_offsets [num_pdfs + 1], dim)."""
+    expect_token(s, binary, "<DIMENSION>")
+    dim = read_int32(s, binary)
+    expect_token(s, binary, "<NUMPDFS>")
+    num_pdfs = read_int32(s, binary)
+    if num_pdfs <= 0:
+        raise ValueError("AmDiagGmm: num_pdfs > 0")
+    w, mi, iv, off = [], [], [], [0]
+    for _ in range(num_pdfs):
+        a, b, c = read_diag_gmm(s, binary)
+        if b.shape[1] != dim or c.shape != b.shape or len(a) != len(b):
+            raise ValueError("AmDiagGmm: inconsistent DiagGmm dimensions")
+        w.append(a); mi.append(b); iv.append(c)
+        off.append(off[-1] + len(a))
+    return dict(weights=np.concatenate(w), means_invvars=np.concatenate(mi, 0), inv_vars=np.concatenate(iv, 0),
+                pdf_offsets=np.asarray(off, np.int32), dim=dim)
+
+
+def read_gmm_model(path):
+    """`final.mdl` as gmm-latgen-faster reads it (gmmbin/gmm-latgen-faster.cc:76-83):
+    TransitionModel, then AmDiagGmm."""
+    with open(path, "rb") as f:
+        s = Stream(f)
+        binary = init_kaldi_input(s)
+        tm = read_transition_model(s, binary)
+        am = read_am_diag_gmm(s, binary)
+    return tm, am
 
 
 def write_topology(f, topo, binary=True):

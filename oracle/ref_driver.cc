@@ -20,6 +20,7 @@
 #include "cudamatrix/cu-matrix-lib.h"
 #include "feat/feature-functions.h"
 #include "feat/feature-mfcc.h"
+#include "gmm/am-diag-gmm.h"
 #include "gmm/diag-gmm.h"
 #include "hmm/hmm-topology.h"
 #include "matrix/matrix-lib.h"
@@ -628,6 +629,24 @@ int ref_write_am_nnet(const char *path, const KoComponent *comps, int n_comps, c
       Output ko(path, binary != 0);
       am.Write(ko.Stream(), binary != 0);
       return ko.Close() ? 0 : -1;
+    }
+    std::ofstream os(path, std::ios::binary);
+    am.Write(os, binary != 0);
+    return os.good() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// AmDiagGmm::Write gmm/am-diag-gmm.cc:163-176 (DiagGmm::Write diag-gmm.cc:705-720): pdf j owns the
+// Gaussians [pdf_offsets[j], pdf_offsets[j+1]) of the concatenated arrays; no "\0B" header.
+int ref_write_am_diag_gmm(const char *path, const float *weights, const float *means, const float *vars,
+                          const int32_t *pdf_offsets, int num_pdfs, int dim, int binary) {
+  try {
+    AmDiagGmm am;
+    for (int j = 0; j < num_pdfs; j++) {
+      const int b = pdf_offsets[j], n = pdf_offsets[j + 1] - b;
+      DiagGmm gmm;
+      FillGmm(&gmm, weights + b, means + static_cast<size_t>(b) * dim, vars + static_cast<size_t>(b) * dim, n, dim);
+      gmm.ComputeGconsts();
+      am.AddPdf(gmm);
     }
     std::ofstream os(path, std::ios::binary);
     am.Write(os, binary != 0);

@@ -263,6 +263,10 @@ def make_kaldi_io():
                 rc = ref.ref_write_am_nnet(b(name), arr, len(net), fp(priors), len(priors), binary, kind, 1)
                 assert rc == 0, (name, rc)
         assert ref.ref_write_am_nnet(b("am_nnet_body_bin"), arr, len(net), fp(priors), len(priors), 1, 2, 0) == 0
+        am = workloads.make_am_gmm(np.random.default_rng(13), 5, 17, 6)
+        for binary, name in ((1, "am_gmm_body_bin"), (0, "am_gmm_body_txt")):
+            assert ref.ref_write_am_diag_gmm(b(name), fp(am["weights"]), fp(am["means"]), fp(am["vars"]),
+                                             ip(am["pdf_offsets"]), 5, 6, binary) == 0
         assert ref.ref_write_topology(b("topo.bin"), b(TOPO_TEXT), 1) == 0
         assert ref.ref_write_topology(b("topo.txt"), b(TOPO_TEXT), 0) == 0
     finally:

@@ -75,3 +75,52 @@ def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatc
         # text lattice = the same lattice at 7 significant digits
         assert np.array_equal(lats_t[k]["arc_dst"], got["arc_dst"]) and np.array_equal(lats_t[k]["arc_il"], got["arc_il"])
         np.testing.assert_allclose(lats_t[k]["arc_a"], got["arc_a"], rtol=1e-6, atol=1e-6)
+
+
+def test_gmm_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch):
+    """gmm-latgen-faster (configs 1 and 2): final.mdl = TransitionModel + the AmDiagGmm bytes
+    written by the REFERENCE (tests/golden/kaldi_io/am_gmm_body_bin)."""
+    from oracle import binding
+    kio, workloads = pkg("kaldi_io"), pkg("workloads")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gmm_latgen_faster as tool
+    am = workloads.make_am_gmm(np.random.default_rng(13), 5, 17, 6)     # what am_gmm_body_bin holds
+    mi, iv = workloads.gmm_inv_params(am)
+    n_pdf, acwt = 5, 0.1
+    rng = np.random.default_rng(31)
+    topo = dict(phones=list(range(1, n_pdf + 1)), phone2idx=[-1] + [0] * n_pdf,
+                entries=[[(0, [(0, 0.5), (1, 0.5)]), (-1, [])]])
+    pdf_of_phone = rng.permutation(n_pdf)
+    triples = [(p + 1, 0, int(pdf_of_phone[p])) for p in range(n_pdf)]
+    log_probs = np.concatenate([[0.0], np.full(2 * n_pdf, np.log(0.5))]).astype(np.float32)
+    g = workloads.make_hclg_like(rng, 300, n_pdf, final_frac=0.2)
+    g["tid2pdf"] = np.concatenate([[-1], np.repeat(pdf_of_phone, 2)]).astype(np.int32)
+    monkeypatch.chdir(tmp_path)
+    with open("final.mdl", "wb") as f:
+        f.write(b"\0B")
+        kio.write_transition_model(f, topo, triples, log_probs, True)
+        f.write(open(os.path.join(GOLD, "am_gmm_body_bin"), "rb").read())
+    with open("HCLG.fst", "wb") as f:
+        kio.write_fst(f, g)
+    utts = {"u%d" % i: rng.standard_normal((T, 6)).astype(np.float32) for i, T in enumerate((41, 9))}
+    with kio.TableWriter("feats.ark") as w:
+        for k, m in utts.items():
+            w.write(k, m)
+    opts = ["--beam=10", "--max-active=200", "--lattice-beam=6", "--acoustic-scale=%g" % acwt, "--allow-partial=true"]
+    assert tool.main(opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark:lat.ark", "ark,t:words.txt"]) == 0
+    lats = dict(kio.read_ark("lat.ark", kind="lattice"))
+    words = dict(kio.read_ark("words.txt", kind="int32_vector"))
+    gconsts, _ = oracle.gmm_compute_gconsts(am["weights"], mi, iv)
+    cfg = binding.decoder_config(beam=10.0, max_active=200, lattice_beam=6.0)
+    for k, x in utts.items():
+        ll = (oracle.am_gmm_loglikes(x, gconsts, mi, iv, am["pdf_offsets"], -1.0) * np.float32(acwt)).astype(np.float32)
+        oc = binding.DecoderOracle(g, cfg, "canonical")
+        oc.decode(ll)
+        want, best = oc.raw_lattice(), oc.best_path()
+        got = lats[k]
+        order = np.argsort(want["arc_src"], kind="stable")
+        assert got["num_states"] == len(want["state_frame"])
+        for key in ("arc_dst", "arc_il", "arc_ol"):
+            assert np.array_equal(got[key], want[key][order]), (k, key)
+        np.testing.assert_allclose(got["arc_a"] * acwt, want["arc_a"][order], atol=2e-4)
+        assert np.array_equal(words[k], best["words"])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""nnet2bin/nnet-latgen-faster.cc's command line over the library; see tools/latgen_faster.py."""
+"""gmmbin/gmm-latgen-faster.cc's command line over the library; see tools/latgen_faster.py."""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import latgen_faster  # noqa: E402
 
 
 def main(argv=None):
-    return latgen_faster.main(argv, kind="nnet2")
+    return latgen_faster.main(argv, kind="gmm")
 
 
 if __name__ == "__main__":
