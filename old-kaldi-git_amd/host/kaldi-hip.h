@@ -5,8 +5,9 @@
 // cu-vector.h, cu-array.h, cu-device.h, cu-math.h, decoder/lattice-faster-decoder.h
 // reads the same here:
 //   kaldi::CuDevice            cudamatrix/cu-device.h:41-143
-//   kaldi::CuMatrix<float>     cudamatrix/cu-matrix.h:62-644  (forward-path subset)
-//   kaldi::CuVector<float>     cudamatrix/cu-vector.h
+//   kaldi::CuMatrixBase / CuMatrix / CuSubMatrix <float>   cudamatrix/cu-matrix.h:62-644  (forward-path
+//                              subset; every operation also works on Range() / RowRange() / ColRange() views)
+//   kaldi::CuVectorBase / CuVector / CuSubVector <float>   cudamatrix/cu-vector.h
 //   kaldi::CuArray<T>          cudamatrix/cu-array.h:36-105
 //   kaldi::cu::Splice          cudamatrix/cu-math.h
 //   kaldi::LatticeFasterDecoderConfig / LatticeFasterDecoder
@@ -151,16 +152,43 @@ class CuArray {
   T *data_;
 };
 
-// ---- CuVector cu-vector.h ---------------------------------------------------------------
-class CuVector {
+// ---- CuVectorBase / CuVector / CuSubVector cu-vector.h ------------------------------------
+class CuSubVector;
+class CuMatrixBase;
+class CuVectorBase {
  public:
-  CuVector() : data_(NULL), dim_(0) {}
-  explicit CuVector(MatrixIndexT dim) : data_(NULL), dim_(0) { Resize(dim); }
-  explicit CuVector(const std::vector<BaseFloat> &host) : data_(NULL), dim_(0) { CopyFromVec(host); }
-  ~CuVector() { if (data_) kh_free(data_); }
   MatrixIndexT Dim() const { return dim_; }
   BaseFloat *Data() { return data_; }
   const BaseFloat *Data() const { return data_; }
+  /// CopyFromVec(const VectorBase&) cu-vector.cc: same dimension required
+  void CopyFromVec(const std::vector<BaseFloat> &h) {
+    KALDI_HIP_ASSERT(static_cast<MatrixIndexT>(h.size()) == dim_);
+    if (dim_) KhCheck(kh_memcpy_2d(data_, 4 * (size_t)dim_, h.data(), 4 * (size_t)dim_, 4 * (size_t)dim_, 1, 0));
+  }
+  void CopyToVec(std::vector<BaseFloat> *h) const {
+    h->resize(dim_);
+    if (dim_) KhCheck(kh_memcpy_2d(h->data(), 4 * (size_t)dim_, data_, 4 * (size_t)dim_, 4 * (size_t)dim_, 1, 1));
+  }
+  void SetZero() { if (dim_) KhCheck(kh_memset(data_, 0, sizeof(BaseFloat) * dim_)); }
+  inline CuSubVector Range(MatrixIndexT origin, MatrixIndexT length) const;  // cu-vector.h Range()
+
+ protected:
+  CuVectorBase() : data_(NULL), dim_(0) {}
+  ~CuVectorBase() {}
+  BaseFloat *data_;
+  MatrixIndexT dim_;
+
+ private:
+  CuVectorBase(const CuVectorBase &);
+  CuVectorBase &operator=(const CuVectorBase &);
+};
+
+class CuVector : public CuVectorBase {
+ public:
+  CuVector() {}
+  explicit CuVector(MatrixIndexT dim) { Resize(dim); }
+  explicit CuVector(const std::vector<BaseFloat> &host) { CopyFromVec(host); }
+  ~CuVector() { if (data_) kh_free(data_); }
   void Resize(MatrixIndexT dim) {
     if (data_) kh_free(data_);
     data_ = NULL;
@@ -170,114 +198,107 @@ class CuVector {
       KhCheck(kh_memset(data_, 0, sizeof(BaseFloat) * dim));
     }
   }
-  void CopyFromVec(const std::vector<BaseFloat> &h) {
-    Resize(static_cast<MatrixIndexT>(h.size()));
-    if (dim_) KhCheck(kh_memcpy_2d(data_, 4 * dim_, h.data(), 4 * dim_, 4 * dim_, 1, 0));
+  void CopyFromVec(const std::vector<BaseFloat> &h) {  // the owning class resizes (CuVector(const VectorBase&))
+    if (static_cast<MatrixIndexT>(h.size()) != dim_) Resize(static_cast<MatrixIndexT>(h.size()));
+    CuVectorBase::CopyFromVec(h);
   }
-  void CopyToVec(std::vector<BaseFloat> *h) const {
-    h->resize(dim_);
-    if (dim_) KhCheck(kh_memcpy_2d(h->data(), 4 * dim_, data_, 4 * dim_, 4 * dim_, 1, 1));
-  }
-
- private:
-  CuVector(const CuVector &);
-  CuVector &operator=(const CuVector &);
-  BaseFloat *data_;
-  MatrixIndexT dim_;
 };
 
-// ---- CuMatrix cu-matrix.h:62-644 (float; members data_, num_cols_, num_rows_,
-// stride_ as cu-matrix.h:500-510) ---------------------------------------------------------
-class CuMatrix {
+/// Non-owning view (cu-vector.h CuSubVector): a range of a vector or one row of a matrix.
+class CuSubVector : public CuVectorBase {
  public:
-  CuMatrix() : data_(NULL), num_cols_(0), num_rows_(0), stride_(0) {}
-  CuMatrix(MatrixIndexT rows, MatrixIndexT cols, MatrixResizeType t = kSetZero)
-      : data_(NULL), num_cols_(0), num_rows_(0), stride_(0) { Resize(rows, cols, t); }
-  ~CuMatrix() { Destroy(); }
+  CuSubVector(const CuVectorBase &t, MatrixIndexT origin, MatrixIndexT length) {
+    KALDI_HIP_ASSERT(origin >= 0 && length >= 0 && origin + length <= t.Dim());
+    data_ = const_cast<BaseFloat *>(t.Data()) + origin;
+    dim_ = length;
+  }
+  inline CuSubVector(const CuMatrixBase &mat, MatrixIndexT row);
+  CuSubVector(const CuSubVector &o) : CuVectorBase() { data_ = o.data_; dim_ = o.dim_; }
+};
+inline CuSubVector CuVectorBase::Range(MatrixIndexT origin, MatrixIndexT length) const {
+  return CuSubVector(*this, origin, length);
+}
+
+// ---- CuMatrixBase / CuMatrix / CuSubMatrix cu-matrix.h:62-644 (float; members data_,
+// num_cols_, num_rows_, stride_ as cu-matrix.h:500-510).  Every operation lives in the base
+// class and works on views as well: the library takes (pointer, rows, cols, stride). ----------
+class CuSubMatrix;
+class CuMatrixBase {
+ public:
   MatrixIndexT NumRows() const { return num_rows_; }
   MatrixIndexT NumCols() const { return num_cols_; }
   MatrixIndexT Stride() const { return stride_; }
   BaseFloat *Data() { return data_; }
   const BaseFloat *Data() const { return data_; }
   KhMatrixDim Dim() const { KhMatrixDim d = {num_rows_, num_cols_, stride_}; return d; }
+  /// Range / RowRange / ColRange cu-matrix.h:447-463
+  inline CuSubMatrix Range(MatrixIndexT row_offset, MatrixIndexT num_rows, MatrixIndexT col_offset,
+                           MatrixIndexT num_cols) const;
+  inline CuSubMatrix RowRange(MatrixIndexT row_offset, MatrixIndexT num_rows) const;
+  inline CuSubMatrix ColRange(MatrixIndexT col_offset, MatrixIndexT num_cols) const;
 
-  void Resize(MatrixIndexT rows, MatrixIndexT cols, MatrixResizeType t = kSetZero) {  // cu-matrix.cc:47-100
-    KALDI_HIP_ASSERT(rows >= 0 && cols >= 0);
-    Destroy();
-    if (rows == 0 || cols == 0) return;
-    size_t pitch;
-    data_ = static_cast<BaseFloat *>(CuDevice::Instantiate().MallocPitch(sizeof(BaseFloat) * cols, rows, &pitch));
-    num_rows_ = rows;
-    num_cols_ = cols;
-    stride_ = static_cast<MatrixIndexT>(pitch / sizeof(BaseFloat));
-    if (t == kSetZero) KhCheck(kh_memset(data_, 0, pitch * rows));
-  }
-  void Destroy() {
-    if (data_) kh_free(data_);
-    data_ = NULL;
-    num_rows_ = num_cols_ = stride_ = 0;
-  }
-  /// CopyFromMat(const MatrixBase&) cu-matrix.cc:283-307: host row-major, stride in elements.
+  /// CopyFromMat(const MatrixBase&) cu-matrix.cc:283-307: host row-major, stride in elements; same size.
   void CopyFromMat(const BaseFloat *host, MatrixIndexT rows, MatrixIndexT cols, MatrixIndexT host_stride) {
-    if (rows != num_rows_ || cols != num_cols_) Resize(rows, cols, kUndefined);
+    KALDI_HIP_ASSERT(rows == num_rows_ && cols == num_cols_);
     if (rows) KhCheck(kh_memcpy_2d(data_, 4 * (size_t)stride_, host, 4 * (size_t)host_stride, 4 * (size_t)cols, rows, 0));
   }
   /// CopyToMat cu-matrix.cc:387-412
   void CopyToMat(BaseFloat *host, MatrixIndexT host_stride) const {
     if (num_rows_) KhCheck(kh_memcpy_2d(host, 4 * (size_t)host_stride, data_, 4 * (size_t)stride_, 4 * (size_t)num_cols_, num_rows_, 1));
   }
-  void CopyFromMat(const CuMatrix &src) {
-    if (src.num_rows_ != num_rows_ || src.num_cols_ != num_cols_) Resize(src.num_rows_, src.num_cols_, kUndefined);
+  void CopyFromMat(const CuMatrixBase &src) {  // cu-matrix.cc:197-231, same size
+    KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
     if (num_rows_) KhCheck(kh_memcpy_2d(data_, 4 * (size_t)stride_, src.data_, 4 * (size_t)src.stride_, 4 * (size_t)num_cols_, num_rows_, 2));
   }
-  void Swap(CuMatrix *o) {
-    std::swap(data_, o->data_); std::swap(num_cols_, o->num_cols_);
-    std::swap(num_rows_, o->num_rows_); std::swap(stride_, o->stride_);
+  void SetZero() {
+    for (MatrixIndexT r = 0; r < num_rows_ && stride_ != num_cols_; r++)
+      KhCheck(kh_memset(data_ + static_cast<size_t>(r) * stride_, 0, sizeof(BaseFloat) * num_cols_));
+    if (stride_ == num_cols_ && num_rows_) KhCheck(kh_memset(data_, 0, sizeof(BaseFloat) * num_cols_ * num_rows_));
   }
 
   // ---- forward-path operations; each = the reference method of the same name
-  void AddMatMat(BaseFloat alpha, const CuMatrix &A, MatrixTransposeType transA, const CuMatrix &B,
+  void AddMatMat(BaseFloat alpha, const CuMatrixBase &A, MatrixTransposeType transA, const CuMatrixBase &B,
                  MatrixTransposeType transB, BaseFloat beta) {  // cu-matrix.cc:947-982
     KhCheck(kh_add_mat_mat(alpha, A.data_, A.Dim(), transA == kTrans, B.data_, B.Dim(), transB == kTrans, beta, data_, Dim()));
     Sync();
   }
-  void ApplySoftMaxPerRow(const CuMatrix &src) {  // :1251-1271
+  void ApplySoftMaxPerRow(const CuMatrixBase &src) {  // :1251-1271
     KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
     KhCheck(kh_softmax_per_row(data_, src.data_, Dim(), src.stride_));
     Sync();
   }
-  void ApplyLogSoftMaxPerRow(const CuMatrix &src) {  // :1274-1295
+  void ApplyLogSoftMaxPerRow(const CuMatrixBase &src) {  // :1274-1295
     KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
     KhCheck(kh_log_softmax_per_row(data_, src.data_, Dim(), src.stride_));
     Sync();
   }
-  void CopyRows(const CuMatrix &src, const std::vector<MatrixIndexT> &indices) {  // :1965-1990
+  void CopyRows(const CuMatrixBase &src, const std::vector<MatrixIndexT> &indices) {  // :1965-1990
     KALDI_HIP_ASSERT(static_cast<MatrixIndexT>(indices.size()) == num_rows_ && src.num_cols_ == num_cols_);
     CuArray<MatrixIndexT> idx(indices);  // the reference uploads the index vector per call too (:1976)
     KhCheck(kh_copy_rows(data_, Dim(), src.data_, src.stride_, idx.Data()));
     Sync();
   }
-  void GroupPnorm(const CuMatrix &src, BaseFloat power) {  // :1147-1164
+  void GroupPnorm(const CuMatrixBase &src, BaseFloat power) {  // :1147-1164
     KALDI_HIP_ASSERT(num_cols_ > 0 && src.num_cols_ % num_cols_ == 0 && src.num_rows_ == num_rows_);
     KhCheck(kh_group_pnorm(data_, src.data_, Dim(), src.stride_, src.num_cols_ / num_cols_, power));
     Sync();
   }
-  void MulRowsVec(const CuVector &scale) {  // :693-713
+  void MulRowsVec(const CuVectorBase &scale) {  // :693-713
     KALDI_HIP_ASSERT(scale.Dim() == num_rows_);
     KhCheck(kh_mul_rows_vec(data_, Dim(), scale.Data()));
     Sync();
   }
-  void MulColsVec(const CuVector &scale) {  // :668
+  void MulColsVec(const CuVectorBase &scale) {  // :668
     KALDI_HIP_ASSERT(scale.Dim() == num_cols_);
     KhCheck(kh_mul_cols_vec(data_, Dim(), scale.Data()));
     Sync();
   }
-  void CopyRowsFromVec(const CuVector &v) {  // :1673-1745
+  void CopyRowsFromVec(const CuVectorBase &v) {  // :1673-1745
     KALDI_HIP_ASSERT(v.Dim() == num_cols_);
     KhCheck(kh_copy_rows_from_vec(data_, Dim(), v.Data()));
     Sync();
   }
-  void AddVecToRows(BaseFloat alpha, const CuVector &row, BaseFloat beta = 1.0) {  // :916-939
+  void AddVecToRows(BaseFloat alpha, const CuVectorBase &row, BaseFloat beta = 1.0) {  // :916-939
     KALDI_HIP_ASSERT(row.Dim() == num_cols_);
     KhCheck(kh_add_vec_to_rows(alpha, row.Data(), beta, data_, Dim()));
     Sync();
@@ -287,27 +308,27 @@ class CuMatrix {
   void ApplyExp() { KhCheck(kh_apply_exp(data_, Dim())); Sync(); }
   void ApplyPow(BaseFloat p) { KhCheck(kh_apply_pow(data_, Dim(), p)); Sync(); }
   void Scale(BaseFloat a) { KhCheck(kh_scale(data_, Dim(), a)); Sync(); }               // :579
-  void SumColumnRanges(const CuMatrix &src, const std::vector<int32> &start_end_pairs) {  // :1994-2028
+  void SumColumnRanges(const CuMatrixBase &src, const std::vector<int32> &start_end_pairs) {  // :1994-2028
     KALDI_HIP_ASSERT(static_cast<MatrixIndexT>(start_end_pairs.size()) == 2 * num_cols_ && src.num_rows_ == num_rows_);
     CuArray<int32> r(start_end_pairs);
     KhCheck(kh_sum_column_ranges(data_, Dim(), src.data_, src.Dim(), r.Data()));
     Sync();
   }
   /// this <- NormalizeComponent::Propagate(src) (nnet2/nnet-component.cc:576-588) in one kernel
-  void NormalizePerRow(const CuMatrix &src) {
+  void NormalizePerRow(const CuMatrixBase &src) {
     KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
     KhCheck(kh_normalize(data_, src.data_, Dim(), src.stride_));
     Sync();
   }
   /// v.AddDiagMat2(alpha, *this, kNoTrans, beta) cu-vector.cc:517-580: v = beta v + alpha diag(M M^T)
-  void AddDiagMat2To(CuVector *v, BaseFloat alpha, BaseFloat beta) const {
+  void AddDiagMat2To(CuVectorBase *v, BaseFloat alpha, BaseFloat beta) const {
     KALDI_HIP_ASSERT(v->Dim() == num_rows_);
     KhCheck(kh_add_diag_mat2(alpha, data_, Dim(), beta, v->Data()));
     Sync();
   }
   /// CompObjfAndDeriv cu-matrix.cc:1198-1248 on *this = the derivative; labels = (row, column, weight)
   struct MatrixElement { int32 row, column; BaseFloat weight; };
-  void CompObjfAndDeriv(const std::vector<MatrixElement> &sv_labels, const CuMatrix &output, BaseFloat *tot_objf,
+  void CompObjfAndDeriv(const std::vector<MatrixElement> &sv_labels, const CuMatrixBase &output, BaseFloat *tot_objf,
                         BaseFloat *tot_weight) {
     std::vector<int32> r(sv_labels.size()), c(sv_labels.size());
     std::vector<BaseFloat> w(sv_labels.size());
@@ -325,17 +346,82 @@ class CuMatrix {
     out.CopyToVec(output);
   }
 
- private:
+ protected:
+  CuMatrixBase() : data_(NULL), num_cols_(0), num_rows_(0), stride_(0) {}
+  CuMatrixBase(BaseFloat *data, MatrixIndexT rows, MatrixIndexT cols, MatrixIndexT stride)
+      : data_(data), num_cols_(cols), num_rows_(rows), stride_(stride) {}
+  ~CuMatrixBase() {}
   static void Sync() { KhCheck(kh_synchronize()); }
-  CuMatrix(const CuMatrix &);
-  CuMatrix &operator=(const CuMatrix &);
   BaseFloat *data_;
   MatrixIndexT num_cols_, num_rows_, stride_;
+
+ private:
+  CuMatrixBase(const CuMatrixBase &);
+  CuMatrixBase &operator=(const CuMatrixBase &);
 };
+
+class CuMatrix : public CuMatrixBase {
+ public:
+  CuMatrix() {}
+  CuMatrix(MatrixIndexT rows, MatrixIndexT cols, MatrixResizeType t = kSetZero) { Resize(rows, cols, t); }
+  ~CuMatrix() { Destroy(); }
+  void Resize(MatrixIndexT rows, MatrixIndexT cols, MatrixResizeType t = kSetZero) {  // cu-matrix.cc:47-100
+    KALDI_HIP_ASSERT(rows >= 0 && cols >= 0);
+    Destroy();
+    if (rows == 0 || cols == 0) return;
+    size_t pitch;
+    data_ = static_cast<BaseFloat *>(CuDevice::Instantiate().MallocPitch(sizeof(BaseFloat) * cols, rows, &pitch));
+    num_rows_ = rows;
+    num_cols_ = cols;
+    stride_ = static_cast<MatrixIndexT>(pitch / sizeof(BaseFloat));
+    if (t == kSetZero) KhCheck(kh_memset(data_, 0, pitch * rows));
+  }
+  void Destroy() {
+    if (data_) kh_free(data_);
+    data_ = NULL;
+    num_rows_ = num_cols_ = stride_ = 0;
+  }
+  /// the owning class resizes to the source (CuMatrix(const MatrixBase&) / operator=)
+  void CopyFromMat(const BaseFloat *host, MatrixIndexT rows, MatrixIndexT cols, MatrixIndexT host_stride) {
+    if (rows != num_rows_ || cols != num_cols_) Resize(rows, cols, kUndefined);
+    CuMatrixBase::CopyFromMat(host, rows, cols, host_stride);
+  }
+  void CopyFromMat(const CuMatrixBase &src) {
+    if (src.NumRows() != num_rows_ || src.NumCols() != num_cols_) Resize(src.NumRows(), src.NumCols(), kUndefined);
+    CuMatrixBase::CopyFromMat(src);
+  }
+  void Swap(CuMatrix *o) {
+    std::swap(data_, o->data_); std::swap(num_cols_, o->num_cols_);
+    std::swap(num_rows_, o->num_rows_); std::swap(stride_, o->stride_);
+  }
+};
+
+/// Non-owning view of a block of another matrix (cu-matrix.h:620-644).
+class CuSubMatrix : public CuMatrixBase {
+ public:
+  CuSubMatrix(const CuMatrixBase &mat, MatrixIndexT row_offset, MatrixIndexT num_rows, MatrixIndexT col_offset,
+              MatrixIndexT num_cols)
+      : CuMatrixBase(const_cast<BaseFloat *>(mat.Data()) + static_cast<size_t>(row_offset) * mat.Stride() + col_offset,
+                     num_rows, num_cols, mat.Stride()) {
+    KALDI_HIP_ASSERT(row_offset >= 0 && col_offset >= 0 && num_rows >= 0 && num_cols >= 0 &&
+                     row_offset + num_rows <= mat.NumRows() && col_offset + num_cols <= mat.NumCols());
+  }
+  CuSubMatrix(const CuSubMatrix &o) : CuMatrixBase(o.data_, o.num_rows_, o.num_cols_, o.stride_) {}
+};
+inline CuSubMatrix CuMatrixBase::Range(MatrixIndexT ro, MatrixIndexT nr, MatrixIndexT co, MatrixIndexT nc) const {
+  return CuSubMatrix(*this, ro, nr, co, nc);
+}
+inline CuSubMatrix CuMatrixBase::RowRange(MatrixIndexT ro, MatrixIndexT nr) const { return CuSubMatrix(*this, ro, nr, 0, num_cols_); }
+inline CuSubMatrix CuMatrixBase::ColRange(MatrixIndexT co, MatrixIndexT nc) const { return CuSubMatrix(*this, 0, num_rows_, co, nc); }
+inline CuSubVector::CuSubVector(const CuMatrixBase &mat, MatrixIndexT row) {
+  KALDI_HIP_ASSERT(row >= 0 && row < mat.NumRows());
+  data_ = const_cast<BaseFloat *>(mat.Data()) + static_cast<size_t>(row) * mat.Stride();
+  dim_ = mat.NumCols();
+}
 
 namespace cu {
 /// cu::Splice cudamatrix/cu-math.cc:130-165
-inline void Splice(const CuMatrix &src, const std::vector<int32> &frame_offsets, CuMatrix *tgt) {
+inline void Splice(const CuMatrixBase &src, const std::vector<int32> &frame_offsets, CuMatrixBase *tgt) {
   KALDI_HIP_ASSERT(src.NumCols() * static_cast<int>(frame_offsets.size()) == tgt->NumCols() &&
                    src.NumRows() == tgt->NumRows());
   CuArray<int32> off(frame_offsets);
@@ -369,7 +455,7 @@ class Nnet {
 
 /// NnetComputation(nnet, input, pad_input, &output) nnet2/nnet-compute.cc:159-166 for one
 /// utterance (utt_row_offsets = {0, T}) or a batch stacked by rows.
-inline void NnetComputation(const Nnet &nnet, const CuMatrix &input, bool pad_input, CuMatrix *output,
+inline void NnetComputation(const Nnet &nnet, const CuMatrixBase &input, bool pad_input, CuMatrix *output,
                             const std::vector<int32> *utt_row_offsets = NULL) {
   std::vector<int32> one;
   if (!utt_row_offsets) { one.push_back(0); one.push_back(input.NumRows()); utt_row_offsets = &one; }
@@ -382,7 +468,7 @@ inline void NnetComputation(const Nnet &nnet, const CuMatrix &input, bool pad_in
 }
 
 /// DecodableAmNnet's matrix (nnet2/decodable-am-nnet.h:47-69): floor, log, -log prior, scale.
-inline void ComputeScaledLogLikes(const Nnet &nnet, const CuMatrix &feats, bool pad_input, BaseFloat prob_scale,
+inline void ComputeScaledLogLikes(const Nnet &nnet, const CuMatrixBase &feats, bool pad_input, BaseFloat prob_scale,
                                   CuMatrix *log_probs, const std::vector<int32> *utt_row_offsets = NULL) {
   std::vector<int32> one;
   if (!utt_row_offsets) { one.push_back(0); one.push_back(feats.NumRows()); utt_row_offsets = &one; }
@@ -411,7 +497,7 @@ class DiagGmm {
   int32 NumGauss() const { return num_mix_; }
   int32 Dim() const { return dim_; }
   /// LogLikelihoods(const MatrixBase &data, Matrix *loglikes) diag-gmm.cc:546-562
-  void LogLikelihoods(const CuMatrix &data, CuMatrix *loglikes) const {
+  void LogLikelihoods(const CuMatrixBase &data, CuMatrix *loglikes) const {
     KALDI_HIP_ASSERT(data.NumCols() == dim_);
     loglikes->Resize(data.NumRows(), num_mix_, kUndefined);
     KhCheck(kh_diag_gmm_loglikes(data.Data(), data.Dim(), gconsts_.Data(), means_invvars_.Data(), inv_vars_.Data(),
@@ -554,7 +640,7 @@ class Mfcc {
 };
 
 /// ComputeDeltas(DeltaFeaturesOptions(order, window), input, &output) feature-functions.cc:361-372
-inline void ComputeDeltas(int32 order, int32 window, const CuMatrix &input, CuMatrix *output) {
+inline void ComputeDeltas(int32 order, int32 window, const CuMatrixBase &input, CuMatrix *output) {
   KALDI_HIP_ASSERT(order >= 0 && order < 1000 && window > 0 && window < 1000);
   std::vector<std::vector<BaseFloat> > sc(order + 1);
   sc[0].assign(1, 1.0f);
@@ -579,7 +665,7 @@ inline void ComputeDeltas(int32 order, int32 window, const CuMatrix &input, CuMa
 }
 
 /// AccCmvnStats(feats, NULL, &stats) transform/cmvn.cc:49-62; stats = 2 x (dim + 1) doubles, row-major
-inline void AccCmvnStats(const CuMatrix &feats, std::vector<double> *stats) {
+inline void AccCmvnStats(const CuMatrixBase &feats, std::vector<double> *stats) {
   if (stats->empty()) stats->assign(2 * (feats.NumCols() + 1), 0.0);
   KALDI_HIP_ASSERT(static_cast<int32>(stats->size()) == 2 * (feats.NumCols() + 1));
   KhCheck(kh_acc_cmvn_stats(feats.Data(), feats.Dim(), stats->data()));

@@ -46,6 +46,75 @@ static void TestAddMatMat() {
   CHECK(threw);  // dimension mismatch -> KALDI_ASSERT -> exception
 }
 
+// CuSubMatrix / CuSubVector (cu-matrix.h:620-644): the same operations on views must give the
+// same numbers as on owning matrices holding copies of the blocks (as cu-matrix-test.cc does
+// with its Range() cases).
+static void TestSubMatrixViews() {
+  const int R = 50, Cc = 70;
+  std::vector<float> X = RandMat(R, Cc, 2.f), Y = RandMat(40, 64, 1.f);
+  CuMatrix big, other;
+  big.CopyFromMat(X.data(), R, Cc, Cc);
+  other.CopyFromMat(Y.data(), 40, 64, 64);
+  // view = rows [5, 35), cols [3, 43) of big; owning copy of the same block
+  CuSubMatrix view(big, 5, 30, 3, 40);
+  CHECK(view.NumRows() == 30 && view.NumCols() == 40 && view.Stride() == big.Stride());
+  CuMatrix blockcopy;
+  blockcopy.CopyFromMat(view);
+  std::vector<float> a(30 * 40), b(30 * 40);
+  view.CopyToMat(a.data(), 40);
+  for (int i = 0; i < 30; i++)
+    for (int j = 0; j < 40; j++) CHECK(a[i * 40 + j] == X[(i + 5) * Cc + j + 3]);
+  // softmax into a view of another matrix vs into an owning matrix
+  CuMatrix out1(30, 40), out2(60, 90);
+  CuSubMatrix out2v = out2.Range(7, 30, 11, 40);
+  out1.ApplySoftMaxPerRow(blockcopy);
+  out2v.ApplySoftMaxPerRow(view);
+  out1.CopyToMat(a.data(), 40);
+  out2v.CopyToMat(b.data(), 40);
+  for (size_t i = 0; i < a.size(); i++) CHECK(a[i] == b[i]);
+  // the rest of out2 is untouched (still zero)
+  std::vector<float> whole(60 * 90);
+  out2.CopyToMat(whole.data(), 90);
+  CHECK(whole[0] == 0.f && whole[6 * 90 + 11] == 0.f && whole[7 * 90 + 10] == 0.f && whole[37 * 90 + 11] == 0.f);
+  // AddMatMat on views: C_view = A_view * B_view^T
+  CuSubMatrix A = big.Range(0, 20, 10, 32), Bv = other.ColRange(16, 32).RowRange(4, 24);
+  CuMatrix Ac, Bc, C1(20, 24);
+  Ac.CopyFromMat(A);
+  Bc.CopyFromMat(Bv);
+  C1.AddMatMat(1.0f, Ac, kNoTrans, Bc, kTrans, 0.0f);
+  CuMatrix C2big(33, 50);
+  CuSubMatrix C2 = C2big.Range(13, 20, 26, 24);
+  C2.AddMatMat(1.0f, A, kNoTrans, Bv, kTrans, 0.0f);
+  std::vector<float> c1(20 * 24), c2(20 * 24);
+  C1.CopyToMat(c1.data(), 24);
+  C2.CopyToMat(c2.data(), 24);
+  for (size_t i = 0; i < c1.size(); i++) CHECK(c1[i] == c2[i]);
+  // CuSubVector: a row of a matrix as the bias of AddVecToRows; a range of a vector as a scale
+  CuSubVector row(big, 9);
+  CHECK(row.Dim() == Cc);
+  CuMatrix M1(8, Cc), M2(8, Cc);
+  std::vector<float> rowh(X.begin() + 9 * Cc, X.begin() + 10 * Cc);
+  CuVector rowc(rowh);
+  M1.AddVecToRows(1.0f, rowc);
+  M2.AddVecToRows(1.0f, row);
+  std::vector<float> m1(8 * Cc), m2(8 * Cc);
+  M1.CopyToMat(m1.data(), Cc);
+  M2.CopyToMat(m2.data(), Cc);
+  for (size_t i = 0; i < m1.size(); i++) CHECK(m1[i] == m2[i] && m1[i] == X[9 * Cc + i % Cc]);
+  CuSubVector part = rowc.Range(10, 8);
+  CuMatrix M3(8, 5);
+  std::vector<float> ones(40, 1.f);
+  M3.CopyFromMat(ones.data(), 8, 5, 5);
+  M3.MulRowsVec(part);
+  std::vector<float> m3(40);
+  M3.CopyToMat(m3.data(), 5);
+  for (int i = 0; i < 8; i++) CHECK(m3[i * 5 + 2] == rowh[10 + i]);
+  // out-of-range views are assertion failures, as in the reference
+  bool threw = false;
+  try { CuSubMatrix bad(big, 40, 20, 0, 10); } catch (const std::exception &) { threw = true; }
+  CHECK(threw);
+}
+
 static void TestSoftmaxPnormCopyRows() {
   const int r = 37, c = 60;
   std::vector<float> X = RandMat(r, c, 5.f);
@@ -252,6 +321,7 @@ int main(int argc, char **argv) {
     printf("device: %s\n", CuDevice::Instantiate().DeviceGetName().c_str());
     TestAddMatMat();
     TestSoftmaxPnormCopyRows();
+    TestSubMatrixViews();
     TestDecoder();
     TestNnetGmmLattice();
     if (argc > 1) TestFeatures(argv[1]);
