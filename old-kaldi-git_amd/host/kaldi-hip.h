@@ -10,6 +10,7 @@
 //   kaldi::CuVectorBase / CuVector / CuSubVector <float>   cudamatrix/cu-vector.h
 //   kaldi::CuArray<T>          cudamatrix/cu-array.h:36-105
 //   kaldi::cu::Splice          cudamatrix/cu-math.h
+//   kaldi::DecodableInterface, DecodableMatrixMapped   itf/decodable-itf.h:82-120, decoder/decodable-matrix.h:33-84
 //   kaldi::LatticeFasterDecoderConfig / LatticeFasterDecoder
 //                              decoder/lattice-faster-decoder.h:40-205
 //   kaldi::LatticeFasterOnlineDecoder  decoder/lattice-faster-online-decoder.h:44-200
@@ -711,6 +712,53 @@ struct LatticeFasterDecoderConfig {
   }
 };
 
+/// DecodableInterface itf/decodable-itf.h:82-120 (same virtuals).
+class DecodableInterface {
+ public:
+  virtual BaseFloat LogLikelihood(int32 frame, int32 index) = 0;
+  virtual bool IsLastFrame(int32 frame) const = 0;
+  virtual int32 NumFramesReady() const {
+    throw std::runtime_error("NumFramesReady() not implemented for this decodable type.");
+  }
+  virtual int32 NumIndices() const = 0;
+  virtual ~DecodableInterface() {}
+};
+
+/// DecodableMatrixScaledMapped (decoder/decodable-matrix.h:33-84) on the device: a matrix of
+/// log-likelihoods [frames x pdfs] that is ALREADY scaled (DecodableAmNnet / the GMM scorer
+/// apply the acoustic scale when they fill it) + the TransitionIdToPdf map (index 0 unused).
+/// This is the decodable the device decoder consumes whole; LogLikelihood(frame, tid) reads
+/// one element back for host-side callers.  Neither the matrix nor the map is owned.
+class DecodableMatrixMapped : public DecodableInterface {
+ public:
+  DecodableMatrixMapped(const CuMatrixBase &likes, const CuArray<int32> &tid2pdf, const std::vector<int32> &tid2pdf_host)
+      : likes_(likes), tid2pdf_(tid2pdf), tid2pdf_host_(tid2pdf_host) {
+    KALDI_HIP_ASSERT(static_cast<MatrixIndexT>(tid2pdf_host.size()) == tid2pdf.Dim());
+    for (size_t i = 1; i < tid2pdf_host.size(); i++)
+      if (tid2pdf_host[i] < 0 || tid2pdf_host[i] >= likes.NumCols())
+        throw std::runtime_error("DecodableMatrixMapped: mismatch, matrix columns vs. pdf-ids of the transition model");
+  }
+  virtual int32 NumFramesReady() const { return likes_.NumRows(); }
+  virtual bool IsLastFrame(int32 frame) const {
+    KALDI_HIP_ASSERT(frame < NumFramesReady());
+    return frame == NumFramesReady() - 1;
+  }
+  virtual BaseFloat LogLikelihood(int32 frame, int32 tid) {
+    KALDI_HIP_ASSERT(frame >= 0 && frame < likes_.NumRows() && tid > 0 && tid < static_cast<int32>(tid2pdf_host_.size()));
+    BaseFloat v;
+    KhCheck(kh_memcpy_2d(&v, 4, likes_.Data() + static_cast<size_t>(frame) * likes_.Stride() + tid2pdf_host_[tid], 4, 4, 1, 1));
+    return v;
+  }
+  virtual int32 NumIndices() const { return static_cast<int32>(tid2pdf_host_.size()) - 1; }
+  const CuMatrixBase &Likes() const { return likes_; }
+  const int32 *TransitionIdToPdfDevice() const { return tid2pdf_.Data(); }
+
+ private:
+  const CuMatrixBase &likes_;
+  const CuArray<int32> &tid2pdf_;
+  const std::vector<int32> &tid2pdf_host_;
+};
+
 /// What DecodeUtteranceLatticeFaster (decoder-wrappers.cc:197-293) takes from the decoder.
 struct RawLattice {
   std::vector<int32> state_frame, state_hclg, arc_src, arc_dst, arc_ilabel, arc_olabel;
@@ -734,6 +782,19 @@ class LatticeFasterDecoder {
     KhCheck(kh_decoder_decode(dec_, loglikes, stride, utt_row_offsets.data(),
                               static_cast<int>(utt_row_offsets.size()) - 1, tid2pdf));
     return true;
+  }
+  /// Decode(DecodableInterface *decodable) lattice-faster-decoder.h:111-114 for ONE utterance.  The
+  /// device decoder consumes the whole matrix, so the decodable must be matrix-backed
+  /// (DecodableMatrixMapped); the decodable is not owned.  Returns true if any tokens survived.
+  bool Decode(DecodableInterface *decodable) {
+    DecodableMatrixMapped *m = dynamic_cast<DecodableMatrixMapped *>(decodable);
+    if (m == NULL) throw std::runtime_error("LatticeFasterDecoder::Decode: the device decoder needs a matrix-backed decodable");
+    std::vector<int32> off(2, 0);
+    off[1] = m->NumFramesReady();
+    Decode(m->Likes().Data(), m->Likes().Stride(), off, m->TransitionIdToPdfDevice());
+    KhDecodeStats st;
+    KhCheck(kh_decoder_get_stats(dec_, 0, &st));
+    return st.num_tokens > 0;
   }
   /// Raw lattices + best paths of the whole batch on host threads (0 = all cores);
   /// optional, the per-utterance getters compute on demand otherwise.

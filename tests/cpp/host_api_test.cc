@@ -189,6 +189,21 @@ static void TestDecoder() {
   RawLattice lat;
   CHECK(dec.GetRawLattice(0, &lat));
   CHECK(lat.state_frame.size() == 4 && lat.arc_src.size() == 3);
+  // Decode(DecodableInterface *): a matrix-backed decodable with a TransitionIdToPdf map
+  // (tid t -> pdf t - 1, what NULL meant above) gives the same result
+  {
+    std::vector<int32> t2p = {-1, 0, 1, 2};
+    CuArray<int32> t2p_dev(t2p);
+    DecodableMatrixMapped decodable(L, t2p_dev, t2p);
+    CHECK(decodable.NumFramesReady() == 3 && decodable.NumIndices() == 3 && decodable.IsLastFrame(2) && !decodable.IsLastFrame(1));
+    CHECK(decodable.LogLikelihood(1, 3) == 0.f && decodable.LogLikelihood(1, 1) == -5.f);
+    DecodableInterface *itf = &decodable;
+    CHECK(dec.Decode(itf));
+    std::vector<int32> ali2, words2;
+    float g2, a2;
+    CHECK(dec.GetBestPath(0, &ali2, &words2, &g2, &a2));
+    CHECK(ali2 == ali && words2 == words && g2 == g && a2 == a);
+  }
   // the same utterance through the online call sequence, one frame + two frames
   LatticeFasterOnlineDecoder online(fst, cfg, 2, 8);
   std::vector<int32> s1(1, 1);
