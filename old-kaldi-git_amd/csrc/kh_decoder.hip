@@ -65,11 +65,11 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 28;            // diagnostic counters per slot
+constexpr int NPH = 27;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x3fffffff;
-constexpr int EU = 2;              // chunks of NT tokens ExpandTokens scans per barrier (2: -1 %; 4 spills)
+constexpr int EU = 2;              // chunks of NT tokens an expansion group scans per barrier (2: -1 %; 4 spills)
 constexpr int KC = 4;              // chunks of NT slots the compaction moves per barrier when the slide has opened a gap
 constexpr int PU = 1;              // token / link slots a lane keeps in flight per round of a sweep (measured: 1 beats 2, 4, 8 - the sweeps are bound by the CU's address pipeline, not by latency, and more slots spill)
 constexpr uint32_t kEncInf = 0xFF800000u;  // Enc(+inf)
@@ -253,6 +253,7 @@ struct Shared {
   int bcast_i[4];
   float bcast_f[8];
   unsigned int hist[1 << 11];       // RadixSelect digit histogram (kRadixBits)
+  int ex_off[EU * NT], ex_ab[EU * NT], ex_tok[EU * NT];  // ExpandSweep: first link slot, first arc, token of the group's items
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
   int front_b;  // first token of the frame under construction (frontier)
@@ -520,15 +521,18 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
   return -1;
 }
 
-// First half of an expansion sweep over the tokens [b, e) (kEps: over entries [b, e) of
-// tmp_epslist, the tokens whose state has epsilon arcs): every token whose cost
-// is <= cutoff gets one link slot per arc of its HCLG state (arc ranges `off`),
-// appended at link slot `lrun` on in token order; the slots are seeded with
-// (link_src = token, link_dst = arc index) for the link-parallel second half.
+// Expansion sweep over the tokens [b, e) (kEps: over entries [b, e) of tmp_epslist, the
+// tokens whose state has epsilon arcs): every token whose cost is <= cutoff gets one link
+// slot per arc of its HCLG state (arc ranges `off`), appended at link slot `lrun` on in token
+// order, and body(link slot, token, arc index) runs once per slot, link-parallel.
+// Per group of EU * NT tokens: a token sweep (cost, state, arc range), ONE scan that assigns
+// the slots, the items' (first slot, first arc, token) through LDS, then one lane per slot
+// finds its owner by binary search over the first slots (11 LDS reads) — no seed arrays in
+// global memory, no per-token store loops.
 // Returns the new end of the link arena, or -1 on overflow (sh->status set).
-template <bool kEps>
-__device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
-                            int frame_cap, long long *arcs, Blk &sh) {
+template <bool kEps, class Body>
+__device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
+                                           int frame_cap, long long *arcs, Blk &sh, Body body) {
   const int lrun0 = lrun;
   for (int base = b; base < e; base += NT * EU) {
     int i[EU], st[EU];
@@ -556,6 +560,7 @@ __device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, 
       }
     }
     int loff[EU], total;
+    // (this barrier also orders the previous group's LDS reads before the writes below)
     BlockExScanK<EU>(cnt, loff, &total, sh);
     if (lrun + total > u.link_cap || lrun + total - lrun0 > frame_cap) {
       if (threadIdx.x == 0) sh->status = (lrun + total > u.link_cap) ? 2 : 3;
@@ -563,19 +568,26 @@ __device__ int ExpandTokens(const Utt &u, Arr<const int32_t> off, int b, int e, 
       return -1;
     }
 #pragma unroll
-    for (int k = 0; k < EU; k++) {
-      if (!in_range[k]) continue;
-      int l0 = lrun + loff[k];
-      KH_BOUND(2, l0, 0, u.link_cap - cnt[k] + 1);
-      for (int j = 0; j < cnt[k]; j++) {
-        u.link_src[l0 + j] = i[k];
-        u.link_dst[l0 + j] = ab[k] + j;
-      }
-      *arcs += cnt[k];
+    for (int k = 0; k < EU; k++) {  // slice-major item order = the scan's order: ex_off is non-decreasing
+      sh->ex_off[k * NT + threadIdx.x] = loff[k];
+      sh->ex_ab[k * NT + threadIdx.x] = ab[k];
+      sh->ex_tok[k * NT + threadIdx.x] = i[k];
     }
+    KhSync();
+    for (int q = threadIdx.x; q < total; q += NT) {
+      // owner = the LAST item whose first slot is <= q (items without arcs share their
+      // successor's first slot and are skipped by "last")
+      int lo = 0, hi = EU * NT - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (sh->ex_off[mid] <= q) lo = mid; else hi = mid - 1;
+      }
+      body(lrun + q, sh->ex_tok[lo], sh->ex_ab[lo] + (q - sh->ex_off[lo]));
+    }
+    if (threadIdx.x == 0) *arcs += total;
     lrun += total;
   }
-  KhSync();  // the seeds are visible to the link sweep
+  KhSync();  // the links are visible to the next phase
   return lrun;
 }
 
@@ -710,53 +722,30 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   const int fe = Uni(sh->tok_end);
   const int blk_b = Uni(sh->link_end);
   long long seeded = 0;
-  const int blk_e = ExpandTokens<true>(u, p.n_off, 0, Uni(sh->eps_n), cutoff, blk_b, u.link_frame_cap, &seeded, sh);
+  const int blk_e = ExpandSweep<true>(
+      u, p.n_off, 0, Uni(sh->eps_n), cutoff, blk_b, u.link_frame_cap, &seeded, sh, [&](int l, int src, int ai) {
+        KH_BOUND(3, src, 0, u.tok_cap);
+        KH_BOUND(4, ai, 0, p.num_eps);
+        const KhInt4 arc = p.n_arcs[ai];
+        const uint32_t co = LoadCostEnc(&u.tok_cost[src]);
+        const float g = __int_as_float(arc.z), tot_cost = Dec(co) + g;
+        int dst = -1;
+        if (tot_cost < cutoff) {  // the token exists already
+          const uint32_t slot = HashState(arc.w & kStateMask) & u.hash_mask;
+          const unsigned long long ent = __hip_atomic_load(&u.hash[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dst = FindExisting(u, arc.w & kStateMask, ent, slot);
+        }
+        u.link_dst[l] = dst;
+        u.link_src[l] = src;
+        u.link_il[l] = 0;
+        u.link_ol[l] = arc.y;
+        u.link_g[l] = g;
+        // The acoustic cost of an epsilon link is 0; its field holds the constant part of
+        // link_extra_cost (:309-311) instead, (cost[src] + 0 + g) - cost[dst]: both costs
+        // are final once the closure has converged.
+        u.link_a[l] = dst >= 0 ? (Dec(co) + 0.0f + g) - Dec(LoadCostEnc(&u.tok_cost[dst])) : 0.0f;
+      });
   if (blk_e < 0) return false;
-  for (int base = blk_b + threadIdx.x; base < blk_e; base += NT * PU) {
-    int l[PU], src[PU], ai[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      l[k] = min(base + k * NT, blk_e - 1);
-      src[k] = u.link_src[l[k]];
-      ai[k] = u.link_dst[l[k]];
-      // a lane past the end re-reads the last slot, which its owner may already have
-      // rewritten: only the loaded values of in-range lanes are seeds
-      if (base + k * NT >= blk_e) { src[k] = fb; ai[k] = 0; }
-      KH_BOUND(3, src[k], 0, u.tok_cap);
-      KH_BOUND(4, ai[k], 0, p.num_eps);
-    }
-    KhInt4 arc[PU];
-    uint32_t co[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      arc[k] = p.n_arcs[ai[k]];
-      co[k] = LoadCostEnc(&u.tok_cost[src[k]]);
-    }
-    bool live[PU];
-    uint32_t slot[PU];
-    unsigned long long ent[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      const float tot_cost = Dec(co[k]) + __int_as_float(arc[k].z);
-      live[k] = base + k * NT < blk_e && tot_cost < cutoff;
-      slot[k] = HashState(arc[k].w & kStateMask) & u.hash_mask;
-      ent[k] = __hip_atomic_load(&u.hash[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      if (base + k * NT >= blk_e) continue;
-      const int dst = live[k] ? FindExisting(u, arc[k].w & kStateMask, ent[k], slot[k]) : -1;  // the token exists already
-      const float g = __int_as_float(arc[k].z);
-      u.link_dst[l[k]] = dst;
-      u.link_il[l[k]] = 0;
-      u.link_ol[l[k]] = arc[k].y;
-      u.link_g[l[k]] = g;
-      // The acoustic cost of an epsilon link is 0; its field holds the constant part of
-      // link_extra_cost (:309-311) instead, (cost[src] + 0 + g) - cost[dst]: both costs
-      // are final once the closure has converged.
-      u.link_a[l[k]] = dst >= 0 ? (Dec(co[k]) + 0.0f + g) - Dec(LoadCostEnc(&u.tok_cost[dst])) : 0.0f;
-    }
-  }
   KhSync();
   if (threadIdx.x == 0) sh->link_end = blk_e;
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
@@ -821,47 +810,27 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // min(tot_cost + adaptive_beam).
   const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
-  const int link_frame_e = ExpandTokens<false>(u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh);
+  const int link_frame_e = ExpandSweep<false>(
+      u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, [&](int l, int src, int ai) {
+        KH_BOUND(5, src, 0, u.tok_cap);
+        KH_BOUND(6, ai, 0, p.num_emit);
+        const KhInt4 arc = p.e_arcs[ai];
+        const uint32_t co = LoadCostEnc(&u.tok_cost[src]);
+        int32_t pdf = p.tid2pdf ? p.tid2pdf[arc.x] : arc.x - 1;
+        KH_BOUND(7, pdf, 0, u.ll_stride);
+        const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
+        const float ac_cost = cost_offset - like, graph_cost = __int_as_float(arc.z),
+                    tot_cost = Dec(co) + ac_cost + graph_cost;  // :726-730
+        u.link_dst[l] = arc.w;  // HCLG next state for now; token index after pass 2
+        u.link_src[l] = src;
+        u.link_il[l] = arc.x;
+        u.link_ol[l] = arc.y;
+        u.link_g[l] = graph_cost;
+        u.link_a[l] = ac_cost;
+        u.link_tot[l - link_frame_b] = tot_cost;
+        est = fminf(est, tot_cost + c.adaptive_beam);
+      });
   if (link_frame_e < 0) return false;
-  for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * PU) {
-    int l[PU], src[PU], ai[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      l[k] = min(base + k * NT, link_frame_e - 1);
-      src[k] = u.link_src[l[k]];
-      ai[k] = u.link_dst[l[k]];
-      if (base + k * NT >= link_frame_e) { src[k] = b; ai[k] = 0; }  // see ProcessNonemitting
-      KH_BOUND(5, src[k], 0, u.tok_cap);
-      KH_BOUND(6, ai[k], 0, p.num_emit);
-    }
-    KhInt4 arc[PU];
-    uint32_t co[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      arc[k] = p.e_arcs[ai[k]];
-      co[k] = LoadCostEnc(&u.tok_cost[src[k]]);
-    }
-    int32_t pdf[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++) { pdf[k] = p.tid2pdf ? p.tid2pdf[arc[k].x] : arc[k].x - 1; KH_BOUND(7, pdf[k], 0, u.ll_stride); }
-    float like[PU];
-#pragma unroll
-    for (int k = 0; k < PU; k++)
-      like[k] = p.ll_cols > 0 ? sh.ll_row[pdf[k]] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf[k]];
-#pragma unroll
-    for (int k = 0; k < PU; k++) {
-      if (base + k * NT >= link_frame_e) continue;
-      const float ac_cost = cost_offset - like[k], graph_cost = __int_as_float(arc[k].z),
-                  tot_cost = Dec(co[k]) + ac_cost + graph_cost;  // :726-730
-      u.link_dst[l[k]] = arc[k].w;  // HCLG next state for now; token index after pass 2
-      u.link_il[l[k]] = arc[k].x;
-      u.link_ol[l[k]] = arc[k].y;
-      u.link_g[l[k]] = graph_cost;
-      u.link_a[l[k]] = ac_cost;
-      u.link_tot[l[k] - link_frame_b] = tot_cost;
-      est = fminf(est, tot_cost + c.adaptive_beam);
-    }
-  }
   // final next_cutoff: the value the reference's running cutoff converges to
   const float next_cutoff = BlockMinF(est, sh);
   Stamp(u, sh, 1);
@@ -2074,7 +2043,8 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.num_eps = static_cast<int32_t>(d->fst->num_eps);
   p.start_has_eps = d->fst->start_has_eps;
   // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
-  p.ll_cols = ll_stride <= 12288 ? ll_stride : 0;
+  // the score row shares the workgroup's 64 KB of LDS with the static block (Shared)
+  p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 64 * 1024) ? ll_stride : 0;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.tid2pdf = (GP(const int32_t))tid2pdf;
   p.max_tid = d->fst->max_ilabel;
