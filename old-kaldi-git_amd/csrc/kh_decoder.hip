@@ -1783,9 +1783,11 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   const long long stable_tok = std::max<long long>(65536, per_frame * (T + 2));
   const long long tok_cap = stable_tok + win_frames * tok_frame_cap;
   const long long link_cap = 3 * stable_tok + win_frames * link_frame_cap;
-  u.window_cap = static_cast<int32_t>(std::min<long long>(tok_cap, 0x7fffffff));
-  u.tok_cap = static_cast<int32_t>(std::min<long long>(tok_cap, 0x7fffffff));
-  u.link_cap = static_cast<int32_t>(std::min<long long>(link_cap, 0x7fffffff));
+  // every arena array holds 4-byte elements addressed with a 32-bit byte offset (Arr<T>): < 2^30 slots
+  const long long kMaxSlots = (1ll << 30) - 1;
+  u.window_cap = static_cast<int32_t>(std::min<long long>(tok_cap, kMaxSlots));
+  u.tok_cap = static_cast<int32_t>(std::min<long long>(tok_cap, kMaxSlots));
+  u.link_cap = static_cast<int32_t>(std::min<long long>(link_cap, kMaxSlots));
   const size_t nt = u.tok_cap, nl = u.link_cap;
   u.tok_state = c.Take<int32_t>(nt);
   u.tok_cost = c.Take<uint32_t>(nt);
@@ -2123,11 +2125,12 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
     return nullptr;
   }
   const int64_t na = arc_offsets[num_states];
-  if (na >= (int64_t(1) << 31)) {
-    SetError("kh_fst_create: %lld arcs exceed int32 indexing", static_cast<long long>(na));
+  // the kernels address the arc tables with 32-bit byte offsets (Arr<T>): 16 bytes per arc
+  if (na >= (int64_t(1) << 28)) {
+    SetError("kh_fst_create: %lld arcs exceed the 2^28 arcs a 32-bit byte offset reaches", static_cast<long long>(na));
     return nullptr;
   }
-  if (num_states > kStateMask) {
+  if (num_states >= kStateMask) {  // (also keeps the (num_states + 1) x 4-byte offset tables under 4 GiB)
     SetError("kh_fst_create: %d states exceed the 30-bit state ids of the arc records", num_states);
     return nullptr;
   }
