@@ -8,8 +8,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkaldi_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-inline-max-bb: the AMDGPU inliner stops inlining into a function that has grown past
+# 1100 basic blocks.  The persistent decoder kernel is larger; past the cap its phases become
+# real calls that take the arena descriptor by reference, which pins that 400-byte struct in
+# scratch memory (every pointer fetched with scratch_load: 1.3x slower kernel, and the cliff
+# moved whenever any phase grew).  All device functions of this library are meant to be inlined.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__"]
+         "-fno-fast-math", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__",
+         "-mllvm", "-amdgpu-inline-max-bb=100000"]
 
 
 def sources():

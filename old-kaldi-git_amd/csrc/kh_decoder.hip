@@ -1044,6 +1044,103 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   *links_pruned = (all & 2) != 0;
 }
 
+// PruneForwardLinks :273-344 (+ PruneTokensForFrame(f + 1) when prune_toks_f1) for a SMALL
+// frame: at most kSmallTok tokens in frames f and f + 1 and one link per lane.  Most visits
+// of the backward pruning are of this kind (a frame more than ~2 prune intervals old holds
+// a handful of tokens), and there the general routine is a chain of ~10 dependent global
+// round trips.  Here everything the visit needs is read ONCE (one round trip), the fixed
+// point runs on LDS accumulators, and the results are written back: same float operations,
+// same unique fixed point.
+constexpr int kSmallTok = 256;
+__device__ void PruneSmallFrame(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
+                                bool prune_toks_f1, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
+  static_assert(EU * NT >= 4 * kSmallTok, "the expansion's LDS arrays are reused here");
+  const float inf = INFINITY, lb = p.lattice_beam;
+  const int t = threadIdx.x;
+  auto s_cost = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_off[0]);            // cost of f's tokens
+  auto s_acc0 = reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(&sh->ex_off[kSmallTok]);  // Enc(min) over emitting links
+  auto s_acc1 = reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(&sh->ex_off[2 * kSmallTok]);  // ... over epsilon links
+  auto s_x = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_off[3 * kSmallTok]);    // extra_cost being computed
+  auto s_nc = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_ab[0]);               // cost of f + 1's tokens
+  auto s_nx = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_ab[kSmallTok]);       // extra_cost of f + 1's tokens
+  if (u.phase_cycles != nullptr && t == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; sh->phase[14] += 1; }
+  // ---- everything the visit reads, in one round trip
+  int st = -1;
+  float old = 0.0f;
+  if (t < e - b) {
+    st = u.tok_state[b + t];
+    old = LoadExtra(&u.tok_extra[b + t]);
+    s_cost[t] = Dec(LoadCostEnc(&u.tok_cost[b + t]));
+    s_acc0[t] = kEncInf;
+    s_acc1[t] = kEncInf;
+  }
+  if (t < e1 - b1) {
+    const float nx = LoadExtra(&u.tok_extra[b1 + t]);
+    s_nc[t] = Dec(LoadCostEnc(&u.tok_cost[b1 + t]));
+    s_nx[t] = nx;
+    // PruneTokensForFrame(f + 1) :450-469: its extra_costs are final
+    if (prune_toks_f1 && nx == inf && u.tok_state[b1 + t] >= 0) u.tok_state[b1 + t] = -1;
+  }
+  int m_dst = -1, m_src = 0, n_dst = -1, n_src = 0;
+  float m_a = 0.0f, m_g = 0.0f, n_a = 0.0f;
+  if (t < me - mb) { m_dst = u.link_dst[mb + t]; m_src = u.link_src[mb + t]; m_a = u.link_a[mb + t]; m_g = u.link_g[mb + t]; }
+  if (t < ne - nb) { n_dst = u.link_dst[nb + t]; n_src = u.link_src[nb + t]; n_a = u.link_a[nb + t]; }
+  KhSync();
+  // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
+  int flags = 0;
+  if (m_dst >= 0) {
+    float lec = s_nx[m_dst - b1] + ((s_cost[m_src - b] + m_a + m_g) - s_nc[m_dst - b1]);
+    if (lec > lb) {
+      u.link_dst[mb + t] = -1;
+      flags |= 2;
+    } else {
+      if (lec < 0.0f) lec = 0.0f;
+      __hip_atomic_fetch_min(&s_acc0[m_src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  KhSync();
+  if (t < e - b) s_x[t] = Dec(s_acc0[t]);
+  // ---- epsilon links (inside the frame): iterate to the fixed point
+  if (ne > nb) {
+    for (;;) {
+      KhSync();
+      if (n_dst >= 0) {
+        float lec = s_x[n_dst - b] + n_a;  // the parenthesis of :309-311 was evaluated when the link was created
+        if (!(lec > lb)) {
+          if (lec < 0.0f) lec = 0.0f;
+          __hip_atomic_fetch_min(&s_acc1[n_src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      KhSync();
+      bool changed = false;
+      if (t < e - b) {
+        const uint32_t a0 = s_acc0[t], a1 = s_acc1[t];
+        const float v = Dec(a1 < a0 ? a1 : a0);
+        changed = !(v == s_x[t]);
+        s_x[t] = v;
+        s_acc1[t] = kEncInf;
+      }
+      if (u.phase_cycles != nullptr && t == 0) sh->phase[14] += 1;
+      if (!BlockAny(changed, sh)) break;
+    }
+    if (n_dst >= 0 && s_x[n_dst - b] + n_a > lb) {  // excise :315
+      u.link_dst[nb + t] = -1;
+      flags |= 2;
+    }
+  } else {
+    KhSync();
+  }
+  // ---- write back; :334 counts the tokens whose extra_cost moved by more than delta
+  if (t < e - b && st >= 0) {
+    const float v = s_x[t];
+    if (!(v == old)) StoreExtra(&u.tok_extra[b + t], v);
+    if (fabsf(v - old) > delta) flags |= 1;
+  }
+  const int all = BlockOr(flags, sh);
+  *extra_costs_changed = (all & 1) != 0;
+  *links_pruned = (all & 2) != 0;
+}
+
 // PruneTokensForFrame :450-469
 __device__ void PruneTokensForFrame(const Utt &u, int b, int e) {
   for (int i = b + threadIdx.x; i < e; i += NT)
@@ -1074,8 +1171,12 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     if (u.phase_cycles != nullptr && threadIdx.x == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (ml) {
       bool ec, lp;
-      PruneForwardLinks(u, p, Uni(u.frame_b[f]), Uni(u.frame_e[f]), Uni(u.femit_b[f]), Uni(u.femit_e[f]), Uni(u.feps_b[f]), Uni(u.feps_e[f]),
-                        delta, false, false, 0.f, mt ? Uni(u.frame_b[f + 1]) : 0, mt ? Uni(u.frame_e[f + 1]) : 0, &ec, &lp, sh);
+      const int b = Uni(u.frame_b[f]), e = Uni(u.frame_e[f]), mb = Uni(u.femit_b[f]), me = Uni(u.femit_e[f]),
+                nb = Uni(u.feps_b[f]), ne = Uni(u.feps_e[f]), b1 = Uni(u.frame_b[f + 1]), e1 = Uni(u.frame_e[f + 1]);
+      if (e - b <= kSmallTok && e1 - b1 <= kSmallTok && me - mb <= NT && ne - nb <= NT)
+        PruneSmallFrame(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
+      else
+        PruneForwardLinks(u, p, b, e, mb, me, nb, ne, delta, false, false, 0.f, mt ? b1 : 0, mt ? e1 : 0, &ec, &lp, sh);
       if (threadIdx.x == 0) {
         if (ec && f > 0) StoreFlag(&u.must_links[f - 1], 1);
         if (lp) StoreFlag(&u.must_toks[f], 1);
