@@ -304,7 +304,7 @@ def main():
                          "arcs_expanded_per_launch": stats["arcs"], "tokens_created_per_launch": stats["toks"]},
             "loglike_per_frame": stats["tot_like"] / frames,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU legs run at N = 1 only
             v, desc, all_cores = cpu_baseline(net, priors, g, feats, off, args.cpu_frames)
             out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port", "sample": desc,
                                    "all_cores": all_cores}
