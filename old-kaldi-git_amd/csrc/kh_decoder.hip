@@ -2347,8 +2347,13 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
                      : std::min<long long>(65536, 3ll * cfg->max_active + 4096);
   if (const char *e = getenv("KH_DECODER_TOKENS_PER_FRAME")) tf = atoll(e);
   d->tok_frame_cap = static_cast<int>(tf);
-  // tokens a frame is sized for in the hash (hash_ratio x this many entries)
-  d->expected_tokens = d->tok_frame_cap;
+  // tokens a frame is sized for in the hash (hash_ratio x this many entries): what a frame typically
+  // holds - the reference resizes to hash_ratio x the previous frame's count (:219-225), which
+  // max_active bounds before the closure adds to it - not the per-frame capacity; the table never
+  // has fewer entries than that capacity (CarveSlot), so every token of a frame finds a slot
+  d->expected_tokens = cfg->max_active == std::numeric_limits<int32_t>::max()
+                           ? d->tok_frame_cap
+                           : static_cast<int>(std::min<long long>(d->tok_frame_cap, cfg->max_active + cfg->max_active / 2));
   if (const char *e = getenv("KH_DECODER_HASH_TOKENS")) d->expected_tokens = atoi(e);
   long long lf = 3 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
