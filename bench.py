@@ -9,17 +9,31 @@ DecodableAmNnet's floor/log/-log prior/x acwt)  ->  LatticeFasterDecoder over th
 whole shard (beam 15, max-active 7000, min-active 200, lattice-beam 8, acwt 0.1:
 steps/nnet2/decode.sh:14-20)  ->  raw lattice + best path of every utterance
 (what DecodeUtteranceLatticeFaster takes from the decoder,
-decoder-wrappers.cc:232-262; lattice determinization is outside SURVEY.md §8).
+decoder-wrappers.cc:232-262).
 
-Workload ("librispeech_nnet_a_synthetic"): no corpus or trained model is
+Workload ("librispeech_nnet_a_structured"): no corpus or trained model is
 available offline, so everything is seeded synthetic data of the reference
 recipe's shape: nnet_a 140 -> 700 -> 4x(3500/350) ->
-12000 -> 5800 pdfs with random weights, a random HCLG-like graph with 10 M
-states / ~25 M arcs, and per GPU a test-clean-sized set of 2620 utterances
-(~1.94 M frames, LibriSpeech-like length distribution).  Multi-GPU = utterance
-sharding (weak scaling: every rank decodes its own 2620-utterance set); the only
-collective is the final all-reduce of {frames, utterances, tot_like}
-(nnet-latgen-faster.cc:100-101,133-135) over RCCL.
+12000 -> 5800 pdfs with random weights (biases centred so that the outputs depend
+on the input, workloads.calibrate_biases), an HCLG-STRUCTURED graph of ~10 M
+states (per LM state a prefix tree of pronunciations, 3-state HMM chains with
+self-loops, pushed LM costs, back-off epsilon arcs: workloads.make_hclg_structured),
+and per GPU a test-clean-sized set of 2620 utterances (~1.94 M frames).  Every
+utterance follows a random path through the graph and its features make the
+network score that path's pdfs (workloads.make_path_features), so the search
+behaves like a real decode: a true hypothesis, competing ones that reconverge,
+lattices of tens of arcs per frame.
+
+Launch.  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts
+the N ranks itself (a child `python -m torch.distributed.run`, created BEFORE this
+process touches a GPU; the parent only relays output and the exit code).  Under
+torchrun (WORLD_SIZE set) the process is one rank.  Multi-GPU = utterance
+sharding with no data-path collective; the only collective is the final
+all-reduce of {frames, utterances, tot_like} (nnet-latgen-faster.cc:100-101,
+133-135) over RCCL.  The headline value is WEAK scaling (every rank decodes its own
+2620-utterance set); for N > 1 the line also carries a "strong_scaling" object:
+ONE 2620-utterance set sharded by sharding.partition_utterances, as the recipes
+split one data set over $nj jobs (steps/nnet2/decode.sh:130-136).
 
 RTF = elapsed * 100 / frames (nnet-latgen-faster.cc:179-182).
 """
@@ -27,6 +41,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -39,30 +54,81 @@ PKG = "old-kaldi-git_amd"
 
 ACWT = 0.1
 DECODE_CFG = dict(beam=15.0, max_active=7000, min_active=200, lattice_beam=8.0)
+FEATURE_NOISE = 0.10          # N(0, .) on the prototype part of the features: sets the frame accuracy (~0.9)
 
 
-def build_workload(seed, rank, n_utts, graph_states, small=False):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--utts", type=int, default=2620, help="utterances per GPU (test-clean has 2620)")
+    ap.add_argument("--graph-states", type=int, default=10_000_000)
+    ap.add_argument("--small", action="store_true", help="tiny model/graph for a quick functional run")
+    ap.add_argument("--cpu-utts", type=int, default=20, help="utterances of the single-thread CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg at N > 1")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (config 2 / 5) legs")
+    ap.add_argument("--no-gpu-dryrun", action="store_true",
+                    help="launcher / sharding / reduction only (gloo, no GPU, nothing decoded): CPU test of the multi-rank path")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`--gpus N` without a torchrun environment: start the N ranks as a child process
+    tree and relay its result.  This process never initialises a GPU."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+def build_model_and_graph(seed, graph_states, small):
     workloads = importlib.import_module(PKG + ".workloads")
     rng = np.random.default_rng(seed)           # model + graph: identical on every rank
     if small:
-        net, priors = workloads.make_pnorm_net(rng, feat_dim=40, splice=2, const_dim=10, pnorm_in=400,
-                                               pnorm_out=40, n_hidden=2, n_mix=600, n_pdf=300, final_scale=2.0)
+        net, _ = workloads.make_pnorm_net(rng, feat_dim=40, splice=2, const_dim=20, pnorm_in=400,
+                                          pnorm_out=40, n_hidden=2, n_mix=600, n_pdf=300, final_scale=14.0)
     else:
-        net, priors = workloads.librispeech_nnet_a(rng, final_scale=2.0)
+        net, _ = workloads.librispeech_nnet_a(rng, final_scale=14.0)
+    priors = workloads.calibrate_biases(np.random.default_rng(seed + 1), net)
     n_pdf = net[-1]["output_dim"]
-    g = workloads.make_hclg_like(rng, graph_states, n_pdf)
-    urng = np.random.default_rng(seed * 1000 + 17 + rank)   # this rank's utterances
+    g = workloads.make_hclg_structured(np.random.default_rng(seed + 2), graph_states, n_pdf)
+    protos, _ = workloads.make_pdf_prototypes(np.random.default_rng(seed + 3), net, priors,
+                                              n_candidates=4096 if small else 16384)
+    return net, priors, g, protos
+
+
+def build_utterances(seed, set_id, n_utts, net, g, protos, small):
+    """One test-clean-sized set of utterances: lengths, true paths, features."""
+    workloads = importlib.import_module(PKG + ".workloads")
+    urng = np.random.default_rng(seed * 1000 + 17 + set_id)
     if small:
         lens = urng.integers(40, 120, n_utts)
     else:
         lens = workloads.utterance_lengths(urng, n_utts)
     lens = np.sort(lens)[::-1].copy()            # longest first (SURVEY §8e)
+    seqs = workloads.sample_paths(urng, g, lens)
+    feats = workloads.make_path_features(urng, net, protos, seqs, noise=FEATURE_NOISE)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    feats = urng.standard_normal((int(off[-1]), net[0]["input_dim"])).astype(np.float32)
-    return net, priors, g, feats, off
+    return feats, off
 
 
-def forward_all(api, torch, nnet, feats_d, off, loglikes, max_rows):
+def take_utterances(feats, off, idx):
+    """Sub-shard (features, offsets) of the utterances `idx` (kept longest first)."""
+    idx = sorted((int(i) for i in idx), key=lambda u: -(int(off[u + 1]) - int(off[u])))
+    parts = [feats[off[u]:off[u + 1]] for u in idx]
+    lens = np.array([len(p) for p in parts], np.int64)
+    f = np.concatenate(parts) if parts else np.zeros((0, feats.shape[1]), np.float32)
+    return f, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+def forward_all(nnet, feats_d, off, loglikes, max_rows):
     """nnet forward in groups of utterances (bounds the activation buffers)."""
     u0 = 0
     n = len(off) - 1
@@ -76,53 +142,57 @@ def forward_all(api, torch, nnet, feats_d, off, loglikes, max_rows):
         u0 = u1
 
 
-def cpu_baseline(net, priors, g, feats, off, budget_frames):
-    """The reference CPU path on a bounded sample of the same workload, 1 thread:
-    nnet2 forward through the reference's own compiled CPU code when oracle/_ref
-    exists (cblas_sgemm as in the reference), else the restatement; decoding by
-    the restatement in reference-iteration-order mode (the reference decoder cannot
-    be compiled here).  Returns (frames_per_sec, description)."""
-    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-    from oracle import binding
-    fwd = binding.OracleLib("ref") if binding.have_ref() else binding.OracleLib("ko")
-    # utterances closest to the median length until the frame budget is reached (the
-    # shortest ones would over-weight the cheap first frames of every utterance)
-    lens = np.diff(off)
-    order = np.argsort(np.abs(lens - np.median(lens)), kind="stable")
-    sample, tot = [], 0
-    for u in order:
-        T = int(off[u + 1] - off[u])
-        if sample and tot + T > budget_frames:
-            break
-        sample.append(int(u))
-        tot += T
+# ---------------------------------------------------------------- CPU baseline
+def _cpu_decode_one(binding, fwd, net, priors, g, x):
     dec = binding.DecoderOracle(g, binding.decoder_config(**DECODE_CFG), "reference")
-    t0 = time.perf_counter()
-    t_fwd = 0.0
-    for u in sample:
-        x = feats[off[u]:off[u + 1]]
-        a = time.perf_counter()
-        ll = fwd.decodable_am_nnet(net, priors, ACWT, x)
-        t_fwd += time.perf_counter() - a
-        dec.decode(ll)
-        dec.best_path()
-        dec.raw_lattice()
-    el = time.perf_counter() - t0
-    desc = ("%d median-length utterances of the rank-0 shard (%d frames): nnet2 forward via %s, "
-            "LatticeFasterDecoder restatement in reference iteration order, 1 thread; "
-            "forward %.1f s + decode %.1f s" %
-            (len(sample), tot, "compiled reference (oracle/_ref, OpenBLAS sgemm)" if fwd.kind == "ref" else "restatement",
-             t_fwd, el - t_fwd))
-    # (ii) many host cores, one utterance per PROCESS — how the recipes' $nj jobs /
-    # nnet-latgen-faster-parallel use a machine (SURVEY §8d).  Forked workers share the graph and
-    # the model copy-on-write and run CPU code only (they never touch the GPU and leave through
-    # os._exit); bounded: at most 32 workers, 120 s.
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_proc = max(1, min(cores, 32, len(order)))
-    mine = [int(u) for u in order[:n_proc]]
-    all_cores = None
-    if hasattr(os, "fork"):
-        import signal
+    a = time.perf_counter()
+    ll = fwd.decodable_am_nnet(net, priors, ACWT, x)
+    t_fwd = time.perf_counter() - a
+    dec.decode(ll)
+    dec.best_path()
+    dec.raw_lattice()
+    return t_fwd
+
+
+def cpu_baseline_child(rfd, wfd, net, priors, g, feats, off, n_utts_1t):
+    """Runs in a process forked BEFORE the parent initialised the GPU (it never touches
+    one): waits for the parent's go (the GPU timing is over), then times the reference
+    CPU path on a bounded sample of the same workload and writes one JSON line back.
+      (i)  1 thread, `n_utts_1t` median-length utterances: nnet2 forward through the
+           reference's own compiled code when oracle/_ref exists (cblas_sgemm as in the
+           reference), else the restatement; LatticeFasterDecoder = the restatement in
+           reference iteration order (the reference decoder needs OpenFst: not buildable);
+      (ii) every host core, one utterance per PROCESS — how the recipes' $nj jobs /
+           nnet-latgen-faster-parallel use a machine."""
+    import signal
+    out = {}
+    try:
+        os.read(rfd, 1)
+        os.environ["OPENBLAS_NUM_THREADS"] = "1"
+        os.environ["OMP_NUM_THREADS"] = "1"
+        from oracle import binding
+        fwd = binding.OracleLib("ref") if binding.have_ref() else binding.OracleLib("ko")
+        lens = np.diff(off)
+        order = np.argsort(np.abs(lens - np.median(lens)), kind="stable")
+        sample = [int(u) for u in order[:max(1, n_utts_1t)]]
+        tot = int(sum(lens[u] for u in sample))
+        t0 = time.perf_counter()
+        t_fwd = 0.0
+        for u in sample:
+            t_fwd += _cpu_decode_one(binding, fwd, net, priors, g, feats[off[u]:off[u + 1]])
+        el = time.perf_counter() - t0
+        out["value"] = tot / el
+        out["kind"] = "port"
+        out["cores"] = 1
+        out["sample"] = ("%d median-length utterances of the rank-0 shard (%d frames): nnet2 forward via %s, "
+                         "LatticeFasterDecoder restatement in reference iteration order, 1 thread; "
+                         "forward %.1f s + decode %.1f s" %
+                         (len(sample), tot,
+                          "compiled reference (oracle/_ref, OpenBLAS sgemm)" if fwd.kind == "ref" else "restatement",
+                          t_fwd, el - t_fwd))
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        n_proc = max(1, min(cores, len(order)))
+        mine = [int(u) for u in order[:n_proc]]
         t1 = time.perf_counter()
         pids = []
         for k in range(n_proc):
@@ -130,16 +200,12 @@ def cpu_baseline(net, priors, g, feats, off, budget_frames):
             if pid == 0:
                 rc = 1
                 try:
-                    x = feats[off[mine[k]]:off[mine[k] + 1]]
-                    d2 = binding.DecoderOracle(g, binding.decoder_config(**DECODE_CFG), "reference")
-                    d2.decode(fwd.decodable_am_nnet(net, priors, ACWT, x))
-                    d2.best_path()
-                    d2.raw_lattice()
+                    _cpu_decode_one(binding, fwd, net, priors, g, feats[off[mine[k]]:off[mine[k] + 1]])
                     rc = 0
                 finally:
                     os._exit(rc)
             pids.append(pid)
-        ok, deadline = True, time.time() + 120.0
+        ok, deadline = True, time.time() + 180.0
         for pid in pids:
             while True:
                 done, status = os.waitpid(pid, os.WNOHANG)
@@ -153,104 +219,135 @@ def cpu_baseline(net, priors, g, feats, off, budget_frames):
                     break
                 time.sleep(0.01)
         el_all = time.perf_counter() - t1
-        tot_all = int(sum(off[u + 1] - off[u] for u in mine))
-        if ok:
-            all_cores = {"value": tot_all / el_all, "unit": "frames/s", "cores": n_proc,
-                         "sample": "%d median-length utterances (%d frames), one per process on %d host cores, %.1f s"
-                                   % (n_proc, tot_all, cores, el_all)}
-    return tot / el, desc, all_cores
+        tot_all = int(sum(lens[u] for u in mine))
+        out["all_cores"] = ({"value": tot_all / el_all, "unit": "frames/s", "cores": n_proc,
+                             "sample": "%d median-length utterances (%d frames), one per process on %d host cores, %.1f s"
+                                       % (n_proc, tot_all, cores, el_all)} if ok else None)
+    except BaseException as e:  # the parent reports the failure
+        out = {"error": repr(e)}
+    finally:
+        os.write(wfd, (json.dumps(out) + "\n").encode())
+        os._exit(0)
 
 
-def measured_traffic(args, n_utts, world):
+def start_cpu_baseline(net, priors, g, feats, off, n_utts_1t):
+    go_r, go_w = os.pipe()
+    res_r, res_w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(go_w)
+        os.close(res_r)
+        cpu_baseline_child(go_r, res_w, net, priors, g, feats, off, n_utts_1t)
+    os.close(go_r)
+    os.close(res_w)
+    return pid, go_w, res_r
+
+
+def finish_cpu_baseline(handle):
+    pid, go_w, res_r = handle
+    os.write(go_w, b"g")
+    buf = b""
+    while True:
+        chunk = os.read(res_r, 65536)
+        if not chunk:
+            break
+        buf += chunk
+    os.waitpid(pid, 0)
+    return json.loads(buf.decode().strip().splitlines()[-1]) if buf.strip() else {"error": "no result"}
+
+
+# ---------------------------------------------------------------- profiles
+def measured_traffic(args, world):
     """HBM bytes per DecodeKernel launch from the PMC passes committed under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, tools/collect_profiles.sh):
-    counters cannot be read inside this process.  Only quoted for the workload they
-    were measured on (the default one, 1 GPU); FETCH_SIZE + WRITE_SIZE are in KB and
-    taken as reported (MI355X guide: FETCH_SIZE is exact for 64-B requests and halves
-    wide coalesced reads, so this is a lower bound)."""
+    counters cannot be read inside this process, so this is a RECORDED figure, quoted only
+    for the workload it was measured on (the default one, 1 GPU) and labelled with its
+    source.  FETCH_SIZE + WRITE_SIZE are in KB and taken as reported (MI355X guide:
+    FETCH_SIZE is exact for 64-B requests and halves wide coalesced reads: a lower bound)."""
     if args.small or args.utts != 2620 or args.graph_states != 10_000_000 or world != 1:
-        return None
-    tot = 0.0
+        return None, None
+    tot, src = 0.0, None
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_%s.txt" % name)
+        path = os.path.join(ROOT, "profiles", "r02_pmc_%s.txt" % name)
         try:
             with open(path) as f:
                 fields = f.readline().strip().split(",")
             tot += float(fields[2]) * 1024.0
+            src = "profiles/r02_pmc_{FETCH,WRITE}_SIZE.txt (recorded by tools/collect_profiles.sh, not measured in this run)"
         except (OSError, IndexError, ValueError):
-            return None
-    return tot
+            return None, None
+    return tot, src
+
+
+def dryrun(args, rank, world):
+    """CPU test of the multi-rank path: gloo process group, the strong-scaling partition,
+    the scalar reduction and the JSON line - nothing is decoded."""
+    import torch
+    import torch.distributed as dist
+    sharding = importlib.import_module(PKG + ".sharding")
+    workloads = importlib.import_module(PKG + ".workloads")
+    if os.environ.get("BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies
+        raise RuntimeError("rank %d: induced failure" % rank)
+    if world > 1:
+        dist.init_process_group("gloo")
+    lens = np.sort(workloads.utterance_lengths(np.random.default_rng(3456017), args.utts))[::-1]
+    parts = sharding.partition_utterances(lens, world)
+    mine = lens[parts[rank]]
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    red = sharding.reduce_decode_totals(int(mine.sum()), -1.0 * float(mine.sum()), len(mine), 0,
+                                        time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "dryrun", "n_gpus": world, "frames": red["frames"], "utterances": red["num_success"],
+                          "elapsed": red["elapsed"], "per_rank_frames_rank0": int(mine.sum()),
+                          "expected_frames": int(lens.sum())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=2620, help="utterances per GPU (test-clean has 2620)")
-    ap.add_argument("--graph-states", type=int, default=10_000_000)
-    ap.add_argument("--small", action="store_true", help="tiny model/graph for a quick functional run")
-    ap.add_argument("--cpu-frames", type=int, default=1500, help="frame budget of the CPU baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.no_gpu_dryrun:
+        return dryrun(args, rank, world)
+
+    # ---- workload (numpy only: no GPU has been touched yet)
+    if args.small:
+        args.graph_states = min(args.graph_states, 200_000)
+    t_build = time.perf_counter()
+    net, priors, g, protos = build_model_and_graph(3456, args.graph_states, args.small)
+    feats, off = build_utterances(3456, rank, args.utts, net, g, protos, args.small)
+    strong = None
+    if world > 1 and not args.no_strong:
+        sharding = importlib.import_module(PKG + ".sharding")
+        f0, o0 = (feats, off) if rank == 0 else build_utterances(3456, 0, args.utts, net, g, protos, args.small)
+        parts = sharding.partition_utterances(np.diff(o0), world)
+        strong = take_utterances(f0, o0, parts[rank])
+        del f0, o0
+    t_build = time.perf_counter() - t_build
+    cpu_handle = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_handle = start_cpu_baseline(net, priors, g, feats, off, args.cpu_utts)   # forked before GPU init
+
+    import torch
+    import torch.distributed as dist
     api = importlib.import_module(PKG + ".api")
     api.select_gpu(local_rank)                   # CuDevice::SelectGpuId(ordinal)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    if args.small:
-        args.graph_states = min(args.graph_states, 200_000)
-    net, priors, g, feats, off = build_workload(3456, rank, args.utts, args.graph_states, args.small)
-    n_utts = len(off) - 1
-    frames = int(off[-1])
     n_pdf = net[-1]["output_dim"]
-
     nnet = api.Nnet(net, priors)
     fst = api.Fst(g)
-    dec = api.LatticeFasterDecoder(fst, api.decoder_config(**DECODE_CFG), max_batch=n_utts,
-                                   max_frames=int(np.diff(off).max()))
-    feats_d = torch.from_numpy(feats).cuda()     # inputs resident in HBM before the timed region
-    stride = (n_pdf + 3) // 4 * 4
-    loglikes = torch.empty((frames, stride), dtype=torch.float32, device="cuda")[:, :n_pdf]
-
-    stats = {}
-
     verbose = bool(os.environ.get("BENCH_VERBOSE"))
-
-    def step():
-        t = [time.perf_counter()]
-        forward_all(api, torch, nnet, feats_d, off, loglikes, max_rows=60000)
-        if verbose:
-            torch.cuda.synchronize(); api.synchronize(); t.append(time.perf_counter())
-        dec.decode(loglikes, off)
-        t.append(time.perf_counter())
-        dec.prepare()                            # raw lattices + best paths, host threads
-        t.append(time.perf_counter())
-        tot_like, n_ok = 0.0, 0
-        arcs = toks = 0
-        for u in range(n_utts):
-            bp = dec.get_best_path(u)            # GetBestPath + lattice export (host part)
-            tot_like += -(bp["graph_cost"] + bp["acoustic_cost"])
-            n_ok += 1
-            st = dec.counters(u)
-            arcs += st["arcs_expanded"]
-            toks += st["tokens_created"]
-        t.append(time.perf_counter())
-        stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, kernel_ms=dec.last_kernel_ms())
-        if verbose and rank == 0:
-            d = np.diff(t) * 1e3
-            print("[bench] forward %.0f ms, decode() %.0f ms (kernel %.0f), prepare %.0f ms, fetch %.0f ms"
-                  % (d[0], d[1], stats["kernel_ms"], d[2], d[3]), file=sys.stderr)
 
     def sync():
         torch.cuda.synchronize()
@@ -258,57 +355,134 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(stats["kernel_ms"])
-    sync()
-    elapsed = time.perf_counter() - t0
+    def run(feats_h, off_h, steps, warmup):
+        """Times `steps` steps over the shard (feats_h, off_h); returns the per-rank record."""
+        n_utts = len(off_h) - 1
+        frames = int(off_h[-1])
+        dec = api.LatticeFasterDecoder(fst, api.decoder_config(**DECODE_CFG), max_batch=max(n_utts, 1),
+                                       max_frames=int(np.diff(off_h).max()) if n_utts else 1)
+        feats_d = torch.from_numpy(feats_h).cuda()     # inputs resident in HBM before the timed region
+        stride = (n_pdf + 3) // 4 * 4
+        loglikes = torch.empty((max(frames, 1), stride), dtype=torch.float32, device="cuda")[:, :n_pdf]
+        stats = {}
 
-    # max over ranks + the final scalar reduction (tot frames / like / utterances)
-    red = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(frames), stats["tot_like"], float(stats["n_ok"])], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(red, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(red.item())
-    total_frames = float(tot[0].item())
+        def step():
+            t = [time.perf_counter()]
+            forward_all(nnet, feats_d, off_h, loglikes, max_rows=60000)
+            if verbose:
+                torch.cuda.synchronize(); api.synchronize(); t.append(time.perf_counter())
+            dec.decode(loglikes, off_h)
+            t.append(time.perf_counter())
+            dec.prepare()                            # raw lattices + best paths, host threads
+            t.append(time.perf_counter())
+            tot_like, n_ok = 0.0, 0
+            arcs = toks = lat_arcs = lat_states = 0
+            for u in range(n_utts):
+                bp = dec.get_best_path(u)            # GetBestPath + lattice export (host part)
+                tot_like += -(bp["graph_cost"] + bp["acoustic_cost"])
+                n_ok += 1
+                st = dec.counters(u)
+                arcs += st["arcs_expanded"]
+                toks += st["tokens_created"]
+                ls = dec.stats(u)
+                lat_arcs += ls["num_links"]
+                lat_states += ls["num_tokens"]
+            t.append(time.perf_counter())
+            stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, lat_arcs=lat_arcs, lat_states=lat_states,
+                         kernel_ms=dec.last_kernel_ms())
+            if verbose and rank == 0:
+                d = np.diff(t) * 1e3
+                print("[bench] forward %.0f ms, decode() %.0f ms (kernel %.0f), prepare %.0f ms, fetch %.0f ms"
+                      % (d[0], d[1], stats["kernel_ms"], d[2], d[3]), file=sys.stderr)
+
+        for _ in range(warmup):
+            step()
+        sync()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            kernel_ms.append(stats["kernel_ms"])
+        sync()
+        elapsed = time.perf_counter() - t0
+        red = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(frames), stats["tot_like"], float(stats["n_ok"])], dtype=torch.float64, device="cuda")
+        kms = torch.zeros(world, dtype=torch.float64, device="cuda")
+        kms[rank] = float(np.mean(kernel_ms))
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(kms, op=dist.ReduceOp.SUM)
+        del dec, feats_d, loglikes
+        return dict(elapsed=float(red.item()), total_frames=float(tot[0].item()), tot_like=float(tot[1].item()),
+                    n_ok=int(tot[2].item()), stats=dict(stats), kernel_ms=float(np.mean(kernel_ms)),
+                    per_rank_kernel_ms=[float(x) for x in kms.tolist()], frames=frames, n_utts=n_utts,
+                    longest=int(np.diff(off_h).max()) if n_utts else 0)
+
+    weak = run(feats, off, args.steps, args.warmup)
+    strong_rec = run(strong[0], strong[1], args.steps, args.warmup) if strong is not None else None
+
+    secondary = None
+    if rank == 0 and not args.no_secondary and not args.small:
+        try:
+            sec = importlib.import_module("tools.bench_secondary")
+            secondary = sec.run_all(api, torch)
+        except Exception as e:  # the secondary legs never fail the headline run
+            secondary = {"error": repr(e)}
 
     if rank == 0:
-        fps = total_frames * args.steps / elapsed
+        st = weak["stats"]
+        fps = weak["total_frames"] * args.steps / weak["elapsed"]
         # roofline of the dominant kernel (DecodeKernel): algorithmic bytes per launch =
         # 60 B per expanded arc + 16 B per created token (SURVEY.md §8d) / measured duration
-        alg_bytes = stats["arcs"] * 60.0 + stats["toks"] * 16.0
-        k_ms = float(np.mean(kernel_ms))
+        alg_bytes = st["arcs"] * 60.0 + st["toks"] * 16.0
+        k_ms = weak["kernel_ms"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args, world)
         out = {
             # BASELINE.json's metric; value = frames/s of nnet2 forward + LatticeFasterDecoder, "rtf" = the
             # real-time factor per GPU (10 ms frames: rtf = 100 / frames-per-second-per-GPU)
             "metric": "frames/sec decoded + real-time factor, LibriSpeech nnet2 decode @1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": weak["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "rtf": elapsed * 100.0 / (total_frames * args.steps) * world,
-            "config": {"workload": "librispeech_nnet_a_synthetic" + ("_small" if args.small else ""),
-                       "utts_per_gpu": n_utts, "frames_per_gpu": frames, "graph_states": int(g["num_states"]),
-                       "graph_arcs": int(g["arc_offsets"][-1]), "nnet": "140-700-4x(3500/350)-12000-5800" if not args.small else "small",
-                       "decoder": DECODE_CFG, "acwt": ACWT, "parallelism": "utterance-shard x%d" % world},
+            "rtf": weak["elapsed"] * 100.0 / (weak["total_frames"] * args.steps) * world,
+            "config": {"workload": "librispeech_nnet_a_structured" + ("_small" if args.small else ""),
+                       "utts_per_gpu": weak["n_utts"], "frames_per_gpu": weak["frames"], "graph_states": int(g["num_states"]),
+                       "graph_arcs": int(g["arc_offsets"][-1]), "graph": "HCLG-structured (prefix trees x 3-state HMM chains, "
+                       "pushed LM costs, back-off epsilons); %d words, %d LM states" % (g["num_words"], g["num_hubs"]),
+                       "nnet": "140-700-4x(3500/350)-12000-5800" if not args.small else "small",
+                       "decoder": DECODE_CFG, "acwt": ACWT, "parallelism": "utterance-shard x%d" % world,
+                       "rccl_world_size": world, "workload_build_s": t_build},
+            "search": {"arcs_expanded_per_frame": st["arcs"] / weak["frames"], "tokens_per_frame": st["toks"] / weak["frames"],
+                       "lattice_arcs_per_frame": st["lat_arcs"] / weak["frames"],
+                       "lattice_states_per_frame": st["lat_states"] / weak["frames"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": measured_traffic(args, n_utts, world),
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "DecodeKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "arcs_expanded_per_launch": stats["arcs"], "tokens_created_per_launch": stats["toks"]},
-            "loglike_per_frame": stats["tot_like"] / frames,
+                         "arcs_expanded_per_launch": st["arcs"], "tokens_created_per_launch": st["toks"]},
+            "per_rank_kernel_ms": weak["per_rank_kernel_ms"],
+            "loglike_per_frame": st["tot_like"] / weak["frames"],
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU legs run at N = 1 only
-            v, desc, all_cores = cpu_baseline(net, priors, g, feats, off, args.cpu_frames)
-            out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port", "sample": desc,
-                                   "all_cores": all_cores}
-            out["speedup_vs_cpu_1thread_per_gpu"] = fps / world / v
+        if strong_rec is not None:
+            s = strong_rec
+            out["strong_scaling"] = {
+                "value": s["total_frames"] * args.steps / s["elapsed"], "unit": "frames/s", "scaling": "strong",
+                "utterances_total": s["n_ok"], "frames_total": s["total_frames"], "ms_per_step": s["elapsed"] / args.steps * 1e3,
+                "per_rank_kernel_ms": s["per_rank_kernel_ms"], "rank0_utterances": s["n_utts"], "rank0_frames": s["frames"],
+                "longest_utterance_frames": s["longest"],
+                "note": "one 2620-utterance set sharded longest-first over the ranks (sharding.partition_utterances)"}
+        if secondary is not None:
+            out["secondary"] = secondary
+        if cpu_handle is not None:                   # the CPU legs run at N = 1 only
+            res = finish_cpu_baseline(cpu_handle)
+            if "error" in res:
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": res["error"]}
+            else:
+                out["cpu_baseline"] = {"value": res["value"], "unit": "frames/s", "cores": 1, "kind": res["kind"],
+                                       "sample": res["sample"], "all_cores": res.get("all_cores")}
+                out["speedup_vs_cpu_1thread_per_gpu"] = fps / world / res["value"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -245,6 +245,12 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start,
                      const int32_t *nextstate, const float *final_cost);
 void kh_fst_destroy(KhFst *fst);
 int64_t kh_fst_num_arcs(const KhFst *fst);
+/* Validates once per (graph, pdf map, model) what the reference asserts on every
+ * DecodableAmNnet::LogLikelihood call (nnet2/decodable-am-nnet.h:76-78) /
+ * TransitionModel::TransitionIdToPdf (hmm/transition-model.h:312): every ilabel of the
+ * graph has an entry in the HOST copy of tid2pdf (NULL: identity minus one) and maps to a
+ * column < num_cols of the log-likelihood matrix.  The decode kernels gather unchecked. */
+int kh_fst_check_pdf_map(const KhFst *fst, const int32_t *tid2pdf_host, int n_tid2pdf, int num_cols);
 
 /* LatticeFasterDecoderConfig lattice-faster-decoder.h:40-95 (same defaults). */
 typedef struct KhDecoderConfig {

@@ -594,8 +594,21 @@ class Fst:
             raise KhError(lib().kh_last_error().decode())
         self._h = C.c_void_p(h)
         self.tid2pdf = None
+        self._tid2pdf_host = None
+        self._checked_cols = set()
         if graph.get("tid2pdf") is not None:
-            self.tid2pdf = torch.as_tensor(np.ascontiguousarray(graph["tid2pdf"], np.int32), device="cuda")
+            self._tid2pdf_host = np.ascontiguousarray(graph["tid2pdf"], np.int32)
+            self.tid2pdf = torch.as_tensor(self._tid2pdf_host, device="cuda")
+
+    def check_pdf_map(self, num_cols):
+        """Every transition-id of the graph maps to a column of the log-likelihood matrix
+        (checked once per matrix width; KhError otherwise)."""
+        if num_cols in self._checked_cols:
+            return
+        h = self._tid2pdf_host
+        check(lib().kh_fst_check_pdf_map(self._h, h.ctypes.data_as(capi.c_int32_p) if h is not None else None,
+                                         len(h) if h is not None else 0, int(num_cols)))
+        self._checked_cols.add(num_cols)
 
     def num_arcs(self):
         return lib().kh_fst_num_arcs(self._h)
@@ -641,6 +654,7 @@ class LatticeFasterDecoder:
         self.n_utts = len(off) - 1
         self._T = np.diff(off)
         t2p = _p(self.fst.tid2pdf) if self.fst.tid2pdf is not None else None
+        self.fst.check_pdf_map(loglikes.shape[1])
         self._ll = loglikes  # keep alive
         check(lib().kh_decoder_decode(self._h, _p(loglikes), _dim(loglikes).stride,
                                       off.ctypes.data_as(capi.c_int32_p), self.n_utts, t2p))
@@ -743,6 +757,9 @@ class LatticeFasterOnlineDecoder:
         ptrs = (C.c_void_p * n)(*[C.c_void_p(c.data_ptr()) if c.shape[0] > 0 else None for c in chunks])
         nf = np.ascontiguousarray([c.shape[0] for c in chunks], np.int32)
         t2p = _p(self.fst.tid2pdf) if self.fst.tid2pdf is not None else None
+        for c in chunks:
+            if c.shape[0] > 0:
+                self.fst.check_pdf_map(c.shape[1])
         self._keep = chunks
         check(lib().kh_online_decoder_advance(self._h, ptr, n, ptrs, stride, nf.ctypes.data_as(capi.c_int32_p), t2p))
 

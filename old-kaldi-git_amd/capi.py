@@ -105,6 +105,7 @@ SIGNATURES = {
     "kh_fst_create": (vp, [i32, i32, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_float_p]),
     "kh_fst_destroy": (None, [vp]),
     "kh_fst_num_arcs": (i64, [vp]),
+    "kh_fst_check_pdf_map": (C.c_int, [vp, c_int32_p, C.c_int, C.c_int]),
     "kh_decoder_config_default": (None, [C.POINTER(KhDecoderConfig)]),
     "kh_decoder_create": (vp, [vp, C.POINTER(KhDecoderConfig), C.c_int, C.c_int]),
     "kh_decoder_destroy": (None, [vp]),

@@ -1670,7 +1670,8 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     const int hw = sh->tok_hw;
     for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
-    for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) u.tmp_acc1[i] = kEncInf;
+    // (a capacity overflow aborts a frame with work-list flags still set: clear them too)
+    for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
     KhSync();
     KhDecodeStats st;
     DecodeOne(u, p, sh, &st);
@@ -1805,11 +1806,12 @@ struct KhDecoder {
   KhDecoderConfig cfg;
   int max_batch = 0, max_frames = 0;
   int tok_frame_cap = 0, link_frame_cap = 0, expected_tokens = 0;
+  int win_tok = 0, win_link = 0;   // tokens / links per frame the compaction window is sized for (averages, not caps)
   int max_slots = 0;
   // slot arenas (one set per persistent workgroup)
   void *slab = nullptr;
   size_t slab_bytes = 0;
-  int slab_slots = 0, slab_T = 0;
+  int slab_slots = 0, slab_T = 0, slab_scale = 1;
   std::vector<Utt> h_slots;
   Utt *d_slots = nullptr;
   UttIn *d_in = nullptr;
@@ -1876,8 +1878,8 @@ struct Carver {
 };
 
 // Arena set of one slot, sized for utterances of up to T frames.
-void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, int prune_interval,
-               float hash_ratio, int expected_tokens) {
+void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, int win_tok, int win_link,
+               int prune_interval, float hash_ratio, int expected_tokens) {
   u.T = T;
   u.tok_frame_cap = tok_frame_cap;
   u.link_frame_cap = link_frame_cap;
@@ -1887,8 +1889,11 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   long long per_frame = 256;
   if (const char *e = getenv("KH_DECODER_STABLE_TOKENS_PER_FRAME")) per_frame = atoll(e);
   const long long stable_tok = std::max<long long>(65536, per_frame * (T + 2));
-  const long long tok_cap = stable_tok + win_frames * tok_frame_cap;
-  const long long link_cap = 3 * stable_tok + win_frames * link_frame_cap;
+  // the window holds win_frames frames of AVERAGE size (win_tok / win_link per frame) plus one
+  // frame of the per-frame caps; an utterance that needs more reports an overflow and is
+  // decoded again with larger arenas (kh_decoder_decode)
+  const long long tok_cap = stable_tok + win_frames * win_tok + tok_frame_cap;
+  const long long link_cap = 3 * stable_tok + win_frames * win_link + link_frame_cap;
   // every arena array holds 4-byte elements addressed with a 32-bit byte offset (Arr<T>): < 2^30 slots
   const long long kMaxSlots = (1ll << 30) - 1;
   u.window_cap = static_cast<int32_t>(std::min<long long>(tok_cap, kMaxSlots));
@@ -1952,8 +1957,16 @@ int BuildLattice(KhDecoder *d, int ui) {
   const int32_t *tf = hp.t_frame.data() + o.tok_off, *ts = hp.t_state.data() + o.tok_off;
   std::vector<int32_t> ord(n);
   for (size_t k = 0; k < n; k++) ord[k] = static_cast<int32_t>(k);
+  // canonical order (frame, HCLG state) with the start token first: lattice state 0 is the
+  // start state (the reference gets that from TopSortTokens :839-914; ComputeBestPath and
+  // the lattice writers rely on it), also when the start state has an epsilon arc to a
+  // lower-numbered state
+  const int32_t start = d->fst->start;
   std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
-    return tf[a] != tf[b] ? tf[a] < tf[b] : ts[a] < ts[b];
+    if (tf[a] != tf[b]) return tf[a] < tf[b];
+    const bool as = !(tf[a] == 0 && ts[a] == start), bs = !(tf[b] == 0 && ts[b] == start);
+    if (as != bs) return as < bs;
+    return ts[a] < ts[b];
   });
   std::vector<int32_t> newidx(n);
   for (size_t k = 0; k < n; k++) newidx[ord[k]] = static_cast<int32_t>(k);
@@ -2074,10 +2087,16 @@ int ComputeBestPath(KhDecoder *d, int utt) {
 
 // Arena slab of the decoder: n_want slots sized for utterances of up to T_max frames
 // (fewer if they do not fit in free memory); establishes the arena invariants.
-int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slots_out) {
+int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slots_out, int scale = 1) {
   int n_slots = n_want;
-  if (T_max <= d->slab_T) n_slots = std::min(n_slots, d->slot_limit);  // an earlier batch found that more do not fit
-  if (n_slots > d->slab_slots || T_max > d->slab_T) {
+  if (T_max <= d->slab_T && scale == d->slab_scale) n_slots = std::min(n_slots, d->slot_limit);  // an earlier batch found that more do not fit
+  const long long kCap = (1ll << 28);
+  const int tfc = static_cast<int>(std::min<long long>(kCap, 1ll * d->tok_frame_cap * scale)),
+            lfc = static_cast<int>(std::min<long long>(kCap, 1ll * d->link_frame_cap * scale)),
+            wt = static_cast<int>(std::min<long long>(kCap, 1ll * d->win_tok * scale)),
+            wl = static_cast<int>(std::min<long long>(kCap, 1ll * d->win_link * scale)),
+            et = static_cast<int>(std::min<long long>(kCap, 1ll * d->expected_tokens * scale));
+  if (n_slots > d->slab_slots || T_max > d->slab_T || scale != d->slab_scale) {
     PoolFree(d->slab);
     d->slab = nullptr;
     size_t slab_bytes = 0;
@@ -2093,7 +2112,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
       Carver sizer{nullptr};
       for (int i = 0; i < n_slots; i++) {
         Utt tmp;
-        CarveSlot(sizer, tmp, T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval, d->cfg.hash_ratio, d->expected_tokens);
+        CarveSlot(sizer, tmp, T_max, tfc, lfc, wt, wl, d->cfg.prune_interval, d->cfg.hash_ratio, et);
       }
       slab_bytes = sizer.off;
       if (slab_bytes <= budget || n_slots == 1) {
@@ -2103,19 +2122,19 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     }
     if (!d->slab) { d->slab_bytes = 0; d->slab_slots = 0; return KH_ENOMEM; }
     if (getenv("KH_DECODER_PROFILE"))
-      fprintf(stderr, "[kh_decoder profile] arenas: %d slots (wanted %d) x %.1f MB = %.1f GB; device memory free %.1f GB of %.1f GB\n",
-              n_slots, want_slots, slab_bytes / 1e6 / n_slots, slab_bytes / 1e9, free_b / 1e9, total_b / 1e9);
+      fprintf(stderr, "[kh_decoder profile] arenas (scale %d): %d slots (wanted %d) x %.1f MB = %.1f GB; device memory free %.1f GB of %.1f GB\n",
+              scale, n_slots, want_slots, slab_bytes / 1e6 / n_slots, slab_bytes / 1e9, free_b / 1e9, total_b / 1e9);
     d->slot_limit = n_slots < want_slots ? n_slots : std::numeric_limits<int>::max();
     Carver sizer{nullptr};
     sizer.off = slab_bytes;
     d->slab_bytes = sizer.off;
     d->slab_slots = n_slots;
     d->slab_T = T_max;
+    d->slab_scale = scale;
     d->h_slots.assign(n_slots, Utt());
     Carver carver{static_cast<char *>(d->slab)};
     for (int i = 0; i < n_slots; i++)
-      CarveSlot(carver, d->h_slots[i], T_max, d->tok_frame_cap, d->link_frame_cap, d->cfg.prune_interval,
-                d->cfg.hash_ratio, d->expected_tokens);
+      CarveSlot(carver, d->h_slots[i], T_max, tfc, lfc, wt, wl, d->cfg.prune_interval, d->cfg.hash_ratio, et);
     // arena invariants for the first utterance of every slot (later ones are
     // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
     for (int i = 0; i < n_slots; i++) {
@@ -2217,6 +2236,37 @@ int FetchPool(KhDecoder *d, const unsigned long long *used, long long pool_tok, 
   return KH_OK;
 }
 
+void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int np, float ms) {
+  static const char *names[16] = {"cutoff", "emit_pass1", "emit_pass2", "eps_closure", "eps_links", "clear_hash",
+                                  "prune", "compact", "finalize", "export", "", "", "", "", "", "other"};
+  long long tot[NPH] = {0};
+  long long all = 0;
+  for (int i = 0; i < grid; i++)
+    for (int k = 0; k < NPH; k++) {
+      tot[k] += h_phase[NPH * i + k];
+      if (k < 16) all += h_phase[NPH * i + k];
+    }
+  fprintf(stderr, "[kh_decoder profile] launch %d: %d utterances, kernel %.1f ms, %d slots; share of shader cycles:",
+          round, np, ms, grid);
+  all -= tot[10] + tot[11] + tot[12] + tot[13] + tot[14];
+  for (int k = 0; k < 16; k++)
+    if (tot[k] && (k < 10 || k == 15)) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
+  fprintf(stderr, "\n[kh_decoder profile] PruneActiveTokens calls %lld, frames pruned %lld (%.1f per call), tokens scanned "
+          "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
+          tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
+          tot[10] ? double(tot[14]) / tot[10] : 0.0, tot[13]);
+  fprintf(stderr, "[kh_decoder profile] prune by frame size: <=1024 tokens: %lld visits, %.1f%% of prune cycles (%.0f cycles each); "
+          "larger: %lld visits, %.1f%% (%.0f cycles each)\n",
+          tot[18], tot[6] ? 100.0 * tot[16] / tot[6] : 0.0, tot[18] ? double(tot[16]) / tot[18] : 0.0,
+          tot[19], tot[6] ? 100.0 * tot[17] / tot[6] : 0.0, tot[19] ? double(tot[17]) / tot[19] : 0.0);
+  fprintf(stderr, "[kh_decoder profile] PruneForwardLinks on frames > %d tokens, share of prune cycles: token init %.1f%%, "
+          "emitting links %.1f%%, token + epsilon sweeps %.1f%%, excise + flags %.1f%%\n",
+          NT, tot[6] ? 100.0 * tot[20] / tot[6] : 0.0, tot[6] ? 100.0 * tot[21] / tot[6] : 0.0,
+          tot[6] ? 100.0 * tot[22] / tot[6] : 0.0, tot[6] ? 100.0 * tot[23] / tot[6] : 0.0);
+  fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
+          tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2311,6 +2361,34 @@ void kh_fst_destroy(KhFst *f) {
 
 int64_t kh_fst_num_arcs(const KhFst *f) { return f ? f->num_arcs : 0; }
 
+// The decode kernels gather tid2pdf[ilabel] and loglikes[t, pdf] unchecked: this validates,
+// once per (graph, pdf map, model), what DecodableAmNnet / TransitionModel assert per call
+// (decodable-am-nnet.h:76-78 "KALDI_ASSERT(transition_id ...)", transition-model.h:312).
+// tid2pdf_host: HOST copy of the map, or NULL for the identity-minus-one map.
+int kh_fst_check_pdf_map(const KhFst *f, const int32_t *tid2pdf_host, int n_tid2pdf, int num_cols) {
+  KH_CHECK_ARG(f && num_cols > 0);
+  if (!tid2pdf_host) {
+    if (f->max_ilabel > num_cols) {
+      SetError("kh_fst_check_pdf_map: largest ilabel %d of the graph exceeds the %d columns of the log-likelihood matrix",
+               f->max_ilabel, num_cols);
+      return KH_EINVAL;
+    }
+    return KH_OK;
+  }
+  if (f->max_ilabel >= n_tid2pdf) {
+    SetError("kh_fst_check_pdf_map: largest ilabel %d of the graph is outside the transition-id -> pdf map (%d entries)",
+             f->max_ilabel, n_tid2pdf);
+    return KH_EINVAL;
+  }
+  for (int t = 1; t <= f->max_ilabel; t++)
+    if (tid2pdf_host[t] < 0 || tid2pdf_host[t] >= num_cols) {
+      SetError("kh_fst_check_pdf_map: transition-id %d maps to pdf %d, outside the %d columns of the log-likelihood matrix",
+               t, tid2pdf_host[t], num_cols);
+      return KH_EINVAL;
+    }
+  return KH_OK;
+}
+
 void kh_decoder_config_default(KhDecoderConfig *c) {
   c->beam = 16.0f;
   c->max_active = std::numeric_limits<int32_t>::max();
@@ -2340,11 +2418,12 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
   d->cfg = *cfg;
   d->max_batch = max_batch;
   d->max_frames = max_frames;
-  // Tokens created per frame: bounded in practice by the expansion of at most
-  // max_active tokens; overflow is detected and reported (KH_ECAPACITY).
-  long long tf = cfg->max_active == std::numeric_limits<int32_t>::max()
-                     ? 65536
-                     : std::min<long long>(65536, 3ll * cfg->max_active + 4096);
+  // Per-frame caps (the temporaries of a frame): the reference has no limit; a frame that
+  // exceeds them reports an overflow and its utterance is decoded again with doubled arenas.
+  // max_active bounds the tokens that EXPAND, not the tokens they create: a language-model
+  // state of an HCLG has hundreds of arcs, and frames of 40 k new tokens occur at
+  // max-active 7000.
+  long long tf = 65536;
   if (const char *e = getenv("KH_DECODER_TOKENS_PER_FRAME")) tf = atoll(e);
   d->tok_frame_cap = static_cast<int>(tf);
   // tokens a frame is sized for in the hash (hash_ratio x this many entries): what a frame typically
@@ -2355,9 +2434,17 @@ KhDecoder *kh_decoder_create(const KhFst *fst, const KhDecoderConfig *cfg, int m
                            ? d->tok_frame_cap
                            : static_cast<int>(std::min<long long>(d->tok_frame_cap, cfg->max_active + cfg->max_active / 2));
   if (const char *e = getenv("KH_DECODER_HASH_TOKENS")) d->expected_tokens = atoi(e);
-  long long lf = 3 * tf;
+  long long lf = 4 * tf;
   if (const char *e = getenv("KH_DECODER_LINKS_PER_FRAME")) lf = atoll(e);
   d->link_frame_cap = static_cast<int>(lf);
+  // average frame the compaction window is sized for
+  long long wt = cfg->max_active == std::numeric_limits<int32_t>::max()
+                     ? tf : std::min<long long>(tf, std::max<long long>(4096, 2ll * cfg->max_active));
+  if (const char *e = getenv("KH_DECODER_WINDOW_TOKENS_PER_FRAME")) wt = atoll(e);
+  d->win_tok = static_cast<int>(wt);
+  long long wl = std::min<long long>(lf, 4 * wt);
+  if (const char *e = getenv("KH_DECODER_WINDOW_LINKS_PER_FRAME")) wl = atoll(e);
+  d->win_link = static_cast<int>(wl);
   d->max_slots = NumCUs() * KH_WG_PER_CU;  // persistent workgroups
   if (const char *e = getenv("KH_DECODER_SLOTS")) d->max_slots = std::max(1, atoi(e));
   return d;
@@ -2393,12 +2480,6 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     T_max = std::max(T_max, T);
     tot_frames += T;
   }
-  // ---- slot arenas
-  int n_slots = 0;
-  rc = EnsureSlots(d, std::min(n_utts, d->max_slots), T_max, st, &n_slots);
-  if (rc) return rc;
-  for (int i = 0; i < n_slots; i++) d->h_slots[i].ll_stride = ll_stride;
-  KH_HIP(hipMemcpyAsync(d->d_slots, d->h_slots.data(), sizeof(Utt) * n_slots, hipMemcpyHostToDevice, st));
   if (!d->d_in) {
     d->d_in = static_cast<UttIn *>(PoolMalloc(sizeof(UttIn) * d->max_batch));
     d->d_out = static_cast<UttOut *>(PoolMalloc(sizeof(UttOut) * d->max_batch));
@@ -2408,6 +2489,13 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       d->d_phase = static_cast<long long *>(PoolMalloc(sizeof(long long) * NPH * d->max_slots));
       if (!d->d_phase) return KH_ENOMEM;
     }
+  }
+  // the graph's transition-ids and pdfs must lie inside the tables they index (the kernel
+  // gathers tid2pdf[ilabel] and the score row unchecked)
+  if (tid2pdf == nullptr && d->fst->max_ilabel > ll_stride) {
+    SetError("kh_decoder_decode: the graph's largest ilabel %d exceeds the %d columns of the log-likelihood matrix",
+             d->fst->max_ilabel, ll_stride);
+    return KH_EINVAL;
   }
   // ---- queue order: longest first (greedy LPT over the persistent workgroups)
   d->order.resize(n_utts);
@@ -2430,21 +2518,35 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     link_per_frame = tok_per_frame * 3 / 2;
   }
   std::vector<int> pending(d->order);
-  // The lattice pool is sized from an estimate; an utterance whose lattice does not
-  // fit reports its exact size and is decoded again in a second launch with a pool
-  // of exactly the needed size (rare: the estimate is ~1.5x the density measured on
-  // the recipe's options).
+  // Two things are sized from estimates, and an utterance that outgrows either is decoded
+  // again in a further launch while the finished ones are kept:
+  //  * the lattice pool (status 6): the utterance reports its exact size, the next pool has it;
+  //  * the slot arenas (status 1-4: tokens / links per frame, window): the next launch runs
+  //    with arenas twice as large (the reference has no such limits).
+  // An utterance that still overflows at 16 x the default arenas is left failed (its stats
+  // carry the status; the getters return KH_ECAPACITY for it) - the caller counts it like the
+  // reference counts a failed Decode() (num_fail, nnet-latgen-faster.cc:170).
   long long need_tok = 0, need_link = 0;
+  int scale = 1;
+  const int kMaxScale = 16;
+  bool pool_exact = false;
   for (int round = 0; !pending.empty(); round++) {
-    if (round > 3) {
-      SetError("kh_decoder_decode: lattice pool still too small after %d launches", round);
+    if (round > 8) {
+      SetError("kh_decoder_decode: %d utterances still unfinished after %d launches", static_cast<int>(pending.size()), round);
       return KH_ECAPACITY;
     }
     const int np = static_cast<int>(pending.size());
     long long frames = 0;
-    for (int ui : pending) frames += d->h_T[ui];
-    const long long pool_tok = round == 0 ? frames * tok_per_frame + 65536 : need_tok + 1024;
-    const long long pool_link = round == 0 ? frames * link_per_frame + 131072 : need_link + 1024;
+    int T_round = 0;
+    for (int ui : pending) { frames += d->h_T[ui]; T_round = std::max(T_round, d->h_T[ui]); }
+    // ---- slot arenas
+    int n_slots = 0;
+    rc = EnsureSlots(d, std::min(np, d->max_slots), scale == 1 ? T_max : T_round, st, &n_slots, scale);
+    if (rc) return rc;
+    for (int i = 0; i < n_slots; i++) d->h_slots[i].ll_stride = ll_stride;
+    KH_HIP(hipMemcpyAsync(d->d_slots, d->h_slots.data(), sizeof(Utt) * n_slots, hipMemcpyHostToDevice, st));
+    const long long pool_tok = !pool_exact ? frames * tok_per_frame + 65536 : need_tok + 1024;
+    const long long pool_link = !pool_exact ? frames * link_per_frame + 131072 : need_link + 1024;
     rc = EnsurePool(d, pool_tok, pool_link);
     if (rc) return rc;
     std::vector<UttIn> h_in(np);
@@ -2497,38 +2599,13 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       KH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bar_misaligned), z, sizeof(z)));
     }
 #endif
-    if (d->d_phase) {
-      static const char *names[16] = {"cutoff", "emit_pass1", "emit_pass2", "eps_closure", "eps_links", "clear_hash",
-                                      "prune", "compact", "finalize", "export", "", "", "", "", "", "other"};
-      long long tot[NPH] = {0};
-      long long all = 0;
-      for (int i = 0; i < grid; i++)
-        for (int k = 0; k < NPH; k++) {
-          tot[k] += h_phase[NPH * i + k];
-          if (k < 16) all += h_phase[NPH * i + k];
-        }
-      fprintf(stderr, "[kh_decoder profile] launch %d: %d utterances, kernel %.1f ms, %d slots; share of shader cycles:",
-              round, np, ms, grid);
-      all -= tot[10] + tot[11] + tot[12] + tot[13] + tot[14];
-      for (int k = 0; k < 16; k++)
-        if (tot[k] && (k < 10 || k == 15)) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
-      fprintf(stderr, "\n[kh_decoder profile] PruneActiveTokens calls %lld, frames pruned %lld (%.1f per call), tokens scanned "
-              "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
-              tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
-              tot[10] ? double(tot[14]) / tot[10] : 0.0, tot[13]);
-      fprintf(stderr, "[kh_decoder profile] prune by frame size: <=1024 tokens: %lld visits, %.1f%% of prune cycles (%.0f cycles each); "
-              "larger: %lld visits, %.1f%% (%.0f cycles each)\n",
-              tot[18], tot[6] ? 100.0 * tot[16] / tot[6] : 0.0, tot[18] ? double(tot[16]) / tot[18] : 0.0,
-              tot[19], tot[6] ? 100.0 * tot[17] / tot[6] : 0.0, tot[19] ? double(tot[17]) / tot[19] : 0.0);
-      fprintf(stderr, "[kh_decoder profile] PruneForwardLinks on frames > %d tokens, share of prune cycles: token init %.1f%%, "
-              "emitting links %.1f%%, token + epsilon sweeps %.1f%%, excise + flags %.1f%%\n",
-              NT, tot[6] ? 100.0 * tot[20] / tot[6] : 0.0, tot[6] ? 100.0 * tot[21] / tot[6] : 0.0,
-              tot[6] ? 100.0 * tot[22] / tot[6] : 0.0, tot[6] ? 100.0 * tot[23] / tot[6] : 0.0);
-      fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
-              tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);
-    }
+    if (d->d_phase) PrintPhases(h_phase, grid, round, np, ms);
     std::vector<int> next;
     need_tok = need_link = 0;
+    bool grow = false, pool_short = false;
+    int n_failed = 0;
+    static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena", "links-per-frame cap",
+                                 "compaction window", "?", "lattice pool"};
     for (int q = 0; q < np; q++) {
       const int ui = pending[q];
       const KhDecodeStats &hs = q_out[q].stats;
@@ -2536,24 +2613,42 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
         next.push_back(ui);
         need_tok += q_out[q].n_tok;
         need_link += q_out[q].n_link;
+        pool_short = true;
         continue;
       }
       if (hs.status != 0) {
-        static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena", "links-per-frame cap",
-                                     "compaction window", "?", "lattice pool"};
-        SetError("kh_decoder_decode: utterance %d overflowed the %s at frame %d (tokens/frame cap %d, "
-                 "links/frame cap %d, arena slots in use: tokens %d/%d, links %d/%d); see "
-                 "KH_DECODER_TOKENS_PER_FRAME / KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME",
-                 ui, what[std::min(std::max(hs.status, 0), 6)], hs.num_frames, d->tok_frame_cap, d->link_frame_cap,
-                 hs.num_tokens, d->h_slots[0].tok_cap, hs.num_links, d->h_slots[0].link_cap);
-        return KH_ECAPACITY;
+        if (scale < kMaxScale) {
+          next.push_back(ui);
+          grow = true;
+          if (getenv("KH_DECODER_PROFILE"))
+            fprintf(stderr, "[kh_decoder profile] utterance %d overflowed the %s at frame %d (scale %d): decoded again with 2 x the arenas\n",
+                    ui, what[std::min(std::max(hs.status, 0), 6)], hs.num_frames, scale);
+          continue;
+        }
+        // give up on this utterance only
+        n_failed++;
+        SetError("kh_decoder_decode: utterance %d overflowed the %s at frame %d even with %d x the default arenas "
+                 "(tokens/frame cap %d, links/frame cap %d); see KH_DECODER_TOKENS_PER_FRAME / "
+                 "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME",
+                 ui, what[std::min(std::max(hs.status, 0), 6)], hs.num_frames, scale, d->tok_frame_cap, d->link_frame_cap);
       }
       d->h_out[ui] = q_out[q];
-      d->h_round[ui] = round;
+      d->h_round[ui] = static_cast<int32_t>(d->rounds.size());
     }
     rc = FetchPool(d, used, pool_tok, pool_link, st);
     if (rc) return rc;
+    // the utterances that need larger arenas have no lattice size yet: estimate again
+    pool_exact = pool_short && !grow;
+    if (grow) scale *= 2;
     pending.swap(next);
+  }
+  if (d->slab_scale != 1) {  // enlarged arenas are not kept: the next batch starts from the defaults
+    PoolFree(d->slab);
+    d->slab = nullptr;
+    d->slab_bytes = 0;
+    d->slab_slots = 0;
+    d->slab_T = 0;
+    d->slab_scale = 1;
   }
   return KH_OK;
 }
@@ -2618,6 +2713,12 @@ int kh_decoder_get_best_path(const KhDecoder *dc, int utt, int32_t *alignment, i
   if (rc) return rc;
   const KhDecoder::Lat &L = d->lats[utt];
   const int a = static_cast<int>(L.bp_ali.size()), w = static_cast<int>(L.bp_words.size());
+  *n_ali = a;
+  *n_words = w;
+  if ((alignment && a > cap_ali) || (words && w > cap_words)) {
+    SetError("kh_decoder_get_best_path: buffers too small (alignment %d > %d or words %d > %d)", a, cap_ali, w, cap_words);
+    return KH_EINVAL;
+  }
   if (alignment) memcpy(alignment, L.bp_ali.data(), sizeof(int32_t) * std::min(a, std::max(cap_ali, 0)));
   if (words) memcpy(words, L.bp_words.data(), sizeof(int32_t) * std::min(w, std::max(cap_words, 0)));
   *n_ali = a;

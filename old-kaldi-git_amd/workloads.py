@@ -193,3 +193,319 @@ def make_loglikes(rng, T, num_pdfs, peak=6.0, acwt=0.1, stickiness=0.9):
     x -= np.log(np.exp(x - x.max(1, keepdims=True)).sum(1, keepdims=True)) + x.max(1, keepdims=True)
     x -= np.float32(np.log(1.0 / num_pdfs))
     return (x * np.float32(acwt)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# HCLG-STRUCTURED decoding graphs.  make_graph above draws next states uniformly,
+# so paths never reconverge and the lattices degenerate to one path.  A real HCLG
+# (graph compilation: egs/wsj/s5/utils/mkgraph.sh; H = 3-state left-to-right HMMs
+# with self-loops, hmm/hmm-topology.h; L = lexicon; G = back-off n-gram) is, per
+# language-model state, a PREFIX TREE of pronunciations whose nodes are phones
+# expanded into HMM-state chains with self-loops, LM costs pushed towards the
+# root, word ends joined to the next LM state, and back-off epsilon arcs to the
+# unigram state.  Alignments of the same word sequence that differ only in state
+# durations reconverge on the same graph state at the same frame, which is what
+# makes real raw lattices tens of arcs per frame wide.
+# --------------------------------------------------------------------------
+def make_hclg_structured(rng, target_states, num_pdfs, n_phones=None, n_words=None, hmm_states=3,
+                         mean_pron=4.5, final_cost_range=(1.0, 5.0)):
+    """Synthetic HCLG with the structure of the real one, about `target_states` states.
+
+    States: hub 0 (unigram / start), hubs 1..H (bigram histories), then `hmm_states`
+    chain states per prefix-tree node.  Every chain state carries an emitting
+    self-loop; every arc INTO a chain state and the state's self-loop score the same
+    pdf (self-loops on the destination: `add-self-loops --reorder=true`, the recipes'
+    default).  Arcs: hub -> first chain state of each first phone (LM look-ahead cost),
+    chain forward arcs, last chain state -> children's first state, word end
+    -(eps, olabel = word, residual LM cost)-> hub of the next history, history hub
+    -(eps, back-off cost)-> hub 0.  Epsilon arcs are acyclic (depth <= 2).
+    Transition-ids: 2 * pdf + 1 = forward, 2 * pdf + 2 = self-loop."""
+    S = hmm_states
+    if n_phones is None:
+        n_phones = int(np.clip(round(target_states ** 0.5 / 20), 6, 160))
+    P = n_phones
+    # entries (history, word) needed: states ~= S * nodes, nodes ~= entries * mean_pron * (1 - sharing)
+    n_entries = max(4, int(target_states / (S * mean_pron * 0.8)))
+    if n_words is None:
+        n_words = max(3, int(n_entries * 0.27))
+    V = n_words
+    # ---- lexicon: pronunciations, Zipf-ish phone and word frequencies
+    plen = np.clip(1 + rng.poisson(mean_pron - 1.0, V), 1, 12).astype(np.int64)
+    Lmax = int(plen.max())
+    phone_p = 1.0 / (np.arange(P) + 3.0)
+    phone_p /= phone_p.sum()
+    prons = rng.choice(P, size=(V, Lmax), p=phone_p).astype(np.int64)
+    uni_p = 1.0 / (rng.permutation(V) + 10.0)
+    uni_p /= uni_p.sum()
+    uni_cost = -np.log(uni_p)
+    # ---- bigram histories: the most frequent words; heavy-tailed successor counts
+    n_bi = max(0, n_entries - V)
+    H = int(min(V, max(1, n_bi // 27))) if n_bi > 0 else 0
+    hist_words = np.argsort(-uni_p, kind="stable")[:H]
+    hist_of_word = np.zeros(V, np.int64)                 # hub reached after word w (0 = unigram hub)
+    hist_of_word[hist_words] = 1 + np.arange(H)
+    if H > 0:
+        share = rng.lognormal(0.0, 1.0, H)
+        n_succ = np.maximum(1, (share / share.sum() * n_bi).astype(np.int64))
+        n_succ = np.minimum(n_succ, V)
+        e_hist = np.repeat(1 + np.arange(H), n_succ)
+        e_word = rng.choice(V, size=int(n_succ.sum()), p=uni_p)
+        # an explicit bigram is more probable than backing off: cost below back-off + unigram
+        e_cost = np.maximum(0.1, uni_cost[e_word] - rng.uniform(0.5, 3.0, len(e_word)))
+        backoff = rng.uniform(0.5, 3.0, H)
+        # drop duplicate (history, word) pairs
+        key = e_hist * V + e_word
+        _, first = np.unique(key, return_index=True)
+        e_hist, e_word, e_cost = e_hist[first], e_word[first], e_cost[first]
+    else:
+        e_hist = np.zeros(0, np.int64); e_word = np.zeros(0, np.int64); e_cost = np.zeros(0); backoff = np.zeros(0)
+    e_hist = np.concatenate([np.zeros(V, np.int64), e_hist])
+    e_word = np.concatenate([np.arange(V, dtype=np.int64), e_word])
+    e_cost = np.concatenate([uni_cost, e_cost])
+    E = len(e_word)
+    e_len = plen[e_word]
+    # ---- prefix trees of all hubs at once, level by level
+    parent_of = []      # per level: parent node (global id) or -(hub + 1) at depth 0
+    phone_of = []
+    cur = -(e_hist + 1)                 # node each entry sits under; negative = a hub
+    leaf = np.full(E, -1, np.int64)
+    n_nodes = 0
+    level_range = []
+    for d in range(Lmax):
+        act = np.nonzero(e_len > d)[0]
+        if len(act) == 0:
+            break
+        ph = prons[e_word[act], d]
+        key = (cur[act] + (H + 1)) * P + ph      # parents: hubs map to [0, H], nodes to H + 1 + id
+        uniq, inv = np.unique(key, return_inverse=True)
+        ids = n_nodes + inv
+        par = uniq // P - (H + 1)                # >= 0: node id; < 0: -(hub + 1)
+        parent_of.append(par)
+        phone_of.append(uniq % P)
+        level_range.append((n_nodes, n_nodes + len(uniq)))
+        n_nodes += len(uniq)
+        cur = cur.copy()
+        cur[act] = ids
+        ends = act[e_len[act] == d + 1]
+        leaf[ends] = cur[ends]
+    parent = np.concatenate(parent_of)
+    phone = np.concatenate(phone_of)
+    N = n_nodes
+    # ---- LM look-ahead: node_min = cheapest word below the node; arcs carry the increments
+    node_min = np.full(N, np.inf)
+    np.minimum.at(node_min, leaf, e_cost)
+    for (b, e) in reversed(level_range[1:]):
+        np.minimum.at(node_min, parent[b:e], node_min[b:e])
+    par_min = np.where(parent >= 0, node_min[np.maximum(parent, 0)], 0.0)
+    into_node = node_min - par_min               # >= 0
+    word_end_res = e_cost - node_min[leaf]       # >= 0
+    # ---- pdfs: (phone, left-context phone, hmm state) -> clustered pdf
+    left = np.where(parent >= 0, phone[np.maximum(parent, 0)], P)      # P = word boundary context
+    pdf_tbl = rng.integers(0, num_pdfs, size=(P, P + 1, S))
+    node_pdf = pdf_tbl[phone, left]              # [N, S]
+    p_self = rng.uniform(0.45, 0.8, size=(N, S))
+    c_self = -np.log(p_self)
+    c_fwd = -np.log1p(-p_self)
+    # ---- states and arcs
+    n_hub = H + 1
+    num_states = n_hub + S * N
+
+    def sid(node, j):
+        return n_hub + node * S + j
+
+    nodes = np.arange(N, dtype=np.int64)
+    srcs, dsts, ils, ols, ws = [], [], [], [], []
+
+    def add(src, dst, il, ol, w):
+        srcs.append(np.asarray(src, np.int64)); dsts.append(np.asarray(dst, np.int64))
+        ils.append(np.asarray(il, np.int64)); ols.append(np.asarray(ol, np.int64)); ws.append(np.asarray(w, np.float64))
+
+    for j in range(S):           # self-loops
+        add(sid(nodes, j), sid(nodes, j), 2 * node_pdf[:, j] + 2, np.zeros(N, np.int64), c_self[:, j])
+    for j in range(S - 1):       # chain
+        add(sid(nodes, j), sid(nodes, j + 1), 2 * node_pdf[:, j + 1] + 1, np.zeros(N, np.int64), c_fwd[:, j])
+    top = parent < 0             # hub -> first phones
+    add(-parent[top] - 1, sid(nodes[top], 0), 2 * node_pdf[top, 0] + 1, np.zeros(int(top.sum()), np.int64), into_node[top])
+    ch = ~top                    # last chain state of the parent -> child
+    add(sid(parent[ch], S - 1), sid(nodes[ch], 0), 2 * node_pdf[ch, 0] + 1, np.zeros(int(ch.sum()), np.int64),
+        c_fwd[parent[ch], S - 1] + into_node[ch])
+    # word ends: epsilon, olabel = word id + 1
+    add(sid(leaf, S - 1), hist_of_word[e_word], np.zeros(E, np.int64), e_word + 1, c_fwd[leaf, S - 1] + word_end_res)
+    if H > 0:                    # back-off
+        add(1 + np.arange(H), np.zeros(H, np.int64), np.zeros(H, np.int64), np.zeros(H, np.int64), backoff)
+    src = np.concatenate(srcs); dst = np.concatenate(dsts)
+    il = np.concatenate(ils); ol = np.concatenate(ols); w = np.concatenate(ws)
+    order = np.argsort(src, kind="stable")
+    src, dst, il, ol, w = src[order], dst[order], il[order], ol[order], w[order]
+    offsets = np.zeros(num_states + 1, np.int64)
+    offsets[1:] = np.cumsum(np.bincount(src, minlength=num_states))
+    final = np.full(num_states, np.inf, np.float32)
+    final[:n_hub] = rng.uniform(final_cost_range[0], final_cost_range[1], n_hub).astype(np.float32)
+    num_tids = 2 * num_pdfs
+    tid2pdf = np.zeros(num_tids + 1, np.int32)
+    tid2pdf[1:] = (np.arange(1, num_tids + 1) - 1) // 2
+    return dict(num_states=int(num_states), start=0, arc_offsets=offsets, ilabel=il.astype(np.int32),
+                olabel=ol.astype(np.int32), weight=w.astype(np.float32), nextstate=dst.astype(np.int32),
+                final=final, tid2pdf=tid2pdf, num_words=int(V), num_hubs=int(n_hub), num_nodes=int(N))
+
+
+def sample_paths(rng, g, lengths):
+    """Random walks through the graph `g` (make_hclg_structured), one per utterance, all
+    advanced in lockstep: every arc is taken with probability proportional to
+    exp(-weight) among the arcs of its state (weights are -log probabilities up to the
+    LM look-ahead's normalisation); an emitting arc consumes one frame.  Returns, per
+    utterance, the int32 array of the pdf scored on each frame (the "true" state
+    sequence the synthetic acoustics below are built around) — utterance u has
+    lengths[u] entries."""
+    off = g["arc_offsets"]
+    il = g["ilabel"]
+    nxt = g["nextstate"]
+    t2p = g["tid2pdf"]
+    cum = np.cumsum(np.exp(-g["weight"].astype(np.float64)))
+    cum0 = np.concatenate([[0.0], cum])
+    lengths = np.asarray(lengths, np.int64)
+    n = len(lengths)
+    Tmax = int(lengths.max())
+    out = np.zeros((n, Tmax), np.int32)
+    state = np.full(n, int(g["start"]), np.int64)
+    t = np.zeros(n, np.int64)
+    alive = np.arange(n)
+    guard = 0
+    while len(alive) and guard < 4 * Tmax + 64:
+        guard += 1
+        s = state[alive]
+        lo, hi = cum0[off[s]], cum0[off[s + 1]]
+        target = lo + rng.random(len(alive)) * (hi - lo)
+        a = np.searchsorted(cum, target, side="right")
+        a = np.minimum(np.maximum(a, off[s]), off[s + 1] - 1)   # guard the segment ends against rounding
+        emit = il[a] != 0
+        ea = alive[emit]
+        out[ea, t[ea]] = t2p[il[a[emit]]]
+        t[ea] += 1
+        state[alive] = nxt[a]
+        alive = alive[t[alive] < lengths[alive]]
+    return [out[u, :lengths[u]].copy() for u in range(n)]
+
+
+def _pnorm_net_hidden(net, const_part):
+    """Input of the last affine layer for frames whose spliced part is zero and whose
+    un-spliced (const_dim) part is `const_part` [K, const_dim] (numpy restatement of the
+    layers of make_pnorm_net; workload construction only, never a checker)."""
+    sp = net[0]
+    K = const_part.shape[0]
+    x = np.zeros((K, sp["output_dim"]), np.float32)
+    x[:, sp["output_dim"] - sp["const_dim"]:] = const_part
+    last = max(i for i, c in enumerate(net) if c["type"] == "affine")
+    for c in net[1:last]:
+        t = c["type"]
+        if t in ("fixed_affine", "affine"):
+            x = x @ c["linear"].T + c["bias"]
+        elif t == "pnorm":
+            G = c["input_dim"] // c["output_dim"]
+            x = np.sqrt((x.reshape(K, c["output_dim"], G) ** 2).sum(-1)) if c["p"] == 2.0 else \
+                (np.abs(x.reshape(K, c["output_dim"], G)) ** c["p"]).sum(-1) ** (1.0 / c["p"])
+        elif t == "normalize":
+            x = x / np.sqrt(np.maximum((x * x).mean(1, keepdims=True), 2.0 ** -66))
+        else:
+            raise ValueError(t)
+    return x, last
+
+
+def _pnorm_net_posteriors(net, hidden, last):
+    x = hidden @ net[last]["linear"].T + net[last]["bias"]
+    for c in net[last + 1:]:
+        t = c["type"]
+        if t == "softmax":
+            x = np.exp(x - x.max(1, keepdims=True))
+            x /= x.sum(1, keepdims=True)
+        elif t == "sum_group":
+            ends = np.cumsum(c["sizes"])
+            x = np.add.reduceat(x, np.concatenate([[0], ends[:-1]]), axis=1)
+        else:
+            raise ValueError(t)
+    return x
+
+
+def pnorm_net_outputs(net, priors, const_part):
+    """DecodableAmNnet log-likelihoods (UNscaled: log posterior - log prior,
+    decodable-am-nnet.h:60-69) of make_pnorm_net's network for such frames.  Used ONLY to
+    construct the synthetic features (which candidate input makes which pdf score high)."""
+    h, last = _pnorm_net_hidden(net, const_part)
+    return np.log(np.maximum(_pnorm_net_posteriors(net, h, last), 1e-20)) - np.log(priors)[None, :]
+
+
+def calibrate_biases(rng, net, n=4096):
+    """Data-dependent initialisation of the random network's biases, so that its outputs
+    depend on the INPUT as a trained model's do.  p-norm activations are non-negative:
+    every hidden layer has a large constant component, which a random affine layer turns
+    into a fixed per-unit offset that swamps the input-dependent part, and after four
+    layers a random p-norm network is a constant function (measured: output std 0.01).
+    Each affine layer behind a p-norm layer gets bias = -W mean(input) over random input
+    frames (the layer then sees centred activations — what batch statistics / training
+    achieve), and the priors become the network's mean posterior over those inputs, which
+    is how the recipes obtain them (average posterior on training data,
+    steps/nnet2/train_pnorm_simple2.sh).  Modifies `net` in place, returns the priors."""
+    sp = net[0]
+    cd = sp["const_dim"]
+    K = n
+    x = np.zeros((K, sp["output_dim"]), np.float32)
+    x[:, sp["output_dim"] - cd:] = rng.standard_normal((K, cd)).astype(np.float32)
+    seen_pnorm = False
+    for c in net[1:]:
+        t = c["type"]
+        if t in ("fixed_affine", "affine"):
+            if seen_pnorm:
+                c["bias"] = (-(c["linear"] @ x.mean(0))).astype(np.float32)
+            x = x @ c["linear"].T + c["bias"]
+        elif t == "pnorm":
+            seen_pnorm = True
+            G = c["input_dim"] // c["output_dim"]
+            x = np.sqrt((x.reshape(K, c["output_dim"], G) ** 2).sum(-1)) if c["p"] == 2.0 else \
+                (np.abs(x.reshape(K, c["output_dim"], G)) ** c["p"]).sum(-1) ** (1.0 / c["p"])
+        elif t == "normalize":
+            x = x / np.sqrt(np.maximum((x * x).mean(1, keepdims=True), 2.0 ** -66))
+        elif t == "softmax":
+            x = np.exp(x - x.max(1, keepdims=True))
+            x /= x.sum(1, keepdims=True)
+        elif t == "sum_group":
+            ends = np.cumsum(c["sizes"])
+            x = np.add.reduceat(x, np.concatenate([[0], ends[:-1]]), axis=1)
+    pri = np.maximum(x.mean(0), 1e-7)
+    return (pri / pri.sum()).astype(np.float32)
+
+
+def make_pdf_prototypes(rng, net, priors, n_candidates=32768, chunk=4096):
+    """For every pdf, the candidate input (a random vector in the un-spliced part of the
+    feature frame) that makes the RANDOM-weight network score that pdf highest.  Returns
+    (protos [n_pdf, const_dim] float32, gain [n_pdf] = ll[pdf] of its prototype)."""
+    cd = net[0]["const_dim"]
+    n_pdf = len(priors)
+    best = np.full(n_pdf, -np.inf, np.float32)
+    protos = np.zeros((n_pdf, cd), np.float32)
+    for b in range(0, n_candidates, chunk):
+        cand = rng.standard_normal((min(chunk, n_candidates - b), cd)).astype(np.float32)
+        ll = pnorm_net_outputs(net, priors, cand)
+        k = ll.argmax(0)
+        v = ll[k, np.arange(n_pdf)]
+        upd = v > best
+        best[upd] = v[upd]
+        protos[upd] = cand[k[upd]]
+    return protos, best
+
+
+def make_path_features(rng, net, protos, pdf_seqs, noise=0.1, spliced_noise=0.01):
+    """Feature matrix [sum T, feat_dim] whose network outputs follow the pdf sequences.
+    The un-spliced part of a frame carries the prototype of a pdf plus N(0, noise^2), the
+    spliced part is N(0, spliced_noise^2).  SpliceComponent copies the un-spliced part of
+    OUTPUT row t from INPUT row t of the context-padded chunk (nnet-component.cc:2681-2687:
+    "it doesn't matter from where we copy"), i.e. from frame t - left_context, so frame s
+    carries the prototype of the pdf of frame s + left_context (the first left_context
+    output frames all see frame 0)."""
+    fd, cd = net[0]["input_dim"], net[0]["const_dim"]
+    left = -min(net[0]["context"])
+    shifted = [np.concatenate([q[left:], np.full(min(left, len(q)), q[-1], q.dtype)])[:len(q)] for q in pdf_seqs]
+    seq = np.concatenate(shifted)
+    x = np.empty((len(seq), fd), np.float32)
+    x[:, :fd - cd] = rng.standard_normal((len(seq), fd - cd)).astype(np.float32) * np.float32(spliced_noise)
+    x[:, fd - cd:] = protos[seq] + rng.standard_normal((len(seq), cd)).astype(np.float32) * np.float32(noise)
+    return x

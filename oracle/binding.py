@@ -600,3 +600,23 @@ def comp_objf_and_deriv(rows, cols, weights, output, deriv):
     lib.ko_comp_objf_and_deriv(C.c_int(len(r)), _ip(r), _ip(c), _fp(w), _fp(out), C.c_int(out.shape[1]),
                                _fp(deriv), C.c_int(deriv.shape[1]), C.byref(objf), C.byref(wt))
     return objf.value, wt.value
+
+
+def lattice_forward_backward_mmi(csr, tid2pdf, num_ali, drop_frames, convert_to_pdf_ids, cancel):
+    """ko_lattice_forward_backward_mmi (LatticeForwardBackwardMmi lat/lattice-functions.cc:1361-1396).
+    Returns dict(post = [[(id, weight), ...] per frame], tot_like, num_disjoint)."""
+    lib = C.CDLL(ORACLE_SO)
+    fn = lib.ko_lattice_forward_backward_mmi
+    fn.restype = C.c_double
+    off, il, ns, g, a, fin = _csr_args(csr)
+    t2p, ali = _i32(tid2pdf), _i32(num_ali)
+    cap = len(il) + len(ali) + 16
+    fo = np.empty(len(ali) + 1, np.int32)
+    ids, w = np.empty(cap, np.int32), np.empty(cap, np.float32)
+    n, nd = C.c_int32(), C.c_int32()
+    tot = fn(C.c_int(csr["n_states"]), off.ctypes.data_as(c_int64_p), _ip(il), _ip(ns), _fp(g), _fp(a), _fp(fin),
+             _ip(t2p), _ip(ali), C.c_int(len(ali)), C.c_int(int(drop_frames)), C.c_int(int(convert_to_pdf_ids)),
+             C.c_int(int(cancel)), _ip(fo), _ip(ids), _fp(w), C.c_int(cap), C.byref(n), C.byref(nd))
+    assert tot > -1.0e29
+    post = [[(int(ids[k]), float(w[k])) for k in range(fo[t], fo[t + 1])] for t in range(len(ali))]
+    return dict(post=post, tot_like=tot, num_disjoint=nd.value)

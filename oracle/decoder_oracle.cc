@@ -288,8 +288,15 @@ class Decoder {
       for (Token *tok = active_toks_[f].toks; tok != NULL; tok = tok->next)
         keys.push_back(Key{f, tok->state, tok});
     }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-      return a.f != b.f ? a.f < b.f : a.s < b.s;
+    // canonical order (frame, HCLG state), except that the start token comes first: the
+    // reference guarantees lattice state 0 = start through TopSortTokens (:839-914), and a
+    // start state with an epsilon arc to a lower-numbered state would otherwise not be first
+    const int32_t start = fst_.start;
+    std::sort(keys.begin(), keys.end(), [start](const Key &a, const Key &b) {
+      if (a.f != b.f) return a.f < b.f;
+      const bool as = !(a.f == 0 && a.s == start), bs = !(b.f == 0 && b.s == start);
+      if (as != bs) return as < bs;
+      return a.s < b.s;
     });
     std::unordered_map<Token *, int32_t> tok_map;
     tok_map.reserve(keys.size() * 2);

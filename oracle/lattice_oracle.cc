@@ -295,3 +295,143 @@ extern "C" void ko_comp_objf_and_deriv(int n, const int32_t *rows, const int32_t
     deriv[static_cast<size_t>(m) * deriv_stride + label] += weight / this_prob;
   }
 }
+
+// ---------------------------------------------------------------------------
+// LatticeForwardBackwardMmi lat/lattice-functions.cc:1361-1396 with the Posterior
+// algebra it uses, restated from hmm/posterior.cc (ScalePosterior :204-214,
+// PosteriorEntriesAreDisjoint :228-238, MergePosteriors :244-274, AlignmentToPosterior
+// :276-285, ConvertPosteriorToPdfs :308-332) and util/stl-utils.h:303-322
+// (MergePairVectorSumming).  hmm/posterior.cc includes hmm/transition-model.h, which
+// needs OpenFst's fst-decl.h: not buildable here, hence restated.  PARITY UNPINNED by the
+// reference (no test of it there); pinned by tests/test_lattice_oracle.py through path
+// enumeration: den posterior of (t, id) = sum over paths through an arc with that id at
+// time t of P(path), MMI posterior = numerator indicator - that.
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+namespace {
+typedef std::vector<std::vector<std::pair<int32_t, float> > > Posterior;
+
+void MergePairVectorSumming(std::vector<std::pair<int32_t, float> > *vec) {  // stl-utils.h:303-322
+  std::sort(vec->begin(), vec->end(),
+            [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) { return a.first < b.first; });
+  std::vector<std::pair<int32_t, float> >::iterator out = vec->begin(), in = vec->begin(), end = vec->end();
+  while (in < end) {
+    *out = *in;
+    ++in;
+    while (in < end && in->first == out->first) {
+      out->second += in->second;
+      ++in;
+    }
+    if (out->second != 0.0f) out++;
+  }
+  vec->erase(out, end);
+}
+
+void ScalePosterior(float scale, Posterior *post) {  // posterior.cc:204-214
+  if (scale == 1.0) return;
+  for (size_t i = 0; i < post->size(); i++) {
+    if (scale == 0.0) (*post)[i].clear();
+    else
+      for (size_t j = 0; j < (*post)[i].size(); j++) (*post)[i][j].second *= scale;
+  }
+}
+
+void ConvertPosteriorToPdfs(const int32_t *tid2pdf, const Posterior &post_in, Posterior *post_out) {  // :308-332
+  post_out->clear();
+  post_out->resize(post_in.size());
+  for (size_t i = 0; i < post_out->size(); i++) {
+    std::unordered_map<int32_t, float> pdf_to_post;
+    for (size_t j = 0; j < post_in[i].size(); j++) {
+      int32_t tid = post_in[i][j].first, pdf_id = tid2pdf[tid];
+      float post = post_in[i][j].second;
+      if (pdf_to_post.count(pdf_id) == 0) pdf_to_post[pdf_id] = post;
+      else pdf_to_post[pdf_id] += post;
+    }
+    (*post_out)[i].reserve(pdf_to_post.size());
+    for (std::unordered_map<int32_t, float>::const_iterator iter = pdf_to_post.begin(); iter != pdf_to_post.end(); ++iter)
+      if (iter->second != 0.0) (*post_out)[i].push_back(std::make_pair(iter->first, iter->second));
+  }
+}
+
+bool PosteriorEntriesAreDisjoint(const std::vector<std::pair<int32_t, float> > &e1,
+                                 const std::vector<std::pair<int32_t, float> > &e2) {  // :228-238
+  std::unordered_set<int32_t> set1;
+  for (size_t i = 0; i < e1.size(); i++) set1.insert(e1[i].first);
+  for (size_t i = 0; i < e2.size(); i++)
+    if (set1.count(e2[i].first) != 0) return false;
+  return true;
+}
+
+int32_t MergePosteriors(const Posterior &post1, const Posterior &post2, bool merge, bool drop_frames, Posterior *post) {  // :244-274
+  if (post1.size() != post2.size()) abort();  // KALDI_ASSERT :249
+  post->resize(post1.size());
+  int32_t num_disjoint = 0;
+  for (size_t i = 0; i < post->size(); i++) {
+    (*post)[i].reserve(post1[i].size() + post2[i].size());
+    (*post)[i].insert((*post)[i].end(), post1[i].begin(), post1[i].end());
+    (*post)[i].insert((*post)[i].end(), post2[i].begin(), post2[i].end());
+    if (merge) MergePairVectorSumming(&((*post)[i]));
+    else std::sort((*post)[i].begin(), (*post)[i].end());
+    if (PosteriorEntriesAreDisjoint(post1[i], post2[i])) {
+      num_disjoint++;
+      if (drop_frames) (*post)[i].clear();
+    }
+  }
+  return num_disjoint;
+}
+}  // namespace
+
+// Returns the denominator's total log-likelihood (:1372-1374).  Output posterior as
+// frame_offsets[num_frames + 1] + (ids, weights); -1.0e30 and *n_entries = needed if cap is too small.
+extern "C" double ko_lattice_forward_backward_mmi(int num_states, const int64_t *arc_offsets, const int32_t *arc_ilabel,
+                                                  const int32_t *arc_nextstate, const float *arc_graph,
+                                                  const float *arc_acoustic, const float *state_final,
+                                                  const int32_t *tid2pdf, const int32_t *num_ali, int n_ali,
+                                                  int drop_frames, int convert_to_pdf_ids, int cancel,
+                                                  int32_t *frame_offsets, int32_t *ids, float *weights, int cap,
+                                                  int32_t *n_entries, int32_t *num_disjoint) {
+  const int64_t n_arcs = arc_offsets[num_states];
+  std::vector<float> arc_post(n_arcs);
+  std::vector<int32_t> times(num_states);
+  // LatticeForwardBackward(lat, &den_post, NULL) :1372-1374
+  const double ans = ko_lattice_forward_backward(num_states, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic,
+                                                 state_final, arc_post.data(), NULL, times.data(), NULL);
+  int32_t max_time = 0;
+  for (int s = 0; s < num_states; s++) max_time = std::max(max_time, times[s]);
+  Posterior den_post(max_time);
+  // the reference pushes the entries in its backward sweep (states descending, arcs ascending) :317-333
+  for (int s = num_states - 1; s >= 0; s--)
+    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
+      if (arc_ilabel[a] != 0) den_post[times[s]].push_back(std::make_pair(arc_ilabel[a], arc_post[a]));
+  for (int32_t t = 0; t < max_time; t++) MergePairVectorSumming(&den_post[t]);  // :349-351
+  Posterior num_post(n_ali);  // AlignmentToPosterior posterior.cc:276-285
+  for (int i = 0; i < n_ali; i++) num_post[i].assign(1, std::make_pair(num_ali[i], 1.0f));
+  ScalePosterior(-1.0f, &den_post);  // :1381
+  if (convert_to_pdf_ids) {  // :1383-1390
+    Posterior num_tmp;
+    ConvertPosteriorToPdfs(tid2pdf, num_post, &num_tmp);
+    num_tmp.swap(num_post);
+    Posterior den_tmp;
+    ConvertPosteriorToPdfs(tid2pdf, den_post, &den_tmp);
+    den_tmp.swap(den_post);
+  }
+  Posterior post;
+  const int32_t nd = MergePosteriors(num_post, den_post, cancel != 0, drop_frames != 0, &post);  // :1392-1393
+  if (num_disjoint) *num_disjoint = nd;
+  int32_t total = 0;
+  for (size_t t = 0; t < post.size(); t++) total += static_cast<int32_t>(post[t].size());
+  *n_entries = total;
+  if (total > cap) return -1.0e30;
+  int32_t k = 0;
+  for (size_t t = 0; t < post.size(); t++) {
+    frame_offsets[t] = k;
+    for (size_t j = 0; j < post[t].size(); j++) {
+      ids[k] = post[t][j].first;
+      weights[k] = post[t][j].second;
+      k++;
+    }
+  }
+  frame_offsets[post.size()] = k;
+  return ans;
+}

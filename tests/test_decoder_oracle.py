@@ -255,3 +255,68 @@ def test_empty_like_edge_cases():
     L = dec.raw_lattice()
     assert L["state_frame"].max() == 1
     assert len(dec.best_path()["alignment"]) == 1
+
+
+def start_eps_graph():
+    """4 states, start = 2, an epsilon arc from the start to the LOWER-numbered state 0
+    (olabel 9): the canonical (frame, state) order alone would put state 0 first."""
+    arcs = {2: [(0, 9, 0.25, 0)], 0: [(1, 7, 0.75, 1)], 1: [(2, 0, 0.5, 1)], 3: []}
+    off, il, ol, w, ns = [0], [], [], [], []
+    for s in range(4):
+        for (i, o, c, n) in arcs[s]:
+            il.append(i); ol.append(o); w.append(c); ns.append(n)
+        off.append(len(il))
+    final = np.array([INF, 0.0, INF, INF], np.float32)
+    return dict(num_states=4, start=2, arc_offsets=np.array(off, np.int64), ilabel=np.array(il, np.int32),
+                olabel=np.array(ol, np.int32), weight=np.array(w, np.float32), nextstate=np.array(ns, np.int32),
+                final=final, tid2pdf=np.array([0, 0, 1], np.int32))
+
+
+def test_start_state_is_lattice_state_zero():
+    """The reference makes the start token lattice state 0 (TopSortTokens,
+    lattice-faster-decoder.cc:839-914): the best path must contain the start state's
+    epsilon arc (words [9, 7], graph cost 0.25 + 0.75 + 0.5)."""
+    g = start_eps_graph()
+    ll = np.zeros((2, 2), np.float32)
+    for mode in ("reference", "canonical"):
+        d = B.DecoderOracle(g, B.decoder_config(), mode)
+        assert d.decode(ll)
+        L = d.raw_lattice()
+        assert L["state_frame"][0] == 0 and L["state_hclg"][0] == 2
+        bp = d.best_path()
+        assert bp["words"].tolist() == [9, 7]
+        assert abs(bp["graph_cost"] - 1.5) < 1e-6
+
+
+def test_structured_graph_and_paths():
+    """make_hclg_structured: valid CSR, acyclic epsilon arcs of depth <= 2, arcs into a chain
+    state and its self-loop score the same pdf; sample_paths follows arcs of the graph."""
+    rng = np.random.default_rng(5)
+    g = workloads.make_hclg_structured(rng, 5000, 40)
+    n, off = g["num_states"], g["arc_offsets"]
+    assert off[0] == 0 and off[-1] == len(g["ilabel"]) and np.all(np.diff(off) >= 0)
+    src = np.repeat(np.arange(n), np.diff(off))
+    eps = g["ilabel"] == 0
+    hubs = g["num_hubs"]
+    assert np.all(g["nextstate"][eps] < hubs)                 # epsilons lead to LM states only
+    assert np.all(g["nextstate"][eps & (src < hubs)] == 0)     # back-off: history -> unigram state
+    assert not np.any(eps & (src == 0))                        # the unigram state has no epsilon arc: depth <= 2
+    assert np.all(g["weight"] >= 0)
+    pdf_in = {}
+    for a in np.nonzero(~eps)[0]:
+        pdf_in.setdefault(int(g["nextstate"][a]), set()).add(int(g["tid2pdf"][g["ilabel"][a]]))
+    assert all(len(v) == 1 for v in pdf_in.values())           # one pdf per chain state (self-loop included)
+    lens = [17, 60, 33]
+    seqs = workloads.sample_paths(np.random.default_rng(6), g, lens)
+    assert [len(s) for s in seqs] == lens
+    # a sampled path is a path of the graph: decoding its one-hot scores recovers it
+    # (every state final, so that the path may end inside a word; a mismatch costs more
+    # than any graph-cost saving)
+    T = 60
+    ll = np.full((T, 40), -100.0, np.float32)
+    ll[np.arange(T), seqs[1]] = 0.0
+    g2 = dict(g, final=np.zeros(n, np.float32))
+    d = B.DecoderOracle(g2, B.decoder_config(beam=60.0, lattice_beam=2.0), "canonical")
+    assert d.decode(ll)
+    ali = d.best_path()["alignment"]
+    assert np.array_equal(g["tid2pdf"][ali], seqs[1])

@@ -253,31 +253,88 @@ def test_random_configurations(api, seed, monkeypatch):
                 assert max_active < 2147483647, (seed, u, c_got, c_want)
 
 
-def test_capacity_overflow_is_reported_not_hidden(api, monkeypatch):
-    """An arena that is too small ends the utterance with KH_ECAPACITY and a message naming
-    the knob — never a silent truncation; the same decoder works again with room."""
+def test_capacity_overflow_is_retried_then_reported(api, monkeypatch):
+    """Arena sizes are estimates.  An utterance that outgrows them is decoded again with
+    doubled arenas (bit-exact result); one that still overflows at 16 x is left FAILED on its
+    own - the other utterances of the batch keep their lattices and the same decoder object
+    decodes the next batch correctly (no stale work-list flags)."""
     rng = np.random.default_rng(9)
     g = graph_like_hclg(rng, 20000, 200)
     x = workloads.make_loglikes(rng, 40, 200)
+    tiny = workloads.make_loglikes(rng, 1, 200)          # one frame: a handful of tokens
     cfg = api.decoder_config(beam=9.0, lattice_beam=6.0)
     fst = api.Fst(g)
-    monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", "64")
-    small = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=40)
-    with pytest.raises(api.KhError, match="KH_DECODER_TOKENS_PER_FRAME"):
-        small.decode(torch.from_numpy(x).cuda())
+    oc = B.DecoderOracle(g, cfg, "canonical")
+    assert oc.decode(x)
+    want_x = oc.raw_lattice()
+    need = oc.stats()["max_tokens_frame"]
+    assert need > 16 * 8
+    oc1 = B.DecoderOracle(g, cfg, "canonical")
+    assert oc1.decode(tiny)
+    want_tiny = oc1.raw_lattice()
+    # (a) first launch too small, a retry with larger arenas succeeds
+    cap = 1
+    while cap * 4 < need:
+        cap *= 2                                         # needs 2-3 doublings
+    monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", str(cap))
+    monkeypatch.setenv("KH_DECODER_WINDOW_TOKENS_PER_FRAME", str(cap))
+    grown = api.LatticeFasterDecoder(fst, cfg, max_batch=2, max_frames=40)
+    off = np.array([0, 40, 41], np.int32)
+    grown.decode(torch.from_numpy(np.concatenate([x, tiny])).cuda(), off)
+    assert_same_lattice(grown.get_raw_lattice(0), want_x)
+    assert_same_lattice(grown.get_raw_lattice(1), want_tiny)
+    # (b) hopeless: the utterance fails alone, with a message naming the knob
+    monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", "8")
+    monkeypatch.setenv("KH_DECODER_WINDOW_TOKENS_PER_FRAME", "8")
+    monkeypatch.setenv("KH_DECODER_SLOTS", "1")          # both utterances on ONE slot: reuse right after the overflow
+    small = api.LatticeFasterDecoder(fst, cfg, max_batch=2, max_frames=40)
+    small.decode(torch.from_numpy(np.concatenate([x, tiny])).cuda(), off)
+    with pytest.raises(api.KhError, match="overflow"):
+        small.get_raw_lattice(0)
+    assert small.counters(0)["status"] != 0
+    assert_same_lattice(small.get_raw_lattice(1), want_tiny)
+    # the same decoder object, next batch
+    small.decode(torch.from_numpy(tiny).cuda())
+    assert_same_lattice(small.get_raw_lattice(0), want_tiny)
     monkeypatch.delenv("KH_DECODER_TOKENS_PER_FRAME")
+    monkeypatch.delenv("KH_DECODER_WINDOW_TOKENS_PER_FRAME")
+    monkeypatch.delenv("KH_DECODER_SLOTS")
     monkeypatch.setenv("KH_DECODER_POOL_TOKENS_PER_FRAME", "1")   # lattice pool far too small: exact-size retry
     ok = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=40)
     ok.decode(torch.from_numpy(x).cuda())
-    oc = B.DecoderOracle(g, cfg, "canonical")
-    assert oc.decode(x)
-    assert_same_lattice(ok.get_raw_lattice(0), oc.raw_lattice())
+    assert_same_lattice(ok.get_raw_lattice(0), want_x)
     # online streams report the overflow from advance_decoding
     monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", "64")
     on = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=1, max_frames=40)
     on.init_decoding([0])
     with pytest.raises(api.KhError, match="overflowed"):
         on.advance_decoding([0], [torch.from_numpy(x).cuda()])
+
+
+def test_start_state_with_epsilon_to_lower_state(api):
+    """Start state 2 with an epsilon arc to state 0: lattice state 0 must be the start token
+    (TopSortTokens :839-914), so the best path keeps the start's epsilon arc."""
+    from test_decoder_oracle import start_eps_graph
+    g = start_eps_graph()
+    ll = np.zeros((2, 2), np.float32)
+    dec = run_case(api, g, [ll], api.decoder_config())
+    L = dec.get_raw_lattice(0)
+    assert L["state_frame"][0] == 0 and L["state_hclg"][0] == 2
+    assert dec.get_best_path(0)["words"].tolist() == [9, 7]
+
+
+def test_pdf_map_is_validated(api):
+    """A transition-id without a pdf column is an error, not an out-of-bounds read."""
+    rng = np.random.default_rng(3)
+    g = graph_like_hclg(rng, 200, 30)
+    fst = api.Fst(g)
+    dec = api.LatticeFasterDecoder(fst, api.decoder_config(), max_batch=1, max_frames=10)
+    with pytest.raises(api.KhError, match="pdf"):
+        dec.decode(torch.zeros((10, 20), device="cuda"))     # 30 pdfs, 20 columns
+    g2 = dict(g, tid2pdf=g["tid2pdf"][:10])
+    with pytest.raises(api.KhError, match="ilabel"):
+        api.LatticeFasterDecoder(api.Fst(g2), api.decoder_config(), max_batch=1, max_frames=10).decode(
+            torch.zeros((10, 30), device="cuda"))
 
 
 def test_decoder_object_reused_across_batches(api):

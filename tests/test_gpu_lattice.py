@@ -125,6 +125,11 @@ def test_mmi_posteriors(api):
     lats = [random_lattice(rng, n_frames=int(T), width=4) for T in (6, 13)]
     _, t2pdf = _trans(rng)
     alis = [rng.integers(1, 50, T).astype(np.int32) for T in (6, 13)]
+    for L, ali in zip(lats, alis):   # half of the numerator labels occur in the lattice (cancellation, non-disjoint frames)
+        times = B.lattice_forward_backward(L)["state_times"]
+        src = np.repeat(np.arange(L["n_states"]), np.diff(L["arc_offsets"]))
+        for t in range(0, len(ali), 2):
+            ali[t] = int(rng.choice(L["arc_ilabel"][(times[src] == t) & (L["arc_ilabel"] != 0)]))
     fb = api.lattice_forward_backward(lats)
     for conv in (False, True):
         for cancel in (False, True):
@@ -138,6 +143,18 @@ def test_mmi_posteriors(api):
                         assert ids == sorted(set(ids))
                     ref_id = int(t2pdf[ali[t]]) if conv else int(ali[t])
                     assert ref_id in ids or cancel              # cancelled entries (exactly 0) are dropped
+    # against the oracle's restatement of LatticeForwardBackwardMmi + hmm/posterior.cc, every flag combination
+    for conv in (False, True):
+        for cancel in (False, True):
+            for drop in (False, True):
+                outs = api.lattice_forward_backward_mmi(lats, t2pdf, alis, drop_frames=drop, convert_to_pdf_ids=conv, cancel=cancel)
+                for L, ali, o in zip(lats, alis, outs):
+                    want = B.lattice_forward_backward_mmi(L, t2pdf, ali, drop, conv, cancel)
+                    assert abs(o["tot_like"] - want["tot_like"]) < 1e-9 * max(1.0, abs(want["tot_like"]))
+                    assert len(o["post"]) == len(want["post"])
+                    for g, w in zip(o["post"], want["post"]):
+                        assert [i for i, _ in g] == [i for i, _ in w], (g, w)
+                        assert np.allclose([v for _, v in g], [v for _, v in w], atol=1e-6)
     # drop_frames: frames where the numerator label is not in the denominator lattice are emptied
     outs = api.lattice_forward_backward_mmi(lats, t2pdf, alis, drop_frames=True, convert_to_pdf_ids=False, cancel=True)
     for o, r, ali in zip(outs, fb, alis):

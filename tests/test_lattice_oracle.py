@@ -203,3 +203,75 @@ def test_rescore_lattice_and_objf_deriv():
     objf, wt = B.comp_objf_and_deriv(rows, cols, w, out, deriv)
     assert abs(objf - sum(x * np.log(out[r, c]) for r, c, x in zip(rows, cols, w))) < 1e-5 and abs(wt - 2.75) < 1e-6
     assert abs(deriv[3, 2] - (-0.5 + 0.25) / out[3, 2]) < 1e-5 and deriv.sum() != 0
+
+
+def mmi_by_enumeration(L, tid2pdf, num_ali, drop_frames, convert_to_pdf_ids, cancel):
+    """LatticeForwardBackwardMmi from its definition: the denominator posterior of (t, id) =
+    sum over complete paths of P(path) x [the path's t-th emitting arc carries id] (float64,
+    every path enumerated); MMI posterior = numerator indicator - denominator posterior, by
+    transition-id or by pdf; `cancel` sums the two per id, `drop_frames` empties the frames
+    whose numerator id does not occur in the denominator."""
+    off = L["arc_offsets"]
+    cost = (L["arc_graph"] + L["arc_acoustic"]).astype(np.float64)
+    T = len(num_ali)
+    den = [dict() for _ in range(T)]
+    tot = 0.0
+    stack = [(0, 0.0, [])]
+    while stack:
+        s, c, path = stack.pop()
+        if np.isfinite(L["state_final"][s]):
+            p = np.exp(-(c + float(L["state_final"][s])))
+            tot += p
+            t = 0
+            for a in path:
+                tid = int(L["arc_ilabel"][a])
+                if tid != 0:
+                    den[t][tid] = den[t].get(tid, 0.0) + p
+                    t += 1
+        for a in range(off[s], off[s + 1]):
+            stack.append((int(L["arc_nextstate"][a]), c + cost[a], path + [a]))
+    key = (lambda i: int(tid2pdf[i])) if convert_to_pdf_ids else (lambda i: int(i))
+    out = []
+    for t in range(T):
+        d = {}
+        for tid, p in den[t].items():
+            d[key(tid)] = d.get(key(tid), 0.0) - p / tot
+        n = {key(int(num_ali[t])): 1.0}
+        disjoint = not (set(n) & set(d))
+        if cancel:
+            fr = dict(d)
+            for k, v in n.items():
+                fr[k] = fr.get(k, 0.0) + v
+            fr = sorted(fr.items())
+        else:
+            fr = sorted(list(n.items()) + list(d.items()))
+        out.append([] if (disjoint and drop_frames) else fr)
+    return out, np.log(tot)
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("convert,cancel,drop", [(False, False, False), (True, True, False), (False, True, True), (True, False, True)])
+def test_mmi_matches_path_enumeration(seed, convert, cancel, drop):
+    """Pins ko_lattice_forward_backward_mmi (LatticeForwardBackwardMmi :1361-1396 + the
+    Posterior algebra of hmm/posterior.cc) against the definition."""
+    rng = np.random.default_rng(100 + seed)
+    L = random_lattice(rng, n_frames=5, width=3)
+    tid2pdf = np.concatenate([[0], rng.integers(0, 8, 50)]).astype(np.int32)
+    # half of the numerator labels are taken from the lattice (so that cancellation and
+    # non-disjoint frames occur), half are random
+    times = B.lattice_forward_backward(L)["state_times"]
+    src = np.repeat(np.arange(L["n_states"]), np.diff(L["arc_offsets"]))
+    ali = []
+    for t in range(5):
+        here = L["arc_ilabel"][(times[src] == t) & (L["arc_ilabel"] != 0)]
+        ali.append(int(rng.choice(here)) if rng.random() < 0.5 else int(rng.integers(1, 50)))
+    got = B.lattice_forward_backward_mmi(L, tid2pdf, ali, drop, convert, cancel)
+    want, logtot = mmi_by_enumeration(L, tid2pdf, ali, drop, convert, cancel)
+    assert abs(got["tot_like"] - logtot) < 1e-9
+    assert len(got["post"]) == 5
+    for g, w in zip(got["post"], want):
+        if cancel:   # exact zeros are dropped by MergePairVectorSumming; enumeration keeps ~1e-17 residues
+            w = [(i, v) for i, v in w if abs(v) > 1e-6]
+            g = [(i, v) for i, v in g if abs(v) > 1e-6]
+        assert [i for i, _ in g] == [i for i, _ in w], (g, w)
+        assert np.allclose([v for _, v in g], [v for _, v in w], atol=2e-6)
