@@ -54,7 +54,7 @@ PKG = "old-kaldi-git_amd"
 
 ACWT = 0.1
 DECODE_CFG = dict(beam=15.0, max_active=7000, min_active=200, lattice_beam=8.0)
-FEATURE_NOISE = 0.10          # N(0, .) on the prototype part of the features: sets the frame accuracy (~0.9)
+FEATURE_NOISE = 0.20          # N(0, .) on the prototype part of the features: sets the frame accuracy (~0.8) and the lattice density
 
 
 def parse_args(argv=None):

@@ -20,10 +20,12 @@
 //    by wave-aggregated atomics; forward links are appended through
 //    workgroup prefix sums (ballot/shuffle scans);
 //  * the max-active / min-active cutoffs (std::nth_element in the reference) are
-//    an exact 4-pass LDS radix select over the cost images;
+//    an exact LDS radix select over the cost images, restricted to the bits in which the
+//    frame's smallest and largest key differ (2 passes of 11 bits);
 //  * backward pruning iterates extra_costs to the exact fixed point per frame;
-//    every prune_interval frames survivors are compacted out of the "raw" arenas
-//    (R) into the compact arenas (C) so the working set stays cache resident.
+//    tokens and links live in ONE append-only arena each, in frame order; every
+//    prune_interval frames the tail of the arenas (the "window") is compacted in place so
+//    that the working set stays small and the slot's memory does not depend on T.
 //
 // Semantics: the order-independent ("canonical") resolution of the reference's
 // iteration-order artefacts, defined in oracle/decoder_oracle.cc (mode 3) and
@@ -65,7 +67,7 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 27;            // diagnostic counters per slot
+constexpr int NPH = 34;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x3fffffff;
@@ -256,6 +258,7 @@ struct Shared {
   int ex_off[EU * NT], ex_ab[EU * NT], ex_tok[EU * NT];  // ExpandSweep: first link slot, first arc, token of the group's items
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
+  int link_cursor;  // ExpandSweepFiltered: next free link slot (LDS atomic, one add per wave)
   int front_b;  // first token of the frame under construction (frontier)
   int status;
   long long arcs_expanded, tokens_created;
@@ -592,6 +595,85 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off,
   return lrun;
 }
 
+// ExpandSweep for the emitting arcs with a FILTER: eval(token, arc index) computes the
+// candidate and says whether it can still be accepted; only those get a link slot (store(slot)),
+// appended per wave through one LDS atomic (ballot + prefix count), so the slots of a frame are
+// dense.  The reference materialises nothing it rejects either (:731 "continue"); here a
+// candidate is known to be rejected when it is above an upper bound of the frame's final
+// next_cutoff.  Returns the new end of the link arena, or -1 on overflow (sh->status set).
+template <class Eval, class Store>
+__device__ __forceinline__ int ExpandSweepFiltered(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
+                                                   int frame_cap, long long *arcs, Blk &sh, Eval eval, Store store) {
+  const int limit = min(u.link_cap, lrun + frame_cap);
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) sh->link_cursor = lrun;  // (visible behind the first group's scan barrier)
+  for (int base = b; base < e; base += NT * EU) {
+    int i[EU], st[EU];
+    uint32_t co[EU];
+    bool in_range[EU];
+#pragma unroll
+    for (int k = 0; k < EU; k++) {
+      i[k] = base + k * NT + threadIdx.x;
+      in_range[k] = i[k] < e;
+      const int ic = min(i[k], e - 1);
+      co[k] = LoadCostEnc(&u.tok_cost[ic]);
+      st[k] = u.tok_state[ic];
+      KH_BOUND(1, st[k], 0, 0x7ffffff0);
+    }
+    int ab[EU], cnt[EU];
+#pragma unroll
+    for (int k = 0; k < EU; k++) {
+      const bool need = in_range[k] && Dec(co[k]) <= cutoff;
+      ab[k] = 0;
+      cnt[k] = 0;
+      if (need) {
+        ab[k] = off[st[k]];
+        cnt[k] = off[st[k] + 1] - ab[k];
+      }
+    }
+    int loff[EU], total;
+    // (this barrier also orders the previous group's LDS reads before the writes below)
+    BlockExScanK<EU>(cnt, loff, &total, sh);
+#pragma unroll
+    for (int k = 0; k < EU; k++) {  // slice-major item order = the scan's order: ex_off is non-decreasing
+      sh->ex_off[k * NT + threadIdx.x] = loff[k];
+      sh->ex_ab[k * NT + threadIdx.x] = ab[k];
+      sh->ex_tok[k * NT + threadIdx.x] = i[k];
+    }
+    KhSync();
+    for (int q0 = 0; q0 < total; q0 += NT) {  // uniform trip count (wave ballots inside)
+      const int q = q0 + threadIdx.x;
+      bool keep = false;
+      if (q < total) {
+        // owner = the LAST item whose first slot is <= q (items without arcs share their
+        // successor's first slot and are skipped by "last")
+        int lo = 0, hi = EU * NT - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (sh->ex_off[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        keep = eval(sh->ex_tok[lo], sh->ex_ab[lo] + (q - sh->ex_off[lo]));
+      }
+      const unsigned long long kb = __ballot(keep);
+      if (kb != 0ull) {
+        const int n_keep = __popcll(kb);
+        int pos = 0;
+        if (lane == 0) pos = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pos = Uni(pos);
+        if (pos + n_keep > limit) {
+          if (lane == 0) sh->status = (pos + n_keep > u.link_cap) ? 2 : 3;
+        } else if (keep) {
+          store(pos + __popcll(kb & ((1ull << lane) - 1ull)));
+        }
+      }
+    }
+    if (threadIdx.x == 0) *arcs += total;
+  }
+  KhSync();  // the links are visible to the next phase
+  if (Uni(sh->status) != 0) return -1;
+  return Uni(sh->link_cursor);
+}
+
 // ---------------------------------------------------------------- frame steps
 struct Cutoff {
   float cur_cutoff, adaptive_beam, best_cost;
@@ -683,40 +765,93 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
     const Arr<const int32_t> cur = r == 0 ? u.tmp_epslist : ((r & 1) ? u.tmp_work1 : u.tmp_work0);
     const Arr<int32_t> nxt = (r & 1) ? u.tmp_work0 : u.tmp_work1;
     auto nxt_n = &sh->wl_n[(r + 1) % 3];
-    for (int q = threadIdx.x; q < n; q += NT) {
-      const int i = cur[q];
-      // leave the queue BEFORE reading the cost: a later improvement queues the token again.
-      // The flag and the cost are different words (different L2 channels): the store must have
-      // been performed before the load is issued, or an improver could see the stale flag (no
-      // re-queue) while this lane still reads the old cost - a lost update.
-      (void)__hip_atomic_exchange(&u.tmp_dirty[i - fb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const float cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
-      if (cur_cost > cutoff) continue;  // :779
-      const int32_t s = u.tok_state[i];
-      const int ab = p.n_off[s], ae = p.n_off[s + 1];
-      for (int a = ab; a < ae; a++) {
-        const KhInt4 arc = p.n_arcs[a];
-        my_arcs++;
-        const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
-        if (tot_cost < cutoff) {  // :794
-          const bool he = (arc.w & kHasEps) != 0;
-          const int dst = FindOrAdd<false>(u, arc.w & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, fb);
+    const int lane = threadIdx.x & 63;
+    long long tcl = 0;
+    const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0;
+    if (prof) tcl = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#define KH_CL_STAMP(k) do { if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tcl; tcl = now_; } } while (0)
+    if (prof) sh->phase[33] += n;
+    for (int q0 = 0; q0 < n; q0 += NT) {  // uniform trip count: the wave-level combine below involves every lane
+      const int q = q0 + threadIdx.x;
+      float cur_cost = INFINITY;
+      int ab = 0, ae = 0;
+      if (q < n) {
+        const int i = cur[q];
+        // leave the queue BEFORE reading the cost: a later improvement queues the token again.
+        // The flag and the cost are different words (different L2 channels): the store must have
+        // been performed before the load is issued, or an improver could see the stale flag (no
+        // re-queue) while this lane still reads the old cost - a lost update.
+        (void)__hip_atomic_exchange(&u.tmp_dirty[i - fb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
+        if (!(cur_cost > cutoff)) {  // :779
+          const int32_t s = u.tok_state[i];
+          ab = p.n_off[s];
+          ae = p.n_off[s + 1];
+        }
+      }
+      KH_CL_STAMP(27);
+      // The arcs of the wave's tokens in lockstep.  In an HCLG the epsilon arcs of a frame
+      // lead to a handful of states (word ends -> language-model states -> the back-off
+      // state): hundreds of lanes doing FindOrAdd + atomicMin on ONE hash slot / cost word
+      // serialise in L2 (35 % of the kernel on the structured workload).  The lanes of a wave
+      // that target the same state are combined first - their minimum goes out once, by the
+      // first of them; all leaders then issue their global operations together.
+      for (int j = 0; __ballot(ab + j < ae) != 0ull; j++) {
+        bool ok = false;
+        int32_t ds = 0;
+        uint32_t enc = 0xFFFFFFFFu;
+        if (ab + j < ae) {
+          const KhInt4 arc = p.n_arcs[ab + j];
+          my_arcs++;
+          const float graph_cost = __int_as_float(arc.z), tot_cost = cur_cost + graph_cost;
+          if (tot_cost < cutoff) {  // :794
+            ok = true;
+            ds = arc.w;
+            enc = Enc(tot_cost);
+          }
+        }
+        unsigned long long todo = __ballot(ok);
+        bool lead = ok;
+        uint32_t gmin = enc;
+        for (int it = 0; todo != 0ull && it < 16; it++) {  // (past 16 distinct states the rest go out one by one)
+          const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+          const int32_t key = __builtin_amdgcn_readlane(ds, leader);
+          const bool mine = ok && ds == key;
+          const unsigned long long grp = __ballot(mine);
+          uint32_t m = mine ? enc : 0xFFFFFFFFu;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), o, 64));
+            m = other < m ? other : m;
+          }
+          if (mine) {
+            gmin = m;
+            lead = lane == leader;
+          }
+          todo &= ~grp;
+        }
+        KH_CL_STAMP(28);
+        if (ok && lead) {
+          const bool he = (ds & kHasEps) != 0;
+          const int dst = FindOrAdd<false>(u, ds & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, fb);
           if (dst < 0) { sh->status = 1; continue; }
-          const uint32_t enc = Enc(tot_cost);
           if (he) {
-            const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (enc < old &&  // "changed": new or cheaper -> (re)process dst
+            const uint32_t old = __hip_atomic_fetch_min(&u.tok_cost[dst], gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gmin < old &&  // "changed": new or cheaper -> (re)process dst
                 __hip_atomic_exchange(&u.tmp_dirty[dst - fb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
               nxt[__hip_atomic_fetch_add(nxt_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = dst;
           } else {
-            (void)__hip_atomic_fetch_min(&u.tok_cost[dst], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_min(&u.tok_cost[dst], gmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        KH_CL_STAMP(29);
       }
     }
     if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
     KhSync();
+    KH_CL_STAMP(30);
+#undef KH_CL_STAMP
     if (Uni(sh->status) != 0) return false;
   }
   KhSync();
@@ -809,31 +944,42 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   }
   if (threadIdx.x == 0) u.cost_offset[frame] = cost_offset;  // :710-711
 
-  // ---- pass 1: one candidate link per emitting arc of every token under
-  // cur_cutoff (token sweep + scan), then a link sweep that fetches the arcs and
-  // the acoustic scores, writes the links with their tot_cost and reduces
-  // min(tot_cost + adaptive_beam).
+  // ---- pass 1: the emitting arcs of every token under cur_cutoff (token sweep + scan, then
+  // one lane per arc): fetches the arc and the acoustic score, reduces
+  // min(tot_cost + adaptive_beam) and materialises the candidates that can still be accepted.
+  // est0 = the estimate from the best token's arcs (:692-704) is an upper bound of the final
+  // next_cutoff, so a candidate above it is rejected whatever the rest of the frame holds.
+  const float est0 = BlockMinF(est, sh);
+  est = est0;
   const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
-  const int link_frame_e = ExpandSweep<false>(
-      u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, [&](int l, int src, int ai) {
+  KhInt4 c_arc;
+  int c_src = 0;
+  float c_ac = 0.f, c_tot = 0.f;
+  const int link_frame_e = ExpandSweepFiltered(
+      u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh,
+      [&](int src, int ai) -> bool {
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_emit);
-        const KhInt4 arc = p.e_arcs[ai];
+        c_arc = p.e_arcs[ai];
+        c_src = src;
         const uint32_t co = LoadCostEnc(&u.tok_cost[src]);
-        int32_t pdf = p.tid2pdf ? p.tid2pdf[arc.x] : arc.x - 1;
+        int32_t pdf = p.tid2pdf ? p.tid2pdf[c_arc.x] : c_arc.x - 1;
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
-        const float ac_cost = cost_offset - like, graph_cost = __int_as_float(arc.z),
-                    tot_cost = Dec(co) + ac_cost + graph_cost;  // :726-730
-        u.link_dst[l] = arc.w;  // HCLG next state for now; token index after pass 2
-        u.link_src[l] = src;
-        u.link_il[l] = arc.x;
-        u.link_ol[l] = arc.y;
-        u.link_g[l] = graph_cost;
-        u.link_a[l] = ac_cost;
-        u.link_tot[l - link_frame_b] = tot_cost;
-        est = fminf(est, tot_cost + c.adaptive_beam);
+        c_ac = cost_offset - like;
+        c_tot = Dec(co) + c_ac + __int_as_float(c_arc.z);  // :726-730
+        est = fminf(est, c_tot + c.adaptive_beam);
+        return !(c_tot > est0);
+      },
+      [&](int l) {
+        u.link_dst[l] = c_arc.w;  // HCLG next state for now; token index after pass 2
+        u.link_src[l] = c_src;
+        u.link_il[l] = c_arc.x;
+        u.link_ol[l] = c_arc.y;
+        u.link_g[l] = __int_as_float(c_arc.z);
+        u.link_a[l] = c_ac;
+        u.link_tot[l - link_frame_b] = c_tot;
       });
   if (link_frame_e < 0) return false;
   // final next_cutoff: the value the reference's running cutoff converges to
@@ -2263,6 +2409,10 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
           "emitting links %.1f%%, token + epsilon sweeps %.1f%%, excise + flags %.1f%%\n",
           NT, tot[6] ? 100.0 * tot[20] / tot[6] : 0.0, tot[6] ? 100.0 * tot[21] / tot[6] : 0.0,
           tot[6] ? 100.0 * tot[22] / tot[6] : 0.0, tot[6] ? 100.0 * tot[23] / tot[6] : 0.0);
+  fprintf(stderr, "[kh_decoder profile] eps closure (thread 0), share of its cycles: list/flag/cost/state/offsets %.1f%%, arcs + wave combine %.1f%%, "
+          "FindOrAdd + min + queue %.1f%%, round barrier %.1f%%; tokens processed per round %.1f\n",
+          tot[3] ? 100.0 * tot[27] / tot[3] : 0.0, tot[3] ? 100.0 * tot[28] / tot[3] : 0.0, tot[3] ? 100.0 * tot[29] / tot[3] : 0.0,
+          tot[3] ? 100.0 * tot[30] / tot[3] : 0.0, tot[13] ? double(tot[33]) / tot[13] : 0.0);
   fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
           tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);
 }

@@ -100,8 +100,37 @@ class CuDevice {
     return buf;
   }
   void PrintMemoryUsage() const { fprintf(stderr, "Memory used: %s\n", GetFreeMemory().c_str()); }  // :465
-  void CheckGpuHealth() { KhCheck(kh_synchronize()); }                                              // :563
-  bool DoublePrecisionSupported() const { return true; }                                           // :407
+  /// CheckGpuHealth() cu-device.cc:509-527: a 50x100 by 100x50 product on the device against
+  /// the same product on the host, relative difference < 1 % (AssertEqual(c, c1, 0.01)).
+  void CheckGpuHealth() {
+    if (!Enabled()) return;
+    const int m = 50, k = 100, n = 50;
+    std::vector<float> a(m * k), b(k * n), c(m * n, 0.f), c1(m * n, 0.f);
+    unsigned s = 12345u;
+    for (size_t i = 0; i < a.size(); i++) { s = s * 1664525u + 1013904223u; a[i] = (int(s >> 8) % 2001 - 1000) * 1e-3f; }
+    for (size_t i = 0; i < b.size(); i++) { s = s * 1664525u + 1013904223u; b[i] = (s >> 8) % 1000 * 1e-3f; }
+    for (int i = 0; i < m; i++)
+      for (int j = 0; j < n; j++) {
+        float acc = 0.f;
+        for (int q = 0; q < k; q++) acc += a[i * k + q] * b[q * n + j];
+        c[i * n + j] = acc;
+      }
+    float *da = static_cast<float *>(Malloc(a.size() * 4)), *db = static_cast<float *>(Malloc(b.size() * 4)),
+          *dc = static_cast<float *>(Malloc(c.size() * 4));
+    KhCheck(kh_memcpy_2d(da, k * 4, a.data(), k * 4, k * 4, m, 0));
+    KhCheck(kh_memcpy_2d(db, n * 4, b.data(), n * 4, n * 4, k, 0));
+    KhMatrixDim dA = {m, k, k}, dB = {k, n, n}, dC = {m, n, n};
+    KhCheck(kh_add_mat_mat(1.0f, da, dA, 0, db, dB, 0, 0.0f, dc, dC));
+    KhCheck(kh_memcpy_2d(c1.data(), n * 4, dc, n * 4, n * 4, m, 1));
+    KhCheck(kh_synchronize());
+    Free(da); Free(db); Free(dc);
+    double diff = 0.0, norm = 0.0;
+    for (size_t i = 0; i < c.size(); i++) { diff += double(c[i] - c1[i]) * (c[i] - c1[i]); norm += double(c[i]) * c[i]; }
+    if (!(std::sqrt(diff) <= 0.01 * std::sqrt(norm))) throw std::runtime_error("CheckGpuHealth: device GEMM differs from the host GEMM");
+  }
+  /// DoublePrecisionSupported() cu-device.cc:407: this library has float kernels only (the
+  /// decode path runs with KALDI_DOUBLEPRECISION=0; the cudaD_* twins are not provided).
+  bool DoublePrecisionSupported() const { return false; }
   void SetVerbose(bool verbose) { verbose_ = verbose; }
   /// AccuProfile / PrintProfile / ResetProfile cu-device.cc:379-405
   void AccuProfile(const std::string &key, double time) { profile_map_[key] += time; }

@@ -208,7 +208,7 @@ def make_loglikes(rng, T, num_pdfs, peak=6.0, acwt=0.1, stickiness=0.9):
 # makes real raw lattices tens of arcs per frame wide.
 # --------------------------------------------------------------------------
 def make_hclg_structured(rng, target_states, num_pdfs, n_phones=None, n_words=None, hmm_states=3,
-                         mean_pron=4.5, final_cost_range=(1.0, 5.0)):
+                         mean_pron=5.5, final_cost_range=(1.0, 5.0)):
     """Synthetic HCLG with the structure of the real one, about `target_states` states.
 
     States: hub 0 (unigram / start), hubs 1..H (bigram histories), then `hmm_states`
@@ -229,12 +229,23 @@ def make_hclg_structured(rng, target_states, num_pdfs, n_phones=None, n_words=No
     if n_words is None:
         n_words = max(3, int(n_entries * 0.27))
     V = n_words
-    # ---- lexicon: pronunciations, Zipf-ish phone and word frequencies
-    plen = np.clip(1 + rng.poisson(mean_pron - 1.0, V), 1, 12).astype(np.int64)
-    Lmax = int(plen.max())
+    # ---- lexicon: pronunciations (>= 2 phones, Zipf-ish phone frequencies), made DISTINCT:
+    # a real lexicon has few homophones; without this the short random words collide by
+    # the dozen and a word-end state gets dozens of epsilon arcs
+    Lcap = 16
+    plen = np.clip(2 + rng.poisson(max(mean_pron - 2.0, 0.5), V), 2, 12).astype(np.int64)
     phone_p = 1.0 / (np.arange(P) + 3.0)
     phone_p /= phone_p.sum()
-    prons = rng.choice(P, size=(V, Lmax), p=phone_p).astype(np.int64)
+    prons = rng.choice(P, size=(V, Lcap), p=phone_p).astype(np.int64)
+    for _ in range(8):
+        padded = np.where(np.arange(Lcap)[None, :] < plen[:, None], prons, -1)
+        _, first, inv, cnt = np.unique(padded, axis=0, return_index=True, return_inverse=True, return_counts=True)
+        inv = inv.reshape(-1)
+        dup = (cnt[inv] > 1) & (first[inv] != np.arange(V))
+        if not dup.any():
+            break
+        plen[dup] = np.minimum(plen[dup] + 1, Lcap)      # one more (random) phone tells them apart
+    Lmax = int(plen.max())
     uni_p = 1.0 / (rng.permutation(V) + 10.0)
     uni_p /= uni_p.sum()
     uni_cost = -np.log(uni_p)

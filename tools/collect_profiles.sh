@@ -8,10 +8,10 @@ out=${1:-gpurun_out/profiles}; tag=${2:-r01}
 mkdir -p "$out"
 export TMPDIR=/tmp
 T=${PROFILE_TIMEOUT:-420}
-timeout -k 10 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json" 2> "$out/kt.log"
+timeout -k 10 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$out/${tag}_bench_under_rocprof.json" 2> "$out/kt.log"
 f=$(find "$out/kt" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/${tag}_bench_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 $T rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$out/pmc_$c.json" 2> "$out/pmc_$c.log"
+  timeout -k 10 $T rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary > "$out/pmc_$c.json" 2> "$out/pmc_$c.log"
   f=$(find "$out/pmc_$c" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools/pmc_summarize.py "$f" DecodeKernel > "$out/${tag}_pmc_$c.txt"
 done

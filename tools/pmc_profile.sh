@@ -7,7 +7,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 run() {
   name=$1; shift
-  timeout -k 10 ${PMC_TIMEOUT:-300} rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline ${PMC_BENCH_ARGS:-} > "$out/$name.log" 2>&1
+  timeout -k 10 ${PMC_TIMEOUT:-300} rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary ${PMC_BENCH_ARGS:-} > "$out/$name.log" 2>&1
   f=$(find "$out/$name" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools/pmc_summarize.py "$f" DecodeKernel > "$out/$name.summary.txt"
   cat "$out/$name.summary.txt"
