@@ -805,6 +805,35 @@ class LatticeFasterOnlineDecoder:
 
 
 # ---------------------------------------------------------------- lattice forward-backward
+def lattice_to_csr(L):
+    """Raw lattice (get_raw_lattice: states in canonical (frame, HCLG state) order, start first)
+    -> top-sorted CSR, the form LatticeForwardBackward needs (the reference top-sorts lattices
+    it reads: TopSortLatticeIfNeeded, lat/lattice-functions.cc, before
+    nnet-compute-discriminative.cc:178).  Epsilon arcs may point backwards in the canonical
+    order, so states are ordered by (frame, epsilon depth, state)."""
+    n = len(L["state_frame"])
+    depth = np.zeros(n, np.int64)
+    eps = L["arc_il"] == 0
+    es, ed = L["arc_src"][eps], L["arc_dst"][eps]
+    for _ in range(n + 1):
+        nd = depth.copy()
+        np.maximum.at(nd, ed, depth[es] + 1)
+        if np.array_equal(nd, depth):
+            break
+        depth = nd
+    order = np.lexsort((L["state_hclg"], depth, L["state_frame"]))
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    src, dst = rank[L["arc_src"]], rank[L["arc_dst"]]
+    perm = np.lexsort((np.arange(len(src)), src))
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(np.bincount(src, minlength=n))
+    return dict(n_states=n, arc_offsets=off, arc_ilabel=L["arc_il"][perm].astype(np.int32),
+                arc_nextstate=dst[perm].astype(np.int32), arc_graph=L["arc_g"][perm].astype(np.float32),
+                arc_acoustic=L["arc_a"][perm].astype(np.float32),
+                state_final=L["state_final"][order].astype(np.float32), perm=perm, order=order)
+
+
 def lattice_forward_backward(lats):
     """LatticeForwardBackward (lat/lattice-functions.cc:272-354) for a batch of
     top-sorted lattices.  Each lattice is a dict with n_states, arc_offsets (int64,

@@ -70,7 +70,10 @@ constexpr int NW = NT / 64;        // waves
 constexpr int NPH = 34;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
-constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x3fffffff;
+constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x1fffffff;
+// bit 29: the state is the destination of some epsilon arc, i.e. the epsilon closure may look
+// it up - only such tokens are entered in the global hash table (the emitting pass dedupes in LDS)
+constexpr int32_t kEpsDst = 0x20000000;
 constexpr int EU = 2;              // chunks of NT tokens an expansion group scans per barrier (2: -1 %; 4 spills)
 constexpr int KC = 4;              // chunks of NT slots the compaction moves per barrier when the slide has opened a gap
 constexpr int PU = 1;              // token / link slots a lane keeps in flight per round of a sweep (measured: 1 beats 2, 4, 8 - the sweeps are bound by the CU's address pipeline, not by latency, and more slots spill)
@@ -244,7 +247,7 @@ __device__ __forceinline__ long long Uni(long long v) { return static_cast<long 
 // ---------------------------------------------------------------- block helpers
 struct Shared {
   int wsum[2][NW];                 // BlockExScan, double buffered
-  int wsumk[2][(PU > KC ? PU : KC) > EU ? (PU > KC ? PU : KC) : EU][NW];  // BlockExScanK, double buffered
+  int wsumk[2][8][NW];             // BlockExScanK (K <= 8), double buffered
   int wl_n[3];                     // nonemitting work-list lengths, rotating ([0] also: prune's epsilon-token list)
   int pr_moved;                    // PruneForwardLinks: tokens whose extra_cost moved by more than delta
   int eps_n;                       // length of tmp_epslist
@@ -266,6 +269,7 @@ struct Shared {
   long long t_last;
   long long phase[NPH];
   int tok_hw;  // highest token slot dirtied by this slot's utterances so far
+  int gc_tok, gc_link;  // arena ends right after the last full compaction (garbage collection)
 };
 
 // Per-thread view of the workgroup state: the LDS block plus the (uniform)
@@ -277,6 +281,26 @@ struct Blk {
   int k_or, k_red, k_scan;
   __device__ __forceinline__ LdsShared *operator->() const { return p; }
 };
+
+// The emitting pass dedupes the frame's new tokens in an LDS table (state -> min cost ->
+// token index) of 8192 slots laid over LDS that is idle at that point of the frame: the
+// keys over the radix-select histogram + the three expansion arrays (32 KB of the static
+// block), the values over the frame's score row (dynamic LDS, at least 32 KB; the row is
+// staged again at the start of the next frame).
+constexpr int kLdsSlots = 8192;
+static_assert(sizeof(unsigned int) * (1 << 11) + 3 * sizeof(int) * EU * NT >= sizeof(uint32_t) * kLdsSlots,
+              "the LDS token table's keys are laid over hist + ex_off + ex_ab + ex_tok");
+static_assert(offsetof(Shared, ex_off) == offsetof(Shared, hist) + sizeof(unsigned int) * (1 << 11) &&
+              offsetof(Shared, ex_ab) == offsetof(Shared, ex_off) + sizeof(int) * EU * NT &&
+              offsetof(Shared, ex_tok) == offsetof(Shared, ex_ab) + sizeof(int) * EU * NT, "contiguous LDS arrays");
+__device__ __forceinline__ __attribute__((address_space(3))) uint32_t *LdsKeys(const Blk &sh) {
+  return (__attribute__((address_space(3))) uint32_t *)&sh.p->hist[0];
+}
+__device__ __forceinline__ __attribute__((address_space(3))) uint32_t *LdsVals(const Blk &sh) {
+  return (__attribute__((address_space(3))) uint32_t *)sh.ll_row;
+}
+// dynamic LDS of the decode kernels: the score row or the table's values, whichever is larger
+inline size_t DynLdsBytes(int ll_cols) { return std::max(sizeof(float) * static_cast<size_t>(ll_cols), sizeof(uint32_t) * static_cast<size_t>(kLdsSlots)); }
 
 // Diagnostic phase timer: thread 0 charges the shader cycles since the previous
 // stamp to `ph`.  Only active when the host passed a phase_cycles buffer.
@@ -905,7 +929,10 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
     // many entries: stream over the whole table (coalesced) instead of one scattered store per token
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
   } else {
-    for (int i = fb + threadIdx.x; i < fe; i += NT) u.hash[u.tmp_slot[i - fb]] = kEmpty;
+    for (int i = fb + threadIdx.x; i < fe; i += NT) {
+      const int32_t sl = u.tmp_slot[i - fb];  // -1: the token was never entered (emitting pass, no epsilon arc leads to its state)
+      if (sl >= 0) u.hash[sl] = kEmpty;
+    }
   }
   KhSync();
 }
@@ -993,19 +1020,130 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   }
   KhSync();
 
-  // ---- pass 2: accept (canonical rule E: tot_cost <= final next_cutoff),
-  // FindOrAddToken + cost min; rejected candidates become dead links.
-  for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-    const float tot_cost = u.link_tot[l - link_frame_b];
-    int dst = -1;
-    if (!(tot_cost > next_cutoff)) {  // :731 "if (tot_cost > next_cutoff) continue"
-      const int32_t ns = u.link_dst[l];
-      const bool he = (ns & kHasEps) != 0;
-      dst = FindOrAdd<true>(u, ns & kStateMask, he, &sh->tok_end, &sh->eps_n, tok_limit, nb);
-      if (dst < 0) sh->status = 1;
-      else (void)__hip_atomic_fetch_min(&u.tok_cost[dst], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- pass 2: accept (canonical rule E: tot_cost <= final next_cutoff) and FindOrAddToken +
+  // cost minimum IN LDS.  Every global atomic of this pool executes at the memory side (one
+  // DRAM read-modify-write per lane: TCC_EA0_ATOMIC == TCC_ATOMIC), and the CAS + publish +
+  // min per accepted arc were 85 % of the kernel's atomics.  The accepted candidates are
+  // split by a hash of their state into P parts of <= ~2800 candidates; each part is deduped
+  // in the 4096-slot LDS table (CAS on the key, min on the cost image), the occupied slots get
+  // consecutive token indices from one scan (a deterministic order), the tokens are written
+  // with plain stores and a second sweep gives the part's links their token index.  Only the
+  // tokens the epsilon closure may look up (kEpsDst states) also enter the global hash.
+  {
+    static_assert(kLdsSlots % NT == 0, "slots per lane");
+    auto keys = LdsKeys(sh);
+    auto vals = LdsVals(sh);
+    const float nan = __int_as_float(0x7fc00000);
+    auto part_of = [](uint32_t h, int parts) { return static_cast<int>(((h >> 12) * static_cast<uint32_t>(parts)) >> 20); };
+    // number of parts: about 11 000 accepted candidates per part (typically half as many
+    // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
+    // parts (the parts nest, and resolved links are marked, so nothing is done twice)
+    int n_acc_mine = 0;
+    for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
+      n_acc_mine += !(u.link_tot[l - link_frame_b] > next_cutoff) ? 1 : 0;
+    const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
+    int parts = 1;
+    while (parts * 11000 < n_acc) parts *= 2;
+    for (int k = 0; k < parts; k++) {
+      for (int i = threadIdx.x; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
+      if (threadIdx.x == 0) sh->flag = 0;
+      KhSync();
+      // (B) insert.  A link that an earlier part resolved carries NaN in link_tot.
+      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
+        const float tot_cost = u.link_tot[l - link_frame_b];
+        if (tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
+        const int32_t ns = u.link_dst[l];
+        const uint32_t h = HashState(ns & kStateMask);
+        if (part_of(h, parts) != k) continue;
+        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+        uint32_t slot = h & (kLdsSlots - 1);
+        int probes = 0;
+        for (; probes < 256; probes++) {
+          uint32_t seen = 0u;
+          __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (seen == 0u || seen == key) break;
+          slot = (slot + 1) & (kLdsSlots - 1);
+        }
+        if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
+        (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      KhSync();
+      if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
+        KhSync();                // (every lane has read the flag before it is reset)
+        if (parts >= (1 << 20)) {
+          if (threadIdx.x == 0) sh->status = 5;
+          KhSync();
+          return false;
+        }
+        parts *= 2;
+        k = 2 * k - 1;
+        continue;
+      }
+      // (C) occupied slots -> consecutive token indices; tokens written with plain stores
+      const int tok_base = Uni(sh->tok_end);
+      int occ[kLdsSlots / NT], off[kLdsSlots / NT], total;
+#pragma unroll
+      for (int j = 0; j < kLdsSlots / NT; j++) occ[j] = keys[threadIdx.x + j * NT] != 0u ? 1 : 0;
+      BlockExScanK<kLdsSlots / NT>(occ, off, &total, sh);
+      if (tok_base + total > tok_limit) {
+        if (threadIdx.x == 0) sh->status = 1;
+        KhSync();
+        return false;
+      }
+#pragma unroll
+      for (int j = 0; j < kLdsSlots / NT; j++) {
+        if (!occ[j]) continue;
+        const int i = threadIdx.x + j * NT;
+        const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
+        const int idx = tok_base + off[j];
+        u.tok_state[idx] = ns & kStateMask;
+        u.tok_cost[idx] = vals[i];
+        u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
+        vals[i] = static_cast<uint32_t>(idx);
+        if ((ns & kHasEps) != 0) {
+          // these tokens are the closure's first work list (every one has a finite cost)
+          u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+          u.tmp_dirty[idx - nb] = 1;
+        }
+        int32_t gslot = -1;
+        if ((ns & kEpsDst) != 0) {  // the closure may look this state up: enter it in the global table
+          const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
+                                          (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
+          uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
+          for (int probes = 0; probes < (1 << 30); probes++) {
+            unsigned long long ent = kEmpty;
+            __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ent == kEmpty) break;
+            g = (g + 1) & u.hash_mask;
+          }
+          gslot = static_cast<int32_t>(g);
+        }
+        u.tmp_slot[idx - nb] = gslot;
+      }
+      if (threadIdx.x == 0) sh->tok_end = tok_base + total;
+      KhSync();
+      // (D) the part's links get their token index; rejected candidates become dead links
+      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
+        const float tot_cost = u.link_tot[l - link_frame_b];
+        if (tot_cost != tot_cost) {  // resolved by an earlier part (a NaN candidate of the first part: rejected)
+          if (k == 0) u.link_dst[l] = -1;
+          continue;
+        }
+        if (tot_cost > next_cutoff) {
+          if (k == 0) u.link_dst[l] = -1;
+          continue;
+        }
+        const int32_t ns = u.link_dst[l];
+        const uint32_t h = HashState(ns & kStateMask);
+        if (part_of(h, parts) != k) continue;
+        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+        uint32_t slot = h & (kLdsSlots - 1);
+        while (keys[slot] != key) slot = (slot + 1) & (kLdsSlots - 1);
+        u.link_dst[l] = static_cast<int32_t>(vals[slot]);
+        if (parts > 1) u.link_tot[l - link_frame_b] = nan;
+      }
+      KhSync();
     }
-    u.link_dst[l] = dst;
   }
   KhSync();
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
@@ -1024,12 +1162,31 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 // branch-free loads, PU slots per lane in flight), the per-token minimum of
 // link_extra_cost (:309-323) is an atomicMin on the order-preserving image Enc().
 
+// Accumulator of PruneForwardLinks (per token of the frame: Enc(min link_extra_cost)): in LDS
+// when the frame has at most kLdsSlots tokens (nearly always: every global atomic is a DRAM
+// read-modify-write on this pool), else in the slot's global scratch array.
+struct Acc {
+  bool lds;
+  __attribute__((address_space(3))) uint32_t *l;
+  Arr<uint32_t> g;
+  __device__ __forceinline__ void Set(int i, uint32_t v) const {
+    if (lds) l[i] = v; else g[i] = v;
+  }
+  __device__ __forceinline__ uint32_t Get(int i) const {
+    return lds ? l[i] : LoadCostEnc(&g[i]);
+  }
+  __device__ __forceinline__ void Min(int i, uint32_t v) const {
+    if (lds) (void)__hip_atomic_fetch_min(&l[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else (void)__hip_atomic_fetch_min(&g[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+
 // One pass over the link slots [lo, hi).  link_extra_cost (:309-311) of every
 // live link with the extra_costs currently stored; kExcise: links over the
 // lattice beam are excised (:315); kAccum: the others are min-ed into
 // acc[src - b].  Returns 2 if this lane excised a link.
 template <bool kEps, bool kAccum, bool kExcise, bool kList = false>
-__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, Arr<uint32_t> acc,
+__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, const Acc &acc,
                                              __attribute__((address_space(3))) int *list_n = nullptr) {
   int flags = 0;
   for (int base = lo + threadIdx.x; base < hi; base += NT * PU) {
@@ -1075,7 +1232,7 @@ __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b
       }
       if (kAccum) {
         if (lec < 0.0f) lec = 0.0f;  // :319-320
-        __hip_atomic_fetch_min(&acc[src[k] - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc.Min(src[k] - b, Enc(lec));
       }
     }
   }
@@ -1099,6 +1256,13 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   // P0 (tokens): start the accumulator of the emitting links.  (tmp_acc1, the one of
   // the epsilon links, is +inf for every token outside this function.)
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->pr_moved = 0; }
+  Acc acc0, acc1;
+  acc0.lds = e - b <= kLdsSlots;  // (uniform) the LDS of the emitting pass's token table is idle here
+  acc0.l = LdsVals(sh);
+  acc0.g = u.tmp_acc0;
+  acc1.lds = false;
+  acc1.l = nullptr;
+  acc1.g = u.tmp_acc1;
   for (int base = b + threadIdx.x; base < e; base += NT * PU) {
     int i[PU], st[PU];
     uint32_t co[PU];
@@ -1116,7 +1280,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
       if (base + k * NT >= e) continue;
       float base_v = inf;
       if (final_frame) base_v = Dec(co[k]) + fc[k] - final_best_cost;  // :385
-      u.tmp_acc0[i[k] - b] = Enc(base_v);
+      acc0.Set(i[k] - b, Enc(base_v));
     }
   }
   // PruneTokensForFrame(f + 1): its extra_costs are final, nothing below reads its states
@@ -1126,7 +1290,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   KH_PRUNE_STAMP(20);
   // P1 (emitting links): a link to the NEXT frame sees final extra_costs there, so
   // its link_extra_cost - hence whether it is excised - is final at first sight.
-  int flags = PruneLinkPass<false, true, true>(u, mb, me, b, lb, u.tmp_acc0);
+  int flags = PruneLinkPass<false, true, true>(u, mb, me, b, lb, acc0);
   KhSync();
   KH_PRUNE_STAMP(21);
   // Epsilon links stay inside the frame (a DAG): the exact fixed point of
@@ -1151,7 +1315,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     if (a1 != kEncInf) u.tmp_acc1[i - b] = kEncInf;
   };
   for (int i = b + threadIdx.x; i < e; i += NT) {  // T0 (tmp_acc1 is +inf for every token here)
-    const uint32_t a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
+    const uint32_t a0 = acc0.Get(i - b);
     const int st = u.tok_state[i];
     const float old = LoadExtra(&u.tok_extra[i]);
     u.tmp_f0[i - b] = old;
@@ -1162,14 +1326,14 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   if (ne > nb) {
     for (int iter = 0;; iter++) {
       KhSync();  // the extra_costs of the previous token sweep are in place
-      if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, u.tmp_acc1, &sh->wl_n[0]);
-      else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, u.tmp_acc1);
+      if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, acc1, &sh->wl_n[0]);
+      else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, acc1);
       KhSync();
       bool again = false;
       const int n_list = Uni(sh->wl_n[0]);
       for (int q = threadIdx.x; q < n_list; q += NT) {
         const int i = u.tmp_work0[q];
-        const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = LoadCostEnc(&u.tmp_acc0[i - b]);
+        const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = acc0.Get(i - b);
         const int st = u.tok_state[i];
         const float old = LoadExtra(&u.tok_extra[i]), entry = u.tmp_f0[i - b];
         bool changed = false;
@@ -1186,7 +1350,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   }
   if (n_moved != 0) __hip_atomic_fetch_add(&sh->pr_moved, n_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   KH_PRUNE_STAMP(22);
-  if (ne > nb) flags |= PruneLinkPass<true, false, true>(u, nb, ne, b, lb, u.tmp_acc1);
+  if (ne > nb) flags |= PruneLinkPass<true, false, true>(u, nb, ne, b, lb, acc1);
   int all = BlockOr(flags, sh);
   if (Uni(sh->pr_moved) > 0) all |= 1;
   KH_PRUNE_STAMP(23);
@@ -1535,6 +1699,8 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->arcs_expanded = 0;
     sh->tokens_created = 0;
     sh->max_tokens_frame = 0;
+    sh->gc_tok = 0;
+    sh->gc_link = 0;
   }
   for (int f = threadIdx.x; f < u.T + 2; f += NT) {
     u.must_links[f] = 1;  // TokenList(): must_prune_forward_links(true), must_prune_tokens(true)
@@ -1575,6 +1741,15 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
       Stamp(u, sh, 6);
       ok = Compact(u, t - win_frames, t, sh);
+      // Frames older than the window keep the slots of what was pruned after they left it
+      // (the backward pruning keeps thinning frames ~200 frames behind the frontier): once that
+      // garbage has grown to a third of an arena, compact everything (rare: every ~700 frames
+      // of a long utterance; a full sweep costs about a dozen frames of decoding).
+      if (ok && (Uni(sh->tok_end) - Uni(sh->gc_tok) > u.tok_cap / 3 || Uni(sh->link_end) - Uni(sh->gc_link) > u.link_cap / 3)) {
+        ok = Compact(u, 0, t, sh);
+        if (threadIdx.x == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; }
+        KhSync();
+      }
       Stamp(u, sh, 7);
       if (!ok) break;
       fb = Uni(u.frame_b[t]);
@@ -1837,7 +2012,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
 // the whole utterance; between launches the workgroup's LDS scalars live in
 // SlotState.  One workgroup per job.
 struct SlotState {
-  int32_t tok_end, link_end, front_b, status, max_tokens_frame, tok_hw;
+  int32_t tok_end, link_end, front_b, status, max_tokens_frame, tok_hw, gc_tok, gc_link;
   int32_t t, fb, fe;          // Run
   int32_t ok, finalized;
   long long arcs_expanded, tokens_created;
@@ -1853,7 +2028,7 @@ struct Job {
 __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
   if (threadIdx.x == 0) {
     sh->tok_end = S.tok_end; sh->link_end = S.link_end; sh->front_b = S.front_b; sh->status = S.status;
-    sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw;
+    sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw; sh->gc_tok = S.gc_tok; sh->gc_link = S.gc_link;
     sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created;
   }
   run->t = S.t; run->fb = S.fb; run->fe = S.fe;
@@ -1863,7 +2038,7 @@ __device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
   KhSync();
   if (threadIdx.x == 0) {
     S->tok_end = sh->tok_end; S->link_end = sh->link_end; S->front_b = sh->front_b; S->status = sh->status;
-    S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw;
+    S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw; S->gc_tok = sh->gc_tok; S->gc_link = sh->gc_link;
     S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created;
     S->t = run.t; S->fb = run.fb; S->fe = run.fe;
     S->ok = (ok && sh->status == 0) ? 1 : 0;
@@ -1982,18 +2157,48 @@ struct KhDecoder {
   float last_kernel_ms = 0.f;
   int slot_limit = std::numeric_limits<int>::max();  // slots that fit in memory (found by a failed allocation)
   // canonical lattices, built lazily per utterance
+  // Array of a canonical lattice: its own vector, or (batch post-pass, kh_decoder_prepare) a
+  // slice of the decoder's batch store.  One mmap + munmap per vector per utterance serialises
+  // the host threads on the process's mm lock (0.7 s per 2620-utterance step before).
+  template <class T>
+  struct Buf {
+    T *p = nullptr;
+    size_t n = 0;
+    bool bound = false;
+    std::vector<T> own;
+    void bind(T *ext, size_t count) { p = ext; n = count; bound = true; }
+    void resize(size_t count) {
+      if (bound && count == n) return;
+      bound = false;
+      own.resize(count);
+      p = own.data();
+      n = count;
+    }
+    void assign(size_t count, T v) {
+      resize(count);
+      for (size_t i = 0; i < count; i++) p[i] = v;
+    }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+  };
   struct Lat {
     bool built = false;
-    std::vector<int32_t> state_frame, state_hclg;
-    std::vector<float> state_final;
-    std::vector<int32_t> arc_src, arc_dst, arc_il, arc_ol;
-    std::vector<float> arc_g, arc_a;
+    Buf<int32_t> state_frame, state_hclg;
+    Buf<float> state_final;
+    Buf<int32_t> arc_src, arc_dst, arc_il, arc_ol;
+    Buf<float> arc_g, arc_a;
     // best path (GetBestPath), cached
     int bp_rc = 1;  // 1 = not computed yet
     std::vector<int32_t> bp_ali, bp_words;
     float bp_graph = 0.f, bp_acoustic = 0.f;
   };
   std::vector<Lat> lats;
+  // batch store of kh_decoder_prepare (kept across calls: the pages stay mapped)
+  std::vector<int32_t> st_i[6];   // state_frame, state_hclg, arc_src, arc_dst, arc_il, arc_ol
+  std::vector<float> st_f[3];     // state_final, arc_g, arc_a
 };
 
 // LatticeFasterOnlineDecoder for num_streams concurrent utterances: stream i owns
@@ -2101,7 +2306,9 @@ int BuildLattice(KhDecoder *d, int ui) {
   const size_t n = o.n_tok, m = o.n_link;
   const KhDecoder::HostPool &hp = d->rounds[d->h_round[ui]];
   const int32_t *tf = hp.t_frame.data() + o.tok_off, *ts = hp.t_state.data() + o.tok_off;
-  std::vector<int32_t> ord(n);
+  // (scratch vectors are per thread and only grow: no allocation per utterance)
+  static thread_local std::vector<int32_t> ord, newidx;
+  ord.resize(n);
   for (size_t k = 0; k < n; k++) ord[k] = static_cast<int32_t>(k);
   // canonical order (frame, HCLG state) with the start token first: lattice state 0 is the
   // start state (the reference gets that from TopSortTokens :839-914; ComputeBestPath and
@@ -2114,7 +2321,7 @@ int BuildLattice(KhDecoder *d, int ui) {
     if (as != bs) return as < bs;
     return ts[a] < ts[b];
   });
-  std::vector<int32_t> newidx(n);
+  newidx.resize(n);
   for (size_t k = 0; k < n; k++) newidx[ord[k]] = static_cast<int32_t>(k);
   const float inf = std::numeric_limits<float>::infinity();
   L.state_frame.resize(n);
@@ -2135,7 +2342,8 @@ int BuildLattice(KhDecoder *d, int ui) {
     }
   }
   struct A { int32_t src, il, ol, dst; float g, a; };
-  std::vector<A> arcs(m);
+  static thread_local std::vector<A> arcs;
+  arcs.resize(m);
   const int32_t *ls = hp.l_src.data() + o.link_off, *ld = hp.l_dst.data() + o.link_off,
                 *li = hp.l_il.data() + o.link_off, *lo = hp.l_ol.data() + o.link_off;
   const float *lg = hp.l_g.data() + o.link_off, *la = hp.l_a.data() + o.link_off;
@@ -2184,8 +2392,10 @@ int ComputeBestPath(KhDecoder *d, int utt) {
     return L.bp_rc = KH_ESTATE;
   }
   const float inf = std::numeric_limits<float>::infinity();
-  std::vector<LatWeight> dist(ns, LatWeight{inf, inf});
-  std::vector<int32_t> parent(ns, -1);
+  static thread_local std::vector<LatWeight> dist;
+  static thread_local std::vector<int32_t> parent;
+  dist.assign(ns, LatWeight{inf, inf});
+  parent.assign(ns, -1);
   dist[0] = LatWeight{0.f, 0.f};
   bool changed = true;
   for (int guard = 0; changed && guard < ns + 2; guard++) {
@@ -2317,7 +2527,7 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.start_has_eps = d->fst->start_has_eps;
   // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
   // the score row shares the workgroup's 64 KB of LDS with the static block (Shared)
-  p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 64 * 1024) ? ll_stride : 0;
+  p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.tid2pdf = (GP(const int32_t))tid2pdf;
   p.max_tid = d->fst->max_ilabel;
@@ -2437,13 +2647,16 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
     return nullptr;
   }
   if (num_states >= kStateMask) {  // (also keeps the (num_states + 1) x 4-byte offset tables under 4 GiB)
-    SetError("kh_fst_create: %d states exceed the 30-bit state ids of the arc records", num_states);
+    SetError("kh_fst_create: %d states exceed the 29-bit state ids of the arc records", num_states);
     return nullptr;
   }
-  std::vector<uint8_t> has_eps(num_states, 0);
+  std::vector<uint8_t> has_eps(num_states, 0), eps_dst(num_states, 0);
   for (int32_t s = 0; s < num_states; s++)
     for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
-      if (ilabel[a] == 0) { has_eps[s] = 1; break; }
+      if (ilabel[a] == 0) {
+        has_eps[s] = 1;
+        if (nextstate[a] >= 0 && nextstate[a] < num_states) eps_dst[nextstate[a]] = 1;
+      }
   std::vector<int32_t> e_off(num_states + 1), n_off(num_states + 1);
   std::vector<int4> e_arcs, n_arcs;
   e_arcs.reserve(na);
@@ -2458,7 +2671,7 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
       }
       int wbits;
       memcpy(&wbits, &weight[a], 4);
-      const int32_t ns = nextstate[a] | (has_eps[nextstate[a]] ? kHasEps : 0);
+      const int32_t ns = nextstate[a] | (has_eps[nextstate[a]] ? kHasEps : 0) | (eps_dst[nextstate[a]] ? kEpsDst : 0);
       if (ilabel[a] != 0) {
         e_arcs.push_back(make_int4(ilabel[a], olabel[a], wbits, ns));
         max_il = std::max(max_il, ilabel[a]);
@@ -2714,7 +2927,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
                            static_cast<size_t>(d->h_slots[i].tok_cap), kEncInf);
     const int grid = std::min(np, n_slots);
     KH_HIP(hipEventRecord(d->ev0, st));
-    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), sizeof(float) * p.ll_cols, st, d->d_slots, d->d_in, d->d_out, np, d->pool, p,
+    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in, d->d_out, np, d->pool, p,
                        (GP(long long))d->d_phase);
     KH_LAUNCH_CHECK();
     KH_HIP(hipEventRecord(d->ev1, st));
@@ -2886,7 +3099,30 @@ int kh_decoder_prepare(KhDecoder *d, int num_threads) {
   const int n = d->n_utts;
   if (n <= 0) return KH_OK;
   int nt = num_threads > 0 ? num_threads : static_cast<int>(std::thread::hardware_concurrency());
-  nt = std::max(1, std::min(nt, n));
+  nt = std::max(1, std::min(std::min(nt, 128), n));
+  // every lattice not built yet gets its slice of the batch store
+  {
+    size_t tot_n = 0, tot_m = 0;
+    for (int ui = 0; ui < n; ui++)
+      if (!d->lats[ui].built && d->h_out[ui].stats.status == 0) { tot_n += d->h_out[ui].n_tok; tot_m += d->h_out[ui].n_link; }
+    for (int k = 0; k < 2; k++) if (d->st_i[k].size() < tot_n) d->st_i[k].resize(tot_n);
+    for (int k = 2; k < 6; k++) if (d->st_i[k].size() < tot_m) d->st_i[k].resize(tot_m);
+    if (d->st_f[0].size() < tot_n) d->st_f[0].resize(tot_n);
+    for (int k = 1; k < 3; k++) if (d->st_f[k].size() < tot_m) d->st_f[k].resize(tot_m);
+    size_t on = 0, om = 0;
+    for (int ui = 0; ui < n; ui++) {
+      KhDecoder::Lat &L = d->lats[ui];
+      if (L.built || d->h_out[ui].stats.status != 0) continue;
+      const size_t cn = d->h_out[ui].n_tok, cm = d->h_out[ui].n_link;
+      L.state_frame.bind(d->st_i[0].data() + on, cn); L.state_hclg.bind(d->st_i[1].data() + on, cn);
+      L.state_final.bind(d->st_f[0].data() + on, cn);
+      L.arc_src.bind(d->st_i[2].data() + om, cm); L.arc_dst.bind(d->st_i[3].data() + om, cm);
+      L.arc_il.bind(d->st_i[4].data() + om, cm); L.arc_ol.bind(d->st_i[5].data() + om, cm);
+      L.arc_g.bind(d->st_f[1].data() + om, cm); L.arc_a.bind(d->st_f[2].data() + om, cm);
+      on += cn;
+      om += cm;
+    }
+  }
   std::atomic<int> next(0), first_rc(0);
   std::mutex mu;
   std::string first_err;
@@ -2894,6 +3130,7 @@ int kh_decoder_prepare(KhDecoder *d, int num_threads) {
     for (;;) {
       const int ui = next.fetch_add(1);
       if (ui >= n) break;
+      if (d->h_out[ui].stats.status != 0) continue;  // an utterance that failed alone (capacity): its getters report it
       const int rc = ComputeBestPath(d, ui);
       if (rc != KH_OK) {
         std::lock_guard<std::mutex> l(mu);
@@ -2970,7 +3207,7 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   if (ll_stride <= 0) p.ll_cols = 0;
   KH_HIP(hipMemcpyAsync(o->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(OnlineKernel, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), sizeof(float) * p.ll_cols, st,
+  hipLaunchKernelGGL(OnlineKernel, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), DynLdsBytes(p.ll_cols), st,
                      b->d_slots, o->d_states, o->d_jobs, b->d_out, b->pool, p);
   KH_LAUNCH_CHECK();
   return KH_OK;

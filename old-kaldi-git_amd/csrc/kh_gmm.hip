@@ -20,6 +20,7 @@
 // cutoff and double accumulation.
 #include <cfloat>
 #include <cmath>
+#include <vector>
 
 #include "kh_common.h"
 
@@ -156,6 +157,146 @@ int LaunchLoglikes(const float *data, KhMatrixDim dd, const float *g,
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Fused frame x pdf scores: the two products of DiagGmm::LogLikelihoods
+// (diag-gmm.cc:546-562) on the matrix cores AND the per-pdf LogSumExp
+// (kaldi-vector.cc:745-763) in one kernel, so that the T x #Gaussians matrix
+// (7.2 GB for 200 k frames of cfg 2) never reaches HBM.
+//
+// A workgroup owns 64 frames, whose [x | x^2] MFMA operands stay in registers, and walks
+// the Gaussians in tiles of <= 128 that hold WHOLE pdfs (tile list built on the host).
+// Per tile: means_invvars / inv_vars / gconsts of the tile -> LDS ([k][gaussian] image,
+// conflict-free ds_read_b32 fragments), two v_mfma_f32_32x32x2_f32 accumulations
+// (k-ordered fmaf chains, as the unfused path), ll = (a1 + g) + (-0.5 a2) -> LDS
+// [frame][gaussian], then one lane per (frame, pdf): max, cutoff, double sum of expf, log.
+// Same operations in the same order as kh_diag_gmm_loglikes + GmmPdfLseRowKernel: the
+// results are bit-identical to the unfused path.
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kFT = 64, kGT = 128, kGTP = kGT + 4, kOTP = kGT + 1;
+
+struct GmmTile { int32_t m_begin, m_end, pdf_begin, pdf_end; };
+
+template <int KS>
+__global__ void __launch_bounds__(256, 2)
+GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride, const float *__restrict__ gconsts,
+                  const float *__restrict__ mi, const float *__restrict__ iv, const int32_t *__restrict__ pdf_offsets,
+                  const GmmTile *__restrict__ tiles, int n_tiles, float prune, float min_log_diff,
+                  float *__restrict__ out, int out_stride) {
+  __shared__ float Bmi[2 * KS][kGTP];
+  __shared__ float Biv[2 * KS][kGTP];
+  __shared__ float Bg[kGT];
+  __shared__ float Ot[kFT][kOTP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1, kk = lane >> 5, l31 = lane & 31;
+  const int t0 = blockIdx.x * kFT;
+  // this wave's 32 frames as MFMA A operands: lane (l31, kk) holds x[frame l31][2 s + kk]
+  float ax[KS], axx[KS];
+  {
+    const int fr = t0 + wm * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int k = 2 * s + kk;
+      const float v = (fr < T && k < D) ? data[static_cast<size_t>(fr) * data_stride + k] : 0.f;
+      ax[s] = v;
+      axx[s] = v * v;  // data_sq.ApplyPow(2.0)
+    }
+  }
+  for (int ti = 0; ti < n_tiles; ti++) {
+    const GmmTile tl = tiles[ti];
+    const int nm = tl.m_end - tl.m_begin;
+    // ---- parameters of the tile -> LDS, transposed to [k][gaussian]; zero padding
+    for (int idx = t; idx < 2 * KS * kGT; idx += 256) {
+      const int m = idx / (2 * KS), k = idx - m * (2 * KS);
+      float a = 0.f, b = 0.f;
+      if (m < nm && k < D) {
+        const size_t o = static_cast<size_t>(tl.m_begin + m) * D + k;
+        a = mi[o];
+        b = iv[o];
+      }
+      Bmi[k][m] = a;
+      Biv[k][m] = b;
+    }
+    if (t < kGT) Bg[t] = t < nm ? gconsts[tl.m_begin + t] : 0.f;
+    __syncthreads();  // (also: the previous tile's LogSumExp has finished reading Ot)
+    f32x16 a1[2], a2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { a1[j][r] = 0.f; a2[j][r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int k = 2 * s + kk;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int col = wn * 64 + j * 32 + l31;
+        a1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], Bmi[k][col], a1[j], 0, 0, 0);
+        a2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(axx[s], Biv[k][col], a2[j], 0, 0, 0);
+      }
+    }
+    // loglikes = gconsts + data * means_invvars^T; loglikes += -0.5 * data_sq * inv_vars^T
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = wn * 64 + j * 32 + l31;
+      const float g = Bg[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        Ot[row][col] = (a1[j][r] + g) + (-0.5f * a2[j][r]);
+      }
+    }
+    __syncthreads();
+    // ---- LogSumExp per (frame, pdf) of the tile
+    const int np = tl.pdf_end - tl.pdf_begin;
+    for (int idx = t; idx < kFT * np; idx += 256) {
+      const int f = idx / np, pj = idx - f * np;
+      if (t0 + f >= T) continue;
+      const int pdf = tl.pdf_begin + pj;
+      const int sidx = pdf_offsets[pdf] - tl.m_begin, eidx = pdf_offsets[pdf + 1] - tl.m_begin;
+      float mx = -INFINITY;
+      for (int m = sidx; m < eidx; m++) mx = fmaxf(mx, Ot[f][m]);
+      float cutoff = mx + min_log_diff;
+      if (prune > 0.0f && mx - prune > cutoff) cutoff = mx - prune;
+      double sum = 0.0;
+      for (int m = sidx; m < eidx; m++) {
+        const float v = Ot[f][m];
+        if (v >= cutoff) sum += static_cast<double>(expf(v - mx));
+      }
+      out[static_cast<size_t>(t0 + f) * out_stride + pdf] = static_cast<float>(static_cast<double>(mx) + log(sum));
+    }
+    // (the next tile's parameter load only touches Bmi / Biv / Bg: no barrier needed here)
+  }
+}
+
+// Tile list: consecutive whole pdfs, <= kGT Gaussians per tile.  Returns false if a single
+// pdf has more than kGT Gaussians (the caller then takes the unfused path).
+bool BuildGmmTiles(const std::vector<int32_t> &off, std::vector<GmmTile> *tiles) {
+  const int P = static_cast<int>(off.size()) - 1;
+  int p = 0;
+  while (p < P) {
+    GmmTile tl{off[p], off[p], p, p};
+    while (tl.pdf_end < P && off[tl.pdf_end + 1] - tl.m_begin <= kGT) {
+      tl.pdf_end++;
+      tl.m_end = off[tl.pdf_end];
+    }
+    if (tl.pdf_end == p) return false;
+    tiles->push_back(tl);
+    p = tl.pdf_end;
+  }
+  return true;
+}
+
+template <int KS>
+int LaunchFused(const float *data, KhMatrixDim dd, const float *g, const float *mi, const float *iv,
+                const int32_t *pdf_offsets, const GmmTile *d_tiles, int n_tiles, float prune, float min_log_diff,
+                float *out, int out_stride) {
+  hipLaunchKernelGGL(GmmFusedPdfKernel<KS>, dim3(DivUp(dd.rows, kFT)), dim3(256), 0, Stream(), data, dd.rows, dd.cols,
+                     dd.stride, g, mi, iv, pdf_offsets, d_tiles, n_tiles, prune, min_log_diff, out, out_stride);
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+}  // namespace
+
 namespace {
 // data_sq = data; data_sq.ApplyPow(2.0) (diag-gmm.cc:552-553), packed to a stride of 4 floats
 __global__ void SquareKernel(float *__restrict__ y, int y_stride, const float *__restrict__ x, int x_stride, int rows, int cols) {
@@ -240,6 +381,30 @@ int kh_am_gmm_loglikes(const float *data, KhMatrixDim dd, const float *gconsts,
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(pdf_offsets && out && num_pdfs > 0 && out_stride >= num_pdfs);
+  const float min_log_diff_f = logf(FLT_EPSILON);  // kMinLogDiffFloat kaldi-math.h:121
+  // Fused path (matrix cores + LogSumExp epilogue, nothing of T x #Gaussians in HBM) whenever
+  // the problem is large enough for the tiles to fill the chip and every pdf fits a tile.
+  if (dd.cols <= 40 && static_cast<int64_t>(dd.rows) * num_mix >= (1 << 22) && !getenv("KH_GMM_NO_FUSION") &&
+      !getenv("KH_GMM_NO_GEMM")) {
+    KH_CHECK_ARG(data && gconsts && means_invvars && inv_vars && dd.rows > 0 && dd.cols > 0 && dd.stride >= dd.cols);
+    std::vector<int32_t> h_off(num_pdfs + 1);
+    KH_HIP(hipMemcpyAsync(h_off.data(), pdf_offsets, sizeof(int32_t) * (num_pdfs + 1), hipMemcpyDeviceToHost, Stream()));
+    KH_HIP(hipStreamSynchronize(Stream()));
+    KH_CHECK_ARG(h_off[0] == 0 && h_off[num_pdfs] == num_mix);
+    std::vector<GmmTile> tiles;
+    if (BuildGmmTiles(h_off, &tiles)) {
+      GmmTile *d_tiles = static_cast<GmmTile *>(PoolMalloc(sizeof(GmmTile) * tiles.size()));
+      if (!d_tiles) return KH_ENOMEM;
+      KH_HIP(hipMemcpyAsync(d_tiles, tiles.data(), sizeof(GmmTile) * tiles.size(), hipMemcpyHostToDevice, Stream()));
+      const int nt = static_cast<int>(tiles.size());
+      if (dd.cols <= 16) rc = LaunchFused<8>(data, dd, gconsts, means_invvars, inv_vars, pdf_offsets, d_tiles, nt, log_sum_exp_prune, min_log_diff_f, out, out_stride);
+      else rc = LaunchFused<20>(data, dd, gconsts, means_invvars, inv_vars, pdf_offsets, d_tiles, nt, log_sum_exp_prune, min_log_diff_f, out, out_stride);
+      hipError_t e = hipStreamSynchronize(Stream());  // the tile list returns to the pool; the host copy goes out of scope
+      PoolFree(d_tiles);
+      if (!rc && e != hipSuccess) { SetError("kh_am_gmm_loglikes: %s", hipGetErrorString(e)); rc = KH_EDEVICE; }
+      return rc;
+    }
+  }
   const int ll_stride = (num_mix + 3) & ~3;
   // Bound the scratch: process frames in slabs of at most ~1 GiB of T x M.
   const int64_t slab_rows = std::max<int64_t>(64, (int64_t(1) << 28) / ll_stride);

@@ -35,6 +35,7 @@ struct LatDesc {
   int64_t arc_b;               // first arc
   int32_t n_levels, level_b;   // range in level_off (n_levels + 1 entries)
   int32_t final_b, n_final;    // range in final_list
+  int32_t max_time, n_reached; // largest state time; states the level sweep reached
 };
 
 // base/kaldi-math.h:178-195 (double)
@@ -343,137 +344,232 @@ struct DevArr {
 
 }  // namespace
 
-// Host preparation shared by the lattice sweeps: validation (top-sorted, consistent
-// state times), dependency levels, the incoming-arc CSR (ascending arc index per
-// destination), the list of final states; everything uploaded.
+// Preparation shared by the lattice sweeps, ON THE DEVICE (one workgroup per lattice):
+// validation (top-sorted, consistent state times: LatticeStateTimes :36-67 and the
+// "must be topologically sorted" checks :38-39,:285-286), dependency levels (Kahn's
+// algorithm: a state joins the level after its last predecessor's = longest distance from
+// a source), the incoming-arc CSR (ascending arc index per destination: the operand order
+// of the reference's sequential sweep), the ascending list of final states.  The host only
+// uploads the caller's arrays (round 1 built all of this on host threads and uploaded
+// twice the bytes: 82 ms per 256-lattice batch for 2.2 ms of kernel).
+namespace {
+
+// Barrier that also waits for this wave's outstanding global stores: words initialised with
+// plain stores are updated by L2 atomics of other waves right after it (hipcc's
+// __syncthreads() is a workgroup-scope fence and does not wait for stores to reach L2).
+__device__ __forceinline__ void PrepSync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+__device__ __forceinline__ int PrepScan(int v, int *total, int *s_w) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  PrepSync();  // s_w of the previous call has been read
+  if (lane == 63) s_w[w] = inc;
+  PrepSync();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int i = 0; i < kThreads / 64; i++) {
+    const int t = s_w[i];
+    before += i < w ? t : 0;
+    all += t;
+  }
+  *total = all;
+  return before + inc - v;
+}
+
+__global__ void __launch_bounds__(kThreads)
+PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ il,
+           const int32_t *__restrict__ next, const float *__restrict__ fin, LatDesc *__restrict__ descs,
+           int32_t *__restrict__ times, int32_t *__restrict__ level_off, int32_t *__restrict__ level_states,
+           int64_t *__restrict__ in_off, int64_t *__restrict__ in_arc, int32_t *__restrict__ in_src,
+           int32_t *__restrict__ final_list, int32_t *__restrict__ indeg, int32_t *__restrict__ fill,
+           int32_t *__restrict__ err) {
+  __shared__ int s_w[kThreads / 64];
+  __shared__ int s_err[4];
+  __shared__ int s_qend, s_maxt;
+  const int l = blockIdx.x, t = threadIdx.x;
+  const int sb = lat_off[l], ns = lat_off[l + 1] - sb;
+  const int64_t arc_b = arc_off[sb];
+  if (t == 0) { s_err[0] = 0; s_err[1] = 0; s_err[2] = 0; s_err[3] = 0; s_maxt = 0; }
+  for (int s = t; s < ns; s += kThreads) {
+    times[sb + s] = s == 0 ? 0 : -1;
+    indeg[sb + s] = 0;
+    fill[sb + s] = 0;
+  }
+  PrepSync();
+  // ---- in-degrees + "input lattice must be topologically sorted"
+  for (int s = t; s < ns; s += kThreads)
+    for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
+      const int nxt = next[a];
+      if (nxt <= s || nxt >= ns) {
+        if (atomicCAS(&s_err[0], 0, 1) == 0) { s_err[1] = s; s_err[2] = nxt; s_err[3] = static_cast<int>(a - arc_b); }
+      } else {
+        atomicAdd(&indeg[sb + nxt], 1);
+      }
+    }
+  PrepSync();
+  if (s_err[0] != 0) {
+    if (t < 4) err[4 * l + t] = s_err[t];
+    return;
+  }
+  // ---- incoming-arc offsets (exclusive scan of the in-degrees), finals and sources (ascending)
+  int carry = 0, nf = 0, nq = 0;
+  for (int base = 0; base < ns; base += kThreads) {
+    const int s = base + t;
+    const int deg = s < ns ? __hip_atomic_load(&indeg[sb + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int is_final = (s < ns && fin[sb + s] != INFINITY) ? 1 : 0;
+    const int is_root = (s < ns && deg == 0) ? 1 : 0;
+    int tot;
+    const int off = PrepScan(deg, &tot, s_w);
+    if (s < ns) in_off[sb + s] = arc_b + carry + off;
+    carry += tot;
+    const int foff = PrepScan(is_final, &tot, s_w);
+    if (is_final) final_list[sb + nf + foff] = s;
+    nf += tot;
+    const int qoff = PrepScan(is_root, &tot, s_w);
+    if (is_root) level_states[sb + nq + qoff] = s;
+    nq += tot;
+  }
+  if (t == 0) in_off[sb + ns] = arc_b + carry;
+  PrepSync();
+  // ---- incoming lists (filled in arrival order, then sorted by arc index)
+  for (int s = t; s < ns; s += kThreads)
+    for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
+      const int nxt = next[a];
+      const int64_t pos = in_off[sb + nxt] + atomicAdd(&fill[sb + nxt], 1);
+      in_arc[pos] = a;
+      in_src[pos] = s;
+    }
+  PrepSync();
+  for (int s = t; s < ns; s += kThreads) {
+    const int64_t b0 = in_off[sb + s], e0 = in_off[sb + s + 1];
+    for (int64_t i = b0 + 1; i < e0; i++) {
+      const int64_t ka = in_arc[i];
+      const int32_t ks = in_src[i];
+      int64_t j = i - 1;
+      while (j >= b0 && in_arc[j] > ka) {
+        in_arc[j + 1] = in_arc[j];
+        in_src[j + 1] = in_src[j];
+        j--;
+      }
+      in_arc[j + 1] = ka;
+      in_src[j + 1] = ks;
+    }
+  }
+  // ---- levels (Kahn) + LatticeStateTimes
+  const int lvb = sb + l;  // level_off has n_states + 1 entries per lattice
+  int lb = 0, le = nq, lv = 0;
+  if (t == 0) { s_qend = nq; level_off[lvb] = 0; }
+  int my_maxt = 0;
+  for (;;) {
+    PrepSync();
+    for (int k = lb + t; k < le; k += kThreads) {
+      const int s = level_states[sb + k];
+      const int ts = __hip_atomic_load(&times[sb + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      my_maxt = ts > my_maxt ? ts : my_maxt;
+      for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
+        const int nxt = next[a];
+        if (ts >= 0) {
+          const int want = ts + (il[a] != 0 ? 1 : 0);
+          const int old = atomicCAS(&times[sb + nxt], -1, want);
+          if (old != -1 && old != want && atomicCAS(&s_err[0], 0, 2) == 0) { s_err[1] = nxt; s_err[2] = old; s_err[3] = want; }
+        }
+        if (atomicSub(&indeg[sb + nxt], 1) == 1) level_states[sb + atomicAdd(&s_qend, 1)] = nxt;
+      }
+    }
+    PrepSync();
+    const int new_end = s_qend;
+    lv++;
+    if (t == 0) level_off[lvb + lv] = le;
+    if (new_end == le) break;
+    lb = le;
+    le = new_end;
+  }
+  atomicMax(&s_maxt, my_maxt);
+  PrepSync();
+  if (t < 4) err[4 * l + t] = s_err[t];
+  if (t == 0) {
+    LatDesc d;
+    d.state_b = sb;
+    d.n_states = ns;
+    d.arc_b = arc_b;
+    d.n_levels = lv;
+    d.level_b = lvb;
+    d.final_b = sb;
+    d.n_final = nf;
+    d.max_time = s_maxt;
+    d.n_reached = le;
+    descs[l] = d;
+  }
+}
+
+}  // namespace
+
 struct LatBatch {
   int n_lats = 0, total_states = 0;
   int64_t total_arcs = 0;
-  std::vector<LatDesc> descs;
-  std::vector<int32_t> level_off, level_states, final_list, in_src, times;
-  std::vector<int64_t> in_off, in_arc;
+  std::vector<LatDesc> descs;      // host copy (max_time, n_levels)
   DevArr<LatDesc> d_descs;
   DevArr<int64_t> d_arc_off, d_in_off, d_in_arc;
-  DevArr<int32_t> d_next, d_ilabel, d_level_off, d_level_states, d_in_src, d_final_list, d_times;
+  DevArr<int32_t> d_lat_off, d_next, d_ilabel, d_level_off, d_level_states, d_in_src, d_final_list, d_times, d_indeg, d_fill, d_err;
   DevArr<float> d_g, d_a, d_fin;
 
   int Build(int n, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
             const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic,
             const float *state_final, hipStream_t st) {
     n_lats = n;
+    for (int l = 0; l < n_lats; l++) KH_CHECK_ARG(lat_state_offsets[l + 1] - lat_state_offsets[l] > 0);
     total_states = lat_state_offsets[n_lats];
     total_arcs = arc_offsets[total_states];
-    const float inf = std::numeric_limits<float>::infinity();
-    descs.resize(n_lats);
-    level_states.resize(total_states);
-    in_src.resize(total_arcs);
-    in_off.assign(static_cast<size_t>(total_states) + 1, 0);
-    in_arc.resize(total_arcs);
-    times.assign(total_states, -1);
-    // Per-lattice work on host threads (the lattices are independent); the shared arrays
-    // are stitched together by two serial prefix passes.
-    struct Local {
-      std::vector<int32_t> level_off, finals;
-      int n_levels = 0, rc = KH_OK;
-      std::string err;
-    };
-    std::vector<Local> loc(n_lats);
-    for (int l = 0; l < n_lats; l++) KH_CHECK_ARG(lat_state_offsets[l + 1] - lat_state_offsets[l] > 0);
-    auto for_each_lattice = [&](const std::function<void(int)> &fn) {
-      int nt = static_cast<int>(std::thread::hardware_concurrency());
-      nt = std::max(1, std::min(std::min(nt, 32), n_lats));
-      std::atomic<int> next(0);
-      auto work = [&]() { for (int l; (l = next.fetch_add(1)) < n_lats;) fn(l); };
-      std::vector<std::thread> th;
-      for (int i = 1; i < nt; i++) th.emplace_back(work);
-      work();
-      for (auto &t : th) t.join();
-    };
-    for_each_lattice([&](int l) {
-      const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
-      Local &L = loc[l];
-      LatDesc &d = descs[l];
-      d.state_b = sb;
-      d.n_states = ns;
-      d.arc_b = arc_offsets[sb];
-      std::vector<int32_t> level(ns, 0);
-      int max_level = 0;
-      char buf[256];
-      // LatticeStateTimes :36-67 + level assignment + topological-order check
-      // ("Input lattice must be topologically sorted", :38-39,:285-286).
-      times[sb] = 0;
-      for (int s = 0; s < ns && L.rc == KH_OK; s++) {
-        const int cur_time = times[sb + s];
-        for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
-          const int nxt = arc_nextstate[a];
-          if (nxt <= s || nxt >= ns) {
-            snprintf(buf, sizeof(buf), "lattice %d: arc %lld (state %d -> %d): input lattice must be topologically sorted",
-                     l, static_cast<long long>(a), s, nxt);
-            L.err = buf;
-            L.rc = KH_EINVAL;
-            break;
-          }
-          if (cur_time >= 0) {
-            const int want = cur_time + (arc_ilabel[a] != 0 ? 1 : 0);
-            if (times[sb + nxt] == -1) times[sb + nxt] = want;
-            else if (times[sb + nxt] != want) {
-              snprintf(buf, sizeof(buf), "lattice %d: inconsistent state times at state %d (KALDI_ASSERT lattice-functions.cc:55,61)", l, nxt);
-              L.err = buf;
-              L.rc = KH_EINVAL;
-              break;
-            }
-          }
-          level[nxt] = std::max(level[nxt], level[s] + 1);
-          in_off[static_cast<size_t>(sb) + nxt + 1]++;  // (indices of this lattice only)
-        }
-        max_level = std::max(max_level, level[s]);
-      }
-      if (L.rc != KH_OK) return;
-      L.n_levels = max_level + 1;
-      std::vector<int32_t> cnt(L.n_levels + 1, 0);
-      for (int s = 0; s < ns; s++) cnt[level[s] + 1]++;
-      for (int i = 0; i < L.n_levels; i++) cnt[i + 1] += cnt[i];
-      L.level_off = cnt;
-      std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
-      for (int s = 0; s < ns; s++) level_states[sb + fill[level[s]]++] = s;
-      for (int s = 0; s < ns; s++)
-        if (state_final[sb + s] != inf) L.finals.push_back(s);
-    });
-    for (int l = 0; l < n_lats; l++) {
-      if (loc[l].rc != KH_OK) {
-        SetError("%s", loc[l].err.c_str());
-        return loc[l].rc;
-      }
-      LatDesc &d = descs[l];
-      d.n_levels = loc[l].n_levels;
-      d.level_b = static_cast<int32_t>(level_off.size());
-      level_off.insert(level_off.end(), loc[l].level_off.begin(), loc[l].level_off.end());
-      d.final_b = static_cast<int32_t>(final_list.size());
-      final_list.insert(final_list.end(), loc[l].finals.begin(), loc[l].finals.end());
-      d.n_final = static_cast<int32_t>(loc[l].finals.size());
-    }
-    for (size_t i = 0; i < static_cast<size_t>(total_states); i++) in_off[i + 1] += in_off[i];
-    for_each_lattice([&](int l) {
-      const int sb = lat_state_offsets[l], ns = lat_state_offsets[l + 1] - sb;
-      std::vector<int64_t> fill(in_off.begin() + sb, in_off.begin() + sb + ns);
-      for (int s = 0; s < ns; s++)
-        for (int64_t a = arc_offsets[sb + s]; a < arc_offsets[sb + s + 1]; a++) {
-          const int64_t pos = fill[arc_nextstate[a]]++;
-          in_arc[pos] = a;  // ascending arc index per destination
-          in_src[pos] = s;
-        }
-    });
-    std::vector<int64_t> h_arc_off(arc_offsets, arc_offsets + total_states + 1);
-    std::vector<int32_t> h_next(arc_nextstate, arc_nextstate + total_arcs), h_il(arc_ilabel, arc_ilabel + total_arcs);
-    std::vector<float> h_g(arc_graph, arc_graph + total_arcs), h_a(arc_acoustic, arc_acoustic + total_arcs),
-        h_fin(state_final, state_final + total_states);
-    int rc;
-#define UP(dev, host) do { rc = dev.Upload(host, st); if (rc) return rc; } while (0)
-    UP(d_descs, descs); UP(d_arc_off, h_arc_off); UP(d_next, h_next); UP(d_ilabel, h_il); UP(d_g, h_g); UP(d_a, h_a);
-    UP(d_fin, h_fin); UP(d_level_off, level_off); UP(d_level_states, level_states); UP(d_in_off, in_off);
-    UP(d_in_arc, in_arc); UP(d_in_src, in_src); UP(d_final_list, final_list); UP(d_times, times);
+    const size_t S = total_states, A = static_cast<size_t>(total_arcs);
+    if (d_lat_off.Alloc(n + 1) || d_arc_off.Alloc(S + 1) || d_next.Alloc(A) || d_ilabel.Alloc(A) || d_g.Alloc(A) ||
+        d_a.Alloc(A) || d_fin.Alloc(S) || d_descs.Alloc(n) || d_times.Alloc(S) || d_level_off.Alloc(S + n) ||
+        d_level_states.Alloc(S) || d_in_off.Alloc(S + 1) || d_in_arc.Alloc(A) || d_in_src.Alloc(A) ||
+        d_final_list.Alloc(S) || d_indeg.Alloc(S) || d_fill.Alloc(S) || d_err.Alloc(4 * static_cast<size_t>(n)))
+      return KH_ENOMEM;
+    // the caller's arrays go up as they are (pageable copies are staged by the runtime and
+    // complete before the call returns: the synchronisation below)
+#define UP(dev, host, count, type) KH_HIP(hipMemcpyAsync(dev.p, host, sizeof(type) * (count), hipMemcpyHostToDevice, st))
+    UP(d_lat_off, lat_state_offsets, n + 1, int32_t);
+    UP(d_arc_off, arc_offsets, S + 1, int64_t);
+    UP(d_next, arc_nextstate, A, int32_t);
+    UP(d_ilabel, arc_ilabel, A, int32_t);
+    UP(d_fin, state_final, S, float);
+    UP(d_g, arc_graph, A, float);
+    UP(d_a, arc_acoustic, A, float);
 #undef UP
-    KH_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope
+    hipLaunchKernelGGL(PrepKernel, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
+                       d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
+                       d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p);
+    KH_LAUNCH_CHECK();
+    descs.resize(n_lats);
+    std::vector<int32_t> h_err(4 * static_cast<size_t>(n_lats));
+    KH_HIP(hipMemcpyAsync(descs.data(), d_descs.p, sizeof(LatDesc) * n_lats, hipMemcpyDeviceToHost, st));
+    KH_HIP(hipMemcpyAsync(h_err.data(), d_err.p, sizeof(int32_t) * h_err.size(), hipMemcpyDeviceToHost, st));
+    KH_HIP(hipStreamSynchronize(st));
+    for (int l = 0; l < n_lats; l++) {
+      const int32_t *e = &h_err[4 * static_cast<size_t>(l)];
+      if (e[0] == 1) {
+        SetError("lattice %d: arc %d (state %d -> %d): input lattice must be topologically sorted", l, e[3], e[1], e[2]);
+        return KH_EINVAL;
+      }
+      if (e[0] == 2) {
+        SetError("lattice %d: inconsistent state times at state %d (%d vs %d; KALDI_ASSERT lattice-functions.cc:55,61)", l, e[1], e[2], e[3]);
+        return KH_EINVAL;
+      }
+    }
+    return KH_OK;
+  }
+  // LatticeStateTimes of every state (device -> caller)
+  int FetchTimes(int32_t *state_times, hipStream_t st) const {
+    KH_HIP(hipMemcpyAsync(state_times, d_times.p, sizeof(int32_t) * total_states, hipMemcpyDeviceToHost, st));
     return KH_OK;
   }
 };
@@ -494,7 +590,7 @@ extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_
   if (rc) return rc;
   const int total_states = B.total_states;
   const int64_t total_arcs = B.total_arcs;
-  if (state_times) memcpy(state_times, B.times.data(), sizeof(int32_t) * total_states);
+  if (state_times && (rc = B.FetchTimes(state_times, st))) return rc;
   DevArr<float> d_post;
   DevArr<double> d_alpha, d_beta, d_tot, d_ac;
   if (d_post.Alloc(total_arcs) || d_alpha.Alloc(total_states) || d_beta.Alloc(total_states) ||
@@ -577,11 +673,10 @@ extern "C" int kh_lattice_forward_backward_mpe(int n_lats, const int32_t *lat_st
   LatBatch B;
   rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
   if (rc) return rc;
-  if (state_times) memcpy(state_times, B.times.data(), sizeof(int32_t) * B.total_states);
+  if (state_times && (rc = B.FetchTimes(state_times, st))) return rc;
   for (int64_t a = 0; a < B.total_arcs; a++) KH_CHECK_ARG(arc_ilabel[a] >= 0 && arc_ilabel[a] <= num_tids);
   for (int l = 0; l < n_lats; l++) {  // max_time == num_ali.size() :764
-    int max_time = 0;
-    for (int s = lat_state_offsets[l]; s < lat_state_offsets[l + 1]; s++) max_time = std::max(max_time, B.times[s]);
+    const int max_time = B.descs[l].max_time;
     if (max_time != num_ali_offsets[l + 1] - num_ali_offsets[l]) {
       SetError("lattice %d: max_time %d != num_ali.size() %d (KALDI_ASSERT lattice-functions.cc:764)", l, max_time,
                num_ali_offsets[l + 1] - num_ali_offsets[l]);

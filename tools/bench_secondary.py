@@ -1,0 +1,117 @@
+"""Secondary legs of bench.py (configs 2, 3, 5 and the online mode of
+config 4), each a bounded measurement on cuda:0 with inputs resident in HBM.  run_all()
+returns a dict that bench.py attaches to its JSON line as "secondary" — the driver-visible
+record of the numbers DESIGN.md quotes.  Product API only (no oracle)."""
+import importlib
+import time
+
+import numpy as np
+
+PKG = "old-kaldi-git_amd"
+
+
+def _timeit(fn, sync, reps=3):
+    fn(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def gmm_cfg2(api, torch, T=200_000):
+    """Config 2 (egs/rm tri1): DiagGmm::LogLikelihoods + per-pdf LogSumExp, 39 dims,
+    1800 pdfs / 9000 Gaussians, T frames -> the frame x pdf matrix."""
+    W = importlib.import_module(PKG + ".workloads")
+    rng = np.random.default_rng(1)
+    am = W.make_am_gmm(rng, 1800, 9000, 39)
+    mi, iv = W.gmm_inv_params(am)
+    g, _ = api.gmm_compute_gconsts(am["weights"], mi, iv)
+    gmm = api.AmDiagGmm(g, mi, iv, am["pdf_offsets"])
+    x = torch.from_numpy(rng.standard_normal((T, 39)).astype(np.float32)).cuda()
+    out = torch.empty((T, 1800), dtype=torch.float32, device="cuda")
+    sync = lambda: (api.synchronize(), torch.cuda.synchronize())
+    dt = _timeit(lambda: gmm.pdf_log_likelihoods(x, out=out), sync)
+    flops = T * 9000 * (2 * 78 + 20)
+    return {"workload": "rm_tri1_synthetic: %d frames x 39 dims, 1800 pdfs / 9000 Gaussians" % T,
+            "ms_per_call": dt * 1e3, "frames_per_s": T / dt, "algorithmic_tflops": flops / dt / 1e12,
+            "bound": "mfma", "peak_tflops": 157.3, "frac": flops / dt / 1e12 / 157.3,
+            "hbm_bytes_algorithmic": T * (39 * 4 + 1800 * 4) + 2.8e6}
+
+
+def nnet_cfg3(api, torch, T=120_000):
+    """Config 3 (egs/wsj nnet5d): p-norm network forward, 40 -> 360 -> 4 x (2000/400) -> 8000 -> 3400."""
+    W = importlib.import_module(PKG + ".workloads")
+    rng = np.random.default_rng(2)
+    net, priors = W.wsj_nnet5d(rng)
+    nnet = api.Nnet(net, priors)
+    lens = np.full(120, T // 120, np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = torch.from_numpy(rng.standard_normal((int(off[-1]), 40)).astype(np.float32)).cuda()
+    out = torch.empty((int(off[-1]), 3400), dtype=torch.float32, device="cuda")
+    sync = lambda: (api.synchronize(), torch.cuda.synchronize())
+
+    def fwd():
+        for u0 in range(0, 120, 60):
+            sub = (off[u0:u0 + 61] - off[u0]).astype(np.int32)
+            nnet.compute(x[off[u0]:off[u0 + 60]], sub, True, epilogue=True, prob_scale=0.1, out=out[off[u0]:off[u0 + 60]])
+    dt = _timeit(fwd, sync)
+    flops = 2.0 * (360 * 360 + 360 * 2000 + 3 * 400 * 2000 + 400 * 8000) * int(off[-1])
+    return {"workload": "wsj_nnet5d_synthetic forward: %d frames" % int(off[-1]), "ms_per_call": dt * 1e3,
+            "frames_per_s": int(off[-1]) / dt, "algorithmic_tflops": flops / dt / 1e12, "bound": "mfma",
+            "peak_tflops": 157.3, "frac": flops / dt / 1e12 / 157.3}
+
+
+def lattice_fb_cfg5(api, torch, N=256, T=400):
+    """Config 5 (egs/swbd MMI): denominator lattices of N utterances (raw lattices of a
+    structured-graph decode) -> LatticeForwardBackward, the sMBR variant and the MMI
+    posteriors, batch calls (host preparation and posterior merging included)."""
+    W = importlib.import_module(PKG + ".workloads")
+    rng = np.random.default_rng(5)
+    P = 2000
+    g = W.make_hclg_structured(rng, 1_000_000, P)
+    seqs = W.sample_paths(rng, g, [T] * N)
+    lls = []
+    for q in seqs:
+        x = (rng.standard_normal((T, P)) * 0.28 - 0.37).astype(np.float32)
+        x[np.arange(T), q] = (0.5 + 0.3 * rng.standard_normal(T)).astype(np.float32)
+        lls.append(x)
+    flat = torch.from_numpy(np.concatenate(lls)).cuda()
+    cfg = api.decoder_config(beam=13.0, max_active=7000, min_active=200, lattice_beam=8.0)
+    dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=N, max_frames=T)
+    dec.decode(flat, (np.arange(N + 1) * T).astype(np.int32))
+    dec.prepare()
+    lats = [api.lattice_to_csr(dec.get_raw_lattice(u)) for u in range(N)]
+    arcs = sum(len(L["arc_ilabel"]) for L in lats)
+    states = sum(L["n_states"] for L in lats)
+    alis = [dec.get_best_path(u)["alignment"] for u in range(N)]
+    ntid = len(g["tid2pdf"]) - 1
+    t2ph = np.concatenate([[0], 1 + (np.arange(ntid) // 6) % 40]).astype(np.int32)
+    res = {"workload": "%d lattices x %d frames (structured graph, lattice-beam 8): %d states, %d arcs (%.1f arcs/frame)"
+                       % (N, T, states, arcs, arcs / (N * T))}
+    for name, fn in (("forward_backward", lambda: api.lattice_forward_backward(lats)),
+                     ("smbr", lambda: api.lattice_forward_backward_mpe(lats, t2ph, g["tid2pdf"], [1, 2], alis, "smbr", True)),
+                     ("mmi", lambda: api.lattice_forward_backward_mmi(lats, g["tid2pdf"], alis, True, True, True))):
+        dt = _timeit(fn, lambda: None, reps=2)
+        res[name] = {"ms_per_batch": dt * 1e3, "arcs_per_s": arcs / dt, "frames_per_s": N * T / dt}
+    return res
+
+
+def run_all(api, torch):
+    out = {}
+    for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5)):
+        try:
+            out[name] = fn(api, torch)
+        except Exception as e:  # a secondary leg never fails the headline run
+            out[name] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    import torch
+    sys.path.insert(0, ".")
+    api = importlib.import_module(PKG + ".api")
+    api.select_gpu(0)
+    print(json.dumps(run_all(api, torch), indent=1))
