@@ -37,6 +37,8 @@
 #include <limits>
 #include <numeric>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1954,7 +1956,7 @@ __global__ void __launch_bounds__(NT)
 __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
 #endif
 DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut *__restrict__ out,
-             int n_utts, Pool pool, Params p, GP(long long) phase_cycles) {
+             int n_utts, Pool pool, Params p, GP(long long) phase_cycles, GP(int32_t) done_list) {
   __shared__ Shared shm;
   extern __shared__ float dyn_ll_row[];
   Blk sh;
@@ -1999,6 +2001,16 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     if (threadIdx.x == 0) out[ui].stats = st;
     KhSync();
     if (st.status == 0) ExportLattice(u, pool, &out[ui], sh);
+    // The lattice pool, `out` and the completion list live in pinned HOST memory: the host
+    // builds the utterance's canonical lattice and best path while this kernel decodes the
+    // next ones.  Every wave's stores are complete behind KhSync(); thread 0 then releases
+    // at system scope and appends the utterance to the list the host threads poll.
+    KhSync();
+    if (done_list != nullptr && threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      const unsigned long long pos = __hip_atomic_fetch_add(&pool.used[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&done_list[pos], static_cast<int32_t>(ui), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     Stamp(u, sh, 9);
   }
   if (threadIdx.x == 0 && u.phase_cycles != nullptr)
@@ -2147,8 +2159,40 @@ struct KhDecoder {
     std::vector<int32_t> t_frame, t_state, l_src, l_dst, l_il, l_ol;
     std::vector<float> l_g, l_a;
   };
-  std::vector<HostPool> rounds;     // one per launch (re-launches only after a pool overflow)
-  std::vector<int32_t> h_round;     // utterance -> round holding its lattice
+  std::vector<HostPool> rounds;     // online snapshots: host copy of the device pool
+  std::vector<int32_t> h_round;     // utterance -> entry of `rounds` holding its lattice; -1 = the pinned pool below
+  // Offline decoding: the kernel exports finished lattices straight into pinned host memory
+  // and the host builds them while the kernel is still running (kh_decoder_decode).
+  void *hp_slab = nullptr;          // pinned: pool arrays
+  size_t hp_bytes = 0;
+  Pool hpool;                       // device-side pointers into hp_slab (+ used counters in device memory)
+  struct PoolView {
+    const int32_t *t_frame, *t_state, *l_src, *l_dst, *l_il, *l_ol;
+    const float *l_g, *l_a;
+  } hview;                          // host-side pointers into hp_slab
+  UttOut *h_out_pinned = nullptr;   // [max_batch] pinned
+  int32_t *h_done = nullptr;        // [max_batch] pinned completion list
+  // bump allocators of the worker threads for the canonical lattices (chunks are kept across calls)
+  struct Arena {
+    std::vector<std::unique_ptr<char[]>> chunks;
+    std::vector<size_t> sizes;
+    size_t cur = 0, used = 0;
+    void Reset() { cur = 0; used = 0; }
+    void *Take(size_t bytes) {
+      bytes = (bytes + 63) & ~static_cast<size_t>(63);
+      while (cur < chunks.size() && used + bytes > sizes[cur]) { cur++; used = 0; }
+      if (cur == chunks.size()) {
+        const size_t sz = std::max<size_t>(bytes, 32u << 20);
+        chunks.emplace_back(new char[sz]);
+        sizes.push_back(sz);
+        used = 0;
+      }
+      void *p = chunks[cur].get() + used;
+      used += bytes;
+      return p;
+    }
+  };
+  std::vector<Arena> arenas;
   std::vector<UttOut> h_out;
   std::vector<int32_t> h_T;
   std::vector<int32_t> order;  // queue position -> utterance
@@ -2304,8 +2348,15 @@ int BuildLattice(KhDecoder *d, int ui) {
   }
   const int T = d->h_T[ui];
   const size_t n = o.n_tok, m = o.n_link;
-  const KhDecoder::HostPool &hp = d->rounds[d->h_round[ui]];
-  const int32_t *tf = hp.t_frame.data() + o.tok_off, *ts = hp.t_state.data() + o.tok_off;
+  KhDecoder::PoolView hp;
+  if (d->h_round[ui] < 0) {
+    hp = d->hview;
+  } else {
+    const KhDecoder::HostPool &r = d->rounds[d->h_round[ui]];
+    hp = KhDecoder::PoolView{r.t_frame.data(), r.t_state.data(), r.l_src.data(), r.l_dst.data(), r.l_il.data(),
+                             r.l_ol.data(), r.l_g.data(), r.l_a.data()};
+  }
+  const int32_t *tf = hp.t_frame + o.tok_off, *ts = hp.t_state + o.tok_off;
   // (scratch vectors are per thread and only grow: no allocation per utterance)
   static thread_local std::vector<int32_t> ord, newidx;
   ord.resize(n);
@@ -2344,9 +2395,9 @@ int BuildLattice(KhDecoder *d, int ui) {
   struct A { int32_t src, il, ol, dst; float g, a; };
   static thread_local std::vector<A> arcs;
   arcs.resize(m);
-  const int32_t *ls = hp.l_src.data() + o.link_off, *ld = hp.l_dst.data() + o.link_off,
-                *li = hp.l_il.data() + o.link_off, *lo = hp.l_ol.data() + o.link_off;
-  const float *lg = hp.l_g.data() + o.link_off, *la = hp.l_a.data() + o.link_off;
+  const int32_t *ls = hp.l_src + o.link_off, *ld = hp.l_dst + o.link_off,
+                *li = hp.l_il + o.link_off, *lo = hp.l_ol + o.link_off;
+  const float *lg = hp.l_g + o.link_off, *la = hp.l_a + o.link_off;
   for (size_t j = 0; j < m; j++) arcs[j] = A{newidx[ls[j]], li[j], lo[j], newidx[ld[j]], lg[j], la[j]};
   std::sort(arcs.begin(), arcs.end(), [](const A &x, const A &y) {
     if (x.src != y.src) return x.src < y.src;
@@ -2538,6 +2589,50 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.max_active = d->cfg.max_active;
   p.min_active = d->cfg.min_active;
   p.prune_interval = d->cfg.prune_interval;
+}
+
+// The same pool in pinned HOST memory (offline decoding: the kernel writes finished lattices
+// there and the host reads them while the kernel keeps running).
+int EnsureHostPool(KhDecoder *d, long long pool_tok, long long pool_link) {
+  Carver sizer{nullptr};
+  sizer.Take<int32_t>(pool_tok); sizer.Take<int32_t>(pool_tok);
+  for (int k = 0; k < 4; k++) sizer.Take<int32_t>(pool_link);
+  sizer.Take<float>(pool_link); sizer.Take<float>(pool_link);
+  if (sizer.off > d->hp_bytes) {
+    if (d->hp_slab) (void)hipHostFree(d->hp_slab);
+    d->hp_slab = nullptr;
+    d->hp_bytes = 0;
+    if (hipHostMalloc(&d->hp_slab, sizer.off, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      SetError("kh_decoder_decode: cannot pin %.1f GB of host memory for the lattice pool", sizer.off / 1e9);
+      return KH_ENOMEM;
+    }
+    d->hp_bytes = sizer.off;
+  }
+  void *dev = nullptr;
+  KH_HIP(hipHostGetDevicePointer(&dev, d->hp_slab, 0));
+  Carver c{static_cast<char *>(dev)};
+  d->hpool.t_frame = c.Take<int32_t>(pool_tok);
+  d->hpool.t_state = c.Take<int32_t>(pool_tok);
+  d->hpool.l_src = c.Take<int32_t>(pool_link);
+  d->hpool.l_dst = c.Take<int32_t>(pool_link);
+  d->hpool.l_il = c.Take<int32_t>(pool_link);
+  d->hpool.l_ol = c.Take<int32_t>(pool_link);
+  d->hpool.l_g = c.Take<float>(pool_link);
+  d->hpool.l_a = c.Take<float>(pool_link);
+  d->hpool.tok_cap = pool_tok;
+  d->hpool.link_cap = pool_link;
+  d->hpool.used = (GP(unsigned long long))d->d_used;
+  Carver h{static_cast<char *>(d->hp_slab)};
+  d->hview.t_frame = (const int32_t *)h.Take<int32_t>(pool_tok);
+  d->hview.t_state = (const int32_t *)h.Take<int32_t>(pool_tok);
+  d->hview.l_src = (const int32_t *)h.Take<int32_t>(pool_link);
+  d->hview.l_dst = (const int32_t *)h.Take<int32_t>(pool_link);
+  d->hview.l_il = (const int32_t *)h.Take<int32_t>(pool_link);
+  d->hview.l_ol = (const int32_t *)h.Take<int32_t>(pool_link);
+  d->hview.l_g = (const float *)h.Take<float>(pool_link);
+  d->hview.l_a = (const float *)h.Take<float>(pool_link);
+  return KH_OK;
 }
 
 // Lattice pool of pool_tok tokens / pool_link links (grown on demand).
@@ -2822,6 +2917,9 @@ void kh_decoder_destroy(KhDecoder *d) {
   PoolFree(d->d_out);
   PoolFree(d->d_used);
   PoolFree(d->d_phase);
+  if (d->hp_slab) (void)hipHostFree(d->hp_slab);
+  if (d->h_out_pinned) (void)hipHostFree(d->h_out_pinned);
+  if (d->h_done) (void)hipHostFree(d->h_done);
   delete d;
 }
 
@@ -2831,6 +2929,9 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   if (rc) return rc;
   KH_CHECK_ARG(d && loglikes && utt_off && n_utts > 0 && n_utts <= d->max_batch && ll_stride > 0);
   hipStream_t st = Stream();
+  const bool tprof = getenv("KH_DECODER_PROFILE") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_enter = tnow();
   d->n_utts = n_utts;
   d->lats.assign(n_utts, KhDecoder::Lat());
   d->h_T.resize(n_utts);
@@ -2851,6 +2952,14 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     if (getenv("KH_DECODER_PROFILE")) {
       d->d_phase = static_cast<long long *>(PoolMalloc(sizeof(long long) * NPH * d->max_slots));
       if (!d->d_phase) return KH_ENOMEM;
+    }
+  }
+  if (!d->h_out_pinned) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&d->h_out_pinned), sizeof(UttOut) * d->max_batch, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&d->h_done), sizeof(int32_t) * d->max_batch, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      SetError("kh_decoder_decode: cannot allocate pinned host memory");
+      return KH_ENOMEM;
     }
   }
   // the graph's transition-ids and pdfs must lie inside the tables they index (the kernel
@@ -2875,12 +2984,20 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   d->h_round.assign(n_utts, 0);
   d->rounds.clear();
   d->last_kernel_ms = 0.f;
-  long long tok_per_frame = 160, link_per_frame = 240;
+  // lattice pool in pinned host memory: ~3 x the density the recipe's options give on the
+  // structured workload (17 states / 27 arcs per frame); an utterance that does not fit reports
+  // its exact size and is decoded again
+  long long tok_per_frame = 48, link_per_frame = 80;
   if (const char *e = getenv("KH_DECODER_POOL_TOKENS_PER_FRAME")) {
     tok_per_frame = atoll(e);
     link_per_frame = tok_per_frame * 3 / 2;
   }
   std::vector<int> pending(d->order);
+  int n_workers = static_cast<int>(std::thread::hardware_concurrency());
+  n_workers = std::max(1, std::min(std::min(n_workers, 64), n_utts));
+  if (const char *e = getenv("KH_DECODER_HOST_THREADS")) n_workers = std::max(1, atoi(e));
+  if (static_cast<int>(d->arenas.size()) < n_workers) d->arenas.resize(n_workers);
+  for (auto &a : d->arenas) a.Reset();
   // Two things are sized from estimates, and an utterance that outgrows either is decoded
   // again in a further launch while the finished ones are kept:
   //  * the lattice pool (status 6): the utterance reports its exact size, the next pool has it;
@@ -2910,7 +3027,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     KH_HIP(hipMemcpyAsync(d->d_slots, d->h_slots.data(), sizeof(Utt) * n_slots, hipMemcpyHostToDevice, st));
     const long long pool_tok = !pool_exact ? frames * tok_per_frame + 65536 : need_tok + 1024;
     const long long pool_link = !pool_exact ? frames * link_per_frame + 131072 : need_link + 1024;
-    rc = EnsurePool(d, pool_tok, pool_link);
+    rc = EnsureHostPool(d, pool_tok, pool_link);
     if (rc) return rc;
     std::vector<UttIn> h_in(np);
     for (int q = 0; q < np; q++) {
@@ -2926,14 +3043,82 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
         hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)d->h_slots[i].tok_cost.p,
                            static_cast<size_t>(d->h_slots[i].tok_cap), kEncInf);
     const int grid = std::min(np, n_slots);
+    for (int q = 0; q < np; q++) d->h_done[q] = -1;
+    void *d_out_dev = nullptr, *d_done_dev = nullptr;
+    KH_HIP(hipHostGetDevicePointer(&d_out_dev, d->h_out_pinned, 0));
+    KH_HIP(hipHostGetDevicePointer(&d_done_dev, d->h_done, 0));
     KH_HIP(hipEventRecord(d->ev0, st));
-    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in, d->d_out, np, d->pool, p,
-                       (GP(long long))d->d_phase);
+    hipLaunchKernelGGL(DecodeKernel, dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in,
+                       static_cast<UttOut *>(d_out_dev), np, d->hpool, p, (GP(long long))d->d_phase, (GP(int32_t))d_done_dev);
     KH_LAUNCH_CHECK();
     KH_HIP(hipEventRecord(d->ev1, st));
+    // ---- host threads: canonical lattice + best path of every utterance as it completes
+    // (GetRawLattice + GetBestPath, decoder-wrappers.cc:215-262), overlapped with the kernel
+    std::atomic<int> next_done(0);
+    std::atomic<bool> kernel_done(false);
+    const int round_now = round;
+    (void)round_now;
+    auto worker = [&](int w) {
+      for (;;) {
+        const int i = next_done.fetch_add(1);
+        if (i >= np) break;
+        int q;
+        for (;;) {
+          q = __atomic_load_n(&d->h_done[i], __ATOMIC_ACQUIRE);
+          if (q >= 0) break;
+          if (kernel_done.load()) {
+            q = __atomic_load_n(&d->h_done[i], __ATOMIC_ACQUIRE);
+            break;
+          }
+          std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (q < 0) break;  // the kernel ended without this completion (launch failure)
+        const UttOut qo = d->h_out_pinned[q];
+        if (qo.stats.status != 0) continue;  // decoded again in a later launch, or left failed
+        const int ui = pending[q];
+        d->h_out[ui] = qo;
+        d->h_round[ui] = -1;
+        KhDecoder::Lat &L = d->lats[ui];
+        KhDecoder::Arena &A = d->arenas[w];
+        const size_t cn = qo.n_tok, cm = qo.n_link;
+        L.state_frame.bind(static_cast<int32_t *>(A.Take(4 * cn)), cn); L.state_hclg.bind(static_cast<int32_t *>(A.Take(4 * cn)), cn);
+        L.state_final.bind(static_cast<float *>(A.Take(4 * cn)), cn);
+        L.arc_src.bind(static_cast<int32_t *>(A.Take(4 * cm)), cm); L.arc_dst.bind(static_cast<int32_t *>(A.Take(4 * cm)), cm);
+        L.arc_il.bind(static_cast<int32_t *>(A.Take(4 * cm)), cm); L.arc_ol.bind(static_cast<int32_t *>(A.Take(4 * cm)), cm);
+        L.arc_g.bind(static_cast<float *>(A.Take(4 * cm)), cm); L.arc_a.bind(static_cast<float *>(A.Take(4 * cm)), cm);
+        (void)ComputeBestPath(d, ui);  // (an utterance without a best path reports it from its getter)
+      }
+    };
+    // (joined on every exit path; a D2H copy into pageable memory would block this thread until
+    // the kernel has finished, so nothing of that kind is issued before the stream is idle)
+    struct Workers {
+      std::vector<std::thread> th;
+      std::atomic<bool> *done;
+      ~Workers() {
+        done->store(true);
+        for (auto &t : th) t.join();
+      }
+    } workers{{}, &kernel_done};
+    const bool overlap = !getenv("KH_DECODER_NO_HOST_OVERLAP");
+    const double t_launched = tnow();
+    if (overlap)
+      for (int w = 0; w < n_workers; w++) workers.th.emplace_back(worker, w);
     std::vector<UttOut> q_out(np);
     unsigned long long used[4] = {0, 0, 0, 0};
-    KH_HIP(hipMemcpyAsync(q_out.data(), d->d_out, sizeof(UttOut) * np, hipMemcpyDeviceToHost, st));
+    const hipError_t sync_err = hipStreamSynchronize(st);
+    const double t_synced = tnow();
+    kernel_done.store(true);
+    if (!overlap)
+      for (int w = 0; w < n_workers; w++) workers.th.emplace_back(worker, w);
+    for (auto &t : workers.th) t.join();
+    workers.th.clear();
+    if (tprof)
+      fprintf(stderr, "[kh_decoder profile] host: %.1f ms before the launch returned, %.1f ms until the stream was idle, %.1f ms more for the host threads (%d)\n",
+              t_launched - t_enter, t_synced - t_launched, tnow() - t_synced, n_workers);
+    if (sync_err != hipSuccess) {
+      SetError("kh_decoder_decode: %s", hipGetErrorString(sync_err));
+      return KH_EDEVICE;
+    }
     KH_HIP(hipMemcpyAsync(used, d->d_used, sizeof(used), hipMemcpyDeviceToHost, st));
     std::vector<long long> h_phase;
     if (d->d_phase) {
@@ -2941,6 +3126,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       KH_HIP(hipMemcpyAsync(h_phase.data(), d->d_phase, sizeof(long long) * NPH * grid, hipMemcpyDeviceToHost, st));
     }
     KH_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < np; q++) q_out[q] = d->h_out_pinned[q];
     float ms = 0.f;
     KH_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
     d->last_kernel_ms += ms;
@@ -2968,7 +3154,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     bool grow = false, pool_short = false;
     int n_failed = 0;
     static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena", "links-per-frame cap",
-                                 "compaction window", "?", "lattice pool"};
+                                 "compaction window", "LDS token table", "lattice pool"};
     for (int q = 0; q < np; q++) {
       const int ui = pending[q];
       const KhDecodeStats &hs = q_out[q].stats;
@@ -2995,11 +3181,12 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
                  "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME",
                  ui, what[std::min(std::max(hs.status, 0), 6)], hs.num_frames, scale, d->tok_frame_cap, d->link_frame_cap);
       }
-      d->h_out[ui] = q_out[q];
-      d->h_round[ui] = static_cast<int32_t>(d->rounds.size());
+      if (hs.status != 0) {  // left failed: its counters and status are what the getters report
+        d->h_out[ui] = q_out[q];
+        d->h_round[ui] = -1;
+      }
     }
-    rc = FetchPool(d, used, pool_tok, pool_link, st);
-    if (rc) return rc;
+    (void)used;
     // the utterances that need larger arenas have no lattice size yet: estimate again
     pool_exact = pool_short && !grow;
     if (grow) scale *= 2;
