@@ -402,6 +402,14 @@ int kh_compute_deltas(const float *in, KhMatrixDim d_in, int order, const float 
  * vectors the caller derives from the stats as the reference does. */
 int kh_acc_cmvn_stats(const float *feats, KhMatrixDim d, double *stats_host);
 
+/* LatticeStateTimes (lat/lattice-functions.cc:36-67) for a batch of top-sorted lattices
+ * (layout as kh_lattice_forward_backward): time of every state (-1: unreachable) and, per
+ * lattice, the number of frames (max_times may be NULL).  KH_EINVAL if a lattice is not
+ * top-sorted or its state times are inconsistent (the KALDI_ASSERTs of :38-39,:55,:61). */
+int kh_lattice_state_times(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                           const int32_t *arc_ilabel, const int32_t *arc_nextstate, const float *state_final,
+                           int32_t *state_times, int32_t *max_times);
+
 /* ------------------------------------------------------------------ a15
  * Lattice forward-backward (lat/lattice-functions.cc:36-67,272-354) for a batch
  * of top-sorted lattices given as HOST CSR (state s owns arcs

@@ -1068,3 +1068,174 @@ def lattice_forward_backward_mmi(lats, tid2pdf, num_alis, drop_frames, convert_t
         post, _ = merge_posteriors(num_post, den_post, cancel, drop_frames)
         out.append(dict(post=post, tot_like=r["tot_like"]))
     return out
+
+
+# ---------------------------------------------------------------- config 5: discriminative pass
+def _lookup_values(M, rows, cols):
+    """CuMatrix::Lookup (cu-matrix.cc:2327) for index arrays."""
+    pairs = np.empty((len(rows), 2), np.int32)
+    pairs[:, 0] = rows
+    pairs[:, 1] = cols
+    out = lookup(M, pairs)
+    synchronize()
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _merge_keyed(rows, cols, weights):
+    """Sum float32 weights per (row, col), drop exact zeros; keys sorted (MergePairVectorSumming
+    per frame, util/stl-utils.h:303-322, for all frames at once)."""
+    if len(rows) == 0:
+        return rows.astype(np.int64), cols.astype(np.int64), weights.astype(np.float32)
+    key = rows.astype(np.int64) * (int(cols.max()) + 1) + cols.astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    key, rows, cols, weights = key[order], rows[order], cols[order], weights[order].astype(np.float32)
+    first = np.ones(len(key), bool)
+    first[1:] = key[1:] != key[:-1]
+    grp = np.cumsum(first) - 1
+    acc = np.zeros(int(grp[-1]) + 1, np.float32)
+    np.add.at(acc, grp, weights)
+    keep = acc != 0.0
+    return rows[first][keep], cols[first][keep], acc[keep]
+
+
+def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="smbr", acoustic_scale=0.1,
+                                        drop_frames=False, one_silence_class=False, tid2phone=None,
+                                        silence_phones=()):
+    """NnetDiscriminativeUpdater::Propagate + LatticeComputations
+    (nnet2/nnet-compute-discriminative.cc:150-321) for a BATCH of examples, as one pipeline
+    on the device: network forward -> CuMatrix::Lookup of the posteriors the numerator
+    alignment and the denominator lattice arcs need (:196-226) -> scaled pseudo log-likelihoods
+    log(post / prior) x acoustic_scale with the 1e-20 floor (:231-247) written into the lattice
+    (:259-277) -> MMI / sMBR / MPFE forward-backward (GetDiscriminativePosteriors :324-343) ->
+    ScalePosterior(weight) -> CompObjfAndDeriv (:279-316).  (--boost is not supported.)
+
+    egs: list of dict(feats = device [T + left + right, D] with exactly the network's context,
+    num_ali = int32 [T], den_lat = top-sorted CSR lattice (lattice_to_csr), weight = float).
+    Returns dict(stats = NnetDiscriminativeStats fields, deriv = device matrix [sum T, num_pdfs]:
+    the derivative at the network output, output = the posteriors)."""
+    if criterion not in ("mmi", "smbr", "mpfe"):
+        raise KhError('criterion must be "mmi", "mpfe" or "smbr"')
+    n = len(egs)
+    t2p = np.ascontiguousarray(tid2pdf, np.int32)
+    pri = np.ascontiguousarray(priors, np.float32)
+    Ts = np.array([len(e["num_ali"]) for e in egs], np.int64)
+    row_off = np.concatenate([[0], np.cumsum(Ts)])
+    # ---- Propagate (:150-175): the examples carry exactly the context the network needs
+    feat_rows = np.array([e["feats"].shape[0] for e in egs], np.int64)
+    foff = np.concatenate([[0], np.cumsum(feat_rows)]).astype(np.int32)
+    feats = torch.cat([e["feats"] for e in egs], 0) if n > 1 else egs[0]["feats"]
+    out, out_off = nnet.compute(feats, foff, pad_input=False)
+    if not np.array_equal(np.diff(np.asarray(out_off)), Ts):
+        raise KhError("KALDI_ASSERT(posteriors.NumRows() == num_frames) nnet-compute-discriminative.cc:194")
+    num_pdfs = out.shape[1]
+    if num_pdfs != len(pri):
+        raise KhError("KALDI_ASSERT(num_pdfs == priors.Dim()) :196")
+    # ---- lattices: state times, the (frame, pdf) every arc with a transition-id needs
+    lats = [e["den_lat"] for e in egs]
+    nl, soff, aoff, il, ns, g, a, fin = _cat_lattices(lats)
+    times = np.empty(int(soff[-1]), np.int32)
+    max_t = np.empty(nl, np.int32)
+    ip, fp = capi.c_int32_p, capi.c_float_p
+    check(lib().kh_lattice_state_times(nl, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p),
+                                       il.ctypes.data_as(ip), ns.ctypes.data_as(ip), fin.ctypes.data_as(fp),
+                                       times.ctypes.data_as(ip), max_t.ctypes.data_as(ip)))
+    if not np.array_equal(max_t, Ts):
+        raise KhError("KALDI_ASSERT(T == num_frames) nnet-compute-discriminative.cc:220")
+    n_arcs_state = np.diff(aoff)
+    src_state = np.repeat(np.arange(len(n_arcs_state)), n_arcs_state)
+    lat_of_state = np.repeat(np.arange(nl), np.diff(soff))
+    em = il != 0
+    arc_row = row_off[lat_of_state[src_state[em]]] + times[src_state[em]]
+    arc_pdf = t2p[il[em]]
+    ali = np.concatenate([np.asarray(e["num_ali"], np.int32) for e in egs])
+    ali_row = np.arange(int(row_off[-1]))
+    ali_pdf = t2p[ali]
+    weights = np.array([float(e.get("weight", 1.0)) for e in egs], np.float32)
+    stats = dict(tot_t=float(Ts.sum()), tot_t_weighted=float((Ts * weights).sum()), tot_num_count=0.0,
+                 tot_num_objf=0.0, tot_den_objf=0.0)
+    # ---- Lookup + pseudo log-likelihoods (:196-247)
+    if criterion == "mmi":
+        rows_req = np.concatenate([ali_row, arc_row])
+        cols_req = np.concatenate([ali_pdf, arc_pdf])
+    else:
+        rows_req, cols_req = arc_row, arc_pdf
+    answers = _lookup_values(out, rows_req, cols_req).astype(np.float32)
+    post = np.maximum(answers, np.float32(1.0e-20))
+    pseudo = (np.log(post / pri[cols_req]) * np.float32(acoustic_scale)).astype(np.float32)
+    index = 0
+    if criterion == "mmi":
+        num_like = pseudo[:len(ali)].astype(np.float64)
+        per_eg = np.add.reduceat(num_like, row_off[:-1]) if len(ali) else np.zeros(n)
+        stats["tot_num_objf"] = float((weights * per_eg).sum())
+        index = len(ali)
+    a = a.copy()
+    a[em] = -pseudo[index:]
+    lats2 = []
+    for i, L in enumerate(lats):
+        a0, a1 = int(aoff[soff[i]]), int(aoff[soff[i + 1]])
+        L2 = dict(L)
+        L2["arc_acoustic"] = a[a0:a1]
+        lats2.append(L2)
+    # ---- MMI / sMBR / MPFE posteriors by pdf (:324-343), scaled by the example weight
+    n_em_per_lat = np.add.reduceat(em.astype(np.int64), aoff[soff[:-1]]) if nl else np.zeros(0, np.int64)
+    lat_of_em = np.repeat(np.arange(nl), n_em_per_lat)
+    if criterion == "mmi":
+        nL, so, ao, il2, ns2, g2, a2, fin2 = _cat_lattices(lats2)
+        arc_post = np.empty(len(il2), np.float32)
+        tot = np.empty(nL)
+        dp = capi.c_double_p
+        check(lib().kh_lattice_forward_backward(
+            nL, so.ctypes.data_as(ip), ao.ctypes.data_as(capi.c_int64_p), il2.ctypes.data_as(ip), ns2.ctypes.data_as(ip),
+            g2.ctypes.data_as(fp), a2.ctypes.data_as(fp), fin2.ctypes.data_as(fp), arc_post.ctypes.data_as(fp),
+            tot.ctypes.data_as(dp), None, None))
+        stats["tot_den_objf"] = float((weights * tot).sum())
+        # denominator: -posterior per (frame, transition-id) merged, then per pdf; numerator +1; cancel
+        dr, dc, dw = _merge_keyed(arc_row, il[em].astype(np.int64), arc_post[em])          # MergePairVectorSumming by tid
+        dr, dc, dw = _merge_keyed(dr, t2p[dc].astype(np.int64), -dw)                      # ScalePosterior(-1), ConvertPosteriorToPdfs
+        den_keys = set(zip(dr.tolist(), dc.tolist())) if drop_frames else None
+        r, c, w = _merge_keyed(np.concatenate([ali_row, dr]), np.concatenate([ali_pdf.astype(np.int64), dc]),
+                               np.concatenate([np.ones(len(ali), np.float32), dw]))
+        if drop_frames:   # frames whose numerator pdf is not in the denominator are emptied (MergePosteriors :266-270)
+            disjoint = np.array([(int(t), int(p)) not in den_keys for t, p in zip(ali_row, ali_pdf)])
+            w = w[~disjoint[r]]
+            c = c[~disjoint[r]]
+            r = r[~disjoint[r]]
+    else:
+        if tid2phone is None:
+            raise KhError("sMBR / MPFE need the transition-id -> phone map")
+        alis = [np.asarray(e["num_ali"], np.int32) for e in egs]
+        res = lattice_forward_backward_mpe_raw(lats2, tid2phone, t2p, silence_phones, alis, criterion, one_silence_class)
+        stats["tot_den_objf"] = float((weights * res["tot_forward_score"]).sum())
+        dr, dc, dw = _merge_keyed(arc_row, il[em].astype(np.int64), res["arc_post"][em])
+        r, c, w = _merge_keyed(dr, t2p[dc].astype(np.int64), dw)
+    lat_of_row = np.repeat(np.arange(n), Ts)
+    w = (w * weights[lat_of_row[r]]).astype(np.float32)           # ScalePosterior(eg.weight) :283
+    stats["tot_num_count"] = float(w[w > 0].astype(np.float64).sum())
+    # ---- CompObjfAndDeriv (:301-316)
+    deriv = torch.zeros_like(out)
+    rr, cc = np.ascontiguousarray(r, np.int32), np.ascontiguousarray(c, np.int32)
+    objf, wt = C.c_float(), C.c_float()
+    check(lib().kh_comp_objf_and_deriv(len(rr), rr.ctypes.data_as(ip), cc.ctypes.data_as(ip),
+                                       np.ascontiguousarray(w).ctypes.data_as(fp), _p(out), _dim(out), _p(deriv), _dim(deriv),
+                                       C.byref(objf), C.byref(wt)))
+    return dict(stats=stats, deriv=deriv, output=out, sv_labels=(rr, cc, w))
+
+
+def lattice_forward_backward_mpe_raw(lats, tid2phone, tid2pdf, silence_phones, num_alis, criterion, one_silence_class):
+    """kh_lattice_forward_backward_mpe for a batch, arrays only (no per-frame Python lists)."""
+    n, soff, aoff, il, ns, g, a, fin = _cat_lattices(lats)
+    t2ph, t2pdf = np.ascontiguousarray(tid2phone, np.int32), np.ascontiguousarray(tid2pdf, np.int32)
+    sil = np.ascontiguousarray(sorted(silence_phones), np.int32)
+    ali_off = np.concatenate([[0], np.cumsum([len(x) for x in num_alis])]).astype(np.int32)
+    ali = np.ascontiguousarray(np.concatenate([np.asarray(x, np.int32) for x in num_alis]), np.int32)
+    post = np.empty(len(il), np.float32)
+    score = np.empty(n)
+    ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
+    check(lib().kh_lattice_forward_backward_mpe(
+        n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
+        g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp), t2ph.ctypes.data_as(ip),
+        t2pdf.ctypes.data_as(ip), len(t2ph) - 1, sil.ctypes.data_as(ip), len(sil), ali.ctypes.data_as(ip),
+        ali_off.ctypes.data_as(ip), int(criterion == "mpfe"), int(bool(one_silence_class)), post.ctypes.data_as(fp),
+        score.ctypes.data_as(dp), None))
+    return dict(arc_post=post, tot_forward_score=score)

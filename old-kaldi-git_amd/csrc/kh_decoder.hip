@@ -264,6 +264,7 @@ struct Shared {
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
   int link_cursor;  // ExpandSweepFiltered: next free link slot (LDS atomic, one add per wave)
+  float wbound[2][NW];  // ExpandSweepFiltered: per-wave minima of the cutoff estimate, double buffered
   int front_b;  // first token of the frame under construction (frontier)
   int status;
   long long arcs_expanded, tokens_created;
@@ -629,7 +630,8 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off,
 // next_cutoff.  Returns the new end of the link arena, or -1 on overflow (sh->status set).
 template <class Eval, class Store>
 __device__ __forceinline__ int ExpandSweepFiltered(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
-                                                   int frame_cap, long long *arcs, Blk &sh, Eval eval, Store store) {
+                                                   int frame_cap, long long *arcs, Blk &sh, float *est, float *bound, Eval eval,
+                                                   Store store) {
   const int limit = min(u.link_cap, lrun + frame_cap);
   const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) sh->link_cursor = lrun;  // (visible behind the first group's scan barrier)
@@ -658,8 +660,21 @@ __device__ __forceinline__ int ExpandSweepFiltered(const Utt &u, Arr<const int32
       }
     }
     int loff[EU], total;
+    // the bound tightens from group to group: the minimum of the estimate over everything the
+    // workgroup has seen so far rides on the scan's barrier
+    const int wb = ((base - b) / (NT * EU)) & 1;
+    {
+      const float wm = kh_wave_min(*est);
+      if (lane == 0) sh->wbound[wb][threadIdx.x >> 6] = wm;
+    }
     // (this barrier also orders the previous group's LDS reads before the writes below)
     BlockExScanK<EU>(cnt, loff, &total, sh);
+    {
+      float m = sh->wbound[wb][0];
+#pragma unroll
+      for (int w = 1; w < NW; w++) m = fminf(m, sh->wbound[wb][w]);
+      *bound = fminf(*bound, Uni(m));
+    }
 #pragma unroll
     for (int k = 0; k < EU; k++) {  // slice-major item order = the scan's order: ex_off is non-decreasing
       sh->ex_off[k * NT + threadIdx.x] = loff[k];
@@ -980,13 +995,14 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // next_cutoff, so a candidate above it is rejected whatever the rest of the frame holds.
   const float est0 = BlockMinF(est, sh);
   est = est0;
+  float bound = est0;  // upper bound of the final next_cutoff; tightens as the sweep proceeds
   const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
   KhInt4 c_arc;
   int c_src = 0;
   float c_ac = 0.f, c_tot = 0.f;
   const int link_frame_e = ExpandSweepFiltered(
-      u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh,
+      u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
       [&](int src, int ai) -> bool {
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_emit);
@@ -999,7 +1015,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         c_ac = cost_offset - like;
         c_tot = Dec(co) + c_ac + __int_as_float(c_arc.z);  // :726-730
         est = fminf(est, c_tot + c.adaptive_beam);
-        return !(c_tot > est0);
+        return !(c_tot > bound);
       },
       [&](int l) {
         u.link_dst[l] = c_arc.w;  // HCLG next state for now; token index after pass 2
@@ -1040,34 +1056,53 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     // number of parts: about 11 000 accepted candidates per part (typically half as many
     // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
     // parts (the parts nest, and resolved links are marked, so nothing is done twice)
-    int n_acc_mine = 0;
-    for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
-      n_acc_mine += !(u.link_tot[l - link_frame_b] > next_cutoff) ? 1 : 0;
-    const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
     int parts = 1;
-    while (parts * 11000 < n_acc) parts *= 2;
+    if (link_frame_e - link_frame_b > 11000) {
+      int n_acc_mine = 0;
+      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
+        n_acc_mine += !(u.link_tot[l - link_frame_b] > next_cutoff) ? 1 : 0;
+      const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
+      while (parts * 11000 < n_acc) parts *= 2;
+      if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
+    }
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[31] += link_frame_e - link_frame_b; sh->phase[13] += 0; }
     for (int k = 0; k < parts; k++) {
       for (int i = threadIdx.x; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
       if (threadIdx.x == 0) sh->flag = 0;
       KhSync();
-      // (B) insert.  A link that an earlier part resolved carries NaN in link_tot.
-      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-        const float tot_cost = u.link_tot[l - link_frame_b];
-        if (tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
-        const int32_t ns = u.link_dst[l];
-        const uint32_t h = HashState(ns & kStateMask);
-        if (part_of(h, parts) != k) continue;
-        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-        uint32_t slot = h & (kLdsSlots - 1);
-        int probes = 0;
-        for (; probes < 256; probes++) {
-          uint32_t seen = 0u;
-          __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (seen == 0u || seen == key) break;
-          slot = (slot + 1) & (kLdsSlots - 1);
+      // (B) insert.  A link that an earlier part resolved carries NaN in link_tot.  kMU
+      // candidates per lane are loaded before any is used (independent loads in flight).
+      constexpr int kMU = 4;
+      for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * kMU) {
+        float tc[kMU];
+        int32_t nsv[kMU];
+#pragma unroll
+        for (int j = 0; j < kMU; j++) {
+          const int l = base + j * NT;
+          const int lc = l < link_frame_e ? l : link_frame_e - 1;
+          tc[j] = u.link_tot[lc - link_frame_b];
+          nsv[j] = u.link_dst[lc];
+          if (l >= link_frame_e) tc[j] = nan;
         }
-        if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
-        (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int j = 0; j < kMU; j++) {
+          const float tot_cost = tc[j];
+          if (tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
+          const int32_t ns = nsv[j];
+          const uint32_t h = HashState(ns & kStateMask);
+          if (part_of(h, parts) != k) continue;
+          const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+          uint32_t slot = h & (kLdsSlots - 1);
+          int probes = 0;
+          for (; probes < 256; probes++) {
+            uint32_t seen = 0u;
+            __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seen == 0u || seen == key) break;
+            slot = (slot + 1) & (kLdsSlots - 1);
+          }
+          if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
+          (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
       KhSync();
       if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
@@ -1125,24 +1160,35 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       if (threadIdx.x == 0) sh->tok_end = tok_base + total;
       KhSync();
       // (D) the part's links get their token index; rejected candidates become dead links
-      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-        const float tot_cost = u.link_tot[l - link_frame_b];
-        if (tot_cost != tot_cost) {  // resolved by an earlier part (a NaN candidate of the first part: rejected)
-          if (k == 0) u.link_dst[l] = -1;
-          continue;
+      for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * kMU) {
+        float tc[kMU];
+        int32_t nsv[kMU];
+#pragma unroll
+        for (int j = 0; j < kMU; j++) {
+          const int l = base + j * NT;
+          const int lc = l < link_frame_e ? l : link_frame_e - 1;
+          tc[j] = u.link_tot[lc - link_frame_b];
+          nsv[j] = u.link_dst[lc];
         }
-        if (tot_cost > next_cutoff) {
-          if (k == 0) u.link_dst[l] = -1;
-          continue;
+#pragma unroll
+        for (int j = 0; j < kMU; j++) {
+          const int l = base + j * NT;
+          if (l >= link_frame_e) continue;
+          const float tot_cost = tc[j];
+          if (tot_cost != tot_cost || tot_cost > next_cutoff) {
+            // resolved by an earlier part (a NaN candidate of the first part: rejected), or rejected
+            if (k == 0) u.link_dst[l] = -1;
+            continue;
+          }
+          const int32_t ns = nsv[j];
+          const uint32_t h = HashState(ns & kStateMask);
+          if (part_of(h, parts) != k) continue;
+          const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+          uint32_t slot = h & (kLdsSlots - 1);
+          while (keys[slot] != key) slot = (slot + 1) & (kLdsSlots - 1);
+          u.link_dst[l] = static_cast<int32_t>(vals[slot]);
+          if (parts > 1) u.link_tot[l - link_frame_b] = nan;
         }
-        const int32_t ns = u.link_dst[l];
-        const uint32_t h = HashState(ns & kStateMask);
-        if (part_of(h, parts) != k) continue;
-        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-        uint32_t slot = h & (kLdsSlots - 1);
-        while (keys[slot] != key) slot = (slot + 1) & (kLdsSlots - 1);
-        u.link_dst[l] = static_cast<int32_t>(vals[slot]);
-        if (parts > 1) u.link_tot[l - link_frame_b] = nan;
       }
       KhSync();
     }
@@ -1361,62 +1407,67 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   *links_pruned = (all & 2) != 0;
 }
 
-// PruneForwardLinks :273-344 (+ PruneTokensForFrame(f + 1) when prune_toks_f1) for a SMALL
-// frame: at most kSmallTok tokens in frames f and f + 1 and one link per lane.  Most visits
-// of the backward pruning are of this kind (a frame more than ~2 prune intervals old holds
-// a handful of tokens), and there the general routine is a chain of ~10 dependent global
-// round trips.  Here everything the visit needs is read ONCE (one round trip), the fixed
-// point runs on LDS accumulators, and the results are written back: same float operations,
-// same unique fixed point.
-constexpr int kSmallTok = 256;
-__device__ void PruneSmallFrame(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
-                                bool prune_toks_f1, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
-  static_assert(EU * NT >= 4 * kSmallTok, "the expansion's LDS arrays are reused here");
+// PruneForwardLinks :273-344 (+ PruneTokensForFrame(f + 1) when prune_toks_f1) for a frame of
+// at most kPruneLdsTok tokens whose successor frame is no larger - nearly every visit of the
+// backward pruning.  The general routine above is a chain of ~10 barrier-separated phases,
+// each with its own global round trip (gathers of cost[src], cost[dst], extra[dst] per link
+// and per iteration).  Here everything the visit needs is read ONCE, coalesced, into LDS (the
+// idle 64 KB of the emitting pass's token table: costs of f, costs and extra_costs of f + 1,
+// the two accumulators, the extra_costs being computed), every gather and the whole fixed
+// point run on LDS, and the results are written back: same float operations, same unique
+// fixed point.
+constexpr int kPruneLdsTok = kLdsSlots / 2;  // 4096
+__device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
+                              bool prune_toks_f1, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY, lb = p.lattice_beam;
   const int t = threadIdx.x;
-  auto s_cost = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_off[0]);            // cost of f's tokens
-  auto s_acc0 = reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(&sh->ex_off[kSmallTok]);  // Enc(min) over emitting links
-  auto s_acc1 = reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(&sh->ex_off[2 * kSmallTok]);  // ... over epsilon links
-  auto s_x = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_off[3 * kSmallTok]);    // extra_cost being computed
-  auto s_nc = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_ab[0]);               // cost of f + 1's tokens
-  auto s_nx = reinterpret_cast<__attribute__((address_space(3))) float *>(&sh->ex_ab[kSmallTok]);       // extra_cost of f + 1's tokens
+  auto ra = LdsKeys(sh);  // 8192 words
+  auto rb = LdsVals(sh);  // 8192 words
+  auto s_cost = reinterpret_cast<__attribute__((address_space(3))) float *>(ra);                  // cost of f's tokens
+  auto s_acc0 = ra + kPruneLdsTok;                                                                  // Enc(min) over emitting links
+  auto s_nc = reinterpret_cast<__attribute__((address_space(3))) float *>(rb);                    // phase 1: cost of f + 1's tokens
+  auto s_nx = reinterpret_cast<__attribute__((address_space(3))) float *>(rb + kPruneLdsTok);     // phase 1: extra_cost of f + 1's tokens
+  auto s_acc1 = rb;                                                                                 // phase 2: Enc(min) over epsilon links
+  auto s_x = reinterpret_cast<__attribute__((address_space(3))) float *>(rb + kPruneLdsTok);      // phase 2: extra_cost being computed
   if (u.phase_cycles != nullptr && t == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; sh->phase[14] += 1; }
   // ---- everything the visit reads, in one round trip
-  int st = -1;
-  float old = 0.0f;
-  if (t < e - b) {
-    st = u.tok_state[b + t];
-    old = LoadExtra(&u.tok_extra[b + t]);
-    s_cost[t] = Dec(LoadCostEnc(&u.tok_cost[b + t]));
-    s_acc0[t] = kEncInf;
-    s_acc1[t] = kEncInf;
+  for (int i = t; i < e - b; i += NT) {
+    s_cost[i] = Dec(LoadCostEnc(&u.tok_cost[b + i]));
+    s_acc0[i] = kEncInf;
   }
-  if (t < e1 - b1) {
-    const float nx = LoadExtra(&u.tok_extra[b1 + t]);
-    s_nc[t] = Dec(LoadCostEnc(&u.tok_cost[b1 + t]));
-    s_nx[t] = nx;
+  for (int i = t; i < e1 - b1; i += NT) {
+    const float nx = LoadExtra(&u.tok_extra[b1 + i]);
+    s_nc[i] = Dec(LoadCostEnc(&u.tok_cost[b1 + i]));
+    s_nx[i] = nx;
     // PruneTokensForFrame(f + 1) :450-469: its extra_costs are final
-    if (prune_toks_f1 && nx == inf && u.tok_state[b1 + t] >= 0) u.tok_state[b1 + t] = -1;
+    if (prune_toks_f1 && nx == inf && u.tok_state[b1 + i] >= 0) u.tok_state[b1 + i] = -1;
   }
-  int m_dst = -1, m_src = 0, n_dst = -1, n_src = 0;
-  float m_a = 0.0f, m_g = 0.0f, n_a = 0.0f;
-  if (t < me - mb) { m_dst = u.link_dst[mb + t]; m_src = u.link_src[mb + t]; m_a = u.link_a[mb + t]; m_g = u.link_g[mb + t]; }
-  if (t < ne - nb) { n_dst = u.link_dst[nb + t]; n_src = u.link_src[nb + t]; n_a = u.link_a[nb + t]; }
+  // the first epsilon link of every lane stays in registers over the iterations
+  int n_dst = -1, n_src = 0;
+  float n_a = 0.0f;
+  if (nb + t < ne) { n_dst = u.link_dst[nb + t]; n_src = u.link_src[nb + t]; n_a = u.link_a[nb + t]; }
   KhSync();
   // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
   int flags = 0;
-  if (m_dst >= 0) {
-    float lec = s_nx[m_dst - b1] + ((s_cost[m_src - b] + m_a + m_g) - s_nc[m_dst - b1]);
+  for (int l = mb + t; l < me; l += NT) {
+    const int dst = u.link_dst[l];
+    if (dst < 0) continue;
+    const int src = u.link_src[l];
+    const float a = u.link_a[l], g = u.link_g[l];
+    float lec = s_nx[dst - b1] + ((s_cost[src - b] + a + g) - s_nc[dst - b1]);
     if (lec > lb) {
-      u.link_dst[mb + t] = -1;
+      u.link_dst[l] = -1;
       flags |= 2;
     } else {
       if (lec < 0.0f) lec = 0.0f;
-      __hip_atomic_fetch_min(&s_acc0[m_src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_min(&s_acc0[src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  KhSync();
-  if (t < e - b) s_x[t] = Dec(s_acc0[t]);
+  KhSync();  // (s_nc / s_nx are dead from here on: their LDS becomes s_acc1 / s_x)
+  for (int i = t; i < e - b; i += NT) {
+    s_x[i] = Dec(s_acc0[i]);
+    s_acc1[i] = kEncInf;
+  }
   // ---- epsilon links (inside the frame): iterate to the fixed point
   if (ne > nb) {
     for (;;) {
@@ -1428,29 +1479,47 @@ __device__ void PruneSmallFrame(const Utt &u, const Params &p, int b, int e, int
           __hip_atomic_fetch_min(&s_acc1[n_src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+      for (int l = nb + NT + t; l < ne; l += NT) {
+        const int dst = u.link_dst[l];
+        if (dst < 0) continue;
+        float lec = s_x[dst - b] + u.link_a[l];
+        if (!(lec > lb)) {
+          if (lec < 0.0f) lec = 0.0f;
+          __hip_atomic_fetch_min(&s_acc1[u.link_src[l] - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       KhSync();
       bool changed = false;
-      if (t < e - b) {
-        const uint32_t a0 = s_acc0[t], a1 = s_acc1[t];
+      for (int i = t; i < e - b; i += NT) {
+        const uint32_t a0 = s_acc0[i], a1 = s_acc1[i];
         const float v = Dec(a1 < a0 ? a1 : a0);
-        changed = !(v == s_x[t]);
-        s_x[t] = v;
-        s_acc1[t] = kEncInf;
+        changed |= !(v == s_x[i]);
+        s_x[i] = v;
+        s_acc1[i] = kEncInf;
       }
       if (u.phase_cycles != nullptr && t == 0) sh->phase[14] += 1;
       if (!BlockAny(changed, sh)) break;
     }
-    if (n_dst >= 0 && s_x[n_dst - b] + n_a > lb) {  // excise :315
+    // excise :315
+    if (n_dst >= 0 && s_x[n_dst - b] + n_a > lb) {
       u.link_dst[nb + t] = -1;
       flags |= 2;
+    }
+    for (int l = nb + NT + t; l < ne; l += NT) {
+      const int dst = u.link_dst[l];
+      if (dst >= 0 && s_x[dst - b] + u.link_a[l] > lb) {
+        u.link_dst[l] = -1;
+        flags |= 2;
+      }
     }
   } else {
     KhSync();
   }
   // ---- write back; :334 counts the tokens whose extra_cost moved by more than delta
-  if (t < e - b && st >= 0) {
-    const float v = s_x[t];
-    if (!(v == old)) StoreExtra(&u.tok_extra[b + t], v);
+  for (int i = t; i < e - b; i += NT) {
+    if (u.tok_state[b + i] < 0) continue;
+    const float old = LoadExtra(&u.tok_extra[b + i]), v = s_x[i];
+    if (!(v == old)) StoreExtra(&u.tok_extra[b + i], v);
     if (fabsf(v - old) > delta) flags |= 1;
   }
   const int all = BlockOr(flags, sh);
@@ -1490,8 +1559,8 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
       bool ec, lp;
       const int b = Uni(u.frame_b[f]), e = Uni(u.frame_e[f]), mb = Uni(u.femit_b[f]), me = Uni(u.femit_e[f]),
                 nb = Uni(u.feps_b[f]), ne = Uni(u.feps_e[f]), b1 = Uni(u.frame_b[f + 1]), e1 = Uni(u.frame_e[f + 1]);
-      if (e - b <= kSmallTok && e1 - b1 <= kSmallTok && me - mb <= NT && ne - nb <= NT)
-        PruneSmallFrame(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
+      if (e - b <= kPruneLdsTok && e1 - b1 <= kPruneLdsTok)
+        PruneFrameLds(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
       else
         PruneForwardLinks(u, p, b, e, mb, me, nb, ne, delta, false, false, 0.f, mt ? b1 : 0, mt ? e1 : 0, &ec, &lp, sh);
       if (threadIdx.x == 0) {
@@ -2718,6 +2787,7 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
           "FindOrAdd + min + queue %.1f%%, round barrier %.1f%%; tokens processed per round %.1f\n",
           tot[3] ? 100.0 * tot[27] / tot[3] : 0.0, tot[3] ? 100.0 * tot[28] / tot[3] : 0.0, tot[3] ? 100.0 * tot[29] / tot[3] : 0.0,
           tot[3] ? 100.0 * tot[30] / tot[3] : 0.0, tot[13] ? double(tot[33]) / tot[13] : 0.0);
+  fprintf(stderr, "[kh_decoder profile] emitting pass: %lld candidates materialised (%lld counted as accepted in the frames with more than 11000)\n", tot[31], tot[32]);
   fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
           tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);
 }

@@ -542,8 +542,8 @@ struct LatBatch {
     UP(d_next, arc_nextstate, A, int32_t);
     UP(d_ilabel, arc_ilabel, A, int32_t);
     UP(d_fin, state_final, S, float);
-    UP(d_g, arc_graph, A, float);
-    UP(d_a, arc_acoustic, A, float);
+    if (arc_graph) UP(d_g, arc_graph, A, float);
+    if (arc_acoustic) UP(d_a, arc_acoustic, A, float);
 #undef UP
     hipLaunchKernelGGL(PrepKernel, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
                        d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
@@ -609,6 +609,28 @@ extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_
   if (acoustic_like_sum)
     KH_HIP(hipMemcpyAsync(acoustic_like_sum, d_ac.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
   KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
+// LatticeStateTimes (lat/lattice-functions.cc:36-67) of a batch of top-sorted lattices: the
+// time of every state (-1 for a state no path from the start reaches) and, per lattice, the
+// number of frames.  Device preparation only (the caller of
+// NnetDiscriminativeUpdater::LatticeComputations needs the times before any sweep,
+// nnet-compute-discriminative.cc:218-220).
+extern "C" int kh_lattice_state_times(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                                      const int32_t *arc_ilabel, const int32_t *arc_nextstate, const float *state_final,
+                                      int32_t *state_times, int32_t *max_times) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && state_final && state_times);
+  hipStream_t st = Stream();
+  LatBatch B;
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, nullptr, nullptr, state_final, st);
+  if (rc) return rc;
+  if ((rc = B.FetchTimes(state_times, st))) return rc;
+  KH_HIP(hipStreamSynchronize(st));
+  if (max_times)
+    for (int l = 0; l < n_lats; l++) max_times[l] = B.descs[l].max_time;
   return KH_OK;
 }
 

@@ -620,3 +620,27 @@ def lattice_forward_backward_mmi(csr, tid2pdf, num_ali, drop_frames, convert_to_
     assert tot > -1.0e29
     post = [[(int(ids[k]), float(w[k])) for k in range(fo[t], fo[t + 1])] for t in range(len(ali))]
     return dict(post=post, tot_like=tot, num_disjoint=nd.value)
+
+
+def discriminative_lattice_computations(posteriors, priors, csr, tid2pdf, tid2phone, silence_phones, num_ali,
+                                        criterion="smbr", acoustic_scale=0.1, drop_frames=False, one_silence_class=False,
+                                        weight=1.0, stats=None):
+    """ko_discriminative_lattice_computations (NnetDiscriminativeUpdater::LatticeComputations,
+    nnet2/nnet-compute-discriminative.cc:178-321) for one example.  Returns (stats[5], deriv)."""
+    lib = C.CDLL(ORACLE_SO)
+    fn = lib.ko_discriminative_lattice_computations
+    fn.restype = C.c_int
+    off, il, ns, g, a, fin = _csr_args(csr)
+    post = _f32(posteriors)
+    pri, t2p, t2ph = _f32(priors), _i32(tid2pdf), _i32(tid2phone if tid2phone is not None else np.zeros(len(tid2pdf), np.int32))
+    sil, ali = _i32(sorted(silence_phones)), _i32(num_ali)
+    st = np.zeros(5, np.float64) if stats is None else stats
+    deriv = np.zeros_like(post)
+    rc = fn(_fp(post), C.c_int(post.shape[0]), C.c_int(post.shape[1]), C.c_int(post.shape[1]), _fp(pri),
+            C.c_int(csr["n_states"]), off.ctypes.data_as(c_int64_p), _ip(il), _ip(ns), _fp(g), _fp(fin), _ip(t2p), _ip(t2ph),
+            _ip(sil), C.c_int(len(sil)), _ip(ali), C.c_int({"mmi": 0, "smbr": 1, "mpfe": 2}[criterion]),
+            C.c_float(acoustic_scale), C.c_int(int(drop_frames)), C.c_int(int(one_silence_class)), C.c_float(weight),
+            st.ctypes.data_as(C.POINTER(C.c_double)), _fp(deriv), C.c_int(deriv.shape[1]))
+    if rc != 0:
+        raise RuntimeError("forward-backward check %d failed" % -rc)
+    return st, deriv

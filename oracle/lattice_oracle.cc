@@ -435,3 +435,104 @@ extern "C" double ko_lattice_forward_backward_mmi(int num_states, const int64_t 
   frame_offsets[post.size()] = k;
   return ans;
 }
+
+// ---------------------------------------------------------------------------
+// NnetDiscriminativeUpdater::LatticeComputations nnet2/nnet-compute-discriminative.cc:178-321
+// for ONE example, given the network's output (the posteriors matrix forward_data_.back()):
+// requested indexes (:203-226), Lookup, floor + pseudo log-likelihoods (:231-247), numerator
+// likelihood (:253-258), lattice acoustic costs (:261-277), GetDiscriminativePosteriors
+// (:324-343), ScalePosterior (:283), sv_labels + CompObjfAndDeriv (:285-316).  boost == 0.
+// stats[5] = {tot_t, tot_t_weighted, tot_num_count, tot_num_objf, tot_den_objf} are ADDED to.
+// Returns 0, or -k when a forward-backward self-check fails.  PARITY UNPINNED by the
+// reference (needs OpenFst); every piece it calls is pinned by path enumeration above.
+extern "C" int ko_discriminative_lattice_computations(
+    const float *posteriors, int num_frames, int num_pdfs, int post_stride, const float *priors, int num_states,
+    const int64_t *arc_offsets, const int32_t *arc_ilabel, const int32_t *arc_nextstate, const float *arc_graph,
+    const float *state_final, const int32_t *tid2pdf, const int32_t *tid2phone, const int32_t *silence_phones, int n_sil,
+    const int32_t *num_ali, int criterion /*0 mmi, 1 smbr, 2 mpfe*/, float acoustic_scale, int drop_frames,
+    int one_silence_class, float weight, double *stats, float *deriv, int deriv_stride) {
+  const int64_t n_arcs = arc_offsets[num_states];
+  stats[0] += num_frames;
+  stats[1] += num_frames * weight;
+  std::vector<std::pair<int32_t, int32_t> > requested;
+  if (criterion == 0)
+    for (int t = 0; t < num_frames; t++) requested.push_back(std::make_pair(t, tid2pdf[num_ali[t]]));
+  // LatticeStateTimes :36-67
+  std::vector<int32_t> times(num_states, -1);
+  times[0] = 0;
+  for (int s = 0; s < num_states; s++)
+    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++) {
+      int32_t want = times[s] + (arc_ilabel[a] != 0 ? 1 : 0), ns = arc_nextstate[a];
+      if (times[ns] == -1) times[ns] = want;
+      else if (times[ns] != want) abort();
+    }
+  for (int s = 0; s < num_states; s++)
+    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
+      if (arc_ilabel[a] != 0) requested.push_back(std::make_pair(times[s], tid2pdf[arc_ilabel[a]]));
+  std::vector<float> answers(requested.size());
+  const float floor_val = 1.0e-20f;
+  for (size_t i = 0; i < requested.size(); i++) {
+    float post = posteriors[static_cast<size_t>(requested[i].first) * post_stride + requested[i].second];  // Lookup
+    if (post < floor_val) post = floor_val;
+    answers[i] = logf(post / priors[requested[i].second]) * acoustic_scale;  // :241
+  }
+  size_t index = 0;
+  if (criterion == 0) {
+    double tot_num_like = 0.0;
+    for (; index < static_cast<size_t>(num_frames); index++) tot_num_like += answers[index];
+    stats[3] += weight * tot_num_like;
+  }
+  std::vector<float> acoustic(n_arcs, 0.0f), fin(state_final, state_final + num_states);
+  for (int s = 0; s < num_states; s++)
+    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
+      if (arc_ilabel[a] != 0) acoustic[a] = -answers[index++];
+  if (index != answers.size()) abort();
+  // GetDiscriminativePosteriors :324-343 -> Posterior by pdf
+  Posterior post;
+  if (criterion == 0) {
+    std::vector<int32_t> fo(num_frames + 1), ids(n_arcs + num_frames + 16);
+    std::vector<float> w(n_arcs + num_frames + 16);
+    int32_t n_ent = 0;
+    const double den = ko_lattice_forward_backward_mmi(num_states, arc_offsets, arc_ilabel, arc_nextstate, arc_graph,
+                                                       acoustic.data(), fin.data(), tid2pdf, num_ali, num_frames, drop_frames,
+                                                       1, 1, fo.data(), ids.data(), w.data(), static_cast<int>(ids.size()),
+                                                       &n_ent, NULL);
+    stats[4] += weight * den;
+    post.resize(num_frames);
+    for (int t = 0; t < num_frames; t++)
+      for (int k = fo[t]; k < fo[t + 1]; k++) post[t].push_back(std::make_pair(ids[k], w[k]));
+  } else {
+    std::vector<float> arc_post(n_arcs);
+    double score = 0.0;
+    const int rc = ko_lattice_forward_backward_mpe(num_states, arc_offsets, arc_ilabel, arc_nextstate, arc_graph,
+                                                   acoustic.data(), fin.data(), tid2phone, tid2pdf, silence_phones, n_sil,
+                                                   num_ali, num_frames, criterion == 2, one_silence_class, arc_post.data(),
+                                                   &score);
+    if (rc != 0) return rc;
+    stats[4] += weight * score;
+    // the Posterior LatticeForwardBackwardMpeVariants returns: (tid, posterior) per frame, merged (:914-916)
+    Posterior tid_post(num_frames);
+    for (int s = 0; s < num_states; s++)
+      for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
+        if (arc_ilabel[a] != 0) tid_post[times[s]].push_back(std::make_pair(arc_ilabel[a], arc_post[a]));
+    for (int t = 0; t < num_frames; t++) MergePairVectorSumming(&tid_post[t]);
+    ConvertPosteriorToPdfs(tid2pdf, tid_post, &post);
+  }
+  ScalePosterior(weight, &post);  // :283
+  double tot_num_post = 0.0;
+  std::vector<int32_t> rows, cols;
+  std::vector<float> wts;
+  for (size_t t = 0; t < post.size(); t++)
+    for (size_t i = 0; i < post[t].size(); i++) {
+      const float wgt = post[t][i].second;
+      if (wgt > 0.0) tot_num_post += wgt;
+      rows.push_back(static_cast<int32_t>(t));
+      cols.push_back(post[t][i].first);
+      wts.push_back(wgt);
+    }
+  stats[2] += tot_num_post;
+  float tot_objf, tot_weight;
+  ko_comp_objf_and_deriv(static_cast<int>(rows.size()), rows.data(), cols.data(), wts.data(), posteriors, post_stride, deriv,
+                         deriv_stride, &tot_objf, &tot_weight);
+  return 0;
+}

@@ -275,3 +275,37 @@ def test_mmi_matches_path_enumeration(seed, convert, cancel, drop):
             g = [(i, v) for i, v in g if abs(v) > 1e-6]
         assert [i for i, _ in g] == [i for i, _ in w], (g, w)
         assert np.allclose([v for _, v in g], [v for _, v in w], atol=2e-6)
+
+
+def test_discriminative_lattice_computations_mmi_by_enumeration():
+    """Pins ko_discriminative_lattice_computations (nnet-compute-discriminative.cc:178-321, MMI)
+    against its definition on a small lattice: pseudo log-likelihoods into the arcs, denominator
+    posteriors by path enumeration, deriv[t, pdf] = weight x posterior / output[t, pdf]."""
+    rng = np.random.default_rng(321)
+    L = random_lattice(rng, n_frames=5, width=3)
+    n_pdf, T = 8, 5
+    tid2pdf = np.concatenate([[0], rng.integers(0, n_pdf, 50)]).astype(np.int32)
+    post = rng.dirichlet(np.ones(n_pdf), T).astype(np.float32)
+    priors = rng.dirichlet(np.ones(n_pdf) * 5).astype(np.float32)
+    times = B.lattice_forward_backward(L)["state_times"]
+    src = np.repeat(np.arange(L["n_states"]), np.diff(L["arc_offsets"]))
+    ali = [int(rng.choice(L["arc_ilabel"][(times[src] == t) & (L["arc_ilabel"] != 0)])) for t in range(T)]
+    acwt, weight = 0.1, 0.7
+    stats, deriv = B.discriminative_lattice_computations(post, priors, L, tid2pdf, None, [], ali, "mmi", acwt, False, False, weight)
+    # definition
+    L2 = dict(L)
+    ac = np.zeros(len(L["arc_ilabel"]), np.float32)
+    for a in range(len(ac)):
+        if L["arc_ilabel"][a] != 0:
+            pdf = tid2pdf[L["arc_ilabel"][a]]
+            ac[a] = -np.float32(np.log(np.float32(post[times[src[a]], pdf] / priors[pdf])) * np.float32(acwt))
+    L2["arc_acoustic"] = ac
+    want_post, logtot = mmi_by_enumeration(L2, tid2pdf, ali, False, True, True)
+    want = np.zeros((T, n_pdf))
+    for t, fr in enumerate(want_post):
+        for pdf, w in fr:
+            want[t, pdf] += weight * w / post[t, pdf]
+    num = sum(np.log(post[t, tid2pdf[ali[t]]] / priors[tid2pdf[ali[t]]]) * acwt for t in range(T))
+    assert np.allclose(stats, [T, T * weight, weight * sum(max(w, 0) for fr in want_post for _, w in fr), weight * num, weight * logtot],
+                       rtol=1e-5, atol=1e-5)
+    assert np.abs(deriv - want).max() < 1e-4 * np.abs(want).max()
