@@ -1193,14 +1193,12 @@ def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="s
         # denominator: -posterior per (frame, transition-id) merged, then per pdf; numerator +1; cancel
         dr, dc, dw = _merge_keyed(arc_row, il[em].astype(np.int64), arc_post[em])          # MergePairVectorSumming by tid
         dr, dc, dw = _merge_keyed(dr, t2p[dc].astype(np.int64), -dw)                      # ScalePosterior(-1), ConvertPosteriorToPdfs
-        den_keys = set(zip(dr.tolist(), dc.tolist())) if drop_frames else None
         r, c, w = _merge_keyed(np.concatenate([ali_row, dr]), np.concatenate([ali_pdf.astype(np.int64), dc]),
                                np.concatenate([np.ones(len(ali), np.float32), dw]))
         if drop_frames:   # frames whose numerator pdf is not in the denominator are emptied (MergePosteriors :266-270)
-            disjoint = np.array([(int(t), int(p)) not in den_keys for t, p in zip(ali_row, ali_pdf)])
-            w = w[~disjoint[r]]
-            c = c[~disjoint[r]]
-            r = r[~disjoint[r]]
+            disjoint = ~np.isin(ali_row.astype(np.int64) * num_pdfs + ali_pdf, dr.astype(np.int64) * num_pdfs + dc)
+            keep = ~disjoint[r]
+            r, c, w = r[keep], c[keep], w[keep]
     else:
         if tid2phone is None:
             raise KhError("sMBR / MPFE need the transition-id -> phone map")

@@ -43,3 +43,48 @@ def reduce_decode_totals(frames, tot_like, num_success, num_fail, elapsed, devic
                 # "real-time factor assuming 100 frames/sec" nnet-latgen-faster.cc:179-182
                 rtf=el * 100.0 / frames_t if frames_t > 0 else float("nan"),
                 loglike_per_frame=like_t / frames_t if frames_t > 0 else float("nan"))
+
+
+DISCRIMINATIVE_STATS = ("tot_t", "tot_t_weighted", "tot_num_count", "tot_num_objf", "tot_den_objf")
+
+
+def reduce_discriminative(stats, grads=None, bucket_bytes=256 << 20, group=None):
+    """Config 5 (nnet-train-discriminative / nnet-combine over $nj jobs): every rank runs
+    NnetDiscriminativeUpdate on its shard of the examples; what is combined is the five doubles
+    of NnetDiscriminativeStats (NnetDiscriminativeStats::Add, nnet-compute-discriminative.h:70-83)
+    and, when gradients are accumulated (nnet_to_update with SetZero(true), :87-90), the
+    parameter gradients - ~43 MB for nnet_a.  One all-reduce (RCCL over xGMI on GPUs, gloo in
+    the CPU tests) for the stats and one per bucket of gradient tensors: xGMI rings are
+    per-link bound (~153 GB/s), so the tensors are packed into few large buckets
+    (default 256 MB: the whole nnet_a gradient is one message) instead of one call per layer.
+    `grads`: list of tensors, reduced in place.  Returns the summed stats dict."""
+    dev = grads[0].device if grads else "cpu"
+    vec = torch.tensor([float(stats[k]) for k in DISCRIMINATIVE_STATS], dtype=torch.float64, device=dev)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+        if grads:
+            bucket, size = [], 0
+            def flush():
+                if not bucket:
+                    return
+                flat = torch.cat([g.reshape(-1) for g in bucket])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+                o = 0
+                for g in bucket:
+                    g.copy_(flat[o:o + g.numel()].view_as(g))
+                    o += g.numel()
+            for g in grads:
+                nb = g.numel() * g.element_size()
+                if bucket and size + nb > bucket_bytes:
+                    flush()
+                    bucket, size = [], 0
+                bucket.append(g)
+                size += nb
+            flush()
+    out = {k: float(v) for k, v in zip(DISCRIMINATIVE_STATS, vec.tolist())}
+    # what NnetDiscriminativeStats::Print reports (nnet-compute-discriminative.cc:372-391)
+    if out["tot_t_weighted"] > 0:
+        out["objf_per_frame"] = (out["tot_num_objf"] - out["tot_den_objf"]) / out["tot_t_weighted"] \
+            if out["tot_num_objf"] != 0.0 else out["tot_den_objf"] / out["tot_t_weighted"]
+    return out

@@ -161,3 +161,42 @@ def test_mmi_posteriors(api):
         for t, ent in enumerate(o["post"]):
             in_den = int(ali[t]) in {i for i, _ in r["post"][t]}
             assert (len(ent) > 0) == in_den or (in_den and len(ent) == 0 and len(r["post"][t]) == 1)
+
+
+def test_config5_sized_lattices(api):
+    """BASELINE config 5 sizes: denominator lattices of 5 k - 50 k states (raw lattices of
+    long utterances decoded on the HCLG-structured graph, time-synchronous, ~1.6 arcs per state):
+    forward-backward, alpha/beta and the sMBR variant against the oracle."""
+    import torch
+    rng = np.random.default_rng(77)
+    P = 500
+    g = workloads.make_hclg_structured(rng, 300_000, P)
+    lens = [1500, 700]
+    seqs = workloads.sample_paths(rng, g, lens)
+    lls = []
+    for q in seqs:
+        x = (rng.standard_normal((len(q), P)) * 0.28 - 0.37).astype(np.float32)
+        x[np.arange(len(q)), q] = (0.45 + 0.3 * rng.standard_normal(len(q))).astype(np.float32)
+        lls.append(x)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    dec = api.LatticeFasterDecoder(api.Fst(g), api.decoder_config(beam=14.0, max_active=7000, lattice_beam=9.0),
+                                   max_batch=2, max_frames=max(lens))
+    dec.decode(torch.from_numpy(np.concatenate(lls)).cuda(), off)
+    lats = [api.lattice_to_csr(dec.get_raw_lattice(u)) for u in range(2)]
+    assert 5000 <= min(L["n_states"] for L in lats) and max(L["n_states"] for L in lats) <= 200000, [L["n_states"] for L in lats]
+    alis = [dec.get_best_path(u)["alignment"].astype(np.int32) for u in range(2)]
+    ntid = len(g["tid2pdf"]) - 1
+    t2ph = np.concatenate([[0], 1 + (np.arange(ntid) // 6) % 30]).astype(np.int32)
+    fb = api.lattice_forward_backward(lats)
+    ab = api.lattice_alphas_betas(lats)
+    mpe = api.lattice_forward_backward_mpe(lats, t2ph, g["tid2pdf"], [1, 2], alis, "smbr", False)
+    for L, ali, r, q, m in zip(lats, alis, fb, ab, mpe):
+        want = B.lattice_forward_backward(L)
+        assert abs(r["tot_like"] - want["tot_like"]) < 1e-8 * max(1.0, abs(want["tot_like"]))
+        assert np.abs(r["arc_post"] - want["arc_post"]).max() < 1e-5
+        assert np.array_equal(r["state_times"], want["state_times"])
+        wab = B.lattice_alphas_betas(L)
+        assert np.allclose(q["alpha"], wab["alpha"], rtol=1e-11, atol=1e-8) and np.allclose(q["beta"], wab["beta"], rtol=1e-11, atol=1e-8)
+        wm = B.lattice_forward_backward_mpe(L, t2ph, g["tid2pdf"], [1, 2], ali, "smbr", False)
+        assert abs(m["tot_forward_score"] - wm["tot_forward_score"]) < 1e-7 * max(1.0, abs(wm["tot_forward_score"]))
+        assert np.abs(m["arc_post"] - wm["arc_post"]).max() < 1e-5

@@ -62,3 +62,40 @@ def test_two_rank_reduction_over_gloo():
 def test_single_process_without_group():
     out = sharding.reduce_decode_totals(1000, -3000.0, 4, 0, 0.5)
     assert out["frames_per_sec"] == 2000.0 and out["rtf"] == 0.05
+
+
+def _disc_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stats = dict(tot_t=100.0 * (rank + 1), tot_t_weighted=50.0 * (rank + 1), tot_num_count=3.0 + rank,
+                 tot_num_objf=-7.0 * (rank + 1), tot_den_objf=-9.0 * (rank + 1))
+    grads = [torch.full((5, 3), float(rank + 1)), torch.full((11,), 10.0 * (rank + 1)), torch.full((2, 2), -1.0)]
+    out = sharding.reduce_discriminative(stats, grads, bucket_bytes=64)   # tiny buckets: several all-reduces
+    q.put((rank, out, [g.clone() for g in grads]))
+    dist.destroy_process_group()
+
+
+def test_discriminative_stats_and_gradients_over_gloo():
+    """Config 5: NnetDiscriminativeStats::Add + the gradient sum across ranks (bucketed all-reduce)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_disc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, grads in res:
+        assert out["tot_t"] == 300.0 and out["tot_t_weighted"] == 150.0 and out["tot_num_count"] == 7.0
+        assert out["tot_num_objf"] == -21.0 and out["tot_den_objf"] == -27.0
+        assert abs(out["objf_per_frame"] - (-21.0 + 27.0) / 150.0) < 1e-12
+        assert torch.all(grads[0] == 3.0) and torch.all(grads[1] == 30.0) and torch.all(grads[2] == -2.0)
+    # single process: identity
+    out = sharding.reduce_discriminative(dict(tot_t=1, tot_t_weighted=1, tot_num_count=0, tot_num_objf=0, tot_den_objf=-2.0))
+    assert out["tot_den_objf"] == -2.0 and out["objf_per_frame"] == -2.0

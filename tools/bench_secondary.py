@@ -63,9 +63,14 @@ def nnet_cfg3(api, torch, T=120_000):
 
 
 def lattice_fb_cfg5(api, torch, N=256, T=400):
-    """Config 5 (egs/swbd MMI): denominator lattices of N utterances (raw lattices of a
-    structured-graph decode) -> LatticeForwardBackward, the sMBR variant and the MMI
-    posteriors, batch calls (host preparation and posterior merging included)."""
+    """Config 5 (egs/swbd MMI / sMBR): denominator lattices of N utterances (raw lattices of a
+    structured-graph decode).  (a) kh_lattice_forward_backward alone: upload, device
+    preparation (levels, incoming-arc CSR, validation), sweeps, download;  (b) the whole
+    NnetDiscriminativeUpdater::Propagate + LatticeComputations pipeline
+    (nnet-compute-discriminative.cc:150-321) per criterion: forward of a wsj-sized p-norm
+    network, Lookup, lattice rescoring, forward-backward, posterior merging, CompObjfAndDeriv."""
+    import ctypes as C
+    capi = importlib.import_module(PKG + ".capi")
     W = importlib.import_module(PKG + ".workloads")
     rng = np.random.default_rng(5)
     P = 2000
@@ -80,20 +85,42 @@ def lattice_fb_cfg5(api, torch, N=256, T=400):
     cfg = api.decoder_config(beam=13.0, max_active=7000, min_active=200, lattice_beam=8.0)
     dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=N, max_frames=T)
     dec.decode(flat, (np.arange(N + 1) * T).astype(np.int32))
-    dec.prepare()
     lats = [api.lattice_to_csr(dec.get_raw_lattice(u)) for u in range(N)]
     arcs = sum(len(L["arc_ilabel"]) for L in lats)
     states = sum(L["n_states"] for L in lats)
-    alis = [dec.get_best_path(u)["alignment"] for u in range(N)]
+    alis = [dec.get_best_path(u)["alignment"].astype(np.int32) for u in range(N)]
+    del dec, flat
     ntid = len(g["tid2pdf"]) - 1
     t2ph = np.concatenate([[0], 1 + (np.arange(ntid) // 6) % 40]).astype(np.int32)
     res = {"workload": "%d lattices x %d frames (structured graph, lattice-beam 8): %d states, %d arcs (%.1f arcs/frame)"
                        % (N, T, states, arcs, arcs / (N * T))}
-    for name, fn in (("forward_backward", lambda: api.lattice_forward_backward(lats)),
-                     ("smbr", lambda: api.lattice_forward_backward_mpe(lats, t2ph, g["tid2pdf"], [1, 2], alis, "smbr", True)),
-                     ("mmi", lambda: api.lattice_forward_backward_mmi(lats, g["tid2pdf"], alis, True, True, True))):
-        dt = _timeit(fn, lambda: None, reps=2)
-        res[name] = {"ms_per_batch": dt * 1e3, "arcs_per_s": arcs / dt, "frames_per_s": N * T / dt}
+    # (a) the C call alone
+    n, soff, aoff, il, ns, gg, aa, fin = api._cat_lattices(lats)
+    post = np.empty(len(il), np.float32)
+    tot, ac = np.empty(n), np.empty(n)
+    ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
+
+    def call():
+        api.check(api.lib().kh_lattice_forward_backward(
+            n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
+            gg.ctypes.data_as(fp), aa.ctypes.data_as(fp), fin.ctypes.data_as(fp), post.ctypes.data_as(fp),
+            tot.ctypes.data_as(dp), ac.ctypes.data_as(dp), None))
+    dt = _timeit(call, lambda: None, reps=3)
+    res["kh_lattice_forward_backward"] = {"ms_per_batch": dt * 1e3, "arcs_per_s": arcs / dt,
+                                          "algorithmic_bytes": arcs * 32 * 2, "frames_per_s": N * T / dt}
+    # (b) the discriminative pipeline
+    net, _ = W.make_pnorm_net(rng, feat_dim=40, splice=4, const_dim=0, pnorm_in=2000, pnorm_out=400, n_hidden=4,
+                              n_mix=2 * P, n_pdf=P, final_scale=4.0)
+    priors = np.full(P, 1.0 / P, np.float32)
+    nnet = api.Nnet(net, priors)
+    Lc, Rc = nnet.left_context(), nnet.right_context()
+    egs = [dict(feats=torch.from_numpy(rng.standard_normal((T + Lc + Rc, 40)).astype(np.float32)).cuda(), num_ali=alis[u],
+                den_lat=lats[u], weight=1.0) for u in range(N)]
+    for crit in ("mmi", "smbr"):
+        fn = lambda: api.discriminative_lattice_computations(nnet, priors, g["tid2pdf"], egs, criterion=crit, acoustic_scale=0.1,
+                                                             drop_frames=True, tid2phone=t2ph, silence_phones=[1, 2])
+        dt = _timeit(fn, lambda: torch.cuda.synchronize(), reps=2)
+        res["pipeline_" + crit] = {"ms_per_batch": dt * 1e3, "frames_per_s": N * T / dt, "arcs_per_s": arcs / dt}
     return res
 
 

@@ -1,0 +1,32 @@
+#!/bin/bash
+# PMC passes for the forward-pass kernels and the fused GMM kernel (MFMA utilisation, VALU, LDS
+# conflicts, HBM traffic); run on the GPU box:  tools/pmc_kernels.sh OUTDIR
+out=${1:-gpurun_out/pmc_kernels}
+mkdir -p "$out"
+export TMPDIR=/tmp
+pass() {  # name, program..., -- counters
+  name=$1; shift
+  prog=()
+  while [ "$1" != "--" ]; do prog+=("$1"); shift; done
+  shift
+  timeout -k 10 ${PMC_TIMEOUT:-400} rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- "${prog[@]}" > "$out/$name.log" 2>&1
+  f=$(find "$out/$name" -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then
+    for k in GemmKernel SoftmaxSumGroupKernel GroupPnorm2RowKernel GmmFusedPdfKernel DecodeKernel; do
+      python3 tools/pmc_summarize.py "$f" $k | sed "s/^/$k,/" >> "$out/$name.summary.txt"
+    done
+  fi
+  rm -rf "$out/$name"
+}
+B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary"
+G="python3 tools/bench_gmm.py"
+pass mfma_bench $B -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
+pass lds_bench $B -- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
+pass fetch_bench $B -- FETCH_SIZE
+pass write_bench $B -- WRITE_SIZE
+pass grbm_bench $B -- GRBM_GUI_ACTIVE
+pass mfma_gmm $G -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU
+pass lds_gmm $G -- SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+pass fetch_gmm $G -- FETCH_SIZE
+pass write_gmm $G -- WRITE_SIZE
+cat "$out"/*.summary.txt
