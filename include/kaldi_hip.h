@@ -475,6 +475,33 @@ int kh_comp_objf_and_deriv(int n, const int32_t *rows, const int32_t *cols, cons
                            const float *output, KhMatrixDim d_output, float *deriv, KhMatrixDim d_deriv,
                            float *tot_objf, float *tot_weight);
 
+/* ------------------------------------------------------------------ f2
+ * DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1497-1519, called by
+ * DecodeUtteranceLatticeFaster, decoder/decoder-wrappers.cc:264-274): the raw state-level
+ * lattice (arrays as kh_decoder_get_raw_lattice returns them: state 0 = start, arcs with
+ * ilabel = transition-id, olabel = word, weight (graph, acoustic); state_final = +inf for
+ * non-final states, else the final graph cost) -> a CompactLattice deterministic on words
+ * (acceptor: ilabel = olabel = word; weight = (graph, acoustic) + transition-id string), pruned
+ * to `beam` (LatticeFasterDecoderConfig::lattice_beam).  delta / max_mem:
+ * DeterminizeLatticePhonePrunedOptions (determinize-lattice-pruned.h:145-162; defaults
+ * kDelta = 2^-10, 50000000; max_mem <= 0: unlimited).  Host code (as in the reference).
+ * Returns NULL on bad arguments.  `complete` = 0 when the determinization stopped at the
+ * memory limit ("Determinization finished earlier than the beam", decoder-wrappers.cc:272). */
+typedef struct KhCompactLattice KhCompactLattice;
+KhCompactLattice *kh_determinize_lattice_pruned(int n_states, int n_arcs, const int32_t *arc_src, const int32_t *arc_dst,
+                                                const int32_t *arc_ilabel, const int32_t *arc_olabel,
+                                                const float *arc_graph, const float *arc_acoustic,
+                                                const float *state_final, double beam, float delta, int max_mem);
+int kh_compact_lattice_sizes(const KhCompactLattice *clat, int32_t *n_states, int32_t *n_arcs,
+                             int32_t *n_arc_string_labels, int32_t *n_final_string_labels, int32_t *complete);
+/* arcs sorted by source state; arc_string_offsets has n_arcs + 1 entries, final_string_offsets
+ * n_states + 1; final_graph / final_acoustic = +inf for non-final states.  NULL skips an array. */
+int kh_compact_lattice_get(const KhCompactLattice *clat, int32_t *arc_src, int32_t *arc_dst, int32_t *arc_label,
+                           float *arc_graph, float *arc_acoustic, int32_t *arc_string_offsets, int32_t *arc_strings,
+                           float *final_graph, float *final_acoustic, int32_t *final_string_offsets,
+                           int32_t *final_strings);
+void kh_compact_lattice_free(KhCompactLattice *clat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1237,3 +1237,56 @@ def lattice_forward_backward_mpe_raw(lats, tid2phone, tid2pdf, silence_phones, n
         ali_off.ctypes.data_as(ip), int(criterion == "mpfe"), int(bool(one_silence_class)), post.ctypes.data_as(fp),
         score.ctypes.data_as(dp), None))
     return dict(arc_post=post, tot_forward_score=score)
+
+
+# ---------------------------------------------------------------- lattice determinization
+def determinize_lattice_pruned(L, beam, delta=2.0 ** -10, max_mem=50000000):
+    """DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1497-1519; call
+    site decoder/decoder-wrappers.cc:264-274) on a raw lattice (get_raw_lattice layout).
+    Returns the CompactLattice as a dict: n_states (state 0 = start), arcs sorted by source
+    (arc_src, arc_dst, arc_label = word, arc_g, arc_a, arc_string = list of int32 arrays of
+    transition-ids), final_g / final_a (+inf for non-final states), final_string, complete
+    (False: "Determinization finished earlier than the beam").  Host code, no GPU involved."""
+    ip, fp = capi.c_int32_p, capi.c_float_p
+    src = np.ascontiguousarray(L["arc_src"], np.int32)
+    dst = np.ascontiguousarray(L["arc_dst"], np.int32)
+    il = np.ascontiguousarray(L["arc_il"], np.int32)
+    ol = np.ascontiguousarray(L["arc_ol"], np.int32)
+    g = np.ascontiguousarray(L["arc_g"], np.float32)
+    a = np.ascontiguousarray(L["arc_a"], np.float32)
+    fin = np.ascontiguousarray(L["state_final"], np.float32)
+    h = lib().kh_determinize_lattice_pruned(len(fin), len(src), src.ctypes.data_as(ip), dst.ctypes.data_as(ip),
+                                            il.ctypes.data_as(ip), ol.ctypes.data_as(ip), g.ctypes.data_as(fp),
+                                            a.ctypes.data_as(fp), fin.ctypes.data_as(fp), float(beam), float(delta), int(max_mem))
+    if not h:
+        raise KhError(lib().kh_last_error().decode())
+    h = C.c_void_p(h)
+    try:
+        n, m, ns_, nf_, comp = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().kh_compact_lattice_sizes(h, C.byref(n), C.byref(m), C.byref(ns_), C.byref(nf_), C.byref(comp)))
+        n, m = n.value, m.value
+        out = dict(n_states=n, arc_src=np.empty(m, np.int32), arc_dst=np.empty(m, np.int32), arc_label=np.empty(m, np.int32),
+                   arc_g=np.empty(m, np.float32), arc_a=np.empty(m, np.float32), final_g=np.empty(n, np.float32),
+                   final_a=np.empty(n, np.float32), complete=bool(comp.value))
+        aso, fso = np.zeros(m + 1, np.int32), np.zeros(n + 1, np.int32)
+        astr, fstr = np.empty(ns_.value, np.int32), np.empty(nf_.value, np.int32)
+        check(lib().kh_compact_lattice_get(h, out["arc_src"].ctypes.data_as(ip), out["arc_dst"].ctypes.data_as(ip),
+                                           out["arc_label"].ctypes.data_as(ip), out["arc_g"].ctypes.data_as(fp),
+                                           out["arc_a"].ctypes.data_as(fp), aso.ctypes.data_as(ip), astr.ctypes.data_as(ip),
+                                           out["final_g"].ctypes.data_as(fp), out["final_a"].ctypes.data_as(fp),
+                                           fso.ctypes.data_as(ip), fstr.ctypes.data_as(ip)))
+        out["arc_string"] = [astr[aso[j]:aso[j + 1]].copy() for j in range(m)]
+        out["final_string"] = [fstr[fso[s]:fso[s + 1]].copy() for s in range(n)]
+        return out
+    finally:
+        lib().kh_compact_lattice_free(h)
+
+
+def determinize_lattices(lats, beam, delta=2.0 ** -10, max_mem=50000000, num_threads=0):
+    """determinize_lattice_pruned for a batch on host threads (the library call releases the
+    GIL; utterances are independent, as the reference's $nj jobs / TaskSequencer threads)."""
+    import concurrent.futures
+    import os as _os
+    nt = num_threads if num_threads > 0 else min(len(lats), len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else 8)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, nt)) as ex:
+        return list(ex.map(lambda L: determinize_lattice_pruned(L, beam, delta, max_mem), lats))

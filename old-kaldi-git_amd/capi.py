@@ -128,6 +128,10 @@ SIGNATURES = {
     "kh_mfcc_compute": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_float_p, C.c_int, c_int32_p, c_int32_p, c_float_p, C.c_int, c_float_p, c_float_p, vp, C.c_int, c_int32_p]),
     "kh_compute_deltas": (C.c_int, [vp, KhMatrixDim, C.c_int, c_float_p, c_int32_p, vp, C.c_int]),
     "kh_acc_cmvn_stats": (C.c_int, [vp, KhMatrixDim, c_double_p]),
+    "kh_determinize_lattice_pruned": (vp, [C.c_int, C.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, C.c_double, C.c_float, C.c_int]),
+    "kh_compact_lattice_sizes": (C.c_int, [vp, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
+    "kh_compact_lattice_get": (C.c_int, [vp, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
+    "kh_compact_lattice_free": (None, [vp]),
     "kh_lattice_state_times": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p]),
     "kh_lattice_forward_backward": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p, c_int32_p]),
     "kh_lattice_alphas_betas": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, C.c_int, c_double_p, c_double_p, c_double_p]),

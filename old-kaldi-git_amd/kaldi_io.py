@@ -374,6 +374,8 @@ def _read_object(s, binary, kind):
                 break
             line += b
         return np.asarray([int(w) for w in line.split()], np.int32)
+    if kind == "compact_lattice":
+        return read_compact_lattice(s, binary)
     if kind == "lattice":
         return read_lattice(s, binary)
     raise ValueError("unknown table object kind " + kind)
@@ -394,6 +396,8 @@ def _write_object(f, binary, kind, obj):
             f.write(b"".join(b"%d " % int(x) for x in v) + b"\n")
     elif kind == "lattice":
         write_lattice(f, obj, binary)
+    elif kind == "compact_lattice":
+        write_compact_lattice(f, obj, binary)
     else:
         raise ValueError("unknown table object kind " + kind)
 
@@ -1014,6 +1018,130 @@ def read_lattice(s, binary=True):
                 arc_g=A[:, 4].astype(np.float32), arc_a=A[:, 5].astype(np.float32),
                 state_final=np.where(fg == np.inf, np.float32(np.inf), fg + fa).astype(np.float32),
                 state_final_graph=fg, state_final_acoustic=fa)
+
+
+def write_compact_lattice(f, clat, binary=True):
+    """WriteCompactLattice (lat/kaldi-lattice.cc:366-392) of api.determinize_lattice_pruned's dict:
+    binary = VectorFst<CompactLatticeArc>::Write, arc type "compactlattice44", weight =
+    LatticeWeight (two floats) + int32 string length + int32 transition-ids
+    (fstext/lattice-weight.h:503-511); text = FstPrinter lines "src dst word word g,a,t1_t2_..."
+    (acceptor: one label column; weight omitted when it is One), fstext/lattice-weight.h:676-686.
+    PARITY UNPINNED (OpenFst absent): round trip + hand-assembled known answers."""
+    n = int(clat["n_states"])
+    src = np.asarray(clat["arc_src"], np.int64)
+    order = np.argsort(src, kind="stable")
+    off = np.concatenate([[0], np.cumsum(np.bincount(src, minlength=n))]).astype(np.int64)
+    inf = np.float32(np.inf)
+    if binary:
+        def fst_str(x):
+            return struct.pack("<i", len(x)) + x
+        props = 0x1 | 0x2
+        f.write(struct.pack("<i", _FST_MAGIC) + fst_str(b"vector") + fst_str(b"compactlattice44") + struct.pack("<ii", 2, 0) +
+                struct.pack("<Qqqq", props, 0 if n else -1, n, len(src)))
+
+        def weight(g, a, string):
+            string = np.asarray(string, np.int32)
+            return struct.pack("<ffi", g, a, len(string)) + string.astype("<i4").tobytes()
+        for st in range(n):
+            if clat["final_g"][st] != inf:
+                f.write(weight(clat["final_g"][st], clat["final_a"][st], clat["final_string"][st]))
+            else:
+                f.write(weight(inf, inf, []))
+            f.write(struct.pack("<q", off[st + 1] - off[st]))
+            for k in order[off[st]:off[st + 1]]:
+                f.write(struct.pack("<ii", clat["arc_label"][k], clat["arc_label"][k]) +
+                        weight(clat["arc_g"][k], clat["arc_a"][k], clat["arc_string"][k]) + struct.pack("<i", clat["arc_dst"][k]))
+        return
+    f.write(b"\n")
+
+    def wstr(g, a, string):
+        return "%s,%s,%s" % (_fst_float(g), _fst_float(a), "_".join(str(int(x)) for x in string))
+    for st in range(n):
+        for k in order[off[st]:off[st + 1]]:
+            line = "%d\t%d\t%d" % (st, clat["arc_dst"][k], clat["arc_label"][k])
+            if not (clat["arc_g"][k] == 0.0 and clat["arc_a"][k] == 0.0 and len(clat["arc_string"][k]) == 0):
+                line += "\t" + wstr(clat["arc_g"][k], clat["arc_a"][k], clat["arc_string"][k])
+            f.write(line.encode() + b"\n")
+        if clat["final_g"][st] != inf:
+            one = clat["final_g"][st] == 0.0 and clat["final_a"][st] == 0.0 and len(clat["final_string"][st]) == 0
+            f.write(("%d" % st if one else "%d\t%s" % (st, wstr(clat["final_g"][st], clat["final_a"][st], clat["final_string"][st]))).encode() + b"\n")
+    f.write(b"\n")
+
+
+def read_compact_lattice(s, binary=True):
+    """ReadCompactLattice (lat/kaldi-lattice.cc:330-364) into api.determinize_lattice_pruned's layout."""
+    s = _as_stream(s)
+    if binary:
+        h = {}
+        magic, = struct.unpack("<i", s.get(4))
+        if magic != _FST_MAGIC:
+            raise ValueError("not an OpenFst file")
+        def rstr():
+            n, = struct.unpack("<i", s.get(4))
+            return s.get(n)
+        fsttype, arctype = rstr(), rstr()
+        if fsttype != b"vector" or arctype != b"compactlattice44":
+            raise ValueError("not a compact lattice: %r %r" % (fsttype, arctype))
+        version, flags = struct.unpack("<ii", s.get(8))
+        props, start, n, narcs = struct.unpack("<Qqqq", s.get(32))
+
+        def weight():
+            g, a, k = struct.unpack("<ffi", s.get(12))
+            return g, a, np.frombuffer(s.get(4 * k), "<i4").astype(np.int32)
+        fg, fa, fs = np.empty(n, np.float32), np.empty(n, np.float32), []
+        asrc, adst, alab, ag, aa, astr = [], [], [], [], [], []
+        for st in range(n):
+            g, a, string = weight()
+            fg[st], fa[st] = g, a
+            fs.append(string)
+            k, = struct.unpack("<q", s.get(8))
+            for _ in range(k):
+                il, ol = struct.unpack("<ii", s.get(8))
+                g, a, string = weight()
+                d, = struct.unpack("<i", s.get(4))
+                asrc.append(st); adst.append(d); alab.append(il); ag.append(g); aa.append(a); astr.append(string)
+        return dict(n_states=int(n), arc_src=np.array(asrc, np.int32), arc_dst=np.array(adst, np.int32),
+                    arc_label=np.array(alab, np.int32), arc_g=np.array(ag, np.float32), arc_a=np.array(aa, np.float32),
+                    arc_string=astr, final_g=fg, final_a=fa, final_string=fs, complete=True)
+    arcs, finals, nstates = [], {}, 0
+
+    def weight(tok):
+        parts = tok.split(",")
+        conv = lambda t: float({"Infinity": "inf", "-Infinity": "-inf"}.get(t, t))
+        string = np.array([int(x) for x in parts[2].split("_")] if len(parts) > 2 and parts[2] else [], np.int32)
+        return conv(parts[0]), conv(parts[1]), string
+    first = True
+    while True:
+        line = bytearray()
+        while True:
+            b = s.get() if not s.eof() else b"\n"
+            if b == b"\n":
+                break
+            line += b
+        txt = line.decode().strip()
+        if not txt:
+            if first:
+                first = False
+                continue
+            break
+        first = False
+        col = txt.split()
+        if len(col) >= 3:
+            g, a, string = weight(col[3]) if len(col) > 3 else (0.0, 0.0, np.zeros(0, np.int32))
+            arcs.append((int(col[0]), int(col[1]), int(col[2]), g, a, string))
+            nstates = max(nstates, int(col[0]) + 1, int(col[1]) + 1)
+        else:
+            finals[int(col[0])] = weight(col[1]) if len(col) > 1 else (0.0, 0.0, np.zeros(0, np.int32))
+            nstates = max(nstates, int(col[0]) + 1)
+    fg = np.full(nstates, np.inf, np.float32)
+    fa = np.full(nstates, np.inf, np.float32)
+    fs = [np.zeros(0, np.int32) for _ in range(nstates)]
+    for st, (g, a, string) in finals.items():
+        fg[st], fa[st], fs[st] = g, a, string
+    return dict(n_states=nstates, arc_src=np.array([x[0] for x in arcs], np.int32), arc_dst=np.array([x[1] for x in arcs], np.int32),
+                arc_label=np.array([x[2] for x in arcs], np.int32), arc_g=np.array([x[3] for x in arcs], np.float32),
+                arc_a=np.array([x[4] for x in arcs], np.float32), arc_string=[x[5] for x in arcs], final_g=fg, final_a=fa,
+                final_string=fs, complete=True)
 
 
 def write_fst(f, g):

@@ -46,8 +46,12 @@ def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatc
         for k, m in utts.items():
             w.write(k, m)
         w.write("empty", np.zeros((0, 6), np.float32))
-    opts = ["--beam=9", "--max-active=300", "--lattice-beam=5", "--acoustic-scale=%g" % acwt, "--allow-partial=true"]
+    det_opts = ["--beam=9", "--max-active=300", "--lattice-beam=5", "--acoustic-scale=%g" % acwt, "--allow-partial=true"]
+    opts = det_opts + ["--determinize-lattice=false"]
     assert tool.main(opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark:lat.ark", "ark:words.ark", "ark,t:ali.txt"]) == 0
+    # the binaries' default: determinized CompactLattices (binary and text)
+    assert tool.main(det_opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark:clat.ark"]) == 0
+    assert tool.main(det_opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark,t:clat.txt"]) == 0
     assert tool.main(opts + ["--batch-frames=1", "final.mdl", "HCLG.fst", "scp:feats.scp", "ark,t:lat.txt"]) == 0
     lats = dict(kio.read_ark("lat.ark", kind="lattice"))
     lats_t = dict(kio.read_ark("lat.txt", kind="lattice"))
@@ -75,6 +79,39 @@ def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatc
         # text lattice = the same lattice at 7 significant digits
         assert np.array_equal(lats_t[k]["arc_dst"], got["arc_dst"]) and np.array_equal(lats_t[k]["arc_il"], got["arc_il"])
         np.testing.assert_allclose(lats_t[k]["arc_a"], got["arc_a"], rtol=1e-6, atol=1e-6)
+    # CompactLattices: deterministic on words; the best path carries the decoder's words, its
+    # alignment (one transition-id per frame) and its cost (acoustic part unscaled); the text
+    # form holds the same lattice
+    clats = dict(kio.read_ark("clat.ark", kind="compact_lattice"))
+    clats_t = dict(kio.read_ark("clat.txt", kind="compact_lattice"))
+    assert sorted(clats) == sorted(utts) == sorted(clats_t)
+    for k, x in utts.items():
+        Cl, Ct = clats[k], clats_t[k]
+        assert len(set(zip(Cl["arc_src"].tolist(), Cl["arc_label"].tolist()))) == len(Cl["arc_src"])
+        assert Cl["n_states"] == Ct["n_states"] and np.array_equal(Cl["arc_dst"], Ct["arc_dst"])
+        assert all(np.array_equal(p, q) for p, q in zip(Cl["arc_string"], Ct["arc_string"]))
+        np.testing.assert_allclose(Cl["arc_a"], Ct["arc_a"], rtol=1e-6, atol=1e-5)
+        n = Cl["n_states"]
+        dist, back = np.full(n, np.inf), {}
+        dist[0] = 0.0
+        changed = True
+        while changed:
+            changed = False
+            for j in range(len(Cl["arc_src"])):
+                c = dist[Cl["arc_src"][j]] + Cl["arc_g"][j] + Cl["arc_a"][j] * acwt
+                if c < dist[Cl["arc_dst"][j]] - 1e-9:
+                    dist[Cl["arc_dst"][j]] = c
+                    back[int(Cl["arc_dst"][j])] = j
+                    changed = True
+        c, st = min((dist[q] + Cl["final_g"][q] + Cl["final_a"][q] * acwt, q) for q in range(n) if np.isfinite(Cl["final_g"][q]))
+        w, tids = [], list(Cl["final_string"][st])
+        while st != 0:
+            j = back[st]
+            w.append(int(Cl["arc_label"][j]))
+            tids = list(Cl["arc_string"][j]) + tids
+            st = int(Cl["arc_src"][j])
+        assert w[::-1] == words[k].tolist()
+        assert len(tids) == len(x)
 
 
 def test_gmm_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch):
@@ -106,7 +143,8 @@ def test_gmm_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch
     with kio.TableWriter("feats.ark") as w:
         for k, m in utts.items():
             w.write(k, m)
-    opts = ["--beam=10", "--max-active=200", "--lattice-beam=6", "--acoustic-scale=%g" % acwt, "--allow-partial=true"]
+    opts = ["--beam=10", "--max-active=200", "--lattice-beam=6", "--acoustic-scale=%g" % acwt, "--allow-partial=true",
+            "--determinize-lattice=false"]
     assert tool.main(opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark:lat.ark", "ark,t:words.txt"]) == 0
     lats = dict(kio.read_ark("lat.ark", kind="lattice"))
     words = dict(kio.read_ark("words.txt", kind="int32_vector"))

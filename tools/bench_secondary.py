@@ -85,7 +85,8 @@ def lattice_fb_cfg5(api, torch, N=256, T=400):
     cfg = api.decoder_config(beam=13.0, max_active=7000, min_active=200, lattice_beam=8.0)
     dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=N, max_frames=T)
     dec.decode(flat, (np.arange(N + 1) * T).astype(np.int32))
-    lats = [api.lattice_to_csr(dec.get_raw_lattice(u)) for u in range(N)]
+    raw = [dec.get_raw_lattice(u) for u in range(N)]
+    lats = [api.lattice_to_csr(L) for L in raw]
     arcs = sum(len(L["arc_ilabel"]) for L in lats)
     states = sum(L["n_states"] for L in lats)
     alis = [dec.get_best_path(u)["alignment"].astype(np.int32) for u in range(N)]
@@ -94,6 +95,14 @@ def lattice_fb_cfg5(api, torch, N=256, T=400):
     t2ph = np.concatenate([[0], 1 + (np.arange(ntid) // 6) % 40]).astype(np.int32)
     res = {"workload": "%d lattices x %d frames (structured graph, lattice-beam 8): %d states, %d arcs (%.1f arcs/frame)"
                        % (N, T, states, arcs, arcs / (N * T))}
+    # (0) the step right behind the decoder: DeterminizeLatticePhonePrunedWrapper (decoder-wrappers.cc:264-274), host threads
+    t0 = time.perf_counter()
+    clats = api.determinize_lattices(raw, 8.0)
+    dt = time.perf_counter() - t0
+    res["determinize"] = {"ms_per_batch": dt * 1e3, "frames_per_s": N * T / dt, "raw_arcs": arcs,
+                          "compact_arcs": int(sum(len(c["arc_src"]) for c in clats)),
+                          "complete": int(sum(1 for c in clats if c["complete"])), "where": "host threads (as the reference)"}
+    del raw, clats
     # (a) the C call alone
     n, soff, aoff, il, ns, gg, aa, fin = api._cat_lattices(lats)
     post = np.empty(len(il), np.float32)

@@ -10,8 +10,9 @@ over the library, reading and writing the reference's own file formats
   <model-in>              final.mdl (TransitionModel + AmNnet | AmDiagGmm), binary or text
   <fst-in>                HCLG.fst (OpenFst vector or const, StdArc)
   <features-rspecifier>   ark:FILE | scp:FILE
-  <lattice-wspecifier>    ark:FILE | ark,t:FILE   state-level lattices, i.e. the binary's
-                          --determinize-lattice=false output (determinization is SURVEY §8f row 2)
+  <lattice-wspecifier>    ark:FILE | ark,t:FILE   CompactLattices (--determinize-lattice=true, the
+                          binaries' default: DeterminizeLatticePhonePrunedWrapper, decoder-wrappers.cc:264-274,
+                          on host threads) or state-level lattices (--determinize-lattice=false)
   words / alignments      ark:FILE | ark,t:FILE   Int32Vector tables
 
 Differences from the binary: utterances are decoded in batches (--batch-frames) — one
@@ -51,6 +52,10 @@ def main(argv=None, kind="nnet2"):
     ap.add_argument("--hash-ratio", type=float, default=2.0)
     ap.add_argument("--acoustic-scale", type=float, default=0.1)
     ap.add_argument("--allow-partial", type=lambda s: s.lower() in ("true", "1", "t"), default=False)
+    ap.add_argument("--determinize-lattice", type=lambda s: s.lower() in ("true", "1", "t"), default=True,
+                    help="If true, determinize the lattice (lattice-determinization, keeping only best pdf-sequence for each word-sequence).")
+    ap.add_argument("--delta", type=float, default=2.0 ** -10, help="Tolerance used in determinization")
+    ap.add_argument("--max-mem", type=int, default=50000000, help="Maximum approximate memory usage in determinization")
     ap.add_argument("--batch-frames", type=int, default=200000, help="frames per forward / decoder launch")
     ap.add_argument("--gpu", type=int, default=0)
     ap.add_argument("model")
@@ -96,7 +101,7 @@ def main(argv=None, kind="nnet2"):
     kind, path, _ = parse_specifier(a.features, False)
     reader = kio.read_ark(path) if kind == "ark" else kio.read_scp(path)
     _, lat_path, lat_text = parse_specifier(a.lattices, True)
-    lat_w = kio.TableWriter(lat_path, kind="lattice", binary=not lat_text)
+    lat_w = kio.TableWriter(lat_path, kind="compact_lattice" if a.determinize_lattice else "lattice", binary=not lat_text)
     words_w = ali_w = None
     if a.words:
         _, p, t = parse_specifier(a.words, True)
@@ -144,9 +149,19 @@ def main(argv=None, kind="nnet2"):
                 ali_w.write(utt, best["alignment"])
             like = -(best["graph_cost"] + best["acoustic_cost"])
             lat = dec.get_raw_lattice(u)
-            if a.acoustic_scale != 0.0:       # "We'll write the lattice without acoustic scaling." :283-285
-                lat["arc_a"] = (lat["arc_a"] * np.float32(1.0 / a.acoustic_scale)).astype(np.float32)
-            lat_w.write(utt, lat)
+            if a.determinize_lattice:         # decoder-wrappers.cc:264-279
+                clat = api.determinize_lattice_pruned(lat, a.lattice_beam, a.delta, a.max_mem)
+                if not clat["complete"]:
+                    print("WARNING Determinization finished earlier than the beam for utterance %s" % utt, file=sys.stderr)
+                if a.acoustic_scale != 0.0:   # "We'll write the lattice without acoustic scaling."
+                    inv = np.float32(1.0 / a.acoustic_scale)
+                    clat["arc_a"] = (clat["arc_a"] * inv).astype(np.float32)
+                    clat["final_a"] = (clat["final_a"] * inv).astype(np.float32)
+                lat_w.write(utt, clat)
+            else:
+                if a.acoustic_scale != 0.0:   # "We'll write the lattice without acoustic scaling." :283-285
+                    lat["arc_a"] = (lat["arc_a"] * np.float32(1.0 / a.acoustic_scale)).astype(np.float32)
+                lat_w.write(utt, lat)
             print("LOG Log-like per frame for utterance %s is %g over %d frames." % (utt, like / max(num_frames, 1), num_frames),
                   file=sys.stderr)
             tot_like += like
