@@ -101,16 +101,17 @@ struct Strings {
   // determinize-lattice-pruned.cc:611-637: 1 if a is "better": shorter string, then the larger label sequence
   int Compare(int32_t a, int32_t b) const {
     if (a == b) return 0;
-    std::vector<int32_t> va, vb;
-    ToVector(a, &va);
-    ToVector(b, &vb);
-    if (va.size() > vb.size()) return -1;
-    if (va.size() < vb.size()) return 1;
-    for (size_t i = 0; i < va.size(); i++) {
-      if (va[i] < vb[i]) return -1;
-      if (va[i] > vb[i]) return 1;
+    if (nodes[a].depth > nodes[b].depth) return -1;
+    if (nodes[a].depth < nodes[b].depth) return 1;
+    // equal lengths: the first position where they differ is just below their common prefix
+    int32_t la = 0, lb = 0;
+    while (a != b) {
+      la = nodes[a].label;
+      lb = nodes[b].label;
+      a = nodes[a].parent;
+      b = nodes[b].parent;
     }
-    return 0;
+    return la < lb ? -1 : (la > lb ? 1 : 0);
   }
 };
 
@@ -157,16 +158,25 @@ struct Determinizer {
     return c != 0 ? c : strs.Compare(s1, s2);
   }
 
-  // follow the arcs without a word inside the subset (determinize-lattice-pruned.cc:639-748)
+  // follow the arcs without a word inside the subset (determinize-lattice-pruned.cc:639-748).
+  // States are expanded in topological order (a heap on the rank), so each is expanded once,
+  // with its final best (weight, string).
+  std::vector<int32_t> rank;        // topological rank of every lattice state
+  std::vector<int32_t> slot_of;     // scratch: position of a state in the subset being closed, -1
   void EpsilonClosure(std::vector<Elem> *subset) {
-    std::unordered_map<int32_t, size_t> pos;
-    for (size_t i = 0; i < subset->size(); i++) pos[(*subset)[i].state] = i;
-    std::vector<int32_t> work;
-    for (const Elem &e : *subset) work.push_back(e.state);
-    while (!work.empty()) {
-      const int32_t s = work.back();
-      work.pop_back();
-      const Elem e = (*subset)[pos[s]];
+    typedef std::pair<int32_t, int32_t> RS;  // (rank, state)
+    std::priority_queue<RS, std::vector<RS>, std::greater<RS>> heap;
+    for (size_t i = 0; i < subset->size(); i++) {
+      slot_of[(*subset)[i].state] = static_cast<int32_t>(i);
+      heap.push(RS(rank[(*subset)[i].state], (*subset)[i].state));
+    }
+    int32_t last = -1;
+    while (!heap.empty()) {
+      const int32_t s = heap.top().second;
+      heap.pop();
+      if (s == last) continue;  // (pushed once per improvement; expanded once: all improvements precede it)
+      last = s;
+      const Elem e = (*subset)[slot_of[s]];
       for (int64_t k = off[s]; k < off[s + 1]; k++) {
         const int32_t j = order[k];
         if (ol[j] != 0) continue;
@@ -174,17 +184,17 @@ struct Determinizer {
         ne.state = dst[j];
         ne.w = Times(e.w, LW{g[j], a[j]});
         ne.str = il[j] != 0 ? strs.Successor(e.str, il[j]) : e.str;
-        auto it = pos.find(ne.state);
-        if (it == pos.end()) {
-          pos[ne.state] = subset->size();
+        const int32_t at = slot_of[ne.state];
+        if (at < 0) {
+          slot_of[ne.state] = static_cast<int32_t>(subset->size());
           subset->push_back(ne);
-          work.push_back(ne.state);
-        } else if (CompareElem(ne.w, ne.str, (*subset)[it->second].w, (*subset)[it->second].str) == 1) {
-          (*subset)[it->second] = ne;
-          work.push_back(ne.state);
+          heap.push(RS(rank[ne.state], ne.state));
+        } else if (CompareElem(ne.w, ne.str, (*subset)[at].w, (*subset)[at].str) == 1) {
+          (*subset)[at] = ne;  // (its rank is larger than s's: not expanded yet, already in the heap)
         }
       }
     }
+    for (const Elem &e : *subset) slot_of[e.state] = -1;
   }
 
   // divide out the best weight and the longest common string prefix (:793-824)
@@ -321,6 +331,9 @@ struct Determinizer {
         if (--indeg[dst[order[k]]] == 0) topo.push_back(dst[order[k]]);
     }
     if (static_cast<int>(topo.size()) != n) return false;  // cycle
+    rank.assign(n, 0);
+    for (int h = 0; h < n; h++) rank[topo[h]] = h;
+    slot_of.assign(n, -1);
     backward.assign(n, std::numeric_limits<double>::infinity());
     has_word_arc.assign(n, 0);
     for (int h = n - 1; h >= 0; h--) {
