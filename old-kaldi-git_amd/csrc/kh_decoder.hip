@@ -628,10 +628,10 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off,
 // dense.  The reference materialises nothing it rejects either (:731 "continue"); here a
 // candidate is known to be rejected when it is above an upper bound of the frame's final
 // next_cutoff.  Returns the new end of the link arena, or -1 on overflow (sh->status set).
-template <class Eval, class Store>
+template <int kLU, class Load, class Finish, class Store>
 __device__ __forceinline__ int ExpandSweepFiltered(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
-                                                   int frame_cap, long long *arcs, Blk &sh, float *est, float *bound, Eval eval,
-                                                   Store store) {
+                                                   int frame_cap, long long *arcs, Blk &sh, float *est, float *bound, Load load,
+                                                   Finish finish, Store store) {
   const int limit = min(u.link_cap, lrun + frame_cap);
   const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) sh->link_cursor = lrun;  // (visible behind the first group's scan barrier)
@@ -682,29 +682,42 @@ __device__ __forceinline__ int ExpandSweepFiltered(const Utt &u, Arr<const int32
       sh->ex_tok[k * NT + threadIdx.x] = i[k];
     }
     KhSync();
-    for (int q0 = 0; q0 < total; q0 += NT) {  // uniform trip count (wave ballots inside)
-      const int q = q0 + threadIdx.x;
-      bool keep = false;
-      if (q < total) {
-        // owner = the LAST item whose first slot is <= q (items without arcs share their
-        // successor's first slot and are skipped by "last")
-        int lo = 0, hi = EU * NT - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (sh->ex_off[mid] <= q) lo = mid; else hi = mid - 1;
+    for (int q0 = 0; q0 < total; q0 += NT * kLU) {  // uniform trip count (wave ballots inside)
+      // kLU candidates per lane: their arc and cost loads are all issued (load) before the
+      // first dependent step (finish), so that a lane has kLU random fetches in flight
+      bool valid[kLU], keep[kLU];
+#pragma unroll
+      for (int k = 0; k < kLU; k++) {
+        const int q = q0 + k * NT + threadIdx.x;
+        valid[k] = q < total;
+        keep[k] = false;
+        if (valid[k]) {
+          // owner = the LAST item whose first slot is <= q (items without arcs share their
+          // successor's first slot and are skipped by "last")
+          int lo = 0, hi = EU * NT - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sh->ex_off[mid] <= q) lo = mid; else hi = mid - 1;
+          }
+          load(k, sh->ex_tok[lo], sh->ex_ab[lo] + (q - sh->ex_off[lo]));
         }
-        keep = eval(sh->ex_tok[lo], sh->ex_ab[lo] + (q - sh->ex_off[lo]));
       }
-      const unsigned long long kb = __ballot(keep);
-      if (kb != 0ull) {
-        const int n_keep = __popcll(kb);
-        int pos = 0;
-        if (lane == 0) pos = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pos = Uni(pos);
-        if (pos + n_keep > limit) {
-          if (lane == 0) sh->status = (pos + n_keep > u.link_cap) ? 2 : 3;
-        } else if (keep) {
-          store(pos + __popcll(kb & ((1ull << lane) - 1ull)));
+#pragma unroll
+      for (int k = 0; k < kLU; k++)
+        if (valid[k]) keep[k] = finish(k);
+#pragma unroll
+      for (int k = 0; k < kLU; k++) {
+        const unsigned long long kb = __ballot(keep[k]);
+        if (kb != 0ull) {
+          const int n_keep = __popcll(kb);
+          int pos = 0;
+          if (lane == 0) pos = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          pos = Uni(pos);
+          if (pos + n_keep > limit) {
+            if (lane == 0) sh->status = (pos + n_keep > u.link_cap) ? 2 : 3;
+          } else if (keep[k]) {
+            store(k, pos + __popcll(kb & ((1ull << lane) - 1ull)));
+          }
         }
       }
     }
@@ -998,33 +1011,37 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   float bound = est0;  // upper bound of the final next_cutoff; tightens as the sweep proceeds
   const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
-  KhInt4 c_arc;
-  int c_src = 0;
-  float c_ac = 0.f, c_tot = 0.f;
-  const int link_frame_e = ExpandSweepFiltered(
+  constexpr int kLU = 1;  // (2 in flight per lane: no gain, +16 B of scratch per lane)
+  KhInt4 c_arc[kLU];
+  int c_src[kLU];
+  uint32_t c_co[kLU];
+  float c_ac[kLU], c_tot[kLU];
+  const int link_frame_e = ExpandSweepFiltered<kLU>(
       u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
-      [&](int src, int ai) -> bool {
+      [&](int k, int src, int ai) {
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_emit);
-        c_arc = p.e_arcs[ai];
-        c_src = src;
-        const uint32_t co = LoadCostEnc(&u.tok_cost[src]);
-        int32_t pdf = p.tid2pdf ? p.tid2pdf[c_arc.x] : c_arc.x - 1;
+        c_arc[k] = p.e_arcs[ai];
+        c_src[k] = src;
+        c_co[k] = LoadCostEnc(&u.tok_cost[src]);
+      },
+      [&](int k) -> bool {
+        int32_t pdf = p.tid2pdf ? p.tid2pdf[c_arc[k].x] : c_arc[k].x - 1;
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
-        c_ac = cost_offset - like;
-        c_tot = Dec(co) + c_ac + __int_as_float(c_arc.z);  // :726-730
-        est = fminf(est, c_tot + c.adaptive_beam);
-        return !(c_tot > bound);
+        c_ac[k] = cost_offset - like;
+        c_tot[k] = Dec(c_co[k]) + c_ac[k] + __int_as_float(c_arc[k].z);  // :726-730
+        est = fminf(est, c_tot[k] + c.adaptive_beam);
+        return !(c_tot[k] > bound);
       },
-      [&](int l) {
-        u.link_dst[l] = c_arc.w;  // HCLG next state for now; token index after pass 2
-        u.link_src[l] = c_src;
-        u.link_il[l] = c_arc.x;
-        u.link_ol[l] = c_arc.y;
-        u.link_g[l] = __int_as_float(c_arc.z);
-        u.link_a[l] = c_ac;
-        u.link_tot[l - link_frame_b] = c_tot;
+      [&](int k, int l) {
+        u.link_dst[l] = c_arc[k].w;  // HCLG next state for now; token index after pass 2
+        u.link_src[l] = c_src[k];
+        u.link_il[l] = c_arc[k].x;
+        u.link_ol[l] = c_arc[k].y;
+        u.link_g[l] = __int_as_float(c_arc[k].z);
+        u.link_a[l] = c_ac[k];
+        u.link_tot[l - link_frame_b] = c_tot[k];
       });
   if (link_frame_e < 0) return false;
   // final next_cutoff: the value the reference's running cutoff converges to

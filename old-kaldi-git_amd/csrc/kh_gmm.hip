@@ -82,12 +82,17 @@ GmmLoglikesKernel(const float *__restrict__ data, int T, int D, int data_stride,
   }
 }
 
-// log of the double sum of LogSumExp (kaldi-vector.cc:761 "max_elem + Log(sum_relto_max_elem)").
-// The sum lies in [1, #Gaussians of the pdf]; its logarithm is taken in float (error ~2e-7,
-// against the 4e-6 ulp of the float result it is added into) - a double log is ~150 VALU
-// instructions per (frame, pdf) and made the fused kernel VALU-bound (measured: 38 VALU per
-// MFMA instruction, MFMA pipe 18 % busy).
-__device__ __forceinline__ double LogOfSum(double sum) { return static_cast<double>(logf(static_cast<float>(sum))); }
+// The two transcendental steps of LogSumExp (kaldi-vector.cc:755-761: "sum += Exp(f - max)",
+// "max + Log(sum)") on the hardware's exp2 / log2 units: exp(x) = exp2(x * log2 e) and
+// log(s) = log2(s) * ln 2, each within ~2 ulp of a float.  The terms lie in (0, 1], the double
+// sum in [1, #Gaussians of the pdf]; against the 4e-6 ulp of the float result (|score| ~ 50)
+// the error is < 1e-6 - north_star asks 1e-4 on frame log-likelihoods.  The libm versions
+// (expf: ~15 VALU instructions, double log: ~150) made the fused kernel VALU-bound: 38 VALU
+// instructions per MFMA instruction, matrix pipe 18 % busy.
+__device__ __forceinline__ float ExpTerm(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ double LogOfSum(double sum) {
+  return static_cast<double>(__builtin_amdgcn_logf(static_cast<float>(sum)) * 0.69314718055994530942f);
+}
 
 // VectorBase::LogSumExp(prune) kaldi-vector.cc:745-763 per (frame, pdf).
 __global__ void __launch_bounds__(kThreads)
@@ -106,7 +111,7 @@ GmmPdfLseKernel(const float *__restrict__ ll, int T, int ll_stride,
       double sum = 0.0;
       for (int m = s; m < e; m++) {
         const float f = row[m];
-        if (f >= cutoff) sum += static_cast<double>(expf(f - mx));
+        if (f >= cutoff) sum += static_cast<double>(ExpTerm(f - mx));
       }
       out[static_cast<size_t>(t) * out_stride + j] =
           static_cast<float>(static_cast<double>(mx) + LogOfSum(sum));
@@ -135,7 +140,7 @@ GmmPdfLseRowKernel(const float *__restrict__ ll, int T, int ll_stride, int num_m
       double sum = 0.0;
       for (int m = s; m < e; m++) {
         const float f = row[m];
-        if (f >= cutoff) sum += static_cast<double>(expf(f - mx));
+        if (f >= cutoff) sum += static_cast<double>(ExpTerm(f - mx));
       }
       out[static_cast<size_t>(t) * out_stride + j] = static_cast<float>(static_cast<double>(mx) + LogOfSum(sum));
     }
@@ -178,9 +183,14 @@ int LaunchLoglikes(const float *data, KhMatrixDim dd, const float *g,
 // [frame][gaussian], then one lane per (frame, pdf): max, cutoff, double sum of expf, log.
 // Same operations in the same order as kh_diag_gmm_loglikes + GmmPdfLseRowKernel: the
 // results are bit-identical to the unfused path.
+// Measured (200 k frames, cfg 2; phases switched off one at a time): 6.2 ms = matrix cores 2.2 ms
+// (their floor: 2 x 200k x 9000 x 40 MAC at the fp32 MFMA rate) + LogSumExp 2.7 ms + staging /
+// barriers 1.4 ms - the phases of the two resident workgroups of a CU run in lockstep and do
+// not overlap yet (next: MFMA waves and LogSumExp waves as producer / consumer on a double-
+// buffered tile).
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kFT = 64, kGT = 128, kGTP = kGT + 4, kOTP = kGT + 1;
+constexpr int kFT = 64, kGT = 128, kGTP = kGT + 5, kOTP = kGT + 1;  // kGTP odd: the transposing tile stores spread over all banks
 
 struct GmmTile { int32_t m_begin, m_end, pdf_begin, pdf_end; };
 
@@ -193,6 +203,8 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
   __shared__ float Bmi[2 * KS][kGTP];
   __shared__ float Biv[2 * KS][kGTP];
   __shared__ float Bg[kGT];
+  __shared__ int Po[2][kGT + 1];  // the tile's pdf boundaries, relative to its first Gaussian (double buffered: the
+                                  // next tile's are stored while slow waves still read this tile's)
   __shared__ float Ot[kFT][kOTP];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1, kk = lane >> 5, l31 = lane & 31;
@@ -209,23 +221,48 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
       axx[s] = v * v;  // data_sq.ApplyPow(2.0)
     }
   }
-  for (int ti = 0; ti < n_tiles; ti++) {
-    const GmmTile tl = tiles[ti];
+  // The tile's parameters travel global -> registers -> LDS, and the NEXT tile's are loaded
+  // into the registers while this tile computes (the staging loop used to cost ~20 dependent
+  // L2 round trips per tile: 21 us per tile against 2 us of MFMA work).
+  constexpr int kPer = 2 * KS * kGT / 256;   // staged elements per lane and array
+  float rmi[kPer], riv[kPer], rg = 0.f;
+  int rp = 0;
+  auto load_tile = [&](const GmmTile &tl) {
     const int nm = tl.m_end - tl.m_begin;
-    // ---- parameters of the tile -> LDS, transposed to [k][gaussian]; zero padding
-    for (int idx = t; idx < 2 * KS * kGT; idx += 256) {
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int idx = t + j * 256;
       const int m = idx / (2 * KS), k = idx - m * (2 * KS);
-      float a = 0.f, b = 0.f;
-      if (m < nm && k < D) {
-        const size_t o = static_cast<size_t>(tl.m_begin + m) * D + k;
-        a = mi[o];
-        b = iv[o];
-      }
-      Bmi[k][m] = a;
-      Biv[k][m] = b;
+      const bool ok = m < nm && k < D;
+      const size_t o = ok ? static_cast<size_t>(tl.m_begin + m) * D + k : 0;
+      const float a = mi[o], b = iv[o];
+      rmi[j] = ok ? a : 0.f;
+      riv[j] = ok ? b : 0.f;
     }
-    if (t < kGT) Bg[t] = t < nm ? gconsts[tl.m_begin + t] : 0.f;
-    __syncthreads();  // (also: the previous tile's LogSumExp has finished reading Ot)
+    rg = (t < kGT && t < nm) ? gconsts[tl.m_begin + t] : 0.f;
+    rp = (t <= tl.pdf_end - tl.pdf_begin) ? pdf_offsets[tl.pdf_begin + t] - tl.m_begin : 0;
+  };
+  GmmTile tl = tiles[0];
+  load_tile(tl);
+  for (int ti = 0; ti < n_tiles; ti++) {
+    const int nm = tl.m_end - tl.m_begin;
+    (void)nm;
+    // ---- parameters of the tile -> LDS, transposed to [k][gaussian]; zero padding
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int idx = t + j * 256;
+      const int m = idx / (2 * KS), k = idx - m * (2 * KS);
+      Bmi[k][m] = rmi[j];
+      Biv[k][m] = riv[j];
+    }
+    if (t < kGT) Bg[t] = rg;
+    if (t <= kGT) Po[ti & 1][t] = rp;
+    __syncthreads();  // (also: the previous tile's LogSumExp has finished reading Ot and Po)
+    const GmmTile cur = tl;
+    if (ti + 1 < n_tiles) {
+      tl = tiles[ti + 1];
+      load_tile(tl);
+    }
     f32x16 a1[2], a2[2];
 #pragma unroll
     for (int j = 0; j < 2; j++)
@@ -253,23 +290,24 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
       }
     }
     __syncthreads();
-    // ---- LogSumExp per (frame, pdf) of the tile
-    const int np = tl.pdf_end - tl.pdf_begin;
-    for (int idx = t; idx < kFT * np; idx += 256) {
-      const int f = idx / np, pj = idx - f * np;
-      if (t0 + f >= T) continue;
-      const int pdf = tl.pdf_begin + pj;
-      const int sidx = pdf_offsets[pdf] - tl.m_begin, eidx = pdf_offsets[pdf + 1] - tl.m_begin;
+    // ---- LogSumExp per (frame, pdf) of the tile: lane = frame, the waves share the pdfs - the
+    // pdf's Gaussian range is wave-uniform (no divergence, no integer division), the 64 lanes
+    // read 64 different rows of Ot (conflict-free: row pitch 129)
+    const int np = cur.pdf_end - cur.pdf_begin;
+    const bool row_ok = t0 + lane < T;
+    float *orow = out + static_cast<size_t>(t0 + lane) * out_stride + cur.pdf_begin;
+    for (int pj = wave; pj < np; pj += 4) {
+      const int sidx = Po[ti & 1][pj], eidx = Po[ti & 1][pj + 1];
       float mx = -INFINITY;
-      for (int m = sidx; m < eidx; m++) mx = fmaxf(mx, Ot[f][m]);
+      for (int m = sidx; m < eidx; m++) mx = fmaxf(mx, Ot[lane][m]);
       float cutoff = mx + min_log_diff;
       if (prune > 0.0f && mx - prune > cutoff) cutoff = mx - prune;
       double sum = 0.0;
       for (int m = sidx; m < eidx; m++) {
-        const float v = Ot[f][m];
-        if (v >= cutoff) sum += static_cast<double>(expf(v - mx));
+        const float v = Ot[lane][m];
+        if (v >= cutoff) sum += static_cast<double>(ExpTerm(v - mx));
       }
-      out[static_cast<size_t>(t0 + f) * out_stride + pdf] = static_cast<float>(static_cast<double>(mx) + LogOfSum(sum));
+      if (row_ok) orow[pj] = static_cast<float>(static_cast<double>(mx) + LogOfSum(sum));
     }
     // (the next tile's parameter load only touches Bmi / Biv / Bg: no barrier needed here)
   }
