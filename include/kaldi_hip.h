@@ -502,6 +502,42 @@ int kh_compact_lattice_get(const KhCompactLattice *clat, int32_t *arc_src, int32
                            int32_t *final_strings);
 void kh_compact_lattice_free(KhCompactLattice *clat);
 
+/* ------------------------------------------------------------------ f3
+ * OnlineIvectorFeature (online2/online-ivector-feature.{h,cc}) in its deterministic mode: no
+ * silence weighting, use_most_recent_ivector = false, a fresh OnlineIvectorExtractorAdaptationState
+ * per utterance (no speaker CMVN stats).  The configuration is OnlineIvectorExtractionInfo
+ * (online-ivector-feature.h:51-134) with its member models:
+ *   lda_mat [feat_dim x lda_cols] (lda_cols = base_dim * (left + right + 1), + 1 for an offset
+ *   column), global_cmvn_stats [2 x (base_dim + 1)] double (matrix of OnlineCmvn), diag UBM
+ *   (gconsts, means_invvars, inv_vars as kh_diag_gmm_loglikes), IvectorExtractor: M
+ *   [num_gauss][feat_dim][ivector_dim], Sigma_inv [num_gauss][feat_dim][feat_dim], prior_offset —
+ * all HOST arrays, uploaded once; the derived U_i / Sigma_i^-1 M_i
+ * (IvectorExtractor::ComputeDerivedVars, ivector/ivector-extractor.cc:186-217) are computed at
+ * creation.  Returns NULL when OnlineIvectorExtractionInfo::Check (online-ivector-feature.cc:70-87)
+ * would fail or a limit is exceeded (base_dim <= 64, num_gauss <= 2048, num_gselect <= 16,
+ * ivector_dim, feat_dim <= 256). */
+typedef struct KhIvectorConfig {
+  int32_t base_dim, splice_left, splice_right, feat_dim, num_gauss, ivector_dim, lda_cols;
+  int32_t cmn_window, speaker_frames, global_frames, normalize_mean, normalize_variance; /* OnlineCmvnOptions */
+  int32_t ivector_period, num_gselect, num_cg_iters;
+  float min_post, posterior_scale, max_count;
+  double prior_offset;
+} KhIvectorConfig;
+typedef struct KhIvectorExtractor KhIvectorExtractor;
+KhIvectorExtractor *kh_ivector_extractor_create(const KhIvectorConfig *cfg, const float *lda_mat,
+                                                const double *global_cmvn_stats, const float *ubm_gconsts,
+                                                const float *ubm_means_invvars, const float *ubm_inv_vars,
+                                                const double *M, const double *Sigma_inv);
+void kh_ivector_extractor_destroy(KhIvectorExtractor *ext);
+/* OnlineIvectorFeature::GetFrame for every frame of a batch of utterances
+ * (online-ivector-feature.cc:286-299): feats = DEVICE base features, the utterances row-
+ * concatenated, utterance u = rows [utt_row_offsets_host[u], utt_row_offsets_host[u + 1]);
+ * ivectors = DEVICE [rows x ivector_dim]: row t holds the iVector estimated from frames
+ * 0 .. (t / ivector_period) * ivector_period of its utterance, first dimension minus
+ * PriorOffset. */
+int kh_ivector_extract(const KhIvectorExtractor *ext, const float *feats, int feat_stride,
+                       const int32_t *utt_row_offsets_host, int n_utts, float *ivectors, int ivector_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1290,3 +1290,66 @@ def determinize_lattices(lats, beam, delta=2.0 ** -10, max_mem=50000000, num_thr
     nt = num_threads if num_threads > 0 else min(len(lats), len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else 8)
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, nt)) as ex:
         return list(ex.map(lambda L: determinize_lattice_pruned(L, beam, delta, max_mem), lats))
+
+
+# ---------------------------------------------------------------- iVector extraction (f3)
+class OnlineIvectorExtractor:
+    """OnlineIvectorExtractionInfo + OnlineIvectorFeature (online2/online-ivector-feature.h:51-134,
+    :226-330) in the deterministic mode (no silence weighting, use_most_recent_ivector = false, a
+    fresh adaptation state per utterance), batched over utterances.  `info`: lda_mat
+    [feat_dim x (spliced dim (+ 1))], global_cmvn_stats [2 x (base_dim + 1)], splice_left/right,
+    cmn_window / speaker_frames / global_frames / normalize_mean / normalize_variance
+    (OnlineCmvnOptions), the diagonal UBM (ubm_weights, ubm_means, ubm_vars), the IvectorExtractor
+    (M [I x D x S], Sigma_inv [I x D x D], prior_offset) and ivector_period, num_gselect, min_post,
+    posterior_scale, max_count, num_cg_iters (online-ivector-feature.h:102-107)."""
+
+    def __init__(self, info):
+        lda = np.ascontiguousarray(info["lda_mat"], np.float32)
+        gs = np.ascontiguousarray(info["global_cmvn_stats"], np.float64)
+        M = np.ascontiguousarray(info["M"], np.float64)
+        si = np.ascontiguousarray(info["Sigma_inv"], np.float64)
+        inv = (1.0 / np.asarray(info["ubm_vars"], np.float64)).astype(np.float32)
+        mi = (np.asarray(info["ubm_means"], np.float64) / np.asarray(info["ubm_vars"], np.float64)).astype(np.float32)
+        g, bad = gmm_compute_gconsts(info["ubm_weights"], mi, inv)
+        if bad:
+            raise KhError("DiagGmm::ComputeGconsts: %d bad gconsts in the UBM" % bad)
+        cfg = capi.KhIvectorConfig()
+        cfg.base_dim = gs.shape[1] - 1
+        cfg.splice_left, cfg.splice_right = int(info["splice_left"]), int(info["splice_right"])
+        cfg.feat_dim, cfg.lda_cols = lda.shape
+        cfg.num_gauss, _, cfg.ivector_dim = M.shape
+        if M.shape[1] != cfg.feat_dim or si.shape != (cfg.num_gauss, cfg.feat_dim, cfg.feat_dim) or mi.shape != (cfg.num_gauss, cfg.feat_dim):
+            raise KhError("OnlineIvectorExtractionInfo: model dimensions do not match")
+        for k in ("cmn_window", "speaker_frames", "global_frames", "normalize_mean", "normalize_variance",
+                  "ivector_period", "num_gselect", "num_cg_iters"):
+            setattr(cfg, k, int(info[k]))
+        for k in ("min_post", "posterior_scale", "max_count", "prior_offset"):
+            setattr(cfg, k, float(info[k]))
+        self.cfg = cfg
+        fp, dp = capi.c_float_p, capi.c_double_p
+        self._h = lib().kh_ivector_extractor_create(C.byref(cfg), lda.ctypes.data_as(fp), gs.ctypes.data_as(dp),
+                                                    g.ctypes.data_as(fp), mi.ctypes.data_as(fp), inv.ctypes.data_as(fp),
+                                                    M.ctypes.data_as(dp), si.ctypes.data_as(dp))
+        if not self._h:
+            raise KhError(lib().kh_last_error().decode())
+
+    @property
+    def ivector_dim(self):
+        return self.cfg.ivector_dim
+
+    def extract(self, feats, utt_row_offsets, out=None):
+        """OnlineIvectorFeature::GetFrame for every frame: `feats` = device [sum T x base_dim] base
+        features of the utterances row-concatenated -> device [sum T x ivector_dim]."""
+        off = np.ascontiguousarray(utt_row_offsets, np.int32)
+        if feats.shape[1] != self.cfg.base_dim or off[-1] != feats.shape[0]:
+            raise KhError("OnlineIvectorFeature: feature dimension / row offsets mismatch")
+        if out is None:
+            out = torch.empty((feats.shape[0], self.cfg.ivector_dim), dtype=torch.float32, device=feats.device)
+        check(lib().kh_ivector_extract(self._h, _p(feats), _dim(feats).stride, off.ctypes.data_as(capi.c_int32_p), len(off) - 1,
+                                       _p(out), _dim(out).stride))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kh_ivector_extractor_destroy(self._h)
+            self._h = None

@@ -37,6 +37,15 @@ class KhDecoderConfig(C.Structure):
     ]
 
 
+class KhIvectorConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "base_dim", "splice_left", "splice_right", "feat_dim", "num_gauss", "ivector_dim", "lda_cols",
+        "cmn_window", "speaker_frames", "global_frames", "normalize_mean", "normalize_variance",
+        "ivector_period", "num_gselect", "num_cg_iters")] + [
+        ("min_post", C.c_float), ("posterior_scale", C.c_float), ("max_count", C.c_float),
+        ("prior_offset", C.c_double)]
+
+
 class KhDecodeStats(C.Structure):
     _fields_ = [
         ("num_frames", C.c_int32), ("reached_final", C.c_int32),
@@ -132,6 +141,9 @@ SIGNATURES = {
     "kh_compact_lattice_sizes": (C.c_int, [vp, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "kh_compact_lattice_get": (C.c_int, [vp, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
     "kh_compact_lattice_free": (None, [vp]),
+    "kh_ivector_extractor_create": (vp, [C.POINTER(KhIvectorConfig), c_float_p, c_double_p, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p]),
+    "kh_ivector_extractor_destroy": (None, [vp]),
+    "kh_ivector_extract": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, vp, C.c_int]),
     "kh_lattice_state_times": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p]),
     "kh_lattice_forward_backward": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p, c_double_p, c_double_p, c_int32_p]),
     "kh_lattice_alphas_betas": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, C.c_int, c_double_p, c_double_p, c_double_p]),

@@ -1,0 +1,483 @@
+// kh_ivector.hip — online iVector extraction on gfx950.
+//
+// Replaces OnlineIvectorFeature (online2/online-ivector-feature.{h,cc}) in its deterministic
+// mode — no silence weighting, use_most_recent_ivector = false, a fresh adaptation state per
+// utterance — for a BATCH of utterances whose base features are resident in HBM:
+//
+//   base --------------------> splice (:383-398) -> LDA (:400-422) = lda_
+//   base -> OnlineCmvn (feat/online-feature.cc:228-331, global stats) -> splice -> LDA = lda_normalized_
+//   per frame:  DiagGmm::LogLikelihoods(lda_normalized_)  ->  VectorToPosteriorEntry
+//               (hmm/posterior.cc:427-466) x posterior_scale  ->
+//               OnlineIvectorEstimationStats::AccStats(lda_)  (ivector/ivector-extractor.cc:522-568)
+//   every ivector_period frames: GetIvector = LinearCgd (:631-655, matrix/optimization.cc:453-565)
+//   feature row t = iVector of estimation point t / period, first dimension - PriorOffset
+//   (online-ivector-feature.cc:286-299).
+//
+// Mapping: the UBM scores are the batched DiagGmm kernel (MFMA GEMM), the LDA the MFMA GEMM with
+// the offset column as bias; the sliding-window CMVN is one wave per utterance (a lane per
+// dimension, running sums in double as the reference); the posterior entry is one wave per
+// frame (softmax, num_gselect rounds of a wave arg-max, pruning by one lane); the statistics and
+// the conjugate-gradient solves are sequential in time, so one workgroup per utterance keeps
+// the quadratic term (S (S + 1) / 2 doubles = 40 KB for S = 100) in LDS and streams the
+// per-Gaussian U_g / Sigma_g^-1 M_g rows (double, L2 / Infinity-Cache resident: 37 MB) through.
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "kh_common.h"
+
+using namespace kh;
+
+struct KhIvectorExtractor {
+  KhIvectorConfig cfg;
+  int sdim = 0, qdim = 0;
+  float *lda = nullptr;        // [feat_dim][sdim] linear part, row-major
+  float *lda_off = nullptr;    // [feat_dim]
+  double *gstats = nullptr;    // [2][base_dim + 1]
+  float *ubm_g = nullptr, *ubm_mi = nullptr, *ubm_iv = nullptr;
+  double *U = nullptr;         // [I][qdim] packed lower triangle by rows (SpMatrix order)
+  double *SiM = nullptr;       // [I][feat_dim][ivector_dim]
+  int *n_exact = nullptr;      // LinearCgd fall-backs to the exact solve (device counter)
+};
+
+namespace {
+
+// ---- sliding-window CMVN with global-stats smoothing: one wave per utterance, lane = dimension
+__global__ void __launch_bounds__(64)
+IvCmvnKernel(const float *__restrict__ x, int x_stride, const int32_t *__restrict__ utt_off, int D,
+             const double *__restrict__ gstats, int cmn_window, int global_frames, int norm_mean, int norm_var,
+             float *__restrict__ y, int y_stride) {
+  const int u = blockIdx.x, d = threadIdx.x;
+  const int b = utt_off[u], e = utt_off[u + 1];
+  if (d >= D) return;
+  const double g0 = gstats[d], g1 = gstats[D + 1 + d], gcount = gstats[D];
+  double s0 = 0.0, s1 = 0.0, count = 0.0;
+  for (int t = b; t < e; t++) {
+    const float xf = x[static_cast<size_t>(t) * x_stride + d];
+    const double xd = static_cast<double>(xf);
+    s0 += xd;                       // ComputeStatsForFrame :238-255
+    s1 += xd * xd;
+    count += 1.0;
+    const int prev = t - cmn_window;
+    if (prev >= b) {
+      const double pd = static_cast<double>(x[static_cast<size_t>(prev) * x_stride + d]);
+      s0 -= pd;
+      s1 -= pd * pd;
+      count -= 1.0;
+    }
+    double a0 = s0, a1 = s1, c = count;
+    if (c < cmn_window) {           // SmoothOnlineCmvnStats :263-298 (no speaker stats)
+      double from_global = cmn_window - c;
+      if (from_global > global_frames) from_global = global_frames;
+      if (from_global > 0.0) {
+        const double f = from_global / gcount;
+        a0 += f * g0;
+        a1 += f * g1;
+        c += f * gcount;
+      }
+    }
+    float out = xf;
+    if (norm_mean) {                // ApplyCmvn transform/cmvn.cc:64-113
+      const double mean = a0 / c;
+      double scale = 1.0, offset = -mean;
+      if (norm_var) {
+        double var = a1 / c - mean * mean;
+        if (var < 1.0e-20) var = 1.0e-20;
+        scale = 1.0 / sqrt(var);
+        offset = -(mean * scale);
+      }
+      out = xf * static_cast<float>(scale) + static_cast<float>(offset);
+    }
+    y[static_cast<size_t>(t) * y_stride + d] = out;
+  }
+}
+
+// ---- OnlineSpliceFrames for a batch: rows clamp to their own utterance
+__global__ void IvSpliceKernel(const float *__restrict__ x, int x_stride, const int32_t *__restrict__ row_utt,
+                               const int32_t *__restrict__ utt_off, int rows, int D, int left, int right,
+                               float *__restrict__ y, int y_stride) {
+  const int nctx = left + right + 1;
+  for (int t = blockIdx.x; t < rows; t += gridDim.x) {
+    const int u = row_utt[t], b = utt_off[u], e = utt_off[u + 1];
+    for (int c = threadIdx.x; c < nctx * D; c += blockDim.x) {
+      const int k = c / D, d = c - k * D;
+      int s = t + k - left;
+      s = s < b ? b : (s >= e ? e - 1 : s);
+      y[static_cast<size_t>(t) * y_stride + c] = x[static_cast<size_t>(s) * x_stride + d];
+    }
+  }
+}
+
+// ---- VectorToPosteriorEntry: one wave per frame
+constexpr int kMaxPerLane = 32;   // num_gauss <= 2048
+constexpr int kMaxGselect = 16;
+__global__ void __launch_bounds__(256)
+IvPosteriorKernel(const float *__restrict__ ll, int ll_stride, int rows, int num_gauss, int num_gselect, float min_post,
+                  float posterior_scale, int32_t *__restrict__ post_idx, float *__restrict__ post_w) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= rows) return;
+  const float *row = ll + static_cast<size_t>(t) * ll_stride;
+  float v[kMaxPerLane];
+  const int per = (num_gauss + 63) / 64;
+  float mx = -INFINITY;
+#pragma unroll 4
+  for (int j = 0; j < kMaxPerLane; j++) {
+    if (j >= per) break;
+    const int g = j * 64 + lane;
+    v[j] = g < num_gauss ? row[g] : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = kh_wave_max(mx);
+  // ApplySoftMax (kaldi-vector.cc): sum += (data[i] = Exp(data[i] - max)) sequentially in the
+  // reference; here per lane then over lanes (float, 1e-7 relative)
+  float sum = 0.f;
+#pragma unroll 4
+  for (int j = 0; j < kMaxPerLane; j++) {
+    if (j >= per) break;
+    v[j] = (j * 64 + lane) < num_gauss ? expf(v[j] - mx) : -1.f;
+    if (v[j] > 0.f) sum += v[j];
+  }
+  sum = kh_wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll 4
+  for (int j = 0; j < kMaxPerLane; j++) {
+    if (j >= per) break;
+    if (v[j] >= 0.f) v[j] *= inv;
+  }
+  // the num_gselect largest, in decreasing order (nth_element + sort in the reference)
+  const int G = num_gselect < num_gauss ? num_gselect : num_gauss;
+  float sel_w[kMaxGselect];
+  int sel_g[kMaxGselect];
+  for (int k = 0; k < G; k++) {
+    float best = -1.f;
+    int best_g = 0x7fffffff;
+#pragma unroll 4
+    for (int j = 0; j < kMaxPerLane; j++) {
+      if (j >= per) break;
+      if (v[j] > best) { best = v[j]; best_g = j * 64 + lane; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int og = __shfl_xor(best_g, o, 64);
+      if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+    }
+    sel_w[k] = best;
+    sel_g[k] = best_g;
+    if ((best_g & 63) == lane) v[best_g >> 6] = -1.f;   // taken
+  }
+  if (lane == 0) {
+    int n = G;
+    while (n > 1 && sel_w[n - 1] < min_post) n--;      // :452-453
+    float tot = 0.0f;
+    for (int k = 0; k < n; k++) tot += sel_w[k];
+    const float inv_tot = 1.0f / tot;
+    for (int k = 0; k < num_gselect; k++) {
+      float w = 0.f;
+      int g = 0;
+      if (k < n) { w = (sel_w[k] * inv_tot) * posterior_scale; g = sel_g[k]; }   // :458-459, online-ivector-feature.cc:195-196
+      post_idx[static_cast<size_t>(t) * num_gselect + k] = g;
+      post_w[static_cast<size_t>(t) * num_gselect + k] = w;
+    }
+  }
+}
+
+// ---- statistics + conjugate gradient: one workgroup per utterance
+__device__ __forceinline__ double BlockSumD(double v, double *red) {
+  v = kh_wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256)
+IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restrict__ utt_off,
+              const int32_t *__restrict__ post_idx, const float *__restrict__ post_w, int num_gselect, int D, int S, int qdim,
+              const double *__restrict__ U, const double *__restrict__ SiM, double prior_offset, double max_count,
+              int period, int cg_iters, float *__restrict__ out, int out_stride, int *__restrict__ n_fallback) {
+  extern __shared__ double lds[];
+  double *quad = lds;             // [qdim] packed lower triangle by rows
+  double *lin = quad + qdim;      // [S]
+  double *xv = lin + S, *rv = xv + S, *pv = rv + S, *x0 = pv + S, *feat = x0 + S;   // [S] x 4, [D]
+  __shared__ double red[4];
+  const int u = blockIdx.x, t_id = threadIdx.x;
+  const int b = utt_off[u], e = utt_off[u + 1];
+  // OnlineIvectorEstimationStats ctor :685-694
+  for (int k = t_id; k < qdim; k += 256) quad[k] = 0.0;
+  __syncthreads();
+  if (t_id < S) {
+    quad[t_id * (t_id + 1) / 2 + t_id] = 1.0;
+    lin[t_id] = t_id == 0 ? prior_offset : 0.0;
+    xv[t_id] = t_id == 0 ? prior_offset : 0.0;   // current_ivector_ :358-359
+  }
+  double num_frames = 0.0;
+  __syncthreads();
+  auto spmv = [&](const double *vec, int s) {   // (A vec)[s], A = quad (symmetric, packed)
+    double acc = 0.0;
+    const int rs = s * (s + 1) / 2;
+    for (int c = 0; c <= s; c++) acc += quad[rs + c] * vec[c];
+    for (int c = s + 1; c < S; c++) acc += quad[c * (c + 1) / 2 + s] * vec[c];
+    return acc;
+  };
+  for (int t = b; t < e; t++) {
+    if (t_id < D) feat[t_id] = static_cast<double>(F[static_cast<size_t>(t) * f_stride + t_id]);
+    __syncthreads();
+    // AccStats :522-568
+    double tot_weight = 0.0;
+    for (int k = 0; k < num_gselect; k++) {
+      const double w = static_cast<double>(post_w[static_cast<size_t>(t) * num_gselect + k]);
+      if (w == 0.0) continue;     // (uniform over the workgroup)
+      const int g = post_idx[static_cast<size_t>(t) * num_gselect + k];
+      if (t_id < S) {
+        const double *m = SiM + (static_cast<size_t>(g) * D) * S + t_id;
+        double acc = 0.0;
+        for (int d = 0; d < D; d++) acc += m[static_cast<size_t>(d) * S] * feat[d];
+        lin[t_id] += w * acc;
+      }
+      const double *ug = U + static_cast<size_t>(g) * qdim;
+      for (int q = t_id; q < qdim; q += 256) quad[q] += w * ug[q];
+      tot_weight += w;
+    }
+    if (max_count > 0.0) {
+      const double old_scale = fmax(num_frames, max_count) / max_count,
+                   new_scale = fmax(num_frames + tot_weight, max_count) / max_count, change = new_scale - old_scale;
+      if (change != 0.0) {
+        __syncthreads();
+        if (t_id == 0) lin[0] += prior_offset * change;
+        if (t_id < S) quad[t_id * (t_id + 1) / 2 + t_id] += change;
+      }
+    }
+    num_frames += tot_weight;
+    __syncthreads();
+    if ((t - b) % period == 0) {
+      // GetIvector :631-655 -> LinearCgd matrix/optimization.cc:453-565 (max_error 0, recompute factor 0.01)
+      if (num_frames > 0.0) {
+        if (t_id == 0 && xv[0] == 0.0) xv[0] = prior_offset;
+        __syncthreads();
+        if (t_id < S) x0[t_id] = xv[t_id];
+        // returns true when the squared residual got worse (:546-547)
+        auto cg = [&](int max_iters) {
+          double my_p = 0.0, my_r = 0.0;
+          if (t_id < S) {
+            my_p = lin[t_id] - spmv(xv, t_id);   // p_0 = b - A x_0
+            my_r = -my_p;
+          }
+          __syncthreads();
+          if (t_id < S) { pv[t_id] = my_p; rv[t_id] = my_r; }
+          double r_cur = BlockSumD(t_id < S ? my_r * my_r : 0.0, red);
+          const double r_init = r_cur;
+          double r_recompute = r_cur;
+          const double rf = 0.01 * 0.01;
+          for (int k = 0; k < S + 5 && k != max_iters; k++) {
+            double ap = 0.0;
+            if (t_id < S) ap = spmv(pv, t_id);
+            const double p_r = BlockSumD(t_id < S ? pv[t_id] * rv[t_id] : 0.0, red);
+            const double p_ap = BlockSumD(t_id < S ? pv[t_id] * ap : 0.0, red);
+            const double alpha = -p_r / p_ap;
+            if (t_id < S) {
+              xv[t_id] += alpha * pv[t_id];
+              rv[t_id] += alpha * ap;
+            }
+            double r_next = BlockSumD(t_id < S ? rv[t_id] * rv[t_id] : 0.0, red);
+            if (r_next < rf * r_recompute || r_next > r_recompute / rf) {
+              double nr = 0.0;
+              if (t_id < S) nr = spmv(xv, t_id) - lin[t_id];
+              __syncthreads();
+              if (t_id < S) rv[t_id] = nr;
+              r_next = BlockSumD(t_id < S ? nr * nr : 0.0, red);
+              r_recompute = r_next;
+            }
+            if (r_next <= DBL_MIN) break;
+            const double beta = r_next / r_cur;
+            if (t_id < S) pv[t_id] = -rv[t_id] + beta * pv[t_id];
+            r_cur = r_next;
+            __syncthreads();
+          }
+          if (!(r_cur > r_init)) return false;
+          const double bb = BlockSumD(t_id < S ? lin[t_id] * lin[t_id] : 0.0, red);
+          return r_cur > r_init + 1.0e-10 * bb;
+        };
+        if (cg(cg_iters)) {
+          // "the squared residual has got worse ... Will do an exact optimization": SolveQuadraticProblem
+          // from x_orig (:553-556).  Here: conjugate gradient run to convergence from x_orig, the same
+          // solution whenever SolveQuadraticProblem floors no eigenvalue (cond(A) <= 1e4, sp-matrix.cc).
+          __syncthreads();
+          if (t_id < S) xv[t_id] = x0[t_id];
+          __syncthreads();
+          cg(-1);
+          if (t_id == 0 && n_fallback) atomicAdd(n_fallback, 1);
+        }
+      } else if (t_id < S) {
+        xv[t_id] = t_id == 0 ? prior_offset : 0.0;
+      }
+      __syncthreads();
+      // the rows of this estimation point: frames [t, t + period)
+      const int last = (t + period < e) ? t + period : e;
+      for (int i = t_id; i < (last - t) * S; i += 256) {
+        const int row = t + i / S, s = i - (i / S) * S;
+        out[static_cast<size_t>(row) * out_stride + s] = static_cast<float>(xv[s] - (s == 0 ? prior_offset : 0.0));
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <class T>
+T *Upload(const T *h, size_t n) {
+  T *d = static_cast<T *>(PoolMalloc(sizeof(T) * (n ? n : 1)));
+  if (d && n && hipMemcpy(d, h, sizeof(T) * n, hipMemcpyHostToDevice) != hipSuccess) {
+    PoolFree(d);
+    return nullptr;
+  }
+  return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+KhIvectorExtractor *kh_ivector_extractor_create(const KhIvectorConfig *cfg, const float *lda_mat,
+                                                const double *global_cmvn_stats, const float *ubm_gconsts,
+                                                const float *ubm_means_invvars, const float *ubm_inv_vars, const double *M,
+                                                const double *Sigma_inv) {
+  if (EnsureDevice() != KH_OK) return nullptr;
+  if (!cfg || !lda_mat || !global_cmvn_stats || !ubm_gconsts || !ubm_means_invvars || !ubm_inv_vars || !M || !Sigma_inv) {
+    SetError("kh_ivector_extractor_create: bad arguments");
+    return nullptr;
+  }
+  const KhIvectorConfig &c = *cfg;
+  const int sdim = c.base_dim * (c.splice_left + c.splice_right + 1);
+  // OnlineIvectorExtractionInfo::Check online-ivector-feature.cc:70-87
+  if (!(c.base_dim > 0 && c.base_dim <= 64 && c.feat_dim > 0 && c.feat_dim <= 256 && c.num_gauss > 0 && c.num_gauss <= 64 * kMaxPerLane &&
+        c.ivector_dim > 0 && c.ivector_dim <= 256 && (c.lda_cols == sdim || c.lda_cols == sdim + 1) && c.ivector_period > 0 &&
+        c.num_gselect > 0 && c.num_gselect <= kMaxGselect && c.min_post < 0.5f && c.posterior_scale > 0.0f &&
+        c.posterior_scale <= 1.0f && c.global_frames <= c.speaker_frames && c.speaker_frames <= c.cmn_window &&
+        global_cmvn_stats[c.base_dim] > 0.0)) {
+    SetError("kh_ivector_extractor_create: OnlineIvectorExtractionInfo::Check() failed");
+    return nullptr;
+  }
+  KhIvectorExtractor *x = new KhIvectorExtractor();
+  x->cfg = c;
+  x->sdim = sdim;
+  const int D = c.feat_dim, S = c.ivector_dim, I = c.num_gauss;
+  x->qdim = S * (S + 1) / 2;
+  std::vector<float> lin(static_cast<size_t>(D) * sdim), off(D, 0.f);
+  for (int r = 0; r < D; r++) {
+    for (int k = 0; k < sdim; k++) lin[static_cast<size_t>(r) * sdim + k] = lda_mat[static_cast<size_t>(r) * c.lda_cols + k];
+    if (c.lda_cols == sdim + 1) off[r] = lda_mat[static_cast<size_t>(r) * c.lda_cols + sdim];   // OnlineTransform :400-415
+  }
+  // IvectorExtractor::ComputeDerivedVars(i) ivector-extractor.cc:207-217
+  std::vector<double> U(static_cast<size_t>(I) * x->qdim), SiM(static_cast<size_t>(I) * D * S);
+  for (int i = 0; i < I; i++) {
+    const double *Mi = M + static_cast<size_t>(i) * D * S, *Si = Sigma_inv + static_cast<size_t>(i) * D * D;
+    double *sm = SiM.data() + static_cast<size_t>(i) * D * S;
+    for (int d = 0; d < D; d++)
+      for (int s = 0; s < S; s++) {
+        double acc = 0.0;
+        for (int k = 0; k < D; k++) acc += Si[static_cast<size_t>(d) * D + k] * Mi[static_cast<size_t>(k) * S + s];
+        sm[static_cast<size_t>(d) * S + s] = acc;
+      }
+    double *ui = U.data() + static_cast<size_t>(i) * x->qdim;
+    for (int r = 0; r < S; r++)
+      for (int cc = 0; cc <= r; cc++) {
+        double acc = 0.0;
+        for (int d = 0; d < D; d++) acc += Mi[static_cast<size_t>(d) * S + r] * sm[static_cast<size_t>(d) * S + cc];
+        ui[r * (r + 1) / 2 + cc] = acc;
+      }
+  }
+  x->lda = Upload(lin.data(), lin.size());
+  x->lda_off = Upload(off.data(), off.size());
+  x->gstats = Upload(global_cmvn_stats, 2 * static_cast<size_t>(c.base_dim + 1));
+  x->ubm_g = Upload(ubm_gconsts, I);
+  x->ubm_mi = Upload(ubm_means_invvars, static_cast<size_t>(I) * D);
+  x->ubm_iv = Upload(ubm_inv_vars, static_cast<size_t>(I) * D);
+  x->U = Upload(U.data(), U.size());
+  x->SiM = Upload(SiM.data(), SiM.size());
+  const int zero = 0;
+  x->n_exact = Upload(&zero, 1);
+  if (!x->lda || !x->lda_off || !x->gstats || !x->ubm_g || !x->ubm_mi || !x->ubm_iv || !x->U || !x->SiM || !x->n_exact) {
+    kh_ivector_extractor_destroy(x);
+    SetError("kh_ivector_extractor_create: out of device memory");
+    return nullptr;
+  }
+  return x;
+}
+
+void kh_ivector_extractor_destroy(KhIvectorExtractor *x) {
+  if (!x) return;
+  PoolFree(x->lda); PoolFree(x->lda_off); PoolFree(x->gstats); PoolFree(x->ubm_g); PoolFree(x->ubm_mi);
+  PoolFree(x->ubm_iv); PoolFree(x->U); PoolFree(x->SiM); PoolFree(x->n_exact);
+  delete x;
+}
+
+int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat_stride, const int32_t *utt_row_offsets_host,
+                       int n_utts, float *ivectors, int ivector_stride) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(x && feats && utt_row_offsets_host && n_utts > 0 && ivectors && feat_stride >= x->cfg.base_dim &&
+               ivector_stride >= x->cfg.ivector_dim && utt_row_offsets_host[0] == 0);
+  const KhIvectorConfig &c = x->cfg;
+  const int rows = utt_row_offsets_host[n_utts];
+  for (int u = 0; u < n_utts; u++) KH_CHECK_ARG(utt_row_offsets_host[u + 1] > utt_row_offsets_host[u]);
+  hipStream_t st = Stream();
+  const int B = c.base_dim, D = c.feat_dim, S = c.ivector_dim, I = c.num_gauss, G = c.num_gselect;
+  const int sstride = (x->sdim + 3) & ~3, dstride = (D + 3) & ~3, istride = (I + 3) & ~3, bstride = (B + 3) & ~3;
+  std::vector<int32_t> row_utt(rows);
+  for (int u = 0; u < n_utts; u++)
+    for (int t = utt_row_offsets_host[u]; t < utt_row_offsets_host[u + 1]; t++) row_utt[t] = u;
+  int32_t *d_off = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * (n_utts + 1)));
+  int32_t *d_row_utt = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * rows));
+  float *d_norm = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(rows) * bstride));
+  float *d_spl = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(rows) * sstride));
+  float *d_F = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(rows) * dstride));
+  float *d_Fn = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(rows) * dstride));
+  float *d_ll = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(rows) * istride));
+  int32_t *d_pi = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * static_cast<size_t>(rows) * G));
+  float *d_pw = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(rows) * G));
+  auto cleanup = [&]() {
+    PoolFree(d_off); PoolFree(d_row_utt); PoolFree(d_norm); PoolFree(d_spl); PoolFree(d_F); PoolFree(d_Fn); PoolFree(d_ll);
+    PoolFree(d_pi); PoolFree(d_pw);
+  };
+  if (!d_off || !d_row_utt || !d_norm || !d_spl || !d_F || !d_Fn || !d_ll || !d_pi || !d_pw) { cleanup(); return KH_ENOMEM; }
+  rc = KH_OK;
+  do {
+    if (hipMemcpyAsync(d_off, utt_row_offsets_host, sizeof(int32_t) * (n_utts + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_row_utt, row_utt.data(), sizeof(int32_t) * rows, hipMemcpyHostToDevice, st) != hipSuccess) { rc = KH_EDEVICE; break; }
+    const KhMatrixDim dspl{rows, x->sdim, sstride}, dlda{D, x->sdim, x->sdim}, dF{rows, D, dstride};
+    const int sgrid = std::min(rows, NumCUs() * 16);
+    // lda_: splice(base) -> LDA
+    hipLaunchKernelGGL(IvSpliceKernel, dim3(sgrid), dim3(256), 0, st, feats, feat_stride, d_row_utt, d_off, rows, B, c.splice_left,
+                       c.splice_right, d_spl, sstride);
+    if ((rc = kh_affine(d_spl, dspl, x->lda, dlda, x->lda_off, d_F, dF))) break;
+    // lda_normalized_: cmvn(base) -> splice -> LDA
+    hipLaunchKernelGGL(IvCmvnKernel, dim3(n_utts), dim3(64), 0, st, feats, feat_stride, d_off, B, x->gstats, c.cmn_window,
+                       c.global_frames, c.normalize_mean, c.normalize_variance, d_norm, bstride);
+    hipLaunchKernelGGL(IvSpliceKernel, dim3(sgrid), dim3(256), 0, st, d_norm, bstride, d_row_utt, d_off, rows, B, c.splice_left,
+                       c.splice_right, d_spl, sstride);
+    if ((rc = kh_affine(d_spl, dspl, x->lda, dlda, x->lda_off, d_Fn, dF))) break;
+    // UBM log-likelihoods, posterior entries
+    if ((rc = kh_diag_gmm_loglikes(d_Fn, dF, x->ubm_g, x->ubm_mi, x->ubm_iv, I, d_ll, istride))) break;
+    hipLaunchKernelGGL(IvPosteriorKernel, dim3(DivUp(rows, 4)), dim3(256), 0, st, d_ll, istride, rows, I, G, c.min_post,
+                       c.posterior_scale, d_pi, d_pw);
+    // statistics + solves
+    const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D);
+    hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(256), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
+                       x->SiM, c.prior_offset, static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors,
+                       ivector_stride, x->n_exact);
+    if (hipGetLastError() != hipSuccess) { SetError("kh_ivector_extract: kernel launch failed"); rc = KH_EDEVICE; break; }
+  } while (0);
+  hipError_t e = hipStreamSynchronize(st);   // the scratch returns to the pool
+  cleanup();
+  int n_exact = 0;
+  if (!rc && e == hipSuccess && (e = hipMemcpy(&n_exact, x->n_exact, sizeof(int), hipMemcpyDeviceToHost)) == hipSuccess && n_exact > 0) {
+    // KALDI_WARN of LinearCgd, optimization.cc:548-552
+    fprintf(stderr, "WARNING (kh_ivector_extract): linear CGD in dimension %d: the squared residual got worse at %d estimation points; did an exact optimization there\n", S, n_exact);
+    (void)hipMemset(x->n_exact, 0, sizeof(int));
+  }
+  if (!rc && e != hipSuccess) { SetError("kh_ivector_extract: %s", hipGetErrorString(e)); rc = KH_EDEVICE; }
+  return rc;
+}
+
+}  // extern "C"

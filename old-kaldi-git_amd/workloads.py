@@ -520,3 +520,40 @@ def make_path_features(rng, net, protos, pdf_seqs, noise=0.1, spliced_noise=0.01
     x[:, :fd - cd] = rng.standard_normal((len(seq), fd - cd)).astype(np.float32) * np.float32(spliced_noise)
     x[:, fd - cd:] = protos[seq] + rng.standard_normal((len(seq), cd)).astype(np.float32) * np.float32(noise)
     return x
+
+
+# --------------------------------------------------------------------------
+# iVector extractor (egs/librispeech/s5/local/online/run_nnet2.sh: UBM of 512 diagonal
+# Gaussians on 40-dim spliced(+-3) + LDA features, 100-dim iVectors re-estimated every 10 frames).
+# --------------------------------------------------------------------------
+def make_ivector_extractor(rng, base_dim=40, splice=3, feat_dim=40, num_gauss=512, ivector_dim=100,
+                           prior_offset=10.0):
+    """Synthetic OnlineIvectorExtractionInfo (online2/online-ivector-feature.h:53-140): LDA
+    matrix (affine: one extra column), global CMVN stats, diagonal UBM, IvectorExtractor
+    parameters (M_i, Sigma_i^-1 full, prior offset; ivector/ivector-extractor.h:140-290) and the
+    config defaults (:102-107) in the deterministic mode (use_most_recent_ivector = false)."""
+    sdim = base_dim * (2 * splice + 1)
+    lda = (rng.standard_normal((feat_dim, sdim + 1)) / np.sqrt(sdim)).astype(np.float32)
+    lda[:, -1] = (rng.standard_normal(feat_dim) * 0.1).astype(np.float32)
+    count = 50000.0
+    mean = rng.standard_normal(base_dim) * 0.5
+    var = np.exp(rng.standard_normal(base_dim) * 0.3)
+    gstats = np.zeros((2, base_dim + 1))
+    gstats[0, :base_dim] = mean * count
+    gstats[1, :base_dim] = (var + mean * mean) * count
+    gstats[0, base_dim] = count
+    w = rng.dirichlet(np.full(num_gauss, 5.0)).astype(np.float32)
+    ubm_means = (rng.standard_normal((num_gauss, feat_dim)) * 1.0).astype(np.float32)
+    ubm_vars = np.exp(rng.standard_normal((num_gauss, feat_dim)) * 0.3).astype(np.float32)
+    M = rng.standard_normal((num_gauss, feat_dim, ivector_dim)) * (0.3 / np.sqrt(ivector_dim))
+    M[:, :, 0] = ubm_means / prior_offset          # mean_i = M_i [prior_offset, 0, ...]
+    sig_inv = np.empty((num_gauss, feat_dim, feat_dim))
+    for i in range(num_gauss):
+        A = rng.standard_normal((feat_dim, feat_dim)) * 0.1
+        S = np.diag(ubm_vars[i].astype(np.float64)) + A @ A.T
+        sig_inv[i] = np.linalg.inv(S)
+    return dict(lda_mat=lda, global_cmvn_stats=gstats, splice_left=splice, splice_right=splice,
+                cmn_window=600, speaker_frames=600, global_frames=200, normalize_mean=True, normalize_variance=False,
+                ubm_weights=w, ubm_means=ubm_means, ubm_vars=ubm_vars, M=M, Sigma_inv=sig_inv,
+                prior_offset=float(prior_offset), ivector_period=10, num_gselect=5, min_post=0.025,
+                posterior_scale=0.1, max_count=0.0, num_cg_iters=15)

@@ -1,0 +1,200 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT CODE: numpy specification of OnlineIvectorFeature
+(online2/online-ivector-feature.cc:333-360,183-216,270-300) in its deterministic mode
+(no silence weighting, use_most_recent_ivector = false, fresh adaptation state):
+
+  base -> OnlineSpliceFrames -> OnlineTransform(lda)                       = lda_
+  base -> OnlineCmvn(global stats) -> OnlineSpliceFrames -> OnlineTransform = lda_normalized_
+  per frame: DiagGmm::LogLikelihoods(lda_normalized_) -> VectorToPosteriorEntry
+  (hmm/posterior.cc:427-466) x posterior_scale -> OnlineIvectorEstimationStats::AccStats(lda_)
+  (ivector/ivector-extractor.cc:522-568); every ivector_period frames GetIvector = LinearCgd
+  (:631-655, matrix/optimization.cc:453-565) -> feature row = iVector, first dim - PriorOffset.
+
+Pinned piecewise against the reference compiled into oracle/_ref (tests/test_ivector_oracle.py):
+the feature chain through the reference's own OnlineCmvn / OnlineSpliceFrames /
+OnlineTransform classes, the UBM log-likelihoods through DiagGmm, the solver through LinearCgd.
+online-ivector-feature.cc, ivector-extractor.cc and posterior.cc themselves need OpenFst headers
+(PARITY UNPINNED for VectorToPosteriorEntry and AccStats, which are restated from those lines).
+Loops in pure Python: small cases only."""
+import numpy as np
+
+
+def online_cmvn(X, m):
+    """OnlineCmvn::GetFrame (feat/online-feature.cc:228-331) with global stats only + ApplyCmvn (transform/cmvn.cc:64-113)."""
+    T, D = X.shape
+    gs = np.asarray(m["global_cmvn_stats"], np.float64)
+    win, gf = m["cmn_window"], m["global_frames"]
+    stats = np.zeros((2, D + 1))
+    out = np.empty((T, D), np.float32)
+    for t in range(T):
+        x = X[t].astype(np.float64)
+        stats[0, :D] += x
+        stats[1, :D] += x * x
+        stats[0, D] += 1.0
+        if t - win >= 0:
+            p = X[t - win].astype(np.float64)
+            stats[0, :D] -= p
+            stats[1, :D] -= p * p
+            stats[0, D] -= 1.0
+        s = stats.copy()
+        cur = s[0, D]
+        if cur < win:
+            cfg = min(win - cur, gf)
+            if cfg > 0.0:
+                s += (cfg / gs[0, D]) * gs
+        count = s[0, D]
+        mean = s[0, :D] / count
+        if not m["normalize_variance"]:
+            scale, offset = np.ones(D), -mean
+        else:
+            var = np.maximum(s[1, :D] / count - mean * mean, 1.0e-20)
+            scale = 1.0 / np.sqrt(var)
+            offset = -(mean * scale)
+        if m["normalize_mean"]:
+            out[t] = X[t] * scale.astype(np.float32) + offset.astype(np.float32)
+        else:
+            out[t] = X[t]
+    return out
+
+
+def splice_lda(X, m):
+    """OnlineSpliceFrames::GetFrame (:383-398) + OnlineTransform::GetFrame (:400-422)."""
+    T, D = X.shape
+    L, R = m["splice_left"], m["splice_right"]
+    idx = np.clip(np.arange(T)[:, None] + np.arange(-L, R + 1)[None, :], 0, T - 1)
+    S = X[idx].reshape(T, (L + R + 1) * D)
+    lda = np.asarray(m["lda_mat"], np.float32)
+    if lda.shape[1] == S.shape[1] + 1:
+        return (S @ lda[:, :-1].T + lda[:, -1]).astype(np.float32)
+    return (S @ lda.T).astype(np.float32)
+
+
+def ubm_params(m):
+    """DiagGmm::ComputeGconsts (gmm/diag-gmm.cc:114-152) in double for the spec."""
+    inv = 1.0 / m["ubm_vars"].astype(np.float64)
+    mi = m["ubm_means"].astype(np.float64) * inv
+    D = inv.shape[1]
+    g = np.log(m["ubm_weights"].astype(np.float64)) - 0.5 * (D * np.log(2 * np.pi) + np.sum(-np.log(inv) + mi * mi / inv, 1))
+    return g.astype(np.float32), mi.astype(np.float32), inv.astype(np.float32)
+
+
+def vector_to_posterior_entry(log_likes, num_gselect, min_post):
+    """hmm/posterior.cc:427-466."""
+    ll = log_likes.astype(np.float32)
+    mx = ll.max()
+    e = np.exp(ll - mx, dtype=np.float32)
+    tot = np.float32(e.sum(dtype=np.float32))
+    p = (e * np.float32(1.0 / tot)).astype(np.float32)
+    n = min(num_gselect, len(p))
+    order = np.argsort(-p, kind="stable")[:n]
+    ent = [(int(g), np.float32(p[g])) for g in order]
+    while len(ent) > 1 and ent[-1][1] < np.float32(min_post):
+        ent.pop()
+    s = np.float32(0.0)
+    for _, v in ent:
+        s = np.float32(s + v)
+    inv = np.float32(1.0) / s
+    return [(g, np.float32(v * inv)) for g, v in ent], float(mx + np.log(tot))
+
+
+def packed_index(S):
+    r, c = np.tril_indices(S)
+    return r, c
+
+
+def derived(m):
+    """IvectorExtractor::ComputeDerivedVars(i) (ivector-extractor.cc:207-217): U_i = M_i^T Sigma_i^-1 M_i
+    (SpMatrix packed, lower triangle by rows), Sigma_inv_M_i."""
+    M, Si = np.asarray(m["M"], np.float64), np.asarray(m["Sigma_inv"], np.float64)
+    SiM = np.einsum("ide,ies->ids", Si, M)
+    Ufull = np.einsum("ids,idt->ist", M, SiM)
+    r, c = packed_index(M.shape[2])
+    return Ufull[:, r, c], SiM
+
+
+def linear_cgd(A, b, x, max_iters, max_error=0.0, recompute_residual_factor=0.01):
+    """matrix/optimization.cc:453-565 (double)."""
+    M = len(b)
+    p = b - A @ x
+    r = -p
+    x_orig = x.copy()
+    r_cur = r @ r
+    r_init = r_cur
+    r_recompute = r_cur
+    max_error_sq = max(max_error * max_error, np.finfo(np.float64).tiny)
+    rf = recompute_residual_factor * recompute_residual_factor
+    k = 0
+    while k < M + 5 and k != max_iters:
+        Ap = A @ p
+        alpha = -(p @ r) / (p @ Ap)
+        x = x + alpha * p
+        r = r + alpha * Ap
+        r_next = r @ r
+        if r_next < rf * r_recompute or r_next > r_recompute / rf:
+            r = A @ x - b
+            r_next = r @ r
+            r_recompute = r_next
+        if r_next <= max_error_sq:
+            break
+        beta = r_next / r_cur
+        p = -r + beta * p
+        r_cur = r_next
+        k += 1
+    if r_cur > r_init and r_cur > r_init + 1.0e-10 * (b @ b):   # :553-564: "will do an exact optimization"
+        x = np.linalg.solve(A, b)
+    return x, k
+
+
+def extract(X, m):
+    """The iVector feature rows [T, ivector_dim] of one utterance."""
+    T = X.shape[0]
+    S = np.asarray(m["M"]).shape[2]
+    F = splice_lda(X, m)
+    Fn = splice_lda(online_cmvn(X, m), m)
+    g, mi, iv = ubm_params(m)
+    U, SiM = derived(m)
+    r, c = packed_index(S)
+    quad = np.zeros((S, S))
+    quad[np.arange(S), np.arange(S)] = 1.0             # OnlineIvectorEstimationStats ctor :685-694
+    lin = np.zeros(S)
+    lin[0] = m["prior_offset"]
+    num_frames = 0.0
+    cur = np.zeros(S)
+    cur[0] = m["prior_offset"]
+    out = np.empty((T, S), np.float32)
+    hist = []
+    for t in range(T):
+        x = Fn[t]
+        ll = (g + mi @ x - 0.5 * (iv @ (x * x))).astype(np.float32)     # DiagGmm::LogLikelihoods :528-543
+        post, _ = vector_to_posterior_entry(ll, m["num_gselect"], m["min_post"])
+        f = F[t].astype(np.float64)
+        tot_w = 0.0
+        for gi, w in post:
+            w = float(np.float32(w * np.float32(m["posterior_scale"] * 1.0)))
+            if w == 0.0:
+                continue
+            lin += w * (SiM[gi].T @ f)
+            Ug = np.zeros((S, S))
+            Ug[r, c] = U[gi]
+            Ug[c, r] = U[gi]
+            quad += w * Ug
+            tot_w += w
+        if m["max_count"] > 0.0:
+            old_s = max(num_frames, m["max_count"]) / m["max_count"]
+            new_s = max(num_frames + tot_w, m["max_count"]) / m["max_count"]
+            if new_s - old_s != 0.0:
+                lin[0] += m["prior_offset"] * (new_s - old_s)
+                quad[np.arange(S), np.arange(S)] += new_s - old_s
+        num_frames += tot_w
+        if t % m["ivector_period"] == 0:
+            if num_frames > 0.0:
+                if cur[0] == 0.0:
+                    cur[0] = m["prior_offset"]
+                cur, _ = linear_cgd(quad, lin, cur, m["num_cg_iters"])
+            else:
+                cur = np.zeros(S)
+                cur[0] = m["prior_offset"]
+            hist.append(cur.copy())
+        v = hist[t // m["ivector_period"]].copy()
+        v[0] -= m["prior_offset"]
+        out[t] = v.astype(np.float32)
+    return out

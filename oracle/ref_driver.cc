@@ -20,6 +20,8 @@
 #include "cudamatrix/cu-matrix-lib.h"
 #include "feat/feature-functions.h"
 #include "feat/feature-mfcc.h"
+#include "feat/online-feature.h"
+#include "matrix/optimization.h"
 #include "gmm/am-diag-gmm.h"
 #include "gmm/diag-gmm.h"
 #include "hmm/hmm-topology.h"
@@ -662,6 +664,61 @@ int ref_write_topology(const char *path, const char *topo_text, int binary) {
     std::ofstream os(path, std::ios::binary);
     topo.Write(os, binary != 0);
     return os.good() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// The feature chain in front of the iVector extractor exactly as OnlineIvectorFeature builds it
+// (online2/online-ivector-feature.cc:333-360; that file itself needs OpenFst headers through
+// decoder/lattice-faster-online-decoder.h, these classes do not): base -> OnlineSpliceFrames
+// -> OnlineTransform(lda) and base -> OnlineCmvn(global stats only) -> OnlineSpliceFrames ->
+// OnlineTransform(lda), feat/online-feature.cc.
+int ref_online_cmvn_splice_lda(const float *feats, int T, int D, const double *global_stats, int cmn_window,
+                               int speaker_frames, int global_frames, int norm_mean, int norm_var, int left, int right,
+                               const float *lda, int lda_rows, int lda_cols, float *out_lda, float *out_lda_norm,
+                               float *out_cmvn) {
+  try {
+    Matrix<BaseFloat> m = In(feats, T, D, D);
+    OnlineMatrixFeature base(m);
+    OnlineCmvnOptions co;
+    co.cmn_window = cmn_window; co.speaker_frames = speaker_frames; co.global_frames = global_frames;
+    co.normalize_mean = norm_mean != 0; co.normalize_variance = norm_var != 0;
+    Matrix<double> gs(2, D + 1);
+    for (int r = 0; r < 2; r++) for (int c = 0; c <= D; c++) gs(r, c) = global_stats[r * (D + 1) + c];
+    OnlineSpliceOptions so;
+    so.left_context = left; so.right_context = right;
+    Matrix<BaseFloat> lda_mat = In(lda, lda_rows, lda_cols, lda_cols);
+    OnlineSpliceFrames splice(so, &base);
+    OnlineTransform lda_t(lda_mat, &splice);
+    OnlineCmvnState st(gs);
+    OnlineCmvn cmvn(co, st, &base);
+    OnlineSpliceFrames splice_n(so, &cmvn);
+    OnlineTransform lda_n(lda_mat, &splice_n);
+    Vector<BaseFloat> v(lda_rows), c(D);
+    for (int t = 0; t < T; t++) {
+      lda_t.GetFrame(t, &v);
+      for (int k = 0; k < lda_rows; k++) out_lda[static_cast<size_t>(t) * lda_rows + k] = v(k);
+      lda_n.GetFrame(t, &v);
+      for (int k = 0; k < lda_rows; k++) out_lda_norm[static_cast<size_t>(t) * lda_rows + k] = v(k);
+      if (out_cmvn) {
+        cmvn.GetFrame(t, &c);
+        for (int k = 0; k < D; k++) out_cmvn[static_cast<size_t>(t) * D + k] = c(k);
+      }
+    }
+    return 0;
+  } catch (...) { return -1; }
+}
+// LinearCgd<double> matrix/optimization.cc:453-565 (what OnlineIvectorEstimationStats::GetIvector
+// calls, ivector/ivector-extractor.cc:631-655); A in SpMatrix packed order.  Returns the iterations.
+int ref_linear_cgd(int dim, const double *a_packed, const double *b, double *x, int max_iters) {
+  try {
+    SpMatrix<double> A(dim);
+    memcpy(A.Data(), a_packed, sizeof(double) * dim * (dim + 1) / 2);
+    Vector<double> bv(dim), xv(dim);
+    for (int i = 0; i < dim; i++) { bv(i) = b[i]; xv(i) = x[i]; }
+    LinearCgdOptions opts;
+    opts.max_iters = max_iters;
+    int it = LinearCgd(opts, A, bv, &xv);
+    for (int i = 0; i < dim; i++) x[i] = xv(i);
+    return it;
   } catch (...) { return -1; }
 }
 }  // extern "C"

@@ -276,8 +276,32 @@ def make_kaldi_io():
     print("kaldi_io:", sorted(os.listdir(out_dir)))
 
 
+def make_ivector():
+    """Reference outputs for the iVector front-end pieces that compile from the reference's own
+    sources (feat/online-feature.cc: OnlineCmvn, OnlineSpliceFrames, OnlineTransform;
+    matrix/optimization.cc: LinearCgd) on the cases of tests/test_ivector_oracle.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_ivector_oracle as T
+    m, m2, X = T.cases()
+    lda_a, lda_norm_a, cmvn_a = T.ref_chain(m, X)
+    lda_b, lda_norm_b, cmvn_b = T.ref_chain(m2, X)
+    rng = np.random.default_rng(3)
+    S = 12
+    Q = rng.standard_normal((S, S))
+    A = Q @ Q.T + np.eye(S)
+    b = rng.standard_normal(S)
+    x0 = np.zeros(S)
+    x0[0] = 2.0
+    x, k = T.ref_cgd(A, b, x0, 15)
+    np.savez_compressed(os.path.join(HERE, "ivector.npz"), lda_a=lda_a, lda_norm_a=lda_norm_a, cmvn_a=cmvn_a, lda_b=lda_b,
+                        lda_norm_b=lda_norm_b, cmvn_b=cmvn_b, cg_A=A, cg_b=b, cg_x0=x0, cg_x=x, cg_k=k)
+    print("ivector: written")
+
+
 if __name__ == "__main__":
-    if "--features" in sys.argv:
+    if "--ivector" in sys.argv:
+        make_ivector()
+    elif "--features" in sys.argv:
         make_features()
     elif "--kaldi-io" in sys.argv:
         make_kaldi_io()
@@ -285,3 +309,4 @@ if __name__ == "__main__":
         main()
         make_features()
         make_kaldi_io()
+        make_ivector()
