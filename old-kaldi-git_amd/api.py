@@ -1351,5 +1351,5 @@ class OnlineIvectorExtractor:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().kh_ivector_extractor_destroy(self._h)
+            capi.load().kh_ivector_extractor_destroy(self._h)
             self._h = None

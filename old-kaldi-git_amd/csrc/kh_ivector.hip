@@ -187,12 +187,13 @@ IvPosteriorKernel(const float *__restrict__ ll, int ll_stride, int rows, int num
 __device__ __forceinline__ double BlockSumD(double v, double *red) {
   v = kh_wave_sum_d(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;   // callers: zero beyond thread S <= 256
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void __launch_bounds__(256)
+constexpr int kIvThreads = 256;
+__global__ void __launch_bounds__(kIvThreads)
 IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restrict__ utt_off,
               const int32_t *__restrict__ post_idx, const float *__restrict__ post_w, int num_gselect, int D, int S, int qdim,
               const double *__restrict__ U, const double *__restrict__ SiM, double prior_offset, double max_count,
@@ -200,12 +201,12 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
   extern __shared__ double lds[];
   double *quad = lds;             // [qdim] packed lower triangle by rows
   double *lin = quad + qdim;      // [S]
-  double *xv = lin + S, *rv = xv + S, *pv = rv + S, *x0 = pv + S, *feat = x0 + S;   // [S] x 4, [D]
+  double *xv = lin + S, *rv = xv + S, *pv = rv + S, *x0 = pv + S, *feat = x0 + S, *part = feat + D;   // [S] x 4, [D], [num_gselect][S]
   __shared__ double red[4];
   const int u = blockIdx.x, t_id = threadIdx.x;
   const int b = utt_off[u], e = utt_off[u + 1];
   // OnlineIvectorEstimationStats ctor :685-694
-  for (int k = t_id; k < qdim; k += 256) quad[k] = 0.0;
+  for (int k = t_id; k < qdim; k += kIvThreads) quad[k] = 0.0;
   __syncthreads();
   if (t_id < S) {
     quad[t_id * (t_id + 1) / 2 + t_id] = 1.0;
@@ -224,21 +225,36 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
   for (int t = b; t < e; t++) {
     if (t_id < D) feat[t_id] = static_cast<double>(F[static_cast<size_t>(t) * f_stride + t_id]);
     __syncthreads();
-    // AccStats :522-568
+    // AccStats :522-568: the frame's postings together, the loads of the U_g / Sigma_g^-1 M_g rows
+    // independent of one another (kIvThreads x num_gselect in flight)
     double tot_weight = 0.0;
-    for (int k = 0; k < num_gselect; k++) {
-      const double w = static_cast<double>(post_w[static_cast<size_t>(t) * num_gselect + k]);
-      if (w == 0.0) continue;     // (uniform over the workgroup)
-      const int g = post_idx[static_cast<size_t>(t) * num_gselect + k];
-      if (t_id < S) {
-        const double *m = SiM + (static_cast<size_t>(g) * D) * S + t_id;
-        double acc = 0.0;
+    const int32_t *pi = post_idx + static_cast<size_t>(t) * num_gselect;
+    const float *pw = post_w + static_cast<size_t>(t) * num_gselect;
+    for (int idx = t_id; idx < num_gselect * S; idx += kIvThreads) {
+      const int k = idx / S, s = idx - k * S;
+      const double w = static_cast<double>(pw[k]);
+      double acc = 0.0;
+      if (w != 0.0) {
+        const double *m = SiM + (static_cast<size_t>(pi[k]) * D) * S + s;
         for (int d = 0; d < D; d++) acc += m[static_cast<size_t>(d) * S] * feat[d];
-        lin[t_id] += w * acc;
       }
-      const double *ug = U + static_cast<size_t>(g) * qdim;
-      for (int q = t_id; q < qdim; q += 256) quad[q] += w * ug[q];
-      tot_weight += w;
+      part[idx] = w * acc;
+    }
+    for (int q = t_id; q < qdim; q += kIvThreads) {
+      double acc = quad[q];
+      for (int k = 0; k < num_gselect; k++) {
+        const double w = static_cast<double>(pw[k]);
+        if (w != 0.0) acc += w * U[static_cast<size_t>(pi[k]) * qdim + q];
+      }
+      quad[q] = acc;
+    }
+    for (int k = 0; k < num_gselect; k++) tot_weight += static_cast<double>(pw[k]);
+    __syncthreads();
+    if (t_id < S) {
+      double acc = lin[t_id];
+      for (int k = 0; k < num_gselect; k++)
+        if (pw[k] != 0.f) acc += part[k * S + t_id];
+      lin[t_id] = acc;
     }
     if (max_count > 0.0) {
       const double old_scale = fmax(num_frames, max_count) / max_count,
@@ -257,8 +273,12 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
         if (t_id == 0 && xv[0] == 0.0) xv[0] = prior_offset;
         __syncthreads();
         if (t_id < S) x0[t_id] = xv[t_id];
-        // returns true when the squared residual got worse (:546-547)
-        auto cg = [&](int max_iters) {
+        // pass 0: LinearCgd with max_iters = num_cg_iters.  If the squared residual got worse
+        // (:546-547: "Will do an exact optimization", SolveQuadraticProblem from x_orig), pass 1:
+        // conjugate gradient run to convergence from x_orig — the same solution whenever
+        // SolveQuadraticProblem floors no eigenvalue (cond(A) <= 1e4, sp-matrix.cc).
+        for (int pass = 0; pass < 2; pass++) {
+          const int max_iters = pass == 0 ? cg_iters : -1;
           double my_p = 0.0, my_r = 0.0;
           if (t_id < S) {
             my_p = lin[t_id] - spmv(xv, t_id);   // p_0 = b - A x_0
@@ -295,19 +315,13 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
             r_cur = r_next;
             __syncthreads();
           }
-          if (!(r_cur > r_init)) return false;
+          if (pass == 1 || !(r_cur > r_init)) break;
           const double bb = BlockSumD(t_id < S ? lin[t_id] * lin[t_id] : 0.0, red);
-          return r_cur > r_init + 1.0e-10 * bb;
-        };
-        if (cg(cg_iters)) {
-          // "the squared residual has got worse ... Will do an exact optimization": SolveQuadraticProblem
-          // from x_orig (:553-556).  Here: conjugate gradient run to convergence from x_orig, the same
-          // solution whenever SolveQuadraticProblem floors no eigenvalue (cond(A) <= 1e4, sp-matrix.cc).
+          if (!(r_cur > r_init + 1.0e-10 * bb)) break;
           __syncthreads();
           if (t_id < S) xv[t_id] = x0[t_id];
-          __syncthreads();
-          cg(-1);
           if (t_id == 0 && n_fallback) atomicAdd(n_fallback, 1);
+          __syncthreads();
         }
       } else if (t_id < S) {
         xv[t_id] = t_id == 0 ? prior_offset : 0.0;
@@ -315,7 +329,7 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
       __syncthreads();
       // the rows of this estimation point: frames [t, t + period)
       const int last = (t + period < e) ? t + period : e;
-      for (int i = t_id; i < (last - t) * S; i += 256) {
+      for (int i = t_id; i < (last - t) * S; i += kIvThreads) {
         const int row = t + i / S, s = i - (i / S) * S;
         out[static_cast<size_t>(row) * out_stride + s] = static_cast<float>(xv[s] - (s == 0 ? prior_offset : 0.0));
       }
@@ -462,8 +476,8 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
     hipLaunchKernelGGL(IvPosteriorKernel, dim3(DivUp(rows, 4)), dim3(256), 0, st, d_ll, istride, rows, I, G, c.min_post,
                        c.posterior_scale, d_pi, d_pw);
     // statistics + solves
-    const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D);
-    hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(256), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
+    const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D + static_cast<size_t>(G) * S);
+    hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(kIvThreads), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
                        x->SiM, c.prior_offset, static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors,
                        ivector_stride, x->n_exact);
     if (hipGetLastError() != hipSuccess) { SetError("kh_ivector_extract: kernel launch failed"); rc = KH_EDEVICE; break; }

@@ -133,9 +133,27 @@ def lattice_fb_cfg5(api, torch, N=256, T=400):
     return res
 
 
+def ivector_f3(api, torch, n_utts=512, mean_len=740):
+    """Online iVector extraction at the reference's default dimensions (online-ivector-feature.h:102-107):
+    40-dim base features, +-3 splice, LDA to 40, 512-Gaussian UBM, 100-dim iVector, period 10."""
+    W = importlib.import_module(PKG + ".workloads")
+    rng = np.random.default_rng(4)
+    m = W.make_ivector_extractor(rng)
+    ext = api.OnlineIvectorExtractor(m)
+    lens = np.clip(rng.gamma(4.0, mean_len / 4.0, n_utts).astype(np.int64), 100, 3500)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = torch.from_numpy(rng.standard_normal((int(off[-1]), 40)).astype(np.float32)).cuda()
+    out = torch.empty((int(off[-1]), 100), dtype=torch.float32, device="cuda")
+    sync = lambda: (api.synchronize(), torch.cuda.synchronize())
+    dt = _timeit(lambda: ext.extract(x, off, out=out), sync, reps=2)
+    return {"workload": "%d utterances, %d frames, UBM 512 x 40, iVector dim 100, period 10, 15 CG iterations" % (n_utts, int(off[-1])),
+            "ms_per_call": dt * 1e3, "frames_per_s": int(off[-1]) / dt, "longest_utterance_frames": int(lens.max())}
+
+
 def run_all(api, torch):
     out = {}
-    for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5)):
+    for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5),
+                     ("ivector_f3", ivector_f3)):
         try:
             out[name] = fn(api, torch)
         except Exception as e:  # a secondary leg never fails the headline run
