@@ -392,6 +392,26 @@ int kh_mfcc_compute(const float *wave, int n_samples, int frame_shift, int frame
                     const int32_t *mel_first_host, const int32_t *mel_off_host,
                     const float *mel_weights_host, int num_ceps, const float *dct_host,
                     const float *lifter_host, float *out, int out_stride, int *num_frames);
+/* The same with the remaining MfccOptions / FrameExtractionOptions (feat/feature-mfcc.h:41-56,
+ * feature-functions.h:77-96): snip_edges = 0: NumFrames = round(n / shift), frame r centred on
+ * shift * (r + 0.5), the signal extended by reflection (ExtractWindow feature-functions.cc:107-135);
+ * use_energy: C0 := log energy of the frame before pre-emphasis and windowing (raw_energy) or of
+ * the windowed frame, floored at log(energy_floor) when energy_floor > 0 (feature-mfcc.cc:138-141,
+ * :167-171); htk_compat: energy / C0 * sqrt(2) moved to the last column (:173-182); dither > 0:
+ * Gaussian noise * dither added to every sample of every window (Dither :51-54) from a
+ * counter-based generator seeded with dither_seed (the reference draws from rand(): same
+ * distribution, not the same numbers).  kh_mfcc_compute = {snip_edges 1, raw_energy 1, rest 0}. */
+typedef struct KhMfccOptions {
+  int32_t snip_edges, use_energy, raw_energy, htk_compat;
+  float energy_floor, dither;
+  uint64_t dither_seed;
+} KhMfccOptions;
+int kh_mfcc_compute_opts(const float *wave, int n_samples, int frame_shift, int frame_length, int padded,
+                         float preemph_coeff, int remove_dc_offset, const float *window_host, int num_bins,
+                         const int32_t *mel_first_host, const int32_t *mel_off_host,
+                         const float *mel_weights_host, int num_ceps, const float *dct_host,
+                         const float *lifter_host, const KhMfccOptions *options, float *out, int out_stride,
+                         int *num_frames);
 /* ComputeDeltas (feat/feature-functions.cc:361-372): scales of DeltaFeatures
  * (:210-242) for orders 0..order back to back (HOST), their lengths in lens_host. */
 int kh_compute_deltas(const float *in, KhMatrixDim d_in, int order, const float *scales_host,

@@ -363,14 +363,19 @@ class DecodableNnet2Online:
 
 # ---------------------------------------------------------------- feature front-end
 class Mfcc:
-    """feat/feature-mfcc.h Mfcc with MfccOptions (use_energy = false, dither = 0,
-    snip_edges = true): the constructor builds the reference's tables (window function,
-    MelBanks, DCT rows, lifter) on the host, compute() runs the frames on the GPU."""
+    """feat/feature-mfcc.h Mfcc with MfccOptions: the constructor builds the reference's tables
+    (window function, MelBanks, DCT rows, lifter) on the host, compute() runs the frames on the
+    GPU.  Defaults here are the recipes' (--use-energy=false, no dither); the reference's
+    struct defaults are use_energy = true, dither = 1.0 (feature-mfcc.h:54, feature-functions.h:91).
+    dither > 0 draws from a counter-based generator seeded with dither_seed."""
 
     def __init__(self, samp_freq=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemph_coeff=0.97,
                  remove_dc_offset=True, window_type="povey", num_bins=23, low_freq=20.0, high_freq=0.0, num_ceps=13,
-                 cepstral_lifter=22.0):
+                 cepstral_lifter=22.0, snip_edges=True, use_energy=False, raw_energy=True, energy_floor=0.0,
+                 htk_compat=False, dither=0.0, dither_seed=0):
         f32 = np.float32
+        self.opts = capi.KhMfccOptions(int(snip_edges), int(use_energy), int(raw_energy), int(htk_compat),
+                                       float(energy_floor), float(dither), int(dither_seed))
         self.frame_shift = int(f32(samp_freq) * f32(0.001) * f32(frame_shift_ms))      # WindowShift() feature-functions.h:119
         self.frame_length = int(f32(samp_freq) * f32(0.001) * f32(frame_length_ms))    # WindowSize()
         self.padded = 1 << int(np.ceil(np.log2(self.frame_length)))                    # PaddedWindowSize()
@@ -432,7 +437,9 @@ class Mfcc:
             self.lifter = (1.0 + 0.5 * q * np.sin(np.pi * np.arange(num_ceps) / q)).astype(np.float32)
 
     def num_frames(self, n_samples):
-        """NumFrames feature-functions.cc:29-48 (snip_edges)."""
+        """NumFrames feature-functions.cc:29-48."""
+        if not self.opts.snip_edges:
+            return int(np.float32(n_samples) * np.float32(1.0) / np.float32(self.frame_shift) + np.float32(0.5))
         return 0 if n_samples < self.frame_length else 1 + (n_samples - self.frame_length) // self.frame_shift
 
     def compute(self, wave):
@@ -442,12 +449,12 @@ class Mfcc:
         out = torch.empty((max(rows, 1), stride), dtype=torch.float32, device=wave.device)[:rows, :self.num_ceps]
         nf = C.c_int32()
         fp, ip = capi.c_float_p, capi.c_int32_p
-        check(lib().kh_mfcc_compute(
+        check(lib().kh_mfcc_compute_opts(
             C.c_void_p(wave.data_ptr()), wave.numel(), self.frame_shift, self.frame_length, self.padded, self.preemph,
             int(self.remove_dc), self.window.ctypes.data_as(fp), self.num_bins, self.mel_first.ctypes.data_as(ip),
             self.mel_off.ctypes.data_as(ip), self.mel_weights.ctypes.data_as(fp), self.num_ceps,
             self.dct.ctypes.data_as(fp), self.lifter.ctypes.data_as(fp) if self.lifter is not None else None,
-            C.c_void_p(out.data_ptr()) if rows else None, stride, C.byref(nf)))
+            C.byref(self.opts), C.c_void_p(out.data_ptr()) if rows else None, stride, C.byref(nf)))
         assert nf.value == rows
         return out
 

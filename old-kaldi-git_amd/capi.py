@@ -37,6 +37,11 @@ class KhDecoderConfig(C.Structure):
     ]
 
 
+class KhMfccOptions(C.Structure):
+    _fields_ = [("snip_edges", C.c_int32), ("use_energy", C.c_int32), ("raw_energy", C.c_int32), ("htk_compat", C.c_int32),
+                ("energy_floor", C.c_float), ("dither", C.c_float), ("dither_seed", C.c_uint64)]
+
+
 class KhIvectorConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "base_dim", "splice_left", "splice_right", "feat_dim", "num_gauss", "ivector_dim", "lda_cols",
@@ -135,6 +140,7 @@ SIGNATURES = {
     "kh_online_decoder_get_raw_lattice": (C.c_int, [vp, C.c_int, C.c_int, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p]),
     "kh_online_decoder_get_best_path": (C.c_int, [vp, C.c_int, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p, c_float_p, c_float_p]),
     "kh_mfcc_compute": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_float_p, C.c_int, c_int32_p, c_int32_p, c_float_p, C.c_int, c_float_p, c_float_p, vp, C.c_int, c_int32_p]),
+    "kh_mfcc_compute_opts": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, c_float_p, C.c_int, c_int32_p, c_int32_p, c_float_p, C.c_int, c_float_p, c_float_p, C.POINTER(KhMfccOptions), vp, C.c_int, c_int32_p]),
     "kh_compute_deltas": (C.c_int, [vp, KhMatrixDim, C.c_int, c_float_p, c_int32_p, vp, C.c_int]),
     "kh_acc_cmvn_stats": (C.c_int, [vp, KhMatrixDim, c_double_p]),
     "kh_determinize_lattice_pruned": (vp, [C.c_int, C.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, C.c_double, C.c_float, C.c_int]),

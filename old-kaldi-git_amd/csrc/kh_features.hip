@@ -29,18 +29,38 @@ MfccKernel(const float *__restrict__ wave, int frame_shift, int frame_length, in
            const float *__restrict__ sin_t, int num_bins, const int32_t *__restrict__ mel_first,
            const int32_t *__restrict__ mel_off, const float *__restrict__ mel_w, int num_ceps,
            const float *__restrict__ dct, const float *__restrict__ lifter, float *__restrict__ out,
-           int out_stride) {
+           int out_stride, int n_samples, KhMfccOptions opt) {
   __shared__ float win[kMaxPadded];
   __shared__ float ct[kMaxPadded], st[kMaxPadded];
   __shared__ float power[kMaxPadded / 2 + 1];
   __shared__ float mel[256];
   __shared__ double red[kThreads / 64];
+  __shared__ float log_energy_s;
   const int r = blockIdx.x;
-  const float *w0 = wave + static_cast<size_t>(frame_shift) * r;
-  // ExtractWindow: copy, remove DC (Sum() accumulates in double), pre-emphasis, window, zero pad
+  // ExtractWindow: copy (snip_edges: frame r starts at r * shift; else it is centred on
+  // shift * (r + 0.5) and the signal extended by reflection, :107-135), dither, remove DC (Sum()
+  // accumulates in double), raw log energy, pre-emphasis, window, zero pad
+  const int begin = opt.snip_edges ? frame_shift * r : static_cast<int>(frame_shift * (r + 0.5)) - frame_length / 2;
   double part = 0.0;
   for (int i = threadIdx.x; i < padded; i += kThreads) {
-    const float v = i < frame_length ? w0[i] : 0.0f;
+    float v = 0.0f;
+    if (i < frame_length) {
+      int f = begin + i;
+      if (f < 0) f = (-f) % n_samples;
+      else if (f >= n_samples) f = n_samples - 1 - (f - n_samples) % n_samples;
+      v = wave[f];
+      if (opt.dither != 0.0f) {
+        // Dither :51-54: RandGauss() * dither per sample of every window (independently for
+        // overlapping frames, as there); counter-based generator instead of rand()
+        uint64_t z = opt.dither_seed + 0x9e3779b97f4a7c15ull * (static_cast<uint64_t>(r) * frame_length + i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        const float u1 = (static_cast<float>(z >> 40) + 1.0f) * (1.0f / 16777216.0f);
+        const float u2 = static_cast<float>((z >> 8) & 0xffffff) * (1.0f / 16777216.0f);
+        v += sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864769f * u2) * opt.dither;
+      }
+    }
     win[i] = v;
     part += v;
     ct[i] = cos_t[i];
@@ -56,6 +76,21 @@ MfccKernel(const float *__restrict__ wave, int frame_shift, int frame_length, in
     for (int i = threadIdx.x; i < frame_length; i += kThreads) win[i] += c;
   }
   __syncthreads();
+  auto log_energy_of = [&](int n) {   // Log(max(VecVec(w, w), FLT_MIN)) :151-155; float products, double sum
+    double e = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) e += static_cast<double>(win[i] * win[i]);
+    e = kh_wave_sum_d(e);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sum = 0.0;
+      for (int i = 0; i < kThreads / 64; i++) sum += red[i];
+      const float ef = static_cast<float>(sum);
+      log_energy_s = logf(ef > 1.17549435e-38f ? ef : 1.17549435e-38f);
+    }
+  };
+  if (opt.use_energy && opt.raw_energy) log_energy_of(frame_length);
   // Preemphasize :61-67 reads the ORIGINAL neighbour (the loop runs from the end): two steps
   float pre[kMaxPadded / kThreads];
   int np = 0;
@@ -65,6 +100,7 @@ MfccKernel(const float *__restrict__ wave, int frame_shift, int frame_length, in
   np = 0;
   for (int i = threadIdx.x; i < frame_length; i += kThreads, np++) win[i] = pre[np] * window[i];
   __syncthreads();
+  if (opt.use_energy && !opt.raw_energy) log_energy_of(padded);   // feature-mfcc.cc:140-142
   // DFT bin k = sum_n x[n] e^{-2 pi i k n / N}; power spectrum (bins 0 .. N/2)
   const int half = padded / 2;
   for (int k = threadIdx.x; k <= half; k += kThreads) {
@@ -94,7 +130,16 @@ MfccKernel(const float *__restrict__ wave, int frame_shift, int frame_length, in
     float s = 0.0f;
     for (int b = 0; b < num_bins; b++) s += dct[c * num_bins + b] * mel[b];
     if (lifter != nullptr) s *= lifter[c];
-    out[static_cast<size_t>(r) * out_stride + c] = s;
+    if (opt.use_energy && c == 0) {   // :167-171
+      s = log_energy_s;
+      if (opt.energy_floor > 0.0f && s < logf(opt.energy_floor)) s = logf(opt.energy_floor);
+    }
+    int col = c;
+    if (opt.htk_compat) {             // :173-182: energy / C0 * sqrt(2) to the last column
+      col = c == 0 ? num_ceps - 1 : c - 1;
+      if (c == 0 && !opt.use_energy) s *= 1.41421356237309504880f;
+    }
+    out[static_cast<size_t>(r) * out_stride + col] = s;
   }
 }
 
@@ -155,13 +200,30 @@ int kh_mfcc_compute(const float *wave, int n_samples, int frame_shift, int frame
                     const int32_t *mel_first_host, const int32_t *mel_off_host, const float *mel_weights_host,
                     int num_ceps, const float *dct_host, const float *lifter_host, float *out, int out_stride,
                     int *num_frames) {
+  KhMfccOptions opt;
+  memset(&opt, 0, sizeof(opt));
+  opt.snip_edges = 1;
+  opt.raw_energy = 1;
+  return kh_mfcc_compute_opts(wave, n_samples, frame_shift, frame_length, padded, preemph_coeff, remove_dc_offset, window_host,
+                              num_bins, mel_first_host, mel_off_host, mel_weights_host, num_ceps, dct_host, lifter_host, &opt,
+                              out, out_stride, num_frames);
+}
+
+int kh_mfcc_compute_opts(const float *wave, int n_samples, int frame_shift, int frame_length, int padded,
+                         float preemph_coeff, int remove_dc_offset, const float *window_host, int num_bins,
+                         const int32_t *mel_first_host, const int32_t *mel_off_host, const float *mel_weights_host,
+                         int num_ceps, const float *dct_host, const float *lifter_host, const KhMfccOptions *options,
+                         float *out, int out_stride, int *num_frames) {
   int rc = EnsureDevice();
   if (rc) return rc;
+  KH_CHECK_ARG(options && n_samples >= 0 && options->dither >= 0.0f && options->energy_floor >= 0.0f);
+  const KhMfccOptions opt = *options;
   KH_CHECK_ARG(wave && window_host && mel_first_host && mel_off_host && mel_weights_host && dct_host && num_frames &&
                frame_shift > 0 && frame_length > 0 && padded >= frame_length && padded <= kMaxPadded &&
                (padded & (padded - 1)) == 0 && num_bins >= 3 && num_bins <= 256 && num_ceps > 0 && num_ceps <= num_bins);
-  // NumFrames feature-functions.cc:29-48 (snip_edges)
-  const int rows = n_samples < frame_length ? 0 : 1 + (n_samples - frame_length) / frame_shift;
+  // NumFrames feature-functions.cc:29-48
+  const int rows = opt.snip_edges ? (n_samples < frame_length ? 0 : 1 + (n_samples - frame_length) / frame_shift)
+                                  : static_cast<int>(n_samples * 1.0f / frame_shift + 0.5f);
   *num_frames = rows;
   if (rows == 0) return KH_OK;
   KH_CHECK_ARG(out && out_stride >= num_ceps);
@@ -185,7 +247,7 @@ int kh_mfcc_compute(const float *wave, int n_samples, int frame_shift, int frame
   if (lifter_host && (rc = d_lift.Up(lifter_host, num_ceps, st))) return rc;
   hipLaunchKernelGGL(MfccKernel, dim3(rows), dim3(kThreads), 0, st, wave, frame_shift, frame_length, padded,
                      preemph_coeff, remove_dc_offset, d_win.p, d_ct.p, d_st.p, num_bins, d_first.p, d_off.p, d_w.p,
-                     num_ceps, d_dct.p, lifter_host ? d_lift.p : nullptr, out, out_stride);
+                     num_ceps, d_dct.p, lifter_host ? d_lift.p : nullptr, out, out_stride, n_samples, opt);
   KH_LAUNCH_CHECK();
   KH_HIP(hipStreamSynchronize(st));
   return KH_OK;

@@ -112,18 +112,18 @@ class OracleLib:
     # ---- feature front-end
     def mfcc_compute(self, wave, samp_freq=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemph_coeff=0.97,
                      remove_dc_offset=True, window_type="povey", num_bins=23, low_freq=20.0, high_freq=0.0,
-                     num_ceps=13, cepstral_lifter=22.0):
-        """Mfcc::Compute (feat/feature-mfcc.cc:96-184), dither 0, use_energy false, snip_edges true."""
+                     num_ceps=13, cepstral_lifter=22.0, snip_edges=True, use_energy=False, raw_energy=True,
+                     energy_floor=0.0, htk_compat=False):
+        """Mfcc::Compute (feat/feature-mfcc.cc:96-184), dither 0."""
         w = _f32(wave).reshape(-1)
         max_rows = len(w) // max(1, int(samp_freq * 0.001 * frame_shift_ms)) + 2
         out = np.empty((max_rows, num_ceps), np.float32)
         args = [_fp(w), C.c_int(len(w)), C.c_float(samp_freq), C.c_float(frame_length_ms), C.c_float(frame_shift_ms),
-                C.c_float(preemph_coeff), C.c_int(int(remove_dc_offset)), C.c_char_p(window_type.encode())]
-        if self.kind == "ref":
-            args.append(C.c_int(1))
-        args += [C.c_int(num_bins), C.c_float(low_freq), C.c_float(high_freq), C.c_int(num_ceps), C.c_float(cepstral_lifter),
-                 _fp(out), C.c_int(num_ceps), C.c_int(max_rows)]
-        rows = self._fn("mfcc_compute")(*args)
+                C.c_float(preemph_coeff), C.c_int(int(remove_dc_offset)), C.c_char_p(window_type.encode()),
+                C.c_int(int(snip_edges)), C.c_int(int(use_energy)), C.c_int(int(raw_energy)), C.c_float(energy_floor),
+                C.c_int(int(htk_compat)), C.c_int(num_bins), C.c_float(low_freq), C.c_float(high_freq), C.c_int(num_ceps),
+                C.c_float(cepstral_lifter), _fp(out), C.c_int(num_ceps), C.c_int(max_rows)]
+        rows = self._fn("mfcc_compute_opts")(*args)
         if rows < 0:
             raise RuntimeError("mfcc_compute failed (%d)" % rows)
         return out[:rows].copy()

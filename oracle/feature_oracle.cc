@@ -104,11 +104,15 @@ int ko_mfcc_tables(float samp_freq, float frame_length_ms, float frame_shift_ms,
   return nw;
 }
 
-// Mfcc::ComputeInternal feature-mfcc.cc:119-184 (use_energy = false), snip_edges = true,
-// dither = 0.  out: rows x num_ceps.
-int ko_mfcc_compute(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
-                    float preemph_coeff, int remove_dc_offset, const char *window_type, int num_bins, float low_freq,
-                    float high_freq, int num_ceps, float cepstral_lifter, float *out, int out_stride, int max_rows) {
+// Mfcc::ComputeInternal feature-mfcc.cc:119-184, dither = 0 (the only random step).
+// snip_edges = 0: frames centred on frame_shift * (r + 0.5), the signal extended by reflection
+// (ExtractWindow :107-135); use_energy: C0 replaced by the log energy, before pre-emphasis and
+// windowing (raw_energy) or of the windowed frame, floored at log(energy_floor) (:138-141,
+// :167-171); htk_compat: the energy / C0 * sqrt(2) moved to the last column (:173-182).
+int ko_mfcc_compute_opts(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
+                         float preemph_coeff, int remove_dc_offset, const char *window_type, int snip_edges, int use_energy,
+                         int raw_energy, float energy_floor, int htk_compat, int num_bins, float low_freq, float high_freq,
+                         int num_ceps, float cepstral_lifter, float *out, int out_stride, int max_rows) {
   int frame_shift, frame_length, padded;
   std::vector<float> window(RoundUpPow2(static_cast<int>(samp_freq * 0.001f * frame_length_ms)) + 8),
       weights(static_cast<size_t>(num_bins) * window.size()), dct(static_cast<size_t>(num_ceps) * num_bins), lifter(num_ceps);
@@ -117,20 +121,37 @@ int ko_mfcc_compute(const float *wave, int n_samples, float samp_freq, float fra
                      cepstral_lifter, &frame_shift, &frame_length, &padded, window.data(), first.data(), off.data(),
                      weights.data(), dct.data(), lifter.data()) < 0)
     return -2;
-  const int rows = ko_num_frames(n_samples, frame_shift, frame_length, 1);
+  const int rows = ko_num_frames(n_samples, frame_shift, frame_length, snip_edges);
   if (rows > max_rows) return -1;
   std::vector<float> win(padded), power(padded / 2 + 1), mel(num_bins);
+  const float fmin = std::numeric_limits<float>::min();
   for (int r = 0; r < rows; r++) {
-    // ExtractWindow :98-167 (snip_edges)
-    const float *w0 = wave + static_cast<size_t>(frame_shift) * r;
-    for (int i = 0; i < frame_length; i++) win[i] = w0[i];
+    // ExtractWindow :98-167
+    if (snip_edges) {
+      const float *w0 = wave + static_cast<size_t>(frame_shift) * r;
+      for (int i = 0; i < frame_length; i++) win[i] = w0[i];
+    } else {
+      const int mid = static_cast<int>(frame_shift * (r + 0.5)), begin = mid - frame_length / 2;
+      for (int i = 0; i < frame_length; i++) {
+        const int f = begin + i;
+        int src = f;
+        if (f < 0) src = (-f) % n_samples;
+        else if (f >= n_samples) src = n_samples - 1 - (f - n_samples) % n_samples;
+        win[i] = wave[src];
+      }
+    }
     if (remove_dc_offset) {  // window_part.Add(-window_part.Sum() / frame_length)
-      float sum = 0.0f;      // VectorBase::Sum kaldi-vector.cc: double accumulation, float result
-      double dsum = 0.0;
+      double dsum = 0.0;     // VectorBase::Sum kaldi-vector.cc: double accumulation, float result
       for (int i = 0; i < frame_length; i++) dsum += win[i];
-      sum = static_cast<float>(dsum);
+      const float sum = static_cast<float>(dsum);
       const float c = -sum / frame_length;
       for (int i = 0; i < frame_length; i++) win[i] += c;
+    }
+    float log_energy = 0.0f;
+    if (use_energy && raw_energy) {  // :151-155 (VecVec: float dot product)
+      float e = 0.0f;
+      for (int i = 0; i < frame_length; i++) e += win[i] * win[i];
+      log_energy = logf(e > fmin ? e : fmin);
     }
     if (preemph_coeff != 0.0f) {  // Preemphasize :61-67
       for (int i = frame_length - 1; i > 0; i--) win[i] -= preemph_coeff * win[i - 1];
@@ -138,6 +159,11 @@ int ko_mfcc_compute(const float *wave, int n_samples, float samp_freq, float fra
     }
     for (int i = 0; i < frame_length; i++) win[i] *= window[i];
     for (int i = frame_length; i < padded; i++) win[i] = 0.0f;
+    if (use_energy && !raw_energy) {  // feature-mfcc.cc:140-142
+      float e = 0.0f;
+      for (int i = 0; i < padded; i++) e += win[i] * win[i];
+      log_energy = logf(e > fmin ? e : fmin);
+    }
     // srfft_->Compute + ComputePowerSpectrum :186-207: |X_k|^2, k = 0 .. N/2
     for (int k = 0; k <= padded / 2; k++) {
       double re = 0.0, im = 0.0;
@@ -153,18 +179,37 @@ int ko_mfcc_compute(const float *wave, int n_samples, float samp_freq, float fra
     for (int b = 0; b < num_bins; b++) {
       float e = 0.0f;
       for (int i = off[b]; i < off[b + 1]; i++) e += weights[i] * power[first[b] + (i - off[b])];
-      if (e < std::numeric_limits<float>::min()) e = std::numeric_limits<float>::min();
+      if (e < fmin) e = fmin;
       mel[b] = logf(e);
     }
     // this_mfcc = dct_matrix_ * mel_energies; MulElements(lifter)
+    float *row = out + static_cast<size_t>(r) * out_stride;
     for (int c = 0; c < num_ceps; c++) {
       float s = 0.0f;
       for (int b = 0; b < num_bins; b++) s += dct[c * num_bins + b] * mel[b];
       if (cepstral_lifter != 0.0f) s *= lifter[c];
-      out[static_cast<size_t>(r) * out_stride + c] = s;
+      row[c] = s;
+    }
+    if (use_energy) {  // :167-171
+      if (energy_floor > 0.0f && log_energy < logf(energy_floor)) log_energy = logf(energy_floor);
+      row[0] = log_energy;
+    }
+    if (htk_compat) {  // :173-182
+      float energy = row[0];
+      for (int i = 0; i < num_ceps - 1; i++) row[i] = row[i + 1];
+      if (!use_energy) energy *= static_cast<float>(M_SQRT2);
+      row[num_ceps - 1] = energy;
     }
   }
   return rows;
+}
+
+int ko_mfcc_compute(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
+                    float preemph_coeff, int remove_dc_offset, const char *window_type, int num_bins, float low_freq,
+                    float high_freq, int num_ceps, float cepstral_lifter, float *out, int out_stride, int max_rows) {
+  return ko_mfcc_compute_opts(wave, n_samples, samp_freq, frame_length_ms, frame_shift_ms, preemph_coeff, remove_dc_offset,
+                              window_type, 1, 0, 1, 0.0f, 0, num_bins, low_freq, high_freq, num_ceps, cepstral_lifter, out,
+                              out_stride, max_rows);
 }
 
 // DeltaFeatures scales :210-242; returns the length of scales[order] (all orders are

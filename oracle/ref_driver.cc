@@ -431,10 +431,10 @@ float ref_log_sum_exp(const float *v, int dim, float prune) {
 // ---- feature front-end: Mfcc::Compute feat/feature-mfcc.cc:96-184,
 // ComputeDeltas feat/feature-functions.cc:361-372, AccCmvnStats / ApplyCmvn
 // transform/cmvn.cc:49-113.  dither is forced to 0 (the only random step).
-int ref_mfcc_compute(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
-                     float preemph_coeff, int remove_dc_offset, const char *window_type, int snip_edges,
-                     int num_bins, float low_freq, float high_freq, int num_ceps, float cepstral_lifter,
-                     float *out, int out_stride, int max_rows) {
+int ref_mfcc_compute_opts(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
+                          float preemph_coeff, int remove_dc_offset, const char *window_type, int snip_edges, int use_energy,
+                          int raw_energy, float energy_floor, int htk_compat, int num_bins, float low_freq, float high_freq,
+                          int num_ceps, float cepstral_lifter, float *out, int out_stride, int max_rows) {
   MfccOptions opts;
   opts.frame_opts.samp_freq = samp_freq;
   opts.frame_opts.frame_length_ms = frame_length_ms;
@@ -449,7 +449,10 @@ int ref_mfcc_compute(const float *wave, int n_samples, float samp_freq, float fr
   opts.mel_opts.high_freq = high_freq;
   opts.num_ceps = num_ceps;
   opts.cepstral_lifter = cepstral_lifter;
-  opts.use_energy = false;
+  opts.use_energy = use_energy != 0;
+  opts.raw_energy = raw_energy != 0;
+  opts.energy_floor = energy_floor;
+  opts.htk_compat = htk_compat != 0;
   Mfcc mfcc(opts);
   Vector<BaseFloat> w(n_samples);
   memcpy(w.Data(), wave, sizeof(float) * n_samples);
@@ -458,6 +461,15 @@ int ref_mfcc_compute(const float *wave, int n_samples, float samp_freq, float fr
   if (feats.NumRows() > max_rows) return -1;
   if (feats.NumRows() > 0) Out(feats, out, out_stride);
   return feats.NumRows();
+}
+
+int ref_mfcc_compute(const float *wave, int n_samples, float samp_freq, float frame_length_ms, float frame_shift_ms,
+                     float preemph_coeff, int remove_dc_offset, const char *window_type, int snip_edges,
+                     int num_bins, float low_freq, float high_freq, int num_ceps, float cepstral_lifter,
+                     float *out, int out_stride, int max_rows) {
+  return ref_mfcc_compute_opts(wave, n_samples, samp_freq, frame_length_ms, frame_shift_ms, preemph_coeff, remove_dc_offset,
+                               window_type, snip_edges, 0, 1, 0.0f, 0, num_bins, low_freq, high_freq, num_ceps,
+                               cepstral_lifter, out, out_stride, max_rows);
 }
 
 void ref_compute_deltas(const float *in, int rows, int cols, int in_stride, int order, int window, float *out,

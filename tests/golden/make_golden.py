@@ -162,12 +162,14 @@ def make_features():
     deltas, CMVN statistics and normalised features."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-    from test_feature_oracle import MFCC_CONFIGS, wave
+    from test_feature_oracle import MFCC_CONFIGS, MFCC_OPTION_CASES, wave
     ref = binding.OracleLib("ref")
     w = wave(7)
     out = dict(wave=w)
     for name, cfg in MFCC_CONFIGS.items():
         out["mfcc_" + name] = ref.mfcc_compute(w, **cfg)
+    for name, kw in MFCC_OPTION_CASES.items():
+        out["mfcc_opt_" + name] = ref.mfcc_compute(w, **kw)
     x = out["mfcc_mfcc13"]
     out["deltas"] = ref.compute_deltas(x, 2, 2)
     out["cmvn_stats"] = ref.acc_cmvn_stats(x)

@@ -15,6 +15,16 @@ MFCC_CONFIGS = {
     # conf/mfcc_hires.conf (egs/librispeech/s5/conf/mfcc_hires.conf): 40 bins, 40 ceps, 40 .. -200 Hz
     "hires40": dict(num_bins=40, num_ceps=40, low_freq=40.0, high_freq=-200.0),
 }
+# MfccOptions / FrameExtractionOptions beyond the recipe defaults (feat/feature-mfcc.h:41-56,
+# feature-functions.h:77-96): energy instead of C0 (the Kaldi default use_energy = true), energy of the
+# windowed frame, an energy floor that binds, frames over the edges, HTK column order
+MFCC_OPTION_CASES = {
+    "energy": dict(use_energy=True),
+    "energy_windowed_floor": dict(use_energy=True, raw_energy=False, energy_floor=3.0e9),
+    "no_snip": dict(snip_edges=False),
+    "no_snip_energy_htk": dict(snip_edges=False, use_energy=True, htk_compat=True),
+    "htk": dict(htk_compat=True),
+}
 
 
 def wave(seed, n=16000 * 2 + 137):
@@ -39,6 +49,16 @@ def test_golden_mfcc(name):
     check_mfcc(ko.mfcc_compute(g["wave"], **MFCC_CONFIGS[name]), g["mfcc_" + name])
 
 
+@pytest.mark.parametrize("name", sorted(MFCC_OPTION_CASES))
+def test_golden_mfcc_options(name):
+    g = np.load(GOLDEN)
+    ko = B.OracleLib("ko")
+    got = ko.mfcc_compute(g["wave"], **MFCC_OPTION_CASES[name])
+    check_mfcc(got, g["mfcc_opt_" + name])
+    if "energy_floor" in MFCC_OPTION_CASES[name]:
+        assert (got[:, 0] == np.log(np.float32(3.0e9))).sum() > 5      # the floor binds on some frames
+
+
 def test_golden_deltas_and_cmvn():
     g = np.load(GOLDEN)
     ko = B.OracleLib("ko")
@@ -60,6 +80,11 @@ def test_against_compiled_reference_on_fresh_input():
     for wt in ("hamming", "hanning", "rectangular"):
         check_mfcc(ko.mfcc_compute(w, window_type=wt, remove_dc_offset=False, preemph_coeff=0.0),
                    ref.mfcc_compute(w, window_type=wt, remove_dc_offset=False, preemph_coeff=0.0))
+    for kw in MFCC_OPTION_CASES.values():
+        check_mfcc(ko.mfcc_compute(w, **kw), ref.mfcc_compute(w, **kw))
+    short = w[:333]                       # shorter than a frame: snip_edges = false reflects modulo the length
+    check_mfcc(ko.mfcc_compute(short, snip_edges=False), ref.mfcc_compute(short, snip_edges=False))
+    assert ko.mfcc_compute(short).shape[0] == 0
     x = ref.mfcc_compute(w)
     for order, window in ((2, 2), (3, 1), (1, 3)):
         assert np.abs(ko.compute_deltas(x, order, window) - ref.compute_deltas(x, order, window)).max() < 1e-5

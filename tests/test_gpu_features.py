@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import binding as B
-from test_feature_oracle import GOLDEN, MFCC_CONFIGS, check_mfcc, wave
+from test_feature_oracle import GOLDEN, MFCC_CONFIGS, MFCC_OPTION_CASES, check_mfcc, wave
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +41,47 @@ def test_mfcc_options_and_edges(api):
         api.Mfcc(window_type="triangular")
     with pytest.raises(api.KhError):
         api.Mfcc(low_freq=9000.0)
+
+
+@pytest.mark.parametrize("name", sorted(MFCC_OPTION_CASES))
+def test_mfcc_energy_snip_edges_htk(api, name):
+    """use_energy / raw_energy / energy_floor / snip_edges = false / htk_compat against the
+    reference's own output (golden) and the oracle on a fresh waveform."""
+    kw = MFCC_OPTION_CASES[name]
+    g = np.load(GOLDEN)
+    mf = api.Mfcc(**kw)
+    got = mf.compute(torch.from_numpy(g["wave"]).cuda()).cpu().numpy()
+    check_mfcc(got, g["mfcc_opt_" + name])
+    ko = B.OracleLib("ko")
+    for n in (16000 + 77, 333, 1):                     # 333, 1: shorter than a frame
+        w = wave(11, 16000 + 77)[:n]
+        want = ko.mfcc_compute(w, **kw)
+        got = mf.compute(torch.from_numpy(w).cuda()).cpu().numpy()
+        assert got.shape[0] == want.shape[0] == mf.num_frames(n)
+        if want.shape[0]:
+            check_mfcc(got, want)
+
+
+def test_mfcc_dither(api):
+    """Dither (feature-functions.cc:51-54) adds N(0, dither^2) to every sample of every window.  The
+    reference draws from rand(), so the check is distributional: on a zero waveform with
+    remove_dc_offset / pre-emphasis off and a rectangular window the raw energy of a frame is
+    dither^2 * chi^2(frame_length); seeds differ, the same seed repeats, dither = 0 is exact."""
+    n = 16000
+    z = torch.zeros(n, device="cuda")
+    kw = dict(use_energy=True, remove_dc_offset=False, preemph_coeff=0.0, window_type="rectangular")
+    a = api.Mfcc(dither=2.0, dither_seed=1, **kw).compute(z).cpu().numpy()
+    b = api.Mfcc(dither=2.0, dither_seed=1, **kw).compute(z).cpu().numpy()
+    c = api.Mfcc(dither=2.0, dither_seed=2, **kw).compute(z).cpu().numpy()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    e = np.exp(a[:, 0].astype(np.float64)) / 4.0       # chi^2 with 400 degrees of freedom per frame
+    assert abs(e.mean() - 400.0) < 4 * np.sqrt(800.0 / len(e)) and 0.5 * 800.0 < e.var() < 1.6 * 800.0
+    w = wave(3, 8000)
+    ko = B.OracleLib("ko")
+    clean = api.Mfcc().compute(torch.from_numpy(w).cuda()).cpu().numpy()
+    check_mfcc(clean, ko.mfcc_compute(w))
+    noisy = api.Mfcc(dither=1.0, dither_seed=5).compute(torch.from_numpy(w).cuda()).cpu().numpy()
+    assert 0 < np.abs(noisy - clean).max() < 0.5       # dither 1.0 on a signal of amplitude ~3000: tiny change
 
 
 def test_deltas_and_cmvn(api):
