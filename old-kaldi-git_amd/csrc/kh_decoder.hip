@@ -195,6 +195,7 @@ struct Params {
   int32_t start, num_states, num_emit, num_eps, start_has_eps;
   int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
   Arr<const int32_t> tid2pdf;
+  Arr<const int32_t> e_pdf;  // [num_emit] tid2pdf[ilabel] of every emitting arc (rebuilt per call), or null
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
@@ -264,6 +265,8 @@ struct Shared {
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
   int link_cursor;  // ExpandSweepFiltered: next free link slot (LDS atomic, one add per wave)
+  int work_cursor;  // ExpandWavesFiltered: next unclaimed token
+  uint32_t bound_enc;  // ExpandWavesFiltered: Enc(upper bound of the final next_cutoff), atomic min
   float wbound[2][NW];  // ExpandSweepFiltered: per-wave minima of the cutoff estimate, double buffered
   int front_b;  // first token of the frame under construction (frontier)
   int status;
@@ -622,106 +625,105 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off,
   return lrun;
 }
 
-// ExpandSweep for the emitting arcs with a FILTER: eval(token, arc index) computes the
-// candidate and says whether it can still be accepted; only those get a link slot (store(slot)),
-// appended per wave through one LDS atomic (ballot + prefix count), so the slots of a frame are
-// dense.  The reference materialises nothing it rejects either (:731 "continue"); here a
-// candidate is known to be rejected when it is above an upper bound of the frame's final
-// next_cutoff.  Returns the new end of the link arena, or -1 on overflow (sh->status set).
-template <int kLU, class Load, class Finish, class Store>
-__device__ __forceinline__ int ExpandSweepFiltered(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
+// ExpandSweep for the emitting arcs with a FILTER: load(token, cost image, arc index) fetches the
+// candidate, finish() computes it and says whether it can still be accepted; only those get a
+// link slot (store(slot)), appended per wave through one LDS atomic (ballot + prefix count), so
+// the slots of a frame are dense.  The reference materialises nothing it rejects either (:731
+// "continue"); here a candidate is known to be rejected when it is above an upper bound of the
+// frame's final next_cutoff.  Returns the new end of the link arena, or -1 on overflow
+// (sh->status set).
+//
+// INDEPENDENT waves: no workgroup barrier inside the sweep.  A wave
+// claims 64 tokens at a time from an LDS cursor, scans their arc counts with shuffles, and maps
+// arc slot -> (token, arc) by a 6-step search over the wave's own prefix sums (ds_bpermute; the
+// workgroup version searches 2048 entries in LDS behind two barriers per group).  Waves are at
+// different stages at any time, so the token / offset / arc round trips of one overlap the
+// arithmetic of the others.  The bound is shared through one LDS word (atomic min on the
+// order-preserving image): a wave reads it when it claims tokens and lowers it after each
+// claim; any stale value is still an upper bound of the final next_cutoff.
+template <class Load, class Finish, class Store>
+__device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
                                                    int frame_cap, long long *arcs, Blk &sh, float *est, float *bound, Load load,
                                                    Finish finish, Store store) {
   const int limit = min(u.link_cap, lrun + frame_cap);
   const int lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) sh->link_cursor = lrun;  // (visible behind the first group's scan barrier)
-  for (int base = b; base < e; base += NT * EU) {
-    int i[EU], st[EU];
-    uint32_t co[EU];
-    bool in_range[EU];
-#pragma unroll
-    for (int k = 0; k < EU; k++) {
-      i[k] = base + k * NT + threadIdx.x;
-      in_range[k] = i[k] < e;
-      const int ic = min(i[k], e - 1);
-      co[k] = LoadCostEnc(&u.tok_cost[ic]);
-      st[k] = u.tok_state[ic];
-      KH_BOUND(1, st[k], 0, 0x7ffffff0);
+  if (threadIdx.x == 0) {
+    sh->link_cursor = lrun;
+    sh->work_cursor = b;
+    sh->bound_enc = Enc(*bound);
+  }
+  KhSync();
+  uint32_t my_bound_enc = Enc(*bound);
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(&sh->work_cursor, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = Uni(base);
+    if (base >= e) break;
+    const int i = base + lane;
+    const bool in_range = i < e;
+    const int ic = min(i, e - 1);
+    const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
+    const int st = u.tok_state[ic];
+    KH_BOUND(1, st, 0, 0x7ffffff0);
+    const bool need = in_range && Dec(co) <= cutoff;
+    int ab = 0, cnt = 0;
+    if (need) {
+      ab = off[st];
+      cnt = off[st + 1] - ab;
     }
-    int ab[EU], cnt[EU];
+    int inc = cnt;
 #pragma unroll
-    for (int k = 0; k < EU; k++) {
-      const bool need = in_range[k] && Dec(co[k]) <= cutoff;
-      ab[k] = 0;
-      cnt[k] = 0;
-      if (need) {
-        ab[k] = off[st[k]];
-        cnt[k] = off[st[k] + 1] - ab[k];
-      }
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += n;
     }
-    int loff[EU], total;
-    // the bound tightens from group to group: the minimum of the estimate over everything the
-    // workgroup has seen so far rides on the scan's barrier
-    const int wb = ((base - b) / (NT * EU)) & 1;
+    const int loff = inc - cnt;
+    const int total = __shfl(inc, 63, 64);
     {
-      const float wm = kh_wave_min(*est);
-      if (lane == 0) sh->wbound[wb][threadIdx.x >> 6] = wm;
+      const uint32_t be = Uni(__hip_atomic_load(&sh->bound_enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      *bound = fminf(*bound, Dec(be));
+      my_bound_enc = min(my_bound_enc, be);
     }
-    // (this barrier also orders the previous group's LDS reads before the writes below)
-    BlockExScanK<EU>(cnt, loff, &total, sh);
-    {
-      float m = sh->wbound[wb][0];
+    for (int q0 = 0; q0 < total; q0 += 64) {  // uniform over the wave
+      const int q = q0 + lane;
+      const bool valid = q < total;
+      // owner = the LAST token whose first slot is <= q (tokens without arcs share their
+      // successor's first slot and are skipped by "last"); every lane takes part in the shuffles
+      int lo = 0, hi = 63;
 #pragma unroll
-      for (int w = 1; w < NW; w++) m = fminf(m, sh->wbound[wb][w]);
-      *bound = fminf(*bound, Uni(m));
-    }
-#pragma unroll
-    for (int k = 0; k < EU; k++) {  // slice-major item order = the scan's order: ex_off is non-decreasing
-      sh->ex_off[k * NT + threadIdx.x] = loff[k];
-      sh->ex_ab[k * NT + threadIdx.x] = ab[k];
-      sh->ex_tok[k * NT + threadIdx.x] = i[k];
-    }
-    KhSync();
-    for (int q0 = 0; q0 < total; q0 += NT * kLU) {  // uniform trip count (wave ballots inside)
-      // kLU candidates per lane: their arc and cost loads are all issued (load) before the
-      // first dependent step (finish), so that a lane has kLU random fetches in flight
-      bool valid[kLU], keep[kLU];
-#pragma unroll
-      for (int k = 0; k < kLU; k++) {
-        const int q = q0 + k * NT + threadIdx.x;
-        valid[k] = q < total;
-        keep[k] = false;
-        if (valid[k]) {
-          // owner = the LAST item whose first slot is <= q (items without arcs share their
-          // successor's first slot and are skipped by "last")
-          int lo = 0, hi = EU * NT - 1;
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (sh->ex_off[mid] <= q) lo = mid; else hi = mid - 1;
-          }
-          load(k, sh->ex_tok[lo], sh->ex_ab[lo] + (q - sh->ex_off[lo]));
-        }
+      for (int step = 0; step < 6; step++) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int v = __shfl(loff, mid, 64);
+        if (v <= q) lo = mid; else hi = mid - 1;
       }
-#pragma unroll
-      for (int k = 0; k < kLU; k++)
-        if (valid[k]) keep[k] = finish(k);
-#pragma unroll
-      for (int k = 0; k < kLU; k++) {
-        const unsigned long long kb = __ballot(keep[k]);
-        if (kb != 0ull) {
-          const int n_keep = __popcll(kb);
-          int pos = 0;
-          if (lane == 0) pos = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          pos = Uni(pos);
-          if (pos + n_keep > limit) {
-            if (lane == 0) sh->status = (pos + n_keep > u.link_cap) ? 2 : 3;
-          } else if (keep[k]) {
-            store(k, pos + __popcll(kb & ((1ull << lane) - 1ull)));
-          }
+      const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64);
+      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      bool keep = false;
+      if (valid) {
+        load(0, base + lo, o_co, o_ab + (q - o_off));
+        keep = finish(0);
+      }
+      const unsigned long long kb = __ballot(keep);
+      if (kb != 0ull) {
+        const int n_keep = __popcll(kb);
+        int pos = 0;
+        if (lane == 0) pos = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pos = Uni(pos);
+        if (pos + n_keep > limit) {
+          if (lane == 0) sh->status = (pos + n_keep > u.link_cap) ? 2 : 3;
+        } else if (keep) {
+          store(0, pos + __popcll(kb & ((1ull << lane) - 1ull)));
         }
       }
     }
-    if (threadIdx.x == 0) *arcs += total;
+    if (lane == 0) *arcs += total;
+    {
+      const uint32_t we = Enc(kh_wave_min(*est));
+      if (we < my_bound_enc) {
+        my_bound_enc = we;
+        if (lane == 0) __hip_atomic_fetch_min(&sh->bound_enc, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
   }
   KhSync();  // the links are visible to the next phase
   if (Uni(sh->status) != 0) return -1;
@@ -1013,20 +1015,21 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   long long my_arcs = 0;
   constexpr int kLU = 1;  // (2 in flight per lane: no gain, +16 B of scratch per lane)
   KhInt4 c_arc[kLU];
-  int c_src[kLU];
+  int c_src[kLU], c_pdf[kLU];
   uint32_t c_co[kLU];
   float c_ac[kLU], c_tot[kLU];
-  const int link_frame_e = ExpandSweepFiltered<kLU>(
+  const int link_frame_e = ExpandWavesFiltered(
       u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
-      [&](int k, int src, int ai) {
+      [&](int k, int src, uint32_t src_cost, int ai) {
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_emit);
         c_arc[k] = p.e_arcs[ai];
+        c_pdf[k] = p.e_pdf ? p.e_pdf[ai] : -1;
         c_src[k] = src;
-        c_co[k] = LoadCostEnc(&u.tok_cost[src]);
+        c_co[k] = src_cost;
       },
       [&](int k) -> bool {
-        int32_t pdf = p.tid2pdf ? p.tid2pdf[c_arc[k].x] : c_arc[k].x - 1;
+        int32_t pdf = p.e_pdf ? c_pdf[k] : (p.tid2pdf ? p.tid2pdf[c_arc[k].x] : c_arc[k].x - 1);
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
         c_ac[k] = cost_offset - like;
@@ -2237,6 +2240,8 @@ struct KhDecoder {
   UttOut *d_out = nullptr;
   unsigned long long *d_used = nullptr;
   long long *d_phase = nullptr;
+  int32_t *e_pdf = nullptr;        // BuildArcPdf
+
   // lattice pool
   void *pool_slab = nullptr;
   size_t pool_bytes = 0;
@@ -2650,6 +2655,28 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
   return KH_OK;
 }
 
+// pdf of every emitting arc: the expansion then reads it next to the arc (coalesced) instead of
+// gathering tid2pdf[ilabel] (64 distinct cache lines per wave instruction).  Rebuilt on every
+// call: the map is the caller's and may change between calls; one pass over the arcs (~20 us).
+__global__ void ArcPdfKernel(const KhInt4 *__restrict__ arcs, long long n, const int32_t *__restrict__ tid2pdf, int32_t *__restrict__ out) {
+  for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x)
+    out[a] = tid2pdf[arcs[a].x];
+}
+
+int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, hipStream_t st) {
+  p->e_pdf = (GP(const int32_t))nullptr;
+  if (tid2pdf == nullptr || d->fst->num_emit == 0) return KH_OK;
+  if (d->e_pdf == nullptr) {
+    d->e_pdf = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * d->fst->num_emit));
+    if (d->e_pdf == nullptr) return KH_OK;   // no memory to spare: the kernel gathers tid2pdf as before
+  }
+  hipLaunchKernelGGL(ArcPdfKernel, dim3(NumCUs() * 8), dim3(256), 0, st, (const KhInt4 *)d->fst->e_arcs,
+                     static_cast<long long>(d->fst->num_emit), tid2pdf, d->e_pdf);
+  KH_LAUNCH_CHECK();
+  p->e_pdf = (GP(const int32_t))d->e_pdf;
+  return KH_OK;
+}
+
 void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *tid2pdf) {
   Params &p = *pp;
   p.e_off = (GP(const int32_t))d->fst->e_off;
@@ -2667,6 +2694,7 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.tid2pdf = (GP(const int32_t))tid2pdf;
+  p.e_pdf = (GP(const int32_t))nullptr;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
   p.lattice_beam = d->cfg.lattice_beam;
@@ -3004,6 +3032,7 @@ void kh_decoder_destroy(KhDecoder *d) {
   PoolFree(d->d_out);
   PoolFree(d->d_used);
   PoolFree(d->d_phase);
+  PoolFree(d->e_pdf);
   if (d->hp_slab) (void)hipHostFree(d->hp_slab);
   if (d->h_out_pinned) (void)hipHostFree(d->h_out_pinned);
   if (d->h_done) (void)hipHostFree(d->h_done);
@@ -3063,6 +3092,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
                    [&](int a, int b) { return d->h_T[a] > d->h_T[b]; });
   Params p;
   FillParams(d, &p, ll_stride, tid2pdf);
+  if ((rc = BuildArcPdf(d, &p, tid2pdf, Stream()))) return rc;
   if (!d->ev0) {
     KH_HIP(hipEventCreate(&d->ev0));
     KH_HIP(hipEventCreate(&d->ev1));
@@ -3480,6 +3510,10 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   Params p;
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   if (ll_stride <= 0) p.ll_cols = 0;
+  {
+    const int rc = BuildArcPdf(b, &p, tid2pdf, st);
+    if (rc) return rc;
+  }
   KH_HIP(hipMemcpyAsync(o->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(OnlineKernel, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), DynLdsBytes(p.ll_cols), st,
                      b->d_slots, o->d_states, o->d_jobs, b->d_out, b->pool, p);
