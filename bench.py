@@ -154,6 +154,67 @@ def _cpu_decode_one(binding, fwd, net, priors, g, x):
     return t_fwd
 
 
+def _cpu_secondary(binding, fwd):
+    """1-thread CPU samples of BASELINE.json configs 2, 3, 5 (the GPU side: tools/bench_secondary.py),
+    a few seconds each: the numbers of BASELINE.md section 2 point 5."""
+    workloads = importlib.import_module(PKG + ".workloads")
+    out = {}
+    ko = binding.OracleLib("ko")
+    # config 2: frame x pdf matrix of rm-tri1-sized GMMs (DiagGmm::LogLikelihoods + LogSumExp per pdf)
+    rng = np.random.default_rng(1)
+    am = workloads.make_am_gmm(rng, 1800, 9000, 39)
+    mi, iv = workloads.gmm_inv_params(am)
+    gc, _ = ko.gmm_compute_gconsts(am["weights"], mi, iv)
+    x = rng.standard_normal((1200, 39)).astype(np.float32)
+    t0 = time.perf_counter()
+    ko.am_gmm_loglikes(x, gc, mi, iv, am["pdf_offsets"])
+    dt = time.perf_counter() - t0
+    out["gmm_cfg2"] = {"frames_per_s": len(x) / dt, "kind": "port", "cores": 1,
+                       "sample": "%d frames x 39 dims, 1800 pdfs / 9000 Gaussians, %.1f s" % (len(x), dt)}
+    # config 3: wsj nnet5d p-norm forward (the reference's compiled code when present)
+    rng = np.random.default_rng(2)
+    net3, priors3 = workloads.wsj_nnet5d(rng)
+    x = rng.standard_normal((1500, 40)).astype(np.float32)
+    t0 = time.perf_counter()
+    fwd.decodable_am_nnet(net3, priors3, 0.1, x)
+    dt = time.perf_counter() - t0
+    out["nnet_cfg3"] = {"frames_per_s": len(x) / dt, "kind": "reference" if fwd.kind == "ref" else "port", "cores": 1,
+                        "sample": "forward of %d frames, %.1f s" % (len(x), dt)}
+    # config 5: lattice forward-backward (denominator lattices: structured graph, lattice-beam 8)
+    rng = np.random.default_rng(5)
+    P, T, N = 600, 200, 6
+    g5 = workloads.make_hclg_structured(rng, 60_000, P)
+    seqs = workloads.sample_paths(rng, g5, [T] * N)
+    dec = binding.DecoderOracle(g5, binding.decoder_config(beam=13.0, max_active=7000, min_active=200, lattice_beam=8.0),
+                                mode="canonical")
+    csrs, alis = [], []
+    for q in seqs:
+        ll = (rng.standard_normal((T, P)) * 0.28 - 0.37).astype(np.float32)
+        ll[np.arange(T), q] = (0.5 + 0.3 * rng.standard_normal(T)).astype(np.float32)
+        dec.decode(ll)
+        csrs.append(binding.lattice_csr(dec.raw_lattice()))
+        alis.append(np.asarray(dec.best_path()["alignment"], np.int32))
+    arcs = sum(len(c["arc_ilabel"]) for c in csrs)
+    reps = 100
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for c in csrs:
+            binding.lattice_forward_backward(c)
+    dt = (time.perf_counter() - t0) / reps
+    ntid = len(g5["tid2pdf"]) - 1
+    t2ph = np.concatenate([[0], 1 + (np.arange(ntid) // 6) % 40]).astype(np.int32)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        for c, a in zip(csrs, alis):
+            binding.lattice_forward_backward_mpe(c, t2ph, g5["tid2pdf"], [1, 2], a, "smbr")
+    dt_mpe = (time.perf_counter() - t1) / reps
+    out["lattice_fb_cfg5"] = {"arcs_per_s": arcs / dt, "frames_per_s": N * T / dt, "smbr_arcs_per_s": arcs / dt_mpe,
+                              "kind": "port", "cores": 1,
+                              "sample": "%d lattices x %d frames, %d arcs, %d repetitions: LatticeForwardBackward %.2f ms, "
+                                        "sMBR variant %.2f ms per pass" % (N, T, arcs, reps, dt * 1e3, dt_mpe * 1e3)}
+    return out
+
+
 def cpu_baseline_child(rfd, wfd, net, priors, g, feats, off, n_utts_1t):
     """Runs in a process forked BEFORE the parent initialised the GPU (it never touches
     one): waits for the parent's go (the GPU timing is over), then times the reference
@@ -223,6 +284,11 @@ def cpu_baseline_child(rfd, wfd, net, priors, g, feats, off, n_utts_1t):
         out["all_cores"] = ({"value": tot_all / el_all, "unit": "frames/s", "cores": n_proc,
                              "sample": "%d median-length utterances (%d frames), one per process on %d host cores, %.1f s"
                                        % (n_proc, tot_all, cores, el_all)} if ok else None)
+        if not os.environ.get("BENCH_NO_CPU_SECONDARY"):
+            try:
+                out["secondary"] = _cpu_secondary(binding, fwd)
+            except Exception as e:  # never fails the headline baseline
+                out["secondary"] = {"error": repr(e)}
     except BaseException as e:  # the parent reports the failure
         out = {"error": repr(e)}
     finally:
