@@ -774,10 +774,22 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   }
   const float beam_cutoff = best_weight + p.beam;
   float min_active_cutoff = inf, max_active_cutoff = inf;
+  // The k-th smallest costs (nth_element :622-648) only matter when they bind, and one count
+  // decides both: with m = #{cost <= beam_cutoff}, the element at sorted index max_active is
+  // > beam_cutoff when m <= max_active (the max-active branch is not taken), and the element at
+  // sorted index min_active is <= beam_cutoff when m > min_active (the beam branch is taken).
+  int within = 0;
+  {
+    const uint32_t bc = Enc(beam_cutoff);
+    for (int i = b + threadIdx.x; i < e; i += NT) within += LoadCostEnc(&u.tok_cost[i]) <= bc ? 1 : 0;
+    within = static_cast<int>(BlockSumLL(within, sh));
+  }
   // largest cost image of the frame (the smallest is the best cost): bounds the bits the selection looks at
-  kmax = ~static_cast<uint32_t>(BlockMinU64(static_cast<unsigned long long>(~kmax), sh));
   const uint32_t kmin = static_cast<uint32_t>(best >> 32);
-  if (n > p.max_active) max_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.max_active, kmin, kmax, sh));
+  const bool need_max = n > p.max_active && within > p.max_active;
+  const bool need_min = n > p.min_active && p.min_active != 0 && within <= p.min_active;
+  if (need_max || need_min) kmax = ~static_cast<uint32_t>(BlockMinU64(static_cast<unsigned long long>(~kmax), sh));
+  if (need_max) max_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.max_active, kmin, kmax, sh));
   if (max_active_cutoff < beam_cutoff) {
     c.adaptive_beam = max_active_cutoff - best_weight + p.beam_delta;
     c.cur_cutoff = max_active_cutoff;
@@ -785,7 +797,8 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   }
   if (n > p.min_active) {
     if (p.min_active == 0) min_active_cutoff = best_weight;
-    else min_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.min_active, kmin, kmax, sh));
+    else if (need_min) min_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.min_active, kmin, kmax, sh));
+    else min_active_cutoff = beam_cutoff;  // (some value <= beam_cutoff: the beam branch below)
   }
   if (min_active_cutoff > beam_cutoff) {
     c.adaptive_beam = min_active_cutoff - best_weight + p.beam_delta;
