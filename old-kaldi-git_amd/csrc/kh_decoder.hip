@@ -1086,6 +1086,18 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     auto vals = LdsVals(sh);
     const float nan = __int_as_float(0x7fc00000);
     auto part_of = [](uint32_t h, int parts) { return static_cast<int>(((h >> 12) * static_cast<uint32_t>(parts)) >> 20); };
+    // LOCALITY: the table is hashed by BLOCKS of 2^kLocBits consecutive state ids (h = hash of the
+    // block), a block's states take consecutive slots, and the slot scan of (C) numbers the tokens
+    // in slot order — so the tokens of neighbouring states are neighbours in the next frame's
+    // expansion: their arc-offset words share a cache line and their arcs are contiguous in the
+    // arc table (an HCLG numbers the states of an HMM chain / a lexicon-tree branch consecutively).
+#ifndef KH_LOC_BITS
+#define KH_LOC_BITS 5
+#endif
+    constexpr int kLocBits = KH_LOC_BITS;
+    auto lds_slot = [](uint32_t h, int32_t ns) {
+      return ((h << kLocBits) | (static_cast<uint32_t>(ns) & ((1u << kLocBits) - 1u))) & (kLdsSlots - 1);
+    };
     // number of parts: about 11 000 accepted candidates per part (typically half as many
     // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
     // parts (the parts nest, and resolved links are marked, so nothing is done twice)
@@ -1122,16 +1134,20 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
           const float tot_cost = tc[j];
           if (tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
           const int32_t ns = nsv[j];
-          const uint32_t h = HashState(ns & kStateMask);
+          const uint32_t h = HashState((ns & kStateMask) >> kLocBits);
           if (part_of(h, parts) != k) continue;
           const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-          uint32_t slot = h & (kLdsSlots - 1);
+          uint32_t slot = lds_slot(h, ns);
+          // double hashing BY BLOCK: a block whose place is taken moves as a whole (same offset within
+          // the block, a step that depends on the block only), so its tokens stay neighbours; linear
+          // probing piles the runs of consecutive active states up (pass 2 twice as slow)
+          const uint32_t step = ((h >> 9) | 1u) << kLocBits;
           int probes = 0;
           for (; probes < 256; probes++) {
             uint32_t seen = 0u;
             __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (seen == 0u || seen == key) break;
-            slot = (slot + 1) & (kLdsSlots - 1);
+            slot = (slot + step) & (kLdsSlots - 1);
           }
           if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
           (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1214,11 +1230,12 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
             continue;
           }
           const int32_t ns = nsv[j];
-          const uint32_t h = HashState(ns & kStateMask);
+          const uint32_t h = HashState((ns & kStateMask) >> kLocBits);
           if (part_of(h, parts) != k) continue;
           const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-          uint32_t slot = h & (kLdsSlots - 1);
-          while (keys[slot] != key) slot = (slot + 1) & (kLdsSlots - 1);
+          uint32_t slot = lds_slot(h, ns);
+          const uint32_t step = ((h >> 9) | 1u) << kLocBits;
+          while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
           u.link_dst[l] = static_cast<int32_t>(vals[slot]);
           if (parts > 1) u.link_tot[l - link_frame_b] = nan;
         }
