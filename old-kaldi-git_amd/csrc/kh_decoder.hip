@@ -69,7 +69,7 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 34;            // diagnostic counters per slot
+constexpr int NPH = 40;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x1fffffff;
@@ -235,6 +235,9 @@ __device__ __forceinline__ void KhSync() {
 #endif
 }
 
+// Barrier for hand-offs through LDS only: no wait for this wave's outstanding global stores.
+__device__ __forceinline__ void LdsSync() { __syncthreads(); }
+
 // Workgroup-uniform values that reach a lane through LDS or a vector load sit in a
 // VGPR (the compiler cannot know they are uniform) and make every loop bound and branch
 // that depends on them a vector one.  Uni() moves such a value to an SGPR
@@ -322,6 +325,7 @@ __device__ __forceinline__ void Stamp(const Utt &u, Blk &sh, int ph) {
 // partials into a buffer selected by a per-thread call counter (uniform across the
 // workgroup) and reads all partials after the barrier; a buffer is rewritten two
 // calls later, i.e. behind at least one more barrier than its last read.
+template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int inc = v;
@@ -332,7 +336,7 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   }
   const int buf = (sh.k_scan++) & 1;
   if (lane == 63) sh->wsum[buf][w] = inc;
-  KhSync();
+  if (kLdsOnly) LdsSync(); else KhSync();
   int before = 0, all = 0;
 #pragma unroll
   for (int i = 0; i < NW; i++) {
@@ -346,7 +350,7 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
 
 // Exclusive scan of K * NT items laid out slice-major (item (k, t) = slice k,
 // thread t): one barrier for all slices.
-template <int K>
+template <int K, bool kLdsOnly = false>
 __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], int *total, Blk &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int buf = (sh.k_scan++) & 1;
@@ -361,7 +365,7 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], i
     }
     if (lane == 63) sh->wsumk[buf][k][w] = inc[k];
   }
-  KhSync();
+  if (kLdsOnly) LdsSync(); else KhSync();
   int run = 0;
 #pragma unroll
   for (int k = 0; k < K; k++) {
@@ -1654,66 +1658,97 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
   const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0;
   if (prof) tc = static_cast<long long>(__builtin_amdgcn_s_memtime());
 #define KH_COMPACT_STAMP(k) do { if (prof) { const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tc; tc = now_; } } while (0)
+  // Both slides run over the window's whole RANGE, not block by block: a frame that is one or
+  // two prune intervals old holds a few hundred slots, and a barrier per block was most of the
+  // barriers of a call.  The blocks are contiguous in arena order, so a block's new bound is the
+  // number of survivors before its old bound: the lane that owns that slot in the group's scan
+  // writes it (bounds staged in LDS, kFB frames at a time so that a full compaction fits).
+  auto bnd = sh->ex_off;   // old bounds (ascending)
+  auto nbn = sh->ex_ab;    // new bounds
+  constexpr int kFB = (EU * NT) / 2;
   // (a) tokens
   int tend = win_b;  // running end of the compacted tokens (uniform)
-  for (int f = w_lo; f <= cur; f++) {
-    const int b = Uni(u.frame_b[f]), e = Uni(u.frame_e[f]);
-    const int new_b = tend;
-    // Up to KC chunks per barrier: only the liveness of the slots is read before the scan, the
-    // survivors' fields after it.  That is safe when none of the group's destinations
-    // [tend, tend + survivors) reaches into the group itself, which a group of at most
-    // (gap / NT) chunks guarantees (gap = base - tend, opened by the slots already dropped).
-    for (int base = b; base < e;) {
-      const int kk = min(KC, (base - tend) / NT);
-      if (kk >= 2) {
-        int st[KC], alive[KC], off[KC];
+  {
+    int base = win_b;
+    for (int f0 = w_lo; f0 <= cur; f0 += kFB) {
+      const int f1 = min(cur, f0 + kFB - 1), nb = f1 - f0 + 1;
+      for (int j = threadIdx.x; j < nb; j += NT) bnd[j] = u.frame_b[f0 + j];
+      const int chunk_e = f1 == cur ? old_tok_end : Uni(u.frame_b[f1 + 1]);
+      KhSync();
+      int bj = 0;
+      while (base < chunk_e) {
+        const int kk = min(KC, (base - tend) / NT);
+        int off[KC], total, span;
+        if (kk >= 2) {
+          // only the liveness is read before the scan, the survivors' fields after it: safe when
+          // none of the group's destinations [tend, tend + survivors) reaches into the group
+          // itself, which a group of at most (gap / NT) chunks guarantees
+          span = min(kk * NT, chunk_e - base);
+          int st[KC], alive[KC];
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
-          const int i = base + k * NT + threadIdx.x;
-          st[k] = (k < kk && i < e) ? u.tok_state[i] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < KC; k++) alive[k] = st[k] >= 0 ? 1 : 0;
-        int total;
-        BlockExScanK<KC>(alive, off, &total, sh);
-#pragma unroll
-        for (int k = 0; k < KC; k++) {
-          const int i = base + k * NT + threadIdx.x;
-          if (k >= kk || i >= e) continue;
-          int ni = -1;
-          if (alive[k]) {
-            ni = tend + off[k];
-            const uint32_t co = LoadCostEnc(&u.tok_cost[i]);
-            const float ex = LoadExtra(&u.tok_extra[i]);
-            u.tok_state[ni] = st[k]; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
+          for (int k = 0; k < KC; k++) {
+            const int i = base + k * NT + threadIdx.x;
+            st[k] = (k < kk && i < chunk_e) ? u.tok_state[i] : -1;
           }
-          u.tmp_remap[i - win_b] = ni;
+#pragma unroll
+          for (int k = 0; k < KC; k++) alive[k] = st[k] >= 0 ? 1 : 0;
+          BlockExScanK<KC, true>(alive, off, &total, sh);
+#pragma unroll
+          for (int k = 0; k < KC; k++) {
+            const int i = base + k * NT + threadIdx.x;
+            if (k >= kk || i >= chunk_e) continue;
+            int ni = -1;
+            if (alive[k]) {
+              ni = tend + off[k];
+              const uint32_t co = LoadCostEnc(&u.tok_cost[i]);
+              const float ex = LoadExtra(&u.tok_extra[i]);
+              u.tok_state[ni] = st[k]; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
+            }
+            u.tmp_remap[i - win_b] = ni;
+          }
+        } else {
+          span = min(NT, chunk_e - base);
+          const int i = base + threadIdx.x;
+          int st = -1;
+          uint32_t co = kEncInf;
+          float ex = 0.f;
+          if (i < chunk_e) { st = u.tok_state[i]; co = LoadCostEnc(&u.tok_cost[i]); ex = LoadExtra(&u.tok_extra[i]); }
+          const int alive = st >= 0 ? 1 : 0;
+          off[0] = BlockExScan(alive, &total, sh);
+#pragma unroll
+          for (int k = 1; k < KC; k++) off[k] = 0;
+          if (i < chunk_e) {
+            int ni = -1;
+            if (alive) {
+              ni = tend + off[0];
+              u.tok_state[ni] = st; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
+            }
+            u.tmp_remap[i - win_b] = ni;
+          }
+        }
+        while (bj < nb) {   // the bounds inside this group
+          const int q = Uni(bnd[bj]) - base;
+          if (q >= span) break;
+          if (threadIdx.x == (q & (NT - 1))) {
+            int o = off[0];
+#pragma unroll
+            for (int k = 1; k < KC; k++) o = (q / NT) == k ? off[k] : o;
+            nbn[bj] = tend + o;
+          }
+          bj++;
         }
         tend += total;
-        base += kk * NT;
-        continue;
+        base += span;
       }
-      const int i = base + threadIdx.x;
-      int st = -1;
-      uint32_t co = kEncInf;
-      float ex = 0.f;
-      if (i < e) { st = u.tok_state[i]; co = LoadCostEnc(&u.tok_cost[i]); ex = LoadExtra(&u.tok_extra[i]); }
-      const int alive = st >= 0 ? 1 : 0;
-      int total;
-      const int off = BlockExScan(alive, &total, sh);
-      if (i < e) {
-        int ni = -1;
-        if (alive) {
-          ni = tend + off;
-          u.tok_state[ni] = st; u.tok_cost[ni] = co; u.tok_extra[ni] = ex;
-        }
-        u.tmp_remap[i - win_b] = ni;
+      for (; bj < nb; bj++)
+        if (threadIdx.x == 0) nbn[bj] = tend;   // empty frames at the end of the batch
+      KhSync();
+      for (int j = threadIdx.x; j < nb; j += NT) {
+        u.frame_b[f0 + j] = nbn[j];
+        u.frame_e[f0 + j] = j + 1 < nb ? nbn[j + 1] : tend;
       }
-      tend += total;
-      base += NT;
+      KhSync();  // (the staging arrays are reused by the next batch)
     }
-    if (b == e) KhSync();  // every lane has read the old range: a non-empty frame passed a scan barrier since, an empty one has none
-    if (threadIdx.x == 0) { u.frame_b[f] = new_b; u.frame_e[f] = tend; }
   }
   KhSync();
   KH_COMPACT_STAMP(24);
@@ -1727,65 +1762,108 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
     }
   }
   KH_COMPACT_STAMP(25);
-  // (c) links, block by block in arena order: eps(f), emit(f)
+  // (c) links: one slide over eps(w_lo) emit(w_lo) eps(w_lo + 1) ... eps(cur)
   int lend = old_link_b;  // running end of the compacted links (uniform)
-  for (int f = w_lo; f <= cur; f++) {
-    for (int kind = 0; kind < 2; kind++) {  // 0: epsilon, 1: emitting
-      if (kind == 1 && f == cur) continue;  // not created yet
-      const int blk_b = kind ? Uni(u.femit_b[f]) : Uni(u.feps_b[f]);
-      const int blk_e = kind ? Uni(u.femit_e[f]) : Uni(u.feps_e[f]);
-      const int new_blk_b = lend;
-      for (int base = blk_b; base < blk_e;) {
+  {
+    const int range_e = Uni(sh->link_end);
+    int base = old_link_b;
+    for (int f0 = w_lo; f0 <= cur; f0 += kFB) {
+      const int f1 = min(cur, f0 + kFB - 1), nb = 2 * (f1 - f0 + 1);
+      for (int j = threadIdx.x; j < nb; j += NT) {
+        const int f = f0 + (j >> 1);
+        // (the emitting block of `cur` is not created yet: empty, at the end of the range)
+        bnd[j] = (j & 1) ? (f == cur ? range_e : u.femit_b[f]) : u.feps_b[f];
+      }
+      const int chunk_e = f1 == cur ? range_e : Uni(u.feps_b[f1 + 1]);
+      KhSync();
+      int bj = 0;
+      while (base < chunk_e) {
         const int kk = min(KC, (base - lend) / NT);  // see the tokens above
+        int off[KC], total, span;
         if (kk >= 2) {
-          int dst[KC], alive[KC], off[KC];
+          span = min(kk * NT, chunk_e - base);
+          int dst[KC], alive[KC];
 #pragma unroll
           for (int k = 0; k < KC; k++) {
             const int l = base + k * NT + threadIdx.x;
-            dst[k] = (k < kk && l < blk_e) ? u.link_dst[l] : -1;
+            dst[k] = (k < kk && l < chunk_e) ? u.link_dst[l] : -1;
           }
 #pragma unroll
           for (int k = 0; k < KC; k++) alive[k] = dst[k] >= 0 ? 1 : 0;
-          int total;
-          BlockExScanK<KC>(alive, off, &total, sh);
+          BlockExScanK<KC, true>(alive, off, &total, sh);
+          if (prof) { sh->phase[35] += 1; sh->phase[36] += span; sh->phase[37] += total; }
+          // three steps over the group so that the loads of its chunks are in flight together:
+          // fields, then the remapped token indices (they depend on the fields), then the stores
+          int src[KC], il[KC], ol[KC];
+          float g[KC], a[KC];
 #pragma unroll
           for (int k = 0; k < KC; k++) {
             if (!alive[k]) continue;
-            const int l = base + k * NT + threadIdx.x, d = lend + off[k];
-            const int src = u.link_src[l], il = u.link_il[l], ol = u.link_ol[l];
-            const float g = u.link_g[l], a = u.link_a[l];
-            u.link_dst[d] = dst[k] >= win_b ? u.tmp_remap[dst[k] - win_b] : dst[k];
+            const int l = base + k * NT + threadIdx.x;
+            src[k] = u.link_src[l]; il[k] = u.link_il[l]; ol[k] = u.link_ol[l];
+            g[k] = u.link_g[l]; a[k] = u.link_a[l];
+          }
+#pragma unroll
+          for (int k = 0; k < KC; k++) {
+            if (!alive[k]) continue;
+            if (dst[k] >= win_b) dst[k] = u.tmp_remap[dst[k] - win_b];
+            if (src[k] >= win_b) src[k] = u.tmp_remap[src[k] - win_b];
+          }
+#pragma unroll
+          for (int k = 0; k < KC; k++) {
+            if (!alive[k]) continue;
+            const int d = lend + off[k];
+            u.link_dst[d] = dst[k]; u.link_src[d] = src[k];
+            u.link_il[d] = il[k]; u.link_ol[d] = ol[k]; u.link_g[d] = g[k]; u.link_a[d] = a[k];
+          }
+        } else {
+          span = min(NT, chunk_e - base);
+          const int l = base + threadIdx.x;
+          int dst = -1, src = 0, il = 0, ol = 0;
+          float g = 0.f, a = 0.f;
+          if (l < chunk_e) {
+            dst = u.link_dst[l];
+            if (dst >= 0) { src = u.link_src[l]; il = u.link_il[l]; ol = u.link_ol[l]; g = u.link_g[l]; a = u.link_a[l]; }
+          }
+          const int alive = dst >= 0 ? 1 : 0;
+          off[0] = BlockExScan(alive, &total, sh);
+#pragma unroll
+          for (int k = 1; k < KC; k++) off[k] = 0;
+          if (prof) { sh->phase[34] += 1; sh->phase[36] += span; sh->phase[37] += total; }
+          if (alive) {
+            const int d = lend + off[0];
+            u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
             u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
             u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
           }
-          lend += total;
-          base += kk * NT;
-          continue;
         }
-        const int l = base + threadIdx.x;
-        int dst = -1, src = 0, il = 0, ol = 0;
-        float g = 0.f, a = 0.f;
-        if (l < blk_e) {
-          dst = u.link_dst[l];
-          if (dst >= 0) { src = u.link_src[l]; il = u.link_il[l]; ol = u.link_ol[l]; g = u.link_g[l]; a = u.link_a[l]; }
-        }
-        const int alive = dst >= 0 ? 1 : 0;
-        int total;
-        const int off = BlockExScan(alive, &total, sh);
-        if (alive) {
-          const int d = lend + off;
-          u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
-          u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
-          u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
+        while (bj < nb) {   // the block bounds inside this group
+          const int q = Uni(bnd[bj]) - base;
+          if (q >= span) break;
+          if (threadIdx.x == (q & (NT - 1))) {
+            int o = off[0];
+#pragma unroll
+            for (int k = 1; k < KC; k++) o = (q / NT) == k ? off[k] : o;
+            nbn[bj] = lend + o;
+          }
+          bj++;
         }
         lend += total;
-        base += NT;
+        base += span;
       }
-      if (blk_b == blk_e) KhSync();  // as for the frames above
-      if (threadIdx.x == 0) {
-        if (kind) { u.femit_b[f] = new_blk_b; u.femit_e[f] = lend; }
-        else { u.feps_b[f] = new_blk_b; u.feps_e[f] = lend; }
+      for (; bj < nb; bj++)
+        if (threadIdx.x == 0) nbn[bj] = lend;   // empty blocks at the end of the batch
+      KhSync();
+      for (int j = threadIdx.x; j < nb; j += NT) {
+        const int f = f0 + (j >> 1);
+        const int nbeg = nbn[j], nend = j + 1 < nb ? nbn[j + 1] : lend;
+        if (j & 1) {
+          if (f != cur) { u.femit_b[f] = nbeg; u.femit_e[f] = nend; }
+        } else {
+          u.feps_b[f] = nbeg; u.feps_e[f] = nend;
+        }
       }
+      KhSync();
     }
   }
   if (threadIdx.x == 0) {
@@ -2865,6 +2943,8 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
   fprintf(stderr, "[kh_decoder profile] emitting pass: %lld candidates materialised (%lld counted as accepted in the frames with more than 11000)\n", tot[31], tot[32]);
   fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
           tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);
+  fprintf(stderr, "[kh_decoder profile] link compaction: %lld single-chunk barriers, %lld group barriers, %lld slots scanned, %lld links moved\n",
+          tot[34], tot[35], tot[36], tot[37]);
 }
 
 }  // namespace
