@@ -195,7 +195,7 @@ struct Params {
   int32_t start, num_states, num_emit, num_eps, start_has_eps;
   int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
   Arr<const int32_t> tid2pdf;
-  Arr<const int32_t> e_pdf;  // [num_emit] tid2pdf[ilabel] of every emitting arc (rebuilt per call), or null
+  Arr<const uint16_t> e_pdf;  // [num_emit] tid2pdf[ilabel] of every emitting arc (rebuilt per call; 16 bits: used when the score matrix has <= 65536 columns), or null
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
@@ -1041,7 +1041,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_emit);
         c_arc[k] = p.e_arcs[ai];
-        c_pdf[k] = p.e_pdf ? p.e_pdf[ai] : -1;
+        c_pdf[k] = p.e_pdf ? static_cast<int>(p.e_pdf[ai]) : -1;
         c_src[k] = src;
         c_co[k] = src_cost;
       },
@@ -1886,7 +1886,10 @@ struct Run {
 // Compaction window: everything younger than 2 * max(prune_interval, 25) frames
 // (frames leave it only once they are >= 25 frames behind the frontier, i.e.
 // thinned to lattice density by the backward pruning).
-__device__ __forceinline__ int WindowFrames(const Params &p) { return 2 * (p.prune_interval > 25 ? p.prune_interval : 25); }
+#ifndef KH_COMPACT_EVERY
+#define KH_COMPACT_EVERY 2   // the window is compacted at every KH_COMPACT_EVERY-th call of PruneActiveTokens
+#endif
+__device__ __forceinline__ int WindowFrames(const Params &p) { return (KH_COMPACT_EVERY + 1) * (p.prune_interval > 25 ? p.prune_interval : 25); }
 
 // InitDecoding :55-72 on a slot whose arenas hold their invariants.
 __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
@@ -1939,7 +1942,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       Stamp(u, sh, 15);
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
       Stamp(u, sh, 6);
-      ok = Compact(u, t - win_frames, t, sh);
+      if ((t / p.prune_interval) % KH_COMPACT_EVERY == 0) ok = Compact(u, t - win_frames, t, sh);
       // Frames older than the window keep the slots of what was pruned after they left it
       // (the backward pruning keeps thinning frames ~200 frames behind the frontier): once that
       // garbage has grown to a third of an arena, compact everything (rare: every ~700 frames
@@ -2348,7 +2351,7 @@ struct KhDecoder {
   UttOut *d_out = nullptr;
   unsigned long long *d_used = nullptr;
   long long *d_phase = nullptr;
-  int32_t *e_pdf = nullptr;        // BuildArcPdf
+  uint16_t *e_pdf = nullptr;       // BuildArcPdf
 
   // lattice pool
   void *pool_slab = nullptr;
@@ -2479,7 +2482,7 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.link_frame_cap = link_frame_cap;
   // window: 2 * max(prune_interval, 25) frames + one interval of new frames + frontier;
   // stable part: lattice density
-  const long long win_frames = std::min<long long>(2ll * std::max(prune_interval, 25) + prune_interval + 3, T + 2);
+  const long long win_frames = std::min<long long>((KH_COMPACT_EVERY + 1ll) * std::max(prune_interval, 25) + 1ll * KH_COMPACT_EVERY * prune_interval + 3, T + 2);
   long long per_frame = 256;
   if (const char *e = getenv("KH_DECODER_STABLE_TOKENS_PER_FRAME")) per_frame = atoll(e);
   const long long stable_tok = std::max<long long>(65536, per_frame * (T + 2));
@@ -2766,22 +2769,23 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
 // pdf of every emitting arc: the expansion then reads it next to the arc (coalesced) instead of
 // gathering tid2pdf[ilabel] (64 distinct cache lines per wave instruction).  Rebuilt on every
 // call: the map is the caller's and may change between calls; one pass over the arcs (~20 us).
-__global__ void ArcPdfKernel(const KhInt4 *__restrict__ arcs, long long n, const int32_t *__restrict__ tid2pdf, int32_t *__restrict__ out) {
+__global__ void ArcPdfKernel(const KhInt4 *__restrict__ arcs, long long n, const int32_t *__restrict__ tid2pdf, uint16_t *__restrict__ out) {
   for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x)
-    out[a] = tid2pdf[arcs[a].x];
+    out[a] = static_cast<uint16_t>(tid2pdf[arcs[a].x]);
 }
 
-int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, hipStream_t st) {
-  p->e_pdf = (GP(const int32_t))nullptr;
-  if (tid2pdf == nullptr || d->fst->num_emit == 0) return KH_OK;
+int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, int ll_stride, hipStream_t st) {
+  p->e_pdf = (GP(const uint16_t))nullptr;
+  // (a valid map sends every transition-id to a column of the score matrix, kh_fst_check_pdf_map)
+  if (tid2pdf == nullptr || d->fst->num_emit == 0 || ll_stride <= 0 || ll_stride > 65536) return KH_OK;
   if (d->e_pdf == nullptr) {
-    d->e_pdf = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * d->fst->num_emit));
+    d->e_pdf = static_cast<uint16_t *>(PoolMalloc(sizeof(uint16_t) * d->fst->num_emit));
     if (d->e_pdf == nullptr) return KH_OK;   // no memory to spare: the kernel gathers tid2pdf as before
   }
   hipLaunchKernelGGL(ArcPdfKernel, dim3(NumCUs() * 8), dim3(256), 0, st, (const KhInt4 *)d->fst->e_arcs,
                      static_cast<long long>(d->fst->num_emit), tid2pdf, d->e_pdf);
   KH_LAUNCH_CHECK();
-  p->e_pdf = (GP(const int32_t))d->e_pdf;
+  p->e_pdf = (GP(const uint16_t))d->e_pdf;
   return KH_OK;
 }
 
@@ -2802,7 +2806,7 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.tid2pdf = (GP(const int32_t))tid2pdf;
-  p.e_pdf = (GP(const int32_t))nullptr;
+  p.e_pdf = (GP(const uint16_t))nullptr;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
   p.lattice_beam = d->cfg.lattice_beam;
@@ -3202,7 +3206,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
                    [&](int a, int b) { return d->h_T[a] > d->h_T[b]; });
   Params p;
   FillParams(d, &p, ll_stride, tid2pdf);
-  if ((rc = BuildArcPdf(d, &p, tid2pdf, Stream()))) return rc;
+  if ((rc = BuildArcPdf(d, &p, tid2pdf, ll_stride, Stream()))) return rc;
   if (!d->ev0) {
     KH_HIP(hipEventCreate(&d->ev0));
     KH_HIP(hipEventCreate(&d->ev1));
@@ -3621,7 +3625,7 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   if (ll_stride <= 0) p.ll_cols = 0;
   {
-    const int rc = BuildArcPdf(b, &p, tid2pdf, st);
+    const int rc = BuildArcPdf(b, &p, tid2pdf, ll_stride, st);
     if (rc) return rc;
   }
   KH_HIP(hipMemcpyAsync(o->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
