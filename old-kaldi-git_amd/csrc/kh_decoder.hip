@@ -1500,14 +1500,19 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
   int n_dst = -1, n_src = 0;
   float n_a = 0.0f;
   if (nb + t < ne) { n_dst = u.link_dst[nb + t]; n_src = u.link_src[nb + t]; n_a = u.link_a[nb + t]; }
+  // ... and the first emitting link is fetched in the same round trip as the tokens
+  int m_dst = -1, m_src = 0;
+  float m_a = 0.0f, m_g = 0.0f;
+  if (mb + t < me) { m_dst = u.link_dst[mb + t]; m_src = u.link_src[mb + t]; m_a = u.link_a[mb + t]; m_g = u.link_g[mb + t]; }
   KhSync();
   // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
   int flags = 0;
   for (int l = mb + t; l < me; l += NT) {
-    const int dst = u.link_dst[l];
+    const bool first = l == mb + t;
+    const int dst = first ? m_dst : u.link_dst[l];
     if (dst < 0) continue;
-    const int src = u.link_src[l];
-    const float a = u.link_a[l], g = u.link_g[l];
+    const int src = first ? m_src : u.link_src[l];
+    const float a = first ? m_a : u.link_a[l], g = first ? m_g : u.link_g[l];
     float lec = s_nx[dst - b1] + ((s_cost[src - b] + a + g) - s_nc[dst - b1]);
     if (lec > lb) {
       u.link_dst[l] = -1;
@@ -1517,7 +1522,18 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
       __hip_atomic_fetch_min(&s_acc0[src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  KhSync();  // (s_nc / s_nx are dead from here on: their LDS becomes s_acc1 / s_x)
+  // what the write-back compares with: fetched now, used behind the epsilon fixed point
+  constexpr int kTPL = kPruneLdsTok / NT;
+  float old_x[kTPL];
+  int old_st[kTPL];
+#pragma unroll
+  for (int k = 0; k < kTPL; k++) {
+    const int i = t + k * NT;
+    old_x[k] = 0.0f;
+    old_st[k] = -1;
+    if (i < e - b) { old_x[k] = LoadExtra(&u.tok_extra[b + i]); old_st[k] = u.tok_state[b + i]; }
+  }
+  LdsSync();  // (s_nc / s_nx are dead from here on: their LDS becomes s_acc1 / s_x)
   for (int i = t; i < e - b; i += NT) {
     s_x[i] = Dec(s_acc0[i]);
     s_acc1[i] = kEncInf;
@@ -1525,7 +1541,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
   // ---- epsilon links (inside the frame): iterate to the fixed point
   if (ne > nb) {
     for (;;) {
-      KhSync();
+      LdsSync();
       if (n_dst >= 0) {
         float lec = s_x[n_dst - b] + n_a;  // the parenthesis of :309-311 was evaluated when the link was created
         if (!(lec > lb)) {
@@ -1542,7 +1558,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
           __hip_atomic_fetch_min(&s_acc1[u.link_src[l] - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      KhSync();
+      LdsSync();
       bool changed = false;
       for (int i = t; i < e - b; i += NT) {
         const uint32_t a0 = s_acc0[i], a1 = s_acc1[i];
@@ -1567,12 +1583,14 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
       }
     }
   } else {
-    KhSync();
+    LdsSync();
   }
   // ---- write back; :334 counts the tokens whose extra_cost moved by more than delta
-  for (int i = t; i < e - b; i += NT) {
-    if (u.tok_state[b + i] < 0) continue;
-    const float old = LoadExtra(&u.tok_extra[b + i]), v = s_x[i];
+#pragma unroll
+  for (int k = 0; k < kTPL; k++) {
+    const int i = t + k * NT;
+    if (i >= e - b || old_st[k] < 0) continue;
+    const float old = old_x[k], v = s_x[i];
     if (!(v == old)) StoreExtra(&u.tok_extra[b + i], v);
     if (fabsf(v - old) > delta) flags |= 1;
   }
@@ -1601,8 +1619,13 @@ __device__ __forceinline__ void StoreFlag(P p, uint8_t v) {
 __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Blk &sh) {
   if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[12] += 1;
   for (int f = cur - 1; f >= 0; f--) {
-    const bool ml = Uni(static_cast<int>(LoadFlag(&u.must_links[f]))) != 0;
-    const bool mt = (f + 1 < cur) && Uni(static_cast<int>(LoadFlag(&u.must_toks[f + 1]))) != 0;
+    // the flags and the frame's bounds in one round trip (the bounds are needed by most visits)
+    const int ml_i = static_cast<int>(LoadFlag(&u.must_links[f]));
+    const int mt_i = (f + 1 < cur) ? static_cast<int>(LoadFlag(&u.must_toks[f + 1])) : 0;
+    const int vb = u.frame_b[f], ve = u.frame_e[f], vmb = u.femit_b[f], vme = u.femit_e[f], vnb = u.feps_b[f], vne = u.feps_e[f],
+              vb1 = u.frame_b[f + 1], ve1 = u.frame_e[f + 1];
+    const bool ml = Uni(ml_i) != 0;
+    const bool mt = Uni(mt_i) != 0;
     // Flags of older frames can only be raised by the frame above them in this
     // pass (all frames visited by earlier passes were cleared), so once a frame
     // has nothing to do the reference's remaining iterations are no-ops.
@@ -1611,8 +1634,7 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     if (u.phase_cycles != nullptr && threadIdx.x == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (ml) {
       bool ec, lp;
-      const int b = Uni(u.frame_b[f]), e = Uni(u.frame_e[f]), mb = Uni(u.femit_b[f]), me = Uni(u.femit_e[f]),
-                nb = Uni(u.feps_b[f]), ne = Uni(u.feps_e[f]), b1 = Uni(u.frame_b[f + 1]), e1 = Uni(u.frame_e[f + 1]);
+      const int b = Uni(vb), e = Uni(ve), mb = Uni(vmb), me = Uni(vme), nb = Uni(vnb), ne = Uni(vne), b1 = Uni(vb1), e1 = Uni(ve1);
       if (e - b <= kPruneLdsTok && e1 - b1 <= kPruneLdsTok)
         PruneFrameLds(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
       else
@@ -1624,7 +1646,7 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
         if (mt) StoreFlag(&u.must_toks[f + 1], 0);
       }
     } else {  // mt
-      PruneTokensForFrame(u, Uni(u.frame_b[f + 1]), Uni(u.frame_e[f + 1]));
+      PruneTokensForFrame(u, Uni(vb1), Uni(ve1));
       if (threadIdx.x == 0) StoreFlag(&u.must_toks[f + 1], 0);
     }
     KhSync();
