@@ -1599,6 +1599,104 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
   *links_pruned = (all & 2) != 0;
 }
 
+// The same visit for a frame of up to 2 * kLdsSlots token slots (a frame that has not been compacted
+// yet keeps the slots of its pruned tokens): only the extra_costs being computed live in LDS,
+// ONE array relaxed in place — extra[t] starts as the minimum over t's emitting links and is
+// lowered by atomic minima over the epsilon links until a sweep changes nothing.  The links of a
+// frame form a DAG and min-plus relaxation is monotone, so any schedule reaches the same unique
+// fixed point as the Jacobi rounds above, with the same float operations; cost[src], cost[dst] and
+// extra[dst] are gathered from L2.  No global atomics (PruneForwardLinks keeps its epsilon
+// accumulator in HBM: a DRAM read-modify-write per link and round).
+__device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
+                                 bool prune_toks_f1, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
+  const float inf = INFINITY, lb = p.lattice_beam;
+  const int t = threadIdx.x;
+  // 2 * kLdsSlots words in two pieces (the value and the key array of the emitting pass's table): Enc(extra_cost) of f's tokens
+  auto x_lo = LdsVals(sh);
+  auto x_hi = LdsKeys(sh);
+  auto x = [&](int i) -> __attribute__((address_space(3))) uint32_t * { return i < kLdsSlots ? &x_lo[i] : &x_hi[i - kLdsSlots]; };
+  if (u.phase_cycles != nullptr && t == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; sh->phase[14] += 1; }
+  for (int i = t; i < e - b; i += NT) *x(i) = kEncInf;
+  if (prune_toks_f1)   // PruneTokensForFrame(f + 1) :450-469: its extra_costs are final
+    for (int i = b1 + t; i < e1; i += NT)
+      if (LoadExtra(&u.tok_extra[i]) == inf && u.tok_state[i] >= 0) u.tok_state[i] = -1;
+  LdsSync();
+  // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
+  int flags = 0;
+  constexpr int kBU = 2;
+  for (int l0 = mb + t; l0 < me; l0 += NT * kBU) {
+    int dst[kBU], src[kBU];
+    float a[kBU], g[kBU];
+#pragma unroll
+    for (int k = 0; k < kBU; k++) {
+      const int l = min(l0 + k * NT, me - 1);
+      dst[k] = u.link_dst[l]; src[k] = u.link_src[l]; a[k] = u.link_a[l]; g[k] = u.link_g[l];
+    }
+    float nx[kBU], cs[kBU], cd[kBU];
+#pragma unroll
+    for (int k = 0; k < kBU; k++) {
+      nx[k] = cs[k] = cd[k] = 0.0f;
+      if (dst[k] >= 0) {
+        nx[k] = LoadExtra(&u.tok_extra[dst[k]]);
+        cd[k] = Dec(LoadCostEnc(&u.tok_cost[dst[k]]));
+        cs[k] = Dec(LoadCostEnc(&u.tok_cost[src[k]]));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kBU; k++) {
+      if (l0 + k * NT >= me || dst[k] < 0) continue;
+      float lec = nx[k] + ((cs[k] + a[k] + g[k]) - cd[k]);
+      if (lec > lb) {
+        u.link_dst[l0 + k * NT] = -1;
+        flags |= 2;
+      } else {
+        if (lec < 0.0f) lec = 0.0f;
+        __hip_atomic_fetch_min(x(src[k] - b), Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  // ---- epsilon links (inside the frame): relax in place to the fixed point
+  if (ne > nb) {
+    for (;;) {
+      LdsSync();
+      bool changed = false;
+      for (int l = nb + t; l < ne; l += NT) {
+        const int dst = u.link_dst[l];
+        if (dst < 0) continue;
+        float lec = Dec(*x(dst - b)) + u.link_a[l];  // the parenthesis of :309-311 was evaluated when the link was created
+        if (!(lec > lb)) {
+          if (lec < 0.0f) lec = 0.0f;
+          const uint32_t v = Enc(lec);
+          const uint32_t old = __hip_atomic_fetch_min(x(u.link_src[l] - b), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          changed |= v < old;
+        }
+      }
+      if (u.phase_cycles != nullptr && t == 0) sh->phase[14] += 1;
+      if (!BlockAny(changed, sh)) break;
+    }
+    // excise :315
+    for (int l = nb + t; l < ne; l += NT) {
+      const int dst = u.link_dst[l];
+      if (dst >= 0 && Dec(*x(dst - b)) + u.link_a[l] > lb) {
+        u.link_dst[l] = -1;
+        flags |= 2;
+      }
+    }
+  } else {
+    LdsSync();
+  }
+  // ---- write back; :334 counts the tokens whose extra_cost moved by more than delta
+  for (int i = t; i < e - b; i += NT) {
+    if (u.tok_state[b + i] < 0) continue;
+    const float old = LoadExtra(&u.tok_extra[b + i]), v = Dec(*x(i));
+    if (!(v == old)) StoreExtra(&u.tok_extra[b + i], v);
+    if (fabsf(v - old) > delta) flags |= 1;
+  }
+  const int all = BlockOr(flags, sh);
+  *extra_costs_changed = (all & 1) != 0;
+  *links_pruned = (all & 2) != 0;
+}
+
 // PruneTokensForFrame :450-469
 __device__ void PruneTokensForFrame(const Utt &u, int b, int e) {
   for (int i = b + threadIdx.x; i < e; i += NT)
@@ -1637,6 +1735,8 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
       const int b = Uni(vb), e = Uni(ve), mb = Uni(vmb), me = Uni(vme), nb = Uni(vnb), ne = Uni(vne), b1 = Uni(vb1), e1 = Uni(ve1);
       if (e - b <= kPruneLdsTok && e1 - b1 <= kPruneLdsTok)
         PruneFrameLds(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
+      else if (e - b <= 2 * kLdsSlots)
+        PruneFrameLdsBig(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
       else
         PruneForwardLinks(u, p, b, e, mb, me, nb, ne, delta, false, false, 0.f, mt ? b1 : 0, mt ? e1 : 0, &ec, &lp, sh);
       if (threadIdx.x == 0) {
