@@ -495,6 +495,15 @@ int kh_comp_objf_and_deriv(int n, const int32_t *rows, const int32_t *cols, cons
                            const float *output, KhMatrixDim d_output, float *deriv, KhMatrixDim d_deriv,
                            float *tot_objf, float *tot_weight);
 
+/* MergePairVectorSumming (util/stl-utils.h:303-322) applied to every frame of a batch at once: the
+ * step between the arc posteriors and the Posterior lists of hmm/posterior.cc
+ * (lattice-functions.cc:351-352, ConvertPosteriorToPdfs, MergePosteriors).  HOST arrays: entries
+ * (row = frame < n_rows, key = transition-id / pdf-id, weight) -> sorted by (row, key), equal keys
+ * summed in input order, exact zeros dropped; the outputs hold at most n entries. */
+int kh_merge_pair_vector_summing(int64_t n, const int32_t *rows, const int32_t *keys, const float *weights,
+                                 int32_t n_rows, int32_t *out_rows, int32_t *out_keys, float *out_weights,
+                                 int64_t *n_out);
+
 /* ------------------------------------------------------------------ f2
  * DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1497-1519, called by
  * DecodeUtteranceLatticeFaster, decoder/decoder-wrappers.cc:264-274): the raw state-level

@@ -1089,21 +1089,25 @@ def _lookup_values(M, rows, cols):
     return out.cpu().numpy()
 
 
-def _merge_keyed(rows, cols, weights):
+def _merge_keyed(rows, cols, weights, n_rows=None):
     """Sum float32 weights per (row, col), drop exact zeros; keys sorted (MergePairVectorSumming
-    per frame, util/stl-utils.h:303-322, for all frames at once)."""
-    if len(rows) == 0:
+    per frame, util/stl-utils.h:303-322, for all frames at once: kh_merge_pair_vector_summing)."""
+    n = len(rows)
+    if n == 0:
         return rows.astype(np.int64), cols.astype(np.int64), weights.astype(np.float32)
-    key = rows.astype(np.int64) * (int(cols.max()) + 1) + cols.astype(np.int64)
-    order = np.argsort(key, kind="stable")
-    key, rows, cols, weights = key[order], rows[order], cols[order], weights[order].astype(np.float32)
-    first = np.ones(len(key), bool)
-    first[1:] = key[1:] != key[:-1]
-    grp = np.cumsum(first) - 1
-    acc = np.zeros(int(grp[-1]) + 1, np.float32)
-    np.add.at(acc, grp, weights)
-    keep = acc != 0.0
-    return rows[first][keep], cols[first][keep], acc[keep]
+    r = np.ascontiguousarray(rows, np.int32)
+    c = np.ascontiguousarray(cols, np.int32)
+    w = np.ascontiguousarray(weights, np.float32)
+    if n_rows is None:
+        n_rows = int(r.max()) + 1
+    orow, ocol, ow = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32)
+    n_out = C.c_int64()
+    ip, fp = capi.c_int32_p, capi.c_float_p
+    check(lib().kh_merge_pair_vector_summing(n, r.ctypes.data_as(ip), c.ctypes.data_as(ip), w.ctypes.data_as(fp), int(n_rows),
+                                             orow.ctypes.data_as(ip), ocol.ctypes.data_as(ip), ow.ctypes.data_as(fp),
+                                             C.byref(n_out)))
+    m = n_out.value
+    return orow[:m].astype(np.int64), ocol[:m].astype(np.int64), ow[:m]
 
 
 def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="smbr", acoustic_scale=0.1,

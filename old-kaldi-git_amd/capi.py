@@ -155,6 +155,7 @@ SIGNATURES = {
     "kh_lattice_alphas_betas": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, C.c_int, c_double_p, c_double_p, c_double_p]),
     "kh_lattice_forward_backward_mpe": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p, c_int32_p, c_int32_p, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, C.c_int, c_float_p, c_double_p, c_int32_p]),
     "kh_rescore_lattice": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, vp, C.c_int, c_int32_p, vp]),
+    "kh_merge_pair_vector_summing": (C.c_int, [i64, c_int32_p, c_int32_p, c_float_p, i32, c_int32_p, c_int32_p, c_float_p, c_int64_p]),
     "kh_comp_objf_and_deriv": (C.c_int, [C.c_int, c_int32_p, c_int32_p, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, c_float_p, c_float_p]),
 }
 

@@ -836,3 +836,48 @@ extern "C" int kh_comp_objf_and_deriv(int n, const int32_t *rows, const int32_t 
   *tot_weight = static_cast<float>(h[1]);
   return KH_OK;
 }
+
+// MergePairVectorSumming (util/stl-utils.h:303-322) for the posteriors of all frames at once
+// (the Posterior algebra of hmm/posterior.cc runs on the host in the reference too): the entries
+// (row = frame, key = transition-id or pdf-id, weight) are sorted by (row, key) — counting sort by
+// row, insertion sort inside a row (a frame holds a handful of entries) — equal keys summed in that
+// order, exact zeros dropped.
+extern "C" int kh_merge_pair_vector_summing(int64_t n, const int32_t *rows, const int32_t *keys, const float *weights,
+                                            int32_t n_rows, int32_t *out_rows, int32_t *out_keys, float *out_weights,
+                                            int64_t *n_out) {
+  KH_CHECK_ARG(n >= 0 && n_rows >= 0 && n_out && (n == 0 || (rows && keys && weights && out_rows && out_keys && out_weights)));
+  std::vector<int64_t> start(static_cast<size_t>(n_rows) + 1, 0);
+  for (int64_t i = 0; i < n; i++) {
+    KH_CHECK_ARG(rows[i] >= 0 && rows[i] < n_rows);
+    start[rows[i] + 1]++;
+  }
+  for (int32_t r = 0; r < n_rows; r++) start[r + 1] += start[r];
+  std::vector<int64_t> fill(start.begin(), start.end() - 1);
+  std::vector<int32_t> k(n);
+  std::vector<float> w(n);
+  for (int64_t i = 0; i < n; i++) {   // stable
+    const int64_t d = fill[rows[i]]++;
+    k[d] = keys[i];
+    w[d] = weights[i];
+  }
+  int64_t o = 0;
+  for (int32_t r = 0; r < n_rows; r++) {
+    const int64_t b = start[r], e = start[r + 1];
+    for (int64_t i = b + 1; i < e; i++) {   // stable insertion sort by key
+      const int32_t ki = k[i];
+      const float wi = w[i];
+      int64_t j = i;
+      for (; j > b && k[j - 1] > ki; j--) { k[j] = k[j - 1]; w[j] = w[j - 1]; }
+      k[j] = ki;
+      w[j] = wi;
+    }
+    for (int64_t i = b; i < e;) {
+      const int32_t key = k[i];
+      float sum = w[i];
+      for (i++; i < e && k[i] == key; i++) sum += w[i];
+      if (sum != 0.0f) { out_rows[o] = r; out_keys[o] = key; out_weights[o] = sum; o++; }
+    }
+  }
+  *n_out = o;
+  return KH_OK;
+}
