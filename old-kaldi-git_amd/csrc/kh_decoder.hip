@@ -667,7 +667,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const int32
     const bool in_range = i < e;
     const int ic = min(i, e - 1);
     const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
-    const int st = u.tok_state[ic];
+    int st = u.tok_state[ic];
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= cutoff;
     int ab = 0, cnt = 0;
