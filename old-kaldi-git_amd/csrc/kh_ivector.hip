@@ -184,12 +184,108 @@ IvPosteriorKernel(const float *__restrict__ ll, int ll_stride, int rows, int num
 }
 
 // ---- statistics + conjugate gradient: one workgroup per utterance
+template <int kNW = 4>
 __device__ __forceinline__ double BlockSumD(double v, double *red) {
   v = kh_wave_sum_d(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;   // callers: zero beyond thread S <= 256
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 64 * kNW) red[threadIdx.x >> 6] = v;   // callers: zero beyond thread S <= 64 kNW
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  double sum = red[0];
+#pragma unroll
+  for (int w = 1; w < kNW; w++) sum += red[w];
+  return sum;
+}
+
+// two sums in one round (their shuffles interleave: a solve is a chain of these)
+template <int kNW = 4>
+__device__ __forceinline__ void BlockSum2D(double &a, double &b, double *red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 64 * kNW) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = red[0];
+  b = red[4];
+#pragma unroll
+  for (int w = 1; w < kNW; w++) { a += red[w]; b += red[4 + w]; }
+}
+
+// GetIvector :631-655 -> LinearCgd matrix/optimization.cc:453-565 (max_error 0, recompute factor 0.01)
+// on the workgroup's LDS copy of the statistics: quad (packed lower triangle by rows), lin; xv = the
+// previous estimate on entry (current_ivector_), the new one on return.
+template <int kNW = 4>
+__device__ void IvGetIvector(const double *quad, const double *lin, double *xv, double *rv, double *pv, double *x0, int S,
+                             int cg_iters, double prior_offset, bool have_frames, double *red, int *n_fallback) {
+  const int t_id = threadIdx.x;
+  auto spmv = [&](const double *vec, int s) {   // (A vec)[s], A = quad (symmetric)
+    double acc = 0.0;
+    {
+      const int rs = s * (s + 1) / 2;
+      for (int c = 0; c <= s; c++) acc += quad[rs + c] * vec[c];
+      for (int c = s + 1; c < S; c++) acc += quad[c * (c + 1) / 2 + s] * vec[c];
+    }
+    return acc;
+  };
+      if (have_frames) {
+        if (t_id == 0 && xv[0] == 0.0) xv[0] = prior_offset;
+        __syncthreads();
+        if (t_id < S) x0[t_id] = xv[t_id];
+        // pass 0: LinearCgd with max_iters = num_cg_iters.  If the squared residual got worse
+        // (:546-547: "Will do an exact optimization", SolveQuadraticProblem from x_orig), pass 1:
+        // conjugate gradient run to convergence from x_orig — the same solution whenever
+        // SolveQuadraticProblem floors no eigenvalue (cond(A) <= 1e4, sp-matrix.cc).
+        for (int pass = 0; pass < 2; pass++) {
+          const int max_iters = pass == 0 ? cg_iters : -1;
+          double my_p = 0.0, my_r = 0.0;
+          if (t_id < S) {
+            my_p = lin[t_id] - spmv(xv, t_id);   // p_0 = b - A x_0
+            my_r = -my_p;
+          }
+          __syncthreads();
+          if (t_id < S) { pv[t_id] = my_p; rv[t_id] = my_r; }
+          double r_cur = BlockSumD<kNW>(t_id < S ? my_r * my_r : 0.0, red);
+          const double r_init = r_cur;
+          double r_recompute = r_cur;
+          const double rf = 0.01 * 0.01;
+          for (int k = 0; k < S + 5 && k != max_iters; k++) {
+            double ap = 0.0;
+            if (t_id < S) ap = spmv(pv, t_id);
+            double p_r = t_id < S ? pv[t_id] * rv[t_id] : 0.0, p_ap = t_id < S ? pv[t_id] * ap : 0.0;
+            BlockSum2D<kNW>(p_r, p_ap, red);
+            const double alpha = -p_r / p_ap;
+            if (t_id < S) {
+              xv[t_id] += alpha * pv[t_id];
+              rv[t_id] += alpha * ap;
+            }
+            double r_next = BlockSumD<kNW>(t_id < S ? rv[t_id] * rv[t_id] : 0.0, red);
+            if (r_next < rf * r_recompute || r_next > r_recompute / rf) {
+              double nr = 0.0;
+              if (t_id < S) nr = spmv(xv, t_id) - lin[t_id];
+              __syncthreads();
+              if (t_id < S) rv[t_id] = nr;
+              r_next = BlockSumD<kNW>(t_id < S ? nr * nr : 0.0, red);
+              r_recompute = r_next;
+            }
+            if (r_next <= DBL_MIN) break;
+            const double beta = r_next / r_cur;
+            if (t_id < S) pv[t_id] = -rv[t_id] + beta * pv[t_id];
+            r_cur = r_next;
+            __syncthreads();
+          }
+          if (pass == 1 || !(r_cur > r_init)) break;
+          const double bb = BlockSumD<kNW>(t_id < S ? lin[t_id] * lin[t_id] : 0.0, red);
+          if (!(r_cur > r_init + 1.0e-10 * bb)) break;
+          __syncthreads();
+          if (t_id < S) xv[t_id] = x0[t_id];
+          if (t_id == 0 && n_fallback) atomicAdd(n_fallback, 1);
+          __syncthreads();
+        }
+      } else if (t_id < S) {
+        xv[t_id] = t_id == 0 ? prior_offset : 0.0;
+      }
 }
 
 constexpr int kIvThreads = 256;
@@ -202,7 +298,7 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
   double *quad = lds;             // [qdim] packed lower triangle by rows
   double *lin = quad + qdim;      // [S]
   double *xv = lin + S, *rv = xv + S, *pv = rv + S, *x0 = pv + S, *feat = x0 + S, *part = feat + D;   // [S] x 4, [D], [num_gselect][S]
-  __shared__ double red[4];
+  __shared__ double red[8];
   const int u = blockIdx.x, t_id = threadIdx.x;
   const int b = utt_off[u], e = utt_off[u + 1];
   // OnlineIvectorEstimationStats ctor :685-694
@@ -215,13 +311,6 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
   }
   double num_frames = 0.0;
   __syncthreads();
-  auto spmv = [&](const double *vec, int s) {   // (A vec)[s], A = quad (symmetric, packed)
-    double acc = 0.0;
-    const int rs = s * (s + 1) / 2;
-    for (int c = 0; c <= s; c++) acc += quad[rs + c] * vec[c];
-    for (int c = s + 1; c < S; c++) acc += quad[c * (c + 1) / 2 + s] * vec[c];
-    return acc;
-  };
   for (int t = b; t < e; t++) {
     if (t_id < D) feat[t_id] = static_cast<double>(F[static_cast<size_t>(t) * f_stride + t_id]);
     __syncthreads();
@@ -268,64 +357,7 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
     num_frames += tot_weight;
     __syncthreads();
     if ((t - b) % period == 0) {
-      // GetIvector :631-655 -> LinearCgd matrix/optimization.cc:453-565 (max_error 0, recompute factor 0.01)
-      if (num_frames > 0.0) {
-        if (t_id == 0 && xv[0] == 0.0) xv[0] = prior_offset;
-        __syncthreads();
-        if (t_id < S) x0[t_id] = xv[t_id];
-        // pass 0: LinearCgd with max_iters = num_cg_iters.  If the squared residual got worse
-        // (:546-547: "Will do an exact optimization", SolveQuadraticProblem from x_orig), pass 1:
-        // conjugate gradient run to convergence from x_orig — the same solution whenever
-        // SolveQuadraticProblem floors no eigenvalue (cond(A) <= 1e4, sp-matrix.cc).
-        for (int pass = 0; pass < 2; pass++) {
-          const int max_iters = pass == 0 ? cg_iters : -1;
-          double my_p = 0.0, my_r = 0.0;
-          if (t_id < S) {
-            my_p = lin[t_id] - spmv(xv, t_id);   // p_0 = b - A x_0
-            my_r = -my_p;
-          }
-          __syncthreads();
-          if (t_id < S) { pv[t_id] = my_p; rv[t_id] = my_r; }
-          double r_cur = BlockSumD(t_id < S ? my_r * my_r : 0.0, red);
-          const double r_init = r_cur;
-          double r_recompute = r_cur;
-          const double rf = 0.01 * 0.01;
-          for (int k = 0; k < S + 5 && k != max_iters; k++) {
-            double ap = 0.0;
-            if (t_id < S) ap = spmv(pv, t_id);
-            const double p_r = BlockSumD(t_id < S ? pv[t_id] * rv[t_id] : 0.0, red);
-            const double p_ap = BlockSumD(t_id < S ? pv[t_id] * ap : 0.0, red);
-            const double alpha = -p_r / p_ap;
-            if (t_id < S) {
-              xv[t_id] += alpha * pv[t_id];
-              rv[t_id] += alpha * ap;
-            }
-            double r_next = BlockSumD(t_id < S ? rv[t_id] * rv[t_id] : 0.0, red);
-            if (r_next < rf * r_recompute || r_next > r_recompute / rf) {
-              double nr = 0.0;
-              if (t_id < S) nr = spmv(xv, t_id) - lin[t_id];
-              __syncthreads();
-              if (t_id < S) rv[t_id] = nr;
-              r_next = BlockSumD(t_id < S ? nr * nr : 0.0, red);
-              r_recompute = r_next;
-            }
-            if (r_next <= DBL_MIN) break;
-            const double beta = r_next / r_cur;
-            if (t_id < S) pv[t_id] = -rv[t_id] + beta * pv[t_id];
-            r_cur = r_next;
-            __syncthreads();
-          }
-          if (pass == 1 || !(r_cur > r_init)) break;
-          const double bb = BlockSumD(t_id < S ? lin[t_id] * lin[t_id] : 0.0, red);
-          if (!(r_cur > r_init + 1.0e-10 * bb)) break;
-          __syncthreads();
-          if (t_id < S) xv[t_id] = x0[t_id];
-          if (t_id == 0 && n_fallback) atomicAdd(n_fallback, 1);
-          __syncthreads();
-        }
-      } else if (t_id < S) {
-        xv[t_id] = t_id == 0 ? prior_offset : 0.0;
-      }
+      IvGetIvector(quad, lin, xv, rv, pv, x0, S, cg_iters, prior_offset, num_frames > 0.0, red, n_fallback);
       __syncthreads();
       // the rows of this estimation point: frames [t, t + period)
       const int last = (t + period < e) ? t + period : e;
@@ -335,6 +367,255 @@ IvStatsKernel(const float *__restrict__ F, int f_stride, const int32_t *__restri
       }
       __syncthreads();
     }
+  }
+}
+
+
+// =====================================================================================
+// Batched statistics (the default path).  The quadratic term of an estimation point is LINEAR in
+// the per-Gaussian counts accumulated so far, quad = I + sum_g gamma_g U_g, and the linear term
+// is a sum over the postings of Sigma_g^-1 M_g^T f_t — so instead of streaming a U_g row (40 KB)
+// and a Sigma_g^-1 M_g block (32 KB) per posting through one workgroup per utterance (360 KB per
+// frame out of L2 / Infinity Cache: that kernel was bound by it at 3.3 TB/s), the batch does
+//   (1) IvGammaKernel: cumulative counts per estimation point  Gc [points x I]       (double)
+//   (2) IvGemmF64Kernel: Quad [points x S(S+1)/2] = Gc x U      — ONE fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64)
+//   (3) postings grouped by Gaussian (histogram + scan + scatter) and IvLinKernel: a workgroup per
+//       Gaussian keeps Sigma_g^-1 M_g in LDS and writes y = w Sigma_g^-1 M_g^T f for its postings
+//   (4) IvSolveKernel: one workgroup per utterance walks its estimation points: loads Quad, adds the
+//       y rows of the period to the linear term, runs the conjugate gradient (sequential in time:
+//       each solve starts from the previous estimate).
+// Sums run in a different order from AccStats (double: 1e-16 relative).
+constexpr int kGemmM = 64, kGemmN = 128, kGemmK = 16;
+typedef double KhDouble4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+IvGammaKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ point_off, const int32_t *__restrict__ post_idx,
+              const float *__restrict__ post_w, int G, int I, int period, double *__restrict__ Gc) {
+  __shared__ double gam[64 * kMaxPerLane];
+  const int u = blockIdx.x, b = utt_off[u], e = utt_off[u + 1];
+  for (int i = threadIdx.x; i < I; i += 256) gam[i] = 0.0;
+  __syncthreads();
+  int prev = b - 1;
+  for (int t = b, p = point_off[u]; t < e; t += period, p++) {
+    // the postings of frames (prev, t]
+    const long long n = static_cast<long long>(t - prev) * G;
+    for (long long j = threadIdx.x; j < n; j += 256) {
+      const long long q = static_cast<long long>(prev + 1) * G + j;
+      const float w = post_w[q];
+      if (w != 0.f) atomicAdd(&gam[post_idx[q]], static_cast<double>(w));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < I; i += 256) Gc[static_cast<size_t>(p) * I + i] = gam[i];
+    __syncthreads();
+    prev = t;
+  }
+}
+
+// C [M x N] = A [M x K] * B [K x N], row-major doubles; 256 threads = 4 waves, block tile 64 x 128,
+// a wave owns 64 x 32 = 4 x 2 MFMA tiles of 16 x 16 (lane l: A[row l & 15][k = l >> 4],
+// B[k = l >> 4][col l & 15]; result register r: row (l >> 4) + 4 r, col l & 15).
+__global__ void __launch_bounds__(256)
+IvGemmF64Kernel(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C, int M, int N, int K) {
+  __shared__ double sa[kGemmK][kGemmM + 1];   // [k][m]
+  __shared__ double sb[kGemmK][kGemmN + 1];   // [k][n]
+  const int bm = blockIdx.y * kGemmM, bn = blockIdx.x * kGemmN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  KhDouble4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = KhDouble4{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += kGemmK) {
+    // A tile 64 x 16: thread -> (m = tid / 4, 4 consecutive k)
+    {
+      const int m = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int gm = bm + m, gk = k0 + kk + j;
+        sa[kk + j][m] = (gm < M && gk < K) ? A[static_cast<size_t>(gm) * K + gk] : 0.0;
+      }
+    }
+    // B tile 16 x 128: thread -> (k = tid / 16, 8 consecutive n)
+    {
+      const int kk = tid >> 4, n = (tid & 15) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int gk = k0 + kk, gn = bn + n + j;
+        sb[kk][n + j] = (gk < K && gn < N) ? B[static_cast<size_t>(gk) * N + gn] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kGemmK; ks += 4) {
+      double af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[i] = sa[ks + (lane >> 4)][i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; j++) bf[j] = sb[ks + (lane >> 4)][wave * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gm = bm + i * 16 + (lane >> 4) + 4 * r, gn = bn + wave * 32 + j * 16 + (lane & 15);
+        if (gm < M && gn < N) C[static_cast<size_t>(gm) * N + gn] = acc[i][j][r];
+      }
+}
+
+// postings grouped by Gaussian: counts, then positions
+__global__ void __launch_bounds__(256)
+IvCountKernel(const int32_t *__restrict__ post_idx, const float *__restrict__ post_w, long long n, int I, int *__restrict__ count) {
+  __shared__ int h[64 * kMaxPerLane];
+  for (int i = threadIdx.x; i < I; i += 256) h[i] = 0;
+  __syncthreads();
+  const long long per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  for (long long q = lo + threadIdx.x; q < hi; q += 256)
+    if (post_w[q] != 0.f) atomicAdd(&h[post_idx[q]], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < I; i += 256)
+    if (h[i]) atomicAdd(&count[i], h[i]);
+}
+// positions of the groups + the work items of IvLinKernel: a Gaussian's postings in pieces of kLinItem
+// (the postings concentrate on few Gaussians: a workgroup per Gaussian would leave the chip idle)
+constexpr int kLinItem = 512;
+__global__ void __launch_bounds__(256) IvScanKernel(const int *__restrict__ count, int I, int *__restrict__ start, int *__restrict__ cursor,
+                                                    int32_t *__restrict__ item_g, int32_t *__restrict__ item_b, int *__restrict__ n_items) {
+  if (threadIdx.x == 0) {   // I <= 2048: a serial scan is nothing
+    int run = 0, ni = 0;
+    for (int i = 0; i < I; i++) {
+      start[i] = run; cursor[i] = run;
+      for (int o = 0; o < count[i]; o += kLinItem) { item_g[ni] = i; item_b[ni] = run + o; ni++; }
+      run += count[i];
+    }
+    start[I] = run;
+    *n_items = ni;
+  }
+}
+__global__ void __launch_bounds__(256)
+IvScatterKernel(const int32_t *__restrict__ post_idx, const float *__restrict__ post_w, long long n, int I, int *__restrict__ cursor,
+                int32_t *__restrict__ sorted) {
+  __shared__ int h[64 * kMaxPerLane], base[64 * kMaxPerLane];
+  for (int i = threadIdx.x; i < I; i += 256) h[i] = 0;
+  __syncthreads();
+  const long long per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  for (long long q = lo + threadIdx.x; q < hi; q += 256)
+    if (post_w[q] != 0.f) atomicAdd(&h[post_idx[q]], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < I; i += 256) { base[i] = h[i] ? atomicAdd(&cursor[i], h[i]) : 0; h[i] = 0; }
+  __syncthreads();
+  for (long long q = lo + threadIdx.x; q < hi; q += 256)
+    if (post_w[q] != 0.f) {
+      const int g = post_idx[q];
+      sorted[base[g] + atomicAdd(&h[g], 1)] = static_cast<int32_t>(q);   // (the order inside a group does not matter)
+    }
+}
+
+// y[posting] = w * (Sigma_g^-1 M_g)^T f_t; a workgroup = one work item (up to kLinItem postings of one Gaussian)
+constexpr int kLinTile = 32;
+__global__ void __launch_bounds__(256)
+IvLinKernel(const float *__restrict__ F, int f_stride, const float *__restrict__ post_w, int G, int D, int S,
+            const double *__restrict__ SiM, const int *__restrict__ start, const int32_t *__restrict__ item_g,
+            const int32_t *__restrict__ item_b, const int *__restrict__ n_items, const int32_t *__restrict__ sorted,
+            double *__restrict__ Y) {
+  extern __shared__ double lds[];
+  double *m = lds;                 // [D][S]
+  double *f = m + D * S;           // [kLinTile][D]
+  __shared__ int32_t ids[kLinTile];
+  __shared__ double ws[kLinTile];
+  if (static_cast<int>(blockIdx.x) >= *n_items) return;
+  const int g = item_g[blockIdx.x], b = item_b[blockIdx.x], e = min(b + kLinItem, start[g + 1]);
+  for (int i = threadIdx.x; i < D * S; i += 256) m[i] = SiM[static_cast<size_t>(g) * D * S + i];
+  for (int t0 = b; t0 < e; t0 += kLinTile) {
+    const int nt = min(kLinTile, e - t0);
+    __syncthreads();
+    if (threadIdx.x < nt) {
+      const int32_t q = sorted[t0 + threadIdx.x];
+      ids[threadIdx.x] = q;
+      ws[threadIdx.x] = static_cast<double>(post_w[q]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * D; i += 256) {
+      const int pp = i / D, d = i - pp * D;
+      f[i] = static_cast<double>(F[static_cast<size_t>(ids[pp] / G) * f_stride + d]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * S; i += 256) {
+      const int pp = i / S, sidx = i - pp * S;
+      double acc = 0.0;
+      for (int d = 0; d < D; d++) acc += m[d * S + sidx] * f[pp * D + d];
+      Y[static_cast<size_t>(ids[pp]) * S + sidx] = ws[pp] * acc;
+    }
+  }
+}
+
+// one workgroup per utterance: estimation points in order.  (Measured: expanding the quadratic term
+// to the full symmetric matrix — conflict-free columns, 80 KB, one workgroup per CU — gives the same
+// rate as the packed triangle at three workgroups per CU: a solve is a chain of ~35 reductions.)
+__global__ void __launch_bounds__(kIvThreads)
+IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ point_off, const float *__restrict__ post_w, int G, int S,
+              int qdim, const double *__restrict__ Quad, const double *__restrict__ Y, double prior_offset, double max_count,
+              int period, int cg_iters, float *__restrict__ out, int out_stride, int *__restrict__ n_fallback) {
+  extern __shared__ double lds[];
+  constexpr int kT = kIvThreads;
+  double *quad = lds;             // [qdim] packed lower triangle by rows
+  double *lin = quad + qdim;      // [S]
+  double *xv = lin + S, *rv = xv + S, *pv = rv + S, *x0 = pv + S;
+  __shared__ double red[8];
+  const int u = blockIdx.x, t_id = threadIdx.x;
+  const int b = utt_off[u], e = utt_off[u + 1];
+  if (t_id < S) {
+    lin[t_id] = t_id == 0 ? prior_offset : 0.0;   // OnlineIvectorEstimationStats ctor :685-694
+    xv[t_id] = t_id == 0 ? prior_offset : 0.0;    // current_ivector_ :358-359
+  }
+  double num_frames = 0.0, diag = 1.0;   // diag: the prior's share of the quadratic term (1, + the max_count rescaling :557-566)
+  int prev = b - 1;
+  for (int t = b, p = point_off[u]; t < e; t += period, p++) {
+    // frames (prev, t]: linear term and counts
+    double lin0_add = 0.0;
+    for (int tt = prev + 1; tt <= t; tt++) {
+      double tot_weight = 0.0;
+      for (int k = 0; k < G; k++) tot_weight += static_cast<double>(post_w[static_cast<size_t>(tt) * G + k]);
+      if (max_count > 0.0) {
+        const double old_scale = fmax(num_frames, max_count) / max_count,
+                     new_scale = fmax(num_frames + tot_weight, max_count) / max_count, change = new_scale - old_scale;
+        lin0_add += prior_offset * change;
+        diag += change;
+      }
+      num_frames += tot_weight;
+    }
+    if (t_id < S) {
+      double acc = lin[t_id];
+      for (int tt = prev + 1; tt <= t; tt++)
+        for (int k = 0; k < G; k++) {
+          const size_t q = static_cast<size_t>(tt) * G + k;
+          if (post_w[q] != 0.f) acc += Y[q * S + t_id];
+        }
+      if (t_id == 0) acc += lin0_add;
+      lin[t_id] = acc;
+    }
+    {
+      for (int q = t_id; q < qdim; q += kT) quad[q] = Quad[static_cast<size_t>(p) * qdim + q];
+      __syncthreads();
+      if (t_id < S) quad[t_id * (t_id + 1) / 2 + t_id] += diag;
+    }
+    __syncthreads();
+    IvGetIvector<kT / 64>(quad, lin, xv, rv, pv, x0, S, cg_iters, prior_offset, num_frames > 0.0, red, n_fallback);
+    __syncthreads();
+    const int last = (t + period < e) ? t + period : e;
+    for (int i = t_id; i < (last - t) * S; i += kT) {
+      const int row = t + i / S, sidx = i - (i / S) * S;
+      out[static_cast<size_t>(row) * out_stride + sidx] = static_cast<float>(xv[sidx] - (sidx == 0 ? prior_offset : 0.0));
+    }
+    __syncthreads();
+    prev = t;
   }
 }
 
@@ -476,10 +757,65 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
     hipLaunchKernelGGL(IvPosteriorKernel, dim3(DivUp(rows, 4)), dim3(256), 0, st, d_ll, istride, rows, I, G, c.min_post,
                        c.posterior_scale, d_pi, d_pw);
     // statistics + solves
-    const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D + static_cast<size_t>(G) * S);
-    hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(kIvThreads), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
-                       x->SiM, c.prior_offset, static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors,
-                       ivector_stride, x->n_exact);
+    const size_t lin_lds = sizeof(double) * (static_cast<size_t>(D) * S + static_cast<size_t>(kLinTile) * D);
+    if (getenv("KH_IVECTOR_SEQUENTIAL") || lin_lds > 64 * 1024) {   // the per-utterance accumulation (A/B reference; very wide models)
+      const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D + static_cast<size_t>(G) * S);
+      hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(kIvThreads), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
+                         x->SiM, c.prior_offset, static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors,
+                         ivector_stride, x->n_exact);
+    } else {
+      // estimation points per utterance; chunks of utterances bound the scratch (Quad: 8 qdim bytes per
+      // point, y: 8 G S bytes per frame)
+      std::vector<int32_t> poff(n_utts + 1, 0);
+      for (int u = 0; u < n_utts; u++)
+        poff[u + 1] = poff[u] + (utt_row_offsets_host[u + 1] - utt_row_offsets_host[u] + c.ivector_period - 1) / c.ivector_period;
+      int32_t *d_poff = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * (n_utts + 1)));
+      int *d_cnt = static_cast<int *>(PoolMalloc(sizeof(int) * (3 * static_cast<size_t>(I) + 3)));
+      if (!d_poff || !d_cnt) { PoolFree(d_poff); PoolFree(d_cnt); rc = KH_ENOMEM; break; }
+      if (hipMemcpyAsync(d_poff, poff.data(), sizeof(int32_t) * (n_utts + 1), hipMemcpyHostToDevice, st) != hipSuccess) rc = KH_EDEVICE;
+      const long long kMaxRows = 4000000;   // scratch per chunk: <= 16 GB of Quad (8 qdim B per point) + 16 GB of y (8 G S B per frame) at the default sizes
+      const size_t solve_lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S);
+      for (int u0 = 0; u0 < n_utts && !rc;) {
+        int u1 = u0 + 1;
+        while (u1 < n_utts && utt_row_offsets_host[u1 + 1] - utt_row_offsets_host[u0] <= kMaxRows) u1++;
+        const int row0 = utt_row_offsets_host[u0], rows_c = utt_row_offsets_host[u1] - row0;
+        const int p0 = poff[u0], pts = poff[u1] - p0;
+        const long long n_post = static_cast<long long>(rows_c) * G;
+        double *d_gc = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(pts) * I));
+        double *d_quad = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(pts) * x->qdim));
+        double *d_y = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(n_post) * S));
+        int32_t *d_sorted = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * static_cast<size_t>(n_post)));
+        const int max_items = static_cast<int>(n_post / kLinItem) + I + 1;
+        int32_t *d_items = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * 2 * static_cast<size_t>(max_items)));
+        if (!d_gc || !d_quad || !d_y || !d_sorted || !d_items) {
+          rc = KH_ENOMEM;
+        } else {
+          int *d_count = d_cnt, *d_start = d_cnt + I, *d_cursor = d_cnt + 2 * I + 1, *d_nitems = d_cnt + 3 * I + 2;
+          const int32_t *pi_c = d_pi + static_cast<size_t>(row0) * G;
+          const float *pw_c = d_pw + static_cast<size_t>(row0) * G;
+          hipLaunchKernelGGL(IvGammaKernel, dim3(u1 - u0), dim3(256), 0, st, d_off + u0, d_poff + u0, d_pi, d_pw, G, I, c.ivector_period,
+                             d_gc - static_cast<ptrdiff_t>(p0) * I);
+          hipLaunchKernelGGL(IvGemmF64Kernel, dim3(DivUp(x->qdim, kGemmN), DivUp(pts, kGemmM)), dim3(256), 0, st, d_gc, x->U, d_quad, pts,
+                             x->qdim, I);
+          (void)hipMemsetAsync(d_count, 0, sizeof(int) * I, st);
+          const int sort_grid = std::max(1, std::min<int>(NumCUs() * 4, static_cast<int>((n_post + 4095) / 4096)));
+          hipLaunchKernelGGL(IvCountKernel, dim3(sort_grid), dim3(256), 0, st, pi_c, pw_c, n_post, I, d_count);
+          hipLaunchKernelGGL(IvScanKernel, dim3(1), dim3(256), 0, st, d_count, I, d_start, d_cursor, d_items, d_items + max_items, d_nitems);
+          hipLaunchKernelGGL(IvScatterKernel, dim3(sort_grid), dim3(256), 0, st, pi_c, pw_c, n_post, I, d_cursor, d_sorted);
+          hipLaunchKernelGGL(IvLinKernel, dim3(max_items), dim3(256), lin_lds, st, d_F + static_cast<size_t>(row0) * dstride, dstride, pw_c, G, D,
+                             S, x->SiM, d_start, d_items, d_items + max_items, d_nitems, d_sorted, d_y);
+          hipLaunchKernelGGL(IvSolveKernel, dim3(u1 - u0), dim3(kIvThreads), solve_lds, st, d_off + u0, d_poff + u0, d_pw, G, S, x->qdim,
+                           d_quad - static_cast<ptrdiff_t>(p0) * x->qdim, d_y - static_cast<ptrdiff_t>(row0) * G * S, c.prior_offset,
+                           static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors, ivector_stride, x->n_exact);
+          if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { SetError("kh_ivector_extract: statistics kernels failed"); rc = KH_EDEVICE; }
+        }
+        PoolFree(d_gc); PoolFree(d_quad); PoolFree(d_y); PoolFree(d_sorted); PoolFree(d_items);
+        u0 = u1;
+      }
+      (void)hipStreamSynchronize(st);
+      PoolFree(d_poff); PoolFree(d_cnt);
+      if (rc) break;
+    }
     if (hipGetLastError() != hipSuccess) { SetError("kh_ivector_extract: kernel launch failed"); rc = KH_EDEVICE; break; }
   } while (0);
   hipError_t e = hipStreamSynchronize(st);   // the scratch returns to the pool

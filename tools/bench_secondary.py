@@ -133,7 +133,7 @@ def lattice_fb_cfg5(api, torch, N=256, T=400):
     return res
 
 
-def ivector_f3(api, torch, n_utts=512, mean_len=740):
+def ivector_f3(api, torch, n_utts=2620, mean_len=740):
     """Online iVector extraction at the reference's default dimensions (online-ivector-feature.h:102-107):
     40-dim base features, +-3 splice, LDA to 40, 512-Gaussian UBM, 100-dim iVector, period 10."""
     W = importlib.import_module(PKG + ".workloads")
