@@ -547,7 +547,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": res["error"]}
             else:
                 out["cpu_baseline"] = {"value": res["value"], "unit": "frames/s", "cores": 1, "kind": res["kind"],
-                                       "sample": res["sample"], "all_cores": res.get("all_cores")}
+                                       "sample": res["sample"], "all_cores": res.get("all_cores"),
+                                       "secondary": res.get("secondary")}
                 out["speedup_vs_cpu_1thread_per_gpu"] = fps / world / res["value"]
         print(json.dumps(out))
     if world > 1:

@@ -773,7 +773,8 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
       int *d_cnt = static_cast<int *>(PoolMalloc(sizeof(int) * (3 * static_cast<size_t>(I) + 3)));
       if (!d_poff || !d_cnt) { PoolFree(d_poff); PoolFree(d_cnt); rc = KH_ENOMEM; break; }
       if (hipMemcpyAsync(d_poff, poff.data(), sizeof(int32_t) * (n_utts + 1), hipMemcpyHostToDevice, st) != hipSuccess) rc = KH_EDEVICE;
-      const long long kMaxRows = 4000000;   // scratch per chunk: <= 16 GB of Quad (8 qdim B per point) + 16 GB of y (8 G S B per frame) at the default sizes
+      // scratch per chunk of utterances: <= 16 GB of Quad (8 qdim B per point) + 16 GB of y (8 G S B per frame) at the default sizes
+      const long long kMaxRows = getenv("KH_IVECTOR_MAX_ROWS") ? atoll(getenv("KH_IVECTOR_MAX_ROWS")) : 4000000;
       const size_t solve_lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S);
       for (int u0 = 0; u0 < n_utts && !rc;) {
         int u1 = u0 + 1;

@@ -81,6 +81,25 @@ def test_rows_of_one_period_share_one_ivector_and_utterances_are_independent():
     assert np.array_equal(a[0], b[1]) and np.array_equal(a[1], b[0])
 
 
+def test_batched_statistics_in_chunks_equal_the_sequential_accumulation(monkeypatch):
+    """The default path batches the statistics (fp64 GEMM for the quadratic terms, postings grouped by
+    Gaussian for the linear terms) over chunks of utterances; KH_IVECTOR_SEQUENTIAL=1 is the
+    per-utterance accumulation.  Same result to 1e-6 whether the batch is one chunk or many."""
+    rng = np.random.default_rng(35)
+    m = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=48, ivector_dim=20, prior_offset=5.0)
+    utts = make_utts(rng, 13, [40, 3, 125, 77, 1, 230, 64])
+    one = run(m, utts)
+    monkeypatch.setenv("KH_IVECTOR_MAX_ROWS", "130")       # chunks of 1-3 utterances
+    many = run(m, utts)
+    monkeypatch.delenv("KH_IVECTOR_MAX_ROWS")
+    monkeypatch.setenv("KH_IVECTOR_SEQUENTIAL", "1")
+    seq = run(m, utts)
+    for a, b, c, u in zip(one, many, seq, utts):
+        assert np.array_equal(a, b)
+        np.testing.assert_allclose(a, c, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(a, IO.extract(u, m), rtol=0, atol=TOL)
+
+
 def test_check_failures_are_errors():
     rng = np.random.default_rng(34)
     m = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=48, ivector_dim=20)
