@@ -18,7 +18,8 @@
 //   kaldi::DiagGmm (likelihoods)       gmm/diag-gmm.h:83-135
 //   kaldi::LatticeForwardBackward, LatticeForwardBackwardMpeVariants
 //                              lat/lattice-functions.cc:272-354,740-919
-//   kaldi::Mfcc, ComputeDeltas, AccCmvnStats, ApplyCmvn
+//   kaldi::Mfcc (all MfccOptions but VTLN), ComputeDeltas, AccCmvnStats, ApplyCmvn
+//   DeterminizeLatticePruned (decoder-wrappers.cc:264-274), OnlineIvectorExtractor (online2/online-ivector-feature.h)
 //                              feat/feature-mfcc.h, feature-functions.cc:361-372, transform/cmvn.cc:49-113
 // Errors throw std::runtime_error exactly as KALDI_ERR does
 // (base/kaldi-error.cc:143,179-182); all operations are synchronous at the API
@@ -585,13 +586,20 @@ struct MfccOptions {  // feature-mfcc.h:37-78 + FrameExtractionOptions + MelBank
   std::string window_type;
   int32 num_bins, num_ceps;
   BaseFloat low_freq, high_freq, cepstral_lifter;
+  // defaults here are the recipes' (conf/mfcc.conf: --use-energy=false, no dither); the reference's struct
+  // defaults are use_energy = true, dither = 1.0 (feature-mfcc.h:54, feature-functions.h:91)
+  bool snip_edges, use_energy, raw_energy, htk_compat;
+  BaseFloat energy_floor, dither;
+  uint64_t dither_seed;  // the reference draws from rand(); here a counter-based generator
   MfccOptions()
       : samp_freq(16000), frame_length_ms(25.0), frame_shift_ms(10.0), preemph_coeff(0.97), remove_dc_offset(true),
-        window_type("povey"), num_bins(23), num_ceps(13), low_freq(20), high_freq(0), cepstral_lifter(22.0) {}
+        window_type("povey"), num_bins(23), num_ceps(13), low_freq(20), high_freq(0), cepstral_lifter(22.0),
+        snip_edges(true), use_energy(false), raw_energy(true), htk_compat(false), energy_floor(0.0), dither(0.0),
+        dither_seed(0) {}
 };
 
-/// Mfcc (use_energy = false, dither = 0, snip_edges = true): the constructor builds the
-/// window function, the mel filters, the DCT rows and the lifter as the reference's does.
+/// Mfcc: the constructor builds the window function, the mel filters, the DCT rows and the
+/// lifter as the reference's does.
 class Mfcc {
  public:
   explicit Mfcc(const MfccOptions &opts) : opts_(opts) {
@@ -651,13 +659,19 @@ class Mfcc {
   int32 Dim() const { return opts_.num_ceps; }
   /// Mfcc::Compute(wave, 1.0, &output): wave = n_samples floats on the device
   void Compute(const BaseFloat *wave_dev, int32 n_samples, CuMatrix *output) const {
-    const int32 rows = n_samples < frame_length_ ? 0 : 1 + (n_samples - frame_length_) / frame_shift_;
+    // NumFrames feature-functions.cc:29-48
+    const int32 rows = opts_.snip_edges ? (n_samples < frame_length_ ? 0 : 1 + (n_samples - frame_length_) / frame_shift_)
+                                        : static_cast<int32>(n_samples * 1.0f / frame_shift_ + 0.5f);
     output->Resize(rows, opts_.num_ceps, kUndefined);
     int32 got = 0;
-    KhCheck(kh_mfcc_compute(wave_dev, n_samples, frame_shift_, frame_length_, padded_, opts_.preemph_coeff,
-                            opts_.remove_dc_offset, window_.data(), opts_.num_bins, mel_first_.data(), mel_off_.data(),
-                            mel_weights_.data(), opts_.num_ceps, dct_.data(), lifter_.empty() ? NULL : lifter_.data(),
-                            output->Data(), output->Stride(), &got));
+    KhMfccOptions o;
+    o.snip_edges = opts_.snip_edges; o.use_energy = opts_.use_energy; o.raw_energy = opts_.raw_energy;
+    o.htk_compat = opts_.htk_compat; o.energy_floor = opts_.energy_floor; o.dither = opts_.dither;
+    o.dither_seed = opts_.dither_seed;
+    KhCheck(kh_mfcc_compute_opts(wave_dev, n_samples, frame_shift_, frame_length_, padded_, opts_.preemph_coeff,
+                                 opts_.remove_dc_offset, window_.data(), opts_.num_bins, mel_first_.data(), mel_off_.data(),
+                                 mel_weights_.data(), opts_.num_ceps, dct_.data(), lifter_.empty() ? NULL : lifter_.data(), &o,
+                                 rows ? output->Data() : NULL, output->Stride(), &got));
     KALDI_HIP_ASSERT(got == rows);
   }
 
@@ -792,6 +806,71 @@ class DecodableMatrixMapped : public DecodableInterface {
 struct RawLattice {
   std::vector<int32> state_frame, state_hclg, arc_src, arc_dst, arc_ilabel, arc_olabel;
   std::vector<BaseFloat> state_final, arc_graph, arc_acoustic;
+};
+
+/// CompactLattice as arrays: arcs sorted by source state, label = word (acceptor), weight =
+/// (graph, acoustic) + the transition-id string [arc_string_offsets[a], arc_string_offsets[a + 1]).
+struct CompactLatticeArrays {
+  int32 num_states;
+  std::vector<int32> arc_src, arc_dst, arc_label, arc_string_offsets, arc_strings, final_string_offsets, final_strings;
+  std::vector<BaseFloat> arc_graph, arc_acoustic, final_graph, final_acoustic;
+};
+
+/// DeterminizeLatticePhonePrunedWrapper as DecodeUtteranceLatticeFaster calls it
+/// (decoder-wrappers.cc:264-274; lat/determinize-lattice-pruned.cc:1497-1519, word-level pass).
+/// Returns false when the determinization stopped at max_mem ("finished earlier than the beam").
+inline bool DeterminizeLatticePruned(const RawLattice &raw, double beam, CompactLatticeArrays *clat,
+                                     BaseFloat delta = 0.0009765625f, int32 max_mem = 50000000) {
+  KhCompactLattice *c = kh_determinize_lattice_pruned(
+      static_cast<int>(raw.state_frame.size()), static_cast<int>(raw.arc_src.size()), raw.arc_src.data(), raw.arc_dst.data(),
+      raw.arc_ilabel.data(), raw.arc_olabel.data(), raw.arc_graph.data(), raw.arc_acoustic.data(), raw.state_final.data(),
+      beam, delta, max_mem);
+  if (c == NULL) throw std::runtime_error(std::string("ERROR (libkaldi_hip) ") + kh_last_error());
+  int32 ns = 0, na = 0, nal = 0, nfl = 0, complete = 0;
+  KhCheck(kh_compact_lattice_sizes(c, &ns, &na, &nal, &nfl, &complete));
+  clat->num_states = ns;
+  clat->arc_src.resize(na); clat->arc_dst.resize(na); clat->arc_label.resize(na);
+  clat->arc_graph.resize(na); clat->arc_acoustic.resize(na);
+  clat->arc_string_offsets.resize(na + 1); clat->arc_strings.resize(nal);
+  clat->final_graph.resize(ns); clat->final_acoustic.resize(ns);
+  clat->final_string_offsets.resize(ns + 1); clat->final_strings.resize(nfl);
+  KhCheck(kh_compact_lattice_get(c, clat->arc_src.data(), clat->arc_dst.data(), clat->arc_label.data(), clat->arc_graph.data(),
+                                 clat->arc_acoustic.data(), clat->arc_string_offsets.data(), clat->arc_strings.data(),
+                                 clat->final_graph.data(), clat->final_acoustic.data(), clat->final_string_offsets.data(),
+                                 clat->final_strings.data()));
+  kh_compact_lattice_free(c);
+  return complete != 0;
+}
+
+/// OnlineIvectorExtractionInfo + OnlineIvectorFeature (online2/online-ivector-feature.h:51-134, :226-330),
+/// deterministic mode, for a batch of utterances; the model arrays are the host copies of the
+/// objects Init() reads (lda_mat_, global_cmvn_stats_, diag_ubm_, extractor_).
+class OnlineIvectorExtractor {
+ public:
+  OnlineIvectorExtractor(const KhIvectorConfig &cfg, const std::vector<BaseFloat> &lda_mat,
+                         const std::vector<double> &global_cmvn_stats, const std::vector<BaseFloat> &ubm_gconsts,
+                         const std::vector<BaseFloat> &ubm_means_invvars, const std::vector<BaseFloat> &ubm_inv_vars,
+                         const std::vector<double> &M, const std::vector<double> &Sigma_inv)
+      : cfg_(cfg) {
+    h_ = kh_ivector_extractor_create(&cfg, lda_mat.data(), global_cmvn_stats.data(), ubm_gconsts.data(), ubm_means_invvars.data(),
+                                     ubm_inv_vars.data(), M.data(), Sigma_inv.data());
+    if (h_ == NULL) throw std::runtime_error(std::string("ERROR (libkaldi_hip) ") + kh_last_error());
+  }
+  ~OnlineIvectorExtractor() { kh_ivector_extractor_destroy(h_); }
+  int32 IvectorDim() const { return cfg_.ivector_dim; }
+  /// GetFrame for every frame: feats = device [sum T x base_dim]; ivectors resized to [sum T x ivector_dim]
+  void Extract(const CuMatrixBase &feats, const std::vector<int32> &utt_row_offsets, CuMatrix *ivectors) const {
+    KALDI_HIP_ASSERT(!utt_row_offsets.empty() && utt_row_offsets.back() == feats.NumRows());
+    ivectors->Resize(feats.NumRows(), cfg_.ivector_dim, kUndefined);
+    KhCheck(kh_ivector_extract(h_, feats.Data(), feats.Stride(), utt_row_offsets.data(),
+                               static_cast<int>(utt_row_offsets.size()) - 1, ivectors->Data(), ivectors->Stride()));
+  }
+
+ private:
+  OnlineIvectorExtractor(const OnlineIvectorExtractor &);
+  OnlineIvectorExtractor &operator=(const OnlineIvectorExtractor &);
+  KhIvectorConfig cfg_;
+  KhIvectorExtractor *h_;
 };
 
 class LatticeFasterDecoder {

@@ -189,6 +189,31 @@ static void TestDecoder() {
   RawLattice lat;
   CHECK(dec.GetRawLattice(0, &lat));
   CHECK(lat.state_frame.size() == 4 && lat.arc_src.size() == 3);
+  // the step behind the decoder (decoder-wrappers.cc:264-274): one word sequence -> one path whose
+  // weights and transition-id strings add up to the best path's
+  {
+    CompactLatticeArrays clat;
+    CHECK(DeterminizeLatticePruned(lat, 10.0, &clat));
+    float cg = 0.f, ca = 0.f;
+    std::vector<int32> cw, cali;
+    int32 st = 0;
+    for (int guard = 0; guard < 10; guard++) {
+      int32 arc = -1;
+      for (size_t i = 0; i < clat.arc_src.size(); i++)
+        if (clat.arc_src[i] == st) { CHECK(arc < 0); arc = static_cast<int32>(i); }   // deterministic + a single path
+      if (arc < 0) break;
+      cg += clat.arc_graph[arc]; ca += clat.arc_acoustic[arc];
+      if (clat.arc_label[arc] != 0) cw.push_back(clat.arc_label[arc]);
+      for (int32 j = clat.arc_string_offsets[arc]; j < clat.arc_string_offsets[arc + 1]; j++) cali.push_back(clat.arc_strings[j]);
+      st = clat.arc_dst[arc];
+    }
+    CHECK(clat.final_graph[st] < 1e30f);
+    cg += clat.final_graph[st]; ca += clat.final_acoustic[st];
+    for (int32 j = clat.final_string_offsets[st]; j < clat.final_string_offsets[st + 1]; j++) cali.push_back(clat.final_strings[j]);
+    CHECK(cw == words && cali == ali);
+    Near(cg, g, 1e-5f, 1e-5f);
+    Near(ca, a, 1e-5f, 1e-5f);
+  }
   // Decode(DecodableInterface *): a matrix-backed decodable with a TransitionIdToPdf map
   // (tid t -> pdf t - 1, what NULL meant above) gives the same result
   {
@@ -329,6 +354,84 @@ static void TestFeatures(const char *path) {
   std::vector<float> got2(want2.size());
   d.CopyToMat(got2.data(), 3 * cols);
   for (size_t i = 0; i < got2.size(); i++) Near(got2[i], want2[i], 1e-3f, 1e-3f);
+  // use_energy / raw_energy: C0 := log energy of the frame after DC removal (feature-mfcc.cc:138, :167-171),
+  // the other columns unchanged; snip_edges = false: round(n / shift) frames
+  {
+    MfccOptions eo = opts;
+    eo.use_energy = true;
+    Mfcc emf(eo);
+    CuMatrix ef;
+    emf.Compute(w.Data(), n, &ef);
+    CHECK(ef.NumRows() == rows && ef.NumCols() == cols);
+    std::vector<float> e(want.size());
+    ef.CopyToMat(e.data(), cols);
+    for (int r = 0; r < rows; r += 37) {
+      const int len = 400, shift = 160;
+      double mean = 0.0, en = 0.0;
+      for (int i = 0; i < len; i++) mean += wave[r * shift + i];
+      const float c = -static_cast<float>(mean) / len;
+      for (int i = 0; i < len; i++) { const float v = wave[r * shift + i] + c; en += static_cast<double>(v * v); }
+      Near(e[static_cast<size_t>(r) * cols], logf(static_cast<float>(en)), 1e-4f, 1e-4f);
+      for (int j = 1; j < cols; j++) CHECK(e[static_cast<size_t>(r) * cols + j] == got[static_cast<size_t>(r) * cols + j]);
+    }
+    MfccOptions so = opts;
+    so.snip_edges = false;
+    Mfcc smf(so);
+    CuMatrix sf;
+    smf.Compute(w.Data(), n, &sf);
+    CHECK(sf.NumRows() == static_cast<int32>(n * 1.0f / 160 + 0.5f));
+  }
+}
+
+// OnlineIvectorExtractor on a toy model: the rows of one period share one estimate, the estimate moves
+// away from the prior as frames accumulate, utterances do not see each other
+static void TestIvector() {
+  KhIvectorConfig c;
+  memset(&c, 0, sizeof(c));
+  c.base_dim = 4; c.splice_left = 0; c.splice_right = 0; c.feat_dim = 4; c.num_gauss = 2; c.ivector_dim = 3; c.lda_cols = 4;
+  c.cmn_window = 600; c.speaker_frames = 600; c.global_frames = 200; c.normalize_mean = 1; c.normalize_variance = 0;
+  c.ivector_period = 2; c.num_gselect = 2; c.num_cg_iters = 15; c.min_post = 0.025f; c.posterior_scale = 0.5f; c.max_count = 0.f;
+  c.prior_offset = 4.0;
+  std::vector<float> lda(16, 0.f);
+  for (int i = 0; i < 4; i++) lda[i * 4 + i] = 1.f;
+  std::vector<double> gstats(10, 0.0);
+  gstats[4] = 100.0;                                       // count; zero mean
+  for (int i = 0; i < 4; i++) gstats[5 + i] = 100.0;      // unit variance
+  // two unit-variance Gaussians at +-1: gconsts = log w - 0.5 (D log 2 pi + sum mu^2)
+  std::vector<float> mi = {1.f, 1.f, 1.f, 1.f, -1.f, -1.f, -1.f, -1.f}, iv(8, 1.f), gc(2);
+  for (int i = 0; i < 2; i++) gc[i] = logf(0.5f) - 0.5f * (4 * logf(6.2831853f) + 4.f);
+  std::vector<double> M(2 * 4 * 3, 0.0), Si(2 * 16, 0.0);
+  for (int g = 0; g < 2; g++)
+    for (int d = 0; d < 4; d++) {
+      M[(g * 4 + d) * 3 + 0] = (g == 0 ? 1.0 : -1.0) / c.prior_offset;   // mean_g = M_g [prior_offset, 0, 0]
+      M[(g * 4 + d) * 3 + 1 + (d & 1)] = 0.5;
+      Si[g * 16 + d * 4 + d] = 1.0;
+    }
+  OnlineIvectorExtractor ext(c, lda, gstats, gc, mi, iv, M, Si);
+  CHECK(ext.IvectorDim() == 3);
+  std::vector<float> x(7 * 4);
+  for (size_t i = 0; i < x.size(); i++) x[i] = 0.3f * static_cast<float>((i * 7) % 5) - 0.2f;
+  CuMatrix feats;
+  feats.CopyFromMat(x.data(), 7, 4, 4);
+  std::vector<int32> off = {0, 5, 7};
+  CuMatrix iv_out;
+  ext.Extract(feats, off, &iv_out);
+  CHECK(iv_out.NumRows() == 7 && iv_out.NumCols() == 3);
+  std::vector<float> h(21);
+  iv_out.CopyToMat(h.data(), 3);
+  for (int j = 0; j < 3; j++) {
+    CHECK(h[0 * 3 + j] == h[1 * 3 + j] && h[2 * 3 + j] == h[3 * 3 + j] && h[5 * 3 + j] == h[6 * 3 + j]);
+    CHECK(std::isfinite(h[4 * 3 + j]));
+  }
+  CHECK(fabsf(h[4 * 3 + 1]) + fabsf(h[4 * 3 + 2]) > 1e-3f);
+  // the second utterance alone gives the same rows
+  CuMatrix f2, o2;
+  f2.CopyFromMat(x.data() + 5 * 4, 2, 4, 4);
+  std::vector<int32> off2 = {0, 2};
+  ext.Extract(f2, off2, &o2);
+  std::vector<float> h2(6);
+  o2.CopyToMat(h2.data(), 3);
+  for (int j = 0; j < 6; j++) CHECK(h2[j] == h[15 + j]);
 }
 
 int main(int argc, char **argv) {
@@ -340,6 +443,7 @@ int main(int argc, char **argv) {
     TestSubMatrixViews();
     TestDecoder();
     TestNnetGmmLattice();
+    TestIvector();
     if (argc > 1) TestFeatures(argv[1]);
   } catch (const std::exception &e) {
     printf("FAIL exception: %s\n", e.what());

@@ -1,7 +1,8 @@
-"""One-off check at the benchmark's own scale: the bench.py workload (10 M-state graph,
-beam 15 / max-active 7000, real forward pass) decoded in one launch with more utterances
-than slots, and a sample of utterances — first and last in their slot's queue — compared
-bit-exactly with the canonical oracle on the SAME log-likelihood rows."""
+"""One-off check at the benchmark's own scale: the bench.py workload (HCLG-structured 10 M-state
+graph, beam 15 / max-active 7000, real forward pass) decoded in one launch with more utterances
+than slots, and a sample of utterances — the longest, first and last in their slot's queue,
+a median one — compared bit-exactly with the canonical oracle on the SAME log-likelihood rows.
+    python tools/validate_bench_scale.py [n_utts=700]"""
 import importlib
 import sys
 import time
@@ -19,7 +20,8 @@ api = importlib.import_module("old-kaldi-git_amd.api")
 api.select_gpu(0)
 n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 700
 t0 = time.time()
-net, priors, g, feats, off = bench.build_workload(3456, 0, n_utts, 10_000_000)
+net, priors, g, protos = bench.build_model_and_graph(3456, 10_000_000, False)
+feats, off = bench.build_utterances(3456, 0, n_utts, net, g, protos, False)
 print("workload built in %.0f s: %d utterances, %d frames" % (time.time() - t0, n_utts, off[-1]))
 nnet = api.Nnet(net, priors)
 fst = api.Fst(g)
@@ -27,7 +29,7 @@ cfg = api.decoder_config(**bench.DECODE_CFG)
 dec = api.LatticeFasterDecoder(fst, cfg, max_batch=n_utts, max_frames=int(np.diff(off).max()))
 n_pdf = net[-1]["output_dim"]
 ll = torch.empty((int(off[-1]), n_pdf), dtype=torch.float32, device="cuda")
-bench.forward_all(api, torch, nnet, torch.from_numpy(feats).cuda(), off, ll, max_rows=60000)
+bench.forward_all(nnet, torch.from_numpy(feats).cuda(), off, ll, max_rows=60000)
 dec.decode(ll, off)
 dec.prepare()
 lens = np.diff(off)
