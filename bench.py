@@ -180,6 +180,22 @@ def _cpu_secondary(binding, fwd):
     dt = time.perf_counter() - t0
     out["nnet_cfg3"] = {"frames_per_s": len(x) / dt, "kind": "reference" if fwd.kind == "ref" else "port", "cores": 1,
                         "sample": "forward of %d frames, %.1f s" % (len(x), dt)}
+    # config 3 end to end: forward + reference-order LatticeFasterDecoder on the wsj-sized structured workload
+    bs = importlib.import_module("tools.bench_secondary")
+    net3d, pri3d, g3, feats3, off3, scores3 = bs.cfg3_workload(333)
+    lens3 = np.diff(off3)
+    pick = np.argsort(np.abs(lens3 - np.median(lens3)), kind="stable")[:2]
+    t0 = time.perf_counter()
+    for u in pick:
+        fwd.decodable_am_nnet(net3d, pri3d, ACWT, feats3[off3[u]:off3[u + 1]])
+        dec3 = binding.DecoderOracle(g3, binding.decoder_config(**DECODE_CFG), mode="reference")
+        dec3.decode(scores3(int(u)))
+        dec3.best_path()
+        dec3.raw_lattice()
+    dt = time.perf_counter() - t0
+    n3 = int(lens3[pick].sum())
+    out["decode_cfg3"] = {"frames_per_s": n3 / dt, "kind": "port", "cores": 1,
+                          "sample": "2 median-length utterances (%d frames), forward + reference-order decode, %.1f s" % (n3, dt)}
     # config 5: lattice forward-backward (denominator lattices: structured graph, lattice-beam 8)
     rng = np.random.default_rng(5)
     P, T, N = 600, 200, 6

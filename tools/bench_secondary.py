@@ -62,6 +62,66 @@ def nnet_cfg3(api, torch, T=120_000):
             "peak_tflops": 157.3, "frac": flops / dt / 1e12 / 157.3}
 
 
+def cfg3_workload(n_utts, graph_states=2_000_000, seed=33):
+    """Config 3 (egs/wsj nnet5d decode) at its sizes: the wsj p-norm network, an HCLG-structured graph
+    with its 3400 pdfs, utterances sampled from the graph.  The wsj network has no constant input
+    part to carry a per-frame target (bench.py's nnet_a workload uses the iVector dimensions for
+    that), so the decoder's scores are synthetic rows that follow the sampled paths (competitors
+    N(-0.37, 0.28), the path's pdf 0.5 +- 0.3 after the acoustic scale: the figures the nnet_a workload
+    produces) and the forward pass is timed on random features of the same shape.  Pure numpy."""
+    W = importlib.import_module(PKG + ".workloads")
+    rng = np.random.default_rng(seed)
+    net, priors = W.wsj_nnet5d(rng)
+    g = W.make_hclg_structured(np.random.default_rng(seed + 2), graph_states, net[-1]["output_dim"])
+    urng = np.random.default_rng(seed + 4)
+    lens = np.sort(W.utterance_lengths(urng, n_utts))[::-1].copy()
+    seqs = W.sample_paths(urng, g, lens)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    feats = urng.standard_normal((int(off[-1]), 40)).astype(np.float32)
+
+    def scores(u):
+        q = seqs[u]
+        r = np.random.default_rng(seed * 1000 + u)
+        x = (r.standard_normal((len(q), net[-1]["output_dim"])) * 0.28 - 0.37).astype(np.float32)
+        x[np.arange(len(q)), q] = (0.5 + 0.3 * r.standard_normal(len(q))).astype(np.float32)
+        return x
+    return net, priors, g, feats, off, scores
+
+
+def decode_cfg3(api, torch, n_utts=333):
+    """Config 3 end to end: forward + LatticeFasterDecoder (beam 15, max-active 7000, lattice-beam 8,
+    acwt 0.1: steps/nnet2/decode.sh) of an eval92-sized set (333 utterances) in one launch."""
+    net, priors, g, feats, off, scores = cfg3_workload(n_utts)
+    nnet = api.Nnet(net, priors)
+    fst = api.Fst(g)
+    cfg = api.decoder_config(beam=15.0, max_active=7000, min_active=200, lattice_beam=8.0)
+    dec = api.LatticeFasterDecoder(fst, cfg, max_batch=n_utts, max_frames=int(np.diff(off).max()))
+    x = torch.from_numpy(feats).cuda()
+    ll = torch.empty((int(off[-1]), net[-1]["output_dim"]), dtype=torch.float32, device="cuda")
+    sc = torch.empty_like(ll)
+    for u in range(n_utts):
+        sc[off[u]:off[u + 1]] = torch.from_numpy(scores(u)).cuda()
+
+    def step():
+        u0 = 0
+        while u0 < n_utts:
+            u1 = u0 + 1
+            while u1 < n_utts and off[u1 + 1] - off[u0] <= 60000:
+                u1 += 1
+            nnet.compute(x[off[u0]:off[u1]], (off[u0:u1 + 1] - off[u0]).astype(np.int32), True, epilogue=True, prob_scale=0.1,
+                         out=ll[off[u0]:off[u1]])
+            u0 = u1
+        dec.decode(sc, off)
+        dec.prepare()
+    dt = _timeit(step, lambda: torch.cuda.synchronize(), reps=2)
+    st = [dec.stats(u) for u in range(0, n_utts, 37)]
+    arcs = sum(s["num_links"] for s in st) / max(1, sum(s["num_frames"] for s in st))
+    return {"workload": "wsj_nnet5d_structured: %d utterances, %d frames, graph %d states / %d arcs, 3400 pdfs; forward on random "
+                        "features, decoder scores synthetic along sampled paths" % (n_utts, int(off[-1]), int(g["num_states"]), int(g["arc_offsets"][-1])),
+            "ms_per_step": dt * 1e3, "frames_per_s": int(off[-1]) / dt, "kernel_ms": dec.last_kernel_ms(),
+            "lattice_arcs_per_frame": arcs, "ok": int(sum(dec.stats(u)["reached_final"] for u in range(n_utts)))}
+
+
 def lattice_fb_cfg5(api, torch, N=256, T=400):
     """Config 5 (egs/swbd MMI / sMBR): denominator lattices of N utterances (raw lattices of a
     structured-graph decode).  (a) kh_lattice_forward_backward alone: upload, device
@@ -152,7 +212,7 @@ def ivector_f3(api, torch, n_utts=2620, mean_len=740):
 
 def run_all(api, torch):
     out = {}
-    for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5),
+    for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("decode_cfg3", decode_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5),
                      ("ivector_f3", ivector_f3)):
         try:
             out[name] = fn(api, torch)
