@@ -162,7 +162,7 @@ struct Utt {
   Arr<float> tok_extra;
   // link arena
   int32_t link_cap;
-  Arr<int32_t> link_dst; Arr<int32_t> link_il; Arr<int32_t> link_ol;   // dst: token index, -1 = excised
+  Arr<int32_t> link_dst; Arr<int32_t> link_arc;   // dst: token index, -1 = excised; arc: index of the emitting arc, or -1 - index of the epsilon arc (labels are read from the arc at export)
   Arr<int32_t> link_src;     // owning token (links are also walked link-parallel)
   Arr<float> link_g; Arr<float> link_a;
   Arr<float> link_tot;       // candidate tot_cost of the frame being expanded [link_frame_cap]
@@ -950,8 +950,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         }
         u.link_dst[l] = dst;
         u.link_src[l] = src;
-        u.link_il[l] = 0;
-        u.link_ol[l] = arc.y;
+        u.link_arc[l] = -1 - ai;
         u.link_g[l] = g;
         // The acoustic cost of an epsilon link is 0; its field holds the constant part of
         // link_extra_cost (:309-311) instead, (cost[src] + 0 + g) - cost[dst]: both costs
@@ -1032,7 +1031,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   long long my_arcs = 0;
   constexpr int kLU = 1;  // (2 in flight per lane: no gain, +16 B of scratch per lane)
   KhInt4 c_arc[kLU];
-  int c_src[kLU], c_pdf[kLU];
+  int c_src[kLU], c_pdf[kLU], c_ai[kLU];
   uint32_t c_co[kLU];
   float c_ac[kLU], c_tot[kLU];
   const int link_frame_e = ExpandWavesFiltered(
@@ -1041,6 +1040,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_emit);
         c_arc[k] = p.e_arcs[ai];
+        c_ai[k] = ai;
         c_pdf[k] = p.e_pdf ? static_cast<int>(p.e_pdf[ai]) : -1;
         c_src[k] = src;
         c_co[k] = src_cost;
@@ -1057,8 +1057,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       [&](int k, int l) {
         u.link_dst[l] = c_arc[k].w;  // HCLG next state for now; token index after pass 2
         u.link_src[l] = c_src[k];
-        u.link_il[l] = c_arc[k].x;
-        u.link_ol[l] = c_arc[k].y;
+        u.link_arc[l] = c_ai[k];
         u.link_g[l] = __int_as_float(c_arc[k].z);
         u.link_a[l] = c_ac[k];
         u.link_tot[l - link_frame_b] = c_tot[k];
@@ -1916,13 +1915,13 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
           if (prof) { sh->phase[35] += 1; sh->phase[36] += span; sh->phase[37] += total; }
           // three steps over the group so that the loads of its chunks are in flight together:
           // fields, then the remapped token indices (they depend on the fields), then the stores
-          int src[KC], il[KC], ol[KC];
+          int src[KC], arc[KC];
           float g[KC], a[KC];
 #pragma unroll
           for (int k = 0; k < KC; k++) {
             if (!alive[k]) continue;
             const int l = base + k * NT + threadIdx.x;
-            src[k] = u.link_src[l]; il[k] = u.link_il[l]; ol[k] = u.link_ol[l];
+            src[k] = u.link_src[l]; arc[k] = u.link_arc[l];
             g[k] = u.link_g[l]; a[k] = u.link_a[l];
           }
 #pragma unroll
@@ -1936,16 +1935,16 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             if (!alive[k]) continue;
             const int d = lend + off[k];
             u.link_dst[d] = dst[k]; u.link_src[d] = src[k];
-            u.link_il[d] = il[k]; u.link_ol[d] = ol[k]; u.link_g[d] = g[k]; u.link_a[d] = a[k];
+            u.link_arc[d] = arc[k]; u.link_g[d] = g[k]; u.link_a[d] = a[k];
           }
         } else {
           span = min(NT, chunk_e - base);
           const int l = base + threadIdx.x;
-          int dst = -1, src = 0, il = 0, ol = 0;
+          int dst = -1, src = 0, arc = 0;
           float g = 0.f, a = 0.f;
           if (l < chunk_e) {
             dst = u.link_dst[l];
-            if (dst >= 0) { src = u.link_src[l]; il = u.link_il[l]; ol = u.link_ol[l]; g = u.link_g[l]; a = u.link_a[l]; }
+            if (dst >= 0) { src = u.link_src[l]; arc = u.link_arc[l]; g = u.link_g[l]; a = u.link_a[l]; }
           }
           const int alive = dst >= 0 ? 1 : 0;
           off[0] = BlockExScan(alive, &total, sh);
@@ -1956,7 +1955,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             const int d = lend + off[0];
             u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
             u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
-            u.link_il[d] = il; u.link_ol[d] = ol; u.link_g[d] = g; u.link_a[d] = a;
+            u.link_arc[d] = arc; u.link_g[d] = g; u.link_a[d] = a;
           }
         }
         while (bj < nb) {   // the block bounds inside this group
@@ -2194,7 +2193,7 @@ __device__ __forceinline__ int FrameOfToken(const Utt &u, int i, int T) {
 }
 
 // GetRawLattice :109-191 device half: survivors -> pool (frame, state) / (src, dst, labels, costs).
-__device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &sh) {
+__device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, UttOut *out, Blk &sh) {
   const int tok_end = Uni(sh->tok_end), link_end = Uni(sh->link_end), T = u.T;
   // pass A: alive tokens -> dense indices (tmp_remap)
   int n_tok = 0;
@@ -2250,7 +2249,9 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &
     const int off = BlockExScan(alive, &total, sh);
     if (alive) {
       const long long d = lbase + lrun + off;
-      const int src = u.link_src[l], il = u.link_il[l];
+      const int src = u.link_src[l], arc = u.link_arc[l];
+      const KhInt4 rec = arc >= 0 ? p.e_arcs[arc] : p.n_arcs[-1 - arc];   // labels: from the arc (3 % of the links survive to here)
+      const int il = arc >= 0 ? rec.x : 0;
       float a = il != 0 ? u.link_a[l] : 0.0f;  // (an epsilon link's field holds its extra-cost constant)
       if (il != 0) {  // :168-174 the acoustic cost without the frame's cost_offset
         const int f = FrameOfToken(u, src, T);
@@ -2259,7 +2260,7 @@ __device__ void ExportLattice(const Utt &u, const Pool &pool, UttOut *out, Blk &
       pool.l_src[d] = u.tmp_remap[src];
       pool.l_dst[d] = u.tmp_remap[dst];
       pool.l_il[d] = il;
-      pool.l_ol[d] = u.link_ol[l];
+      pool.l_ol[d] = rec.y;
       pool.l_g[d] = u.link_g[l];
       pool.l_a[d] = a;
     }
@@ -2322,7 +2323,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     DecodeOne(u, p, sh, &st);
     if (threadIdx.x == 0) out[ui].stats = st;
     KhSync();
-    if (st.status == 0) ExportLattice(u, pool, &out[ui], sh);
+    if (st.status == 0) ExportLattice(u, p, pool, &out[ui], sh);
     // The lattice pool, `out` and the completion list live in pinned HOST memory: the host
     // builds the utterance's canonical lattice and best path while this kernel decodes the
     // next ones.  Every wave's stores are complete behind KhSync(); thread 0 then releases
@@ -2442,7 +2443,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
       out[blockIdx.x].stats = st;
     }
     KhSync();
-    ExportLattice(u, pool, &out[blockIdx.x], sh);
+    ExportLattice(u, p, pool, &out[blockIdx.x], sh);
   }
 }
 
@@ -2625,8 +2626,7 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tmp_remap = c.Take<int32_t>(nt);
   u.link_dst = c.Take<int32_t>(nl);
   u.link_src = c.Take<int32_t>(nl);
-  u.link_il = c.Take<int32_t>(nl);
-  u.link_ol = c.Take<int32_t>(nl);
+  u.link_arc = c.Take<int32_t>(nl);
   u.link_g = c.Take<float>(nl);
   u.link_a = c.Take<float>(nl);
   u.link_tot = c.Take<float>(link_frame_cap);
