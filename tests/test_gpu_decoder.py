@@ -337,6 +337,24 @@ def test_pdf_map_is_validated(api):
             torch.zeros((10, 30), device="cuda"))
 
 
+def test_score_matrix_wider_than_16_bit_pdf_ids(api):
+    """The pdf of every emitting arc normally rides next to the arcs as 16 bits; a score matrix with
+    more than 65536 columns takes the transition-id -> pdf gather instead.  Same lattices either way:
+    the rows are padded with columns no transition-id maps to."""
+    rng = np.random.default_rng(77)
+    g = graph_like_hclg(rng, 3000, 60)
+    cfg = api.decoder_config(beam=10.0, max_active=500, min_active=20, lattice_beam=5.0)
+    x = workloads.make_loglikes(rng, 40, 60)
+    wide = np.full((40, 65600), -30.0, np.float32)
+    wide[:, :60] = x
+    dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=1, max_frames=40)
+    dec.decode(torch.from_numpy(wide).cuda())
+    oc = B.DecoderOracle(g, cfg, "canonical")
+    assert oc.decode(x)
+    assert_same_lattice(dec.get_raw_lattice(0), oc.raw_lattice())
+    assert_same_best_path(dec.get_best_path(0), oc.best_path())
+
+
 def test_decoder_object_reused_across_batches(api):
     """One LatticeFasterDecoder object, successive Decode() batches of growing utterance
     count and length (arena slab re-carved, slots refilled): every batch bit-exact."""
