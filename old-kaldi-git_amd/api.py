@@ -1364,3 +1364,41 @@ class OnlineIvectorExtractor:
         if getattr(self, "_h", None):
             capi.load().kh_ivector_extractor_destroy(self._h)
             self._h = None
+
+
+class OnlineNnet2FeaturePipeline:
+    """online2/online-nnet2-feature-pipeline.{h,cc} for a batch of whole utterances (what
+    online2-wav-nnet2-latgen-faster --online=false feeds the decoder): base features (OnlineMfcc,
+    :83) of every waveform, the iVector of every frame (OnlineIvectorFeature, :105-106) and
+    OnlineAppendFeature (:107-108): row = [mfcc, ivector]."""
+
+    def __init__(self, mfcc, ivector_extractor=None):
+        self.mfcc, self.ivector = mfcc, ivector_extractor
+        if ivector_extractor is not None and ivector_extractor.cfg.base_dim != mfcc.num_ceps:
+            raise KhError("OnlineNnet2FeaturePipeline: iVector extractor expects %d-dim base features, MFCC gives %d"
+                          % (ivector_extractor.cfg.base_dim, mfcc.num_ceps))
+
+    def dim(self):
+        return self.mfcc.num_ceps + (self.ivector.ivector_dim if self.ivector is not None else 0)
+
+    def compute(self, waves):
+        """waves: list of 1-D float32 device tensors.  Returns (features [sum T x Dim()] on the device,
+        utterance row offsets); an utterance shorter than one frame contributes no rows."""
+        base = [self.mfcc.compute(w) for w in waves]
+        lens = np.array([b.shape[0] for b in base], np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = int(off[-1])
+        d0 = self.mfcc.num_ceps
+        stride = (self.dim() + 3) // 4 * 4
+        dev = waves[0].device if waves else "cuda"
+        out = torch.empty((max(rows, 1), stride), dtype=torch.float32, device=dev)[:rows, :self.dim()]
+        if rows == 0:
+            return out, off
+        allbase = torch.cat([b for b in base if b.shape[0]], 0).contiguous()
+        out[:, :d0] = allbase
+        if self.ivector is not None:
+            keep = lens > 0                      # kh_ivector_extract takes non-empty utterances
+            off_nz = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.int32)
+            iv = self.ivector.extract(allbase, off_nz)
+            out[:, d0:] = iv
+        return out, off

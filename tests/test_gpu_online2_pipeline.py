@@ -1,0 +1,100 @@
+"""GPU: BASELINE config 4 front to back, the flow of online2-wav-nnet2-latgen-faster --online=false
+(online2bin/online2-wav-nnet2-latgen-faster.cc): waveform -> MFCC -> iVector per frame ->
+[mfcc, ivector] -> p-norm network with the iVector as the splice component's constant part ->
+LatticeFasterDecoder -> pruned determinization, every stage on the device behind the C-ABI and
+every stage checked against its oracle: features and log-likelihoods within the stated tolerances,
+lattices bit-exact against the canonical decoder oracle run on the same log-likelihood rows, the
+determinized lattice's best path = the raw lattice's."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import binding as B
+from oracle import ivector_oracle as IO
+from test_feature_oracle import check_mfcc, wave
+from test_gpu_decoder import assert_same_best_path, assert_same_lattice
+
+pytestmark = pytest.mark.gpu
+api = importlib.import_module("old-kaldi-git_amd.api")
+workloads = importlib.import_module("old-kaldi-git_amd.workloads")
+ACWT = 0.1
+
+
+def compact_best_path(C):
+    """(words, transition-ids, total cost) of the cheapest path of a CompactLattice dict (a DAG)."""
+    out = {}
+    for j in range(len(C["arc_src"])):
+        out.setdefault(int(C["arc_src"][j]), []).append(j)
+    memo = {}
+
+    def best(s):
+        if s in memo:
+            return memo[s]
+        res = (float("inf"), [], [])
+        if np.isfinite(C["final_g"][s]):
+            res = (float(C["final_g"][s]) + float(C["final_a"][s]), [], [int(t) for t in C["final_string"][s]])
+        for j in out.get(s, []):
+            c, w, a = best(int(C["arc_dst"][j]))
+            c += float(C["arc_g"][j]) + float(C["arc_a"][j])
+            if c < res[0]:
+                lab = int(C["arc_label"][j])
+                res = (c, ([lab] if lab else []) + w, [int(t) for t in C["arc_string"][j]] + a)
+        memo[s] = res
+        return res
+    c, w, a = best(0)
+    return w, a, c
+
+
+def test_wave_to_determinized_lattice(oracle):
+    rng = np.random.default_rng(91)
+    mfcc_kw = dict(num_bins=23, num_ceps=13, low_freq=20.0, high_freq=0.0)
+    iv_model = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=32, ivector_dim=10, prior_offset=5.0)
+    n_pdf = 40
+    net, priors = workloads.make_pnorm_net(rng, feat_dim=13, splice=2, const_dim=10, pnorm_in=60, pnorm_out=12, n_hidden=2,
+                                           n_mix=2 * n_pdf, n_pdf=n_pdf, final_scale=3.0)
+    g = workloads.make_hclg_structured(rng, 20_000, n_pdf)
+    waves = [wave(5, 16000 + 123), wave(6, 9000), wave(7, 200)]        # the last one is shorter than a frame
+    pipe = api.OnlineNnet2FeaturePipeline(api.Mfcc(**mfcc_kw), api.OnlineIvectorExtractor(iv_model))
+    feats, off = pipe.compute([torch.from_numpy(w).cuda() for w in waves])
+    assert pipe.dim() == 23 and off.tolist()[-1] == feats.shape[0] and off[3] == off[2]
+    ko = B.OracleLib("ko")
+    want = []
+    for w in waves[:2]:
+        m = ko.mfcc_compute(w, **mfcc_kw)
+        want.append(np.concatenate([m, IO.extract(m, iv_model)], 1))
+    got = feats.cpu().numpy()
+    for u in range(2):
+        gu = got[off[u]:off[u + 1]]
+        check_mfcc(gu[:, :13], want[u][:, :13])
+        # the iVector is estimated from the MFCCs: their 2e-3 (float FFT vs DFT) reaches it damped
+        assert np.abs(gu[:, 13:] - want[u][:, 13:]).max() < 5e-3
+    # network: log-likelihoods of the GPU features against the oracle on the SAME features
+    nnet = api.Nnet(net, priors)
+    off2 = off[:3].copy()
+    ll, ll_off = nnet.compute(feats, off2, True, epilogue=True, prob_scale=ACWT)
+    torch.cuda.synchronize()
+    ll_h = ll.cpu().numpy()
+    for u in range(2):
+        ref = oracle.decodable_am_nnet(net, priors, ACWT, got[off[u]:off[u + 1]])
+        assert np.abs(ll_h[ll_off[u]:ll_off[u + 1]] - ref).max() < 1e-4
+    # decoder + determinization
+    cfg = api.decoder_config(beam=13.0, max_active=3000, min_active=100, lattice_beam=6.0)
+    dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=2, max_frames=int(np.diff(ll_off).max()))
+    dec.decode(ll, np.asarray(ll_off, np.int32))
+    for u in range(2):
+        x = np.ascontiguousarray(ll_h[ll_off[u]:ll_off[u + 1]])
+        oc = B.DecoderOracle(g, cfg, "canonical")
+        assert oc.decode(x)
+        raw = dec.get_raw_lattice(u)
+        assert_same_lattice(raw, oc.raw_lattice())
+        bp = dec.get_best_path(u)
+        assert_same_best_path(bp, oc.best_path())
+        clat = api.determinize_lattice_pruned(raw, cfg["lattice_beam"])
+        assert clat["complete"]
+        # best path of the determinized lattice: the raw lattice's words, alignment and total cost
+        words, ali, cost = compact_best_path(clat)
+        assert words == [int(w) for w in bp["words"]]
+        assert ali == [int(t) for t in bp["alignment"]]
+        assert abs(cost - (float(bp["graph_cost"]) + float(bp["acoustic_cost"]))) < 1e-3
