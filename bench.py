@@ -505,7 +505,7 @@ def main():
     strong_rec = run(strong[0], strong[1], args.steps, args.warmup) if strong is not None else None
 
     secondary = None
-    if rank == 0 and not args.no_secondary and not args.small:
+    if rank == 0 and world == 1 and not args.no_secondary and not args.small:   # (the other ranks would wait at the final barrier)
         try:
             sec = importlib.import_module("tools.bench_secondary")
             secondary = sec.run_all(api, torch)
