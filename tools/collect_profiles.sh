@@ -17,6 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # the bench line LAST: its roofline.traffic reads the PMC summaries of THIS build
 cp "$out/${tag}_pmc_FETCH_SIZE.txt" "$out/${tag}_pmc_WRITE_SIZE.txt" profiles/ 2>/dev/null
-KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout $T python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/${tag}_decoder_phases.txt"
+KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout $T python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/bench.err"
+python3 tools/phases_extract.py "$out/bench.err" > "$out/${tag}_decoder_phases.txt"
 rm -rf "$out/kt" "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE
 ls -la "$out"
