@@ -1159,3 +1159,206 @@ def write_fst(f, g):
     fin = np.asarray(g["final"], np.float32)
     for st in range(n):
         f.write(struct.pack("<f", fin[st]) + struct.pack("<q", off[st + 1] - off[st]) + arcs[off[st]:off[st + 1]].tobytes())
+
+
+# ---------------------------------------------------------------- online2 front-end files
+def read_sp_matrix(s, binary=True):
+    """SpMatrix<Real> = PackedMatrix<Real>::Read (matrix/packed-matrix.cc:132-234): binary "FP"/"DP" +
+    int32 rows + the lower triangle by rows; text "[ r0 \\n r1 r1 ... ]".  Returns the FULL symmetric
+    matrix (float64 for "DP")."""
+    s = _as_stream(s)
+    if binary:
+        tok = read_token(s, binary)
+        if tok not in ("FP", "DP"):
+            raise ValueError("Expected token FP or DP, got " + tok)
+        n = read_int32(s)
+        dt, w = ("<f4", 4) if tok == "FP" else ("<f8", 8)
+        m = n * (n + 1) // 2
+        packed = np.frombuffer(s.get(m * w), dtype=dt)
+    else:
+        s.skip_ws()
+        if s.get() != b"[":
+            raise ValueError("Expected \"[\" at the start of a text packed matrix")
+        rows = _read_text_rows(s)
+        n = len(rows)
+        if any(len(r) != i + 1 for i, r in enumerate(rows)):
+            raise ValueError("PackedMatrix: row i must hold i + 1 elements")
+        packed = np.asarray([x for r in rows for x in r], np.float64)
+    out = np.zeros((n, n), packed.dtype)
+    r, c = np.tril_indices(n)
+    out[r, c] = packed
+    out[c, r] = packed
+    return out
+
+
+def write_sp_matrix(f, M, binary=True):
+    """PackedMatrix<Real>::Write (packed-matrix.cc:236-271) of the lower triangle of M."""
+    M = np.asarray(M)
+    dt, tok = ("<f8", b"DP ") if M.dtype == np.float64 else ("<f4", b"FP ")
+    n = M.shape[0]
+    r, c = np.tril_indices(n)
+    packed = np.ascontiguousarray(M[r, c], dt)
+    if binary:
+        f.write(tok + b"\x04" + struct.pack("<i", n) + packed.tobytes())
+    elif n == 0:
+        f.write(b"[ ]\n")
+    else:
+        f.write(b"[\n")
+        i = 0
+        for j in range(n):
+            f.write(b"".join((_fmt(x) + " ").encode() for x in packed[i:i + j + 1]))
+            i += j + 1
+            f.write(b"]\n" if j == n - 1 else b"\n")
+
+
+def read_double(s, binary=True):
+    """ReadBasicType<double> (io-funcs-inl.h: size byte 8 + the value; text: a word)."""
+    if binary:
+        if s.get() != b"\x08":
+            raise ValueError("ReadBasicType: expected a double")
+        return struct.unpack("<d", s.get(8))[0]
+    return float(_text_word(s))
+
+
+def write_double(f, binary, v):
+    f.write(b"\x08" + struct.pack("<d", float(v)) if binary else (repr(float(v)) + " ").encode())
+
+
+def write_diag_gmm(f, weights, means_invvars, inv_vars, binary=True):
+    """DiagGmm::Write (gmm/diag-gmm.cc:705-720); the gconsts are recomputed as ComputeGconsts does
+    (in float: the reader drops them anyway)."""
+    w = np.asarray(weights, np.float32)
+    mi = np.asarray(means_invvars, np.float32)
+    iv = np.asarray(inv_vars, np.float32)
+    D = mi.shape[1]
+    g = np.log(w.astype(np.float64)) - 0.5 * (D * np.log(2 * np.pi) + np.sum(-np.log(iv.astype(np.float64)) +
+                                                                           mi.astype(np.float64) ** 2 / iv.astype(np.float64), 1))
+    write_token(f, binary, "<DiagGMM>")
+    if not binary:
+        f.write(b"\n")
+    write_token(f, binary, "<GCONSTS>")
+    write_vector(f, g.astype(np.float32), binary)
+    write_token(f, binary, "<WEIGHTS>")
+    write_vector(f, w, binary)
+    write_token(f, binary, "<MEANS_INVVARS>")
+    write_matrix(f, mi, binary)
+    write_token(f, binary, "<INV_VARS>")
+    write_matrix(f, iv, binary)
+    write_token(f, binary, "</DiagGMM>")
+    if not binary:
+        f.write(b"\n")
+
+
+def read_ivector_extractor(s, binary=True):
+    """IvectorExtractor::Read (ivector/ivector-extractor.cc:727-748): dict(w [n x S] or empty, w_vec [n],
+    M [n x D x S], Sigma_inv [n x D x D] (full), prior_offset), all float64."""
+    expect_token(s, binary, "<IvectorExtractor>")
+    expect_token(s, binary, "<w>")
+    w = read_matrix(s, binary).astype(np.float64)
+    expect_token(s, binary, "<w_vec>")
+    w_vec = read_vector(s, binary).astype(np.float64)
+    expect_token(s, binary, "<M>")
+    n = read_int32(s, binary)
+    if n <= 0:
+        raise ValueError("IvectorExtractor::Read: size > 0")
+    M = np.stack([read_matrix(s, binary).astype(np.float64) for _ in range(n)])
+    expect_token(s, binary, "<SigmaInv>")
+    Si = np.stack([read_sp_matrix(s, binary).astype(np.float64) for _ in range(n)])
+    expect_token(s, binary, "<IvectorOffset>")
+    off = read_double(s, binary)
+    expect_token(s, binary, "</IvectorExtractor>")
+    return dict(w=w, w_vec=w_vec, M=M, Sigma_inv=Si, prior_offset=off)
+
+
+def write_ivector_extractor(f, ext, binary=True):
+    """IvectorExtractor::Write (ivector-extractor.cc:706-724)."""
+    write_token(f, binary, "<IvectorExtractor>")
+    write_token(f, binary, "<w>")
+    write_matrix(f, np.asarray(ext["w"], np.float64), binary)
+    write_token(f, binary, "<w_vec>")
+    write_vector(f, np.asarray(ext["w_vec"], np.float64), binary)
+    write_token(f, binary, "<M>")
+    M = np.asarray(ext["M"], np.float64)
+    write_int32(f, binary, len(M))
+    for Mi in M:
+        write_matrix(f, Mi, binary)
+    write_token(f, binary, "<SigmaInv>")
+    for Si in np.asarray(ext["Sigma_inv"], np.float64):
+        write_sp_matrix(f, Si, binary)
+    write_token(f, binary, "<IvectorOffset>")
+    write_double(f, binary, ext["prior_offset"])
+    write_token(f, binary, "</IvectorExtractor>")
+
+
+def read_kaldi_object(path, reader):
+    """A Kaldi object file: optional "\\0B" header, then the object (Input::Open + Read)."""
+    with open(path, "rb") as f:
+        s = Stream(f)
+        binary = init_kaldi_input(s)
+        return reader(s, binary)
+
+
+def read_wave(path_or_file):
+    """WaveData::Read (feat/wave-reader.cc:105-270) for little-endian RIFF PCM-16 files: returns
+    (samp_freq, data [channels x samples] float32 with the int16 values, as the reference keeps them)."""
+    f = open(path_or_file, "rb") if isinstance(path_or_file, (str, bytes)) else path_or_file
+    try:
+        b = f.read()
+    finally:
+        if isinstance(path_or_file, (str, bytes)):
+            f.close()
+    if b[:4] != b"RIFF":
+        raise ValueError("WaveData: expected RIFF, got %r" % b[:4])
+    if b[8:12] != b"WAVE" or b[12:16] != b"fmt ":
+        raise ValueError("WaveData: expected WAVE and a fmt chunk")
+    sub1 = struct.unpack("<I", b[16:20])[0]
+    fmt, ch, rate, byte_rate, align, bits = struct.unpack("<HHIIHH", b[20:36])
+    if fmt != 1:
+        raise ValueError("WaveData: can read only PCM data, format id in file is: %d" % fmt)
+    if ch == 0:
+        raise ValueError("WaveData: no channels present")
+    if bits != 16:
+        raise ValueError("WaveData: unsupported bits_per_sample = %d" % bits)
+    if byte_rate != rate * bits // 8 * ch or align != ch * bits // 8:
+        raise ValueError("WaveData: unexpected byte rate / block align")
+    p = 20 + sub1
+    while b[p:p + 4] != b"data":       # "fact" / "LIST" chunks between fmt and data are skipped
+        if p + 8 > len(b):
+            raise ValueError("WaveData: expected data chunk")
+        p += 8 + struct.unpack("<I", b[p + 4:p + 8])[0]
+    n = struct.unpack("<I", b[p + 4:p + 8])[0]
+    raw = np.frombuffer(b[p + 8:p + 8 + n - n % (2 * ch)], "<i2")
+    return float(rate), raw.reshape(-1, ch).T.astype(np.float32)
+
+
+def write_wave(f, samp_freq, data):
+    """WaveData::Write (wave-reader.cc:274-360): 16-bit PCM; the samples are truncated to integers
+    (static_cast<int32>) and must fit int16 as there."""
+    d = np.asarray(data, np.float32)
+    if d.ndim == 1:
+        d = d[None, :]
+    ch, n = d.shape
+    q = np.trunc(d.T).astype(np.int64)
+    if q.size and (q.min() < -32768 or q.max() > 32767):
+        raise ValueError("Wave file is out of range for 16-bit.")
+    pcm = q.astype("<i2").tobytes()
+    rate = int(samp_freq)
+    f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, ch, rate, rate * 2 * ch, 2 * ch, 16) +
+            b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def read_config_file(path):
+    """ParseOptions::ReadConfigFile (util/parse-options.cc:451-500): one "--name=value" (or "--flag")
+    per line, "#" comments; names keep their dashes -> dict name -> string."""
+    out = {}
+    with open(path) as f:
+        for n, line in enumerate(f, 1):
+            line = line.split("#", 1)[0].strip()
+            if not line:
+                continue
+            if not line.startswith("--"):
+                raise ValueError("Reading config file %s: line %d does not look like a line from a Kaldi command-line "
+                                 "program's config file: should be of the form --x=y" % (path, n))
+            k, _, v = line[2:].partition("=")
+            out[k.strip()] = v.strip() if _ else "true"
+    return out

@@ -20,6 +20,7 @@
 #include "cudamatrix/cu-matrix-lib.h"
 #include "feat/feature-functions.h"
 #include "feat/feature-mfcc.h"
+#include "feat/wave-reader.h"
 #include "feat/online-feature.h"
 #include "matrix/optimization.h"
 #include "gmm/am-diag-gmm.h"
@@ -664,6 +665,72 @@ int ref_write_am_diag_gmm(const char *path, const float *weights, const float *m
     }
     std::ofstream os(path, std::ios::binary);
     am.Write(os, binary != 0);
+    return os.good() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// One DiagGmm as a Kaldi file ("\0B" header + DiagGmm::Write, diag-gmm.cc:705-720): final.dubm
+int ref_write_diag_gmm_file(const char *path, const float *weights, const float *means, const float *vars, int n, int dim,
+                            int binary) {
+  try {
+    DiagGmm gmm;
+    FillGmm(&gmm, weights, means, vars, n, dim);
+    gmm.ComputeGconsts();
+    Output ko(path, binary != 0);
+    gmm.Write(ko.Stream(), binary != 0);
+    return ko.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// The byte sequence of IvectorExtractor::Write (ivector/ivector-extractor.cc:706-724) produced with the
+// reference's own primitives (WriteToken, Matrix<double>::Write, SpMatrix<double>::Write,
+// WriteBasicType) - ivector-extractor.cc itself needs OpenFst headers.  M: [n][feat_dim][ivector_dim],
+// Sigma_inv: [n][feat_dim][feat_dim] full (symmetric), w: [n][ivector_dim] or empty (ivector_dim_w = 0).
+int ref_write_ivector_extractor(const char *path, const double *w, int w_rows, int w_cols, const double *w_vec, int n,
+                                int feat_dim, int ivector_dim, const double *M, const double *Sigma_inv, double prior_offset,
+                                int binary) {
+  try {
+    Output ko(path, binary != 0);
+    std::ostream &os = ko.Stream();
+    const bool b = binary != 0;
+    WriteToken(os, b, "<IvectorExtractor>");
+    WriteToken(os, b, "<w>");
+    Matrix<double> wm(w_rows, w_cols);
+    for (int r = 0; r < w_rows; r++)
+      for (int c = 0; c < w_cols; c++) wm(r, c) = w[static_cast<size_t>(r) * w_cols + c];
+    wm.Write(os, b);
+    WriteToken(os, b, "<w_vec>");
+    Vector<double> wv(n);
+    for (int i = 0; i < n; i++) wv(i) = w_vec[i];
+    wv.Write(os, b);
+    WriteToken(os, b, "<M>");
+    int32 size = n;
+    WriteBasicType(os, b, size);
+    for (int i = 0; i < n; i++) {
+      Matrix<double> Mi(feat_dim, ivector_dim);
+      for (int r = 0; r < feat_dim; r++)
+        for (int c = 0; c < ivector_dim; c++) Mi(r, c) = M[(static_cast<size_t>(i) * feat_dim + r) * ivector_dim + c];
+      Mi.Write(os, b);
+    }
+    WriteToken(os, b, "<SigmaInv>");
+    for (int i = 0; i < n; i++) {
+      SpMatrix<double> Si(feat_dim);
+      for (int r = 0; r < feat_dim; r++)
+        for (int c = 0; c <= r; c++) Si(r, c) = Sigma_inv[(static_cast<size_t>(i) * feat_dim + r) * feat_dim + c];
+      Si.Write(os, b);
+    }
+    WriteToken(os, b, "<IvectorOffset>");
+    WriteBasicType(os, b, prior_offset);
+    WriteToken(os, b, "</IvectorExtractor>");
+    return ko.Close() ? 0 : -1;
+  } catch (...) { return -1; }
+}
+// WaveData::Write (feat/wave-reader.cc): 16-bit PCM RIFF file of one channel
+int ref_write_wave(const char *path, const float *samples, int n, float samp_freq) {
+  try {
+    Matrix<BaseFloat> data(1, n);
+    for (int i = 0; i < n; i++) data(0, i) = samples[i];
+    WaveData wave(samp_freq, data);
+    std::ofstream os(path, std::ios::binary);
+    wave.Write(os);
     return os.good() ? 0 : -1;
   } catch (...) { return -1; }
 }

@@ -271,10 +271,23 @@ def make_kaldi_io():
                                              ip(am["pdf_offsets"]), 5, 6, binary) == 0
         assert ref.ref_write_topology(b("topo.bin"), b(TOPO_TEXT), 1) == 0
         assert ref.ref_write_topology(b("topo.txt"), b(TOPO_TEXT), 0) == 0
+        # the online2 front-end's files: final.dubm, final.ie, a wave file
+        ie = workloads.make_ivector_extractor(np.random.default_rng(14), base_dim=5, splice=1, feat_dim=4, num_gauss=3,
+                                              ivector_dim=6, prior_offset=7.5)
+        dp = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.POINTER(C.c_double))
+        for binary, name in ((1, "final.dubm"), (0, "final_dubm.txt")):
+            assert ref.ref_write_diag_gmm_file(b(name), fp(ie["ubm_weights"]), fp(ie["ubm_means"]), fp(ie["ubm_vars"]), 3, 4, binary) == 0
+        w_vec = np.log(ie["ubm_weights"].astype(np.float64))
+        for binary, name in ((1, "final.ie"), (0, "final_ie.txt")):
+            assert ref.ref_write_ivector_extractor(b(name), dp(np.zeros(0)), 0, 0, dp(w_vec), 3, 4, 6, dp(ie["M"]), dp(ie["Sigma_inv"]),
+                                                   C.c_double(ie["prior_offset"]), binary) == 0
+        wav = (np.random.default_rng(15).standard_normal(500) * 3000).astype(np.float32)
+        assert ref.ref_write_wave(b("utt.wav"), fp(wav), 500, C.c_float(16000.0)) == 0
     finally:
         os.chdir(cwd)
     np.savez_compressed(os.path.join(out_dir, "expected.npz"), M=M, v=v, big=big, small=small, big_rt=big_rt,
-                        small_rt=small_rt, iv=iv, feats=feats, off=off, feats_cm=feats_cm, ali=ali, ali_off=ali_off)
+                        small_rt=small_rt, iv=iv, feats=feats, off=off, feats_cm=feats_cm, ali=ali, ali_off=ali_off, wav=wav,
+                        ie_w_vec=w_vec)
     print("kaldi_io:", sorted(os.listdir(out_dir)))
 
 
