@@ -551,6 +551,10 @@ typedef struct KhIvectorConfig {
   int32_t ivector_period, num_gselect, num_cg_iters;
   float min_post, posterior_scale, max_count;
   double prior_offset;
+  /* 1: use_most_recent_ivector + greedy_ivector_extractor (what --online=false sets,
+   * online2-wav-nnet2-latgen-faster.cc: one estimate from all the frames of the utterance on every row);
+   * 0: use_most_recent_ivector = false (row t: the estimate of frame (t / period) * period) */
+  int32_t greedy_most_recent;
 } KhIvectorConfig;
 typedef struct KhIvectorExtractor KhIvectorExtractor;
 KhIvectorExtractor *kh_ivector_extractor_create(const KhIvectorConfig *cfg, const float *lda_mat,

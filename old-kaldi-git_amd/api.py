@@ -1336,6 +1336,8 @@ class OnlineIvectorExtractor:
             setattr(cfg, k, int(info[k]))
         for k in ("min_post", "posterior_scale", "max_count", "prior_offset"):
             setattr(cfg, k, float(info[k]))
+        # use_most_recent_ivector + greedy_ivector_extractor (--online=false): one estimate per utterance
+        cfg.greedy_most_recent = int(bool(info.get("greedy_most_recent", False)))
         self.cfg = cfg
         fp, dp = capi.c_float_p, capi.c_double_p
         self._h = lib().kh_ivector_extractor_create(C.byref(cfg), lda.ctypes.data_as(fp), gs.ctypes.data_as(dp),

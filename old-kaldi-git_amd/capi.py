@@ -48,7 +48,7 @@ class KhIvectorConfig(C.Structure):
         "cmn_window", "speaker_frames", "global_frames", "normalize_mean", "normalize_variance",
         "ivector_period", "num_gselect", "num_cg_iters")] + [
         ("min_post", C.c_float), ("posterior_scale", C.c_float), ("max_count", C.c_float),
-        ("prior_offset", C.c_double)]
+        ("prior_offset", C.c_double), ("greedy_most_recent", C.c_int32)]
 
 
 class KhDecodeStats(C.Structure):

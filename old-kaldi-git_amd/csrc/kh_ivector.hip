@@ -396,7 +396,10 @@ IvGammaKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
   for (int i = threadIdx.x; i < I; i += 256) gam[i] = 0.0;
   __syncthreads();
   int prev = b - 1;
-  for (int t = b, p = point_off[u]; t < e; t += period, p++) {
+  // period <= 0: use_most_recent_ivector + greedy_ivector_extractor (--online=false): ONE estimation
+  // point per utterance, at its last frame
+  const int step = period > 0 ? period : (e - b);
+  for (int t = period > 0 ? b : e - 1, p = point_off[u]; t < e; t += step, p++) {
     // the postings of frames (prev, t]
     const long long n = static_cast<long long>(t - prev) * G;
     for (long long j = threadIdx.x; j < n; j += 256) {
@@ -577,7 +580,8 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
   }
   double num_frames = 0.0, diag = 1.0;   // diag: the prior's share of the quadratic term (1, + the max_count rescaling :557-566)
   int prev = b - 1;
-  for (int t = b, p = point_off[u]; t < e; t += period, p++) {
+  const int step = period > 0 ? period : (e - b);   // period <= 0: one point at the last frame, its iVector on every row
+  for (int t = period > 0 ? b : e - 1, p = point_off[u]; t < e; t += step, p++) {
     // frames (prev, t]: linear term and counts
     double lin0_add = 0.0;
     for (int tt = prev + 1; tt <= t; tt++) {
@@ -609,9 +613,9 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
     __syncthreads();
     IvGetIvector<kT / 64>(quad, lin, xv, rv, pv, x0, S, cg_iters, prior_offset, num_frames > 0.0, red, n_fallback);
     __syncthreads();
-    const int last = (t + period < e) ? t + period : e;
-    for (int i = t_id; i < (last - t) * S; i += kT) {
-      const int row = t + i / S, sidx = i - (i / S) * S;
+    const int first = period > 0 ? t : b, last = period > 0 ? ((t + period < e) ? t + period : e) : e;
+    for (int i = t_id; i < (last - first) * S; i += kT) {
+      const int row = first + i / S, sidx = i - (i / S) * S;
       out[static_cast<size_t>(row) * out_stride + sidx] = static_cast<float>(xv[sidx] - (sidx == 0 ? prior_offset : 0.0));
     }
     __syncthreads();
@@ -758,7 +762,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
                        c.posterior_scale, d_pi, d_pw);
     // statistics + solves
     const size_t lin_lds = sizeof(double) * (static_cast<size_t>(D) * S + static_cast<size_t>(kLinTile) * D);
-    if (getenv("KH_IVECTOR_SEQUENTIAL") || lin_lds > 64 * 1024) {   // the per-utterance accumulation (A/B reference; very wide models)
+    if (!c.greedy_most_recent && (getenv("KH_IVECTOR_SEQUENTIAL") || lin_lds > 64 * 1024)) {   // the per-utterance accumulation (A/B reference; very wide models)
       const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D + static_cast<size_t>(G) * S);
       hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(kIvThreads), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
                          x->SiM, c.prior_offset, static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors,
@@ -768,7 +772,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
       // point, y: 8 G S bytes per frame)
       std::vector<int32_t> poff(n_utts + 1, 0);
       for (int u = 0; u < n_utts; u++)
-        poff[u + 1] = poff[u] + (utt_row_offsets_host[u + 1] - utt_row_offsets_host[u] + c.ivector_period - 1) / c.ivector_period;
+        poff[u + 1] = poff[u] + (c.greedy_most_recent ? 1 : (utt_row_offsets_host[u + 1] - utt_row_offsets_host[u] + c.ivector_period - 1) / c.ivector_period);
       int32_t *d_poff = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * (n_utts + 1)));
       int *d_cnt = static_cast<int *>(PoolMalloc(sizeof(int) * (3 * static_cast<size_t>(I) + 3)));
       if (!d_poff || !d_cnt) { PoolFree(d_poff); PoolFree(d_cnt); rc = KH_ENOMEM; break; }
@@ -794,7 +798,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
           int *d_count = d_cnt, *d_start = d_cnt + I, *d_cursor = d_cnt + 2 * I + 1, *d_nitems = d_cnt + 3 * I + 2;
           const int32_t *pi_c = d_pi + static_cast<size_t>(row0) * G;
           const float *pw_c = d_pw + static_cast<size_t>(row0) * G;
-          hipLaunchKernelGGL(IvGammaKernel, dim3(u1 - u0), dim3(256), 0, st, d_off + u0, d_poff + u0, d_pi, d_pw, G, I, c.ivector_period,
+          hipLaunchKernelGGL(IvGammaKernel, dim3(u1 - u0), dim3(256), 0, st, d_off + u0, d_poff + u0, d_pi, d_pw, G, I, c.greedy_most_recent ? 0 : c.ivector_period,
                              d_gc - static_cast<ptrdiff_t>(p0) * I);
           hipLaunchKernelGGL(IvGemmF64Kernel, dim3(DivUp(x->qdim, kGemmN), DivUp(pts, kGemmM)), dim3(256), 0, st, d_gc, x->U, d_quad, pts,
                              x->qdim, I);
@@ -807,7 +811,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
                              S, x->SiM, d_start, d_items, d_items + max_items, d_nitems, d_sorted, d_y);
           hipLaunchKernelGGL(IvSolveKernel, dim3(u1 - u0), dim3(kIvThreads), solve_lds, st, d_off + u0, d_poff + u0, d_pw, G, S, x->qdim,
                            d_quad - static_cast<ptrdiff_t>(p0) * x->qdim, d_y - static_cast<ptrdiff_t>(row0) * G * S, c.prior_offset,
-                           static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors, ivector_stride, x->n_exact);
+                           static_cast<double>(c.max_count), c.greedy_most_recent ? 0 : c.ivector_period, c.num_cg_iters, ivectors, ivector_stride, x->n_exact);
           if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { SetError("kh_ivector_extract: statistics kernels failed"); rc = KH_EDEVICE; }
         }
         PoolFree(d_gc); PoolFree(d_quad); PoolFree(d_y); PoolFree(d_sorted); PoolFree(d_items);

@@ -185,7 +185,8 @@ def extract(X, m):
                 lin[0] += m["prior_offset"] * (new_s - old_s)
                 quad[np.arange(S), np.arange(S)] += new_s - old_s
         num_frames += tot_w
-        if t % m["ivector_period"] == 0:
+        greedy = bool(m.get("greedy_most_recent", False))   # use_most_recent_ivector + greedy (:203-204, :259-272)
+        if (t == T - 1) if greedy else (t % m["ivector_period"] == 0):
             if num_frames > 0.0:
                 if cur[0] == 0.0:
                     cur[0] = m["prior_offset"]
@@ -194,7 +195,12 @@ def extract(X, m):
                 cur = np.zeros(S)
                 cur[0] = m["prior_offset"]
             hist.append(cur.copy())
-        v = hist[t // m["ivector_period"]].copy()
+        if not greedy:
+            v = hist[t // m["ivector_period"]].copy()
+            v[0] -= m["prior_offset"]
+            out[t] = v.astype(np.float32)
+    if bool(m.get("greedy_most_recent", False)):
+        v = hist[-1].copy()
         v[0] -= m["prior_offset"]
-        out[t] = v.astype(np.float32)
+        out[:] = v.astype(np.float32)
     return out

@@ -35,7 +35,7 @@ def make_utts(rng, dim, lengths):
     return [(rng.standard_normal((T, dim)) * 1.2 + rng.standard_normal(dim) * 0.5).astype(np.float32) for T in lengths]
 
 
-@pytest.mark.parametrize("variant", ["default", "var_norm_short_window", "linear_lda", "max_count", "period_1"])
+@pytest.mark.parametrize("variant", ["default", "var_norm_short_window", "linear_lda", "max_count", "period_1", "greedy"])
 def test_ragged_batch_matches_the_specification(variant):
     rng = np.random.default_rng(31)
     m = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=48, ivector_dim=20, prior_offset=5.0)
@@ -47,6 +47,8 @@ def test_ragged_batch_matches_the_specification(variant):
         m.update(max_count=3.0, posterior_scale=0.5)
     elif variant == "period_1":
         m.update(ivector_period=1, num_gselect=3, min_post=0.2)
+    elif variant == "greedy":      # --online=false: use_most_recent_ivector + greedy_ivector_extractor
+        m.update(greedy_most_recent=True, max_count=100.0)
     utts = make_utts(rng, 13, [1, 7, 64, 143, 10])
     got = run(m, utts)
     for u, g in zip(utts, got):
