@@ -376,6 +376,7 @@ class Mfcc:
         f32 = np.float32
         self.opts = capi.KhMfccOptions(int(snip_edges), int(use_energy), int(raw_energy), int(htk_compat),
                                        float(energy_floor), float(dither), int(dither_seed))
+        self.samp_freq = float(samp_freq)
         self.frame_shift = int(f32(samp_freq) * f32(0.001) * f32(frame_shift_ms))      # WindowShift() feature-functions.h:119
         self.frame_length = int(f32(samp_freq) * f32(0.001) * f32(frame_length_ms))    # WindowSize()
         self.padded = 1 << int(np.ceil(np.log2(self.frame_length)))                    # PaddedWindowSize()

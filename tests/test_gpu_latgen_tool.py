@@ -162,3 +162,87 @@ def test_gmm_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch
             assert np.array_equal(got[key], want[key][order]), (k, key)
         np.testing.assert_allclose(got["arc_a"] * acwt, want["arc_a"][order], atol=2e-4)
         assert np.array_equal(words[k], best["words"])
+
+
+def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch):
+    """tools/online2_wav_nnet2_latgen_faster.py --online=false: wave files + the online2 configuration
+    files in, CompactLattices out; checked against the chain of oracles (MFCC, iVector in the
+    use_most_recent + greedy mode, network, canonical decoder) on the same waveforms."""
+    from oracle import binding
+    from oracle import ivector_oracle as IO
+    from test_feature_oracle import wave
+    from test_gpu_online2_pipeline import compact_best_path
+    kio, workloads = pkg("kaldi_io"), pkg("workloads")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    tool = importlib.import_module("tools.online2_wav_nnet2_latgen_faster")
+    net, priors = make_golden.kaldi_io_net(np.random.default_rng(12))     # 6-dim input: 4 MFCCs + 2 iVector dims (the constant part)
+    n_pdf, acwt = 5, 0.2
+    rng = np.random.default_rng(22)
+    topo = dict(phones=list(range(1, n_pdf + 1)), phone2idx=[-1] + [0] * n_pdf,
+                entries=[[(0, [(0, 0.5), (1, 0.5)]), (-1, [])]])
+    pdf_of_phone = rng.permutation(n_pdf)
+    triples = [(p + 1, 0, int(pdf_of_phone[p])) for p in range(n_pdf)]
+    log_probs = np.concatenate([[0.0], np.full(2 * n_pdf, np.log(0.5))]).astype(np.float32)
+    g = workloads.make_hclg_like(rng, 400, n_pdf, final_frac=0.2)
+    g["tid2pdf"] = np.concatenate([[-1], np.repeat(pdf_of_phone, 2)]).astype(np.int32)
+    ie = workloads.make_ivector_extractor(rng, base_dim=4, splice=1, feat_dim=5, num_gauss=6, ivector_dim=2, prior_offset=3.0)
+    ie.update(greedy_most_recent=True, ivector_period=10, max_count=0.0)
+    mfcc_kw = dict(num_bins=10, num_ceps=4, low_freq=20.0, high_freq=0.0)
+    monkeypatch.chdir(tmp_path)
+    with open("final.mdl", "wb") as f:
+        f.write(b"\0B")
+        kio.write_transition_model(f, topo, triples, log_probs, True)
+        f.write(open(os.path.join(GOLD, "am_nnet_body_bin"), "rb").read())
+    with open("HCLG.fst", "wb") as f:
+        kio.write_fst(f, g)
+    inv = 1.0 / ie["ubm_vars"].astype(np.float64)
+    for name, writer in (("final.mat", lambda f: kio.write_matrix(f, ie["lda_mat"])),
+                         ("global_cmvn.stats", lambda f: kio.write_matrix(f, np.asarray(ie["global_cmvn_stats"], np.float64))),
+                         ("final.dubm", lambda f: kio.write_diag_gmm(f, ie["ubm_weights"], (ie["ubm_means"] * inv).astype(np.float32),
+                                                                     inv.astype(np.float32))),
+                         ("final.ie", lambda f: kio.write_ivector_extractor(
+                             f, dict(w=np.zeros((0, 0)), w_vec=np.log(ie["ubm_weights"].astype(np.float64)), M=ie["M"],
+                                     Sigma_inv=ie["Sigma_inv"], prior_offset=ie["prior_offset"])))):
+        with open(name, "wb") as f:
+            f.write(b"\0B")
+            writer(f)
+    open("mfcc.conf", "w").write("--use-energy=false   # only non-default options\n--num-mel-bins=10\n--num-ceps=4\n--dither=0\n")
+    open("splice.conf", "w").write("--left-context=1\n--right-context=1\n")
+    open("online_cmvn.conf", "w").write("# defaults\n")
+    open("ivector_extractor.conf", "w").write(
+        "--splice-config=splice.conf\n--cmvn-config=online_cmvn.conf\n--lda-matrix=final.mat\n--global-cmvn-stats=global_cmvn.stats\n"
+        "--diag-ubm=final.dubm\n--ivector-extractor=final.ie\n--num-gselect=5\n--min-post=0.025\n--posterior-scale=0.1\n"
+        "--max-remembered-frames=1000\n--max-count=0\n")
+    open("online_nnet2_decoding.conf", "w").write(
+        "--feature-type=mfcc\n--mfcc-config=mfcc.conf\n--ivector-extraction-config=ivector_extractor.conf\n"
+        "--beam=9\n--max-active=300\n--lattice-beam=5\n--acoustic-scale=%g\n" % acwt)
+    waves = {"utt%d" % i: np.trunc(wave(30 + i, n)) for i, n in enumerate((16000, 6400))}
+    with open("wav.scp", "w") as f:
+        for k, w in waves.items():
+            with open(k + ".wav", "wb") as wf:
+                kio.write_wave(wf, 16000.0, w)
+            f.write("%s %s.wav\n" % (k, k))
+        f.write("missing nowhere.wav\n")
+    open("spk2utt", "w").write("utt0 utt0\nutt1 utt1\nghost ghost\n")
+    assert tool.main(["--config=online_nnet2_decoding.conf", "--online=false", "final.mdl", "HCLG.fst", "ark:spk2utt", "scp:wav.scp",
+                      "ark:clat.ark"]) == 0
+    with pytest.raises(SystemExit):       # the chunk-wise mode is refused, not approximated
+        tool.main(["--config=online_nnet2_decoding.conf", "final.mdl", "HCLG.fst", "ark:spk2utt", "scp:wav.scp", "ark:clat2.ark"])
+    clats = dict(kio.read_ark("clat.ark", kind="compact_lattice"))
+    assert sorted(clats) == sorted(waves)
+    ko = binding.OracleLib("ko")
+    cfg = binding.decoder_config(beam=9.0, max_active=300, lattice_beam=5.0)
+    for k, w in waves.items():
+        m = ko.mfcc_compute(w.astype(np.float32), **mfcc_kw)
+        x = np.concatenate([m, IO.extract(m, ie)], 1)
+        ll = oracle.decodable_am_nnet(net, priors, acwt, x)
+        oc = binding.DecoderOracle(g, cfg, "canonical")
+        assert oc.decode(ll)
+        best = oc.best_path()
+        C = clats[k]
+        cl = dict(arc_src=C["arc_src"], arc_dst=C["arc_dst"], arc_label=C["arc_label"], arc_g=C["arc_g"], arc_a=C["arc_a"] * acwt,
+                  arc_string=C["arc_string"], final_g=C["final_g"], final_a=C["final_a"] * acwt, final_string=C["final_string"])
+        words, ali, cost = compact_best_path(cl)
+        assert words == [int(v) for v in best["words"]] and ali == [int(v) for v in best["alignment"]], k
+        assert abs(cost - (best["graph_cost"] + best["acoustic_cost"])) < 5e-3
