@@ -18,10 +18,16 @@ Loops in pure Python: small cases only."""
 import numpy as np
 
 
-def online_cmvn(X, m):
-    """OnlineCmvn::GetFrame (feat/online-feature.cc:228-331) with global stats only + ApplyCmvn (transform/cmvn.cc:64-113)."""
+def online_cmvn(X, m, speaker_stats=None, return_state=False):
+    """OnlineCmvn::GetFrame (feat/online-feature.cc:228-331) + ApplyCmvn (transform/cmvn.cc:64-113);
+    speaker_stats [2 x (D + 1)] = OnlineCmvnState::speaker_cmvn_stats carried from the speaker's previous
+    utterances (SmoothOnlineCmvnStats :263-298 takes from it before the global stats); return_state:
+    also the state GetState(T - 1) returns (:333-356: the speaker stats + every frame of this utterance)."""
     T, D = X.shape
     gs = np.asarray(m["global_cmvn_stats"], np.float64)
+    sp = None if speaker_stats is None else np.asarray(speaker_stats, np.float64)
+    if sp is not None and sp[0, D] == 0.0:
+        sp = None
     win, gf = m["cmn_window"], m["global_frames"]
     stats = np.zeros((2, D + 1))
     out = np.empty((T, D), np.float32)
@@ -37,6 +43,11 @@ def online_cmvn(X, m):
             stats[0, D] -= 1.0
         s = stats.copy()
         cur = s[0, D]
+        if cur < win and sp is not None:
+            cfs = min(win - cur, m["speaker_frames"], sp[0, D])
+            if cfs > 0.0:
+                s += (cfs / sp[0, D]) * sp
+                cur = s[0, D]
         if cur < win:
             cfg = min(win - cur, gf)
             if cfg > 0.0:
@@ -53,6 +64,13 @@ def online_cmvn(X, m):
             out[t] = X[t] * scale.astype(np.float32) + offset.astype(np.float32)
         else:
             out[t] = X[t]
+    if return_state:
+        st = np.zeros((2, D + 1)) if speaker_stats is None else np.asarray(speaker_stats, np.float64).copy()
+        Xd = X.astype(np.float64)
+        st[0, :D] += Xd.sum(0)
+        st[1, :D] += (Xd * Xd).sum(0)
+        st[0, D] += T
+        return out, st
     return out
 
 
@@ -144,20 +162,58 @@ def linear_cgd(A, b, x, max_iters, max_error=0.0, recompute_residual_factor=0.01
     return x, k
 
 
-def extract(X, m):
-    """The iVector feature rows [T, ivector_dim] of one utterance."""
+def fresh_state(m):
+    """OnlineIvectorExtractorAdaptationState of a new speaker (online-ivector-feature.h:138-176): no CMVN
+    speaker stats, OnlineIvectorEstimationStats as constructed (ivector-extractor.cc:685-694)."""
+    D = np.asarray(m["global_cmvn_stats"]).shape[1] - 1
+    S = np.asarray(m["M"]).shape[2]
+    quad = np.eye(S)
+    lin = np.zeros(S)
+    lin[0] = m["prior_offset"]
+    return dict(cmvn=np.zeros((2, D + 1)), quad=quad, lin=lin, num_frames=0.0)
+
+
+def stats_scale(st, scale, m):
+    """OnlineIvectorEstimationStats::Scale (ivector-extractor.cc:570-592) in place."""
+    old = st["num_frames"]
+    st["num_frames"] *= scale
+    st["quad"] *= scale
+    st["lin"] *= scale
+    S = len(st["lin"])
+    if m["max_count"] == 0.0:
+        add = 1.0 - scale
+    else:
+        add = max(st["num_frames"], m["max_count"]) / m["max_count"] - scale * max(old, m["max_count"]) / m["max_count"]
+    st["lin"][0] += m["prior_offset"] * add
+    st["quad"][np.arange(S), np.arange(S)] += add
+
+
+def limit_frames(st, m, max_remembered_frames=1000.0):
+    """OnlineIvectorExtractorAdaptationState::LimitFrames (online-ivector-feature.cc:99-117) in place."""
+    D = st["cmvn"].shape[1] - 1
+    count = np.float32(st["cmvn"][0, D])
+    if count > max_remembered_frames:
+        st["cmvn"] *= float(np.float32(max_remembered_frames) / count)
+    lim = np.float32(max_remembered_frames) * np.float32(m["posterior_scale"])
+    if st["num_frames"] > lim:
+        stats_scale(st, float(lim) / st["num_frames"], m)
+
+
+def extract(X, m, state=None, return_state=False):
+    """The iVector feature rows [T, ivector_dim] of one utterance.  state: the speaker's adaptation
+    state (SetAdaptationState, online-ivector-feature.cc:151-160); return_state: also the state
+    GetAdaptationState returns BEFORE LimitFrames."""
     T = X.shape[0]
     S = np.asarray(m["M"]).shape[2]
     F = splice_lda(X, m)
-    Fn = splice_lda(online_cmvn(X, m), m)
+    st = fresh_state(m) if state is None else dict(cmvn=state["cmvn"].copy(), quad=state["quad"].copy(), lin=state["lin"].copy(),
+                                                   num_frames=float(state["num_frames"]))
+    Xn, cmvn_out = online_cmvn(X, m, st["cmvn"], True)
+    Fn = splice_lda(Xn, m)
     g, mi, iv = ubm_params(m)
     U, SiM = derived(m)
     r, c = packed_index(S)
-    quad = np.zeros((S, S))
-    quad[np.arange(S), np.arange(S)] = 1.0             # OnlineIvectorEstimationStats ctor :685-694
-    lin = np.zeros(S)
-    lin[0] = m["prior_offset"]
-    num_frames = 0.0
+    quad, lin, num_frames = st["quad"], st["lin"], st["num_frames"]
     cur = np.zeros(S)
     cur[0] = m["prior_offset"]
     out = np.empty((T, S), np.float32)
@@ -203,4 +259,6 @@ def extract(X, m):
         v = hist[-1].copy()
         v[0] -= m["prior_offset"]
         out[:] = v.astype(np.float32)
+    if return_state:
+        return out, dict(cmvn=cmvn_out, quad=quad, lin=lin, num_frames=num_frames)
     return out

@@ -785,6 +785,38 @@ int ref_online_cmvn_splice_lda(const float *feats, int T, int D, const double *g
     return 0;
   } catch (...) { return -1; }
 }
+// OnlineCmvn with a SPEAKER state (OnlineCmvnState::speaker_cmvn_stats, what
+// OnlineIvectorExtractorAdaptationState carries from one utterance of a speaker to the next):
+// the normalised frames, and the state GetState(last frame) returns.  speaker_stats: [2 x (D + 1)]
+// or NULL (no rows).
+int ref_online_cmvn_speaker(const float *feats, int T, int D, const double *global_stats, const double *speaker_stats,
+                            int cmn_window, int speaker_frames, int global_frames, int norm_mean, int norm_var,
+                            float *out_cmvn, double *out_speaker_stats) {
+  try {
+    Matrix<BaseFloat> m = In(feats, T, D, D);
+    OnlineMatrixFeature base(m);
+    OnlineCmvnOptions co;
+    co.cmn_window = cmn_window; co.speaker_frames = speaker_frames; co.global_frames = global_frames;
+    co.normalize_mean = norm_mean != 0; co.normalize_variance = norm_var != 0;
+    Matrix<double> gs(2, D + 1);
+    for (int r = 0; r < 2; r++) for (int c = 0; c <= D; c++) gs(r, c) = global_stats[r * (D + 1) + c];
+    OnlineCmvnState st(gs);
+    if (speaker_stats) {
+      st.speaker_cmvn_stats.Resize(2, D + 1);
+      for (int r = 0; r < 2; r++) for (int c = 0; c <= D; c++) st.speaker_cmvn_stats(r, c) = speaker_stats[r * (D + 1) + c];
+    }
+    OnlineCmvn cmvn(co, st, &base);
+    Vector<BaseFloat> c(D);
+    for (int t = 0; t < T; t++) {
+      cmvn.GetFrame(t, &c);
+      for (int k = 0; k < D; k++) out_cmvn[static_cast<size_t>(t) * D + k] = c(k);
+    }
+    OnlineCmvnState fin;
+    cmvn.GetState(T - 1, &fin);
+    for (int r = 0; r < 2; r++) for (int cc = 0; cc <= D; cc++) out_speaker_stats[r * (D + 1) + cc] = fin.speaker_cmvn_stats(r, cc);
+    return 0;
+  } catch (...) { return -1; }
+}
 // LinearCgd<double> matrix/optimization.cc:453-565 (what OnlineIvectorEstimationStats::GetIvector
 // calls, ivector/ivector-extractor.cc:631-655); A in SpMatrix packed order.  Returns the iterations.
 int ref_linear_cgd(int dim, const double *a_packed, const double *b, double *x, int max_iters) {

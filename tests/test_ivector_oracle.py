@@ -55,6 +55,20 @@ def ref_cgd(A, b, x0, iters):
     return x, k
 
 
+def ref_cmvn_speaker(m, X, speaker_stats):
+    lib = C.CDLL(B.REF_SO)
+    T, D = X.shape
+    gs = np.ascontiguousarray(m["global_cmvn_stats"], np.float64)
+    out, st = np.empty((T, D), np.float32), np.empty((2, D + 1), np.float64)
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    sp = None if speaker_stats is None else np.ascontiguousarray(speaker_stats, np.float64).ctypes.data_as(dp)
+    rc = lib.ref_online_cmvn_speaker(np.ascontiguousarray(X).ctypes.data_as(fp), T, D, gs.ctypes.data_as(dp), sp, m["cmn_window"],
+                                     m["speaker_frames"], m["global_frames"], int(m["normalize_mean"]), int(m["normalize_variance"]),
+                                     out.ctypes.data_as(fp), st.ctypes.data_as(dp))
+    assert rc == 0
+    return out, st
+
+
 def cases():
     rng = np.random.default_rng(12)
     m = small_model(rng)
@@ -141,3 +155,40 @@ def test_golden_fixture_matches_the_specification():
     np.testing.assert_allclose(IO.splice_lda(X, m), z["lda_a"], atol=2e-6)
     got, _ = IO.linear_cgd(z["cg_A"], z["cg_b"], z["cg_x0"].copy(), 15)
     np.testing.assert_allclose(got, z["cg_x"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.skipif(not B.have_ref(), reason="oracle/_ref not built")
+def test_cmvn_with_speaker_state_matches_the_reference():
+    """The adaptation state's CMVN half: OnlineCmvn started from the speaker stats of the previous
+    utterances (SetState) and the stats GetState returns, chained over three utterances of a speaker."""
+    m, m2, X = cases()
+    for mm in (m, dict(m2, speaker_frames=20)):
+        sp_ref = sp_ora = None
+        for seg in (X[:40], X[40:52], X[52:]):
+            want, st_ref = ref_cmvn_speaker(mm, seg, sp_ref)
+            got, st_ora = IO.online_cmvn(seg, mm, sp_ora, True)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+            np.testing.assert_allclose(st_ora, st_ref, rtol=1e-12, atol=1e-9)
+            sp_ref, sp_ora = st_ref, st_ora
+
+
+def test_adaptation_state_algebra():
+    """Scale (ivector-extractor.cc:570-592) keeps the prior's share of the statistics; LimitFrames
+    (online-ivector-feature.cc:99-117) caps the remembered counts; a fresh state is what extract() starts from."""
+    rng = np.random.default_rng(8)
+    for max_count in (0.0, 2.0):
+        m = dict(small_model(rng), max_count=max_count, posterior_scale=0.5)
+        X = (rng.standard_normal((60, 10)) + 0.2).astype(np.float32)
+        a = IO.extract(X, m)
+        b, st = IO.extract(X, m, IO.fresh_state(m), True)
+        assert np.array_equal(a, b)
+        n0 = st["num_frames"]
+        S = len(st["lin"])
+        data_quad = st["quad"] - np.eye(S) * (max(n0, max_count) / max_count if max_count > 0 else 1.0)
+        IO.limit_frames(st, m, 10.0)
+        assert abs(st["num_frames"] - 5.0) < 1e-6 and abs(st["cmvn"][0, 10] - 10.0) < 1e-5      # 10 frames x posterior_scale (the CMVN ratio is a BaseFloat)
+        prior = max(st["num_frames"], max_count) / max_count if max_count > 0 else 1.0
+        np.testing.assert_allclose(st["quad"], data_quad * (5.0 / n0) + np.eye(S) * prior, rtol=1e-9, atol=1e-9)
+        # the next utterance of the speaker starts from it: its first rows already lean on the speaker
+        c, st2 = IO.extract(X[:15], m, st, True)
+        assert np.abs(c[0] - a[0]).max() > 1e-3 and st2["num_frames"] > st["num_frames"]
