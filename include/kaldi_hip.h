@@ -570,6 +570,17 @@ void kh_ivector_extractor_destroy(KhIvectorExtractor *ext);
  * PriorOffset. */
 int kh_ivector_extract(const KhIvectorExtractor *ext, const float *feats, int feat_stride,
                        const int32_t *utt_row_offsets_host, int n_utts, float *ivectors, int ivector_stride);
+/* The same with the speaker's OnlineIvectorExtractorAdaptationState (online-ivector-feature.h:138-176:
+ * SetAdaptationState before the utterance, GetAdaptationState after it, :151-171): per utterance
+ * kh_ivector_state_dim(ext) HOST doubles — CMVN speaker stats [2 x (base_dim + 1)], num_frames, the prior's
+ * share of the quadratic diagonal, the linear term [ivector_dim], the per-Gaussian counts [num_gauss] (the
+ * quadratic term is diag * I + sum_g count_g U_g).  state_in NULL: fresh speakers; state_out: the state
+ * BEFORE LimitFrames (the caller applies it, as GetAdaptationState does, and chains the utterances of a
+ * speaker through successive calls). */
+int kh_ivector_state_dim(const KhIvectorExtractor *ext);
+int kh_ivector_extract_adapt(const KhIvectorExtractor *ext, const float *feats, int feat_stride,
+                             const int32_t *utt_row_offsets_host, int n_utts, const double *state_in_host,
+                             double *state_out_host, float *ivectors, int ivector_stride);
 
 #ifdef __cplusplus
 }

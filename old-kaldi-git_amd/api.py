@@ -1351,17 +1351,67 @@ class OnlineIvectorExtractor:
     def ivector_dim(self):
         return self.cfg.ivector_dim
 
-    def extract(self, feats, utt_row_offsets, out=None):
+    def state_dim(self):
+        return int(lib().kh_ivector_state_dim(self._h))
+
+    def fresh_state(self, n):
+        """OnlineIvectorExtractorAdaptationState of n new speakers (online-ivector-feature.h:138-176) in the
+        library's layout: CMVN speaker stats [2 (B + 1)], num_frames, prior share of the quadratic diagonal (1),
+        linear term [S] (prior_offset in the first dimension), per-Gaussian counts [I]."""
+        st = np.zeros((n, self.state_dim()))
+        lo = 2 * (self.cfg.base_dim + 1) + 2
+        st[:, lo - 1] = 1.0
+        st[:, lo] = self.cfg.prior_offset
+        return st
+
+    def limit_frames(self, state, max_remembered_frames=1000.0):
+        """OnlineIvectorExtractorAdaptationState::LimitFrames (online-ivector-feature.cc:99-117) +
+        OnlineIvectorEstimationStats::Scale (ivector-extractor.cc:570-592), in place on [n x state_dim]."""
+        B, S = self.cfg.base_dim, self.cfg.ivector_dim
+        nc, lo = 2 * (B + 1), 2 * (B + 1) + 2
+        mc, po = float(self.cfg.max_count), float(self.cfg.prior_offset)
+        for st in state:
+            count = np.float32(st[B])
+            if count > max_remembered_frames:
+                st[:nc] *= float(np.float32(max_remembered_frames) / count)
+            lim = float(np.float32(max_remembered_frames) * np.float32(self.cfg.posterior_scale))
+            n = st[lo - 2]
+            if n > lim:
+                scale = lim / n
+                st[lo - 2] = n * scale
+                st[lo + S:] *= scale                      # the counts: the data part of the quadratic term
+                st[lo:lo + S] *= scale
+                add = (1.0 - scale) if mc == 0.0 else max(n * scale, mc) / mc - scale * max(n, mc) / mc
+                st[lo - 1] = st[lo - 1] * scale + add
+                st[lo] += po * add
+        return state
+
+    def extract(self, feats, utt_row_offsets, out=None, state=None, return_state=False):
         """OnlineIvectorFeature::GetFrame for every frame: `feats` = device [sum T x base_dim] base
-        features of the utterances row-concatenated -> device [sum T x ivector_dim]."""
+        features of the utterances row-concatenated -> device [sum T x ivector_dim].  state: [n_utts x
+        state_dim()] adaptation states the utterances start from (SetAdaptationState); return_state:
+        also the states after them, before LimitFrames (GetAdaptationState)."""
         off = np.ascontiguousarray(utt_row_offsets, np.int32)
         if feats.shape[1] != self.cfg.base_dim or off[-1] != feats.shape[0]:
             raise KhError("OnlineIvectorFeature: feature dimension / row offsets mismatch")
         if out is None:
             out = torch.empty((feats.shape[0], self.cfg.ivector_dim), dtype=torch.float32, device=feats.device)
-        check(lib().kh_ivector_extract(self._h, _p(feats), _dim(feats).stride, off.ctypes.data_as(capi.c_int32_p), len(off) - 1,
-                                       _p(out), _dim(out).stride))
-        return out
+        n = len(off) - 1
+        if state is None and not return_state:
+            check(lib().kh_ivector_extract(self._h, _p(feats), _dim(feats).stride, off.ctypes.data_as(capi.c_int32_p), n,
+                                           _p(out), _dim(out).stride))
+            return out
+        sin = None
+        if state is not None:
+            sin = np.ascontiguousarray(state, np.float64)
+            if sin.shape != (n, self.state_dim()):
+                raise KhError("OnlineIvectorFeature::SetAdaptationState: state of the wrong shape")
+        sout = np.empty((n, self.state_dim())) if return_state else None
+        dp = capi.c_double_p
+        check(lib().kh_ivector_extract_adapt(self._h, _p(feats), _dim(feats).stride, off.ctypes.data_as(capi.c_int32_p), n,
+                                             sin.ctypes.data_as(dp) if sin is not None else None,
+                                             sout.ctypes.data_as(dp) if sout is not None else None, _p(out), _dim(out).stride))
+        return (out, sout) if return_state else out
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -45,19 +45,28 @@ namespace {
 // ---- sliding-window CMVN with global-stats smoothing: one wave per utterance, lane = dimension
 __global__ void __launch_bounds__(64)
 IvCmvnKernel(const float *__restrict__ x, int x_stride, const int32_t *__restrict__ utt_off, int D,
-             const double *__restrict__ gstats, int cmn_window, int global_frames, int norm_mean, int norm_var,
-             float *__restrict__ y, int y_stride) {
+             const double *__restrict__ gstats, int cmn_window, int speaker_frames, int global_frames, int norm_mean,
+             int norm_var, float *__restrict__ y, int y_stride, const double *__restrict__ state_in,
+             double *__restrict__ state_out, int state_dim) {
   const int u = blockIdx.x, d = threadIdx.x;
   const int b = utt_off[u], e = utt_off[u + 1];
   if (d >= D) return;
   const double g0 = gstats[d], g1 = gstats[D + 1 + d], gcount = gstats[D];
-  double s0 = 0.0, s1 = 0.0, count = 0.0;
+  // OnlineCmvnState::speaker_cmvn_stats of the speaker's previous utterances (adaptation state)
+  double p0 = 0.0, p1 = 0.0, pcount = 0.0;
+  if (state_in != nullptr) {
+    const double *sp = state_in + static_cast<size_t>(u) * state_dim;
+    p0 = sp[d]; p1 = sp[D + 1 + d]; pcount = sp[D];
+  }
+  double s0 = 0.0, s1 = 0.0, count = 0.0, t0 = 0.0, t1 = 0.0;
   for (int t = b; t < e; t++) {
     const float xf = x[static_cast<size_t>(t) * x_stride + d];
     const double xd = static_cast<double>(xf);
     s0 += xd;                       // ComputeStatsForFrame :238-255
     s1 += xd * xd;
     count += 1.0;
+    t0 += xd;                       // GetState :333-356: every frame of the utterance
+    t1 += xd * xd;
     const int prev = t - cmn_window;
     if (prev >= b) {
       const double pd = static_cast<double>(x[static_cast<size_t>(prev) * x_stride + d]);
@@ -66,7 +75,18 @@ IvCmvnKernel(const float *__restrict__ x, int x_stride, const int32_t *__restric
       count -= 1.0;
     }
     double a0 = s0, a1 = s1, c = count;
-    if (c < cmn_window) {           // SmoothOnlineCmvnStats :263-298 (no speaker stats)
+    if (c < cmn_window && pcount > 0.0) {   // SmoothOnlineCmvnStats :263-298: the speaker's stats first
+      double from_speaker = cmn_window - c;
+      if (from_speaker > speaker_frames) from_speaker = speaker_frames;
+      if (from_speaker > pcount) from_speaker = pcount;
+      if (from_speaker > 0.0) {
+        const double f = from_speaker / pcount;
+        a0 += f * p0;
+        a1 += f * p1;
+        c += f * pcount;
+      }
+    }
+    if (c < cmn_window) {           // ... then the global ones
       double from_global = cmn_window - c;
       if (from_global > global_frames) from_global = global_frames;
       if (from_global > 0.0) {
@@ -89,6 +109,12 @@ IvCmvnKernel(const float *__restrict__ x, int x_stride, const int32_t *__restric
       out = xf * static_cast<float>(scale) + static_cast<float>(offset);
     }
     y[static_cast<size_t>(t) * y_stride + d] = out;
+  }
+  if (state_out != nullptr) {
+    double *so = state_out + static_cast<size_t>(u) * state_dim;
+    so[d] = p0 + t0;
+    so[D + 1 + d] = p1 + t1;
+    if (d == 0) { so[D] = pcount + (e - b); so[2 * D + 1] = 0.0; }
   }
 }
 
@@ -390,10 +416,12 @@ typedef double KhDouble4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 IvGammaKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ point_off, const int32_t *__restrict__ post_idx,
-              const float *__restrict__ post_w, int G, int I, int period, double *__restrict__ Gc) {
+              const float *__restrict__ post_w, int G, int I, int period, double *__restrict__ Gc,
+              const double *__restrict__ gamma_in, double *__restrict__ gamma_out, int state_dim) {
   __shared__ double gam[64 * kMaxPerLane];
   const int u = blockIdx.x, b = utt_off[u], e = utt_off[u + 1];
-  for (int i = threadIdx.x; i < I; i += 256) gam[i] = 0.0;
+  // (the counts the speaker's previous utterances left in the adaptation state)
+  for (int i = threadIdx.x; i < I; i += 256) gam[i] = gamma_in ? gamma_in[static_cast<size_t>(u) * state_dim + i] : 0.0;
   __syncthreads();
   int prev = b - 1;
   // period <= 0: use_most_recent_ivector + greedy_ivector_extractor (--online=false): ONE estimation
@@ -411,6 +439,16 @@ IvGammaKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
     for (int i = threadIdx.x; i < I; i += 256) Gc[static_cast<size_t>(p) * I + i] = gam[i];
     __syncthreads();
     prev = t;
+  }
+  if (gamma_out != nullptr) {   // the frames behind the last estimation point belong to the state too
+    const long long n = static_cast<long long>(e - 1 - prev) * G;
+    for (long long j = threadIdx.x; j < n; j += 256) {
+      const long long q = static_cast<long long>(prev + 1) * G + j;
+      const float w = post_w[q];
+      if (w != 0.f) atomicAdd(&gam[post_idx[q]], static_cast<double>(w));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < I; i += 256) gamma_out[static_cast<size_t>(u) * state_dim + i] = gam[i];
   }
 }
 
@@ -565,7 +603,8 @@ IvLinKernel(const float *__restrict__ F, int f_stride, const float *__restrict__
 __global__ void __launch_bounds__(kIvThreads)
 IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ point_off, const float *__restrict__ post_w, int G, int S,
               int qdim, const double *__restrict__ Quad, const double *__restrict__ Y, double prior_offset, double max_count,
-              int period, int cg_iters, float *__restrict__ out, int out_stride, int *__restrict__ n_fallback) {
+              int period, int cg_iters, float *__restrict__ out, int out_stride, int *__restrict__ n_fallback,
+              const double *__restrict__ state_in, double *__restrict__ state_out, int state_dim, int lin_off) {
   extern __shared__ double lds[];
   constexpr int kT = kIvThreads;
   double *quad = lds;             // [qdim] packed lower triangle by rows
@@ -574,11 +613,14 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
   __shared__ double red[8];
   const int u = blockIdx.x, t_id = threadIdx.x;
   const int b = utt_off[u], e = utt_off[u + 1];
+  // adaptation state (SetAdaptationState :151-160): [lin_off - 2] = num_frames, [lin_off - 1] = the prior's
+  // share of the quadratic diagonal, [lin_off ...) = the linear term; the counts went into Quad with IvGammaKernel
+  const double *sin = state_in ? state_in + static_cast<size_t>(u) * state_dim : nullptr;
   if (t_id < S) {
-    lin[t_id] = t_id == 0 ? prior_offset : 0.0;   // OnlineIvectorEstimationStats ctor :685-694
+    lin[t_id] = sin ? sin[lin_off + t_id] : (t_id == 0 ? prior_offset : 0.0);   // OnlineIvectorEstimationStats ctor :685-694
     xv[t_id] = t_id == 0 ? prior_offset : 0.0;    // current_ivector_ :358-359
   }
-  double num_frames = 0.0, diag = 1.0;   // diag: the prior's share of the quadratic term (1, + the max_count rescaling :557-566)
+  double num_frames = sin ? sin[lin_off - 2] : 0.0, diag = sin ? sin[lin_off - 1] : 1.0;   // diag: 1, + the max_count rescaling :557-566
   int prev = b - 1;
   const int step = period > 0 ? period : (e - b);   // period <= 0: one point at the last frame, its iVector on every row
   for (int t = period > 0 ? b : e - 1, p = point_off[u]; t < e; t += step, p++) {
@@ -621,7 +663,35 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
     __syncthreads();
     prev = t;
   }
+  if (state_out != nullptr) {   // GetAdaptationState :162-171 before LimitFrames: the frames behind the last point too
+    double lin0_add = 0.0;
+    for (int tt = prev + 1; tt < e; tt++) {
+      double tot_weight = 0.0;
+      for (int k = 0; k < G; k++) tot_weight += static_cast<double>(post_w[static_cast<size_t>(tt) * G + k]);
+      if (max_count > 0.0) {
+        const double old_scale = fmax(num_frames, max_count) / max_count,
+                     new_scale = fmax(num_frames + tot_weight, max_count) / max_count, change = new_scale - old_scale;
+        lin0_add += prior_offset * change;
+        diag += change;
+      }
+      num_frames += tot_weight;
+    }
+    double *so = state_out + static_cast<size_t>(u) * state_dim;
+    if (t_id < S) {
+      double acc = lin[t_id];
+      for (int tt = prev + 1; tt < e; tt++)
+        for (int k = 0; k < G; k++) {
+          const size_t q = static_cast<size_t>(tt) * G + k;
+          if (post_w[q] != 0.f) acc += Y[q * S + t_id];
+        }
+      if (t_id == 0) acc += lin0_add;
+      so[lin_off + t_id] = acc;
+    }
+    if (t_id == 0) { so[lin_off - 2] = num_frames; so[lin_off - 1] = diag; }
+  }
 }
+
+
 
 template <class T>
 T *Upload(const T *h, size_t n) {
@@ -711,8 +781,18 @@ void kh_ivector_extractor_destroy(KhIvectorExtractor *x) {
   delete x;
 }
 
+int kh_ivector_state_dim(const KhIvectorExtractor *x) {
+  if (!x) return 0;
+  return 2 * (x->cfg.base_dim + 1) + 2 + x->cfg.ivector_dim + x->cfg.num_gauss;
+}
+
 int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat_stride, const int32_t *utt_row_offsets_host,
                        int n_utts, float *ivectors, int ivector_stride) {
+  return kh_ivector_extract_adapt(x, feats, feat_stride, utt_row_offsets_host, n_utts, nullptr, nullptr, ivectors, ivector_stride);
+}
+
+int kh_ivector_extract_adapt(const KhIvectorExtractor *x, const float *feats, int feat_stride, const int32_t *utt_row_offsets_host,
+                             int n_utts, const double *state_in_host, double *state_out_host, float *ivectors, int ivector_stride) {
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(x && feats && utt_row_offsets_host && n_utts > 0 && ivectors && feat_stride >= x->cfg.base_dim &&
@@ -722,6 +802,23 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
   for (int u = 0; u < n_utts; u++) KH_CHECK_ARG(utt_row_offsets_host[u + 1] > utt_row_offsets_host[u]);
   hipStream_t st = Stream();
   const int B = c.base_dim, D = c.feat_dim, S = c.ivector_dim, I = c.num_gauss, G = c.num_gselect;
+  // adaptation state per utterance (doubles): CMVN speaker stats [2 (B + 1)], num_frames, the prior's share of the
+  // quadratic diagonal, linear term [S], per-Gaussian counts [I] (quadratic term = diag * I + sum_g count_g U_g)
+  const int state_dim = kh_ivector_state_dim(x), lin_off = 2 * (B + 1) + 2, gamma_off = lin_off + S;
+  const bool adapt = state_in_host != nullptr || state_out_host != nullptr;
+  double *d_sin = nullptr, *d_sout = nullptr;
+  if (state_in_host) {
+    d_sin = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(n_utts) * state_dim));
+    if (!d_sin) return KH_ENOMEM;
+    if (hipMemcpy(d_sin, state_in_host, sizeof(double) * static_cast<size_t>(n_utts) * state_dim, hipMemcpyHostToDevice) != hipSuccess) {
+      PoolFree(d_sin);
+      return KH_EDEVICE;
+    }
+  }
+  if (state_out_host) {
+    d_sout = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(n_utts) * state_dim));
+    if (!d_sout) { PoolFree(d_sin); return KH_ENOMEM; }
+  }
   const int sstride = (x->sdim + 3) & ~3, dstride = (D + 3) & ~3, istride = (I + 3) & ~3, bstride = (B + 3) & ~3;
   std::vector<int32_t> row_utt(rows);
   for (int u = 0; u < n_utts; u++)
@@ -739,7 +836,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
     PoolFree(d_off); PoolFree(d_row_utt); PoolFree(d_norm); PoolFree(d_spl); PoolFree(d_F); PoolFree(d_Fn); PoolFree(d_ll);
     PoolFree(d_pi); PoolFree(d_pw);
   };
-  if (!d_off || !d_row_utt || !d_norm || !d_spl || !d_F || !d_Fn || !d_ll || !d_pi || !d_pw) { cleanup(); return KH_ENOMEM; }
+  if (!d_off || !d_row_utt || !d_norm || !d_spl || !d_F || !d_Fn || !d_ll || !d_pi || !d_pw) { cleanup(); PoolFree(d_sin); PoolFree(d_sout); return KH_ENOMEM; }
   rc = KH_OK;
   do {
     if (hipMemcpyAsync(d_off, utt_row_offsets_host, sizeof(int32_t) * (n_utts + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -752,7 +849,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
     if ((rc = kh_affine(d_spl, dspl, x->lda, dlda, x->lda_off, d_F, dF))) break;
     // lda_normalized_: cmvn(base) -> splice -> LDA
     hipLaunchKernelGGL(IvCmvnKernel, dim3(n_utts), dim3(64), 0, st, feats, feat_stride, d_off, B, x->gstats, c.cmn_window,
-                       c.global_frames, c.normalize_mean, c.normalize_variance, d_norm, bstride);
+                       c.speaker_frames, c.global_frames, c.normalize_mean, c.normalize_variance, d_norm, bstride, d_sin, d_sout, state_dim);
     hipLaunchKernelGGL(IvSpliceKernel, dim3(sgrid), dim3(256), 0, st, d_norm, bstride, d_row_utt, d_off, rows, B, c.splice_left,
                        c.splice_right, d_spl, sstride);
     if ((rc = kh_affine(d_spl, dspl, x->lda, dlda, x->lda_off, d_Fn, dF))) break;
@@ -762,7 +859,7 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
                        c.posterior_scale, d_pi, d_pw);
     // statistics + solves
     const size_t lin_lds = sizeof(double) * (static_cast<size_t>(D) * S + static_cast<size_t>(kLinTile) * D);
-    if (!c.greedy_most_recent && (getenv("KH_IVECTOR_SEQUENTIAL") || lin_lds > 64 * 1024)) {   // the per-utterance accumulation (A/B reference; very wide models)
+    if (!c.greedy_most_recent && !adapt && (getenv("KH_IVECTOR_SEQUENTIAL") || lin_lds > 64 * 1024)) {   // the per-utterance accumulation (A/B reference; very wide models)
       const size_t lds = sizeof(double) * (static_cast<size_t>(x->qdim) + 5 * S + D + static_cast<size_t>(G) * S);
       hipLaunchKernelGGL(IvStatsKernel, dim3(n_utts), dim3(kIvThreads), lds, st, d_F, dstride, d_off, d_pi, d_pw, G, D, S, x->qdim, x->U,
                          x->SiM, c.prior_offset, static_cast<double>(c.max_count), c.ivector_period, c.num_cg_iters, ivectors,
@@ -799,7 +896,9 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
           const int32_t *pi_c = d_pi + static_cast<size_t>(row0) * G;
           const float *pw_c = d_pw + static_cast<size_t>(row0) * G;
           hipLaunchKernelGGL(IvGammaKernel, dim3(u1 - u0), dim3(256), 0, st, d_off + u0, d_poff + u0, d_pi, d_pw, G, I, c.greedy_most_recent ? 0 : c.ivector_period,
-                             d_gc - static_cast<ptrdiff_t>(p0) * I);
+                             d_gc - static_cast<ptrdiff_t>(p0) * I,
+                             d_sin ? d_sin + static_cast<size_t>(u0) * state_dim + gamma_off : nullptr,
+                             d_sout ? d_sout + static_cast<size_t>(u0) * state_dim + gamma_off : nullptr, state_dim);
           hipLaunchKernelGGL(IvGemmF64Kernel, dim3(DivUp(x->qdim, kGemmN), DivUp(pts, kGemmM)), dim3(256), 0, st, d_gc, x->U, d_quad, pts,
                              x->qdim, I);
           (void)hipMemsetAsync(d_count, 0, sizeof(int) * I, st);
@@ -811,7 +910,9 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
                              S, x->SiM, d_start, d_items, d_items + max_items, d_nitems, d_sorted, d_y);
           hipLaunchKernelGGL(IvSolveKernel, dim3(u1 - u0), dim3(kIvThreads), solve_lds, st, d_off + u0, d_poff + u0, d_pw, G, S, x->qdim,
                            d_quad - static_cast<ptrdiff_t>(p0) * x->qdim, d_y - static_cast<ptrdiff_t>(row0) * G * S, c.prior_offset,
-                           static_cast<double>(c.max_count), c.greedy_most_recent ? 0 : c.ivector_period, c.num_cg_iters, ivectors, ivector_stride, x->n_exact);
+                           static_cast<double>(c.max_count), c.greedy_most_recent ? 0 : c.ivector_period, c.num_cg_iters, ivectors, ivector_stride, x->n_exact,
+                             d_sin ? d_sin + static_cast<size_t>(u0) * state_dim : nullptr,
+                             d_sout ? d_sout + static_cast<size_t>(u0) * state_dim : nullptr, state_dim, lin_off);
           if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { SetError("kh_ivector_extract: statistics kernels failed"); rc = KH_EDEVICE; }
         }
         PoolFree(d_gc); PoolFree(d_quad); PoolFree(d_y); PoolFree(d_sorted); PoolFree(d_items);
@@ -825,6 +926,10 @@ int kh_ivector_extract(const KhIvectorExtractor *x, const float *feats, int feat
   } while (0);
   hipError_t e = hipStreamSynchronize(st);   // the scratch returns to the pool
   cleanup();
+  if (!rc && e == hipSuccess && d_sout)
+    e = hipMemcpy(state_out_host, d_sout, sizeof(double) * static_cast<size_t>(n_utts) * state_dim, hipMemcpyDeviceToHost);
+  PoolFree(d_sin);
+  PoolFree(d_sout);
   int n_exact = 0;
   if (!rc && e == hipSuccess && (e = hipMemcpy(&n_exact, x->n_exact, sizeof(int), hipMemcpyDeviceToHost)) == hipSuccess && n_exact > 0) {
     // KALDI_WARN of LinearCgd, optimization.cc:548-552

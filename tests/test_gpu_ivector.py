@@ -102,6 +102,50 @@ def test_batched_statistics_in_chunks_equal_the_sequential_accumulation(monkeypa
         np.testing.assert_allclose(a, IO.extract(u, m), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("greedy,max_count", [(False, 0.0), (True, 0.0), (True, 3.0)])
+def test_speaker_adaptation_state_chain(greedy, max_count):
+    """Three utterances of one speaker and two of another through SetAdaptationState /
+    GetAdaptationState + LimitFrames (online2-wav-nnet2-latgen-faster.cc:186-200, :283), round by round
+    on the device, against the same chain on the oracle."""
+    rng = np.random.default_rng(36)
+    m = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=48, ivector_dim=20, prior_offset=5.0)
+    m.update(greedy_most_recent=greedy, max_count=max_count, posterior_scale=0.5, cmn_window=60, speaker_frames=40, global_frames=20)
+    spk = {"a": make_utts(rng, 13, [47, 9, 130]), "b": make_utts(rng, 13, [25, 64])}
+    max_rem = 50.0
+    ext = api.OnlineIvectorExtractor(m)
+    B_, S_ = 13, 20
+    lo = 2 * (B_ + 1) + 2
+    U, _ = IO.derived(m)
+    r_, c_ = IO.packed_index(S_)
+    ora = {k: None for k in spk}
+    dev = {k: ext.fresh_state(1)[0] for k in spk}
+    for rnd in range(3):
+        who = [k for k in spk if rnd < len(spk[k])]
+        utts = [spk[k][rnd] for k in who]
+        off = np.concatenate([[0], np.cumsum([len(u) for u in utts])]).astype(np.int32)
+        out, st = ext.extract(torch.as_tensor(np.concatenate(utts, 0), device="cuda"), off, state=np.stack([dev[k] for k in who]),
+                              return_state=True)
+        api.synchronize()
+        out = out.cpu().numpy()
+        for j, k in enumerate(who):
+            want, ost = IO.extract(utts[j], m, ora[k], True)
+            np.testing.assert_allclose(out[off[j]:off[j + 1]], want, rtol=0, atol=TOL)
+            # the state: CMVN sums, counts, linear term; the quadratic term from the per-Gaussian counts
+            np.testing.assert_allclose(st[j, :2 * (B_ + 1)].reshape(2, B_ + 1), ost["cmvn"], rtol=1e-9, atol=1e-6)
+            assert abs(st[j, lo - 2] - ost["num_frames"]) < 1e-5
+            # (the features are float on both sides with different summation orders: 1e-6 relative reaches the sums)
+            np.testing.assert_allclose(st[j, lo:lo + S_], ost["lin"], rtol=1e-4, atol=5e-5)
+            quad = np.eye(S_) * st[j, lo - 1]
+            Q = np.zeros((S_, S_))
+            Q[r_, c_] = st[j, lo + S_:] @ U
+            quad += Q + np.tril(Q, -1).T
+            np.testing.assert_allclose(quad, ost["quad"], rtol=1e-4, atol=5e-5)
+            IO.limit_frames(ost, m, max_rem)
+            ora[k] = ost
+            dev[k] = ext.limit_frames(st[j:j + 1].copy(), max_rem)[0]
+    assert rnd == 2
+
+
 def test_check_failures_are_errors():
     rng = np.random.default_rng(34)
     m = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=48, ivector_dim=20)
