@@ -1434,9 +1434,12 @@ class OnlineNnet2FeaturePipeline:
     def dim(self):
         return self.mfcc.num_ceps + (self.ivector.ivector_dim if self.ivector is not None else 0)
 
-    def compute(self, waves):
+    def compute(self, waves, speakers=None, max_remembered_frames=1000.0):
         """waves: list of 1-D float32 device tensors.  Returns (features [sum T x Dim()] on the device,
-        utterance row offsets); an utterance shorter than one frame contributes no rows."""
+        utterance row offsets); an utterance shorter than one frame contributes no rows.  speakers: one
+        label per waveform — the utterances of a speaker are processed in list order with the adaptation
+        state carried from one to the next (SetAdaptationState / GetAdaptationState,
+        online2-wav-nnet2-latgen-faster.cc:186-200, :283), round by round over the speakers."""
         base = [self.mfcc.compute(w) for w in waves]
         lens = np.array([b.shape[0] for b in base], np.int64)
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -1447,11 +1450,35 @@ class OnlineNnet2FeaturePipeline:
         out = torch.empty((max(rows, 1), stride), dtype=torch.float32, device=dev)[:rows, :self.dim()]
         if rows == 0:
             return out, off
-        allbase = torch.cat([b for b in base if b.shape[0]], 0).contiguous()
-        out[:, :d0] = allbase
-        if self.ivector is not None:
-            keep = lens > 0                      # kh_ivector_extract takes non-empty utterances
-            off_nz = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.int32)
-            iv = self.ivector.extract(allbase, off_nz)
-            out[:, d0:] = iv
+        for u, b in enumerate(base):
+            if b.shape[0]:
+                out[off[u]:off[u + 1], :d0] = b
+        if self.ivector is None:
+            return out, off
+        if speakers is None:
+            speakers = list(range(len(waves)))
+        # round r: the r-th utterance (with frames) of every speaker, from the state its predecessor left
+        queues = {}
+        for u, s in enumerate(speakers):
+            if lens[u] > 0:
+                queues.setdefault(s, []).append(u)
+        state = {s: self.ivector.fresh_state(1)[0] for s in queues}
+        chained = any(len(q) > 1 for q in queues.values())
+        r = 0
+        while True:
+            batch = [(s, q[r]) for s, q in queues.items() if r < len(q)]
+            if not batch:
+                break
+            feats = torch.cat([base[u] for _, u in batch], 0).contiguous()
+            boff = np.concatenate([[0], np.cumsum([lens[u] for _, u in batch])]).astype(np.int32)
+            if chained:
+                iv, st = self.ivector.extract(feats, boff, state=np.stack([state[s] for s, _ in batch]), return_state=True)
+                self.ivector.limit_frames(st, max_remembered_frames)
+                for j, (s, _) in enumerate(batch):
+                    state[s] = st[j]
+            else:
+                iv = self.ivector.extract(feats, boff)
+            for j, (_, u) in enumerate(batch):
+                out[off[u]:off[u + 1], d0:] = iv[boff[j]:boff[j + 1]]
+            r += 1
         return out, off

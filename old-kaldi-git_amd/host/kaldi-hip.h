@@ -865,6 +865,47 @@ class OnlineIvectorExtractor {
     KhCheck(kh_ivector_extract(h_, feats.Data(), feats.Stride(), utt_row_offsets.data(),
                                static_cast<int>(utt_row_offsets.size()) - 1, ivectors->Data(), ivectors->Stride()));
   }
+  /// One OnlineIvectorExtractorAdaptationState per utterance, row-concatenated [n x StateDim()] doubles
+  /// (layout: include/kaldi_hip.h kh_ivector_extract_adapt).  FreshStates = the default-constructed state.
+  int32 StateDim() const { return kh_ivector_state_dim(h_); }
+  std::vector<double> FreshStates(int32 n) const {
+    const int32 sd = StateDim(), lo = 2 * (cfg_.base_dim + 1) + 2;
+    std::vector<double> st(static_cast<size_t>(n) * sd, 0.0);
+    for (int32 u = 0; u < n; u++) {
+      st[static_cast<size_t>(u) * sd + lo - 1] = 1.0;                 // the prior's quadratic term: the unit matrix
+      st[static_cast<size_t>(u) * sd + lo] = cfg_.prior_offset;       // its linear term: prior_offset * e_0
+    }
+    return st;
+  }
+  /// SetAdaptationState(states[u]) -> every GetFrame -> GetAdaptationState into states[u] (before LimitFrames)
+  void Extract(const CuMatrixBase &feats, const std::vector<int32> &utt_row_offsets, std::vector<double> *states,
+               CuMatrix *ivectors) const {
+    const int32 n = static_cast<int32>(utt_row_offsets.size()) - 1;
+    KALDI_HIP_ASSERT(n >= 0 && utt_row_offsets.back() == feats.NumRows() && states->size() == static_cast<size_t>(n) * StateDim());
+    ivectors->Resize(feats.NumRows(), cfg_.ivector_dim, kUndefined);
+    std::vector<double> out(states->size());
+    KhCheck(kh_ivector_extract_adapt(h_, feats.Data(), feats.Stride(), utt_row_offsets.data(), n, states->data(), out.data(),
+                                     ivectors->Data(), ivectors->Stride()));
+    states->swap(out);
+  }
+  /// OnlineIvectorExtractorAdaptationState::LimitFrames (online-ivector-feature.cc:99-117) on one state
+  void LimitFrames(double *st, BaseFloat max_remembered_frames) const {
+    const int32 B = cfg_.base_dim, S = cfg_.ivector_dim, nc = 2 * (B + 1), lo = nc + 2, sd = StateDim();
+    const BaseFloat count = static_cast<BaseFloat>(st[B]);
+    if (count > max_remembered_frames) {
+      const double f = max_remembered_frames / count;
+      for (int32 i = 0; i < nc; i++) st[i] *= f;
+    }
+    const double lim = static_cast<BaseFloat>(max_remembered_frames * cfg_.posterior_scale), n = st[lo - 2];
+    if (n > lim) {                                           // OnlineIvectorEstimationStats::Scale (ivector-extractor.cc:570-592)
+      const double scale = lim / n, mc = cfg_.max_count;
+      st[lo - 2] = n * scale;
+      for (int32 i = lo; i < sd; i++) st[i] *= scale;        // the linear term and the per-Gaussian counts
+      const double add = mc == 0.0 ? 1.0 - scale : std::max(n * scale, mc) / mc - scale * std::max(n, mc) / mc;
+      st[lo - 1] = st[lo - 1] * scale + add;
+      st[lo] += cfg_.prior_offset * add;
+    }
+  }
 
  private:
   OnlineIvectorExtractor(const OnlineIvectorExtractor &);

@@ -432,6 +432,29 @@ static void TestIvector() {
   std::vector<float> h2(6);
   o2.CopyToMat(h2.data(), 3);
   for (int j = 0; j < 6; j++) CHECK(h2[j] == h[15 + j]);
+  // adaptation state: from fresh states the rows are those of Extract without a state; the second
+  // utterance from the state the first one left sees its frames (a different estimate), and LimitFrames
+  // scales the statistics down to max_remembered_frames * posterior_scale
+  std::vector<double> st = ext.FreshStates(2);
+  const int sd = ext.StateDim(), lo = 2 * 5 + 2;
+  CHECK(sd == lo + 3 + 2);
+  CuMatrix o3;
+  ext.Extract(feats, off, &st, &o3);
+  std::vector<float> h3(21);
+  o3.CopyToMat(h3.data(), 3);
+  for (int j = 0; j < 21; j++) CHECK(fabsf(h3[j] - h[j]) < 1e-6f);
+  CHECK(fabs(st[4] - 5.0) < 1e-9 && fabs(st[sd + 4] - 2.0) < 1e-9);                   // CMVN counts
+  CHECK(fabs(st[lo - 2] - 2.5) < 1e-6 && fabs(st[sd + lo - 2] - 1.0) < 1e-6);         // posterior_scale * frames
+  std::vector<double> carried(st.begin(), st.begin() + sd);
+  ext.LimitFrames(carried.data(), 3.f);
+  CHECK(fabs(carried[4] - 3.0) < 1e-6 && fabs(carried[lo - 2] - 1.5) < 1e-6);
+  CuMatrix o4;
+  ext.Extract(f2, off2, &carried, &o4);
+  std::vector<float> h4(6);
+  o4.CopyToMat(h4.data(), 3);
+  float moved = 0.f;
+  for (int j = 0; j < 6; j++) moved += fabsf(h4[j] - h2[j]);
+  CHECK(moved > 1e-3f && fabs(carried[lo - 2] - 2.5) < 1e-6);
 }
 
 int main(int argc, char **argv) {

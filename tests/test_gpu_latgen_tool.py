@@ -167,7 +167,8 @@ def test_gmm_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch
 def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch):
     """tools/online2_wav_nnet2_latgen_faster.py --online=false: wave files + the online2 configuration
     files in, CompactLattices out; checked against the chain of oracles (MFCC, iVector in the
-    use_most_recent + greedy mode, network, canonical decoder) on the same waveforms."""
+    use_most_recent + greedy mode with the adaptation state carried from a speaker's utterance to the
+    next and LimitFrames in between, network, canonical decoder) on the same waveforms."""
     from oracle import binding
     from oracle import ivector_oracle as IO
     from test_feature_oracle import wave
@@ -213,18 +214,18 @@ def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_pat
     open("ivector_extractor.conf", "w").write(
         "--splice-config=splice.conf\n--cmvn-config=online_cmvn.conf\n--lda-matrix=final.mat\n--global-cmvn-stats=global_cmvn.stats\n"
         "--diag-ubm=final.dubm\n--ivector-extractor=final.ie\n--num-gselect=5\n--min-post=0.025\n--posterior-scale=0.1\n"
-        "--max-remembered-frames=1000\n--max-count=0\n")
+        "--max-remembered-frames=5\n--max-count=0\n")
     open("online_nnet2_decoding.conf", "w").write(
         "--feature-type=mfcc\n--mfcc-config=mfcc.conf\n--ivector-extraction-config=ivector_extractor.conf\n"
         "--beam=9\n--max-active=300\n--lattice-beam=5\n--acoustic-scale=%g\n" % acwt)
-    waves = {"utt%d" % i: np.trunc(wave(30 + i, n)) for i, n in enumerate((16000, 6400))}
+    waves = {"utt%d" % i: np.trunc(wave(30 + i, n)) for i, n in enumerate((16000, 6400, 8000))}
     with open("wav.scp", "w") as f:
         for k, w in waves.items():
             with open(k + ".wav", "wb") as wf:
                 kio.write_wave(wf, 16000.0, w)
             f.write("%s %s.wav\n" % (k, k))
         f.write("missing nowhere.wav\n")
-    open("spk2utt", "w").write("utt0 utt0\nutt1 utt1\nghost ghost\n")
+    open("spk2utt", "w").write("spkA utt0 utt1\nutt2 utt2\nghost ghost\n")
     assert tool.main(["--config=online_nnet2_decoding.conf", "--online=false", "final.mdl", "HCLG.fst", "ark:spk2utt", "scp:wav.scp",
                       "ark:clat.ark"]) == 0
     with pytest.raises(SystemExit):       # the chunk-wise mode is refused, not approximated
@@ -233,9 +234,16 @@ def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_pat
     assert sorted(clats) == sorted(waves)
     ko = binding.OracleLib("ko")
     cfg = binding.decoder_config(beam=9.0, max_active=300, lattice_beam=5.0)
+    spk_state, different = {"spkA": None, "utt2": None}, 0.0
     for k, w in waves.items():
         m = ko.mfcc_compute(w.astype(np.float32), **mfcc_kw)
-        x = np.concatenate([m, IO.extract(m, ie)], 1)
+        spk = "spkA" if k in ("utt0", "utt1") else k
+        iv, st = IO.extract(m, ie, spk_state[spk], True)
+        IO.limit_frames(st, ie, 5.0)
+        spk_state[spk] = st
+        if k == "utt1":                     # the carried state matters: from the prior the rows differ
+            different = np.abs(iv - IO.extract(m, ie)).max()
+        x = np.concatenate([m, iv], 1)
         ll = oracle.decodable_am_nnet(net, priors, acwt, x)
         oc = binding.DecoderOracle(g, cfg, "canonical")
         assert oc.decode(ll)
@@ -246,3 +254,4 @@ def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_pat
         words, ali, cost = compact_best_path(cl)
         assert words == [int(v) for v in best["words"]] and ali == [int(v) for v in best["alignment"]], k
         assert abs(cost - (best["graph_cost"] + best["acoustic_cost"])) < 5e-3
+    assert different > 0.05

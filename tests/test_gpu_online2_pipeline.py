@@ -98,3 +98,31 @@ def test_wave_to_determinized_lattice(oracle):
         assert words == [int(w) for w in bp["words"]]
         assert ali == [int(t) for t in bp["alignment"]]
         assert abs(cost - (float(bp["graph_cost"]) + float(bp["acoustic_cost"]))) < 1e-3
+
+
+def test_speakers_carry_the_adaptation_state():
+    """compute(waves, speakers=...): the utterances of a speaker in list order, each from the state the
+    previous one left (after LimitFrames); utterances of different speakers independent of the batch."""
+    rng = np.random.default_rng(92)
+    mfcc_kw = dict(num_bins=23, num_ceps=13, low_freq=20.0, high_freq=0.0)
+    iv_model = workloads.make_ivector_extractor(rng, base_dim=13, splice=2, feat_dim=16, num_gauss=32, ivector_dim=10, prior_offset=5.0)
+    iv_model.update(greedy_most_recent=True, posterior_scale=0.5)
+    waves = [wave(11, 9000), wave(12, 150), wave(13, 12000), wave(14, 7000), wave(15, 8000)]
+    speakers = ["a", "a", "b", "a", "b"]                 # a's second utterance has no frames: the state passes it by
+    pipe = api.OnlineNnet2FeaturePipeline(api.Mfcc(**mfcc_kw), api.OnlineIvectorExtractor(iv_model))
+    feats, off = pipe.compute([torch.from_numpy(w).cuda() for w in waves], speakers=speakers, max_remembered_frames=40.0)
+    got = feats.cpu().numpy()
+    ko = B.OracleLib("ko")
+    state = {"a": None, "b": None}
+    for u, (w, s) in enumerate(zip(waves, speakers)):
+        if off[u + 1] == off[u]:
+            continue
+        m = ko.mfcc_compute(w, **mfcc_kw)
+        iv, st = IO.extract(m, iv_model, state[s], True)
+        IO.limit_frames(st, iv_model, 40.0)
+        state[s] = st
+        gu = got[off[u]:off[u + 1]]
+        check_mfcc(gu[:, :13], m)
+        assert np.abs(gu[:, 13:] - iv).max() < 5e-3, u
+        if u >= 3:
+            assert np.abs(iv - IO.extract(m, iv_model)).max() > 0.05      # the carried state is not a no-op

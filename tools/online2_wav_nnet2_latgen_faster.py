@@ -16,11 +16,11 @@ final.ie, RIFF wave files) with old-kaldi-git_amd/kaldi_io.py.
   <wav-rspecifier>      scp:FILE  "utt path.wav" per line (files; commands ending in | are not run)
   <lattice-wspecifier>  ark:FILE | ark,t:FILE  CompactLattices, acoustic costs unscaled (:61-66 of the binary's GetLattice use)
 
-Differences from the binary, stated: all utterances are processed as one batch per stage (one MFCC /
-iVector / forward / decoder launch); the iVector adaptation state is NOT carried from one utterance
-of a speaker to the next (every utterance starts from the prior: list utterances as their own
-speakers to get the binary's exact behaviour); --online=true (chunk-wise estimates, endpointing,
-silence weighting) is not implemented and is refused.
+Differences from the binary, stated: the utterances are processed as one batch per stage (one MFCC /
+forward / decoder launch; the iVectors in rounds — the r-th utterance of every speaker together, with
+the adaptation state SetAdaptationState / GetAdaptationState carry from one utterance of a speaker to
+the next, --max-remembered-frames); --online=true (chunk-wise estimates, endpointing, silence
+weighting) is not implemented and is refused.
 """
 import argparse
 import importlib
@@ -134,6 +134,7 @@ def main(argv=None):
     ivec = api.OnlineIvectorExtractor(ivector_info(a.ivector_extraction_config, kio, a.online)) if a.ivector_extraction_config else None
     if ivec is None and a.online:
         raise SystemExit("--online=true is not implemented: run with --online=false")
+    max_rem = float(kio.read_config_file(a.ivector_extraction_config).get("max-remembered-frames", 1000)) if a.ivector_extraction_config else 1000.0
     pipe = api.OnlineNnet2FeaturePipeline(mfcc, ivec)
     tm, comps, priors = kio.read_nnet2_model(a.nnet2)
     nnet = api.Nnet(comps, priors)
@@ -154,13 +155,10 @@ def main(argv=None):
             k, _, v = line.strip().partition(" ")
             if k:
                 wav_of[k] = v.strip()
-    utts, num_err = [], 0
+    utts, spk_of, num_err = [], [], 0
     with open(spk_path) as f:
         for line in f:
             toks = line.split()
-            if len(toks) > 2:
-                print("WARNING speaker %s: the iVector adaptation state is not carried across its %d utterances" % (toks[0], len(toks) - 1),
-                      file=sys.stderr)
             for utt in toks[1:]:
                 if utt not in wav_of:
                     print("WARNING Did not find audio for utterance %s" % utt, file=sys.stderr)
@@ -169,6 +167,7 @@ def main(argv=None):
                     raise SystemExit("wav.scp commands are not run: " + wav_of[utt])
                 else:
                     utts.append(utt)
+                    spk_of.append(toks[0])
     _, lat_path, lat_text = lf.parse_specifier(a.lattices, True)
     lat_w = kio.TableWriter(lat_path, kind="compact_lattice", binary=not lat_text)
     waves = []
@@ -177,7 +176,7 @@ def main(argv=None):
         if rate != mfcc.samp_freq:
             raise SystemExit("Sampling frequency mismatch, expected %g, got %g" % (mfcc.samp_freq, rate))   # online-feature.cc AcceptWaveform
         waves.append(torch.from_numpy(np.ascontiguousarray(data[0])).cuda())    # channel zero (:196-198)
-    feats, off = pipe.compute(waves)
+    feats, off = pipe.compute(waves, speakers=spk_of, max_remembered_frames=max_rem)
     keep = [u for u in range(len(utts)) if off[u + 1] > off[u]]
     for u in range(len(utts)):
         if off[u + 1] == off[u]:
