@@ -344,18 +344,24 @@ def measured_traffic(args, world):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, tools/collect_profiles.sh):
     counters cannot be read inside this process, so this is a RECORDED figure, quoted only
     for the workload it was measured on (the default one, 1 GPU) and labelled with its
-    source.  FETCH_SIZE + WRITE_SIZE are in KB and taken as reported (MI355X guide:
-    FETCH_SIZE is exact for 64-B requests and halves wide coalesced reads: a lower bound)."""
+    source.  Both counters are in KiB.  On gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B although a read
+    request moves a 128-byte line (MI355X guide, HBM section: "double it"): calibrated for THIS kernel's
+    access shapes by tools/pmc_calibrate.hip (profiles/r02_pmc_calibration.txt: one dword out of a
+    128-byte line and both of its halves cost the same single request) and confirmed on DecodeKernel
+    itself by the request-size and DRAM-side tallies (TCC_EA0_RDREQ_128B = 99.6 % of the requests,
+    TCC_EA0_RDREQ_DRAM_32B x 32 B = 2 x FETCH_SIZE).  WRITE_SIZE is exact (64-B full and 32-B partial
+    writes, = TCC_EA0_WRREQ_WRITE_DRAM_32B x 32 B).  traffic = 2 x FETCH_SIZE + WRITE_SIZE."""
     if args.small or args.utts != 2620 or args.graph_states != 10_000_000 or world != 1:
         return None, None
     tot, src = 0.0, None
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    for name, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         path = os.path.join(ROOT, "profiles", "r02_pmc_%s.txt" % name)
         try:
             with open(path) as f:
                 fields = f.readline().strip().split(",")
-            tot += float(fields[2]) * 1024.0
-            src = "profiles/r02_pmc_{FETCH,WRITE}_SIZE.txt (recorded by tools/collect_profiles.sh, not measured in this run)"
+            tot += float(fields[2]) * 1024.0 * corr
+            src = ("2 x FETCH_SIZE + WRITE_SIZE from profiles/r02_pmc_{FETCH,WRITE}_SIZE.txt (recorded by tools/collect_profiles.sh, "
+                   "not measured in this run; read correction: profiles/r02_pmc_calibration.txt)")
         except (OSError, IndexError, ValueError):
             return None, None
     return tot, src

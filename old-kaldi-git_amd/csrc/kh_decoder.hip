@@ -49,17 +49,27 @@
 using namespace kh;
 
 // ================================================================ device FST
+// The graph as the kernel reads it: ONE table of 16-byte units in which a state is a RECORD
+//   [header {#emitting arcs, first epsilon arc, #epsilon arcs, final cost}] [emitting arc] ... [emitting arc]
+// and a state's id IS the unit index of its header (monotone in the caller's ids, so every smallest-
+// state-id tie-break is unchanged).  Every read of this part moves a whole 128-byte line
+// (profiles/r02_pmc_calibration.txt): with an offsets array + an arc table + a pdf table a token of a
+// 2-arc HMM state cost three lines; its record is 48 bytes of one, next to the records of the states
+// of the same HMM chain.  The epsilon arcs (3 % of the traffic) stay in their own table.
 struct KhFst {
-  int32_t num_states = 0, start = 0;
-  int64_t num_arcs = 0, num_emit = 0, num_eps = 0;
-  int32_t *e_off = nullptr;  // [num_states+1]
-  int32_t *n_off = nullptr;  // [num_states+1]
-  int4 *e_arcs = nullptr;    // {ilabel, olabel, weight bits, nextstate}
-  int4 *n_arcs = nullptr;    // {0, olabel, weight bits, nextstate}
-  float *final_cost = nullptr;
-  std::vector<float> final_host;  // host copy for lattice export
+  int32_t num_states = 0, start = 0, start_state = 0;  // start: unit id; start_state: the caller's id
+  int64_t num_arcs = 0, num_emit = 0, num_eps = 0, num_units = 0;
+  int4 *rec = nullptr;             // [num_units] header {n_emit, eps_base, n_eps, final bits} | arc {ilabel, olabel, weight bits, nextstate unit | flags}
+  int32_t *unit_ilabel = nullptr;  // [num_units] ilabel (> 0) of an arc unit (the decoder's copy of rec holds the pdf there); -1 - the caller's state id for a header
+  int4 *n_arcs = nullptr;          // {0, olabel, weight bits, nextstate unit | flags}
+  std::vector<int32_t> unit_of_state;  // host: caller's state -> unit id (sorted: the inverse is a binary search)
+  std::vector<float> final_host;       // host copy for lattice export, by the caller's state
   int start_has_eps = 0;
   int32_t max_ilabel = 0;
+  float FinalOfUnit(int32_t unit) const {
+    const auto it = std::lower_bound(unit_of_state.begin(), unit_of_state.end(), unit);
+    return final_host[static_cast<size_t>(it - unit_of_state.begin())];
+  }
 };
 
 namespace {
@@ -189,13 +199,11 @@ struct Utt {
 };
 
 struct Params {
-  Arr<const int32_t> e_off; Arr<const int32_t> n_off;
-  Arr<const KhInt4> e_arcs; Arr<const KhInt4> n_arcs;
-  Arr<const float> final_cost;
-  int32_t start, num_states, num_emit, num_eps, start_has_eps;
+  Arr<const KhInt4> rec;      // the decoder's copy of KhFst::rec with the pdf in the first word of every arc unit
+  Arr<const KhInt4> n_arcs;
+  Arr<const int32_t> unit_ilabel;
+  int32_t start, num_units, num_eps, start_has_eps;
   int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
-  Arr<const int32_t> tid2pdf;
-  Arr<const uint16_t> e_pdf;  // [num_emit] tid2pdf[ilabel] of every emitting arc (rebuilt per call; 16 bits: used when the score matrix has <= 65536 columns), or null
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
@@ -561,7 +569,7 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
 
 // Expansion sweep over the tokens [b, e) (kEps: over entries [b, e) of tmp_epslist, the
 // tokens whose state has epsilon arcs): every token whose cost is <= cutoff gets one link
-// slot per arc of its HCLG state (arc ranges `off`), appended at link slot `lrun` on in token
+// slot per arc of its HCLG state (arc ranges from the state records `rec`), appended at link slot `lrun` on in token
 // order, and body(link slot, token, arc index) runs once per slot, link-parallel.
 // Per group of EU * NT tokens: a token sweep (cost, state, arc range), ONE scan that assigns
 // the slots, the items' (first slot, first arc, token) through LDS, then one lane per slot
@@ -569,7 +577,7 @@ __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigne
 // global memory, no per-token store loops.
 // Returns the new end of the link arena, or -1 on overflow (sh->status set).
 template <bool kEps, class Body>
-__device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
+__device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const KhInt4> rec, int b, int e, float cutoff, int lrun,
                                            int frame_cap, long long *arcs, Blk &sh, Body body) {
   const int lrun0 = lrun;
   for (int base = b; base < e; base += NT * EU) {
@@ -592,9 +600,10 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off,
       const bool need = in_range[k] && Dec(co[k]) <= cutoff;
       ab[k] = 0;
       cnt[k] = 0;
-      if (need) {
-        ab[k] = off[st[k]];
-        cnt[k] = off[st[k] + 1] - ab[k];
+      if (need) {  // the state's record header: {#emitting arcs (they follow it), first epsilon arc, #epsilon arcs, final}
+        const KhInt4 h = rec[st[k]];
+        ab[k] = kEps ? h.y : st[k] + 1;
+        cnt[k] = kEps ? h.z : h.x;
       }
     }
     int loff[EU], total;
@@ -646,7 +655,7 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const int32_t> off,
 // order-preserving image): a wave reads it when it claims tokens and lowers it after each
 // claim; any stale value is still an upper bound of the final next_cutoff.
 template <class Load, class Finish, class Store>
-__device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const int32_t> off, int b, int e, float cutoff, int lrun,
+__device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt4> rec, int b, int e, float cutoff, int lrun,
                                                    int frame_cap, long long *arcs, Blk &sh, float *est, float *bound, Load load,
                                                    Finish finish, Store store) {
   const int limit = min(u.link_cap, lrun + frame_cap);
@@ -671,9 +680,9 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const int32
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= cutoff;
     int ab = 0, cnt = 0;
-    if (need) {
-      ab = off[st];
-      cnt = off[st + 1] - ab;
+    if (need) {  // the emitting arcs follow the state's header in its record
+      ab = st + 1;
+      cnt = rec[st].x;
     }
     int inc = cnt;
 #pragma unroll
@@ -814,8 +823,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   return c;
 }
 
-__device__ __forceinline__ float LogLike(const Utt &u, const Params &p, const Blk &sh, int frame, int32_t tid) {
-  const int32_t pdf = p.tid2pdf ? p.tid2pdf[tid] : tid - 1;
+__device__ __forceinline__ float LogLike(const Utt &u, const Params &p, const Blk &sh, int frame, int32_t pdf) {
   if (p.ll_cols > 0) return sh.ll_row[pdf];
   return u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
 }
@@ -859,8 +867,9 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         cur_cost = Dec(LoadCostEnc(&u.tok_cost[i]));
         if (!(cur_cost > cutoff)) {  // :779
           const int32_t s = u.tok_state[i];
-          ab = p.n_off[s];
-          ae = p.n_off[s + 1];
+          const KhInt4 h = p.rec[s];
+          ab = h.y;
+          ae = h.y + h.z;
         }
       }
       KH_CL_STAMP(27);
@@ -936,7 +945,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
   const int blk_b = Uni(sh->link_end);
   long long seeded = 0;
   const int blk_e = ExpandSweep<true>(
-      u, p.n_off, 0, Uni(sh->eps_n), cutoff, blk_b, u.link_frame_cap, &seeded, sh, [&](int l, int src, int ai) {
+      u, p.rec, 0, Uni(sh->eps_n), cutoff, blk_b, u.link_frame_cap, &seeded, sh, [&](int l, int src, int ai) {
         KH_BOUND(3, src, 0, u.tok_cap);
         KH_BOUND(4, ai, 0, p.num_eps);
         const KhInt4 arc = p.n_arcs[ai];
@@ -1009,9 +1018,9 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     // from the main loop: ((w + (offset - ll)) + tot_cost) + adaptive_beam)
     const int32_t s = u.tok_state[c.best_tok];
     const float tot = c.best_cost;
-    const int ab = p.e_off[s], ae = p.e_off[s + 1];
+    const int ab = s + 1, ae = ab + p.rec[s].x;
     for (int a = ab + threadIdx.x; a < ae; a += NT) {
-      const KhInt4 arc = p.e_arcs[a];
+      const KhInt4 arc = p.rec[a];   // {pdf, olabel, weight, nextstate}
       const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
       const float new_weight = w + tot;
       est = fminf(est, new_weight + c.adaptive_beam);
@@ -1031,22 +1040,21 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   long long my_arcs = 0;
   constexpr int kLU = 1;  // (2 in flight per lane: no gain, +16 B of scratch per lane)
   KhInt4 c_arc[kLU];
-  int c_src[kLU], c_pdf[kLU], c_ai[kLU];
+  int c_src[kLU], c_ai[kLU];
   uint32_t c_co[kLU];
   float c_ac[kLU], c_tot[kLU];
   const int link_frame_e = ExpandWavesFiltered(
-      u, p.e_off, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
+      u, p.rec, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
       [&](int k, int src, uint32_t src_cost, int ai) {
         KH_BOUND(5, src, 0, u.tok_cap);
-        KH_BOUND(6, ai, 0, p.num_emit);
-        c_arc[k] = p.e_arcs[ai];
+        KH_BOUND(6, ai, 0, p.num_units);
+        c_arc[k] = p.rec[ai];
         c_ai[k] = ai;
-        c_pdf[k] = p.e_pdf ? static_cast<int>(p.e_pdf[ai]) : -1;
         c_src[k] = src;
         c_co[k] = src_cost;
       },
       [&](int k) -> bool {
-        int32_t pdf = p.e_pdf ? c_pdf[k] : (p.tid2pdf ? p.tid2pdf[c_arc[k].x] : c_arc[k].x - 1);
+        int32_t pdf = c_arc[k].x;
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
         c_ac[k] = cost_offset - like;
@@ -1097,9 +1105,14 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 #ifndef KH_LOC_BITS
 #define KH_LOC_BITS 5
 #endif
-    constexpr int kLocBits = KH_LOC_BITS;
+    // A state id is the unit index of its record (header + emitting arcs: ~3 units for the states of
+    // an HMM chain), so a block of 2^kLocBits table slots stands for 2^(kLocBits + kLocShift) units.
+#ifndef KH_LOC_SHIFT
+#define KH_LOC_SHIFT 1
+#endif
+    constexpr int kLocBits = KH_LOC_BITS, kLocShift = KH_LOC_SHIFT;
     auto lds_slot = [](uint32_t h, int32_t ns) {
-      return ((h << kLocBits) | (static_cast<uint32_t>(ns) & ((1u << kLocBits) - 1u))) & (kLdsSlots - 1);
+      return ((h << kLocBits) | ((static_cast<uint32_t>(ns) >> kLocShift) & ((1u << kLocBits) - 1u))) & (kLdsSlots - 1);
     };
     // number of parts: about 11 000 accepted candidates per part (typically half as many
     // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
@@ -1137,7 +1150,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
           const float tot_cost = tc[j];
           if (tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
           const int32_t ns = nsv[j];
-          const uint32_t h = HashState((ns & kStateMask) >> kLocBits);
+          const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
           if (part_of(h, parts) != k) continue;
           const uint32_t key = static_cast<uint32_t>(ns) + 1u;
           uint32_t slot = lds_slot(h, ns);
@@ -1233,7 +1246,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
             continue;
           }
           const int32_t ns = nsv[j];
-          const uint32_t h = HashState((ns & kStateMask) >> kLocBits);
+          const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
           if (part_of(h, parts) != k) continue;
           const uint32_t key = static_cast<uint32_t>(ns) + 1u;
           uint32_t slot = lds_slot(h, ns);
@@ -1375,7 +1388,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     }
     float fc[PU];
 #pragma unroll
-    for (int k = 0; k < PU; k++) fc[k] = (final_frame && have_final && st[k] >= 0) ? p.final_cost[st[k]] : 0.0f;
+    for (int k = 0; k < PU; k++) fc[k] = (final_frame && have_final && st[k] >= 0) ? __int_as_float(p.rec[st[k]].w) : 0.0f;
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       if (base + k * NT >= e) continue;
@@ -2119,7 +2132,7 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
     float best_cost = inf, best_with_final = inf;
     for (int i = fb + threadIdx.x; i < fe; i += NT) {
       const float cost = Dec(LoadCostEnc(&u.tok_cost[i]));
-      const float final_cost = p.final_cost[u.tok_state[i]];
+      const float final_cost = __int_as_float(p.rec[u.tok_state[i]].w);
       best_cost = fminf(best_cost, cost);
       best_with_final = fminf(best_with_final, cost + final_cost);
     }
@@ -2237,7 +2250,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
     const int ni = u.tmp_remap[i];
     if (ni < 0) continue;
     pool.t_frame[tb + ni] = FrameOfToken(u, i, T);
-    pool.t_state[tb + ni] = u.tok_state[i];
+    pool.t_state[tb + ni] = -1 - p.unit_ilabel[u.tok_state[i]];   // the caller's state id (kept in the header's slot of the label table)
   }
   // pass D: links, in arena order
   int lrun = 0;
@@ -2250,8 +2263,8 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
     if (alive) {
       const long long d = lbase + lrun + off;
       const int src = u.link_src[l], arc = u.link_arc[l];
-      const KhInt4 rec = arc >= 0 ? p.e_arcs[arc] : p.n_arcs[-1 - arc];   // labels: from the arc (3 % of the links survive to here)
-      const int il = arc >= 0 ? rec.x : 0;
+      const KhInt4 rec = arc >= 0 ? p.rec[arc] : p.n_arcs[-1 - arc];   // labels: from the arc (3 % of the links survive to here)
+      const int il = arc >= 0 ? p.unit_ilabel[arc] : 0;
       float a = il != 0 ? u.link_a[l] : 0.0f;  // (an epsilon link's field holds its extra-cost constant)
       if (il != 0) {  // :168-174 the acoustic cost without the frame's cost_offset
         const int f = FrameOfToken(u, src, T);
@@ -2474,7 +2487,7 @@ struct KhDecoder {
   UttOut *d_out = nullptr;
   unsigned long long *d_used = nullptr;
   long long *d_phase = nullptr;
-  uint16_t *e_pdf = nullptr;       // BuildArcPdf
+  int4 *rec = nullptr;             // BuildArcPdf: the state records with the pdf of every arc
 
   // lattice pool
   void *pool_slab = nullptr;
@@ -2689,7 +2702,7 @@ int BuildLattice(KhDecoder *d, int ui) {
   // start state (the reference gets that from TopSortTokens :839-914; ComputeBestPath and
   // the lattice writers rely on it), also when the start state has an epsilon arc to a
   // lower-numbered state
-  const int32_t start = d->fst->start;
+  const int32_t start = d->fst->start_state;
   std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
     if (tf[a] != tf[b]) return tf[a] < tf[b];
     const bool as = !(tf[a] == 0 && ts[a] == start), bs = !(tf[b] == 0 && ts[b] == start);
@@ -2888,47 +2901,46 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
   return KH_OK;
 }
 
-// pdf of every emitting arc: the expansion then reads it next to the arc (coalesced) instead of
-// gathering tid2pdf[ilabel] (64 distinct cache lines per wave instruction).  Rebuilt on every
-// call: the map is the caller's and may change between calls; one pass over the arcs (~20 us).
-__global__ void ArcPdfKernel(const KhInt4 *__restrict__ arcs, long long n, const int32_t *__restrict__ tid2pdf, uint16_t *__restrict__ out) {
-  for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x)
-    out[a] = static_cast<uint16_t>(tid2pdf[arcs[a].x]);
+// The decoder's own copy of the state records with the PDF in the first word of every arc unit
+// (tid2pdf[ilabel], or ilabel - 1 without a map): the expansion needs the score column, not the
+// transition-id, and reads it with the arc instead of gathering the map.  Rebuilt on every call
+// (the map is the caller's and may change between calls): one pass over the label table.
+__global__ void ArcPdfKernel(const int32_t *__restrict__ unit_ilabel, long long n, const int32_t *__restrict__ tid2pdf, int4 *__restrict__ rec) {
+  for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int32_t il = unit_ilabel[a];
+    if (il > 0) rec[a].x = tid2pdf ? tid2pdf[il] : il - 1;
+  }
 }
 
 int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, int ll_stride, hipStream_t st) {
-  p->e_pdf = (GP(const uint16_t))nullptr;
-  // (a valid map sends every transition-id to a column of the score matrix, kh_fst_check_pdf_map)
-  if (tid2pdf == nullptr || d->fst->num_emit == 0 || ll_stride <= 0 || ll_stride > 65536) return KH_OK;
-  if (d->e_pdf == nullptr) {
-    d->e_pdf = static_cast<uint16_t *>(PoolMalloc(sizeof(uint16_t) * d->fst->num_emit));
-    if (d->e_pdf == nullptr) return KH_OK;   // no memory to spare: the kernel gathers tid2pdf as before
+  (void)ll_stride;   // (a valid map sends every transition-id to a column of the score matrix, kh_fst_check_pdf_map)
+  const size_t bytes = sizeof(int4) * static_cast<size_t>(d->fst->num_units);
+  if (d->rec == nullptr) {
+    d->rec = static_cast<int4 *>(PoolMalloc(bytes));
+    if (d->rec == nullptr) return KH_ENOMEM;
+    KH_HIP(hipMemcpyAsync(d->rec, d->fst->rec, bytes, hipMemcpyDeviceToDevice, st));
   }
-  hipLaunchKernelGGL(ArcPdfKernel, dim3(NumCUs() * 8), dim3(256), 0, st, (const KhInt4 *)d->fst->e_arcs,
-                     static_cast<long long>(d->fst->num_emit), tid2pdf, d->e_pdf);
+  hipLaunchKernelGGL(ArcPdfKernel, dim3(NumCUs() * 8), dim3(256), 0, st, (const int32_t *)d->fst->unit_ilabel,
+                     static_cast<long long>(d->fst->num_units), tid2pdf, d->rec);
   KH_LAUNCH_CHECK();
-  p->e_pdf = (GP(const uint16_t))d->e_pdf;
+  p->rec = (GP(const KhInt4))d->rec;
   return KH_OK;
 }
 
 void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *tid2pdf) {
   Params &p = *pp;
-  p.e_off = (GP(const int32_t))d->fst->e_off;
-  p.n_off = (GP(const int32_t))d->fst->n_off;
-  p.e_arcs = (GP(const KhInt4))d->fst->e_arcs;
+  (void)tid2pdf;
+  p.rec = (GP(const KhInt4))d->rec;   // (BuildArcPdf allocates it on the first call and sets it again)
   p.n_arcs = (GP(const KhInt4))d->fst->n_arcs;
-  p.final_cost = (GP(const float))d->fst->final_cost;
+  p.unit_ilabel = (GP(const int32_t))d->fst->unit_ilabel;
   p.start = d->fst->start;
-  p.num_states = d->fst->num_states;
-  p.num_emit = static_cast<int32_t>(d->fst->num_emit);
+  p.num_units = static_cast<int32_t>(d->fst->num_units);
   p.num_eps = static_cast<int32_t>(d->fst->num_eps);
   p.start_has_eps = d->fst->start_has_eps;
   // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
   // the score row shares the workgroup's 64 KB of LDS with the static block (Shared)
   p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
-  p.tid2pdf = (GP(const int32_t))tid2pdf;
-  p.e_pdf = (GP(const uint16_t))nullptr;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
   p.lattice_beam = d->cfg.lattice_beam;
@@ -3087,56 +3099,70 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
     return nullptr;
   }
   const int64_t na = arc_offsets[num_states];
-  // the kernels address the arc tables with 32-bit byte offsets (Arr<T>): 16 bytes per arc
-  if (na >= (int64_t(1) << 28)) {
-    SetError("kh_fst_create: %lld arcs exceed the 2^28 arcs a 32-bit byte offset reaches", static_cast<long long>(na));
-    return nullptr;
-  }
-  if (num_states >= kStateMask) {  // (also keeps the (num_states + 1) x 4-byte offset tables under 4 GiB)
-    SetError("kh_fst_create: %d states exceed the 29-bit state ids of the arc records", num_states);
-    return nullptr;
-  }
   std::vector<uint8_t> has_eps(num_states, 0), eps_dst(num_states, 0);
-  for (int32_t s = 0; s < num_states; s++)
-    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++)
-      if (ilabel[a] == 0) {
-        has_eps[s] = 1;
-        if (nextstate[a] >= 0 && nextstate[a] < num_states) eps_dst[nextstate[a]] = 1;
-      }
-  std::vector<int32_t> e_off(num_states + 1), n_off(num_states + 1);
-  std::vector<int4> e_arcs, n_arcs;
-  e_arcs.reserve(na);
-  int32_t max_il = 0;
+  std::vector<int32_t> unit_of_state(num_states);
+  int64_t units = 0, n_eps_total = 0;
   for (int32_t s = 0; s < num_states; s++) {
-    e_off[s] = static_cast<int32_t>(e_arcs.size());
-    n_off[s] = static_cast<int32_t>(n_arcs.size());
+    unit_of_state[s] = static_cast<int32_t>(units);
+    units += 1;
     for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++) {
       if (nextstate[a] < 0 || nextstate[a] >= num_states || ilabel[a] < 0) {
         SetError("kh_fst_create: arc %lld out of range", static_cast<long long>(a));
         return nullptr;
       }
+      if (ilabel[a] == 0) {
+        has_eps[s] = 1;
+        eps_dst[nextstate[a]] = 1;
+        n_eps_total++;
+      } else {
+        units++;
+      }
+    }
+    // the kernels address the tables with 32-bit byte offsets (Arr<T>), 16 bytes per unit, and a
+    // state id (= unit index) shares its word with two flag bits
+    if (units >= (int64_t(1) << 28) || n_eps_total >= (int64_t(1) << 28)) {
+      SetError("kh_fst_create: %lld states + emitting arcs exceed the 2^28 units a 32-bit byte offset reaches", static_cast<long long>(units));
+      return nullptr;
+    }
+  }
+  static_assert(kStateMask >= (1 << 28) - 1, "unit ids must fit the state field of an arc");
+  std::vector<int4> rec(static_cast<size_t>(units)), n_arcs;
+  std::vector<int32_t> unit_ilabel(static_cast<size_t>(units), 0);   // (every unit is written below)
+  n_arcs.reserve(static_cast<size_t>(n_eps_total));
+  int32_t max_il = 0;
+  for (int32_t s = 0; s < num_states; s++) {
+    const int32_t base = unit_of_state[s], eps_base = static_cast<int32_t>(n_arcs.size());
+    int32_t ne = 0;
+    for (int64_t a = arc_offsets[s]; a < arc_offsets[s + 1]; a++) {
       int wbits;
       memcpy(&wbits, &weight[a], 4);
-      const int32_t ns = nextstate[a] | (has_eps[nextstate[a]] ? kHasEps : 0) | (eps_dst[nextstate[a]] ? kEpsDst : 0);
+      const int32_t ns = unit_of_state[nextstate[a]] | (has_eps[nextstate[a]] ? kHasEps : 0) | (eps_dst[nextstate[a]] ? kEpsDst : 0);
       if (ilabel[a] != 0) {
-        e_arcs.push_back(make_int4(ilabel[a], olabel[a], wbits, ns));
+        ne++;
+        rec[static_cast<size_t>(base) + ne] = make_int4(ilabel[a], olabel[a], wbits, ns);
+        unit_ilabel[static_cast<size_t>(base) + ne] = ilabel[a];
         max_il = std::max(max_il, ilabel[a]);
       } else {
         n_arcs.push_back(make_int4(0, olabel[a], wbits, ns));
       }
     }
+    int fbits;
+    memcpy(&fbits, &final_cost[s], 4);
+    rec[base] = make_int4(ne, eps_base, static_cast<int32_t>(n_arcs.size()) - eps_base, fbits);
+    unit_ilabel[base] = -1 - s;
   }
-  e_off[num_states] = static_cast<int32_t>(e_arcs.size());
-  n_off[num_states] = static_cast<int32_t>(n_arcs.size());
   KhFst *f = new KhFst();
   f->num_states = num_states;
-  f->start = start;
+  f->start = unit_of_state[start];
+  f->start_state = start;
   f->num_arcs = na;
-  f->num_emit = static_cast<int64_t>(e_arcs.size());
+  f->num_units = units;
+  f->num_emit = units - num_states;
   f->num_eps = static_cast<int64_t>(n_arcs.size());
   f->max_ilabel = max_il;
   f->final_host.assign(final_cost, final_cost + num_states);
   f->start_has_eps = has_eps[start];
+  f->unit_of_state.swap(unit_of_state);
   auto up = [&](void **dst, const void *src, size_t bytes) -> bool {
     *dst = PoolMalloc(bytes ? bytes : 16);
     if (!*dst) return false;
@@ -3146,11 +3172,9 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
     }
     return true;
   };
-  bool ok = up(reinterpret_cast<void **>(&f->e_off), e_off.data(), sizeof(int32_t) * e_off.size()) &&
-            up(reinterpret_cast<void **>(&f->n_off), n_off.data(), sizeof(int32_t) * n_off.size()) &&
-            up(reinterpret_cast<void **>(&f->e_arcs), e_arcs.data(), sizeof(int4) * e_arcs.size()) &&
-            up(reinterpret_cast<void **>(&f->n_arcs), n_arcs.data(), sizeof(int4) * n_arcs.size()) &&
-            up(reinterpret_cast<void **>(&f->final_cost), final_cost, sizeof(float) * num_states);
+  bool ok = up(reinterpret_cast<void **>(&f->rec), rec.data(), sizeof(int4) * rec.size()) &&
+            up(reinterpret_cast<void **>(&f->unit_ilabel), unit_ilabel.data(), sizeof(int32_t) * unit_ilabel.size()) &&
+            up(reinterpret_cast<void **>(&f->n_arcs), n_arcs.data(), sizeof(int4) * n_arcs.size());
   if (!ok) {
     kh_fst_destroy(f);
     return nullptr;
@@ -3160,11 +3184,9 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
 
 void kh_fst_destroy(KhFst *f) {
   if (!f) return;
-  PoolFree(f->e_off);
-  PoolFree(f->n_off);
-  PoolFree(f->e_arcs);
+  PoolFree(f->rec);
+  PoolFree(f->unit_ilabel);
   PoolFree(f->n_arcs);
-  PoolFree(f->final_cost);
   delete f;
 }
 
@@ -3268,7 +3290,7 @@ void kh_decoder_destroy(KhDecoder *d) {
   PoolFree(d->d_out);
   PoolFree(d->d_used);
   PoolFree(d->d_phase);
-  PoolFree(d->e_pdf);
+  PoolFree(d->rec);
   if (d->hp_slab) (void)hipHostFree(d->hp_slab);
   if (d->h_out_pinned) (void)hipHostFree(d->h_out_pinned);
   if (d->h_done) (void)hipHostFree(d->h_done);

@@ -15,6 +15,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find "$out/pmc_$c" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools/pmc_summarize.py "$f" DecodeKernel > "$out/${tag}_pmc_$c.txt"
 done
+# request sizes and DRAM-side byte tallies of DecodeKernel (the FETCH_SIZE correction, see tools/pmc_calibrate.sh)
+{
+  echo "# DecodeKernel, one launch: read request sizes and DRAM-side tallies in 32-byte units (separate rocprofv3 --pmc passes)"
+  for set in "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_WRREQ_WRITE_DRAM_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"; do
+    rm -rf "$out/pmc_x"
+    timeout -k 10 $T rocprofv3 --pmc $set --output-format csv -d "$out/pmc_x" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-strong > /dev/null 2> "$out/pmc_x.log"
+    f=$(find "$out/pmc_x" -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python3 tools/pmc_summarize.py "$f" DecodeKernel
+  done
+  rm -rf "$out/pmc_x"
+} > "$out/${tag}_pmc_request_sizes.txt"
 # the bench line LAST: its roofline.traffic reads the PMC summaries of THIS build
 cp "$out/${tag}_pmc_FETCH_SIZE.txt" "$out/${tag}_pmc_WRITE_SIZE.txt" profiles/ 2>/dev/null
 KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout $T python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/bench.err"
