@@ -174,8 +174,11 @@ struct Utt {
   int32_t link_cap;
   Arr<int32_t> link_dst; Arr<int32_t> link_arc;   // dst: token index, -1 = excised; arc: index of the emitting arc, or -1 - index of the epsilon arc (labels are read from the arc at export)
   Arr<int32_t> link_src;     // owning token (links are also walked link-parallel)
-  Arr<float> link_g; Arr<float> link_a;
-  Arr<float> link_tot;       // candidate tot_cost of the frame being expanded [link_frame_cap]
+  // link_k: the part of link_extra_cost (:309-311) that does not depend on extra_costs: for an emitting link the
+  // candidate's tot_cost = (cost[src] + acoustic) + graph until the frame's first pruning visit, which turns it
+  // into tot_cost - cost[dst] (cost[dst] is final by then); for an epsilon link that difference from its creation
+  // on.  link_a: acoustic cost (emitting links only).  The graph cost of a link is its arc's weight (read at export).
+  Arr<float> link_k; Arr<float> link_a;
   // per-frame bookkeeping
   Arr<int32_t> frame_b; Arr<int32_t> frame_e;      // [T+2] token range of frame f
   Arr<int32_t> feps_b; Arr<int32_t> feps_e;        // [T+2] link range of eps(f)
@@ -280,6 +283,7 @@ struct Shared {
   uint32_t bound_enc;  // ExpandWavesFiltered: Enc(upper bound of the final next_cutoff), atomic min
   float wbound[2][NW];  // ExpandSweepFiltered: per-wave minima of the cutoff estimate, double buffered
   int front_b;  // first token of the frame under construction (frontier)
+  int conv_upto;  // frames below it have had their first pruning visit (link_k of their emitting links is converted)
   int status;
   long long arcs_expanded, tokens_created;
   int max_tokens_frame;
@@ -960,11 +964,9 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
         u.link_dst[l] = dst;
         u.link_src[l] = src;
         u.link_arc[l] = -1 - ai;
-        u.link_g[l] = g;
-        // The acoustic cost of an epsilon link is 0; its field holds the constant part of
-        // link_extra_cost (:309-311) instead, (cost[src] + 0 + g) - cost[dst]: both costs
-        // are final once the closure has converged.
-        u.link_a[l] = dst >= 0 ? (Dec(co) + 0.0f + g) - Dec(LoadCostEnc(&u.tok_cost[dst])) : 0.0f;
+        // the constant part of link_extra_cost (:309-311), (cost[src] + 0 + g) - cost[dst]: both costs
+        // are final once the closure has converged (the acoustic cost of an epsilon link is 0: not stored)
+        u.link_k[l] = dst >= 0 ? (Dec(co) + 0.0f + g) - Dec(LoadCostEnc(&u.tok_cost[dst])) : 0.0f;
       });
   if (blk_e < 0) return false;
   KhSync();
@@ -1063,12 +1065,11 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         return !(c_tot[k] > bound);
       },
       [&](int k, int l) {
-        u.link_dst[l] = c_arc[k].w;  // HCLG next state for now; token index after pass 2
+        u.link_dst[l] = -2 - c_arc[k].w;  // <= -2: the HCLG next state (+ flags), unresolved; token index after pass 2
         u.link_src[l] = c_src[k];
         u.link_arc[l] = c_ai[k];
-        u.link_g[l] = __int_as_float(c_arc[k].z);
         u.link_a[l] = c_ac[k];
-        u.link_tot[l - link_frame_b] = c_tot[k];
+        u.link_k[l] = c_tot[k];
       });
   if (link_frame_e < 0) return false;
   // final next_cutoff: the value the reference's running cutoff converges to
@@ -1121,7 +1122,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     if (link_frame_e - link_frame_b > 11000) {
       int n_acc_mine = 0;
       for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
-        n_acc_mine += !(u.link_tot[l - link_frame_b] > next_cutoff) ? 1 : 0;
+        n_acc_mine += !(u.link_k[l] > next_cutoff) ? 1 : 0;
       const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
       while (parts * 11000 < n_acc) parts *= 2;
       if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
@@ -1131,7 +1132,8 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       for (int i = threadIdx.x; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
       if (threadIdx.x == 0) sh->flag = 0;
       KhSync();
-      // (B) insert.  A link that an earlier part resolved carries NaN in link_tot.  kMU
+      // (B) insert.  A link that an earlier part resolved holds its token index (>= 0), a rejected one -1,
+      // an unresolved one -2 - (next state + flags).  kMU
       // candidates per lane are loaded before any is used (independent loads in flight).
       constexpr int kMU = 4;
       for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * kMU) {
@@ -1141,15 +1143,15 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         for (int j = 0; j < kMU; j++) {
           const int l = base + j * NT;
           const int lc = l < link_frame_e ? l : link_frame_e - 1;
-          tc[j] = u.link_tot[lc - link_frame_b];
+          tc[j] = u.link_k[lc];
           nsv[j] = u.link_dst[lc];
           if (l >= link_frame_e) tc[j] = nan;
         }
 #pragma unroll
         for (int j = 0; j < kMU; j++) {
           const float tot_cost = tc[j];
-          if (tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
-          const int32_t ns = nsv[j];
+          if (nsv[j] >= -1 || tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
+          const int32_t ns = -2 - nsv[j];
           const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
           if (part_of(h, parts) != k) continue;
           const uint32_t key = static_cast<uint32_t>(ns) + 1u;
@@ -1232,20 +1234,19 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         for (int j = 0; j < kMU; j++) {
           const int l = base + j * NT;
           const int lc = l < link_frame_e ? l : link_frame_e - 1;
-          tc[j] = u.link_tot[lc - link_frame_b];
+          tc[j] = u.link_k[lc];
           nsv[j] = u.link_dst[lc];
         }
 #pragma unroll
         for (int j = 0; j < kMU; j++) {
           const int l = base + j * NT;
-          if (l >= link_frame_e) continue;
+          if (l >= link_frame_e || nsv[j] >= -1) continue;   // resolved by an earlier part, or rejected
           const float tot_cost = tc[j];
           if (tot_cost != tot_cost || tot_cost > next_cutoff) {
-            // resolved by an earlier part (a NaN candidate of the first part: rejected), or rejected
-            if (k == 0) u.link_dst[l] = -1;
+            u.link_dst[l] = -1;  // rejected (:731; a NaN candidate too)
             continue;
           }
-          const int32_t ns = nsv[j];
+          const int32_t ns = -2 - nsv[j];
           const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
           if (part_of(h, parts) != k) continue;
           const uint32_t key = static_cast<uint32_t>(ns) + 1u;
@@ -1253,7 +1254,6 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
           const uint32_t step = ((h >> 9) | 1u) << kLocBits;
           while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
           u.link_dst[l] = static_cast<int32_t>(vals[slot]);
-          if (parts > 1) u.link_tot[l - link_frame_b] = nan;
         }
       }
       KhSync();
@@ -1300,31 +1300,26 @@ struct Acc {
 // lattice beam are excised (:315); kAccum: the others are min-ed into
 // acc[src - b].  Returns 2 if this lane excised a link.
 template <bool kEps, bool kAccum, bool kExcise, bool kList = false>
-__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, const Acc &acc,
+__device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, const Acc &acc, bool fresh,
                                              __attribute__((address_space(3))) int *list_n = nullptr) {
   int flags = 0;
   for (int base = lo + threadIdx.x; base < hi; base += NT * PU) {
     int l[PU], dst[PU], src[PU];
-    float a[PU], g[PU];
+    float kk[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
       l[k] = min(base + k * NT, hi - 1);  // clamped: the tail repeats the last slot
       dst[k] = u.link_dst[l[k]];
       src[k] = u.link_src[l[k]];
-      a[k] = u.link_a[l[k]];
-      g[k] = kEps ? 0.0f : u.link_g[l[k]];
+      kk[k] = u.link_k[l[k]];
     }
-    uint32_t cs[PU], cd[PU];
     float ex[PU];
 #pragma unroll
     for (int k = 0; k < PU; k++) {
-      cs[k] = cd[k] = 0u;
       ex[k] = 0.0f;
       if (dst[k] < 0) continue;  // excised slot: no gathers
-      if (!kEps) {
-        cs[k] = LoadCostEnc(&u.tok_cost[src[k]]);
-        cd[k] = LoadCostEnc(&u.tok_cost[dst[k]]);
-      }
+      // fresh (the frame's first visit): link_k of an emitting link still holds the candidate's tot_cost
+      if (!kEps && fresh) kk[k] = kk[k] - Dec(LoadCostEnc(&u.tok_cost[dst[k]]));
       ex[k] = LoadExtra(&u.tok_extra[dst[k]]);
     }
 #pragma unroll
@@ -1338,12 +1333,13 @@ __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b
         (void)__hip_atomic_fetch_or(&u.tmp_dirty[dst[k] - b], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (kEps && kExcise) u.tmp_dirty[dst[k] - b] = 0;  // last pass over the epsilon links: leave tmp_dirty all zero
-      // :309-311; for an epsilon link the parenthesis was evaluated when it was created
-      float lec = kEps ? ex[k] + a[k] : ex[k] + ((Dec(cs[k]) + a[k] + g[k]) - Dec(cd[k]));
+      // :309-311; the parenthesis is link_k
+      float lec = ex[k] + kk[k];
       if (lec > lb) {  // :315 excise
         if (kExcise) { u.link_dst[l[k]] = -1; flags |= 2; }
         continue;
       }
+      if (!kEps && fresh) u.link_k[l[k]] = kk[k];
       if (kAccum) {
         if (lec < 0.0f) lec = 0.0f;  // :319-320
         acc.Min(src[k] - b, Enc(lec));
@@ -1359,7 +1355,7 @@ __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b
 // to run PruneTokensForFrame :450-469 on in the same sweep (tb == te: none).
 __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne,
                                   float delta, bool final_frame, bool have_final, float final_best_cost,
-                                  int tb, int te, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
+                                  int tb, int te, bool fresh, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY;
   const float lb = p.lattice_beam;
   if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; }
@@ -1404,7 +1400,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   KH_PRUNE_STAMP(20);
   // P1 (emitting links): a link to the NEXT frame sees final extra_costs there, so
   // its link_extra_cost - hence whether it is excised - is final at first sight.
-  int flags = PruneLinkPass<false, true, true>(u, mb, me, b, lb, acc0);
+  int flags = PruneLinkPass<false, true, true>(u, mb, me, b, lb, acc0, fresh);
   KhSync();
   KH_PRUNE_STAMP(21);
   // Epsilon links stay inside the frame (a DAG): the exact fixed point of
@@ -1440,8 +1436,8 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   if (ne > nb) {
     for (int iter = 0;; iter++) {
       KhSync();  // the extra_costs of the previous token sweep are in place
-      if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, acc1, &sh->wl_n[0]);
-      else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, acc1);
+      if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, acc1, false, &sh->wl_n[0]);
+      else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, acc1, false);
       KhSync();
       bool again = false;
       const int n_list = Uni(sh->wl_n[0]);
@@ -1464,7 +1460,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   }
   if (n_moved != 0) __hip_atomic_fetch_add(&sh->pr_moved, n_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   KH_PRUNE_STAMP(22);
-  if (ne > nb) flags |= PruneLinkPass<true, false, true>(u, nb, ne, b, lb, acc1);
+  if (ne > nb) flags |= PruneLinkPass<true, false, true>(u, nb, ne, b, lb, acc1, false);
   int all = BlockOr(flags, sh);
   if (Uni(sh->pr_moved) > 0) all |= 1;
   KH_PRUNE_STAMP(23);
@@ -1484,26 +1480,22 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
 // fixed point.
 constexpr int kPruneLdsTok = kLdsSlots / 2;  // 4096
 __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
-                              bool prune_toks_f1, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
+                              bool prune_toks_f1, bool fresh, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY, lb = p.lattice_beam;
   const int t = threadIdx.x;
   auto ra = LdsKeys(sh);  // 8192 words
   auto rb = LdsVals(sh);  // 8192 words
-  auto s_cost = reinterpret_cast<__attribute__((address_space(3))) float *>(ra);                  // cost of f's tokens
   auto s_acc0 = ra + kPruneLdsTok;                                                                  // Enc(min) over emitting links
-  auto s_nc = reinterpret_cast<__attribute__((address_space(3))) float *>(rb);                    // phase 1: cost of f + 1's tokens
+  auto s_nc = reinterpret_cast<__attribute__((address_space(3))) float *>(rb);                    // phase 1, first visit: cost of f + 1's tokens
   auto s_nx = reinterpret_cast<__attribute__((address_space(3))) float *>(rb + kPruneLdsTok);     // phase 1: extra_cost of f + 1's tokens
   auto s_acc1 = rb;                                                                                 // phase 2: Enc(min) over epsilon links
   auto s_x = reinterpret_cast<__attribute__((address_space(3))) float *>(rb + kPruneLdsTok);      // phase 2: extra_cost being computed
   if (u.phase_cycles != nullptr && t == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; sh->phase[14] += 1; }
   // ---- everything the visit reads, in one round trip
-  for (int i = t; i < e - b; i += NT) {
-    s_cost[i] = Dec(LoadCostEnc(&u.tok_cost[b + i]));
-    s_acc0[i] = kEncInf;
-  }
+  for (int i = t; i < e - b; i += NT) s_acc0[i] = kEncInf;
   for (int i = t; i < e1 - b1; i += NT) {
     const float nx = LoadExtra(&u.tok_extra[b1 + i]);
-    s_nc[i] = Dec(LoadCostEnc(&u.tok_cost[b1 + i]));
+    if (fresh) s_nc[i] = Dec(LoadCostEnc(&u.tok_cost[b1 + i]));
     s_nx[i] = nx;
     // PruneTokensForFrame(f + 1) :450-469: its extra_costs are final
     if (prune_toks_f1 && nx == inf && u.tok_state[b1 + i] >= 0) u.tok_state[b1 + i] = -1;
@@ -1511,11 +1503,11 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
   // the first epsilon link of every lane stays in registers over the iterations
   int n_dst = -1, n_src = 0;
   float n_a = 0.0f;
-  if (nb + t < ne) { n_dst = u.link_dst[nb + t]; n_src = u.link_src[nb + t]; n_a = u.link_a[nb + t]; }
+  if (nb + t < ne) { n_dst = u.link_dst[nb + t]; n_src = u.link_src[nb + t]; n_a = u.link_k[nb + t]; }
   // ... and the first emitting link is fetched in the same round trip as the tokens
   int m_dst = -1, m_src = 0;
-  float m_a = 0.0f, m_g = 0.0f;
-  if (mb + t < me) { m_dst = u.link_dst[mb + t]; m_src = u.link_src[mb + t]; m_a = u.link_a[mb + t]; m_g = u.link_g[mb + t]; }
+  float m_k = 0.0f;
+  if (mb + t < me) { m_dst = u.link_dst[mb + t]; m_src = u.link_src[mb + t]; m_k = u.link_k[mb + t]; }
   KhSync();
   // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
   int flags = 0;
@@ -1524,12 +1516,14 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
     const int dst = first ? m_dst : u.link_dst[l];
     if (dst < 0) continue;
     const int src = first ? m_src : u.link_src[l];
-    const float a = first ? m_a : u.link_a[l], g = first ? m_g : u.link_g[l];
-    float lec = s_nx[dst - b1] + ((s_cost[src - b] + a + g) - s_nc[dst - b1]);
+    float kk = first ? m_k : u.link_k[l];
+    if (fresh) kk = kk - s_nc[dst - b1];  // first visit: link_k still holds the candidate's tot_cost (:309-311's parenthesis = tot_cost - cost[dst])
+    float lec = s_nx[dst - b1] + kk;
     if (lec > lb) {
       u.link_dst[l] = -1;
       flags |= 2;
     } else {
+      if (fresh) u.link_k[l] = kk;
       if (lec < 0.0f) lec = 0.0f;
       __hip_atomic_fetch_min(&s_acc0[src - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -1564,7 +1558,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
       for (int l = nb + NT + t; l < ne; l += NT) {
         const int dst = u.link_dst[l];
         if (dst < 0) continue;
-        float lec = s_x[dst - b] + u.link_a[l];
+        float lec = s_x[dst - b] + u.link_k[l];
         if (!(lec > lb)) {
           if (lec < 0.0f) lec = 0.0f;
           __hip_atomic_fetch_min(&s_acc1[u.link_src[l] - b], Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1589,7 +1583,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
     }
     for (int l = nb + NT + t; l < ne; l += NT) {
       const int dst = u.link_dst[l];
-      if (dst >= 0 && s_x[dst - b] + u.link_a[l] > lb) {
+      if (dst >= 0 && s_x[dst - b] + u.link_k[l] > lb) {
         u.link_dst[l] = -1;
         flags |= 2;
       }
@@ -1620,7 +1614,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
 // extra[dst] are gathered from L2.  No global atomics (PruneForwardLinks keeps its epsilon
 // accumulator in HBM: a DRAM read-modify-write per link and round).
 __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
-                                 bool prune_toks_f1, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
+                                 bool prune_toks_f1, bool fresh, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY, lb = p.lattice_beam;
   const int t = threadIdx.x;
   // 2 * kLdsSlots words in two pieces (the value and the key array of the emitting pass's table): Enc(extra_cost) of f's tokens
@@ -1638,30 +1632,31 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
   constexpr int kBU = 2;
   for (int l0 = mb + t; l0 < me; l0 += NT * kBU) {
     int dst[kBU], src[kBU];
-    float a[kBU], g[kBU];
+    float kk[kBU];
 #pragma unroll
     for (int k = 0; k < kBU; k++) {
       const int l = min(l0 + k * NT, me - 1);
-      dst[k] = u.link_dst[l]; src[k] = u.link_src[l]; a[k] = u.link_a[l]; g[k] = u.link_g[l];
+      dst[k] = u.link_dst[l]; src[k] = u.link_src[l]; kk[k] = u.link_k[l];
     }
-    float nx[kBU], cs[kBU], cd[kBU];
+    float nx[kBU];
 #pragma unroll
     for (int k = 0; k < kBU; k++) {
-      nx[k] = cs[k] = cd[k] = 0.0f;
+      nx[k] = 0.0f;
       if (dst[k] >= 0) {
         nx[k] = LoadExtra(&u.tok_extra[dst[k]]);
-        cd[k] = Dec(LoadCostEnc(&u.tok_cost[dst[k]]));
-        cs[k] = Dec(LoadCostEnc(&u.tok_cost[src[k]]));
+        // first visit: link_k still holds the candidate's tot_cost (:309-311's parenthesis = tot_cost - cost[dst])
+        if (fresh) kk[k] = kk[k] - Dec(LoadCostEnc(&u.tok_cost[dst[k]]));
       }
     }
 #pragma unroll
     for (int k = 0; k < kBU; k++) {
       if (l0 + k * NT >= me || dst[k] < 0) continue;
-      float lec = nx[k] + ((cs[k] + a[k] + g[k]) - cd[k]);
+      float lec = nx[k] + kk[k];
       if (lec > lb) {
         u.link_dst[l0 + k * NT] = -1;
         flags |= 2;
       } else {
+        if (fresh) u.link_k[l0 + k * NT] = kk[k];
         if (lec < 0.0f) lec = 0.0f;
         __hip_atomic_fetch_min(x(src[k] - b), Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -1675,7 +1670,7 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
       for (int l = nb + t; l < ne; l += NT) {
         const int dst = u.link_dst[l];
         if (dst < 0) continue;
-        float lec = Dec(*x(dst - b)) + u.link_a[l];  // the parenthesis of :309-311 was evaluated when the link was created
+        float lec = Dec(*x(dst - b)) + u.link_k[l];  // the parenthesis of :309-311 was evaluated when the link was created
         if (!(lec > lb)) {
           if (lec < 0.0f) lec = 0.0f;
           const uint32_t v = Enc(lec);
@@ -1689,7 +1684,7 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
     // excise :315
     for (int l = nb + t; l < ne; l += NT) {
       const int dst = u.link_dst[l];
-      if (dst >= 0 && Dec(*x(dst - b)) + u.link_a[l] > lb) {
+      if (dst >= 0 && Dec(*x(dst - b)) + u.link_k[l] > lb) {
         u.link_dst[l] = -1;
         flags |= 2;
       }
@@ -1728,6 +1723,9 @@ __device__ __forceinline__ void StoreFlag(P p, uint8_t v) {
 
 __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Blk &sh) {
   if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[12] += 1;
+  // every frame below conv_upto has been visited (a new frame has must_prune_forward_links set, and the
+  // loop below cannot stop above it)
+  const int conv_upto = Uni(sh->conv_upto);
   for (int f = cur - 1; f >= 0; f--) {
     // the flags and the frame's bounds in one round trip (the bounds are needed by most visits)
     const int ml_i = static_cast<int>(LoadFlag(&u.must_links[f]));
@@ -1744,13 +1742,14 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     if (u.phase_cycles != nullptr && threadIdx.x == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (ml) {
       bool ec, lp;
+      const bool fresh = f >= conv_upto;  // the frame's first visit: its emitting links still carry tot_cost in link_k
       const int b = Uni(vb), e = Uni(ve), mb = Uni(vmb), me = Uni(vme), nb = Uni(vnb), ne = Uni(vne), b1 = Uni(vb1), e1 = Uni(ve1);
       if (e - b <= kPruneLdsTok && e1 - b1 <= kPruneLdsTok)
-        PruneFrameLds(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
+        PruneFrameLds(u, p, b, e, mb, me, nb, ne, b1, e1, mt, fresh, delta, &ec, &lp, sh);
       else if (e - b <= 2 * kLdsSlots)
-        PruneFrameLdsBig(u, p, b, e, mb, me, nb, ne, b1, e1, mt, delta, &ec, &lp, sh);
+        PruneFrameLdsBig(u, p, b, e, mb, me, nb, ne, b1, e1, mt, fresh, delta, &ec, &lp, sh);
       else
-        PruneForwardLinks(u, p, b, e, mb, me, nb, ne, delta, false, false, 0.f, mt ? b1 : 0, mt ? e1 : 0, &ec, &lp, sh);
+        PruneForwardLinks(u, p, b, e, mb, me, nb, ne, delta, false, false, 0.f, mt ? b1 : 0, mt ? e1 : 0, fresh, &ec, &lp, sh);
       if (threadIdx.x == 0) {
         if (ec && f > 0) StoreFlag(&u.must_links[f - 1], 1);
         if (lp) StoreFlag(&u.must_toks[f], 1);
@@ -1768,6 +1767,7 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
       sh->phase[18 + thick] += 1;
     }
   }
+  if (threadIdx.x == 0) sh->conv_upto = cur;
   KhSync();
 }
 
@@ -1935,7 +1935,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             if (!alive[k]) continue;
             const int l = base + k * NT + threadIdx.x;
             src[k] = u.link_src[l]; arc[k] = u.link_arc[l];
-            g[k] = u.link_g[l]; a[k] = u.link_a[l];
+            g[k] = u.link_k[l]; a[k] = u.link_a[l];
           }
 #pragma unroll
           for (int k = 0; k < KC; k++) {
@@ -1948,7 +1948,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             if (!alive[k]) continue;
             const int d = lend + off[k];
             u.link_dst[d] = dst[k]; u.link_src[d] = src[k];
-            u.link_arc[d] = arc[k]; u.link_g[d] = g[k]; u.link_a[d] = a[k];
+            u.link_arc[d] = arc[k]; u.link_k[d] = g[k]; u.link_a[d] = a[k];
           }
         } else {
           span = min(NT, chunk_e - base);
@@ -1957,7 +1957,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
           float g = 0.f, a = 0.f;
           if (l < chunk_e) {
             dst = u.link_dst[l];
-            if (dst >= 0) { src = u.link_src[l]; arc = u.link_arc[l]; g = u.link_g[l]; a = u.link_a[l]; }
+            if (dst >= 0) { src = u.link_src[l]; arc = u.link_arc[l]; g = u.link_k[l]; a = u.link_a[l]; }
           }
           const int alive = dst >= 0 ? 1 : 0;
           off[0] = BlockExScan(alive, &total, sh);
@@ -1968,7 +1968,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             const int d = lend + off[0];
             u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
             u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
-            u.link_arc[d] = arc; u.link_g[d] = g; u.link_a[d] = a;
+            u.link_arc[d] = arc; u.link_k[d] = g; u.link_a[d] = a;
           }
         }
         while (bj < nb) {   // the block bounds inside this group
@@ -2031,6 +2031,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->tok_end = 0;
     sh->link_end = 0;
     sh->front_b = 0;
+    sh->conv_upto = 0;
     sh->status = 0;
     sh->arcs_expanded = 0;
     sh->tokens_created = 0;
@@ -2145,10 +2146,12 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
     st.final_best_cost = final_best_cost;
     bool b1, b2;
     PruneForwardLinks(u, p, fb, fe, 0, 0, Uni(u.feps_b[last]), Uni(u.feps_e[last]), 0.0f, true, have_final, final_best_cost,
-                      0, 0, &b1, &b2, sh);
+                      0, 0, false, &b1, &b2, sh);
+    const int conv_upto = Uni(sh->conv_upto);  // frames from here on see their first pruning visit now
     for (int f = last - 1; f >= 0; f--)
       PruneForwardLinks(u, p, Uni(u.frame_b[f]), Uni(u.frame_e[f]), Uni(u.femit_b[f]), Uni(u.femit_e[f]), Uni(u.feps_b[f]), Uni(u.feps_e[f]),
-                        0.0f, false, false, 0.f, Uni(u.frame_b[f + 1]), Uni(u.frame_e[f + 1]), &b1, &b2, sh);
+                        0.0f, false, false, 0.f, Uni(u.frame_b[f + 1]), Uni(u.frame_e[f + 1]), f >= conv_upto, &b1, &b2, sh);
+    if (threadIdx.x == 0) sh->conv_upto = last;
     PruneTokensForFrame(u, Uni(u.frame_b[0]), Uni(u.frame_e[0]));
     // final compaction of the window so the export below copies little
     ok = Compact(u, last - WindowFrames(p), last, sh);
@@ -2265,7 +2268,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
       const int src = u.link_src[l], arc = u.link_arc[l];
       const KhInt4 rec = arc >= 0 ? p.rec[arc] : p.n_arcs[-1 - arc];   // labels: from the arc (3 % of the links survive to here)
       const int il = arc >= 0 ? p.unit_ilabel[arc] : 0;
-      float a = il != 0 ? u.link_a[l] : 0.0f;  // (an epsilon link's field holds its extra-cost constant)
+      float a = il != 0 ? u.link_a[l] : 0.0f;  // (not stored for an epsilon link)
       if (il != 0) {  // :168-174 the acoustic cost without the frame's cost_offset
         const int f = FrameOfToken(u, src, T);
         a -= f < T ? u.cost_offset[f] : 0.0f;
@@ -2274,7 +2277,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
       pool.l_dst[d] = u.tmp_remap[dst];
       pool.l_il[d] = il;
       pool.l_ol[d] = rec.y;
-      pool.l_g[d] = u.link_g[l];
+      pool.l_g[d] = __int_as_float(rec.z);   // the graph cost is the arc's weight
       pool.l_a[d] = a;
     }
     lrun += total;
@@ -2362,7 +2365,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
 struct SlotState {
   int32_t tok_end, link_end, front_b, status, max_tokens_frame, tok_hw, gc_tok, gc_link;
   int32_t t, fb, fe;          // Run
-  int32_t ok, finalized;
+  int32_t ok, finalized, conv_upto;
   long long arcs_expanded, tokens_created;
   KhDecodeStats stats;        // valid once finalized
 };
@@ -2377,7 +2380,7 @@ __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
   if (threadIdx.x == 0) {
     sh->tok_end = S.tok_end; sh->link_end = S.link_end; sh->front_b = S.front_b; sh->status = S.status;
     sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw; sh->gc_tok = S.gc_tok; sh->gc_link = S.gc_link;
-    sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created;
+    sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created; sh->conv_upto = S.conv_upto;
   }
   run->t = S.t; run->fb = S.fb; run->fe = S.fe;
   KhSync();
@@ -2387,7 +2390,7 @@ __device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
   if (threadIdx.x == 0) {
     S->tok_end = sh->tok_end; S->link_end = sh->link_end; S->front_b = sh->front_b; S->status = sh->status;
     S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw; S->gc_tok = sh->gc_tok; S->gc_link = sh->gc_link;
-    S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created;
+    S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created; S->conv_upto = sh->conv_upto;
     S->t = run.t; S->fb = run.fb; S->fe = run.fe;
     S->ok = (ok && sh->status == 0) ? 1 : 0;
   }
@@ -2640,9 +2643,8 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.link_dst = c.Take<int32_t>(nl);
   u.link_src = c.Take<int32_t>(nl);
   u.link_arc = c.Take<int32_t>(nl);
-  u.link_g = c.Take<float>(nl);
+  u.link_k = c.Take<float>(nl);
   u.link_a = c.Take<float>(nl);
-  u.link_tot = c.Take<float>(link_frame_cap);
   u.frame_b = c.Take<int32_t>(T + 2);
   u.frame_e = c.Take<int32_t>(T + 2);
   u.feps_b = c.Take<int32_t>(T + 2);
