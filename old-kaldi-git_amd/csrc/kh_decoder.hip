@@ -134,6 +134,32 @@ struct Arr {
 // 16-byte arc record as a native vector (HIP's int4 is a class; it cannot be
 // loaded through an address-space-qualified pointer)
 typedef int KhInt4 __attribute__((ext_vector_type(4)));
+// Four consecutive 4-byte elements of an SoA array with ONE 16-byte access per lane, at any 4-byte
+// alignment: a coalesced dword-per-lane sweep streams at 3.3 TB/s on this part, the same sweep with 16
+// bytes per lane at 5.6 TB/s (profiles/r02_pmc_calibration.txt: CalStreamDword / CalStreamDwordx4).
+typedef int KhInt4U __attribute__((ext_vector_type(4), aligned(4)));
+typedef float KhFloat4 __attribute__((ext_vector_type(4)));
+typedef float KhFloat4U __attribute__((ext_vector_type(4), aligned(4)));
+template <class T>
+__device__ __forceinline__ KhInt4 Load4I(const Arr<T> &a, int i) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  return *(__attribute__((address_space(1))) const KhInt4U *)((__attribute__((address_space(1))) const char *)a.p + static_cast<uint32_t>(i) * 4u);
+}
+template <class T>
+__device__ __forceinline__ KhFloat4 Load4F(const Arr<T> &a, int i) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  return *(__attribute__((address_space(1))) const KhFloat4U *)((__attribute__((address_space(1))) const char *)a.p + static_cast<uint32_t>(i) * 4u);
+}
+template <class T>
+__device__ __forceinline__ void Store4I(const Arr<T> &a, int i, KhInt4 v) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  *(__attribute__((address_space(1))) KhInt4U *)((__attribute__((address_space(1))) char *)a.p + static_cast<uint32_t>(i) * 4u) = v;
+}
+template <class T>
+__device__ __forceinline__ void Store4F(const Arr<T> &a, int i, KhFloat4 v) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  *(__attribute__((address_space(1))) KhFloat4U *)((__attribute__((address_space(1))) char *)a.p + static_cast<uint32_t>(i) * 4u) = v;
+}
 
 // Token costs are updated with L2 atomics (atomicMin), which do not refresh this
 // CU's vector L1: a plain load could return a stale L1 copy of the line (e.g. one
@@ -1136,16 +1162,23 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       // an unresolved one -2 - (next state + flags).  kMU
       // candidates per lane are loaded before any is used (independent loads in flight).
       constexpr int kMU = 4;
-      for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * kMU) {
+      for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
         float tc[kMU];
         int32_t nsv[kMU];
+        if (base + kMU <= link_frame_e) {   // a lane owns kMU = 4 consecutive candidates: one 16-byte load per array
+          const KhFloat4 t4 = Load4F(u.link_k, base);
+          const KhInt4 n4 = Load4I(u.link_dst, base);
+          tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
+          nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < kMU; j++) {
-          const int l = base + j * NT;
-          const int lc = l < link_frame_e ? l : link_frame_e - 1;
-          tc[j] = u.link_k[lc];
-          nsv[j] = u.link_dst[lc];
-          if (l >= link_frame_e) tc[j] = nan;
+          for (int j = 0; j < kMU; j++) {
+            const int l = base + j;
+            const int lc = l < link_frame_e ? l : link_frame_e - 1;
+            tc[j] = u.link_k[lc];
+            nsv[j] = u.link_dst[lc];
+            if (l >= link_frame_e) tc[j] = nan;
+          }
         }
 #pragma unroll
         for (int j = 0; j < kMU; j++) {
@@ -1227,23 +1260,33 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       if (threadIdx.x == 0) sh->tok_end = tok_base + total;
       KhSync();
       // (D) the part's links get their token index; rejected candidates become dead links
-      for (int base = link_frame_b + threadIdx.x; base < link_frame_e; base += NT * kMU) {
+      for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
         float tc[kMU];
         int32_t nsv[kMU];
+        const bool full = base + kMU <= link_frame_e;
+        if (full) {
+          const KhFloat4 t4 = Load4F(u.link_k, base);
+          const KhInt4 n4 = Load4I(u.link_dst, base);
+          tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
+          nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < kMU; j++) {
-          const int l = base + j * NT;
-          const int lc = l < link_frame_e ? l : link_frame_e - 1;
-          tc[j] = u.link_k[lc];
-          nsv[j] = u.link_dst[lc];
+          for (int j = 0; j < kMU; j++) {
+            const int lc = base + j < link_frame_e ? base + j : link_frame_e - 1;
+            tc[j] = u.link_k[lc];
+            nsv[j] = u.link_dst[lc];
+          }
         }
+        bool wrote = false;
 #pragma unroll
         for (int j = 0; j < kMU; j++) {
-          const int l = base + j * NT;
+          const int l = base + j;
           if (l >= link_frame_e || nsv[j] >= -1) continue;   // resolved by an earlier part, or rejected
           const float tot_cost = tc[j];
           if (tot_cost != tot_cost || tot_cost > next_cutoff) {
-            u.link_dst[l] = -1;  // rejected (:731; a NaN candidate too)
+            nsv[j] = -1;  // rejected (:731; a NaN candidate too)
+            wrote = true;
+            if (!full) u.link_dst[l] = -1;
             continue;
           }
           const int32_t ns = -2 - nsv[j];
@@ -1253,7 +1296,14 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
           uint32_t slot = lds_slot(h, ns);
           const uint32_t step = ((h >> 9) | 1u) << kLocBits;
           while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
-          u.link_dst[l] = static_cast<int32_t>(vals[slot]);
+          nsv[j] = static_cast<int32_t>(vals[slot]);
+          wrote = true;
+          if (!full) u.link_dst[l] = nsv[j];
+        }
+        if (full && wrote) {   // the lane owns the four slots: one 16-byte store
+          KhInt4 o4;
+          o4.x = nsv[0]; o4.y = nsv[1]; o4.z = nsv[2]; o4.w = nsv[3];
+          Store4I(u.link_dst, base, o4);
         }
       }
       KhSync();
@@ -1629,14 +1679,23 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
   LdsSync();
   // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
   int flags = 0;
-  constexpr int kBU = 2;
-  for (int l0 = mb + t; l0 < me; l0 += NT * kBU) {
+  constexpr int kBU = 4;   // a lane owns 4 consecutive links: one 16-byte access per array
+  for (int l0 = mb + t * kBU; l0 < me; l0 += NT * kBU) {
     int dst[kBU], src[kBU];
     float kk[kBU];
+    const bool full = l0 + kBU <= me;
+    if (full) {
+      const KhInt4 d4 = Load4I(u.link_dst, l0), s4 = Load4I(u.link_src, l0);
+      const KhFloat4 k4 = Load4F(u.link_k, l0);
+      dst[0] = d4.x; dst[1] = d4.y; dst[2] = d4.z; dst[3] = d4.w;
+      src[0] = s4.x; src[1] = s4.y; src[2] = s4.z; src[3] = s4.w;
+      kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < kBU; k++) {
-      const int l = min(l0 + k * NT, me - 1);
-      dst[k] = u.link_dst[l]; src[k] = u.link_src[l]; kk[k] = u.link_k[l];
+      for (int k = 0; k < kBU; k++) {
+        const int l = min(l0 + k, me - 1);
+        dst[k] = u.link_dst[l]; src[k] = u.link_src[l]; kk[k] = u.link_k[l];
+      }
     }
     float nx[kBU];
 #pragma unroll
@@ -1648,18 +1707,26 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
         if (fresh) kk[k] = kk[k] - Dec(LoadCostEnc(&u.tok_cost[dst[k]]));
       }
     }
+    bool killed = false;
 #pragma unroll
     for (int k = 0; k < kBU; k++) {
-      if (l0 + k * NT >= me || dst[k] < 0) continue;
+      if (l0 + k >= me || dst[k] < 0) continue;
       float lec = nx[k] + kk[k];
       if (lec > lb) {
-        u.link_dst[l0 + k * NT] = -1;
+        dst[k] = -1;
+        killed = true;
+        if (!full) u.link_dst[l0 + k] = -1;
         flags |= 2;
       } else {
-        if (fresh) u.link_k[l0 + k * NT] = kk[k];
+        if (fresh && !full) u.link_k[l0 + k] = kk[k];
         if (lec < 0.0f) lec = 0.0f;
         __hip_atomic_fetch_min(x(src[k] - b), Enc(lec), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+    }
+    if (full) {
+      if (killed) { KhInt4 o; o.x = dst[0]; o.y = dst[1]; o.z = dst[2]; o.w = dst[3]; Store4I(u.link_dst, l0, o); }
+      // (the k of a link that died in this visit or earlier is never read again: any value may be stored)
+      if (fresh) { KhFloat4 o; o.x = kk[0]; o.y = kk[1]; o.z = kk[2]; o.w = kk[3]; Store4F(u.link_k, l0, o); }
     }
   }
   // ---- epsilon links (inside the frame): relax in place to the fixed point

@@ -1,4 +1,3 @@
-tools/collect_profiles.sh gpurun_out/profiles_r02j r02 > gpurun_out/collect.log 2>&1
-tail -2 gpurun_out/collect.log
-cat gpurun_out/profiles_r02j/r02_pmc_request_sizes.txt gpurun_out/profiles_r02j/r02_pmc_FETCH_SIZE.txt gpurun_out/profiles_r02j/r02_pmc_WRITE_SIZE.txt
-head -c 600 gpurun_out/profiles_r02j/r02_bench.json
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 900 python tools/validate_bench_scale.py 700 2>&1 | tail -6
+KH_FUZZ_SEEDS=400 timeout 1200 python -m pytest tests/test_gpu_decoder.py -x -q -k fuzz 2>&1 | tail -3
