@@ -183,19 +183,25 @@ int LaunchLoglikes(const float *data, KhMatrixDim dd, const float *g,
 // [frame][gaussian], then one lane per (frame, pdf): max, cutoff, double sum of expf, log.
 // Same operations in the same order as kh_diag_gmm_loglikes + GmmPdfLseRowKernel: the
 // results are bit-identical to the unfused path.
-// Measured (200 k frames, cfg 2; phases switched off one at a time): 6.2 ms = matrix cores 2.2 ms
-// (their floor: 2 x 200k x 9000 x 40 MAC at the fp32 MFMA rate) + LogSumExp 2.7 ms + staging /
-// barriers 1.4 ms - the phases of the two resident workgroups of a CU run in lockstep and do
-// not overlap yet (next: MFMA waves and LogSumExp waves as producer / consumer on a double-
-// buffered tile).
+// Measured (200 k frames, cfg 2): 5.0 ms.  History: 6.2 ms = matrix cores 2.2 ms (their floor: 2 x 200k x
+// 9000 x 40 MAC at the fp32 MFMA rate) + LogSumExp 2.7 ms + staging / barriers 1.4 ms, phases switched
+// off one at a time; the LogSumExp phase was LDS latency (a dependent read per Gaussian, twice): chunks
+// of 8 independent reads -> 5.4 ms; 8 waves per workgroup (4 per SIMD with the CU's second workgroup, so
+// one workgroup's LogSumExp runs under the other's MFMAs) -> 5.2 ms; the tile list split over
+// blockIdx.y so that the last round of workgroups is short -> 5.0 ms.
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kFT = 64, kGT = 128, kGTP = kGT + 5, kOTP = kGT + 1;  // kGTP odd: the transposing tile stores spread over all banks
+#ifndef KH_GMM_WAVES
+#define KH_GMM_WAVES 8
+#endif
+constexpr int kGW = KH_GMM_WAVES, kGThreads = 64 * kGW, kGJ = 8 / kGW;  // waves per workgroup; 32-column MFMA tiles per wave (2 x 4 tiles of 32 x 32 cover 64 frames x 128 Gaussians)
+static_assert(kGW == 4 || kGW == 8, "waves");
 
 struct GmmTile { int32_t m_begin, m_end, pdf_begin, pdf_end; };
 
 template <int KS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(kGThreads, 2)
 GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride, const float *__restrict__ gconsts,
                   const float *__restrict__ mi, const float *__restrict__ iv, const int32_t *__restrict__ pdf_offsets,
                   const GmmTile *__restrict__ tiles, int n_tiles, float prune, float min_log_diff,
@@ -207,7 +213,7 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
                                   // next tile's are stored while slow waves still read this tile's)
   __shared__ float Ot[kFT][kOTP];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, kk = lane >> 5, l31 = lane & 31;
+  const int wm = wave / (kGW / 2), wn = wave % (kGW / 2), kk = lane >> 5, l31 = lane & 31;
   const int t0 = blockIdx.x * kFT;
   // this wave's 32 frames as MFMA A operands: lane (l31, kk) holds x[frame l31][2 s + kk]
   float ax[KS], axx[KS];
@@ -224,14 +230,14 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
   // The tile's parameters travel global -> registers -> LDS, and the NEXT tile's are loaded
   // into the registers while this tile computes (the staging loop used to cost ~20 dependent
   // L2 round trips per tile: 21 us per tile against 2 us of MFMA work).
-  constexpr int kPer = 2 * KS * kGT / 256;   // staged elements per lane and array
+  constexpr int kPer = 2 * KS * kGT / kGThreads;   // staged elements per lane and array
   float rmi[kPer], riv[kPer], rg = 0.f;
   int rp = 0;
   auto load_tile = [&](const GmmTile &tl) {
     const int nm = tl.m_end - tl.m_begin;
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
-      const int idx = t + j * 256;
+      const int idx = t + j * kGThreads;
       const int m = idx / (2 * KS), k = idx - m * (2 * KS);
       const bool ok = m < nm && k < D;
       const size_t o = ok ? static_cast<size_t>(tl.m_begin + m) * D + k : 0;
@@ -242,15 +248,20 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
     rg = (t < kGT && t < nm) ? gconsts[tl.m_begin + t] : 0.f;
     rp = (t <= tl.pdf_end - tl.pdf_begin) ? pdf_offsets[tl.pdf_begin + t] - tl.m_begin : 0;
   };
-  GmmTile tl = tiles[0];
+  // blockIdx.y = which share of the tile list: the units of work are short enough that the last round of
+  // workgroups does not leave most of the chip idle (3125 frame blocks on 512 slots = 6.1 rounds)
+  const int ti_begin = static_cast<int>(static_cast<long long>(n_tiles) * blockIdx.y / gridDim.y);
+  const int ti_end = static_cast<int>(static_cast<long long>(n_tiles) * (blockIdx.y + 1) / gridDim.y);
+  if (ti_begin >= ti_end) return;
+  GmmTile tl = tiles[ti_begin];
   load_tile(tl);
-  for (int ti = 0; ti < n_tiles; ti++) {
+  for (int ti = ti_begin; ti < ti_end; ti++) {
     const int nm = tl.m_end - tl.m_begin;
     (void)nm;
     // ---- parameters of the tile -> LDS, transposed to [k][gaussian]; zero padding
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
-      const int idx = t + j * 256;
+      const int idx = t + j * kGThreads;
       const int m = idx / (2 * KS), k = idx - m * (2 * KS);
       Bmi[k][m] = rmi[j];
       Biv[k][m] = riv[j];
@@ -259,29 +270,29 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
     if (t <= kGT) Po[ti & 1][t] = rp;
     __syncthreads();  // (also: the previous tile's LogSumExp has finished reading Ot and Po)
     const GmmTile cur = tl;
-    if (ti + 1 < n_tiles) {
+    if (ti + 1 < ti_end) {
       tl = tiles[ti + 1];
       load_tile(tl);
     }
-    f32x16 a1[2], a2[2];
+    f32x16 a1[kGJ], a2[kGJ];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < kGJ; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { a1[j][r] = 0.f; a2[j][r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       const int k = 2 * s + kk;
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int col = wn * 64 + j * 32 + l31;
+      for (int j = 0; j < kGJ; j++) {
+        const int col = (wn * kGJ + j) * 32 + l31;
         a1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[s], Bmi[k][col], a1[j], 0, 0, 0);
         a2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(axx[s], Biv[k][col], a2[j], 0, 0, 0);
       }
     }
     // loglikes = gconsts + data * means_invvars^T; loglikes += -0.5 * data_sq * inv_vars^T
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = wn * 64 + j * 32 + l31;
+    for (int j = 0; j < kGJ; j++) {
+      const int col = (wn * kGJ + j) * 32 + l31;
       const float g = Bg[col];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -296,18 +307,46 @@ GmmFusedPdfKernel(const float *__restrict__ data, int T, int D, int data_stride,
     const int np = cur.pdf_end - cur.pdf_begin;
     const bool row_ok = t0 + lane < T;
     float *orow = out + static_cast<size_t>(t0 + lane) * out_stride + cur.pdf_begin;
-    for (int pj = wave; pj < np; pj += 4) {
-      const int sidx = Po[ti & 1][pj], eidx = Po[ti & 1][pj + 1];
+    // The pdf's scores in chunks of kLC registers: the LDS reads of a chunk are independent and go
+    // out together (a loop "read, wait, fmax" per Gaussian was 10 dependent LDS round trips per pdf:
+    // the LogSumExp phase was bound by that latency, 2.7 of the kernel's 6.2 ms; two pdfs per wave in
+    // flight on top of that measured slower).  The ranges are wave-uniform; the maximum does not depend on the order, the
+    // double sum keeps the Gaussian order.
+    constexpr int kLC = 8;
+    auto finish = [&](int sidx, int eidx, const float (&v0)[kLC]) -> float {
       float mx = -INFINITY;
-      for (int m = sidx; m < eidx; m++) mx = fmaxf(mx, Ot[lane][m]);
+#pragma unroll
+      for (int j = 0; j < kLC; j++) mx = fmaxf(mx, sidx + j < eidx ? v0[j] : -INFINITY);
+      for (int m0 = sidx + kLC; m0 < eidx; m0 += kLC) {
+        float v[kLC];
+#pragma unroll
+        for (int j = 0; j < kLC; j++) v[j] = Ot[lane][min(m0 + j, kGT - 1)];
+#pragma unroll
+        for (int j = 0; j < kLC; j++) mx = fmaxf(mx, m0 + j < eidx ? v[j] : -INFINITY);
+      }
       float cutoff = mx + min_log_diff;
       if (prune > 0.0f && mx - prune > cutoff) cutoff = mx - prune;
       double sum = 0.0;
-      for (int m = sidx; m < eidx; m++) {
-        const float v = Ot[lane][m];
-        if (v >= cutoff) sum += static_cast<double>(ExpTerm(v - mx));
+#pragma unroll
+      for (int j = 0; j < kLC; j++)
+        if (sidx + j < eidx && v0[j] >= cutoff) sum += static_cast<double>(ExpTerm(v0[j] - mx));
+      for (int m0 = sidx + kLC; m0 < eidx; m0 += kLC) {
+        float v[kLC];
+#pragma unroll
+        for (int j = 0; j < kLC; j++) v[j] = Ot[lane][min(m0 + j, kGT - 1)];
+#pragma unroll
+        for (int j = 0; j < kLC; j++)
+          if (m0 + j < eidx && v[j] >= cutoff) sum += static_cast<double>(ExpTerm(v[j] - mx));
       }
-      if (row_ok) orow[pj] = static_cast<float>(static_cast<double>(mx) + LogOfSum(sum));
+      return static_cast<float>(static_cast<double>(mx) + LogOfSum(sum));
+    };
+    for (int pj = wave; pj < np; pj += kGW) {
+      const int sa = Po[ti & 1][pj], ea = Po[ti & 1][pj + 1];
+      float va[kLC];
+#pragma unroll
+      for (int j = 0; j < kLC; j++) va[j] = Ot[lane][min(sa + j, kGT - 1)];
+      const float ra = finish(sa, ea, va);
+      if (row_ok) orow[pj] = ra;
     }
     // (the next tile's parameter load only touches Bmi / Biv / Bg: no barrier needed here)
   }
@@ -335,7 +374,11 @@ template <int KS>
 int LaunchFused(const float *data, KhMatrixDim dd, const float *g, const float *mi, const float *iv,
                 const int32_t *pdf_offsets, const GmmTile *d_tiles, int n_tiles, float prune, float min_log_diff,
                 float *out, int out_stride) {
-  hipLaunchKernelGGL(GmmFusedPdfKernel<KS>, dim3(DivUp(dd.rows, kFT)), dim3(256), 0, Stream(), data, dd.rows, dd.cols,
+  const int blocks = DivUp(dd.rows, kFT);
+  int split = DivUp(16 * 2 * NumCUs(), blocks);   // >= 16 rounds of the 2 x #CU resident workgroups
+  if (const char *e = getenv("KH_GMM_SPLIT")) split = atoi(e);
+  split = std::max(1, std::min(std::min(split, 8), n_tiles));
+  hipLaunchKernelGGL(GmmFusedPdfKernel<KS>, dim3(blocks, split), dim3(kGThreads), 0, Stream(), data, dd.rows, dd.cols,
                      dd.stride, g, mi, iv, pdf_offsets, d_tiles, n_tiles, prune, min_log_diff, out, out_stride);
   KH_LAUNCH_CHECK();
   return KH_OK;
