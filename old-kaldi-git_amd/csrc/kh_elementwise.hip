@@ -83,16 +83,60 @@ __global__ void __launch_bounds__(BLOCK)
 SoftmaxSumGroupKernel(float *__restrict__ y, const float *__restrict__ x, int in_cols, int out_cols,
                       int y_stride, int x_stride, const int32_t *__restrict__ ranges,
                       const float *__restrict__ log_priors, float prob_scale) {
-  __shared__ float cache[kSoftmaxLdsFloats];
+  __shared__ __attribute__((aligned(16))) float cache[kSoftmaxLdsFloats];
   __shared__ float red[BLOCK / 64];
   const int r = blockIdx.x;
   const float *xr = x + static_cast<size_t>(r) * x_stride;
   float *yr = y + static_cast<size_t>(r) * y_stride;
+  // the column ranges and priors of this lane's outputs do not depend on the row: fetched first, so
+  // that the output pass does not start with two dependent L2 round trips per output
+  constexpr int kPre = 8;
+  const bool pre = out_cols <= kPre * BLOCK;
+  int pb[kPre], pe[kPre];
+  float pl[kPre];
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < kPre; k++) {
+      const int c = threadIdx.x + k * BLOCK;
+      pb[k] = pe[k] = 0;
+      pl[k] = 0.f;
+      if (c < out_cols) {
+        pb[k] = ranges[2 * c];
+        pe[k] = ranges[2 * c + 1];
+        if (log_priors != nullptr) pl[k] = log_priors[c];
+      }
+    }
+  }
   float m = -INFINITY;
-  for (int c = threadIdx.x; c < in_cols; c += BLOCK) {
-    const float v = xr[c];
-    cache[c] = v;
-    m = fmaxf(m, v);
+  if ((in_cols & 3) == 0 && (x_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // 16 bytes per lane, a lane's loads independent of each other (all in flight); the maximum does
+    // not depend on the order and the later passes keep their column partition
+    const float4 *x4 = reinterpret_cast<const float4 *>(xr);
+    float4 *c4 = reinterpret_cast<float4 *>(cache);
+    const int n4 = in_cols >> 2;
+    constexpr int kV = 4;
+    for (int c0 = threadIdx.x; c0 < n4; c0 += kV * BLOCK) {
+      float4 v[kV];
+#pragma unroll
+      for (int k = 0; k < kV; k++) {
+        const int c = c0 + k * BLOCK;
+        v[k] = c < n4 ? x4[c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int k = 0; k < kV; k++) {
+        const int c = c0 + k * BLOCK;
+        if (c < n4) {
+          c4[c] = v[k];
+          m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+        }
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < in_cols; c += BLOCK) {
+      const float v = xr[c];
+      cache[c] = v;
+      m = fmaxf(m, v);
+    }
   }
   m = BlockMax(m, red);
   float s = 0.f;
@@ -103,21 +147,42 @@ SoftmaxSumGroupKernel(float *__restrict__ y, const float *__restrict__ x, int in
   }
   s = BlockSum(s, red);
   const float inv = 1.0f / s;
-  for (int c = threadIdx.x; c < out_cols; c += BLOCK) {
-    const int b = ranges[2 * c], e = ranges[2 * c + 1];
+  auto emit = [&](int c, int b, int e, float lp) {
     float sum = 0.f;
-    for (int j = b; j < e; j++) {
-      float p = cache[j] * inv;          // softmax
-      if (p < 1.0e-20f) p = 1.0e-20f;    // SoftmaxComponent::Propagate floor :942
-      sum += p;                          // SumGroupComponent
+    // the first four members of the group as independent LDS reads (groups of the p-norm recipes hold 1-4)
+    float q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = cache[min(b + k, in_cols - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (b + k < e) {
+        float p = q[k] * inv;              // softmax
+        if (p < 1.0e-20f) p = 1.0e-20f;    // SoftmaxComponent::Propagate floor :942
+        sum += p;                          // SumGroupComponent
+      }
+    }
+    for (int j = b + 4; j < e; j++) {
+      float p = cache[j] * inv;
+      if (p < 1.0e-20f) p = 1.0e-20f;
+      sum += p;
     }
     if (log_priors != nullptr) {
       if (sum < 1.0e-20f) sum = 1.0e-20f;        // ApplyFloor(1.0e-20)
       sum = logf(sum);                           // ApplyLog()
-      sum = sum + (-1.0f) * log_priors[c];       // AddVecToRows(-1.0, log priors)
+      sum = sum + (-1.0f) * lp;                  // AddVecToRows(-1.0, log priors)
       sum = sum * prob_scale;                    // Scale(prob_scale)
     }
     yr[c] = sum;
+  };
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < kPre; k++) {
+      const int c = threadIdx.x + k * BLOCK;
+      if (c < out_cols) emit(c, pb[k], pe[k], pl[k]);
+    }
+  } else {
+    for (int c = threadIdx.x; c < out_cols; c += BLOCK)
+      emit(c, ranges[2 * c], ranges[2 * c + 1], log_priors != nullptr ? log_priors[c] : 0.f);
   }
 }
 
