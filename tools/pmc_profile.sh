@@ -14,6 +14,5 @@ run() {
 }
 if [ -n "$PMC_ONLY" ]; then run custom $PMC_ONLY; exit 0; fi
 run sq SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
-# (the TA_* counters abort rocprofv3 on this pool: not collected)
-run tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TAGRAM0_REQ_sum
+# (the TA_* and TCP_* counters abort rocprofv3 on this pool: not collected)
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_ATOMIC_sum
