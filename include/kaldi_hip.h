@@ -238,7 +238,11 @@ int kh_am_gmm_loglikes(const float *data, KhMatrixDim d_data,
 typedef struct KhFst KhFst;
 /* fst::Fst<StdArc> as read by ReadFstKaldi (nnet-latgen-faster.cc:108):
  * HOST CSR arrays; arc_offsets has num_states+1 entries; final[s] = +inf for
- * non-final states (TropicalWeight::Zero()). */
+ * non-final states (TropicalWeight::Zero()).  Limits (NULL + kh_last_error otherwise):
+ * num_states + #arcs with ilabel != 0 < 2^28 and #arcs with ilabel == 0 < 2^28 (the
+ * device tables are addressed with 32-bit byte offsets, 16 bytes per state / arc);
+ * device memory: 20 bytes per state and per emitting arc, 16 per epsilon arc, and
+ * 16 more per state and emitting arc in every decoder created on the graph. */
 KhFst *kh_fst_create(int32_t num_states, int32_t start,
                      const int64_t *arc_offsets, const int32_t *ilabel,
                      const int32_t *olabel, const float *weight,
