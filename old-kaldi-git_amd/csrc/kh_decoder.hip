@@ -62,14 +62,9 @@ struct KhFst {
   int4 *rec = nullptr;             // [num_units] header {n_emit, eps_base, n_eps, final bits} | arc {ilabel, olabel, weight bits, nextstate unit | flags}
   int32_t *unit_ilabel = nullptr;  // [num_units] ilabel (> 0) of an arc unit (the decoder's copy of rec holds the pdf there); -1 - the caller's state id for a header
   int4 *n_arcs = nullptr;          // {0, olabel, weight bits, nextstate unit | flags}
-  std::vector<int32_t> unit_of_state;  // host: caller's state -> unit id (sorted: the inverse is a binary search)
   std::vector<float> final_host;       // host copy for lattice export, by the caller's state
   int start_has_eps = 0;
   int32_t max_ilabel = 0;
-  float FinalOfUnit(int32_t unit) const {
-    const auto it = std::lower_bound(unit_of_state.begin(), unit_of_state.end(), unit);
-    return final_host[static_cast<size_t>(it - unit_of_state.begin())];
-  }
 };
 
 namespace {
@@ -3231,7 +3226,6 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
   f->max_ilabel = max_il;
   f->final_host.assign(final_cost, final_cost + num_states);
   f->start_has_eps = has_eps[start];
-  f->unit_of_state.swap(unit_of_state);
   auto up = [&](void **dst, const void *src, size_t bytes) -> bool {
     *dst = PoolMalloc(bytes ? bytes : 16);
     if (!*dst) return false;
