@@ -80,3 +80,16 @@ def _wait(procs):
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)
+
+
+def build_tools():
+    """Standalone HIP programs under tools/ (gfx950): tools/pmc_calibrate.hip -> build/pmc_calibrate, the
+    known-byte-count kernels behind profiles/r02_pmc_calibration.txt (tools/pmc_calibrate.sh)."""
+    root = os.path.join(HERE, "..")
+    src = os.path.join(root, "tools", "pmc_calibrate.hip")
+    exe = os.path.join(HERE, "build", "pmc_calibrate")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O2", "-o", exe, src])
+    return exe
+
