@@ -242,17 +242,32 @@ __device__ __forceinline__ void BlockSum2D(double &a, double &b, double *red) {
 // GetIvector :631-655 -> LinearCgd matrix/optimization.cc:453-565 (max_error 0, recompute factor 0.01)
 // on the workgroup's LDS copy of the statistics: quad (packed lower triangle by rows), lin; xv = the
 // previous estimate on entry (current_ivector_), the new one on return.
+// (forced inline: as a called function its LDS arguments are generic pointers and every access a FLAT
+// instruction - the solve ran at a third of the speed)
 template <int kNW = 4>
-__device__ void IvGetIvector(const double *quad, const double *lin, double *xv, double *rv, double *pv, double *x0, int S,
+__device__ __forceinline__ void IvGetIvector(const double *quad, const double *lin, double *xv, double *rv, double *pv, double *x0, int S,
                              int cg_iters, double prior_offset, bool have_frames, double *red, int *n_fallback) {
   const int t_id = threadIdx.x;
-  auto spmv = [&](const double *vec, int s) {   // (A vec)[s], A = quad (symmetric)
+  // (A vec)[s], A = quad (symmetric, packed lower triangle).  ONE loop of S trips for every lane - element
+  // (s, c) sits at tri(max) + min - with four independent LDS reads in flight: as two loops of s + 1 and
+  // S - s - 1 trips the lanes of a wave diverged (a wave ran ~160 trips) and every trip waited for its own
+  // read, 8 us per product where the solve is a chain of them.  Same products, same order of additions.
+  auto spmv = [&](const double *vec, int s) {
     double acc = 0.0;
-    {
-      const int rs = s * (s + 1) / 2;
-      for (int c = 0; c <= s; c++) acc += quad[rs + c] * vec[c];
-      for (int c = s + 1; c < S; c++) acc += quad[c * (c + 1) / 2 + s] * vec[c];
+    const int rs = s * (s + 1) / 2;
+    int c = 0;
+    for (; c + 4 <= S; c += 4) {
+      double q[4], v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int cc = c + j;
+        q[j] = quad[cc <= s ? rs + cc : cc * (cc + 1) / 2 + s];
+        v[j] = vec[cc];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc += q[j] * v[j];
     }
+    for (; c < S; c++) acc += quad[c <= s ? rs + c : c * (c + 1) / 2 + s] * vec[c];
     return acc;
   };
       if (have_frames) {
@@ -611,6 +626,8 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
   double *lin = quad + qdim;      // [S]
   double *xv = lin + S, *rv = xv + S, *pv = rv + S, *x0 = pv + S;
   __shared__ double red[8];
+  constexpr int kWChunk = 16, kYU = 10;   // frames per chunk of weights (kWChunk x num_gselect <= 256 floats); rows of Y in flight per lane
+  __shared__ float s_w[kWChunk * 16];
   const int u = blockIdx.x, t_id = threadIdx.x;
   const int b = utt_off[u], e = utt_off[u + 1];
   // adaptation state (SetAdaptationState :151-160): [lin_off - 2] = num_frames, [lin_off - 1] = the prior's
@@ -624,31 +641,59 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
   int prev = b - 1;
   const int step = period > 0 ? period : (e - b);   // period <= 0: one point at the last frame, its iVector on every row
   for (int t = period > 0 ? b : e - 1, p = point_off[u]; t < e; t += step, p++) {
-    // frames (prev, t]: linear term and counts
+    // frames (prev, t]: linear term and counts.  A frame's weights decide which rows of Y are read: as a
+    // loop "weight, branch, row" per posting this was a chain of dependent HBM round trips (50 per
+    // estimation point, most of the kernel's time).  The weights of a chunk of frames go to LDS in one
+    // round trip; the rows are then fetched kYU at a time (independent loads) and added in posting order.
     double lin0_add = 0.0;
-    for (int tt = prev + 1; tt <= t; tt++) {
-      double tot_weight = 0.0;
-      for (int k = 0; k < G; k++) tot_weight += static_cast<double>(post_w[static_cast<size_t>(tt) * G + k]);
-      if (max_count > 0.0) {
-        const double old_scale = fmax(num_frames, max_count) / max_count,
-                     new_scale = fmax(num_frames + tot_weight, max_count) / max_count, change = new_scale - old_scale;
-        lin0_add += prior_offset * change;
-        diag += change;
+    double acc = t_id < S ? lin[t_id] : 0.0;
+    for (int c0 = prev + 1; c0 <= t; c0 += kWChunk) {
+      const int nf = min(kWChunk, t + 1 - c0), nw = nf * G;
+      __syncthreads();   // (the previous chunk's readers are done)
+      for (int i = t_id; i < nw; i += kT) s_w[i] = post_w[static_cast<size_t>(c0) * G + i];
+      __syncthreads();
+      for (int f = 0; f < nf; f++) {
+        double tot_weight = 0.0;
+        for (int k = 0; k < G; k++) tot_weight += static_cast<double>(s_w[f * G + k]);
+        if (max_count > 0.0) {
+          const double old_scale = fmax(num_frames, max_count) / max_count,
+                       new_scale = fmax(num_frames + tot_weight, max_count) / max_count, change = new_scale - old_scale;
+          lin0_add += prior_offset * change;
+          diag += change;
+        }
+        num_frames += tot_weight;
       }
-      num_frames += tot_weight;
+      if (t_id < S) {
+        const double *yb = Y + static_cast<size_t>(c0) * G * S + t_id;
+        for (int q0 = 0; q0 < nw; q0 += kYU) {
+          double y[kYU];
+#pragma unroll
+          for (int j = 0; j < kYU; j++) {
+            const int q = q0 + j;
+            y[j] = (q < nw && s_w[q] != 0.f) ? yb[static_cast<size_t>(q) * S] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < kYU; j++)
+            if (q0 + j < nw && s_w[q0 + j] != 0.f) acc += y[j];
+        }
+      }
     }
     if (t_id < S) {
-      double acc = lin[t_id];
-      for (int tt = prev + 1; tt <= t; tt++)
-        for (int k = 0; k < G; k++) {
-          const size_t q = static_cast<size_t>(tt) * G + k;
-          if (post_w[q] != 0.f) acc += Y[q * S + t_id];
-        }
       if (t_id == 0) acc += lin0_add;
       lin[t_id] = acc;
     }
     {
-      for (int q = t_id; q < qdim; q += kT) quad[q] = Quad[static_cast<size_t>(p) * qdim + q];
+      // the point's quadratic term (40 KB at S = 100): eight independent loads per lane in flight (a loop
+      // "load, store to LDS" per element was 20 dependent HBM round trips per estimation point)
+      const double *qsrc = Quad + static_cast<size_t>(p) * qdim;
+      for (int q0 = t_id; q0 < qdim; q0 += 8 * kT) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = q0 + j * kT < qdim ? qsrc[q0 + j * kT] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          if (q0 + j * kT < qdim) quad[q0 + j * kT] = v[j];
+      }
       __syncthreads();
       if (t_id < S) quad[t_id * (t_id + 1) / 2 + t_id] += diag;
     }
