@@ -57,21 +57,33 @@ SoftmaxKernel(float *__restrict__ y, const float *__restrict__ x, int cols,
   }
   m = BlockMax(m, red);
   float s = 0.f;
-  for (int c = threadIdx.x; c < cols; c += kBlock) {
-    float v = (cached ? cache[c] : xr[c]) - m;
-    float e = expf(v);
-    if (cached) cache[c] = LOG ? v : e;
-    s += e;
+  // (two loops, not "cached ? cache[c] : xr[c]": the compiler turns that into a select of the two POINTERS
+  // and a FLAT load)
+  if (cached) {
+    for (int c = threadIdx.x; c < cols; c += kBlock) {
+      const float v = cache[c] - m;
+      const float e = expf(v);
+      cache[c] = LOG ? v : e;
+      s += e;
+    }
+  } else {
+    for (int c = threadIdx.x; c < cols; c += kBlock) s += expf(xr[c] - m);
   }
   s = BlockSum(s, red);
   if (LOG) {
     const float ls = -1.0f * logf(s);
-    for (int c = threadIdx.x; c < cols; c += kBlock)
-      yr[c] = (cached ? cache[c] : (xr[c] - m)) + ls;
+    if (cached) {
+      for (int c = threadIdx.x; c < cols; c += kBlock) yr[c] = cache[c] + ls;
+    } else {
+      for (int c = threadIdx.x; c < cols; c += kBlock) yr[c] = (xr[c] - m) + ls;
+    }
   } else {
     const float inv = 1.0f / s;
-    for (int c = threadIdx.x; c < cols; c += kBlock)
-      yr[c] = (cached ? cache[c] : expf(xr[c] - m)) * inv;
+    if (cached) {
+      for (int c = threadIdx.x; c < cols; c += kBlock) yr[c] = cache[c] * inv;
+    } else {
+      for (int c = threadIdx.x; c < cols; c += kBlock) yr[c] = expf(xr[c] - m) * inv;
+    }
   }
 }
 
