@@ -619,7 +619,8 @@ __global__ void __launch_bounds__(kIvThreads)
 IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ point_off, const float *__restrict__ post_w, int G, int S,
               int qdim, const double *__restrict__ Quad, const double *__restrict__ Y, double prior_offset, double max_count,
               int period, int cg_iters, float *__restrict__ out, int out_stride, int *__restrict__ n_fallback,
-              const double *__restrict__ state_in, double *__restrict__ state_out, int state_dim, int lin_off) {
+              const double *__restrict__ state_in, double *__restrict__ state_out, int state_dim, int lin_off,
+              const int32_t *__restrict__ order) {
   extern __shared__ double lds[];
   constexpr int kT = kIvThreads;
   double *quad = lds;             // [qdim] packed lower triangle by rows
@@ -628,7 +629,9 @@ IvSolveKernel(const int32_t *__restrict__ utt_off, const int32_t *__restrict__ p
   __shared__ double red[8];
   constexpr int kWChunk = 16, kYU = 10;   // frames per chunk of weights (kWChunk x num_gselect <= 256 floats); rows of Y in flight per lane
   __shared__ float s_w[kWChunk * 16];
-  const int u = blockIdx.x, t_id = threadIdx.x;
+  // longest utterance first: a workgroup's time is proportional to its utterance's length, and in list
+  // order the long ones that start last set the kernel's duration
+  const int u = order[blockIdx.x], t_id = threadIdx.x;
   const int b = utt_off[u], e = utt_off[u + 1];
   // adaptation state (SetAdaptationState :151-160): [lin_off - 2] = num_frames, [lin_off - 1] = the prior's
   // share of the quadratic diagonal, [lin_off ...) = the linear term; the counts went into Quad with IvGammaKernel
@@ -916,8 +919,10 @@ int kh_ivector_extract_adapt(const KhIvectorExtractor *x, const float *feats, in
       for (int u = 0; u < n_utts; u++)
         poff[u + 1] = poff[u] + (c.greedy_most_recent ? 1 : (utt_row_offsets_host[u + 1] - utt_row_offsets_host[u] + c.ivector_period - 1) / c.ivector_period);
       int32_t *d_poff = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * (n_utts + 1)));
+      int32_t *d_order = static_cast<int32_t *>(PoolMalloc(sizeof(int32_t) * (n_utts + 1)));
+      std::vector<int32_t> order(n_utts);
       int *d_cnt = static_cast<int *>(PoolMalloc(sizeof(int) * (3 * static_cast<size_t>(I) + 3)));
-      if (!d_poff || !d_cnt) { PoolFree(d_poff); PoolFree(d_cnt); rc = KH_ENOMEM; break; }
+      if (!d_poff || !d_cnt || !d_order) { PoolFree(d_poff); PoolFree(d_cnt); PoolFree(d_order); rc = KH_ENOMEM; break; }
       if (hipMemcpyAsync(d_poff, poff.data(), sizeof(int32_t) * (n_utts + 1), hipMemcpyHostToDevice, st) != hipSuccess) rc = KH_EDEVICE;
       // scratch per chunk of utterances: <= 16 GB of Quad (8 qdim B per point) + 16 GB of y (8 G S B per frame) at the default sizes
       const long long kMaxRows = getenv("KH_IVECTOR_MAX_ROWS") ? atoll(getenv("KH_IVECTOR_MAX_ROWS")) : 4000000;
@@ -928,6 +933,12 @@ int kh_ivector_extract_adapt(const KhIvectorExtractor *x, const float *feats, in
         const int row0 = utt_row_offsets_host[u0], rows_c = utt_row_offsets_host[u1] - row0;
         const int p0 = poff[u0], pts = poff[u1] - p0;
         const long long n_post = static_cast<long long>(rows_c) * G;
+        // the chunk's utterances (indices relative to u0), longest first: the order the solve kernel's workgroups take them in
+        for (int u = u0; u < u1; u++) order[u] = u - u0;
+        std::stable_sort(order.begin() + u0, order.begin() + u1, [&](int32_t a, int32_t b) {
+          return utt_row_offsets_host[u0 + a + 1] - utt_row_offsets_host[u0 + a] > utt_row_offsets_host[u0 + b + 1] - utt_row_offsets_host[u0 + b];
+        });
+        if (hipMemcpyAsync(d_order + u0, order.data() + u0, sizeof(int32_t) * (u1 - u0), hipMemcpyHostToDevice, st) != hipSuccess) rc = KH_EDEVICE;
         double *d_gc = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(pts) * I));
         double *d_quad = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(pts) * x->qdim));
         double *d_y = static_cast<double *>(PoolMalloc(sizeof(double) * static_cast<size_t>(n_post) * S));
@@ -957,14 +968,14 @@ int kh_ivector_extract_adapt(const KhIvectorExtractor *x, const float *feats, in
                            d_quad - static_cast<ptrdiff_t>(p0) * x->qdim, d_y - static_cast<ptrdiff_t>(row0) * G * S, c.prior_offset,
                            static_cast<double>(c.max_count), c.greedy_most_recent ? 0 : c.ivector_period, c.num_cg_iters, ivectors, ivector_stride, x->n_exact,
                              d_sin ? d_sin + static_cast<size_t>(u0) * state_dim : nullptr,
-                             d_sout ? d_sout + static_cast<size_t>(u0) * state_dim : nullptr, state_dim, lin_off);
+                             d_sout ? d_sout + static_cast<size_t>(u0) * state_dim : nullptr, state_dim, lin_off, d_order + u0);
           if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { SetError("kh_ivector_extract: statistics kernels failed"); rc = KH_EDEVICE; }
         }
         PoolFree(d_gc); PoolFree(d_quad); PoolFree(d_y); PoolFree(d_sorted); PoolFree(d_items);
         u0 = u1;
       }
       (void)hipStreamSynchronize(st);
-      PoolFree(d_poff); PoolFree(d_cnt);
+      PoolFree(d_poff); PoolFree(d_cnt); PoolFree(d_order);
       if (rc) break;
     }
     if (hipGetLastError() != hipSuccess) { SetError("kh_ivector_extract: kernel launch failed"); rc = KH_EDEVICE; break; }
