@@ -1,4 +1,3 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-tools/collect_profiles.sh gpurun_out/profiles_r02m r02 > gpurun_out/collect.log 2>&1
-tail -2 gpurun_out/collect.log
-cat gpurun_out/profiles_r02m/r02_pmc_request_sizes.txt gpurun_out/profiles_r02m/r02_pmc_FETCH_SIZE.txt gpurun_out/profiles_r02m/r02_pmc_WRITE_SIZE.txt
+python -m pytest tests/test_gpu_decoder.py tests/test_gpu_structured.py tests/test_gpu_online_decoder.py -x -q 2>&1 | tail -2
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-strong 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms'])"
+bash tools/pmc_traffic.sh gpurun_out/traffic_clear 2>&1 | tail -2
