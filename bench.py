@@ -463,18 +463,16 @@ def main():
             t.append(time.perf_counter())
             dec.prepare()                            # raw lattices + best paths, host threads
             t.append(time.perf_counter())
-            tot_like, n_ok = 0.0, 0
-            arcs = toks = lat_arcs = lat_states = 0
-            for u in range(n_utts):
-                bp = dec.get_best_path(u)            # GetBestPath + lattice export (host part)
-                tot_like += -(bp["graph_cost"] + bp["acoustic_cost"])
-                n_ok += 1
-                st = dec.counters(u)
-                arcs += st["arcs_expanded"]
-                toks += st["tokens_created"]
-                ls = dec.stats(u)
-                lat_arcs += ls["num_links"]
-                lat_states += ls["num_tokens"]
+            # GetBestPath (words + alignments of every utterance) and the lattice sizes, one library call each
+            # for the whole shard; the sum runs over the utterances in order, in double, as the per-utterance
+            # loop it replaces did
+            bp = dec.get_best_paths()
+            tot_like, n_ok = 0.0, n_utts
+            for gc, ac in zip(bp["graph_cost"].tolist(), bp["acoustic_cost"].tolist()):
+                tot_like += -(gc + ac)
+            cnt, ls = dec.stats_batch()
+            arcs, toks = int(cnt["arcs_expanded"].sum()), int(cnt["tokens_created"].sum())
+            lat_arcs, lat_states = int(ls["num_links"].sum()), int(ls["num_tokens"].sum())
             t.append(time.perf_counter())
             stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, lat_arcs=lat_arcs, lat_states=lat_states,
                          kernel_ms=dec.last_kernel_ms())

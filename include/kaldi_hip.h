@@ -330,6 +330,15 @@ int kh_decoder_get_best_path(const KhDecoder *dec, int utt, int32_t *alignment,
                              int cap_ali, int32_t *n_ali, int32_t *words,
                              int cap_words, int32_t *n_words,
                              float *graph_cost, float *acoustic_cost);
+/* kh_decoder_get_best_path for utterances [first, first + n) in one call (the per-utterance loop of
+ * nnet-latgen-faster.cc:163-186 on the library's side of a foreign-function interface): alignments and
+ * word sequences row-concatenated, ali_off / words_off = n + 1 offsets into them, one cost pair per
+ * utterance.  KH_EINVAL if a buffer is too small. */
+int kh_decoder_get_best_paths(const KhDecoder *d, int first, int n, int32_t *alignment, int64_t cap_ali,
+                              int64_t *ali_off, int32_t *words, int64_t cap_words, int64_t *words_off,
+                              float *graph_cost, float *acoustic_cost);
+/* kh_decoder_get_counters / kh_decoder_get_stats for utterances [first, first + n); either array may be NULL. */
+int kh_decoder_get_stats_batch(const KhDecoder *d, int first, int n, KhDecodeStats *counters, KhDecodeStats *stats);
 /* Host post-pass of the whole batch on num_threads host threads (<= 0: all
  * cores): GetRawLattice + GetBestPath of every utterance, i.e. what
  * DecodeUtteranceLatticeFaster (decoder-wrappers.cc:215-262) does one utterance

@@ -719,6 +719,30 @@ class LatticeFasterDecoder:
         return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
                     graph_cost=g.value, acoustic_cost=a.value)
 
+    def get_best_paths(self, first=0, n=None):
+        """get_best_path of utterances [first, first + n) in one call: dict of alignment / words (concatenated,
+        with ali_off / words_off = n + 1 offsets), graph_cost / acoustic_cost arrays [n]."""
+        n = len(self._T) - first if n is None else int(n)
+        cap = int(np.sum(self._T[first:first + n])) + 16 * n + 16
+        capw = 4 * cap + 64
+        ali, words = np.empty(cap, np.int32), np.empty(capw, np.int32)
+        ao, wo = np.empty(n + 1, np.int64), np.empty(n + 1, np.int64)
+        g, a = np.empty(n, np.float32), np.empty(n, np.float32)
+        i64 = C.POINTER(C.c_int64)
+        check(lib().kh_decoder_get_best_paths(self._h, int(first), n, ali.ctypes.data_as(capi.c_int32_p), cap, ao.ctypes.data_as(i64),
+                                              words.ctypes.data_as(capi.c_int32_p), capw, wo.ctypes.data_as(i64),
+                                              g.ctypes.data_as(capi.c_float_p), a.ctypes.data_as(capi.c_float_p)))
+        return dict(alignment=ali[:ao[n]], ali_off=ao, words=words[:wo[n]], words_off=wo, graph_cost=g, acoustic_cost=a)
+
+    def stats_batch(self, first=0, n=None, counters=True, stats=True):
+        """counters(u) / stats(u) of utterances [first, first + n) in one call: two structured arrays (or None)."""
+        n = len(self._T) - first if n is None else int(n)
+        ca = (KhDecodeStats * n)() if counters else None
+        sa = (KhDecodeStats * n)() if stats else None
+        check(lib().kh_decoder_get_stats_batch(self._h, int(first), n, ca, sa))
+        as_np = lambda arr: None if arr is None else np.ctypeslib.as_array(arr)
+        return as_np(ca), as_np(sa)
+
 
 class LatticeFasterOnlineDecoder:
     """decoder/lattice-faster-online-decoder.h:44-200 for num_streams concurrent

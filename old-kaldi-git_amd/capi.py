@@ -129,6 +129,9 @@ SIGNATURES = {
     "kh_decoder_last_kernel_ms": (C.c_int, [vp, c_float_p]),
     "kh_decoder_get_raw_lattice": (C.c_int, [vp, C.c_int, c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_float_p, c_float_p]),
     "kh_decoder_get_best_path": (C.c_int, [vp, C.c_int, c_int32_p, C.c_int, c_int32_p, c_int32_p, C.c_int, c_int32_p, c_float_p, c_float_p]),
+    "kh_decoder_get_best_paths": (C.c_int, [vp, C.c_int, C.c_int, c_int32_p, C.c_int64, C.POINTER(C.c_int64), c_int32_p, C.c_int64,
+                                            C.POINTER(C.c_int64), c_float_p, c_float_p]),
+    "kh_decoder_get_stats_batch": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(KhDecodeStats), C.POINTER(KhDecodeStats)]),
     "kh_decoder_prepare": (C.c_int, [vp, C.c_int]),
     "kh_online_decoder_create": (vp, [vp, C.POINTER(KhDecoderConfig), C.c_int, C.c_int]),
     "kh_online_decoder_destroy": (None, [vp]),

@@ -14,6 +14,7 @@ from oracle import binding as B
 
 pytestmark = pytest.mark.gpu
 workloads = importlib.import_module("old-kaldi-git_amd.workloads")
+capi = importlib.import_module("old-kaldi-git_amd.capi")
 
 LAT_KEYS = ("state_frame", "state_hclg", "state_final", "arc_src", "arc_dst", "arc_il", "arc_ol", "arc_g", "arc_a")
 
@@ -375,3 +376,30 @@ def test_decoder_object_reused_across_batches(api):
             assert_same_best_path(dec.get_best_path(u), oc.best_path())
     with pytest.raises(api.KhError):   # more utterances than max_batch
         dec.decode(torch.zeros((90, 100), device="cuda"), np.arange(10, dtype=np.int32) * 10)
+
+
+def test_batched_accessors_equal_the_per_utterance_ones(api):
+    """kh_decoder_get_best_paths / kh_decoder_get_stats_batch = the per-utterance calls, concatenated."""
+    rng = np.random.default_rng(71)
+    g = graph_like_hclg(rng, 3000, 40)
+    lls = [workloads.make_loglikes(rng, int(T), 40) for T in (37, 1, 90, 12)]
+    dec = api.LatticeFasterDecoder(api.Fst(g), api.decoder_config(beam=11.0, max_active=400, min_active=20, lattice_beam=5.0),
+                                   max_batch=4, max_frames=90)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
+    dec.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
+    for first, n in ((0, 4), (1, 2), (3, 1), (2, 0)):
+        bp = dec.get_best_paths(first, n)
+        cnt, st = dec.stats_batch(first, n)
+        assert len(bp["graph_cost"]) == n and bp["ali_off"][0] == 0 and bp["words_off"][0] == 0
+        for i in range(n):
+            one = dec.get_best_path(first + i)
+            assert np.array_equal(bp["alignment"][bp["ali_off"][i]:bp["ali_off"][i + 1]], one["alignment"])
+            assert np.array_equal(bp["words"][bp["words_off"][i]:bp["words_off"][i + 1]], one["words"])
+            assert np.float32(bp["graph_cost"][i]) == np.float32(one["graph_cost"])
+            assert np.float32(bp["acoustic_cost"][i]) == np.float32(one["acoustic_cost"])
+            c1, s1 = dec.counters(first + i), dec.stats(first + i)
+            for k in c1:
+                assert cnt[k][i] == c1[k] and st[k][i] == s1[k], k
+    with pytest.raises(capi.KhError):
+        dec.get_best_paths(3, 2)
+
