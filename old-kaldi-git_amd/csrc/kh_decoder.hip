@@ -228,6 +228,9 @@ struct Params {
   Arr<const int32_t> unit_ilabel;
   int32_t start, num_units, num_eps, start_has_eps;
   int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
+  int32_t keep_ac;  // 1: links store their acoustic cost (online decoding: a chunk's scores are gone when the lattice is
+                    // exported); 0: it is recomputed at export from the score matrix, cost_offset[f] - loglike(f, pdf of the
+                    // arc) - the same float expression - and the expansion writes one stream less per candidate
   int32_t max_tid;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
@@ -1089,7 +1092,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         u.link_dst[l] = -2 - c_arc[k].w;  // <= -2: the HCLG next state (+ flags), unresolved; token index after pass 2
         u.link_src[l] = c_src[k];
         u.link_arc[l] = c_ai[k];
-        u.link_a[l] = c_ac[k];
+        if (p.keep_ac) u.link_a[l] = c_ac[k];
         u.link_k[l] = c_tot[k];
       });
   if (link_frame_e < 0) return false;
@@ -1842,7 +1845,7 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
 // links point into the window, so their dst fields are rewritten too).  A chunk's
 // slots are all read before the barrier of its scan and written at or below their
 // old position after it, so one barrier per chunk orders the slide.
-__device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
+__device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) {
   if (w_lo < 0) w_lo = 0;
   const int win_b = Uni(u.frame_b[w_lo]);
   const int old_tok_end = Uni(sh->tok_end);
@@ -2000,7 +2003,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             if (!alive[k]) continue;
             const int l = base + k * NT + threadIdx.x;
             src[k] = u.link_src[l]; arc[k] = u.link_arc[l];
-            g[k] = u.link_k[l]; a[k] = u.link_a[l];
+            g[k] = u.link_k[l]; a[k] = keep_ac ? u.link_a[l] : 0.0f;
           }
 #pragma unroll
           for (int k = 0; k < KC; k++) {
@@ -2013,7 +2016,8 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             if (!alive[k]) continue;
             const int d = lend + off[k];
             u.link_dst[d] = dst[k]; u.link_src[d] = src[k];
-            u.link_arc[d] = arc[k]; u.link_k[d] = g[k]; u.link_a[d] = a[k];
+            u.link_arc[d] = arc[k]; u.link_k[d] = g[k];
+            if (keep_ac) u.link_a[d] = a[k];
           }
         } else {
           span = min(NT, chunk_e - base);
@@ -2022,7 +2026,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
           float g = 0.f, a = 0.f;
           if (l < chunk_e) {
             dst = u.link_dst[l];
-            if (dst >= 0) { src = u.link_src[l]; arc = u.link_arc[l]; g = u.link_k[l]; a = u.link_a[l]; }
+            if (dst >= 0) { src = u.link_src[l]; arc = u.link_arc[l]; g = u.link_k[l]; a = keep_ac ? u.link_a[l] : 0.0f; }
           }
           const int alive = dst >= 0 ? 1 : 0;
           off[0] = BlockExScan(alive, &total, sh);
@@ -2033,7 +2037,8 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, Blk &sh) {
             const int d = lend + off[0];
             u.link_dst[d] = dst >= win_b ? u.tmp_remap[dst - win_b] : dst;
             u.link_src[d] = src >= win_b ? u.tmp_remap[src - win_b] : src;
-            u.link_arc[d] = arc; u.link_k[d] = g; u.link_a[d] = a;
+            u.link_arc[d] = arc; u.link_k[d] = g;
+            if (keep_ac) u.link_a[d] = a;
           }
         }
         while (bj < nb) {   // the block bounds inside this group
@@ -2142,13 +2147,13 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       Stamp(u, sh, 15);
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
       Stamp(u, sh, 6);
-      if ((t / p.prune_interval) % KH_COMPACT_EVERY == 0) ok = Compact(u, t - win_frames, t, sh);
+      if ((t / p.prune_interval) % KH_COMPACT_EVERY == 0) ok = Compact(u, t - win_frames, t, p.keep_ac != 0, sh);
       // Frames older than the window keep the slots of what was pruned after they left it
       // (the backward pruning keeps thinning frames ~200 frames behind the frontier): once that
       // garbage has grown to a third of an arena, compact everything (rare: every ~700 frames
       // of a long utterance; a full sweep costs about a dozen frames of decoding).
       if (ok && (Uni(sh->tok_end) - Uni(sh->gc_tok) > u.tok_cap / 3 || Uni(sh->link_end) - Uni(sh->gc_link) > u.link_cap / 3)) {
-        ok = Compact(u, 0, t, sh);
+        ok = Compact(u, 0, t, p.keep_ac != 0, sh);
         if (threadIdx.x == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; }
         KhSync();
       }
@@ -2219,7 +2224,7 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
     if (threadIdx.x == 0) sh->conv_upto = last;
     PruneTokensForFrame(u, Uni(u.frame_b[0]), Uni(u.frame_e[0]));
     // final compaction of the window so the export below copies little
-    ok = Compact(u, last - WindowFrames(p), last, sh);
+    ok = Compact(u, last - WindowFrames(p), last, p.keep_ac != 0, sh);
     Stamp(u, sh, 8);
   }
   KhSync();
@@ -2333,10 +2338,13 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
       const int src = u.link_src[l], arc = u.link_arc[l];
       const KhInt4 rec = arc >= 0 ? p.rec[arc] : p.n_arcs[-1 - arc];   // labels: from the arc (3 % of the links survive to here)
       const int il = arc >= 0 ? p.unit_ilabel[arc] : 0;
-      float a = il != 0 ? u.link_a[l] : 0.0f;  // (not stored for an epsilon link)
+      float a = 0.0f;  // (an epsilon link has none)
       if (il != 0) {  // :168-174 the acoustic cost without the frame's cost_offset
         const int f = FrameOfToken(u, src, T);
-        a -= f < T ? u.cost_offset[f] : 0.0f;
+        const float co = f < T ? u.cost_offset[f] : 0.0f;
+        // ac_cost = cost_offset - loglike (:724-725): stored with the link, or evaluated again from the score matrix
+        a = p.keep_ac ? u.link_a[l] : (f < T ? co - u.ll[static_cast<size_t>(f) * u.ll_stride + rec.x] : 0.0f);
+        a -= co;
       }
       pool.l_src[d] = u.tmp_remap[src];
       pool.l_dst[d] = u.tmp_remap[dst];
@@ -3007,6 +3015,7 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
   // the score row shares the workgroup's 64 KB of LDS with the static block (Shared)
   p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
+  p.keep_ac = 1;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
@@ -3416,6 +3425,9 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
                    [&](int a, int b) { return d->h_T[a] > d->h_T[b]; });
   Params p;
   FillParams(d, &p, ll_stride, tid2pdf);
+  // the whole score matrix stays in place until the lattices are exported: the acoustic costs of the links
+  // are recomputed there instead of stored (KH_DECODER_KEEP_AC=1: stored, as the online decoder has to)
+  p.keep_ac = getenv("KH_DECODER_KEEP_AC") != nullptr && atoi(getenv("KH_DECODER_KEEP_AC")) != 0 ? 1 : 0;
   if ((rc = BuildArcPdf(d, &p, tid2pdf, ll_stride, Stream()))) return rc;
   if (!d->ev0) {
     KH_HIP(hipEventCreate(&d->ev0));
