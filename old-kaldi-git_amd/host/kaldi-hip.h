@@ -985,6 +985,30 @@ class LatticeFasterDecoder {
     words->resize(nw);
     return true;
   }
+  /// GetBestPath of utterances [first, first + n) in one library call: alignments / words row-concatenated,
+  /// *_offsets = n + 1 offsets into them, one cost pair per utterance
+  void GetBestPaths(int first, int n, std::vector<int32> *alignments, std::vector<int64_t> *alignment_offsets,
+                    std::vector<int32> *words, std::vector<int64_t> *word_offsets, std::vector<BaseFloat> *graph_costs,
+                    std::vector<BaseFloat> *acoustic_costs) const {
+    int64_t frames = 0;
+    for (int u = first; u < first + n; u++) {
+      KhDecodeStats st;
+      KhCheck(kh_decoder_get_counters(dec_, u, &st));
+      frames += st.num_frames + 16;
+    }
+    alignments->resize(static_cast<size_t>(frames) + 16);
+    words->resize(4 * static_cast<size_t>(frames) + 64);
+    alignment_offsets->resize(n + 1);
+    word_offsets->resize(n + 1);
+    graph_costs->resize(n);
+    acoustic_costs->resize(n);
+    float dummy = 0.f;   // (n == 0: valid pointers for the argument check)
+    KhCheck(kh_decoder_get_best_paths(dec_, first, n, alignments->data(), static_cast<int64_t>(alignments->size()),
+                                      alignment_offsets->data(), words->data(), static_cast<int64_t>(words->size()),
+                                      word_offsets->data(), n ? graph_costs->data() : &dummy, n ? acoustic_costs->data() : &dummy));
+    alignments->resize(static_cast<size_t>(alignment_offsets->back()));
+    words->resize(static_cast<size_t>(word_offsets->back()));
+  }
 
  private:
   LatticeFasterDecoder(const LatticeFasterDecoder &);

@@ -186,6 +186,13 @@ static void TestDecoder() {
   CHECK(words.size() == 1 && words[0] == 10);
   Near(g, 0.5f + 0.75f + 0.25f + 0.1f, 1e-6f);
   Near(a, 0.f, 1e-6f, 1e-6f);
+  {  // the batched accessor gives the same path
+    std::vector<int32> alis, wrds;
+    std::vector<int64_t> aoff, woff;
+    std::vector<float> gs, as;
+    dec.GetBestPaths(0, 1, &alis, &aoff, &wrds, &woff, &gs, &as);
+    CHECK(alis == ali && wrds == words && aoff.size() == 2 && aoff[1] == 3 && woff[1] == 1 && gs[0] == g && as[0] == a);
+  }
   RawLattice lat;
   CHECK(dec.GetRawLattice(0, &lat));
   CHECK(lat.state_frame.size() == 4 && lat.arc_src.size() == 3);
