@@ -2343,7 +2343,9 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
         const int f = FrameOfToken(u, src, T);
         const float co = f < T ? u.cost_offset[f] : 0.0f;
         // ac_cost = cost_offset - loglike (:724-725): stored with the link, or evaluated again from the score matrix
-        a = p.keep_ac ? u.link_a[l] : (f < T ? co - u.ll[static_cast<size_t>(f) * u.ll_stride + rec.x] : 0.0f);
+        int pdf = rec.x;
+        KH_BOUND(8, pdf, 0, u.ll_stride);
+        a = p.keep_ac ? u.link_a[l] : (f < T ? co - u.ll[static_cast<size_t>(f) * u.ll_stride + pdf] : 0.0f);
         a -= co;
       }
       pool.l_src[d] = u.tmp_remap[src];
