@@ -318,6 +318,20 @@ int kh_decoder_get_counters(const KhDecoder *dec, int utt, KhDecodeStats *stats)
  * next visit through memory.  All zero under KH_DECODER_PRUNE_SCHEDULE=interval (PruneActiveTokens every
  * prune_interval frames, lattice-faster-decoder.cc:88-89); the lattice is the same either way. */
 int kh_decoder_get_schedule_counters(const KhDecoder *dec, int utt, int32_t *counters);
+/* enable != 0: kh_decoder_decode reproduces the reference's own ITERATION ORDER, so that tokens and forward links are the
+ * ones LatticeFasterDecoder itself creates: ProcessEmitting prunes against the running next_cutoff
+ * (lattice-faster-decoder.cc:728-733) with the tokens in HashList order (util/hash-list-inl.h:118-147: buckets
+ * state % hash_size in order of first occupation, insertion order inside a bucket; hash_size as :37, :219-225), the best
+ * token of GetCutoff is the first minimum in that order (:599, :611), and the epsilon closure inserts in the order of its
+ * LIFO queue (:766-811).  Each utterance is decoded as by a freshly constructed decoder (hash_size 1000 at its start).
+ * enable == 0 (default): the order-independent resolution of those three places (DESIGN.md "Decoder parity": accept against
+ * the FINAL next_cutoff, ties to the smallest state id), which is what the reference computes whenever no token lies
+ * between the final and the running cutoff.  The environment variable KH_DECODER_ORDER=reference|canonical overrides. */
+int kh_decoder_set_reference_order(KhDecoder *dec, int enable);
+/* Search counters of utterance `utt` in the last kh_decoder_decode call (measurement aid): counters[0] = emitting
+ * candidates that were materialised (given a link slot: the rest of arcs_expanded were read and rejected),
+ * counters[1] = 1 if the call ran in reference order. */
+int kh_decoder_get_search_counters(const KhDecoder *dec, int utt, int64_t *counters);
 /* Duration of the decode kernel of the last kh_decoder_decode call, from HIP
  * events recorded on the launch stream (measurement aid; the reference wraps
  * every CuMatrix op in a Timer, cu-device.cc:384-389). */
@@ -326,12 +340,16 @@ int kh_decoder_last_kernel_ms(const KhDecoder *dec, float *ms);
  * kh_decoder_set_determinize is on) still needed after the decode kernel had finished: what the overlap with the
  * kernel did not hide (measurement aid). */
 int kh_decoder_last_host_tail_ms(const KhDecoder *dec, float *ms);
-/* fn(arg) is called by kh_decoder_decode on the calling thread right after the decode kernel has been launched and the
- * completion threads have been started (first launch of the call only), before it waits for either: the caller's turn
- * while the GPU decodes.  What a binary's main loop does there — nnet-latgen-faster.cc:139-160 would compute the NEXT
- * batch's log-likelihoods (kh_nnet_compute on the library's stream: they run after the decode kernel, under the
- * determinization of this batch's last lattices).  The scores of the batch being decoded must not be overwritten before
- * the kernel has read them: work enqueued on the library's stream is ordered after it.  fn = NULL: none (default). */
+/* fn(arg) is called by kh_decoder_decode on the calling thread, once per call, when the LAST decode kernel of the call has
+ * finished — i.e. no utterance is waiting to be decoded again after an arena / lattice-pool overflow, and nothing on the
+ * device will read the score matrix of this batch any more (offline decoding re-evaluates the acoustic cost of an exported
+ * link from it inside the kernel) — and BEFORE the call waits for its completion threads (raw lattices, best paths,
+ * determinization): the caller's turn while the host finishes the batch.  What a binary's main loop does there —
+ * nnet-latgen-faster.cc:139-160 would compute the NEXT batch's log-likelihoods (kh_nnet_compute on the library's stream),
+ * into the same score buffer if it likes.  The hook should return quickly (start the work, do not wait for it): the call's
+ * host tail is measured from before it.  Nothing of kh_decoder_decode waits for work the hook enqueues.  (Until round 4
+ * the hook fired right after the FIRST launch, which was wrong for a caller that reuses the score buffer when an utterance
+ * had to be decoded again.)  fn = NULL: none (default). */
 int kh_decoder_set_after_launch(KhDecoder *dec, void (*fn)(void *), void *arg);
 /* GetRawLattice (lattice-faster-decoder.cc:109-191), use_final_probs = true,
  * in canonical form: states are the surviving tokens sorted by

@@ -39,6 +39,11 @@ def synchronize():
     check(lib().kh_synchronize())
 
 
+def pool_release():
+    """Return the blocks cached by the library's device-memory pool to the driver (kh_pool_release)."""
+    check(lib().kh_pool_release())
+
+
 def select_gpu(ordinal):
     """CuDevice::SelectGpuId with explicit ordinal (cu-device.cc:93-192)."""
     check(lib().kh_select_gpu(int(ordinal)))
@@ -661,7 +666,7 @@ class LatticeFasterDecoder:
     DecodableMatrixScaledMapped-style decodable (decoder/decodable-matrix.h:33-84):
     loglikes[t, tid2pdf[ilabel]] already scaled."""
 
-    def __init__(self, fst, config=None, max_batch=256, max_frames=4096):
+    def __init__(self, fst, config=None, max_batch=256, max_frames=4096, exact_reference_order=False):
         self.fst = fst
         cfg = decoder_config() if config is None else config
         self.cfg = KhDecoderConfig(**cfg)
@@ -670,6 +675,19 @@ class LatticeFasterDecoder:
             raise KhError(lib().kh_last_error().decode())
         self._h = C.c_void_p(h)
         self.n_utts = 0
+        if exact_reference_order:
+            self.set_reference_order(True)
+
+    def set_reference_order(self, enable):
+        """True: the reference's own iteration order (running next_cutoff in HashList order, first-minimum ties, LIFO
+        closure insertions: include/kaldi_hip.h kh_decoder_set_reference_order) - tokens and links are the ones
+        LatticeFasterDecoder itself creates.  False (default): the order-independent rule."""
+        check(lib().kh_decoder_set_reference_order(self._h, int(bool(enable))))
+
+    def search_counters(self, utt=0):
+        c = (C.c_int64 * 2)()
+        check(lib().kh_decoder_get_search_counters(self._h, int(utt), c))
+        return dict(candidates_materialised=int(c[0]), reference_order=bool(c[1]))
 
     def __del__(self):
         try:
@@ -749,9 +767,10 @@ class LatticeFasterDecoder:
         return ms.value
 
     def set_after_launch(self, fn):
-        """fn() is called inside decode() right after the kernel launch, on the calling thread (the caller's turn while the
-        GPU decodes: e.g. the next batch's forward pass, which then runs under this batch's determinization).  None: off.
-        An exception raised by fn is re-raised by decode()."""
+        """fn() is called inside decode() when its LAST decode kernel has finished (nothing on the device reads this batch's
+        scores any more) and before decode() waits for its host threads, on the calling thread: the caller's turn while
+        the host finishes the batch - e.g. start the next batch's forward pass, which then runs under this batch's
+        determinization.  None: off.  An exception raised by fn is re-raised by decode()."""
         self._after_exc = None
         if fn is None:
             self._after_cb = None

@@ -126,6 +126,8 @@ SIGNATURES = {
     "kh_decoder_create": (vp, [vp, C.POINTER(KhDecoderConfig), C.c_int, C.c_int]),
     "kh_decoder_destroy": (None, [vp]),
     "kh_decoder_decode": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, vp]),
+    "kh_decoder_set_reference_order": (C.c_int, [vp, C.c_int]),
+    "kh_decoder_get_search_counters": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64)]),
     "kh_decoder_get_stats": (C.c_int, [vp, C.c_int, C.POINTER(KhDecodeStats)]),
     "kh_decoder_get_counters": (C.c_int, [vp, C.c_int, C.POINTER(KhDecodeStats)]),
     "kh_decoder_get_schedule_counters": (C.c_int, [vp, C.c_int, c_int32_p]),

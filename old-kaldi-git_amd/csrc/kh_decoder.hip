@@ -224,6 +224,23 @@ struct Utt {
   Arr<unsigned long long> hash;
   uint32_t hash_mask;
   GP(long long) phase_cycles;  // [16] diagnostic (KH_DECODER_PROFILE=1), else nullptr
+  // ---- exact reference order (Params::exact_order; carved only then).  [tok_frame_cap] unless noted.
+  Arr<int32_t> x_pos;      // frontier token (i - frame begin) -> its position in the reference's HashList order
+  Arr<uint32_t> x_m;       // by list position: Enc(min tot_cost + adaptive_beam) over the token's emitting arcs; after the scan the running next_cutoff BEFORE the token
+  Arr<int32_t> x_c;        // by list position: # emitting arcs expanded; after the scan their exclusive prefix sum (ordinal of the token's first candidate)
+  Arr<uint32_t> x_q;       // token of the frame under construction (i - nb) -> insertion key (order of HashList::Insert calls)
+  Arr<uint32_t> x_cost0;   // ... -> cost image before the epsilon closure
+  Arr<int32_t> x_bkt;      // ... -> HashList bucket (caller's state id % hash size)
+  Arr<int32_t> x_epsidx;   // ... -> index in tmp_epslist, or -1
+  Arr<int32_t> x_nl0; Arr<int32_t> x_nl1;   // closure replay, by tmp_epslist index: the token's epsilon link slots [l0, l1) relative to the block
+  Arr<float> x_ncost;      // closure replay: token cost as the replay proceeds
+  Arr<int32_t> x_ord;      // [link_frame_cap] candidate ordinal of a materialised emitting candidate; then the closure replay's link destination codes
+  Arr<float> x_lw;         // [link_frame_cap] closure replay: link weight
+  Arr<int32_t> x_stack;    // [link_frame_cap] closure replay: the LIFO queue (:766-811)
+  Arr<uint32_t> x_bmin;    // [x_hcap] HashList bucket -> smallest insertion key in it (all ones = empty: invariant between frames)
+  Arr<unsigned long long> x_key0; Arr<unsigned long long> x_key1;   // radix sort keys, double buffered
+  Arr<int32_t> x_val0; Arr<int32_t> x_val1;                         // radix sort payload
+  int32_t x_hcap;
 };
 
 struct Params {
@@ -245,6 +262,10 @@ struct Params {
   // token's extra_cost from scratch.  0: PruneActiveTokens every prune_interval frames as :88-89 (online decoding, whose
   // mid-utterance getters expose that state).
   int32_t lazy_prune;
+  // 1: the reference's iteration order is reproduced (HashList order, running next_cutoff, first-minimum tie, the LIFO
+  // order of the epsilon closure's insertions) - see "exact reference order" below; the kernels are instantiated for it
+  int32_t exact_order;
+  float hash_ratio;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
 };
@@ -331,6 +352,13 @@ struct Shared {
   int surv_nt, surv_nl; // FinalBackward: survivors listed so far (tokens, links)
   int map_n;            // FinalBackward: entries in the hand-off map (survivors of the frame just visited)
   int sched[4];         // lazy schedule, per utterance: garbage collections, dense / general final visits, hand-offs through memory
+  long long cand_mat;   // emitting candidates that got a link slot (materialised), per utterance
+  // exact reference order
+  uint32_t x_hsize;     // HashList::hash_size_ (:219-225: grows to hash_ratio x the frame's token count, never shrinks)
+  uint32_t x_qbase;     // first insertion key of the epsilon closure's insertions (> every emitting candidate's ordinal)
+  int x_ne_emit;        // end of the tokens the emitting pass created (the closure's follow)
+  int x_eps_emit;       // entries of tmp_epslist the emitting pass made
+  int x_n_new;          // closure replay: insertions counted
 };
 
 // Per-thread view of the workgroup state: the LDS block plus the (uniform)
@@ -793,7 +821,9 @@ struct Cutoff {
   int best_tok, count;
 };
 
-// GetCutoff :591-658 over the tokens [b, e) of the current frame.
+// GetCutoff :591-658 over the tokens [b, e) of the current frame.  kExact: the best token on a tie is the FIRST one
+// in the reference's list order (the strict '<' of :599 / :611), else the one with the smallest state id (rule B).
+template <bool kExact = false>
 __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh) {
   Cutoff c;
   const int n = e - b;
@@ -804,7 +834,8 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   for (int i = b + threadIdx.x; i < e; i += NT) {
     // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
     const uint32_t enc = LoadCostEnc(&u.tok_cost[i]);
-    const unsigned long long key = (static_cast<unsigned long long>(enc) << 32) | static_cast<uint32_t>(u.tok_state[i]);
+    const unsigned long long key = (static_cast<unsigned long long>(enc) << 32) |
+                                   static_cast<uint32_t>(kExact ? u.x_pos[i - b] : u.tok_state[i]);
     if (key < best) { best = key; best_i = i; }
     kmax = enc > kmax ? enc : kmax;
   }
@@ -1120,6 +1151,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     u.femit_e[frame] = link_frame_e;
     sh->link_end = link_frame_e;
     sh->front_b = nb;
+    sh->cand_mat += link_frame_e - link_frame_b;
   }
   KhSync();
 
@@ -1337,6 +1369,664 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   *next_cutoff_out = next_cutoff;
   return Uni(sh->status) == 0;
 }
+
+// ================================================================ exact reference order
+// Params::exact_order (kh_decoder_set_reference_order): the search of LatticeFasterDecoder with the reference's OWN
+// iteration order, so that the token and link sets equal the reference's bit for bit (oracle mode 0), not only the
+// order-independent resolution (mode 3).  What depends on the order (DESIGN.md "Decoder parity"):
+//   (1) ProcessEmitting accepts an arc iff tot_cost <= the RUNNING next_cutoff (:728-733), i.e. the minimum of the
+//       estimate from the best token (:688-705) and of tot_cost + adaptive_beam over the arcs visited BEFORE it, tokens in
+//       the order of the HashList's list (hash-list-inl.h:118-147), arcs in arc order;
+//   (2) GetCutoff's best token is the first minimum in that order (:599, :611);
+//   (3) the list order of the next frame = buckets (state % hash_size) in the order of their first occupation, elements
+//       of a bucket in insertion order; insertions = the accepted arcs in visiting order, then the insertions of
+//       ProcessNonemitting's LIFO queue (:766-811) in the order that queue makes them; hash_size follows :219-225.
+// How it is computed here:
+//   * every frontier token carries its list position (x_pos).  A first sweep over the emitting arcs reduces, per token,
+//     min(tot_cost) (x_m, by list position) and the arc count (x_c); ONE scan in list order turns them into the running
+//     cutoff in front of the token and the ordinal of its first arc; the second sweep accepts arc k of a token against
+//     min(that, the token's earlier arcs) - a segmented prefix minimum inside the wave - and materialises only what the
+//     reference would, each candidate with its ordinal;
+//   * the LDS token table of pass 2 keeps, per new state, the minimum cost AND the minimum ordinal = its insertion key;
+//   * the epsilon closure runs as the parallel fixed point it always was (costs, token set and links do not depend on the
+//     order), and the ORDER of its insertions is then replayed by one lane over the frame's epsilon links only (a few
+//     hundred pops per frame on an HCLG), from LDS;
+//   * bucket minima (one atomicMin per token into a table of hash_size words), the key (first occupation of the bucket,
+//     insertion key) and one stable radix sort give the next frame's list positions.
+// The backward pruning needs no order: the lattice FinalizeDecoding returns does not depend on the sweep order or on
+// delta (Params::lazy_prune explains why; tests hold oracle mode 0 against mode 2 on thousands of random cases).
+// hash_size starts at 1000 for every utterance (a freshly constructed decoder, lattice-faster-decoder.cc:37).
+
+// Workgroup exclusive scan of (sum, min) pairs: ONE barrier.
+__device__ __forceinline__ void BlockExScanSumMin(int v, uint32_t m, int *ex_sum, uint32_t *ex_min, int *tot_sum, uint32_t *tot_min, Blk &sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+  uint32_t im = m;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(inc, o, 64);
+    const uint32_t nm = static_cast<uint32_t>(__shfl_up(static_cast<int>(im), o, 64));
+    if (lane >= o) {
+      inc += n;
+      im = nm < im ? nm : im;
+    }
+  }
+  const int b1 = (sh.k_scan++) & 1, b2 = (sh.k_red++) & 1;
+  if (lane == 63) {
+    sh->wsum[b1][w] = inc;
+    sh->wred[b2][w] = im;
+  }
+  uint32_t pm = static_cast<uint32_t>(__shfl_up(static_cast<int>(im), 1, 64));
+  if (lane == 0) pm = 0xFFFFFFFFu;
+  KhSync();
+  int before = 0, all = 0;
+  uint32_t bm = 0xFFFFFFFFu, am = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    const int t = sh->wsum[b1][i];
+    const uint32_t tm = static_cast<uint32_t>(sh->wred[b2][i]);
+    if (i < w) {
+      before += t;
+      bm = tm < bm ? tm : bm;
+    }
+    all += t;
+    am = tm < am ? tm : am;
+  }
+  bm = Uni(bm);
+  *ex_sum = Uni(before) + inc - v;
+  *ex_min = pm < bm ? pm : bm;
+  *tot_sum = Uni(all);
+  *tot_min = Uni(am);
+}
+
+// Stable LSD radix sort of the n (key, value) pairs in (x_key0, x_val0) by the low `bits` bits of each 32-bit half of the
+// key (the other bits are zero by construction), 9 bits per pass.  Per pass: per-wave digit histograms in LDS (over the
+// idle token-table area), one scan in (digit, wave) order, and a scatter in which the lanes of a tile that hold the same
+// digit find each other with ballots (rank = lanes before me with my digit).  Waves own contiguous segments and walk
+// them in order, so the sort is stable.  Returns 0 / 1: the buffer pair that holds the result.
+constexpr int kSortBits = 9;
+static_assert(NW * (1 << kSortBits) <= kLdsSlots, "per-wave digit histograms fit the LDS token-table area");
+__device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
+  auto hist = LdsKeys(sh);   // [NW][1 << kSortBits]
+  constexpr int kBins = 1 << kSortBits;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seg = ((n + NW - 1) / NW + 63) & ~63;
+  const int s0 = min(n, w * seg), s1 = min(n, s0 + seg);
+  int cur = 0;
+  for (int half = 0; half < 2; half++) {
+    for (int sb = 0; sb < bits; sb += kSortBits) {
+      const int shift = half * 32 + sb;
+      const Arr<const unsigned long long> kin = cur ? u.x_key1 : u.x_key0;
+      const Arr<const int32_t> vin = cur ? u.x_val1 : u.x_val0;
+      const Arr<unsigned long long> kout = cur ? u.x_key0 : u.x_key1;
+      const Arr<int32_t> vout = cur ? u.x_val0 : u.x_val1;
+      for (int i = threadIdx.x; i < NW * kBins; i += NT) hist[i] = 0u;
+      LdsSync();
+      for (int i = s0 + lane; i < s1; i += 64) {
+        const uint32_t d = static_cast<uint32_t>(kin[i] >> shift) & (kBins - 1);
+        __hip_atomic_fetch_add(&hist[w * kBins + d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      LdsSync();
+      {  // exclusive scan in (digit, wave) order: entry idx = digit * NW + wave; a lane owns NW * kBins / NT consecutive entries
+        constexpr int kPer = NW * kBins / NT;
+        static_assert(kPer * NT == NW * kBins, "entries per lane");
+        uint32_t c[kPer];
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+          const int idx = threadIdx.x * kPer + j;
+          c[j] = hist[(idx % NW) * kBins + idx / NW];
+          mine += static_cast<int>(c[j]);
+        }
+        int total;
+        int run = BlockExScan<true>(mine, &total, sh);
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+          const int idx = threadIdx.x * kPer + j;
+          hist[(idx % NW) * kBins + idx / NW] = static_cast<uint32_t>(run);
+          run += static_cast<int>(c[j]);
+        }
+      }
+      LdsSync();
+      for (int base = s0; base < s1; base += 64) {   // (uniform over the wave)
+        const int i = base + lane;
+        const bool act = i < s1;
+        const unsigned long long key = act ? kin[i] : 0ull;
+        const int32_t val = act ? vin[i] : 0;
+        const uint32_t d = static_cast<uint32_t>(key >> shift) & (kBins - 1);
+        unsigned long long peers = __ballot(act);
+#pragma unroll
+        for (int bit = 0; bit < kSortBits; bit++) {
+          const bool set = ((d >> bit) & 1u) != 0u;
+          const unsigned long long m = __ballot(set);
+          peers &= set ? m : ~m;
+        }
+        if (act) {
+          const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+          const uint32_t at = hist[w * kBins + d];
+          if (rank == 0) hist[w * kBins + d] = at + static_cast<uint32_t>(__popcll(peers));
+          kout[at + rank] = key;
+          vout[at + rank] = val;
+        }
+      }
+      KhSync();   // the scattered pairs are the next pass's input
+      cur ^= 1;
+    }
+  }
+  return cur;
+}
+
+// The LIFO queue of ProcessNonemitting (:766-811) replayed by ONE lane over the frame's epsilon links: which insertion
+// comes when.  ncost: cost of the tokens with epsilon arcs (index = entry of tmp_epslist; +inf = not inserted yet), nl0 /
+// nl1: their link slots, lcode: destination of a link slot (-1 dead or without effect on the order; an entry of
+// tmp_epslist; 0x40000000 | (token - nb) for a token without epsilon arcs that the closure creates), lw: arc weight.
+// Only tokens with epsilon arcs are pushed (popping another one is a no-op in the reference).  Returns the number of
+// insertions, or -1 when the queue outgrew its arrays.
+template <class FP, class IP>
+__device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack_lo, int lo_cap, const Utt &u, int top,
+                             float cutoff, int nb, uint32_t qbase) {
+  int cnt = 0;
+  const int hi_cap = u.link_frame_cap;
+  while (top > 0) {
+    --top;
+    const int uu = top < lo_cap ? stack_lo[top] : u.x_stack[top - lo_cap];
+    const float c = ncost[uu];
+    if (c > cutoff) continue;   // :779
+    const int l1 = nl1[uu];
+    for (int l = nl0[uu]; l < l1; l++) {
+      const int code = lcode[l];
+      if (code < 0) continue;
+      const float tot = c + lw[l];
+      if (!(tot < cutoff)) continue;   // :794
+      if ((code & 0x40000000) != 0) {
+        const int k = code & 0x3fffffff;
+        if (u.x_q[k] == 0xFFFFFFFFu) u.x_q[k] = qbase + static_cast<uint32_t>(cnt++);   // FindOrAddToken inserts it; changed, pushed, popped without effect
+      } else {
+        const float cv = ncost[code];
+        bool push = false;
+        if (cv == INFINITY) {   // new: inserted, changed
+          u.x_q[u.tmp_epslist[code] - nb] = qbase + static_cast<uint32_t>(cnt++);
+          push = true;
+        } else if (tot < cv) {  // :252-254 cheaper: changed
+          push = true;
+        }
+        if (push) {
+          ncost[code] = tot;
+          if (top < lo_cap) stack_lo[top] = code;
+          else if (top - lo_cap < hi_cap) u.x_stack[top - lo_cap] = code;
+          else return -1;
+          top++;
+        }
+      }
+    }
+  }
+  return cnt;
+}
+
+// List positions (x_pos) of the frame under construction, tokens [nb, fe): the emitting pass made [nb, ne_emit) with
+// their insertion keys in x_q and their costs in x_cost0; the closure has converged and the frame's epsilon links are
+// the block [lb, le).  Leaves x_bmin all ones.  Returns false on a capacity overflow (sh->status).
+__device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
+  const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
+  const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
+  const int nl = le - lb;
+  // buckets; first occupation among the emitting pass's tokens; closure replay tables
+  for (int i = nb + threadIdx.x; i < fe; i += NT) {
+    const int32_t sid = -1 - p.unit_ilabel[u.tok_state[i]];   // the caller's state id (what the reference hashes)
+    const int32_t bk = static_cast<int32_t>(static_cast<uint32_t>(sid) % H);
+    u.x_bkt[i - nb] = bk;
+    u.x_epsidx[i - nb] = -1;
+    if (i < ne_emit) __hip_atomic_fetch_min(&u.x_bmin[bk], u.x_q[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else u.x_q[i - nb] = 0xFFFFFFFFu;
+  }
+  KhSync();
+  for (int j = threadIdx.x; j < eps_n; j += NT) {
+    const int tok = u.tmp_epslist[j];
+    u.x_epsidx[tok - nb] = j;
+    u.x_nl0[j] = 0;
+    u.x_nl1[j] = 0;
+    u.x_ncost[j] = tok < ne_emit ? Dec(u.x_cost0[tok - nb]) : INFINITY;
+    if (j < eps_emit) {   // (the first eps_emit entries are the emitting pass's: the queue's initial content, :766-767)
+      u.x_key0[j] = (static_cast<unsigned long long>(__hip_atomic_load(&u.x_bmin[u.x_bkt[tok - nb]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) |
+                    u.x_q[tok - nb];
+      u.x_val0[j] = j;
+    }
+  }
+  KhSync();
+  for (int l = lb + threadIdx.x; l < le; l += NT) {
+    const int src = u.link_src[l], dst = u.link_dst[l];
+    const int j = u.x_epsidx[src - nb];
+    if (l == lb || u.link_src[l - 1] != src) u.x_nl0[j] = l - lb;
+    if (l + 1 == le || u.link_src[l + 1] != src) u.x_nl1[j] = l - lb + 1;
+    int code = -1;
+    if (dst >= 0) {
+      const int e = u.x_epsidx[dst - nb];
+      if (e >= 0) code = e;
+      else if (dst >= ne_emit) code = 0x40000000 | (dst - nb);
+    }
+    u.x_ord[l - lb] = code;
+    u.x_lw[l - lb] = __int_as_float(p.n_arcs[-1 - u.link_arc[l]].z);
+  }
+  const int bits = 32 - __clz(static_cast<int>(qbase + static_cast<uint32_t>(fe - ne_emit)) | 1);
+  const int sb = eps_emit > 1 ? BlockRadixSort(u, eps_emit, bits, sh) : 0;   // (its first barrier orders the writes above)
+  KhSync();
+  const Arr<const int32_t> sorted = sb ? u.x_val1 : u.x_val0;
+  // ---- closure replay from LDS when the frame's epsilon structure fits (it nearly always does), else from memory
+  constexpr int kNodeCap = kLdsSlots / 4, kLinkCap = kLdsSlots / 2;
+  const bool in_lds = eps_n <= kNodeCap && nl <= kLinkCap;   // (the dynamic LDS block holds at least kLdsSlots words: DynLdsBytes)
+  auto l_ncost = (__attribute__((address_space(3))) float *)LdsKeys(sh);
+  auto l_nl0 = (__attribute__((address_space(3))) int *)(LdsKeys(sh) + kNodeCap);
+  auto l_nl1 = (__attribute__((address_space(3))) int *)(LdsKeys(sh) + 2 * kNodeCap);
+  auto l_stack = (__attribute__((address_space(3))) int *)(LdsKeys(sh) + 3 * kNodeCap);
+  auto l_code = (__attribute__((address_space(3))) int *)LdsVals(sh);
+  auto l_lw = (__attribute__((address_space(3))) float *)(LdsVals(sh) + kLinkCap);
+  if (in_lds) {
+    for (int j = threadIdx.x; j < eps_n; j += NT) {
+      l_ncost[j] = u.x_ncost[j];
+      l_nl0[j] = u.x_nl0[j];
+      l_nl1[j] = u.x_nl1[j];
+    }
+    for (int j = threadIdx.x; j < eps_emit; j += NT) l_stack[j] = sorted[j];
+    for (int l = threadIdx.x; l < nl; l += NT) {
+      l_code[l] = u.x_ord[l];
+      l_lw[l] = u.x_lw[l];
+    }
+  } else {
+    for (int j = threadIdx.x; j < eps_emit; j += NT) u.x_stack[j] = sorted[j];
+  }
+  KhSync();
+  if (threadIdx.x == 0) {
+    int cnt;
+    if (in_lds) cnt = ReplayClosure(l_ncost, l_nl0, l_nl1, l_code, l_lw, l_stack, kNodeCap, u, eps_emit, cutoff, nb, qbase);
+    else cnt = ReplayClosure((GP(float))u.x_ncost.p, (GP(int32_t))u.x_nl0.p, (GP(int32_t))u.x_nl1.p, (GP(int32_t))u.x_ord.p, (GP(float))u.x_lw.p,
+                             (GP(int32_t))u.x_stack.p, 0, u, eps_emit, cutoff, nb, qbase);
+    // every token the closure created was inserted by the replay (the parallel fixed point and the queue reach the same set)
+    if (cnt != fe - ne_emit) sh->status = cnt < 0 ? 3 : 8;
+    sh->x_n_new = cnt;
+  }
+  KhSync();
+  if (Uni(sh->status) != 0) return false;
+  // ---- the closure's tokens enter their buckets; key = (first occupation of the bucket, insertion key); sort
+  for (int i = ne_emit + threadIdx.x; i < fe; i += NT)
+    __hip_atomic_fetch_min(&u.x_bmin[u.x_bkt[i - nb]], u.x_q[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  KhSync();
+  for (int i = threadIdx.x; i < n; i += NT) {
+    u.x_key0[i] = (static_cast<unsigned long long>(__hip_atomic_load(&u.x_bmin[u.x_bkt[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) | u.x_q[i];
+    u.x_val0[i] = i;
+  }
+  KhSync();
+  for (int i = threadIdx.x; i < n; i += NT) u.x_bmin[u.x_bkt[i]] = 0xFFFFFFFFu;   // the table's invariant between frames
+  const int fb2 = n > 1 ? BlockRadixSort(u, n, bits, sh) : 0;
+  KhSync();
+  const Arr<const int32_t> order = fb2 ? u.x_val1 : u.x_val0;
+  for (int r = threadIdx.x; r < n; r += NT) u.x_pos[order[r]] = r;
+  KhSync();
+  return true;
+}
+
+// ProcessEmitting :660-750 with the reference's running cutoff (see above).  Tokens [b, e) with list positions x_pos.
+__device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, int b, int e, float *next_cutoff_out, Blk &sh) {
+  const int nb = Uni(sh->tok_end);  // first token of frame + 1
+  const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
+  const int n = e - b;
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }
+  for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
+  Stamp(u, sh, 15);
+  const Cutoff c = GetCutoff<true>(u, p, b, e, sh);
+  Stamp(u, sh, 0);
+  if (threadIdx.x == 0) {
+    if (c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
+    // PossiblyResizeHash(tok_cnt) :219-225
+    const uint32_t new_sz = static_cast<uint32_t>(static_cast<float>(c.count) * p.hash_ratio);
+    if (new_sz > sh->x_hsize) sh->x_hsize = new_sz;
+  }
+  const float inf = INFINITY;
+  float cost_offset = 0.0f;
+  float est = inf;
+  if (c.best_tok >= 0) {
+    cost_offset = -c.best_cost;  // :691
+    const int32_t s = u.tok_state[c.best_tok];
+    const float tot = c.best_cost;
+    const int ab = s + 1, ae = ab + p.rec[s].x;
+    for (int a = ab + threadIdx.x; a < ae; a += NT) {   // :692-704
+      const KhInt4 arc = p.rec[a];
+      const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
+      const float new_weight = w + tot;
+      est = fminf(est, new_weight + c.adaptive_beam);
+    }
+  }
+  if (threadIdx.x == 0) {
+    u.cost_offset[frame] = cost_offset;  // :710-711
+    sh->work_cursor = b;
+  }
+  const float est0 = BlockMinF(est, sh);   // (its barrier publishes the cursor)
+  const int lane = threadIdx.x & 63;
+  long long my_arcs = 0;
+  // ---- sweep 1: per token, min tot_cost over its emitting arcs and their number, by list position
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(&sh->work_cursor, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = Uni(base);
+    if (base >= e) break;
+    const int i = base + lane;
+    const bool in_range = i < e;
+    const int ic = min(i, e - 1);
+    const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
+    int st = u.tok_state[ic];
+    KH_BOUND(1, st, 0, 0x7ffffff0);
+    const bool need = in_range && Dec(co) <= c.cur_cutoff;
+    int ab = 0, cnt = 0;
+    if (need) {
+      ab = st + 1;
+      cnt = p.rec[st].x;
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int nn = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += nn;
+    }
+    const int loff = inc - cnt;
+    const int total = __shfl(inc, 63, 64);
+    float acc = inf;
+    for (int q0 = 0; q0 < total; q0 += 64) {
+      const int q = q0 + lane;
+      const bool valid = q < total;
+      int lo = 0, hi = 63;
+#pragma unroll
+      for (int step = 0; step < 6; step++) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int v = __shfl(loff, mid, 64);
+        if (v <= q) lo = mid; else hi = mid - 1;
+      }
+      const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64);
+      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      float m = inf;
+      if (valid) {
+        const KhInt4 arc = p.rec[o_ab + (q - o_off)];
+        int32_t pdf = arc.x;
+        KH_BOUND(7, pdf, 0, u.ll_stride);
+        const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
+        const float ac = cost_offset - like;
+        m = Dec(o_co) + ac + __int_as_float(arc.z);  // :726-730
+      }
+      // inclusive minimum over the lanes of the same token (the lanes of a token are consecutive)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float nm = __shfl_up(m, o, 64);
+        const int nlo = __shfl_up(lo, o, 64);
+        if (lane >= o && nlo == lo) m = fminf(m, nm);
+      }
+      // the token's lane fetches the value at the last of its arcs in this batch
+      const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
+      const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
+      const float got = __shfl(m, has ? tail : 0, 64);
+      if (has) acc = fminf(acc, got);
+    }
+    if (in_range) {
+      const int pos = u.x_pos[i - b];
+      u.x_m[pos] = Enc(acc + c.adaptive_beam);   // (+inf for a token without arcs or above the cutoff)
+      u.x_c[pos] = cnt;
+    }
+    if (lane == 0) my_arcs += total;
+  }
+  KhSync();
+  // ---- ONE scan in list order: the running next_cutoff in front of every token (it starts at the estimate) and the
+  // ordinal of its first arc
+  uint32_t run_min = Enc(est0);
+  int run_sum = 0;
+  for (int base = 0; base < n; base += NT) {
+    const int q = base + threadIdx.x;
+    const bool valid = q < n;
+    const uint32_t m = valid ? u.x_m[q] : 0xFFFFFFFFu;
+    const int cnt = valid ? u.x_c[q] : 0;
+    int ex_sum, tot_sum;
+    uint32_t ex_min, tot_min;
+    BlockExScanSumMin(cnt, m, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
+    if (valid) {
+      u.x_m[q] = run_min < ex_min ? run_min : ex_min;
+      u.x_c[q] = run_sum + ex_sum;
+    }
+    run_min = run_min < tot_min ? run_min : tot_min;
+    run_sum += tot_sum;
+  }
+  const float next_cutoff = Dec(run_min);   // the value the running cutoff ends at
+  Stamp(u, sh, 1);
+  // ---- sweep 2: accept arc k of a token against min(running cutoff in front of the token, its arcs before k), in
+  // arc order (:728-733); only accepted candidates are materialised, each with its ordinal
+  const int link_frame_b = Uni(sh->link_end);
+  const int limit = min(u.link_cap, link_frame_b + u.link_frame_cap);
+  if (threadIdx.x == 0) {
+    sh->link_cursor = link_frame_b;
+    sh->work_cursor = b;
+    sh->x_qbase = static_cast<uint32_t>(run_sum);
+  }
+  KhSync();
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(&sh->work_cursor, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = Uni(base);
+    if (base >= e) break;
+    const int i = base + lane;
+    const bool in_range = i < e;
+    const int ic = min(i, e - 1);
+    const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
+    int st = u.tok_state[ic];
+    KH_BOUND(1, st, 0, 0x7ffffff0);
+    const bool need = in_range && Dec(co) <= c.cur_cutoff;
+    int ab = 0, cnt = 0;
+    if (need) {
+      ab = st + 1;
+      cnt = p.rec[st].x;
+    }
+    const int pos = u.x_pos[ic - b];
+    const float r_tok = Dec(u.x_m[pos]);
+    const int a_tok = u.x_c[pos];
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int nn = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += nn;
+    }
+    const int loff = inc - cnt;
+    const int total = __shfl(inc, 63, 64);
+    float acc = inf;   // min(tot_cost + adaptive_beam) over this token's arcs in the batches before the current one
+    for (int q0 = 0; q0 < total; q0 += 64) {
+      const int q = q0 + lane;
+      const bool valid = q < total;
+      int lo = 0, hi = 63;
+#pragma unroll
+      for (int step = 0; step < 6; step++) {
+        const int mid = (lo + hi + 1) >> 1;
+        const int v = __shfl(loff, mid, 64);
+        if (v <= q) lo = mid; else hi = mid - 1;
+      }
+      const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64), o_a = __shfl(a_tok, lo, 64);
+      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      const float o_r = __shfl(r_tok, lo, 64), o_acc = __shfl(acc, lo, 64);
+      KhInt4 arc;
+      arc.x = 0; arc.y = 0; arc.z = 0; arc.w = 0;
+      float tot = inf, ac = 0.0f;
+      const int ai = o_ab + (q - o_off);
+      if (valid) {
+        arc = p.rec[ai];
+        int32_t pdf = arc.x;
+        KH_BOUND(7, pdf, 0, u.ll_stride);
+        const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
+        ac = cost_offset - like;
+        tot = Dec(o_co) + ac + __int_as_float(arc.z);  // :726-730
+      }
+      float m = tot + c.adaptive_beam;   // what this arc lowers next_cutoff to (:732-733)
+      if (!(m == m)) m = inf;            // (a NaN never lowers it)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float nm = __shfl_up(m, o, 64);
+        const int nlo = __shfl_up(lo, o, 64);
+        if (lane >= o && nlo == lo) m = fminf(m, nm);
+      }
+      const float pm = __shfl_up(m, 1, 64);
+      const int plo = __shfl_up(lo, 1, 64);
+      const float before = (lane >= 1 && plo == lo) ? pm : inf;
+      const float running = fminf(fminf(o_r, o_acc), before);
+      const bool keep = valid && !(tot > running) && tot == tot;   // :731 (a NaN candidate is dropped, as in the canonical rule)
+      const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
+      const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
+      const float got = __shfl(m, has ? tail : 0, 64);
+      if (has) acc = fminf(acc, got);
+      const unsigned long long kb = __ballot(keep);
+      if (kb != 0ull) {
+        const int n_keep = __popcll(kb);
+        int at = 0;
+        if (lane == 0) at = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        at = Uni(at);
+        if (at + n_keep > limit) {
+          if (lane == 0) sh->status = (at + n_keep > u.link_cap) ? 2 : 3;
+        } else if (keep) {
+          const int l = at + __popcll(kb & ((1ull << lane) - 1ull));
+          u.link_dst[l] = -2 - arc.w;
+          u.link_src[l] = base + lo;
+          u.link_arc[l] = ai;
+          if (p.keep_ac) u.link_a[l] = ac;
+          u.link_k[l] = tot;
+          u.x_ord[l - link_frame_b] = o_a + (q - o_off);
+        }
+      }
+    }
+  }
+  KhSync();
+  if (Uni(sh->status) != 0) return false;
+  const int link_frame_e = Uni(sh->link_cursor);
+  if (threadIdx.x == 0) {
+    u.femit_b[frame] = link_frame_b;
+    u.femit_e[frame] = link_frame_e;
+    sh->link_end = link_frame_e;
+    sh->front_b = nb;
+    sh->cand_mat += link_frame_e - link_frame_b;
+  }
+  KhSync();
+  // ---- pass 2: FindOrAddToken + minimum cost + minimum ordinal (= the state's insertion key) in an LDS table of
+  // kXSlots slots: keys | ordinals over the static area, costs over the dynamic one.  Every candidate here is accepted.
+  {
+    constexpr int kXSlots = kLdsSlots / 2;
+    static_assert(kXSlots % NT == 0, "slots per lane");
+    auto keys = LdsKeys(sh);
+    auto ords = LdsKeys(sh) + kXSlots;
+    auto vals = LdsVals(sh);
+    constexpr int kLocBits = KH_LOC_BITS, kLocShift = KH_LOC_SHIFT;
+    auto part_of = [](uint32_t h, int parts) { return static_cast<int>(((h >> 12) * static_cast<uint32_t>(parts)) >> 20); };
+    auto lds_slot = [](uint32_t h, int32_t ns) {
+      return ((h << kLocBits) | ((static_cast<uint32_t>(ns) >> kLocShift) & ((1u << kLocBits) - 1u))) & (kXSlots - 1);
+    };
+    int parts = 1;
+    while (parts * (KH_PART_CAND / 2) < link_frame_e - link_frame_b) parts *= 2;
+    for (int k = 0; k < parts; k++) {
+      for (int i = threadIdx.x; i < kXSlots; i += NT) { keys[i] = 0u; ords[i] = 0xFFFFFFFFu; vals[i] = 0xFFFFFFFFu; }
+      if (threadIdx.x == 0) sh->flag = 0;
+      KhSync();
+      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
+        const int32_t nsv = u.link_dst[l];
+        if (nsv >= -1) continue;   // resolved by an earlier part
+        const int32_t ns = -2 - nsv;
+        const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
+        if (part_of(h, parts) != k) continue;
+        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+        uint32_t slot = lds_slot(h, ns);
+        const uint32_t step = ((h >> 9) | 1u) << kLocBits;
+        int probes = 0;
+        for (; probes < 256; probes++) {
+          uint32_t seen = 0u;
+          __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (seen == 0u || seen == key) break;
+          slot = (slot + step) & (kXSlots - 1);
+        }
+        if (probes == 256) { sh->flag = 1; continue; }
+        (void)__hip_atomic_fetch_min(&vals[slot], Enc(u.link_k[l]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        (void)__hip_atomic_fetch_min(&ords[slot], static_cast<uint32_t>(u.x_ord[l - link_frame_b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      KhSync();
+      if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
+        KhSync();
+        if (parts >= (1 << 20)) {
+          if (threadIdx.x == 0) sh->status = 5;
+          KhSync();
+          return false;
+        }
+        parts *= 2;
+        k = 2 * k - 1;
+        continue;
+      }
+      const int tok_base = Uni(sh->tok_end);
+      int occ[kXSlots / NT], off[kXSlots / NT], total;
+#pragma unroll
+      for (int j = 0; j < kXSlots / NT; j++) occ[j] = keys[threadIdx.x + j * NT] != 0u ? 1 : 0;
+      BlockExScanK<kXSlots / NT>(occ, off, &total, sh);
+      if (tok_base + total > tok_limit) {
+        if (threadIdx.x == 0) sh->status = 1;
+        KhSync();
+        return false;
+      }
+#pragma unroll
+      for (int j = 0; j < kXSlots / NT; j++) {
+        if (!occ[j]) continue;
+        const int i = threadIdx.x + j * NT;
+        const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
+        const int idx = tok_base + off[j];
+        u.tok_state[idx] = ns & kStateMask;
+        u.tok_cost[idx] = vals[i];
+        u.tok_extra[idx] = 0.0f;
+        u.x_q[idx - nb] = ords[i];
+        u.x_cost0[idx - nb] = vals[i];
+        vals[i] = static_cast<uint32_t>(idx);
+        if ((ns & kHasEps) != 0) {
+          u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+          u.tmp_dirty[idx - nb] = 1;
+        }
+        int32_t gslot = -1;
+        if ((ns & kEpsDst) != 0) {
+          const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
+                                          (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
+          uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
+          for (int probes = 0; probes < (1 << 30); probes++) {
+            unsigned long long ent = kEmpty;
+            __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ent == kEmpty) break;
+            g = (g + 1) & u.hash_mask;
+          }
+          gslot = static_cast<int32_t>(g);
+        }
+        u.tmp_slot[idx - nb] = gslot;
+      }
+      if (threadIdx.x == 0) sh->tok_end = tok_base + total;
+      KhSync();
+      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
+        const int32_t nsv = u.link_dst[l];
+        if (nsv >= -1) continue;
+        const int32_t ns = -2 - nsv;
+        const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
+        if (part_of(h, parts) != k) continue;
+        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+        uint32_t slot = lds_slot(h, ns);
+        const uint32_t step = ((h >> 9) | 1u) << kLocBits;
+        while (keys[slot] != key) slot = (slot + step) & (kXSlots - 1);
+        u.link_dst[l] = static_cast<int32_t>(vals[slot]);
+      }
+      KhSync();
+    }
+  }
+  KhSync();
+  const long long tot_arcs = BlockSumLL(my_arcs, sh);
+  if (threadIdx.x == 0) {
+    sh->arcs_expanded += tot_arcs;
+    sh->wl_n[0] = sh->eps_n;
+    sh->x_eps_emit = sh->eps_n;
+    sh->x_ne_emit = sh->tok_end;
+  }
+  KhSync();
+  Stamp(u, sh, 2);
+  *next_cutoff_out = next_cutoff;
+  return Uni(sh->status) == 0;
+}
+
 
 // ---------------------------------------------------------------- pruning
 // PruneForwardLinks walks LINKS, not tokens: one lane per link slot (coalesced,
@@ -2312,6 +3002,7 @@ struct Run {
 __device__ __forceinline__ int WindowFrames(const Params &p) { return (KH_COMPACT_EVERY + 1) * (p.prune_interval > 25 ? p.prune_interval : 25); }
 
 // InitDecoding :55-72 on a slot whose arenas hold their invariants.
+template <bool kExact = false>
 __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   if (threadIdx.x == 0) {
     sh->tok_end = 0;
@@ -2326,6 +3017,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->gc_link = 0;
     sh->surv_nt = 0;
     sh->surv_nl = 0;
+    sh->cand_mat = 0;
     for (int i = 0; i < 4; i++) sh->sched[i] = 0;
   }
   for (int f = threadIdx.x; f < u.T + 2; f += NT) {
@@ -2340,9 +3032,18 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     u.frame_b[0] = idx;
     sh->wl_n[0] = sh->eps_n;  // 1 if the start state has epsilon arcs: the closure's first work list
     sh->wl_n[1] = 0;
+    if (kExact) {   // the start token is the first insertion (:66) into a table of 1000 buckets (:37)
+      u.x_q[0] = 0u;
+      u.x_cost0[0] = Enc(0.0f);
+      sh->x_hsize = 1000u;
+      sh->x_qbase = 1u;
+      sh->x_ne_emit = sh->tok_end;
+      sh->x_eps_emit = sh->eps_n;
+    }
   }
   KhSync();
-  const bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
+  bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
+  if (kExact && ok) ok = OrderFrontier(u, p, 0, Uni(sh->tok_end), Uni(u.feps_b[0]), Uni(u.feps_e[0]), p.beam, sh);
   run->t = 0;
   run->fb = 0;  // token range of the frontier frame
   run->fe = Uni(sh->tok_end);
@@ -2357,7 +3058,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
 
 // Decode :77-95 / AdvanceDecoding (lattice-faster-online-decoder.cc:747-769): frames
 // [run->t, t_end).  u.ll is addressed by absolute frame.
-template <bool kLazy>
+template <bool kLazy, bool kExact = false>
 __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, int t_end) {
   const int win_frames = WindowFrames(p);
   bool ok = true;
@@ -2405,12 +3106,18 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       fe = Uni(u.frame_e[t]);
     }
     float next_cutoff;
-    ok = ProcessEmitting(u, p, t, fb, fe, &next_cutoff, sh);
+    ok = kExact ? ProcessEmittingExact(u, p, t, fb, fe, &next_cutoff, sh) : ProcessEmitting(u, p, t, fb, fe, &next_cutoff, sh);
     if (!ok) break;
     ok = ProcessNonemitting(u, p, t + 1, next_cutoff, sh);
     if (!ok) break;
     fb = Uni(sh->front_b);
     fe = Uni(sh->tok_end);
+    if (kExact) {   // the new frame's list positions (the order the reference would walk it in)
+      Stamp(u, sh, 4);
+      ok = OrderFrontier(u, p, fb, fe, Uni(u.feps_b[t + 1]), Uni(u.feps_e[t + 1]), next_cutoff, sh);
+      Stamp(u, sh, 45);
+      if (!ok) break;
+    }
     if (threadIdx.x == 0) {
       u.frame_b[t + 1] = fb;
       u.frame_e[t + 1] = fe;
@@ -2488,11 +3195,11 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
 }
 
 // One utterance: InitDecoding, Decode, FinalizeDecoding.
-template <bool kLazy>
+template <bool kLazy, bool kExact>
 __device__ bool DecodeOne(const Utt &u, const Params &p, Blk &sh, KhDecodeStats *st_out) {
   Run run;
-  bool ok = DecodeInit(u, p, sh, &run);
-  if (ok) ok = DecodeFrames<kLazy>(u, p, sh, &run, u.T);
+  bool ok = DecodeInit<kExact>(u, p, sh, &run);
+  if (ok) ok = DecodeFrames<kLazy, kExact>(u, p, sh, &run, u.T);
   return DecodeFinalize<kLazy>(u, p, sh, run, ok, st_out);
 }
 
@@ -2507,6 +3214,7 @@ struct UttOut {
   long long tok_off, link_off;  // position in the pool
   int32_t n_tok, n_link;
   int32_t sched[4];             // Shared::sched of the utterance
+  long long cand_mat;           // emitting candidates materialised (got a link slot)
 };
 struct Pool {
   GP(int32_t) t_frame; GP(int32_t) t_state;   // per exported token
@@ -2669,7 +3377,7 @@ __device__ void ExportSurvivors(const Utt &u, const Params &p, const Pool &pool,
 #ifndef KH_WG_PER_CU
 #define KH_WG_PER_CU 2   // two 1024-thread workgroups per CU (<= 64 VGPRs): more loads in flight
 #endif
-template <bool kLazy>
+template <bool kLazy, bool kExact>
 __global__ void __launch_bounds__(NT)
 #if KH_WG_PER_CU > 1
 __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
@@ -2714,12 +3422,15 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
     // (a capacity overflow aborts a frame with work-list flags still set: clear them too)
     for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
+    if (kExact)   // (an aborted frame may have left bucket minima behind)
+      for (int i = threadIdx.x; i < u.x_hcap; i += NT) u.x_bmin[i] = 0xFFFFFFFFu;
     KhSync();
     KhDecodeStats st;
-    DecodeOne<kLazy>(u, p, sh, &st);
+    DecodeOne<kLazy, kExact>(u, p, sh, &st);
     if (threadIdx.x == 0) {
       out[ui].stats = st;
       for (int i = 0; i < 4; i++) out[ui].sched[i] = sh->sched[i];
+      out[ui].cand_mat = sh->cand_mat;
     }
     KhSync();
     if (st.status == 0) {
@@ -2889,6 +3600,7 @@ struct KhDecoder {
   int slab_slots = 0, slab_T = 0, slab_scale = 1;
   int lazy = 0, alloc_link_a = 1;         // Params::lazy_prune / keep_ac of the calls this decoder serves (kh_decoder_decode sets them)
   int slab_lazy = 0, slab_link_a = 1;     // ... and what the slab was carved for
+  int exact = 0, slab_exact = 0;          // kh_decoder_set_reference_order; whether the slab holds the exact-order temporaries
   std::vector<Utt> h_slots;
   Utt *d_slots = nullptr;
   UttIn *d_in = nullptr;
@@ -3092,7 +3804,7 @@ ArenaCaps LazyCaps(const ArenaCaps &floor, int T, int tok_frame_cap, int link_fr
 
 // Arena set of one slot, sized for utterances of up to T frames.
 void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, const ArenaCaps &caps, bool link_a,
-               float hash_ratio, int expected_tokens) {
+               float hash_ratio, int expected_tokens, bool exact) {
   u.T = T;
   u.tok_frame_cap = tok_frame_cap;
   u.link_frame_cap = link_frame_cap;
@@ -3139,6 +3851,30 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   while (hs < static_cast<size_t>(hash_ratio * expected_tokens) || hs <= static_cast<size_t>(tok_frame_cap)) hs <<= 1;
   u.hash_mask = static_cast<uint32_t>(hs - 1);
   u.hash = c.Take<unsigned long long>(hs);
+  // exact reference order: per-frame temporaries (8 MB per slot at the default caps)
+  {
+    const size_t tf = exact ? tok_frame_cap : 0, lf = exact ? link_frame_cap : 0;
+    // the reference's table has at most hash_ratio x (tokens of a frame) buckets, 1000 to begin with (:37, :219-225)
+    u.x_hcap = exact ? static_cast<int32_t>(std::max<double>(1000.0, static_cast<double>(hash_ratio) * tok_frame_cap) + 16) : 0;
+    u.x_pos = c.Take<int32_t>(tf);
+    u.x_m = c.Take<uint32_t>(tf);
+    u.x_c = c.Take<int32_t>(tf);
+    u.x_q = c.Take<uint32_t>(tf);
+    u.x_cost0 = c.Take<uint32_t>(tf);
+    u.x_bkt = c.Take<int32_t>(tf);
+    u.x_epsidx = c.Take<int32_t>(tf);
+    u.x_nl0 = c.Take<int32_t>(tf);
+    u.x_nl1 = c.Take<int32_t>(tf);
+    u.x_ncost = c.Take<float>(tf);
+    u.x_ord = c.Take<int32_t>(lf);
+    u.x_lw = c.Take<float>(lf);
+    u.x_stack = c.Take<int32_t>(lf);
+    u.x_bmin = c.Take<uint32_t>(static_cast<size_t>(u.x_hcap));
+    u.x_key0 = c.Take<unsigned long long>(tf);
+    u.x_key1 = c.Take<unsigned long long>(tf);
+    u.x_val0 = c.Take<int32_t>(tf);
+    u.x_val1 = c.Take<int32_t>(tf);
+  }
   u.ll = (GP(const float))nullptr;
   u.ll_stride = 0;
   u.phase_cycles = (GP(long long))nullptr;
@@ -3379,7 +4115,7 @@ int DeterminizeUtt(KhDecoder *d, int utt) {
 // (fewer if they do not fit in free memory); establishes the arena invariants.
 int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slots_out, int scale = 1) {
   int n_slots = n_want;
-  const bool same_kind = d->slab_lazy == d->lazy && d->slab_link_a == d->alloc_link_a;
+  const bool same_kind = d->slab_lazy == d->lazy && d->slab_link_a == d->alloc_link_a && d->slab_exact == d->exact;
   if (T_max <= d->slab_T && scale == d->slab_scale && same_kind) n_slots = std::min(n_slots, d->slot_limit);  // an earlier batch found that more do not fit
   const long long kCap = (1ll << 28);
   const int tfc = static_cast<int>(std::min<long long>(kCap, 1ll * d->tok_frame_cap * scale)),
@@ -3407,7 +4143,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     auto slot_bytes = [&](const ArenaCaps &c) {
       Carver sizer{nullptr};
       Utt tmp;
-      CarveSlot(sizer, tmp, T_max, tfc, lfc, c, d->alloc_link_a != 0, d->cfg.hash_ratio, et);
+      CarveSlot(sizer, tmp, T_max, tfc, lfc, c, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0);
       return sizer.off;
     };
     for (;; n_slots = (n_slots + 1) / 2) {
@@ -3443,10 +4179,11 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     d->slab_scale = scale;
     d->slab_lazy = d->lazy;
     d->slab_link_a = d->alloc_link_a;
+    d->slab_exact = d->exact;
     d->h_slots.assign(n_slots, Utt());
     Carver carver{static_cast<char *>(d->slab)};
     for (int i = 0; i < n_slots; i++)
-      CarveSlot(carver, d->h_slots[i], T_max, tfc, lfc, caps, d->alloc_link_a != 0, d->cfg.hash_ratio, et);
+      CarveSlot(carver, d->h_slots[i], T_max, tfc, lfc, caps, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0);
     // arena invariants for the first utterance of every slot (later ones are
     // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
     for (int i = 0; i < n_slots; i++) {
@@ -3454,6 +4191,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
       hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost.p, static_cast<size_t>(u.tok_cap), kEncInf);
       KH_HIP(hipMemsetAsync((void *)(unsigned long long *)u.hash.p, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
       KH_HIP(hipMemsetAsync((void *)(int32_t *)u.tmp_dirty.p, 0, sizeof(int32_t) * u.tok_frame_cap, st));
+      if (u.x_hcap > 0) KH_HIP(hipMemsetAsync((void *)(uint32_t *)u.x_bmin.p, 0xFF, sizeof(uint32_t) * static_cast<size_t>(u.x_hcap), st));
     }
     PoolFree(d->d_slots);
     d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
@@ -3537,6 +4275,8 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
   p.keep_ac = 1;
   p.lazy_prune = 0;
+  p.exact_order = 0;
+  p.hash_ratio = d->cfg.hash_ratio;
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
@@ -3657,8 +4397,10 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
   fprintf(stderr, "[kh_decoder profile] launch %d: %d utterances, kernel %.1f ms, %d slots; share of shader cycles:",
           round, np, ms, grid);
   all -= tot[10] + tot[11] + tot[12] + tot[13] + tot[14];
+  all += tot[45];
   for (int k = 0; k < 16; k++)
     if (tot[k] && (k < 10 || k == 15)) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
+  if (tot[45]) fprintf(stderr, " list_order=%.1f%%", 100.0 * tot[45] / all);
   fprintf(stderr, "\n[kh_decoder profile] PruneActiveTokens calls %lld, frames pruned %lld (%.1f per call), tokens scanned "
           "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
           tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
@@ -3998,6 +4740,13 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   }
   d->lazy = p.lazy_prune;
   d->alloc_link_a = p.keep_ac;
+  // the reference's own iteration order (kh_decoder_set_reference_order; KH_DECODER_ORDER=reference|canonical overrides)
+  {
+    int ex = d->exact;
+    if (const char *e = getenv("KH_DECODER_ORDER")) ex = strcmp(e, "reference") == 0 ? 1 : (strcmp(e, "canonical") == 0 ? 0 : ex);
+    d->exact = ex;
+    p.exact_order = ex;
+  }
   if ((rc = BuildArcPdf(d, &p, tid2pdf, ll_stride, Stream()))) return rc;
   if (!d->ev0) {
     KH_HIP(hipEventCreate(&d->ev0));
@@ -4041,6 +4790,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
   int scale = 1;
   const int kMaxScale = 16;
   bool pool_exact = false;
+  bool hook_called = false;   // kh_decoder_set_after_launch: once per call, after the last launch
   for (int round = 0; !pending.empty(); round++) {
     if (round > 8) {
       SetError("kh_decoder_decode: %d utterances still unfinished after %d launches", static_cast<int>(pending.size()), round);
@@ -4079,12 +4829,15 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     KH_HIP(hipHostGetDevicePointer(&d_out_dev, d->h_out_pinned, 0));
     KH_HIP(hipHostGetDevicePointer(&d_done_dev, d->h_done, 0));
     KH_HIP(hipEventRecord(d->ev0, st));
-    if (p.lazy_prune)
-      hipLaunchKernelGGL(DecodeKernel<true>, dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in,
-                         static_cast<UttOut *>(d_out_dev), np, d->hpool, p, (GP(long long))d->d_phase, (GP(int32_t))d_done_dev);
-    else
-      hipLaunchKernelGGL(DecodeKernel<false>, dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in,
-                         static_cast<UttOut *>(d_out_dev), np, d->hpool, p, (GP(long long))d->d_phase, (GP(int32_t))d_done_dev);
+#define KH_LAUNCH_DECODE(LAZY, EXACT)                                                                                          \
+  hipLaunchKernelGGL((DecodeKernel<LAZY, EXACT>), dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in,          \
+                     static_cast<UttOut *>(d_out_dev), np, d->hpool, p, (GP(long long))d->d_phase, (GP(int32_t))d_done_dev)
+    if (p.exact_order) {
+      if (p.lazy_prune) KH_LAUNCH_DECODE(true, true); else KH_LAUNCH_DECODE(false, true);
+    } else {
+      if (p.lazy_prune) KH_LAUNCH_DECODE(true, false); else KH_LAUNCH_DECODE(false, false);
+    }
+#undef KH_LAUNCH_DECODE
     KH_LAUNCH_CHECK();
     KH_HIP(hipEventRecord(d->ev1, st));
     // ---- host threads: canonical lattice + best path of every utterance as it completes
@@ -4139,9 +4892,6 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     const double t_launched = tnow();
     if (overlap)
       for (int w = 0; w < n_workers; w++) workers.th.emplace_back(worker, w);
-    // the caller's turn while the GPU decodes and the completion threads drain it (kh_decoder_set_after_launch): work it
-    // enqueues on the library's stream runs after the decode kernel
-    if (round == 0 && d->after_launch != nullptr) d->after_launch(d->after_launch_arg);
     std::vector<UttOut> q_out(np);
     unsigned long long used[4] = {0, 0, 0, 0};
     // wait for the kernel without spinning on a core (hipStreamSynchronize busy-waits): the completion threads need the
@@ -4155,6 +4905,34 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     }
     const double t_synced = tnow();
     kernel_done.store(true);
+    // the few words the host still wants from the device, while the stream is idle (the caller's turn below may queue a
+    // whole forward pass on it: nothing of this call waits behind that)
+    std::vector<long long> h_phase;
+    if (sync_err == hipSuccess) {
+      sync_err = hipMemcpyAsync(used, d->d_used, sizeof(used), hipMemcpyDeviceToHost, st);
+      if (sync_err == hipSuccess && d->d_phase) {
+        h_phase.resize(NPH * static_cast<size_t>(grid));
+        sync_err = hipMemcpyAsync(h_phase.data(), d->d_phase, sizeof(long long) * NPH * grid, hipMemcpyDeviceToHost, st);
+      }
+      if (sync_err == hipSuccess) sync_err = hipStreamSynchronize(st);
+    }
+    for (int q = 0; q < np; q++) q_out[q] = d->h_out_pinned[q];
+    // The caller's turn (kh_decoder_set_after_launch): the LAST decode kernel of this call has finished - no utterance is
+    // waiting to be decoded again from the score matrix (an arena or pool overflow: the loop below), and with
+    // Params::keep_ac == 0 the export inside the kernel was the last reader of the scores - while the completion threads
+    // still build / determinize this batch's lattices.  Work the hook enqueues (the next batch's forward pass, into the
+    // same score buffer if the caller likes) overlaps that host tail.
+    if (sync_err == hipSuccess && d->after_launch != nullptr && !hook_called) {
+      bool again = false;
+      for (int q = 0; q < np && !again; q++) {
+        const int s6 = q_out[q].stats.status;
+        again = s6 == 6 || (s6 != 0 && scale < kMaxScale);
+      }
+      if (!again) {
+        hook_called = true;
+        d->after_launch(d->after_launch_arg);
+      }
+    }
     if (!overlap)
       for (int w = 0; w < n_workers; w++) workers.th.emplace_back(worker, w);
     for (auto &t : workers.th) t.join();
@@ -4167,14 +4945,6 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       SetError("kh_decoder_decode: %s", hipGetErrorString(sync_err));
       return KH_EDEVICE;
     }
-    KH_HIP(hipMemcpyAsync(used, d->d_used, sizeof(used), hipMemcpyDeviceToHost, st));
-    std::vector<long long> h_phase;
-    if (d->d_phase) {
-      h_phase.resize(NPH * static_cast<size_t>(grid));
-      KH_HIP(hipMemcpyAsync(h_phase.data(), d->d_phase, sizeof(long long) * NPH * grid, hipMemcpyDeviceToHost, st));
-    }
-    KH_HIP(hipStreamSynchronize(st));
-    for (int q = 0; q < np; q++) q_out[q] = d->h_out_pinned[q];
     float ms = 0.f;
     KH_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
     d->last_kernel_ms += ms;
@@ -4202,7 +4972,8 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     bool grow = false, pool_short = false;
     int n_failed = 0;
     static const char *what[] = {"", "token arena / tokens-per-frame cap", "link arena", "links-per-frame cap",
-                                 "compaction window", "LDS token table", "lattice pool", "survivor lists"};
+                                 "compaction window", "LDS token table", "lattice pool", "survivor lists",
+                                 "closure replay (insertions do not match the closure's tokens: a defect, not a capacity)"};
     for (int q = 0; q < np; q++) {
       const int ui = pending[q];
       const KhDecodeStats &hs = q_out[q].stats;
@@ -4219,7 +4990,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
           grow = true;
           if (getenv("KH_DECODER_PROFILE"))
             fprintf(stderr, "[kh_decoder profile] utterance %d overflowed the %s at frame %d (scale %d): decoded again with 2 x the arenas\n",
-                    ui, what[std::min(std::max(hs.status, 0), 7)], hs.num_frames, scale);
+                    ui, what[std::min(std::max(hs.status, 0), 8)], hs.num_frames, scale);
           continue;
         }
         // give up on this utterance only
@@ -4227,7 +4998,7 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
         SetError("kh_decoder_decode: utterance %d overflowed the %s at frame %d even with %d x the default arenas "
                  "(tokens/frame cap %d, links/frame cap %d); see KH_DECODER_TOKENS_PER_FRAME / "
                  "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME",
-                 ui, what[std::min(std::max(hs.status, 0), 7)], hs.num_frames, scale, d->tok_frame_cap, d->link_frame_cap);
+                 ui, what[std::min(std::max(hs.status, 0), 8)], hs.num_frames, scale, d->tok_frame_cap, d->link_frame_cap);
       }
       if (hs.status != 0) {  // left failed: its counters and status are what the getters report
         d->h_out[ui] = q_out[q];
@@ -4248,6 +5019,19 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     d->slab_T = 0;
     d->slab_scale = 1;
   }
+  return KH_OK;
+}
+
+int kh_decoder_set_reference_order(KhDecoder *d, int enable) {
+  KH_CHECK_ARG(d);
+  d->exact = enable != 0;
+  return KH_OK;
+}
+
+int kh_decoder_get_search_counters(const KhDecoder *d, int utt, int64_t *counters) {
+  KH_CHECK_ARG(d && counters && utt >= 0 && utt < d->n_utts);
+  counters[0] = d->h_out[utt].cand_mat;
+  counters[1] = d->exact;
   return KH_OK;
 }
 

@@ -1,0 +1,189 @@
+"""The decoder in the reference's OWN iteration order (kh_decoder_set_reference_order): bit-exact raw lattice
+(every state, arc, cost), best path and counters against oracle mode 0 = the line-by-line restatement of
+LatticeFasterDecoder with its HashList order (hash-list-inl.h:118-147), running next_cutoff
+(lattice-faster-decoder.cc:728-733), first-minimum tie (:599, :611), LIFO closure (:766-811) and
+delta-tolerant prune sweeps (:296-343) — not against the order-independent rule the default mode implements.
+
+Covered: the hand-picked configurations of test_gpu_decoder.py (max-active binding, min-active, tiny prune
+intervals, no final state, epsilon-heavy), random graphs / options (KH_FUZZ_SEEDS, default 24; the round's
+record is in DESIGN.md), config 3 and config 4 on the HCLG-structured workload through the real forward
+pass, and a slice of bench.py's own shard."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import binding as B
+from test_gpu_decoder import assert_same_lattice, assert_same_best_path, graph_like_hclg
+
+pytestmark = pytest.mark.gpu
+workloads = importlib.import_module("old-kaldi-git_amd.workloads")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_exact(api, graph, lls, cfg, fst=None):
+    fst = fst or api.Fst(graph)
+    dec = api.LatticeFasterDecoder(fst, cfg, max_batch=max(1, len(lls)), max_frames=max(len(x) for x in lls),
+                                   exact_reference_order=True)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
+    dec.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
+    for u, x in enumerate(lls):
+        orf = B.DecoderOracle(graph, cfg, "reference")
+        ok = orf.decode(x)
+        so, sg = orf.stats(), dec.stats(u)
+        for k in ("num_frames", "reached_final", "tokens_created", "max_tokens_frame", "num_tokens", "num_links"):
+            assert so[k] == sg[k], (u, k, so[k], sg[k])
+        assert np.float32(so["final_relative_cost"]).tobytes() == np.float32(sg["final_relative_cost"]).tobytes()
+        if not ok:
+            continue
+        assert_same_lattice(dec.get_raw_lattice(u), orf.raw_lattice())
+        assert_same_best_path(dec.get_best_path(u), orf.best_path())
+        assert dec.search_counters(u)["reference_order"]
+    return dec
+
+
+def test_tiny_and_medium(api):
+    rng = np.random.default_rng(1)
+    g = graph_like_hclg(rng, 50, 10)
+    run_exact(api, g, [workloads.make_loglikes(rng, T, 10) for T in (1, 2, 26, 60)], api.decoder_config())
+    rng = np.random.default_rng(2)
+    g = graph_like_hclg(rng, 20000, 200)
+    run_exact(api, g, [workloads.make_loglikes(rng, T, 200) for T in (75, 130)], api.decoder_config(beam=9.0, lattice_beam=6.0))
+
+
+def test_max_active_binding(api):
+    """The regime in which the two rules part: max-active binds, the running cutoff admits tokens the final one does not."""
+    rng = np.random.default_rng(3)
+    g = graph_like_hclg(rng, 100000, 1000)
+    lls = [workloads.make_loglikes(rng, T, 1000) for T in (60, 101, 37)]
+    cfg = api.decoder_config(beam=15.0, max_active=2000, min_active=200, lattice_beam=8.0)
+    dec = run_exact(api, g, lls, cfg)
+    # ... and the canonical mode really is a different search here (else this test would prove nothing)
+    can = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=3, max_frames=101)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
+    can.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
+    assert any(can.stats(u)["tokens_created"] != dec.stats(u)["tokens_created"] for u in range(3))
+
+
+def test_min_active_prune_interval_no_final_eps_heavy(api):
+    rng = np.random.default_rng(4)
+    g = graph_like_hclg(rng, 5000, 100)
+    lls = [workloads.make_loglikes(rng, 90, 100)]
+    run_exact(api, g, lls, api.decoder_config(beam=2.0, max_active=3000, min_active=500, lattice_beam=1.5, prune_interval=7))
+    run_exact(api, g, lls, api.decoder_config(beam=12.0, max_active=3000, min_active=0, lattice_beam=7.0, prune_interval=3))
+    rng = np.random.default_rng(5)
+    g = graph_like_hclg(rng, 3000, 50, final_frac=0.0)
+    run_exact(api, g, [workloads.make_loglikes(rng, 40, 50)], api.decoder_config(beam=10.0, lattice_beam=6.0))
+    rng = np.random.default_rng(6)
+    g = graph_like_hclg(rng, 8000, 80, eps_frac=0.45, mean_degree=3.5)
+    run_exact(api, g, [workloads.make_loglikes(rng, 64, 80)], api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
+
+
+def test_interval_schedule_and_small_slots(api, monkeypatch):
+    """The periodic pruning schedule and slot reuse (more utterances than slots) in reference order."""
+    rng = np.random.default_rng(8)
+    g = graph_like_hclg(rng, 20000, 200, eps_frac=0.2)
+    lls = [workloads.make_loglikes(rng, int(T), 200) for T in (90, 33, 120, 61, 75)]
+    cfg = api.decoder_config(beam=12.0, max_active=900, min_active=100, lattice_beam=6.0, prune_interval=10)
+    monkeypatch.setenv("KH_DECODER_SLOTS", "2")
+    run_exact(api, g, lls, cfg)
+    monkeypatch.setenv("KH_DECODER_PRUNE_SCHEDULE", "interval")
+    run_exact(api, g, lls, cfg)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "24"))))
+def test_random_configurations(api, seed, monkeypatch):
+    """test_gpu_decoder.py's fuzz (random graphs, tiny max_active, prune_interval down to 1, epsilon-free and
+    epsilon-heavy graphs, one-frame utterances, more utterances than slots), held to the reference ORDER."""
+    rng = np.random.default_rng(1000 + seed)
+    n_states = int(rng.choice([30, 300, 3000, 20000]))
+    n_pdf = int(rng.choice([5, 40, 200]))
+    g = graph_like_hclg(rng, n_states, n_pdf, eps_frac=float(rng.choice([0.0, 0.05, 0.2, 0.4])),
+                        final_frac=float(rng.choice([0.0, 0.05, 0.5])))
+    n_utt = int(rng.integers(1, 6))
+    lls = [workloads.make_loglikes(rng, int(T), n_pdf) for T in rng.integers(1, 130, n_utt)]
+    max_active = int(rng.choice([2, 5, 60, 800, 2147483647]))
+    min_active = int(rng.choice([m for m in (0, 1, 20, 300) if m < max_active]))
+    cfg = api.decoder_config(beam=float(rng.choice([2.0, 6.0, 11.0, 15.0])),
+                             max_active=max_active, min_active=min_active,
+                             lattice_beam=float(rng.choice([0.3, 2.0, 6.0, 10.0])),
+                             prune_interval=int(rng.choice([1, 2, 7, 25, 30])),
+                             beam_delta=float(rng.choice([0.1, 0.5])),
+                             prune_scale=float(rng.choice([0.05, 0.1, 0.5])),
+                             hash_ratio=float(rng.choice([1.0, 2.0, 2.0, 3.5])))
+    if rng.random() < 0.5:
+        monkeypatch.setenv("KH_DECODER_SLOTS", str(int(rng.integers(1, 4))))
+    run_exact(api, g, lls, cfg)
+
+
+def decode_structured(api, g, ll_dev, off, cfg, sample):
+    n = len(off) - 1
+    dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=n, max_frames=int(np.diff(off).max()), exact_reference_order=True)
+    dec.decode(ll_dev, off)
+    ll = ll_dev.cpu().numpy()
+    dens = []
+    for u in sample:
+        x = np.ascontiguousarray(ll[off[u]:off[u + 1]])
+        orf = B.DecoderOracle(g, cfg, "reference")
+        assert orf.decode(x)
+        got = dec.get_raw_lattice(u)
+        assert_same_lattice(got, orf.raw_lattice())
+        assert_same_best_path(dec.get_best_path(u), orf.best_path())
+        assert orf.stats()["tokens_created"] == dec.stats(u)["tokens_created"]
+        dens.append(len(got["arc_src"]) / len(x))
+    return dec, dens
+
+
+def test_cfg4_nnet_a_structured(api):
+    """BASELINE config 4: nnet_a forward pass, 1 M-state structured graph, the recipe's options."""
+    import test_gpu_structured as S
+    rng = np.random.default_rng(404)
+    net, _ = workloads.librispeech_nnet_a(rng, final_scale=14.0)
+    priors = workloads.calibrate_biases(rng, net)
+    g = workloads.make_hclg_structured(rng, 1_000_000, 5800)
+    lens = [380, 150, 260]
+    feats, off, seqs = S.path_workload(rng, net, priors, g, lens, noise=0.12)
+    nnet = api.Nnet(net, priors)
+    ll_dev, _ = nnet.compute(torch.from_numpy(feats).cuda(), off, True, epilogue=True, prob_scale=S.ACWT)
+    torch.cuda.synchronize()
+    dec, dens = decode_structured(api, g, ll_dev, off, api.decoder_config(**S.RECIPE), range(3))
+    assert min(dens) > 8.0, dens
+
+
+def test_cfg3_wsj_structured(api):
+    """BASELINE config 3: 2 M-state structured graph with 3400 pdfs, scores following sampled paths."""
+    import test_gpu_structured as S
+    rng = np.random.default_rng(303)
+    g = workloads.make_hclg_structured(rng, 2_000_000, 3400)
+    lens = [300, 120]
+    seqs = workloads.sample_paths(rng, g, lens)
+    lls = []
+    for q in seqs:
+        x = (rng.standard_normal((len(q), 3400)) * 0.28 - 0.37).astype(np.float32)
+        x[np.arange(len(q)), q] = (0.5 + 0.3 * rng.standard_normal(len(q))).astype(np.float32)
+        lls.append(x)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    dec, dens = decode_structured(api, g, torch.from_numpy(np.concatenate(lls)).cuda(), off, api.decoder_config(**S.RECIPE), range(2))
+    assert min(dens) > 8.0, dens
+
+
+def test_bench_workload_slice(api):
+    """A slice of bench.py's own workload (its model, its 10 M-state graph, its features, its options): the longest, a
+    median and the shortest utterance (the 100-frame one on which the canonical search keeps 16 word sequences the
+    reference order does not) bit-exact against the reference order."""
+    sys.path.insert(0, ROOT)
+    import bench
+    net, priors, g, protos = bench.build_model_and_graph(3456, 10_000_000, False)
+    feats, off = bench.build_utterances(3456, 0, 2620, net, g, protos, False)
+    pick = [0, 1300, 2619] + list(range(1000, 1045))
+    feats, off = bench.take_utterances(feats, off, pick)
+    nnet = api.Nnet(net, priors)
+    ll_dev, _ = nnet.compute(torch.from_numpy(feats).cuda(), off, True, epilogue=True, prob_scale=bench.ACWT)
+    torch.cuda.synchronize()
+    lens = np.diff(off)
+    sample = [int(np.argmax(lens)), int(np.argsort(lens)[len(lens) // 2]), int(np.argmin(lens))]
+    dec, dens = decode_structured(api, g, ll_dev, off, api.decoder_config(**bench.DECODE_CFG), sample)
+    print("bench slice in reference order: lattice arcs/frame %s" % dens)

@@ -316,12 +316,26 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
     return res
 
 
+def release_device_memory(api, torch):
+    """Between legs: drop what the previous leg left cached (python cycles, torch's caching allocator, the library's own
+    block pool) so that the next leg sizes its arenas from the memory that is really free.  The driver's round-3 run lost
+    the online leg to exactly that: hipMemGetInfo does not count blocks torch holds in its cache, and with the headline
+    run's score matrices (45 GB each) still cached only 64 of 256 stream slots fitted."""
+    import gc
+    gc.collect()
+    api.synchronize()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    api.pool_release()
+
+
 def run_all(api, torch, main_workload=None):
     """main_workload: bench.py's (net, priors, graph, feats, utt offsets, decoder config, acwt) for the online leg."""
     out = {}
     for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("decode_cfg3", decode_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5),
                      ("ivector_f3", ivector_f3), ("online2_cfg4", lambda a, t: online2_cfg4(a, t, main_workload))):
         try:
+            release_device_memory(api, torch)
             out[name] = fn(api, torch)
         except Exception as e:  # a secondary leg never fails the headline run
             out[name] = {"error": repr(e)}
