@@ -69,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg at N > 1")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (config 2 / 5) legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the unpipelined and the reference-order repeats of the step")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the value_end_to_end leg (the same steps with determinization timed)")
     ap.add_argument("--no-gpu-dryrun", action="store_true",
                     help="launcher / sharding / reduction only (gloo, no GPU, nothing decoded): CPU test of the multi-rank path")
@@ -592,13 +593,14 @@ def main():
                 tot_like += -(gc + ac)
             cnt, ls = dec.stats_batch()
             arcs, toks = int(cnt["arcs_expanded"].sum()), int(cnt["tokens_created"].sum())
+            cand = dec.search_counters(-1)["candidates_materialised"]
             lat_arcs, lat_states = int(ls["num_links"].sum()), int(ls["num_tokens"].sum())
             t.append(time.perf_counter())
             if determinize:
                 stats["clat"] = dec.compact_lattice_totals()   # (every lattice is there: the host threads finished inside decode())
                 stats["host_tail_ms"] = dec.last_host_tail_ms()
                 t.append(time.perf_counter())
-            stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, lat_arcs=lat_arcs, lat_states=lat_states,
+            stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, cand=cand, lat_arcs=lat_arcs, lat_states=lat_states,
                          kernel_ms=dec.last_kernel_ms())
             if verbose and rank == 0:
                 d = np.diff(t) * 1e3
@@ -627,6 +629,39 @@ def main():
         join_background()
         sync()
         elapsed = time.perf_counter() - t0
+        pipelined = pipelined and not pipe["disabled"]   # (a failed background forward pass: the rest ran one after the other)
+        main_stats = dict(stats)
+        # ---- the same step strictly one after the other (round-to-round comparison with the unpipelined headline of
+        # rounds 1-2), and in the reference's own iteration order (kh_decoder_set_reference_order): min(K, 5) steps each
+        extra = {}
+        if end_to_end and not args.no_extra_legs:
+            k2 = max(1, min(steps, 5))
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                step()
+            sync()
+            extra["unpipelined"] = dict(elapsed=time.perf_counter() - t1, steps=k2, kernel_ms=stats["kernel_ms"])
+            try:
+                dec.set_reference_order(True)
+                step()        # (the slot arenas are carved again with the order's temporaries)
+                sync()
+                t1 = time.perf_counter()
+                kms_x = []
+                for _ in range(k2):
+                    step()
+                    kms_x.append(stats["kernel_ms"])
+                sync()
+                extra["exact_order"] = dict(elapsed=time.perf_counter() - t1, steps=k2, kernel_ms=float(np.mean(kms_x)),
+                                            tot_like=stats["tot_like"], arcs=stats["arcs"], toks=stats["toks"], cand=stats["cand"],
+                                            lat_arcs=stats["lat_arcs"], lat_states=stats["lat_states"])
+            except Exception as e:   # noqa: BLE001 - an extra leg never costs the headline
+                extra["exact_order"] = {"error": repr(e)}
+            finally:
+                dec.set_reference_order(False)
+            step()            # back to the default arenas before the end-to-end loops
+            sync()
+        stats.clear()
+        stats.update(main_stats)
         # ---- the same K steps with determinization in the timed region (value_end_to_end)
         e2e = None
         if end_to_end and not args.no_end_to_end:
@@ -649,7 +684,7 @@ def main():
                 tail.append(stats["host_tail_ms"])
             sync()
             e2e = dict(elapsed=time.perf_counter() - t1, kernel_ms=float(np.mean(kms_e)), tail_ms=float(np.mean(tail)), clat=stats["clat"],
-                       pipelined=pipelined)
+                       pipelined=pipelined and not pipe["disabled"])
             # ---- and from the waveform: config 4's binary reads audio (front end + the region above)
             if n_utts > 0 and frames >= 1000:
                 step(True, True)
@@ -673,7 +708,10 @@ def main():
                 fe.clear()
             dec.set_determinize(False)
             dec.set_after_launch(None)
-        red = torch.tensor([elapsed, e2e["elapsed"] if e2e else 0.0, e2e.get("wave_elapsed", 0.0) if e2e else 0.0], dtype=torch.float64, device="cuda")
+        red = torch.tensor([elapsed, e2e["elapsed"] if e2e else 0.0, e2e.get("wave_elapsed", 0.0) if e2e else 0.0,
+                            0.0 if pipelined else 1.0, 0.0 if (e2e and e2e["pipelined"]) else 1.0,
+                            extra.get("unpipelined", {}).get("elapsed", 0.0), extra.get("exact_order", {}).get("elapsed", 0.0)],
+                           dtype=torch.float64, device="cuda")
         tot = torch.tensor([float(frames), stats["tot_like"], float(stats["n_ok"])], dtype=torch.float64, device="cuda")
         kms = torch.zeros(world, dtype=torch.float64, device="cuda")
         kms[rank] = float(np.mean(kernel_ms))
@@ -684,9 +722,15 @@ def main():
         del dec, feats_d, loglikes
         if e2e:
             e2e["elapsed"] = float(red[1].item())
+            e2e["pipelined"] = float(red[4].item()) == 0.0   # on every rank
             if "wave_elapsed" in e2e:
                 e2e["wave_elapsed"] = float(red[2].item())
-        return dict(elapsed=float(red[0].item()), e2e=e2e, total_frames=float(tot[0].item()), tot_like=float(tot[1].item()),
+        if "unpipelined" in extra:
+            extra["unpipelined"]["elapsed"] = float(red[5].item())
+        if "exact_order" in extra and "elapsed" in extra["exact_order"]:
+            extra["exact_order"]["elapsed"] = float(red[6].item())
+        return dict(elapsed=float(red[0].item()), e2e=e2e, extra=extra, pipelined=float(red[3].item()) == 0.0,
+                    total_frames=float(tot[0].item()), tot_like=float(tot[1].item()),
                     n_ok=int(tot[2].item()), stats=dict(stats), kernel_ms=float(np.mean(kernel_ms)),
                     per_rank_kernel_ms=[float(x) for x in kms.tolist()], frames=frames, n_utts=n_utts,
                     longest=int(np.diff(off_h).max()) if n_utts else 0)
@@ -708,6 +752,7 @@ def main():
         # roofline of the dominant kernel (DecodeKernel): algorithmic bytes per launch =
         # 60 B per expanded arc + 16 B per created token / measured duration
         alg_bytes = st["arcs"] * 60.0 + st["toks"] * 16.0
+        tight_bytes = (st["arcs"] - st["cand"]) * 28.0 + st["cand"] * 60.0 + st["toks"] * 16.0
         k_ms = weak["kernel_ms"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args, world, k_ms)
@@ -726,11 +771,13 @@ def main():
                        "nnet": "140-700-4x(3500/350)-12000-5800" if not args.small else "small",
                        "decoder": DECODE_CFG, "acwt": ACWT, "parallelism": "utterance-shard x%d" % world,
                        "rccl_world_size": world, "workload_build_s": t_build,
-                       "steps_pipelined": not os.environ.get("KH_BENCH_NO_PIPELINE"),
+                       "steps_pipelined": bool(weak["pipelined"]),
                        "step": "forward pass + decode + best paths and lattice sizes of the whole shard; K steps run as a binary's "
-                               "main loop would: step i + 1's forward pass is enqueued behind step i's decode kernel from a second "
-                               "host thread (kh_decoder_set_after_launch) - K forward passes and K decodes inside the timed region; "
-                               "KH_BENCH_NO_PIPELINE=1: strictly one after the other"},
+                               "main loop would: when step i's decode kernel has finished, a second host thread starts step "
+                               "i + 1's forward pass (kh_decoder_set_after_launch) while the host finishes step i (lattices, best "
+                               "paths) - K forward passes and K decodes inside the timed region; steps_pipelined = false "
+                               "(KH_BENCH_NO_PIPELINE=1, or a background pass failed on some rank): strictly one after the other; "
+                               "value_unpipelined is that figure in every run"},
             "search": {"arcs_expanded_per_frame": st["arcs"] / weak["frames"], "tokens_per_frame": st["toks"] / weak["frames"],
                        "lattice_arcs_per_frame": st["lat_arcs"] / weak["frames"],
                        "lattice_states_per_frame": st["lat_states"] / weak["frames"]},
@@ -738,10 +785,41 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "DecodeKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "arcs_expanded_per_launch": st["arcs"], "tokens_created_per_launch": st["toks"]},
+                         "arcs_expanded_per_launch": st["arcs"], "tokens_created_per_launch": st["toks"],
+                         # the same kernel against a TIGHT byte count: an arc that is read and rejected costs its 16-byte
+                         # record + 4 (score) + 8 (source token) = 28 B, only a materialised candidate the full 60 B
+                         "candidates_materialised_per_launch": st["cand"],
+                         "tight_bytes_per_launch": tight_bytes,
+                         "frac_tight": tight_bytes / (k_ms * 1e-3) / 1e9 / 8000.0,
+                         # ... and the bytes the fabric really moved (PMC record) over the peak
+                         "frac_traffic": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
+                         "traffic_over_tight": (traffic / tight_bytes) if traffic else None},
             "per_rank_kernel_ms": weak["per_rank_kernel_ms"],
             "loglike_per_frame": st["tot_like"] / weak["frames"],
         }
+        ex = weak.get("extra") or {}
+        if "unpipelined" in ex:
+            u_ = ex["unpipelined"]
+            out["value_unpipelined"] = weak["total_frames"] * u_["steps"] / u_["elapsed"]
+        if "exact_order" in ex:
+            x_ = ex["exact_order"]
+            if "error" in x_:
+                out["exact_order"] = x_
+            else:
+                # the same step with the decoder in the reference's OWN iteration order (running next_cutoff in HashList
+                # order, first-minimum ties, LIFO closure insertions): bit-exact against the line-by-line oracle
+                # (tests/test_gpu_exact_order.py); measured one step after the other, to be held against value_unpipelined
+                out["value_exact_order"] = weak["total_frames"] * x_["steps"] / x_["elapsed"]
+                out["exact_order"] = {
+                    "unit": "frames/s", "steps": x_["steps"], "ms_per_step": x_["elapsed"] / x_["steps"] * 1e3,
+                    "kernel_ms": x_["kernel_ms"], "kernel_ms_canonical": k_ms,
+                    "kernel_cost_vs_canonical": x_["kernel_ms"] / k_ms - 1.0,
+                    "arcs_expanded_per_frame": x_["arcs"] / weak["frames"], "tokens_per_frame": x_["toks"] / weak["frames"],
+                    "candidates_materialised_per_frame": x_["cand"] / weak["frames"],
+                    "lattice_arcs_per_frame": x_["lat_arcs"] / weak["frames"],
+                    "loglike_per_frame": x_["tot_like"] / weak["frames"],
+                    "note": "kh_decoder_set_reference_order(1): what LatticeFasterDecoder itself computes; the default "
+                            "(order-independent) rule is kept for the headline because it is cheaper"}
         if weak["e2e"] is not None:
             e = weak["e2e"]
             # DecodeUtteranceLatticeFaster in full: what the reference binary's timer brackets per utterance

@@ -328,7 +328,7 @@ int kh_decoder_get_schedule_counters(const KhDecoder *dec, int utt, int32_t *cou
  * the FINAL next_cutoff, ties to the smallest state id), which is what the reference computes whenever no token lies
  * between the final and the running cutoff.  The environment variable KH_DECODER_ORDER=reference|canonical overrides. */
 int kh_decoder_set_reference_order(KhDecoder *dec, int enable);
-/* Search counters of utterance `utt` in the last kh_decoder_decode call (measurement aid): counters[0] = emitting
+/* Search counters of utterance `utt` (-1: summed over the batch) in the last kh_decoder_decode call (measurement aid): counters[0] = emitting
  * candidates that were materialised (given a link slot: the rest of arcs_expanded were read and rejected),
  * counters[1] = 1 if the call ran in reference order. */
 int kh_decoder_get_search_counters(const KhDecoder *dec, int utt, int64_t *counters);

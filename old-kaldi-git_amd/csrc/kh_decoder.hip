@@ -75,7 +75,7 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 48;            // diagnostic counters per slot
+constexpr int NPH = 56;            // diagnostic counters per slot
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x1fffffff;
@@ -174,6 +174,32 @@ __device__ __forceinline__ uint32_t LoadCostEnc(P p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Per-slot temporaries of the exact reference order (see "exact reference order" below).
+struct UttX {
+  // ---- exact reference order (Params::exact_order; carved only then).  [tok_frame_cap] unless noted.
+  Arr<int32_t> x_pos;      // frontier token (i - frame begin) -> its position in the reference's HashList order
+  Arr<uint32_t> x_m;       // by list position: Enc(min tot_cost + adaptive_beam) over the token's emitting arcs; after the scan the running next_cutoff BEFORE the token
+  Arr<int32_t> x_c;        // by list position: # emitting arcs expanded; after the scan their exclusive prefix sum (ordinal of the token's first candidate)
+  Arr<uint32_t> x_q;       // token of the frame under construction (i - nb) -> insertion key (order of HashList::Insert calls)
+  Arr<uint32_t> x_cost0;   // ... -> cost image before the epsilon closure
+  Arr<int32_t> x_bkt;      // ... -> HashList bucket (caller's state id % hash size)
+  Arr<int32_t> x_epsidx;   // ... -> index in tmp_epslist, or -1
+  Arr<int32_t> x_nl0; Arr<int32_t> x_nl1;   // closure replay, by tmp_epslist index: the token's epsilon link slots [l0, l1) relative to the block
+  Arr<float> x_ncost;      // closure replay: token cost as the replay proceeds
+  Arr<int32_t> x_ord;      // [link_frame_cap] candidate ordinal of a materialised emitting candidate; then the closure replay's link destination codes
+  Arr<float> x_lw;         // [link_frame_cap] closure replay: link weight
+  Arr<int32_t> x_stack;    // [link_frame_cap] closure replay: the LIFO queue (:766-811)
+  Arr<uint32_t> x_bmin;    // [x_hcap] HashList bucket -> smallest insertion key in it (all ones = empty: invariant between frames)
+  Arr<unsigned long long> x_key0; Arr<unsigned long long> x_key1;   // radix sort keys, double buffered
+  Arr<int32_t> x_val0; Arr<int32_t> x_val1;                         // radix sort payload
+  int32_t x_hcap;
+};
+
+// An array of UttX (constant address space: the pointer is fetched with a scalar load where it is used)
+template <class T>
+__device__ __forceinline__ Arr<T> XArr(const __attribute__((address_space(4))) Arr<T> &a) { return Arr<T>(a.p); }
+#define UX(field) XArr(u.x->field)
+
 // Per-utterance arenas and parameters (device-resident array of these).
 //
 // Tokens and links live in one append-only arena each, in frame order:
@@ -224,23 +250,10 @@ struct Utt {
   Arr<unsigned long long> hash;
   uint32_t hash_mask;
   GP(long long) phase_cycles;  // [16] diagnostic (KH_DECODER_PROFILE=1), else nullptr
-  // ---- exact reference order (Params::exact_order; carved only then).  [tok_frame_cap] unless noted.
-  Arr<int32_t> x_pos;      // frontier token (i - frame begin) -> its position in the reference's HashList order
-  Arr<uint32_t> x_m;       // by list position: Enc(min tot_cost + adaptive_beam) over the token's emitting arcs; after the scan the running next_cutoff BEFORE the token
-  Arr<int32_t> x_c;        // by list position: # emitting arcs expanded; after the scan their exclusive prefix sum (ordinal of the token's first candidate)
-  Arr<uint32_t> x_q;       // token of the frame under construction (i - nb) -> insertion key (order of HashList::Insert calls)
-  Arr<uint32_t> x_cost0;   // ... -> cost image before the epsilon closure
-  Arr<int32_t> x_bkt;      // ... -> HashList bucket (caller's state id % hash size)
-  Arr<int32_t> x_epsidx;   // ... -> index in tmp_epslist, or -1
-  Arr<int32_t> x_nl0; Arr<int32_t> x_nl1;   // closure replay, by tmp_epslist index: the token's epsilon link slots [l0, l1) relative to the block
-  Arr<float> x_ncost;      // closure replay: token cost as the replay proceeds
-  Arr<int32_t> x_ord;      // [link_frame_cap] candidate ordinal of a materialised emitting candidate; then the closure replay's link destination codes
-  Arr<float> x_lw;         // [link_frame_cap] closure replay: link weight
-  Arr<int32_t> x_stack;    // [link_frame_cap] closure replay: the LIFO queue (:766-811)
-  Arr<uint32_t> x_bmin;    // [x_hcap] HashList bucket -> smallest insertion key in it (all ones = empty: invariant between frames)
-  Arr<unsigned long long> x_key0; Arr<unsigned long long> x_key1;   // radix sort keys, double buffered
-  Arr<int32_t> x_val0; Arr<int32_t> x_val1;                         // radix sort payload
-  int32_t x_hcap;
+  // exact reference order (Params::exact_order): the frame temporaries of that mode live in a struct of their own in
+  // constant memory and are fetched where they are used (scalar loads) - twenty more pointers in this struct, which the
+  // kernels hold in registers for the whole launch, spilled every phase of the kernel (scratch 312 -> 888 bytes per lane)
+  __attribute__((address_space(4))) const struct UttX *x;
 };
 
 struct Params {
@@ -345,7 +358,7 @@ struct Shared {
   int status;
   long long arcs_expanded, tokens_created;
   int max_tokens_frame;
-  long long t_last;
+  long long t_last, t_sub;
   long long phase[NPH];
   int tok_hw;  // highest token slot dirtied by this slot's utterances so far
   int gc_tok, gc_link;  // arena ends right after the last full compaction (garbage collection)
@@ -835,7 +848,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
     // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
     const uint32_t enc = LoadCostEnc(&u.tok_cost[i]);
     const unsigned long long key = (static_cast<unsigned long long>(enc) << 32) |
-                                   static_cast<uint32_t>(kExact ? u.x_pos[i - b] : u.tok_state[i]);
+                                   static_cast<uint32_t>(kExact ? UX(x_pos)[i - b] : u.tok_state[i]);
     if (key < best) { best = key; best_i = i; }
     kmax = enc > kmax ? enc : kmax;
   }
@@ -1067,6 +1080,214 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
   KhSync();
 }
 
+// ---- pass 2 of ProcessEmitting (shared by the canonical and the reference-order sweep): accept `tot_cost <= next_cutoff`
+// (the canonical rule E tests the frame's FINAL next_cutoff here; the reference-order sweep has applied the running
+// cutoff already and passes +inf) and FindOrAddToken +
+// cost minimum IN LDS.  Every global atomic of this pool executes at the memory side (one
+// DRAM read-modify-write per lane: TCC_EA0_ATOMIC == TCC_ATOMIC), and the CAS + publish +
+// min per accepted arc were 85 % of the kernel's atomics.  The accepted candidates are
+// split by a hash of their state into P parts of <= ~2800 candidates; each part is deduped
+// in the 4096-slot LDS table (CAS on the key, min on the cost image), the occupied slots get
+// consecutive token indices from one scan (a deterministic order), the tokens are written
+// with plain stores and a second sweep gives the part's links their token index.  Only the
+// tokens the epsilon closure may look up (kEpsDst states) also enter the global hash.
+__device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok_limit, int link_frame_b, int link_frame_e,
+                                          float next_cutoff) {
+  static_assert(kLdsSlots % NT == 0, "slots per lane");
+  auto keys = LdsKeys(sh);
+  auto vals = LdsVals(sh);
+  const float nan = __int_as_float(0x7fc00000);
+  auto part_of = [](uint32_t h, int parts) { return static_cast<int>(((h >> 12) * static_cast<uint32_t>(parts)) >> 20); };
+  // LOCALITY: the table is hashed by BLOCKS of 2^kLocBits consecutive state ids (h = hash of the
+  // block), a block's states take consecutive slots, and the slot scan of (C) numbers the tokens
+  // in slot order — so the tokens of neighbouring states are neighbours in the next frame's
+  // expansion: their arc-offset words share a cache line and their arcs are contiguous in the
+  // arc table (an HCLG numbers the states of an HMM chain / a lexicon-tree branch consecutively).
+#ifndef KH_PART_CAND
+#define KH_PART_CAND 11000   // accepted candidates per part of pass 2 (7 k / 9 k / 13 k / 15 k measured: +6 % / 0 / +1 % / +8 %)
+#endif
+#ifndef KH_LOC_BITS
+#define KH_LOC_BITS 5
+#endif
+  // A state id is the unit index of its record (header + emitting arcs: ~3 units for the states of
+  // an HMM chain), so a block of 2^kLocBits table slots stands for 2^(kLocBits + kLocShift) units.
+#ifndef KH_LOC_SHIFT
+#define KH_LOC_SHIFT 1
+#endif
+  constexpr int kLocBits = KH_LOC_BITS, kLocShift = KH_LOC_SHIFT;
+  auto lds_slot = [](uint32_t h, int32_t ns) {
+    return ((h << kLocBits) | ((static_cast<uint32_t>(ns) >> kLocShift) & ((1u << kLocBits) - 1u))) & (kLdsSlots - 1);
+  };
+  // number of parts: about 11 000 accepted candidates per part (typically half as many
+  // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
+  // parts (the parts nest, and resolved links are marked, so nothing is done twice)
+  int parts = 1;
+  if (link_frame_e - link_frame_b > KH_PART_CAND) {
+    int n_acc_mine = 0;
+    for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
+      n_acc_mine += !(u.link_k[l] > next_cutoff) ? 1 : 0;
+    const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
+    while (parts * KH_PART_CAND < n_acc) parts *= 2;
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
+  }
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[31] += link_frame_e - link_frame_b; sh->phase[13] += 0; }
+  for (int k = 0; k < parts; k++) {
+    for (int i = threadIdx.x; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) sh->flag = 0;
+    KhSync();
+    // (B) insert.  A link that an earlier part resolved holds its token index (>= 0), a rejected one -1,
+    // an unresolved one -2 - (next state + flags).  kMU
+    // candidates per lane are loaded before any is used (independent loads in flight).
+    constexpr int kMU = 4;
+    for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
+      float tc[kMU];
+      int32_t nsv[kMU];
+      if (base + kMU <= link_frame_e) {   // a lane owns kMU = 4 consecutive candidates: one 16-byte load per array
+        const KhFloat4 t4 = Load4F(u.link_k, base);
+        const KhInt4 n4 = Load4I(u.link_dst, base);
+        tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
+        nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < kMU; j++) {
+          const int l = base + j;
+          const int lc = l < link_frame_e ? l : link_frame_e - 1;
+          tc[j] = u.link_k[lc];
+          nsv[j] = u.link_dst[lc];
+          if (l >= link_frame_e) tc[j] = nan;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kMU; j++) {
+        const float tot_cost = tc[j];
+        if (nsv[j] >= -1 || tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
+        const int32_t ns = -2 - nsv[j];
+        const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
+        if (part_of(h, parts) != k) continue;
+        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+        uint32_t slot = lds_slot(h, ns);
+        // double hashing BY BLOCK: a block whose place is taken moves as a whole (same offset within
+        // the block, a step that depends on the block only), so its tokens stay neighbours; linear
+        // probing piles the runs of consecutive active states up (pass 2 twice as slow)
+        const uint32_t step = ((h >> 9) | 1u) << kLocBits;
+        int probes = 0;
+        for (; probes < 256; probes++) {
+          uint32_t seen = 0u;
+          __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (seen == 0u || seen == key) break;
+          slot = (slot + step) & (kLdsSlots - 1);
+        }
+        if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
+        (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    KhSync();
+    if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
+      KhSync();                // (every lane has read the flag before it is reset)
+      if (parts >= (1 << 20)) {
+        if (threadIdx.x == 0) sh->status = 5;
+        KhSync();
+        return false;
+      }
+      parts *= 2;
+      k = 2 * k - 1;
+      continue;
+    }
+    // (C) occupied slots -> consecutive token indices; tokens written with plain stores
+    const int tok_base = Uni(sh->tok_end);
+    int occ[kLdsSlots / NT], off[kLdsSlots / NT], total;
+#pragma unroll
+    for (int j = 0; j < kLdsSlots / NT; j++) occ[j] = keys[threadIdx.x + j * NT] != 0u ? 1 : 0;
+    BlockExScanK<kLdsSlots / NT>(occ, off, &total, sh);
+    if (tok_base + total > tok_limit) {
+      if (threadIdx.x == 0) sh->status = 1;
+      KhSync();
+      return false;
+    }
+#pragma unroll
+    for (int j = 0; j < kLdsSlots / NT; j++) {
+      if (!occ[j]) continue;
+      const int i = threadIdx.x + j * NT;
+      const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
+      const int idx = tok_base + off[j];
+      u.tok_state[idx] = ns & kStateMask;
+      u.tok_cost[idx] = vals[i];
+      u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
+      vals[i] = static_cast<uint32_t>(idx);
+      if ((ns & kHasEps) != 0) {
+        // these tokens are the closure's first work list (every one has a finite cost)
+        u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+        u.tmp_dirty[idx - nb] = 1;
+      }
+      int32_t gslot = -1;
+      if ((ns & kEpsDst) != 0) {  // the closure may look this state up: enter it in the global table
+        const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
+                                        (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
+        uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
+        for (int probes = 0; probes < (1 << 30); probes++) {
+          unsigned long long ent = kEmpty;
+          __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ent == kEmpty) break;
+          g = (g + 1) & u.hash_mask;
+        }
+        gslot = static_cast<int32_t>(g);
+      }
+      u.tmp_slot[idx - nb] = gslot;
+    }
+    if (threadIdx.x == 0) sh->tok_end = tok_base + total;
+    KhSync();
+    // (D) the part's links get their token index; rejected candidates become dead links
+    for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
+      float tc[kMU];
+      int32_t nsv[kMU];
+      const bool full = base + kMU <= link_frame_e;
+      if (full) {
+        const KhFloat4 t4 = Load4F(u.link_k, base);
+        const KhInt4 n4 = Load4I(u.link_dst, base);
+        tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
+        nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < kMU; j++) {
+          const int lc = base + j < link_frame_e ? base + j : link_frame_e - 1;
+          tc[j] = u.link_k[lc];
+          nsv[j] = u.link_dst[lc];
+        }
+      }
+      bool wrote = false;
+#pragma unroll
+      for (int j = 0; j < kMU; j++) {
+        const int l = base + j;
+        if (l >= link_frame_e || nsv[j] >= -1) continue;   // resolved by an earlier part, or rejected
+        const float tot_cost = tc[j];
+        if (tot_cost != tot_cost || tot_cost > next_cutoff) {
+          nsv[j] = -1;  // rejected (:731; a NaN candidate too)
+          wrote = true;
+          if (!full) u.link_dst[l] = -1;
+          continue;
+        }
+        const int32_t ns = -2 - nsv[j];
+        const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
+        if (part_of(h, parts) != k) continue;
+        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
+        uint32_t slot = lds_slot(h, ns);
+        const uint32_t step = ((h >> 9) | 1u) << kLocBits;
+        while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
+        nsv[j] = static_cast<int32_t>(vals[slot]);
+        wrote = true;
+        if (!full) u.link_dst[l] = nsv[j];
+      }
+      if (full && wrote) {   // the lane owns the four slots: one 16-byte store
+        KhInt4 o4;
+        o4.x = nsv[0]; o4.y = nsv[1]; o4.z = nsv[2]; o4.w = nsv[3];
+        Store4I(u.link_dst, base, o4);
+      }
+    }
+    KhSync();
+  }
+  return true;
+}
+
 // ProcessEmitting :660-750 for frame `frame` (tokens [b, e) -> new tokens appended
 // at sh->tok_end, which becomes the new frontier sh->front_b).  Returns next_cutoff
 // through *next_cutoff_out; false on overflow.
@@ -1155,209 +1376,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   }
   KhSync();
 
-  // ---- pass 2: accept (canonical rule E: tot_cost <= final next_cutoff) and FindOrAddToken +
-  // cost minimum IN LDS.  Every global atomic of this pool executes at the memory side (one
-  // DRAM read-modify-write per lane: TCC_EA0_ATOMIC == TCC_ATOMIC), and the CAS + publish +
-  // min per accepted arc were 85 % of the kernel's atomics.  The accepted candidates are
-  // split by a hash of their state into P parts of <= ~2800 candidates; each part is deduped
-  // in the 4096-slot LDS table (CAS on the key, min on the cost image), the occupied slots get
-  // consecutive token indices from one scan (a deterministic order), the tokens are written
-  // with plain stores and a second sweep gives the part's links their token index.  Only the
-  // tokens the epsilon closure may look up (kEpsDst states) also enter the global hash.
-  {
-    static_assert(kLdsSlots % NT == 0, "slots per lane");
-    auto keys = LdsKeys(sh);
-    auto vals = LdsVals(sh);
-    const float nan = __int_as_float(0x7fc00000);
-    auto part_of = [](uint32_t h, int parts) { return static_cast<int>(((h >> 12) * static_cast<uint32_t>(parts)) >> 20); };
-    // LOCALITY: the table is hashed by BLOCKS of 2^kLocBits consecutive state ids (h = hash of the
-    // block), a block's states take consecutive slots, and the slot scan of (C) numbers the tokens
-    // in slot order — so the tokens of neighbouring states are neighbours in the next frame's
-    // expansion: their arc-offset words share a cache line and their arcs are contiguous in the
-    // arc table (an HCLG numbers the states of an HMM chain / a lexicon-tree branch consecutively).
-#ifndef KH_PART_CAND
-#define KH_PART_CAND 11000   // accepted candidates per part of pass 2 (7 k / 9 k / 13 k / 15 k measured: +6 % / 0 / +1 % / +8 %)
-#endif
-#ifndef KH_LOC_BITS
-#define KH_LOC_BITS 5
-#endif
-    // A state id is the unit index of its record (header + emitting arcs: ~3 units for the states of
-    // an HMM chain), so a block of 2^kLocBits table slots stands for 2^(kLocBits + kLocShift) units.
-#ifndef KH_LOC_SHIFT
-#define KH_LOC_SHIFT 1
-#endif
-    constexpr int kLocBits = KH_LOC_BITS, kLocShift = KH_LOC_SHIFT;
-    auto lds_slot = [](uint32_t h, int32_t ns) {
-      return ((h << kLocBits) | ((static_cast<uint32_t>(ns) >> kLocShift) & ((1u << kLocBits) - 1u))) & (kLdsSlots - 1);
-    };
-    // number of parts: about 11 000 accepted candidates per part (typically half as many
-    // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
-    // parts (the parts nest, and resolved links are marked, so nothing is done twice)
-    int parts = 1;
-    if (link_frame_e - link_frame_b > KH_PART_CAND) {
-      int n_acc_mine = 0;
-      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
-        n_acc_mine += !(u.link_k[l] > next_cutoff) ? 1 : 0;
-      const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
-      while (parts * KH_PART_CAND < n_acc) parts *= 2;
-      if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
-    }
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[31] += link_frame_e - link_frame_b; sh->phase[13] += 0; }
-    for (int k = 0; k < parts; k++) {
-      for (int i = threadIdx.x; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
-      if (threadIdx.x == 0) sh->flag = 0;
-      KhSync();
-      // (B) insert.  A link that an earlier part resolved holds its token index (>= 0), a rejected one -1,
-      // an unresolved one -2 - (next state + flags).  kMU
-      // candidates per lane are loaded before any is used (independent loads in flight).
-      constexpr int kMU = 4;
-      for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
-        float tc[kMU];
-        int32_t nsv[kMU];
-        if (base + kMU <= link_frame_e) {   // a lane owns kMU = 4 consecutive candidates: one 16-byte load per array
-          const KhFloat4 t4 = Load4F(u.link_k, base);
-          const KhInt4 n4 = Load4I(u.link_dst, base);
-          tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
-          nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < kMU; j++) {
-            const int l = base + j;
-            const int lc = l < link_frame_e ? l : link_frame_e - 1;
-            tc[j] = u.link_k[lc];
-            nsv[j] = u.link_dst[lc];
-            if (l >= link_frame_e) tc[j] = nan;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kMU; j++) {
-          const float tot_cost = tc[j];
-          if (nsv[j] >= -1 || tot_cost > next_cutoff || tot_cost != tot_cost) continue;  // :731 "if (tot_cost > next_cutoff) continue"
-          const int32_t ns = -2 - nsv[j];
-          const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
-          if (part_of(h, parts) != k) continue;
-          const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-          uint32_t slot = lds_slot(h, ns);
-          // double hashing BY BLOCK: a block whose place is taken moves as a whole (same offset within
-          // the block, a step that depends on the block only), so its tokens stay neighbours; linear
-          // probing piles the runs of consecutive active states up (pass 2 twice as slow)
-          const uint32_t step = ((h >> 9) | 1u) << kLocBits;
-          int probes = 0;
-          for (; probes < 256; probes++) {
-            uint32_t seen = 0u;
-            __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (seen == 0u || seen == key) break;
-            slot = (slot + step) & (kLdsSlots - 1);
-          }
-          if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
-          (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      KhSync();
-      if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
-        KhSync();                // (every lane has read the flag before it is reset)
-        if (parts >= (1 << 20)) {
-          if (threadIdx.x == 0) sh->status = 5;
-          KhSync();
-          return false;
-        }
-        parts *= 2;
-        k = 2 * k - 1;
-        continue;
-      }
-      // (C) occupied slots -> consecutive token indices; tokens written with plain stores
-      const int tok_base = Uni(sh->tok_end);
-      int occ[kLdsSlots / NT], off[kLdsSlots / NT], total;
-#pragma unroll
-      for (int j = 0; j < kLdsSlots / NT; j++) occ[j] = keys[threadIdx.x + j * NT] != 0u ? 1 : 0;
-      BlockExScanK<kLdsSlots / NT>(occ, off, &total, sh);
-      if (tok_base + total > tok_limit) {
-        if (threadIdx.x == 0) sh->status = 1;
-        KhSync();
-        return false;
-      }
-#pragma unroll
-      for (int j = 0; j < kLdsSlots / NT; j++) {
-        if (!occ[j]) continue;
-        const int i = threadIdx.x + j * NT;
-        const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
-        const int idx = tok_base + off[j];
-        u.tok_state[idx] = ns & kStateMask;
-        u.tok_cost[idx] = vals[i];
-        u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
-        vals[i] = static_cast<uint32_t>(idx);
-        if ((ns & kHasEps) != 0) {
-          // these tokens are the closure's first work list (every one has a finite cost)
-          u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
-          u.tmp_dirty[idx - nb] = 1;
-        }
-        int32_t gslot = -1;
-        if ((ns & kEpsDst) != 0) {  // the closure may look this state up: enter it in the global table
-          const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
-                                          (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
-          uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
-          for (int probes = 0; probes < (1 << 30); probes++) {
-            unsigned long long ent = kEmpty;
-            __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ent == kEmpty) break;
-            g = (g + 1) & u.hash_mask;
-          }
-          gslot = static_cast<int32_t>(g);
-        }
-        u.tmp_slot[idx - nb] = gslot;
-      }
-      if (threadIdx.x == 0) sh->tok_end = tok_base + total;
-      KhSync();
-      // (D) the part's links get their token index; rejected candidates become dead links
-      for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
-        float tc[kMU];
-        int32_t nsv[kMU];
-        const bool full = base + kMU <= link_frame_e;
-        if (full) {
-          const KhFloat4 t4 = Load4F(u.link_k, base);
-          const KhInt4 n4 = Load4I(u.link_dst, base);
-          tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
-          nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < kMU; j++) {
-            const int lc = base + j < link_frame_e ? base + j : link_frame_e - 1;
-            tc[j] = u.link_k[lc];
-            nsv[j] = u.link_dst[lc];
-          }
-        }
-        bool wrote = false;
-#pragma unroll
-        for (int j = 0; j < kMU; j++) {
-          const int l = base + j;
-          if (l >= link_frame_e || nsv[j] >= -1) continue;   // resolved by an earlier part, or rejected
-          const float tot_cost = tc[j];
-          if (tot_cost != tot_cost || tot_cost > next_cutoff) {
-            nsv[j] = -1;  // rejected (:731; a NaN candidate too)
-            wrote = true;
-            if (!full) u.link_dst[l] = -1;
-            continue;
-          }
-          const int32_t ns = -2 - nsv[j];
-          const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
-          if (part_of(h, parts) != k) continue;
-          const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-          uint32_t slot = lds_slot(h, ns);
-          const uint32_t step = ((h >> 9) | 1u) << kLocBits;
-          while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
-          nsv[j] = static_cast<int32_t>(vals[slot]);
-          wrote = true;
-          if (!full) u.link_dst[l] = nsv[j];
-        }
-        if (full && wrote) {   // the lane owns the four slots: one 16-byte store
-          KhInt4 o4;
-          o4.x = nsv[0]; o4.y = nsv[1]; o4.z = nsv[2]; o4.w = nsv[3];
-          Store4I(u.link_dst, base, o4);
-        }
-      }
-      KhSync();
-    }
-  }
+  if (!EmitPass2(u, sh, nb, tok_limit, link_frame_b, link_frame_e, next_cutoff)) return false;
   KhSync();
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
   if (threadIdx.x == 0) {
@@ -1456,15 +1475,26 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
   for (int half = 0; half < 2; half++) {
     for (int sb = 0; sb < bits; sb += kSortBits) {
       const int shift = half * 32 + sb;
-      const Arr<const unsigned long long> kin = cur ? u.x_key1 : u.x_key0;
-      const Arr<const int32_t> vin = cur ? u.x_val1 : u.x_val0;
-      const Arr<unsigned long long> kout = cur ? u.x_key0 : u.x_key1;
-      const Arr<int32_t> vout = cur ? u.x_val0 : u.x_val1;
+      const Arr<const unsigned long long> kin = cur ? UX(x_key1) : UX(x_key0);
+      const Arr<const int32_t> vin = cur ? UX(x_val1) : UX(x_val0);
+      const Arr<unsigned long long> kout = cur ? UX(x_key0) : UX(x_key1);
+      const Arr<int32_t> vout = cur ? UX(x_val0) : UX(x_val1);
       for (int i = threadIdx.x; i < NW * kBins; i += NT) hist[i] = 0u;
       LdsSync();
-      for (int i = s0 + lane; i < s1; i += 64) {
-        const uint32_t d = static_cast<uint32_t>(kin[i] >> shift) & (kBins - 1);
-        __hip_atomic_fetch_add(&hist[w * kBins + d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      constexpr int kTU = 4;   // tiles of a wave's segment whose loads are in flight together (the passes are latency-bound)
+      for (int base = s0; base < s1; base += 64 * kTU) {
+        unsigned long long k4[kTU];
+#pragma unroll
+        for (int j = 0; j < kTU; j++) {
+          const int i = base + j * 64 + lane;
+          k4[j] = i < s1 ? kin[i] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < kTU; j++) {
+          if (base + j * 64 + lane < s1)
+            __hip_atomic_fetch_add(&hist[w * kBins + (static_cast<uint32_t>(k4[j] >> shift) & (kBins - 1))], 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
       LdsSync();
       {  // exclusive scan in (digit, wave) order: entry idx = digit * NW + wave; a lane owns NW * kBins / NT consecutive entries
@@ -1488,25 +1518,34 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
         }
       }
       LdsSync();
-      for (int base = s0; base < s1; base += 64) {   // (uniform over the wave)
-        const int i = base + lane;
-        const bool act = i < s1;
-        const unsigned long long key = act ? kin[i] : 0ull;
-        const int32_t val = act ? vin[i] : 0;
-        const uint32_t d = static_cast<uint32_t>(key >> shift) & (kBins - 1);
-        unsigned long long peers = __ballot(act);
+      for (int base = s0; base < s1; base += 64 * kTU) {   // (uniform over the wave)
+        unsigned long long k4[kTU];
+        int32_t v4[kTU];
 #pragma unroll
-        for (int bit = 0; bit < kSortBits; bit++) {
-          const bool set = ((d >> bit) & 1u) != 0u;
-          const unsigned long long m = __ballot(set);
-          peers &= set ? m : ~m;
+        for (int j = 0; j < kTU; j++) {
+          const int i = base + j * 64 + lane;
+          k4[j] = i < s1 ? kin[i] : 0ull;
+          v4[j] = i < s1 ? vin[i] : 0;
         }
-        if (act) {
-          const int rank = __popcll(peers & ((1ull << lane) - 1ull));
-          const uint32_t at = hist[w * kBins + d];
-          if (rank == 0) hist[w * kBins + d] = at + static_cast<uint32_t>(__popcll(peers));
-          kout[at + rank] = key;
-          vout[at + rank] = val;
+#pragma unroll
+        for (int j = 0; j < kTU; j++) {
+          const bool act = base + j * 64 + lane < s1;
+          const uint32_t d = static_cast<uint32_t>(k4[j] >> shift) & (kBins - 1);
+          unsigned long long peers = __ballot(act);
+          if (peers == 0ull) continue;
+#pragma unroll
+          for (int bit = 0; bit < kSortBits; bit++) {
+            const bool set = ((d >> bit) & 1u) != 0u;
+            const unsigned long long m = __ballot(set);
+            peers &= set ? m : ~m;
+          }
+          if (act) {
+            const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+            const uint32_t at = hist[w * kBins + d];
+            if (rank == 0) hist[w * kBins + d] = at + static_cast<uint32_t>(__popcll(peers));
+            kout[at + rank] = k4[j];
+            vout[at + rank] = v4[j];
+          }
         }
       }
       KhSync();   // the scattered pairs are the next pass's input
@@ -1529,7 +1568,7 @@ __device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack
   const int hi_cap = u.link_frame_cap;
   while (top > 0) {
     --top;
-    const int uu = top < lo_cap ? stack_lo[top] : u.x_stack[top - lo_cap];
+    const int uu = top < lo_cap ? stack_lo[top] : UX(x_stack)[top - lo_cap];
     const float c = ncost[uu];
     if (c > cutoff) continue;   // :779
     const int l1 = nl1[uu];
@@ -1540,12 +1579,12 @@ __device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack
       if (!(tot < cutoff)) continue;   // :794
       if ((code & 0x40000000) != 0) {
         const int k = code & 0x3fffffff;
-        if (u.x_q[k] == 0xFFFFFFFFu) u.x_q[k] = qbase + static_cast<uint32_t>(cnt++);   // FindOrAddToken inserts it; changed, pushed, popped without effect
+        if (UX(x_q)[k] == 0xFFFFFFFFu) UX(x_q)[k] = qbase + static_cast<uint32_t>(cnt++);   // FindOrAddToken inserts it; changed, pushed, popped without effect
       } else {
         const float cv = ncost[code];
         bool push = false;
         if (cv == INFINITY) {   // new: inserted, changed
-          u.x_q[u.tmp_epslist[code] - nb] = qbase + static_cast<uint32_t>(cnt++);
+          UX(x_q)[u.tmp_epslist[code] - nb] = qbase + static_cast<uint32_t>(cnt++);
           push = true;
         } else if (tot < cv) {  // :252-254 cheaper: changed
           push = true;
@@ -1553,7 +1592,7 @@ __device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack
         if (push) {
           ncost[code] = tot;
           if (top < lo_cap) stack_lo[top] = code;
-          else if (top - lo_cap < hi_cap) u.x_stack[top - lo_cap] = code;
+          else if (top - lo_cap < hi_cap) UX(x_stack)[top - lo_cap] = code;
           else return -1;
           top++;
         }
@@ -1563,6 +1602,103 @@ __device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack
   return cnt;
 }
 
+// The same replay by ONE WAVE with all its state in LDS.  Most pops change nothing (a word-end token whose epsilon arc
+// leads to a language-model state that an earlier pop has already given a cheaper cost): the wave takes the next 64 queue
+// entries, every lane evaluates its entry against the CURRENT costs, and only the first lane whose pop would insert or
+// improve something is executed (by lane 0, depth first with an LDS stack, exactly as the queue would run it); the lanes
+// before it are no-ops - costs only fall, and nothing has changed since they were evaluated - and the lanes after it are
+// evaluated again.  LDS link codes: -1 dead; 0x40000000 | (token - ne_emit) a token without epsilon arcs the closure
+// creates; else entry of tmp_epslist in bits 0-11 and, if the closure creates that token, (token - ne_emit) + 1 in bits 12-.
+// queue: the initial queue in list order (popped from its end).  Returns the insertions, -1 if the depth-first stack
+// outgrew its LDS array (the caller then runs ReplayClosure from memory).
+constexpr int kRpNodes = kLdsSlots / 4, kRpLinks = kLdsSlots / 2;
+typedef __attribute__((address_space(3))) float *LdsF;
+typedef __attribute__((address_space(3))) int *LdsI;
+__device__ int ReplayClosureWave(LdsF ncost, LdsI nlr, LdsI dstack, LdsI newq, LdsI lcode, LdsF lw, Arr<const int32_t> queue, int n_queue,
+                                 float cutoff) {
+  const int lane = threadIdx.x & 63;
+  int cnt = 0;
+  for (int top = n_queue; top > 0; top -= 64) {   // uniform
+    const int bsz = min(64, top);
+    const int node = lane < bsz ? queue[top - 1 - lane] : -1;   // lane j holds the j-th pop from here
+    unsigned long long pending = __ballot(lane < bsz);
+    while (pending != 0ull) {
+      bool act = false;
+      if (((pending >> lane) & 1ull) != 0ull) {
+        const float c = ncost[node];
+        if (!(c > cutoff)) {
+          const int r = nlr[node];
+          for (int l = r & 0xffff; l < (r >> 16) && !act; l++) {
+            const int code = lcode[l];
+            if (code < 0) continue;
+            const float tot = c + lw[l];
+            if (!(tot < cutoff)) continue;
+            if ((code & 0x40000000) != 0) {
+              act = newq[code & 0x3fffffff] < 0;
+            } else {
+              const float cv = ncost[code & 0xfff];
+              act = cv == INFINITY || tot < cv;
+            }
+          }
+        }
+      }
+      const unsigned long long am = __ballot(act) & pending;
+      if (am == 0ull) break;
+      const int L = Uni(__ffsll(static_cast<long long>(am)) - 1);
+      pending &= ~((2ull << L) - 1ull);
+      const int first = __builtin_amdgcn_readlane(node, L);
+      if (lane == 0) {   // the pop of `first` and everything it pushes, depth first
+        int sp = 0;
+        dstack[sp++] = first;
+        while (sp > 0) {
+          const int uu = dstack[--sp];
+          const float c = ncost[uu];
+          if (c > cutoff) continue;   // :779
+          const int r = nlr[uu];
+          for (int l = r & 0xffff; l < (r >> 16); l++) {
+            const int code = lcode[l];
+            if (code < 0) continue;
+            const float tot = c + lw[l];
+            if (!(tot < cutoff)) continue;   // :794
+            if ((code & 0x40000000) != 0) {
+              const int k = code & 0x3fffffff;
+              if (newq[k] < 0) newq[k] = cnt++;
+            } else {
+              const int v = code & 0xfff;
+              const float cv = ncost[v];
+              bool push = false;
+              if (cv == INFINITY) {
+                newq[(code >> 12) - 1] = cnt++;
+                push = true;
+              } else if (tot < cv) {
+                push = true;
+              }
+              if (push) {
+                ncost[v] = tot;
+                if (sp >= kRpNodes) { cnt = -1; sp = 0; break; }
+                dstack[sp++] = v;
+              }
+            }
+          }
+        }
+      }
+      cnt = __builtin_amdgcn_readfirstlane(cnt);
+      if (cnt < 0) return -1;
+    }
+  }
+  return cnt;
+}
+
+// Diagnostic: cycles since the previous SubStamp / Stamp of this workgroup into phase[ph] WITHOUT moving the phase timer
+// (sub-phases of a phase that Stamp charges as a whole).
+__device__ __forceinline__ void SubStamp(const Utt &u, Blk &sh, int ph) {
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh->phase[ph] += now - sh->t_sub;
+    sh->t_sub = now;
+  }
+}
+
 // List positions (x_pos) of the frame under construction, tokens [nb, fe): the emitting pass made [nb, ne_emit) with
 // their insertion keys in x_q and their costs in x_cost0; the closure has converged and the frame's epsilon links are
 // the block [lb, le).  Leaves x_bmin all ones.  Returns false on a capacity overflow (sh->status).
@@ -1570,97 +1706,134 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
   const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
   const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
   const int nl = le - lb;
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    sh->t_sub = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh->phase[47] += 1; sh->phase[52] += eps_emit; sh->phase[53] += eps_n; sh->phase[54] += nl; sh->phase[55] += fe - ne_emit; sh->phase[46] += n;
+  }
   // buckets; first occupation among the emitting pass's tokens; closure replay tables
   for (int i = nb + threadIdx.x; i < fe; i += NT) {
     const int32_t sid = -1 - p.unit_ilabel[u.tok_state[i]];   // the caller's state id (what the reference hashes)
     const int32_t bk = static_cast<int32_t>(static_cast<uint32_t>(sid) % H);
-    u.x_bkt[i - nb] = bk;
-    u.x_epsidx[i - nb] = -1;
-    if (i < ne_emit) __hip_atomic_fetch_min(&u.x_bmin[bk], u.x_q[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else u.x_q[i - nb] = 0xFFFFFFFFu;
+    UX(x_bkt)[i - nb] = bk;
+    UX(x_epsidx)[i - nb] = -1;
+    if (i < ne_emit) __hip_atomic_fetch_min(&UX(x_bmin)[bk], UX(x_q)[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else UX(x_q)[i - nb] = 0xFFFFFFFFu;
   }
   KhSync();
   for (int j = threadIdx.x; j < eps_n; j += NT) {
     const int tok = u.tmp_epslist[j];
-    u.x_epsidx[tok - nb] = j;
-    u.x_nl0[j] = 0;
-    u.x_nl1[j] = 0;
-    u.x_ncost[j] = tok < ne_emit ? Dec(u.x_cost0[tok - nb]) : INFINITY;
+    UX(x_epsidx)[tok - nb] = j;
+    UX(x_nl0)[j] = 0;
+    UX(x_nl1)[j] = 0;
+    UX(x_ncost)[j] = tok < ne_emit ? Dec(UX(x_cost0)[tok - nb]) : INFINITY;
     if (j < eps_emit) {   // (the first eps_emit entries are the emitting pass's: the queue's initial content, :766-767)
-      u.x_key0[j] = (static_cast<unsigned long long>(__hip_atomic_load(&u.x_bmin[u.x_bkt[tok - nb]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) |
-                    u.x_q[tok - nb];
-      u.x_val0[j] = j;
+      UX(x_key0)[j] = (static_cast<unsigned long long>(__hip_atomic_load(&UX(x_bmin)[UX(x_bkt)[tok - nb]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) |
+                    UX(x_q)[tok - nb];
+      UX(x_val0)[j] = j;
     }
   }
   KhSync();
   for (int l = lb + threadIdx.x; l < le; l += NT) {
     const int src = u.link_src[l], dst = u.link_dst[l];
-    const int j = u.x_epsidx[src - nb];
-    if (l == lb || u.link_src[l - 1] != src) u.x_nl0[j] = l - lb;
-    if (l + 1 == le || u.link_src[l + 1] != src) u.x_nl1[j] = l - lb + 1;
+    const int j = UX(x_epsidx)[src - nb];
+    if (l == lb || u.link_src[l - 1] != src) UX(x_nl0)[j] = l - lb;
+    if (l + 1 == le || u.link_src[l + 1] != src) UX(x_nl1)[j] = l - lb + 1;
     int code = -1;
     if (dst >= 0) {
-      const int e = u.x_epsidx[dst - nb];
+      const int e = UX(x_epsidx)[dst - nb];
       if (e >= 0) code = e;
       else if (dst >= ne_emit) code = 0x40000000 | (dst - nb);
     }
-    u.x_ord[l - lb] = code;
-    u.x_lw[l - lb] = __int_as_float(p.n_arcs[-1 - u.link_arc[l]].z);
+    UX(x_ord)[l - lb] = code;
+    UX(x_lw)[l - lb] = __int_as_float(p.n_arcs[-1 - u.link_arc[l]].z);
   }
   const int bits = 32 - __clz(static_cast<int>(qbase + static_cast<uint32_t>(fe - ne_emit)) | 1);
-  const int sb = eps_emit > 1 ? BlockRadixSort(u, eps_emit, bits, sh) : 0;   // (its first barrier orders the writes above)
   KhSync();
-  const Arr<const int32_t> sorted = sb ? u.x_val1 : u.x_val0;
-  // ---- closure replay from LDS when the frame's epsilon structure fits (it nearly always does), else from memory
-  constexpr int kNodeCap = kLdsSlots / 4, kLinkCap = kLdsSlots / 2;
-  const bool in_lds = eps_n <= kNodeCap && nl <= kLinkCap;   // (the dynamic LDS block holds at least kLdsSlots words: DynLdsBytes)
-  auto l_ncost = (__attribute__((address_space(3))) float *)LdsKeys(sh);
-  auto l_nl0 = (__attribute__((address_space(3))) int *)(LdsKeys(sh) + kNodeCap);
-  auto l_nl1 = (__attribute__((address_space(3))) int *)(LdsKeys(sh) + 2 * kNodeCap);
-  auto l_stack = (__attribute__((address_space(3))) int *)(LdsKeys(sh) + 3 * kNodeCap);
-  auto l_code = (__attribute__((address_space(3))) int *)LdsVals(sh);
-  auto l_lw = (__attribute__((address_space(3))) float *)(LdsVals(sh) + kLinkCap);
+  SubStamp(u, sh, 48);
+  // ---- the queue's initial content in list order -> x_stack[0, eps_emit)
+  if (eps_emit <= 1) {
+    if (threadIdx.x == 0 && eps_emit == 1) UX(x_stack)[0] = 0;
+  } else {   // (ranking a few hundred keys by counting over an LDS copy measured 4 x slower than these four passes)
+    const int sb = BlockRadixSort(u, eps_emit, bits, sh);
+    const Arr<const int32_t> sorted = sb ? UX(x_val1) : UX(x_val0);
+    for (int j = threadIdx.x; j < eps_emit; j += NT) UX(x_stack)[j] = sorted[j];
+  }
+  KhSync();
+  SubStamp(u, sh, 49);
+  // ---- closure replay: by one wave from LDS when the frame's epsilon structure fits (it nearly always does), else by
+  // one lane from memory
+  const int n_new = fe - ne_emit;
+  bool in_lds = eps_n <= kRpNodes && nl <= kRpLinks && n_new <= kRpNodes;
+  LdsF l_ncost = (LdsF)LdsKeys(sh);
+  LdsI l_nlr = (LdsI)(LdsKeys(sh) + kRpNodes);
+  LdsI l_dstack = (LdsI)(LdsKeys(sh) + 2 * kRpNodes);
+  LdsI l_newq = (LdsI)(LdsKeys(sh) + 3 * kRpNodes);
+  LdsI l_code = (LdsI)LdsVals(sh);
+  LdsF l_lw = (LdsF)(LdsVals(sh) + kRpLinks);
   if (in_lds) {
     for (int j = threadIdx.x; j < eps_n; j += NT) {
-      l_ncost[j] = u.x_ncost[j];
-      l_nl0[j] = u.x_nl0[j];
-      l_nl1[j] = u.x_nl1[j];
+      l_ncost[j] = UX(x_ncost)[j];
+      l_nlr[j] = UX(x_nl0)[j] | (UX(x_nl1)[j] << 16);
     }
-    for (int j = threadIdx.x; j < eps_emit; j += NT) l_stack[j] = sorted[j];
+    for (int k = threadIdx.x; k < n_new; k += NT) l_newq[k] = -1;
     for (int l = threadIdx.x; l < nl; l += NT) {
-      l_code[l] = u.x_ord[l];
-      l_lw[l] = u.x_lw[l];
+      int code = UX(x_ord)[l];
+      if (code >= 0) {
+        if ((code & 0x40000000) != 0) {
+          code = 0x40000000 | ((code & 0x3fffffff) - (ne_emit - nb));
+        } else {
+          const int tok = u.tmp_epslist[code];
+          code |= (tok >= ne_emit ? tok - ne_emit + 1 : 0) << 12;
+        }
+      }
+      l_code[l] = code;
+      l_lw[l] = UX(x_lw)[l];
     }
-  } else {
-    for (int j = threadIdx.x; j < eps_emit; j += NT) u.x_stack[j] = sorted[j];
+    KhSync();
+    if (threadIdx.x < 64) {
+      const int cnt = ReplayClosureWave(l_ncost, l_nlr, l_dstack, l_newq, l_code, l_lw, UX(x_stack), eps_emit, cutoff);
+      if (threadIdx.x == 0) sh->x_n_new = cnt;
+    }
+    KhSync();
+    in_lds = Uni(sh->x_n_new) >= 0;   // (-1: the depth-first stack outgrew LDS - from memory then)
+    if (in_lds) {
+      bool bad = false;
+      for (int k = threadIdx.x; k < n_new; k += NT) {
+        const int q = l_newq[k];
+        bad |= q < 0;
+        UX(x_q)[ne_emit - nb + k] = qbase + static_cast<uint32_t>(q);
+      }
+      // every token the closure created was inserted by the replay (the parallel fixed point and the queue reach the same set)
+      if (bad || Uni(sh->x_n_new) != n_new) sh->status = 8;
+    }
+  }
+  if (!in_lds) {
+    KhSync();
+    if (threadIdx.x == 0) {
+      const int cnt = ReplayClosure((GP(float))UX(x_ncost).p, (GP(int32_t))UX(x_nl0).p, (GP(int32_t))UX(x_nl1).p, (GP(int32_t))UX(x_ord).p,
+                                    (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, eps_emit, cutoff, nb, qbase);
+      if (cnt != n_new) sh->status = cnt < 0 ? 3 : 8;
+    }
   }
   KhSync();
-  if (threadIdx.x == 0) {
-    int cnt;
-    if (in_lds) cnt = ReplayClosure(l_ncost, l_nl0, l_nl1, l_code, l_lw, l_stack, kNodeCap, u, eps_emit, cutoff, nb, qbase);
-    else cnt = ReplayClosure((GP(float))u.x_ncost.p, (GP(int32_t))u.x_nl0.p, (GP(int32_t))u.x_nl1.p, (GP(int32_t))u.x_ord.p, (GP(float))u.x_lw.p,
-                             (GP(int32_t))u.x_stack.p, 0, u, eps_emit, cutoff, nb, qbase);
-    // every token the closure created was inserted by the replay (the parallel fixed point and the queue reach the same set)
-    if (cnt != fe - ne_emit) sh->status = cnt < 0 ? 3 : 8;
-    sh->x_n_new = cnt;
-  }
-  KhSync();
+  SubStamp(u, sh, 50);
   if (Uni(sh->status) != 0) return false;
   // ---- the closure's tokens enter their buckets; key = (first occupation of the bucket, insertion key); sort
   for (int i = ne_emit + threadIdx.x; i < fe; i += NT)
-    __hip_atomic_fetch_min(&u.x_bmin[u.x_bkt[i - nb]], u.x_q[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_min(&UX(x_bmin)[UX(x_bkt)[i - nb]], UX(x_q)[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   KhSync();
   for (int i = threadIdx.x; i < n; i += NT) {
-    u.x_key0[i] = (static_cast<unsigned long long>(__hip_atomic_load(&u.x_bmin[u.x_bkt[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) | u.x_q[i];
-    u.x_val0[i] = i;
+    UX(x_key0)[i] = (static_cast<unsigned long long>(__hip_atomic_load(&UX(x_bmin)[UX(x_bkt)[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) | UX(x_q)[i];
+    UX(x_val0)[i] = i;
   }
   KhSync();
-  for (int i = threadIdx.x; i < n; i += NT) u.x_bmin[u.x_bkt[i]] = 0xFFFFFFFFu;   // the table's invariant between frames
+  for (int i = threadIdx.x; i < n; i += NT) UX(x_bmin)[UX(x_bkt)[i]] = 0xFFFFFFFFu;   // the table's invariant between frames
   const int fb2 = n > 1 ? BlockRadixSort(u, n, bits, sh) : 0;
   KhSync();
-  const Arr<const int32_t> order = fb2 ? u.x_val1 : u.x_val0;
-  for (int r = threadIdx.x; r < n; r += NT) u.x_pos[order[r]] = r;
+  const Arr<const int32_t> order = fb2 ? UX(x_val1) : UX(x_val0);
+  for (int r = threadIdx.x; r < n; r += NT) UX(x_pos)[order[r]] = r;
   KhSync();
+  SubStamp(u, sh, 51);
   return true;
 }
 
@@ -1764,9 +1937,9 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       if (has) acc = fminf(acc, got);
     }
     if (in_range) {
-      const int pos = u.x_pos[i - b];
-      u.x_m[pos] = Enc(acc + c.adaptive_beam);   // (+inf for a token without arcs or above the cutoff)
-      u.x_c[pos] = cnt;
+      const int pos = UX(x_pos)[i - b];
+      UX(x_m)[pos] = Enc(acc + c.adaptive_beam);   // (+inf for a token without arcs or above the cutoff)
+      UX(x_c)[pos] = cnt;
     }
     if (lane == 0) my_arcs += total;
   }
@@ -1778,14 +1951,14 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   for (int base = 0; base < n; base += NT) {
     const int q = base + threadIdx.x;
     const bool valid = q < n;
-    const uint32_t m = valid ? u.x_m[q] : 0xFFFFFFFFu;
-    const int cnt = valid ? u.x_c[q] : 0;
+    const uint32_t m = valid ? UX(x_m)[q] : 0xFFFFFFFFu;
+    const int cnt = valid ? UX(x_c)[q] : 0;
     int ex_sum, tot_sum;
     uint32_t ex_min, tot_min;
     BlockExScanSumMin(cnt, m, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
     if (valid) {
-      u.x_m[q] = run_min < ex_min ? run_min : ex_min;
-      u.x_c[q] = run_sum + ex_sum;
+      UX(x_m)[q] = run_min < ex_min ? run_min : ex_min;
+      UX(x_c)[q] = run_sum + ex_sum;
     }
     run_min = run_min < tot_min ? run_min : tot_min;
     run_sum += tot_sum;
@@ -1819,9 +1992,9 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       ab = st + 1;
       cnt = p.rec[st].x;
     }
-    const int pos = u.x_pos[ic - b];
-    const float r_tok = Dec(u.x_m[pos]);
-    const int a_tok = u.x_c[pos];
+    const int pos = UX(x_pos)[ic - b];
+    const float r_tok = Dec(UX(x_m)[pos]);
+    const int a_tok = UX(x_c)[pos];
     int inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1888,7 +2061,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           u.link_arc[l] = ai;
           if (p.keep_ac) u.link_a[l] = ac;
           u.link_k[l] = tot;
-          u.x_ord[l - link_frame_b] = o_a + (q - o_off);
+          UX(x_ord)[l - link_frame_b] = o_a + (q - o_off);
         }
       }
     }
@@ -1904,113 +2077,30 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     sh->cand_mat += link_frame_e - link_frame_b;
   }
   KhSync();
-  // ---- pass 2: FindOrAddToken + minimum cost + minimum ordinal (= the state's insertion key) in an LDS table of
-  // kXSlots slots: keys | ordinals over the static area, costs over the dynamic one.  Every candidate here is accepted.
+  // ---- pass 2: FindOrAddToken + minimum cost in the LDS token table, as in the canonical sweep (every candidate here
+  // has been accepted: no cutoff test)
+  if (!EmitPass2(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf)) return false;
+  // ---- the insertion key of a new token = the smallest ordinal among its candidates (the arc that made the reference
+  // call HashList::Insert for it); its cost before the closure
   {
-    constexpr int kXSlots = kLdsSlots / 2;
-    static_assert(kXSlots % NT == 0, "slots per lane");
-    auto keys = LdsKeys(sh);
-    auto ords = LdsKeys(sh) + kXSlots;
-    auto vals = LdsVals(sh);
-    constexpr int kLocBits = KH_LOC_BITS, kLocShift = KH_LOC_SHIFT;
-    auto part_of = [](uint32_t h, int parts) { return static_cast<int>(((h >> 12) * static_cast<uint32_t>(parts)) >> 20); };
-    auto lds_slot = [](uint32_t h, int32_t ns) {
-      return ((h << kLocBits) | ((static_cast<uint32_t>(ns) >> kLocShift) & ((1u << kLocBits) - 1u))) & (kXSlots - 1);
-    };
-    int parts = 1;
-    while (parts * (KH_PART_CAND / 2) < link_frame_e - link_frame_b) parts *= 2;
-    for (int k = 0; k < parts; k++) {
-      for (int i = threadIdx.x; i < kXSlots; i += NT) { keys[i] = 0u; ords[i] = 0xFFFFFFFFu; vals[i] = 0xFFFFFFFFu; }
-      if (threadIdx.x == 0) sh->flag = 0;
-      KhSync();
-      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-        const int32_t nsv = u.link_dst[l];
-        if (nsv >= -1) continue;   // resolved by an earlier part
-        const int32_t ns = -2 - nsv;
-        const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
-        if (part_of(h, parts) != k) continue;
-        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-        uint32_t slot = lds_slot(h, ns);
-        const uint32_t step = ((h >> 9) | 1u) << kLocBits;
-        int probes = 0;
-        for (; probes < 256; probes++) {
-          uint32_t seen = 0u;
-          __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (seen == 0u || seen == key) break;
-          slot = (slot + step) & (kXSlots - 1);
-        }
-        if (probes == 256) { sh->flag = 1; continue; }
-        (void)__hip_atomic_fetch_min(&vals[slot], Enc(u.link_k[l]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        (void)__hip_atomic_fetch_min(&ords[slot], static_cast<uint32_t>(u.x_ord[l - link_frame_b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      KhSync();
-      if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
-        KhSync();
-        if (parts >= (1 << 20)) {
-          if (threadIdx.x == 0) sh->status = 5;
-          KhSync();
-          return false;
-        }
-        parts *= 2;
-        k = 2 * k - 1;
-        continue;
-      }
-      const int tok_base = Uni(sh->tok_end);
-      int occ[kXSlots / NT], off[kXSlots / NT], total;
-#pragma unroll
-      for (int j = 0; j < kXSlots / NT; j++) occ[j] = keys[threadIdx.x + j * NT] != 0u ? 1 : 0;
-      BlockExScanK<kXSlots / NT>(occ, off, &total, sh);
-      if (tok_base + total > tok_limit) {
-        if (threadIdx.x == 0) sh->status = 1;
-        KhSync();
-        return false;
-      }
-#pragma unroll
-      for (int j = 0; j < kXSlots / NT; j++) {
-        if (!occ[j]) continue;
-        const int i = threadIdx.x + j * NT;
-        const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
-        const int idx = tok_base + off[j];
-        u.tok_state[idx] = ns & kStateMask;
-        u.tok_cost[idx] = vals[i];
-        u.tok_extra[idx] = 0.0f;
-        u.x_q[idx - nb] = ords[i];
-        u.x_cost0[idx - nb] = vals[i];
-        vals[i] = static_cast<uint32_t>(idx);
-        if ((ns & kHasEps) != 0) {
-          u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
-          u.tmp_dirty[idx - nb] = 1;
-        }
-        int32_t gslot = -1;
-        if ((ns & kEpsDst) != 0) {
-          const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
-                                          (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
-          uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
-          for (int probes = 0; probes < (1 << 30); probes++) {
-            unsigned long long ent = kEmpty;
-            __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ent == kEmpty) break;
-            g = (g + 1) & u.hash_mask;
-          }
-          gslot = static_cast<int32_t>(g);
-        }
-        u.tmp_slot[idx - nb] = gslot;
-      }
-      if (threadIdx.x == 0) sh->tok_end = tok_base + total;
-      KhSync();
-      for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-        const int32_t nsv = u.link_dst[l];
-        if (nsv >= -1) continue;
-        const int32_t ns = -2 - nsv;
-        const uint32_t h = HashState((ns & kStateMask) >> (kLocBits + kLocShift));
-        if (part_of(h, parts) != k) continue;
-        const uint32_t key = static_cast<uint32_t>(ns) + 1u;
-        uint32_t slot = lds_slot(h, ns);
-        const uint32_t step = ((h >> 9) | 1u) << kLocBits;
-        while (keys[slot] != key) slot = (slot + step) & (kXSlots - 1);
-        u.link_dst[l] = static_cast<int32_t>(vals[slot]);
-      }
-      KhSync();
+    const int n_new = Uni(sh->tok_end) - nb;
+    auto qtab = LdsKeys(sh);
+    const bool in_lds = n_new <= kLdsSlots;
+    for (int i = threadIdx.x; i < n_new; i += NT) {
+      if (in_lds) qtab[i] = 0xFFFFFFFFu; else UX(x_q)[i] = 0xFFFFFFFFu;
+    }
+    KhSync();
+    for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
+      const int dst = u.link_dst[l];
+      if (dst < 0) continue;   // (a dropped NaN candidate)
+      const uint32_t ord = static_cast<uint32_t>(UX(x_ord)[l - link_frame_b]);
+      if (in_lds) (void)__hip_atomic_fetch_min(&qtab[dst - nb], ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else (void)__hip_atomic_fetch_min(&UX(x_q)[dst - nb], ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    KhSync();
+    for (int i = threadIdx.x; i < n_new; i += NT) {
+      if (in_lds) UX(x_q)[i] = qtab[i];
+      UX(x_cost0)[i] = u.tok_cost[nb + i];
     }
   }
   KhSync();
@@ -3033,8 +3123,8 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->wl_n[0] = sh->eps_n;  // 1 if the start state has epsilon arcs: the closure's first work list
     sh->wl_n[1] = 0;
     if (kExact) {   // the start token is the first insertion (:66) into a table of 1000 buckets (:37)
-      u.x_q[0] = 0u;
-      u.x_cost0[0] = Enc(0.0f);
+      UX(x_q)[0] = 0u;
+      UX(x_cost0)[0] = Enc(0.0f);
       sh->x_hsize = 1000u;
       sh->x_qbase = 1u;
       sh->x_ne_emit = sh->tok_end;
@@ -3423,7 +3513,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     // (a capacity overflow aborts a frame with work-list flags still set: clear them too)
     for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
     if (kExact)   // (an aborted frame may have left bucket minima behind)
-      for (int i = threadIdx.x; i < u.x_hcap; i += NT) u.x_bmin[i] = 0xFFFFFFFFu;
+      for (int i = threadIdx.x; i < u.x->x_hcap; i += NT) UX(x_bmin)[i] = 0xFFFFFFFFu;
     KhSync();
     KhDecodeStats st;
     DecodeOne<kLazy, kExact>(u, p, sh, &st);
@@ -3603,6 +3693,8 @@ struct KhDecoder {
   int exact = 0, slab_exact = 0;          // kh_decoder_set_reference_order; whether the slab holds the exact-order temporaries
   std::vector<Utt> h_slots;
   Utt *d_slots = nullptr;
+  std::vector<UttX> h_slotsx;      // exact reference order: the slots' temporaries (Utt::x points into d_slotsx)
+  UttX *d_slotsx = nullptr;
   UttIn *d_in = nullptr;
   UttOut *d_out = nullptr;
   unsigned long long *d_used = nullptr;
@@ -3804,7 +3896,7 @@ ArenaCaps LazyCaps(const ArenaCaps &floor, int T, int tok_frame_cap, int link_fr
 
 // Arena set of one slot, sized for utterances of up to T frames.
 void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, const ArenaCaps &caps, bool link_a,
-               float hash_ratio, int expected_tokens, bool exact) {
+               float hash_ratio, int expected_tokens, bool exact, UttX *xo = nullptr, int scale = 1) {
   u.T = T;
   u.tok_frame_cap = tok_frame_cap;
   u.link_frame_cap = link_frame_cap;
@@ -3840,8 +3932,8 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.tmp_acc1 = c.Take<uint32_t>(tok_frame_cap);
   // survivor lists of FinalBackward: ~4 x the lattice density the recipe's options give (17 states / 27 arcs per frame);
   // an utterance that needs more is decoded again with everything doubled (tok_frame_cap scales with the retry)
-  u.surv_tok_cap = static_cast<int32_t>(std::min<long long>(caps.tok, 64ll * (T + 2) + tok_frame_cap));
-  u.surv_link_cap = static_cast<int32_t>(std::min<long long>(caps.link, 128ll * (T + 2) + 2ll * tok_frame_cap));
+  u.surv_tok_cap = static_cast<int32_t>(std::min<long long>(caps.tok, 64ll * scale * (T + 2) + tok_frame_cap));
+  u.surv_link_cap = static_cast<int32_t>(std::min<long long>(caps.link, 128ll * scale * (T + 2) + 2ll * tok_frame_cap));
   u.surv_tok = c.Take<int32_t>(2 * static_cast<size_t>(u.surv_tok_cap));
   u.surv_link = c.Take<int32_t>(2 * static_cast<size_t>(u.surv_link_cap));
   // hash_ratio x the tokens a frame is expected to hold (lattice-faster-decoder.cc:193-199
@@ -3853,27 +3945,30 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
   u.hash = c.Take<unsigned long long>(hs);
   // exact reference order: per-frame temporaries (8 MB per slot at the default caps)
   {
+    UttX x;
     const size_t tf = exact ? tok_frame_cap : 0, lf = exact ? link_frame_cap : 0;
     // the reference's table has at most hash_ratio x (tokens of a frame) buckets, 1000 to begin with (:37, :219-225)
-    u.x_hcap = exact ? static_cast<int32_t>(std::max<double>(1000.0, static_cast<double>(hash_ratio) * tok_frame_cap) + 16) : 0;
-    u.x_pos = c.Take<int32_t>(tf);
-    u.x_m = c.Take<uint32_t>(tf);
-    u.x_c = c.Take<int32_t>(tf);
-    u.x_q = c.Take<uint32_t>(tf);
-    u.x_cost0 = c.Take<uint32_t>(tf);
-    u.x_bkt = c.Take<int32_t>(tf);
-    u.x_epsidx = c.Take<int32_t>(tf);
-    u.x_nl0 = c.Take<int32_t>(tf);
-    u.x_nl1 = c.Take<int32_t>(tf);
-    u.x_ncost = c.Take<float>(tf);
-    u.x_ord = c.Take<int32_t>(lf);
-    u.x_lw = c.Take<float>(lf);
-    u.x_stack = c.Take<int32_t>(lf);
-    u.x_bmin = c.Take<uint32_t>(static_cast<size_t>(u.x_hcap));
-    u.x_key0 = c.Take<unsigned long long>(tf);
-    u.x_key1 = c.Take<unsigned long long>(tf);
-    u.x_val0 = c.Take<int32_t>(tf);
-    u.x_val1 = c.Take<int32_t>(tf);
+    x.x_hcap = exact ? static_cast<int32_t>(std::max<double>(1000.0, static_cast<double>(hash_ratio) * tok_frame_cap) + 16) : 0;
+    x.x_pos = c.Take<int32_t>(tf);
+    x.x_m = c.Take<uint32_t>(tf);
+    x.x_c = c.Take<int32_t>(tf);
+    x.x_q = c.Take<uint32_t>(tf);
+    x.x_cost0 = c.Take<uint32_t>(tf);
+    x.x_bkt = c.Take<int32_t>(tf);
+    x.x_epsidx = c.Take<int32_t>(tf);
+    x.x_nl0 = c.Take<int32_t>(tf);
+    x.x_nl1 = c.Take<int32_t>(tf);
+    x.x_ncost = c.Take<float>(tf);
+    x.x_ord = c.Take<int32_t>(lf);
+    x.x_lw = c.Take<float>(lf);
+    x.x_stack = c.Take<int32_t>(lf);
+    x.x_bmin = c.Take<uint32_t>(static_cast<size_t>(x.x_hcap));
+    x.x_key0 = c.Take<unsigned long long>(tf);
+    x.x_key1 = c.Take<unsigned long long>(tf);
+    x.x_val0 = c.Take<int32_t>(tf);
+    x.x_val1 = c.Take<int32_t>(tf);
+    if (xo) *xo = x;
+    u.x = nullptr;   // (the device address of the slot's UttX: EnsureSlots)
   }
   u.ll = (GP(const float))nullptr;
   u.ll_stride = 0;
@@ -4143,7 +4238,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     auto slot_bytes = [&](const ArenaCaps &c) {
       Carver sizer{nullptr};
       Utt tmp;
-      CarveSlot(sizer, tmp, T_max, tfc, lfc, c, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0);
+      CarveSlot(sizer, tmp, T_max, tfc, lfc, c, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0, nullptr, scale);
       return sizer.off;
     };
     for (;; n_slots = (n_slots + 1) / 2) {
@@ -4182,8 +4277,9 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     d->slab_exact = d->exact;
     d->h_slots.assign(n_slots, Utt());
     Carver carver{static_cast<char *>(d->slab)};
+    d->h_slotsx.assign(n_slots, UttX());
     for (int i = 0; i < n_slots; i++)
-      CarveSlot(carver, d->h_slots[i], T_max, tfc, lfc, caps, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0);
+      CarveSlot(carver, d->h_slots[i], T_max, tfc, lfc, caps, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0, &d->h_slotsx[i], scale);
     // arena invariants for the first utterance of every slot (later ones are
     // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
     for (int i = 0; i < n_slots; i++) {
@@ -4191,11 +4287,17 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
       hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, st, (uint32_t *)u.tok_cost.p, static_cast<size_t>(u.tok_cap), kEncInf);
       KH_HIP(hipMemsetAsync((void *)(unsigned long long *)u.hash.p, 0, sizeof(unsigned long long) * (static_cast<size_t>(u.hash_mask) + 1), st));
       KH_HIP(hipMemsetAsync((void *)(int32_t *)u.tmp_dirty.p, 0, sizeof(int32_t) * u.tok_frame_cap, st));
-      if (u.x_hcap > 0) KH_HIP(hipMemsetAsync((void *)(uint32_t *)u.x_bmin.p, 0xFF, sizeof(uint32_t) * static_cast<size_t>(u.x_hcap), st));
+      const UttX &x = d->h_slotsx[i];
+      if (x.x_hcap > 0) KH_HIP(hipMemsetAsync((void *)(uint32_t *)x.x_bmin.p, 0xFF, sizeof(uint32_t) * static_cast<size_t>(x.x_hcap), st));
     }
     PoolFree(d->d_slots);
+    PoolFree(d->d_slotsx);
     d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
-    if (!d->d_slots) return KH_ENOMEM;
+    d->d_slotsx = static_cast<UttX *>(PoolMalloc(sizeof(UttX) * n_slots));
+    if (!d->d_slots || !d->d_slotsx) return KH_ENOMEM;
+    for (int i = 0; i < n_slots; i++)
+      d->h_slots[i].x = (__attribute__((address_space(4))) const UttX *)(d->d_slotsx + i);
+    KH_HIP(hipMemcpyAsync(d->d_slotsx, d->h_slotsx.data(), sizeof(UttX) * n_slots, hipMemcpyHostToDevice, st));
   } else {
     // slots were left with dirty token costs by the previous call: refill
     for (int i = 0; i < n_slots; i++) {
@@ -4400,7 +4502,10 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
   all += tot[45];
   for (int k = 0; k < 16; k++)
     if (tot[k] && (k < 10 || k == 15)) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
-  if (tot[45]) fprintf(stderr, " list_order=%.1f%%", 100.0 * tot[45] / all);
+  if (tot[47]) fprintf(stderr, " [per frame: %.0f tokens, %.0f with epsilon arcs from the emitting pass, %.0f in all, %.0f epsilon link slots, %.0f tokens from the closure]",
+                       double(tot[46]) / tot[47], double(tot[52]) / tot[47], double(tot[53]) / tot[47], double(tot[54]) / tot[47], double(tot[55]) / tot[47]);
+  if (tot[45]) fprintf(stderr, " list_order=%.1f%% (buckets + replay tables %.1f%%, queue sort %.1f%%, replay %.1f%%, list sort %.1f%% of it)", 100.0 * tot[45] / all,
+                       100.0 * tot[48] / tot[45], 100.0 * tot[49] / tot[45], 100.0 * tot[50] / tot[45], 100.0 * tot[51] / tot[45]);
   fprintf(stderr, "\n[kh_decoder profile] PruneActiveTokens calls %lld, frames pruned %lld (%.1f per call), tokens scanned "
           "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
           tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
@@ -4663,6 +4768,7 @@ void kh_decoder_destroy(KhDecoder *d) {
   PoolFree(d->slab);
   PoolFree(d->pool_slab);
   PoolFree(d->d_slots);
+  PoolFree(d->d_slotsx);
   PoolFree(d->d_in);
   PoolFree(d->d_out);
   PoolFree(d->d_used);
@@ -5029,8 +5135,9 @@ int kh_decoder_set_reference_order(KhDecoder *d, int enable) {
 }
 
 int kh_decoder_get_search_counters(const KhDecoder *d, int utt, int64_t *counters) {
-  KH_CHECK_ARG(d && counters && utt >= 0 && utt < d->n_utts);
-  counters[0] = d->h_out[utt].cand_mat;
+  KH_CHECK_ARG(d && counters && utt >= -1 && utt < d->n_utts);
+  counters[0] = 0;
+  for (int u = std::max(utt, 0); u < (utt < 0 ? d->n_utts : utt + 1); u++) counters[0] += d->h_out[u].cand_mat;
   counters[1] = d->exact;
   return KH_OK;
 }

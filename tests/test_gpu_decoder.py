@@ -209,10 +209,10 @@ def test_determinization_on_the_completion_threads(api):
 
 
 def test_after_launch_hook_runs_the_callers_work_under_the_decode(api):
-    """kh_decoder_set_after_launch: decode() calls the hook once, after the kernel launch, on the calling thread; work
-    the hook enqueues on the library's stream (here: it overwrites a COPY target with the next batch's scores and runs a
-    GEMM) is ordered after the decode kernel, the results of the decode are those of a call without a hook, an
-    exception of the hook surfaces from decode(), and None switches it off."""
+    """kh_decoder_set_after_launch: decode() calls the hook once, when its last decode kernel has finished, on the calling
+    thread and before it waits for its host threads; the caller's GPU work (here a GEMM) runs under the call's host
+    tail, the results of the decode are those of a call without a hook, an exception of the hook surfaces from
+    decode(), and None switches it off."""
     rng = np.random.default_rng(23)
     g = graph_like_hclg(rng, 20000, 200)
     lls = [workloads.make_loglikes(rng, int(T), 200) for T in rng.integers(3, 90, 9)]
@@ -252,6 +252,49 @@ def test_after_launch_hook_runs_the_callers_work_under_the_decode(api):
     dec.set_after_launch(None)
     dec.decode(ll, off)
     assert calls == [1]
+
+
+def test_after_launch_hook_may_overwrite_the_scores_even_when_utterances_are_decoded_again(api, monkeypatch):
+    """the hook used to fire after the FIRST launch; an utterance that overflowed its arenas or the lattice
+    pool is decoded again from the score matrix (and offline decoding re-evaluates acoustic costs from it at export), so
+    a main loop that scores the next batch into the same buffer from the hook corrupted the retried utterances.  Now the
+    hook fires once, when the call's LAST kernel has finished: a hook that scribbles over the scores changes nothing."""
+    rng = np.random.default_rng(29)
+    g = graph_like_hclg(rng, 20000, 200)
+    lls = [workloads.make_loglikes(rng, int(T), 200) for T in (40, 25, 33)]
+    cfg = api.decoder_config(beam=9.0, lattice_beam=6.0)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
+    host = np.concatenate(lls, 0)
+    fst = api.Fst(g)
+    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=3, max_frames=40)
+    ref.decode(torch.from_numpy(host).cuda(), off)
+    want = [(ref.get_raw_lattice(u), ref.get_best_path(u)) for u in range(3)]
+    need = max(ref.stats(u)["max_tokens_frame"] for u in range(3))
+    cap = 1
+    while cap * 4 < need:
+        cap *= 2                                         # the arenas fit after 2-3 doublings
+    for env in ({"KH_DECODER_POOL_TOKENS_PER_FRAME": "1"},                                                  # lattice pool: exact-size retry
+                {"KH_DECODER_TOKENS_PER_FRAME": str(cap), "KH_DECODER_WINDOW_TOKENS_PER_FRAME": str(cap)}):  # arenas: doubled until they fit
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ll = torch.from_numpy(host).cuda()
+        calls = []
+
+        def hook():
+            calls.append(1)
+            ll.fill_(-1000.0)           # the "next batch's scores" into the same buffer
+            torch.cuda.synchronize()
+
+        dec = api.LatticeFasterDecoder(fst, cfg, max_batch=3, max_frames=40)
+        dec.set_after_launch(hook)
+        dec.decode(ll, off)
+        assert calls == [1]
+        assert float(ll[0, 0]) == -1000.0
+        for u, (raw, bp) in enumerate(want):
+            assert_same_lattice(dec.get_raw_lattice(u), raw)
+            assert_same_best_path(dec.get_best_path(u), bp)
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_long_utterances_sparse_epsilons(api, monkeypatch):
