@@ -44,6 +44,11 @@ typedef struct MatrixElementF { /* MatrixElement<float> */
   int32_t column;
   float weight;
 } MatrixElementF;
+typedef struct MatrixElementD { /* MatrixElement<double> */
+  int32_t row;
+  int32_t column;
+  double weight;
+} MatrixElementD;
 #endif
 /* CUDA's dim3 as a C struct (three 32-bit unsigned, passed by value). */
 typedef struct KhDim3 {
@@ -94,6 +99,36 @@ void cudaF_comp_obj_deriv(KhDim3 Gr, KhDim3 Bl, MatrixElementF *x, int s, const 
 /* legacy cuBLAS v1 SGEMM, column-major (cublas-wrappers.h:28-30; caller cu-matrix.cc:947-982) */
 void cublasSgemm(char transa, char transb, int m, int n, int k, float alpha, const float *A, int lda,
                  const float *B, int ldb, float beta, float *C, int ldc);
+
+/* ---- the <double> twins of the same subset (cu-kernels-ansi.h:187-308; CuMatrix<double> is instantiated by
+ * cu-matrix.cc:2415-2418) and cublasDgemm (cublas-wrappers.h:31-33).  Same argument meaning as the cudaF_* above. */
+void cudaD_softmax_reduce(size_t Gr, size_t Bl, double *y, const double *x, MatrixDim d, int src_stride);
+void cudaD_log_softmax_reduce(size_t Gr, size_t Bl, double *y, const double *x, MatrixDim d, int src_stride);
+void cudaD_copy_rows(KhDim3 Gr, KhDim3 Bl, double *dst, const double *src, const int32_t *reorder, MatrixDim dst_dim,
+                     int src_stride);
+void cudaD_splice(KhDim3 Gr, KhDim3 Bl, double *y, const double *x, const int32_t *off, MatrixDim d_out, MatrixDim d_in);
+void cudaD_group_pnorm(KhDim3 Gr, KhDim3 Bl, double *y, const double *x, MatrixDim d, int src_stride, int group_size,
+                       double power);
+void cudaD_add_diag_mat_mat(int Gr, int Bl, double alpha, double *v, int v_dim, const double *M, int M_cols,
+                            int M_row_stride, int M_col_stride, const double *N, int N_row_stride, int N_col_stride,
+                            int threads_per_element, double beta);
+void cudaD_mul_cols_vec(KhDim3 Gr, KhDim3 Bl, double *mat, const double *scale, MatrixDim d);
+void cudaD_mul_rows_vec(KhDim3 Gr, KhDim3 Bl, double *mat, const double *scale, MatrixDim d);
+void cudaD_copy_rows_from_vec(KhDim3 Gr, KhDim3 Bl, double *mat_out, MatrixDim d_out, const double *v_in);
+void cudaD_add_vec_to_rows(KhDim3 Gr, KhDim3 Bl, double alpha, const double *row, double beta, double *dst, MatrixDim d);
+void cudaD_apply_exp(KhDim3 Gr, KhDim3 Bl, double *mat, MatrixDim d);
+void cudaD_apply_pow(KhDim3 Gr, KhDim3 Bl, double *mat, double power, MatrixDim d);
+void cudaD_apply_floor(KhDim3 Gr, KhDim3 Bl, double *mat, double floor_val, MatrixDim d);
+void cudaD_scale(KhDim3 Gr, KhDim3 Bl, double *mat, double value, MatrixDim d);
+void cudaD_apply_log(KhDim3 Gr, KhDim3 Bl, double *mat, MatrixDim d);
+void cudaD_sum_column_ranges(KhDim3 Gr, KhDim3 Bl, double *data, MatrixDim dim, const double *src_data, MatrixDim src_dim,
+                             const Int32Pair *indices);
+void cudaD_matrix_lookup(KhDim3 Gr, KhDim3 Bl, const double *data, MatrixDim dim, const Int32Pair *indices, int indices_size,
+                         double *output);
+void cudaD_comp_obj_deriv(KhDim3 Gr, KhDim3 Bl, MatrixElementD *x, int s, const double *z, MatrixDim d, double *z2,
+                          MatrixDim d2, double *t);
+void cublasDgemm(char transa, char transb, int m, int n, int k, double alpha, const double *A, int lda, const double *B,
+                 int ldb, double beta, double *C, int ldc);
 
 #ifdef __cplusplus
 }

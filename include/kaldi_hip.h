@@ -160,6 +160,31 @@ int kh_matrix_lookup(const float *M, KhMatrixDim d, const int32_t *pairs, int n,
 int kh_log_prior_scale(float *M, KhMatrixDim d, const float *log_priors,
                        float prob_scale);
 
+/* ------------------------------------------------------------------ a1-a7, <double>
+ * The CuMatrix<double> / CuVector<double> instantiation (cu-matrix.cc:2415-2418, cu-vector.cc) of the primitives above:
+ * same argument meaning, double elements (strides in elements).  AddMatMat runs on the fp64 matrix cores
+ * (v_mfma_f64_16x16x4_f64).  csrc/kh_double.hip; the cudaD_* launchers of include/cu_kernels_ansi_hip.h forward here. */
+int kh_add_mat_mat_d(double alpha, const double *A, KhMatrixDim dA, int transA, const double *B, KhMatrixDim dB,
+                     int transB, double beta, double *C, KhMatrixDim dC);
+int kh_softmax_per_row_d(double *y, const double *x, KhMatrixDim d, int src_stride);
+int kh_log_softmax_per_row_d(double *y, const double *x, KhMatrixDim d, int src_stride);
+int kh_copy_rows_d(double *dst, KhMatrixDim dst_dim, const double *src, int src_stride, const int32_t *indices);
+int kh_splice_d(double *y, KhMatrixDim d_out, const double *x, KhMatrixDim d_in, const int32_t *frame_offsets,
+                int n_offsets);
+int kh_group_pnorm_d(double *y, const double *x, KhMatrixDim d, int src_stride, int group_size, double power);
+int kh_add_diag_mat2_d(double alpha, const double *M, KhMatrixDim d, double beta, double *v);
+int kh_mul_rows_vec_d(double *M, KhMatrixDim d, const double *scale);
+int kh_mul_cols_vec_d(double *M, KhMatrixDim d, const double *scale);
+int kh_copy_rows_from_vec_d(double *M, KhMatrixDim d, const double *v);
+int kh_add_vec_to_rows_d(double alpha, const double *v, double beta, double *M, KhMatrixDim d);
+int kh_apply_floor_d(double *M, KhMatrixDim d, double floor_val);
+int kh_apply_log_d(double *M, KhMatrixDim d);
+int kh_apply_exp_d(double *M, KhMatrixDim d);
+int kh_apply_pow_d(double *M, KhMatrixDim d, double power);
+int kh_scale_d(double *M, KhMatrixDim d, double alpha);
+int kh_sum_column_ranges_d(double *y, KhMatrixDim d, const double *x, KhMatrixDim d_src, const int32_t *ranges);
+int kh_matrix_lookup_d(const double *M, KhMatrixDim d, const int32_t *pairs, int n, double *out);
+
 /* ------------------------------------------------------------------ a8
  * nnet2 forward: Nnet + NnetComputer + DecodableAmNnet
  * (nnet2/nnet-nnet.h, nnet2/nnet-compute.cc:63-108,159-166,

@@ -51,8 +51,16 @@ def select_gpu(ordinal):
     use_torch_stream()
 
 
+def _fn(name, t):
+    """The entry point for the tensor's element type: kh_<name> (float) or its <double> twin kh_<name>_d."""
+    if t.dtype == torch.float64:
+        return getattr(lib(), name + "_d")
+    assert t.dtype == torch.float32
+    return getattr(lib(), name)
+
+
 def _dim(t):
-    assert t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda
+    assert t.dim() == 2 and t.dtype in (torch.float32, torch.float64) and t.is_cuda
     assert t.stride(1) == 1 or t.shape[1] <= 1
     return KhMatrixDim(t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
 
@@ -71,7 +79,7 @@ def _dev_i32(a, device):
 # ---------------------------------------------------------------- CuMatrix ops
 def add_mat_mat(Cm, alpha, A, transA, B, transB, beta):
     """CuMatrixBase::AddMatMat (cu-matrix.cc:947-982): C = alpha op(A) op(B) + beta C."""
-    check(lib().kh_add_mat_mat(alpha, _p(A), _dim(A), int(transA), _p(B), _dim(B), int(transB), beta, _p(Cm), _dim(Cm)))
+    check(_fn("kh_add_mat_mat", Cm)(alpha, _p(A), _dim(A), int(transA), _p(B), _dim(B), int(transB), beta, _p(Cm), _dim(Cm)))
     return Cm
 
 
@@ -89,13 +97,13 @@ def affine_pnorm(out, A, W, bias):
 def apply_softmax_per_row(dst, src):
     """CuMatrixBase::ApplySoftMaxPerRow (cu-matrix.cc:1251-1271)."""
     assert dst.shape == src.shape  # KALDI_ASSERT(SameDim(*this, src))
-    check(lib().kh_softmax_per_row(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    check(_fn("kh_softmax_per_row", dst)(_p(dst), _p(src), _dim(dst), _dim(src).stride))
     return dst
 
 
 def apply_log_softmax_per_row(dst, src):
     assert dst.shape == src.shape
-    check(lib().kh_log_softmax_per_row(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    check(_fn("kh_log_softmax_per_row", dst)(_p(dst), _p(src), _dim(dst), _dim(src).stride))
     return dst
 
 
@@ -104,14 +112,14 @@ def copy_rows(dst, src, indices):
     idx = _dev_i32(indices, dst.device)
     if dst.shape[1] != src.shape[1] or dst.shape[0] != idx.numel():
         raise KhError("CopyRows: dimension mismatch")
-    check(lib().kh_copy_rows(_p(dst), _dim(dst), _p(src), _dim(src).stride, _p(idx)))
+    check(_fn("kh_copy_rows", dst)(_p(dst), _dim(dst), _p(src), _dim(src).stride, _p(idx)))
     return dst
 
 
 def splice(src, frame_offsets, tgt):
     """cu::Splice (cudamatrix/cu-math.cc:130-165)."""
     off = _dev_i32(frame_offsets, src.device)
-    check(lib().kh_splice(_p(tgt), _dim(tgt), _p(src), _dim(src), _p(off), off.numel()))
+    check(_fn("kh_splice", tgt)(_p(tgt), _dim(tgt), _p(src), _dim(src), _p(off), off.numel()))
     return tgt
 
 
@@ -119,7 +127,7 @@ def group_pnorm(dst, src, power):
     """CuMatrixBase::GroupPnorm (cu-matrix.cc:1147-1164)."""
     if src.shape[1] % dst.shape[1] != 0 or src.shape[0] != dst.shape[0]:
         raise KhError("GroupPnorm: dimension mismatch")
-    check(lib().kh_group_pnorm(_p(dst), _p(src), _dim(dst), _dim(src).stride, src.shape[1] // dst.shape[1], power))
+    check(_fn("kh_group_pnorm", dst)(_p(dst), _p(src), _dim(dst), _dim(src).stride, src.shape[1] // dst.shape[1], power))
     return dst
 
 
@@ -133,56 +141,56 @@ def normalize(dst, src):
 def add_diag_mat2(v, alpha, M, beta):
     """CuVectorBase::AddDiagMat2 kNoTrans (cu-vector.cc:517-580)."""
     assert v.numel() == M.shape[0]
-    check(lib().kh_add_diag_mat2(alpha, _p(M), _dim(M), beta, _p(v)))
+    check(_fn("kh_add_diag_mat2", M)(alpha, _p(M), _dim(M), beta, _p(v)))
     return v
 
 
 def mul_rows_vec(M, s):
     assert s.numel() == M.shape[0]
-    check(lib().kh_mul_rows_vec(_p(M), _dim(M), _p(s)))
+    check(_fn("kh_mul_rows_vec", M)(_p(M), _dim(M), _p(s)))
     return M
 
 
 def mul_cols_vec(M, s):
     assert s.numel() == M.shape[1]
-    check(lib().kh_mul_cols_vec(_p(M), _dim(M), _p(s)))
+    check(_fn("kh_mul_cols_vec", M)(_p(M), _dim(M), _p(s)))
     return M
 
 
 def copy_rows_from_vec(M, v):
     assert v.numel() == M.shape[1]
-    check(lib().kh_copy_rows_from_vec(_p(M), _dim(M), _p(v)))
+    check(_fn("kh_copy_rows_from_vec", M)(_p(M), _dim(M), _p(v)))
     return M
 
 
 def add_vec_to_rows(M, alpha, v, beta=1.0):
     assert v.numel() == M.shape[1]
-    check(lib().kh_add_vec_to_rows(alpha, _p(v), beta, _p(M), _dim(M)))
+    check(_fn("kh_add_vec_to_rows", M)(alpha, _p(v), beta, _p(M), _dim(M)))
     return M
 
 
 def apply_floor(M, f):
-    check(lib().kh_apply_floor(_p(M), _dim(M), f))
+    check(_fn("kh_apply_floor", M)(_p(M), _dim(M), f))
     return M
 
 
 def apply_log(M):
-    check(lib().kh_apply_log(_p(M), _dim(M)))
+    check(_fn("kh_apply_log", M)(_p(M), _dim(M)))
     return M
 
 
 def apply_exp(M):
-    check(lib().kh_apply_exp(_p(M), _dim(M)))
+    check(_fn("kh_apply_exp", M)(_p(M), _dim(M)))
     return M
 
 
 def apply_pow(M, p):
-    check(lib().kh_apply_pow(_p(M), _dim(M), p))
+    check(_fn("kh_apply_pow", M)(_p(M), _dim(M), p))
     return M
 
 
 def scale(M, a):
-    check(lib().kh_scale(_p(M), _dim(M), a))
+    check(_fn("kh_scale", M)(_p(M), _dim(M), a))
     return M
 
 
@@ -190,7 +198,7 @@ def sum_column_ranges(dst, src, ranges):
     """CuMatrixBase::SumColumnRanges (cu-matrix.cc:1994-2028)."""
     r = _dev_i32(ranges, dst.device)
     assert r.numel() == 2 * dst.shape[1]
-    check(lib().kh_sum_column_ranges(_p(dst), _dim(dst), _p(src), _dim(src), _p(r)))
+    check(_fn("kh_sum_column_ranges", dst)(_p(dst), _dim(dst), _p(src), _dim(src), _p(r)))
     return dst
 
 
@@ -198,8 +206,8 @@ def lookup(M, pairs):
     """CuMatrixBase::Lookup (cu-matrix.cc:2327)."""
     pr = _dev_i32(pairs, M.device)
     n = pr.numel() // 2
-    out = torch.empty(n, dtype=torch.float32, device=M.device)
-    check(lib().kh_matrix_lookup(_p(M), _dim(M), _p(pr), n, _p(out)))
+    out = torch.empty(n, dtype=M.dtype, device=M.device)
+    check(_fn("kh_matrix_lookup", M)(_p(M), _dim(M), _p(pr), n, _p(out)))
     return out
 
 

@@ -126,6 +126,24 @@ SIGNATURES = {
     "kh_decoder_create": (vp, [vp, C.POINTER(KhDecoderConfig), C.c_int, C.c_int]),
     "kh_decoder_destroy": (None, [vp]),
     "kh_decoder_decode": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, vp]),
+    "kh_add_mat_mat_d": (C.c_int, [C.c_double, vp, D, C.c_int, vp, D, C.c_int, C.c_double, vp, D]),
+    "kh_softmax_per_row_d": (C.c_int, [vp, vp, D, C.c_int]),
+    "kh_log_softmax_per_row_d": (C.c_int, [vp, vp, D, C.c_int]),
+    "kh_copy_rows_d": (C.c_int, [vp, D, vp, C.c_int, vp]),
+    "kh_splice_d": (C.c_int, [vp, D, vp, D, vp, C.c_int]),
+    "kh_group_pnorm_d": (C.c_int, [vp, vp, D, C.c_int, C.c_int, C.c_double]),
+    "kh_add_diag_mat2_d": (C.c_int, [C.c_double, vp, D, C.c_double, vp]),
+    "kh_mul_rows_vec_d": (C.c_int, [vp, D, vp]),
+    "kh_mul_cols_vec_d": (C.c_int, [vp, D, vp]),
+    "kh_copy_rows_from_vec_d": (C.c_int, [vp, D, vp]),
+    "kh_add_vec_to_rows_d": (C.c_int, [C.c_double, vp, C.c_double, vp, D]),
+    "kh_apply_floor_d": (C.c_int, [vp, D, C.c_double]),
+    "kh_apply_log_d": (C.c_int, [vp, D]),
+    "kh_apply_exp_d": (C.c_int, [vp, D]),
+    "kh_apply_pow_d": (C.c_int, [vp, D, C.c_double]),
+    "kh_scale_d": (C.c_int, [vp, D, C.c_double]),
+    "kh_sum_column_ranges_d": (C.c_int, [vp, D, vp, D, vp]),
+    "kh_matrix_lookup_d": (C.c_int, [vp, D, vp, C.c_int, vp]),
     "kh_decoder_set_reference_order": (C.c_int, [vp, C.c_int]),
     "kh_decoder_get_search_counters": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64)]),
     "kh_decoder_get_stats": (C.c_int, [vp, C.c_int, C.POINTER(KhDecodeStats)]),

@@ -7,8 +7,8 @@
 //   kaldi::CuDevice            cudamatrix/cu-device.h:41-143
 //   kaldi::CuMatrixBase<Real> / CuMatrix<Real> / CuSubMatrix<Real>   cudamatrix/cu-matrix.h:62-644  (forward-path
 //                              subset; every operation also works on Range() / RowRange() / ColRange() views;
-//                              templates like the reference's: storage and copies for float and double,
-//                              kernels for float - a <double> operation throws, see KhF below)
+//                              templates like the reference's: float and double (the matrix primitives of the forward
+//                              path have <double> kernels; what is float-only throws on a <double> object, see KhF below)
 //   kaldi::CuVectorBase<Real> / CuVector<Real> / CuSubVector<Real>   cudamatrix/cu-vector.h
 //   kaldi::CuValue<Real>       cudamatrix/cu-value.h:33-81
 //   kaldi::Matrix<Real> / Vector<Real> (host)   kaldi-matrix-lite.h, or matrix/kaldi-matrix.h when already included
@@ -130,9 +130,9 @@ class CuDevice {
     for (size_t i = 0; i < c.size(); i++) { diff += double(c[i] - c1[i]) * (c[i] - c1[i]); norm += double(c[i]) * c[i]; }
     if (!(std::sqrt(diff) <= 0.01 * std::sqrt(norm))) throw std::runtime_error("CheckGpuHealth: device GEMM differs from the host GEMM");
   }
-  /// DoublePrecisionSupported() cu-device.cc:407: this library has float kernels only (the
-  /// decode path runs with KALDI_DOUBLEPRECISION=0; the cudaD_* twins are not provided).
-  bool DoublePrecisionSupported() const { return false; }
+  /// DoublePrecisionSupported() cu-device.cc:407 (device capability >= 1.3 there): the matrix primitives exist for
+  /// <double> (csrc/kh_double.hip, the cudaD_* twins); gfx950 has fp64 matrix cores.
+  bool DoublePrecisionSupported() const { return true; }
   void SetVerbose(bool verbose) { verbose_ = verbose; }
   /// AccuProfile / PrintProfile / ResetProfile cu-device.cc:379-405
   void AccuProfile(const std::string &key, double time) { profile_map_[key] += time; }
@@ -156,16 +156,58 @@ class CuDevice {
 // ---- float / double dispatch -----------------------------------------------------------
 // The classes below are templates on Real like the reference's (cu-matrix.h:62, cu-vector.h, cu-value.h),
 // so code written against CuMatrix<BaseFloat> compiles unchanged.  Storage, copies, views and element access
-// work for float and double; the KERNELS exist for float only (KALDI_DOUBLEPRECISION=0 is what the decode
-// path runs with, CuDevice::DoublePrecisionSupported() says so): an arithmetic operation on a <double>
-// object throws as KALDI_ERR would, it never computes on the host.
+// work for float and double, and so do the matrix primitives of the forward path (khx:: below: AddMatMat on the
+// fp64 matrix cores, softmax, CopyRows, GroupPnorm, the element-wise set, cu::Splice).  What exists for float only
+// (the fused Normalize, CompObjfAndDeriv - and everything above the matrix classes: KALDI_DOUBLEPRECISION=0 is
+// what the decode path runs with) throws on a <double> object as KALDI_ERR would; nothing computes on the host.
 inline float *KhF(float *p) { return p; }
 inline const float *KhF(const float *p) { return p; }
 inline float *KhF(double *) {
-  throw std::runtime_error("ERROR (libkaldi_hip) double-precision kernels are not built (CuDevice::DoublePrecisionSupported() "
-                           "is false): use CuMatrix<float> / CuVector<float>");
+  throw std::runtime_error("ERROR (libkaldi_hip) this operation has no double-precision kernel: use CuMatrix<float> / "
+                           "CuVector<float>");
 }
 inline const float *KhF(const double *p) { return KhF(const_cast<double *>(p)); }
+
+// ---- float / double dispatch of the primitives that exist for both (csrc/kh_double.hip holds the <double> kernels:
+// cu-matrix.cc:2415-2418 instantiates CuMatrix<double> too).  khx::op(...) picks kh_op or kh_op_d by the element type.
+namespace khx {
+inline int add_mat_mat(float alpha, const float *A, KhMatrixDim dA, int tA, const float *B, KhMatrixDim dB, int tB, float beta, float *C, KhMatrixDim dC) { return kh_add_mat_mat(alpha, A, dA, tA, B, dB, tB, beta, C, dC); }
+inline int add_mat_mat(double alpha, const double *A, KhMatrixDim dA, int tA, const double *B, KhMatrixDim dB, int tB, double beta, double *C, KhMatrixDim dC) { return kh_add_mat_mat_d(alpha, A, dA, tA, B, dB, tB, beta, C, dC); }
+inline int softmax_per_row(float *y, const float *x, KhMatrixDim d, int ss) { return kh_softmax_per_row(y, x, d, ss); }
+inline int softmax_per_row(double *y, const double *x, KhMatrixDim d, int ss) { return kh_softmax_per_row_d(y, x, d, ss); }
+inline int log_softmax_per_row(float *y, const float *x, KhMatrixDim d, int ss) { return kh_log_softmax_per_row(y, x, d, ss); }
+inline int log_softmax_per_row(double *y, const double *x, KhMatrixDim d, int ss) { return kh_log_softmax_per_row_d(y, x, d, ss); }
+inline int copy_rows(float *dst, KhMatrixDim dd, const float *src, int ss, const int32_t *idx) { return kh_copy_rows(dst, dd, src, ss, idx); }
+inline int copy_rows(double *dst, KhMatrixDim dd, const double *src, int ss, const int32_t *idx) { return kh_copy_rows_d(dst, dd, src, ss, idx); }
+inline int group_pnorm(float *y, const float *x, KhMatrixDim d, int ss, int g, float p) { return kh_group_pnorm(y, x, d, ss, g, p); }
+inline int group_pnorm(double *y, const double *x, KhMatrixDim d, int ss, int g, double p) { return kh_group_pnorm_d(y, x, d, ss, g, p); }
+inline int mul_rows_vec(float *M, KhMatrixDim d, const float *v) { return kh_mul_rows_vec(M, d, v); }
+inline int mul_rows_vec(double *M, KhMatrixDim d, const double *v) { return kh_mul_rows_vec_d(M, d, v); }
+inline int mul_cols_vec(float *M, KhMatrixDim d, const float *v) { return kh_mul_cols_vec(M, d, v); }
+inline int mul_cols_vec(double *M, KhMatrixDim d, const double *v) { return kh_mul_cols_vec_d(M, d, v); }
+inline int copy_rows_from_vec(float *M, KhMatrixDim d, const float *v) { return kh_copy_rows_from_vec(M, d, v); }
+inline int copy_rows_from_vec(double *M, KhMatrixDim d, const double *v) { return kh_copy_rows_from_vec_d(M, d, v); }
+inline int add_vec_to_rows(float alpha, const float *v, float beta, float *M, KhMatrixDim d) { return kh_add_vec_to_rows(alpha, v, beta, M, d); }
+inline int add_vec_to_rows(double alpha, const double *v, double beta, double *M, KhMatrixDim d) { return kh_add_vec_to_rows_d(alpha, v, beta, M, d); }
+inline int apply_floor(float *M, KhMatrixDim d, float f) { return kh_apply_floor(M, d, f); }
+inline int apply_floor(double *M, KhMatrixDim d, double f) { return kh_apply_floor_d(M, d, f); }
+inline int apply_log(float *M, KhMatrixDim d) { return kh_apply_log(M, d); }
+inline int apply_log(double *M, KhMatrixDim d) { return kh_apply_log_d(M, d); }
+inline int apply_exp(float *M, KhMatrixDim d) { return kh_apply_exp(M, d); }
+inline int apply_exp(double *M, KhMatrixDim d) { return kh_apply_exp_d(M, d); }
+inline int apply_pow(float *M, KhMatrixDim d, float p) { return kh_apply_pow(M, d, p); }
+inline int apply_pow(double *M, KhMatrixDim d, double p) { return kh_apply_pow_d(M, d, p); }
+inline int scale(float *M, KhMatrixDim d, float a) { return kh_scale(M, d, a); }
+inline int scale(double *M, KhMatrixDim d, double a) { return kh_scale_d(M, d, a); }
+inline int sum_column_ranges(float *y, KhMatrixDim d, const float *x, KhMatrixDim ds, const int32_t *r) { return kh_sum_column_ranges(y, d, x, ds, r); }
+inline int sum_column_ranges(double *y, KhMatrixDim d, const double *x, KhMatrixDim ds, const int32_t *r) { return kh_sum_column_ranges_d(y, d, x, ds, r); }
+inline int add_diag_mat2(float alpha, const float *M, KhMatrixDim d, float beta, float *v) { return kh_add_diag_mat2(alpha, M, d, beta, v); }
+inline int add_diag_mat2(double alpha, const double *M, KhMatrixDim d, double beta, double *v) { return kh_add_diag_mat2_d(alpha, M, d, beta, v); }
+inline int matrix_lookup(const float *M, KhMatrixDim d, const int32_t *pairs, int n, float *out) { return kh_matrix_lookup(M, d, pairs, n, out); }
+inline int matrix_lookup(const double *M, KhMatrixDim d, const int32_t *pairs, int n, double *out) { return kh_matrix_lookup_d(M, d, pairs, n, out); }
+inline int splice(float *y, KhMatrixDim dout, const float *x, KhMatrixDim din, const int32_t *off, int n) { return kh_splice(y, dout, x, din, off, n); }
+inline int splice(double *y, KhMatrixDim dout, const double *x, KhMatrixDim din, const int32_t *off, int n) { return kh_splice_d(y, dout, x, din, off, n); }
+}  // namespace khx
 
 /// Int32Pair cudamatrix/cu-matrixdim.h:59-62 (the index pairs of SumColumnRanges and Lookup)
 struct Int32Pair { int32 first, second; };
@@ -444,44 +486,44 @@ class CuMatrixBase {
   // ---- forward-path operations; each = the reference method of the same name
   void AddMatMat(Real alpha, const CuMatrixBase<Real> &A, MatrixTransposeType transA, const CuMatrixBase<Real> &B,
                  MatrixTransposeType transB, Real beta) {  // cu-matrix.cc:947-982
-    KhCheck(kh_add_mat_mat(static_cast<float>(alpha), KhF(A.data_), A.Dim(), transA == kTrans, KhF(B.data_), B.Dim(),
-                           transB == kTrans, static_cast<float>(beta), KhF(data_), Dim()));
+    KhCheck(khx::add_mat_mat(static_cast<Real>(alpha), A.data_, A.Dim(), transA == kTrans, B.data_, B.Dim(),
+                           transB == kTrans, static_cast<Real>(beta), data_, Dim()));
     Sync();
   }
   void ApplySoftMaxPerRow(const CuMatrixBase<Real> &src) {  // :1251-1271
     KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
-    KhCheck(kh_softmax_per_row(KhF(data_), KhF(src.data_), Dim(), src.stride_));
+    KhCheck(khx::softmax_per_row(data_, src.data_, Dim(), src.stride_));
     Sync();
   }
   void ApplyLogSoftMaxPerRow(const CuMatrixBase<Real> &src) {  // :1274-1295
     KALDI_HIP_ASSERT(src.num_rows_ == num_rows_ && src.num_cols_ == num_cols_);
-    KhCheck(kh_log_softmax_per_row(KhF(data_), KhF(src.data_), Dim(), src.stride_));
+    KhCheck(khx::log_softmax_per_row(data_, src.data_, Dim(), src.stride_));
     Sync();
   }
   void CopyRows(const CuMatrixBase<Real> &src, const std::vector<MatrixIndexT> &indices) {  // :1965-1990
     KALDI_HIP_ASSERT(static_cast<MatrixIndexT>(indices.size()) == num_rows_ && src.num_cols_ == num_cols_);
     CuArray<MatrixIndexT> idx(indices);  // the reference uploads the index vector per call too (:1976)
-    KhCheck(kh_copy_rows(KhF(data_), Dim(), KhF(src.data_), src.stride_, idx.Data()));
+    KhCheck(khx::copy_rows(data_, Dim(), src.data_, src.stride_, idx.Data()));
     Sync();
   }
   void GroupPnorm(const CuMatrixBase<Real> &src, Real power) {  // :1147-1164
     KALDI_HIP_ASSERT(num_cols_ > 0 && src.num_cols_ % num_cols_ == 0 && src.num_rows_ == num_rows_);
-    KhCheck(kh_group_pnorm(KhF(data_), KhF(src.data_), Dim(), src.stride_, src.num_cols_ / num_cols_, static_cast<float>(power)));
+    KhCheck(khx::group_pnorm(data_, src.data_, Dim(), src.stride_, src.num_cols_ / num_cols_, static_cast<Real>(power)));
     Sync();
   }
   void MulRowsVec(const CuVectorBase<Real> &scale) {  // :693-713
     KALDI_HIP_ASSERT(scale.Dim() == num_rows_);
-    KhCheck(kh_mul_rows_vec(KhF(data_), Dim(), KhF(scale.Data())));
+    KhCheck(khx::mul_rows_vec(data_, Dim(), scale.Data()));
     Sync();
   }
   void MulColsVec(const CuVectorBase<Real> &scale) {  // :668
     KALDI_HIP_ASSERT(scale.Dim() == num_cols_);
-    KhCheck(kh_mul_cols_vec(KhF(data_), Dim(), KhF(scale.Data())));
+    KhCheck(khx::mul_cols_vec(data_, Dim(), scale.Data()));
     Sync();
   }
   void CopyRowsFromVec(const CuVectorBase<Real> &v) {  // :1673-1745: NumCols() entries -> every row; NumRows() * NumCols() -> the matrix
     if (v.Dim() == num_cols_) {
-      KhCheck(kh_copy_rows_from_vec(KhF(data_), Dim(), KhF(v.Data())));
+      KhCheck(khx::copy_rows_from_vec(data_, Dim(), v.Data()));
     } else {
       KALDI_HIP_ASSERT(v.Dim() == num_rows_ * num_cols_);
       if (num_rows_) KhCheck(kh_memcpy_2d(data_, sizeof(Real) * (size_t)stride_, v.Data(), sizeof(Real) * (size_t)num_cols_, sizeof(Real) * (size_t)num_cols_, num_rows_, 2));
@@ -490,23 +532,23 @@ class CuMatrixBase {
   }
   void AddVecToRows(Real alpha, const CuVectorBase<Real> &row, Real beta = 1.0) {  // :916-939
     KALDI_HIP_ASSERT(row.Dim() == num_cols_);
-    KhCheck(kh_add_vec_to_rows(static_cast<float>(alpha), KhF(row.Data()), static_cast<float>(beta), KhF(data_), Dim()));
+    KhCheck(khx::add_vec_to_rows(static_cast<Real>(alpha), row.Data(), static_cast<Real>(beta), data_, Dim()));
     Sync();
   }
-  void ApplyFloor(Real f) { KhCheck(kh_apply_floor(KhF(data_), Dim(), static_cast<float>(f))); Sync(); }   // :1845
-  void ApplyLog() { KhCheck(kh_apply_log(KhF(data_), Dim())); Sync(); }                                     // :600
-  void ApplyExp() { KhCheck(kh_apply_exp(KhF(data_), Dim())); Sync(); }
-  void ApplyPow(Real p) { KhCheck(kh_apply_pow(KhF(data_), Dim(), static_cast<float>(p))); Sync(); }
-  void Scale(Real a) { KhCheck(kh_scale(KhF(data_), Dim(), static_cast<float>(a))); Sync(); }               // :579
+  void ApplyFloor(Real f) { KhCheck(khx::apply_floor(data_, Dim(), static_cast<Real>(f))); Sync(); }   // :1845
+  void ApplyLog() { KhCheck(khx::apply_log(data_, Dim())); Sync(); }                                     // :600
+  void ApplyExp() { KhCheck(khx::apply_exp(data_, Dim())); Sync(); }
+  void ApplyPow(Real p) { KhCheck(khx::apply_pow(data_, Dim(), static_cast<Real>(p))); Sync(); }
+  void Scale(Real a) { KhCheck(khx::scale(data_, Dim(), static_cast<Real>(a))); Sync(); }               // :579
   void SumColumnRanges(const CuMatrixBase<Real> &src, const CuArray<Int32Pair> &indices) {  // :1994-2028, the reference's signature
     KALDI_HIP_ASSERT(indices.Dim() == num_cols_ && src.num_rows_ == num_rows_);
-    KhCheck(kh_sum_column_ranges(KhF(data_), Dim(), KhF(src.data_), src.Dim(), reinterpret_cast<const int32 *>(indices.Data())));
+    KhCheck(khx::sum_column_ranges(data_, Dim(), src.data_, src.Dim(), reinterpret_cast<const int32 *>(indices.Data())));
     Sync();
   }
   void SumColumnRanges(const CuMatrixBase<Real> &src, const std::vector<int32> &start_end_pairs) {
     KALDI_HIP_ASSERT(static_cast<MatrixIndexT>(start_end_pairs.size()) == 2 * num_cols_ && src.num_rows_ == num_rows_);
     CuArray<int32> r(start_end_pairs);
-    KhCheck(kh_sum_column_ranges(KhF(data_), Dim(), KhF(src.data_), src.Dim(), r.Data()));
+    KhCheck(khx::sum_column_ranges(data_, Dim(), src.data_, src.Dim(), r.Data()));
     Sync();
   }
   /// this <- NormalizeComponent::Propagate(src) (nnet2/nnet-component.cc:576-588) in one kernel
@@ -518,7 +560,7 @@ class CuMatrixBase {
   /// v.AddDiagMat2(alpha, *this, kNoTrans, beta) cu-vector.cc:517-580: v = beta v + alpha diag(M M^T)
   void AddDiagMat2To(CuVectorBase<Real> *v, Real alpha, Real beta) const {
     KALDI_HIP_ASSERT(v->Dim() == num_rows_);
-    KhCheck(kh_add_diag_mat2(static_cast<float>(alpha), KhF(data_), Dim(), static_cast<float>(beta), KhF(v->Data())));
+    KhCheck(khx::add_diag_mat2(static_cast<Real>(alpha), data_, Dim(), static_cast<Real>(beta), v->Data()));
     Sync();
   }
   /// CompObjfAndDeriv cu-matrix.cc:1198-1248 on *this = the derivative; labels = (row, column, weight)
@@ -548,7 +590,7 @@ class CuMatrixBase {
     if (!n) return;
     CuArray<int32> idx(row_col_pairs);
     CuVector<Real> out(n);
-    KhCheck(kh_matrix_lookup(KhF(data_), Dim(), idx.Data(), n, KhF(out.Data())));
+    KhCheck(khx::matrix_lookup(data_, Dim(), idx.Data(), n, out.Data()));
     out.CopyToVec(output);
   }
 
@@ -696,7 +738,7 @@ namespace cu {
 template <typename Real>
 inline void Splice(const CuMatrixBase<Real> &src, const CuArray<int32> &frame_offsets, CuMatrixBase<Real> *tgt) {
   KALDI_HIP_ASSERT(src.NumCols() * frame_offsets.Dim() == tgt->NumCols() && src.NumRows() == tgt->NumRows());
-  KhCheck(kh_splice(KhF(tgt->Data()), tgt->Dim(), KhF(src.Data()), src.Dim(), frame_offsets.Data(), frame_offsets.Dim()));
+  KhCheck(khx::splice(tgt->Data(), tgt->Dim(), src.Data(), src.Dim(), frame_offsets.Data(), frame_offsets.Dim()));
   KhCheck(kh_synchronize());
 }
 /// the same from a host vector of offsets
@@ -705,7 +747,7 @@ inline void Splice(const CuMatrixBase<Real> &src, const std::vector<int32> &fram
   KALDI_HIP_ASSERT(src.NumCols() * static_cast<int>(frame_offsets.size()) == tgt->NumCols() &&
                    src.NumRows() == tgt->NumRows());
   CuArray<int32> off(frame_offsets);
-  KhCheck(kh_splice(KhF(tgt->Data()), tgt->Dim(), KhF(src.Data()), src.Dim(), off.Data(), off.Dim()));
+  KhCheck(khx::splice(tgt->Data(), tgt->Dim(), src.Data(), src.Dim(), off.Data(), off.Dim()));
   KhCheck(kh_synchronize());
 }
 }  // namespace cu

@@ -298,6 +298,85 @@ static Nnet *BuildNnet(const KoComponent *comps, int n_comps) {
   return nnet;
 }
 
+// ---- the <double> instantiation (cu-matrix.cc:2415-2418; the reference's own tests run CudaMatrixUnitTest<double>()):
+// ONE entry point over the reference's CuMatrix<double> / CuVector<double> methods, dense operands (stride = cols).
+// op: 0 AddMatMat(alpha, A, tA, B, tB, beta) into C | 1 ApplySoftMaxPerRow(A) | 2 ApplyLogSoftMaxPerRow(A) |
+// 3 CopyRows(A, idx) | 4 cu::Splice(A, idx) | 5 GroupPnorm(A, alpha) | 6 C(vector, c_rows) .AddDiagMat2(alpha, A, kNoTrans, beta) |
+// 7 C.MulRowsVec(B) | 8 C.MulColsVec(B) | 9 C.CopyRowsFromVec(B) | 10 C.AddVecToRows(alpha, B, beta) | 11 C.ApplyFloor(alpha) |
+// 12 C.ApplyLog | 13 C.ApplyExp | 14 C.ApplyPow(alpha) | 15 C.Scale(alpha) | 16 C.SumColumnRanges(A, idx pairs) |
+// 17 A.Lookup(idx pairs) -> C[n_idx / 2].  B as a vector has b_cols elements.  C holds the in/out matrix.
+int ref_op_d(int op, double alpha, double beta, const double *A, int a_rows, int a_cols, int transA, const double *B,
+             int b_rows, int b_cols, int transB, const int32_t *idx, int n_idx, double *C, int c_rows, int c_cols) {
+  auto in = [](const double *p, int rows, int cols) {
+    Matrix<double> m(rows, cols, kUndefined);
+    for (int r = 0; r < rows; r++) memcpy(m.RowData(r), p + static_cast<size_t>(r) * cols, sizeof(double) * cols);
+    return m;
+  };
+  auto out = [](const MatrixBase<double> &m, double *p) {
+    for (int r = 0; r < m.NumRows(); r++) memcpy(p + static_cast<size_t>(r) * m.NumCols(), m.RowData(r), sizeof(double) * m.NumCols());
+  };
+  auto vec = [](const double *p, int dim) {
+    Vector<double> v(dim, kUndefined);
+    memcpy(v.Data(), p, sizeof(double) * dim);
+    return v;
+  };
+  auto pairs = [&]() {
+    std::vector<Int32Pair> v(n_idx / 2);
+    for (int i = 0; i < n_idx / 2; i++) { v[i].first = idx[2 * i]; v[i].second = idx[2 * i + 1]; }
+    return v;
+  };
+  CuMatrix<double> a, b, c;
+  if (A) a = CuMatrix<double>(in(A, a_rows, a_cols));
+  if (C && op != 6 && op != 17) c = CuMatrix<double>(in(C, c_rows, c_cols));
+  switch (op) {
+    case 0:
+      b = CuMatrix<double>(in(B, b_rows, b_cols));
+      c.AddMatMat(alpha, a, transA ? kTrans : kNoTrans, b, transB ? kTrans : kNoTrans, beta);
+      break;
+    case 1: c.ApplySoftMaxPerRow(a); break;
+    case 2: c.ApplyLogSoftMaxPerRow(a); break;
+    case 3: c.CopyRows(a, std::vector<int32>(idx, idx + n_idx)); break;
+    case 4: {
+      CuArray<int32> off(std::vector<int32>(idx, idx + n_idx));
+      cu::Splice(a, off, &c);
+      break;
+    }
+    case 5: c.GroupPnorm(a, alpha); break;
+    case 6: {
+      CuVector<double> v(vec(C, c_rows));
+      v.AddDiagMat2(alpha, a, kNoTrans, beta);
+      Vector<double> h(c_rows);
+      v.CopyToVec(&h);
+      memcpy(C, h.Data(), sizeof(double) * c_rows);
+      return 0;
+    }
+    case 7: c.MulRowsVec(CuVector<double>(vec(B, b_cols))); break;
+    case 8: c.MulColsVec(CuVector<double>(vec(B, b_cols))); break;
+    case 9: c.CopyRowsFromVec(CuVector<double>(vec(B, b_cols))); break;
+    case 10: c.AddVecToRows(alpha, CuVector<double>(vec(B, b_cols)), beta); break;
+    case 11: c.ApplyFloor(alpha); break;
+    case 12: c.ApplyLog(); break;
+    case 13: c.ApplyExp(); break;
+    case 14: c.ApplyPow(alpha); break;
+    case 15: c.Scale(alpha); break;
+    case 16: {
+      CuArray<Int32Pair> cu_idx(pairs());
+      c.SumColumnRanges(a, cu_idx);
+      break;
+    }
+    case 17: {
+      std::vector<double> o;
+      a.Lookup(pairs(), &o);
+      memcpy(C, o.data(), sizeof(double) * o.size());
+      return 0;
+    }
+    default: return -1;
+  }
+  out(c.Mat(), C);
+  return 0;
+}
+
+
 int ref_nnet_left_context(const KoComponent *comps, int n) {
   Nnet *nnet = BuildNnet(comps, n);
   int ans = nnet->LeftContext();

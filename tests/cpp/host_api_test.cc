@@ -321,7 +321,7 @@ static void TestNnetGmmLattice() {
   std::vector<float> dv(2);
   deriv.CopyToMat(dv.data(), 2);
   Near(dv[1], 2.0f / 0.75f, 1e-6f);
-  CHECK(CuDevice::Instantiate().ActiveGpuId() >= 0 && !CuDevice::Instantiate().DoublePrecisionSupported());
+  CHECK(CuDevice::Instantiate().ActiveGpuId() >= 0 && CuDevice::Instantiate().DoublePrecisionSupported());
   CuDevice::Instantiate().CheckGpuHealth();  // device GEMM against the host GEMM, < 1 % (cu-device.cc:509-527)
   int64_t fr = 0, to = 0;
   CuDevice::Instantiate().GetFreeMemory(&fr, &to);

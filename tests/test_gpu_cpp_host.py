@@ -34,9 +34,9 @@ def test_cpp_host_api_program(api, tmp_path):
 
 
 def test_cpp_reference_cu_matrix_unit_tests():
-    """tests/cpp/cu_matrix_test.cc: UnitTestCuMatrixAddMatMat / CuSoftmax / CopyRows / GroupPnorm of
-    cudamatrix/cu-matrix-test.cc with the reference's call syntax (CuMatrix<Real>, Matrix<Real>), the <double>
-    refusal and LatticeFasterDecoder(fst, config).Decode(&decodable)."""
+    """tests/cpp/cu_matrix_test.cc: the CuMatrix<Real> / CuVector<Real> primitives through the reference's class API
+    (call syntax of cudamatrix/cu-matrix.h), for float and double, against identities / closed forms / host loops
+    (this repo's own test designs), views, copies between precisions, and LatticeFasterDecoder(fst, config).Decode(&decodable)."""
     exe = pkg("build").build_host_test("cu_matrix_test")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
