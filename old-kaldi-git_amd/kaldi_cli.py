@@ -617,7 +617,7 @@ def read_kaldi_object(rxfilename, reader):
 # ---------------------------------------------------------------- tables
 class SequentialTableReader:
     """SequentialTableReader<Holder> (kaldi-table-inl.h:63-520): iterate (key, object) of an rspecifier.  `kind` names the
-    Holder ("matrix", "vector", "int32_vector", "lattice", "compact_lattice", "wave", "token_vector")."""
+    Holder ("matrix", "vector", "int32_vector", "lattice", "compact_lattice", "wave", "token_vector", "fst" = fst::VectorFstHolder)."""
 
     def __init__(self, rspecifier, kind="matrix"):
         self.kind = kind
@@ -637,6 +637,9 @@ class SequentialTableReader:
                     if s.eof():
                         break
                     key = kio.read_token(s, False)
+                    if self.kind == "fst":        # fst::VectorFstHolder has no binary-mode header (fstext-utils.h:403-406)
+                        yield key, kio.read_fst_holder(s)
+                        continue
                     binary = kio.init_kaldi_input(s)
                     yield key, _read_holder(s, binary, self.kind)
             else:
@@ -654,8 +657,11 @@ class SequentialTableReader:
                         raise
                     try:
                         s = kio.Stream(g)
-                        binary = kio.init_kaldi_input(s)
-                        obj = _read_holder(s, binary, self.kind)
+                        if self.kind == "fst":
+                            obj = kio.read_fst_holder(s)
+                        else:
+                            binary = kio.init_kaldi_input(s)
+                            obj = _read_holder(s, binary, self.kind)
                     finally:
                         _close(g, gkind)
                     yield key, obj
@@ -751,6 +757,11 @@ class TableWriter:
         self.f.write(key.encode() + b" ")
         if self.scp is not None:
             self.scp.write(("%s %s:%d\n" % (key, self.ark_wx, self.f.tell())).encode())
+        if self.kind == "fst":                # (no header: the holder's binary form is the OpenFst file)
+            kio.write_fst_holder(self.f, obj, binary)
+            if self.opts["flush"]:
+                self.f.flush()
+            return
         if binary:
             self.f.write(b"\0B")
         kio._write_object(self.f, binary, self.kind, obj)

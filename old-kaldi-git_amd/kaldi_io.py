@@ -412,6 +412,81 @@ def _write_object(f, binary, kind, obj):
         raise ValueError("unknown table object kind " + kind)
 
 
+def read_fst_holder(s):
+    """fst::VectorFstHolder::Read (fstext/fstext-utils.h:416-520), the object of a table of decoding graphs
+    (`SequentialTableReader<fst::VectorFstHolder>`, nnet-latgen-faster.cc:141): NO "\\0B" header - the binary form is the
+    OpenFst file itself (it starts with the magic number, never with a space), the text form starts with a newline,
+    holds one arc "src dst ilabel olabel [weight]" or one final state "state [weight]" per line and ends with an empty
+    line.  Returns the CSR graph dict of read_fst."""
+    s = _as_stream(s)
+    c = s.peek()
+    if not c:
+        raise EOFError("End of stream detected reading Fst")
+    if c not in b" \t\r\n":
+        return read_fst(s)
+    while s.peek() in (b" ", b"\t", b"\r"):
+        s.get()
+    if s.peek() != b"\n":
+        raise ValueError("Reading FST: unexpected sequence of spaces")
+    s.get()
+    arcs, finals, n_states, start = [], {}, 0, None
+    while True:
+        line = bytearray()
+        while not s.eof():
+            b = s.get()
+            if b == b"\n":
+                break
+            line += b
+        col = line.decode().split()
+        if not col:
+            break          # the terminating empty line (or the end of the stream)
+        if len(col) > 5:
+            raise ValueError("Bad line in FST: " + line.decode())
+        src = int(col[0])
+        if start is None:
+            start = src    # "the first state mentioned is the start state" (:455-458)
+        n_states = max(n_states, src + 1)
+        if len(col) <= 2:   # final state [weight]
+            finals[src] = float(col[1]) if len(col) == 2 else 0.0
+        else:
+            dst = int(col[1])
+            n_states = max(n_states, dst + 1)
+            il = int(col[2])
+            ol = int(col[3]) if len(col) >= 4 else il     # (3 columns: an acceptor arc)
+            w = float(col[4]) if len(col) == 5 else 0.0
+            arcs.append((src, dst, il, ol, w))
+    order = sorted(range(len(arcs)), key=lambda i: arcs[i][0])   # stable: arcs of a state keep their order
+    off = np.zeros(n_states + 1, np.int64)
+    for a in arcs:
+        off[a[0] + 1] += 1
+    off = np.cumsum(off)
+    fin = np.full(n_states, np.inf, np.float32)
+    for st, w in finals.items():
+        fin[st] = w
+    return dict(num_states=n_states, start=0 if start is None else start, arc_offsets=off,
+                ilabel=np.asarray([arcs[i][2] for i in order], np.int32), olabel=np.asarray([arcs[i][3] for i in order], np.int32),
+                weight=np.asarray([arcs[i][4] for i in order], np.float32), nextstate=np.asarray([arcs[i][1] for i in order], np.int32),
+                final=fin)
+
+
+def write_fst_holder(f, g, binary):
+    """fst::VectorFstHolder::Write (fstext/fstext-utils.h:378-408): see read_fst_holder."""
+    if binary:
+        write_fst(f, g)
+        return
+    off = np.asarray(g["arc_offsets"], np.int64)
+    out = [b"\n"]
+    states = [int(g["start"])] + [st for st in range(int(g["num_states"])) if st != int(g["start"])]   # the start state first
+    for st in states:
+        for a in range(int(off[st]), int(off[st + 1])):
+            out.append(b"%d\t%d\t%d\t%d\t%r\n" % (st, int(g["nextstate"][a]), int(g["ilabel"][a]), int(g["olabel"][a]),
+                                                   float(np.float32(g["weight"][a]))))
+        if np.isfinite(g["final"][st]):
+            out.append(b"%d\t%r\n" % (st, float(np.float32(g["final"][st]))))
+    out.append(b"\n")
+    f.write(b"".join(out))
+
+
 def read_ark(path_or_file, kind="matrix"):
     """SequentialTableReader over an archive (kaldi-table-inl.h:340-520): yields (key, object)."""
     f = open(path_or_file, "rb") if isinstance(path_or_file, (str, os.PathLike)) else path_or_file

@@ -746,3 +746,78 @@ def test_online2_silence_weighting_of_the_ivector_statistics(api, oracle, tmp_pa
         assert len(istr) == decoded, (k, len(istr), decoded)
     assert n_downweighted > 20                       # the weighting did something in this run
     assert (n_stopped >= 1) == endpointing
+
+
+def test_reference_named_executables_on_path_and_a_table_of_graphs(api, oracle, tmp_path):
+    """SURVEY 8 f4 leftovers: (1) `nnet-latgen-faster` BY NAME, found on PATH (bin/), with the literal argv of
+    steps/nnet2/decode.sh:130-136 - nothing of the recipe line changes but PATH; (2) the fsts-rspecifier branch
+    (nnet-latgen-faster.cc:140-176): a table of per-utterance decoding graphs, a new decoder per utterance, features looked
+    up by the graph's key, an utterance without features counted as failed."""
+    import gzip
+    import subprocess
+    from oracle import binding
+    kio, workloads = pkg("kaldi_io"), pkg("workloads")
+    cli = pkg("kaldi_cli")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    net, priors = make_golden.kaldi_io_net(np.random.default_rng(12))
+    n_pdf, acwt = 5, 0.2
+    rng = np.random.default_rng(31)
+    topo = dict(phones=list(range(1, n_pdf + 1)), phone2idx=[-1] + [0] * n_pdf, entries=[[(0, [(0, 0.5), (1, 0.5)]), (-1, [])]])
+    triples = [(p + 1, 0, p) for p in range(n_pdf)]
+    log_probs = np.concatenate([[0.0], np.full(2 * n_pdf, np.log(0.5))]).astype(np.float32)
+    tid2pdf = np.concatenate([[-1], np.repeat(np.arange(n_pdf), 2)]).astype(np.int32)
+    g = workloads.make_hclg_like(rng, 300, n_pdf, final_frac=0.2)
+    os.makedirs(tmp_path / "graph")
+    os.makedirs(tmp_path / "exp" / "decode")
+    with open(tmp_path / "final.mdl", "wb") as f:
+        f.write(b"\0B")
+        kio.write_transition_model(f, topo, triples, log_probs, True)
+        f.write(open(os.path.join(GOLD, "am_nnet_body_bin"), "rb").read())
+    with open(tmp_path / "graph" / "HCLG.fst", "wb") as f:
+        kio.write_fst(f, g)
+    n_words = int(g["olabel"].max())
+    with open(tmp_path / "graph" / "words.txt", "w") as f:
+        f.write("<eps> 0\n" + "".join("W%d %d\n" % (i, i) for i in range(1, n_words + 1)))
+    utts = {"spk1-utt%d" % i: rng.standard_normal((T, 6)).astype(np.float32) for i, T in enumerate((33, 12, 50))}
+    with kio.TableWriter(str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")) as w:
+        for k, m in utts.items():
+            w.write(k, m)
+    env = dict(os.environ, PATH=os.path.join(ROOT, "bin") + os.pathsep + os.environ["PATH"], PYTHON=sys.executable)
+    # (1) decode.sh:130-136 as the recipe writes it (JOB = 1, $thread_string empty)
+    line = ("nnet-latgen-faster --minimize=false --max-active=300 --min-active=200 --beam=9 --lattice-beam=5 "
+            "--acoustic-scale=%g --allow-partial=true --word-symbol-table=graph/words.txt final.mdl graph/HCLG.fst "
+            "\"ark,s,cs:cat feats.ark |\" \"ark:|gzip -c > exp/decode/lat.1.gz\"" % acwt)
+    p = subprocess.run(line, shell=True, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "LOG (nnet-latgen-faster:main()) Done 3 utterances, failed for 0" in p.stderr
+    clats = dict(kio.read_ark(gzip.open(tmp_path / "exp" / "decode" / "lat.1.gz"), kind="compact_lattice"))
+    assert sorted(clats) == sorted(utts)
+    for name in ("gmm-latgen-faster", "online2-wav-nnet2-latgen-faster", "lattice-to-post"):   # the others resolve and print their usage
+        q = subprocess.run([name], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+        assert q.returncode == 1 and "Usage" in q.stderr, (name, q.stderr[-500:])
+    # (2) a table of graphs: each utterance its own (here: differently seeded) graph; one key has no features
+    graphs = {k: workloads.make_hclg_like(np.random.default_rng(100 + i), 120 + 40 * i, n_pdf, final_frac=0.3) for i, k in enumerate(utts)}
+    graphs["spk9-missing"] = graphs["spk1-utt0"]
+    w = cli.TableWriter("ark:" + str(tmp_path / "graphs.fsts"), "fst")
+    for k, gg in graphs.items():
+        w.write(k, gg)
+    assert w.close()
+    line = ("nnet-latgen-faster --determinize-lattice=false --beam=9 --lattice-beam=5 --acoustic-scale=%g --allow-partial=true final.mdl "
+            "ark:graphs.fsts scp:feats.scp ark:raw.ark ark,t:words.txt ark,t:ali.txt" % acwt)
+    p = subprocess.run(line, shell=True, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "Not decoding utterance spk9-missing because no features available." in p.stderr
+    assert "Done 3 utterances, failed for 1" in p.stderr
+    lats = dict(kio.read_ark(str(tmp_path / "raw.ark"), kind="lattice"))
+    ali = dict(kio.read_ark(str(tmp_path / "ali.txt"), kind="int32_vector"))
+    cfg = binding.decoder_config(beam=9.0, lattice_beam=5.0)
+    nnet_oracle = oracle
+    for k, m in utts.items():
+        gg = dict(graphs[k], tid2pdf=tid2pdf)
+        ll = nnet_oracle.decodable_am_nnet(net, priors, acwt, m)
+        od = binding.DecoderOracle(gg, cfg, "canonical")
+        assert od.decode(ll)
+        want = od.best_path()
+        assert np.array_equal(ali[k], want["alignment"]), k
+        assert len(lats[k]["arc_src"]) == len(od.raw_lattice()["arc_src"]), k

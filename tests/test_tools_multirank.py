@@ -96,6 +96,29 @@ def test_nnet_latgen_faster_two_ranks_dry_run(tmp_path):
     assert rc != 0 and "needs JOB in its name" in err
 
 
+def test_job_in_options_empty_optional_output_and_a_failing_rank(tmp_path):
+    """(1) an EMPTY optional wspecifier ("" for the words table) is legal next to `ali.JOB`; (2) run.pl replaces JOB
+    in the whole command line, options included (--config=conf/JOB/decode.conf); (3) a rank that fails before the summary
+    joins the reduction anyway - its peer ends with the totals instead of waiting for the backend's timeout."""
+    rng = write_model_and_graph(tmp_path)
+    for job in (1, 2):
+        os.makedirs(tmp_path / "conf" / str(job))
+        open(tmp_path / "conf" / str(job) / "decode.conf", "w").write("--beam=%d\n" % (8 + job))
+    with kio.TableWriter(str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")) as w:
+        for i, T in enumerate([12, 9, 20]):
+            w.write("utt%d" % i, rng.standard_normal((T, 6)).astype(np.float32))
+    rc, err = launch("nnet_latgen_faster.py", ["--dry-run", "--config=conf/JOB/decode.conf", "final.mdl", "HCLG.fst", "ark:feats.ark",
+                                               "ark:lat.JOB.ark", "", "ark:ali.JOB.ark"], str(tmp_path))
+    assert rc == 0, err[-3000:]
+    assert "All 2 ranks: done 3 utterances" in err
+    # rank 1's configuration file does not exist: it fails, rank 0 still finishes with the reduction (no hang)
+    os.remove(tmp_path / "conf" / "2" / "decode.conf")
+    rc, err = launch("nnet_latgen_faster.py", ["--dry-run", "--config=conf/JOB/decode.conf", "final.mdl", "HCLG.fst", "ark:feats.ark",
+                                               "ark:lat.JOB.ark"], str(tmp_path))
+    assert rc != 0
+    assert "decode.conf" in err and "All 2 ranks: done 2 utterances, failed for 1" in err, err[-3000:]
+
+
 def test_online2_two_ranks_shard_by_speaker_dry_run(tmp_path):
     write_model_and_graph(tmp_path)
     rng = np.random.default_rng(1)

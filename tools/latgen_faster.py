@@ -128,9 +128,31 @@ def main(argv=None, kind="nnet2"):
         return run(cli, argv, kind, prog)
     except cli.KaldiError as e:           # "catch(const std::exception &e) { std::cerr << e.what(); return -1; }"
         sys.stderr.write("ERROR (%s) %s\n" % (prog, e))
+        leave_group_after_failure()
         return 255
     finally:
         cli.stop_pipe_helper()
+
+
+def leave_group_after_failure():
+    """A rank that fails before the summary (a feature-dimension mismatch, an unreadable model) still joins the reduction -
+    with nothing decoded and one failure - so that its peers, started by a launcher that does not kill siblings, do not wait
+    for it until the backend's timeout.  Best effort: errors here are not reported over the original one."""
+    try:
+        sharding = importlib.import_module("old-kaldi-git_amd.sharding")
+        rank, world = sharding.tool_ranks()
+        # the backend the surviving ranks use in finish(): gloo for --dry-run, else nccl (which needs this rank's device)
+        backend = "gloo" if any(a.startswith("--dry-run") and not a.endswith("=false") for a in sys.argv[1:]) else "nccl"
+        if world > 1 and backend == "nccl":
+            api = importlib.import_module("old-kaldi-git_amd.api")
+            api.select_gpu(int(os.environ.get("LOCAL_RANK", "0")))
+        if sharding.init_tool_group(world, backend):
+            import torch.distributed as dist
+            sharding.reduce_decode_totals(0, 0.0, 0, 1, 0.0, device="cuda" if backend == "nccl" else "cpu")
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:   # noqa: BLE001
+        pass
 
 
 def run(cli, argv, kind, prog):
@@ -150,23 +172,40 @@ def run(cli, argv, kind, prog):
     po.register("rank", -1, "[MI355X] this process's rank (default: RANK, else 0)", int)
     po.register("dry-run", False, "[MI355X] read the inputs and the shard, decode nothing, write nothing into the lattices "
                 "(multi-rank plumbing test without a GPU)")
+    sharding = importlib.import_module("old-kaldi-git_amd.sharding")
+    # run.pl replaces JOB in the WHOLE command line (options too: --config=$dir/JOB/decode.conf, --word-symbol-table=...):
+    # so --world / --rank are looked at first, the substitution is applied to every argument, then the options are parsed
+    pre = cli.ParseOptions("")
+    pre.register("world", 0, "", int)
+    pre.register("rank", -1, "", int)
+    w_opt = r_opt = None
+    for a in argv[1:]:
+        if a.startswith("--world="):
+            w_opt = int(a.split("=", 1)[1])
+        elif a.startswith("--rank="):
+            r_opt = int(a.split("=", 1)[1])
+    rank, world = sharding.tool_ranks(w_opt or 0, -1 if r_opt is None else r_opt)
+    raw_args = list(argv)
+    if world > 1:
+        argv = [argv[0]] + sharding.job_substitute(argv[1:], rank)
     po.read(argv)
     cli.set_program_name(prog)
     if po.num_args() < 4 or po.num_args() > 6:
         po.print_usage()
         return 1
-    sharding = importlib.import_module("old-kaldi-git_amd.sharding")
-    rank, world = sharding.tool_ranks(po["world"], po["rank"])
-    had_job = ["JOB" in po.get_arg(i) for i in range(1, po.num_args() + 1)]
+    raw_pos = [a for a in raw_args[1:] if not a.startswith("--")]
+    had_job = ["JOB" in a for a in raw_pos] + [False] * 6
     if world > 1:
-        po.positional = sharding.job_substitute(po.positional, rank)
-        if not all(had_job[3:]):
+        # an EMPTY optional output ("" for the words table) is legal and writes nothing: only real outputs need JOB
+        outs = [i for i in range(3, po.num_args()) if po.get_arg(i + 1) != ""]
+        if not all(had_job[i] for i in outs):
             raise cli.KaldiError("--world=%d: every output table needs JOB in its name (lat.JOB.gz), or the ranks overwrite each other" % world)
     round_robin = world > 1 and not had_job[2]
     model_rx, fst_rx, feats_rspec, lat_wspec = (po.get_arg(i) for i in (1, 2, 3, 4))
     words_wspec, ali_wspec = po.get_opt_arg(5), po.get_opt_arg(6)
-    if cli.classify_rspecifier(fst_rx)[0] is not None:
-        raise cli.KaldiError("a table of decoding graphs (%s) is not supported: give one HCLG.fst" % fst_rx)
+    fst_table = cli.classify_rspecifier(fst_rx)[0] is not None   # ":103 ClassifyRspecifier(fst_in_str) == kNoRspecifier"
+    if fst_table and round_robin:
+        raise cli.KaldiError("--world=%d with a table of decoding graphs: give every rank its own graph table (JOB in its name)" % world)
 
     kio = importlib.import_module("old-kaldi-git_amd.kaldi_io")
     # model (":76-83 Input ki(model_in_filename, &binary); trans_model.Read; am.Read")
@@ -180,14 +219,24 @@ def run(cli, argv, kind, prog):
         raise cli.KaldiError("Could not open table for writing lattices: " + lat_wspec)
     words_w, ali_w = cli.TableWriter(words_wspec, "int32_vector"), cli.TableWriter(ali_wspec, "int32_vector")
     word_syms = cli.read_symbol_table(po["word-symbol-table"]) if po["word-symbol-table"] != "" else None
-    graph = cli.read_kaldi_object(fst_rx, lambda s, b: kio.read_fst(s))
-    graph["tid2pdf"] = tm["tid2pdf"]
-    if int(graph["ilabel"].max(initial=0)) >= len(tm["tid2pdf"]):
-        raise cli.KaldiError("HCLG has transition-ids the model does not define")
-    reader = cli.SequentialTableReader(feats_rspec, "matrix")
+
+    def check_graph(graph, what):
+        graph["tid2pdf"] = tm["tid2pdf"]
+        if int(graph["ilabel"].max(initial=0)) >= len(tm["tid2pdf"]):
+            raise cli.KaldiError("%s has transition-ids the model does not define" % what)
+        return graph
+    if fst_table:     # ":140-142 SequentialTableReader<fst::VectorFstHolder> fst_reader; RandomAccessBaseFloatCuMatrixReader feature_reader"
+        graph = None
+        fst_reader = cli.SequentialTableReader(fst_rx, "fst")
+        reader = cli.RandomAccessTableReader(feats_rspec, "matrix")
+    else:
+        graph = check_graph(cli.read_kaldi_object(fst_rx, lambda s, b: kio.read_fst(s)), "HCLG")
+        reader = cli.SequentialTableReader(feats_rspec, "matrix")
 
     if po["dry-run"]:
         n_utts = n_frames = 0
+        if fst_table:
+            reader = ((utt, reader.value(utt)) for utt, _ in fst_reader if reader.has_key(utt))
         for k, (utt, m) in enumerate(reader):
             if round_robin and k % world != rank:
                 continue
@@ -216,11 +265,39 @@ def run(cli, argv, kind, prog):
             ll = gmm.pdf_log_likelihoods(feats)
             api.scale(ll, acwt)
             return ll
-    fst = api.Fst(graph)
     cfg = decoder_config(api, po)
     det_opts = determinize_options(api, po, tm)
     totals = [0.0, 0, 0, 0]     # tot_like, frame_count, num_success, num_fail
     state = dict(dec=None, max_batch=0, max_frames=0)
+    if fst_table:
+        # :140-176 a different graph for every utterance: "LatticeFasterDecoder decoder(fst_reader.Value(), config)" per
+        # utterance, features looked up by the graph's key.  (Such graphs are small - an utterance's own alignment or
+        # rescoring graph - so there is one device graph, one decoder object and one launch per utterance; the batched path
+        # below is for the shared HCLG.)
+        for utt, g in fst_reader:
+            if not reader.has_key(utt):
+                cli.warn("Not decoding utterance %s because no features available." % utt)
+                totals[3] += 1
+                continue
+            m = reader.value(utt)
+            if m.shape[0] == 0:
+                cli.warn("Zero-length utterance: " + utt)
+                totals[3] += 1
+                continue
+            if m.shape[1] != input_dim:
+                raise cli.KaldiError("feature dimension %d of %s does not match the model's input %d" % (m.shape[1], utt, input_dim))
+            off = np.array([0, m.shape[0]], np.int32)
+            loglikes = score(torch.from_numpy(np.ascontiguousarray(m, np.float32)).cuda(), off)
+            dec = api.LatticeFasterDecoder(api.Fst(check_graph(g, "the graph of " + utt)), cfg, max_batch=1, max_frames=int(m.shape[0]))
+            dec.set_determinize(determinize, **det_opts)
+            dec.decode(loglikes, off)
+            dec.prepare()
+            write_utterance(cli, api, dec, 0, utt, m.shape[0], po, (lat_w, words_w, ali_w), word_syms, totals, prog)
+        ok = lat_w.close()
+        words_w.close()
+        ali_w.close()
+        return finish(cli, sharding, world, "nccl", time.time() - t_start, totals, lat_wspec, ok)
+    fst = api.Fst(graph)
 
     def flush(batch):
         if not batch:
