@@ -547,6 +547,28 @@ int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_offsets,
                                 double *tot_like, double *acoustic_like_sum,
                                 int32_t *state_times);
 
+/* A batch of lattices KEPT ON THE DEVICE: the caller's arrays are uploaded and prepared (validation, LatticeStateTimes,
+ * dependency levels, incoming-arc lists) once, and every computation on the batch — the numerator's and the denominator's
+ * forward-backward, rescoring with a new score matrix, the forward-backward after it — runs from there
+ * (lat/lattice-functions.cc:272-354, :1307-1358; nnet-compute-discriminative.cc:178-321 does exactly this sequence on one
+ * lattice).  kh_lattice_batch_create takes the arguments of kh_lattice_forward_backward and returns NULL on an error
+ * (kh_last_error).  kh_lattice_batch_forward_backward: outputs as kh_lattice_forward_backward, any may be NULL.
+ * kh_lattice_batch_rescore: RescoreLattice with a DEVICE score matrix (lattice l uses rows ll_row_offsets[l]..., HOST
+ * offsets; tid2pdf DEVICE or NULL = ilabel - 1); the acoustic costs change on the device, arc_acoustic_out (HOST, may be
+ * NULL) receives them.  kh_lattice_last_timings: milliseconds the last lattice call of this thread spent in
+ * { upload, device preparation, sweeps, download } (HIP events on the library's stream; measurement aid). */
+typedef struct KhLatticeBatch KhLatticeBatch;
+KhLatticeBatch *kh_lattice_batch_create(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                                        const int32_t *arc_ilabel, const int32_t *arc_nextstate, const float *arc_graph,
+                                        const float *arc_acoustic, const float *state_final);
+void kh_lattice_batch_destroy(KhLatticeBatch *batch);
+int kh_lattice_batch_sizes(const KhLatticeBatch *batch, int32_t *n_lats, int32_t *total_states, int64_t *total_arcs);
+int kh_lattice_batch_forward_backward(KhLatticeBatch *batch, float *arc_post, double *tot_like, double *acoustic_like_sum,
+                                      int32_t *state_times);
+int kh_lattice_batch_rescore(KhLatticeBatch *batch, const float *loglikes, int ll_stride, const int32_t *ll_row_offsets,
+                             const int32_t *tid2pdf, float *arc_acoustic_out);
+int kh_lattice_last_timings(float *ms4);
+
 /* ComputeLatticeAlphasAndBetas (lat/lattice-functions.cc:412-463) for a batch (same CSR
  * layout as above): alpha / beta per state (log-semiring, or the tropical one when
  * viterbi != 0: LogAddOrMax :395-410), tot[l] = 0.5 * (forward + backward total). */

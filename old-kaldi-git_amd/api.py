@@ -1118,6 +1118,58 @@ def lattice_state_times(L):
     return times
 
 
+class LatticeBatch:
+    """A batch of top-sorted lattices kept on the device (kh_lattice_batch_*): uploaded and prepared once; forward-backward,
+    rescoring with a new score matrix and the forward-backward after it run from there (what
+    NnetDiscriminativeUpdater::LatticeComputations does to one lattice, nnet-compute-discriminative.cc:178-321)."""
+
+    def __init__(self, lats):
+        self.n, self.soff, self.aoff, il, ns, g, a, fin = _cat_lattices(lats) if not isinstance(lats, tuple) else lats
+        self._il = il
+        ip, fp = capi.c_int32_p, capi.c_float_p
+        h = lib().kh_lattice_batch_create(self.n, self.soff.ctypes.data_as(ip), self.aoff.ctypes.data_as(capi.c_int64_p),
+                                          il.ctypes.data_as(ip), ns.ctypes.data_as(ip), g.ctypes.data_as(fp), a.ctypes.data_as(fp),
+                                          fin.ctypes.data_as(fp))
+        if not h:
+            raise KhError(lib().kh_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.total_arcs, self.total_states = len(il), int(self.soff[-1])
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kh_lattice_batch_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def forward_backward(self, want_times=False):
+        """LatticeForwardBackward of every lattice: dict(arc_post [total_arcs], tot_like [n], acoustic_like_sum [n], state_times)."""
+        post = np.empty(self.total_arcs, np.float32)
+        tot, ac = np.empty(self.n, np.float64), np.empty(self.n, np.float64)
+        times = np.empty(self.total_states, np.int32) if want_times else None
+        check(lib().kh_lattice_batch_forward_backward(self._h, post.ctypes.data_as(capi.c_float_p), tot.ctypes.data_as(capi.c_double_p),
+                                                      ac.ctypes.data_as(capi.c_double_p),
+                                                      times.ctypes.data_as(capi.c_int32_p) if want_times else None))
+        return dict(arc_post=post, tot_like=tot, acoustic_like_sum=ac, state_times=times)
+
+    def rescore(self, loglikes, utt_row_offsets, tid2pdf=None, fetch=False):
+        """RescoreLattice with a device score matrix; the acoustic costs change on the device (fetch: return them)."""
+        off = np.ascontiguousarray(utt_row_offsets, np.int32)
+        out = np.empty(self.total_arcs, np.float32) if fetch else None
+        check(lib().kh_lattice_batch_rescore(self._h, _p(loglikes), _dim(loglikes).stride, off.ctypes.data_as(capi.c_int32_p),
+                                             _p(tid2pdf) if tid2pdf is not None else None,
+                                             out.ctypes.data_as(capi.c_float_p) if fetch else None))
+        return out
+
+
+def lattice_last_timings():
+    """Milliseconds the last lattice call of this thread spent in upload / device preparation / sweeps / download."""
+    ms = (C.c_float * 4)()
+    check(lib().kh_lattice_last_timings(ms))
+    return dict(upload_ms=ms[0], prep_ms=ms[1], sweeps_ms=ms[2], download_ms=ms[3])
+
+
 def rescore_lattice(lats, loglikes, utt_row_offsets, tid2pdf=None):
     """RescoreLattice (lat/lattice-functions.cc:1307-1358) for a batch: loglikes = device
     matrix (rows of lattice i at utt_row_offsets[i]...).  Returns the new arc_acoustic arrays."""

@@ -144,6 +144,12 @@ SIGNATURES = {
     "kh_scale_d": (C.c_int, [vp, D, C.c_double]),
     "kh_sum_column_ranges_d": (C.c_int, [vp, D, vp, D, vp]),
     "kh_matrix_lookup_d": (C.c_int, [vp, D, vp, C.c_int, vp]),
+    "kh_lattice_batch_create": (vp, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "kh_lattice_batch_destroy": (None, [vp]),
+    "kh_lattice_batch_sizes": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "kh_lattice_batch_forward_backward": (C.c_int, [vp, vp, vp, vp, vp]),
+    "kh_lattice_batch_rescore": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
+    "kh_lattice_last_timings": (C.c_int, [C.POINTER(C.c_float)]),
     "kh_decoder_set_reference_order": (C.c_int, [vp, C.c_int]),
     "kh_decoder_get_search_counters": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64)]),
     "kh_decoder_get_stats": (C.c_int, [vp, C.c_int, C.POINTER(KhDecodeStats)]),

@@ -386,24 +386,34 @@ __device__ __forceinline__ int PrepScan(int v, int *total, int *s_w) {
   return before + inc - v;
 }
 
+constexpr int kPrepLdsStates = 5120;   // 60 KB of LDS for the three work arrays
 __global__ void __launch_bounds__(kThreads)
 PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ il,
            const int32_t *__restrict__ next, const float *__restrict__ fin, LatDesc *__restrict__ descs,
-           int32_t *__restrict__ times, int32_t *__restrict__ level_off, int32_t *__restrict__ level_states,
+           int32_t *times, int32_t *__restrict__ level_off, int32_t *__restrict__ level_states,
            int64_t *__restrict__ in_off, int64_t *__restrict__ in_arc, int32_t *__restrict__ in_src,
-           int32_t *__restrict__ final_list, int32_t *__restrict__ indeg, int32_t *__restrict__ fill,
+           int32_t *__restrict__ final_list, int32_t *indeg, int32_t *fill,
            int32_t *__restrict__ err) {
   __shared__ int s_w[kThreads / 64];
   __shared__ int s_err[4];
   __shared__ int s_qend, s_maxt;
+  // The three per-state work arrays (state times, in-degrees, fill counters) take ~1.3 M atomic updates per 256-lattice
+  // batch; in device memory every one of them is a read-modify-write at the memory side (4.4 ms for 256 lattices, more
+  // than both sweeps).  A lattice of up to kPrepLdsStates states keeps them in LDS; the times are copied out at the end.
+  __shared__ int s_work[3 * kPrepLdsStates];
   const int l = blockIdx.x, t = threadIdx.x;
   const int sb = lat_off[l], ns = lat_off[l + 1] - sb;
   const int64_t arc_b = arc_off[sb];
+  const bool in_lds = ns <= kPrepLdsStates;
+  // (indexed with the lattice-local state from here on)
+  int32_t *const tw = in_lds ? s_work : times + sb;
+  int32_t *const dw = in_lds ? s_work + kPrepLdsStates : indeg + sb;
+  int32_t *const fw = in_lds ? s_work + 2 * kPrepLdsStates : fill + sb;
   if (t == 0) { s_err[0] = 0; s_err[1] = 0; s_err[2] = 0; s_err[3] = 0; s_maxt = 0; }
   for (int s = t; s < ns; s += kThreads) {
-    times[sb + s] = s == 0 ? 0 : -1;
-    indeg[sb + s] = 0;
-    fill[sb + s] = 0;
+    tw[s] = s == 0 ? 0 : -1;
+    dw[s] = 0;
+    fw[s] = 0;
   }
   PrepSync();
   // ---- in-degrees + "input lattice must be topologically sorted"
@@ -413,7 +423,7 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
       if (nxt <= s || nxt >= ns) {
         if (atomicCAS(&s_err[0], 0, 1) == 0) { s_err[1] = s; s_err[2] = nxt; s_err[3] = static_cast<int>(a - arc_b); }
       } else {
-        atomicAdd(&indeg[sb + nxt], 1);
+        atomicAdd(&dw[nxt], 1);
       }
     }
   PrepSync();
@@ -425,7 +435,7 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
   int carry = 0, nf = 0, nq = 0;
   for (int base = 0; base < ns; base += kThreads) {
     const int s = base + t;
-    const int deg = s < ns ? __hip_atomic_load(&indeg[sb + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int deg = s < ns ? __hip_atomic_load(&dw[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const int is_final = (s < ns && fin[sb + s] != INFINITY) ? 1 : 0;
     const int is_root = (s < ns && deg == 0) ? 1 : 0;
     int tot;
@@ -445,7 +455,7 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
   for (int s = t; s < ns; s += kThreads)
     for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
       const int nxt = next[a];
-      const int64_t pos = in_off[sb + nxt] + atomicAdd(&fill[sb + nxt], 1);
+      const int64_t pos = in_off[sb + nxt] + atomicAdd(&fw[nxt], 1);
       in_arc[pos] = a;
       in_src[pos] = s;
     }
@@ -474,16 +484,16 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
     PrepSync();
     for (int k = lb + t; k < le; k += kThreads) {
       const int s = level_states[sb + k];
-      const int ts = __hip_atomic_load(&times[sb + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int ts = __hip_atomic_load(&tw[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       my_maxt = ts > my_maxt ? ts : my_maxt;
       for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
         const int nxt = next[a];
         if (ts >= 0) {
           const int want = ts + (il[a] != 0 ? 1 : 0);
-          const int old = atomicCAS(&times[sb + nxt], -1, want);
+          const int old = atomicCAS(&tw[nxt], -1, want);
           if (old != -1 && old != want && atomicCAS(&s_err[0], 0, 2) == 0) { s_err[1] = nxt; s_err[2] = old; s_err[3] = want; }
         }
-        if (atomicSub(&indeg[sb + nxt], 1) == 1) level_states[sb + atomicAdd(&s_qend, 1)] = nxt;
+        if (atomicSub(&dw[nxt], 1) == 1) level_states[sb + atomicAdd(&s_qend, 1)] = nxt;
       }
     }
     PrepSync();
@@ -494,6 +504,183 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
     lb = le;
     le = new_end;
   }
+  atomicMax(&s_maxt, my_maxt);
+  PrepSync();
+  if (in_lds)
+    for (int s = t; s < ns; s += kThreads) times[sb + s] = tw[s];
+  if (t < 4) err[4 * l + t] = s_err[t];
+  if (t == 0) {
+    LatDesc d;
+    d.state_b = sb;
+    d.n_states = ns;
+    d.arc_b = arc_b;
+    d.n_levels = lv;
+    d.level_b = lvb;
+    d.final_b = sb;
+    d.n_final = nf;
+    d.max_time = s_maxt;
+    d.n_reached = le;
+    descs[l] = d;
+  }
+}
+
+
+constexpr int kWin = 4096;   // states whose value the dataflow sweeps keep in their LDS window
+static_assert((kWin / 64) % (kThreads / 64) == 0, "a window slot is rewritten by the wave that wrote it");
+__global__ void __launch_bounds__(kThreads)
+PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ il,
+           const int32_t *__restrict__ next, const float *__restrict__ fin, LatDesc *__restrict__ descs,
+           int32_t *times, int32_t *__restrict__ level_off, int32_t *__restrict__ level_states,
+           int64_t *__restrict__ in_off, int64_t *__restrict__ in_arc, int32_t *__restrict__ in_src,
+           int32_t *__restrict__ final_list, int32_t *indeg, int32_t *fill,
+           int32_t *__restrict__ err) {
+  __shared__ int s_w[kThreads / 64];
+  __shared__ int s_err[4];
+  __shared__ int s_qend, s_maxt;
+  // The three per-state work arrays (state times, in-degrees, fill counters) take ~1.3 M atomic updates per 256-lattice
+  // batch; in device memory every one of them is a read-modify-write at the memory side (4.4 ms for 256 lattices, more
+  // than both sweeps).  A lattice of up to kPrepLdsStates states keeps them in LDS; the times are copied out at the end.
+  __shared__ int s_work[2 * kPrepLdsStates];
+  const int l = blockIdx.x, t = threadIdx.x;
+  const int sb = lat_off[l], ns = lat_off[l + 1] - sb;
+  const int64_t arc_b = arc_off[sb];
+  const bool in_lds = ns <= kPrepLdsStates;
+  // (indexed with the lattice-local state from here on)
+  int32_t *const tw = times + sb;   // (only initialised here: the dataflow pass below writes the times)
+  int32_t *const dw = in_lds ? s_work : indeg + sb;
+  int32_t *const fw = in_lds ? s_work + kPrepLdsStates : fill + sb;
+  if (t == 0) { s_err[0] = 0; s_err[1] = 0; s_err[2] = 0; s_err[3] = 0; s_maxt = 0; }
+  for (int s = t; s < ns; s += kThreads) {
+    tw[s] = s == 0 ? 0 : -1;
+    dw[s] = 0;
+    fw[s] = 0;
+  }
+  PrepSync();
+  // ---- in-degrees + "input lattice must be topologically sorted"
+  for (int s = t; s < ns; s += kThreads)
+    for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
+      const int nxt = next[a];
+      if (nxt <= s || nxt >= ns) {
+        if (atomicCAS(&s_err[0], 0, 1) == 0) { s_err[1] = s; s_err[2] = nxt; s_err[3] = static_cast<int>(a - arc_b); }
+      } else {
+        atomicAdd(&dw[nxt], 1);
+      }
+    }
+  PrepSync();
+  if (s_err[0] != 0) {
+    if (t < 4) err[4 * l + t] = s_err[t];
+    return;
+  }
+  // ---- incoming-arc offsets (exclusive scan of the in-degrees), finals and sources (ascending)
+  int carry = 0, nf = 0, nq = 0;
+  for (int base = 0; base < ns; base += kThreads) {
+    const int s = base + t;
+    const int deg = s < ns ? __hip_atomic_load(&dw[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int is_final = (s < ns && fin[sb + s] != INFINITY) ? 1 : 0;
+    const int is_root = (s < ns && deg == 0) ? 1 : 0;
+    int tot;
+    const int off = PrepScan(deg, &tot, s_w);
+    if (s < ns) in_off[sb + s] = arc_b + carry + off;
+    carry += tot;
+    const int foff = PrepScan(is_final, &tot, s_w);
+    if (is_final) final_list[sb + nf + foff] = s;
+    nf += tot;
+    const int qoff = PrepScan(is_root, &tot, s_w);
+    if (is_root) level_states[sb + nq + qoff] = s;
+    nq += tot;
+  }
+  if (t == 0) in_off[sb + ns] = arc_b + carry;
+  PrepSync();
+  // ---- incoming lists (filled in arrival order, then sorted by arc index)
+  for (int s = t; s < ns; s += kThreads)
+    for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
+      const int nxt = next[a];
+      const int64_t pos = in_off[sb + nxt] + atomicAdd(&fw[nxt], 1);
+      in_arc[pos] = a;
+      in_src[pos] = s;
+    }
+  PrepSync();
+  for (int s = t; s < ns; s += kThreads) {
+    const int64_t b0 = in_off[sb + s], e0 = in_off[sb + s + 1];
+    for (int64_t i = b0 + 1; i < e0; i++) {
+      const int64_t ka = in_arc[i];
+      const int32_t ks = in_src[i];
+      int64_t j = i - 1;
+      while (j >= b0 && in_arc[j] > ka) {
+        in_arc[j + 1] = in_arc[j];
+        in_src[j + 1] = in_src[j];
+        j--;
+      }
+      in_arc[j + 1] = ka;
+      in_src[j + 1] = ks;
+    }
+  }
+  // ---- LatticeStateTimes (:36-67) without dependency levels: the states in INDEX order (the lattice is top-sorted), a
+  // wave per block of 64 consecutive states, a state waits until the predecessors it reads have published their time
+  // (sliding LDS window with tags; an evicted entry is read from memory, where it was stored before it was published)
+  constexpr int kTStage = 384;
+  __shared__ int w_tag[kWin], w_time[kWin];
+  __shared__ int st_src[kThreads / 64][kTStage];
+  __shared__ signed char st_inc[kThreads / 64][kTStage];
+  for (int i = t; i < kWin; i += kThreads) w_tag[i] = -1;
+  PrepSync();
+  int my_maxt = 0;
+  {
+    const int lane = t & 63, wave = t >> 6;
+    for (int blk = wave; blk * 64 < ns; blk += kThreads / 64) {
+      const int s = blk * 64 + lane;
+      const bool active = s < ns;
+      int64_t j = 0, ie = 0;
+      if (active) { j = in_off[sb + s]; ie = in_off[sb + s + 1]; }
+      int tval = (active && s == 0) ? 0 : -1;
+      bool done = !active;
+      // (the block's entries staged in LDS before anything is waited for: see ForwardBackwardDFKernel)
+      const int64_t jb = in_off[sb + blk * 64], je = in_off[sb + min(ns, blk * 64 + 64)];
+      const int n_st = static_cast<int>(min<int64_t>(je - jb, kTStage));
+      for (int e2 = lane; e2 < n_st; e2 += 64) {
+        st_src[wave][e2] = in_src[jb + e2];
+        st_inc[wave][e2] = il[in_arc[jb + e2]] != 0 ? 1 : 0;
+      }
+      while (__ballot(!done) != 0ull) {
+        if (!done) {
+          while (j < ie) {
+            const int64_t e2 = j - jb;
+            const int src = e2 < kTStage ? st_src[wave][e2] : in_src[j];
+            const int slot = src & (kWin - 1);
+            const int tag1 = __hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int tp;
+            if (tag1 == src) {
+              tp = __hip_atomic_load(&w_time[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (__hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != src)   // evicted meanwhile
+                tp = __hip_atomic_load(&times[sb + src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (tag1 > src || tag1 == -2) {
+              if (tag1 == -2) break;                 // the slot is being rewritten: look again
+              tp = __hip_atomic_load(&times[sb + src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              break;                                 // not computed yet
+            }
+            if (tp >= 0) {
+              const int want = tp + (e2 < kTStage ? st_inc[wave][e2] : (il[in_arc[j]] != 0 ? 1 : 0));
+              if (tval == -1) tval = want;
+              else if (tval != want && atomicCAS(&s_err[0], 0, 2) == 0) { s_err[1] = s; s_err[2] = tval; s_err[3] = want; }
+            }
+            j++;
+          }
+          if (j >= ie) {
+            const int slot = s & (kWin - 1);
+            __hip_atomic_store(&w_tag[slot], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (to memory at the end of the block: see WinPublish)
+            __hip_atomic_store(&w_time[slot], tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&w_tag[slot], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            my_maxt = tval > my_maxt ? tval : my_maxt;
+            done = true;
+          }
+        }
+      }
+      if (active) __hip_atomic_store(&times[sb + s], tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  const int lv = 0, le = ns, lvb = sb + l;   // (no levels: n_levels = 0 tells the level-based kernels apart)
   atomicMax(&s_maxt, my_maxt);
   PrepSync();
   if (t < 4) err[4 * l + t] = s_err[t];
@@ -514,6 +701,206 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
 
 }  // namespace
 
+namespace {
+
+// LatticeForwardBackward :272-354 WITHOUT dependency levels (PrepKernelDF batches).  The level-based kernel above spends
+// its time on latency: ~420 levels per lattice, each a workgroup barrier plus a chain of four dependent loads from device
+// memory (2.6 ms per 256-lattice batch for 2.8 M arc visits).  Here the states go in INDEX order - a top-sorted lattice's
+// own valid schedule - a wave per block of 64 consecutive states; a state's first two incoming (forward) / outgoing
+// (backward) arcs are fetched before it waits for anything, the alpha / beta values it needs come from a sliding LDS
+// window of the last kWin states (tags say which state a slot holds; a value that has left the window is read from
+// memory, where it was stored before it was published), and a state proceeds as soon as the operands it needs next are
+// there: no barrier, no level structure, the dependent chain runs at LDS latency.  Operand order per state = ascending
+// arc index, as in the reference's sequential sweep: results equal the level-based kernel's bit for bit.
+__device__ __forceinline__ bool WinRead(const int *w_tag, const double *w_val, const double *mem, int idx, bool forward, double *out) {
+  const int slot = idx & (kWin - 1);
+  const int tag1 = __hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (tag1 == idx) {
+    const double v = __hip_atomic_load(&w_val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == idx) { *out = v; return true; }
+    *out = __hip_atomic_load(&mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // evicted while we looked
+    return true;
+  }
+  // a slot that holds a LATER state of the sweep's order means idx has been through the window already
+  const bool evicted = tag1 >= 0 && (forward ? tag1 > idx : tag1 < idx);
+  if (!evicted) return false;   // not computed yet (or the slot is being rewritten: look again)
+  *out = __hip_atomic_load(&mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+// Publishes a value in the window (LDS only).  The value goes to memory when the wave has finished its block of states
+// (the callers), NOT here: on gfx9 `vmcnt` counts stores, and the compiler's s_waitcnt vmcnt(0) in front of the polling
+// loop's next load would put the store's round trip to device memory (~2 us) on every step of the dependent chain - that
+// was 3 ms per 256-lattice batch, more than the arithmetic.  In memory before anybody can find the slot evicted: a slot is
+// rewritten by the state kWin further on, which belongs to the SAME wave (kWin / 64 is a multiple of the waves), and the
+// wave stores and waits at the end of every block.
+__device__ __forceinline__ void WinPublish(int *w_tag, double *w_val, int idx, double v) {
+  const int slot = idx & (kWin - 1);
+  __hip_atomic_store(&w_tag[slot], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_store(&w_val[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_store(&w_tag[slot], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void __launch_bounds__(kThreads)
+ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off,
+                        const int32_t *__restrict__ arc_next, const float *__restrict__ arc_g,
+                        const float *__restrict__ arc_a, const float *__restrict__ state_final,
+                        const int64_t *__restrict__ in_off, const int64_t *__restrict__ in_arc,
+                        const int32_t *__restrict__ in_src, const int32_t *__restrict__ final_list,
+                        double *alpha, double *beta, float *__restrict__ arc_post, double *__restrict__ tot_like,
+                        double *__restrict__ ac_sum, double min_log_diff) {
+  // A block's arcs are staged in LDS before the block waits for anything (they do not depend on alpha / beta): inside the
+  // polling loop ONE lane's load from device memory would stall the whole wave for a round trip on every step of the
+  // dependent chain (SIMT) - that, not the arithmetic, was the 3 ms of the first version of this kernel.
+  constexpr int kStage = 384, kWaves = kThreads / 64;
+  __shared__ double w_val[kWin];
+  __shared__ int w_tag[kWin];
+  __shared__ double st_like[kWaves][kStage];
+  __shared__ int st_idx[kWaves][kStage];     // forward: source state; backward: next state
+  __shared__ float st_ac[kWaves][kStage];    // backward: acoustic cost, then the arc's posterior
+  __shared__ double s_tot;
+  __shared__ double s_red[kWaves];
+  const LatDesc L = lats[blockIdx.x];
+  const double kLogZero = -INFINITY;
+  const int ns = L.n_states, sb = L.state_b, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *al = alpha + sb, *be = beta + sb;
+  const float *fin = state_final + sb;
+  for (int i = threadIdx.x; i < kWin; i += kThreads) w_tag[i] = -1;
+  __syncthreads();
+  // ---- forward :300-316
+  for (int blk = wave; blk * 64 < ns; blk += kWaves) {
+    const int s = blk * 64 + lane;
+    const bool active = s < ns;
+    int64_t ib = 0, ie = 0;
+    if (active) { ib = in_off[sb + s]; ie = in_off[sb + s + 1]; }
+    // the block's incoming entries are contiguous: [eb, ee)
+    const int64_t eb = in_off[sb + blk * 64], ee = in_off[sb + min(ns, blk * 64 + 64)];
+    const int n_st = static_cast<int>(min<int64_t>(ee - eb, kStage));
+    for (int e = lane; e < n_st; e += 64) {
+      const int64_t arc = in_arc[eb + e];
+      st_idx[wave][e] = in_src[eb + e];
+      st_like[wave][e] = -static_cast<double>(arc_g[arc] + arc_a[arc]);  // -ConvertToCost
+    }
+    double a = (active && s == 0) ? 0.0 : kLogZero;
+    int64_t j = ib;
+    bool done = !active;
+    while (__ballot(!done) != 0ull) {
+      if (!done) {
+        while (j < ie) {
+          int src;
+          double like;
+          const int64_t e = j - eb;
+          if (e < kStage) { src = st_idx[wave][e]; like = st_like[wave][e]; }
+          else { const int64_t arc = in_arc[j]; src = in_src[j]; like = -static_cast<double>(arc_g[arc] + arc_a[arc]); }
+          double av;
+          if (!WinRead(w_tag, w_val, al, src, true, &av)) break;
+          a = LogAddD(a, av + like, min_log_diff);
+          j++;
+        }
+        if (j >= ie) {
+          WinPublish(w_tag, w_val, s, a);
+          done = true;
+        }
+      }
+    }
+    if (active) __hip_atomic_store(&al[s], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see WinPublish)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = kLogZero;
+    for (int k = 0; k < L.n_final; k++) {  // ascending state order, as the sweep meets them
+      const int s = final_list[L.final_b + k];
+      const double final_like = __hip_atomic_load(&al[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - static_cast<double>(fin[s] + 0.0f);
+      tot = LogAddD(tot, final_like, min_log_diff);
+    }
+    s_tot = tot;
+  }
+  for (int i = threadIdx.x; i < kWin; i += kThreads) w_tag[i] = -1;
+  __syncthreads();
+  const double tot_forward = s_tot;
+  // ---- backward :317-344 (blocks of states from the end; inside a block the highest state is the first to be ready)
+  double my_ac = 0.0;
+  const int n_blk = (ns + 63) / 64;
+  for (int bi = wave; bi < n_blk; bi += kWaves) {
+    const int s0 = (n_blk - 1 - bi) * 64, s = s0 + lane;
+    const bool active = s < ns;
+    int64_t ab = 0, ae = 0;
+    double as = 0.0, this_beta = 0.0;
+    if (active) {
+      ab = arc_off[sb + s];
+      ae = arc_off[sb + s + 1];
+      as = __hip_atomic_load(&al[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      this_beta = -static_cast<double>(fin[s] + 0.0f);
+    }
+    const int64_t eb = arc_off[sb + s0], ee = arc_off[sb + min(ns, s0 + 64)];   // the block's outgoing arcs: contiguous
+    const int n_st = static_cast<int>(min<int64_t>(ee - eb, kStage));
+    for (int e = lane; e < n_st; e += 64) {
+      const float ac = arc_a[eb + e];
+      st_idx[wave][e] = arc_next[eb + e];
+      st_ac[wave][e] = ac;
+      st_like[wave][e] = -static_cast<double>(arc_g[eb + e] + ac);
+    }
+    int64_t arc = ab;
+    bool done = !active;
+    while (__ballot(!done) != 0ull) {
+      if (!done) {
+        while (arc < ae) {
+          int nx;
+          double like;
+          float ac;
+          const int64_t e = arc - eb;
+          if (e < kStage) { nx = st_idx[wave][e]; like = st_like[wave][e]; ac = st_ac[wave][e]; }
+          else { nx = arc_next[arc]; ac = arc_a[arc]; like = -static_cast<double>(arc_g[arc] + ac); }
+          double bv;
+          if (!WinRead(w_tag, w_val, be, nx, false, &bv)) break;
+          const double arc_beta = bv + like;
+          this_beta = LogAddD(this_beta, arc_beta, min_log_diff);
+          const double posterior = exp(as + arc_beta - tot_forward);
+          if (e < kStage) st_ac[wave][e] = static_cast<float>(posterior);   // (written out when the block is done)
+          else arc_post[arc] = static_cast<float>(posterior);
+          my_ac -= posterior * static_cast<double>(ac);
+          arc++;
+        }
+        if (arc >= ae) {
+          WinPublish(w_tag, w_val, s, this_beta);
+          done = true;
+        }
+      }
+    }
+    if (active) __hip_atomic_store(&be[s], this_beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = lane; e < n_st; e += 64) arc_post[eb + e] = st_ac[wave][e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see WinPublish)
+  }
+  my_ac = kh_wave_sum_d(my_ac);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = my_ac;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kWaves; i++) t += s_red[i];
+    ac_sum[blockIdx.x] = t;
+    tot_like[blockIdx.x] = __hip_atomic_load(&be[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tot_backward_prob :345
+  }
+}
+}  // namespace
+
+// Where the time of the last lattice call of this thread went (kh_lattice_last_timings): upload of the caller's arrays,
+// device preparation (PrepKernel + the descriptors' way back), sweeps, download.  HIP events on the library's stream.
+struct LatTimer {
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float ms[4] = {0.f, 0.f, 0.f, 0.f};
+  bool have[5] = {false, false, false, false, false};
+  void Mark(int i, hipStream_t st) {
+    if (!ev[i] && hipEventCreate(&ev[i]) != hipSuccess) { (void)hipGetLastError(); return; }
+    have[i] = hipEventRecord(ev[i], st) == hipSuccess;
+  }
+  void Begin() { for (int i = 0; i < 5; i++) have[i] = false; for (int i = 0; i < 4; i++) ms[i] = 0.f; }
+  void Finish() {   // (the stream has been synchronised)
+    for (int i = 0; i < 4; i++)
+      if (have[i] && have[i + 1] && hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) { (void)hipGetLastError(); ms[i] = 0.f; }
+  }
+};
+static thread_local LatTimer g_lat_timer;
+
 struct LatBatch {
   int n_lats = 0, total_states = 0;
   int64_t total_arcs = 0;
@@ -523,10 +910,12 @@ struct LatBatch {
   DevArr<int32_t> d_lat_off, d_next, d_ilabel, d_level_off, d_level_states, d_in_src, d_final_list, d_times, d_indeg, d_fill, d_err;
   DevArr<float> d_g, d_a, d_fin;
 
+  bool has_levels = true;   // dependency levels built (the MPE / alpha-beta / discriminative kernels sweep by level)
   int Build(int n, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
             const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic,
-            const float *state_final, hipStream_t st) {
+            const float *state_final, hipStream_t st, bool want_levels = true) {
     n_lats = n;
+    has_levels = want_levels;
     for (int l = 0; l < n_lats; l++) KH_CHECK_ARG(lat_state_offsets[l + 1] - lat_state_offsets[l] > 0);
     total_states = lat_state_offsets[n_lats];
     total_arcs = arc_offsets[total_states];
@@ -539,6 +928,8 @@ struct LatBatch {
     // the caller's arrays go up as they are (pageable copies are staged by the runtime and
     // complete before the call returns: the synchronisation below)
 #define UP(dev, host, count, type) KH_HIP(hipMemcpyAsync(dev.p, host, sizeof(type) * (count), hipMemcpyHostToDevice, st))
+    g_lat_timer.Begin();
+    g_lat_timer.Mark(0, st);
     UP(d_lat_off, lat_state_offsets, n + 1, int32_t);
     UP(d_arc_off, arc_offsets, S + 1, int64_t);
     UP(d_next, arc_nextstate, A, int32_t);
@@ -547,14 +938,21 @@ struct LatBatch {
     if (arc_graph) UP(d_g, arc_graph, A, float);
     if (arc_acoustic) UP(d_a, arc_acoustic, A, float);
 #undef UP
-    hipLaunchKernelGGL(PrepKernel, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
-                       d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
-                       d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p);
+    g_lat_timer.Mark(1, st);
+    if (want_levels)
+      hipLaunchKernelGGL(PrepKernel, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
+                         d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
+                         d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p);
+    else
+      hipLaunchKernelGGL(PrepKernelDF, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
+                         d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
+                         d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p);
     KH_LAUNCH_CHECK();
     descs.resize(n_lats);
     std::vector<int32_t> h_err(4 * static_cast<size_t>(n_lats));
     KH_HIP(hipMemcpyAsync(descs.data(), d_descs.p, sizeof(LatDesc) * n_lats, hipMemcpyDeviceToHost, st));
     KH_HIP(hipMemcpyAsync(h_err.data(), d_err.p, sizeof(int32_t) * h_err.size(), hipMemcpyDeviceToHost, st));
+    g_lat_timer.Mark(2, st);
     KH_HIP(hipStreamSynchronize(st));
     for (int l = 0; l < n_lats; l++) {
       const int32_t *e = &h_err[4 * static_cast<size_t>(l)];
@@ -576,6 +974,134 @@ struct LatBatch {
   }
 };
 
+// LatticeForwardBackward :272-354 on a batch that is resident on the device: sweeps + download.
+static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_like, double *acoustic_like_sum, hipStream_t st) {
+  const int n_lats = B.n_lats, total_states = B.total_states;
+  const int64_t total_arcs = B.total_arcs;
+  DevArr<float> d_post;
+  DevArr<double> d_alpha, d_beta, d_tot, d_ac;
+  if (d_post.Alloc(total_arcs) || d_alpha.Alloc(total_states) || d_beta.Alloc(total_states) ||
+      d_tot.Alloc(n_lats) || d_ac.Alloc(n_lats))
+    return KH_ENOMEM;
+  const double min_log_diff = log(DBL_EPSILON);  // kMinLogDiffDouble kaldi-math.h:120
+  g_lat_timer.Mark(2, st);
+  if (B.has_levels && !getenv("KH_LATTICE_DATAFLOW"))
+    hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p,
+                       B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p,
+                       B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p, d_alpha.p, d_beta.p,
+                       d_post.p, d_tot.p, d_ac.p, min_log_diff);
+  else
+    hipLaunchKernelGGL(ForwardBackwardDFKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p,
+                       B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,
+                       B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff);
+  KH_LAUNCH_CHECK();
+  g_lat_timer.Mark(3, st);
+  if (arc_post)
+    KH_HIP(hipMemcpyAsync(arc_post, d_post.p, sizeof(float) * total_arcs, hipMemcpyDeviceToHost, st));
+  if (tot_like)
+    KH_HIP(hipMemcpyAsync(tot_like, d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  if (acoustic_like_sum)
+    KH_HIP(hipMemcpyAsync(acoustic_like_sum, d_ac.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  g_lat_timer.Mark(4, st);
+  KH_HIP(hipStreamSynchronize(st));
+  g_lat_timer.Finish();
+  return KH_OK;
+}
+
+extern "C" int kh_lattice_last_timings(float *ms) {
+  KH_CHECK_ARG(ms);
+  for (int i = 0; i < 4; i++) ms[i] = g_lat_timer.ms[i];
+  return KH_OK;
+}
+
+// ---- a batch of lattices kept on the device (one upload + one preparation for every computation on them)
+struct KhLatticeBatch {
+  LatBatch B;
+  std::vector<int32_t> lat_off;   // host copy of the state offsets
+};
+
+extern "C" KhLatticeBatch *kh_lattice_batch_create(int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets,
+                                                   const int32_t *arc_ilabel, const int32_t *arc_nextstate, const float *arc_graph,
+                                                   const float *arc_acoustic, const float *state_final) {
+  if (EnsureDevice() != KH_OK) return nullptr;
+  if (!(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_graph && arc_acoustic && state_final)) {
+    SetError("kh_lattice_batch_create: bad arguments");
+    return nullptr;
+  }
+  KhLatticeBatch *h = new KhLatticeBatch();
+  if (h->B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, Stream(),
+                 getenv("KH_LATTICE_LEVELS") != nullptr) != KH_OK) {
+    delete h;
+    return nullptr;
+  }
+  h->lat_off.assign(lat_state_offsets, lat_state_offsets + n_lats + 1);
+  g_lat_timer.Finish();
+  return h;
+}
+
+extern "C" void kh_lattice_batch_destroy(KhLatticeBatch *h) { delete h; }
+
+extern "C" int kh_lattice_batch_sizes(const KhLatticeBatch *h, int32_t *n_lats, int32_t *total_states, int64_t *total_arcs) {
+  KH_CHECK_ARG(h);
+  if (n_lats) *n_lats = h->B.n_lats;
+  if (total_states) *total_states = h->B.total_states;
+  if (total_arcs) *total_arcs = h->B.total_arcs;
+  return KH_OK;
+}
+
+extern "C" int kh_lattice_batch_forward_backward(KhLatticeBatch *h, float *arc_post, double *tot_like, double *acoustic_like_sum,
+                                                 int32_t *state_times) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(h);
+  hipStream_t st = Stream();
+  g_lat_timer.Begin();
+  if (state_times && (rc = h->B.FetchTimes(state_times, st))) return rc;
+  return RunForwardBackward(h->B, arc_post, tot_like, acoustic_like_sum, st);
+}
+
+// RescoreLattice :1307-1358 on the resident batch: one workgroup per lattice, the acoustic costs are updated on the device
+// (states at time utt_len and beyond have no transition-id arcs to rescore: :1343-1345 skips them)
+__global__ void __launch_bounds__(kThreads)
+RescoreBatchKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ ilabel,
+                   const int32_t *__restrict__ times, const int32_t *__restrict__ ll_row_off, float *__restrict__ arc_a,
+                   const float *__restrict__ loglikes, int ll_stride, const int32_t *__restrict__ tid2pdf) {
+  const LatDesc L = lats[blockIdx.x];
+  for (int s = threadIdx.x; s < L.n_states; s += kThreads) {
+    const int t = times[L.state_b + s];
+    if (t < 0 || t >= L.max_time) continue;
+    const float *row = loglikes + static_cast<size_t>(ll_row_off[blockIdx.x] + t) * ll_stride;
+    for (int64_t a = arc_off[L.state_b + s]; a < arc_off[L.state_b + s + 1]; a++) {
+      const int il = ilabel[a];
+      if (il != 0) arc_a[a] = -row[tid2pdf ? tid2pdf[il] : il - 1] + arc_a[a];  // :1349-1350
+    }
+  }
+}
+
+extern "C" int kh_lattice_batch_rescore(KhLatticeBatch *h, const float *loglikes, int ll_stride, const int32_t *ll_row_offsets,
+                                        const int32_t *tid2pdf, float *arc_acoustic_out) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(h && loglikes && ll_stride > 0 && ll_row_offsets);
+  const LatBatch &B = h->B;
+  for (int l = 0; l < B.n_lats; l++)
+    if (B.descs[l].max_time > ll_row_offsets[l + 1] - ll_row_offsets[l]) {
+      SetError("lattice %d: Features are too short for lattice: utt-len is %d (lattice-functions.cc:1337-1341)", l, B.descs[l].max_time);
+      return KH_EINVAL;
+    }
+  hipStream_t st = Stream();
+  DevArr<int32_t> d_rows;
+  std::vector<int32_t> h_rows(ll_row_offsets, ll_row_offsets + B.n_lats + 1);
+  if ((rc = d_rows.Upload(h_rows, st))) return rc;
+  hipLaunchKernelGGL(RescoreBatchKernel, dim3(B.n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_ilabel.p, B.d_times.p,
+                     d_rows.p, B.d_a.p, loglikes, ll_stride, tid2pdf);
+  KH_LAUNCH_CHECK();
+  if (arc_acoustic_out)
+    KH_HIP(hipMemcpyAsync(arc_acoustic_out, B.d_a.p, sizeof(float) * B.total_arcs, hipMemcpyDeviceToHost, st));
+  KH_HIP(hipStreamSynchronize(st));
+  return KH_OK;
+}
+
 extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_offsets,
                                            const int64_t *arc_offsets, const int32_t *arc_ilabel,
                                            const int32_t *arc_nextstate, const float *arc_graph,
@@ -588,30 +1114,11 @@ extern "C" int kh_lattice_forward_backward(int n_lats, const int32_t *lat_state_
                arc_graph && arc_acoustic && state_final);
   hipStream_t st = Stream();
   LatBatch B;
-  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st,
+               getenv("KH_LATTICE_LEVELS") != nullptr);
   if (rc) return rc;
-  const int total_states = B.total_states;
-  const int64_t total_arcs = B.total_arcs;
   if (state_times && (rc = B.FetchTimes(state_times, st))) return rc;
-  DevArr<float> d_post;
-  DevArr<double> d_alpha, d_beta, d_tot, d_ac;
-  if (d_post.Alloc(total_arcs) || d_alpha.Alloc(total_states) || d_beta.Alloc(total_states) ||
-      d_tot.Alloc(n_lats) || d_ac.Alloc(n_lats))
-    return KH_ENOMEM;
-  const double min_log_diff = log(DBL_EPSILON);  // kMinLogDiffDouble kaldi-math.h:120
-  hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p,
-                     B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p,
-                     B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p, d_alpha.p, d_beta.p,
-                     d_post.p, d_tot.p, d_ac.p, min_log_diff);
-  KH_LAUNCH_CHECK();
-  if (arc_post)
-    KH_HIP(hipMemcpyAsync(arc_post, d_post.p, sizeof(float) * total_arcs, hipMemcpyDeviceToHost, st));
-  if (tot_like)
-    KH_HIP(hipMemcpyAsync(tot_like, d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-  if (acoustic_like_sum)
-    KH_HIP(hipMemcpyAsync(acoustic_like_sum, d_ac.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-  KH_HIP(hipStreamSynchronize(st));
-  return KH_OK;
+  return RunForwardBackward(B, arc_post, tot_like, acoustic_like_sum, st);
 }
 
 // LatticeStateTimes (lat/lattice-functions.cc:36-67) of a batch of top-sorted lattices: the
@@ -627,7 +1134,8 @@ extern "C" int kh_lattice_state_times(int n_lats, const int32_t *lat_state_offse
   KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && state_final && state_times);
   hipStream_t st = Stream();
   LatBatch B;
-  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, nullptr, nullptr, state_final, st);
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, nullptr, nullptr, state_final, st,
+               getenv("KH_LATTICE_LEVELS") != nullptr);
   if (rc) return rc;
   if ((rc = B.FetchTimes(state_times, st))) return rc;
   KH_HIP(hipStreamSynchronize(st));

@@ -200,3 +200,39 @@ def test_config5_sized_lattices(api):
         wm = B.lattice_forward_backward_mpe(L, t2ph, g["tid2pdf"], [1, 2], ali, "smbr", False)
         assert abs(m["tot_forward_score"] - wm["tot_forward_score"]) < 1e-7 * max(1.0, abs(wm["tot_forward_score"]))
         assert np.abs(m["arc_post"] - wm["arc_post"]).max() < 1e-5
+
+
+def test_resident_batch_shares_one_upload(api):
+    """kh_lattice_batch_*: forward-backward, RescoreLattice and the forward-backward after it on ONE uploaded batch equal the
+    one-shot calls (which upload and prepare every time), bit for bit; kh_lattice_last_timings reports the split."""
+    import torch
+    rng = np.random.default_rng(12)
+    lats = [random_lattice(rng, n_frames=int(rng.integers(5, 60)), width=5) for _ in range(9)]
+    want = api.lattice_forward_backward(lats)
+    B = api.LatticeBatch(lats)
+    got = B.forward_backward(want_times=True)
+    t = api.lattice_last_timings()
+    assert t["sweeps_ms"] > 0.0 and t["upload_ms"] == 0.0            # nothing was uploaded by this call
+    a0 = 0
+    for i, L in enumerate(lats):
+        na = len(L["arc_ilabel"])
+        assert np.array_equal(got["arc_post"][a0:a0 + na], want[i]["arc_post"])
+        assert got["tot_like"][i] == want[i]["tot_like"] and got["acoustic_like_sum"][i] == want[i]["acoustic_like_sum"]
+        a0 += na
+    T = [int(w["state_times"].max()) for w in want]
+    off = np.concatenate([[0], np.cumsum(T)]).astype(np.int32)
+    ll = torch.from_numpy(rng.standard_normal((int(off[-1]), 60)).astype(np.float32)).cuda()
+    new_a = api.rescore_lattice(lats, ll, off)
+    got_a = B.rescore(ll, off, fetch=True)
+    assert np.array_equal(got_a, np.concatenate(new_a))
+    want2 = api.lattice_forward_backward([dict(L, arc_acoustic=a) for L, a in zip(lats, new_a)])
+    got2 = B.forward_backward()
+    a0 = 0
+    for i, L in enumerate(lats):
+        na = len(L["arc_ilabel"])
+        assert np.array_equal(got2["arc_post"][a0:a0 + na], want2[i]["arc_post"])
+        assert got2["tot_like"][i] == want2[i]["tot_like"]
+        a0 += na
+    api.lattice_forward_backward(lats)
+    t = api.lattice_last_timings()
+    assert t["upload_ms"] > 0.0 and t["prep_ms"] > 0.0 and t["sweeps_ms"] > 0.0

@@ -1,59 +1,64 @@
-"""Lattice forward-backward rate (BASELINE config 5 shape): raw lattices
-of N decoded utterances -> LatticeForwardBackward and the sMBR variant, batch calls;
-arcs/s including the host preparation (levels, incoming-arc CSR) and uploads."""
+#!/usr/bin/env python3
+"""Config 5's lattice forward-backward leg alone, with the call split into upload / device preparation / sweeps / download
+(kh_lattice_last_timings) and the resident-batch path (kh_lattice_batch_*): python tools/bench_lattice_fb.py [N]"""
 import importlib
+import json
+import os
 import sys
 import time
 
 import numpy as np
-import torch
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
-api = importlib.import_module("old-kaldi-git_amd.api")
-W = importlib.import_module("old-kaldi-git_amd.workloads")
-from oracle import binding as B   # lattice_csr (host top-sort helper of the tests), checker only
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "old-kaldi-git_amd"
 
-api.select_gpu(0)
-rng = np.random.default_rng(5)
-N, T, P = 256, 500, 2000
-g = W.make_hclg_like(rng, 1_000_000, P)
-cfg = api.decoder_config(beam=13.0, max_active=3000, min_active=200, lattice_beam=8.0)
-ll = torch.from_numpy(np.stack([W.make_loglikes(rng, T, P) for _ in range(8)])).cuda()
-flat = ll[torch.arange(N) % 8].reshape(N * T, P).contiguous()
-dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=N, max_frames=T)
-dec.decode(flat, (np.arange(N + 1) * T).astype(np.int32))
-dec.prepare()
-lats = [B.lattice_csr(dec.get_raw_lattice(u)) for u in range(N)]
-arcs = sum(len(L["arc_ilabel"]) for L in lats)
-states = sum(L["n_states"] for L in lats)
-print("%d lattices, %d states, %d arcs (%.0f arcs per frame)" % (N, states, arcs, arcs / (N * T)))
-ntid = int(max(L["arc_ilabel"].max() for L in lats))
-t2ph = np.concatenate([[0], rng.integers(1, 40, ntid)]).astype(np.int32)
-t2pdf = np.concatenate([[0], rng.integers(0, P, ntid)]).astype(np.int32)
-alis = [rng.integers(1, ntid + 1, T).astype(np.int32) for _ in range(N)]
-for name, fn in (("LatticeForwardBackward", lambda: api.lattice_forward_backward(lats)),
-                 ("LatticeForwardBackwardMpeVariants(smbr)", lambda: api.lattice_forward_backward_mpe(lats, t2ph, t2pdf, [1, 2], alis, "smbr", True))):
-    fn()
-    t0 = time.perf_counter()
-    fn()
-    dt = time.perf_counter() - t0
-    print("%s: %.1f ms per batch, %.1f M arcs/s, %.2f M frames/s (host posterior merge included)" %
-          (name, dt * 1e3, arcs / dt / 1e6, N * T / dt / 1e6))
 
-# the C call alone (host preparation + uploads + kernel + download), without the Python lists
-import ctypes as C
-capi = importlib.import_module("old-kaldi-git_amd.capi")
-n, soff, aoff, il, ns, gg, aa, fin = api._cat_lattices(lats)
-post = np.empty(len(il), np.float32)
-tot, ac = np.empty(n), np.empty(n)
-times = np.empty(int(soff[-1]), np.int32)
-ip, fp, dp = capi.c_int32_p, capi.c_float_p, capi.c_double_p
-def call():
-    api.check(api.lib().kh_lattice_forward_backward(
-        n, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
-        gg.ctypes.data_as(fp), aa.ctypes.data_as(fp), fin.ctypes.data_as(fp), post.ctypes.data_as(fp),
-        tot.ctypes.data_as(dp), ac.ctypes.data_as(dp), times.ctypes.data_as(ip)))
-call()
-t0 = time.perf_counter(); call(); dt = time.perf_counter() - t0
-print("kh_lattice_forward_backward alone: %.1f ms per batch, %.1f M arcs/s" % (dt * 1e3, arcs / dt / 1e6))
+def main():
+    import torch
+    api = importlib.import_module(PKG + ".api")
+    W = importlib.import_module(PKG + ".workloads")
+    api.select_gpu(0)
+    N, T, P = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 400, 2000
+    rng = np.random.default_rng(5)
+    g = W.make_hclg_structured(rng, 1_000_000, P)
+    seqs = W.sample_paths(rng, g, [T] * N)
+    lls = []
+    for q in seqs:
+        x = (rng.standard_normal((T, P)) * 0.28 - 0.37).astype(np.float32)
+        x[np.arange(T), q] = (0.5 + 0.3 * rng.standard_normal(T)).astype(np.float32)
+        lls.append(x)
+    flat = torch.from_numpy(np.concatenate(lls)).cuda()
+    dec = api.LatticeFasterDecoder(api.Fst(g), api.decoder_config(beam=13.0, max_active=7000, min_active=200, lattice_beam=8.0),
+                                   max_batch=N, max_frames=T)
+    dec.decode(flat, (np.arange(N + 1) * T).astype(np.int32))
+    lats = [api.lattice_to_csr(dec.get_raw_lattice(u)) for u in range(N)]
+    del dec, flat
+    out = {}
+    for mult in (1, 8):
+        batch = lats * mult
+        cat = api._cat_lattices(batch)
+        na = len(cat[3])
+        best = None
+        for rep in range(4):
+            t0 = time.perf_counter()
+            api.lattice_forward_backward_cat(cat) if hasattr(api, "lattice_forward_backward_cat") else None
+            B = api.LatticeBatch(cat)
+            t1 = time.perf_counter()
+            tb = api.lattice_last_timings()
+            B.forward_backward()
+            t2 = time.perf_counter()
+            tf = api.lattice_last_timings()
+            rec = dict(lattices=len(batch), arcs=na, create_ms=(t1 - t0) * 1e3, fb_ms=(t2 - t1) * 1e3, upload_ms=tb["upload_ms"], prep_ms=tb["prep_ms"],
+                       sweeps_ms=tf["sweeps_ms"], download_ms=tf["download_ms"])
+            if best is None or rec["create_ms"] + rec["fb_ms"] < best["create_ms"] + best["fb_ms"]:
+                best = rec
+            del B
+        best["arcs_per_s_resident"] = na / (best["fb_ms"] * 1e-3)
+        best["arcs_per_s_kernel"] = na / (best["sweeps_ms"] * 1e-3)
+        out["x%d" % mult] = best
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
