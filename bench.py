@@ -593,7 +593,8 @@ def main():
                 tot_like += -(gc + ac)
             cnt, ls = dec.stats_batch()
             arcs, toks = int(cnt["arcs_expanded"].sum()), int(cnt["tokens_created"].sum())
-            cand = dec.search_counters(-1)["candidates_materialised"]
+            # (an A/B run against an older build of the library, KH_LIB_OVERRIDE, may predate the counter)
+            cand = dec.search_counters(-1)["candidates_materialised"] if hasattr(api.lib(), "kh_decoder_get_search_counters") else 0
             lat_arcs, lat_states = int(ls["num_links"].sum()), int(ls["num_tokens"].sum())
             t.append(time.perf_counter())
             if determinize:

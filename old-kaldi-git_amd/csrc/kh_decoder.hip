@@ -198,7 +198,7 @@ struct UttX {
 // An array of UttX (constant address space: the pointer is fetched with a scalar load where it is used)
 template <class T>
 __device__ __forceinline__ Arr<T> XArr(const __attribute__((address_space(4))) Arr<T> &a) { return Arr<T>(a.p); }
-#define UX(field) XArr(u.x->field)
+#define UX(field) XArr(sh.x->field)
 
 // Per-utterance arenas and parameters (device-resident array of these).
 //
@@ -250,10 +250,6 @@ struct Utt {
   Arr<unsigned long long> hash;
   uint32_t hash_mask;
   GP(long long) phase_cycles;  // [16] diagnostic (KH_DECODER_PROFILE=1), else nullptr
-  // exact reference order (Params::exact_order): the frame temporaries of that mode live in a struct of their own in
-  // constant memory and are fetched where they are used (scalar loads) - twenty more pointers in this struct, which the
-  // kernels hold in registers for the whole launch, spilled every phase of the kernel (scratch 312 -> 888 bytes per lane)
-  __attribute__((address_space(4))) const struct UttX *x;
 };
 
 struct Params {
@@ -380,6 +376,10 @@ typedef __attribute__((address_space(3))) Shared LdsShared;
 struct Blk {
   LdsShared *p;
   __attribute__((address_space(3))) float *ll_row;  // the frame's log-likelihood row staged in LDS (ll_cols > 0)
+  // exact reference order: the slot's temporaries (UttX), in constant memory, fetched where they are used.  NOT a member
+  // of Utt: the kernels hold that struct in registers for the whole launch, and one more pointer in it cost the canonical
+  // kernel 5 % (scratch 168 -> 184 bytes per lane; same-box A/B against the round-3 build)
+  __attribute__((address_space(4))) const struct UttX *x;
   int k_or, k_red, k_scan;
   __device__ __forceinline__ LdsShared *operator->() const { return p; }
 };
@@ -1292,7 +1292,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
 // at sh->tok_end, which becomes the new frontier sh->front_b).  Returns next_cutoff
 // through *next_cutoff_out; false on overflow.
 __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b, int e,
-                                float *next_cutoff_out, Blk &sh) {
+                                float *next_cutoff_out, int *cand_out, Blk &sh) {
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
@@ -1372,7 +1372,6 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     u.femit_e[frame] = link_frame_e;
     sh->link_end = link_frame_e;
     sh->front_b = nb;
-    sh->cand_mat += link_frame_e - link_frame_b;
   }
   KhSync();
 
@@ -1386,6 +1385,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   KhSync();
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
+  *cand_out = link_frame_e - link_frame_b;
   return Uni(sh->status) == 0;
 }
 
@@ -1562,7 +1562,7 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
 // Only tokens with epsilon arcs are pushed (popping another one is a no-op in the reference).  Returns the number of
 // insertions, or -1 when the queue outgrew its arrays.
 template <class FP, class IP>
-__device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack_lo, int lo_cap, const Utt &u, int top,
+__device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack_lo, int lo_cap, const Utt &u, const Blk &sh, int top,
                              float cutoff, int nb, uint32_t qbase) {
   int cnt = 0;
   const int hi_cap = u.link_frame_cap;
@@ -1811,7 +1811,7 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     KhSync();
     if (threadIdx.x == 0) {
       const int cnt = ReplayClosure((GP(float))UX(x_ncost).p, (GP(int32_t))UX(x_nl0).p, (GP(int32_t))UX(x_nl1).p, (GP(int32_t))UX(x_ord).p,
-                                    (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, eps_emit, cutoff, nb, qbase);
+                                    (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, sh, eps_emit, cutoff, nb, qbase);
       if (cnt != n_new) sh->status = cnt < 0 ? 3 : 8;
     }
   }
@@ -1838,7 +1838,8 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
 }
 
 // ProcessEmitting :660-750 with the reference's running cutoff (see above).  Tokens [b, e) with list positions x_pos.
-__device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, int b, int e, float *next_cutoff_out, Blk &sh) {
+__device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, int b, int e, float *next_cutoff_out, int *cand_out,
+                                     Blk &sh) {
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   const int n = e - b;
@@ -2074,7 +2075,6 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     u.femit_e[frame] = link_frame_e;
     sh->link_end = link_frame_e;
     sh->front_b = nb;
-    sh->cand_mat += link_frame_e - link_frame_b;
   }
   KhSync();
   // ---- pass 2: FindOrAddToken + minimum cost in the LDS token table, as in the canonical sweep (every candidate here
@@ -2114,6 +2114,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   KhSync();
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
+  *cand_out = link_frame_e - link_frame_b;
   return Uni(sh->status) == 0;
 }
 
@@ -3081,6 +3082,8 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
 // the token range of the newest frame.
 struct Run {
   int t, fb, fe;
+  long long cand;   // emitting candidates materialised so far (uniform: kept in scalar registers, not in LDS - an LDS
+                    // accumulator updated inside ProcessEmitting cost the kernel 5 % through its register allocation)
 };
 
 // Compaction window: everything younger than 2 * max(prune_interval, 25) frames
@@ -3107,7 +3110,6 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->gc_link = 0;
     sh->surv_nt = 0;
     sh->surv_nl = 0;
-    sh->cand_mat = 0;
     for (int i = 0; i < 4; i++) sh->sched[i] = 0;
   }
   for (int f = threadIdx.x; f < u.T + 2; f += NT) {
@@ -3135,6 +3137,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
   if (kExact && ok) ok = OrderFrontier(u, p, 0, Uni(sh->tok_end), Uni(u.feps_b[0]), Uni(u.feps_e[0]), p.beam, sh);
   run->t = 0;
+  run->cand = 0;
   run->fb = 0;  // token range of the frontier frame
   run->fe = Uni(sh->tok_end);
   if (threadIdx.x == 0) {
@@ -3153,6 +3156,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
   const int win_frames = WindowFrames(p);
   bool ok = true;
   int t = run->t, fb = run->fb, fe = run->fe;
+  long long cand = run->cand;
   int last_gc = 0;  // (lazy schedule) frame of the last garbage collection
   for (; ok && t < t_end; t++) {
     if (kLazy) {
@@ -3196,8 +3200,10 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       fe = Uni(u.frame_e[t]);
     }
     float next_cutoff;
-    ok = kExact ? ProcessEmittingExact(u, p, t, fb, fe, &next_cutoff, sh) : ProcessEmitting(u, p, t, fb, fe, &next_cutoff, sh);
+    int n_cand = 0;
+    ok = kExact ? ProcessEmittingExact(u, p, t, fb, fe, &next_cutoff, &n_cand, sh) : ProcessEmitting(u, p, t, fb, fe, &next_cutoff, &n_cand, sh);
     if (!ok) break;
+    cand += n_cand;
     ok = ProcessNonemitting(u, p, t + 1, next_cutoff, sh);
     if (!ok) break;
     fb = Uni(sh->front_b);
@@ -3221,6 +3227,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
   run->t = t;
   run->fb = fb;
   run->fe = fe;
+  run->cand = cand;
   return ok;
 }
 
@@ -3272,6 +3279,7 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
     }
     Stamp(u, sh, 8);
   }
+  if (threadIdx.x == 0) sh->cand_mat = run.cand;
   KhSync();
   st.arcs_expanded = sh->arcs_expanded;
   st.tokens_created = sh->tokens_created;
@@ -3473,7 +3481,7 @@ __global__ void __launch_bounds__(NT)
 __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
 #endif
 DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut *__restrict__ out,
-             int n_utts, Pool pool, Params p, GP(long long) phase_cycles, GP(int32_t) done_list) {
+             int n_utts, Pool pool, Params p, GP(long long) phase_cycles, GP(int32_t) done_list, const UttX *slotsx) {
   __shared__ Shared shm;
   extern __shared__ float dyn_ll_row[];
   Blk sh;
@@ -3482,6 +3490,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
   sh.k_or = 0;
   sh.k_red = 0;
   sh.k_scan = 0;
+  sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + blockIdx.x) : nullptr;
   Utt u = slots[blockIdx.x];
   u.phase_cycles = phase_cycles ? phase_cycles + NPH * blockIdx.x : (GP(long long))nullptr;
   if (threadIdx.x == 0) {
@@ -3513,7 +3522,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     // (a capacity overflow aborts a frame with work-list flags still set: clear them too)
     for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
     if (kExact)   // (an aborted frame may have left bucket minima behind)
-      for (int i = threadIdx.x; i < u.x->x_hcap; i += NT) UX(x_bmin)[i] = 0xFFFFFFFFu;
+      for (int i = threadIdx.x; i < sh.x->x_hcap; i += NT) UX(x_bmin)[i] = 0xFFFFFFFFu;
     KhSync();
     KhDecodeStats st;
     DecodeOne<kLazy, kExact>(u, p, sh, &st);
@@ -3570,6 +3579,7 @@ __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
     sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created; sh->conv_upto = S.conv_upto;
   }
   run->t = S.t; run->fb = S.fb; run->fe = S.fe;
+  run->cand = 0;   // (the online decoder does not report the counter)
   KhSync();
 }
 __device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
@@ -3597,6 +3607,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
   sh.k_or = 0;
   sh.k_red = 0;
   sh.k_scan = 0;
+  sh.x = nullptr;
   const Job job = jobs[blockIdx.x];
   Utt u = slots[job.slot];
   SlotState *S = &states[job.slot];
@@ -3968,7 +3979,6 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
     x.x_val0 = c.Take<int32_t>(tf);
     x.x_val1 = c.Take<int32_t>(tf);
     if (xo) *xo = x;
-    u.x = nullptr;   // (the device address of the slot's UttX: EnsureSlots)
   }
   u.ll = (GP(const float))nullptr;
   u.ll_stride = 0;
@@ -4295,8 +4305,6 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     d->d_slots = static_cast<Utt *>(PoolMalloc(sizeof(Utt) * n_slots));
     d->d_slotsx = static_cast<UttX *>(PoolMalloc(sizeof(UttX) * n_slots));
     if (!d->d_slots || !d->d_slotsx) return KH_ENOMEM;
-    for (int i = 0; i < n_slots; i++)
-      d->h_slots[i].x = (__attribute__((address_space(4))) const UttX *)(d->d_slotsx + i);
     KH_HIP(hipMemcpyAsync(d->d_slotsx, d->h_slotsx.data(), sizeof(UttX) * n_slots, hipMemcpyHostToDevice, st));
   } else {
     // slots were left with dirty token costs by the previous call: refill
@@ -4937,7 +4945,8 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     KH_HIP(hipEventRecord(d->ev0, st));
 #define KH_LAUNCH_DECODE(LAZY, EXACT)                                                                                          \
   hipLaunchKernelGGL((DecodeKernel<LAZY, EXACT>), dim3(grid), dim3(NT), DynLdsBytes(p.ll_cols), st, d->d_slots, d->d_in,          \
-                     static_cast<UttOut *>(d_out_dev), np, d->hpool, p, (GP(long long))d->d_phase, (GP(int32_t))d_done_dev)
+                     static_cast<UttOut *>(d_out_dev), np, d->hpool, p, (GP(long long))d->d_phase, (GP(int32_t))d_done_dev,       \
+                     (const UttX *)d->d_slotsx)
     if (p.exact_order) {
       if (p.lazy_prune) KH_LAUNCH_DECODE(true, true); else KH_LAUNCH_DECODE(false, true);
     } else {
