@@ -455,6 +455,12 @@ int kh_online_decoder_advance(KhOnlineDecoder *dec, const int32_t *streams, int 
                               const int32_t *num_frames, const int32_t *tid2pdf);
 /* NumFramesDecoded() :194. */
 int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream, int32_t *num_frames);
+/* Serving loops call kh_online_decoder_advance once per chunk with the same transition-id -> pdf map (DEVICE, or NULL) and
+ * the same number of score columns: this builds the decoder's arc records for that pair ONCE (a pass over the whole graph
+ * and a synchronisation otherwise repeated by every advance call) and validates the map as kh_online_decoder_advance
+ * does.  Later advance calls with the same pointer and ll_stride == num_cols reuse the records; the caller must not change
+ * the map's contents in between (any other pointer / stride rebuilds as before). */
+int kh_online_decoder_set_pdf_map(KhOnlineDecoder *dec, const int32_t *tid2pdf, int num_cols);
 /* FinalizeDecoding() :180 (.cc:775-790). */
 int kh_online_decoder_finalize(KhOnlineDecoder *dec, const int32_t *streams, int n);
 /* GetRawLattice(ofst, use_final_probs) :143 (.cc:143-233), GetBestPath :107 and the
@@ -519,6 +525,28 @@ int kh_compute_deltas(const float *in, KhMatrixDim d_in, int order, const float 
  * ApplyCmvn (:64-113) is kh_mul_cols_vec + kh_add_vec_to_rows with the offset / scale
  * vectors the caller derives from the stats as the reference does. */
 int kh_acc_cmvn_stats(const float *feats, KhMatrixDim d, double *stats_host);
+
+/* ------------------------------------------------------------------ (f)1, serving
+ * The per-chunk loop of online2-wav-nnet2-latgen-faster (online2bin/online2-wav-nnet2-latgen-faster.cc:213-262) for many
+ * concurrent streams in ONE call per step: the chunk's feature rows enter DecodableNnet2Online
+ * (nnet2/online-nnet2-decodable.{h,cc}: NumFramesReady :75-89, ComputeForFrame :91-143 - the context-padded rows of every
+ * advancing stream gathered into one matrix, one forward pass, the floor / log / -log prior / acoustic-scale epilogue) and
+ * LatticeFasterOnlineDecoder::AdvanceDecoding consumes what became ready.  nnet (with priors set) and dec stay owned by
+ * the caller and must outlive the object; results are read from dec (kh_online_decoder_get_*; kh_online_decoder_finalize at
+ * the end of an utterance).  kh_online_nnet2_reset: a new utterance on the listed streams (InitDecoding).
+ * kh_online_nnet2_step: stream streams[i] receives rows [src_rows[i], src_rows[i] + counts[i]) of the DEVICE matrix src
+ * (counts[i] >= 0), finished[i] != 0 = InputFinished() after them; every listed stream then advances by the frames that
+ * became ready (at most max_nnet_batch_size per call); frames_decoded (may be NULL) = NumFramesDecoded() afterwards.
+ * tid2pdf as kh_online_decoder_advance (pin it with kh_online_decoder_set_pdf_map).  Synchronous. */
+typedef struct KhOnlineNnet2 KhOnlineNnet2;
+KhOnlineNnet2 *kh_online_nnet2_create(KhNnet *nnet, KhOnlineDecoder *dec, int num_streams, int max_frames, float acoustic_scale,
+                                      int pad_input, int max_nnet_batch_size);
+void kh_online_nnet2_destroy(KhOnlineNnet2 *h);
+int kh_online_nnet2_reset(KhOnlineNnet2 *h, const int32_t *streams, int n);
+int kh_online_nnet2_step(KhOnlineNnet2 *h, const int32_t *streams, int n, const float *src, int src_stride,
+                         const int32_t *src_rows, const int32_t *counts, const int32_t *finished, const int32_t *tid2pdf,
+                         int32_t *frames_decoded);
+int kh_online_nnet2_num_frames_ready(const KhOnlineNnet2 *h, int stream, int32_t *ready);
 
 /* LatticeStateTimes (lat/lattice-functions.cc:36-67) for a batch of top-sorted lattices
  * (layout as kh_lattice_forward_backward): time of every state (-1: unreachable) and, per

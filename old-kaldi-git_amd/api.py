@@ -398,6 +398,51 @@ class DecodableNnet2Online:
         return res
 
 
+class OnlineNnet2Pipeline:
+    """The serving loop of online2-wav-nnet2-latgen-faster (:213-262) for num_streams concurrent utterances with ONE library
+    call per step (kh_online_nnet2_*): step() hands every live stream its chunk of feature rows, DecodableNnet2Online's
+    ComputeForFrame runs for all advancing streams in one forward pass, AdvanceDecoding consumes the frames.  `decoder` is a
+    LatticeFasterOnlineDecoder (results are read from it: get_best_path, get_raw_lattice, finalize_decoding)."""
+
+    def __init__(self, nnet, decoder, max_frames, acoustic_scale=0.1, pad_input=True, max_nnet_batch_size=256):
+        self.nnet, self.decoder = nnet, decoder
+        h = lib().kh_online_nnet2_create(nnet._h, decoder._h, decoder.num_streams, int(max_frames), float(acoustic_scale),
+                                         int(bool(pad_input)), int(max_nnet_batch_size))
+        if not h:
+            raise KhError(lib().kh_last_error().decode())
+        self._h = C.c_void_p(h)
+        fst = decoder.fst
+        self._t2p = _p(fst.tid2pdf) if fst.tid2pdf is not None else None
+        fst.check_pdf_map(nnet.output_dim())
+        # the decoder's arc records for this (map, columns) pair once, not at every chunk
+        check(lib().kh_online_decoder_set_pdf_map(decoder._h, self._t2p, (nnet.output_dim() + 3) // 4 * 4))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().kh_online_nnet2_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def reset(self, streams):
+        st = np.ascontiguousarray(streams, np.int32)
+        check(lib().kh_online_nnet2_reset(self._h, st.ctypes.data_as(capi.c_int32_p), len(st)))
+
+    def step(self, streams, src, src_rows, counts, finished):
+        """streams[i] receives rows [src_rows[i], src_rows[i] + counts[i]) of the device matrix src; finished[i]:
+        InputFinished().  Returns NumFramesDecoded() of the listed streams after the step."""
+        st = np.ascontiguousarray(streams, np.int32)
+        sr = np.ascontiguousarray(src_rows, np.int32)
+        ct = np.ascontiguousarray(counts, np.int32)
+        fi = np.ascontiguousarray(finished, np.int32)
+        out = np.empty(len(st), np.int32)
+        ip = capi.c_int32_p
+        check(lib().kh_online_nnet2_step(self._h, st.ctypes.data_as(ip), len(st), _p(src), _dim(src).stride, sr.ctypes.data_as(ip),
+                                         ct.ctypes.data_as(ip), fi.ctypes.data_as(ip), self._t2p, out.ctypes.data_as(ip)))
+        return out
+
+
 # ---------------------------------------------------------------- feature front-end
 class Mfcc:
     """feat/feature-mfcc.h Mfcc with MfccOptions: the constructor builds the reference's tables

@@ -144,6 +144,12 @@ SIGNATURES = {
     "kh_scale_d": (C.c_int, [vp, D, C.c_double]),
     "kh_sum_column_ranges_d": (C.c_int, [vp, D, vp, D, vp]),
     "kh_matrix_lookup_d": (C.c_int, [vp, D, vp, C.c_int, vp]),
+    "kh_online_decoder_set_pdf_map": (C.c_int, [vp, vp, C.c_int]),
+    "kh_online_nnet2_create": (vp, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
+    "kh_online_nnet2_destroy": (None, [vp]),
+    "kh_online_nnet2_reset": (C.c_int, [vp, vp, C.c_int]),
+    "kh_online_nnet2_step": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "kh_online_nnet2_num_frames_ready": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int32)]),
     "kh_lattice_batch_create": (vp, [C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "kh_lattice_batch_destroy": (None, [vp]),
     "kh_lattice_batch_sizes": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),

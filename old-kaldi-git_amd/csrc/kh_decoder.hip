@@ -3832,6 +3832,10 @@ struct KhOnlineDecoder {
   std::vector<int32_t> frames;       // NumFramesDecoded() per stream
   std::vector<char> inited, finalized;
   std::vector<long long> lat_key;    // what base->lats[stream] was built from (-1: nothing)
+  // kh_online_decoder_set_pdf_map: the (map, columns) pair the decoder's arc records were last built for
+  const int32_t *pinned_map = nullptr;
+  int pinned_cols = 0;
+  bool pinned = false;
 };
 
 namespace {
@@ -5405,9 +5409,12 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   Params p;
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   if (ll_stride <= 0) p.ll_cols = 0;
-  {
+  if (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols && b->rec != nullptr) {
+    p.rec = (GP(const KhInt4))b->rec;   // (the records hold this map's pdfs already: kh_online_decoder_set_pdf_map)
+  } else {
     const int rc = BuildArcPdf(b, &p, tid2pdf, ll_stride, st);
     if (rc) return rc;
+    o->pinned = false;
   }
   KH_HIP(hipMemcpyAsync(o->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(OnlineKernel, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), DynLdsBytes(p.ll_cols), st,
@@ -5498,6 +5505,19 @@ int kh_online_decoder_advance(KhOnlineDecoder *o, const int32_t *streams, int n,
   rc = LaunchJobs(o, jobs, ll_stride, tid2pdf);
   if (rc) return rc;
   return CheckStreams(o, streams, n, "kh_online_decoder_advance");
+}
+
+int kh_online_decoder_set_pdf_map(KhOnlineDecoder *o, const int32_t *tid2pdf, int num_cols) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o && num_cols > 0);
+  Params p;
+  FillParams(o->base, &p, num_cols, tid2pdf);
+  if ((rc = BuildArcPdf(o->base, &p, tid2pdf, num_cols, Stream()))) return rc;
+  o->pinned_map = tid2pdf;
+  o->pinned_cols = num_cols;
+  o->pinned = true;
+  return KH_OK;
 }
 
 int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *o, int stream, int32_t *num_frames) {

@@ -92,3 +92,65 @@ def test_features_to_lattice_online_equals_offline(api):
     for s in range(2):
         assert_same_lattice(dec.get_raw_lattice(s), offline.get_raw_lattice(s))
         assert_same_best_path(dec.get_best_path(s), offline.get_best_path(s))
+
+
+@pytest.mark.parametrize("pad_input", [True, False])
+def test_serving_step_in_one_call_equals_offline(api, pad_input):
+    """kh_online_nnet2_* (api.OnlineNnet2Pipeline): the whole per-chunk step - features in, ComputeForFrame for every
+    advancing stream in one forward pass, AdvanceDecoding - as ONE library call; ragged chunk sizes, streams that finish at
+    different steps, a stream restarted with a second utterance: lattices and best paths equal the offline pipeline."""
+    rng = np.random.default_rng(53)
+    n_pdf = 40
+    nnet = _setup(api, rng, n_pdf)
+    L, R = nnet.left_context(), nnet.right_context()
+    g = workloads.make_hclg_like(rng, 5000, n_pdf)
+    cfg = api.decoder_config(beam=10.0, max_active=800, min_active=50, lattice_beam=5.0)
+    fst = api.Fst(g)
+    Ts = [75, 140, 33, 98]
+    feats = [rng.standard_normal((T, 13)).astype(np.float32) for T in Ts]
+    x = torch.from_numpy(np.concatenate(feats, 0)).cuda()
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+
+    def offline(sel):
+        xs = torch.from_numpy(np.concatenate([feats[i] for i in sel], 0)).cuda()
+        o = np.concatenate([[0], np.cumsum([Ts[i] for i in sel])]).astype(np.int32)
+        ll, oo = nnet.compute(xs, o, pad_input=pad_input, epilogue=True, prob_scale=0.1)
+        d = api.LatticeFasterDecoder(fst, cfg, max_batch=len(sel), max_frames=max(Ts))
+        d.decode(ll, oo if not pad_input else o)
+        return d
+    ref = offline([0, 1, 2, 3])
+    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)
+    pipe = api.OnlineNnet2Pipeline(nnet, dec, max_frames=160, acoustic_scale=0.1, pad_input=pad_input, max_nnet_batch_size=40)
+    # streams 0..2 take utterances 0..2; when stream 2 (the short one) is done it takes utterance 3
+    utt_of = {0: 0, 1: 1, 2: 2}
+    fed = {0: 0, 1: 0, 2: 0}
+    pipe.reset([0, 1, 2])
+    results = {}
+    n_out = lambda u: Ts[u] if pad_input else Ts[u] - L - R
+    for step in range(400):
+        live = sorted(utt_of)
+        if not live:
+            break
+        cnt, rows, fin = [], [], []
+        for s in live:
+            u = utt_of[s]
+            k = int(min(Ts[u] - fed[s], rng.integers(0, 27)))     # (0 rows: a step in which the stream gets nothing new)
+            cnt.append(k)
+            rows.append(int(off[u] + fed[s]))
+            fed[s] += k
+            fin.append(fed[s] == Ts[u])
+        done = pipe.step(live, x, rows, cnt, fin)
+        for s, nd in zip(live, done.tolist()):
+            u = utt_of[s]
+            assert nd == dec.num_frames_decoded(s) and nd <= n_out(u)
+            if nd == n_out(u) and fed[s] == Ts[u]:
+                dec.finalize_decoding([s])
+                results[u] = (dec.get_raw_lattice(s), dec.get_best_path(s))
+                del utt_of[s]
+                if s == 2 and 3 not in results and u != 3:
+                    utt_of[2], fed[2] = 3, 0
+                    pipe.reset([2])
+    assert sorted(results) == [0, 1, 2, 3]
+    for u in range(4):
+        assert_same_lattice(results[u][0], ref.get_raw_lattice(u))
+        assert_same_best_path(results[u][1], ref.get_best_path(u))
