@@ -309,6 +309,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                 cnt = np.minimum(c, all_lens[u] - given[live])
                 fin = given[live] + cnt == all_lens[u]
                 done = pipe.step(live, x_all, off[u].astype(np.int64) + given[live], cnt, fin)
+                t_adv = time.perf_counter() - t0
                 given[live] += cnt
                 ended = live[done >= all_lens[u]]
                 if len(ended):
@@ -326,14 +327,22 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                         pipe.reset(fresh)
                     live = np.array([s for s in live if slot_utt[s] >= 0], np.int64)
                 api.synchronize()
-                lat.append((time.perf_counter() - t0, len(u), int(cnt.sum())))
+                lat.append((time.perf_counter() - t0, len(u), int(cnt.sum()), t_adv, len(ended)))
         ms = np.array([l[0] for l in lat]) * 1e3
         full = np.array([l[1] == n for l in lat])
         fr = np.array([l[2] for l in lat])
+        adv = np.array([l[3] for l in lat]) * 1e3
+        n_end = np.array([l[4] for l in lat])
         res["chunk_%d_frames" % c] = {
             "chunk_seconds": c * 0.01, "steps": len(lat), "steps_with_every_slot_busy": int(full.sum()), "utterances_served": int(n_done),
             "frames_per_s": float(fr[full].sum() / (ms[full].sum() * 1e-3)) if full.any() else None,
             "real_time_streams_sustained": float(fr[full].sum() / (ms[full].sum() * 1e-3) / 100.0) if full.any() else None,
+            # the chunk's own work (features in -> every slot advanced): what a caller waits for a partial result
+            "advance_ms": {"mean": float(adv[full].mean()) if full.any() else None, "p50": float(np.percentile(adv[full], 50)) if full.any() else None,
+                           "p95": float(np.percentile(adv[full], 95)) if full.any() else None},
+            # ... and the end-of-utterance work done inside the same steps (FinalizeDecoding of the slots that ended +
+            # InitDecoding of their next utterance; synchronous here, so it is charged to every slot's step)
+            "end_of_utterance_ms_per_utterance": float((ms[full] - adv[full]).sum() / max(1, n_end[full].sum())) if full.any() else None,
             "step_latency_ms": {"mean": float(ms[full].mean()) if full.any() else None,
                                 "p50": float(np.percentile(ms[full], 50)) if full.any() else None,
                                 "p95": float(np.percentile(ms[full], 95)) if full.any() else None, "max": float(ms.max())},
