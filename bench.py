@@ -633,10 +633,10 @@ def main():
         pipelined = pipelined and not pipe["disabled"]   # (a failed background forward pass: the rest ran one after the other)
         main_stats = dict(stats)
         # ---- the same step strictly one after the other (round-to-round comparison with the unpipelined headline of
-        # rounds 1-2), and in the reference's own iteration order (kh_decoder_set_reference_order): min(K, 5) steps each
+        # rounds 1-2), and in the reference's own iteration order (kh_decoder_set_reference_order): min(K, 3) steps each
         extra = {}
         if end_to_end and not args.no_extra_legs:
-            k2 = max(1, min(steps, 5))
+            k2 = max(1, min(steps, 3))
             t1 = time.perf_counter()
             for _ in range(k2):
                 step()
