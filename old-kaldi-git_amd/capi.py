@@ -226,6 +226,14 @@ def load():
         raise ImportError(
             "libkaldi_hip.so not found at %s — build it with `python __graft_entry__.py` "
             "(there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: the torch wheel carries its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever
+    # is loaded first serves both torch and this library; if libkaldi_hip.so came first and torch second, each would
+    # initialise its own copy and the second one finds no device (seen as "no ROCm-capable device" in smoke() after
+    # build()).  The Python layers above hold their device buffers in torch tensors, so torch's copy goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if os.environ.get("KH_LIB_OVERRIDE") and not hasattr(lib, name):
