@@ -409,10 +409,16 @@ int kh_decoder_get_best_paths(const KhDecoder *d, int first, int n, int32_t *ali
 /* kh_decoder_get_counters / kh_decoder_get_stats for utterances [first, first + n); either array may be NULL. */
 int kh_decoder_get_stats_batch(const KhDecoder *d, int first, int n, KhDecodeStats *counters, KhDecodeStats *stats);
 /* Host post-pass of the whole batch on num_threads host threads (<= 0: all
- * cores): GetRawLattice + GetBestPath of every utterance, i.e. what
+ * cores): GetBestPath of every utterance that has none yet, i.e. what
  * DecodeUtteranceLatticeFaster (decoder-wrappers.cc:215-262) does one utterance
  * at a time after Decode().  The per-utterance getters above then return the
- * cached results.  Optional: the getters compute on demand otherwise. */
+ * cached results.  Optional: the getters compute on demand otherwise, and
+ * kh_decoder_decode's own completion threads have normally done it already.
+ * Since round 4 the best path (and kh_decoder_get_stats' lattice sizes) come
+ * straight from the exported token / link arrays; the CANONICAL raw lattice of an
+ * utterance is built on first access (kh_decoder_get_raw_lattice, determinization)
+ * - the sort of every utterance's lattice was 2 ms of host CPU per utterance that a
+ * rank with few host threads does not have. */
 int kh_decoder_prepare(KhDecoder *dec, int num_threads);
 /* DeterminizeLatticePhonePrunedWrapper behind the decoder, as DecodeUtteranceLatticeFaster runs it when
  * determinize_lattice is set (decoder/decoder-wrappers.cc:264-274; LatticeFasterDecoderConfig::det_opts,

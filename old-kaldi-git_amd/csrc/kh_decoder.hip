@@ -4141,8 +4141,161 @@ inline int Compare(const LatWeight &w1, const LatWeight &w2) {
   else return 0;
 }
 
-// Best path of utterance `utt` on its canonical lattice, cached in the Lat.
+// Best path of utterance `utt` straight from the exported pool arrays, cached in the Lat: the result of ComputeBestPath
+// below (same LatticeWeight arithmetic, same tie rule) without building the canonical lattice first - two counting sorts
+// and one relaxation per link instead of the canonical sort of ~12 k states / ~20 k arcs and Bellman-Ford sweeps over all
+// of them (2 ms of CPU per utterance, which a rank with two host threads does not have: DESIGN.md section 5).
+// The raw lattice is layered: an emitting link goes from frame f to f + 1, an epsilon link stays inside its frame.  So the
+// links are bucketed by (destination frame, emitting before epsilon) and relaxed frame by frame, the epsilon links of a
+// frame to their fixed point.  Tie rule: ComputeBestPath prefers the smaller CANONICAL arc index among the arcs that reach
+// a state with Compare-equal weights; canonical arcs are ordered by (source state's canonical index = (frame, start token
+// first, HCLG state), ilabel, olabel, destination, graph cost, acoustic cost), which is compared on the keys here.
+// Returns 1 if the pool's layout is not the one expected (the caller then takes the canonical route).
+int ComputeBestPathLean(KhDecoder *d, int utt) {
+  KhDecoder::Lat &L = d->lats[utt];
+  const UttOut &o = d->h_out[utt];
+  if (o.stats.status != 0) {
+    SetError("utterance %d: decoder capacity overflow (code %d)", utt, o.stats.status);
+    return KH_ECAPACITY;
+  }
+  if (d->h_round[utt] >= 0) return 1;   // (online snapshots arrive built)
+  const KhDecoder::PoolView hp = d->hview;
+  const int T = d->h_T[utt];
+  const int n = static_cast<int>(o.n_tok), m = static_cast<int>(o.n_link);
+  if (n == 0) {
+    SetError("GetBestPath: empty lattice for utterance %d", utt);
+    return L.bp_rc = KH_ESTATE;
+  }
+  const int32_t *tf = hp.t_frame + o.tok_off, *ts = hp.t_state + o.tok_off;
+  const int32_t *ls = hp.l_src + o.link_off, *ld = hp.l_dst + o.link_off, *li = hp.l_il + o.link_off, *lo = hp.l_ol + o.link_off;
+  const float *lg = hp.l_g + o.link_off, *la = hp.l_a + o.link_off;
+  const int32_t start = d->fst->start_state;
+  const float inf = std::numeric_limits<float>::infinity();
+  static thread_local std::vector<int32_t> cnt, ord, parent;
+  static thread_local std::vector<LatWeight> dist;
+  int max_f = 0;
+  for (int k = 0; k < n; k++) {
+    if (tf[k] < 0) return 1;
+    max_f = std::max(max_f, tf[k]);
+  }
+  cnt.assign(2 * static_cast<size_t>(max_f) + 3, 0);
+  for (int j = 0; j < m; j++) {
+    if (ls[j] < 0 || ls[j] >= n || ld[j] < 0 || ld[j] >= n) return 1;
+    const int fs = tf[ls[j]], fd = tf[ld[j]];
+    if (fd != fs && fd != fs + 1) return 1;
+    cnt[2 * fd + (fd == fs ? 1 : 0) + 1]++;
+  }
+  for (size_t b = 0; b + 1 < cnt.size(); b++) cnt[b + 1] += cnt[b];
+  ord.resize(m);
+  {
+    static thread_local std::vector<int32_t> fill;
+    fill.assign(cnt.begin(), cnt.end() - 1);
+    for (int j = 0; j < m; j++) {
+      const int fs = tf[ls[j]], fd = tf[ld[j]];
+      ord[fill[2 * fd + (fd == fs ? 1 : 0)]++] = j;
+    }
+  }
+  // canonical state 0: the first token of frame 0 in the order (start token first, HCLG state)
+  int s0 = -1;
+  for (int k = 0; k < n; k++) {
+    if (tf[k] != 0) continue;
+    if (s0 < 0) { s0 = k; continue; }
+    const bool xs = ts[k] != start, ys = ts[s0] != start;
+    if (xs != ys ? xs < ys : ts[k] < ts[s0]) s0 = k;
+  }
+  if (s0 < 0) return 1;
+  dist.assign(n, LatWeight{inf, inf});
+  parent.assign(n, -1);
+  dist[s0] = LatWeight{0.f, 0.f};
+  // is link j in front of link p in the canonical arc order?  (both end in the same state)
+  auto before = [&](int j, int p) {
+    const int a = ls[j], b = ls[p];
+    if (a != b) {
+      if (tf[a] != tf[b]) return tf[a] < tf[b];
+      if (tf[a] == 0) {
+        const bool xs = ts[a] != start, ys = ts[b] != start;
+        if (xs != ys) return xs < ys;
+      }
+      if (ts[a] != ts[b]) return ts[a] < ts[b];
+    }
+    if (li[j] != li[p]) return li[j] < li[p];
+    if (lo[j] != lo[p]) return lo[j] < lo[p];
+    if (lg[j] != lg[p]) return lg[j] < lg[p];
+    return la[j] < la[p];
+  };
+  auto relax = [&](int j) -> bool {
+    const LatWeight sd = dist[ls[j]];
+    if (sd.v1 == inf) return false;
+    const LatWeight w{sd.v1 + lg[j], sd.v2 + la[j]};
+    LatWeight &nd = dist[ld[j]];
+    const int c = (nd.v1 == inf && nd.v2 == inf) ? 1 : Compare(w, nd);
+    if (c == 1 || (c == 0 && parent[ld[j]] != j && (parent[ld[j]] < 0 || before(j, parent[ld[j]])))) {
+      nd = w;
+      parent[ld[j]] = j;
+      return true;
+    }
+    return false;
+  };
+  for (int f = 0; f <= max_f; f++) {
+    for (int q = cnt[2 * f]; q < cnt[2 * f + 1]; q++) (void)relax(ord[q]);   // emitting links into frame f
+    const int eb = cnt[2 * f + 1], ee = cnt[2 * f + 2];
+    for (int guard = 0; guard < ee - eb + 2; guard++) {                      // epsilon links inside frame f
+      bool changed = false;
+      for (int q = eb; q < ee; q++) changed |= relax(ord[q]);
+      if (!changed) break;
+    }
+  }
+  // the final state: best dist + final cost (:177-186 as BuildLattice), ties to the smaller canonical state
+  const bool have_final = o.stats.reached_final != 0;
+  LatWeight best{inf, inf};
+  int best_state = -1;
+  for (int k = 0; k < n; k++) {
+    if (tf[k] != T || dist[k].v1 == inf) continue;
+    float fc = 0.0f;
+    if (have_final) {
+      fc = d->fst->final_host[ts[k]];
+      if (fc == inf) continue;
+    }
+    const LatWeight w{dist[k].v1 + fc, dist[k].v2 + 0.0f};
+    bool take = best_state < 0;
+    if (!take) {
+      const int c = Compare(w, best);
+      if (c == 1) take = true;
+      else if (c == 0) {
+        const bool xs = T == 0 && ts[k] != start, ys = T == 0 && ts[best_state] != start;
+        take = xs != ys ? xs < ys : ts[k] < ts[best_state];
+      }
+    }
+    if (take) { best = w; best_state = k; }
+  }
+  if (best_state < 0) {
+    SetError("GetBestPath: no final state reachable for utterance %d", utt);
+    return L.bp_rc = KH_ESTATE;
+  }
+  L.bp_ali.clear();
+  L.bp_words.clear();
+  for (int s = best_state; parent[s] >= 0; s = ls[parent[s]]) {
+    const int j = parent[s];
+    if (li[j] != 0) L.bp_ali.push_back(li[j]);
+    if (lo[j] != 0) L.bp_words.push_back(lo[j]);
+  }
+  std::reverse(L.bp_ali.begin(), L.bp_ali.end());
+  std::reverse(L.bp_words.begin(), L.bp_words.end());
+  L.bp_graph = best.v1;
+  L.bp_acoustic = best.v2;
+  return L.bp_rc = KH_OK;
+}
+
+// Best path of utterance `utt`, cached in the Lat: from the pool (above) unless the canonical lattice exists already or
+// KH_DECODER_CANONICAL_BESTPATH asks for the route over it (the cross-check of tests/test_gpu_decoder.py).
 int ComputeBestPath(KhDecoder *d, int utt) {
+  {
+    KhDecoder::Lat &L0 = d->lats[utt];
+    if (L0.bp_rc == 1 && !L0.built && !getenv("KH_DECODER_CANONICAL_BESTPATH")) {
+      const int rc = ComputeBestPathLean(d, utt);
+      if (rc != 1) return rc;
+    }
+  }
   int rc = BuildLattice(d, utt);
   if (rc) return rc;
   KhDecoder::Lat &L = d->lats[utt];
@@ -5125,6 +5278,25 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
       }
     }
     (void)used;
+    // Another launch follows and will write its lattices over this one's in the pool: the canonical lattices of the
+    // utterances that finished in this launch are built now (they are otherwise built on first access, from the pool).
+    if (!next.empty()) {
+      std::vector<int> keep;
+      for (int q = 0; q < np; q++)
+        if (q_out[q].stats.status == 0 && !d->lats[pending[q]].built) keep.push_back(pending[q]);
+      std::atomic<int> nk(0);
+      auto build = [&]() {
+        for (;;) {
+          const int i = nk.fetch_add(1);
+          if (i >= static_cast<int>(keep.size())) break;
+          (void)BuildLattice(d, keep[i]);   // (an error is reported again by the getter that asks for the lattice)
+        }
+      };
+      std::vector<std::thread> th;
+      for (int w = 1; w < std::min<int>(n_workers, static_cast<int>(keep.size())); w++) th.emplace_back(build);
+      build();
+      for (auto &t : th) t.join();
+    }
     // the utterances that need larger arenas have no lattice size yet: estimate again
     pool_exact = pool_short && !grow;
     if (grow) scale *= 2;
@@ -5190,11 +5362,14 @@ int kh_decoder_get_counters(const KhDecoder *d, int utt, KhDecodeStats *stats) {
 int kh_decoder_get_stats(const KhDecoder *dc, int utt, KhDecodeStats *stats) {
   KhDecoder *d = const_cast<KhDecoder *>(dc);
   KH_CHECK_ARG(d && stats && utt >= 0 && utt < d->n_utts);
-  int rc = BuildLattice(d, utt);
-  if (rc) return rc;
+  // the raw lattice's sizes are those of the export (the canonical lattice keeps every exported token and link)
+  if (d->h_out[utt].stats.status != 0) {
+    SetError("utterance %d: decoder capacity overflow (code %d)", utt, d->h_out[utt].stats.status);
+    return KH_ECAPACITY;
+  }
   *stats = d->h_out[utt].stats;
-  stats->num_tokens = static_cast<int32_t>(d->lats[utt].state_frame.size());
-  stats->num_links = static_cast<int32_t>(d->lats[utt].arc_src.size());
+  stats->num_tokens = static_cast<int32_t>(d->h_out[utt].n_tok);
+  stats->num_links = static_cast<int32_t>(d->h_out[utt].n_link);
   return KH_OK;
 }
 

@@ -48,9 +48,17 @@ def run_case(api, graph, lls, cfg, check_reference_lattice=False, check_referenc
     off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
     ll = torch.from_numpy(np.concatenate(lls, 0)).cuda()
     dec.decode(ll, off)
+    # before any raw lattice is asked for, the best paths come straight from the exported pool (ComputeBestPathLean);
+    # the route over the canonical lattice is held to the oracle in test_gpu_structured.py (decode_and_compare asks for
+    # the raw lattice first) and to this one in its check_pool_best_paths
+    pool_bp = dec.get_best_paths()
     for u, x in enumerate(lls):
         oc = B.DecoderOracle(graph, cfg, "canonical")
         assert oc.decode(x)
+        a0, a1, w0, w1 = pool_bp["ali_off"][u], pool_bp["ali_off"][u + 1], pool_bp["words_off"][u], pool_bp["words_off"][u + 1]
+        assert_same_best_path(dict(alignment=pool_bp["alignment"][a0:a1], words=pool_bp["words"][w0:w1],
+                                   graph_cost=float(pool_bp["graph_cost"][u]), acoustic_cost=float(pool_bp["acoustic_cost"][u])),
+                              oc.best_path())
         want, got = oc.raw_lattice(), dec.get_raw_lattice(u)
         assert_same_lattice(got, want)
         assert_same_best_path(dec.get_best_path(u), oc.best_path())

@@ -170,3 +170,26 @@ def test_bench_workload_slice(api):
     dec, dens, diffs = decode_and_compare(api, g, ll_dev, off, cfg, sample, max_inequivalent=1)   # (the 100-frame utterance)
     print("bench slice: lattice arcs/frame %s, arc difference vs reference order %s" % (dens, diffs))
     assert min(dens) > 5.0, dens
+    # the best paths the decoder computes straight from the exported pool (no canonical lattice) are those of the
+    # Bellman-Ford pass over the canonical lattice, for all 48 utterances: alignments, words, both costs bit for bit
+    check_pool_best_paths(api, dec, ll_dev, off)
+
+
+def check_pool_best_paths(api, dec, ll_dev, off):
+    assert "KH_DECODER_CANONICAL_BESTPATH" not in os.environ
+    dec.decode(ll_dev, off)
+    lean = dec.get_best_paths()
+    sizes = dec.stats_batch()[1]
+    os.environ["KH_DECODER_CANONICAL_BESTPATH"] = "1"
+    try:
+        dec.decode(ll_dev, off)
+        canon = dec.get_best_paths()
+    finally:
+        del os.environ["KH_DECODER_CANONICAL_BESTPATH"]
+    for k in ("alignment", "ali_off", "words", "words_off"):
+        assert np.array_equal(lean[k], canon[k]), k
+    for k in ("graph_cost", "acoustic_cost"):
+        assert np.array_equal(lean[k].view(np.uint32), canon[k].view(np.uint32)), k
+    for u in range(len(off) - 1):   # the sizes the stats report without building = those of the built lattice
+        lat = dec.get_raw_lattice(u)
+        assert sizes["num_tokens"][u] == len(lat["state_frame"]) and sizes["num_links"][u] == len(lat["arc_src"]), u
