@@ -461,6 +461,30 @@ int kh_online_decoder_advance(KhOnlineDecoder *dec, const int32_t *streams, int 
                               const int32_t *num_frames, const int32_t *tid2pdf);
 /* NumFramesDecoded() :194. */
 int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream, int32_t *num_frames);
+/* The same three calls without a kernel launch per chunk: a PERSISTENT serving kernel, one resident workgroup per stream
+ * (num_streams <= 2 x the CU count), which waits on a control block in pinned host memory (online2-wav-nnet2-latgen-faster's
+ * per-chunk loop :213-262 for many connections; a stream that is pruning - AdvanceDecoding prunes every prune_interval
+ * frames, lattice-faster-online-decoder.cc:811-813 - no longer holds up the others, which a lockstep launch cannot avoid).
+ * kh_online_decoder_serve_start: loglikes = the streams' score buffers (DEVICE, stream s owns rows
+ * [s * rows_per_stream, (s + 1) * rows_per_stream), row t = frame t of its current utterance; rows_per_stream >= max_frames),
+ * tid2pdf as kh_online_decoder_advance; the streams continue from where kh_online_decoder_* calls left them.
+ * kh_online_decoder_serve_init / _finalize: InitDecoding / FinalizeDecoding requests (asynchronous; FinalizeDecoding
+ * runs after the frames published so far).  kh_online_decoder_serve_publish: frames [0, avail[i]) of stream streams[i]
+ * have their scores in the buffer - the kernels that wrote them must have COMPLETED - and the stream decodes up to
+ * there.  kh_online_decoder_serve_poll: NumFramesDecoded() so far and whether a request is still in flight (either
+ * may be NULL); kh_online_decoder_serve_wait: blocks until the listed streams have caught up (timeout_ms <= 0: 60 s);
+ * afterwards the getters (kh_online_decoder_get_best_path, _get_raw_lattice, _get_stats) may be used on them while the
+ * kernel keeps serving the others.  kh_online_decoder_serve_stop: the kernel leaves (it also leaves by itself after
+ * 2 s without work, KH_SERVE_IDLE_MS, and is launched again by the next request: a device-wide synchronisation never
+ * waits longer than that); the launch-per-job calls work again.  Results are those of the launch-per-job calls. */
+int kh_online_decoder_serve_start(KhOnlineDecoder *dec, const float *loglikes, int ll_stride, int64_t rows_per_stream,
+                                  const int32_t *tid2pdf);
+int kh_online_decoder_serve_stop(KhOnlineDecoder *dec);
+int kh_online_decoder_serve_init(KhOnlineDecoder *dec, const int32_t *streams, int n);
+int kh_online_decoder_serve_publish(KhOnlineDecoder *dec, const int32_t *streams, int n, const int32_t *avail);
+int kh_online_decoder_serve_finalize(KhOnlineDecoder *dec, const int32_t *streams, int n);
+int kh_online_decoder_serve_poll(KhOnlineDecoder *dec, const int32_t *streams, int n, int32_t *decoded, int32_t *in_flight);
+int kh_online_decoder_serve_wait(KhOnlineDecoder *dec, const int32_t *streams, int n, int timeout_ms);
 /* Serving loops call kh_online_decoder_advance once per chunk with the same transition-id -> pdf map (DEVICE, or NULL) and
  * the same number of score columns: this builds the decoder's arc records for that pair ONCE (a pass over the whole graph
  * and a synchronisation otherwise repeated by every advance call) and validates the map as kh_online_decoder_advance
@@ -553,6 +577,17 @@ int kh_online_nnet2_step(KhOnlineNnet2 *h, const int32_t *streams, int n, const 
                          const int32_t *src_rows, const int32_t *counts, const int32_t *finished, const int32_t *tid2pdf,
                          int32_t *frames_decoded);
 int kh_online_nnet2_num_frames_ready(const KhOnlineNnet2 *h, int stream, int32_t *ready);
+/* Serving through the decoder's persistent kernel (kh_online_decoder_serve_*): after kh_online_nnet2_serve_start,
+ * kh_online_nnet2_step returns as soon as the chunk's scores are in the streams' score buffers and published (its
+ * frames_decoded = how far the decoder has got, which runs behind), kh_online_nnet2_reset requests InitDecoding,
+ * kh_online_nnet2_serve_finalize requests FinalizeDecoding (after the frames submitted so far); _serve_poll / _serve_wait
+ * as the decoder's calls.  The score buffers take num_streams x max_frames x output-dim floats of device memory.
+ * kh_online_nnet2_serve_stop: back to one launch per step.  Same lattices either way. */
+int kh_online_nnet2_serve_start(KhOnlineNnet2 *h, const int32_t *tid2pdf);
+int kh_online_nnet2_serve_stop(KhOnlineNnet2 *h);
+int kh_online_nnet2_serve_finalize(KhOnlineNnet2 *h, const int32_t *streams, int n);
+int kh_online_nnet2_serve_poll(KhOnlineNnet2 *h, const int32_t *streams, int n, int32_t *decoded, int32_t *in_flight);
+int kh_online_nnet2_serve_wait(KhOnlineNnet2 *h, const int32_t *streams, int n, int timeout_ms);
 
 /* LatticeStateTimes (lat/lattice-functions.cc:36-67) for a batch of top-sorted lattices
  * (layout as kh_lattice_forward_backward): time of every state (-1: unreachable) and, per

@@ -442,6 +442,31 @@ class OnlineNnet2Pipeline:
                                          ct.ctypes.data_as(ip), fi.ctypes.data_as(ip), self._t2p, out.ctypes.data_as(ip)))
         return out
 
+    # ---- serving through the decoder's persistent kernel (kh_online_nnet2_serve_*): step() then returns once the chunk's
+    # scores are published, the decoder follows at its own pace (a stream that prunes does not hold up the others)
+    def serve_start(self):
+        check(lib().kh_online_nnet2_serve_start(self._h, self._t2p))
+
+    def serve_stop(self):
+        check(lib().kh_online_nnet2_serve_stop(self._h))
+
+    def serve_finalize(self, streams):
+        """FinalizeDecoding of the streams once everything submitted to them is decoded (asynchronous)."""
+        st = np.ascontiguousarray(streams, np.int32)
+        check(lib().kh_online_nnet2_serve_finalize(self._h, st.ctypes.data_as(capi.c_int32_p), len(st)))
+
+    def serve_poll(self, streams):
+        """(NumFramesDecoded() so far, request still in flight) of the streams."""
+        st = np.ascontiguousarray(streams, np.int32)
+        dec, fl = np.empty(len(st), np.int32), np.empty(len(st), np.int32)
+        ip = capi.c_int32_p
+        check(lib().kh_online_nnet2_serve_poll(self._h, st.ctypes.data_as(ip), len(st), dec.ctypes.data_as(ip), fl.ctypes.data_as(ip)))
+        return dec, fl.astype(bool)
+
+    def serve_wait(self, streams, timeout_ms=0):
+        st = np.ascontiguousarray(streams, np.int32)
+        check(lib().kh_online_nnet2_serve_wait(self._h, st.ctypes.data_as(capi.c_int32_p), len(st), int(timeout_ms)))
+
 
 # ---------------------------------------------------------------- feature front-end
 class Mfcc:

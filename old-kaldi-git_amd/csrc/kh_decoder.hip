@@ -3679,6 +3679,127 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
 }
 
 
+// ---------------------------------------------------------------- persistent serving kernel
+// The same three jobs (InitDecoding / AdvanceDecoding / FinalizeDecoding) without a launch per chunk: one RESIDENT workgroup
+// per stream waits on a control block in pinned host memory.  The host publishes `avail` = the number of frames whose scores
+// are in the stream's score buffer (after the forward pass that wrote them has completed) and the workgroup decodes up to
+// there - pruning at the reference's own frames (NumFramesDecoded() % prune_interval == 0, inside DecodeFrames) - at its own
+// pace: a stream that prunes does not hold up the others, which is what a lockstep launch per chunk cannot avoid (the
+// launch lasts as long as its slowest workgroup, and with streams out of phase some workgroup prunes in every launch).
+// Commands (cmd_seq / cmd_op): InitDecoding has priority over pending frames, FinalizeDecoding runs after them.  After
+// every action the slot's state is saved to memory (SlotState + arenas, agent-scope fence) before it is acknowledged, so
+// an export job of OnlineKernel - launched by the host while this workgroup idles - sees it.  A workgroup leaves when the
+// host sets *quit, or after idle_ticks (wall clock, 100 MHz) without work: the kernel can never outlive its caller by
+// more than that (a device-wide synchronisation waits that long at most).
+struct ServeCtl {
+  int32_t avail, cmd_seq, cmd_op, pad0;     // host -> device
+  int32_t ack_seq, decoded, ok, alive;      // device -> host
+  int32_t pad1[8];
+};
+static_assert(sizeof(ServeCtl) == 64, "one control block per 64-byte line");
+enum { kCmdInit = 1, kCmdFinalize = 2 };
+
+template <class T>
+__device__ __forceinline__ int32_t SysLoad(T p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <class T>
+__device__ __forceinline__ void SysStore(T p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+__global__ void __launch_bounds__(NT)
+#if KH_WG_PER_CU > 1
+__attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
+#endif
+ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, ServeCtl *ctl, const int32_t *quit,
+            const float *ll_base, long long ll_rows_per_stream, int ll_stride, Params p, long long idle_ticks) {
+  __shared__ Shared shm;
+  extern __shared__ float dyn_ll_row[];
+  Blk sh;
+  sh.p = (LdsShared *)&shm;
+  sh.ll_row = (__attribute__((address_space(3))) float *)dyn_ll_row;
+  sh.k_or = 0;
+  sh.k_red = 0;
+  sh.k_scan = 0;
+  sh.x = nullptr;
+  const int s = blockIdx.x;
+  Utt u = slots[s];
+  SlotState *S = &states[s];
+  ServeCtl *c = &ctl[s];
+  u.phase_cycles = (GP(long long))nullptr;
+  u.ll = (GP(const float))(ll_base + static_cast<size_t>(s) * ll_rows_per_stream * ll_stride);
+  u.ll_stride = ll_stride;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
+    for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
+  }
+  KhSync();
+  Run run;
+  LoadState(*S, sh, &run);
+  bool ok = S->ok != 0;
+  bool fin = S->finalized != 0;
+  int acked = c->ack_seq;   // (the host set cmd_seq = ack_seq before the launch)
+  long long t_idle = wall_clock64();
+  if (threadIdx.x == 0) SysStore(&c->alive, 1);
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int act = 0, arg = 0;
+      const int q = SysLoad(quit);
+      const int seq = SysLoad(&c->cmd_seq);
+      const int op = SysLoad(&c->cmd_op);
+      const int av = SysLoad(&c->avail);
+      if (seq != acked && op == kCmdInit) act = 1;
+      else if (!fin && ok && av > run.t) { act = 2; arg = av; }
+      else if (seq != acked && op == kCmdFinalize) act = 3;
+      else if (seq != acked) act = 5;   // an unknown command: acknowledged, nothing done
+      else if (q != 0 || wall_clock64() - t_idle > idle_ticks) act = 4;
+      sh->bcast_i[0] = act;
+      sh->bcast_i[1] = arg;
+      sh->bcast_i[2] = seq;
+    }
+    KhSync();
+    const int act = Uni(sh->bcast_i[0]), arg = Uni(sh->bcast_i[1]), seq = Uni(sh->bcast_i[2]);
+    KhSync();
+    if (act == 0) {
+      __builtin_amdgcn_s_sleep(127);
+      continue;
+    }
+    if (act == 4) break;
+    if (act == 1) {          // InitDecoding (the body of OnlineKernel's kJobInit)
+      const int hw = S->tok_hw;
+      KhSync();
+      for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
+      for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+      for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
+      if (threadIdx.x == 0) sh->tok_hw = 0;
+      KhSync();
+      ok = DecodeInit(u, p, sh, &run);
+      SaveState(S, sh, run, ok);
+      if (threadIdx.x == 0) S->finalized = 0;
+      fin = false;
+      ok = ok && Uni(sh->status) == 0;
+    } else if (act == 2) {   // AdvanceDecoding up to the frames the host has published
+      ok = DecodeFrames<false>(u, p, sh, &run, arg);
+      SaveState(S, sh, run, ok);
+      ok = ok && Uni(sh->status) == 0;
+    } else if (act == 3) {   // FinalizeDecoding
+      KhDecodeStats st;
+      ok = DecodeFinalize<false>(u, p, sh, run, ok, &st);
+      SaveState(S, sh, run, ok);
+      if (threadIdx.x == 0) { S->finalized = 1; S->stats = st; }
+      fin = true;
+    }
+    __threadfence();   // the slot's arenas and SlotState are in memory before the acknowledgement
+    KhSync();
+    if (threadIdx.x == 0) {
+      SysStore(&c->ok, ok ? 1 : 0);
+      SysStore(&c->decoded, run.t);
+      if (act != 2) SysStore(&c->ack_seq, seq);
+    }
+    if (act != 2) acked = seq;
+    t_idle = wall_clock64();
+  }
+  KhSync();
+  if (threadIdx.x == 0) SysStore(&c->alive, 0);
+}
+
 __global__ void FillU32(uint32_t *p, size_t n, uint32_t v) {
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -3836,6 +3957,16 @@ struct KhOnlineDecoder {
   const int32_t *pinned_map = nullptr;
   int pinned_cols = 0;
   bool pinned = false;
+  // persistent serving kernel (kh_online_decoder_serve_*)
+  ServeCtl *serve_ctl = nullptr;          // pinned host memory, one 64-byte block per stream
+  int32_t *serve_quit = nullptr;          // pinned
+  hipStream_t serve_stream = nullptr;
+  bool serve_launched = false;            // a kernel has been launched and not yet seen to have ended
+  const float *serve_ll = nullptr;
+  long long serve_rows = 0;
+  int serve_stride = 0;
+  const int32_t *serve_map = nullptr;
+  std::vector<int32_t> serve_seq;         // last command sequence number issued per stream
 };
 
 namespace {
@@ -5572,6 +5703,10 @@ KhOnlineDecoder *kh_online_decoder_create(const KhFst *fst, const KhDecoderConfi
 
 void kh_online_decoder_destroy(KhOnlineDecoder *o) {
   if (!o) return;
+  (void)kh_online_decoder_serve_stop(o);
+  if (o->serve_ctl) (void)hipHostFree(o->serve_ctl);
+  if (o->serve_quit) (void)hipHostFree(o->serve_quit);
+  if (o->serve_stream) (void)hipStreamDestroy(o->serve_stream);
   PoolFree(o->d_states);
   PoolFree(o->d_jobs);
   kh_decoder_destroy(o->base);
@@ -5584,8 +5719,11 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   Params p;
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   if (ll_stride <= 0) p.ll_cols = 0;
-  if (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols && b->rec != nullptr) {
-    p.rec = (GP(const KhInt4))b->rec;   // (the records hold this map's pdfs already: kh_online_decoder_set_pdf_map)
+  if (b->rec != nullptr && (ll_stride <= 0 || (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols))) {
+    // the records hold this map's pdfs already (kh_online_decoder_set_pdf_map) - or the jobs read no scores at all
+    // (InitDecoding, FinalizeDecoding, export: only the graph's structure), and the records must not be rewritten under
+    // a serving kernel that is using them
+    p.rec = (GP(const KhInt4))b->rec;
   } else {
     const int rc = BuildArcPdf(b, &p, tid2pdf, ll_stride, st);
     if (rc) return rc;
@@ -5630,6 +5768,10 @@ int kh_online_decoder_init_decoding(KhOnlineDecoder *o, const int32_t *streams, 
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(o && streams && n > 0 && n <= o->num_streams && DistinctStreams(o, streams, n));
+  if (o->serve_launched) {
+    SetError("%s: the serving kernel owns the streams (kh_online_decoder_serve_* / kh_online_decoder_serve_stop)", "kh_online_decoder_init_decoding");
+    return KH_ESTATE;
+  }
   std::vector<Job> jobs(n);
   for (int i = 0; i < n; i++) {
     jobs[i].slot = streams[i];
@@ -5655,6 +5797,10 @@ int kh_online_decoder_advance(KhOnlineDecoder *o, const int32_t *streams, int n,
   if (rc) return rc;
   KH_CHECK_ARG(o && streams && loglikes && num_frames && n > 0 && n <= o->num_streams && ll_stride > 0 &&
                DistinctStreams(o, streams, n));
+  if (o->serve_launched) {
+    SetError("kh_online_decoder_advance: the serving kernel owns the streams (kh_online_decoder_serve_publish / kh_online_decoder_serve_stop)");
+    return KH_ESTATE;
+  }
   std::vector<Job> jobs;
   for (int i = 0; i < n; i++) {
     const int sidx = streams[i];
@@ -5706,6 +5852,10 @@ int kh_online_decoder_finalize(KhOnlineDecoder *o, const int32_t *streams, int n
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(o && streams && n > 0 && n <= o->num_streams && DistinctStreams(o, streams, n));
+  if (o->serve_launched) {
+    SetError("%s: the serving kernel owns the streams (kh_online_decoder_serve_* / kh_online_decoder_serve_stop)", "kh_online_decoder_finalize");
+    return KH_ESTATE;
+  }
   std::vector<Job> jobs(n);
   for (int i = 0; i < n; i++) {
     const int sidx = streams[i];
@@ -5724,6 +5874,201 @@ int kh_online_decoder_finalize(KhOnlineDecoder *o, const int32_t *streams, int n
   rc = LaunchJobs(o, jobs, 0, nullptr);
   if (rc) return rc;
   return CheckStreams(o, streams, n, "kh_online_decoder_finalize");
+}
+
+// ---- the persistent serving kernel (ServeKernel): start / stop, commands, progress
+static int ServeEnsureRunning(KhOnlineDecoder *o) {
+  if (!o->serve_ctl) {
+    SetError("the serving kernel has not been started (kh_online_decoder_serve_start)");
+    return KH_ESTATE;
+  }
+  if (o->serve_launched) {
+    const hipError_t q = hipStreamQuery(o->serve_stream);
+    if (q == hipErrorNotReady) return KH_OK;
+    (void)hipGetLastError();
+    if (q != hipSuccess) {
+      SetError("serving kernel: %s", hipGetErrorString(q));
+      return KH_EDEVICE;
+    }
+    o->serve_launched = false;   // it left after its idle time: launched again below
+  }
+  KhDecoder *b = o->base;
+  hipStream_t st = Stream();
+  Params p;
+  FillParams(b, &p, o->serve_stride, o->serve_map);
+  if (!(o->pinned && o->serve_map == o->pinned_map && o->serve_stride == o->pinned_cols && b->rec != nullptr)) {
+    const int rc = kh_online_decoder_set_pdf_map(o, o->serve_map, o->serve_stride);
+    if (rc) return rc;
+  }
+  p.rec = (GP(const KhInt4))b->rec;
+  KH_HIP(hipStreamSynchronize(st));   // whatever launch-per-job work is queued has written its SlotStates
+  __atomic_store_n(o->serve_quit, 0, __ATOMIC_RELEASE);
+  void *ctl_dev = nullptr, *quit_dev = nullptr;
+  KH_HIP(hipHostGetDevicePointer(&ctl_dev, o->serve_ctl, 0));
+  KH_HIP(hipHostGetDevicePointer(&quit_dev, o->serve_quit, 0));
+  long long idle_ticks = 200000000ll;   // 2 s of the 100 MHz wall clock
+  if (const char *e = getenv("KH_SERVE_IDLE_MS")) idle_ticks = std::max(1ll, static_cast<long long>(atof(e) * 1e5));
+  hipLaunchKernelGGL(ServeKernel, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
+                     b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<const int32_t *>(quit_dev), o->serve_ll,
+                     o->serve_rows, o->serve_stride, p, idle_ticks);
+  KH_LAUNCH_CHECK();
+  o->serve_launched = true;
+  return KH_OK;
+}
+
+int kh_online_decoder_serve_start(KhOnlineDecoder *o, const float *loglikes, int ll_stride, int64_t rows_per_stream,
+                                  const int32_t *tid2pdf) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o && loglikes && ll_stride > 0 && rows_per_stream >= o->max_frames);
+  if (o->num_streams > KH_WG_PER_CU * NumCUs()) {
+    SetError("kh_online_decoder_serve_start: %d streams, but only %d workgroups can be resident at once", o->num_streams,
+             KH_WG_PER_CU * NumCUs());
+    return KH_EINVAL;
+  }
+  if ((rc = kh_online_decoder_serve_stop(o))) return rc;
+  if (!o->serve_ctl) {
+    KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&o->serve_ctl), sizeof(ServeCtl) * o->num_streams, hipHostMallocMapped));
+    KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&o->serve_quit), 64, hipHostMallocMapped));
+    KH_HIP(hipStreamCreateWithFlags(&o->serve_stream, hipStreamNonBlocking));
+    memset(o->serve_ctl, 0, sizeof(ServeCtl) * o->num_streams);
+    o->serve_seq.assign(o->num_streams, 0);
+  }
+  for (int s = 0; s < o->num_streams; s++) {   // pick up where the launch-per-job calls left the streams
+    o->serve_ctl[s].avail = o->frames[s];
+    o->serve_ctl[s].decoded = o->frames[s];
+    o->serve_ctl[s].ok = 1;
+  }
+  o->serve_ll = loglikes;
+  o->serve_stride = ll_stride;
+  o->serve_rows = rows_per_stream;
+  o->serve_map = tid2pdf;
+  return ServeEnsureRunning(o);
+}
+
+int kh_online_decoder_serve_stop(KhOnlineDecoder *o) {
+  KH_CHECK_ARG(o);
+  if (!o->serve_ctl || !o->serve_launched) return KH_OK;
+  __atomic_store_n(o->serve_quit, 1, __ATOMIC_RELEASE);
+  const hipError_t e = hipStreamSynchronize(o->serve_stream);
+  o->serve_launched = false;
+  if (e != hipSuccess) {
+    SetError("kh_online_decoder_serve_stop: %s", hipGetErrorString(e));
+    return KH_EDEVICE;
+  }
+  for (int s = 0; s < o->num_streams; s++) {
+    o->frames[s] = __atomic_load_n(&o->serve_ctl[s].decoded, __ATOMIC_ACQUIRE);
+    o->lat_key[s] = -1;
+  }
+  return KH_OK;
+}
+
+static int ServeCommand(KhOnlineDecoder *o, const int32_t *streams, int n, int op) {
+  for (int i = 0; i < n; i++) {
+    ServeCtl &c = o->serve_ctl[streams[i]];
+    if (op == kCmdInit) __atomic_store_n(&c.avail, 0, __ATOMIC_RELEASE);
+    __atomic_store_n(&c.cmd_op, op, __ATOMIC_RELEASE);
+    __atomic_store_n(&c.cmd_seq, ++o->serve_seq[streams[i]], __ATOMIC_RELEASE);
+  }
+  return ServeEnsureRunning(o);
+}
+
+// InitDecoding of the listed streams by the serving kernel (asynchronous: kh_online_decoder_serve_wait).
+int kh_online_decoder_serve_init(KhOnlineDecoder *o, const int32_t *streams, int n) {
+  KH_CHECK_ARG(o && o->serve_ctl && streams && n > 0 && n <= o->num_streams && DistinctStreams(o, streams, n));
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
+    if (o->serve_seq[s] != __atomic_load_n(&o->serve_ctl[s].ack_seq, __ATOMIC_ACQUIRE)) {
+      SetError("kh_online_decoder_serve_init: stream %d still has a command in flight", s);
+      return KH_ESTATE;
+    }
+    o->inited[s] = 1;
+    o->finalized[s] = 0;
+    o->frames[s] = 0;
+    o->lat_key[s] = -1;
+  }
+  return ServeCommand(o, streams, n, kCmdInit);
+}
+
+// Scores of frames [0, avail[i]) of stream streams[i] are in its score buffer (the kernels that wrote them have completed):
+// the stream decodes up to there.
+int kh_online_decoder_serve_publish(KhOnlineDecoder *o, const int32_t *streams, int n, const int32_t *avail) {
+  KH_CHECK_ARG(o && o->serve_ctl && streams && avail && n > 0 && n <= o->num_streams);
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
+    KH_CHECK_ARG(s >= 0 && s < o->num_streams && avail[i] >= 0 && avail[i] <= o->max_frames);
+    if (!o->inited[s] || o->finalized[s]) {
+      SetError("kh_online_decoder_serve_publish: stream %d: call InitDecoding() first, and not after FinalizeDecoding()", s);
+      return KH_ESTATE;
+    }
+    __atomic_store_n(&o->serve_ctl[s].avail, avail[i], __ATOMIC_RELEASE);
+    o->lat_key[s] = -1;
+  }
+  return ServeEnsureRunning(o);
+}
+
+// FinalizeDecoding of the listed streams once their published frames are decoded (asynchronous).
+int kh_online_decoder_serve_finalize(KhOnlineDecoder *o, const int32_t *streams, int n) {
+  KH_CHECK_ARG(o && o->serve_ctl && streams && n > 0 && n <= o->num_streams && DistinctStreams(o, streams, n));
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
+    if (!o->inited[s] || o->finalized[s]) {
+      SetError("kh_online_decoder_serve_finalize: stream %d is not in a decoding run", s);
+      return KH_ESTATE;
+    }
+    o->finalized[s] = 1;
+    o->lat_key[s] = -1;
+  }
+  return ServeCommand(o, streams, n, kCmdFinalize);
+}
+
+// Progress of the listed streams: NumFramesDecoded() so far, and whether a command (InitDecoding / FinalizeDecoding) is
+// still in flight.  Either output may be NULL.
+int kh_online_decoder_serve_poll(KhOnlineDecoder *o, const int32_t *streams, int n, int32_t *decoded, int32_t *in_flight) {
+  KH_CHECK_ARG(o && o->serve_ctl && streams && n > 0);
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
+    KH_CHECK_ARG(s >= 0 && s < o->num_streams);
+    const ServeCtl &c = o->serve_ctl[s];
+    const int ack = __atomic_load_n(&c.ack_seq, __ATOMIC_ACQUIRE);
+    const int dec = __atomic_load_n(&c.decoded, __ATOMIC_ACQUIRE);
+    if (!__atomic_load_n(&c.ok, __ATOMIC_ACQUIRE)) {
+      SetError("serving kernel: stream %d overflowed a decoder arena at frame %d; see KH_DECODER_TOKENS_PER_FRAME / "
+               "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME", s, dec);
+      return KH_ECAPACITY;
+    }
+    const bool pending = ack != o->serve_seq[s];
+    // (between an InitDecoding command and its acknowledgement `decoded` still belongs to the previous utterance)
+    o->frames[s] = (pending && c.cmd_op == kCmdInit) ? 0 : dec;
+    if (decoded) decoded[i] = o->frames[s];
+    if (in_flight) in_flight[i] = pending ? 1 : 0;
+  }
+  return KH_OK;
+}
+
+// Blocks until the listed streams have decoded everything published to them and acknowledged their commands
+// (timeout_ms <= 0: 60 s).  The getters of the online decoder may be used on them afterwards.
+int kh_online_decoder_serve_wait(KhOnlineDecoder *o, const int32_t *streams, int n, int timeout_ms) {
+  KH_CHECK_ARG(o && o->serve_ctl && streams && n > 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  const double limit = timeout_ms > 0 ? timeout_ms : 60000.0;
+  std::vector<int32_t> dec(n), fl(n);
+  for (;;) {
+    int rc = ServeEnsureRunning(o);
+    if (rc) return rc;
+    if ((rc = kh_online_decoder_serve_poll(o, streams, n, dec.data(), fl.data()))) return rc;
+    bool all = true;
+    for (int i = 0; i < n && all; i++) {
+      const ServeCtl &c = o->serve_ctl[streams[i]];
+      all = !fl[i] && (o->finalized[streams[i]] || dec[i] >= __atomic_load_n(&c.avail, __ATOMIC_ACQUIRE));
+    }
+    if (all) return KH_OK;
+    if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      SetError("kh_online_decoder_serve_wait: timed out after %.0f ms", limit);
+      return KH_EDEVICE;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
 }
 
 // Snapshot of a stream's raw lattice into base->lats[stream] (GetRawLattice,

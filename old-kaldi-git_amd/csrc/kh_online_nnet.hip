@@ -58,6 +58,12 @@ struct KhOnlineNnet2 {
   size_t h_cap = 0;
   std::vector<int32_t> v_idx, off, out_off, act, nfr;
   std::vector<const float *> ptrs;
+  // serving through the decoder's persistent kernel (kh_online_nnet2_serve_start): every stream's scores of the current
+  // utterance, row t = frame t; `decoded` then counts the frames SUBMITTED to the decoder, which follows at its own pace
+  bool serving = false;
+  float *ll = nullptr;                    // [num_streams * max_frames, out_stride]
+  const int32_t *serve_map = nullptr;
+  std::vector<int32_t> avail;
 };
 
 extern "C" {
@@ -97,6 +103,8 @@ KhOnlineNnet2 *kh_online_nnet2_create(KhNnet *nnet, KhOnlineDecoder *dec, int nu
 
 void kh_online_nnet2_destroy(KhOnlineNnet2 *h) {
   if (!h) return;
+  (void)kh_online_nnet2_serve_stop(h);
+  if (h->ll) PoolFree(h->ll);
   PoolFree(h->feats);
   if (h->h_idx) (void)hipHostFree(h->h_idx);
   delete h;
@@ -111,6 +119,7 @@ int kh_online_nnet2_reset(KhOnlineNnet2 *h, const int32_t *streams, int n) {
     h->finished[streams[i]] = 0;
     h->decoded[streams[i]] = 0;
   }
+  if (h->serving) return kh_online_decoder_serve_init(h->dec, streams, n);
   return kh_online_decoder_init_decoding(h->dec, streams, n);
 }
 
@@ -170,6 +179,16 @@ int kh_online_nnet2_step(KhOnlineNnet2 *h, const int32_t *streams, int n, const 
     h->nfr.push_back(m);
   }
   const int n_act = static_cast<int>(h->act.size()), n_rows = h->off.back();
+  // (serving) the rows of the network's output go to the streams' score buffers: destination rows, then source rows
+  const size_t score_b = v.size();
+  size_t n_score = 0;
+  if (h->serving) {
+    for (int k = 0; k < n_act; k++)
+      for (int j = 0; j < h->nfr[k]; j++) v.push_back(h->act[k] * h->max_frames + h->decoded[h->act[k]] + j);
+    for (int k = 0, r = 0; k < n_act; k++)
+      for (int j = 0; j < h->nfr[k]; j++) v.push_back(r++);
+    n_score = (v.size() - score_b) / 2;
+  }
   // ---- (3) one upload of all indices, the scatter, the gather, the forward pass
   if (!v.empty()) {
     if (v.size() > h->h_cap) {
@@ -209,14 +228,78 @@ int kh_online_nnet2_step(KhOnlineNnet2 *h, const int32_t *streams, int n, const 
       }
       h->ptrs[k] = h->d_out.p + static_cast<size_t>(h->out_off[k]) * h->out_stride;
     }
-    if ((rc = kh_online_decoder_advance(h->dec, h->act.data(), n_act, h->ptrs.data(), h->out_stride, h->nfr.data(), tid2pdf))) return rc;
-    for (int k = 0; k < n_act; k++) h->decoded[h->act[k]] += h->nfr[k];
+    if (h->serving) {
+      // the scores into the streams' buffers; once they are there (the stream is idle) the decoder is told how far it may go
+      hipLaunchKernelGGL(ScatterRowsKernel, dim3(static_cast<unsigned>(std::min<size_t>(n_score, 4096))), dim3(256), 0, st, h->ll,
+                         h->out_stride, h->d_out.p, h->out_stride, h->d_idx.p + score_b, h->d_idx.p + score_b + n_score,
+                         static_cast<int>(n_score), h->out_dim);
+      KH_LAUNCH_CHECK();
+      KH_HIP(hipStreamSynchronize(st));
+      h->avail.resize(n_act);
+      for (int k = 0; k < n_act; k++) {
+        h->decoded[h->act[k]] += h->nfr[k];
+        h->avail[k] = h->decoded[h->act[k]];
+      }
+      if ((rc = kh_online_decoder_serve_publish(h->dec, h->act.data(), n_act, h->avail.data()))) return rc;
+    } else {
+      if ((rc = kh_online_decoder_advance(h->dec, h->act.data(), n_act, h->ptrs.data(), h->out_stride, h->nfr.data(), tid2pdf))) return rc;
+      for (int k = 0; k < n_act; k++) h->decoded[h->act[k]] += h->nfr[k];
+    }
   } else {
     KH_HIP(hipStreamSynchronize(st));
   }
-  if (frames_decoded)
+  if (h->serving) {   // what the decoder has reached so far (it runs behind the submissions)
+    if (frames_decoded && (rc = kh_online_decoder_serve_poll(h->dec, streams, n, frames_decoded, nullptr))) return rc;
+  } else if (frames_decoded) {
     for (int i = 0; i < n; i++) frames_decoded[i] = h->decoded[streams[i]];
+  }
   return KH_OK;
+}
+
+// Serving through the decoder's persistent kernel: from here on kh_online_nnet2_step returns when the chunk's scores are
+// in the streams' buffers and published; the decoder follows at its own pace (kh_online_nnet2_serve_poll / _wait), a
+// finished utterance is finalized by kh_online_nnet2_serve_finalize (asynchronous) and read through the online decoder's
+// getters after kh_online_nnet2_serve_wait.  tid2pdf as kh_online_nnet2_step.
+int kh_online_nnet2_serve_start(KhOnlineNnet2 *h, const int32_t *tid2pdf) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(h);
+  if (h->serving) return KH_OK;
+  if (!h->ll) {
+    h->ll = static_cast<float *>(PoolMalloc(sizeof(float) * static_cast<size_t>(h->num_streams) * h->max_frames * h->out_stride));
+    if (!h->ll) {
+      SetError("kh_online_nnet2_serve_start: no device memory for %d streams x %d frames of scores", h->num_streams, h->max_frames);
+      return KH_ENOMEM;
+    }
+  }
+  h->serve_map = tid2pdf;
+  if ((rc = kh_online_decoder_serve_start(h->dec, h->ll, h->out_stride, h->max_frames, tid2pdf))) return rc;
+  h->serving = true;
+  return KH_OK;
+}
+
+int kh_online_nnet2_serve_stop(KhOnlineNnet2 *h) {
+  KH_CHECK_ARG(h);
+  if (!h->serving) return KH_OK;
+  h->serving = false;
+  return kh_online_decoder_serve_stop(h->dec);
+}
+
+// FinalizeDecoding of the listed streams once everything submitted to them is decoded (asynchronous).
+int kh_online_nnet2_serve_finalize(KhOnlineNnet2 *h, const int32_t *streams, int n) {
+  KH_CHECK_ARG(h && h->serving);
+  return kh_online_decoder_serve_finalize(h->dec, streams, n);
+}
+
+// NumFramesDecoded() of the listed streams so far / whether InitDecoding or FinalizeDecoding is still in flight.
+int kh_online_nnet2_serve_poll(KhOnlineNnet2 *h, const int32_t *streams, int n, int32_t *decoded, int32_t *in_flight) {
+  KH_CHECK_ARG(h && h->serving);
+  return kh_online_decoder_serve_poll(h->dec, streams, n, decoded, in_flight);
+}
+
+int kh_online_nnet2_serve_wait(KhOnlineNnet2 *h, const int32_t *streams, int n, int timeout_ms) {
+  KH_CHECK_ARG(h && h->serving);
+  return kh_online_decoder_serve_wait(h->dec, streams, n, timeout_ms);
 }
 
 // NumFramesReady() (:75-89) of a stream, and whether `frame` is its last one (IsLastFrame :67-73; -1 = unknown yet).

@@ -154,3 +154,93 @@ def test_serving_step_in_one_call_equals_offline(api, pad_input):
     for u in range(4):
         assert_same_lattice(results[u][0], ref.get_raw_lattice(u))
         assert_same_best_path(results[u][1], ref.get_best_path(u))
+
+
+@pytest.mark.parametrize("pad_input", [True, False])
+def test_persistent_serving_kernel_equals_offline(api, pad_input, monkeypatch):
+    """The same loop through the decoder's PERSISTENT serving kernel (kh_online_nnet2_serve_*): step() only publishes the
+    chunk's scores, the resident workgroups decode at their own pace, FinalizeDecoding is requested asynchronously and the
+    lattice is read after serve_wait - while the kernel keeps serving the other streams, and once more after the kernel
+    has left by its idle time and been launched again.  Same lattices and best paths as the offline pipeline; a partial
+    hypothesis mid-utterance equals the one of the launch-per-step path."""
+    monkeypatch.setenv("KH_SERVE_IDLE_MS", "300")
+    rng = np.random.default_rng(54)
+    n_pdf = 40
+    nnet = _setup(api, rng, n_pdf)
+    L, R = nnet.left_context(), nnet.right_context()
+    g = workloads.make_hclg_like(rng, 5000, n_pdf)
+    cfg = api.decoder_config(beam=10.0, max_active=800, min_active=50, lattice_beam=5.0, prune_interval=7)
+    fst = api.Fst(g)
+    Ts = [75, 140, 33, 98, 61]
+    feats = [rng.standard_normal((T, 13)).astype(np.float32) for T in Ts]
+    x = torch.from_numpy(np.concatenate(feats, 0)).cuda()
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+    ll, oo = nnet.compute(x, off, pad_input=pad_input, epilogue=True, prob_scale=0.1)
+    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=len(Ts), max_frames=max(Ts))
+    ref.decode(ll, oo if not pad_input else off)
+    n_out = lambda u: Ts[u] if pad_input else Ts[u] - L - R
+
+    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)
+    pipe = api.OnlineNnet2Pipeline(nnet, dec, max_frames=160, acoustic_scale=0.1, pad_input=pad_input, max_nnet_batch_size=40)
+    pipe.serve_start()
+    queue = [3, 4]                       # utterances waiting for a free stream
+    utt_of = {0: 0, 1: 1, 2: 2}
+    fed = {0: 0, 1: 0, 2: 0}
+    finalizing = {}                      # stream -> utterance whose FinalizeDecoding is in flight
+    pipe.reset([0, 1, 2])
+    results, partial = {}, {}
+    import time
+    for step in range(2000):
+        if not utt_of and not finalizing:
+            break
+        live = sorted(utt_of)
+        if live:
+            cnt, rows, fin = [], [], []
+            for s in live:
+                u = utt_of[s]
+                k = int(min(Ts[u] - fed[s], rng.integers(0, 27)))
+                cnt.append(k)
+                rows.append(int(off[u] + fed[s]))
+                fed[s] += k
+                fin.append(fed[s] == Ts[u])
+            done = pipe.step(live, x, rows, cnt, fin)
+            for s, nd in zip(live, done.tolist()):
+                assert 0 <= nd <= n_out(utt_of[s])
+            for s in live:               # everything handed over: FinalizeDecoding behind the frames still to be decoded
+                if fed[s] == Ts[utt_of[s]]:
+                    pipe.serve_finalize([s])
+                    finalizing[s] = utt_of.pop(s)
+            if step == 3 and 1 in utt_of:    # a partial result mid-utterance, while the kernel serves on
+                pipe.serve_wait([1])
+                partial["frames"] = dec.num_frames_decoded(1)
+                partial["bp"] = dec.get_best_path(1, use_final_probs=False)
+        for s in sorted(finalizing):
+            dcd, busy = pipe.serve_poll([s])
+            if busy[0]:
+                continue
+            u = finalizing.pop(s)
+            assert dcd[0] == n_out(u)
+            results[u] = (dec.get_raw_lattice(s), dec.get_best_path(s))
+            if len(results) == 3:
+                time.sleep(0.6)          # the kernel leaves after 300 ms without work; the next request launches it again
+            if queue:
+                utt_of[s], fed[s] = queue.pop(0), 0
+                pipe.reset([s])
+    pipe.serve_stop()
+    assert sorted(results) == list(range(len(Ts)))
+    for u in range(len(Ts)):
+        assert_same_lattice(results[u][0], ref.get_raw_lattice(u))
+        assert_same_best_path(results[u][1], ref.get_best_path(u))
+    # the partial hypothesis: that of the launch-per-step path after the same number of frames of utterance 1
+    assert partial and partial["frames"] > 0
+    dec2 = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=1, max_frames=160)
+    dec2.init_decoding([0])
+    lo = int(oo[1]) if not pad_input else int(off[1])
+    dec2.advance_decoding([0], [ll[lo:lo + partial["frames"]]])
+    assert_same_best_path(partial["bp"], dec2.get_best_path(0, use_final_probs=False))
+    # after serve_stop the launch-per-step calls work again on the same objects
+    pipe.reset([0])
+    done = pipe.step([0], x, [int(off[2])], [Ts[2]], [True])
+    assert done[0] == n_out(2)
+    dec.finalize_decoding([0])
+    assert_same_lattice(dec.get_raw_lattice(0), ref.get_raw_lattice(2))

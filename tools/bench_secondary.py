@@ -3,6 +3,7 @@ config 4), each a bounded measurement on cuda:0 with inputs resident in HBM.  ru
 returns a dict that bench.py attaches to its JSON line as "secondary" — the driver-visible
 record of the numbers DESIGN.md quotes.  Product API only (no oracle)."""
 import importlib
+import os
 import time
 
 import numpy as np
@@ -348,6 +349,91 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                                 "p95": float(np.percentile(ms[full], 95)) if full.any() else None, "max": float(ms.max())},
             "step": "kh_online_nnet2_step (one library call per chunk; finished slots finalized and given the next utterance "
                     "inside the timed step)"}
+    R = nnet.right_context()
+    ahead = int(os.environ.get("KH_BENCH_SERVE_AHEAD", "1"))
+    for c in chunks:
+        # The same service through the decoder's PERSISTENT kernel (kh_online_nnet2_serve_*): no decode launch per chunk, one
+        # resident workgroup per stream.  A stream is handed its next chunk while at most ONE chunk of its frames is still
+        # waiting to be decoded (the next chunk of audio arrives while the previous one is being worked on) - a
+        # stream that is pruning (every prune_interval frames) or finalizing simply misses turns instead of holding the
+        # step up for everybody; FinalizeDecoding is requested asynchronously and the slot takes its next utterance when it
+        # is acknowledged.  step_call_ms = the host's step (features in -> scores published); chunk_latency_ms = per stream
+        # and chunk, from handing the chunk over to NumFramesDecoded() having reached its frames (polled once per turn).
+        pipe.serve_start()
+        for rep in range(2):
+            slot_utt = np.arange(n)
+            next_utt = n
+            given = np.zeros(n, np.int64)
+            state = np.zeros(n, np.int8)           # 0 running, 1 FinalizeDecoding in flight, 2 no utterance left
+            out = [[] for _ in range(n)]           # per slot: (time handed over, NumFramesDecoded() that completes the chunk)
+            pipe.reset(list(range(n)))
+            all_slots = np.arange(n)
+            calls, chunk_lat, marks = [], [], []
+            n_done = frames_done = 0
+            t_begin = time.perf_counter()
+            while (state != 2).any():
+                dcd, busy = pipe.serve_poll(all_slots)
+                now = time.perf_counter()
+                u = np.maximum(slot_utt, 0)
+                want = np.where(given >= all_lens[u], all_lens[u], np.maximum(0, given - R))   # frames submitted to the decoder
+                for sl in np.nonzero(~busy)[0]:
+                    q = out[sl]
+                    while q and dcd[sl] >= q[0][1]:
+                        chunk_lat.append(now - q.pop(0)[0])
+                for sl in np.nonzero((state == 1) & ~busy)[0]:       # finalized: the slot's next utterance
+                    n_done += 1
+                    frames_done += int(all_lens[slot_utt[sl]])
+                    out[sl] = []
+                    if next_utt < n_utts and all_lens[next_utt] <= max_t:
+                        slot_utt[sl], given[sl], state[sl] = next_utt, 0, 0
+                        want[sl] = dcd[sl] = 0
+                        next_utt += 1
+                        pipe.reset([int(sl)])
+                    else:
+                        slot_utt[sl], state[sl] = -1, 2
+                marks.append((now, n_done, frames_done, int((state != 2).sum())))
+                # a stream takes its next chunk while at most `ahead` chunks of frames are still waiting to be decoded
+                ready = np.nonzero((state == 0) & (want - dcd <= ahead * c))[0]
+                if len(ready) == 0:
+                    time.sleep(5e-5)
+                    continue
+                t0 = time.perf_counter()
+                uu = slot_utt[ready]
+                cnt = np.minimum(c, all_lens[uu] - given[ready])
+                fin = given[ready] + cnt == all_lens[uu]
+                pipe.step(ready, x_all, off[uu].astype(np.int64) + given[ready], cnt, fin)
+                given[ready] += cnt
+                tgt = np.where(fin, all_lens[uu], np.maximum(0, given[ready] - R))
+                for sl, tg in zip(ready.tolist(), tgt.tolist()):
+                    out[sl].append((t0, tg))
+                ended = ready[fin]
+                if len(ended):
+                    pipe.serve_finalize(ended)
+                    state[ended] = 1
+                calls.append((time.perf_counter() - t0, len(ready), int(cnt.sum())))
+            total = time.perf_counter() - t_begin
+        pipe.serve_stop()
+        marks = np.array(marks)
+        full = marks[:, 3] == n                      # every slot had an utterance
+        if full.any():
+            i0, i1 = np.nonzero(full)[0][[0, -1]]
+            # frames of the utterances that COMPLETED inside the window in which every slot was busy
+            fps = float((marks[i1, 2] - marks[i0, 2]) / max(1e-9, marks[i1, 0] - marks[i0, 0]))
+        else:
+            fps = None
+        cm = np.array([x_[0] for x_ in calls]) * 1e3
+        cl = np.array(chunk_lat) * 1e3
+        res["chunk_%d_frames_persistent" % c] = {
+            "chunk_seconds": c * 0.01, "utterances_served": int(n_done), "frames_per_s": fps,
+            "real_time_streams_sustained": fps / 100.0 if fps else None,
+            "frames_per_s_whole_run": float(frames_done / total),
+            "step_calls": len(calls), "streams_per_step_call": float(np.mean([x_[1] for x_ in calls])),
+            "step_call_ms": {"mean": float(cm.mean()), "p50": float(np.percentile(cm, 50)), "p95": float(np.percentile(cm, 95))},
+            "chunk_latency_ms": {"mean": float(cl.mean()), "p50": float(np.percentile(cl, 50)), "p95": float(np.percentile(cl, 95)),
+                                 "max": float(cl.max())},
+            "chunks_ahead": ahead,
+            "step": "kh_online_nnet2_serve_*: persistent decode kernel, one resident workgroup per stream; a stream gets its next "
+                    "chunk while at most `chunks_ahead` chunks of its frames wait to be decoded; FinalizeDecoding asynchronous"}
     for c in chunks[:1]:
         # ... and the same loop through the Python-side DecodableNnet2Online + advance_decoding (round 3's leg)
         dn = api.DecodableNnet2Online(nnet, n, max_t, acoustic_scale=acwt, pad_input=True, max_nnet_batch_size=max(256, c))
