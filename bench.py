@@ -529,9 +529,10 @@ def main():
         background = []   # [(thread, exception box)] of the next step's acoustic part
 
         def acoustic_in_background(with_front_end):
-            """decode()'s after-launch hook: starts a host thread that runs the next step's acoustic part (its kernels
-            queue behind the decode kernel) and returns, so that decode() goes on to drain the kernel's completions and the
-            step's host work (best paths, lattice sizes) runs while the GPU is already computing the next scores."""
+            """decode()'s after-launch hook (called when the LAST decode kernel of the call has finished and the stream is
+            idle): starts a host thread that runs the next step's acoustic part and returns, so that decode() goes on to
+            join its completion threads and the step's host work (lattices, best paths, sizes) runs while the GPU is
+            already computing the next scores."""
             import threading
             box = {}
 
@@ -612,7 +613,7 @@ def main():
             step()
         sync()
         kernel_ms = []
-        # K steps as a binary's main loop runs them: step i + 1's forward pass is enqueued behind step i's decode kernel
+        # K steps as a binary's main loop runs them: step i + 1's forward pass is started when step i's decode kernel has finished
         # (kh_decoder_set_after_launch) from a second host thread, so the GPU goes on while the host finishes step i
         # (lattice sizes, best paths).  K forward passes and K decodes inside the timed region; KH_BENCH_NO_PIPELINE=1:
         # strictly one after the other.
@@ -669,8 +670,8 @@ def main():
             step(True)
             sync()
             tail, kms_e = [], []
-            # K steps, pipelined as a binary's main loop would: step i + 1's forward pass is enqueued behind step i's decode
-            # kernel and runs while the host threads finish step i's determinization (K forward passes, K decodes, K sets
+            # K steps, pipelined as a binary's main loop would: step i + 1's forward pass starts when step i's decode kernel
+            # has finished and runs while the host threads finish step i's determinization (K forward passes, K decodes, K sets
             # of CompactLattices, all inside the timed region; `pipelined: false` = KH_BENCH_NO_PIPELINE=1, one after the other)
             t1 = time.perf_counter()
             if pipelined:
@@ -834,8 +835,8 @@ def main():
                           "(as many as the container's CPU quota), started per "
                           "utterance as the decode kernel exports it; host_tail_ms = wall time the host threads still needed "
                           "after the kernel had finished (what the overlap with the kernel does not hide).  pipelined = true: the K "
-                          "steps run as a binary's main loop would - step i + 1's forward pass is enqueued behind step i's decode "
-                          "kernel (kh_decoder_set_after_launch) and runs under step i's host tail; K forward passes, K decodes and "
+                          "steps run as a binary's main loop would - step i + 1's forward pass is started when step i's decode kernel has "
+                          "finished (kh_decoder_set_after_launch) and runs under step i's host tail; K forward passes, K decodes and "
                           "K sets of CompactLattices inside the timed region (KH_BENCH_NO_PIPELINE=1: one after the other)"
                           % DECODE_CFG["lattice_beam"],
                 "pipelined": bool(e.get("pipelined")),
