@@ -17,13 +17,16 @@ see tools/README or DESIGN.md "Command line").  Every pipe child is therefore st
 by start_pipe_helper() BEFORE anything touches the GPU and never touches it itself: the tool asks it (over a pipe) to run
 `/bin/sh -c cmd` with its standard output or input connected to a FIFO, and opens the FIFO's other end.  That also covers
 script files whose entries are commands ("utt1 sox a.flac -t wav - |"), which are only met while decoding."""
+import atexit
 import os
 import shlex
+import shutil
 import signal
 import struct
 import sys
 import tempfile
 import threading
+import time
 
 import numpy as np
 
@@ -441,6 +444,8 @@ class _PipeHelper:
             buf += chunk
         return buf
 
+    _RUNNING = -0x7fffffff   # reply to a poll of a child that has not exited yet
+
     def _serve(self, req, rep):
         import subprocess
         signal.signal(signal.SIGINT, signal.SIG_IGN)
@@ -455,12 +460,20 @@ class _PipeHelper:
                 fifo, cmd = body.decode().split("\0", 1)
                 # the FIFO is opened by the shell itself, so this process never blocks on it
                 redirect = (" > " if op == b"r" else " < ") + shlex.quote(fifo)
-                p = subprocess.Popen(["/bin/sh", "-c", "( " + cmd + " )" + redirect], stdin=subprocess.DEVNULL if op == b"r" else None)
-                children[ident] = p
-                os.write(rep, struct.pack("<Ii", ident, 0))
-            elif op == b"c":      # wait for the child: its exit status is what pclose() returns
-                p = children.pop(ident, None)
-                rc = p.wait() if p is not None else -1
+                try:
+                    p = subprocess.Popen(["/bin/sh", "-c", "( " + cmd + " )" + redirect], stdin=subprocess.DEVNULL if op == b"r" else None)
+                    children[ident] = p
+                    status = 0
+                except OSError as e:      # the requester raises instead of opening a FIFO nobody will ever open
+                    status = e.errno or 1
+                os.write(rep, struct.pack("<Ii", ident, status))
+            elif op == b"p":      # has the child exited?  (never blocks: a slow child must not stall the other requesters)
+                p = children.get(ident)
+                rc = -1 if p is None else p.poll()
+                if rc is None:
+                    rc = self._RUNNING
+                else:
+                    children.pop(ident, None)
                 os.write(rep, struct.pack("<Ii", ident, rc))
             elif op == b"q":
                 break
@@ -470,6 +483,16 @@ class _PipeHelper:
             except Exception:
                 p.kill()
 
+    def _poll(self, ident):
+        """Exit status of the child, _RUNNING while it runs, None if the helper is gone."""
+        with self.lock:
+            try:
+                os.write(self.req, struct.pack("<cII", b"p", ident, 0))
+            except OSError:
+                return None
+            rep = self._read_exact(self.rep, 8)
+        return struct.unpack("<Ii", rep)[1] if rep else None
+
     def spawn(self, cmd, reading):
         with self.lock:
             self.n += 1
@@ -477,17 +500,65 @@ class _PipeHelper:
             fifo = os.path.join(self.dir, "p%d" % ident)
             os.mkfifo(fifo)
             body = (fifo + "\0" + cmd).encode()
-            os.write(self.req, struct.pack("<cII", b"r" if reading else b"w", ident, len(body)) + body)
-            self._read_exact(self.rep, 8)
-        f = open(fifo, "rb" if reading else "wb")
-        os.unlink(fifo)
+            try:
+                os.write(self.req, struct.pack("<cII", b"r" if reading else b"w", ident, len(body)) + body)
+                rep = self._read_exact(self.rep, 8)
+            except OSError:
+                rep = None
+        if rep is None or struct.unpack("<Ii", rep)[1] != 0:
+            os.unlink(fifo)
+            raise KaldiError("pipe %s: cannot start the command (%s)"
+                             % (cmd, "the pipe helper process is gone" if rep is None else os.strerror(struct.unpack("<Ii", rep)[1])))
+        # The open below returns when the shell has opened its end.  If the child dies before it does, nobody ever will:
+        # a watchdog polls the child and, once it has exited with the open still pending, opens the other end itself
+        # (O_RDWR never blocks on a FIFO) so that the open returns and the failure is reported.
+        state = {"opened": False, "dead": None}
+        stop = threading.Event()
+
+        def watchdog():
+            while not stop.wait(0.05):
+                rc = self._poll(ident)
+                if rc is None or rc != self._RUNNING:
+                    if not state["opened"]:
+                        state["dead"] = -1 if rc is None else rc
+                        try:
+                            fd = os.open(fifo, os.O_RDWR | os.O_NONBLOCK)
+                            stop.wait(0.2)
+                            os.close(fd)
+                        except OSError:
+                            pass
+                    return
+        th = threading.Thread(target=watchdog, daemon=True)
+        th.start()
+        try:
+            f = open(fifo, "rb" if reading else "wb")
+            state["opened"] = True
+        finally:
+            stop.set()
+        th.join()
+        try:
+            os.unlink(fifo)
+        except OSError:
+            pass
+        if state["dead"] is not None and (not reading or state["dead"] != 0):
+            # (a reader whose command exited with status 0 before the open returned has simply produced its output already:
+            # the shell held the FIFO open while it ran)
+            f.close()
+            raise KaldiError("pipe %s: the command exited with status %d before its pipe was connected" % (cmd, state["dead"]))
         return ident, f
 
     def wait(self, ident):
-        with self.lock:
-            os.write(self.req, struct.pack("<cII", b"c", ident, 0))
-            rep = self._read_exact(self.rep, 8)
-        return struct.unpack("<Ii", rep)[1] if rep else -1
+        """pclose(): the child's exit status.  Polls, so that one slow child does not hold the helper (and with it every
+        other pipe of the process) for the duration of its exit."""
+        delay = 0.002
+        while True:
+            rc = self._poll(ident)
+            if rc is None:
+                return -1
+            if rc != self._RUNNING:
+                return rc
+            time.sleep(delay)
+            delay = min(0.05, delay * 1.5)
 
     def stop(self):
         try:
@@ -496,10 +567,7 @@ class _PipeHelper:
             os.waitpid(self.pid, 0)
         except OSError:
             pass
-        try:
-            os.rmdir(self.dir)
-        except OSError:
-            pass
+        shutil.rmtree(self.dir, ignore_errors=True)
 
 
 _helper = None
@@ -510,6 +578,7 @@ def start_pipe_helper():
     global _helper
     if _helper is None:
         _helper = _PipeHelper()
+        atexit.register(stop_pipe_helper)   # the FIFO directory does not outlive the process, however it ends its main()
     return _helper
 
 

@@ -203,3 +203,35 @@ def test_stdin_and_stdout_specifiers(tmp_path):
     (tmp_path / "out.ark").write_bytes(out)
     got = dict(kio.read_ark(str(tmp_path / "out.ark")))
     np.testing.assert_allclose(got["a"], 2 * m)
+
+
+def test_pipe_helper_is_not_stalled_by_a_slow_child_and_reports_its_own_death(tmp_path, monkeypatch):
+    """pclose() of a child that takes its time must not hold up the other pipes of the process (the helper polls its
+    children, it does not wait for them), a command that cannot be connected raises instead of blocking in open(), and
+    the FIFO directory goes away with the helper."""
+    import threading
+    import time
+    monkeypatch.chdir(tmp_path)
+    h = cli.start_pipe_helper()
+    d = h.dir
+    try:
+        slow = cli._PipeFile("cat > /dev/null; sleep 1.5", reading=False)   # exits 1.5 s after its input ends
+        slow.f.write(b"x")
+        t0 = time.perf_counter()
+        box = {}
+        th = threading.Thread(target=lambda: box.setdefault("rc", slow.close()))
+        th.start()
+        time.sleep(0.1)                         # the close of `slow` is under way
+        quick = cli._PipeFile("printf abc", reading=True)
+        assert quick.f.read() == b"abc" and quick.close() == 0
+        assert time.perf_counter() - t0 < 1.0, "a second pipe had to wait for the first one's child"
+        th.join()
+        assert box["rc"] == 0
+        # the helper process gone: an error, not a blocked open()
+        os.kill(h.pid, 9)
+        os.waitpid(h.pid, 0)
+        with pytest.raises(cli.KaldiError):
+            cli._PipeFile("printf abc", reading=True)
+    finally:
+        cli.stop_pipe_helper()
+    assert not os.path.exists(d)
