@@ -634,6 +634,9 @@ void kh_lattice_batch_destroy(KhLatticeBatch *batch);
 int kh_lattice_batch_sizes(const KhLatticeBatch *batch, int32_t *n_lats, int32_t *total_states, int64_t *total_arcs);
 int kh_lattice_batch_forward_backward(KhLatticeBatch *batch, float *arc_post, double *tot_like, double *acoustic_like_sum,
                                       int32_t *state_times);
+/* ... with the arc posteriors left on the DEVICE (arc_post_dev: total_arcs floats in the batch's arc order; tot_like /
+ * acoustic_like_sum HOST, may be NULL): no 4 bytes per arc over PCIe when the next consumer is a kernel. */
+int kh_lattice_batch_forward_backward_dev(KhLatticeBatch *batch, float *arc_post_dev, double *tot_like, double *acoustic_like_sum);
 int kh_lattice_batch_rescore(KhLatticeBatch *batch, const float *loglikes, int ll_stride, const int32_t *ll_row_offsets,
                              const int32_t *tid2pdf, float *arc_acoustic_out);
 int kh_lattice_last_timings(float *ms4);

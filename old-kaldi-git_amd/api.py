@@ -1223,6 +1223,17 @@ class LatticeBatch:
                                                       times.ctypes.data_as(capi.c_int32_p) if want_times else None))
         return dict(arc_post=post, tot_like=tot, acoustic_like_sum=ac, state_times=times)
 
+    def forward_backward_device(self, out=None):
+        """The same with the arc posteriors left on the device: dict(arc_post = torch tensor [total_arcs] on the GPU, tot_like,
+        acoustic_like_sum)."""
+        import torch
+        if out is None:
+            out = torch.empty(self.total_arcs, dtype=torch.float32, device="cuda")
+        tot, ac = np.empty(self.n, np.float64), np.empty(self.n, np.float64)
+        check(lib().kh_lattice_batch_forward_backward_dev(self._h, _p(out), tot.ctypes.data_as(capi.c_double_p),
+                                                          ac.ctypes.data_as(capi.c_double_p)))
+        return dict(arc_post=out, tot_like=tot, acoustic_like_sum=ac)
+
     def rescore(self, loglikes, utt_row_offsets, tid2pdf=None, fetch=False):
         """RescoreLattice with a device score matrix; the acoustic costs change on the device (fetch: return them)."""
         off = np.ascontiguousarray(utt_row_offsets, np.int32)

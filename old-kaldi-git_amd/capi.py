@@ -166,6 +166,7 @@ SIGNATURES = {
     "kh_lattice_batch_destroy": (None, [vp]),
     "kh_lattice_batch_sizes": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "kh_lattice_batch_forward_backward": (C.c_int, [vp, vp, vp, vp, vp]),
+    "kh_lattice_batch_forward_backward_dev": (C.c_int, [vp, vp, c_double_p, c_double_p]),
     "kh_lattice_batch_rescore": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "kh_lattice_last_timings": (C.c_int, [C.POINTER(C.c_float)]),
     "kh_decoder_set_reference_order": (C.c_int, [vp, C.c_int]),

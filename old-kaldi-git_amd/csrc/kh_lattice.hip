@@ -975,14 +975,17 @@ struct LatBatch {
 };
 
 // LatticeForwardBackward :272-354 on a batch that is resident on the device: sweeps + download.
-static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_like, double *acoustic_like_sum, hipStream_t st) {
+// post_dev != NULL: the posteriors stay on the device, in the caller's buffer (arc_post is then ignored)
+static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_like, double *acoustic_like_sum, hipStream_t st,
+                              float *post_dev = nullptr) {
   const int n_lats = B.n_lats, total_states = B.total_states;
   const int64_t total_arcs = B.total_arcs;
-  DevArr<float> d_post;
+  DevArr<float> d_post_own;
   DevArr<double> d_alpha, d_beta, d_tot, d_ac;
-  if (d_post.Alloc(total_arcs) || d_alpha.Alloc(total_states) || d_beta.Alloc(total_states) ||
+  if ((post_dev == nullptr && d_post_own.Alloc(total_arcs)) || d_alpha.Alloc(total_states) || d_beta.Alloc(total_states) ||
       d_tot.Alloc(n_lats) || d_ac.Alloc(n_lats))
     return KH_ENOMEM;
+  struct { float *p; } d_post{post_dev ? post_dev : d_post_own.p};
   const double min_log_diff = log(DBL_EPSILON);  // kMinLogDiffDouble kaldi-math.h:120
   g_lat_timer.Mark(2, st);
   if (B.has_levels && !getenv("KH_LATTICE_DATAFLOW"))
@@ -996,7 +999,7 @@ static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_li
                        B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff);
   KH_LAUNCH_CHECK();
   g_lat_timer.Mark(3, st);
-  if (arc_post)
+  if (arc_post && !post_dev)
     KH_HIP(hipMemcpyAsync(arc_post, d_post.p, sizeof(float) * total_arcs, hipMemcpyDeviceToHost, st));
   if (tot_like)
     KH_HIP(hipMemcpyAsync(tot_like, d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
@@ -1058,6 +1061,16 @@ extern "C" int kh_lattice_batch_forward_backward(KhLatticeBatch *h, float *arc_p
   g_lat_timer.Begin();
   if (state_times && (rc = h->B.FetchTimes(state_times, st))) return rc;
   return RunForwardBackward(h->B, arc_post, tot_like, acoustic_like_sum, st);
+}
+
+// The same with the arc posteriors left on the device (arc_post_dev: DEVICE, total_arcs floats, in the batch's arc order):
+// what a training loop does with them next (the posterior algebra, the derivative) runs there too.
+extern "C" int kh_lattice_batch_forward_backward_dev(KhLatticeBatch *h, float *arc_post_dev, double *tot_like, double *acoustic_like_sum) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(h && arc_post_dev);
+  g_lat_timer.Begin();
+  return RunForwardBackward(h->B, nullptr, tot_like, acoustic_like_sum, Stream(), arc_post_dev);
 }
 
 // RescoreLattice :1307-1358 on the resident batch: one workgroup per lattice, the acoustic costs are updated on the device

@@ -233,6 +233,8 @@ def test_resident_batch_shares_one_upload(api):
         assert np.array_equal(got2["arc_post"][a0:a0 + na], want2[i]["arc_post"])
         assert got2["tot_like"][i] == want2[i]["tot_like"]
         a0 += na
+    got3 = B.forward_backward_device()            # ... and with the posteriors left in HBM
+    assert np.array_equal(got3["arc_post"].cpu().numpy(), got2["arc_post"]) and np.array_equal(got3["tot_like"], got2["tot_like"])
     api.lattice_forward_backward(lats)
     t = api.lattice_last_timings()
     assert t["upload_ms"] > 0.0 and t["prep_ms"] > 0.0 and t["sweeps_ms"] > 0.0
