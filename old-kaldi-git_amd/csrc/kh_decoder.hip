@@ -1168,7 +1168,11 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         uint32_t slot = lds_slot(h, ns);
         // double hashing BY BLOCK: a block whose place is taken moves as a whole (same offset within
         // the block, a step that depends on the block only), so its tokens stay neighbours; linear
-        // probing piles the runs of consecutive active states up (pass 2 twice as slow)
+        // probing piles the runs of consecutive active states up (pass 2 twice as slow).
+        // (Round 4, thread-0 stamps inside this pass: count sweep 6 %, clear + insert 45 %, slot scan + token writes 27 %,
+        // resolve sweep 22 % of its cycles.  The lane's four probe sequences side by side - every round issues the
+        // compare-and-swaps of all candidates still looking for a slot before it waits - measured +1.5 % on the
+        // kernel: the insert is not bound by the chain of LDS round trips.)
         const uint32_t step = ((h >> 9) | 1u) << kLocBits;
         int probes = 0;
         for (; probes < 256; probes++) {
