@@ -461,6 +461,12 @@ int kh_online_decoder_advance(KhOnlineDecoder *dec, const int32_t *streams, int 
                               const int32_t *num_frames, const int32_t *tid2pdf);
 /* NumFramesDecoded() :194. */
 int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream, int32_t *num_frames);
+/* The offline kernel's lazy pruning schedule for the streams (default 0 = the reference's: PruneActiveTokens every
+ * prune_interval frames, lattice-faster-online-decoder.cc:811-813): nothing is pruned while a stream advances unless its
+ * arenas run low, FinalizeDecoding prunes every frame once.  The final lattice, every best path and the endpointing
+ * quantities are unchanged; a raw lattice asked for BEFORE FinalizeDecoding is pruned as of the current frame, not as of
+ * the last multiple of prune_interval.  Re-carves the arenas (as much memory as is free, less 48 GB): every stream must be idle. */
+int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *dec, int enable);
 /* The same three calls without a kernel launch per chunk: a PERSISTENT serving kernel, one resident workgroup per stream
  * (num_streams <= 2 x the CU count), which waits on a control block in pinned host memory (online2-wav-nnet2-latgen-faster's
  * per-chunk loop :213-262 for many connections; a stream that is pruning - AdvanceDecoding prunes every prune_interval

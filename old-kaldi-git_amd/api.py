@@ -976,6 +976,11 @@ class LatticeFasterOnlineDecoder:
         self._keep = chunks
         check(lib().kh_online_decoder_advance(self._h, ptr, n, ptrs, stride, nf.ctypes.data_as(capi.c_int32_p), t2p))
 
+    def set_lazy_prune(self, enable=True):
+        """The offline kernel's lazy pruning schedule (kh_online_decoder_set_lazy_prune): same final lattices and best paths,
+        no pruning while the streams advance; every stream must be idle."""
+        check(lib().kh_online_decoder_set_lazy_prune(self._h, int(bool(enable))))
+
     def num_frames_decoded(self, stream=0):
         n = C.c_int32()
         check(lib().kh_online_decoder_num_frames_decoded(self._h, int(stream), C.byref(n)))

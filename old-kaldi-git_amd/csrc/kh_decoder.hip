@@ -3566,6 +3566,7 @@ struct SlotState {
   int32_t tok_end, link_end, front_b, status, max_tokens_frame, tok_hw, gc_tok, gc_link;
   int32_t t, fb, fe;          // Run
   int32_t ok, finalized, conv_upto;
+  int32_t surv_nt, surv_nl;   // (lazy schedule) survivor lists of FinalizeDecoding
   long long arcs_expanded, tokens_created;
   KhDecodeStats stats;        // valid once finalized
 };
@@ -3581,6 +3582,7 @@ __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
     sh->tok_end = S.tok_end; sh->link_end = S.link_end; sh->front_b = S.front_b; sh->status = S.status;
     sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw; sh->gc_tok = S.gc_tok; sh->gc_link = S.gc_link;
     sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created; sh->conv_upto = S.conv_upto;
+    sh->surv_nt = S.surv_nt; sh->surv_nl = S.surv_nl;
   }
   run->t = S.t; run->fb = S.fb; run->fe = S.fe;
   run->cand = 0;   // (the online decoder does not report the counter)
@@ -3592,6 +3594,7 @@ __device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
     S->tok_end = sh->tok_end; S->link_end = sh->link_end; S->front_b = sh->front_b; S->status = sh->status;
     S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw; S->gc_tok = sh->gc_tok; S->gc_link = sh->gc_link;
     S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created; S->conv_upto = sh->conv_upto;
+    S->surv_nt = sh->surv_nt; S->surv_nl = sh->surv_nl;
     S->t = run.t; S->fb = run.fb; S->fe = run.fe;
     S->ok = (ok && sh->status == 0) ? 1 : 0;
   }
@@ -3639,17 +3642,31 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
     u.ll = job.ll;
     u.ll_stride = job.ll_stride;
     bool ok = S->ok != 0;
-    if (ok) ok = DecodeFrames<false>(u, p, sh, &run, run.t + job.n_frames);
+    if (ok) ok = p.lazy_prune ? DecodeFrames<true>(u, p, sh, &run, run.t + job.n_frames) : DecodeFrames<false>(u, p, sh, &run, run.t + job.n_frames);
     SaveState(S, sh, run, ok);
   } else if (job.op == kJobFinalize) {
     LoadState(*S, sh, &run);
     KhDecodeStats st;
-    const bool ok = DecodeFinalize<false>(u, p, sh, run, S->ok != 0, &st);
+    const bool ok = p.lazy_prune ? DecodeFinalize<true>(u, p, sh, run, S->ok != 0, &st) : DecodeFinalize<false>(u, p, sh, run, S->ok != 0, &st);
     SaveState(S, sh, run, ok);
     if (threadIdx.x == 0) { S->finalized = 1; S->stats = st; }
-  } else {  // kJobExport: non-destructive snapshot of the current lattice
+  } else {  // kJobExport: snapshot of the current lattice
     LoadState(*S, sh, &run);
     u.T = run.t;
+    if (p.lazy_prune && !S->finalized && S->ok != 0 && run.t > 0) {
+      // lazy schedule: nothing has been pruned since the last collection, and what is exported is what the arenas hold -
+      // so the collection runs now (PruneActiveTokens at the current frame + compaction, as DecodeFrames does when an
+      // arena runs low).  The snapshot is therefore pruned as of THIS frame, not as of the last multiple of
+      // prune_interval; best paths and the final lattice do not depend on it (Params::lazy_prune).
+      PruneActiveTokens(u, p, run.t, p.lattice_beam * p.prune_scale, sh);
+      const bool okc = Compact(u, 0, run.t, p.keep_ac != 0, sh);
+      if (threadIdx.x == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; sh->sched[0] += 1; }
+      KhSync();
+      run.fb = Uni(u.frame_b[run.t]);
+      run.fe = Uni(u.frame_e[run.t]);
+      SaveState(S, sh, run, okc);
+      KhSync();
+    }
     // FinalRelativeCost() before FinalizeDecoding (ComputeFinalCosts, lattice-faster-online-decoder.cc:860-900): over the
     // frontier tokens, best cost with the state's final cost - best cost; +inf when no token is in a final state.  What the
     // endpointing rules of online2/online-endpoint.cc test.
@@ -3678,7 +3695,8 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
       out[blockIdx.x].stats = st;
     }
     KhSync();
-    ExportLattice(u, p, pool, &out[blockIdx.x], sh);
+    if (p.lazy_prune && S->finalized) ExportSurvivors(u, p, pool, &out[blockIdx.x], sh);   // (FinalBackward's lists: the arenas are not pruned)
+    else ExportLattice(u, p, pool, &out[blockIdx.x], sh);
   }
 }
 
@@ -3780,12 +3798,15 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
       fin = false;
       ok = ok && Uni(sh->status) == 0;
     } else if (act == 2) {   // AdvanceDecoding up to the frames the host has published
-      ok = DecodeFrames<false>(u, p, sh, &run, arg);
+      LoadState(*S, sh, &run);   // (an export job may have collected the slot's garbage in between: lazy schedule)
+      ok = ok && S->ok != 0;
+      if (ok) ok = p.lazy_prune ? DecodeFrames<true>(u, p, sh, &run, arg) : DecodeFrames<false>(u, p, sh, &run, arg);
       SaveState(S, sh, run, ok);
       ok = ok && Uni(sh->status) == 0;
     } else if (act == 3) {   // FinalizeDecoding
       KhDecodeStats st;
-      ok = DecodeFinalize<false>(u, p, sh, run, ok, &st);
+      LoadState(*S, sh, &run);
+      ok = p.lazy_prune ? DecodeFinalize<true>(u, p, sh, run, ok, &st) : DecodeFinalize<false>(u, p, sh, run, ok, &st);
       SaveState(S, sh, run, ok);
       if (threadIdx.x == 0) { S->finalized = 1; S->stats = st; }
       fin = true;
@@ -5722,6 +5743,7 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   hipStream_t st = Stream();
   Params p;
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
+  p.lazy_prune = b->lazy;   // kh_online_decoder_set_lazy_prune
   if (ll_stride <= 0) p.ll_cols = 0;
   if (b->rec != nullptr && (ll_stride <= 0 || (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols))) {
     // the records hold this map's pdfs already (kh_online_decoder_set_pdf_map) - or the jobs read no scores at all
@@ -5880,6 +5902,43 @@ int kh_online_decoder_finalize(KhOnlineDecoder *o, const int32_t *streams, int n
   return CheckStreams(o, streams, n, "kh_online_decoder_finalize");
 }
 
+// The offline kernel's LAZY pruning schedule for the streams (default off = the reference's: PruneActiveTokens every
+// prune_interval frames): nothing is pruned while a stream advances unless its arenas run low, FinalizeDecoding prunes
+// every frame once.  The final lattice, every best path and the endpointing quantities are those of the interval schedule
+// (rule P, DESIGN.md section 2: the result does not depend on when the sweeps run); a raw lattice asked for BEFORE
+// FinalizeDecoding is pruned as of the current frame instead of the last multiple of prune_interval.  The arenas are
+// re-carved (every stream must be idle: before InitDecoding or after FinalizeDecoding + the last getter).
+int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *o, int enable) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o);
+  KhDecoder *b = o->base;
+  if ((b->lazy != 0) == (enable != 0)) return KH_OK;
+  if (o->serve_launched) {
+    SetError("kh_online_decoder_set_lazy_prune: stop the serving kernel first");
+    return KH_ESTATE;
+  }
+  for (int s = 0; s < o->num_streams; s++)
+    if (o->inited[s] && !o->finalized[s]) {
+      SetError("kh_online_decoder_set_lazy_prune: stream %d is in a decoding run", s);
+      return KH_ESTATE;
+    }
+  b->lazy = enable != 0;
+  hipStream_t st = Stream();
+  int n_slots = 0;
+  rc = EnsureSlots(b, o->num_streams, o->max_frames, st, &n_slots);
+  if (rc == KH_OK && n_slots < o->num_streams) {
+    SetError("kh_online_decoder_set_lazy_prune: only %d of %d streams fit in device memory", n_slots, o->num_streams);
+    rc = KH_ENOMEM;
+  }
+  if (rc) return rc;
+  KH_HIP(hipMemsetAsync(o->d_states, 0, sizeof(SlotState) * o->num_streams, st));
+  KH_HIP(hipMemcpyAsync(b->d_slots, b->h_slots.data(), sizeof(Utt) * o->num_streams, hipMemcpyHostToDevice, st));
+  KH_HIP(hipStreamSynchronize(st));
+  for (int s = 0; s < o->num_streams; s++) { o->inited[s] = 0; o->finalized[s] = 0; o->frames[s] = 0; o->lat_key[s] = -1; }
+  return KH_OK;
+}
+
 // ---- the persistent serving kernel (ServeKernel): start / stop, commands, progress
 static int ServeEnsureRunning(KhOnlineDecoder *o) {
   if (!o->serve_ctl) {
@@ -5900,6 +5959,7 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   hipStream_t st = Stream();
   Params p;
   FillParams(b, &p, o->serve_stride, o->serve_map);
+  p.lazy_prune = b->lazy;
   if (!(o->pinned && o->serve_map == o->pinned_map && o->serve_stride == o->pinned_cols && b->rec != nullptr)) {
     const int rc = kh_online_decoder_set_pdf_map(o, o->serve_map, o->serve_stride);
     if (rc) return rc;

@@ -106,3 +106,50 @@ def test_call_sequence_errors_and_stream_reuse(api):
     oc = B.DecoderOracle(g, cfg, "canonical")
     assert oc.decode(x.cpu().numpy())
     assert_same_lattice(first, oc.raw_lattice())
+
+
+def test_lazy_prune_schedule_same_results(api):
+    """kh_online_decoder_set_lazy_prune: streams advanced in random chunks without any pruning on the way (an arena small
+    enough to force garbage collections in one case), partial best paths and FinalRelativeCost mid-utterance, then
+    FinalizeDecoding: lattice, best path and statistics of the interval schedule / the offline decoder, bit for bit."""
+    rng = np.random.default_rng(77)
+    g = workloads.make_hclg_like(rng, 8000, 60)
+    cfg = api.decoder_config(beam=11.0, max_active=1500, min_active=100, lattice_beam=6.0, prune_interval=9)
+    fst = api.Fst(g)
+    Ts = [97, 41, 150]
+    lls = [workloads.make_loglikes(rng, T, 60) for T in Ts]
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=3, max_frames=max(Ts))
+    ref.decode(torch.from_numpy(np.concatenate(lls)).cuda(), off)
+    base = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)     # the interval schedule, same chunks
+    lazy = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)
+    lazy.set_lazy_prune(True)
+    dev = [torch.from_numpy(x).cuda() for x in lls]
+    for d in (base, lazy):
+        d.init_decoding([0, 1, 2])
+    fed = [0, 0, 0]
+    while any(f < T for f, T in zip(fed, Ts)):
+        act, chunks = [], []
+        for s in range(3):
+            if fed[s] < Ts[s]:
+                k = int(min(Ts[s] - fed[s], rng.integers(1, 40)))
+                act.append(s)
+                chunks.append(dev[s][fed[s]:fed[s] + k])
+                fed[s] += k
+        for d in (base, lazy):
+            d.advance_decoding(act, chunks)
+        s = act[0]
+        if fed[s] < Ts[s]:      # a partial hypothesis and the endpointing quantities: the same under both schedules
+            assert_same_best_path(lazy.get_best_path(s, use_final_probs=False), base.get_best_path(s, use_final_probs=False))
+            a, b = lazy.stats(s, use_final_probs=False), base.stats(s, use_final_probs=False)
+            assert a["num_frames"] == b["num_frames"]
+            assert np.float32(a["final_relative_cost"]).tobytes() == np.float32(b["final_relative_cost"]).tobytes()
+    lazy.finalize_decoding([0, 1, 2])
+    for s in range(3):
+        assert_same_lattice(lazy.get_raw_lattice(s), ref.get_raw_lattice(s))
+        assert_same_best_path(lazy.get_best_path(s), ref.get_best_path(s))
+    lazy.set_lazy_prune(False)          # ... and back: the interval schedule on the same object
+    lazy.init_decoding([1])
+    lazy.advance_decoding([1], [dev[1]])
+    lazy.finalize_decoding([1])
+    assert_same_lattice(lazy.get_raw_lattice(1), ref.get_raw_lattice(1))

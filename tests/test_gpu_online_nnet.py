@@ -156,8 +156,8 @@ def test_serving_step_in_one_call_equals_offline(api, pad_input):
         assert_same_best_path(results[u][1], ref.get_best_path(u))
 
 
-@pytest.mark.parametrize("pad_input", [True, False])
-def test_persistent_serving_kernel_equals_offline(api, pad_input, monkeypatch):
+@pytest.mark.parametrize("pad_input,lazy", [(True, False), (False, False), (True, True)])
+def test_persistent_serving_kernel_equals_offline(api, pad_input, lazy, monkeypatch):
     """The same loop through the decoder's PERSISTENT serving kernel (kh_online_nnet2_serve_*): step() only publishes the
     chunk's scores, the resident workgroups decode at their own pace, FinalizeDecoding is requested asynchronously and the
     lattice is read after serve_wait - while the kernel keeps serving the other streams, and once more after the kernel
@@ -181,6 +181,8 @@ def test_persistent_serving_kernel_equals_offline(api, pad_input, monkeypatch):
     n_out = lambda u: Ts[u] if pad_input else Ts[u] - L - R
 
     dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)
+    if lazy:   # no pruning while the streams advance (kh_online_decoder_set_lazy_prune): same lattices and best paths
+        dec.set_lazy_prune(True)
     pipe = api.OnlineNnet2Pipeline(nnet, dec, max_frames=160, acoustic_scale=0.1, pad_input=pad_input, max_nnet_batch_size=40)
     pipe.serve_start()
     queue = [3, 4]                       # utterances waiting for a free stream

@@ -354,7 +354,8 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                     "inside the timed step)"}
     R = nnet.right_context()
     ahead = int(os.environ.get("KH_BENCH_SERVE_AHEAD", "1"))
-    for c in chunks:
+
+    def serve_leg(c, tag, note):
         # The same service through the decoder's PERSISTENT kernel (kh_online_nnet2_serve_*): no decode launch per chunk, one
         # resident workgroup per stream.  A stream is handed its next chunk while at most ONE chunk of its frames is still
         # waiting to be decoded (the next chunk of audio arrives while the previous one is being worked on) - a
@@ -375,6 +376,9 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
             n_done = frames_done = 0
             t_begin = time.perf_counter()
             while (state != 2).any():
+                if time.perf_counter() - t_begin > 180.0:
+                    pipe.serve_stop()
+                    raise RuntimeError("serving leg: no progress within 180 s (%d utterances served)" % n_done)
                 dcd, busy = pipe.serve_poll(all_slots)
                 now = time.perf_counter()
                 u = np.maximum(slot_utt, 0)
@@ -426,7 +430,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
             fps = None
         cm = np.array([x_[0] for x_ in calls]) * 1e3
         cl = np.array(chunk_lat) * 1e3
-        res["chunk_%d_frames_persistent" % c] = {
+        res["chunk_%d_frames_persistent%s" % (c, tag)] = {
             "chunk_seconds": c * 0.01, "utterances_served": int(n_done), "frames_per_s": fps,
             "real_time_streams_sustained": fps / 100.0 if fps else None,
             "frames_per_s_whole_run": float(frames_done / total),
@@ -436,7 +440,16 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                                  "max": float(cl.max())},
             "chunks_ahead": ahead,
             "step": "kh_online_nnet2_serve_*: persistent decode kernel, one resident workgroup per stream; a stream gets its next "
-                    "chunk while at most `chunks_ahead` chunks of its frames wait to be decoded; FinalizeDecoding asynchronous"}
+                    "chunk while at most `chunks_ahead` chunks of its frames wait to be decoded; FinalizeDecoding asynchronous" + note}
+    for c in chunks:
+        serve_leg(c, "", "")
+    # ... and with the offline kernel's lazy pruning schedule for the streams (kh_online_decoder_set_lazy_prune: nothing is
+    # pruned while a stream advances, FinalizeDecoding prunes every frame once; same final lattices and best paths)
+    dec.set_lazy_prune(True)
+    for c in chunks:
+        serve_leg(c, "_lazy", "; lazy pruning schedule (no PruneActiveTokens every prune_interval frames: "
+                              "FinalizeDecoding prunes every frame once)")
+    dec.set_lazy_prune(False)
     for c in chunks[:1]:
         # ... and the same loop through the Python-side DecodableNnet2Online + advance_decoding (round 3's leg)
         dn = api.DecodableNnet2Online(nnet, n, max_t, acoustic_scale=acwt, pad_input=True, max_nnet_batch_size=max(256, c))
