@@ -2,7 +2,7 @@
 scalar reduction) that bench.py / a multi-GPU decode job uses."""
 import importlib
 import os
-import socket
+import tempfile
 
 import numpy as np
 import pytest
@@ -25,9 +25,8 @@ def test_partition_is_balanced_and_complete():
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous: a TCP port picked by bind-and-close can be taken by a parallel test (pytest -n)
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world)
     lens = np.random.default_rng(1).integers(50, 400, 37)
     mine = sharding.partition_utterances(lens, world)[rank]
     frames = int(lens[mine].sum())
@@ -38,10 +37,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_reduction_over_gloo():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = os.path.join(tempfile.mkdtemp(prefix="kh_gloo_"), "rendezvous")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
@@ -65,9 +61,8 @@ def test_single_process_without_group():
 
 
 def _disc_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous: a TCP port picked by bind-and-close can be taken by a parallel test (pytest -n)
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world)
     stats = dict(tot_t=100.0 * (rank + 1), tot_t_weighted=50.0 * (rank + 1), tot_num_count=3.0 + rank,
                  tot_num_objf=-7.0 * (rank + 1), tot_den_objf=-9.0 * (rank + 1))
     grads = [torch.full((5, 3), float(rank + 1)), torch.full((11,), 10.0 * (rank + 1)), torch.full((2, 2), -1.0)]
@@ -78,10 +73,7 @@ def _disc_worker(rank, world, port, q):
 
 def test_discriminative_stats_and_gradients_over_gloo():
     """Config 5: NnetDiscriminativeStats::Add + the gradient sum across ranks (bucketed all-reduce)."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = os.path.join(tempfile.mkdtemp(prefix="kh_gloo_"), "rendezvous")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_disc_worker, args=(r, 2, port, q)) for r in range(2)]
