@@ -279,6 +279,49 @@ struct Params {
   int32_t max_active, min_active, prune_interval;
 };
 
+// SGPR hygiene.  `Utt u = slots[...]` and the by-value `Params` arrive through s_load_dwordx8 / x16: the fields of one
+// load form ONE 256- / 512-bit register tuple, and when the allocator runs out of scalar registers (these two structs
+// alone hold ~60 pointers) it spills and reloads such a tuple AS A WHOLE - the round-4 listing of DecodeKernel<1,0> had
+// 5 700 v_readlane_b32 among its 22 k instructions (a quarter of them, every one a VALU issue slot), e.g. sixteen of them
+// in front of a single global_load inside the expansion loops to recover one pointer.  An empty asm with a "+s" operand
+// per field ends the tuple's life at kernel entry: every field becomes a scalar value of its own, which is kept,
+// spilled (two lanes of a VGPR) and reloaded (two v_readlane) on its own.
+// (A tied "+s" operand is coalesced straight back into the tuple; a real s_mov inside the asm gives the copy a register
+// of its own.  ~60 scalar moves per workgroup, once.)
+template <class T>
+__device__ __forceinline__ void LaunderOne(T &x) {
+  T y;
+  if constexpr (sizeof(T) == 8) asm volatile("s_mov_b64 %0, %1" : "=s"(y) : "s"(x));
+  else asm volatile("s_mov_b32 %0, %1" : "=s"(y) : "s"(x));
+  x = y;
+}
+#ifndef KH_NO_LAUNDER
+#define KH_LAUNDER(x) LaunderOne(x)
+#else
+#define KH_LAUNDER(x) do {} while (0)
+#endif
+__device__ __forceinline__ void Launder(Utt &u) {
+  KH_LAUNDER(u.ll); KH_LAUNDER(u.ll_stride); KH_LAUNDER(u.T); KH_LAUNDER(u.tok_cap);
+  KH_LAUNDER(u.tok_state.p); KH_LAUNDER(u.tok_cost.p); KH_LAUNDER(u.tok_extra.p);
+  KH_LAUNDER(u.link_cap);
+  KH_LAUNDER(u.link_dst.p); KH_LAUNDER(u.link_arc.p); KH_LAUNDER(u.link_src.p); KH_LAUNDER(u.link_k.p); KH_LAUNDER(u.link_a.p);
+  KH_LAUNDER(u.frame_b.p); KH_LAUNDER(u.frame_e.p); KH_LAUNDER(u.feps_b.p); KH_LAUNDER(u.feps_e.p);
+  KH_LAUNDER(u.femit_b.p); KH_LAUNDER(u.femit_e.p); KH_LAUNDER(u.cost_offset.p);
+  KH_LAUNDER(u.must_links.p); KH_LAUNDER(u.must_toks.p);
+  KH_LAUNDER(u.tmp_slot.p); KH_LAUNDER(u.tmp_dirty.p); KH_LAUNDER(u.tmp_work0.p); KH_LAUNDER(u.tmp_work1.p);
+  KH_LAUNDER(u.tmp_epslist.p); KH_LAUNDER(u.tmp_f0.p); KH_LAUNDER(u.tmp_acc0.p); KH_LAUNDER(u.tmp_acc1.p); KH_LAUNDER(u.tmp_remap.p);
+  KH_LAUNDER(u.tok_frame_cap); KH_LAUNDER(u.link_frame_cap); KH_LAUNDER(u.window_cap);
+  KH_LAUNDER(u.surv_tok.p); KH_LAUNDER(u.surv_link.p); KH_LAUNDER(u.surv_tok_cap); KH_LAUNDER(u.surv_link_cap);
+  KH_LAUNDER(u.hash.p); KH_LAUNDER(u.hash_mask);
+}
+__device__ __forceinline__ void Launder(Params &p) {
+  KH_LAUNDER(p.rec.p); KH_LAUNDER(p.n_arcs.p); KH_LAUNDER(p.unit_ilabel.p);
+  KH_LAUNDER(p.start); KH_LAUNDER(p.num_units); KH_LAUNDER(p.num_eps); KH_LAUNDER(p.start_has_eps); KH_LAUNDER(p.ll_cols);
+  KH_LAUNDER(p.keep_ac); KH_LAUNDER(p.max_tid); KH_LAUNDER(p.lazy_prune); KH_LAUNDER(p.exact_order);
+  KH_LAUNDER(p.hash_ratio); KH_LAUNDER(p.beam); KH_LAUNDER(p.lattice_beam); KH_LAUNDER(p.beam_delta); KH_LAUNDER(p.prune_scale);
+  KH_LAUNDER(p.max_active); KH_LAUNDER(p.min_active); KH_LAUNDER(p.prune_interval);
+}
+
 // Workgroup barrier that also waits for this wave's outstanding vector-memory
 // operations.  hipcc's __syncthreads() is a WORKGROUP-scope fence: on gfx950 (one
 // CU, shared L1) it does not wait for global stores to be performed at L2.  This
@@ -349,6 +392,7 @@ struct Shared {
   int work_cursor;  // ExpandWavesFiltered: next unclaimed token
   uint32_t bound_enc;  // ExpandWavesFiltered: Enc(upper bound of the final next_cutoff), atomic min
   float wbound[2][NW];  // ExpandSweepFiltered: per-wave minima of the cutoff estimate, double buffered
+  int own[NW][64];      // ExpandWavesFiltered: per wave, arc slot of the current 64-arc batch -> (batch tag, lane of the token that starts there)
   int front_b;  // first token of the frame under construction (frontier)
   int conv_upto;  // frames below it have had their first pruning visit (link_k of their emitting links is converted)
   int status;
@@ -414,6 +458,116 @@ __device__ __forceinline__ void Stamp(const Utt &u, Blk &sh, int ph) {
   }
 }
 
+// ---------------------------------------------------------------- wave primitives
+// Cross-lane scans as DPP modifiers of VALU instructions (row_shr:1/2/4/8 inside the 16-lane rows, then row_bcast:15 and
+// row_bcast:31 across them - the gfx9 wave scan): six VALU instructions and nothing on the LDS pipe.  A __shfl_up step is
+// a ds_bpermute_b32 (an LDS-pipe instruction with its round trip) + the lane address + a select under a lane mask that
+// the compiler keeps in a scalar register pair - and, this kernel being short of scalar registers, reloads from a spill
+// VGPR with two v_readlane in front of every step.  KH_NO_DPP keeps the shuffles (same-box A/B).
+#ifndef KH_NO_DPP
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int DppMov(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, kCtrl, kRowMask, 0xf, false);
+}
+#define KH_DPP_SCAN(v, id, OP)                  \
+  v = OP(v, DppMov<0x111, 0xf>(id, v));         \
+  v = OP(v, DppMov<0x112, 0xf>(id, v));         \
+  v = OP(v, DppMov<0x114, 0xf>(id, v));         \
+  v = OP(v, DppMov<0x118, 0xf>(id, v));         \
+  v = OP(v, DppMov<0x142, 0xa>(id, v));         \
+  v = OP(v, DppMov<0x143, 0xc>(id, v))
+#endif
+__device__ __forceinline__ int OpAddI(int a, int b) { return a + b; }
+__device__ __forceinline__ int OpMaxI(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int OpMinUBits(int a, int b) { return static_cast<uint32_t>(b) < static_cast<uint32_t>(a) ? b : a; }
+__device__ __forceinline__ int OpMinFBits(int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); }
+// inclusive scans over the 64 lanes
+__device__ __forceinline__ int WaveIncSum(int v) {
+#ifndef KH_NO_DPP
+  KH_DPP_SCAN(v, 0, OpAddI);
+#else
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v += n; }
+#endif
+  return v;
+}
+__device__ __forceinline__ int WaveIncMax(int v) {   // (values >= 0)
+#ifndef KH_NO_DPP
+  KH_DPP_SCAN(v, 0, OpMaxI);
+#else
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v = OpMaxI(v, n); }
+#endif
+  return v;
+}
+__device__ __forceinline__ uint32_t WaveIncMinU(uint32_t u) {
+  int v = static_cast<int>(u);
+#ifndef KH_NO_DPP
+  KH_DPP_SCAN(v, -1, OpMinUBits);
+#else
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v = OpMinUBits(v, n); }
+#endif
+  return static_cast<uint32_t>(v);
+}
+__device__ __forceinline__ float WaveIncMinF(float f) {
+  int v = __float_as_int(f);
+#ifndef KH_NO_DPP
+  KH_DPP_SCAN(v, 0x7f800000, OpMinFBits);
+#else
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v = OpMinFBits(v, n); }
+#endif
+  return __int_as_float(v);
+}
+// the value of lane 63 (the total of an inclusive scan), in a scalar register
+__device__ __forceinline__ int WaveLast(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float WaveMinF(float f) { return __int_as_float(WaveLast(__float_as_int(WaveIncMinF(f)))); }
+// 64-bit reductions: the two halves travel separately (identity per half), the total ends in lane 63
+#ifndef KH_NO_DPP
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ unsigned long long DppMov64(int id_half, unsigned long long v) {
+  const uint32_t hi = static_cast<uint32_t>(DppMov<kCtrl, kRowMask>(id_half, static_cast<int>(static_cast<uint32_t>(v >> 32))));
+  const uint32_t lo = static_cast<uint32_t>(DppMov<kCtrl, kRowMask>(id_half, static_cast<int>(static_cast<uint32_t>(v))));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+#endif
+__device__ __forceinline__ unsigned long long OpMinU64(unsigned long long a, unsigned long long b) { return b < a ? b : a; }
+__device__ __forceinline__ unsigned long long OpAddU64(unsigned long long a, unsigned long long b) { return a + b; }
+__device__ __forceinline__ unsigned long long WaveMinU64ToLast(unsigned long long v) {
+#ifndef KH_NO_DPP
+  v = OpMinU64(v, DppMov64<0x111, 0xf>(-1, v));
+  v = OpMinU64(v, DppMov64<0x112, 0xf>(-1, v));
+  v = OpMinU64(v, DppMov64<0x114, 0xf>(-1, v));
+  v = OpMinU64(v, DppMov64<0x118, 0xf>(-1, v));
+  v = OpMinU64(v, DppMov64<0x142, 0xa>(-1, v));
+  v = OpMinU64(v, DppMov64<0x143, 0xc>(-1, v));
+#else
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long n = __shfl_xor(v, o, 64); v = n < v ? n : v; }
+#endif
+  return v;
+}
+__device__ __forceinline__ long long WaveSumLLToLast(long long x) {
+  unsigned long long v = static_cast<unsigned long long>(x);
+#ifndef KH_NO_DPP
+  v = OpAddU64(v, DppMov64<0x111, 0xf>(0, v));
+  v = OpAddU64(v, DppMov64<0x112, 0xf>(0, v));
+  v = OpAddU64(v, DppMov64<0x114, 0xf>(0, v));
+  v = OpAddU64(v, DppMov64<0x118, 0xf>(0, v));
+  v = OpAddU64(v, DppMov64<0x142, 0xa>(0, v));
+  v = OpAddU64(v, DppMov64<0x143, 0xc>(0, v));
+#else
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+#endif
+  return static_cast<long long>(v);
+}
+
 // Block primitives with ONE barrier each.  Every primitive writes its per-wave
 // partials into a buffer selected by a per-thread call counter (uniform across the
 // workgroup) and reads all partials after the barrier; a buffer is rewritten two
@@ -421,12 +575,7 @@ __device__ __forceinline__ void Stamp(const Utt &u, Blk &sh, int ph) {
 template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int n = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += n;
-  }
+  const int inc = WaveIncSum(v);
   const int buf = (sh.k_scan++) & 1;
   if (lane == 63) sh->wsum[buf][w] = inc;
   if (kLdsOnly) LdsSync(); else KhSync();
@@ -450,12 +599,7 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], i
   int inc[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    inc[k] = v[k];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      int n = __shfl_up(inc[k], o, 64);
-      if (lane >= o) inc[k] += n;
-    }
+    inc[k] = WaveIncSum(v[k]);
     if (lane == 63) sh->wsumk[buf][k][w] = inc[k];
   }
   if (kLdsOnly) LdsSync(); else KhSync();
@@ -477,12 +621,8 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], i
 
 __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, Blk &sh) {
   const int buf = (sh.k_red++) & 1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long n = __shfl_xor(v, o, 64);
-    v = n < v ? n : v;
-  }
-  if ((threadIdx.x & 63) == 0) sh->wred[buf][threadIdx.x >> 6] = v;
+  v = WaveMinU64ToLast(v);
+  if ((threadIdx.x & 63) == 63) sh->wred[buf][threadIdx.x >> 6] = v;
   KhSync();
   unsigned long long r = sh->wred[buf][0];
 #pragma unroll
@@ -492,8 +632,8 @@ __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, 
 
 __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
   const int buf = (sh.k_red++) & 1;
-  v = kh_wave_min(v);
-  if ((threadIdx.x & 63) == 0) sh->wred[buf][threadIdx.x >> 6] = __float_as_uint(v);
+  v = WaveIncMinF(v);
+  if ((threadIdx.x & 63) == 63) sh->wred[buf][threadIdx.x >> 6] = __float_as_uint(v);
   KhSync();
   float r = __uint_as_float(static_cast<uint32_t>(sh->wred[buf][0]));
 #pragma unroll
@@ -503,9 +643,8 @@ __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
 
 __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
   const int buf = (sh.k_red++) & 1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63) == 0) sh->wred[buf][threadIdx.x >> 6] = static_cast<unsigned long long>(v);
+  v = WaveSumLLToLast(v);
+  if ((threadIdx.x & 63) == 63) sh->wred[buf][threadIdx.x >> 6] = static_cast<unsigned long long>(v);
   KhSync();
   long long r = 0;
 #pragma unroll
@@ -723,6 +862,41 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const KhInt4> rec, 
   return lrun;
 }
 
+// Arc slot -> owning token inside a wave, for the independent-wave sweeps below.  A wave holds 64 tokens with their arc
+// counts and first slots (loff, an exclusive prefix sum: non-decreasing); the owner of slot q is the LAST token whose
+// first slot is <= q (tokens without arcs share their successor's first slot and are skipped by "last").  Per 64-slot
+// batch every token WITH arcs whose first slot lies in the batch writes its lane into that slot of the wave's own LDS
+// row (distinct slots: the first slots of tokens with arcs are distinct), and an inclusive maximum scan over the row
+// (DPP) hands every slot the last such token at or before it; slot 0 is seeded with the owner that runs on from the
+// previous batch.  The entries carry the batch's sequence number above the lane, so a stale entry of an earlier batch
+// is smaller than anything written now and the row is cleared once per sweep only.  A wave's LDS instructions execute
+// in order: no barrier between the write and the read.  (Rounds 2-4 ran a 6-step binary search over the prefix sums:
+// six DEPENDENT ds_bpermute round trips per batch.)
+struct OwnerScan {
+  __attribute__((address_space(3))) int *row;
+  int seq;     // batch sequence number of this wave in units of 128 (lane + 1 sits below it)
+  int carry;   // owner of the previous batch's last slot (its arcs may go on in this batch); -1 at the start of a claim
+};
+__device__ __forceinline__ OwnerScan OwnerScanInit(Blk &sh) {   // (a workgroup barrier must follow before the first batch: none needed, the row is the wave's own)
+  OwnerScan os;
+  os.row = &sh->own[threadIdx.x >> 6][0];
+  os.row[threadIdx.x & 63] = 0;
+  os.seq = 0;
+  os.carry = -1;
+  return os;
+}
+__device__ __forceinline__ int OwnerLane(OwnerScan &os, int cnt, int loff, int q0, int lane) {
+  os.seq += 128;
+  if (cnt > 0 && loff >= q0 && loff < q0 + 64) os.row[loff - q0] = os.seq | (lane + 1);
+  __builtin_amdgcn_wave_barrier();
+  int ov = os.row[lane];
+  if (lane == 0) ov = max(ov, os.seq | (os.carry + 1));
+  ov = WaveIncMax(ov);
+  const int lo = (ov & 127) - 1;
+  os.carry = WaveLast(lo);
+  return lo;
+}
+
 // ExpandSweep for the emitting arcs with a FILTER: load(token, cost image, arc index) fetches the
 // candidate, finish() computes it and says whether it can still be accepted; only those get a
 // link slot (store(slot)), appended per wave through one LDS atomic (ballot + prefix count), so
@@ -750,6 +924,12 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     sh->work_cursor = b;
     sh->bound_enc = Enc(*bound);
   }
+#ifndef KH_OWNER_SEARCH
+  OwnerScan os = OwnerScanInit(sh);
+#endif
+  Arr<uint32_t> w_cost = u.tok_cost;
+  Arr<int32_t> w_state = u.tok_state;
+  KH_LAUNDER(w_cost.p); KH_LAUNDER(w_state.p);
   KhSync();
   uint32_t my_bound_enc = Enc(*bound);
   for (;;) {
@@ -760,8 +940,8 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     const int i = base + lane;
     const bool in_range = i < e;
     const int ic = min(i, e - 1);
-    const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
-    int st = u.tok_state[ic];
+    const uint32_t co = LoadCostEnc(&w_cost[ic]);
+    int st = w_state[ic];
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= cutoff;
     int ab = 0, cnt = 0;
@@ -769,24 +949,29 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
       ab = st + 1;
       cnt = rec[st].x;
     }
-    int inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int n = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += n;
-    }
+    const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
-    const int total = __shfl(inc, 63, 64);
+    const int total = WaveLast(inc);
     {
       const uint32_t be = Uni(__hip_atomic_load(&sh->bound_enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       *bound = fminf(*bound, Dec(be));
       my_bound_enc = min(my_bound_enc, be);
     }
+#ifndef KH_OWNER_SEARCH
+    os.carry = -1;
+    const int rel = ab - loff;   // arc index = rel(owner) + slot
+#endif
     for (int q0 = 0; q0 < total; q0 += 64) {  // uniform over the wave
       const int q = q0 + lane;
       const bool valid = q < total;
       // owner = the LAST token whose first slot is <= q (tokens without arcs share their
-      // successor's first slot and are skipped by "last"); every lane takes part in the shuffles
+      // successor's first slot and are skipped by "last")
+#ifndef KH_OWNER_SEARCH
+      const int lo = OwnerLane(os, cnt, loff, q0, lane);
+      const int o_rel = __shfl(rel, lo, 64);
+      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      const int o_ai = o_rel + q;
+#else
       int lo = 0, hi = 63;
 #pragma unroll
       for (int step = 0; step < 6; step++) {
@@ -796,9 +981,11 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
       }
       const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64);
       const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      const int o_ai = o_ab + (q - o_off);
+#endif
       bool keep = false;
       if (valid) {
-        load(0, base + lo, o_co, o_ab + (q - o_off));
+        load(0, base + lo, o_co, o_ai);
         keep = finish(0);
       }
       const unsigned long long kb = __ballot(keep);
@@ -816,7 +1003,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     }
     if (lane == 0) *arcs += total;
     {
-      const uint32_t we = Enc(kh_wave_min(*est));
+      const uint32_t we = Enc(WaveMinF(*est));
       if (we < my_bound_enc) {
         my_bound_enc = we;
         if (lane == 0) __hip_atomic_fetch_min(&sh->bound_enc, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -839,6 +1026,9 @@ struct Cutoff {
 template <bool kExact = false>
 __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh) {
   Cutoff c;
+  Arr<uint32_t> g_cost = u.tok_cost;
+  Arr<int32_t> g_state = u.tok_state;
+  KH_LAUNDER(g_cost.p); KH_LAUNDER(g_state.p);
   const int n = e - b;
   c.count = n;
   unsigned long long best = ~0ull;
@@ -846,9 +1036,9 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   uint32_t kmax = 0;
   for (int i = b + threadIdx.x; i < e; i += NT) {
     // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
-    const uint32_t enc = LoadCostEnc(&u.tok_cost[i]);
+    const uint32_t enc = LoadCostEnc(&g_cost[i]);
     const unsigned long long key = (static_cast<unsigned long long>(enc) << 32) |
-                                   static_cast<uint32_t>(kExact ? UX(x_pos)[i - b] : u.tok_state[i]);
+                                   static_cast<uint32_t>(kExact ? UX(x_pos)[i - b] : g_state[i]);
     if (key < best) { best = key; best_i = i; }
     kmax = enc > kmax ? enc : kmax;
   }
@@ -882,7 +1072,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   int within = 0;
   {
     const uint32_t bc = Enc(beam_cutoff);
-    for (int i = b + threadIdx.x; i < e; i += NT) within += LoadCostEnc(&u.tok_cost[i]) <= bc ? 1 : 0;
+    for (int i = b + threadIdx.x; i < e; i += NT) within += LoadCostEnc(&g_cost[i]) <= bc ? 1 : 0;
     within = static_cast<int>(BlockSumLL(within, sh));
   }
   // largest cost image of the frame (the smallest is the best cost): bounds the bits the selection looks at
@@ -890,7 +1080,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   const bool need_max = n > p.max_active && within > p.max_active;
   const bool need_min = n > p.min_active && p.min_active != 0 && within <= p.min_active;
   if (need_max || need_min) kmax = ~static_cast<uint32_t>(BlockMinU64(static_cast<unsigned long long>(~kmax), sh));
-  if (need_max) max_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.max_active, kmin, kmax, sh));
+  if (need_max) max_active_cutoff = Dec(RadixSelect(g_cost, b, e, p.max_active, kmin, kmax, sh));
   if (max_active_cutoff < beam_cutoff) {
     c.adaptive_beam = max_active_cutoff - best_weight + p.beam_delta;
     c.cur_cutoff = max_active_cutoff;
@@ -898,7 +1088,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   }
   if (n > p.min_active) {
     if (p.min_active == 0) min_active_cutoff = best_weight;
-    else if (need_min) min_active_cutoff = Dec(RadixSelect(u.tok_cost, b, e, p.min_active, kmin, kmax, sh));
+    else if (need_min) min_active_cutoff = Dec(RadixSelect(g_cost, b, e, p.min_active, kmin, kmax, sh));
     else min_active_cutoff = beam_cutoff;  // (some value <= beam_cutoff: the beam branch below)
   }
   if (min_active_cutoff > beam_cutoff) {
@@ -919,7 +1109,15 @@ __device__ __forceinline__ float LogLike(const Utt &u, const Params &p, const Bl
 // ProcessNonemitting :752-812 on the tokens of the frame under construction
 // ([sh->front_b, sh->tok_end)), then generation of the epsilon links with the
 // converged costs.  Returns false on arena overflow.
-__device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, float cutoff, Blk &sh) {
+__device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int frame, float cutoff, Blk &sh) {
+  // the phase's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
+  Utt u = u_in;
+  Params p = p_in;
+  KH_LAUNDER(u.tmp_epslist.p); KH_LAUNDER(u.tmp_work0.p); KH_LAUNDER(u.tmp_work1.p); KH_LAUNDER(u.tmp_dirty.p);
+  KH_LAUNDER(u.tok_cost.p); KH_LAUNDER(u.tok_state.p); KH_LAUNDER(u.tok_extra.p); KH_LAUNDER(u.tmp_slot.p);
+  KH_LAUNDER(u.hash.p); KH_LAUNDER(u.hash_mask);
+  KH_LAUNDER(u.link_dst.p); KH_LAUNDER(u.link_src.p); KH_LAUNDER(u.link_arc.p); KH_LAUNDER(u.link_k.p);
+  KH_LAUNDER(p.rec.p); KH_LAUNDER(p.n_arcs.p);
   const int fb = Uni(sh->front_b);
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff, driven by work lists.
@@ -989,12 +1187,7 @@ __device__ bool ProcessNonemitting(const Utt &u, const Params &p, int frame, flo
           const int32_t key = __builtin_amdgcn_readlane(ds, leader);
           const bool mine = ok && ds == key;
           const unsigned long long grp = __ballot(mine);
-          uint32_t m = mine ? enc : 0xFFFFFFFFu;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t other = static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), o, 64));
-            m = other < m ? other : m;
-          }
+          const uint32_t m = static_cast<uint32_t>(WaveLast(static_cast<int>(WaveIncMinU(mine ? enc : 0xFFFFFFFFu))));
           if (mine) {
             gmin = m;
             lead = lane == leader;
@@ -1094,6 +1287,14 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
 __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok_limit, int link_frame_b, int link_frame_e,
                                           float next_cutoff) {
   static_assert(kLdsSlots % NT == 0, "slots per lane");
+  // the pass's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
+  Arr<float> e_k = u.link_k, e_extra = u.tok_extra;
+  Arr<int32_t> e_dst = u.link_dst, e_state = u.tok_state, e_epslist = u.tmp_epslist, e_dirty = u.tmp_dirty, e_slot = u.tmp_slot;
+  Arr<uint32_t> e_cost = u.tok_cost;
+  Arr<unsigned long long> e_hash = u.hash;
+  uint32_t e_hmask = u.hash_mask;
+  KH_LAUNDER(e_k.p); KH_LAUNDER(e_extra.p); KH_LAUNDER(e_dst.p); KH_LAUNDER(e_state.p); KH_LAUNDER(e_epslist.p);
+  KH_LAUNDER(e_dirty.p); KH_LAUNDER(e_slot.p); KH_LAUNDER(e_cost.p); KH_LAUNDER(e_hash.p); KH_LAUNDER(e_hmask);
   auto keys = LdsKeys(sh);
   auto vals = LdsVals(sh);
   const float nan = __int_as_float(0x7fc00000);
@@ -1125,7 +1326,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
   if (link_frame_e - link_frame_b > KH_PART_CAND) {
     int n_acc_mine = 0;
     for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
-      n_acc_mine += !(u.link_k[l] > next_cutoff) ? 1 : 0;
+      n_acc_mine += !(e_k[l] > next_cutoff) ? 1 : 0;
     const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
     while (parts * KH_PART_CAND < n_acc) parts *= 2;
     if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
@@ -1143,8 +1344,8 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       float tc[kMU];
       int32_t nsv[kMU];
       if (base + kMU <= link_frame_e) {   // a lane owns kMU = 4 consecutive candidates: one 16-byte load per array
-        const KhFloat4 t4 = Load4F(u.link_k, base);
-        const KhInt4 n4 = Load4I(u.link_dst, base);
+        const KhFloat4 t4 = Load4F(e_k, base);
+        const KhInt4 n4 = Load4I(e_dst, base);
         tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
         nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
       } else {
@@ -1152,8 +1353,8 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         for (int j = 0; j < kMU; j++) {
           const int l = base + j;
           const int lc = l < link_frame_e ? l : link_frame_e - 1;
-          tc[j] = u.link_k[lc];
-          nsv[j] = u.link_dst[lc];
+          tc[j] = e_k[lc];
+          nsv[j] = e_dst[lc];
           if (l >= link_frame_e) tc[j] = nan;
         }
       }
@@ -1175,6 +1376,9 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         // kernel: the insert is not bound by the chain of LDS round trips.)
         const uint32_t step = ((h >> 9) | 1u) << kLocBits;
         int probes = 0;
+        // (not unrolled: the compiler's 8-fold unrolling of this early-exit loop cost ~100 scalar mask instructions per
+        // candidate; most candidates stop at the first or second probe)
+#pragma nounroll
         for (; probes < 256; probes++) {
           uint32_t seen = 0u;
           __hip_atomic_compare_exchange_strong(&keys[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1214,29 +1418,29 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       const int i = threadIdx.x + j * NT;
       const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
       const int idx = tok_base + off[j];
-      u.tok_state[idx] = ns & kStateMask;
-      u.tok_cost[idx] = vals[i];
-      u.tok_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
+      e_state[idx] = ns & kStateMask;
+      e_cost[idx] = vals[i];
+      e_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
       vals[i] = static_cast<uint32_t>(idx);
       if ((ns & kHasEps) != 0) {
         // these tokens are the closure's first work list (every one has a finite cost)
-        u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
-        u.tmp_dirty[idx - nb] = 1;
+        e_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+        e_dirty[idx - nb] = 1;
       }
       int32_t gslot = -1;
       if ((ns & kEpsDst) != 0) {  // the closure may look this state up: enter it in the global table
         const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
                                         (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
-        uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
+        uint32_t g = HashState(ns & kStateMask) & e_hmask;
         for (int probes = 0; probes < (1 << 30); probes++) {
           unsigned long long ent = kEmpty;
-          __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_compare_exchange_strong(&e_hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (ent == kEmpty) break;
-          g = (g + 1) & u.hash_mask;
+          g = (g + 1) & e_hmask;
         }
         gslot = static_cast<int32_t>(g);
       }
-      u.tmp_slot[idx - nb] = gslot;
+      e_slot[idx - nb] = gslot;
     }
     if (threadIdx.x == 0) sh->tok_end = tok_base + total;
     KhSync();
@@ -1246,16 +1450,16 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       int32_t nsv[kMU];
       const bool full = base + kMU <= link_frame_e;
       if (full) {
-        const KhFloat4 t4 = Load4F(u.link_k, base);
-        const KhInt4 n4 = Load4I(u.link_dst, base);
+        const KhFloat4 t4 = Load4F(e_k, base);
+        const KhInt4 n4 = Load4I(e_dst, base);
         tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
         nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
       } else {
 #pragma unroll
         for (int j = 0; j < kMU; j++) {
           const int lc = base + j < link_frame_e ? base + j : link_frame_e - 1;
-          tc[j] = u.link_k[lc];
-          nsv[j] = u.link_dst[lc];
+          tc[j] = e_k[lc];
+          nsv[j] = e_dst[lc];
         }
       }
       bool wrote = false;
@@ -1267,7 +1471,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         if (tot_cost != tot_cost || tot_cost > next_cutoff) {
           nsv[j] = -1;  // rejected (:731; a NaN candidate too)
           wrote = true;
-          if (!full) u.link_dst[l] = -1;
+          if (!full) e_dst[l] = -1;
           continue;
         }
         const int32_t ns = -2 - nsv[j];
@@ -1276,15 +1480,16 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         const uint32_t key = static_cast<uint32_t>(ns) + 1u;
         uint32_t slot = lds_slot(h, ns);
         const uint32_t step = ((h >> 9) | 1u) << kLocBits;
+#pragma nounroll
         while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
         nsv[j] = static_cast<int32_t>(vals[slot]);
         wrote = true;
-        if (!full) u.link_dst[l] = nsv[j];
+        if (!full) e_dst[l] = nsv[j];
       }
       if (full && wrote) {   // the lane owns the four slots: one 16-byte store
         KhInt4 o4;
         o4.x = nsv[0]; o4.y = nsv[1]; o4.z = nsv[2]; o4.w = nsv[3];
-        Store4I(u.link_dst, base, o4);
+        Store4I(e_dst, base, o4);
       }
     }
     KhSync();
@@ -1341,12 +1546,23 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   int c_src[kLU], c_ai[kLU];
   uint32_t c_co[kLU];
   float c_ac[kLU], c_tot[kLU];
+  // The sweep's own copies of the pointers it uses (a scalar move each, once per frame): short-lived values with all
+  // their uses inside the sweep, which the register allocator keeps in scalar registers for its duration - the
+  // originals live for the whole launch and were reloaded from their spill lanes in front of every access of the
+  // 64-arc batch loop (22 v_readlane per batch in the round-4 listing).
+  Arr<const KhInt4> x_rec = p.rec;
+  Arr<int32_t> x_dst = u.link_dst, x_src = u.link_src, x_arc = u.link_arc;
+  Arr<float> x_k = u.link_k, x_a = u.link_a;
+  GP(const float) x_ll = u.ll + static_cast<size_t>(frame) * u.ll_stride;
+  int x_keep_ac = p.keep_ac, x_ll_cols = p.ll_cols;
+  KH_LAUNDER(x_rec.p); KH_LAUNDER(x_dst.p); KH_LAUNDER(x_src.p); KH_LAUNDER(x_arc.p); KH_LAUNDER(x_k.p); KH_LAUNDER(x_a.p);
+  KH_LAUNDER(x_ll); KH_LAUNDER(x_keep_ac); KH_LAUNDER(x_ll_cols);
   const int link_frame_e = ExpandWavesFiltered(
-      u, p.rec, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
+      u, x_rec, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
       [&](int k, int src, uint32_t src_cost, int ai) {
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_units);
-        c_arc[k] = p.rec[ai];
+        c_arc[k] = x_rec[ai];
         c_ai[k] = ai;
         c_src[k] = src;
         c_co[k] = src_cost;
@@ -1354,18 +1570,18 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       [&](int k) -> bool {
         int32_t pdf = c_arc[k].x;
         KH_BOUND(7, pdf, 0, u.ll_stride);
-        const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
+        const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
         c_ac[k] = cost_offset - like;
         c_tot[k] = Dec(c_co[k]) + c_ac[k] + __int_as_float(c_arc[k].z);  // :726-730
         est = fminf(est, c_tot[k] + c.adaptive_beam);
         return !(c_tot[k] > bound);
       },
       [&](int k, int l) {
-        u.link_dst[l] = -2 - c_arc[k].w;  // <= -2: the HCLG next state (+ flags), unresolved; token index after pass 2
-        u.link_src[l] = c_src[k];
-        u.link_arc[l] = c_ai[k];
-        if (p.keep_ac) u.link_a[l] = c_ac[k];
-        u.link_k[l] = c_tot[k];
+        x_dst[l] = -2 - c_arc[k].w;  // <= -2: the HCLG next state (+ flags), unresolved; token index after pass 2
+        x_src[l] = c_src[k];
+        x_arc[l] = c_ai[k];
+        if (x_keep_ac) x_a[l] = c_ac[k];
+        x_k[l] = c_tot[k];
       });
   if (link_frame_e < 0) return false;
   // final next_cutoff: the value the reference's running cutoff converges to
@@ -1423,24 +1639,19 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 // Workgroup exclusive scan of (sum, min) pairs: ONE barrier.
 __device__ __forceinline__ void BlockExScanSumMin(int v, uint32_t m, int *ex_sum, uint32_t *ex_min, int *tot_sum, uint32_t *tot_min, Blk &sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = v;
-  uint32_t im = m;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int n = __shfl_up(inc, o, 64);
-    const uint32_t nm = static_cast<uint32_t>(__shfl_up(static_cast<int>(im), o, 64));
-    if (lane >= o) {
-      inc += n;
-      im = nm < im ? nm : im;
-    }
-  }
+  const int inc = WaveIncSum(v);
+  const uint32_t im = WaveIncMinU(m);
   const int b1 = (sh.k_scan++) & 1, b2 = (sh.k_red++) & 1;
   if (lane == 63) {
     sh->wsum[b1][w] = inc;
     sh->wred[b2][w] = im;
   }
+#ifndef KH_NO_DPP
+  const uint32_t pm = static_cast<uint32_t>(DppMov<0x138, 0xf>(-1, static_cast<int>(im)));   // wave_shr:1; lane 0 keeps the identity
+#else
   uint32_t pm = static_cast<uint32_t>(__shfl_up(static_cast<int>(im), 1, 64));
   if (lane == 0) pm = 0xFFFFFFFFu;
+#endif
   KhSync();
   int before = 0, all = 0;
   uint32_t bm = 0xFFFFFFFFu, am = 0xFFFFFFFFu;
@@ -1877,9 +2088,37 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     u.cost_offset[frame] = cost_offset;  // :710-711
     sh->work_cursor = b;
   }
+  // the sweeps' own copies of the pointers they use (see ProcessEmitting: kept in scalar registers for their duration)
+  Arr<const KhInt4> x_rec = p.rec;
+  Arr<uint32_t> x_cost = u.tok_cost;
+  Arr<int32_t> x_state = u.tok_state;
+  GP(const float) x_ll = u.ll + static_cast<size_t>(frame) * u.ll_stride;
+  int x_ll_cols = p.ll_cols;
+  Arr<int32_t> xp_pos = UX(x_pos), xp_c = UX(x_c);
+  Arr<uint32_t> xp_m = UX(x_m);
+  KH_LAUNDER(x_rec.p); KH_LAUNDER(x_cost.p); KH_LAUNDER(x_state.p); KH_LAUNDER(x_ll); KH_LAUNDER(x_ll_cols);
+  KH_LAUNDER(xp_pos.p); KH_LAUNDER(xp_c.p); KH_LAUNDER(xp_m.p);
+  OwnerScan os = OwnerScanInit(sh);
   const float est0 = BlockMinF(est, sh);   // (its barrier publishes the cursor)
   const int lane = threadIdx.x & 63;
   long long my_arcs = 0;
+  // inclusive minimum over the lanes that have the same owner (the lanes of a token are consecutive and `lo` is
+  // non-decreasing): the wave scan with a segment test, on DPP
+  auto seg_min_scan = [&](float m, int lo) -> float {
+#ifndef KH_NO_DPP
+#define KH_SEG_STEP(ctrl, rm) { const float nm = __int_as_float(DppMov<ctrl, rm>(0x7f800000, __float_as_int(m))); const int nlo = DppMov<ctrl, rm>(-2, lo); if (nlo == lo) m = fminf(m, nm); }
+    KH_SEG_STEP(0x111, 0xf) KH_SEG_STEP(0x112, 0xf) KH_SEG_STEP(0x114, 0xf) KH_SEG_STEP(0x118, 0xf) KH_SEG_STEP(0x142, 0xa) KH_SEG_STEP(0x143, 0xc)
+#undef KH_SEG_STEP
+#else
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float nm = __shfl_up(m, o, 64);
+      const int nlo = __shfl_up(lo, o, 64);
+      if (lane >= o && nlo == lo) m = fminf(m, nm);
+    }
+#endif
+    return m;
+  };
   // ---- sweep 1: per token, min tot_cost over its emitting arcs and their number, by list position
   for (;;) {
     int base = 0;
@@ -1889,52 +2128,37 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const int i = base + lane;
     const bool in_range = i < e;
     const int ic = min(i, e - 1);
-    const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
-    int st = u.tok_state[ic];
+    const uint32_t co = LoadCostEnc(&x_cost[ic]);
+    int st = x_state[ic];
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= c.cur_cutoff;
     int ab = 0, cnt = 0;
     if (need) {
       ab = st + 1;
-      cnt = p.rec[st].x;
+      cnt = x_rec[st].x;
     }
-    int inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int nn = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += nn;
-    }
+    const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
-    const int total = __shfl(inc, 63, 64);
+    const int total = WaveLast(inc);
+    const int rel = ab - loff;
+    os.carry = -1;
     float acc = inf;
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < total;
-      int lo = 0, hi = 63;
-#pragma unroll
-      for (int step = 0; step < 6; step++) {
-        const int mid = (lo + hi + 1) >> 1;
-        const int v = __shfl(loff, mid, 64);
-        if (v <= q) lo = mid; else hi = mid - 1;
-      }
-      const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64);
+      const int lo = OwnerLane(os, cnt, loff, q0, lane);
+      const int o_rel = __shfl(rel, lo, 64);
       const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
       float m = inf;
       if (valid) {
-        const KhInt4 arc = p.rec[o_ab + (q - o_off)];
+        const KhInt4 arc = x_rec[o_rel + q];
         int32_t pdf = arc.x;
         KH_BOUND(7, pdf, 0, u.ll_stride);
-        const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
+        const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
         const float ac = cost_offset - like;
         m = Dec(o_co) + ac + __int_as_float(arc.z);  // :726-730
       }
-      // inclusive minimum over the lanes of the same token (the lanes of a token are consecutive)
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const float nm = __shfl_up(m, o, 64);
-        const int nlo = __shfl_up(lo, o, 64);
-        if (lane >= o && nlo == lo) m = fminf(m, nm);
-      }
+      m = seg_min_scan(m, lo);
       // the token's lane fetches the value at the last of its arcs in this batch
       const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
       const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
@@ -1942,9 +2166,9 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       if (has) acc = fminf(acc, got);
     }
     if (in_range) {
-      const int pos = UX(x_pos)[i - b];
-      UX(x_m)[pos] = Enc(acc + c.adaptive_beam);   // (+inf for a token without arcs or above the cutoff)
-      UX(x_c)[pos] = cnt;
+      const int pos = xp_pos[i - b];
+      xp_m[pos] = Enc(acc + c.adaptive_beam);   // (+inf for a token without arcs or above the cutoff)
+      xp_c[pos] = cnt;
     }
     if (lane == 0) my_arcs += total;
   }
@@ -1956,14 +2180,14 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   for (int base = 0; base < n; base += NT) {
     const int q = base + threadIdx.x;
     const bool valid = q < n;
-    const uint32_t m = valid ? UX(x_m)[q] : 0xFFFFFFFFu;
-    const int cnt = valid ? UX(x_c)[q] : 0;
+    const uint32_t m = valid ? xp_m[q] : 0xFFFFFFFFu;
+    const int cnt = valid ? xp_c[q] : 0;
     int ex_sum, tot_sum;
     uint32_t ex_min, tot_min;
     BlockExScanSumMin(cnt, m, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
     if (valid) {
-      UX(x_m)[q] = run_min < ex_min ? run_min : ex_min;
-      UX(x_c)[q] = run_sum + ex_sum;
+      xp_m[q] = run_min < ex_min ? run_min : ex_min;
+      xp_c[q] = run_sum + ex_sum;
     }
     run_min = run_min < tot_min ? run_min : tot_min;
     run_sum += tot_sum;
@@ -1979,6 +2203,11 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     sh->work_cursor = b;
     sh->x_qbase = static_cast<uint32_t>(run_sum);
   }
+  Arr<int32_t> x_dst = u.link_dst, x_src = u.link_src, x_arc = u.link_arc, xp_ord = UX(x_ord);
+  Arr<float> x_k = u.link_k, x_a = u.link_a;
+  int x_keep_ac = p.keep_ac;
+  KH_LAUNDER(x_dst.p); KH_LAUNDER(x_src.p); KH_LAUNDER(x_arc.p); KH_LAUNDER(xp_ord.p); KH_LAUNDER(x_k.p); KH_LAUNDER(x_a.p);
+  KH_LAUNDER(x_keep_ac);
   KhSync();
   for (;;) {
     int base = 0;
@@ -1988,63 +2217,55 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const int i = base + lane;
     const bool in_range = i < e;
     const int ic = min(i, e - 1);
-    const uint32_t co = LoadCostEnc(&u.tok_cost[ic]);
-    int st = u.tok_state[ic];
+    const uint32_t co = LoadCostEnc(&x_cost[ic]);
+    int st = x_state[ic];
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= c.cur_cutoff;
     int ab = 0, cnt = 0;
     if (need) {
       ab = st + 1;
-      cnt = p.rec[st].x;
+      cnt = x_rec[st].x;
     }
-    const int pos = UX(x_pos)[ic - b];
-    const float r_tok = Dec(UX(x_m)[pos]);
-    const int a_tok = UX(x_c)[pos];
-    int inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int nn = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += nn;
-    }
+    const int pos = xp_pos[ic - b];
+    const float r_tok = Dec(xp_m[pos]);
+    const int a_tok = xp_c[pos];
+    const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
-    const int total = __shfl(inc, 63, 64);
+    const int total = WaveLast(inc);
+    const int rel = ab - loff, arel = a_tok - loff;   // arc index / candidate ordinal = (...)(owner) + slot
+    os.carry = -1;
     float acc = inf;   // min(tot_cost + adaptive_beam) over this token's arcs in the batches before the current one
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < total;
-      int lo = 0, hi = 63;
-#pragma unroll
-      for (int step = 0; step < 6; step++) {
-        const int mid = (lo + hi + 1) >> 1;
-        const int v = __shfl(loff, mid, 64);
-        if (v <= q) lo = mid; else hi = mid - 1;
-      }
-      const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64), o_a = __shfl(a_tok, lo, 64);
+      const int lo = OwnerLane(os, cnt, loff, q0, lane);
+      const int o_rel = __shfl(rel, lo, 64), o_arel = __shfl(arel, lo, 64);
       const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
       const float o_r = __shfl(r_tok, lo, 64), o_acc = __shfl(acc, lo, 64);
       KhInt4 arc;
       arc.x = 0; arc.y = 0; arc.z = 0; arc.w = 0;
       float tot = inf, ac = 0.0f;
-      const int ai = o_ab + (q - o_off);
+      const int ai = o_rel + q;
       if (valid) {
-        arc = p.rec[ai];
+        arc = x_rec[ai];
         int32_t pdf = arc.x;
         KH_BOUND(7, pdf, 0, u.ll_stride);
-        const float like = p.ll_cols > 0 ? sh.ll_row[pdf] : u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
+        const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
         ac = cost_offset - like;
         tot = Dec(o_co) + ac + __int_as_float(arc.z);  // :726-730
       }
       float m = tot + c.adaptive_beam;   // what this arc lowers next_cutoff to (:732-733)
       if (!(m == m)) m = inf;            // (a NaN never lowers it)
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const float nm = __shfl_up(m, o, 64);
-        const int nlo = __shfl_up(lo, o, 64);
-        if (lane >= o && nlo == lo) m = fminf(m, nm);
-      }
+      m = seg_min_scan(m, lo);
+#ifndef KH_NO_DPP
+      const float pm = __int_as_float(DppMov<0x138, 0xf>(0x7f800000, __float_as_int(m)));   // wave_shr:1
+      const int plo = DppMov<0x138, 0xf>(-2, lo);
+      const float before = plo == lo ? pm : inf;
+#else
       const float pm = __shfl_up(m, 1, 64);
       const int plo = __shfl_up(lo, 1, 64);
       const float before = (lane >= 1 && plo == lo) ? pm : inf;
+#endif
       const float running = fminf(fminf(o_r, o_acc), before);
       const bool keep = valid && !(tot > running) && tot == tot;   // :731 (a NaN candidate is dropped, as in the canonical rule)
       const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
@@ -2061,12 +2282,12 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           if (lane == 0) sh->status = (at + n_keep > u.link_cap) ? 2 : 3;
         } else if (keep) {
           const int l = at + __popcll(kb & ((1ull << lane) - 1ull));
-          u.link_dst[l] = -2 - arc.w;
-          u.link_src[l] = base + lo;
-          u.link_arc[l] = ai;
-          if (p.keep_ac) u.link_a[l] = ac;
-          u.link_k[l] = tot;
-          UX(x_ord)[l - link_frame_b] = o_a + (q - o_off);
+          x_dst[l] = -2 - arc.w;
+          x_src[l] = base + lo;
+          x_arc[l] = ai;
+          if (x_keep_ac) x_a[l] = ac;
+          x_k[l] = tot;
+          xp_ord[l - link_frame_b] = o_arel + q;
         }
       }
     }
@@ -2675,7 +2896,12 @@ __device__ __forceinline__ void SurvAddLink(const Utt &u, Blk &sh, int l, int f)
   else sh->status = 7;
 }
 
-__device__ void FinalBackward(const Utt &u, const Params &p, int last, int fb, int fe, Blk &sh) {
+__device__ void FinalBackward(const Utt &u_in, const Params &p, int last, int fb, int fe, Blk &sh) {
+  // the pass's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
+  Utt u = u_in;
+  KH_LAUNDER(u.link_dst.p); KH_LAUNDER(u.link_src.p); KH_LAUNDER(u.link_k.p); KH_LAUNDER(u.tok_extra.p); KH_LAUNDER(u.tok_state.p);
+  KH_LAUNDER(u.tok_cost.p); KH_LAUNDER(u.surv_tok.p); KH_LAUNDER(u.surv_link.p);
+  KH_LAUNDER(u.feps_b.p); KH_LAUNDER(u.feps_e.p); KH_LAUNDER(u.femit_b.p); KH_LAUNDER(u.femit_e.p); KH_LAUNDER(u.frame_b.p); KH_LAUNDER(u.frame_e.p);
   const float inf = INFINITY, lb = p.lattice_beam;
   const int t = threadIdx.x;
   auto x_lo = LdsVals(sh);
@@ -3496,6 +3722,8 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
   sh.k_scan = 0;
   sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + blockIdx.x) : nullptr;
   Utt u = slots[blockIdx.x];
+  Launder(u);
+  Launder(p);
   u.phase_cycles = phase_cycles ? phase_cycles + NPH * blockIdx.x : (GP(long long))nullptr;
   if (threadIdx.x == 0) {
     for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
@@ -3617,6 +3845,8 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
   sh.x = nullptr;
   const Job job = jobs[blockIdx.x];
   Utt u = slots[job.slot];
+  Launder(u);
+  Launder(p);
   SlotState *S = &states[job.slot];
   u.phase_cycles = (GP(long long))nullptr;
   if (threadIdx.x == 0) {
@@ -3743,6 +3973,8 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   sh.x = nullptr;
   const int s = blockIdx.x;
   Utt u = slots[s];
+  Launder(u);
+  Launder(p);
   SlotState *S = &states[s];
   ServeCtl *c = &ctl[s];
   u.phase_cycles = (GP(long long))nullptr;
