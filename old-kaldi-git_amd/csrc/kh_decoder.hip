@@ -300,6 +300,32 @@ __device__ __forceinline__ void LaunderOne(T &x) {
 #else
 #define KH_LAUNDER(x) do {} while (0)
 #endif
+// per-phase switches of the local copies (same-box A/B builds)
+#ifdef KH_NO_P2_LOCAL
+#define KH_LAUNDER_P2(x) do {} while (0)
+#else
+#define KH_LAUNDER_P2(x) KH_LAUNDER(x)
+#endif
+#ifdef KH_NO_GC_LOCAL
+#define KH_LAUNDER_GC(x) do {} while (0)
+#else
+#define KH_LAUNDER_GC(x) KH_LAUNDER(x)
+#endif
+#ifdef KH_NO_NE_LOCAL
+#define KH_LAUNDER_NE(x) do {} while (0)
+#else
+#define KH_LAUNDER_NE(x) KH_LAUNDER(x)
+#endif
+#ifdef KH_NO_FB_LOCAL
+#define KH_LAUNDER_FB(x) do {} while (0)
+#else
+#define KH_LAUNDER_FB(x) KH_LAUNDER(x)
+#endif
+#ifdef KH_NO_X_LOCAL
+#define KH_LAUNDER_X(x) do {} while (0)
+#else
+#define KH_LAUNDER_X(x) KH_LAUNDER(x)
+#endif
 __device__ __forceinline__ void Launder(Utt &u) {
   KH_LAUNDER(u.ll); KH_LAUNDER(u.ll_stride); KH_LAUNDER(u.T); KH_LAUNDER(u.tok_cap);
   KH_LAUNDER(u.tok_state.p); KH_LAUNDER(u.tok_cost.p); KH_LAUNDER(u.tok_extra.p);
@@ -526,6 +552,11 @@ __device__ __forceinline__ float WaveIncMinF(float f) {
 }
 // the value of lane 63 (the total of an inclusive scan), in a scalar register
 __device__ __forceinline__ int WaveLast(int v) { return __builtin_amdgcn_readlane(v, 63); }
+// value of lane `src` (0 .. 63), per lane: ds_bpermute_b32 directly (__shfl also folds the caller's lane into the
+// source index, which costs two more VALU instructions and a live register per call site in a 64-lane wave)
+__device__ __forceinline__ int ShflI(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+__device__ __forceinline__ uint32_t ShflU(uint32_t v, int src) { return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src << 2, static_cast<int>(v))); }
+__device__ __forceinline__ float ShflF(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
 __device__ __forceinline__ float WaveMinF(float f) { return __int_as_float(WaveLast(__float_as_int(WaveIncMinF(f)))); }
 // 64-bit reductions: the two halves travel separately (identity per half), the total ends in lane 63
 #ifndef KH_NO_DPP
@@ -735,6 +766,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute_
                          __attribute__((address_space(3))) int *eps_n /*LDS counter*/, int tok_limit, int front_b) {
   uint32_t slot = HashState(state) & u.hash_mask;
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
+  #pragma nounroll
   for (int probes = 0; probes < (1 << 30); probes++) {
     // ONE L2 round trip per probe: the compare-and-swap claims the slot if it is empty
     // and otherwise returns its occupant (a failed CAS is an atomic load)
@@ -779,6 +811,7 @@ __device__ int FindOrAdd(const Utt &u, int32_t state, bool has_eps, __attribute_
 __device__ __forceinline__ int FindExisting(const Utt &u, int32_t state, unsigned long long first_probe, uint32_t slot) {
   const unsigned long long want_key = static_cast<unsigned long long>(static_cast<uint32_t>(state) + 1u);
   unsigned long long ent = first_probe;
+  #pragma nounroll
   for (int probes = 0; probes < (1 << 30); probes++) {
     if ((ent & 0xFFFFFFFFull) == want_key) {
       const uint32_t hi = static_cast<uint32_t>(ent >> 32);
@@ -862,6 +895,36 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const KhInt4> rec, 
   return lrun;
 }
 
+// number of set bits of `mask` below this lane: v_mbcnt_lo / v_mbcnt_hi (no per-lane 64-bit mask constant, which the
+// sweeps kept in two VGPRs - or reloaded from scratch inside the batch loop)
+__device__ __forceinline__ int LanePrefixCount(unsigned long long mask) {
+  return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
+}
+// One LDS fetch-add per wave, issued by lane 0 alone and returned in a scalar register.  Written with the execution mask
+// set by hand: `if (lane == 0) atomic` costs the compare (or two v_readlane for its hoisted, spilled mask), the mask
+// save / branch, and on top of that the compiler's atomic optimizer wraps the single-lane atomic in its own
+// mbcnt / bcnt / multiply sequence - a dozen instructions per 64-arc batch.  Precondition: lane 0 is active.
+__device__ __forceinline__ int WaveLdsFetchAdd(__attribute__((address_space(3))) int *addr, int v) {
+#ifndef KH_NO_ASM_ATOMIC
+  int r;
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %1, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "ds_add_rtn_u32 %0, %2, %3\n\t"
+      "s_mov_b64 exec, %1\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r), "=&s"(saved)
+      : "v"(addr), "v"(v)
+      : "memory");
+  return __builtin_amdgcn_readfirstlane(r);
+#else
+  int r = 0;
+  if ((threadIdx.x & 63) == 0) r = __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(r);
+#endif
+}
+
 // Arc slot -> owning token inside a wave, for the independent-wave sweeps below.  A wave holds 64 tokens with their arc
 // counts and first slots (loff, an exclusive prefix sum: non-decreasing); the owner of slot q is the LAST token whose
 // first slot is <= q (tokens without arcs share their successor's first slot and are skipped by "last").  Per 64-slot
@@ -879,7 +942,7 @@ struct OwnerScan {
 };
 __device__ __forceinline__ OwnerScan OwnerScanInit(Blk &sh) {   // (a workgroup barrier must follow before the first batch: none needed, the row is the wave's own)
   OwnerScan os;
-  os.row = &sh->own[threadIdx.x >> 6][0];
+  os.row = &sh->own[Uni(static_cast<int>(threadIdx.x >> 6))][0];
   os.row[threadIdx.x & 63] = 0;
   os.seq = 0;
   os.carry = -1;
@@ -933,9 +996,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
   KhSync();
   uint32_t my_bound_enc = Enc(*bound);
   for (;;) {
-    int base = 0;
-    if (lane == 0) base = __hip_atomic_fetch_add(&sh->work_cursor, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    base = Uni(base);
+    const int base = WaveLdsFetchAdd(&sh->work_cursor, 64);
     if (base >= e) break;
     const int i = base + lane;
     const bool in_range = i < e;
@@ -952,6 +1013,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
     const int total = WaveLast(inc);
+    const float cof = Dec(co);   // (decoded once per token, not once per arc)
     {
       const uint32_t be = Uni(__hip_atomic_load(&sh->bound_enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       *bound = fminf(*bound, Dec(be));
@@ -968,8 +1030,8 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
       // successor's first slot and are skipped by "last")
 #ifndef KH_OWNER_SEARCH
       const int lo = OwnerLane(os, cnt, loff, q0, lane);
-      const int o_rel = __shfl(rel, lo, 64);
-      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      const int o_rel = ShflI(rel, lo);
+      const float o_co = ShflF(cof, lo);
       const int o_ai = o_rel + q;
 #else
       int lo = 0, hi = 63;
@@ -980,7 +1042,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
         if (v <= q) lo = mid; else hi = mid - 1;
       }
       const int o_off = __shfl(loff, lo, 64), o_ab = __shfl(ab, lo, 64);
-      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      const float o_co = __shfl(cof, lo, 64);
       const int o_ai = o_ab + (q - o_off);
 #endif
       bool keep = false;
@@ -991,13 +1053,11 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
       const unsigned long long kb = __ballot(keep);
       if (kb != 0ull) {
         const int n_keep = __popcll(kb);
-        int pos = 0;
-        if (lane == 0) pos = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pos = Uni(pos);
+        const int pos = WaveLdsFetchAdd(&sh->link_cursor, n_keep);
         if (pos + n_keep > limit) {
           if (lane == 0) sh->status = (pos + n_keep > u.link_cap) ? 2 : 3;
         } else if (keep) {
-          store(0, pos + __popcll(kb & ((1ull << lane) - 1ull)));
+          store(0, pos + LanePrefixCount(kb));
         }
       }
     }
@@ -1019,6 +1079,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
 struct Cutoff {
   float cur_cutoff, adaptive_beam, best_cost;
   int best_tok, count;
+  int32_t best_state;   // canonical rule only: the best token's HCLG state (it is part of the reduction key)
 };
 
 // GetCutoff :591-658 over the tokens [b, e) of the current frame.  kExact: the best token on a tie is the FIRST one
@@ -1028,7 +1089,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   Cutoff c;
   Arr<uint32_t> g_cost = u.tok_cost;
   Arr<int32_t> g_state = u.tok_state;
-  KH_LAUNDER(g_cost.p); KH_LAUNDER(g_state.p);
+  KH_LAUNDER_GC(g_cost.p); KH_LAUNDER_GC(g_state.p);
   const int n = e - b;
   c.count = n;
   unsigned long long best = ~0ull;
@@ -1048,15 +1109,23 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   if (n == 0) {
     c.best_cost = inf;
     c.best_tok = -1;
+    c.best_state = -1;
     c.cur_cutoff = inf;
     c.adaptive_beam = p.beam;
     return c;
   }
   c.best_cost = Dec(static_cast<uint32_t>(best >> 32));
-  // the lane that holds the winning key (states are unique within a frame) publishes its token
-  if (mine == best && best_i >= 0) sh->bcast_i[0] = best_i;
-  KhSync();
-  c.best_tok = Uni(sh->bcast_i[0]);
+  if (kExact) {
+    // the lane that holds the winning key (list positions are unique within a frame) publishes its token
+    if (mine == best && best_i >= 0) sh->bcast_i[0] = best_i;
+    KhSync();
+    c.best_tok = Uni(sh->bcast_i[0]);
+    c.best_state = -1;
+  } else {
+    // the winning key carries the state itself: no broadcast, no barrier, no dependent load of tok_state[best]
+    c.best_tok = 0;
+    c.best_state = static_cast<int32_t>(static_cast<uint32_t>(best));
+  }
   const float best_weight = c.best_cost;
   if (p.max_active == 0x7fffffff && p.min_active == 0) {
     c.adaptive_beam = p.beam;
@@ -1113,11 +1182,11 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
   // the phase's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
   Utt u = u_in;
   Params p = p_in;
-  KH_LAUNDER(u.tmp_epslist.p); KH_LAUNDER(u.tmp_work0.p); KH_LAUNDER(u.tmp_work1.p); KH_LAUNDER(u.tmp_dirty.p);
-  KH_LAUNDER(u.tok_cost.p); KH_LAUNDER(u.tok_state.p); KH_LAUNDER(u.tok_extra.p); KH_LAUNDER(u.tmp_slot.p);
-  KH_LAUNDER(u.hash.p); KH_LAUNDER(u.hash_mask);
-  KH_LAUNDER(u.link_dst.p); KH_LAUNDER(u.link_src.p); KH_LAUNDER(u.link_arc.p); KH_LAUNDER(u.link_k.p);
-  KH_LAUNDER(p.rec.p); KH_LAUNDER(p.n_arcs.p);
+  KH_LAUNDER_NE(u.tmp_epslist.p); KH_LAUNDER_NE(u.tmp_work0.p); KH_LAUNDER_NE(u.tmp_work1.p); KH_LAUNDER_NE(u.tmp_dirty.p);
+  KH_LAUNDER_NE(u.tok_cost.p); KH_LAUNDER_NE(u.tok_state.p); KH_LAUNDER_NE(u.tok_extra.p); KH_LAUNDER_NE(u.tmp_slot.p);
+  KH_LAUNDER_NE(u.hash.p); KH_LAUNDER_NE(u.hash_mask);
+  KH_LAUNDER_NE(u.link_dst.p); KH_LAUNDER_NE(u.link_src.p); KH_LAUNDER_NE(u.link_arc.p); KH_LAUNDER_NE(u.link_k.p);
+  KH_LAUNDER_NE(p.rec.p); KH_LAUNDER_NE(p.n_arcs.p);
   const int fb = Uni(sh->front_b);
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff, driven by work lists.
@@ -1284,17 +1353,21 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
 // consecutive token indices from one scan (a deterministic order), the tokens are written
 // with plain stores and a second sweep gives the part's links their token index.  Only the
 // tokens the epsilon closure may look up (kEpsDst states) also enter the global hash.
+template <bool kLocal>
 __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok_limit, int link_frame_b, int link_frame_e,
                                           float next_cutoff) {
   static_assert(kLdsSlots % NT == 0, "slots per lane");
-  // the pass's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
+  // the pass's own copies of the pointers it uses (see ProcessEmitting) - in the reference-order kernel only:
+  // same-box A/B, canonical kernel 691 ms with them / 676 ms without, reference-order kernel 2208 / 2246 ms
   Arr<float> e_k = u.link_k, e_extra = u.tok_extra;
   Arr<int32_t> e_dst = u.link_dst, e_state = u.tok_state, e_epslist = u.tmp_epslist, e_dirty = u.tmp_dirty, e_slot = u.tmp_slot;
   Arr<uint32_t> e_cost = u.tok_cost;
   Arr<unsigned long long> e_hash = u.hash;
   uint32_t e_hmask = u.hash_mask;
-  KH_LAUNDER(e_k.p); KH_LAUNDER(e_extra.p); KH_LAUNDER(e_dst.p); KH_LAUNDER(e_state.p); KH_LAUNDER(e_epslist.p);
-  KH_LAUNDER(e_dirty.p); KH_LAUNDER(e_slot.p); KH_LAUNDER(e_cost.p); KH_LAUNDER(e_hash.p); KH_LAUNDER(e_hmask);
+  if constexpr (kLocal) {
+    KH_LAUNDER_P2(e_k.p); KH_LAUNDER_P2(e_extra.p); KH_LAUNDER_P2(e_dst.p); KH_LAUNDER_P2(e_state.p); KH_LAUNDER_P2(e_epslist.p);
+    KH_LAUNDER_P2(e_dirty.p); KH_LAUNDER_P2(e_slot.p); KH_LAUNDER_P2(e_cost.p); KH_LAUNDER_P2(e_hash.p); KH_LAUNDER_P2(e_hmask);
+  }
   auto keys = LdsKeys(sh);
   auto vals = LdsVals(sh);
   const float nan = __int_as_float(0x7fc00000);
@@ -1432,6 +1505,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
                                         (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
         uint32_t g = HashState(ns & kStateMask) & e_hmask;
+        #pragma nounroll
         for (int probes = 0; probes < (1 << 30); probes++) {
           unsigned long long ent = kEmpty;
           __hip_atomic_compare_exchange_strong(&e_hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1519,11 +1593,24 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     cost_offset = -c.best_cost;  // :691
     // :692-704 estimate from the best token's arcs (different association order
     // from the main loop: ((w + (offset - ll)) + tot_cost) + adaptive_beam)
-    const int32_t s = u.tok_state[c.best_tok];
+    const int32_t s = c.best_state;
     const float tot = c.best_cost;
-    const int ab = s + 1, ae = ab + p.rec[s].x;
-    for (int a = ab + threadIdx.x; a < ae; a += NT) {
-      const KhInt4 arc = p.rec[a];   // {pdf, olabel, weight, nextstate}
+    // The record's header (arc count) and its first 64 arcs are requested TOGETHER - the first wave reads the units
+    // behind the header before it knows how many of them are arcs of this state (they are units of the same table;
+    // the index is clamped to it) - one round trip instead of two dependent ones in front of the frame's expansion.
+    const int ab = s + 1;
+    const int a0 = ab + threadIdx.x;
+    KhInt4 arc0;
+    arc0.x = 0; arc0.y = 0; arc0.z = 0; arc0.w = 0;
+    if (threadIdx.x < 64) arc0 = p.rec[min(a0, p.num_units - 1)];
+    const int ae = ab + p.rec[s].x;
+    if (threadIdx.x < 64 && a0 < ae) {
+      const float w = __int_as_float(arc0.z) + (cost_offset - LogLike(u, p, sh, frame, arc0.x));   // {pdf, olabel, weight, nextstate}
+      const float new_weight = w + tot;
+      est = fminf(est, new_weight + c.adaptive_beam);
+    }
+    for (int a = a0 + (threadIdx.x < 64 ? NT : 0); a < ae; a += NT) {
+      const KhInt4 arc = p.rec[a];
       const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
       const float new_weight = w + tot;
       est = fminf(est, new_weight + c.adaptive_beam);
@@ -1544,7 +1631,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   constexpr int kLU = 1;  // (2 in flight per lane: no gain, +16 B of scratch per lane)
   KhInt4 c_arc[kLU];
   int c_src[kLU], c_ai[kLU];
-  uint32_t c_co[kLU];
+  float c_co[kLU];
   float c_ac[kLU], c_tot[kLU];
   // The sweep's own copies of the pointers it uses (a scalar move each, once per frame): short-lived values with all
   // their uses inside the sweep, which the register allocator keeps in scalar registers for its duration - the
@@ -1559,7 +1646,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   KH_LAUNDER(x_ll); KH_LAUNDER(x_keep_ac); KH_LAUNDER(x_ll_cols);
   const int link_frame_e = ExpandWavesFiltered(
       u, x_rec, b, e, c.cur_cutoff, link_frame_b, u.link_frame_cap, &my_arcs, sh, &est, &bound,
-      [&](int k, int src, uint32_t src_cost, int ai) {
+      [&](int k, int src, float src_cost, int ai) {
         KH_BOUND(5, src, 0, u.tok_cap);
         KH_BOUND(6, ai, 0, p.num_units);
         c_arc[k] = x_rec[ai];
@@ -1572,7 +1659,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
         c_ac[k] = cost_offset - like;
-        c_tot[k] = Dec(c_co[k]) + c_ac[k] + __int_as_float(c_arc[k].z);  // :726-730
+        c_tot[k] = c_co[k] + c_ac[k] + __int_as_float(c_arc[k].z);  // :726-730
         est = fminf(est, c_tot[k] + c.adaptive_beam);
         return !(c_tot[k] > bound);
       },
@@ -1595,7 +1682,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   }
   KhSync();
 
-  if (!EmitPass2(u, sh, nb, tok_limit, link_frame_b, link_frame_e, next_cutoff)) return false;
+  if (!EmitPass2<false>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, next_cutoff)) return false;
   KhSync();
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
   if (threadIdx.x == 0) {
@@ -1755,7 +1842,7 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
             peers &= set ? m : ~m;
           }
           if (act) {
-            const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+            const int rank = LanePrefixCount(peers);
             const uint32_t at = hist[w * kBins + d];
             if (rank == 0) hist[w * kBins + d] = at + static_cast<uint32_t>(__popcll(peers));
             kout[at + rank] = k4[j];
@@ -2096,8 +2183,8 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   int x_ll_cols = p.ll_cols;
   Arr<int32_t> xp_pos = UX(x_pos), xp_c = UX(x_c);
   Arr<uint32_t> xp_m = UX(x_m);
-  KH_LAUNDER(x_rec.p); KH_LAUNDER(x_cost.p); KH_LAUNDER(x_state.p); KH_LAUNDER(x_ll); KH_LAUNDER(x_ll_cols);
-  KH_LAUNDER(xp_pos.p); KH_LAUNDER(xp_c.p); KH_LAUNDER(xp_m.p);
+  KH_LAUNDER_X(x_rec.p); KH_LAUNDER_X(x_cost.p); KH_LAUNDER_X(x_state.p); KH_LAUNDER_X(x_ll); KH_LAUNDER_X(x_ll_cols);
+  KH_LAUNDER_X(xp_pos.p); KH_LAUNDER_X(xp_c.p); KH_LAUNDER_X(xp_m.p);
   OwnerScan os = OwnerScanInit(sh);
   const float est0 = BlockMinF(est, sh);   // (its barrier publishes the cursor)
   const int lane = threadIdx.x & 63;
@@ -2121,9 +2208,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   };
   // ---- sweep 1: per token, min tot_cost over its emitting arcs and their number, by list position
   for (;;) {
-    int base = 0;
-    if (lane == 0) base = __hip_atomic_fetch_add(&sh->work_cursor, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    base = Uni(base);
+    const int base = WaveLdsFetchAdd(&sh->work_cursor, 64);
     if (base >= e) break;
     const int i = base + lane;
     const bool in_range = i < e;
@@ -2141,14 +2226,15 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const int loff = inc - cnt;
     const int total = WaveLast(inc);
     const int rel = ab - loff;
+    const float cof = Dec(co);
     os.carry = -1;
     float acc = inf;
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < total;
       const int lo = OwnerLane(os, cnt, loff, q0, lane);
-      const int o_rel = __shfl(rel, lo, 64);
-      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
+      const int o_rel = ShflI(rel, lo);
+      const float o_co = ShflF(cof, lo);
       float m = inf;
       if (valid) {
         const KhInt4 arc = x_rec[o_rel + q];
@@ -2156,13 +2242,13 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
         const float ac = cost_offset - like;
-        m = Dec(o_co) + ac + __int_as_float(arc.z);  // :726-730
+        m = o_co + ac + __int_as_float(arc.z);  // :726-730
       }
       m = seg_min_scan(m, lo);
       // the token's lane fetches the value at the last of its arcs in this batch
       const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
       const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
-      const float got = __shfl(m, has ? tail : 0, 64);
+      const float got = ShflF(m, has ? tail : 0);
       if (has) acc = fminf(acc, got);
     }
     if (in_range) {
@@ -2206,13 +2292,11 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   Arr<int32_t> x_dst = u.link_dst, x_src = u.link_src, x_arc = u.link_arc, xp_ord = UX(x_ord);
   Arr<float> x_k = u.link_k, x_a = u.link_a;
   int x_keep_ac = p.keep_ac;
-  KH_LAUNDER(x_dst.p); KH_LAUNDER(x_src.p); KH_LAUNDER(x_arc.p); KH_LAUNDER(xp_ord.p); KH_LAUNDER(x_k.p); KH_LAUNDER(x_a.p);
-  KH_LAUNDER(x_keep_ac);
+  KH_LAUNDER_X(x_dst.p); KH_LAUNDER_X(x_src.p); KH_LAUNDER_X(x_arc.p); KH_LAUNDER_X(xp_ord.p); KH_LAUNDER_X(x_k.p); KH_LAUNDER_X(x_a.p);
+  KH_LAUNDER_X(x_keep_ac);
   KhSync();
   for (;;) {
-    int base = 0;
-    if (lane == 0) base = __hip_atomic_fetch_add(&sh->work_cursor, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    base = Uni(base);
+    const int base = WaveLdsFetchAdd(&sh->work_cursor, 64);
     if (base >= e) break;
     const int i = base + lane;
     const bool in_range = i < e;
@@ -2233,15 +2317,16 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const int loff = inc - cnt;
     const int total = WaveLast(inc);
     const int rel = ab - loff, arel = a_tok - loff;   // arc index / candidate ordinal = (...)(owner) + slot
+    const float cof = Dec(co);
     os.carry = -1;
     float acc = inf;   // min(tot_cost + adaptive_beam) over this token's arcs in the batches before the current one
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < total;
       const int lo = OwnerLane(os, cnt, loff, q0, lane);
-      const int o_rel = __shfl(rel, lo, 64), o_arel = __shfl(arel, lo, 64);
-      const uint32_t o_co = static_cast<uint32_t>(__shfl(static_cast<int>(co), lo, 64));
-      const float o_r = __shfl(r_tok, lo, 64), o_acc = __shfl(acc, lo, 64);
+      const int o_rel = ShflI(rel, lo), o_arel = ShflI(arel, lo);
+      const float o_co = ShflF(cof, lo);
+      const float o_racc = ShflF(fminf(r_tok, acc), lo);   // running cutoff in front of the token, lowered by its arcs in earlier batches
       KhInt4 arc;
       arc.x = 0; arc.y = 0; arc.z = 0; arc.w = 0;
       float tot = inf, ac = 0.0f;
@@ -2252,7 +2337,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         KH_BOUND(7, pdf, 0, u.ll_stride);
         const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
         ac = cost_offset - like;
-        tot = Dec(o_co) + ac + __int_as_float(arc.z);  // :726-730
+        tot = o_co + ac + __int_as_float(arc.z);  // :726-730
       }
       float m = tot + c.adaptive_beam;   // what this arc lowers next_cutoff to (:732-733)
       if (!(m == m)) m = inf;            // (a NaN never lowers it)
@@ -2266,22 +2351,20 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       const int plo = __shfl_up(lo, 1, 64);
       const float before = (lane >= 1 && plo == lo) ? pm : inf;
 #endif
-      const float running = fminf(fminf(o_r, o_acc), before);
+      const float running = fminf(o_racc, before);
       const bool keep = valid && !(tot > running) && tot == tot;   // :731 (a NaN candidate is dropped, as in the canonical rule)
       const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
       const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
-      const float got = __shfl(m, has ? tail : 0, 64);
+      const float got = ShflF(m, has ? tail : 0);
       if (has) acc = fminf(acc, got);
       const unsigned long long kb = __ballot(keep);
       if (kb != 0ull) {
         const int n_keep = __popcll(kb);
-        int at = 0;
-        if (lane == 0) at = __hip_atomic_fetch_add(&sh->link_cursor, n_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        at = Uni(at);
+        const int at = WaveLdsFetchAdd(&sh->link_cursor, n_keep);
         if (at + n_keep > limit) {
           if (lane == 0) sh->status = (at + n_keep > u.link_cap) ? 2 : 3;
         } else if (keep) {
-          const int l = at + __popcll(kb & ((1ull << lane) - 1ull));
+          const int l = at + LanePrefixCount(kb);
           x_dst[l] = -2 - arc.w;
           x_src[l] = base + lo;
           x_arc[l] = ai;
@@ -2304,7 +2387,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   KhSync();
   // ---- pass 2: FindOrAddToken + minimum cost in the LDS token table, as in the canonical sweep (every candidate here
   // has been accepted: no cutoff test)
-  if (!EmitPass2(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf)) return false;
+  if (!EmitPass2<true>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf)) return false;
   // ---- the insertion key of a new token = the smallest ordinal among its candidates (the arc that made the reference
   // call HashList::Insert for it); its cost before the closure
   {
@@ -2899,9 +2982,9 @@ __device__ __forceinline__ void SurvAddLink(const Utt &u, Blk &sh, int l, int f)
 __device__ void FinalBackward(const Utt &u_in, const Params &p, int last, int fb, int fe, Blk &sh) {
   // the pass's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
   Utt u = u_in;
-  KH_LAUNDER(u.link_dst.p); KH_LAUNDER(u.link_src.p); KH_LAUNDER(u.link_k.p); KH_LAUNDER(u.tok_extra.p); KH_LAUNDER(u.tok_state.p);
-  KH_LAUNDER(u.tok_cost.p); KH_LAUNDER(u.surv_tok.p); KH_LAUNDER(u.surv_link.p);
-  KH_LAUNDER(u.feps_b.p); KH_LAUNDER(u.feps_e.p); KH_LAUNDER(u.femit_b.p); KH_LAUNDER(u.femit_e.p); KH_LAUNDER(u.frame_b.p); KH_LAUNDER(u.frame_e.p);
+  KH_LAUNDER_FB(u.link_dst.p); KH_LAUNDER_FB(u.link_src.p); KH_LAUNDER_FB(u.link_k.p); KH_LAUNDER_FB(u.tok_extra.p); KH_LAUNDER_FB(u.tok_state.p);
+  KH_LAUNDER_FB(u.tok_cost.p); KH_LAUNDER_FB(u.surv_tok.p); KH_LAUNDER_FB(u.surv_link.p);
+  KH_LAUNDER_FB(u.feps_b.p); KH_LAUNDER_FB(u.feps_e.p); KH_LAUNDER_FB(u.femit_b.p); KH_LAUNDER_FB(u.femit_e.p); KH_LAUNDER_FB(u.frame_b.p); KH_LAUNDER_FB(u.frame_e.p);
   const float inf = INFINITY, lb = p.lattice_beam;
   const int t = threadIdx.x;
   auto x_lo = LdsVals(sh);
