@@ -231,11 +231,13 @@ __device__ __forceinline__ double BlockSumD(double v, double *red) {
 // two sums in one round (their shuffles interleave: a solve is a chain of these)
 template <int kNW = 4>
 __device__ __forceinline__ void BlockSum2D(double &a, double &b, double *red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    b += __shfl_xor(b, o, 64);
-  }
+  // (the same butterfly as before, lane exchanges on DPP / ds_swizzle: kh_common.h)
+  a += kh_lane_xor_d<32>(a); b += kh_lane_xor_d<32>(b);
+  a += kh_lane_xor_d<16>(a); b += kh_lane_xor_d<16>(b);
+  a += kh_lane_xor_d<8>(a);  b += kh_lane_xor_d<8>(b);
+  a += kh_lane_xor_d<4>(a);  b += kh_lane_xor_d<4>(b);
+  a += kh_lane_xor_d<2>(a);  b += kh_lane_xor_d<2>(b);
+  a += kh_lane_xor_d<1>(a);  b += kh_lane_xor_d<1>(b);
   __syncthreads();
   if ((threadIdx.x & 63) == 0 && threadIdx.x < 64 * kNW) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
   __syncthreads();
