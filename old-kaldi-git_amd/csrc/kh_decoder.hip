@@ -274,6 +274,10 @@ struct Params {
   // 1: the reference's iteration order is reproduced (HashList order, running next_cutoff, first-minimum tie, the LIFO
   // order of the epsilon closure's insertions) - see "exact reference order" below; the kernels are instantiated for it
   int32_t exact_order;
+  // epsilon closure in LDS (ClosureLds): entries its table may take (<= kClMaxLoad; 0 = every frame takes the general
+  // routine).  KH_DECODER_CLOSURE_CAP lowers it: the tests run whole suites through the general routine (0) and through
+  // tables that fill up on the way (a handful of entries).
+  int32_t cl_max_load;
   float hash_ratio;
   float beam, lattice_beam, beam_delta, prune_scale;
   int32_t max_active, min_active, prune_interval;
@@ -343,7 +347,7 @@ __device__ __forceinline__ void Launder(Utt &u) {
 __device__ __forceinline__ void Launder(Params &p) {
   KH_LAUNDER(p.rec.p); KH_LAUNDER(p.n_arcs.p); KH_LAUNDER(p.unit_ilabel.p);
   KH_LAUNDER(p.start); KH_LAUNDER(p.num_units); KH_LAUNDER(p.num_eps); KH_LAUNDER(p.start_has_eps); KH_LAUNDER(p.ll_cols);
-  KH_LAUNDER(p.keep_ac); KH_LAUNDER(p.max_tid); KH_LAUNDER(p.lazy_prune); KH_LAUNDER(p.exact_order);
+  KH_LAUNDER(p.keep_ac); KH_LAUNDER(p.max_tid); KH_LAUNDER(p.lazy_prune); KH_LAUNDER(p.exact_order); KH_LAUNDER(p.cl_max_load);
   KH_LAUNDER(p.hash_ratio); KH_LAUNDER(p.beam); KH_LAUNDER(p.lattice_beam); KH_LAUNDER(p.beam_delta); KH_LAUNDER(p.prune_scale);
   KH_LAUNDER(p.max_active); KH_LAUNDER(p.min_active); KH_LAUNDER(p.prune_interval);
 }
@@ -438,6 +442,10 @@ struct Shared {
   int x_ne_emit;        // end of the tokens the emitting pass created (the closure's follow)
   int x_eps_emit;       // entries of tmp_epslist the emitting pass made
   int x_n_new;          // closure replay: insertions counted
+  // epsilon closure in LDS (ClosureLds)
+  int erel_n;           // entries of the frame's list of epsilon-relevant tokens (pass 2 appends; tmp_work0 / tmp_work1)
+  int cl_n;             // entries of the LDS closure table
+  int hash_dirty;       // 1: the global hash holds entries of the frontier (frames that took the general closure path)
 };
 
 // Per-thread view of the workgroup state: the LDS block plus the (uniform)
@@ -681,6 +689,28 @@ __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
 #pragma unroll
   for (int i = 0; i < NW; i++) r += static_cast<long long>(sh->wred[buf][i]);
   return Uni(r);
+}
+
+// sum of an int and minimum of a float over the workgroup: ONE barrier for both
+__device__ __forceinline__ void BlockSumMinF(int v, float m, int *sum, float *mn, Blk &sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int inc = WaveIncSum(v);
+  const float im = WaveIncMinF(m);
+  const int b1 = (sh.k_scan++) & 1, b2 = (sh.k_red++) & 1;
+  if (lane == 63) {
+    sh->wsum[b1][w] = inc;
+    sh->wred[b2][w] = __float_as_uint(im);
+  }
+  KhSync();
+  int all = 0;
+  float am = INFINITY;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    all += sh->wsum[b1][i];
+    am = fminf(am, __uint_as_float(static_cast<uint32_t>(sh->wred[b2][i])));
+  }
+  *sum = Uni(all);
+  *mn = Uni(am);
 }
 
 // OR over the workgroup.  Slot k is reset two calls ahead (by thread 0, before the
@@ -1080,13 +1110,18 @@ struct Cutoff {
   float cur_cutoff, adaptive_beam, best_cost;
   int best_tok, count;
   int32_t best_state;   // canonical rule only: the best token's HCLG state (it is part of the reduction key)
+  float est_min;        // canonical rule only: min over the best token's arcs of (w + (cost_offset - ll)) + tot_cost (:692-704 without the beam)
+  bool has_est;
 };
 
 // GetCutoff :591-658 over the tokens [b, e) of the current frame.  kExact: the best token on a tie is the FIRST one
 // in the reference's list order (the strict '<' of :599 / :611), else the one with the smallest state id (rule B).
-template <bool kExact = false>
-__device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh) {
+struct NoEst { __device__ float operator()(int32_t, float) const { return INFINITY; } };
+template <bool kExact = false, class EstFn = NoEst>
+__device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh, EstFn est_fn = EstFn()) {
   Cutoff c;
+  c.est_min = INFINITY;
+  c.has_est = false;
   Arr<uint32_t> g_cost = u.tok_cost;
   Arr<int32_t> g_state = u.tok_state;
   KH_LAUNDER_GC(g_cost.p); KH_LAUNDER_GC(g_state.p);
@@ -1127,9 +1162,19 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
     c.best_state = static_cast<int32_t>(static_cast<uint32_t>(best));
   }
   const float best_weight = c.best_cost;
+  // Canonical rule: the estimate from the best token's arcs (:692-704) is requested NOW, together with the sweep that
+  // counts the tokens under the beam, and its minimum shares that count's barrier (min(x) + beam = min(x + beam) in
+  // floats: the beam is added by the caller) - one barrier and one exposed round trip less per frame than
+  // "cutoff, then estimate".
+  float est_mine = INFINITY;
+  if (!kExact) {
+    est_mine = est_fn(c.best_state, c.best_cost);
+    c.has_est = true;
+  }
   if (p.max_active == 0x7fffffff && p.min_active == 0) {
     c.adaptive_beam = p.beam;
     c.cur_cutoff = best_weight + p.beam;
+    if (!kExact) c.est_min = BlockMinF(est_mine, sh);
     return c;
   }
   const float beam_cutoff = best_weight + p.beam;
@@ -1142,7 +1187,8 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   {
     const uint32_t bc = Enc(beam_cutoff);
     for (int i = b + threadIdx.x; i < e; i += NT) within += LoadCostEnc(&g_cost[i]) <= bc ? 1 : 0;
-    within = static_cast<int>(BlockSumLL(within, sh));
+    if (kExact) within = static_cast<int>(BlockSumLL(within, sh));
+    else BlockSumMinF(within, est_mine, &within, &c.est_min, sh);
   }
   // largest cost image of the frame (the smallest is the best cost): bounds the bits the selection looks at
   const uint32_t kmin = static_cast<uint32_t>(best >> 32);
@@ -1175,10 +1221,271 @@ __device__ __forceinline__ float LogLike(const Utt &u, const Params &p, const Bl
   return u.ll[static_cast<size_t>(frame) * u.ll_stride + pdf];
 }
 
+// ---------------------------------------------------------------- epsilon closure in LDS
+// ProcessNonemitting + the frame's epsilon links without a global atomic.  The closure of an HCLG frame touches a few
+// hundred tokens (the benchmark: 330 tokens with epsilon arcs, 32 created by the closure, 328 link slots per frame), but
+// the general routine below pays ~8 DEPENDENT L2 / memory round trips per round for them - queued flag (atomic), cost,
+// state, record header, arcs, hash compare-and-swap, cost minimum (memory-side atomic), queue flag - 2.5 rounds per
+// frame: 12 % of the kernel.  Here the tokens the closure can touch (listed by pass 2: those with epsilon arcs and those
+// on states that epsilon arcs lead to) go into an LDS table {state + flags, cost image, token, epsilon arc range}; the
+// rounds run on the table - one read-only gather of the arcs per round is the only memory access - with work lists and
+// queued flags in LDS; new tokens get their arena index from the LDS counter as before; when the fixed point is reached
+// the costs and the new tokens are written back with plain stores and the links are made from the table.  The fixed
+// point is the least one, whatever the schedule: costs, token set and links equal the general routine's.  A frame whose
+// list does not fit (or a table that fills up on the way: nothing has been written to memory by then) takes the general
+// routine.  The global hash is not used by such a frame at all: no ClearHash, no hash slot per token.
+constexpr int kClSlots = 2048, kClMaxLoad = 1300, kClList = 2048;
+constexpr uint32_t kClQueued = 0x80000000u, kClUnknown = 0xFFFFFFFFu;
+typedef __attribute__((address_space(3))) uint32_t *LdsU32;
+typedef __attribute__((address_space(3))) uint16_t *LdsU16;
+struct ClTab {
+  LdsU32 key, cost, idx, rng;   // [kClSlots]: state + flags + 1 (0 = empty) | Enc(cost) | token - frontier begin (+ queued bit) | epsilon arcs: first << 7 | count (127 = read the header)
+  LdsU16 l0, l1;                // [kClList] work lists (slots), double buffered
+};
+static_assert(4 * kClSlots <= kLdsSlots && 2 * kClList * sizeof(uint16_t) <= sizeof(unsigned int) * (1 << 11), "closure table over the token table's values, work lists over the histogram");
+__device__ __forceinline__ ClTab ClLayout(const Blk &sh) {
+  ClTab t;
+  LdsU32 v = (LdsU32)LdsVals(sh);
+  t.key = v; t.cost = v + kClSlots; t.idx = v + 2 * kClSlots; t.rng = v + 3 * kClSlots;
+  LdsU16 h = (LdsU16)LdsKeys(sh);
+  t.l0 = h; t.l1 = h + kClList;
+  return t;
+}
+// slot of `key` (inserted if absent: *inserted); -1 = the table is full
+__device__ __forceinline__ int ClFindOrAdd(const ClTab &t, uint32_t key, bool *inserted) {
+  uint32_t slot = HashState(static_cast<int32_t>(key)) & (kClSlots - 1);
+#pragma nounroll
+  for (int probes = 0; probes < kClSlots; probes++) {
+    uint32_t seen = 0u;
+    __hip_atomic_compare_exchange_strong(&t.key[slot], &seen, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (seen == 0u) { *inserted = true; return static_cast<int>(slot); }
+    if (seen == key) { *inserted = false; return static_cast<int>(slot); }
+    slot = (slot + 1) & (kClSlots - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ int ClFind(const ClTab &t, uint32_t key) {
+  uint32_t slot = HashState(static_cast<int32_t>(key)) & (kClSlots - 1);
+#pragma nounroll
+  for (int probes = 0; probes < kClSlots; probes++) {
+    const uint32_t seen = t.key[slot];
+    if (seen == key) return static_cast<int>(slot);
+    if (seen == 0u) return -1;
+    slot = (slot + 1) & (kClSlots - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ uint32_t ClPackRange(int ab, int cnt) {
+  return (static_cast<uint32_t>(ab) < (1u << 25)) ? ((static_cast<uint32_t>(ab) << 7) | static_cast<uint32_t>(cnt < 127 ? cnt : 127)) : 127u;
+}
+
+// Returns 1 = done (closure + links of frame `frame`), 0 = not applicable (nothing changed: take the general routine),
+// -1 = failed (sh->status set).
+__device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff, Blk &sh) {
+  const int n_list = Uni(sh->erel_n);
+  if (n_list > p.cl_max_load || p.cl_max_load == 0) return 0;
+  const ClTab t = ClLayout(sh);
+  const int fb = Uni(sh->front_b), tok_end0 = Uni(sh->tok_end);
+  const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
+  for (int i = threadIdx.x; i < kClSlots; i += NT) { t.key[i] = 0u; t.cost[i] = kEncInf; t.idx[i] = 0u; t.rng[i] = kClUnknown; }
+  if (threadIdx.x == 0) { sh->cl_n = n_list; sh->flag = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
+  LdsSync();
+  // ---- the table from the list; the tokens with epsilon arcs are the first work list (:766-767)
+  for (int k = threadIdx.x; k < n_list; k += NT) {
+    const int32_t ns = u.tmp_work0[k];
+    const int idx = u.tmp_work1[k];
+    const uint32_t enc = __float_as_uint(u.tmp_f0[k]);
+    bool ins;
+    const int slot = ClFindOrAdd(t, static_cast<uint32_t>(ns) + 1u, &ins);   // (states are unique within a frame; <= kClMaxLoad entries: never full)
+    t.cost[slot] = enc;
+    uint32_t iv = static_cast<uint32_t>(idx - fb);
+    if ((ns & kHasEps) != 0) {
+      const KhInt4 h = p.rec[ns & kStateMask];
+      t.rng[slot] = ClPackRange(h.y, h.z);
+      iv |= kClQueued;
+      t.l0[__hip_atomic_fetch_add(&sh->wl_n[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = static_cast<uint16_t>(slot);
+    }
+    t.idx[slot] = iv;
+  }
+  LdsSync();
+  // ---- rounds
+  long long my_arcs = 0;
+  for (int r = 0;; r++) {
+    const int n = Uni(sh->wl_n[r % 3]);
+    if (threadIdx.x == 0) sh->wl_n[(r + 2) % 3] = 0;
+    if (n == 0) break;
+    const LdsU16 cur = (r & 1) ? t.l1 : t.l0, nxt = (r & 1) ? t.l0 : t.l1;
+    auto nxt_n = &sh->wl_n[(r + 1) % 3];
+    for (int q = threadIdx.x; q < n; q += NT) {
+      const int s = cur[q];
+      // leave the queue BEFORE reading the cost (a later improvement queues the token again; the LDS unit executes the
+      // workgroup's operations one after the other, so "clear, then read" cannot miss an update that found the flag set)
+      (void)__hip_atomic_fetch_and(&t.idx[s], ~kClQueued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const float cur_cost = Dec(__hip_atomic_load(&t.cost[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (cur_cost > cutoff) continue;  // :779
+      uint32_t rg = t.rng[s];
+      int ab, cnt;
+      if (rg == kClUnknown || (rg & 127u) == 127u) {
+        const KhInt4 h = p.rec[static_cast<int32_t>(t.key[s] - 1u) & kStateMask];
+        ab = h.y;
+        cnt = h.z;
+        if (rg == kClUnknown) t.rng[s] = ClPackRange(ab, cnt);
+      } else {
+        ab = static_cast<int>(rg >> 7);
+        cnt = static_cast<int>(rg & 127u);
+      }
+      for (int j = 0; j < cnt; j++) {
+        const KhInt4 arc = p.n_arcs[ab + j];
+        my_arcs++;
+        const float tot_cost = cur_cost + __int_as_float(arc.z);
+        if (!(tot_cost < cutoff)) continue;  // :794
+        bool ins;
+        const int d = ClFindOrAdd(t, static_cast<uint32_t>(arc.w & (kStateMask | kHasEps | kEpsDst)) + 1u, &ins);
+        if (d < 0) { sh->flag = 1; continue; }
+        if (ins) {
+          const int cn = __hip_atomic_fetch_add(&sh->cl_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cn >= p.cl_max_load) sh->flag = 1;
+          const int idx = __hip_atomic_fetch_add(&sh->tok_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (idx >= tok_limit) sh->status = 1;
+          (void)__hip_atomic_fetch_or(&t.idx[d], static_cast<uint32_t>(idx - fb) & ~kClQueued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const uint32_t enc = Enc(tot_cost);
+        const uint32_t old = __hip_atomic_fetch_min(&t.cost[d], enc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (enc < old && (arc.w & kHasEps) != 0) {   // "changed": new or cheaper -> (re)process the destination
+          const uint32_t was = __hip_atomic_fetch_or(&t.idx[d], kClQueued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((was & kClQueued) == 0u) {
+            const int pos = __hip_atomic_fetch_add(nxt_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pos < kClList) nxt[pos] = static_cast<uint16_t>(d); else sh->flag = 1;
+          }
+        }
+      }
+    }
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
+    LdsSync();
+    if (Uni(sh->flag) != 0 && Uni(sh->status) == 0) {
+      // the table (or a work list) filled up: nothing has reached memory - undo the token reservations and let the
+      // general routine do the frame
+      LdsSync();
+      if (threadIdx.x == 0) { sh->tok_end = tok_end0; sh->flag = 0; sh->wl_n[0] = sh->eps_n; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
+      LdsSync();
+      return 0;
+    }
+    if (Uni(sh->status) != 0) return -1;
+  }
+  LdsSync();
+  // ---- write back: final costs; the tokens the closure created (those with epsilon arcs join tmp_epslist)
+  for (int s = threadIdx.x; s < kClSlots; s += NT) {
+    const uint32_t key = t.key[s];
+    if (key == 0u) continue;
+    const int32_t ns = static_cast<int32_t>(key - 1u);
+    const int i = fb + static_cast<int>(t.idx[s] & ~kClQueued);
+    u.tok_cost[i] = t.cost[s];
+    if (i >= tok_end0) {
+      u.tok_state[i] = ns & kStateMask;
+      u.tok_extra[i] = 0.0f;  // :241
+      if ((ns & kHasEps) != 0) u.tmp_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = i;
+    }
+  }
+  Stamp(u, sh, 3);
+  // ---- epsilon links {(tok, arc): cost[tok] <= cutoff}: one slot per epsilon arc of every token under the cutoff, a
+  // token's slots consecutive and in arc order; the slots whose tot_cost is not under the cutoff stay dead (dst = -1)
+  const int blk_b = Uni(sh->link_end);
+  const int limit = min(u.link_cap, blk_b + u.link_frame_cap);
+  if (threadIdx.x == 0) sh->link_cursor = blk_b;
+  LdsSync();
+  for (int s0 = 0; s0 < kClSlots; s0 += NT) {   // (uniform: the wave scan involves every lane)
+    const int s = s0 + threadIdx.x;
+    const uint32_t key = t.key[s];
+    const float cost = Dec(t.cost[s]);
+    int ab = 0, cnt = 0;
+    if (key != 0u && (static_cast<int32_t>(key - 1u) & kHasEps) != 0 && !(cost > cutoff)) {
+      const uint32_t rg = t.rng[s];
+      if (rg == kClUnknown || (rg & 127u) == 127u) {
+        const KhInt4 h = p.rec[static_cast<int32_t>(key - 1u) & kStateMask];
+        ab = h.y;
+        cnt = h.z;
+      } else {
+        ab = static_cast<int>(rg >> 7);
+        cnt = static_cast<int>(rg & 127u);
+      }
+    }
+    const int inc = WaveIncSum(cnt);
+    const int total = WaveLast(inc);
+    if (total == 0) continue;   // (uniform over the wave)
+    const int base = WaveLdsFetchAdd(&sh->link_cursor, total);
+    if (base + total > limit) {
+      if ((threadIdx.x & 63) == 0) sh->status = (base + total > u.link_cap) ? 2 : 3;
+      continue;
+    }
+    const int src = fb + static_cast<int>(t.idx[s] & ~kClQueued);
+    int l = base + inc - cnt;
+    for (int j = 0; j < cnt; j++, l++) {
+      const int ai = ab + j;
+      const KhInt4 arc = p.n_arcs[ai];
+      const float g = __int_as_float(arc.z), tot_cost = cost + g;
+      int dst = -1;
+      float k = 0.0f;
+      if (tot_cost < cutoff) {  // the token exists
+        const int d = ClFind(t, static_cast<uint32_t>(arc.w & (kStateMask | kHasEps | kEpsDst)) + 1u);
+        if (d >= 0) {
+          dst = fb + static_cast<int>(t.idx[d] & ~kClQueued);
+          // the constant part of link_extra_cost (:309-311), (cost[src] + 0 + g) - cost[dst]: both costs are final
+          k = (cost + 0.0f + g) - Dec(t.cost[d]);
+        }
+      }
+      u.link_dst[l] = dst;
+      u.link_src[l] = src;
+      u.link_arc[l] = -1 - ai;
+      u.link_k[l] = k;
+    }
+  }
+  KhSync();
+  if (Uni(sh->status) != 0) return -1;
+  const long long tot_arcs = BlockSumLL(my_arcs, sh);
+  if (threadIdx.x == 0) {
+    sh->link_end = sh->link_cursor;
+    sh->arcs_expanded += tot_arcs;
+    u.feps_b[frame] = blk_b;
+    u.feps_e[frame] = sh->link_end;
+  }
+  KhSync();
+  Stamp(u, sh, 4);
+  return 1;
+}
+
+// A frame that does not take ClosureLds: what pass 2 no longer does for the general routine - the listed tokens on
+// epsilon-destination states enter the global hash, every frontier token gets its hash slot (-1 = none) for ClearHash,
+// and the tokens with epsilon arcs are marked queued.
+__device__ void ClosureGeneralPrep(const Utt &u, Blk &sh) {
+  const int fb = Uni(sh->front_b), fe = Uni(sh->tok_end), n_list = Uni(sh->erel_n);
+  for (int i = fb + threadIdx.x; i < fe; i += NT) u.tmp_slot[i - fb] = -1;
+  if (threadIdx.x == 0) sh->hash_dirty = 1;
+  KhSync();
+  for (int k = threadIdx.x; k < n_list; k += NT) {
+    const int32_t ns = u.tmp_work0[k];
+    const int idx = u.tmp_work1[k];
+    if ((ns & kHasEps) != 0) u.tmp_dirty[idx - fb] = 1;
+    if ((ns & kEpsDst) != 0) {
+      const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
+                                      (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
+      uint32_t g = HashState(ns & kStateMask) & u.hash_mask;
+#pragma nounroll
+      for (int probes = 0; probes < (1 << 30); probes++) {
+        unsigned long long ent = kEmpty;
+        __hip_atomic_compare_exchange_strong(&u.hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ent == kEmpty) break;
+        g = (g + 1) & u.hash_mask;
+      }
+      u.tmp_slot[idx - fb] = static_cast<int32_t>(g);
+    }
+  }
+  KhSync();
+}
+
 // ProcessNonemitting :752-812 on the tokens of the frame under construction
 // ([sh->front_b, sh->tok_end)), then generation of the epsilon links with the
 // converged costs.  Returns false on arena overflow.
-__device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int frame, float cutoff, Blk &sh) {
+__device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int frame, float cutoff, Blk &sh, bool from_list = true) {
   // the phase's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
   Utt u = u_in;
   Params p = p_in;
@@ -1187,6 +1494,15 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
   KH_LAUNDER_NE(u.hash.p); KH_LAUNDER_NE(u.hash_mask);
   KH_LAUNDER_NE(u.link_dst.p); KH_LAUNDER_NE(u.link_src.p); KH_LAUNDER_NE(u.link_arc.p); KH_LAUNDER_NE(u.link_k.p);
   KH_LAUNDER_NE(p.rec.p); KH_LAUNDER_NE(p.n_arcs.p);
+  KH_LAUNDER_NE(u.feps_b.p); KH_LAUNDER_NE(u.feps_e.p); KH_LAUNDER_NE(u.tmp_f0.p);
+  if (from_list) {   // (false: frame 0, whose start token DecodeInit entered in the global hash itself)
+#ifndef KH_NO_LDS_CLOSURE
+    const int rc = ClosureLds(u, p, frame, cutoff, sh);
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[rc != 0 ? 38 : 39] += 1;
+    if (rc != 0) return rc > 0;
+#endif
+    ClosureGeneralPrep(u, sh);
+  }
   const int fb = Uni(sh->front_b);
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
   // ---- cost fixed point: min-plus closure under the cutoff, driven by work lists.
@@ -1329,7 +1645,8 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
 }
 
 // Clears the hash entries of the frontier tokens [fb, fe) (inserted this frame).
-__device__ void ClearHash(const Utt &u, int fb, int fe) {
+__device__ void ClearHash(const Utt &u, int fb, int fe, Blk &sh) {
+  if (Uni(sh->hash_dirty) == 0) return;   // (the frame's closure ran in LDS: the global hash was not touched)
   if (2 * (fe - fb) > static_cast<int>(u.hash_mask >> 2)) {
     // many entries: stream over the whole table (coalesced) instead of one scattered store per token
     for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
@@ -1340,6 +1657,7 @@ __device__ void ClearHash(const Utt &u, int fb, int fe) {
     }
   }
   KhSync();
+  if (threadIdx.x == 0) sh->hash_dirty = 0;
 }
 
 // ---- pass 2 of ProcessEmitting (shared by the canonical and the reference-order sweep): accept `tot_cost <= next_cutoff`
@@ -1360,13 +1678,13 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
   // the pass's own copies of the pointers it uses (see ProcessEmitting) - in the reference-order kernel only:
   // same-box A/B, canonical kernel 691 ms with them / 676 ms without, reference-order kernel 2208 / 2246 ms
   Arr<float> e_k = u.link_k, e_extra = u.tok_extra;
-  Arr<int32_t> e_dst = u.link_dst, e_state = u.tok_state, e_epslist = u.tmp_epslist, e_dirty = u.tmp_dirty, e_slot = u.tmp_slot;
+  Arr<int32_t> e_dst = u.link_dst, e_state = u.tok_state, e_epslist = u.tmp_epslist, e_work0 = u.tmp_work0, e_work1 = u.tmp_work1;
   Arr<uint32_t> e_cost = u.tok_cost;
-  Arr<unsigned long long> e_hash = u.hash;
-  uint32_t e_hmask = u.hash_mask;
+  Arr<float> e_f0 = u.tmp_f0;
   if constexpr (kLocal) {
+    KH_LAUNDER_P2(e_f0.p);
     KH_LAUNDER_P2(e_k.p); KH_LAUNDER_P2(e_extra.p); KH_LAUNDER_P2(e_dst.p); KH_LAUNDER_P2(e_state.p); KH_LAUNDER_P2(e_epslist.p);
-    KH_LAUNDER_P2(e_dirty.p); KH_LAUNDER_P2(e_slot.p); KH_LAUNDER_P2(e_cost.p); KH_LAUNDER_P2(e_hash.p); KH_LAUNDER_P2(e_hmask);
+    KH_LAUNDER_P2(e_work0.p); KH_LAUNDER_P2(e_work1.p); KH_LAUNDER_P2(e_cost.p);
   }
   auto keys = LdsKeys(sh);
   auto vals = LdsVals(sh);
@@ -1492,29 +1810,23 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
       const int idx = tok_base + off[j];
       e_state[idx] = ns & kStateMask;
-      e_cost[idx] = vals[i];
+      const uint32_t cost_enc = vals[i];
+      e_cost[idx] = cost_enc;
       e_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
       vals[i] = static_cast<uint32_t>(idx);
-      if ((ns & kHasEps) != 0) {
-        // these tokens are the closure's first work list (every one has a finite cost)
-        e_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
-        e_dirty[idx - nb] = 1;
+      // these tokens are the closure's first work list (every one has a finite cost)
+      if ((ns & kHasEps) != 0) e_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+      // The tokens the epsilon closure can touch - those with epsilon arcs and those whose state is the destination of
+      // one - are LISTED (state + flags, token); the closure builds its LDS table from the list (ClosureLds), or, for the
+      // rare frame that does not fit it, enters them in the global hash first (ClosureGeneralPrep).  Rounds 2-4 entered the
+      // kEpsDst tokens in the global hash here: a memory-side compare-and-swap per token on the pass's critical path,
+      // plus the hash slot and the queued flag of EVERY new token written for ClearHash / the work lists.
+      if ((ns & (kHasEps | kEpsDst)) != 0) {
+        const int k = __hip_atomic_fetch_add(&sh->erel_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        e_work0[k] = ns;
+        e_work1[k] = idx;
+        e_f0[k] = __uint_as_float(cost_enc);   // (the cost image, bit for bit: saves the closure a dependent gather)
       }
-      int32_t gslot = -1;
-      if ((ns & kEpsDst) != 0) {  // the closure may look this state up: enter it in the global table
-        const unsigned long long want = static_cast<unsigned long long>(static_cast<uint32_t>(ns & kStateMask) + 1u) |
-                                        (static_cast<unsigned long long>(static_cast<uint32_t>(idx) + 1u) << 32);
-        uint32_t g = HashState(ns & kStateMask) & e_hmask;
-        #pragma nounroll
-        for (int probes = 0; probes < (1 << 30); probes++) {
-          unsigned long long ent = kEmpty;
-          __hip_atomic_compare_exchange_strong(&e_hash[g], &ent, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (ent == kEmpty) break;
-          g = (g + 1) & e_hmask;
-        }
-        gslot = static_cast<int32_t>(g);
-      }
-      e_slot[idx - nb] = gslot;
     }
     if (threadIdx.x == 0) sh->tok_end = tok_base + total;
     KhSync();
@@ -1578,26 +1890,20 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
                                 float *next_cutoff_out, int *cand_out, Blk &sh) {
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
   // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
   // against the last readers of the previous row and the first readers of this one)
   for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
   Stamp(u, sh, 15);
-  const Cutoff c = GetCutoff(u, p, b, e, sh);
-  Stamp(u, sh, 0);
-  if (threadIdx.x == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
   const float inf = INFINITY;
-  float cost_offset = 0.0f;
-  float est = inf;
-  if (c.best_tok >= 0) {
-    cost_offset = -c.best_cost;  // :691
-    // :692-704 estimate from the best token's arcs (different association order
-    // from the main loop: ((w + (offset - ll)) + tot_cost) + adaptive_beam)
-    const int32_t s = c.best_state;
-    const float tot = c.best_cost;
-    // The record's header (arc count) and its first 64 arcs are requested TOGETHER - the first wave reads the units
-    // behind the header before it knows how many of them are arcs of this state (they are units of the same table;
-    // the index is clamped to it) - one round trip instead of two dependent ones in front of the frame's expansion.
+  // :692-704 estimate from the best token's arcs (different association order from the main loop:
+  // ((w + (offset - ll)) + tot_cost) + adaptive_beam; the beam is added below).  Runs inside GetCutoff, as soon as the
+  // best token is known.  The record's header (arc count) and its first 64 arcs are requested TOGETHER - the first
+  // wave reads the units behind the header before it knows how many of them are arcs of this state (they are units of
+  // the same table; the index is clamped to it) - one round trip instead of two dependent ones.
+  auto est_fn = [&](int32_t s, float tot) -> float {
+    const float off = -tot;   // cost_offset :691
+    float m = inf;
     const int ab = s + 1;
     const int a0 = ab + threadIdx.x;
     KhInt4 arc0;
@@ -1605,17 +1911,21 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     if (threadIdx.x < 64) arc0 = p.rec[min(a0, p.num_units - 1)];
     const int ae = ab + p.rec[s].x;
     if (threadIdx.x < 64 && a0 < ae) {
-      const float w = __int_as_float(arc0.z) + (cost_offset - LogLike(u, p, sh, frame, arc0.x));   // {pdf, olabel, weight, nextstate}
-      const float new_weight = w + tot;
-      est = fminf(est, new_weight + c.adaptive_beam);
+      const float w = __int_as_float(arc0.z) + (off - LogLike(u, p, sh, frame, arc0.x));   // {pdf, olabel, weight, nextstate}
+      m = fminf(m, w + tot);
     }
     for (int a = a0 + (threadIdx.x < 64 ? NT : 0); a < ae; a += NT) {
       const KhInt4 arc = p.rec[a];
-      const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
-      const float new_weight = w + tot;
-      est = fminf(est, new_weight + c.adaptive_beam);
+      const float w = __int_as_float(arc.z) + (off - LogLike(u, p, sh, frame, arc.x));
+      m = fminf(m, w + tot);
     }
-  }
+    return m;
+  };
+  const Cutoff c = GetCutoff<false>(u, p, b, e, sh, est_fn);
+  Stamp(u, sh, 0);
+  if (threadIdx.x == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
+  float cost_offset = 0.0f;
+  if (c.best_tok >= 0) cost_offset = -c.best_cost;  // :691
   if (threadIdx.x == 0) u.cost_offset[frame] = cost_offset;  // :710-711
 
   // ---- pass 1: the emitting arcs of every token under cur_cutoff (token sweep + scan, then
@@ -1623,8 +1933,8 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // min(tot_cost + adaptive_beam) and materialises the candidates that can still be accepted.
   // est0 = the estimate from the best token's arcs (:692-704) is an upper bound of the final
   // next_cutoff, so a candidate above it is rejected whatever the rest of the frame holds.
-  const float est0 = BlockMinF(est, sh);
-  est = est0;
+  const float est0 = c.best_tok >= 0 ? c.est_min + c.adaptive_beam : inf;   // (min(x) + beam = min(x + beam))
+  float est = est0;
   float bound = est0;  // upper bound of the final next_cutoff; tightens as the sweep proceeds
   const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
@@ -2145,7 +2455,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   const int n = e - b;
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; }
+  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }
   for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff<true>(u, p, b, e, sh);
@@ -3432,6 +3742,8 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   KhSync();
   if (threadIdx.x == 0) {
     sh->eps_n = 0;
+    sh->erel_n = 0;
+    sh->hash_dirty = 1;
     const int idx = FindOrAdd<true>(u, p.start, p.start_has_eps != 0, &sh->tok_end, &sh->eps_n, u.tok_cap, 0);
     u.tok_cost[idx] = Enc(0.0f);
     u.frame_b[0] = idx;
@@ -3447,7 +3759,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     }
   }
   KhSync();
-  bool ok = ProcessNonemitting(u, p, 0, p.beam, sh);
+  bool ok = ProcessNonemitting(u, p, 0, p.beam, sh, false);
   if (kExact && ok) ok = OrderFrontier(u, p, 0, Uni(sh->tok_end), Uni(u.feps_b[0]), Uni(u.feps_e[0]), p.beam, sh);
   run->t = 0;
   run->cand = 0;
@@ -3458,7 +3770,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->tokens_created += run->fe - run->fb;
     if (run->fe > sh->tok_hw) sh->tok_hw = run->fe;
   }
-  if (ok) ClearHash(u, run->fb, run->fe);
+  if (ok) ClearHash(u, run->fb, run->fe, sh);
   return ok;
 }
 
@@ -3534,7 +3846,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       if (fe > sh->tok_hw) sh->tok_hw = fe;
     }
     Stamp(u, sh, 15);
-    ClearHash(u, fb, fe);
+    ClearHash(u, fb, fe, sh);
     Stamp(u, sh, 5);
   }
   run->t = t;
@@ -3813,6 +4125,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     sh->t_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->tok_hw = 0;
     for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
+    sh->hash_dirty = 0;
 #ifdef KH_BARRIER_CHECK
     for (int i = 0; i < 16; i++) __hip_atomic_store(&g_bar_cnt[blockIdx.x * 16 + i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -3935,6 +4248,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
   if (threadIdx.x == 0) {
     for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
     for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
+    sh->hash_dirty = 0;
   }
   KhSync();
   Run run;
@@ -4066,6 +4380,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   if (threadIdx.x == 0) {
     for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
     for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
+    sh->hash_dirty = 0;
   }
   KhSync();
   Run run;
@@ -5015,6 +5330,8 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.lazy_prune = 0;
   p.exact_order = 0;
   p.hash_ratio = d->cfg.hash_ratio;
+  p.cl_max_load = kClMaxLoad;
+  if (const char *e = getenv("KH_DECODER_CLOSURE_CAP")) p.cl_max_load = std::max(0, std::min(kClMaxLoad, atoi(e)));
   if (getenv("KH_DECODER_NO_LDS_SCORES")) p.ll_cols = 0;
   p.max_tid = d->fst->max_ilabel;
   p.beam = d->cfg.beam;
@@ -5155,9 +5472,10 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
           NT, tot[6] ? 100.0 * tot[20] / tot[6] : 0.0, tot[6] ? 100.0 * tot[21] / tot[6] : 0.0,
           tot[6] ? 100.0 * tot[22] / tot[6] : 0.0, tot[6] ? 100.0 * tot[23] / tot[6] : 0.0);
   fprintf(stderr, "[kh_decoder profile] eps closure (thread 0), share of its cycles: list/flag/cost/state/offsets %.1f%%, arcs + wave combine %.1f%%, "
-          "FindOrAdd + min + queue %.1f%%, round barrier %.1f%%; tokens processed per round %.1f\n",
+          "FindOrAdd + min + queue %.1f%%, round barrier %.1f%%; tokens processed per round %.1f; frames whose closure ran in LDS %lld, "
+          "through the general routine %lld\n",
           tot[3] ? 100.0 * tot[27] / tot[3] : 0.0, tot[3] ? 100.0 * tot[28] / tot[3] : 0.0, tot[3] ? 100.0 * tot[29] / tot[3] : 0.0,
-          tot[3] ? 100.0 * tot[30] / tot[3] : 0.0, tot[13] ? double(tot[33]) / tot[13] : 0.0);
+          tot[3] ? 100.0 * tot[30] / tot[3] : 0.0, tot[13] ? double(tot[33]) / tot[13] : 0.0, tot[38], tot[39]);
   fprintf(stderr, "[kh_decoder profile] emitting pass: %lld candidates materialised (%lld counted as accepted in the frames with more than 11000)\n", tot[31], tot[32]);
   fprintf(stderr, "[kh_decoder profile] compaction, share of its cycles: tokens %.1f%%, +inf fill and boundary links %.1f%%, links %.1f%%\n",
           tot[7] ? 100.0 * tot[24] / tot[7] : 0.0, tot[7] ? 100.0 * tot[25] / tot[7] : 0.0, tot[7] ? 100.0 * tot[26] / tot[7] : 0.0);

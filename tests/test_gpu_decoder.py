@@ -126,6 +126,23 @@ def test_epsilon_heavy_graph(api):
     run_case(api, g, lls, api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
 
 
+@pytest.mark.parametrize("cap", ["0", "3", "40"])
+def test_epsilon_closure_paths(api, monkeypatch, cap):
+    """The epsilon closure runs in an LDS table when the frame's epsilon-relevant tokens fit it (ClosureLds,
+    csrc/kh_decoder.hip) and through the general routine (global hash, memory atomics) otherwise.
+    KH_DECODER_CLOSURE_CAP = 0: every frame takes the general routine; 3 / 40: the list does not fit, or the table fills
+    up while the closure runs and the frame is done again by the general routine.  Bit-exact against the oracle either
+    way (and therefore equal to the default path, which the other tests of this file run)."""
+    monkeypatch.setenv("KH_DECODER_CLOSURE_CAP", cap)
+    rng = np.random.default_rng(61)
+    g = graph_like_hclg(rng, 8000, 80, eps_frac=0.45, mean_degree=3.5)
+    lls = [workloads.make_loglikes(rng, T, 80) for T in (64, 9)]
+    run_case(api, g, lls, api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
+    g = graph_like_hclg(rng, 3000, 40, eps_frac=0.2)
+    lls = [workloads.make_loglikes(rng, 50, 40)]
+    run_case(api, g, lls, api.decoder_config(beam=9.0, max_active=800, min_active=20, lattice_beam=5.0, prune_interval=7))
+
+
 def test_config_check_rejects_bad_options(api):
     rng = np.random.default_rng(7)
     fst = api.Fst(graph_like_hclg(rng, 20, 5))
@@ -392,6 +409,8 @@ def test_random_configurations(api, seed, monkeypatch):
                              prune_scale=float(rng.choice([0.05, 0.1, 0.5])))
     if rng.random() < 0.5:
         monkeypatch.setenv("KH_DECODER_SLOTS", str(int(rng.integers(1, 4))))
+    if seed % 3 == 2:   # (drawn from the seed, not from rng: the cases of the other seeds stay what they were)
+        monkeypatch.setenv("KH_DECODER_CLOSURE_CAP", str([0, 2, 25][(seed // 3) % 3]))
     # Against the reference-ORDER oracle only where its order dependence is bounded: a
     # max_active of a handful of tokens makes the running cutoff (DESIGN.md "Decoder
     # parity") decide most of the search, best path included.

@@ -82,6 +82,19 @@ def test_min_active_prune_interval_no_final_eps_heavy(api):
     run_exact(api, g, [workloads.make_loglikes(rng, 64, 80)], api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
 
 
+@pytest.mark.parametrize("cap", ["0", "3", "40"])
+def test_epsilon_closure_paths_in_reference_order(api, monkeypatch, cap):
+    """The general closure routine (KH_DECODER_CLOSURE_CAP=0) and LDS tables that fill up on the way (3, 40) under the
+    reference's order: the replay of the LIFO queue reads what either path leaves behind (tmp_epslist, the frame's
+    epsilon links in arc order per source token, the costs before and after the closure)."""
+    monkeypatch.setenv("KH_DECODER_CLOSURE_CAP", cap)
+    rng = np.random.default_rng(6)
+    g = graph_like_hclg(rng, 8000, 80, eps_frac=0.45, mean_degree=3.5)
+    run_exact(api, g, [workloads.make_loglikes(rng, T, 80) for T in (64, 11)], api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
+    g = graph_like_hclg(rng, 20000, 200, eps_frac=0.2)
+    run_exact(api, g, [workloads.make_loglikes(rng, 70, 200)], api.decoder_config(beam=12.0, max_active=900, min_active=100, lattice_beam=6.0, prune_interval=10))
+
+
 def test_interval_schedule_and_small_slots(api, monkeypatch):
     """The periodic pruning schedule and slot reuse (more utterances than slots) in reference order."""
     rng = np.random.default_rng(8)
@@ -116,6 +129,8 @@ def test_random_configurations(api, seed, monkeypatch):
                              hash_ratio=float(rng.choice([1.0, 2.0, 2.0, 3.5])))
     if rng.random() < 0.5:
         monkeypatch.setenv("KH_DECODER_SLOTS", str(int(rng.integers(1, 4))))
+    if seed % 3 == 1:
+        monkeypatch.setenv("KH_DECODER_CLOSURE_CAP", str([0, 2, 25][(seed // 3) % 3]))
     run_exact(api, g, lls, cfg)
 
 
