@@ -691,40 +691,21 @@ __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
   return Uni(r);
 }
 
-// sum of an int and minimum of a float over the workgroup: ONE barrier for both
-__device__ __forceinline__ void BlockSumMinF(int v, float m, int *sum, float *mn, Blk &sh) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int inc = WaveIncSum(v);
-  const float im = WaveIncMinF(m);
-  const int b1 = (sh.k_scan++) & 1, b2 = (sh.k_red++) & 1;
-  if (lane == 63) {
-    sh->wsum[b1][w] = inc;
-    sh->wred[b2][w] = __float_as_uint(im);
-  }
-  KhSync();
-  int all = 0;
-  float am = INFINITY;
-#pragma unroll
-  for (int i = 0; i < NW; i++) {
-    all += sh->wsum[b1][i];
-    am = fminf(am, __uint_as_float(static_cast<uint32_t>(sh->wred[b2][i])));
-  }
-  *sum = Uni(all);
-  *mn = Uni(am);
-}
-
 // OR over the workgroup.  Slot k is reset two calls ahead (by thread 0, before the
 // barrier of call n it clears the slot of call n + 2): its previous use (call n - 2)
 // was fully read before every thread reached the barrier of call n - 1.
+template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockOr(int bits, Blk &sh) {
   const int k = (sh.k_or++) & 3;
   if (threadIdx.x == 0) sh->orbuf[(k + 2) & 3] = 0;
   if (bits) __hip_atomic_fetch_or(&sh->orbuf[k], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  KhSync();
+  if (kLdsOnly) LdsSync(); else KhSync();
   return Uni(sh->orbuf[k]);
 }
 
 __device__ __forceinline__ bool BlockAny(bool p, Blk &sh) { return BlockOr(p ? 1 : 0, sh) != 0; }
+// (for hand-offs through LDS only: the barrier does not wait for this wave's outstanding stores)
+__device__ __forceinline__ bool BlockAnyLds(bool p, Blk &sh) { return BlockOr<true>(p ? 1 : 0, sh) != 0; }
 
 // Exact k-th smallest (0-based) of the cost images tok_cost[b..e): what
 // std::nth_element yields at position k (GetCutoff :621-626,:633-640).  Radix select
@@ -747,9 +728,15 @@ __device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k, u
     const int bins = 1 << w;
     for (int i = threadIdx.x; i < bins; i += NT) sh->hist[i] = 0;
     KhSync();
-    for (int i = b + threadIdx.x; i < e; i += NT) {
-      const uint32_t key = LoadCostEnc(&keys[i]);
-      if ((key & mask) == prefix) __hip_atomic_fetch_add(&sh->hist[(key >> shift) & dmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    constexpr int kRU = 8;
+    for (int i0 = b + threadIdx.x; i0 < e; i0 += NT * kRU) {
+      uint32_t ks[kRU];
+#pragma unroll
+      for (int k = 0; k < kRU; k++) ks[k] = LoadCostEnc(&keys[min(i0 + k * NT, e - 1)]);
+#pragma unroll
+      for (int k = 0; k < kRU; k++)
+        if (i0 + k * NT < e && (ks[k] & mask) == prefix)
+          __hip_atomic_fetch_add(&sh->hist[(ks[k] >> shift) & dmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     KhSync();
     // the bin that holds rank k: workgroup scan of the counts (lane t owns bins [t kPerLane, (t + 1) kPerLane))
@@ -1025,7 +1012,34 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
   KH_LAUNDER(w_cost.p); KH_LAUNDER(w_state.p);
   KhSync();
   uint32_t my_bound_enc = Enc(*bound);
+#ifndef KH_NO_CLAIM_PREFETCH
+  // A wave always holds its NEXT claim: cursor and the 64 tokens' cost / state are requested while the current claim's
+  // batches run, so a claim starts with the record headers instead of two dependent round trips (554.5 against 557 ms;
+  // no change of the kernel's scratch).
+  int base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
+  uint32_t co_next = 0u;
+  int st_next = 0;
+  if (base_next < e) {
+    const int ic = min(base_next + lane, e - 1);
+    co_next = LoadCostEnc(&w_cost[ic]);
+    st_next = w_state[ic];
+  }
+#endif
   for (;;) {
+#ifndef KH_NO_CLAIM_PREFETCH
+    const int base = base_next;
+    if (base >= e) break;
+    const int i = base + lane;
+    const bool in_range = i < e;
+    const uint32_t co = co_next;
+    int st = st_next;
+    base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
+    if (base_next < e) {
+      const int icn = min(base_next + lane, e - 1);
+      co_next = LoadCostEnc(&w_cost[icn]);
+      st_next = w_state[icn];
+    }
+#else
     const int base = WaveLdsFetchAdd(&sh->work_cursor, 64);
     if (base >= e) break;
     const int i = base + lane;
@@ -1033,6 +1047,7 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     const int ic = min(i, e - 1);
     const uint32_t co = LoadCostEnc(&w_cost[ic]);
     int st = w_state[ic];
+#endif
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= cutoff;
     int ab = 0, cnt = 0;
@@ -1110,18 +1125,13 @@ struct Cutoff {
   float cur_cutoff, adaptive_beam, best_cost;
   int best_tok, count;
   int32_t best_state;   // canonical rule only: the best token's HCLG state (it is part of the reduction key)
-  float est_min;        // canonical rule only: min over the best token's arcs of (w + (cost_offset - ll)) + tot_cost (:692-704 without the beam)
-  bool has_est;
 };
 
 // GetCutoff :591-658 over the tokens [b, e) of the current frame.  kExact: the best token on a tie is the FIRST one
 // in the reference's list order (the strict '<' of :599 / :611), else the one with the smallest state id (rule B).
-struct NoEst { __device__ float operator()(int32_t, float) const { return INFINITY; } };
-template <bool kExact = false, class EstFn = NoEst>
-__device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh, EstFn est_fn = EstFn()) {
+template <bool kExact = false>
+__device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh) {
   Cutoff c;
-  c.est_min = INFINITY;
-  c.has_est = false;
   Arr<uint32_t> g_cost = u.tok_cost;
   Arr<int32_t> g_state = u.tok_state;
   KH_LAUNDER_GC(g_cost.p); KH_LAUNDER_GC(g_state.p);
@@ -1130,13 +1140,25 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   unsigned long long best = ~0ull;
   int best_i = -1;
   uint32_t kmax = 0;
-  for (int i = b + threadIdx.x; i < e; i += NT) {
-    // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
-    const uint32_t enc = LoadCostEnc(&g_cost[i]);
-    const unsigned long long key = (static_cast<unsigned long long>(enc) << 32) |
-                                   static_cast<uint32_t>(kExact ? UX(x_pos)[i - b] : g_state[i]);
-    if (key < best) { best = key; best_i = i; }
-    kmax = enc > kmax ? enc : kmax;
+  // (kGU tokens of a lane in flight together: a plain loop waits for every trip's loads before it issues the next ones)
+  constexpr int kGU = 4;
+  for (int i0 = b + threadIdx.x; i0 < e; i0 += NT * kGU) {
+    uint32_t encs[kGU], lows[kGU];
+#pragma unroll
+    for (int k = 0; k < kGU; k++) {
+      const int i = min(i0 + k * NT, e - 1);
+      encs[k] = LoadCostEnc(&g_cost[i]);
+      lows[k] = static_cast<uint32_t>(kExact ? UX(x_pos)[i - b] : g_state[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < kGU; k++) {
+      const int i = i0 + k * NT;
+      if (i >= e) continue;
+      // (cost image, state): smallest cost, ties -> smallest state id (canonical rule B)
+      const unsigned long long key = (static_cast<unsigned long long>(encs[k]) << 32) | lows[k];
+      if (key < best) { best = key; best_i = i; }
+      kmax = encs[k] > kmax ? encs[k] : kmax;
+    }
   }
   const unsigned long long mine = best;
   best = BlockMinU64(best, sh);
@@ -1162,19 +1184,9 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
     c.best_state = static_cast<int32_t>(static_cast<uint32_t>(best));
   }
   const float best_weight = c.best_cost;
-  // Canonical rule: the estimate from the best token's arcs (:692-704) is requested NOW, together with the sweep that
-  // counts the tokens under the beam, and its minimum shares that count's barrier (min(x) + beam = min(x + beam) in
-  // floats: the beam is added by the caller) - one barrier and one exposed round trip less per frame than
-  // "cutoff, then estimate".
-  float est_mine = INFINITY;
-  if (!kExact) {
-    est_mine = est_fn(c.best_state, c.best_cost);
-    c.has_est = true;
-  }
   if (p.max_active == 0x7fffffff && p.min_active == 0) {
     c.adaptive_beam = p.beam;
     c.cur_cutoff = best_weight + p.beam;
-    if (!kExact) c.est_min = BlockMinF(est_mine, sh);
     return c;
   }
   const float beam_cutoff = best_weight + p.beam;
@@ -1186,9 +1198,15 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   int within = 0;
   {
     const uint32_t bc = Enc(beam_cutoff);
-    for (int i = b + threadIdx.x; i < e; i += NT) within += LoadCostEnc(&g_cost[i]) <= bc ? 1 : 0;
-    if (kExact) within = static_cast<int>(BlockSumLL(within, sh));
-    else BlockSumMinF(within, est_mine, &within, &c.est_min, sh);
+    constexpr int kWU = 8;
+    for (int i0 = b + threadIdx.x; i0 < e; i0 += NT * kWU) {
+      uint32_t encs[kWU];
+#pragma unroll
+      for (int k = 0; k < kWU; k++) encs[k] = LoadCostEnc(&g_cost[min(i0 + k * NT, e - 1)]);
+#pragma unroll
+      for (int k = 0; k < kWU; k++) within += (i0 + k * NT < e && encs[k] <= bc) ? 1 : 0;
+    }
+    within = static_cast<int>(BlockSumLL(within, sh));
   }
   // largest cost image of the frame (the smallest is the best cost): bounds the bits the selection looks at
   const uint32_t kmin = static_cast<uint32_t>(best >> 32);
@@ -1287,7 +1305,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
   const ClTab t = ClLayout(sh);
   const int fb = Uni(sh->front_b), tok_end0 = Uni(sh->tok_end);
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
-  for (int i = threadIdx.x; i < kClSlots; i += NT) { t.key[i] = 0u; t.cost[i] = kEncInf; t.idx[i] = 0u; t.rng[i] = kClUnknown; }
+  for (int i = threadIdx.x; i < kClSlots; i += NT) { t.key[i] = 0u; t.cost[i] = kEncInf; t.idx[i] = 0u; }   // (rng: set by whoever inserts)
   if (threadIdx.x == 0) { sh->cl_n = n_list; sh->flag = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
   LdsSync();
   // ---- the table from the list; the tokens with epsilon arcs are the first work list (:766-767)
@@ -1299,6 +1317,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
     const int slot = ClFindOrAdd(t, static_cast<uint32_t>(ns) + 1u, &ins);   // (states are unique within a frame; <= kClMaxLoad entries: never full)
     t.cost[slot] = enc;
     uint32_t iv = static_cast<uint32_t>(idx - fb);
+    t.rng[slot] = kClUnknown;
     if ((ns & kHasEps) != 0) {
       const KhInt4 h = p.rec[ns & kStateMask];
       t.rng[slot] = ClPackRange(h.y, h.z);
@@ -1347,6 +1366,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
           if (cn >= p.cl_max_load) sh->flag = 1;
           const int idx = __hip_atomic_fetch_add(&sh->tok_end, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (idx >= tok_limit) sh->status = 1;
+          t.rng[d] = kClUnknown;   // (read by the token's own processing only, a barrier from here)
           (void)__hip_atomic_fetch_or(&t.idx[d], static_cast<uint32_t>(idx - fb) & ~kClQueued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         const uint32_t enc = Enc(tot_cost);
@@ -1439,6 +1459,20 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
       u.link_k[l] = k;
     }
   }
+#ifndef KH_CL_BLOCKSUM
+  {  // the arcs visited, for the utterance's counter: one LDS add per wave (no barrier of its own)
+    const long long wave_arcs = WaveSumLLToLast(my_arcs);
+    if ((threadIdx.x & 63) == 63 && wave_arcs != 0)
+      __hip_atomic_fetch_add(&sh->arcs_expanded, wave_arcs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  KhSync();
+  if (Uni(sh->status) != 0) return -1;
+  if (threadIdx.x == 0) {
+    sh->link_end = sh->link_cursor;
+    u.feps_b[frame] = blk_b;
+    u.feps_e[frame] = sh->link_end;
+  }
+#else
   KhSync();
   if (Uni(sh->status) != 0) return -1;
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
@@ -1448,6 +1482,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
     u.feps_b[frame] = blk_b;
     u.feps_e[frame] = sh->link_end;
   }
+#endif
   KhSync();
   Stamp(u, sh, 4);
   return 1;
@@ -1716,8 +1751,16 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
   int parts = 1;
   if (link_frame_e - link_frame_b > KH_PART_CAND) {
     int n_acc_mine = 0;
-    for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT)
-      n_acc_mine += !(e_k[l] > next_cutoff) ? 1 : 0;
+    {
+      constexpr int kCU = 8;   // loads of a lane in flight together (a frame of this size took 11+ dependent round trips here)
+      for (int l0 = link_frame_b + threadIdx.x; l0 < link_frame_e; l0 += NT * kCU) {
+        float ks[kCU];
+#pragma unroll
+        for (int k = 0; k < kCU; k++) ks[k] = e_k[min(l0 + k * NT, link_frame_e - 1)];
+#pragma unroll
+        for (int k = 0; k < kCU; k++) n_acc_mine += (l0 + k * NT < link_frame_e && !(ks[k] > next_cutoff)) ? 1 : 0;
+      }
+    }
     const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
     while (parts * KH_PART_CAND < n_acc) parts *= 2;
     if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
@@ -1731,10 +1774,9 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     // an unresolved one -2 - (next state + flags).  kMU
     // candidates per lane are loaded before any is used (independent loads in flight).
     constexpr int kMU = 4;
-    for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
-      float tc[kMU];
-      int32_t nsv[kMU];
-      if (base + kMU <= link_frame_e) {   // a lane owns kMU = 4 consecutive candidates: one 16-byte load per array
+    // a lane's kMU = 4 consecutive candidates: one 16-byte load per array (element by element, clamped, in the frame's last group)
+    auto load_group = [&](int base, float (&tc)[kMU], int32_t (&nsv)[kMU]) {
+      if (base + kMU <= link_frame_e) {
         const KhFloat4 t4 = Load4F(e_k, base);
         const KhInt4 n4 = Load4I(e_dst, base);
         tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
@@ -1749,6 +1791,25 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
           if (l >= link_frame_e) tc[j] = nan;
         }
       }
+    };
+    // KH_P2_PREFETCH: the NEXT group's loads issued before this group's candidates are inserted (the sweep waits for a
+    // round trip per trip: loads, s_waitcnt, work - ten in a row per part for a 40 k-candidate frame, twice per part).
+    // Measured: 575-581 ms against 558 without - the eight registers of the group in flight push the kernel's scratch
+    // from 144 to 164 bytes per lane, which costs more than the round trips; off by default.
+    float tc[kMU], tc_next[kMU];
+    int32_t nsv[kMU], nsv_next[kMU];
+    {
+      const int base0 = link_frame_b + threadIdx.x * kMU;
+      if (base0 < link_frame_e) load_group(base0, tc, nsv);
+    }
+    for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
+#ifdef KH_P2_PREFETCH
+      const bool more = base + NT * kMU < link_frame_e;
+#else
+      const bool more = false;
+      if (base != link_frame_b + static_cast<int>(threadIdx.x) * kMU) load_group(base, tc, nsv);
+#endif
+      if (more) load_group(base + NT * kMU, tc_next, nsv_next);
 #pragma unroll
       for (int j = 0; j < kMU; j++) {
         const float tot_cost = tc[j];
@@ -1778,6 +1839,10 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         }
         if (probes == 256) { sh->flag = 1; continue; }  // the table is (nearly) full
         (void)__hip_atomic_fetch_min(&vals[slot], Enc(tot_cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < kMU; j++) { tc[j] = tc_next[j]; nsv[j] = nsv_next[j]; }
       }
     }
     KhSync();
@@ -1831,23 +1896,19 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     if (threadIdx.x == 0) sh->tok_end = tok_base + total;
     KhSync();
     // (D) the part's links get their token index; rejected candidates become dead links
+    {
+      const int base0 = link_frame_b + threadIdx.x * kMU;
+      if (base0 < link_frame_e) load_group(base0, tc, nsv);
+    }
     for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
-      float tc[kMU];
-      int32_t nsv[kMU];
       const bool full = base + kMU <= link_frame_e;
-      if (full) {
-        const KhFloat4 t4 = Load4F(e_k, base);
-        const KhInt4 n4 = Load4I(e_dst, base);
-        tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
-        nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < kMU; j++) {
-          const int lc = base + j < link_frame_e ? base + j : link_frame_e - 1;
-          tc[j] = e_k[lc];
-          nsv[j] = e_dst[lc];
-        }
-      }
+#ifdef KH_P2_PREFETCH
+      const bool more = base + NT * kMU < link_frame_e;
+#else
+      const bool more = false;
+      if (base != link_frame_b + static_cast<int>(threadIdx.x) * kMU) load_group(base, tc, nsv);
+#endif
+      if (more) load_group(base + NT * kMU, tc_next, nsv_next);   // (as in (B): the next group's loads under this group's work)
       bool wrote = false;
 #pragma unroll
       for (int j = 0; j < kMU; j++) {
@@ -1877,10 +1938,30 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         o4.x = nsv[0]; o4.y = nsv[1]; o4.z = nsv[2]; o4.w = nsv[3];
         Store4I(e_dst, base, o4);
       }
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < kMU; j++) { tc[j] = tc_next[j]; nsv[j] = nsv_next[j]; }
+      }
     }
     KhSync();
   }
   return true;
+}
+
+// The frame's score row -> LDS with all of a lane's loads in flight together.  (`for (c = t; c < n; c += NT) lds[c] = g[c]`
+// compiles to one load, one s_waitcnt vmcnt(0), one store per trip: six DEPENDENT HBM round trips for a 5800-column row
+// at the head of every frame.  hipcc does not software-pipeline a loop whose trip count it does not know.)
+__device__ __forceinline__ void StageScoreRow(const Utt &u, const Params &p, Blk &sh, int frame) {
+  constexpr int kU = 8;
+  GP(const float) src = u.ll + static_cast<size_t>(frame) * u.ll_stride;
+  for (int c0 = threadIdx.x; c0 < p.ll_cols; c0 += NT * kU) {
+    float v[kU];
+#pragma unroll
+    for (int k = 0; k < kU; k++) v[k] = c0 + k * NT < p.ll_cols ? src[c0 + k * NT] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < kU; k++)
+      if (c0 + k * NT < p.ll_cols) sh.ll_row[c0 + k * NT] = v[k];
+  }
 }
 
 // ProcessEmitting :660-750 for frame `frame` (tokens [b, e) -> new tokens appended
@@ -1893,17 +1974,23 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
   // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
   // against the last readers of the previous row and the first readers of this one)
-  for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
+  StageScoreRow(u, p, sh, frame);
   Stamp(u, sh, 15);
+  const Cutoff c = GetCutoff(u, p, b, e, sh);
+  Stamp(u, sh, 0);
+  if (threadIdx.x == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
   const float inf = INFINITY;
-  // :692-704 estimate from the best token's arcs (different association order from the main loop:
-  // ((w + (offset - ll)) + tot_cost) + adaptive_beam; the beam is added below).  Runs inside GetCutoff, as soon as the
-  // best token is known.  The record's header (arc count) and its first 64 arcs are requested TOGETHER - the first
-  // wave reads the units behind the header before it knows how many of them are arcs of this state (they are units of
-  // the same table; the index is clamped to it) - one round trip instead of two dependent ones.
-  auto est_fn = [&](int32_t s, float tot) -> float {
-    const float off = -tot;   // cost_offset :691
-    float m = inf;
+  float cost_offset = 0.0f;
+  float est = inf;
+  if (c.best_tok >= 0) {
+    cost_offset = -c.best_cost;  // :691
+    // :692-704 estimate from the best token's arcs (different association order
+    // from the main loop: ((w + (offset - ll)) + tot_cost) + adaptive_beam)
+    const int32_t s = c.best_state;
+    const float tot = c.best_cost;
+    // The record's header (arc count) and its first 64 arcs are requested TOGETHER - the first wave reads the units
+    // behind the header before it knows how many of them are arcs of this state (they are units of the same table;
+    // the index is clamped to it) - one round trip instead of two dependent ones in front of the frame's expansion.
     const int ab = s + 1;
     const int a0 = ab + threadIdx.x;
     KhInt4 arc0;
@@ -1911,21 +1998,17 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     if (threadIdx.x < 64) arc0 = p.rec[min(a0, p.num_units - 1)];
     const int ae = ab + p.rec[s].x;
     if (threadIdx.x < 64 && a0 < ae) {
-      const float w = __int_as_float(arc0.z) + (off - LogLike(u, p, sh, frame, arc0.x));   // {pdf, olabel, weight, nextstate}
-      m = fminf(m, w + tot);
+      const float w = __int_as_float(arc0.z) + (cost_offset - LogLike(u, p, sh, frame, arc0.x));   // {pdf, olabel, weight, nextstate}
+      const float new_weight = w + tot;
+      est = fminf(est, new_weight + c.adaptive_beam);
     }
     for (int a = a0 + (threadIdx.x < 64 ? NT : 0); a < ae; a += NT) {
       const KhInt4 arc = p.rec[a];
-      const float w = __int_as_float(arc.z) + (off - LogLike(u, p, sh, frame, arc.x));
-      m = fminf(m, w + tot);
+      const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
+      const float new_weight = w + tot;
+      est = fminf(est, new_weight + c.adaptive_beam);
     }
-    return m;
-  };
-  const Cutoff c = GetCutoff<false>(u, p, b, e, sh, est_fn);
-  Stamp(u, sh, 0);
-  if (threadIdx.x == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
-  float cost_offset = 0.0f;
-  if (c.best_tok >= 0) cost_offset = -c.best_cost;  // :691
+  }
   if (threadIdx.x == 0) u.cost_offset[frame] = cost_offset;  // :710-711
 
   // ---- pass 1: the emitting arcs of every token under cur_cutoff (token sweep + scan, then
@@ -1933,8 +2016,8 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // min(tot_cost + adaptive_beam) and materialises the candidates that can still be accepted.
   // est0 = the estimate from the best token's arcs (:692-704) is an upper bound of the final
   // next_cutoff, so a candidate above it is rejected whatever the rest of the frame holds.
-  const float est0 = c.best_tok >= 0 ? c.est_min + c.adaptive_beam : inf;   // (min(x) + beam = min(x + beam))
-  float est = est0;
+  const float est0 = BlockMinF(est, sh);
+  est = est0;
   float bound = est0;  // upper bound of the final next_cutoff; tightens as the sweep proceeds
   const int link_frame_b = Uni(sh->link_end);
   long long my_arcs = 0;
@@ -2323,13 +2406,32 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     sh->phase[47] += 1; sh->phase[52] += eps_emit; sh->phase[53] += eps_n; sh->phase[54] += nl; sh->phase[55] += fe - ne_emit; sh->phase[46] += n;
   }
   // buckets; first occupation among the emitting pass's tokens; closure replay tables
-  for (int i = nb + threadIdx.x; i < fe; i += NT) {
-    const int32_t sid = -1 - p.unit_ilabel[u.tok_state[i]];   // the caller's state id (what the reference hashes)
-    const int32_t bk = static_cast<int32_t>(static_cast<uint32_t>(sid) % H);
-    UX(x_bkt)[i - nb] = bk;
-    UX(x_epsidx)[i - nb] = -1;
-    if (i < ne_emit) __hip_atomic_fetch_min(&UX(x_bmin)[bk], UX(x_q)[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else UX(x_q)[i - nb] = 0xFFFFFFFFu;
+  {
+    // (kOU tokens of a lane in flight together: the plain loop paid two dependent round trips - state, then the caller's
+    // id - per trip, five trips per frame)
+    constexpr int kOU = 4;
+    for (int i0 = nb + threadIdx.x; i0 < fe; i0 += NT * kOU) {
+      int32_t st[kOU], sid[kOU];
+      uint32_t qv[kOU];
+#pragma unroll
+      for (int k = 0; k < kOU; k++) {
+        const int i = min(i0 + k * NT, fe - 1);
+        st[k] = u.tok_state[i];
+        qv[k] = UX(x_q)[i - nb];
+      }
+#pragma unroll
+      for (int k = 0; k < kOU; k++) sid[k] = -1 - p.unit_ilabel[st[k]];   // the caller's state id (what the reference hashes)
+#pragma unroll
+      for (int k = 0; k < kOU; k++) {
+        const int i = i0 + k * NT;
+        if (i >= fe) continue;
+        const int32_t bk = static_cast<int32_t>(static_cast<uint32_t>(sid[k]) % H);
+        UX(x_bkt)[i - nb] = bk;
+        UX(x_epsidx)[i - nb] = -1;
+        if (i < ne_emit) __hip_atomic_fetch_min(&UX(x_bmin)[bk], qv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else UX(x_q)[i - nb] = 0xFFFFFFFFu;
+      }
+    }
   }
   KhSync();
   for (int j = threadIdx.x; j < eps_n; j += NT) {
@@ -2434,16 +2536,54 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
   for (int i = ne_emit + threadIdx.x; i < fe; i += NT)
     __hip_atomic_fetch_min(&UX(x_bmin)[UX(x_bkt)[i - nb]], UX(x_q)[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   KhSync();
-  for (int i = threadIdx.x; i < n; i += NT) {
-    UX(x_key0)[i] = (static_cast<unsigned long long>(__hip_atomic_load(&UX(x_bmin)[UX(x_bkt)[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) | UX(x_q)[i];
-    UX(x_val0)[i] = i;
+  {
+    constexpr int kOU = 4;
+    for (int i0 = threadIdx.x; i0 < n; i0 += NT * kOU) {
+      int32_t bk[kOU];
+      uint32_t qv[kOU], bm[kOU];
+#pragma unroll
+      for (int k = 0; k < kOU; k++) {
+        const int i = min(i0 + k * NT, n - 1);
+        bk[k] = UX(x_bkt)[i];
+        qv[k] = UX(x_q)[i];
+      }
+#pragma unroll
+      for (int k = 0; k < kOU; k++) bm[k] = __hip_atomic_load(&UX(x_bmin)[bk[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < kOU; k++) {
+        const int i = i0 + k * NT;
+        if (i >= n) continue;
+        UX(x_key0)[i] = (static_cast<unsigned long long>(bm[k]) << 32) | qv[k];
+        UX(x_val0)[i] = i;
+      }
+    }
   }
   KhSync();
-  for (int i = threadIdx.x; i < n; i += NT) UX(x_bmin)[UX(x_bkt)[i]] = 0xFFFFFFFFu;   // the table's invariant between frames
+  {
+    constexpr int kOU = 4;
+    for (int i0 = threadIdx.x; i0 < n; i0 += NT * kOU) {   // the table's invariant between frames
+      int32_t bk[kOU];
+#pragma unroll
+      for (int k = 0; k < kOU; k++) bk[k] = UX(x_bkt)[min(i0 + k * NT, n - 1)];
+#pragma unroll
+      for (int k = 0; k < kOU; k++)
+        if (i0 + k * NT < n) UX(x_bmin)[bk[k]] = 0xFFFFFFFFu;
+    }
+  }
   const int fb2 = n > 1 ? BlockRadixSort(u, n, bits, sh) : 0;
   KhSync();
   const Arr<const int32_t> order = fb2 ? UX(x_val1) : UX(x_val0);
-  for (int r = threadIdx.x; r < n; r += NT) UX(x_pos)[order[r]] = r;
+  {
+    constexpr int kOU = 8;
+    for (int r0 = threadIdx.x; r0 < n; r0 += NT * kOU) {
+      int32_t o[kOU];
+#pragma unroll
+      for (int k = 0; k < kOU; k++) o[k] = order[min(r0 + k * NT, n - 1)];
+#pragma unroll
+      for (int k = 0; k < kOU; k++)
+        if (r0 + k * NT < n) UX(x_pos)[o[k]] = r0 + k * NT;
+    }
+  }
   KhSync();
   SubStamp(u, sh, 51);
   return true;
@@ -2456,7 +2596,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   const int n = e - b;
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }
-  for (int c = threadIdx.x; c < p.ll_cols; c += NT) sh.ll_row[c] = u.ll[static_cast<size_t>(frame) * u.ll_stride + c];
+  StageScoreRow(u, p, sh, frame);
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff<true>(u, p, b, e, sh);
   Stamp(u, sh, 0);
@@ -2573,20 +2713,30 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   // ordinal of its first arc
   uint32_t run_min = Enc(est0);
   int run_sum = 0;
-  for (int base = 0; base < n; base += NT) {
-    const int q = base + threadIdx.x;
-    const bool valid = q < n;
-    const uint32_t m = valid ? xp_m[q] : 0xFFFFFFFFu;
-    const int cnt = valid ? xp_c[q] : 0;
-    int ex_sum, tot_sum;
-    uint32_t ex_min, tot_min;
-    BlockExScanSumMin(cnt, m, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
-    if (valid) {
-      xp_m[q] = run_min < ex_min ? run_min : ex_min;
-      xp_c[q] = run_sum + ex_sum;
+  constexpr int kSU = 4;   // chunks of NT positions whose loads are in flight together (the scans themselves are sequential)
+  for (int base0 = 0; base0 < n; base0 += NT * kSU) {
+    uint32_t ms[kSU];
+    int cs[kSU];
+#pragma unroll
+    for (int k = 0; k < kSU; k++) {
+      const int q = base0 + k * NT + threadIdx.x;
+      ms[k] = q < n ? xp_m[q] : 0xFFFFFFFFu;
+      cs[k] = q < n ? xp_c[q] : 0;
     }
-    run_min = run_min < tot_min ? run_min : tot_min;
-    run_sum += tot_sum;
+#pragma unroll
+    for (int k = 0; k < kSU; k++) {
+      if (base0 + k * NT >= n) break;   // (uniform)
+      const int q = base0 + k * NT + threadIdx.x;
+      int ex_sum, tot_sum;
+      uint32_t ex_min, tot_min;
+      BlockExScanSumMin(cs[k], ms[k], &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
+      if (q < n) {
+        xp_m[q] = run_min < ex_min ? run_min : ex_min;
+        xp_c[q] = run_sum + ex_sum;
+      }
+      run_min = run_min < tot_min ? run_min : tot_min;
+      run_sum += tot_sum;
+    }
   }
   const float next_cutoff = Dec(run_min);   // the value the running cutoff ends at
   Stamp(u, sh, 1);
@@ -2708,12 +2858,24 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       if (in_lds) qtab[i] = 0xFFFFFFFFu; else UX(x_q)[i] = 0xFFFFFFFFu;
     }
     KhSync();
-    for (int l = link_frame_b + threadIdx.x; l < link_frame_e; l += NT) {
-      const int dst = u.link_dst[l];
-      if (dst < 0) continue;   // (a dropped NaN candidate)
-      const uint32_t ord = static_cast<uint32_t>(UX(x_ord)[l - link_frame_b]);
-      if (in_lds) (void)__hip_atomic_fetch_min(&qtab[dst - nb], ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else (void)__hip_atomic_fetch_min(&UX(x_q)[dst - nb], ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      constexpr int kOU = 4;   // (a lane's loads of four trips in flight together)
+      for (int l0 = link_frame_b + threadIdx.x; l0 < link_frame_e; l0 += NT * kOU) {
+        int dsts[kOU];
+        uint32_t ords[kOU];
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          const int l = min(l0 + k * NT, link_frame_e - 1);
+          dsts[k] = u.link_dst[l];
+          ords[k] = static_cast<uint32_t>(UX(x_ord)[l - link_frame_b]);
+        }
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          if (l0 + k * NT >= link_frame_e || dsts[k] < 0) continue;   // (dst < 0: a dropped NaN candidate)
+          if (in_lds) (void)__hip_atomic_fetch_min(&qtab[dsts[k] - nb], ords[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else (void)__hip_atomic_fetch_min(&UX(x_q)[dsts[k] - nb], ords[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
     KhSync();
     for (int i = threadIdx.x; i < n_new; i += NT) {
@@ -3392,7 +3554,29 @@ __device__ void FinalBackward(const Utt &u_in, const Params &p, int last, int fb
       }
     }
     // ---- epsilon links (inside the frame): relax in place to the fixed point
-    if (ne > nb) {
+    if (ne > nb && ne - nb <= NT) {
+      // (nearly every frame: a few hundred slots) one link per lane, held in registers over the rounds; one barrier per
+      // round - the vote's - which also orders the round's minima before the next round's reads, and does not wait
+      // for the survivor lists' stores
+      LdsSync();
+      int dst = -1, src = b;
+      float kk = 0.0f;
+      if (t < ne - nb) { dst = u.link_dst[nb + t]; src = u.link_src[nb + t]; kk = u.link_k[nb + t]; }
+      for (;;) {
+        bool changed = false;
+        if (dst >= 0) {
+          float lec = Dec(*x(dst - b)) + kk;  // the parenthesis of :309-311 was evaluated when the link was created
+          if (!(lec > lb)) {
+            if (lec < 0.0f) lec = 0.0f;
+            const uint32_t v = Enc(lec);
+            const uint32_t old = __hip_atomic_fetch_min(x(src - b), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            changed = v < old;
+          }
+        }
+        if (!BlockAnyLds(changed, sh)) break;
+      }
+      if (dst >= 0 && !(Dec(*x(dst - b)) + kk > lb)) SurvAddLink(u, sh, nb + t, f);
+    } else if (ne > nb) {
       for (;;) {
         LdsSync();
         bool changed = false;
