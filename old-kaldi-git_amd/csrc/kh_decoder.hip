@@ -1015,7 +1015,10 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
 #ifndef KH_NO_CLAIM_PREFETCH
   // A wave always holds its NEXT claim: cursor and the 64 tokens' cost / state are requested while the current claim's
   // batches run, so a claim starts with the record headers instead of two dependent round trips (554.5 against 557 ms;
-  // no change of the kernel's scratch).
+  // no change of the kernel's scratch).  KH_CLAIM_PREFETCH2: the next claim's record headers as well (its arc counts),
+  // requested from the cost / state that arrived during the claim before - two claims deep.  Measured 559-569 ms
+  // against 553: a wave that owns three claims at a time (48 of a frame's ~76 taken up front) balances worse than
+  // the round trip is worth; off by default.
   int base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
   uint32_t co_next = 0u;
   int st_next = 0;
@@ -1024,9 +1027,38 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     co_next = LoadCostEnc(&w_cost[ic]);
     st_next = w_state[ic];
   }
+#ifdef KH_CLAIM_PREFETCH2
+  int base_nn = WaveLdsFetchAdd(&sh->work_cursor, 64);
+  uint32_t co_nn = 0u;
+  int st_nn = 0, cnt_next = 0;
+  if (base_nn < e) {
+    const int ic = min(base_nn + lane, e - 1);
+    co_nn = LoadCostEnc(&w_cost[ic]);
+    st_nn = w_state[ic];
+  }
+  if (base_next < e && base_next + lane < e && Dec(co_next) <= cutoff) cnt_next = rec[st_next].x;
+#endif
 #endif
   for (;;) {
-#ifndef KH_NO_CLAIM_PREFETCH
+#if !defined(KH_NO_CLAIM_PREFETCH) && defined(KH_CLAIM_PREFETCH2)
+    const int base = base_next;
+    if (base >= e) break;
+    const int i = base + lane;
+    const bool in_range = i < e;
+    const uint32_t co = co_next;
+    int st = st_next;
+    const int cnt_pre = cnt_next;
+    // shift the pipeline: claim + 1 becomes the next one (its headers are requested now), a new claim + 2 is taken
+    base_next = base_nn; co_next = co_nn; st_next = st_nn;
+    cnt_next = 0;
+    if (base_next < e && base_next + lane < e && Dec(co_next) <= cutoff) cnt_next = rec[st_next].x;
+    base_nn = WaveLdsFetchAdd(&sh->work_cursor, 64);
+    if (base_nn < e) {
+      const int icn = min(base_nn + lane, e - 1);
+      co_nn = LoadCostEnc(&w_cost[icn]);
+      st_nn = w_state[icn];
+    }
+#elif !defined(KH_NO_CLAIM_PREFETCH)
     const int base = base_next;
     if (base >= e) break;
     const int i = base + lane;
@@ -1053,7 +1085,11 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
     int ab = 0, cnt = 0;
     if (need) {  // the emitting arcs follow the state's header in its record
       ab = st + 1;
+#if !defined(KH_NO_CLAIM_PREFETCH) && defined(KH_CLAIM_PREFETCH2)
+      cnt = cnt_pre;
+#else
       cnt = rec[st].x;
+#endif
     }
     const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
