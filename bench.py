@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg at N > 1")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (config 2 / 5) legs")
+    ap.add_argument("--secondary-timeout", type=int, default=300,
+                    help="seconds the secondary legs may take before the line is printed without the one that hangs")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the unpipelined and the reference-order repeats of the step")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the value_end_to_end leg (the same steps with determinization timed)")
     ap.add_argument("--no-gpu-dryrun", action="store_true",
@@ -740,14 +742,6 @@ def main():
     weak = run(feats, off, args.steps, args.warmup)
     strong_rec = run(strong[0], strong[1], args.steps, args.warmup, end_to_end=False) if strong is not None else None
 
-    secondary = None
-    if rank == 0 and world == 1 and not args.no_secondary and not args.small:   # (the other ranks would wait at the final barrier)
-        try:
-            sec = importlib.import_module("tools.bench_secondary")
-            secondary = sec.run_all(api, torch, (net, priors, g, feats, off, DECODE_CFG, ACWT))
-        except Exception as e:  # the secondary legs never fail the headline run
-            secondary = {"error": repr(e)}
-
     if rank == 0:
         st = weak["stats"]
         fps = weak["total_frames"] * args.steps / weak["elapsed"]
@@ -858,8 +852,6 @@ def main():
                 "per_rank_kernel_ms": s["per_rank_kernel_ms"], "rank0_utterances": s["n_utts"], "rank0_frames": s["frames"],
                 "longest_utterance_frames": s["longest"],
                 "note": "one 2620-utterance set sharded longest-first over the ranks (sharding.partition_utterances)"}
-        if secondary is not None:
-            out["secondary"] = secondary
         if cpu_handle is not None:                   # the CPU legs run at N = 1 only
             res = finish_cpu_baseline(cpu_handle)
             if "error" in res:
@@ -869,6 +861,43 @@ def main():
                                        "sample": res["sample"], "all_cores": res.get("all_cores"),
                                        "secondary": res.get("secondary")}
                 out["speedup_vs_cpu_1thread_per_gpu"] = fps / world / res["value"]
+        # The secondary legs (configs 2, 3, 5, iVectors, config 4 as a serving loop) run LAST, when the headline and its
+        # baselines are final, and under a watchdog: a leg that does not come back (round 4 saw the serving legs of a
+        # full run stop once in a while, inside a blocking library call) costs its own figures, not the line - the
+        # watchdog prints what is there, names the leg, and leaves.
+        if world == 1 and not args.no_secondary and not args.small:   # (at N > 1 the other ranks would wait at the final barrier)
+            import threading
+            secondary = {}
+            out["secondary"] = secondary
+            state = {"leg": None, "printed": False}
+            lock = threading.Lock()
+
+            def emit_and_leave():
+                with lock:
+                    if state["printed"]:
+                        return
+                    state["printed"] = True
+                    sec_out = dict(secondary)
+                    if state["leg"] is not None and state["leg"] not in sec_out:
+                        sec_out[state["leg"]] = {"error": "no result within %d s (watchdog): the leg was abandoned" % args.secondary_timeout}
+                    out["secondary"] = sec_out
+                    print(json.dumps(out))
+                    sys.stdout.flush()
+                os._exit(0)
+
+            timer = threading.Timer(float(args.secondary_timeout), emit_and_leave)
+            timer.daemon = True
+            timer.start()
+            try:
+                sec = importlib.import_module("tools.bench_secondary")
+                sec.run_all(api, torch, (net, priors, g, feats, off, DECODE_CFG, ACWT), out=secondary, state=state)
+            except Exception as e:  # the secondary legs never fail the headline run
+                secondary["error"] = repr(e)
+            timer.cancel()
+            with lock:
+                if state["printed"]:      # (the watchdog is printing / has printed: it also leaves)
+                    time.sleep(3600)
+                state["printed"] = True
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -4,6 +4,7 @@ returns a dict that bench.py attaches to its JSON line as "secondary" — the dr
 record of the numbers DESIGN.md quotes.  Product API only (no oracle)."""
 import importlib
 import os
+import sys
 import time
 
 import numpy as np
@@ -293,7 +294,12 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
     pipe = api.OnlineNnet2Pipeline(nnet, dec, max_frames=max_t, acoustic_scale=acwt, pad_input=True, max_nnet_batch_size=256)
     n_utts = len(off) - 1
     all_lens = np.diff(off).astype(np.int64)
+    def progress(msg):
+        if os.environ.get("BENCH_VERBOSE"):
+            print("[bench online2] " + msg, file=sys.stderr, flush=True)
+
     for c in chunks:
+        progress("launch-per-step loop, chunk %d" % c)
         # CONTINUOUS serving, the step as ONE library call (kh_online_nnet2_step): `n` stream slots; a slot whose utterance
         # has been decoded is finalized and takes the next utterance of the set (InitDecoding), until the set is used up.
         # Throughput and latency are those of the steps in which every slot was busy (the drain at the end is a property of
@@ -363,6 +369,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
         # step up for everybody; FinalizeDecoding is requested asynchronously and the slot takes its next utterance when it
         # is acknowledged.  step_call_ms = the host's step (features in -> scores published); chunk_latency_ms = per stream
         # and chunk, from handing the chunk over to NumFramesDecoded() having reached its frames (polled once per turn).
+        progress("persistent kernel, chunk %d%s" % (c, tag))
         pipe.serve_start()
         for rep in range(2):
             slot_utt = np.arange(n)
@@ -510,16 +517,21 @@ def release_device_memory(api, torch):
     api.pool_release()
 
 
-def run_all(api, torch, main_workload=None):
-    """main_workload: bench.py's (net, priors, graph, feats, utt offsets, decoder config, acwt) for the online leg."""
-    out = {}
+def run_all(api, torch, main_workload=None, out=None, state=None):
+    """main_workload: bench.py's (net, priors, graph, feats, utt offsets, decoder config, acwt) for the online leg.
+    out / state: filled in place (results by leg; state["leg"] = the leg that is running) for bench.py's watchdog."""
+    out = {} if out is None else out
     for name, fn in (("gmm_cfg2", gmm_cfg2), ("nnet_cfg3", nnet_cfg3), ("decode_cfg3", decode_cfg3), ("lattice_fb_cfg5", lattice_fb_cfg5),
                      ("ivector_f3", ivector_f3), ("online2_cfg4", lambda a, t: online2_cfg4(a, t, main_workload))):
+        if state is not None:
+            state["leg"] = name
         try:
             release_device_memory(api, torch)
             out[name] = fn(api, torch)
         except Exception as e:  # a secondary leg never fails the headline run
             out[name] = {"error": repr(e)}
+    if state is not None:
+        state["leg"] = None
     return out
 
 
