@@ -877,6 +877,13 @@ def main():
                     if state["printed"]:
                         return
                     state["printed"] = True
+                    try:   # where every thread stands, for whoever reads the run's stderr
+                        import faulthandler
+                        print("[bench] watchdog: the secondary leg %r has not returned within %d s; Python stacks of all threads:"
+                              % (state["leg"], args.secondary_timeout), file=sys.stderr, flush=True)
+                        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    except Exception:   # noqa: BLE001
+                        pass
                     sec_out = dict(secondary)
                     if state["leg"] is not None and state["leg"] not in sec_out:
                         sec_out[state["leg"]] = {"error": "no result within %d s (watchdog): the leg was abandoned" % args.secondary_timeout}
