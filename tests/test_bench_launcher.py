@@ -37,3 +37,31 @@ def test_rank_failure_is_reported():
     rc, out, err = _run(["--gpus", "2", "--utts", "20", "--no-gpu-dryrun", "--master-port", "29733"],
                         {"BENCH_FAIL_RANK": "1"})
     assert rc != 0 and out is None
+
+
+def test_secondary_legs_report_progress_for_the_watchdog(monkeypatch):
+    """bench.py runs the secondary legs last and under a watchdog that prints the line without a leg that does not come
+    back: tools.bench_secondary.run_all fills the caller's dict leg by leg and names the leg that is running."""
+    import importlib
+    sec = importlib.import_module("tools.bench_secondary")
+    seen = []
+    state = {"leg": None}
+
+    def leg(name, fail=False):
+        def fn(api, torch, *a):
+            seen.append((name, state["leg"]))
+            if fail:
+                raise RuntimeError("boom")
+            return {"ok": name}
+        return fn
+
+    monkeypatch.setattr(sec, "release_device_memory", lambda api, torch: None)
+    for name in ("gmm_cfg2", "nnet_cfg3", "decode_cfg3", "lattice_fb_cfg5", "ivector_f3"):
+        monkeypatch.setattr(sec, name, leg(name, fail=(name == "decode_cfg3")))
+    monkeypatch.setattr(sec, "online2_cfg4", leg("online2_cfg4"))
+    out = {}
+    ret = sec.run_all(None, None, main_workload=None, out=out, state=state)
+    assert ret is out and state["leg"] is None
+    assert [s[0] for s in seen] == ["gmm_cfg2", "nnet_cfg3", "decode_cfg3", "lattice_fb_cfg5", "ivector_f3", "online2_cfg4"]
+    assert all(name == running for name, running in seen)          # the watchdog would have named the right leg
+    assert out["gmm_cfg2"] == {"ok": "gmm_cfg2"} and "boom" in out["decode_cfg3"]["error"] and out["online2_cfg4"] == {"ok": "online2_cfg4"}
