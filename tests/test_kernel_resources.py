@@ -1,0 +1,34 @@
+"""Compile-only guard on the decoder kernel's register economy (no GPU: hipcc cross-compiles).
+
+Round 4 found the persistent decode kernel at its 64-VGPR limit (two 1024-thread workgroups per CU) spending a quarter of
+its instructions on scalar-register spill reloads (5 719 v_readlane_b32), and measured that every change which raised its
+scratch by 8-24 bytes per lane cost 4-12 % on the GPU ("the instruction stream").  The listing tells
+both before a GPU does: tools/isa_mix.py."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_decode_kernel_spill_budget():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "kh_decoder.hip"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = {}
+    for line in p.stdout.splitlines():
+        m = re.match(r"^(.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s*$", line)
+        if m:
+            rows[m.group(1).strip()] = [int(x) for x in m.groups()[1:]]
+    key = next(k for k in rows if "DecodeKernel<true, false>" in k)     # the offline kernel, canonical rule, lazy schedule
+    instr, readlane, writelane, scr_ld, scr_st, scr_bytes, bpermute, dpp = rows[key]
+    # end of round 4: 19 758 instructions, 1 876 readlanes, 132 bytes of scratch, 2 ds_bpermute (the sweeps' data fetches are
+    # counted per call site), 306 DPP instructions.  Generous bounds: this is a tripwire, not a benchmark.
+    assert scr_bytes <= 160, "DecodeKernel<1,0> scratch %d B per lane (132 at the end of round 4; +8..24 B cost 4-12 %%)" % scr_bytes
+    assert readlane <= 2600, "DecodeKernel<1,0> has %d v_readlane_b32 (1 876 at the end of round 4; 5 719 before Launder)" % readlane
+    assert dpp >= 200 and bpermute <= 40, "the wave scans are expected on DPP, not on ds_bpermute (%d DPP, %d bpermute)" % (dpp, bpermute)
