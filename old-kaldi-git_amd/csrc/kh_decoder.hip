@@ -75,7 +75,7 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 56;            // diagnostic counters per slot
+constexpr int NPH = 160;           // diagnostic counters per slot (96 on: the fine stamps of -DKH_X_STAMPS builds)
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x1fffffff;
@@ -181,7 +181,6 @@ struct UttX {
   Arr<uint32_t> x_m;       // by list position: Enc(min tot_cost + adaptive_beam) over the token's emitting arcs; after the scan the running next_cutoff BEFORE the token
   Arr<int32_t> x_c;        // by list position: # emitting arcs expanded; after the scan their exclusive prefix sum (ordinal of the token's first candidate)
   Arr<uint32_t> x_q;       // token of the frame under construction (i - nb) -> insertion key (order of HashList::Insert calls)
-  Arr<uint32_t> x_cost0;   // ... -> cost image before the epsilon closure
   Arr<int32_t> x_bkt;      // ... -> HashList bucket (caller's state id % hash size)
   Arr<int32_t> x_epsidx;   // ... -> index in tmp_epslist, or -1
   Arr<int32_t> x_nl0; Arr<int32_t> x_nl1;   // closure replay, by tmp_epslist index: the token's epsilon link slots [l0, l1) relative to the block
@@ -192,6 +191,8 @@ struct UttX {
   Arr<uint32_t> x_bmin;    // [x_hcap] HashList bucket -> smallest insertion key in it (all ones = empty: invariant between frames)
   Arr<unsigned long long> x_key0; Arr<unsigned long long> x_key1;   // radix sort keys, double buffered
   Arr<int32_t> x_val0; Arr<int32_t> x_val1;                         // radix sort payload
+  Arr<int32_t> x_h; Arr<int32_t> x_inb;   // token of the frame under construction -> insertion rank of its bucket's first token; its rank inside the bucket
+  Arr<uint32_t> x_c0e;     // entry of tmp_epslist made by the emitting pass -> the token's cost image before the epsilon closure
   int32_t x_hcap;
 };
 
@@ -414,7 +415,7 @@ struct Shared {
   int flag;
   int bcast_i[4];
   float bcast_f[8];
-  unsigned int hist[1 << 11];       // RadixSelect digit histogram (kRadixBits)
+  alignas(16) unsigned int hist[1 << 11];   // RadixSelect digit histogram (kRadixBits); 16-byte aligned: the areas laid over it take 64-bit LDS atomics
   int ex_off[EU * NT], ex_ab[EU * NT], ex_tok[EU * NT];  // ExpandSweep: first link slot, first arc, token of the group's items
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
@@ -442,6 +443,7 @@ struct Shared {
   int x_ne_emit;        // end of the tokens the emitting pass created (the closure's follow)
   int x_eps_emit;       // entries of tmp_epslist the emitting pass made
   int x_n_new;          // closure replay: insertions counted
+  uint32_t x_cb[16];    // sweep of the emitting arcs: Enc(upper bound of the running next_cutoff) in front of the k-th sixteenth of the list
   // epsilon closure in LDS (ClosureLds)
   int erel_n;           // entries of the frame's list of epsilon-relevant tokens (pass 2 appends; tmp_work0 / tmp_work1)
   int cl_n;             // entries of the LDS closure table
@@ -470,6 +472,7 @@ struct Blk {
 constexpr int kLdsSlots = 8192;
 static_assert(sizeof(unsigned int) * (1 << 11) + 3 * sizeof(int) * EU * NT >= sizeof(uint32_t) * kLdsSlots,
               "the LDS token table's keys are laid over hist + ex_off + ex_ab + ex_tok");
+static_assert(offsetof(Shared, hist) % 16 == 0, "the LDS token-table area is 16-byte aligned (64-bit LDS atomics on it)");
 static_assert(offsetof(Shared, ex_off) == offsetof(Shared, hist) + sizeof(unsigned int) * (1 << 11) &&
               offsetof(Shared, ex_ab) == offsetof(Shared, ex_off) + sizeof(int) * EU * NT &&
               offsetof(Shared, ex_tok) == offsetof(Shared, ex_ab) + sizeof(int) * EU * NT, "contiguous LDS arrays");
@@ -1744,7 +1747,7 @@ __device__ void ClearHash(const Utt &u, int fb, int fe, Blk &sh) {
 // tokens the epsilon closure may look up (kEpsDst states) also enter the global hash.
 template <bool kLocal>
 __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok_limit, int link_frame_b, int link_frame_e,
-                                          float next_cutoff) {
+                                          float next_cutoff, int n_acc_known = 0) {
   static_assert(kLdsSlots % NT == 0, "slots per lane");
   // the pass's own copies of the pointers it uses (see ProcessEmitting) - in the reference-order kernel only:
   // same-box A/B, canonical kernel 691 ms with them / 676 ms without, reference-order kernel 2208 / 2246 ms
@@ -1785,7 +1788,9 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
   // distinct states: a load of ~0.65); a part whose table fills up is redone with twice the
   // parts (the parts nest, and resolved links are marked, so nothing is done twice)
   int parts = 1;
-  if (link_frame_e - link_frame_b > KH_PART_CAND) {
+  if constexpr (kLocal) {   // (reference order: the caller has counted the live candidates)
+    while (parts * KH_PART_CAND < n_acc_known) parts *= 2;
+  } else if (link_frame_e - link_frame_b > KH_PART_CAND) {
     int n_acc_mine = 0;
     {
       constexpr int kCU = 8;   // loads of a lane in flight together (a frame of this size took 11+ dependent round trips here)
@@ -1916,7 +1921,11 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       e_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
       vals[i] = static_cast<uint32_t>(idx);
       // these tokens are the closure's first work list (every one has a finite cost)
-      if ((ns & kHasEps) != 0) e_epslist[__hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = idx;
+      if ((ns & kHasEps) != 0) {
+        const int je = __hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        e_epslist[je] = idx;
+        if constexpr (kLocal) UX(x_c0e)[je] = cost_enc;   // (reference order: the closure's replay starts from these costs)
+      }
       // The tokens the epsilon closure can touch - those with epsilon arcs and those whose state is the destination of
       // one - are LISTED (state + flags, token); the closure builds its LDS table from the list (ClosureLds), or, for the
       // rare frame that does not fit it, enters them in the global hash first (ClosureGeneralPrep).  Rounds 2-4 entered the
@@ -2294,10 +2303,11 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
 // insertions, or -1 when the queue outgrew its arrays.
 template <class FP, class IP>
 __device__ int ReplayClosure(FP ncost, IP nl0, IP nl1, IP lcode, FP lw, IP stack_lo, int lo_cap, const Utt &u, const Blk &sh, int top,
-                             float cutoff, int nb, uint32_t qbase) {
+                             float cutoff, int nb, uint32_t qbase, int n_new) {
   int cnt = 0;
   const int hi_cap = u.link_frame_cap;
-  while (top > 0) {
+  // (once every token the closure creates has been inserted the rest of the queue only moves costs, which are known)
+  while (top > 0 && cnt < n_new) {
     --top;
     const int uu = top < lo_cap ? stack_lo[top] : UX(x_stack)[top - lo_cap];
     const float c = ncost[uu];
@@ -2346,14 +2356,22 @@ constexpr int kRpNodes = kLdsSlots / 4, kRpLinks = kLdsSlots / 2;
 typedef __attribute__((address_space(3))) float *LdsF;
 typedef __attribute__((address_space(3))) int *LdsI;
 __device__ int ReplayClosureWave(LdsF ncost, LdsI nlr, LdsI dstack, LdsI newq, LdsI lcode, LdsF lw, Arr<const int32_t> queue, int n_queue,
-                                 float cutoff) {
+                                 float cutoff, int n_new, Blk &sh) {
   const int lane = threadIdx.x & 63;
   int cnt = 0;
+#ifdef KH_X_STAMPS
+#define RC(k, v) do { if (lane == 0) sh->phase[96 + 44 + (k)] += (v); } while (0)
+#else
+#define RC(k, v) do {} while (0)
+#endif
+  if (n_new == 0) return 0;   // (nothing to order: the pops only move costs, which the parallel closure has computed)
   for (int top = n_queue; top > 0; top -= 64) {   // uniform
     const int bsz = min(64, top);
     const int node = lane < bsz ? queue[top - 1 - lane] : -1;   // lane j holds the j-th pop from here
     unsigned long long pending = __ballot(lane < bsz);
+    RC(0, 1);
     while (pending != 0ull) {
+      RC(1, 1);
       bool act = false;
       if (((pending >> lane) & 1ull) != 0ull) {
         const float c = ncost[node];
@@ -2378,10 +2396,12 @@ __device__ int ReplayClosureWave(LdsF ncost, LdsI nlr, LdsI dstack, LdsI newq, L
       const int L = Uni(__ffsll(static_cast<long long>(am)) - 1);
       pending &= ~((2ull << L) - 1ull);
       const int first = __builtin_amdgcn_readlane(node, L);
+      RC(2, 1);
       if (lane == 0) {   // the pop of `first` and everything it pushes, depth first
         int sp = 0;
         dstack[sp++] = first;
         while (sp > 0) {
+          RC(3, 1);
           const int uu = dstack[--sp];
           const float c = ncost[uu];
           if (c > cutoff) continue;   // :779
@@ -2415,9 +2435,11 @@ __device__ int ReplayClosureWave(LdsF ncost, LdsI nlr, LdsI dstack, LdsI newq, L
       }
       cnt = __builtin_amdgcn_readfirstlane(cnt);
       if (cnt < 0) return -1;
+      if (cnt >= n_new) { RC(4, 1); RC(5, top); return cnt; }   // every token of the closure has its place: the rest of the queue only moves costs
     }
   }
   return cnt;
+#undef RC
 }
 
 // Diagnostic: cycles since the previous SubStamp / Stamp of this workgroup into phase[ph] WITHOUT moving the phase timer
@@ -2430,10 +2452,20 @@ __device__ __forceinline__ void SubStamp(const Utt &u, Blk &sh, int ph) {
   }
 }
 
+// Fine stamps of the reference-order phases (-DKH_X_STAMPS builds only): cycles since the previous XS / SubStamp into phase[64 + k].
+#if defined(KH_X_STAMPS) && KH_X_STAMPS == 2
+// (every wave first waits for its own outstanding memory operations and for the others: a step is charged the stores it issued)
+#define XS(k) do { KhSync(); SubStamp(u, sh, 96 + (k)); } while (0)
+#elif defined(KH_X_STAMPS)
+#define XS(k) SubStamp(u, sh, 96 + (k))
+#else
+#define XS(k) do {} while (0)
+#endif
+
 // List positions (x_pos) of the frame under construction, tokens [nb, fe): the emitting pass made [nb, ne_emit) with
-// their insertion keys in x_q and their costs in x_cost0; the closure has converged and the frame's epsilon links are
+// their insertion keys in x_q and, for those with epsilon arcs, their costs in x_c0e; the closure has converged and the frame's epsilon links are
 // the block [lb, le).  Leaves x_bmin all ones.  Returns false on a capacity overflow (sh->status).
-__device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
+__device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
   const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
   const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
   const int nl = le - lb;
@@ -2475,7 +2507,7 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     UX(x_epsidx)[tok - nb] = j;
     UX(x_nl0)[j] = 0;
     UX(x_nl1)[j] = 0;
-    UX(x_ncost)[j] = tok < ne_emit ? Dec(UX(x_cost0)[tok - nb]) : INFINITY;
+    UX(x_ncost)[j] = j < eps_emit ? Dec(UX(x_c0e)[j]) : INFINITY;
     if (j < eps_emit) {   // (the first eps_emit entries are the emitting pass's: the queue's initial content, :766-767)
       UX(x_key0)[j] = (static_cast<unsigned long long>(__hip_atomic_load(&UX(x_bmin)[UX(x_bkt)[tok - nb]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) << 32) |
                     UX(x_q)[tok - nb];
@@ -2541,7 +2573,7 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     }
     KhSync();
     if (threadIdx.x < 64) {
-      const int cnt = ReplayClosureWave(l_ncost, l_nlr, l_dstack, l_newq, l_code, l_lw, UX(x_stack), eps_emit, cutoff);
+      const int cnt = ReplayClosureWave(l_ncost, l_nlr, l_dstack, l_newq, l_code, l_lw, UX(x_stack), eps_emit, cutoff, n_new, sh);
       if (threadIdx.x == 0) sh->x_n_new = cnt;
     }
     KhSync();
@@ -2561,7 +2593,7 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     KhSync();
     if (threadIdx.x == 0) {
       const int cnt = ReplayClosure((GP(float))UX(x_ncost).p, (GP(int32_t))UX(x_nl0).p, (GP(int32_t))UX(x_nl1).p, (GP(int32_t))UX(x_ord).p,
-                                    (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, sh, eps_emit, cutoff, nb, qbase);
+                                    (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, sh, eps_emit, cutoff, nb, qbase, n_new);
       if (cnt != n_new) sh->status = cnt < 0 ? 3 : 8;
     }
   }
@@ -2625,7 +2657,644 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
   return true;
 }
 
-// ProcessEmitting :660-750 with the reference's running cutoff (see above).  Tokens [b, e) with list positions x_pos.
+// ---------------------------------------------------------------- list order without a sort (round 5)
+// The same list positions from DENSE RANKS instead of sorted 64-bit keys.  What a HashList position is made of:
+//   r(t)   the rank of token t in the order of HashList::Insert calls: the emitting pass's tokens by the ordinal of their
+//          first accepted arc (distinct integers below the frame's arc count: a BITMAP over the ordinals + a popcount
+//          scan ranks them - no comparison sort), then the closure's tokens in the order the replay finds;
+//   h(t)   the rank of the first token of t's bucket (state % hash_size), inb(t) t's rank inside its bucket;
+//   pos(t) = #{t': h(t') < h(t)} + inb(t): buckets in the order of their first occupation, a bucket's tokens in
+//          insertion order (hash-list-inl.h:118-147).
+// Buckets: a second bitmap over the bucket ids gives every occupied bucket a dense index, a counting sort by that index
+// lays the ranks of a bucket's tokens side by side, and a token reads its bucket's few members for h and inb.  The
+// counts by h and ONE scan over the rank space turn (h, inb) into positions.  Everything lives in the two 32 KB LDS
+// areas of the token table (idle between the closure and the next frame); the only global traffic is the per-token
+// arrays, read and written coalesced.  The closure's initial queue (the emitting pass's tokens with epsilon arcs in
+// list order) is ranked the same way - a bitmap over the positions among the emitting pass's tokens - and the few
+// tokens the closure creates find their bucket mates among themselves by direct comparison.
+// Frames beyond the LDS capacity (more than kFastN tokens, more than 2^18 buckets, more than kFastNew closure tokens)
+// take OrderFrontierSort.
+constexpr int kFastN = 65535, kFastNew = 1024, kFastMulti = 2 * kLdsSlots;
+
+// The lane's index in the workgroup as a value the optimizer cannot see through.  The persistent kernel is one loop over
+// frames around everything; with plain threadIdx.x the loop-invariant code motion hoists every `tid * 8 + j`, `w < W`
+// and LDS address out of that loop, the 64-register budget cannot hold them, and each USE becomes a scratch_load with its
+// own s_waitcnt vmcnt(0) - the round-5 listing of the 8-word LDS scans below had sixteen of those in a row (24 k cycles
+// for a scan whose arithmetic takes a few hundred).  An opaque copy makes the address arithmetic a per-call VALU
+// instruction again.
+__device__ __forceinline__ int OpaqueTid() {
+  int t = static_cast<int>(threadIdx.x);
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+// exclusive prefix of the set-bit counts of bits[0, W) -> pre[0, W), W <= kLdsSlots; returns the number of set bits.
+// One barrier inside; the caller syncs before it reads pre.
+__device__ __forceinline__ int BitmapPrefix(LdsU32 bits, LdsU32 pre, int W, Blk &sh) {
+  const int tid = OpaqueTid();
+  constexpr int kPer = kLdsSlots / NT;
+  int c[kPer], mine = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int w = tid * kPer + j;
+    const uint32_t v = bits[w];   // (unguarded: inside the area whatever W is - the eight reads go out together)
+    c[j] = w < W ? __popc(v) : 0;
+    mine += c[j];
+  }
+  int total;
+  int run = BlockExScan<true>(mine, &total, sh);
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int w = tid * kPer + j;
+    if (w < W) pre[w] = static_cast<uint32_t>(run);
+    run += c[j];
+  }
+  return total;
+}
+// a[0, W) -> its exclusive prefix sums, in place (a lane owns kLdsSlots / NT consecutive words); returns the total
+__device__ __forceinline__ int LdsExScanInPlace(LdsU32 a, int W, Blk &sh) {
+  const int tid = OpaqueTid();
+  constexpr int kPer = kLdsSlots / NT;
+  int c[kPer], mine = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int w = tid * kPer + j;
+    const uint32_t v = a[w];   // (unguarded: inside the area whatever W is - the eight reads go out together)
+    c[j] = w < W ? static_cast<int>(v) : 0;
+    mine += c[j];
+  }
+  int total;
+  int run = BlockExScan<true>(mine, &total, sh);
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int w = tid * kPer + j;
+    if (w < W) a[w] = static_cast<uint32_t>(run);
+    run += c[j];
+  }
+  return total;
+}
+__device__ __forceinline__ uint32_t LdsLoadU(LdsU32 p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int BitRank(LdsU32 bits, LdsU32 pre, uint32_t q) {   // set bits below bit q
+  return static_cast<int>(pre[q >> 5]) + __popc(bits[q >> 5] & ((1u << (q & 31u)) - 1u));
+}
+
+// The closure replay's tables in global memory (frames whose epsilon structure does not fit LDS, or whose depth-first
+// stack outgrew it) and the replay by one lane.  x_epsidx must hold -1 for every token of the frame.
+__device__ void ReplayFromMemory(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, uint32_t qbase, Blk &sh) {
+  const int ne_emit = Uni(sh->x_ne_emit), eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n), n_new = fe - ne_emit;
+  for (int j = threadIdx.x; j < eps_n; j += NT) {
+    const int tok = u.tmp_epslist[j];
+    UX(x_epsidx)[tok - nb] = j;
+    UX(x_nl0)[j] = 0;
+    UX(x_nl1)[j] = 0;
+    UX(x_ncost)[j] = j < eps_emit ? Dec(UX(x_c0e)[j]) : INFINITY;
+  }
+  for (int i = ne_emit + threadIdx.x; i < fe; i += NT) UX(x_q)[i - nb] = 0xFFFFFFFFu;
+  KhSync();
+  for (int l = lb + threadIdx.x; l < le; l += NT) {
+    const int src = u.link_src[l], dst = u.link_dst[l];
+    const int j = UX(x_epsidx)[src - nb];
+    if (l == lb || u.link_src[l - 1] != src) UX(x_nl0)[j] = l - lb;
+    if (l + 1 == le || u.link_src[l + 1] != src) UX(x_nl1)[j] = l - lb + 1;
+    int code = -1;
+    if (dst >= 0) {
+      const int e = UX(x_epsidx)[dst - nb];
+      if (e >= 0) code = e;
+      else if (dst >= ne_emit) code = 0x40000000 | (dst - nb);
+    }
+    UX(x_ord)[l - lb] = code;
+    UX(x_lw)[l - lb] = __int_as_float(p.n_arcs[-1 - u.link_arc[l]].z);
+  }
+  KhSync();
+  if (threadIdx.x == 0) {
+    const int cnt = ReplayClosure((GP(float))UX(x_ncost).p, (GP(int32_t))UX(x_nl0).p, (GP(int32_t))UX(x_nl1).p, (GP(int32_t))UX(x_ord).p,
+                                  (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, sh, eps_emit, cutoff, nb, qbase, n_new);
+    if (cnt != n_new) sh->status = cnt < 0 ? 3 : 8;
+  }
+  KhSync();
+}
+
+// pos(t) = #{t': h(t') < h(t)} + inb(t) for the tokens [0, cnt) of the frame under construction -> x_pos.  One count per
+// first-of-bucket rank and one scan over the rank space, 8192 ranks at a time.
+__device__ void PositionsFromHeads(const Utt &u, int cnt, Blk &sh, int xs0) {
+  const int tid = OpaqueTid();
+  const LdsU32 K = (LdsU32)LdsKeys(sh);
+  constexpr int kU = 8;   // (a lane's loads of eight trips in flight together: a loop that waits per trip pays a memory round trip per trip)
+  int pbase = 0;
+  for (int h0 = 0; h0 < cnt; h0 += kLdsSlots) {
+    const uint32_t W = static_cast<uint32_t>(min(kLdsSlots, cnt - h0));
+    for (uint32_t w = tid; w < W; w += NT) K[w] = 0u;
+    LdsSync();
+    XS(xs0 + 0);
+    for (int i0 = tid; i0 < cnt; i0 += NT * kU) {
+      int hh[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) hh[k] = UX(x_h)[min(i0 + k * NT, cnt - 1)];
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const uint32_t at = static_cast<uint32_t>(hh[k] - h0);
+        if (i0 + k * NT < cnt && at < W) (void)__hip_atomic_fetch_add(&K[at], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    LdsSync();
+    XS(xs0 + 1);
+    const int total = LdsExScanInPlace(K, static_cast<int>(W), sh);
+    LdsSync();
+    XS(xs0 + 2);
+    for (int i0 = tid; i0 < cnt; i0 += NT * kU) {
+      int hh[kU], ib[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = min(i0 + k * NT, cnt - 1);
+        hh[k] = UX(x_h)[i];
+        ib[k] = UX(x_inb)[i];
+      }
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const uint32_t at = static_cast<uint32_t>(hh[k] - h0);
+        if (i0 + k * NT < cnt && at < W) UX(x_pos)[i0 + k * NT] = pbase + static_cast<int>(K[at]) + ib[k];
+      }
+    }
+    pbase += total;
+    LdsSync();
+    XS(xs0 + 3);
+  }
+}
+
+// Returns 1 = done, 0 = failed (sh->status), 2 = not applicable after all (more than kFastMulti tokens share their
+// bucket with another one: nothing the sort needs has been touched - it takes the frame).
+__device__ int OrderFrontierFast(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
+  const int tid = OpaqueTid();
+  const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, n_emit = ne_emit - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
+  const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
+  const int nl = le - lb, n_new = fe - ne_emit;
+  const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);
+  const LdsU16 V16 = (LdsU16)LdsVals(sh);
+  const int Hw = static_cast<int>((H + 31u) >> 5), qw = static_cast<int>((qbase + 31u) >> 5);
+  const Arr<int32_t> xr = UX(x_val0);   // insertion ranks
+  constexpr int kU = 8;   // (a lane's loads of eight trips in flight together)
+  if (u.phase_cycles != nullptr && tid == 0) {
+    sh->t_sub = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh->phase[47] += 1; sh->phase[52] += eps_emit; sh->phase[53] += eps_n; sh->phase[54] += nl; sh->phase[55] += n_new; sh->phase[46] += n;
+  }
+  // ---- 1. three bitmaps: the ordinals of the emitting pass's tokens (their ranks), the occupied buckets, the buckets
+  // that hold more than one token (a token that finds its bucket's bit set, and a token of the closure whose bucket is
+  // occupied, set the second bit).  A token alone in its bucket is done here: h = its own rank, inb = 0.
+  const bool comb = qw + 2 * Hw <= kLdsSlots;
+  const int o1 = comb ? qw : 0, o2 = o1 + Hw, W1 = o2 + Hw;
+  if (!comb) {   // the ordinals alone, 2^18 at a time
+    int rbase = 0;
+    for (uint32_t c0 = 0; c0 < qbase; c0 += static_cast<uint32_t>(kLdsSlots) * 32u) {
+      const int W = min(kLdsSlots, static_cast<int>((qbase - c0 + 31u) >> 5));
+      for (int w = tid; w < W; w += NT) K[w] = 0u;
+      LdsSync();
+      XS(0);
+      for (int i = tid; i < n_emit; i += NT) {
+        const uint32_t q = UX(x_q)[i] - c0;
+        if (q < static_cast<uint32_t>(kLdsSlots) * 32u) (void)__hip_atomic_fetch_or(&K[q >> 5], 1u << (q & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      LdsSync();
+      XS(1);
+      const int total = BitmapPrefix(K, V, W, sh);
+      LdsSync();
+      XS(2);
+      for (int i = tid; i < n_emit; i += NT) {
+        const uint32_t q = UX(x_q)[i] - c0;
+        if (q < static_cast<uint32_t>(kLdsSlots) * 32u) xr[i] = rbase + BitRank(K, V, q);
+      }
+      rbase += total;
+      LdsSync();
+      XS(3);
+    }
+  }
+  for (int w = tid; w < W1; w += NT) K[w] = 0u;
+  LdsSync();
+  XS(4);
+  for (int i0 = tid; i0 < n; i0 += NT * kU) {
+    int32_t st[kU], sid[kU];
+    uint32_t qv[kU];
+#pragma unroll
+    for (int k = 0; k < kU; k++) {
+      const int i = min(i0 + k * NT, n - 1);
+      st[k] = u.tok_state[nb + i];
+      qv[k] = UX(x_q)[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kU; k++) sid[k] = -1 - p.unit_ilabel[st[k]];   // the caller's state id (what the reference hashes)
+#pragma unroll
+    for (int k = 0; k < kU; k++) {
+      const int i = i0 + k * NT;
+      if (i >= n) continue;
+      const uint32_t bk = static_cast<uint32_t>(sid[k]) % H;
+      UX(x_bkt)[i] = static_cast<int32_t>(bk);
+      UX(x_epsidx)[i] = -1;
+      if (i < n_emit) {
+        const uint32_t m = 1u << (bk & 31u);
+        const uint32_t old = __hip_atomic_fetch_or(&K[o1 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((old & m) != 0u) (void)__hip_atomic_fetch_or(&K[o2 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (comb) (void)__hip_atomic_fetch_or(&K[qv[k] >> 5], 1u << (qv[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  LdsSync();
+  XS(5);
+  // (the closure's tokens, by the lane that stored their bucket id above: i = lane + a multiple of NT)
+  for (int i = n_emit + static_cast<int>((tid + NT - n_emit % NT) % NT); i < n; i += NT) {
+    const uint32_t bk = static_cast<uint32_t>(UX(x_bkt)[i]), m = 1u << (bk & 31u);
+    if ((K[o1 + (bk >> 5)] & m) != 0u) (void)__hip_atomic_fetch_or(&K[o2 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  LdsSync();
+  XS(6);
+  const int n_bits = BitmapPrefix(K, V, W1, sh);
+  LdsSync();
+  XS(7);
+  const int pre2 = static_cast<int>(V[o2]);   // set bits in front of the third bitmap
+  const int n_b2 = n_bits - pre2;             // buckets with more than one token
+  if (n_b2 > kLdsSlots) return 2;
+  for (int i0 = tid; i0 < n; i0 += NT * kU) {
+    uint32_t bks[kU], qv[kU];
+#pragma unroll
+    for (int k = 0; k < kU; k++) {
+      const int i = min(i0 + k * NT, n - 1);
+      bks[k] = static_cast<uint32_t>(UX(x_bkt)[i]);   // (this lane's own store)
+      qv[k] = (comb || i >= n_emit) ? UX(x_q)[i] : static_cast<uint32_t>(xr[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < kU; k++) {
+      const int i = i0 + k * NT;
+      if (i >= n) continue;
+      const uint32_t bk = bks[k], m = 1u << (bk & 31u);
+      const int w2 = o2 + static_cast<int>(bk >> 5);
+      const uint32_t bits2 = K[w2];
+      const int r = i < n_emit ? (comb ? BitRank(K, V, qv[k]) : static_cast<int>(qv[k])) : -1;
+      if (comb && i < n_emit) xr[i] = r;
+      if ((bits2 & m) != 0u) {
+        UX(x_bkt)[i] = static_cast<int>(V[w2]) - pre2 + __popc(bits2 & (m - 1u));   // dense index among the shared buckets
+      } else {
+        // alone: the token's own rank heads its bucket.  A token of the closure whose bucket holds none of the
+        // emitting pass's tokens keeps its bucket id, as -2 - id (its mates are among the closure's tokens).
+        UX(x_bkt)[i] = i < n_emit ? -1 : -2 - static_cast<int32_t>(bk);
+        UX(x_h)[i] = r;
+        UX(x_inb)[i] = 0;
+      }
+    }
+  }
+  LdsSync();
+  XS(8);
+  // ---- 2. the tokens of the shared buckets: counting sort by bucket index, a bucket's ranks side by side (16 bits each)
+  if (n_b2 > 0) {
+    for (int w = tid; w < n_b2; w += NT) K[w] = 0u;
+    LdsSync();
+    XS(9);
+    for (int i0 = tid; i0 < n_emit; i0 += NT * kU) {
+      int ds[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) ds[k] = UX(x_bkt)[min(i0 + k * NT, n_emit - 1)];
+#pragma unroll
+      for (int k = 0; k < kU; k++)
+        if (i0 + k * NT < n_emit && ds[k] >= 0) (void)__hip_atomic_fetch_add(&K[ds[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    LdsSync();
+    XS(10);
+    const int n_multi = LdsExScanInPlace(K, n_b2, sh);
+    LdsSync();
+    XS(11);
+    if (n_multi > kFastMulti) return 2;
+    for (int i0 = tid; i0 < n_emit; i0 += NT * kU) {
+      int ds[kU], rs[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = min(i0 + k * NT, n_emit - 1);
+        ds[k] = UX(x_bkt)[i];
+        rs[k] = xr[i];
+      }
+#pragma unroll
+      for (int k = 0; k < kU; k++)
+        if (i0 + k * NT < n_emit && ds[k] >= 0)
+          V16[__hip_atomic_fetch_add(&K[ds[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = static_cast<uint16_t>(rs[k]);
+    }
+    LdsSync();   // K[d] = end of bucket d's run = start of bucket d + 1's
+    XS(12);
+    for (int i0 = tid; i0 < n; i0 += NT * kU) {
+      int ds[kU], rs[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = min(i0 + k * NT, n - 1);
+        ds[k] = UX(x_bkt)[i];
+        rs[k] = xr[i];
+      }
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = i0 + k * NT, d = ds[k];
+        if (i >= n || d < 0) continue;
+        const int s0 = d > 0 ? static_cast<int>(K[d - 1]) : 0, s1 = static_cast<int>(K[d]);
+        const uint32_t r = i < n_emit ? static_cast<uint32_t>(rs[k]) : 0xFFFFFFFFu;   // (a token of the closure comes after all of them)
+        uint32_t hm = 0xFFFFFFFFu;
+        int inb = 0;
+        for (int m = s0; m < s1; m++) {
+          const uint32_t rr = V16[m];
+          hm = rr < hm ? rr : hm;
+          inb += rr < r ? 1 : 0;
+        }
+        UX(x_h)[i] = static_cast<int>(hm);
+        UX(x_inb)[i] = inb;
+      }
+    }
+  }
+  KhSync();   // (x_h / x_inb / x_epsidx = -1 have reached memory: other lanes read them from here on)
+  XS(13);
+  if (u.phase_cycles != nullptr && tid == 0) sh->phase[56] += 1;
+  SubStamp(u, sh, 48);
+  if (n_new > 0) {
+    // ---- 3. the closure's initial queue: the emitting pass's tokens with epsilon arcs, in the order of the list as it is
+    // BEFORE the closure inserts anything (:766-767) -> x_stack[0, eps_emit) (entries of tmp_epslist).  A few hundred
+    // tokens: their (first-of-bucket rank, rank inside the bucket) pairs go to LDS and every token counts the smaller ones
+    // (all lanes read the same words: broadcasts).  l_dstack[entry] = its pop (the queue is popped from the back).
+    LdsI l_dstack = (LdsI)(LdsKeys(sh) + 2 * kRpNodes);
+    if (eps_emit <= kRpNodes) {
+      for (int j = tid; j < eps_emit; j += NT) {
+        const int i = u.tmp_epslist[j] - nb;
+        V[j] = (static_cast<uint32_t>(UX(x_h)[i]) << 16) | static_cast<uint32_t>(UX(x_inb)[i]);
+      }
+      LdsSync();
+      XS(14);
+      for (int j = tid; j < eps_emit; j += NT) {
+        const uint32_t key = V[j];
+        int rank = 0;
+        int j2 = 0;
+        for (; j2 + 4 <= eps_emit; j2 += 4) {
+          const uint32_t a0 = V[j2], a1 = V[j2 + 1], a2 = V[j2 + 2], a3 = V[j2 + 3];
+          rank += (a0 < key ? 1 : 0) + (a1 < key ? 1 : 0) + (a2 < key ? 1 : 0) + (a3 < key ? 1 : 0);
+        }
+        for (; j2 < eps_emit; j2++) rank += V[j2] < key ? 1 : 0;
+        UX(x_stack)[rank] = j;
+        l_dstack[j] = eps_emit - 1 - rank;
+      }
+    } else if (eps_emit > 1) {
+      PositionsFromHeads(u, n_emit, sh, 20);   // positions among the emitting pass's tokens
+      KhSync();
+      const int pw = (n_emit + 31) >> 5;   // (<= 2048 words)
+      for (int w = tid; w < pw; w += NT) V[w] = 0u;
+      LdsSync();
+      for (int j = tid; j < eps_emit; j += NT) {
+        const uint32_t pe = static_cast<uint32_t>(UX(x_pos)[u.tmp_epslist[j] - nb]);
+        (void)__hip_atomic_fetch_or(&V[pe >> 5], 1u << (pe & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      LdsSync();
+      (void)BitmapPrefix(V, V + kLdsSlots / 2, pw, sh);
+      LdsSync();
+      for (int j = tid; j < eps_emit; j += NT) {
+        const uint32_t pe = static_cast<uint32_t>(UX(x_pos)[u.tmp_epslist[j] - nb]);
+        UX(x_stack)[BitRank(V, V + kLdsSlots / 2, pe)] = j;
+      }
+    }
+    KhSync();
+    XS(18);
+    SubStamp(u, sh, 49);
+    // ---- 4. closure replay: its tables straight into LDS when the frame's epsilon structure fits (it nearly always does)
+    bool in_lds = eps_n <= kRpNodes && nl <= kRpLinks && n_new <= kRpNodes;
+    LdsF l_ncost = (LdsF)LdsKeys(sh);
+    LdsI l_nlr = (LdsI)(LdsKeys(sh) + kRpNodes);
+    LdsI l_newq = (LdsI)(LdsKeys(sh) + 3 * kRpNodes);
+    LdsI l_code = (LdsI)LdsVals(sh);
+    LdsF l_lw = (LdsF)(LdsVals(sh) + kRpLinks);
+    if (in_lds) {
+      for (int j = tid; j < eps_n; j += NT) {
+        const int tok = u.tmp_epslist[j];
+        UX(x_epsidx)[tok - nb] = j;
+        l_ncost[j] = j < eps_emit ? Dec(UX(x_c0e)[j]) : INFINITY;
+        l_nlr[j] = 0;
+      }
+      for (int k = tid; k < n_new; k += NT) l_newq[k] = -1;
+      KhSync();
+      XS(19);
+      constexpr int kLU = 4;
+      for (int l0 = lb + tid; l0 < le; l0 += NT * kLU) {
+        int srcs[kLU], dsts[kLU], arcs[kLU], prevs[kLU], nexts[kLU], js[kLU], es[kLU];
+        float ws[kLU];
+#pragma unroll
+        for (int k = 0; k < kLU; k++) {
+          const int l = min(l0 + k * NT, le - 1);
+          srcs[k] = u.link_src[l];
+          dsts[k] = u.link_dst[l];
+          arcs[k] = u.link_arc[l];
+          prevs[k] = l > lb ? u.link_src[l - 1] : -1;
+          nexts[k] = l + 1 < le ? u.link_src[l + 1] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < kLU; k++) {
+          js[k] = UX(x_epsidx)[srcs[k] - nb];
+          es[k] = dsts[k] >= 0 ? UX(x_epsidx)[dsts[k] - nb] : -1;
+          ws[k] = __int_as_float(p.n_arcs[-1 - arcs[k]].z);
+        }
+#pragma unroll
+        for (int k = 0; k < kLU; k++) {
+          const int l = l0 + k * NT;
+          if (l >= le) continue;
+          int rng = 0;
+          if (prevs[k] != srcs[k]) rng |= l - lb;
+          if (nexts[k] != srcs[k]) rng |= (l - lb + 1) << 16;
+          if (rng != 0) (void)__hip_atomic_fetch_or(&l_nlr[js[k]], rng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          int code = -1;
+          if (dsts[k] >= 0) {
+            if (es[k] >= 0) code = es[k] | ((dsts[k] >= ne_emit ? dsts[k] - ne_emit + 1 : 0) << 12);
+            else if (dsts[k] >= ne_emit) code = 0x40000000 | (dsts[k] - ne_emit);
+          }
+          l_code[l - lb] = code;
+          l_lw[l - lb] = ws[k];
+        }
+      }
+      LdsSync();
+      XS(30);
+      // ---- insertion order without the queue, when the frame's epsilon structure allows it (it does on an HCLG: the
+      // tokens epsilon arcs lead to - language-model states - are all made by the closure, none by the emitting pass).
+      // If no processed link leads to a token of the initial queue, the queue's tokens keep their costs while it runs,
+      // and a token X of the closure is inserted at the FIRST pop p(u) of a queue token u from which a path leads to X
+      // on which every total stays under the cutoff: an arrival that finds a token on the way already as cheap was
+      // preceded by one that went further with totals at least as good.  So every live link of a queue token walks
+      // down its chain (tokens of the closure with ONE live link each) and leaves (pop, depth, first link of the walk)
+      // at every token it reaches, minimum wins; the insertion order is the order of those keys - siblings of one pop in
+      // arc order, then ONE chain by depth.  Anything else (a link into the initial queue, a closure token with two
+      // live links, two chains of one pop with tokens beyond their first, a walk of 30 steps) leaves the frame to the
+      // interpreter of the LIFO queue below.  ~33 insertions per frame took it ~50 us (round-5 stamps), one lane
+      // chasing LDS round trips; this takes a few barriers.
+      bool by_walks = false;
+#ifndef KH_X_NO_WALKS
+      if (n_new <= kRpNodes / 2 && eps_emit <= kRpNodes) {
+        typedef __attribute__((address_space(3))) unsigned long long *LdsU64;
+        const LdsU64 key64 = (LdsU64)l_newq;   // [n_new] over newq (written last)
+        for (int k = tid; k < n_new; k += NT) key64[k] = ~0ull;
+        if (tid == 0) sh->flag = 0;
+        LdsSync();
+        for (int j = tid; j < eps_emit; j += NT) {
+          const float c0 = l_ncost[j];
+          if (c0 > cutoff) continue;   // :779
+          const unsigned long long pop = static_cast<unsigned long long>(l_dstack[j]) << 40;
+          const int r = l_nlr[j];
+          for (int l = r & 0xffff; l < (r >> 16); l++) {
+            int code = l_code[l];
+            if (code < 0) continue;
+            float tot = c0 + l_lw[l];
+            if (!(tot < cutoff)) continue;   // :794
+            for (unsigned long long depth = 1;; depth++) {
+              const bool leaf = (code & 0x40000000) != 0;
+              const int k = leaf ? (code & 0x3fffffff) : (code >> 12) - 1;
+              if (k < 0 || depth > 30) { sh->flag = 1; break; }   // a token of the emitting pass with epsilon arcs: it sits in the queue
+              (void)__hip_atomic_fetch_min(&key64[k], pop | (depth << 32) | static_cast<unsigned long long>(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (leaf) break;
+              const int r2 = l_nlr[code & 0xfff];
+              int l2 = -1;
+              for (int ll = r2 & 0xffff; ll < (r2 >> 16); ll++)
+                if (l_code[ll] >= 0) { if (l2 >= 0) sh->flag = 1; l2 = ll; }
+              if (l2 < 0) break;
+              tot = tot + l_lw[l2];
+              if (!(tot < cutoff)) break;
+              code = l_code[l2];
+            }
+          }
+        }
+        LdsSync();
+        int my_rank = 0;
+        bool bad = false;
+        const int k = tid;   // (n_new <= 1024: a lane per token)
+        if (k < n_new) {
+          const unsigned long long mine = key64[k];
+          bad = mine == ~0ull;
+          const unsigned long long my_pop = mine >> 40, my_depth = (mine >> 32) & 0xffull, my_chain = mine & 0xffffffffull;
+          for (int k2 = 0; k2 < n_new; k2++) {
+            const unsigned long long o = key64[k2];
+            my_rank += o < mine ? 1 : 0;
+            if (k2 != k && (o >> 40) == my_pop) {
+              const unsigned long long od = (o >> 32) & 0xffull;
+              if (od == my_depth && (my_depth >= 2 || o == mine)) bad = true;                      // two tokens of one pop at one depth beyond the first
+              if (my_depth >= 2 && od >= 2 && (o & 0xffffffffull) != my_chain) bad = true;       // two chains of one pop
+            }
+          }
+        }
+        if (bad) sh->flag = 1;
+        LdsSync();
+        by_walks = Uni(sh->flag) == 0;
+        LdsSync();   // (every lane has read the keys and the flag)
+        if (by_walks) {
+          if (k < n_new) l_newq[k] = my_rank;
+          if (tid == 0) sh->x_n_new = n_new;
+        } else {
+          for (int k3 = tid; k3 < n_new; k3 += NT) l_newq[k3] = -1;
+        }
+        if (u.phase_cycles != nullptr && tid == 0) sh->phase[by_walks ? 64 : 65] += 1;
+        LdsSync();
+      }
+#endif
+      if (!by_walks && tid < 64) {
+        const int cnt = ReplayClosureWave(l_ncost, l_nlr, l_dstack, l_newq, l_code, l_lw, UX(x_stack), eps_emit, cutoff, n_new, sh);
+        if (tid == 0) sh->x_n_new = cnt;
+      }
+      LdsSync();
+      XS(31);
+      in_lds = Uni(sh->x_n_new) >= 0;   // (-1: the depth-first stack outgrew LDS - from memory then)
+      if (in_lds) {
+        bool bad = false;
+        for (int k = tid; k < n_new; k += NT) {
+          const int q = l_newq[k];
+          bad |= q < 0;
+          xr[n_emit + k] = n_emit + q;
+        }
+        // every token the closure created was inserted by the replay (the parallel fixed point and the queue reach the same set)
+        if (bad || Uni(sh->x_n_new) != n_new) sh->status = 8;
+      }
+    }
+    if (!in_lds) {
+      KhSync();
+      XS(32);
+      ReplayFromMemory(u, p, nb, fe, lb, le, cutoff, qbase, sh);
+      for (int k = tid; k < n_new; k += NT) xr[n_emit + k] = n_emit + static_cast<int>(UX(x_q)[n_emit + k] - qbase);
+    }
+    LdsSync();
+    XS(33);
+    SubStamp(u, sh, 50);
+    if (Uni(sh->status) != 0) return 0;
+    // ---- 5. the closure's tokens find their bucket mates among themselves: the same x_bkt value = the same bucket
+    // (>= 0: a bucket that holds tokens of the emitting pass - they come behind those; <= -2: a bucket of their own)
+    for (int k = tid; k < n_new; k += NT) {
+      V[k] = static_cast<uint32_t>(UX(x_bkt)[n_emit + k]);
+      V[kFastNew + k] = static_cast<uint32_t>(xr[n_emit + k]);   // (this lane's own store)
+    }
+    LdsSync();
+    XS(34);
+    for (int k = tid; k < n_new; k += NT) {
+      const uint32_t key = V[k], r = V[kFastNew + k];
+      uint32_t minr = r;
+      int before = 0;
+      for (int k2 = 0; k2 < n_new; k2++) {
+        if (V[k2] != key) continue;
+        const uint32_t r2 = V[kFastNew + k2];
+        before += r2 < r ? 1 : 0;
+        minr = r2 < minr ? r2 : minr;
+      }
+      const int i = n_emit + k;
+      if (static_cast<int32_t>(key) >= 0) {
+        UX(x_inb)[i] += before;   // behind the bucket's tokens of the emitting pass (x_h: their first)
+      } else {
+        UX(x_h)[i] = static_cast<int>(minr);
+        UX(x_inb)[i] = before;
+      }
+    }
+    KhSync();
+    XS(35);
+  } else {
+    SubStamp(u, sh, 49);
+    SubStamp(u, sh, 50);
+  }
+  // ---- 6. positions
+  PositionsFromHeads(u, n, sh, 40);
+  KhSync();
+  XS(36);
+  SubStamp(u, sh, 51);
+  return 1;
+}
+
+// List positions (x_pos) of the frame under construction.  Params::exact_order == 2 forces the sort (tests).
+__device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
+  const int n = fe - nb, n_new = fe - Uni(sh->x_ne_emit);
+  const uint32_t H = Uni(sh->x_hsize);
+  const bool fast = p.exact_order == 1 && n >= 1 && n <= kFastN && 2u * ((H + 31u) >> 5) <= static_cast<uint32_t>(kLdsSlots) && n_new <= kFastNew &&
+                    Uni(sh->x_qbase) < 0x7fffffffu;
+  long long t0 = 0;
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    sh->phase[n <= 8160 ? 61 : (n <= 16384 ? 62 : 63)] += 1;
+  }
+  int rc = fast ? OrderFrontierFast(u, p, nb, fe, lb, le, cutoff, sh) : 2;
+  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    const long long t1 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    if (rc == 1) sh->phase[59] += t1 - t0;
+    t0 = t1;
+  }
+  if (rc == 2) {
+    rc = OrderFrontierSort(u, p, nb, fe, lb, le, cutoff, sh) ? 1 : 0;
+    if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+      sh->phase[60] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - t0;
+      sh->phase[57] += 1;
+    }
+  }
+  return rc == 1;
+}
+
+// ProcessEmitting :660-750 with the reference's running cutoff.  Tokens [b, e) with list positions x_pos.
+// ONE sweep over the emitting arcs (round 5; rounds 1-4 read them twice).  The reference accepts arc k of the token at
+// list position q iff tot_cost <= min(R[q], W[k]): R[q] = next_cutoff when the list walk reaches the token = min(estimate,
+// tot_cost + adaptive_beam over the arcs of the tokens before it), W[k] = the same minimum over the token's own arcs
+// before k.  (Rejected arcs never lower the running value: tot > cutoff implies tot + adaptive_beam > cutoff.)
+//   * the sweep knows W[k] (a segmented prefix minimum inside the wave, carried over the token's 64-arc batches) but not
+//     R[q]; it materialises a candidate iff tot_cost <= min(B, W[k]) for an upper bound B >= R[q], and leaves per token
+//     M = min(tot_cost + adaptive_beam) and its arc count;
+//   * B: the list is cut into 16 runs of positions; x_cb[j] = min(estimate, M of the tokens in runs < j seen so far) -
+//     every contributor lies before every position of run j, so whatever subset has been published the value is an upper
+//     bound of R there, and it tightens while the sweep runs (with the estimate alone the sweep would materialise every
+//     arc the estimate admits: the densest part of the beam);
+//   * ONE scan in list order - in LDS, over the position space - turns (M, count) into (R, ordinal of the token's first arc), stored by token;
+//   * a sweep over the CANDIDATES (a quarter of the arcs, coalesced) drops those above R of their source token and gives
+//     each its ordinal; pass 2 is the canonical one.
 __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, int b, int e, float *next_cutoff_out, int *cand_out,
                                      Blk &sh) {
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
@@ -2636,6 +3305,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff<true>(u, p, b, e, sh);
   Stamp(u, sh, 0);
+  const int link_frame_b = Uni(sh->link_end);
   if (threadIdx.x == 0) {
     if (c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
     // PossiblyResizeHash(tok_cnt) :219-225
@@ -2660,19 +3330,41 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   if (threadIdx.x == 0) {
     u.cost_offset[frame] = cost_offset;  // :710-711
     sh->work_cursor = b;
+    sh->link_cursor = link_frame_b;
   }
-  // the sweeps' own copies of the pointers they use (see ProcessEmitting: kept in scalar registers for their duration)
+  // the sweep's own copies of the pointers it uses (see ProcessEmitting: kept in scalar registers for its duration)
   Arr<const KhInt4> x_rec = p.rec;
   Arr<uint32_t> x_cost = u.tok_cost;
   Arr<int32_t> x_state = u.tok_state;
   GP(const float) x_ll = u.ll + static_cast<size_t>(frame) * u.ll_stride;
   int x_ll_cols = p.ll_cols;
-  Arr<int32_t> xp_pos = UX(x_pos), xp_c = UX(x_c);
+  Arr<int32_t> xp_pos = UX(x_pos), xp_c = UX(x_c), xp_ord = UX(x_ord);
   Arr<uint32_t> xp_m = UX(x_m);
+  Arr<int32_t> x_dst = u.link_dst, x_src = u.link_src, x_arc = u.link_arc;
+  Arr<float> x_k = u.link_k, x_a = u.link_a;
+  int x_keep_ac = p.keep_ac;
   KH_LAUNDER_X(x_rec.p); KH_LAUNDER_X(x_cost.p); KH_LAUNDER_X(x_state.p); KH_LAUNDER_X(x_ll); KH_LAUNDER_X(x_ll_cols);
-  KH_LAUNDER_X(xp_pos.p); KH_LAUNDER_X(xp_c.p); KH_LAUNDER_X(xp_m.p);
+  KH_LAUNDER_X(xp_pos.p); KH_LAUNDER_X(xp_c.p); KH_LAUNDER_X(xp_m.p); KH_LAUNDER_X(xp_ord.p);
+  KH_LAUNDER_X(x_dst.p); KH_LAUNDER_X(x_src.p); KH_LAUNDER_X(x_arc.p); KH_LAUNDER_X(x_k.p); KH_LAUNDER_X(x_a.p);
+  KH_LAUNDER_X(x_keep_ac);
   OwnerScan os = OwnerScanInit(sh);
-  const float est0 = BlockMinF(est, sh);   // (its barrier publishes the cursor)
+  const float est0 = BlockMinF(est, sh);   // (its barrier publishes the cursors)
+  XS(59);
+  constexpr int kCB = 16;
+  if (threadIdx.x < kCB) sh->x_cb[threadIdx.x] = Enc(est0);
+  // run of positions a token belongs to: pos >> bshift, at most kCB runs
+  const int bshift = n > kCB ? 32 - __clz(n - 1) - 4 : 0;
+  const int limit = min(u.link_cap, link_frame_b + u.link_frame_cap);
+  // Frames of up to kScanLds tokens: the sweep leaves a token's arc count at its list POSITION in LDS (K[pos]; the area
+  // is idle during the sweep) and marks the few positions whose token has arcs under the bound in a bitmap behind the
+  // counts (their M goes to x_m[pos]); the scan in list order then runs on LDS alone and the candidates read its results
+  // by position.  Larger frames: (M, count) by token through memory, the scan in chunks of 8192 positions.
+  constexpr int kScanLds = kLdsSlots - kLdsSlots / 32;
+  const bool lds_scan = n <= kScanLds;
+  const LdsU32 sK = (LdsU32)LdsKeys(sh);
+  if (lds_scan)
+    for (int w = n + static_cast<int>(threadIdx.x); w < n + ((n + 31) >> 5); w += NT) sK[w] = 0u;
+  LdsSync();
   const int lane = threadIdx.x & 63;
   long long my_arcs = 0;
   // inclusive minimum over the lanes that have the same owner (the lanes of a token are consecutive and `lo` is
@@ -2692,15 +3384,37 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
 #endif
     return m;
   };
-  // ---- sweep 1: per token, min tot_cost over its emitting arcs and their number, by list position
+  // ---- the sweep: candidates under min(bound of the token's run, the token's own earlier arcs); per token M and count.
+  // Nearly every 64-arc batch holds no arc that lowers the cutoff (tot_cost + adaptive_beam under the bound takes an arc
+  // better than the best token's best arc): then W[k] plays no part, the test is `tot_cost <= bound` and the batch costs
+  // what it costs in the canonical sweep.  Only a batch with such an arc runs the segmented scans, and only such arcs
+  // enter M (an arc at or above the bound of its token's run cannot lower R behind it either: M is exact wherever it matters).
+  // A wave holds its next claim (cursor, cost, state, position requested under the current claim's batches).
+  int base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
+  uint32_t co_next = 0u;
+  int st_next = 0, pos_next = 0;
+  if (base_next < e) {
+    const int icn = min(base_next + lane, e - 1);
+    co_next = LoadCostEnc(&x_cost[icn]);
+    st_next = x_state[icn];
+    pos_next = xp_pos[icn - b];
+  }
   for (;;) {
-    const int base = WaveLdsFetchAdd(&sh->work_cursor, 64);
+    const int base = base_next;
     if (base >= e) break;
     const int i = base + lane;
     const bool in_range = i < e;
-    const int ic = min(i, e - 1);
-    const uint32_t co = LoadCostEnc(&x_cost[ic]);
-    int st = x_state[ic];
+    const uint32_t co = co_next;
+    int st = st_next;
+    const int pos = pos_next;
+    const int blk = pos >> bshift;
+    base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
+    if (base_next < e) {
+      const int icn = min(base_next + lane, e - 1);
+      co_next = LoadCostEnc(&x_cost[icn]);
+      st_next = x_state[icn];
+      pos_next = xp_pos[icn - b];
+    }
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= c.cur_cutoff;
     int ab = 0, cnt = 0;
@@ -2708,121 +3422,21 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       ab = st + 1;
       cnt = x_rec[st].x;
     }
+    const float bnd = Dec(__hip_atomic_load(&sh->x_cb[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
     const int total = WaveLast(inc);
-    const int rel = ab - loff;
+    const int rel = ab - loff;   // arc index = rel(owner) + slot
     const float cof = Dec(co);
     os.carry = -1;
-    float acc = inf;
+    float acc = inf;   // min(tot_cost + adaptive_beam) over this token's arcs under the bound, in the batches before the current one
     for (int q0 = 0; q0 < total; q0 += 64) {
       const int q = q0 + lane;
       const bool valid = q < total;
       const int lo = OwnerLane(os, cnt, loff, q0, lane);
       const int o_rel = ShflI(rel, lo);
       const float o_co = ShflF(cof, lo);
-      float m = inf;
-      if (valid) {
-        const KhInt4 arc = x_rec[o_rel + q];
-        int32_t pdf = arc.x;
-        KH_BOUND(7, pdf, 0, u.ll_stride);
-        const float like = x_ll_cols > 0 ? sh.ll_row[pdf] : x_ll[pdf];
-        const float ac = cost_offset - like;
-        m = o_co + ac + __int_as_float(arc.z);  // :726-730
-      }
-      m = seg_min_scan(m, lo);
-      // the token's lane fetches the value at the last of its arcs in this batch
-      const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
-      const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
-      const float got = ShflF(m, has ? tail : 0);
-      if (has) acc = fminf(acc, got);
-    }
-    if (in_range) {
-      const int pos = xp_pos[i - b];
-      xp_m[pos] = Enc(acc + c.adaptive_beam);   // (+inf for a token without arcs or above the cutoff)
-      xp_c[pos] = cnt;
-    }
-    if (lane == 0) my_arcs += total;
-  }
-  KhSync();
-  // ---- ONE scan in list order: the running next_cutoff in front of every token (it starts at the estimate) and the
-  // ordinal of its first arc
-  uint32_t run_min = Enc(est0);
-  int run_sum = 0;
-  constexpr int kSU = 4;   // chunks of NT positions whose loads are in flight together (the scans themselves are sequential)
-  for (int base0 = 0; base0 < n; base0 += NT * kSU) {
-    uint32_t ms[kSU];
-    int cs[kSU];
-#pragma unroll
-    for (int k = 0; k < kSU; k++) {
-      const int q = base0 + k * NT + threadIdx.x;
-      ms[k] = q < n ? xp_m[q] : 0xFFFFFFFFu;
-      cs[k] = q < n ? xp_c[q] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < kSU; k++) {
-      if (base0 + k * NT >= n) break;   // (uniform)
-      const int q = base0 + k * NT + threadIdx.x;
-      int ex_sum, tot_sum;
-      uint32_t ex_min, tot_min;
-      BlockExScanSumMin(cs[k], ms[k], &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
-      if (q < n) {
-        xp_m[q] = run_min < ex_min ? run_min : ex_min;
-        xp_c[q] = run_sum + ex_sum;
-      }
-      run_min = run_min < tot_min ? run_min : tot_min;
-      run_sum += tot_sum;
-    }
-  }
-  const float next_cutoff = Dec(run_min);   // the value the running cutoff ends at
-  Stamp(u, sh, 1);
-  // ---- sweep 2: accept arc k of a token against min(running cutoff in front of the token, its arcs before k), in
-  // arc order (:728-733); only accepted candidates are materialised, each with its ordinal
-  const int link_frame_b = Uni(sh->link_end);
-  const int limit = min(u.link_cap, link_frame_b + u.link_frame_cap);
-  if (threadIdx.x == 0) {
-    sh->link_cursor = link_frame_b;
-    sh->work_cursor = b;
-    sh->x_qbase = static_cast<uint32_t>(run_sum);
-  }
-  Arr<int32_t> x_dst = u.link_dst, x_src = u.link_src, x_arc = u.link_arc, xp_ord = UX(x_ord);
-  Arr<float> x_k = u.link_k, x_a = u.link_a;
-  int x_keep_ac = p.keep_ac;
-  KH_LAUNDER_X(x_dst.p); KH_LAUNDER_X(x_src.p); KH_LAUNDER_X(x_arc.p); KH_LAUNDER_X(xp_ord.p); KH_LAUNDER_X(x_k.p); KH_LAUNDER_X(x_a.p);
-  KH_LAUNDER_X(x_keep_ac);
-  KhSync();
-  for (;;) {
-    const int base = WaveLdsFetchAdd(&sh->work_cursor, 64);
-    if (base >= e) break;
-    const int i = base + lane;
-    const bool in_range = i < e;
-    const int ic = min(i, e - 1);
-    const uint32_t co = LoadCostEnc(&x_cost[ic]);
-    int st = x_state[ic];
-    KH_BOUND(1, st, 0, 0x7ffffff0);
-    const bool need = in_range && Dec(co) <= c.cur_cutoff;
-    int ab = 0, cnt = 0;
-    if (need) {
-      ab = st + 1;
-      cnt = x_rec[st].x;
-    }
-    const int pos = xp_pos[ic - b];
-    const float r_tok = Dec(xp_m[pos]);
-    const int a_tok = xp_c[pos];
-    const int inc = WaveIncSum(cnt);
-    const int loff = inc - cnt;
-    const int total = WaveLast(inc);
-    const int rel = ab - loff, arel = a_tok - loff;   // arc index / candidate ordinal = (...)(owner) + slot
-    const float cof = Dec(co);
-    os.carry = -1;
-    float acc = inf;   // min(tot_cost + adaptive_beam) over this token's arcs in the batches before the current one
-    for (int q0 = 0; q0 < total; q0 += 64) {
-      const int q = q0 + lane;
-      const bool valid = q < total;
-      const int lo = OwnerLane(os, cnt, loff, q0, lane);
-      const int o_rel = ShflI(rel, lo), o_arel = ShflI(arel, lo);
-      const float o_co = ShflF(cof, lo);
-      const float o_racc = ShflF(fminf(r_tok, acc), lo);   // running cutoff in front of the token, lowered by its arcs in earlier batches
+      const float o_racc = ShflF(fminf(bnd, acc), lo);   // bound in front of the token, lowered by its arcs in earlier batches
       KhInt4 arc;
       arc.x = 0; arc.y = 0; arc.z = 0; arc.w = 0;
       float tot = inf, ac = 0.0f;
@@ -2835,24 +3449,27 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         ac = cost_offset - like;
         tot = o_co + ac + __int_as_float(arc.z);  // :726-730
       }
-      float m = tot + c.adaptive_beam;   // what this arc lowers next_cutoff to (:732-733)
-      if (!(m == m)) m = inf;            // (a NaN never lowers it)
-      m = seg_min_scan(m, lo);
+      const float m0 = tot + c.adaptive_beam;   // what this arc lowers next_cutoff to (:732-733)
+      bool keep = valid && !(tot > o_racc) && tot == tot;   // :731 against an upper bound (a NaN candidate is dropped, as in the canonical rule)
+      if (__ballot(valid && m0 < o_racc) != 0ull) {
+        // some arc of the batch lowers the cutoff in front of the arcs behind it: the token's own earlier arcs count
+        float m = (m0 == m0) ? m0 : inf;   // (a NaN never lowers it)
+        m = seg_min_scan(m, lo);
 #ifndef KH_NO_DPP
-      const float pm = __int_as_float(DppMov<0x138, 0xf>(0x7f800000, __float_as_int(m)));   // wave_shr:1
-      const int plo = DppMov<0x138, 0xf>(-2, lo);
-      const float before = plo == lo ? pm : inf;
+        const float pm = __int_as_float(DppMov<0x138, 0xf>(0x7f800000, __float_as_int(m)));   // wave_shr:1
+        const int plo = DppMov<0x138, 0xf>(-2, lo);
+        const float before = plo == lo ? pm : inf;
 #else
-      const float pm = __shfl_up(m, 1, 64);
-      const int plo = __shfl_up(lo, 1, 64);
-      const float before = (lane >= 1 && plo == lo) ? pm : inf;
+        const float pm = __shfl_up(m, 1, 64);
+        const int plo = __shfl_up(lo, 1, 64);
+        const float before = (lane >= 1 && plo == lo) ? pm : inf;
 #endif
-      const float running = fminf(o_racc, before);
-      const bool keep = valid && !(tot > running) && tot == tot;   // :731 (a NaN candidate is dropped, as in the canonical rule)
-      const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
-      const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
-      const float got = ShflF(m, has ? tail : 0);
-      if (has) acc = fminf(acc, got);
+        keep = keep && !(tot > before);
+        const bool has = cnt > 0 && loff < q0 + 64 && loff + cnt > q0;
+        const int tail = min(loff + cnt, q0 + 64) - 1 - q0;
+        const float got = ShflF(m, has ? tail : 0);
+        if (has) acc = fminf(acc, got);
+      }
       const unsigned long long kb = __ballot(keep);
       if (kb != 0ull) {
         const int n_keep = __popcll(kb);
@@ -2866,37 +3483,229 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           x_arc[l] = ai;
           if (x_keep_ac) x_a[l] = ac;
           x_k[l] = tot;
-          xp_ord[l - link_frame_b] = o_arel + q;
         }
       }
     }
+    if (in_range) {
+      const uint32_t me = Enc(acc);   // (+inf for a token none of whose arcs came under the bound)
+      if (lds_scan) {
+        sK[pos] = static_cast<uint32_t>(cnt);
+        if (me < kEncInf) {
+          xp_m[pos] = me;
+          (void)__hip_atomic_fetch_or(&sK[n + (pos >> 5)], 1u << (pos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        xp_m[i - b] = me;
+        xp_c[i - b] = cnt;
+      }
+#ifndef KH_X_NO_RUN_BOUND
+      if (me < kEncInf) {
+#pragma nounroll
+        for (int jj = blk + 1; jj < kCB; jj++) {
+          const uint32_t old = __hip_atomic_fetch_min(&sh->x_cb[jj], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (old <= me) break;   // (whoever put that value there carries it on to the runs behind)
+        }
+      }
+#endif
+    }
+    if (lane == 0) my_arcs += total;
   }
   KhSync();
+  XS(60);
   if (Uni(sh->status) != 0) return false;
   const int link_frame_e = Uni(sh->link_cursor);
-  if (threadIdx.x == 0) {
+  const int tid = OpaqueTid();
+  // ---- the scan in list order, in LDS over the POSITION space: every token puts (M, arc count) at its position, one
+  // exclusive (min, sum) scan over the positions gives the running next_cutoff in front of every token (it starts at the
+  // estimate) and the ordinal of its first arc, and the token takes them back: x_m = that cutoff, x_c = the ordinal of
+  // its first arc minus the index of that arc (a candidate's ordinal = its arc index + x_c of its source).  No gather
+  // through the inverse permutation, no workgroup scan per 1024 positions.  8192 positions at a time.
+  uint32_t run_min = Enc(est0);
+  int run_sum = 0;
+  if (lds_scan) {
+    // counts at K[0, n), the bitmap of positions with a finite M behind them; a lane owns eight consecutive positions
+    const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);   // (the score row is not read again in this frame)
+    constexpr int kPer = kLdsSlots / NT;
+    static_assert(kPer == 8, "a lane's positions are one byte of the bitmap");
+    const int w0 = tid * kPer;
+    uint32_t mm[kPer], lane_min = 0xFFFFFFFFu;
+    int cc[kPer], lane_sum = 0;
+    const uint32_t bits = w0 < n ? (K[n + (w0 >> 5)] >> (w0 & 31)) & 0xffu : 0u;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const uint32_t kv = K[w0 + j];   // (unguarded: inside the area)
+      cc[j] = w0 + j < n ? static_cast<int>(kv) : 0;
+      mm[j] = 0xFFFFFFFFu;
+      lane_sum += cc[j];
+    }
+    if (bits != 0u) {   // (rare: a token with arcs under the bound of its run)
+#pragma unroll
+      for (int j = 0; j < kPer; j++)
+        if (((bits >> j) & 1u) != 0u) {
+          mm[j] = xp_m[w0 + j];
+          lane_min = mm[j] < lane_min ? mm[j] : lane_min;
+        }
+    }
+    int ex_sum, tot_sum;
+    uint32_t ex_min, tot_min;
+    BlockExScanSumMin(lane_sum, lane_min, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);   // (its barrier: every lane has read its counts and bits)
+    uint32_t rm = run_min < ex_min ? run_min : ex_min;
+    int rs = ex_sum;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      if (w0 + j < n) { V[w0 + j] = rm; K[w0 + j] = static_cast<uint32_t>(rs); }
+      rm = mm[j] < rm ? mm[j] : rm;
+      rs += cc[j];
+    }
+    run_min = run_min < tot_min ? run_min : tot_min;
+    run_sum = tot_sum;
+    LdsSync();
+  } else {
+    const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);   // (the score row is not read again in this frame)
+    constexpr int kTU = 4, kPer = kLdsSlots / NT;
+    for (int p0 = 0; p0 < n; p0 += kLdsSlots) {
+      const uint32_t W = static_cast<uint32_t>(min(kLdsSlots, n - p0));
+      for (int i0 = tid; i0 < n; i0 += NT * kTU) {
+        int ps[kTU], cs[kTU];
+        uint32_t ms[kTU];
+#pragma unroll
+        for (int k = 0; k < kTU; k++) {
+          const int i = min(i0 + k * NT, n - 1);
+          ps[k] = xp_pos[i];
+          ms[k] = xp_m[i];
+          cs[k] = xp_c[i];
+        }
+#pragma unroll
+        for (int k = 0; k < kTU; k++) {
+          const uint32_t at = static_cast<uint32_t>(ps[k] - p0);
+          if (i0 + k * NT < n && at < W) { K[at] = ms[k]; V[at] = static_cast<uint32_t>(cs[k]); }
+        }
+      }
+      LdsSync();
+      {
+        uint32_t mm[kPer], lane_min = 0xFFFFFFFFu;
+        int cc[kPer], lane_sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+          const uint32_t w = tid * kPer + j;
+          const uint32_t kv = K[w], vv = V[w];   // (unguarded: the reads go out together)
+          mm[j] = w < W ? kv : 0xFFFFFFFFu;
+          cc[j] = w < W ? static_cast<int>(vv) : 0;
+          lane_min = mm[j] < lane_min ? mm[j] : lane_min;
+          lane_sum += cc[j];
+        }
+        int ex_sum, tot_sum;
+        uint32_t ex_min, tot_min;
+        BlockExScanSumMin(lane_sum, lane_min, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);
+        uint32_t rm = run_min < ex_min ? run_min : ex_min;
+        int rs = run_sum + ex_sum;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+          const uint32_t w = tid * kPer + j;
+          if (w < W) { K[w] = rm; V[w] = static_cast<uint32_t>(rs); }
+          rm = mm[j] < rm ? mm[j] : rm;
+          rs += cc[j];
+        }
+        run_min = run_min < tot_min ? run_min : tot_min;
+        run_sum += tot_sum;
+      }
+      LdsSync();
+      for (int i0 = tid; i0 < n; i0 += NT * kTU) {
+        int ps[kTU], sts[kTU];
+#pragma unroll
+        for (int k = 0; k < kTU; k++) {
+          const int i = min(i0 + k * NT, n - 1);
+          ps[k] = xp_pos[i];
+          sts[k] = x_state[b + i];
+        }
+#pragma unroll
+        for (int k = 0; k < kTU; k++) {
+          const uint32_t at = static_cast<uint32_t>(ps[k] - p0);
+          if (i0 + k * NT < n && at < W) {
+            xp_m[i0 + k * NT] = K[at];
+            xp_c[i0 + k * NT] = static_cast<int>(V[at]) - (sts[k] + 1);
+          }
+        }
+      }
+      LdsSync();
+    }
+  }
+  const float next_cutoff = Dec(run_min);   // the value the running cutoff ends at
+  XS(61);
+  if (tid == 0) {
+    sh->x_qbase = static_cast<uint32_t>(run_sum);
     u.femit_b[frame] = link_frame_b;
     u.femit_e[frame] = link_frame_e;
     sh->link_end = link_frame_e;
     sh->front_b = nb;
   }
   KhSync();
-  // ---- pass 2: FindOrAddToken + minimum cost in the LDS token table, as in the canonical sweep (every candidate here
+  // ---- the candidates against the running cutoff in front of their source token (:731); ordinals
+  int n_acc = 0;
+  {
+    constexpr int kOU = 4;
+    for (int l0 = link_frame_b + tid; l0 < link_frame_e; l0 += NT * kOU) {
+      float ks[kOU];
+      int srcs[kOU], ords[kOU], as[kOU];
+      uint32_t rs[kOU];
+#pragma unroll
+      for (int k = 0; k < kOU; k++) {
+        const int l = min(l0 + k * NT, link_frame_e - 1);
+        ks[k] = x_k[l];
+        srcs[k] = x_src[l];
+        ords[k] = x_arc[l];
+      }
+      if (lds_scan) {   // the scan's results by list position: V = the running cutoff, K = the ordinal of the token's first arc
+        const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);
+        int ps[kOU], sts[kOU];
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          ps[k] = xp_pos[srcs[k] - b];
+          sts[k] = x_state[srcs[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          rs[k] = V[ps[k]];
+          as[k] = static_cast<int>(K[ps[k]]) - (sts[k] + 1);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          rs[k] = xp_m[srcs[k] - b];
+          as[k] = xp_c[srcs[k] - b];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kOU; k++) {
+        const int l = l0 + k * NT;
+        if (l >= link_frame_e) continue;
+        if (ks[k] > Dec(rs[k])) x_dst[l] = -1;   // the reference's `continue`: nothing was made of this arc
+        else n_acc++;
+        xp_ord[l - link_frame_b] = ords[k] + as[k];
+      }
+    }
+  }
+  n_acc = static_cast<int>(BlockSumLL(n_acc, sh));   // (its barrier: the dead candidates and the ordinals are in place)
+  if (u.phase_cycles != nullptr && tid == 0) sh->phase[58] += n_acc;
+  XS(62);
+  Stamp(u, sh, 1);
+  // ---- pass 2: FindOrAddToken + minimum cost in the LDS token table, as in the canonical sweep (every live candidate
   // has been accepted: no cutoff test)
-  if (!EmitPass2<true>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf)) return false;
+  if (!EmitPass2<true>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf, n_acc)) return false;
+  XS(63);
   // ---- the insertion key of a new token = the smallest ordinal among its candidates (the arc that made the reference
   // call HashList::Insert for it); its cost before the closure
   {
     const int n_new = Uni(sh->tok_end) - nb;
     auto qtab = LdsKeys(sh);
     const bool in_lds = n_new <= kLdsSlots;
-    for (int i = threadIdx.x; i < n_new; i += NT) {
+    for (int i = tid; i < n_new; i += NT) {
       if (in_lds) qtab[i] = 0xFFFFFFFFu; else UX(x_q)[i] = 0xFFFFFFFFu;
     }
     KhSync();
     {
       constexpr int kOU = 4;   // (a lane's loads of four trips in flight together)
-      for (int l0 = link_frame_b + threadIdx.x; l0 < link_frame_e; l0 += NT * kOU) {
+      for (int l0 = link_frame_b + tid; l0 < link_frame_e; l0 += NT * kOU) {
         int dsts[kOU];
         uint32_t ords[kOU];
 #pragma unroll
@@ -2907,27 +3716,25 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         }
 #pragma unroll
         for (int k = 0; k < kOU; k++) {
-          if (l0 + k * NT >= link_frame_e || dsts[k] < 0) continue;   // (dst < 0: a dropped NaN candidate)
+          if (l0 + k * NT >= link_frame_e || dsts[k] < 0) continue;   // (dst < 0: rejected by the running cutoff)
           if (in_lds) (void)__hip_atomic_fetch_min(&qtab[dsts[k] - nb], ords[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           else (void)__hip_atomic_fetch_min(&UX(x_q)[dsts[k] - nb], ords[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
-    KhSync();
-    for (int i = threadIdx.x; i < n_new; i += NT) {
-      if (in_lds) UX(x_q)[i] = qtab[i];
-      UX(x_cost0)[i] = u.tok_cost[nb + i];
-    }
+    LdsSync();
+    if (in_lds)
+      for (int i = tid; i < n_new; i += NT) UX(x_q)[i] = qtab[i];
   }
-  KhSync();
-  const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) {
+  const long long tot_arcs = BlockSumLL(my_arcs, sh);   // (its barrier waits for the stores above)
+  if (tid == 0) {
     sh->arcs_expanded += tot_arcs;
     sh->wl_n[0] = sh->eps_n;
     sh->x_eps_emit = sh->eps_n;
     sh->x_ne_emit = sh->tok_end;
   }
   KhSync();
+  XS(58);
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
   *cand_out = link_frame_e - link_frame_b;
@@ -3971,7 +4778,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->wl_n[1] = 0;
     if (kExact) {   // the start token is the first insertion (:66) into a table of 1000 buckets (:37)
       UX(x_q)[0] = 0u;
-      UX(x_cost0)[0] = Enc(0.0f);
+      UX(x_c0e)[0] = Enc(0.0f);
       sh->x_hsize = 1000u;
       sh->x_qbase = 1u;
       sh->x_ne_emit = sh->tok_end;
@@ -4974,7 +5781,6 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
     x.x_m = c.Take<uint32_t>(tf);
     x.x_c = c.Take<int32_t>(tf);
     x.x_q = c.Take<uint32_t>(tf);
-    x.x_cost0 = c.Take<uint32_t>(tf);
     x.x_bkt = c.Take<int32_t>(tf);
     x.x_epsidx = c.Take<int32_t>(tf);
     x.x_nl0 = c.Take<int32_t>(tf);
@@ -4988,6 +5794,9 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
     x.x_key1 = c.Take<unsigned long long>(tf);
     x.x_val0 = c.Take<int32_t>(tf);
     x.x_val1 = c.Take<int32_t>(tf);
+    x.x_h = c.Take<int32_t>(tf);
+    x.x_inb = c.Take<int32_t>(tf);
+    x.x_c0e = c.Take<uint32_t>(tf);
     if (xo) *xo = x;
   }
   u.ll = (GP(const float))nullptr;
@@ -5677,8 +6486,17 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
     if (tot[k] && (k < 10 || k == 15)) fprintf(stderr, " %s=%.1f%%", names[k], 100.0 * tot[k] / all);
   if (tot[47]) fprintf(stderr, " [per frame: %.0f tokens, %.0f with epsilon arcs from the emitting pass, %.0f in all, %.0f epsilon link slots, %.0f tokens from the closure]",
                        double(tot[46]) / tot[47], double(tot[52]) / tot[47], double(tot[53]) / tot[47], double(tot[54]) / tot[47], double(tot[55]) / tot[47]);
-  if (tot[45]) fprintf(stderr, " list_order=%.1f%% (buckets + replay tables %.1f%%, queue sort %.1f%%, replay %.1f%%, list sort %.1f%% of it)", 100.0 * tot[45] / all,
-                       100.0 * tot[48] / tot[45], 100.0 * tot[49] / tot[45], 100.0 * tot[50] / tot[45], 100.0 * tot[51] / tot[45]);
+  if (tot[45]) fprintf(stderr, " list_order=%.1f%% (ranks + buckets %.1f%%, queue order %.1f%%, replay %.1f%%, positions %.1f%% of it; %lld frames from LDS, %lld by the sort; "
+                       "%lld of the %lld candidates under the running cutoff)", 100.0 * tot[45] / all,
+                       100.0 * tot[48] / tot[45], 100.0 * tot[49] / tot[45], 100.0 * tot[50] / tot[45], 100.0 * tot[51] / tot[45], tot[56], tot[57], tot[58], tot[31]);
+  if (tot[45]) fprintf(stderr, " [frames of <= 8160 / <= 16384 / more tokens: %lld / %lld / %lld; cycles per frame from LDS %.0f, by the sort %.0f; closure order by walks in %lld frames, by the queue in %lld]",
+                       tot[61], tot[62], tot[63], tot[56] ? double(tot[59]) / tot[56] : 0.0, tot[57] ? double(tot[60]) / tot[57] : 0.0, tot[64], tot[65]);
+#ifdef KH_X_STAMPS
+  if (tot[47]) {
+    fprintf(stderr, "\n[kh_decoder profile] fine stamps, cycles per frame:");
+    for (int k = 0; k < 64; k++) if (tot[96 + k]) fprintf(stderr, " %d:%.0f", k, double(tot[96 + k]) / tot[47]);
+  }
+#endif
   fprintf(stderr, "\n[kh_decoder profile] PruneActiveTokens calls %lld, frames pruned %lld (%.1f per call), tokens scanned "
           "per pruned frame %.0f, eps iterations per pruned frame %.2f, eps-closure rounds %lld\n",
           tot[12], tot[10], tot[12] ? double(tot[10]) / tot[12] : 0.0, tot[10] ? double(tot[11]) / tot[10] : 0.0,
@@ -6026,6 +6844,9 @@ int kh_decoder_decode(KhDecoder *d, const float *loglikes, int ll_stride,
     if (const char *e = getenv("KH_DECODER_ORDER")) ex = strcmp(e, "reference") == 0 ? 1 : (strcmp(e, "canonical") == 0 ? 0 : ex);
     d->exact = ex;
     p.exact_order = ex;
+    // KH_DECODER_ORDER_SORT=1: list positions by the comparison-free radix sort of rounds 4 (OrderFrontierSort) in every
+    // frame - the path frames beyond the LDS construction's capacity take; the tests run the suites through it
+    if (ex && getenv("KH_DECODER_ORDER_SORT") != nullptr && atoi(getenv("KH_DECODER_ORDER_SORT")) != 0) p.exact_order = 2;
   }
   if ((rc = BuildArcPdf(d, &p, tid2pdf, ll_stride, Stream()))) return rc;
   if (!d->ev0) {

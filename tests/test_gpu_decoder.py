@@ -385,7 +385,7 @@ def test_lazy_schedule_large_frames_and_many_survivors(api):
     assert c["general_final_visits"] > 0 and c["handoffs_through_memory"] > 0 and c["dense_final_visits"] > 0, c
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "16"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "100"))))
 def test_random_configurations(api, seed, monkeypatch):
     """Random graphs and LatticeFasterDecoderConfig values (tiny max_active, prune_interval
     down to 1, lattice_beam below the beam_delta, epsilon-free and epsilon-heavy graphs,

@@ -5,7 +5,7 @@ LatticeFasterDecoder with its HashList order (hash-list-inl.h:118-147), running 
 delta-tolerant prune sweeps (:296-343) — not against the order-independent rule the default mode implements.
 
 Covered: the hand-picked configurations of test_gpu_decoder.py (max-active binding, min-active, tiny prune
-intervals, no final state, epsilon-heavy), random graphs / options (KH_FUZZ_SEEDS, default 24; the round's
+intervals, no final state, epsilon-heavy), random graphs / options (KH_FUZZ_SEEDS, default 100; the round's
 record is in DESIGN.md), config 3 and config 4 on the HCLG-structured workload through the real forward
 pass, and a slice of bench.py's own shard."""
 import importlib
@@ -107,7 +107,31 @@ def test_interval_schedule_and_small_slots(api, monkeypatch):
     run_exact(api, g, lls, cfg)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "24"))))
+def test_list_order_by_the_sort(api, monkeypatch):
+    """KH_DECODER_ORDER_SORT=1: every frame's list positions by the radix sort (OrderFrontierSort) instead of the LDS
+    construction from dense ranks - the path frames beyond the LDS capacity take; the same lattices."""
+    monkeypatch.setenv("KH_DECODER_ORDER_SORT", "1")
+    rng = np.random.default_rng(3)
+    g = graph_like_hclg(rng, 100000, 1000)
+    run_exact(api, g, [workloads.make_loglikes(rng, T, 1000) for T in (60, 37)],
+              api.decoder_config(beam=15.0, max_active=2000, min_active=200, lattice_beam=8.0))
+    rng = np.random.default_rng(6)
+    g = graph_like_hclg(rng, 8000, 80, eps_frac=0.45, mean_degree=3.5)
+    run_exact(api, g, [workloads.make_loglikes(rng, 64, 80)], api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
+
+
+def test_frames_beyond_the_lds_construction(api):
+    """Frames of more than 8160 tokens (the LDS construction's capacity) inside an utterance whose other frames fit:
+    both list-order paths in one decode, hash sizes growing on the way."""
+    rng = np.random.default_rng(11)
+    g = graph_like_hclg(rng, 300000, 1000, mean_degree=3.0)
+    lls = [workloads.make_loglikes(rng, T, 1000) for T in (40, 25)]
+    cfg = api.decoder_config(beam=16.0, max_active=30000, min_active=200, lattice_beam=6.0)
+    dec = run_exact(api, g, lls, cfg)
+    assert max(dec.stats(u)["max_tokens_frame"] for u in range(2)) > 8160
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "100"))))
 def test_random_configurations(api, seed, monkeypatch):
     """test_gpu_decoder.py's fuzz (random graphs, tiny max_active, prune_interval down to 1, epsilon-free and
     epsilon-heavy graphs, one-frame utterances, more utterances than slots), held to the reference ORDER."""
@@ -131,6 +155,8 @@ def test_random_configurations(api, seed, monkeypatch):
         monkeypatch.setenv("KH_DECODER_SLOTS", str(int(rng.integers(1, 4))))
     if seed % 3 == 1:
         monkeypatch.setenv("KH_DECODER_CLOSURE_CAP", str([0, 2, 25][(seed // 3) % 3]))
+    if seed % 5 == 4:
+        monkeypatch.setenv("KH_DECODER_ORDER_SORT", "1")
     run_exact(api, g, lls, cfg)
 
 
