@@ -75,7 +75,10 @@ namespace {
 #endif
 constexpr int NT = KH_NT;          // threads per workgroup (one utterance)
 constexpr int NW = NT / 64;        // waves
-constexpr int NPH = 160;           // diagnostic counters per slot (96 on: the fine stamps of -DKH_X_STAMPS builds)
+#ifndef KH_NPH
+#define KH_NPH 160
+#endif
+constexpr int NPH = KH_NPH;        // diagnostic counters per slot (96 on: the fine stamps of -DKH_X_STAMPS builds)
 // Arc records carry, in bit 30 of the next state, whether that state has epsilon
 // arcs: a token knows it at creation without touching the graph again.
 constexpr int32_t kHasEps = 0x40000000, kStateMask = 0x1fffffff;
@@ -415,7 +418,8 @@ struct Shared {
   int flag;
   int bcast_i[4];
   float bcast_f[8];
-  alignas(16) unsigned int hist[1 << 11];   // RadixSelect digit histogram (kRadixBits); 16-byte aligned: the areas laid over it take 64-bit LDS atomics
+  unsigned int hist[1 << 11];   // RadixSelect digit histogram (kRadixBits).  (NOT alignas(16): same-box A/B in round 5, the canonical kernel 554 -> 603 ms with the
+                                    // array moved to a 16-byte boundary - every LDS array behind it moves with it)
   int ex_off[EU * NT], ex_ab[EU * NT], ex_tok[EU * NT];  // ExpandSweep: first link slot, first arc, token of the group's items
   // running state (owned by thread 0, read after barriers)
   int tok_end, link_end;
@@ -472,7 +476,6 @@ struct Blk {
 constexpr int kLdsSlots = 8192;
 static_assert(sizeof(unsigned int) * (1 << 11) + 3 * sizeof(int) * EU * NT >= sizeof(uint32_t) * kLdsSlots,
               "the LDS token table's keys are laid over hist + ex_off + ex_ab + ex_tok");
-static_assert(offsetof(Shared, hist) % 16 == 0, "the LDS token-table area is 16-byte aligned (64-bit LDS atomics on it)");
 static_assert(offsetof(Shared, ex_off) == offsetof(Shared, hist) + sizeof(unsigned int) * (1 << 11) &&
               offsetof(Shared, ex_ab) == offsetof(Shared, ex_off) + sizeof(int) * EU * NT &&
               offsetof(Shared, ex_tok) == offsetof(Shared, ex_ab) + sizeof(int) * EU * NT, "contiguous LDS arrays");
@@ -3120,9 +3123,10 @@ __device__ int OrderFrontierFast(const Utt &u, const Params &p, int nb, int fe, 
       // chasing LDS round trips; this takes a few barriers.
       bool by_walks = false;
 #ifndef KH_X_NO_WALKS
-      if (n_new <= kRpNodes / 2 && eps_emit <= kRpNodes) {
+      if (n_new < kRpNodes / 2 && eps_emit <= kRpNodes) {
         typedef __attribute__((address_space(3))) unsigned long long *LdsU64;
-        const LdsU64 key64 = (LdsU64)l_newq;   // [n_new] over newq (written last)
+        // [n_new] over newq (written last); the area starts on a 4-byte boundary: the 64-bit atomics need 8
+        const LdsU64 key64 = (LdsU64)(l_newq + ((reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)l_newq) >> 2) & 1u));
         for (int k = tid; k < n_new; k += NT) key64[k] = ~0ull;
         if (tid == 0) sh->flag = 0;
         LdsSync();
@@ -3271,7 +3275,12 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     t0 = t1;
   }
   if (rc == 2) {
+#ifdef KH_X_NO_SORT
+    if (threadIdx.x == 0) sh->status = 9;
+    rc = 0;
+#else
     rc = OrderFrontierSort(u, p, nb, fe, lb, le, cutoff, sh) ? 1 : 0;
+#endif
     if (u.phase_cycles != nullptr && threadIdx.x == 0) {
       sh->phase[60] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - t0;
       sh->phase[57] += 1;
