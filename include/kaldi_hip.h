@@ -33,6 +33,7 @@ extern "C" {
 #define KH_ENOMEM (-3)
 #define KH_ESTATE (-4)   /* call sequence violation */
 #define KH_ECAPACITY (-5) /* a decoder arena overflowed; see message */
+#define KH_ETIMEOUT (-6)  /* a wait for the device ran past its deadline (serving kernel); kh_last_error() holds the streams' state */
 
 /* cudamatrix/cu-matrixdim.h:49-53 */
 typedef struct KhMatrixDim {
@@ -478,11 +479,18 @@ int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *dec, int enable);
  * runs after the frames published so far).  kh_online_decoder_serve_publish: frames [0, avail[i]) of stream streams[i]
  * have their scores in the buffer - the kernels that wrote them must have COMPLETED - and the stream decodes up to
  * there.  kh_online_decoder_serve_poll: NumFramesDecoded() so far and whether a request is still in flight (either
- * may be NULL); kh_online_decoder_serve_wait: blocks until the listed streams have caught up (timeout_ms <= 0: 60 s);
+ * may be NULL); kh_online_decoder_serve_wait: blocks until the listed streams have caught up (timeout_ms <= 0:
+ * KH_SERVE_TIMEOUT_MS, default 30 s);
  * afterwards the getters (kh_online_decoder_get_best_path, _get_raw_lattice, _get_stats) may be used on them while the
- * kernel keeps serving the others.  kh_online_decoder_serve_stop: the kernel leaves (it also leaves by itself after
- * 2 s without work, KH_SERVE_IDLE_MS, and is launched again by the next request: a device-wide synchronisation never
- * waits longer than that); the launch-per-job calls work again.  Results are those of the launch-per-job calls. */
+ * kernel keeps serving the others.  kh_online_decoder_serve_stop: the kernel leaves (the grid also leaves by itself - as a
+ * whole, never one stream's workgroup alone - once EVERY stream has been without work for 2 s, KH_SERVE_IDLE_MS, and is
+ * launched again by the next request or poll that finds work: a device-wide synchronisation never waits longer than that);
+ * the launch-per-job calls work again.  Results are those of the launch-per-job calls.
+ * No call blocks for ever: every wait for the device has a deadline (the timeout argument of _serve_wait;
+ * KH_SERVE_TIMEOUT_MS for _serve_stop and the relaunch), after which it returns KH_ETIMEOUT and kh_last_error() holds the
+ * control blocks of the streams concerned - frames published / decoded, command and acknowledgement numbers, whether the
+ * stream's workgroup is resident and what it was doing (InitDecoding / AdvanceDecoding to which frame / FinalizeDecoding)
+ * when it last reported. */
 int kh_online_decoder_serve_start(KhOnlineDecoder *dec, const float *loglikes, int ll_stride, int64_t rows_per_stream,
                                   const int32_t *tid2pdf);
 int kh_online_decoder_serve_stop(KhOnlineDecoder *dec);

@@ -5373,16 +5373,28 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
 // launch lasts as long as its slowest workgroup, and with streams out of phase some workgroup prunes in every launch).
 // Commands (cmd_seq / cmd_op): InitDecoding has priority over pending frames, FinalizeDecoding runs after them.  After
 // every action the slot's state is saved to memory (SlotState + arenas, agent-scope fence) before it is acknowledged, so
-// an export job of OnlineKernel - launched by the host while this workgroup idles - sees it.  A workgroup leaves when the
-// host sets *quit, or after idle_ticks (wall clock, 100 MHz) without work: the kernel can never outlive its caller by
-// more than that (a device-wide synchronisation waits that long at most).
+// an export job of OnlineKernel - launched by the host while this workgroup idles - sees it.  A workgroup leaves ONLY when
+// *quit is set - by the host (kh_online_decoder_serve_stop), or by workgroup 0 once EVERY stream has been without work
+// for idle_ticks (wall clock, 100 MHz; the streams' activity stamps in device memory): the kernel can never outlive its
+// caller by more than that (a device-wide synchronisation waits that long at most), and the grid leaves as a whole.
+// (Until round 5 every workgroup left on its own after idle_ticks: a stream that paused while the others kept decoding
+// lost its workgroup, the host - which relaunches when the whole kernel has ended - never noticed, and the stream's next
+// chunk or command waited for ever.  That is the intermittent stall of the round-4 serving legs.)
 struct ServeCtl {
   int32_t avail, cmd_seq, cmd_op, pad0;     // host -> device
   int32_t ack_seq, decoded, ok, alive;      // device -> host
-  int32_t pad1[8];
+  // device -> host, diagnostics: what the stream's workgroup is doing (0 waiting, kActInit / kActAdvance / kActFinalize,
+  // 9 = has left), the frame count it is advancing to, how many actions it has finished, the low word of the wall clock
+  // (100 MHz) when it last started or finished one - what kh_online_decoder_serve_wait / _stop report when they time out
+  int32_t hb_phase, hb_arg, hb_actions, hb_clock;
+  int32_t hw;                               // device -> host: token slots of the stream's arena that hold something (InitDecoding resets them)
+  int32_t pad1[3];
 };
 static_assert(sizeof(ServeCtl) == 64, "one control block per 64-byte line");
-enum { kCmdInit = 1, kCmdFinalize = 2 };
+// kCmdInitCleared: InitDecoding whose reset of the token arena the HOST has done (a fill kernel over the whole chip: the
+// unpruned utterance of a lazy-schedule stream leaves ~70 MB to reset, 0.23 s for one workgroup - the 200 ms outliers of the
+// round-4 chunk latencies were the first chunk of a slot's next utterance waiting for it)
+enum { kCmdInit = 1, kCmdFinalize = 2, kCmdInitCleared = 3 };
 
 template <class T>
 __device__ __forceinline__ int32_t SysLoad(T p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -5393,8 +5405,9 @@ __global__ void __launch_bounds__(NT)
 #if KH_WG_PER_CU > 1
 __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
 #endif
-ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, ServeCtl *ctl, const int32_t *quit,
-            const float *ll_base, long long ll_rows_per_stream, int ll_stride, Params p, long long idle_ticks) {
+ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, ServeCtl *ctl, int32_t *quit,
+            const float *ll_base, long long ll_rows_per_stream, int ll_stride, Params p, long long idle_ticks,
+            long long *act_clock /* [gridDim.x] wall clock of every stream's last activity */) {
   __shared__ Shared shm;
   extern __shared__ float dyn_ll_row[];
   Blk sh;
@@ -5424,8 +5437,14 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   bool ok = S->ok != 0;
   bool fin = S->finalized != 0;
   int acked = c->ack_seq;   // (the host set cmd_seq = ack_seq before the launch)
-  long long t_idle = wall_clock64();
-  if (threadIdx.x == 0) SysStore(&c->alive, 1);
+  long long t_idle = wall_clock64(), t_scan = t_idle;
+  int n_actions = 0;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&act_clock[s], t_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SysStore(&c->hb_phase, 0);
+    SysStore(&c->hb_clock, static_cast<int32_t>(t_idle));
+    SysStore(&c->alive, 1);
+  }
   for (;;) {
     if (threadIdx.x == 0) {
       int act = 0, arg = 0;
@@ -5433,14 +5452,32 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
       const int seq = SysLoad(&c->cmd_seq);
       const int op = SysLoad(&c->cmd_op);
       const int av = SysLoad(&c->avail);
-      if (seq != acked && op == kCmdInit) act = 1;
+      if (seq != acked && (op == kCmdInit || op == kCmdInitCleared)) { act = 1; arg = op == kCmdInitCleared ? 1 : 0; }
       else if (!fin && ok && av > run.t) { act = 2; arg = av; }
       else if (seq != acked && op == kCmdFinalize) act = 3;
       else if (seq != acked) act = 5;   // an unknown command: acknowledged, nothing done
-      else if (q != 0 || wall_clock64() - t_idle > idle_ticks) act = 4;
+      else if (q != 0) act = 4;
+      else if (s == 0) {
+        // the grid's idle decision: this workgroup has been without work for idle_ticks - has every other one?  (looked at
+        // at most four times per idle_ticks; a stream in the middle of a long action carries an old stamp: it finishes the
+        // action, acknowledges it and leaves with the others, and the host's next call launches the grid again)
+        const long long now = wall_clock64();
+        if (now - t_idle > idle_ticks && now - t_scan > (idle_ticks >> 2)) {
+          t_scan = now;
+          bool all_idle = true;
+          for (int k = 1; k < static_cast<int>(gridDim.x) && all_idle; k++)
+            all_idle = now - __hip_atomic_load(&act_clock[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > idle_ticks;
+          if (all_idle) SysStore(quit, 2);
+        }
+      }
       sh->bcast_i[0] = act;
       sh->bcast_i[1] = arg;
       sh->bcast_i[2] = seq;
+      if (act != 0 && act != 4) {
+        SysStore(&c->hb_arg, arg);
+        SysStore(&c->hb_clock, static_cast<int32_t>(wall_clock64()));
+        SysStore(&c->hb_phase, act);
+      }
     }
     KhSync();
     const int act = Uni(sh->bcast_i[0]), arg = Uni(sh->bcast_i[1]), seq = Uni(sh->bcast_i[2]);
@@ -5451,7 +5488,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
     }
     if (act == 4) break;
     if (act == 1) {          // InitDecoding (the body of OnlineKernel's kJobInit)
-      const int hw = S->tok_hw;
+      const int hw = arg != 0 ? 0 : S->tok_hw;   // (arg: the host has reset the token arena)
       KhSync();
       for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
       for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
@@ -5479,16 +5516,25 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
     }
     __threadfence();   // the slot's arenas and SlotState are in memory before the acknowledgement
     KhSync();
+    n_actions++;
+    t_idle = wall_clock64();
     if (threadIdx.x == 0) {
+      __hip_atomic_store(&act_clock[s], t_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       SysStore(&c->ok, ok ? 1 : 0);
       SysStore(&c->decoded, run.t);
+      SysStore(&c->hw, sh->tok_hw);
+      SysStore(&c->hb_actions, n_actions);
+      SysStore(&c->hb_clock, static_cast<int32_t>(t_idle));
+      SysStore(&c->hb_phase, 0);
       if (act != 2) SysStore(&c->ack_seq, seq);
     }
     if (act != 2) acked = seq;
-    t_idle = wall_clock64();
   }
   KhSync();
-  if (threadIdx.x == 0) SysStore(&c->alive, 0);
+  if (threadIdx.x == 0) {
+    SysStore(&c->hb_phase, 9);
+    SysStore(&c->alive, 0);
+  }
 }
 
 __global__ void FillU32(uint32_t *p, size_t n, uint32_t v) {
@@ -5653,6 +5699,8 @@ struct KhOnlineDecoder {
   int32_t *serve_quit = nullptr;          // pinned
   hipStream_t serve_stream = nullptr;
   bool serve_launched = false;            // a kernel has been launched and not yet seen to have ended
+  long long *d_serve_act = nullptr;       // device: wall clock of every stream's last activity (the grid's idle decision)
+  long long serve_relaunches = 0;         // how often the kernel was launched again after it had left
   const float *serve_ll = nullptr;
   long long serve_rows = 0;
   int serve_stride = 0;
@@ -7415,6 +7463,7 @@ void kh_online_decoder_destroy(KhOnlineDecoder *o) {
   if (o->serve_ctl) (void)hipHostFree(o->serve_ctl);
   if (o->serve_quit) (void)hipHostFree(o->serve_quit);
   if (o->serve_stream) (void)hipStreamDestroy(o->serve_stream);
+  if (o->d_serve_act) PoolFree(o->d_serve_act);
   PoolFree(o->d_states);
   PoolFree(o->d_jobs);
   kh_decoder_destroy(o->base);
@@ -7623,20 +7672,78 @@ int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *o, int enable) {
 }
 
 // ---- the persistent serving kernel (ServeKernel): start / stop, commands, progress
+// No call below blocks for ever: every wait for the device has a deadline (KH_SERVE_TIMEOUT_MS, default 30 s) and reports
+// KH_ETIMEOUT with the state of the streams' control blocks (what each workgroup was doing when it last spoke).
+static double ServeTimeoutMs() {
+  if (const char *e = getenv("KH_SERVE_TIMEOUT_MS")) return std::max(1.0, atof(e));
+  return 30000.0;
+}
+static std::string ServeDump(const KhOnlineDecoder *o, const int32_t *streams, int n) {
+  std::string out;
+  char buf[256];
+  int shown = 0;
+  for (int i = 0; i < (streams ? n : o->num_streams) && shown < 8; i++) {
+    const int s = streams ? streams[i] : i;
+    const ServeCtl &c = o->serve_ctl[s];
+    const int ack = __atomic_load_n(&c.ack_seq, __ATOMIC_ACQUIRE), dec = __atomic_load_n(&c.decoded, __ATOMIC_ACQUIRE);
+    const bool pending = ack != o->serve_seq[s] || (!o->finalized[s] && __atomic_load_n(&c.avail, __ATOMIC_ACQUIRE) > dec);
+    if (streams == nullptr && !pending && __atomic_load_n(&c.hb_phase, __ATOMIC_ACQUIRE) == 0) continue;
+    snprintf(buf, sizeof buf, "%s stream %d: avail %d decoded %d cmd %d/%d ack %d alive %d phase %d (to frame %d) actions %d clock %u", shown ? ";" : "",
+             s, c.avail, dec, c.cmd_op, o->serve_seq[s], ack, c.alive, c.hb_phase, c.hb_arg, c.hb_actions, static_cast<unsigned>(c.hb_clock));
+    out += buf;
+    shown++;
+  }
+  snprintf(buf, sizeof buf, "%s quit %d, launched %d, relaunches %lld", shown ? ";" : "", o->serve_quit ? *o->serve_quit : -1,
+           o->serve_launched ? 1 : 0, o->serve_relaunches);
+  out += buf;
+  return out;
+}
+// waits (bounded) for the serving kernel to have ended; KH_ETIMEOUT if it has not
+static int ServeJoin(KhOnlineDecoder *o, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const double limit = ServeTimeoutMs();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(o->serve_stream);
+    if (q == hipSuccess) break;
+    (void)hipGetLastError();
+    if (q != hipErrorNotReady) {
+      o->serve_launched = false;
+      SetError("%s: serving kernel: %s", what, hipGetErrorString(q));
+      return KH_EDEVICE;
+    }
+    if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      SetError("%s: the serving kernel did not leave within %.0f ms [%s]", what, limit, ServeDump(o, nullptr, 0).c_str());
+      return KH_ETIMEOUT;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+  o->serve_launched = false;
+  return KH_OK;
+}
+
 static int ServeEnsureRunning(KhOnlineDecoder *o) {
   if (!o->serve_ctl) {
     SetError("the serving kernel has not been started (kh_online_decoder_serve_start)");
     return KH_ESTATE;
   }
   if (o->serve_launched) {
-    const hipError_t q = hipStreamQuery(o->serve_stream);
-    if (q == hipErrorNotReady) return KH_OK;
-    (void)hipGetLastError();
-    if (q != hipSuccess) {
-      SetError("serving kernel: %s", hipGetErrorString(q));
-      return KH_EDEVICE;
+    // running, and nobody has told it to leave: every stream has its workgroup (they leave only together)
+    if (__atomic_load_n(o->serve_quit, __ATOMIC_ACQUIRE) == 0) {
+      const hipError_t q = hipStreamQuery(o->serve_stream);
+      if (q == hipErrorNotReady) return KH_OK;
+      (void)hipGetLastError();
+      if (q != hipSuccess) {
+        o->serve_launched = false;
+        SetError("serving kernel: %s", hipGetErrorString(q));
+        return KH_EDEVICE;
+      }
+      o->serve_launched = false;   // (ended without being told to: cannot happen; launched again below)
+    } else {
+      // the grid has decided to leave (idle time): it is on its way out - launched again once it has gone
+      const int rc = ServeJoin(o, "kh_online_decoder_serve");
+      if (rc) return rc;
     }
-    o->serve_launched = false;   // it left after its idle time: launched again below
+    o->serve_relaunches++;
   }
   KhDecoder *b = o->base;
   hipStream_t st = Stream();
@@ -7656,8 +7763,8 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   long long idle_ticks = 200000000ll;   // 2 s of the 100 MHz wall clock
   if (const char *e = getenv("KH_SERVE_IDLE_MS")) idle_ticks = std::max(1ll, static_cast<long long>(atof(e) * 1e5));
   hipLaunchKernelGGL(ServeKernel, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
-                     b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<const int32_t *>(quit_dev), o->serve_ll,
-                     o->serve_rows, o->serve_stride, p, idle_ticks);
+                     b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<int32_t *>(quit_dev), o->serve_ll,
+                     o->serve_rows, o->serve_stride, p, idle_ticks, o->d_serve_act);
   KH_LAUNCH_CHECK();
   o->serve_launched = true;
   return KH_OK;
@@ -7678,6 +7785,12 @@ int kh_online_decoder_serve_start(KhOnlineDecoder *o, const float *loglikes, int
     KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&o->serve_ctl), sizeof(ServeCtl) * o->num_streams, hipHostMallocMapped));
     KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&o->serve_quit), 64, hipHostMallocMapped));
     KH_HIP(hipStreamCreateWithFlags(&o->serve_stream, hipStreamNonBlocking));
+    o->d_serve_act = static_cast<long long *>(PoolMalloc(sizeof(long long) * o->num_streams));
+    if (!o->d_serve_act) {
+      SetError("kh_online_decoder_serve_start: out of device memory");
+      return KH_ENOMEM;
+    }
+    KH_HIP(hipMemset(o->d_serve_act, 0, sizeof(long long) * o->num_streams));
     memset(o->serve_ctl, 0, sizeof(ServeCtl) * o->num_streams);
     o->serve_seq.assign(o->num_streams, 0);
   }
@@ -7697,12 +7810,8 @@ int kh_online_decoder_serve_stop(KhOnlineDecoder *o) {
   KH_CHECK_ARG(o);
   if (!o->serve_ctl || !o->serve_launched) return KH_OK;
   __atomic_store_n(o->serve_quit, 1, __ATOMIC_RELEASE);
-  const hipError_t e = hipStreamSynchronize(o->serve_stream);
-  o->serve_launched = false;
-  if (e != hipSuccess) {
-    SetError("kh_online_decoder_serve_stop: %s", hipGetErrorString(e));
-    return KH_EDEVICE;
-  }
+  const int rc = ServeJoin(o, "kh_online_decoder_serve_stop");
+  if (rc) return rc;
   for (int s = 0; s < o->num_streams; s++) {
     o->frames[s] = __atomic_load_n(&o->serve_ctl[s].decoded, __ATOMIC_ACQUIRE);
     o->lat_key[s] = -1;
@@ -7710,10 +7819,11 @@ int kh_online_decoder_serve_stop(KhOnlineDecoder *o) {
   return KH_OK;
 }
 
-static int ServeCommand(KhOnlineDecoder *o, const int32_t *streams, int n, int op) {
+static int ServeCommand(KhOnlineDecoder *o, const int32_t *streams, int n, int op_all, const int32_t *ops = nullptr) {
   for (int i = 0; i < n; i++) {
     ServeCtl &c = o->serve_ctl[streams[i]];
-    if (op == kCmdInit) __atomic_store_n(&c.avail, 0, __ATOMIC_RELEASE);
+    const int op = ops ? ops[i] : op_all;
+    if (op == kCmdInit || op == kCmdInitCleared) __atomic_store_n(&c.avail, 0, __ATOMIC_RELEASE);
     __atomic_store_n(&c.cmd_op, op, __ATOMIC_RELEASE);
     __atomic_store_n(&c.cmd_seq, ++o->serve_seq[streams[i]], __ATOMIC_RELEASE);
   }
@@ -7729,12 +7839,31 @@ int kh_online_decoder_serve_init(KhOnlineDecoder *o, const int32_t *streams, int
       SetError("kh_online_decoder_serve_init: stream %d still has a command in flight", s);
       return KH_ESTATE;
     }
+  }
+  // The reset of a large token arena by a fill kernel over the whole chip instead of by the stream's one workgroup - only
+  // for a stream whose utterance is finalized and acknowledged (its workgroup waits; nobody else touches the arena).
+  std::vector<int32_t> ops(n, kCmdInit);
+  bool filled = false;
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
+    const int hw = __atomic_load_n(&o->serve_ctl[s].hw, __ATOMIC_ACQUIRE);
+    // (one workgroup per CU at most: the fill kernel needs room next to the resident workgroups)
+    if (o->num_streams <= NumCUs() && o->inited[s] && o->finalized[s] && hw >= (1 << 18) && hw <= o->base->h_slots[s].tok_cap) {
+      hipLaunchKernelGGL(FillU32, dim3(256), dim3(256), 0, Stream(), (uint32_t *)o->base->h_slots[s].tok_cost.p, static_cast<size_t>(hw), kEncInf);
+      KH_LAUNCH_CHECK();
+      ops[i] = kCmdInitCleared;
+      filled = true;
+    }
+  }
+  if (filled) KH_HIP(hipStreamSynchronize(Stream()));
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
     o->inited[s] = 1;
     o->finalized[s] = 0;
     o->frames[s] = 0;
     o->lat_key[s] = -1;
   }
-  return ServeCommand(o, streams, n, kCmdInit);
+  return ServeCommand(o, streams, n, kCmdInit, ops.data());
 }
 
 // Scores of frames [0, avail[i]) of stream streams[i] are in its score buffer (the kernels that wrote them have completed):
@@ -7773,6 +7902,7 @@ int kh_online_decoder_serve_finalize(KhOnlineDecoder *o, const int32_t *streams,
 // still in flight.  Either output may be NULL.
 int kh_online_decoder_serve_poll(KhOnlineDecoder *o, const int32_t *streams, int n, int32_t *decoded, int32_t *in_flight) {
   KH_CHECK_ARG(o && o->serve_ctl && streams && n > 0);
+  bool work = false, lost = false;
   for (int i = 0; i < n; i++) {
     const int s = streams[i];
     KH_CHECK_ARG(s >= 0 && s < o->num_streams);
@@ -7786,10 +7916,22 @@ int kh_online_decoder_serve_poll(KhOnlineDecoder *o, const int32_t *streams, int
     }
     const bool pending = ack != o->serve_seq[s];
     // (between an InitDecoding command and its acknowledgement `decoded` still belongs to the previous utterance)
-    o->frames[s] = (pending && c.cmd_op == kCmdInit) ? 0 : dec;
+    o->frames[s] = (pending && (c.cmd_op == kCmdInit || c.cmd_op == kCmdInitCleared)) ? 0 : dec;
     if (decoded) decoded[i] = o->frames[s];
     if (in_flight) in_flight[i] = pending ? 1 : 0;
+    work |= pending || (!o->finalized[s] && __atomic_load_n(&c.avail, __ATOMIC_ACQUIRE) > dec);
+    // a stream with work whose workgroup has left while the kernel is neither leaving nor gone: the protocol's invariant
+    // (workgroups leave only together) is broken - stop the grid and start it again rather than wait for ever
+    lost |= work && o->serve_launched && __atomic_load_n(&c.alive, __ATOMIC_ACQUIRE) == 0 && __atomic_load_n(o->serve_quit, __ATOMIC_ACQUIRE) == 0 &&
+            __atomic_load_n(&c.hb_phase, __ATOMIC_ACQUIRE) == 9;
   }
+  if (lost) {
+    __atomic_store_n(o->serve_quit, 1, __ATOMIC_RELEASE);
+    const int rc = ServeJoin(o, "kh_online_decoder_serve_poll");
+    if (rc) return rc;
+  }
+  // a caller that only polls must still get its streams served after the grid has left by its idle time
+  if (work && (!o->serve_launched || __atomic_load_n(o->serve_quit, __ATOMIC_ACQUIRE) != 0)) return ServeEnsureRunning(o);
   return KH_OK;
 }
 
@@ -7798,7 +7940,7 @@ int kh_online_decoder_serve_poll(KhOnlineDecoder *o, const int32_t *streams, int
 int kh_online_decoder_serve_wait(KhOnlineDecoder *o, const int32_t *streams, int n, int timeout_ms) {
   KH_CHECK_ARG(o && o->serve_ctl && streams && n > 0);
   const auto t0 = std::chrono::steady_clock::now();
-  const double limit = timeout_ms > 0 ? timeout_ms : 60000.0;
+  const double limit = timeout_ms > 0 ? timeout_ms : ServeTimeoutMs();
   std::vector<int32_t> dec(n), fl(n);
   for (;;) {
     int rc = ServeEnsureRunning(o);
@@ -7811,8 +7953,8 @@ int kh_online_decoder_serve_wait(KhOnlineDecoder *o, const int32_t *streams, int
     }
     if (all) return KH_OK;
     if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > limit) {
-      SetError("kh_online_decoder_serve_wait: timed out after %.0f ms", limit);
-      return KH_EDEVICE;
+      SetError("kh_online_decoder_serve_wait: timed out after %.0f ms [%s]", limit, ServeDump(o, streams, n).c_str());
+      return KH_ETIMEOUT;
     }
     std::this_thread::sleep_for(std::chrono::microseconds(50));
   }

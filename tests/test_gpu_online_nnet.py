@@ -246,3 +246,75 @@ def test_persistent_serving_kernel_equals_offline(api, pad_input, lazy, monkeypa
     assert done[0] == n_out(2)
     dec.finalize_decoding([0])
     assert_same_lattice(dec.get_raw_lattice(0), ref.get_raw_lattice(2))
+
+
+def test_serving_stream_pauses_longer_than_the_idle_time_while_others_decode(api, monkeypatch):
+    """Round 4's intermittent stall, as a regression test.  Every workgroup of the serving kernel used to leave on its own
+    after the idle time; the host relaunches only when the WHOLE kernel has ended - so a stream that paused while the others
+    kept decoding lost its workgroup and its next chunk waited for ever.  Now the grid leaves only as a whole (workgroup 0
+    decides when every stream has been idle).  Stream 0 pauses for ten idle times while streams 1 and 2 are fed frame by
+    frame, resumes, and everything equals the offline pipeline; then every stream pauses (the grid leaves), and a caller
+    that only POLLS gets its pending chunk decoded all the same."""
+    import time
+    monkeypatch.setenv("KH_SERVE_IDLE_MS", "30")
+    monkeypatch.setenv("KH_SERVE_TIMEOUT_MS", "8000")
+    rng = np.random.default_rng(77)
+    n_pdf = 40
+    nnet = _setup(api, rng, n_pdf)
+    g = workloads.make_hclg_like(rng, 5000, n_pdf)
+    cfg = api.decoder_config(beam=10.0, max_active=800, min_active=50, lattice_beam=5.0, prune_interval=7)
+    fst = api.Fst(g)
+    Ts = [90, 150, 150]
+    feats = [rng.standard_normal((T, 13)).astype(np.float32) for T in Ts]
+    x = torch.from_numpy(np.concatenate(feats, 0)).cuda()
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+    ll, _ = nnet.compute(x, off, pad_input=True, epilogue=True, prob_scale=0.1)
+    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=len(Ts), max_frames=max(Ts))
+    ref.decode(ll, off)
+    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)
+    pipe = api.OnlineNnet2Pipeline(nnet, dec, max_frames=160, acoustic_scale=0.1, pad_input=True, max_nnet_batch_size=40)
+    pipe.serve_start()
+    pipe.reset([0, 1, 2])
+    fed = [0, 0, 0]
+    pipe.step([0], x, [int(off[0])], [20], [False])
+    fed[0] = 20
+    t0 = time.perf_counter()
+    while fed[1] < 100:                      # streams 1 and 2 keep the kernel busy for ~0.4 s = a dozen idle times
+        pipe.step([1, 2], x, [int(off[1] + fed[1]), int(off[2] + fed[2])], [1, 1], [False, False])
+        fed[1] += 1
+        fed[2] += 1
+        time.sleep(0.004)
+    assert time.perf_counter() - t0 > 0.3
+    def feed_rest(streams):   # (a step submits at most max_nnet_batch_size frames per stream: chunks of 25, then the context's tail)
+        while any(fed[s_] < Ts[s_] for s_ in streams):
+            live = [s_ for s_ in streams if fed[s_] < Ts[s_]]
+            cnt = [min(25, Ts[s_] - fed[s_]) for s_ in live]
+            pipe.step(live, x, [int(off[s_] + fed[s_]) for s_ in live], cnt, [fed[s_] + k == Ts[s_] for s_, k in zip(live, cnt)])
+            for s_, k in zip(live, cnt):
+                fed[s_] += k
+        for _ in range(2):
+            pipe.step(streams, x, [0] * len(streams), [0] * len(streams), [True] * len(streams))
+
+    # stream 0 comes back: its workgroup must still be there
+    feed_rest([0])
+    pipe.serve_finalize([0])
+    pipe.serve_wait([0], timeout_ms=5000)
+    assert dec.num_frames_decoded(0) == Ts[0]
+    assert_same_lattice(dec.get_raw_lattice(0), ref.get_raw_lattice(0))
+    # now everybody pauses: the grid leaves by its idle time ...
+    time.sleep(0.3)
+    # ... and a chunk handed over afterwards is decoded for a caller that only polls (no serve_wait, no further command)
+    feed_rest([1, 2])
+    t0 = time.perf_counter()
+    while True:
+        dcd, busy = pipe.serve_poll([1, 2])
+        if dcd[0] == Ts[1] and dcd[1] == Ts[2]:
+            break
+        assert time.perf_counter() - t0 < 5.0, (dcd, busy)
+        time.sleep(0.002)
+    pipe.serve_finalize([1, 2])
+    pipe.serve_wait([1, 2], timeout_ms=5000)
+    for s_ in (1, 2):
+        assert_same_lattice(dec.get_raw_lattice(s_), ref.get_raw_lattice(s_))
+        assert_same_best_path(dec.get_best_path(s_), ref.get_best_path(s_))
+    pipe.serve_stop()

@@ -264,7 +264,7 @@ def ivector_f3(api, torch, n_utts=2620, mean_len=740):
             "ms_per_call": dt * 1e3, "frames_per_s": int(off[-1]) / dt, "longest_utterance_frames": int(lens.max())}
 
 
-def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
+def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50), only_persistent=False):
     """Config 4 in its default mode (online2-wav-nnet2-latgen-faster --online=true, :213-262) as a serving loop: `streams`
     concurrent utterances advance in lockstep, one chunk of audio per step (--chunk-length 0.05 s = 5 frames, and 0.5 s).
     A step = what one chunk triggers for every live stream: the chunk's feature rows (MFCC + iVector: already in HBM, their
@@ -298,7 +298,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
         if os.environ.get("BENCH_VERBOSE"):
             print("[bench online2] " + msg, file=sys.stderr, flush=True)
 
-    for c in chunks:
+    for c in (() if only_persistent else chunks):   # (only_persistent: tools/stress_serving.py runs the serving legs alone)
         progress("launch-per-step loop, chunk %d" % c)
         # CONTINUOUS serving, the step as ONE library call (kh_online_nnet2_step): `n` stream slots; a slot whose utterance
         # has been decoded is finalized and takes the next utterance of the set (InitDecoding), until the set is used up.
@@ -379,7 +379,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
             out = [[] for _ in range(n)]           # per slot: (time handed over, NumFramesDecoded() that completes the chunk)
             pipe.reset(list(range(n)))
             all_slots = np.arange(n)
-            calls, chunk_lat, marks = [], [], []
+            calls, chunk_lat, last_lat, marks = [], [], [], []
             n_done = frames_done = 0
             t_begin = time.perf_counter()
             while (state != 2).any():
@@ -393,7 +393,10 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                 for sl in np.nonzero(~busy)[0]:
                     q = out[sl]
                     while q and dcd[sl] >= q[0][1]:
-                        chunk_lat.append(now - q.pop(0)[0])
+                        # (an utterance's LAST chunk is only seen complete once FinalizeDecoding has been acknowledged - the
+                        # stream reports busy until then - so its figure includes that call: kept apart)
+                        t_h, _, was_last = q.pop(0)
+                        (last_lat if was_last else chunk_lat).append(now - t_h)
                 for sl in np.nonzero((state == 1) & ~busy)[0]:       # finalized: the slot's next utterance
                     n_done += 1
                     frames_done += int(all_lens[slot_utt[sl]])
@@ -418,8 +421,8 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
                 pipe.step(ready, x_all, off[uu].astype(np.int64) + given[ready], cnt, fin)
                 given[ready] += cnt
                 tgt = np.where(fin, all_lens[uu], np.maximum(0, given[ready] - R))
-                for sl, tg in zip(ready.tolist(), tgt.tolist()):
-                    out[sl].append((t0, tg))
+                for sl, tg, fl in zip(ready.tolist(), tgt.tolist(), fin.tolist()):
+                    out[sl].append((t0, tg, bool(fl)))
                 ended = ready[fin]
                 if len(ended):
                     pipe.serve_finalize(ended)
@@ -437,6 +440,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
             fps = None
         cm = np.array([x_[0] for x_ in calls]) * 1e3
         cl = np.array(chunk_lat) * 1e3
+        ll_ = np.array(last_lat) * 1e3 if last_lat else np.zeros(1)
         res["chunk_%d_frames_persistent%s" % (c, tag)] = {
             "chunk_seconds": c * 0.01, "utterances_served": int(n_done), "frames_per_s": fps,
             "real_time_streams_sustained": fps / 100.0 if fps else None,
@@ -445,6 +449,8 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
             "step_call_ms": {"mean": float(cm.mean()), "p50": float(np.percentile(cm, 50)), "p95": float(np.percentile(cm, 95))},
             "chunk_latency_ms": {"mean": float(cl.mean()), "p50": float(np.percentile(cl, 50)), "p95": float(np.percentile(cl, 95)),
                                  "max": float(cl.max())},
+            # the last chunk of an utterance, FinalizeDecoding included (the lazy schedule prunes every frame THERE, once)
+            "last_chunk_and_finalize_ms": {"mean": float(ll_.mean()), "p95": float(np.percentile(ll_, 95)), "max": float(ll_.max())},
             "chunks_ahead": ahead,
             "step": "kh_online_nnet2_serve_*: persistent decode kernel, one resident workgroup per stream; a stream gets its next "
                     "chunk while at most `chunks_ahead` chunks of its frames wait to be decoded; FinalizeDecoding asynchronous" + note}
@@ -457,7 +463,7 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50)):
         serve_leg(c, "_lazy", "; lazy pruning schedule (no PruneActiveTokens every prune_interval frames: "
                               "FinalizeDecoding prunes every frame once)")
     dec.set_lazy_prune(False)
-    for c in chunks[:1]:
+    for c in (() if only_persistent else chunks[:1]):
         # ... and the same loop through the Python-side DecodableNnet2Online + advance_decoding (round 3's leg)
         dn = api.DecodableNnet2Online(nnet, n, max_t, acoustic_scale=acwt, pad_input=True, max_nnet_batch_size=max(256, c))
         all_streams = list(range(n))
