@@ -468,6 +468,14 @@ int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream,
  * quantities are unchanged; a raw lattice asked for BEFORE FinalizeDecoding is pruned as of the current frame, not as of
  * the last multiple of prune_interval.  Re-carves the arenas (as much memory as is free, less 48 GB): every stream must be idle. */
 int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *dec, int enable);
+/* kh_decoder_set_reference_order for the streams: LatticeFasterOnlineDecoder::ProcessEmitting (decoder/lattice-faster-online-
+ * decoder.cc:864-951) walks the same HashList against the same running next_cutoff as the offline decoder, and with this set
+ * the launch-per-job calls (kh_online_decoder_init_decoding / _advance / _finalize) reproduce it: chunked decoding, the
+ * offline kernel in reference order and the line-by-line oracle (mode 0) give the same lattices bit for bit.  Between
+ * utterances only (KH_ESTATE while a stream is in a decoding run).  The persistent serving kernel keeps the
+ * order-independent rule: kh_online_decoder_serve_start refuses to start in this mode.  KH_DECODER_ORDER=reference in the
+ * environment sets it at creation. */
+int kh_online_decoder_set_reference_order(KhOnlineDecoder *dec, int enable);
 /* The same three calls without a kernel launch per chunk: a PERSISTENT serving kernel, one resident workgroup per stream
  * (num_streams <= 2 x the CU count), which waits on a control block in pinned host memory (online2-wav-nnet2-latgen-faster's
  * per-chunk loop :213-262 for many connections; a stream that is pruning - AdvanceDecoding prunes every prune_interval

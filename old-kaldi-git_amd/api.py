@@ -51,16 +51,22 @@ def select_gpu(ordinal):
     use_torch_stream()
 
 
-def _fn(name, t):
-    """The entry point for the tensor's element type: kh_<name> (float) or its <double> twin kh_<name>_d."""
+def _fn(name, t, *others):
+    """The entry point for the tensors' element type: kh_<name> (float) or its <double> twin kh_<name>_d.  Every
+    floating-point operand of the call must have that one type (a float operand handed to the double kernel - or the
+    other way round - would be reinterpreted, not converted)."""
+    for o in others:
+        assert not o.dtype.is_floating_point or o.dtype == t.dtype, "operands of different element types: %s and %s" % (t.dtype, o.dtype)
     if t.dtype == torch.float64:
         return getattr(lib(), name + "_d")
     assert t.dtype == torch.float32
     return getattr(lib(), name)
 
 
-def _dim(t):
-    assert t.dim() == 2 and t.dtype in (torch.float32, torch.float64) and t.is_cuda
+def _dim(t, dtype=torch.float32):
+    """MatrixDim of a 2-D device tensor of element type `dtype` - float32 unless the caller dispatches on the type (_fn):
+    the entry points without a <double> twin (affine, the network, the decoder, the GMM, iVectors, lattices) take float only."""
+    assert t.dim() == 2 and t.dtype == dtype and t.is_cuda, "a 2-D %s device tensor is expected, got %s" % (dtype, t.dtype)
     assert t.stride(1) == 1 or t.shape[1] <= 1
     return KhMatrixDim(t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
 
@@ -79,7 +85,7 @@ def _dev_i32(a, device):
 # ---------------------------------------------------------------- CuMatrix ops
 def add_mat_mat(Cm, alpha, A, transA, B, transB, beta):
     """CuMatrixBase::AddMatMat (cu-matrix.cc:947-982): C = alpha op(A) op(B) + beta C."""
-    check(_fn("kh_add_mat_mat", Cm)(alpha, _p(A), _dim(A), int(transA), _p(B), _dim(B), int(transB), beta, _p(Cm), _dim(Cm)))
+    check(_fn("kh_add_mat_mat", Cm, A, B)(alpha, _p(A), _dim(A, Cm.dtype), int(transA), _p(B), _dim(B, Cm.dtype), int(transB), beta, _p(Cm), _dim(Cm, Cm.dtype)))
     return Cm
 
 
@@ -97,13 +103,13 @@ def affine_pnorm(out, A, W, bias):
 def apply_softmax_per_row(dst, src):
     """CuMatrixBase::ApplySoftMaxPerRow (cu-matrix.cc:1251-1271)."""
     assert dst.shape == src.shape  # KALDI_ASSERT(SameDim(*this, src))
-    check(_fn("kh_softmax_per_row", dst)(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    check(_fn("kh_softmax_per_row", dst, src)(_p(dst), _p(src), _dim(dst, dst.dtype), _dim(src, dst.dtype).stride))
     return dst
 
 
 def apply_log_softmax_per_row(dst, src):
     assert dst.shape == src.shape
-    check(_fn("kh_log_softmax_per_row", dst)(_p(dst), _p(src), _dim(dst), _dim(src).stride))
+    check(_fn("kh_log_softmax_per_row", dst, src)(_p(dst), _p(src), _dim(dst, dst.dtype), _dim(src, dst.dtype).stride))
     return dst
 
 
@@ -112,14 +118,14 @@ def copy_rows(dst, src, indices):
     idx = _dev_i32(indices, dst.device)
     if dst.shape[1] != src.shape[1] or dst.shape[0] != idx.numel():
         raise KhError("CopyRows: dimension mismatch")
-    check(_fn("kh_copy_rows", dst)(_p(dst), _dim(dst), _p(src), _dim(src).stride, _p(idx)))
+    check(_fn("kh_copy_rows", dst, src, idx)(_p(dst), _dim(dst, dst.dtype), _p(src), _dim(src, dst.dtype).stride, _p(idx)))
     return dst
 
 
 def splice(src, frame_offsets, tgt):
     """cu::Splice (cudamatrix/cu-math.cc:130-165)."""
     off = _dev_i32(frame_offsets, src.device)
-    check(_fn("kh_splice", tgt)(_p(tgt), _dim(tgt), _p(src), _dim(src), _p(off), off.numel()))
+    check(_fn("kh_splice", tgt, src, off)(_p(tgt), _dim(tgt, tgt.dtype), _p(src), _dim(src, tgt.dtype), _p(off), off.numel()))
     return tgt
 
 
@@ -127,7 +133,7 @@ def group_pnorm(dst, src, power):
     """CuMatrixBase::GroupPnorm (cu-matrix.cc:1147-1164)."""
     if src.shape[1] % dst.shape[1] != 0 or src.shape[0] != dst.shape[0]:
         raise KhError("GroupPnorm: dimension mismatch")
-    check(_fn("kh_group_pnorm", dst)(_p(dst), _p(src), _dim(dst), _dim(src).stride, src.shape[1] // dst.shape[1], power))
+    check(_fn("kh_group_pnorm", dst, src)(_p(dst), _p(src), _dim(dst, dst.dtype), _dim(src, dst.dtype).stride, src.shape[1] // dst.shape[1], power))
     return dst
 
 
@@ -141,56 +147,56 @@ def normalize(dst, src):
 def add_diag_mat2(v, alpha, M, beta):
     """CuVectorBase::AddDiagMat2 kNoTrans (cu-vector.cc:517-580)."""
     assert v.numel() == M.shape[0]
-    check(_fn("kh_add_diag_mat2", M)(alpha, _p(M), _dim(M), beta, _p(v)))
+    check(_fn("kh_add_diag_mat2", M, v)(alpha, _p(M), _dim(M, M.dtype), beta, _p(v)))
     return v
 
 
 def mul_rows_vec(M, s):
     assert s.numel() == M.shape[0]
-    check(_fn("kh_mul_rows_vec", M)(_p(M), _dim(M), _p(s)))
+    check(_fn("kh_mul_rows_vec", M, s)(_p(M), _dim(M, M.dtype), _p(s)))
     return M
 
 
 def mul_cols_vec(M, s):
     assert s.numel() == M.shape[1]
-    check(_fn("kh_mul_cols_vec", M)(_p(M), _dim(M), _p(s)))
+    check(_fn("kh_mul_cols_vec", M, s)(_p(M), _dim(M, M.dtype), _p(s)))
     return M
 
 
 def copy_rows_from_vec(M, v):
     assert v.numel() == M.shape[1]
-    check(_fn("kh_copy_rows_from_vec", M)(_p(M), _dim(M), _p(v)))
+    check(_fn("kh_copy_rows_from_vec", M, v)(_p(M), _dim(M, M.dtype), _p(v)))
     return M
 
 
 def add_vec_to_rows(M, alpha, v, beta=1.0):
     assert v.numel() == M.shape[1]
-    check(_fn("kh_add_vec_to_rows", M)(alpha, _p(v), beta, _p(M), _dim(M)))
+    check(_fn("kh_add_vec_to_rows", M, v)(alpha, _p(v), beta, _p(M), _dim(M, M.dtype)))
     return M
 
 
 def apply_floor(M, f):
-    check(_fn("kh_apply_floor", M)(_p(M), _dim(M), f))
+    check(_fn("kh_apply_floor", M)(_p(M), _dim(M, M.dtype), f))
     return M
 
 
 def apply_log(M):
-    check(_fn("kh_apply_log", M)(_p(M), _dim(M)))
+    check(_fn("kh_apply_log", M)(_p(M), _dim(M, M.dtype)))
     return M
 
 
 def apply_exp(M):
-    check(_fn("kh_apply_exp", M)(_p(M), _dim(M)))
+    check(_fn("kh_apply_exp", M)(_p(M), _dim(M, M.dtype)))
     return M
 
 
 def apply_pow(M, p):
-    check(_fn("kh_apply_pow", M)(_p(M), _dim(M), p))
+    check(_fn("kh_apply_pow", M)(_p(M), _dim(M, M.dtype), p))
     return M
 
 
 def scale(M, a):
-    check(_fn("kh_scale", M)(_p(M), _dim(M), a))
+    check(_fn("kh_scale", M)(_p(M), _dim(M, M.dtype), a))
     return M
 
 
@@ -198,7 +204,7 @@ def sum_column_ranges(dst, src, ranges):
     """CuMatrixBase::SumColumnRanges (cu-matrix.cc:1994-2028)."""
     r = _dev_i32(ranges, dst.device)
     assert r.numel() == 2 * dst.shape[1]
-    check(_fn("kh_sum_column_ranges", dst)(_p(dst), _dim(dst), _p(src), _dim(src), _p(r)))
+    check(_fn("kh_sum_column_ranges", dst, src, r)(_p(dst), _dim(dst, dst.dtype), _p(src), _dim(src, dst.dtype), _p(r)))
     return dst
 
 
@@ -207,7 +213,7 @@ def lookup(M, pairs):
     pr = _dev_i32(pairs, M.device)
     n = pr.numel() // 2
     out = torch.empty(n, dtype=M.dtype, device=M.device)
-    check(_fn("kh_matrix_lookup", M)(_p(M), _dim(M), _p(pr), n, _p(out)))
+    check(_fn("kh_matrix_lookup", M, pr, out)(_p(M), _dim(M, M.dtype), _p(pr), n, _p(out)))
     return out
 
 
@@ -932,7 +938,7 @@ class LatticeFasterOnlineDecoder:
     log-likelihood chunks are what DecodableNnet2Online would serve for the next
     frames (rows [t, t + n) of the utterance's matrix)."""
 
-    def __init__(self, fst, config=None, num_streams=1, max_frames=4096):
+    def __init__(self, fst, config=None, num_streams=1, max_frames=4096, exact_reference_order=False):
         self.fst = fst
         cfg = decoder_config() if config is None else config
         self.cfg = KhDecoderConfig(**cfg)
@@ -941,6 +947,8 @@ class LatticeFasterOnlineDecoder:
         if not h:
             raise KhError(lib().kh_last_error().decode())
         self._h = C.c_void_p(h)
+        if exact_reference_order:
+            self.set_reference_order(True)
 
     def __del__(self):
         try:
@@ -980,6 +988,12 @@ class LatticeFasterOnlineDecoder:
         """The offline kernel's lazy pruning schedule (kh_online_decoder_set_lazy_prune): same final lattices and best paths,
         no pruning while the streams advance; every stream must be idle."""
         check(lib().kh_online_decoder_set_lazy_prune(self._h, int(bool(enable))))
+
+    def set_reference_order(self, enable=True):
+        """The reference's own iteration order for the streams (kh_online_decoder_set_reference_order;
+        lattice-faster-online-decoder.cc:864-951): the lattices LatticeFasterOnlineDecoder itself would build.  Every
+        stream must be idle; the persistent serving kernel does not run in this mode."""
+        check(lib().kh_online_decoder_set_reference_order(self._h, int(bool(enable))))
 
     def num_frames_decoded(self, stream=0):
         n = C.c_int32()

@@ -158,6 +158,7 @@ SIGNATURES = {
     "kh_online_decoder_serve_start": (C.c_int, [vp, vp, C.c_int, C.c_int64, vp]),
     "kh_online_decoder_serve_stop": (C.c_int, [vp]),
     "kh_online_decoder_set_lazy_prune": (C.c_int, [vp, C.c_int]),
+    "kh_online_decoder_set_reference_order": (C.c_int, [vp, C.c_int]),
     "kh_online_decoder_serve_init": (C.c_int, [vp, C.POINTER(C.c_int32), C.c_int]),
     "kh_online_decoder_serve_publish": (C.c_int, [vp, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32)]),
     "kh_online_decoder_serve_finalize": (C.c_int, [vp, C.POINTER(C.c_int32), C.c_int]),

@@ -5227,6 +5227,8 @@ struct SlotState {
   int32_t t, fb, fe;          // Run
   int32_t ok, finalized, conv_upto;
   int32_t surv_nt, surv_nl;   // (lazy schedule) survivor lists of FinalizeDecoding
+  uint32_t x_hsize;           // (reference order) HashList::hash_size_ of the stream's decoder (:219-225: it never shrinks)
+  int32_t pad_;
   long long arcs_expanded, tokens_created;
   KhDecodeStats stats;        // valid once finalized
 };
@@ -5243,6 +5245,7 @@ __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
     sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw; sh->gc_tok = S.gc_tok; sh->gc_link = S.gc_link;
     sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created; sh->conv_upto = S.conv_upto;
     sh->surv_nt = S.surv_nt; sh->surv_nl = S.surv_nl;
+    sh->x_hsize = S.x_hsize;
   }
   run->t = S.t; run->fb = S.fb; run->fe = S.fe;
   run->cand = 0;   // (the online decoder does not report the counter)
@@ -5255,17 +5258,21 @@ __device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
     S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw; S->gc_tok = sh->gc_tok; S->gc_link = sh->gc_link;
     S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created; S->conv_upto = sh->conv_upto;
     S->surv_nt = sh->surv_nt; S->surv_nl = sh->surv_nl;
+    S->x_hsize = sh->x_hsize;
     S->t = run.t; S->fb = run.fb; S->fe = run.fe;
     S->ok = (ok && sh->status == 0) ? 1 : 0;
   }
 }
 
+// kExact: the reference's own iteration order (kh_online_decoder_set_reference_order; LatticeFasterOnlineDecoder::ProcessEmitting
+// prunes against the same running cutoff in the same HashList order, lattice-faster-online-decoder.cc:864-951).
+template <bool kExact>
 __global__ void __launch_bounds__(NT)
 #if KH_WG_PER_CU > 1
 __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
 #endif
 OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, const Job *__restrict__ jobs,
-             UttOut *__restrict__ out, Pool pool, Params p) {
+             UttOut *__restrict__ out, Pool pool, Params p, const UttX *slotsx) {
   __shared__ Shared shm;
   extern __shared__ float dyn_ll_row[];
   Blk sh;
@@ -5274,8 +5281,8 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
   sh.k_or = 0;
   sh.k_red = 0;
   sh.k_scan = 0;
-  sh.x = nullptr;
   const Job job = jobs[blockIdx.x];
+  sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + job.slot) : nullptr;
   Utt u = slots[job.slot];
   Launder(u);
   Launder(p);
@@ -5297,7 +5304,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
     for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
     if (threadIdx.x == 0) sh->tok_hw = 0;
     KhSync();
-    const bool ok = DecodeInit(u, p, sh, &run);
+    const bool ok = DecodeInit<kExact>(u, p, sh, &run);
     SaveState(S, sh, run, ok);
     if (threadIdx.x == 0) S->finalized = 0;
   } else if (job.op == kJobAdvance) {
@@ -5305,7 +5312,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
     u.ll = job.ll;
     u.ll_stride = job.ll_stride;
     bool ok = S->ok != 0;
-    if (ok) ok = p.lazy_prune ? DecodeFrames<true>(u, p, sh, &run, run.t + job.n_frames) : DecodeFrames<false>(u, p, sh, &run, run.t + job.n_frames);
+    if (ok) ok = p.lazy_prune ? DecodeFrames<true, kExact>(u, p, sh, &run, run.t + job.n_frames) : DecodeFrames<false, kExact>(u, p, sh, &run, run.t + job.n_frames);
     SaveState(S, sh, run, ok);
   } else if (job.op == kJobFinalize) {
     LoadState(*S, sh, &run);
@@ -7420,6 +7427,7 @@ KhOnlineDecoder *kh_online_decoder_create(const KhFst *fst, const KhDecoderConfi
                                           int max_frames) {
   KhDecoder *b = kh_decoder_create(fst, cfg, num_streams, max_frames);
   if (!b) return nullptr;
+  if (const char *e = getenv("KH_DECODER_ORDER")) b->exact = strcmp(e, "reference") == 0;   // (as kh_decoder_decode reads it)
   KhOnlineDecoder *o = new KhOnlineDecoder();
   o->base = b;
   o->num_streams = num_streams;
@@ -7488,8 +7496,15 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
     o->pinned = false;
   }
   KH_HIP(hipMemcpyAsync(o->d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(OnlineKernel, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), DynLdsBytes(p.ll_cols), st,
-                     b->d_slots, o->d_states, o->d_jobs, b->d_out, b->pool, p);
+  p.exact_order = b->exact ? 1 : 0;
+  if (b->exact) {
+    if (getenv("KH_DECODER_ORDER_SORT") != nullptr && atoi(getenv("KH_DECODER_ORDER_SORT")) != 0) p.exact_order = 2;
+    hipLaunchKernelGGL(OnlineKernel<true>, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), DynLdsBytes(p.ll_cols), st,
+                       b->d_slots, o->d_states, o->d_jobs, b->d_out, b->pool, p, (const UttX *)b->d_slotsx);
+  } else {
+    hipLaunchKernelGGL(OnlineKernel<false>, dim3(static_cast<unsigned>(jobs.size())), dim3(NT), DynLdsBytes(p.ll_cols), st,
+                       b->d_slots, o->d_states, o->d_jobs, b->d_out, b->pool, p, (const UttX *)nullptr);
+  }
   KH_LAUNCH_CHECK();
   return KH_OK;
 }
@@ -7640,6 +7655,46 @@ int kh_online_decoder_finalize(KhOnlineDecoder *o, const int32_t *streams, int n
 // (rule P, DESIGN.md section 2: the result does not depend on when the sweeps run); a raw lattice asked for BEFORE
 // FinalizeDecoding is pruned as of the current frame instead of the last multiple of prune_interval.  The arenas are
 // re-carved (every stream must be idle: before InitDecoding or after FinalizeDecoding + the last getter).
+// The streams decode in the reference's own iteration order (kh_decoder_set_reference_order for the online decoder:
+// LatticeFasterOnlineDecoder::ProcessEmitting, lattice-faster-online-decoder.cc:864-951, walks the same HashList against the
+// same running next_cutoff).  Between utterances only; the launch-per-job calls only - the persistent serving kernel keeps
+// the order-independent rule and refuses to start in this mode.
+int kh_online_decoder_set_reference_order(KhOnlineDecoder *o, int enable) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(o);
+  KhDecoder *b = o->base;
+  if ((b->exact != 0) == (enable != 0)) return KH_OK;
+  if (o->serve_launched) {
+    SetError("kh_online_decoder_set_reference_order: stop the serving kernel first");
+    return KH_ESTATE;
+  }
+  for (int s = 0; s < o->num_streams; s++)
+    if (o->inited[s] && !o->finalized[s]) {
+      SetError("kh_online_decoder_set_reference_order: stream %d is in a decoding run", s);
+      return KH_ESTATE;
+    }
+  b->exact = enable != 0;
+  hipStream_t st = Stream();
+  int n_slots = 0;
+  rc = EnsureSlots(b, o->num_streams, o->max_frames, st, &n_slots);
+  if (rc == KH_OK && n_slots < o->num_streams) {
+    SetError("kh_online_decoder_set_reference_order: only %d of %d streams fit in device memory", n_slots, o->num_streams);
+    rc = KH_ENOMEM;
+  }
+  if (rc) return rc;
+  KH_HIP(hipMemsetAsync(o->d_states, 0, sizeof(SlotState) * o->num_streams, st));
+  KH_HIP(hipMemcpyAsync(b->d_slots, b->h_slots.data(), sizeof(Utt) * o->num_streams, hipMemcpyHostToDevice, st));
+  KH_HIP(hipStreamSynchronize(st));
+  for (int s = 0; s < o->num_streams; s++) {
+    o->inited[s] = 0;
+    o->finalized[s] = 0;
+    o->frames[s] = 0;
+    o->lat_key[s] = -1;
+  }
+  return KH_OK;
+}
+
 int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *o, int enable) {
   int rc = EnsureDevice();
   if (rc) return rc;
@@ -7779,6 +7834,11 @@ int kh_online_decoder_serve_start(KhOnlineDecoder *o, const float *loglikes, int
     SetError("kh_online_decoder_serve_start: %d streams, but only %d workgroups can be resident at once", o->num_streams,
              KH_WG_PER_CU * NumCUs());
     return KH_EINVAL;
+  }
+  if (o->base->exact) {
+    SetError("kh_online_decoder_serve_start: the serving kernel decodes with the order-independent rule only "
+             "(kh_online_decoder_set_reference_order(0) first, or use the launch-per-job calls)");
+    return KH_ESTATE;
   }
   if ((rc = kh_online_decoder_serve_stop(o))) return rc;
   if (!o->serve_ctl) {

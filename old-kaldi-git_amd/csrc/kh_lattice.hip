@@ -22,8 +22,6 @@
 #include <thread>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
-
 #include "kh_common.h"
 
 using namespace kh;
@@ -343,6 +341,159 @@ struct DevArr {
     return p ? KH_OK : KH_ENOMEM;
   }
 };
+
+// ---------------------------------------------------------------- device radix sort (64-bit keys, 32-bit payload)
+// A stable least-significant-digit radix sort over chosen bit fields of the key, 8 bits per pass, written for this file's
+// one use - the (row, pdf) order of a batch's lattice arcs, 1.4-11 M pairs, of whose 64 key bits only the pdf's ~13 and the
+// row's ~20 are ever set.  (Rounds 3-4 called hipcub::DeviceRadixSort here; the repository's rule is that device code on
+// the path is its own.)  Per pass three launches:
+//   SortHistKernel     a block counts the digits of its tile of kSortTile consecutive pairs -> hist[digit][block];
+//   SortScanKernel     block d scans row d of the table in place (exclusive) and leaves the row's total; one more block
+//                      scans the 256 totals;
+//   SortScatterKernel  a block counts its tile again per WAVE (a wave owns a contiguous quarter of the tile), turns
+//                      (digit base + blocks before + waves before) into the wave's cursors, and walks its quarter 64 pairs
+//                      at a time: the lanes that hold the same digit find each other with ballots (eight, one per digit
+//                      bit), a lane's rank is the number of its peers below it, the first of them advances the cursor.
+//                      Blocks, waves and tiles are visited in order, so equal keys keep their order: the sort is stable.
+// Traffic per pass: 40 bytes per pair (keys three times - the third read hits L2 -, payload once, both written once).
+constexpr int kSortThreads = 256, kSortWaves = kSortThreads / 64, kSortItems = 16, kSortTile = kSortThreads * kSortItems, kSortBins = 256;
+
+__global__ void __launch_bounds__(kSortThreads)
+SortHistKernel(const unsigned long long *__restrict__ keys, int64_t n, int shift, uint32_t mask, uint32_t *__restrict__ hist, int n_blocks) {
+  __shared__ uint32_t h[kSortBins];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t b0 = static_cast<int64_t>(blockIdx.x) * kSortTile;
+#pragma unroll 4
+  for (int j = 0; j < kSortItems; j++) {
+    const int64_t i = b0 + j * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[static_cast<uint32_t>(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  hist[static_cast<size_t>(threadIdx.x) * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__device__ __forceinline__ uint32_t SortBlockExScan(uint32_t v, uint32_t *total, uint32_t *ws) {   // 256 threads; ws[kSortWaves]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();   // (ws of the previous call has been read)
+  if (lane == 63) ws[w] = inc;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < kSortWaves; k++) {
+    before += k < w ? ws[k] : 0u;
+    all += ws[k];
+  }
+  *total = all;
+  return before + inc - v;
+}
+
+// gridDim.x = kSortBins + 1: block d < 256 scans row d in place; the last block waits for nobody - it is launched as a second
+// call (rows first, totals after), see SortPairs64.
+__global__ void __launch_bounds__(kSortThreads)
+SortScanKernel(uint32_t *__restrict__ hist, int n_blocks, uint32_t *__restrict__ totals, int totals_only) {
+  __shared__ uint32_t ws[kSortWaves];
+  if (totals_only) {   // one block: exclusive scan of the 256 row totals
+    uint32_t tot;
+    const uint32_t ex = SortBlockExScan(totals[threadIdx.x], &tot, ws);
+    totals[threadIdx.x] = ex;
+    return;
+  }
+  uint32_t *row = hist + static_cast<size_t>(blockIdx.x) * n_blocks;
+  uint32_t run = 0;
+  for (int c0 = 0; c0 < n_blocks; c0 += kSortThreads) {   // (uniform)
+    const int c = c0 + threadIdx.x;
+    const uint32_t v = c < n_blocks ? row[c] : 0u;
+    uint32_t tot;
+    const uint32_t ex = SortBlockExScan(v, &tot, ws);
+    if (c < n_blocks) row[c] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+SortScatterKernel(const unsigned long long *__restrict__ kin, const int32_t *__restrict__ vin, unsigned long long *__restrict__ kout,
+                  int32_t *__restrict__ vout, int64_t n, int shift, uint32_t mask, const uint32_t *__restrict__ hist,
+                  const uint32_t *__restrict__ base, int n_blocks) {
+  __shared__ uint32_t cur[kSortWaves][kSortBins];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < kSortWaves * kSortBins; k += kSortThreads) (&cur[0][0])[k] = 0u;
+  __syncthreads();
+  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSortTile + static_cast<int64_t>(w) * (kSortTile / kSortWaves);   // the wave's quarter
+  constexpr int kTiles = kSortTile / kSortWaves / 64;
+  for (int t = 0; t < kTiles; t++) {
+    const int64_t i = w0 + t * 64 + lane;
+    if (i < n) atomicAdd(&cur[w][static_cast<uint32_t>(kin[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  {  // counts per wave -> the wave's first output slot per digit
+    const int d = threadIdx.x;
+    uint32_t at = base[d] + hist[static_cast<size_t>(d) * n_blocks + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kSortWaves; k++) {
+      const uint32_t c = cur[k][d];
+      cur[k][d] = at;
+      at += c;
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < kTiles; t++) {   // (uniform over the wave)
+    const int64_t i = w0 + t * 64 + lane;
+    const bool act = i < n;
+    const unsigned long long key = act ? kin[i] : 0ull;
+    const int32_t val = act ? vin[i] : 0;
+    const uint32_t d = static_cast<uint32_t>(key >> shift) & mask;
+    unsigned long long peers = __ballot(act);
+    if (peers == 0ull) break;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const bool set = ((d >> bit) & 1u) != 0u;
+      const unsigned long long m = __ballot(set);
+      peers &= set ? m : ~m;
+    }
+    if (act) {
+      const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+      const uint32_t at = cur[w][d];
+      if (rank == 0) cur[w][d] = at + static_cast<uint32_t>(__popcll(peers));
+      kout[at + rank] = key;
+      vout[at + rank] = val;
+    }
+  }
+}
+
+// Sorts the n pairs (k0, v0) by the key bits [lo_bits) of the low word and [32, 32 + hi_bits) of the high word; the result is
+// in (k1, v1) (returned through *in_second = 1) or back in (k0, v0).  work: kSortBins * n_blocks + kSortBins words.
+int SortPairs64(unsigned long long *k0, int32_t *v0, unsigned long long *k1, int32_t *v1, int64_t n, int lo_bits, int hi_bits,
+                uint32_t *work, hipStream_t st, int *in_second) {
+  const int n_blocks = static_cast<int>((n + kSortTile - 1) / kSortTile);
+  uint32_t *hist = work, *totals = work + static_cast<size_t>(kSortBins) * n_blocks;
+  int cur = 0;
+  for (int half = 0; half < 2; half++) {
+    const int bits = half ? hi_bits : lo_bits;
+    for (int sb = 0; sb < bits; sb += 8) {
+      const int shift = half * 32 + sb;
+      const uint32_t mask = (1u << std::min(8, bits - sb)) - 1u;
+      const unsigned long long *kin = cur ? k1 : k0;
+      const int32_t *vin = cur ? v1 : v0;
+      hipLaunchKernelGGL(SortHistKernel, dim3(n_blocks), dim3(kSortThreads), 0, st, kin, n, shift, mask, hist, n_blocks);
+      hipLaunchKernelGGL(SortScanKernel, dim3(kSortBins), dim3(kSortThreads), 0, st, hist, n_blocks, totals, 0);
+      hipLaunchKernelGGL(SortScanKernel, dim3(1), dim3(kSortThreads), 0, st, hist, n_blocks, totals, 1);
+      hipLaunchKernelGGL(SortScatterKernel, dim3(n_blocks), dim3(kSortThreads), 0, st, kin, vin, cur ? k0 : k1, cur ? v0 : v1, n, shift, mask,
+                         hist, totals, n_blocks);
+      KH_LAUNCH_CHECK();
+      cur ^= 1;
+    }
+  }
+  *in_second = cur;
+  return KH_OK;
+}
 
 }  // namespace
 
@@ -1668,21 +1819,22 @@ extern "C" int kh_discriminative_lattice_computations(
     KH_LAUNCH_CHECK();
     KH_HIP(hipMemcpyAsync(h_tot.data(), d_score.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
   }
-  // stable sort of the arcs by (row, pdf); arcs without a transition-id carry row = total_rows and end up last
-  int end_bit = 33;
-  while (end_bit < 64 && (static_cast<unsigned long long>(total_rows) >> (end_bit - 32)) != 0) end_bit++;
-  size_t tmp_bytes = 0;
-  if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, static_cast<int>(A), 0, end_bit, st) != hipSuccess)
-    return KH_EDEVICE;
-  DevArr<char> d_tmp;
-  if (d_tmp.Alloc(tmp_bytes)) return KH_ENOMEM;
-  if (hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, static_cast<int>(A), 0, end_bit, st) != hipSuccess)
-    return KH_EDEVICE;
+  // stable sort of the arcs by (row, pdf); arcs without a transition-id carry row = total_rows and end up last.  Only the
+  // bits that can be set take part: the pdf's (the low word) and the row's (the high word).
+  int hi_bits = 1, lo_bits = 1;
+  while (hi_bits < 31 && (static_cast<unsigned long long>(total_rows) >> hi_bits) != 0) hi_bits++;
+  while (lo_bits < 31 && (static_cast<unsigned long long>(std::max(1, d_posteriors.cols - 1)) >> lo_bits) != 0) lo_bits++;
+  DevArr<uint32_t> d_sort;
+  if (d_sort.Alloc(static_cast<size_t>(kSortBins) * ((A + kSortTile - 1) / kSortTile + 1) + kSortBins)) return KH_ENOMEM;
+  int in_second = 0;
+  if ((rc = SortPairs64(d_keys.p, d_vals.p, d_keys2.p, d_vals2.p, A, lo_bits, hi_bits, d_sort.p, st, &in_second))) return rc;
+  const unsigned long long *s_keys = in_second ? d_keys2.p : d_keys.p;
+  const int32_t *s_vals = in_second ? d_vals2.p : d_vals.p;
   const int seg_blocks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(4096, (A + 255) / 256)));
-  hipLaunchKernelGGL(SegmentKernel, dim3(seg_blocks), dim3(256), 0, st, A, d_keys2.p, d_vals2.p, B.d_ilabel.p, d_post.p, total_rows,
+  hipLaunchKernelGGL(SegmentKernel, dim3(seg_blocks), dim3(256), 0, st, A, s_keys, s_vals, B.d_ilabel.p, d_post.p, total_rows,
                      is_mmi ? -1.0f : 1.0f, is_mmi ? d_ali_pdf.p : nullptr, d_seg.p, d_has_num.p);
   KH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(EmitKernel, dim3(kEmitBlocks), dim3(kThreads), 0, st, A, d_keys2.p, d_seg.p, total_rows, is_mmi, drop_frames,
+  hipLaunchKernelGGL(EmitKernel, dim3(kEmitBlocks), dim3(kThreads), 0, st, A, s_keys, d_seg.p, total_rows, is_mmi, drop_frames,
                      d_ali_pdf.p, d_has_num.p, d_row_off.p, n_lats, d_w.p, posteriors, d_posteriors.stride, deriv, d_deriv.stride,
                      d_part.p);
   KH_LAUNCH_CHECK();

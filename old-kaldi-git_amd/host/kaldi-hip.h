@@ -1355,6 +1355,8 @@ class LatticeFasterOnlineDecoder {
     if (!dec_) KhCheck(KH_EINVAL);
   }
   ~LatticeFasterOnlineDecoder() { kh_online_decoder_destroy(dec_); }
+  /// The reference's own iteration order (kh_online_decoder_set_reference_order); between utterances only.
+  void SetReferenceOrder(bool enable) { KhCheck(kh_online_decoder_set_reference_order(dec_, enable ? 1 : 0)); }
   void InitDecoding(const std::vector<int32> &streams) {
     KhCheck(kh_online_decoder_init_decoding(dec_, streams.data(), static_cast<int>(streams.size())));
   }

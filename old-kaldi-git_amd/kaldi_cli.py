@@ -468,12 +468,13 @@ class _PipeHelper:
                     status = e.errno or 1
                 os.write(rep, struct.pack("<Ii", ident, status))
             elif op == b"p":      # has the child exited?  (never blocks: a slow child must not stall the other requesters)
+                # The child stays in the table: subprocess caches its return code, so every later poll - the watchdog's and
+                # the close's wait - gets the same status.  (Popping it on the first poll that saw it gone let the watchdog
+                # consume the exit status of a fast command, and the pclose that followed reported a successful pipe as failed.)
                 p = children.get(ident)
                 rc = -1 if p is None else p.poll()
                 if rc is None:
                     rc = self._RUNNING
-                else:
-                    children.pop(ident, None)
                 os.write(rep, struct.pack("<Ii", ident, rc))
             elif op == b"q":
                 break

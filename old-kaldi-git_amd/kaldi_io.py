@@ -440,7 +440,7 @@ def read_fst_holder(s):
         col = line.decode().split()
         if not col:
             break          # the terminating empty line (or the end of the stream)
-        if len(col) > 5:
+        if len(col) > 5 or len(col) == 3:   # (3 columns: "not ok ...; it's not an acceptor", fstext-utils.h:479-481 - the read fails)
             raise ValueError("Bad line in FST: " + line.decode())
         src = int(col[0])
         if start is None:
@@ -452,7 +452,7 @@ def read_fst_holder(s):
             dst = int(col[1])
             n_states = max(n_states, dst + 1)
             il = int(col[2])
-            ol = int(col[3]) if len(col) >= 4 else il     # (3 columns: an acceptor arc)
+            ol = int(col[3])
             w = float(col[4]) if len(col) == 5 else 0.0
             arcs.append((src, dst, il, ol, w))
     order = sorted(range(len(arcs)), key=lambda i: arcs[i][0])   # stable: arcs of a state keep their order

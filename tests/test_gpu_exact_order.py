@@ -228,3 +228,87 @@ def test_bench_workload_slice(api):
     sample = [int(np.argmax(lens)), int(np.argsort(lens)[len(lens) // 2]), int(np.argmin(lens))]
     dec, dens = decode_structured(api, g, ll_dev, off, api.decoder_config(**bench.DECODE_CFG), sample)
     print("bench slice in reference order: lattice arcs/frame %s" % dens)
+
+
+def _online_reference_order(api, g, lls, cfg, rng, monkeypatch=None, lazy=False):
+    """Streams advanced in random chunks with kh_online_decoder_set_reference_order: after FinalizeDecoding the lattices of
+    oracle mode 0 (= of the offline kernel in reference order), and at intermediate points those of the oracle's own
+    Begin / Advance sequence in mode 0 (LatticeFasterOnlineDecoder walks the same HashList against the same running
+    cutoff, lattice-faster-online-decoder.cc:864-951)."""
+    Ts = [len(x) for x in lls]
+    fst = api.Fst(g)
+    dev = [torch.from_numpy(x).cuda() for x in lls]
+    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=len(Ts), max_frames=max(Ts), exact_reference_order=True)
+    if lazy:
+        dec.set_lazy_prune(True)
+    dec.init_decoding(list(range(len(Ts))))
+    pos = [0] * len(Ts)
+    snapshots = {}
+    step = 0
+    while any(p < T for p, T in zip(pos, Ts)):
+        act = [s for s in range(len(Ts)) if pos[s] < Ts[s] and rng.random() < 0.8]
+        if not act:
+            continue
+        n = [int(min(Ts[s] - pos[s], rng.integers(0, 40))) for s in act]
+        dec.advance_decoding(act, [dev[s][pos[s]:pos[s] + k] for s, k in zip(act, n)])
+        for s, k in zip(act, n):
+            pos[s] += k
+        step += 1
+        if step in (2, 5) and not lazy:
+            s = act[0]
+            if pos[s] > 0:
+                snapshots[(s, pos[s])] = (dec.get_raw_lattice(s, use_final_probs=False), dec.get_best_path(s, use_final_probs=True))
+    dec.finalize_decoding(list(range(len(Ts))))
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+    offline = api.LatticeFasterDecoder(fst, cfg, max_batch=len(Ts), max_frames=max(Ts), exact_reference_order=True)
+    offline.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
+    for s, x in enumerate(lls):
+        orf = B.DecoderOracle(g, cfg, "reference")
+        ok = orf.decode(x)
+        so, sg = orf.stats(), dec.stats(s)
+        for k in ("num_frames", "reached_final", "tokens_created", "max_tokens_frame"):
+            assert so[k] == sg[k], (s, k, so[k], sg[k])
+        if not ok:
+            continue
+        got = dec.get_raw_lattice(s)
+        assert_same_lattice(got, orf.raw_lattice())
+        assert_same_lattice(got, offline.get_raw_lattice(s))
+        assert_same_best_path(dec.get_best_path(s), orf.best_path())
+    for (s, t), (l_nofinal, bp) in snapshots.items():
+        orf = B.DecoderOracle(g, cfg, "reference")
+        orf.begin(lls[s])
+        assert orf.advance(t) == t
+        orf.snapshot(False)
+        assert_same_lattice(l_nofinal, orf.raw_lattice())
+        orf.snapshot(True)
+        assert_same_best_path(bp, orf.best_path())
+    return dec
+
+
+def test_online_streams_in_reference_order(api):
+    rng = np.random.default_rng(41)
+    g = graph_like_hclg(rng, 30000, 300)
+    lls = [workloads.make_loglikes(rng, T, 300) for T in (97, 160, 33, 211)]
+    # max-active binds: the regime in which the reference order is a different search from the canonical rule
+    cfg = api.decoder_config(beam=12.0, max_active=700, min_active=100, lattice_beam=6.0, prune_interval=10)
+    dec = _online_reference_order(api, g, lls, cfg, rng)
+    can = api.LatticeFasterOnlineDecoder(api.Fst(g), cfg, num_streams=1, max_frames=211)
+    can.init_decoding([0])
+    can.advance_decoding([0], [torch.from_numpy(lls[3]).cuda()])
+    can.finalize_decoding([0])
+    assert can.stats(0)["tokens_created"] != dec.stats(3)["tokens_created"]   # (else the test would prove nothing)
+    # the mode is switched between utterances only, and the serving kernel refuses it
+    dec.init_decoding([0])
+    with pytest.raises(api.KhError):
+        dec.set_reference_order(False)
+
+
+def test_online_streams_in_reference_order_eps_heavy_and_lazy(api, monkeypatch):
+    rng = np.random.default_rng(6)
+    g = graph_like_hclg(rng, 8000, 80, eps_frac=0.45, mean_degree=3.5)
+    lls = [workloads.make_loglikes(rng, T, 80) for T in (64, 11, 90)]
+    cfg = api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0, prune_interval=7)
+    _online_reference_order(api, g, lls, cfg, rng)
+    _online_reference_order(api, g, lls, cfg, rng, lazy=True)
+    monkeypatch.setenv("KH_DECODER_CLOSURE_CAP", "3")
+    _online_reference_order(api, g, lls, cfg, rng)

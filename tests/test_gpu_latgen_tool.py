@@ -16,7 +16,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden", "kaldi_io")
 
 
-def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("rule", ["canonical", "reference"])
+def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch, rule):
+    """rule = reference: --reference-order=true, the lattices of LatticeFasterDecoder's own iteration order (oracle mode 0) -
+    what nnet2bin/nnet-latgen-faster.cc:139-160 itself writes; max-active binds in this test, so the two orders are
+    different searches."""
     from oracle import binding
     kio, workloads = pkg("kaldi_io"), pkg("workloads")
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -47,6 +51,8 @@ def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatc
             w.write(k, m)
         w.write("empty", np.zeros((0, 6), np.float32))
     det_opts = ["--beam=9", "--max-active=300", "--lattice-beam=5", "--acoustic-scale=%g" % acwt, "--allow-partial=true"]
+    if rule == "reference":
+        det_opts.append("--reference-order=true")
     opts = det_opts + ["--determinize-lattice=false"]
     assert tool.main(opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark:lat.ark", "ark:words.ark", "ark,t:ali.txt"]) == 0
     # the binaries' default: determinized CompactLattices (binary and text)
@@ -61,7 +67,7 @@ def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatc
     cfg = binding.decoder_config(beam=9.0, max_active=300, lattice_beam=5.0)
     for k, x in utts.items():
         ll = oracle.decodable_am_nnet(net, priors, acwt, x)
-        oc = binding.DecoderOracle(g, cfg, "canonical")
+        oc = binding.DecoderOracle(g, cfg, rule)
         oc.decode(ll)
         want, best = oc.raw_lattice(), oc.best_path()
         got = lats[k]
