@@ -196,6 +196,9 @@ struct UttX {
   Arr<int32_t> x_val0; Arr<int32_t> x_val1;                         // radix sort payload
   Arr<int32_t> x_h; Arr<int32_t> x_inb;   // token of the frame under construction -> insertion rank of its bucket's first token; its rank inside the bucket
   Arr<uint32_t> x_c0e;     // entry of tmp_epslist made by the emitting pass -> the token's cost image before the epsilon closure
+  Arr<int32_t> x_csid;     // [link_frame_cap] materialised candidate -> the caller's id of its destination state (what the reference hashes)
+  Arr<const KhInt4> x_rec0;   // the graph's own records (KhFst::rec): in this mode the decoder's copy carries the caller's id of an
+                              // arc's destination state where the output label was, and the export reads the label from here
   int32_t x_hcap;
 };
 
@@ -2874,16 +2877,16 @@ __device__ int OrderFrontierFast(const Utt &u, const Params &p, int nb, int fe, 
   LdsSync();
   XS(4);
   for (int i0 = tid; i0 < n; i0 += NT * kU) {
-    int32_t st[kU], sid[kU];
+    int32_t sid[kU];
     uint32_t qv[kU];
+    // the caller's state id (what the reference hashes): the emitting pass's tokens got it from their candidates (x_bkt), the
+    // few tokens of the closure look it up (unit id -> label table)
 #pragma unroll
     for (int k = 0; k < kU; k++) {
       const int i = min(i0 + k * NT, n - 1);
-      st[k] = u.tok_state[nb + i];
+      sid[k] = i < n_emit ? UX(x_bkt)[i] : -1 - p.unit_ilabel[u.tok_state[nb + i]];
       qv[k] = UX(x_q)[i];
     }
-#pragma unroll
-    for (int k = 0; k < kU; k++) sid[k] = -1 - p.unit_ilabel[st[k]];   // the caller's state id (what the reference hashes)
 #pragma unroll
     for (int k = 0; k < kU; k++) {
       const int i = i0 + k * NT;
@@ -3347,13 +3350,13 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   Arr<int32_t> x_state = u.tok_state;
   GP(const float) x_ll = u.ll + static_cast<size_t>(frame) * u.ll_stride;
   int x_ll_cols = p.ll_cols;
-  Arr<int32_t> xp_pos = UX(x_pos), xp_c = UX(x_c), xp_ord = UX(x_ord);
+  Arr<int32_t> xp_pos = UX(x_pos), xp_c = UX(x_c), xp_ord = UX(x_ord), xp_csid = UX(x_csid);
   Arr<uint32_t> xp_m = UX(x_m);
   Arr<int32_t> x_dst = u.link_dst, x_src = u.link_src, x_arc = u.link_arc;
   Arr<float> x_k = u.link_k, x_a = u.link_a;
   int x_keep_ac = p.keep_ac;
   KH_LAUNDER_X(x_rec.p); KH_LAUNDER_X(x_cost.p); KH_LAUNDER_X(x_state.p); KH_LAUNDER_X(x_ll); KH_LAUNDER_X(x_ll_cols);
-  KH_LAUNDER_X(xp_pos.p); KH_LAUNDER_X(xp_c.p); KH_LAUNDER_X(xp_m.p); KH_LAUNDER_X(xp_ord.p);
+  KH_LAUNDER_X(xp_pos.p); KH_LAUNDER_X(xp_c.p); KH_LAUNDER_X(xp_m.p); KH_LAUNDER_X(xp_ord.p); KH_LAUNDER_X(xp_csid.p);
   KH_LAUNDER_X(x_dst.p); KH_LAUNDER_X(x_src.p); KH_LAUNDER_X(x_arc.p); KH_LAUNDER_X(x_k.p); KH_LAUNDER_X(x_a.p);
   KH_LAUNDER_X(x_keep_ac);
   OwnerScan os = OwnerScanInit(sh);
@@ -3492,6 +3495,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           x_arc[l] = ai;
           if (x_keep_ac) x_a[l] = ac;
           x_k[l] = tot;
+          xp_csid[l - link_frame_b] = arc.y;   // the caller's id of the destination state (ArcPdfKernel)
         }
       }
     }
@@ -3708,6 +3712,8 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const int n_new = Uni(sh->tok_end) - nb;
     auto qtab = LdsKeys(sh);
     const bool in_lds = n_new <= kLdsSlots;
+    const bool sid_lds = 2 * n_new <= kLdsSlots;
+    auto stab = LdsKeys(sh) + kLdsSlots / 2;
     for (int i = tid; i < n_new; i += NT) {
       if (in_lds) qtab[i] = 0xFFFFFFFFu; else UX(x_q)[i] = 0xFFFFFFFFu;
     }
@@ -3715,25 +3721,33 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     {
       constexpr int kOU = 4;   // (a lane's loads of four trips in flight together)
       for (int l0 = link_frame_b + tid; l0 < link_frame_e; l0 += NT * kOU) {
-        int dsts[kOU];
+        int dsts[kOU], sids[kOU];
         uint32_t ords[kOU];
 #pragma unroll
         for (int k = 0; k < kOU; k++) {
           const int l = min(l0 + k * NT, link_frame_e - 1);
           dsts[k] = u.link_dst[l];
           ords[k] = static_cast<uint32_t>(UX(x_ord)[l - link_frame_b]);
+          sids[k] = UX(x_csid)[l - link_frame_b];
         }
 #pragma unroll
         for (int k = 0; k < kOU; k++) {
           if (l0 + k * NT >= link_frame_e || dsts[k] < 0) continue;   // (dst < 0: rejected by the running cutoff)
           if (in_lds) (void)__hip_atomic_fetch_min(&qtab[dsts[k] - nb], ords[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           else (void)__hip_atomic_fetch_min(&UX(x_q)[dsts[k] - nb], ords[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the new token's state id (every candidate of a token carries the same one): through LDS, so that it reaches
+          // memory as one coalesced sweep (a scattered 4-byte store per candidate was 0.5 MB of partial writes per frame)
+          if (sid_lds) stab[dsts[k] - nb] = static_cast<uint32_t>(sids[k]);
+          else UX(x_bkt)[dsts[k] - nb] = sids[k];
         }
       }
     }
     LdsSync();
     if (in_lds)
-      for (int i = tid; i < n_new; i += NT) UX(x_q)[i] = qtab[i];
+      for (int i = tid; i < n_new; i += NT) {
+        UX(x_q)[i] = qtab[i];
+        if (sid_lds) UX(x_bkt)[i] = static_cast<int32_t>(stab[i]);
+      }
   }
   const long long tot_arcs = BlockSumLL(my_arcs, sh);   // (its barrier waits for the stores above)
   if (tid == 0) {
@@ -4788,6 +4802,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     if (kExact) {   // the start token is the first insertion (:66) into a table of 1000 buckets (:37)
       UX(x_q)[0] = 0u;
       UX(x_c0e)[0] = Enc(0.0f);
+      UX(x_bkt)[0] = -1 - p.unit_ilabel[p.start];   // the start state's own id
       sh->x_hsize = 1000u;
       sh->x_qbase = 1u;
       sh->x_ne_emit = sh->tok_end;
@@ -5069,7 +5084,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
       pool.l_src[d] = u.tmp_remap[src];
       pool.l_dst[d] = u.tmp_remap[dst];
       pool.l_il[d] = il;
-      pool.l_ol[d] = rec.y;
+      pool.l_ol[d] = (sh.x != nullptr && arc >= 0) ? UX(x_rec0)[arc].y : rec.y;   // (reference order: see ArcPdfKernel)
       pool.l_g[d] = __int_as_float(rec.z);   // the graph cost is the arc's weight
       pool.l_a[d] = a;
     }
@@ -5124,7 +5139,7 @@ __device__ void ExportSurvivors(const Utt &u, const Params &p, const Pool &pool,
     pool.l_src[d] = u.tmp_remap[src];
     pool.l_dst[d] = u.tmp_remap[dst];
     pool.l_il[d] = il;
-    pool.l_ol[d] = rec.y;
+    pool.l_ol[d] = (sh.x != nullptr && arc >= 0) ? UX(x_rec0)[arc].y : rec.y;   // (reference order: see ArcPdfKernel)
     pool.l_g[d] = __int_as_float(rec.z);   // the graph cost is the arc's weight
     pool.l_a[d] = a;
   }
@@ -5567,6 +5582,7 @@ struct KhDecoder {
   int lazy = 0, alloc_link_a = 1;         // Params::lazy_prune / keep_ac of the calls this decoder serves (kh_decoder_decode sets them)
   int slab_lazy = 0, slab_link_a = 1;     // ... and what the slab was carved for
   int exact = 0, slab_exact = 0;          // kh_decoder_set_reference_order; whether the slab holds the exact-order temporaries
+  int rec_order_ids = -1;            // what the second word of the arcs in `rec` holds: 0 output labels, 1 state ids (ArcPdfKernel), -1 not built
   std::vector<Utt> h_slots;
   Utt *d_slots = nullptr;
   std::vector<UttX> h_slotsx;      // exact reference order: the slots' temporaries (Utt::x points into d_slotsx)
@@ -5861,6 +5877,8 @@ void CarveSlot(Carver &c, Utt &u, int T, int tok_frame_cap, int link_frame_cap, 
     x.x_h = c.Take<int32_t>(tf);
     x.x_inb = c.Take<int32_t>(tf);
     x.x_c0e = c.Take<uint32_t>(tf);
+    x.x_csid = c.Take<int32_t>(lf);
+    x.x_rec0 = Arr<const KhInt4>((GP(const KhInt4))nullptr);
     if (xo) *xo = x;
   }
   u.ll = (GP(const float))nullptr;
@@ -6326,6 +6344,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
     d->h_slotsx.assign(n_slots, UttX());
     for (int i = 0; i < n_slots; i++)
       CarveSlot(carver, d->h_slots[i], T_max, tfc, lfc, caps, d->alloc_link_a != 0, d->cfg.hash_ratio, et, d->exact != 0, &d->h_slotsx[i], scale);
+    for (int i = 0; i < n_slots; i++) d->h_slotsx[i].x_rec0 = Arr<const KhInt4>((GP(const KhInt4))d->fst->rec);
     // arena invariants for the first utterance of every slot (later ones are
     // restored by the kernel): token costs = +inf, hash empty, dirty flags zero
     for (int i = 0; i < n_slots; i++) {
@@ -6357,11 +6376,16 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
 // (tid2pdf[ilabel], or ilabel - 1 without a map): the expansion needs the score column, not the
 // transition-id, and reads it with the arc instead of gathering the map.  Rebuilt on every call
 // (the map is the caller's and may change between calls): one pass over the label table.
+// order_ids = 1 (reference order): the second word of an arc - its output label, which the search never reads - carries the
+// CALLER'S id of the arc's destination state instead: what HashList hashes (state % hash_size).  The expansion reads it with
+// the arc; looking it up per new token (unit id -> caller's id, a 4-byte gather into a 40 MB table per token and frame) was
+// 1.2 TB of the reference-order kernel's 4.4 TB of reads.  The export reads output labels from the graph's own records then.
 __global__ void ArcPdfKernel(const int32_t *__restrict__ unit_ilabel, long long n, const int32_t *__restrict__ tid2pdf, int4 *__restrict__ rec,
-                             int num_cols, int *__restrict__ bad) {
+                             int num_cols, int *__restrict__ bad, const int4 *__restrict__ rec0, int order_ids) {
   for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x) {
     const int32_t il = unit_ilabel[a];
     if (il > 0) {
+      rec[a].y = order_ids ? -1 - unit_ilabel[rec0[a].w & kStateMask] : rec0[a].y;
       int32_t pdf = tid2pdf ? tid2pdf[il] : il - 1;
       // the decoder gathers the score row at this column unchecked: a map entry outside the matrix is reported (first
       // offender: transition-id, pdf) and clamped so that the launch that follows cannot read out of bounds
@@ -6392,7 +6416,7 @@ int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, int ll_stride, 
   hipLaunchKernelGGL(ArcPdfKernel, dim3(NumCUs() * 8), dim3(256), 0, st, (const int32_t *)d->fst->unit_ilabel,
                      static_cast<long long>(d->fst->num_units), tid2pdf, d->rec,
                      ll_stride > 0 ? ll_stride : std::numeric_limits<int>::max(),   // (a launch without score rows: InitDecoding / FinalizeDecoding jobs)
-                     d->d_bad);
+                     d->d_bad, (const int4 *)d->fst->rec, d->exact ? 1 : 0);
   KH_LAUNCH_CHECK();
   int bad[4] = {0, 0, 0, 0};
   KH_HIP(hipMemcpyAsync(bad, d->d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
@@ -6402,6 +6426,7 @@ int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, int ll_stride, 
              "log-likelihood matrix", bad[1], bad[2], ll_stride);
     return KH_EINVAL;
   }
+  d->rec_order_ids = d->exact ? 1 : 0;
   p->rec = (GP(const KhInt4))d->rec;
   return KH_OK;
 }
@@ -7485,7 +7510,8 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   p.lazy_prune = b->lazy;   // kh_online_decoder_set_lazy_prune
   if (ll_stride <= 0) p.ll_cols = 0;
-  if (b->rec != nullptr && (ll_stride <= 0 || (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols))) {
+  if (b->rec != nullptr && b->rec_order_ids == (b->exact ? 1 : 0) &&
+      (ll_stride <= 0 || (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols))) {
     // the records hold this map's pdfs already (kh_online_decoder_set_pdf_map) - or the jobs read no scores at all
     // (InitDecoding, FinalizeDecoding, export: only the graph's structure), and the records must not be rewritten under
     // a serving kernel that is using them
@@ -7675,6 +7701,7 @@ int kh_online_decoder_set_reference_order(KhOnlineDecoder *o, int enable) {
       return KH_ESTATE;
     }
   b->exact = enable != 0;
+  o->pinned = false;   // (the decoder's arc records carry state ids in this mode: built again by the next launch)
   hipStream_t st = Stream();
   int n_slots = 0;
   rc = EnsureSlots(b, o->num_streams, o->max_frames, st, &n_slots);

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result",
-         "-D__HIP_PLATFORM_AMD__", "-mllvm", "-amdgpu-inline-max-bb=100000", "-gline-tables-only", "--cuda-device-only", "-S"]
+         "-D__HIP_PLATFORM_AMD__", "-mllvm", "-amdgpu-inline-max-bb=100000", "-mllvm", "-disable-machine-licm", "-gline-tables-only", "--cuda-device-only", "-S"]
 
 
 def main():
