@@ -3260,6 +3260,353 @@ __device__ int OrderFrontierFast(const Utt &u, const Params &p, int nb, int fe, 
   return 1;
 }
 
+// The same construction with every per-token intermediate in LDS (round 5, second half).  The kernel in reference order
+// moved 5.9 TB per launch against the canonical kernel's 2.6 TB and ran at the fabric's limit (rocprofv3 FETCH_SIZE /
+// WRITE_SIZE); the list order's share was its per-token arrays - bucket, rank, first-of-bucket rank, rank inside the bucket -
+// written to memory by one step and read back by the next, ~0.5 MB per frame (nothing survives in L2 between the phases of
+// 64 workgroups per XCD).  For a frame of up to 8192 tokens ONE word per token stays in the dynamic LDS area (T), the
+// bitmaps, the counting sort and the closure's tables share the static one; memory sees the inputs (state id, ordinal: one
+// coalesced read each, the ordinals twice) and the positions.  Returns 1 = done, 2 = not applicable (a capacity below is
+// exceeded, or the closure's order needs the queue's interpreter): nothing has been written - OrderFrontierFast takes the frame.
+//   T[i]: step 2 bucket id -> step 4 rank | shared-bucket index << 13 | shared << 26 -> step 5 on: first-of-bucket rank (13
+//   bits) | rank inside the bucket (8 bits) << 13 | (entry of tmp_epslist + 1) << 21.
+constexpr int kT1Nodes = 1024, kT1Links = 1024, kT1New = 511;
+__device__ int OrderFrontierLds(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
+  const int tid = OpaqueTid();
+  const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, n_emit = ne_emit - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
+  const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
+  const int nl = le - lb, n_new = fe - ne_emit;
+  const int Hw = static_cast<int>((H + 31u) >> 5), qw = static_cast<int>((qbase + 31u) >> 5);
+  // Bitmaps: the ordinals (qw words) need their prefix counts, the shared buckets (Hw) too, the occupied buckets (Hw) do not.
+  // Side by side when everything fits the static area; else the ordinals first (the rank joins the bucket id in T: 17 + 13
+  // bits), then the two bucket bitmaps - the table never shrinks (:219-225), so an utterance that once held a 40 k-token
+  // frame keeps 2 x 2500 words of bucket bits for good.
+  const bool comb = 2 * (qw + 2 * Hw) <= kLdsSlots;
+  if (n > kLdsSlots || (!comb && (2 * qw > kLdsSlots || 3 * Hw > kLdsSlots || H > (1u << 17))) || eps_n > kT1Nodes || nl > kT1Links || n_new > kT1New)
+    return 2;
+  const LdsU32 K = (LdsU32)LdsKeys(sh), T = (LdsU32)LdsVals(sh);
+  constexpr int kU = 8;
+  if (u.phase_cycles != nullptr && tid == 0) sh->t_sub = static_cast<long long>(__builtin_amdgcn_s_memtime());
+  // word offsets of the ordinal bits, the occupied-bucket bits, the shared-bucket bits; P / P2: prefix counts of the first / last
+  const int o1 = comb ? qw : 0, o2 = o1 + Hw, W1 = o2 + Hw;
+  const LdsU32 P = comb ? K + W1 : K + qw;          // prefix counts of the ordinal bits (comb: of all three bitmaps)
+  const LdsU32 P2 = comb ? K + W1 + o2 : K + 2 * Hw;   // ... of the shared-bucket bits, by word of that bitmap
+  if (tid == 0) sh->flag = 0;
+  if (!comb) {
+    // ---- 1a. the ordinals alone: ranks into T next to the bucket id
+    for (int w = tid; w < qw; w += NT) K[w] = 0u;
+    LdsSync();
+    for (int i0 = tid; i0 < n; i0 += NT * kU) {
+      int32_t sid[kU];
+      uint32_t qv[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = min(i0 + k * NT, n - 1);
+        sid[k] = i < n_emit ? UX(x_bkt)[i] : -1 - p.unit_ilabel[u.tok_state[nb + i]];
+        qv[k] = UX(x_q)[i];
+      }
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = i0 + k * NT;
+        if (i >= n) continue;
+        T[i] = static_cast<uint32_t>(sid[k]) % H;
+        if (i < n_emit) (void)__hip_atomic_fetch_or(&K[qv[k] >> 5], 1u << (qv[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    LdsSync();
+    (void)BitmapPrefix(K, P, qw, sh);
+    LdsSync();
+    for (int i = tid; i < n_emit; i += NT) T[i] |= static_cast<uint32_t>(BitRank(K, P, UX(x_q)[i])) << 17;
+    LdsSync();
+    // ---- 1b. the bucket bitmaps
+    for (int w = tid; w < 2 * Hw; w += NT) K[w] = 0u;
+    LdsSync();
+    for (int i = tid; i < n_emit; i += NT) {
+      const uint32_t bk = T[i] & 0x1ffffu, m = 1u << (bk & 31u);
+      const uint32_t old = __hip_atomic_fetch_or(&K[o1 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((old & m) != 0u) (void)__hip_atomic_fetch_or(&K[o2 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  } else {
+    // ---- 1-2. bitmaps (ordinals, occupied buckets, shared buckets); T = bucket id
+    for (int w = tid; w < W1; w += NT) K[w] = 0u;
+    LdsSync();
+    for (int i0 = tid; i0 < n; i0 += NT * kU) {
+      int32_t sid[kU];
+      uint32_t qv[kU];
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = min(i0 + k * NT, n - 1);
+        sid[k] = i < n_emit ? UX(x_bkt)[i] : -1 - p.unit_ilabel[u.tok_state[nb + i]];
+        qv[k] = UX(x_q)[i];
+      }
+#pragma unroll
+      for (int k = 0; k < kU; k++) {
+        const int i = i0 + k * NT;
+        if (i >= n) continue;
+        const uint32_t bk = static_cast<uint32_t>(sid[k]) % H;
+        T[i] = bk;
+        if (i < n_emit) {
+          const uint32_t m = 1u << (bk & 31u);
+          const uint32_t old = __hip_atomic_fetch_or(&K[o1 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((old & m) != 0u) (void)__hip_atomic_fetch_or(&K[o2 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_or(&K[qv[k] >> 5], 1u << (qv[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+  LdsSync();
+  for (int i = n_emit + tid; i < n; i += NT) {   // a token of the closure in an occupied bucket shares it
+    const uint32_t bk = T[i] & 0x1ffffu, m = 1u << (bk & 31u);
+    if ((K[o1 + (bk >> 5)] & m) != 0u) (void)__hip_atomic_fetch_or(&K[o2 + (bk >> 5)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  LdsSync();
+  int n_b2;   // buckets with more than one token
+  if (comb) {
+    const int n_bits = BitmapPrefix(K, P, W1, sh);
+    LdsSync();
+    const int pre2 = static_cast<int>(P[o2]);
+    n_b2 = n_bits - pre2;
+    LdsSync();   // (every lane has read P[o2] = P2[0] before it is rewritten)
+    for (int w = tid; w < Hw; w += NT) P2[w] -= static_cast<uint32_t>(pre2);   // (prefix counts of the shared-bucket bits alone)
+    LdsSync();
+  } else {
+    n_b2 = BitmapPrefix(K + o2, P2, Hw, sh);
+    LdsSync();
+  }
+  if (n_b2 > kLdsSlots / 2) return 2;
+  // ---- 4. ranks, shared-bucket indices.  (The closure's tokens alone in their bucket keep the bucket id in a side array.)
+  uint32_t tw[kU];   // (a lane's words: the bitmaps are read here, T is rewritten behind a barrier - the side array lies over them)
+  int cb[kU];
+#pragma unroll
+  for (int k = 0; k < kU; k++) {
+    tw[k] = 0u;
+    cb[k] = -1;
+    const int i = tid + k * NT;
+    if (i >= n) continue;
+    const uint32_t t0 = T[i], bk = t0 & 0x1ffffu, m = 1u << (bk & 31u);
+    const uint32_t bits2 = K[o2 + (bk >> 5)];
+    uint32_t word = 0u;
+    if (i < n_emit) word = comb ? static_cast<uint32_t>(BitRank(K, P, UX(x_q)[i])) : t0 >> 17;
+    if ((bits2 & m) != 0u) word |= ((P2[bk >> 5] + static_cast<uint32_t>(__popc(bits2 & (m - 1u)))) << 13) | (1u << 26);
+    else if (i >= n_emit) cb[k] = static_cast<int>(bk);
+    tw[k] = word;
+  }
+  LdsSync();   // (every lane has read the bitmaps and its T words)
+  const LdsU32 Cb = K + 7168;          // [512] closure token -> bucket id + 1 if it is alone there, else 0
+  const LdsU32 Cr = K + 7168 + 512;    // [512] closure token -> its rank
+#pragma unroll
+  for (int k = 0; k < kU; k++) {
+    const int i = tid + k * NT;
+    if (i >= n) continue;
+    T[i] = tw[k];
+    if (i >= n_emit) Cb[i - n_emit] = static_cast<uint32_t>(cb[k] + 1);
+  }
+  // ---- 5. the tokens of the shared buckets: counting sort by bucket index (counts K[0, n_b2), ranks as 16-bit words behind)
+  const LdsU16 M16 = (LdsU16)(K + kLdsSlots / 2);
+  if (n_b2 > 0) {
+    for (int w = tid; w < n_b2; w += NT) K[w] = 0u;
+    LdsSync();
+    for (int i = tid; i < n_emit; i += NT) {
+      const uint32_t w = T[i];
+      if ((w >> 26) & 1u) (void)__hip_atomic_fetch_add(&K[(w >> 13) & 0x1fffu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    LdsSync();
+    const int n_multi = LdsExScanInPlace(K, n_b2, sh);
+    LdsSync();
+    if (n_multi > 2 * (7168 - kLdsSlots / 2)) return 2;   // (the ranks' 16-bit words end where the closure's side arrays begin)
+    for (int i = tid; i < n_emit; i += NT) {
+      const uint32_t w = T[i];
+      if ((w >> 26) & 1u)
+        M16[__hip_atomic_fetch_add(&K[(w >> 13) & 0x1fffu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = static_cast<uint16_t>(w & 0x1fffu);
+    }
+    LdsSync();   // K[d] = end of bucket d's run = start of bucket d + 1's
+    bool wide = false;
+    for (int i = tid; i < n; i += NT) {
+      const uint32_t w = T[i];
+      if (((w >> 26) & 1u) == 0u) continue;
+      const int d = static_cast<int>((w >> 13) & 0x1fffu);
+      const int s0 = d > 0 ? static_cast<int>(K[d - 1]) : 0, s1 = static_cast<int>(K[d]);
+      const uint32_t r = i < n_emit ? (w & 0x1fffu) : 0xFFFFFFFFu;   // (a token of the closure comes after all of them)
+      uint32_t hm = 0xFFFFFFFFu;
+      int inb = 0;
+      for (int m = s0; m < s1; m++) {
+        const uint32_t rr = M16[m];
+        hm = rr < hm ? rr : hm;
+        inb += rr < r ? 1 : 0;
+      }
+      wide |= inb > 255;
+      T[i] = hm | (static_cast<uint32_t>(inb & 255) << 13);
+    }
+    if (wide) sh->flag = 1;
+  } else {
+    LdsSync();
+  }
+  LdsSync();
+  if (Uni(sh->flag) != 0) return 2;   // (a bucket of more than 255 tokens)
+  SubStamp(u, sh, 48);
+  const LdsU32 kQ = K, kPop = K + 1024;
+  const LdsF kNcost = (LdsF)(K + 2048);
+  const LdsI kNlr = (LdsI)(K + 3072), kCode = (LdsI)(K + 4096);
+  const LdsF kLw = (LdsF)(K + 5120);
+  typedef __attribute__((address_space(3))) unsigned long long *LdsU64;
+  const LdsU64 key64 = (LdsU64)(K + 6144 + ((reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)(K + 6144)) >> 2) & 1u));
+  int my_rank = 0;   // closure token tid: its place among the closure's insertions
+  if (n_new > 0) {
+    // ---- 6. the closure: entries of tmp_epslist into T, the queue's order by counting, the tables, the walks
+    for (int j = tid; j < eps_n; j += NT) {
+      const int i = u.tmp_epslist[j] - nb;
+      (void)__hip_atomic_fetch_or(&T[i], static_cast<uint32_t>(j + 1) << 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      kNcost[j] = j < eps_emit ? Dec(UX(x_c0e)[j]) : INFINITY;
+      kNlr[j] = 0;
+      if (j < eps_emit) {
+        const uint32_t w = T[i];   // (its low 21 bits are final; the entry number lands above them)
+        kQ[j] = ((w & 0x1fffu) << 8) | ((w >> 13) & 0xffu);
+      }
+    }
+    for (int k = tid; k < n_new; k += NT) key64[k] = ~0ull;
+    LdsSync();
+    for (int j = tid; j < eps_emit; j += NT) {
+      const uint32_t key = kQ[j];
+      int rank = 0, j2 = 0;
+      for (; j2 + 4 <= eps_emit; j2 += 4) {
+        const uint32_t a0 = kQ[j2], a1 = kQ[j2 + 1], a2 = kQ[j2 + 2], a3 = kQ[j2 + 3];
+        rank += (a0 < key ? 1 : 0) + (a1 < key ? 1 : 0) + (a2 < key ? 1 : 0) + (a3 < key ? 1 : 0);
+      }
+      for (; j2 < eps_emit; j2++) rank += kQ[j2] < key ? 1 : 0;
+      kPop[j] = static_cast<uint32_t>(eps_emit - 1 - rank);
+    }
+    {
+      constexpr int kLU = 4;
+      for (int l0 = lb + tid; l0 < le; l0 += NT * kLU) {
+        int srcs[kLU], dsts[kLU], arcs[kLU], prevs[kLU], nexts[kLU];
+        float ws[kLU];
+#pragma unroll
+        for (int k = 0; k < kLU; k++) {
+          const int l = min(l0 + k * NT, le - 1);
+          srcs[k] = u.link_src[l];
+          dsts[k] = u.link_dst[l];
+          arcs[k] = u.link_arc[l];
+          prevs[k] = l > lb ? u.link_src[l - 1] : -1;
+          nexts[k] = l + 1 < le ? u.link_src[l + 1] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < kLU; k++) ws[k] = __int_as_float(p.n_arcs[-1 - arcs[k]].z);
+#pragma unroll
+        for (int k = 0; k < kLU; k++) {
+          const int l = l0 + k * NT;
+          if (l >= le) continue;
+          const int js = static_cast<int>(T[srcs[k] - nb] >> 21) - 1;
+          int rng = 0;
+          if (prevs[k] != srcs[k]) rng |= l - lb;
+          if (nexts[k] != srcs[k]) rng |= (l - lb + 1) << 16;
+          if (rng != 0) (void)__hip_atomic_fetch_or(&kNlr[js], rng, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          int code = -1;
+          if (dsts[k] >= 0) {
+            const int e = static_cast<int>(T[dsts[k] - nb] >> 21) - 1;
+            if (e >= 0) code = e | ((dsts[k] >= ne_emit ? dsts[k] - ne_emit + 1 : 0) << 12);
+            else if (dsts[k] >= ne_emit) code = 0x40000000 | (dsts[k] - ne_emit);
+          }
+          kCode[l - lb] = code;
+          kLw[l - lb] = ws[k];
+        }
+      }
+    }
+    LdsSync();
+    // (see OrderFrontierFast for why the first pop from which a path under the cutoff leads to a token is its insertion)
+    for (int j = tid; j < eps_emit; j += NT) {
+      const float c0 = kNcost[j];
+      if (c0 > cutoff) continue;   // :779
+      const unsigned long long pop = static_cast<unsigned long long>(kPop[j]) << 40;
+      const int r = kNlr[j];
+      for (int l = r & 0xffff; l < (r >> 16); l++) {
+        int code = kCode[l];
+        if (code < 0) continue;
+        float tot = c0 + kLw[l];
+        if (!(tot < cutoff)) continue;   // :794
+        for (unsigned long long depth = 1;; depth++) {
+          const bool leaf = (code & 0x40000000) != 0;
+          const int k = leaf ? (code & 0x3fffffff) : (code >> 12) - 1;
+          if (k < 0 || depth > 30) { sh->flag = 1; break; }
+          (void)__hip_atomic_fetch_min(&key64[k], pop | (depth << 32) | static_cast<unsigned long long>(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (leaf) break;
+          const int r2 = kNlr[code & 0xfff];
+          int l2 = -1;
+          for (int ll = r2 & 0xffff; ll < (r2 >> 16); ll++)
+            if (kCode[ll] >= 0) { if (l2 >= 0) sh->flag = 1; l2 = ll; }
+          if (l2 < 0) break;
+          tot = tot + kLw[l2];
+          if (!(tot < cutoff)) break;
+          code = kCode[l2];
+        }
+      }
+    }
+    LdsSync();
+    bool bad = false;
+    if (tid < n_new) {
+      const unsigned long long mine = key64[tid];
+      bad = mine == ~0ull;
+      const unsigned long long my_pop = mine >> 40, my_depth = (mine >> 32) & 0xffull, my_chain = mine & 0xffffffffull;
+      for (int k2 = 0; k2 < n_new; k2++) {
+        const unsigned long long o = key64[k2];
+        my_rank += o < mine ? 1 : 0;
+        if (k2 != tid && (o >> 40) == my_pop) {
+          const unsigned long long od = (o >> 32) & 0xffull;
+          if (od == my_depth && (my_depth >= 2 || o == mine)) bad = true;
+          if (my_depth >= 2 && od >= 2 && (o & 0xffffffffull) != my_chain) bad = true;
+        }
+      }
+    }
+    if (bad) sh->flag = 1;
+    LdsSync();
+    if (Uni(sh->flag) != 0) return 2;   // (the queue's interpreter: OrderFrontierFast)
+    if (u.phase_cycles != nullptr && tid == 0) sh->phase[64] += 1;
+    // ---- 7. the closure's tokens: ranks; bucket mates among themselves (shared bucket: behind its tokens of the emitting pass)
+    if (tid < n_new) Cr[tid] = static_cast<uint32_t>(n_emit + my_rank);
+    LdsSync();
+    if (tid < n_new) {
+      const int i = n_emit + tid;
+      const uint32_t w = T[i], r = Cr[tid], alone = Cb[tid];
+      const uint32_t key = alone != 0u ? alone : 0x80000000u | (w & 0x1fffu);   // the bucket: its id, or the rank of its first token
+      uint32_t minr = r;
+      int before = 0;
+      for (int k2 = 0; k2 < n_new; k2++) {
+        const uint32_t a2 = Cb[k2];
+        const uint32_t key2 = a2 != 0u ? a2 : 0x80000000u | (T[n_emit + k2] & 0x1fffu);
+        if (key2 != key) continue;
+        const uint32_t r2 = Cr[k2];
+        before += r2 < r ? 1 : 0;
+        minr = r2 < minr ? r2 : minr;
+      }
+      const int inb = (alone != 0u ? 0 : static_cast<int>((w >> 13) & 0xffu)) + before;
+      if (inb > 255) sh->flag = 1;
+      my_rank = static_cast<int>((alone != 0u ? minr : (w & 0x1fffu)) | (static_cast<uint32_t>(inb & 255) << 13));   // the token's (h, inb) word
+    }
+    LdsSync();   // (every closure lane has read the others' T words)
+    if (Uni(sh->flag) != 0) return 2;
+    if (tid < n_new) T[n_emit + tid] = (T[n_emit + tid] & 0xffe00000u) | static_cast<uint32_t>(my_rank);
+  }
+  SubStamp(u, sh, 50);
+  // ---- 8. positions: tokens per first-of-bucket rank, one scan over the rank space, + the rank inside the bucket
+  LdsSync();
+  for (int w = tid; w < n; w += NT) K[w] = 0u;
+  LdsSync();
+  for (int i = tid; i < n; i += NT) (void)__hip_atomic_fetch_add(&K[T[i] & 0x1fffu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  LdsSync();
+  (void)LdsExScanInPlace(K, n, sh);
+  LdsSync();
+  for (int i = tid; i < n; i += NT) {
+    const uint32_t w = T[i];
+    UX(x_pos)[i] = static_cast<int>(K[w & 0x1fffu]) + static_cast<int>((w >> 13) & 0xffu);
+  }
+  KhSync();
+  SubStamp(u, sh, 51);
+  if (u.phase_cycles != nullptr && tid == 0) {
+    sh->phase[47] += 1; sh->phase[52] += eps_emit; sh->phase[53] += eps_n; sh->phase[54] += nl; sh->phase[55] += n_new; sh->phase[46] += n;
+    sh->phase[66] += 1;
+  }
+  return 1;
+}
+
 // List positions (x_pos) of the frame under construction.  Params::exact_order == 2 forces the sort (tests).
 __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
   const int n = fe - nb, n_new = fe - Uni(sh->x_ne_emit);
@@ -3271,7 +3618,11 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
     t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->phase[n <= 8160 ? 61 : (n <= 16384 ? 62 : 63)] += 1;
   }
-  int rc = fast ? OrderFrontierFast(u, p, nb, fe, lb, le, cutoff, sh) : 2;
+  int rc = 2;
+#ifndef KH_X_NO_LDS_TIER
+  if (fast) rc = OrderFrontierLds(u, p, nb, fe, lb, le, cutoff, sh);
+#endif
+  if (fast && rc == 2) rc = OrderFrontierFast(u, p, nb, fe, lb, le, cutoff, sh);
   if (u.phase_cycles != nullptr && threadIdx.x == 0) {
     const long long t1 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (rc == 1) sh->phase[59] += t1 - t0;
@@ -6578,8 +6929,8 @@ void PrintPhases(const std::vector<long long> &h_phase, int grid, int round, int
   if (tot[45]) fprintf(stderr, " list_order=%.1f%% (ranks + buckets %.1f%%, queue order %.1f%%, replay %.1f%%, positions %.1f%% of it; %lld frames from LDS, %lld by the sort; "
                        "%lld of the %lld candidates under the running cutoff)", 100.0 * tot[45] / all,
                        100.0 * tot[48] / tot[45], 100.0 * tot[49] / tot[45], 100.0 * tot[50] / tot[45], 100.0 * tot[51] / tot[45], tot[56], tot[57], tot[58], tot[31]);
-  if (tot[45]) fprintf(stderr, " [frames of <= 8160 / <= 16384 / more tokens: %lld / %lld / %lld; cycles per frame from LDS %.0f, by the sort %.0f; closure order by walks in %lld frames, by the queue in %lld]",
-                       tot[61], tot[62], tot[63], tot[56] ? double(tot[59]) / tot[56] : 0.0, tot[57] ? double(tot[60]) / tot[57] : 0.0, tot[64], tot[65]);
+  if (tot[45]) fprintf(stderr, " [frames of <= 8160 / <= 16384 / more tokens: %lld / %lld / %lld; cycles per frame from LDS %.0f, by the sort %.0f; closure order by walks in %lld frames, by the queue in %lld; %lld frames with every intermediate in LDS]",
+                       tot[61], tot[62], tot[63], tot[56] + tot[66] ? double(tot[59]) / (tot[56] + tot[66]) : 0.0, tot[57] ? double(tot[60]) / tot[57] : 0.0, tot[64], tot[65], tot[66]);
 #ifdef KH_X_STAMPS
   if (tot[47]) {
     fprintf(stderr, "\n[kh_decoder profile] fine stamps, cycles per frame:");
