@@ -3664,10 +3664,13 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   const int n = e - b;
   if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }
+  XS(27);
   StageScoreRow(u, p, sh, frame);
   Stamp(u, sh, 15);
+  XS(24);
   const Cutoff c = GetCutoff<true>(u, p, b, e, sh);
   Stamp(u, sh, 0);
+  XS(25);
   const int link_frame_b = Uni(sh->link_end);
   if (threadIdx.x == 0) {
     if (c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
@@ -4003,7 +4006,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     sh->link_end = link_frame_e;
     sh->front_b = nb;
   }
-  KhSync();
+  if (lds_scan) LdsSync(); else KhSync();   // (the scan through memory: its results by token have landed)
   // ---- the candidates against the running cutoff in front of their source token (:731); ordinals
   int n_acc = 0;
   {
@@ -4068,7 +4071,9 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     for (int i = tid; i < n_new; i += NT) {
       if (in_lds) qtab[i] = 0xFFFFFFFFu; else UX(x_q)[i] = 0xFFFFFFFFu;
     }
-    KhSync();
+    // (pass 2 ended behind a barrier that waited for its stores: the links' destinations are in memory; only a table in
+    // memory needs another such barrier)
+    if (in_lds) LdsSync(); else KhSync();
     {
       constexpr int kOU = 4;   // (a lane's loads of four trips in flight together)
       for (int l0 = link_frame_b + tid; l0 < link_frame_e; l0 += NT * kOU) {
@@ -4100,14 +4105,15 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         if (sid_lds) UX(x_bkt)[i] = static_cast<int32_t>(stab[i]);
       }
   }
-  const long long tot_arcs = BlockSumLL(my_arcs, sh);   // (its barrier waits for the stores above)
+  // the arcs visited, for the utterance's counter: one LDS add per wave (lane 0 holds the wave's count), no block reduction;
+  // the insertion keys and state ids are read by the list order, several store-draining barriers from here
+  if ((tid & 63) == 0 && my_arcs != 0) (void)__hip_atomic_fetch_add(&sh->arcs_expanded, my_arcs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (tid == 0) {
-    sh->arcs_expanded += tot_arcs;
     sh->wl_n[0] = sh->eps_n;
     sh->x_eps_emit = sh->eps_n;
     sh->x_ne_emit = sh->tok_end;
   }
-  KhSync();
+  LdsSync();
   XS(58);
   Stamp(u, sh, 2);
   *next_cutoff_out = next_cutoff;
@@ -5239,6 +5245,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       Stamp(u, sh, 4);
       ok = OrderFrontier(u, p, fb, fe, Uni(u.feps_b[t + 1]), Uni(u.feps_e[t + 1]), next_cutoff, sh);
       Stamp(u, sh, 45);
+      XS(28);
       if (!ok) break;
     }
     if (threadIdx.x == 0) {
@@ -5250,6 +5257,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
     Stamp(u, sh, 15);
     ClearHash(u, fb, fe, sh);
     Stamp(u, sh, 5);
+    XS(29);
   }
   run->t = t;
   run->fb = fb;
