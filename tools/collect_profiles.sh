@@ -41,6 +41,17 @@ rm -rf "$out/kt_lat"
 # the decoder in the reference's own iteration order: phase shares
 KH_DECODER_ORDER=reference KH_DECODER_PROFILE=1 timeout $T python3 bench.py --steps 1 --warmup 0 --no-secondary --no-extra-legs --no-end-to-end --no-cpu-baseline > /dev/null 2> "$out/exact.err"
 python3 tools/phases_extract.py "$out/exact.err" > "$out/${tag}_decoder_phases_reference_order.txt"
+# ... and its bytes and instructions (the kernel that is bit-exact to the reference: roofline.reference_order of the bench line)
+{
+  echo "# DecodeKernel<reference order> (KH_DECODER_ORDER=reference), one launch: separate rocprofv3 --pmc passes over bench.py --steps 1 --warmup 0"
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+    rm -rf "$out/pmc_x"
+    KH_DECODER_ORDER=reference timeout -k 10 $T rocprofv3 --pmc $set --output-format csv -d "$out/pmc_x" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-extra-legs --no-end-to-end > /dev/null 2> "$out/pmc_x.log"
+    f=$(find "$out/pmc_x" -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python3 tools/pmc_summarize.py "$f" DecodeKernel | grep -v "^#"
+  done
+  rm -rf "$out/pmc_x"
+} > "$out/${tag}_pmc_reference_order.txt"
 # the bench line LAST: its roofline.traffic reads the PMC record of THIS build (pmc_record.py fails when a pass
 # left no summary, and stamps the record with the kernel source's hash: bench.py refuses a record of another build)
 python3 tools/pmc_record.py "$out/${tag}_pmc_FETCH_SIZE.txt" "$out/${tag}_pmc_WRITE_SIZE.txt" "$out/${tag}_bench_kernel_stats.csv" "$out/${tag}_pmc_traffic.json" || { echo "collect_profiles: PMC record incomplete" >&2; exit 1; }
