@@ -1,0 +1,406 @@
+// gemm_lab2.hip — round 5: the operand image in LDS as [row][16 k] with the k of a row permuted so that ONE ds_read_b128
+// gives a lane its operand of four consecutive v_mfma_f32_32x32x2_f32 steps (lanes 0-31: k = 8g + 0,2,4,6; lanes 32-63:
+// k = 8g + 1,3,5,7), and a thread's float4 of global memory goes to LDS as two ds_write_b64 — against the production
+// image [k][row + 4] (one ds_read_b32 per operand and step, four ds_write_b32 per float4).  16-byte chunks of a row are
+// XOR-swizzled with (row >> 2) & 3: the b128 reads of 16 consecutive rows cover the 64 banks once.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math tools/gemm_lab2.hip -o tools/gemm_lab2
+//   tools/gemm_lab2 [group_m] [reps]
+// Every variant must give the bits of the first row (the production tiling): one k-ordered fmaf chain per element.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x)                                                          \
+  do {                                                                 \
+    hipError_t e_ = (x);                                               \
+    if (e_ != hipSuccess) {                                            \
+      printf("%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      exit(1);                                                         \
+    }                                                                  \
+  } while (0)
+
+namespace {
+
+constexpr int BK = 16;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float *A, *B;
+  float *C;
+  const float *bias;
+  int M, N, K;
+  long a_si, b_sj;
+  int c_stride;
+  int tiles_m, tiles_n, group_m;
+};
+
+__device__ __forceinline__ int XcdRemap(int bid, int nwg) {
+  const int cpx = nwg >> 3, rem = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  return xcd < rem ? xcd * (cpx + 1) + local : rem * (cpx + 1) + (xcd - rem) * cpx + local;
+}
+
+__device__ __forceinline__ float4 LoadRow4(const float *base, long s_row, int row, int k, int rows, int K) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < rows) {
+    const float *p = base + row * s_row + k;
+    if (k + 3 < K) {
+      v = *reinterpret_cast<const float4 *>(p);
+    } else {
+      if (k < K) v.x = p[0];
+      if (k + 1 < K) v.y = p[1];
+      if (k + 2 < K) v.z = p[2];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ void TileOf(const GemmArgs &g, int *tm, int *tn) {
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int tile = XcdRemap(blockIdx.x, nwg);
+  const int per = g.group_m * g.tiles_n;
+  const int gid = tile / per, in = tile - gid * per;
+  const int first_m = gid * g.group_m;
+  const int gsz = min(g.tiles_m - first_m, g.group_m);
+  *tn = in / gsz;
+  *tm = first_m + (in - *tn * gsz);
+}
+
+__device__ __forceinline__ void Prio() {
+  switch ((blockIdx.x >> 8) & 3) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+}
+
+// ---- the production tiling (kh_gemm.hip GemmKernel): [k][row + 4] image, 2 x 2 waves of 2 x 2 MFMA tiles
+__global__ void __launch_bounds__(256, 4) GemmBase(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, NT = 256, LA = BM + 4;
+  __shared__ float As[2][BK][LA];
+  __shared__ float Bs[2][BK][LA];
+  Prio();
+  int tm, tn;
+  TileOf(g, &tm, &tn);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int lrow = t >> 2, lk = (t & 3) << 2, kk = lane >> 5, l31 = lane & 31;
+  const int nk = (g.K + BK - 1) / BK;
+  const int m0 = tm * BM, n0 = tn * BN, rowsA = g.M - m0, rowsB = g.N - n0;
+  const float *Ab = g.A + static_cast<long>(m0) * g.a_si, *Bb = g.B + static_cast<long>(n0) * g.b_sj;
+  const bool full = rowsA >= BM && rowsB >= BN;
+  float4 ra[2], rb[2];
+  unsigned offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    offa[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.a_si) + lk) * 4u;
+    offb[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.b_sj) + lk) * 4u;
+  }
+  auto load_tile = [&](int k0) {
+    if (full && k0 + BK <= g.K) {
+      const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+      for (int i = 0; i < 2; i++) { ra[i] = *reinterpret_cast<const float4 *>(pa + offa[i]); rb[i] = *reinterpret_cast<const float4 *>(pb + offb[i]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ra[i] = LoadRow4(Ab, g.a_si, lrow + NT / 4 * i, k0 + lk, rowsA, g.K);
+        rb[i] = LoadRow4(Bb, g.b_sj, lrow + NT / 4 * i, k0 + lk, rowsB, g.K);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int m = lrow + NT / 4 * i;
+      As[buf][lk + 0][m] = ra[i].x; As[buf][lk + 1][m] = ra[i].y; As[buf][lk + 2][m] = ra[i].z; As[buf][lk + 3][m] = ra[i].w;
+      Bs[buf][lk + 0][m] = rb[i].x; Bs[buf][lk + 1][m] = rb[i].y; Bs[buf][lk + 2][m] = rb[i].z; Bs[buf][lk + 3][m] = rb[i].w;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      const int k = 2 * s + kk;
+      float a0 = As[buf][k][wm * 64 + l31], a1 = As[buf][k][wm * 64 + 32 + l31];
+      float b0 = Bs[buf][k][wn * 64 + l31], b1 = Bs[buf][k][wn * 64 + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int col = n0 + (wu & 1) * 64 + l31;
+    const float bv0 = g.bias[col], bv1 = g.bias[col + 32];
+    float *cb = g.C + static_cast<size_t>(m0 + (wu >> 1) * 64) * g.c_stride + n0 + (wu & 1) * 64;
+    const unsigned voff = static_cast<unsigned>(4 * kk) * g.c_stride + l31;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *cp = cb + static_cast<size_t>(i * 32 + (r & 3) + 8 * (r >> 2)) * g.c_stride;
+        cp[voff] = acc[i][0][r] + bv0;
+        cp[voff + 32] = acc[i][1][r] + bv1;
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row >= g.M) continue;
+        g.C[static_cast<size_t>(row) * g.c_stride + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+
+// ---- [row][16 k] image, b128 operand reads.  WM x WN waves, each TM x TN MFMA tiles of 32 x 32.
+template <int WM, int WN, int TM, int TN, int OCC, bool PRIO>
+__global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
+  constexpr int RA = BM * 4 / NT, RB = BN * 4 / NT;
+  static_assert(RA * NT == BM * 4 && RB * NT == BN * 4, "whole float4 loads per thread");
+  __shared__ __attribute__((aligned(16))) float As[2][BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][BK];
+  if (PRIO) Prio();
+  int tm, tn;
+  TileOf(g, &tm, &tn);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = t >> 2, quad = t & 3, lk = quad << 2, kk = lane >> 5, l31 = lane & 31;
+  const int nk = (g.K + BK - 1) / BK;
+  const int m0 = tm * BM, n0 = tn * BN, rowsA = g.M - m0, rowsB = g.N - n0;
+  const float *Ab = g.A + static_cast<long>(m0) * g.a_si, *Bb = g.B + static_cast<long>(n0) * g.b_sj;
+  const bool full = rowsA >= BM && rowsB >= BN;
+  float4 ra[RA], rb[RB];
+  unsigned offa[RA], offb[RB];
+#pragma unroll
+  for (int i = 0; i < RA; i++) offa[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.a_si) + lk) * 4u;
+#pragma unroll
+  for (int i = 0; i < RB; i++) offb[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.b_sj) + lk) * 4u;
+  auto load_tile = [&](int k0) {
+    if (full && k0 + BK <= g.K) {
+      const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+      for (int i = 0; i < RA; i++) ra[i] = *reinterpret_cast<const float4 *>(pa + offa[i]);
+#pragma unroll
+      for (int i = 0; i < RB; i++) rb[i] = *reinterpret_cast<const float4 *>(pb + offb[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; i++) ra[i] = LoadRow4(Ab, g.a_si, lrow + NT / 4 * i, k0 + lk, rowsA, g.K);
+#pragma unroll
+      for (int i = 0; i < RB; i++) rb[i] = LoadRow4(Bb, g.b_sj, lrow + NT / 4 * i, k0 + lk, rowsB, g.K);
+    }
+  };
+  // a thread's float4 = k 4 quad .. 4 quad + 3 of one row: (x, z) go to the even-k chunk of the row's 8-group, (y, w) to the odd one
+  const int grp = quad >> 1, q2 = (quad & 1) * 2;
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; i++) {
+      const int m = lrow + NT / 4 * i, sw = (m >> 2) & 3;
+      *reinterpret_cast<float2 *>(&As[buf][m][((grp * 2 + 0) ^ sw) * 4 + q2]) = make_float2(ra[i].x, ra[i].z);
+      *reinterpret_cast<float2 *>(&As[buf][m][((grp * 2 + 1) ^ sw) * 4 + q2]) = make_float2(ra[i].y, ra[i].w);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+      const int m = lrow + NT / 4 * i, sw = (m >> 2) & 3;
+      *reinterpret_cast<float2 *>(&Bs[buf][m][((grp * 2 + 0) ^ sw) * 4 + q2]) = make_float2(rb[i].x, rb[i].z);
+      *reinterpret_cast<float2 *>(&Bs[buf][m][((grp * 2 + 1) ^ sw) * 4 + q2]) = make_float2(rb[i].y, rb[i].w);
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int swl = (l31 >> 2) & 3;   // (a tile's first row is a multiple of 32)
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int g2 = 0; g2 < 2; g2++) {
+      const int ch = ((g2 * 2 + kk) ^ swl) * 4;
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const float4 *>(&As[buf][(wm * TM + i) * 32 + l31][ch]);
+#pragma unroll
+      for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * TN + j) * 32 + l31][ch]);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            const float a = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+            const float b = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+    }
+    if (kt + 1 < nk) {
+      store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) bv[j] = g.bias[n0 + (wn * TN + j) * 32 + l31];
+    float *cb = g.C + static_cast<size_t>(m0 + wm * TM * 32) * g.c_stride + n0 + wn * TN * 32;
+    const unsigned voff = static_cast<unsigned>(4 * kk) * g.c_stride + l31;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *cp = cb + static_cast<size_t>(i * 32 + (r & 3) + 8 * (r >> 2)) * g.c_stride;
+#pragma unroll
+        for (int j = 0; j < TN; j++) cp[voff + 32 * j] = acc[i][j][r] + bv[j];
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row >= g.M) continue;
+        g.C[static_cast<size_t>(row) * g.c_stride + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+
+void LaunchBase(GemmArgs g) {
+  g.tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.N + 127) / 128;
+  hipLaunchKernelGGL(GemmBase, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, 0, g);
+}
+template <int WM, int WN, int TM, int TN, int OCC, bool PRIO>
+void LaunchV(GemmArgs g) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL((GemmV<WM, WN, TM, TN, OCC, PRIO>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WM * WN), 0, 0, g);
+}
+
+typedef void (*LaunchFn)(GemmArgs);
+struct Var {
+  const char *name;
+  LaunchFn fn;
+};
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const int group_m = argc > 1 ? atoi(argv[1]) : 8;
+  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  const Var vars[] = {
+      {"production tiling 128x128 [k][row]", LaunchBase},
+      {"b128 128x128, 2x2 waves of 2x2, occ 4, prio", LaunchV<2, 2, 2, 2, 4, true>},
+      {"b128 128x128, 2x2 waves of 2x2, occ 4", LaunchV<2, 2, 2, 2, 4, false>},
+      {"b128 128x128, 2x2 waves of 2x2, occ 3", LaunchV<2, 2, 2, 2, 3, true>},
+      {"b128 128x128, 4x1 waves of 1x4, occ 4", LaunchV<4, 1, 1, 4, 4, true>},
+      {"b128 256x128, 2x2 waves of 4x2, occ 2", LaunchV<2, 2, 4, 2, 2, true>},
+      {"b128 128x256, 2x2 waves of 2x4, occ 2", LaunchV<2, 2, 2, 4, 2, true>},
+      {"b128 256x128, 4x2 waves of 2x2, occ 2", LaunchV<4, 2, 2, 2, 2, true>},
+      {"b128 256x256, 2x2 waves of 4x4, occ 1", LaunchV<2, 2, 4, 4, 1, false>},
+      {"b128 256x256, 4x2 waves of 2x4, occ 1", LaunchV<4, 2, 2, 4, 1, false>},
+      {"b128 192x128, 2x2 waves of 3x2, occ 3", LaunchV<2, 2, 3, 2, 3, true>},
+  };
+  const int shapes[][3] = {{60000, 3500, 350}, {60000, 12000, 350}};
+  for (const auto &sh : shapes) {
+    const int M = sh[0], N = sh[1], K = sh[2];
+    const int lda = (K + 3) & ~3, ldc = (N + 3) & ~3;
+    std::vector<float> hA(static_cast<size_t>(M) * lda), hB(static_cast<size_t>(N) * lda), hbias(N);
+    uint32_t s = 12345u + K + N;
+    auto rnd = [&]() {
+      s = s * 1664525u + 1013904223u;
+      return (static_cast<int>(s >> 8) & 0xffff) / 32768.0f - 1.0f;
+    };
+    for (auto &x : hA) x = rnd();
+    for (auto &x : hB) x = rnd() * 0.05f;
+    for (auto &x : hbias) x = rnd();
+    float *dA, *dB, *dC, *dbias;
+    const size_t c_bytes = static_cast<size_t>(M) * ldc * 4;
+    CK(hipMalloc(&dA, hA.size() * 4));
+    CK(hipMalloc(&dB, hB.size() * 4));
+    CK(hipMalloc(&dbias, N * 4));
+    CK(hipMalloc(&dC, c_bytes));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice));
+    GemmArgs g;
+    g.A = dA; g.B = dB; g.C = dC; g.bias = dbias;
+    g.M = M; g.N = N; g.K = K; g.a_si = lda; g.b_sj = lda; g.c_stride = ldc;
+    g.group_m = group_m;
+    printf("== M %d N %d K %d (group_m %d)\n", M, N, K, group_m);
+    const double flop = 2.0 * M * N * K;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<float> h0(static_cast<size_t>(M) * ldc), h1(static_cast<size_t>(M) * ldc);
+    bool first = true;
+    for (const Var &v : vars) {
+      int same = 1;
+      CK(hipMemset(dC, 0xff, c_bytes));
+      v.fn(g);
+      CK(hipDeviceSynchronize());
+      if (first) {
+        CK(hipMemcpy(h0.data(), dC, c_bytes, hipMemcpyDeviceToHost));
+        first = false;
+      } else {
+        CK(hipMemcpy(h1.data(), dC, c_bytes, hipMemcpyDeviceToHost));
+        for (int i = 0; i < M && same; i++)
+          if (memcmp(&h0[static_cast<size_t>(i) * ldc], &h1[static_cast<size_t>(i) * ldc], N * 4)) same = 0;
+      }
+      for (int r = 0; r < 4 * reps; r++) v.fn(g);
+      CK(hipEventRecord(e0, 0));
+      for (int r = 0; r < reps; r++) v.fn(g);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= reps;
+      printf("%-48s %8.3f ms  %6.1f TFLOP/s  %s\n", v.name, ms, flop / ms / 1e9, same ? "bits ok" : "BITS DIFFER");
+    }
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dbias));
+  }
+  return 0;
+}
