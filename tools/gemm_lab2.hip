@@ -207,19 +207,18 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
   for (int i = 0; i < RA; i++) offa[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.a_si) + lk) * 4u;
 #pragma unroll
   for (int i = 0; i < RB; i++) offb[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.b_sj) + lk) * 4u;
+  auto load_fast = [&](int k0) {
+    const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+    for (int i = 0; i < RA; i++) ra[i] = *reinterpret_cast<const float4 *>(pa + offa[i]);
+#pragma unroll
+    for (int i = 0; i < RB; i++) rb[i] = *reinterpret_cast<const float4 *>(pb + offb[i]);
+  };
   auto load_tile = [&](int k0) {
-    if (full && k0 + BK <= g.K) {
-      const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
 #pragma unroll
-      for (int i = 0; i < RA; i++) ra[i] = *reinterpret_cast<const float4 *>(pa + offa[i]);
+    for (int i = 0; i < RA; i++) ra[i] = LoadRow4(Ab, g.a_si, lrow + NT / 4 * i, k0 + lk, rowsA, g.K);
 #pragma unroll
-      for (int i = 0; i < RB; i++) rb[i] = *reinterpret_cast<const float4 *>(pb + offb[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < RA; i++) ra[i] = LoadRow4(Ab, g.a_si, lrow + NT / 4 * i, k0 + lk, rowsA, g.K);
-#pragma unroll
-      for (int i = 0; i < RB; i++) rb[i] = LoadRow4(Bb, g.b_sj, lrow + NT / 4 * i, k0 + lk, rowsB, g.K);
-    }
+    for (int i = 0; i < RB; i++) rb[i] = LoadRow4(Bb, g.b_sj, lrow + NT / 4 * i, k0 + lk, rowsB, g.K);
   };
   // a thread's float4 = k 4 quad .. 4 quad + 3 of one row: (x, z) go to the even-k chunk of the row's 8-group, (y, w) to the odd one
   const int grp = quad >> 1, q2 = (quad & 1) * 2;
@@ -227,14 +226,16 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < RA; i++) {
       const int m = lrow + NT / 4 * i, sw = (m >> 2) & 3;
-      *reinterpret_cast<float2 *>(&As[buf][m][((grp * 2 + 0) ^ sw) * 4 + q2]) = make_float2(ra[i].x, ra[i].z);
-      *reinterpret_cast<float2 *>(&As[buf][m][((grp * 2 + 1) ^ sw) * 4 + q2]) = make_float2(ra[i].y, ra[i].w);
+      float *pe = &As[buf][m][((grp * 2 + 0) ^ sw) * 4 + q2], *po = &As[buf][m][((grp * 2 + 1) ^ sw) * 4 + q2];
+      pe[0] = ra[i].x; pe[1] = ra[i].z;   // (two dwords of one ds_write2_b32: no register pair to assemble)
+      po[0] = ra[i].y; po[1] = ra[i].w;
     }
 #pragma unroll
     for (int i = 0; i < RB; i++) {
       const int m = lrow + NT / 4 * i, sw = (m >> 2) & 3;
-      *reinterpret_cast<float2 *>(&Bs[buf][m][((grp * 2 + 0) ^ sw) * 4 + q2]) = make_float2(rb[i].x, rb[i].z);
-      *reinterpret_cast<float2 *>(&Bs[buf][m][((grp * 2 + 1) ^ sw) * 4 + q2]) = make_float2(rb[i].y, rb[i].w);
+      float *pe = &Bs[buf][m][((grp * 2 + 0) ^ sw) * 4 + q2], *po = &Bs[buf][m][((grp * 2 + 1) ^ sw) * 4 + q2];
+      pe[0] = rb[i].x; pe[1] = rb[i].z;
+      po[0] = rb[i].y; po[1] = rb[i].w;
     }
   };
   f32x16 acc[TM][TN];
@@ -248,9 +249,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
   store_tile(0);
   __syncthreads();
   const int swl = (l31 >> 2) & 3;   // (a tile's first row is a multiple of 32)
-  for (int kt = 0; kt < nk; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+  auto mma = [&](int buf) {
 #pragma unroll
     for (int g2 = 0; g2 < 2; g2++) {
       const int ch = ((g2 * 2 + kk) ^ swl) * 4;
@@ -270,6 +269,23 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
           }
     }
+  };
+  int kt = 0;
+  if (full) {   // whole slabs of an interior tile: a loop without a branch in it
+    const int nfast = g.K / BK;
+    for (; kt + 1 < nfast; kt++) {
+      load_fast((kt + 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);   // (the loads first: left to itself the scheduler sinks them to the end of the MFMA run)
+      mma(kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tile((kt & 1) ^ 1);
+      __syncthreads();
+    }
+  }
+  for (; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    mma(buf);
     if (kt + 1 < nk) {
       store_tile(buf ^ 1);
       __syncthreads();
