@@ -470,11 +470,10 @@ int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream,
 int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *dec, int enable);
 /* kh_decoder_set_reference_order for the streams: LatticeFasterOnlineDecoder::ProcessEmitting (decoder/lattice-faster-online-
  * decoder.cc:864-951) walks the same HashList against the same running next_cutoff as the offline decoder, and with this set
- * the launch-per-job calls (kh_online_decoder_init_decoding / _advance / _finalize) reproduce it: chunked decoding, the
- * offline kernel in reference order and the line-by-line oracle (mode 0) give the same lattices bit for bit.  Between
- * utterances only (KH_ESTATE while a stream is in a decoding run).  The persistent serving kernel keeps the
- * order-independent rule: kh_online_decoder_serve_start refuses to start in this mode.  KH_DECODER_ORDER=reference in the
- * environment sets it at creation. */
+ * the launch-per-job calls (kh_online_decoder_init_decoding / _advance / _finalize) and the persistent serving kernel
+ * (kh_online_decoder_serve_*, started afterwards) reproduce it: chunked decoding, the offline kernel in reference order and
+ * the line-by-line oracle (mode 0) give the same lattices bit for bit.  Between utterances only (KH_ESTATE while a stream is
+ * in a decoding run or the serving kernel is running).  KH_DECODER_ORDER=reference in the environment sets it at creation. */
 int kh_online_decoder_set_reference_order(KhOnlineDecoder *dec, int enable);
 /* The same three calls without a kernel launch per chunk: a PERSISTENT serving kernel, one resident workgroup per stream
  * (num_streams <= 2 x the CU count), which waits on a control block in pinned host memory (online2-wav-nnet2-latgen-faster's

@@ -5782,13 +5782,15 @@ __device__ __forceinline__ int32_t SysLoad(T p) { return __hip_atomic_load(p, __
 template <class T>
 __device__ __forceinline__ void SysStore(T p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// kExact: the streams decode in the reference's own iteration order (OnlineKernel<true>'s routines; the slots' temporaries in slotsx).
+template <bool kExact>
 __global__ void __launch_bounds__(NT)
 #if KH_WG_PER_CU > 1
 __attribute__((amdgpu_waves_per_eu(NT / 256 * KH_WG_PER_CU, NT / 256 * KH_WG_PER_CU)))
 #endif
 ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, ServeCtl *ctl, int32_t *quit,
             const float *ll_base, long long ll_rows_per_stream, int ll_stride, Params p, long long idle_ticks,
-            long long *act_clock /* [gridDim.x] wall clock of every stream's last activity */) {
+            long long *act_clock /* [gridDim.x] wall clock of every stream's last activity */, const UttX *slotsx) {
   __shared__ Shared shm;
   extern __shared__ float dyn_ll_row[];
   Blk sh;
@@ -5797,8 +5799,8 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   sh.k_or = 0;
   sh.k_red = 0;
   sh.k_scan = 0;
-  sh.x = nullptr;
   const int s = blockIdx.x;
+  sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + s) : nullptr;
   Utt u = slots[s];
   Launder(u);
   Launder(p);
@@ -5876,7 +5878,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
       for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
       if (threadIdx.x == 0) sh->tok_hw = 0;
       KhSync();
-      ok = DecodeInit(u, p, sh, &run);
+      ok = DecodeInit<kExact>(u, p, sh, &run);
       SaveState(S, sh, run, ok);
       if (threadIdx.x == 0) S->finalized = 0;
       fin = false;
@@ -5884,7 +5886,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
     } else if (act == 2) {   // AdvanceDecoding up to the frames the host has published
       LoadState(*S, sh, &run);   // (an export job may have collected the slot's garbage in between: lazy schedule)
       ok = ok && S->ok != 0;
-      if (ok) ok = p.lazy_prune ? DecodeFrames<true>(u, p, sh, &run, arg) : DecodeFrames<false>(u, p, sh, &run, arg);
+      if (ok) ok = p.lazy_prune ? DecodeFrames<true, kExact>(u, p, sh, &run, arg) : DecodeFrames<false, kExact>(u, p, sh, &run, arg);
       SaveState(S, sh, run, ok);
       ok = ok && Uni(sh->status) == 0;
     } else if (act == 3) {   // FinalizeDecoding
@@ -8042,8 +8044,8 @@ int kh_online_decoder_finalize(KhOnlineDecoder *o, const int32_t *streams, int n
 // re-carved (every stream must be idle: before InitDecoding or after FinalizeDecoding + the last getter).
 // The streams decode in the reference's own iteration order (kh_decoder_set_reference_order for the online decoder:
 // LatticeFasterOnlineDecoder::ProcessEmitting, lattice-faster-online-decoder.cc:864-951, walks the same HashList against the
-// same running next_cutoff).  Between utterances only; the launch-per-job calls only - the persistent serving kernel keeps
-// the order-independent rule and refuses to start in this mode.
+// same running next_cutoff).  Between utterances only, with the serving kernel stopped; a serving kernel started afterwards
+// decodes in the same order (ServeKernel<true>).
 int kh_online_decoder_set_reference_order(KhOnlineDecoder *o, int enable) {
   int rc = EnsureDevice();
   if (rc) return rc;
@@ -8191,7 +8193,8 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   Params p;
   FillParams(b, &p, o->serve_stride, o->serve_map);
   p.lazy_prune = b->lazy;
-  if (!(o->pinned && o->serve_map == o->pinned_map && o->serve_stride == o->pinned_cols && b->rec != nullptr)) {
+  if (!(o->pinned && o->serve_map == o->pinned_map && o->serve_stride == o->pinned_cols && b->rec != nullptr &&
+        b->rec_order_ids == (b->exact ? 1 : 0))) {
     const int rc = kh_online_decoder_set_pdf_map(o, o->serve_map, o->serve_stride);
     if (rc) return rc;
   }
@@ -8203,9 +8206,17 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   KH_HIP(hipHostGetDevicePointer(&quit_dev, o->serve_quit, 0));
   long long idle_ticks = 200000000ll;   // 2 s of the 100 MHz wall clock
   if (const char *e = getenv("KH_SERVE_IDLE_MS")) idle_ticks = std::max(1ll, static_cast<long long>(atof(e) * 1e5));
-  hipLaunchKernelGGL(ServeKernel, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
-                     b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<int32_t *>(quit_dev), o->serve_ll,
-                     o->serve_rows, o->serve_stride, p, idle_ticks, o->d_serve_act);
+  p.exact_order = b->exact ? 1 : 0;
+  if (b->exact) {
+    if (getenv("KH_DECODER_ORDER_SORT") != nullptr && atoi(getenv("KH_DECODER_ORDER_SORT")) != 0) p.exact_order = 2;
+    hipLaunchKernelGGL(ServeKernel<true>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
+                       b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<int32_t *>(quit_dev), o->serve_ll,
+                       o->serve_rows, o->serve_stride, p, idle_ticks, o->d_serve_act, (const UttX *)b->d_slotsx);
+  } else {
+    hipLaunchKernelGGL(ServeKernel<false>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
+                       b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<int32_t *>(quit_dev), o->serve_ll,
+                       o->serve_rows, o->serve_stride, p, idle_ticks, o->d_serve_act, (const UttX *)nullptr);
+  }
   KH_LAUNCH_CHECK();
   o->serve_launched = true;
   return KH_OK;
@@ -8220,11 +8231,6 @@ int kh_online_decoder_serve_start(KhOnlineDecoder *o, const float *loglikes, int
     SetError("kh_online_decoder_serve_start: %d streams, but only %d workgroups can be resident at once", o->num_streams,
              KH_WG_PER_CU * NumCUs());
     return KH_EINVAL;
-  }
-  if (o->base->exact) {
-    SetError("kh_online_decoder_serve_start: the serving kernel decodes with the order-independent rule only "
-             "(kh_online_decoder_set_reference_order(0) first, or use the launch-per-job calls)");
-    return KH_ESTATE;
   }
   if ((rc = kh_online_decoder_serve_stop(o))) return rc;
   if (!o->serve_ctl) {

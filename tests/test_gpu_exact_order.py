@@ -297,7 +297,7 @@ def test_online_streams_in_reference_order(api):
     can.advance_decoding([0], [torch.from_numpy(lls[3]).cuda()])
     can.finalize_decoding([0])
     assert can.stats(0)["tokens_created"] != dec.stats(3)["tokens_created"]   # (else the test would prove nothing)
-    # the mode is switched between utterances only, and the serving kernel refuses it
+    # the mode is switched between utterances only
     dec.init_decoding([0])
     with pytest.raises(api.KhError):
         dec.set_reference_order(False)

@@ -156,13 +156,17 @@ def test_serving_step_in_one_call_equals_offline(api, pad_input):
         assert_same_best_path(results[u][1], ref.get_best_path(u))
 
 
-@pytest.mark.parametrize("pad_input,lazy", [(True, False), (False, False), (True, True)])
-def test_persistent_serving_kernel_equals_offline(api, pad_input, lazy, monkeypatch):
+@pytest.mark.parametrize("pad_input,lazy,rule", [(True, False, "canonical"), (False, False, "canonical"), (True, True, "canonical"),
+                                                 (True, False, "reference"), (False, True, "reference")])
+def test_persistent_serving_kernel_equals_offline(api, pad_input, lazy, rule, monkeypatch):
     """The same loop through the decoder's PERSISTENT serving kernel (kh_online_nnet2_serve_*): step() only publishes the
     chunk's scores, the resident workgroups decode at their own pace, FinalizeDecoding is requested asynchronously and the
     lattice is read after serve_wait - while the kernel keeps serving the other streams, and once more after the kernel
     has left by its idle time and been launched again.  Same lattices and best paths as the offline pipeline; a partial
-    hypothesis mid-utterance equals the one of the launch-per-step path."""
+    hypothesis mid-utterance equals the one of the launch-per-step path.  rule = "reference": the streams in the reference's
+    own iteration order (kh_online_decoder_set_reference_order before the kernel starts: ServeKernel<true>) - the lattices
+    of the offline kernel in that order and of the line-by-line oracle (mode 0)."""
+    exact = rule == "reference"
     monkeypatch.setenv("KH_SERVE_IDLE_MS", "300")
     rng = np.random.default_rng(54)
     n_pdf = 40
@@ -176,11 +180,11 @@ def test_persistent_serving_kernel_equals_offline(api, pad_input, lazy, monkeypa
     x = torch.from_numpy(np.concatenate(feats, 0)).cuda()
     off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
     ll, oo = nnet.compute(x, off, pad_input=pad_input, epilogue=True, prob_scale=0.1)
-    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=len(Ts), max_frames=max(Ts))
+    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=len(Ts), max_frames=max(Ts), exact_reference_order=exact)
     ref.decode(ll, oo if not pad_input else off)
     n_out = lambda u: Ts[u] if pad_input else Ts[u] - L - R
 
-    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160)
+    dec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=3, max_frames=160, exact_reference_order=exact)
     if lazy:   # no pruning while the streams advance (kh_online_decoder_set_lazy_prune): same lattices and best paths
         dec.set_lazy_prune(True)
     pipe = api.OnlineNnet2Pipeline(nnet, dec, max_frames=160, acoustic_scale=0.1, pad_input=pad_input, max_nnet_batch_size=40)
@@ -235,7 +239,20 @@ def test_persistent_serving_kernel_equals_offline(api, pad_input, lazy, monkeypa
         assert_same_best_path(results[u][1], ref.get_best_path(u))
     # the partial hypothesis: that of the launch-per-step path after the same number of frames of utterance 1
     assert partial and partial["frames"] > 0
-    dec2 = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=1, max_frames=160)
+    if exact:   # ... and the oracle's own, on the rows the forward pass produced
+        from oracle import binding as B
+        o_off = oo if not pad_input else off
+        ll_host = ll.cpu().numpy()
+        for u in (0, 3):
+            orf = B.DecoderOracle(g, cfg, "reference")
+            assert orf.decode(ll_host[int(o_off[u]):int(o_off[u + 1])])
+            assert_same_lattice(results[u][0], orf.raw_lattice())
+            assert_same_best_path(results[u][1], orf.best_path())
+        with pytest.raises(api.KhError):   # (between utterances and with the kernel stopped only)
+            pipe.serve_start()
+            dec.set_reference_order(False)
+        pipe.serve_stop()
+    dec2 = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=1, max_frames=160, exact_reference_order=exact)
     dec2.init_decoding([0])
     lo = int(oo[1]) if not pad_input else int(off[1])
     dec2.advance_decoding([0], [ll[lo:lo + partial["frames"]]])
