@@ -22,7 +22,10 @@
 #include <thread>
 #include <vector>
 
+#include <type_traits>
+
 #include "kh_common.h"
+#include "kh_logadd.h"
 
 using namespace kh;
 
@@ -38,18 +41,7 @@ struct LatDesc {
   int32_t max_time, n_reached; // largest state time; states the level sweep reached
 };
 
-// base/kaldi-math.h:178-195 (double)
-__device__ __forceinline__ double LogAddD(double x, double y, double min_log_diff) {
-  double diff;
-  if (x < y) {
-    diff = x - y;
-    x = y;
-  } else {
-    diff = y - x;
-  }
-  if (diff >= min_log_diff) return x + log1p(exp(diff));
-  return x;
-}
+// LogAddD: base/kaldi-math.h:178-195 (double), kh_logadd.h
 
 __global__ void __launch_bounds__(kThreads)
 ForwardBackwardKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off,
@@ -678,35 +670,46 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
 
 constexpr int kWin = 4096;   // states whose value the dataflow sweeps keep in their LDS window
 static_assert((kWin / 64) % (kThreads / 64) == 0, "a window slot is rewritten by the wave that wrote it");
+// KH_LATTICE_PROFILE=1: shader-clock stamps of thread 0 of every workgroup (kProf instantiations; [16] words per lattice)
+constexpr int kLatProf = 16;
+#define LAT_STAMP(k) do { if (kProf && threadIdx.x == 0) { const long long now_ = clock64(); prof[blockIdx.x * kLatProf + (k)] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+// lds_states ints of dynamic LDS: the per-state counter of a lattice of up to that many states (in-degrees, then - the
+// in-degrees are consumed by the scan - the fill counters of the incoming lists); win_slots 8-byte words behind it: the
+// state-time window.
+template <bool kProf>
 __global__ void __launch_bounds__(kThreads)
 PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ il,
            const int32_t *__restrict__ next, const float *__restrict__ fin, LatDesc *__restrict__ descs,
            int32_t *times, int32_t *__restrict__ level_off, int32_t *__restrict__ level_states,
            int64_t *__restrict__ in_off, int64_t *__restrict__ in_arc, int32_t *__restrict__ in_src,
            int32_t *__restrict__ final_list, int32_t *indeg, int32_t *fill,
-           int32_t *__restrict__ err) {
+           int32_t *__restrict__ err, long long *__restrict__ prof, int lds_states, int win_slots) {
   __shared__ int s_w[kThreads / 64];
   __shared__ int s_err[4];
   __shared__ int s_qend, s_maxt;
-  // The three per-state work arrays (state times, in-degrees, fill counters) take ~1.3 M atomic updates per 256-lattice
-  // batch; in device memory every one of them is a read-modify-write at the memory side (4.4 ms for 256 lattices, more
-  // than both sweeps).  A lattice of up to kPrepLdsStates states keeps them in LDS; the times are copied out at the end.
-  __shared__ int s_work[2 * kPrepLdsStates];
+  // The per-state work arrays (in-degrees, fill counters) take ~1.3 M atomic updates per 256-lattice batch; in device
+  // memory every one of them is a read-modify-write at the memory side (4.4 ms for 256 lattices, more than both sweeps).
+  // A lattice of up to lds_states states keeps them in LDS.
+  extern __shared__ unsigned long long dyn_prep[];   // [win_slots] window words, then [lds_states] ints
+  unsigned long long *const w_tt = dyn_prep;
+  int *const s_work = reinterpret_cast<int *>(dyn_prep + win_slots);
+  long long t_prev_ = kProf ? clock64() : 0;
   const int l = blockIdx.x, t = threadIdx.x;
   const int sb = lat_off[l], ns = lat_off[l + 1] - sb;
   const int64_t arc_b = arc_off[sb];
-  const bool in_lds = ns <= kPrepLdsStates;
+  const bool in_lds = ns <= lds_states;
   // (indexed with the lattice-local state from here on)
   int32_t *const tw = times + sb;   // (only initialised here: the dataflow pass below writes the times)
   int32_t *const dw = in_lds ? s_work : indeg + sb;
-  int32_t *const fw = in_lds ? s_work + kPrepLdsStates : fill + sb;
+  int32_t *const fw = in_lds ? s_work : fill + sb;   // (in LDS: the same words, zeroed again once the scan has read the in-degrees)
   if (t == 0) { s_err[0] = 0; s_err[1] = 0; s_err[2] = 0; s_err[3] = 0; s_maxt = 0; }
   for (int s = t; s < ns; s += kThreads) {
     tw[s] = s == 0 ? 0 : -1;
     dw[s] = 0;
-    fw[s] = 0;
+    if (!in_lds) fw[s] = 0;
   }
   PrepSync();
+  LAT_STAMP(0);
   // ---- in-degrees + "input lattice must be topologically sorted"
   for (int s = t; s < ns; s += kThreads)
     for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
@@ -722,6 +725,7 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
     if (t < 4) err[4 * l + t] = s_err[t];
     return;
   }
+  LAT_STAMP(1);
   // ---- incoming-arc offsets (exclusive scan of the in-degrees), finals and sources (ascending)
   int carry = 0, nf = 0, nq = 0;
   for (int base = 0; base < ns; base += kThreads) {
@@ -742,6 +746,11 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
   }
   if (t == 0) in_off[sb + ns] = arc_b + carry;
   PrepSync();
+  if (in_lds) {
+    for (int s = t; s < ns; s += kThreads) fw[s] = 0;
+    PrepSync();
+  }
+  LAT_STAMP(2);
   // ---- incoming lists (filled in arrival order, then sorted by arc index)
   for (int s = t; s < ns; s += kThreads)
     for (int64_t a = arc_off[sb + s]; a < arc_off[sb + s + 1]; a++) {
@@ -751,6 +760,7 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
       in_src[pos] = s;
     }
   PrepSync();
+  LAT_STAMP(3);
   for (int s = t; s < ns; s += kThreads) {
     const int64_t b0 = in_off[sb + s], e0 = in_off[sb + s + 1];
     for (int64_t i = b0 + 1; i < e0; i++) {
@@ -767,17 +777,21 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
     }
   }
   // ---- LatticeStateTimes (:36-67) without dependency levels: the states in INDEX order (the lattice is top-sorted), a
-  // wave per block of 64 consecutive states, a state waits until the predecessors it reads have published their time
-  // (sliding LDS window with tags; an evicted entry is read from memory, where it was stored before it was published)
+  // wave per block of 64 consecutive states, a state waits until the predecessor it reads next has published its time.
+  // Sliding LDS window, ONE 8-byte word per slot = state << 32 | time (all ones: nothing yet): an operand is one LDS read, a
+  // result one LDS store; a slot that holds a later state means the wanted one has left the window - its time is read
+  // from memory, where it was stored before it was published (a slot is rewritten by the state win_slots further on, which
+  // belongs to the same wave, and the wave stores and waits at the end of every block).  One operand per lane and pass.
   constexpr int kTStage = 384;
-  __shared__ int w_tag[kWin], w_time[kWin];
   __shared__ int st_src[kThreads / 64][kTStage];
   __shared__ signed char st_inc[kThreads / 64][kTStage];
-  for (int i = t; i < kWin; i += kThreads) w_tag[i] = -1;
+  for (int i = t; i < win_slots; i += kThreads) w_tt[i] = ~0ull;
   PrepSync();
+  LAT_STAMP(4);
   int my_maxt = 0;
   {
     const int lane = t & 63, wave = t >> 6;
+    const int wmask = win_slots - 1;
     for (int blk = wave; blk * 64 < ns; blk += kThreads / 64) {
       const int s = blk * 64 + lane;
       const bool active = s < ns;
@@ -792,36 +806,35 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
         st_src[wave][e2] = in_src[jb + e2];
         st_inc[wave][e2] = il[in_arc[jb + e2]] != 0 ? 1 : 0;
       }
+      int src = 0, inc = 0;
+      auto fetch = [&](int64_t jj) {
+        const int64_t e2 = jj - jb;
+        if (e2 < kTStage) { src = st_src[wave][e2]; inc = st_inc[wave][e2]; }
+        else { src = in_src[jj]; inc = il[in_arc[jj]] != 0 ? 1 : 0; }
+      };
+      if (!done && j < ie) fetch(j);
       while (__ballot(!done) != 0ull) {
         if (!done) {
-          while (j < ie) {
-            const int64_t e2 = j - jb;
-            const int src = e2 < kTStage ? st_src[wave][e2] : in_src[j];
-            const int slot = src & (kWin - 1);
-            const int tag1 = __hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int tp;
-            if (tag1 == src) {
-              tp = __hip_atomic_load(&w_time[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (__hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != src)   // evicted meanwhile
-                tp = __hip_atomic_load(&times[sb + src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (tag1 > src || tag1 == -2) {
-              if (tag1 == -2) break;                 // the slot is being rewritten: look again
-              tp = __hip_atomic_load(&times[sb + src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-              break;                                 // not computed yet
+          if (j < ie) {
+            const unsigned long long wv = __hip_atomic_load(&w_tt[src & wmask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int tag = static_cast<int>(wv >> 32);   // (-1: empty)
+            bool have = false;
+            int tp = -1;
+            if (tag == src) { tp = static_cast<int>(static_cast<uint32_t>(wv)); have = true; }
+            else if (tag > src) { tp = __hip_atomic_load(&times[sb + src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); have = true; }
+            if (have) {
+              if (tp >= 0) {
+                const int want = tp + inc;
+                if (tval == -1) tval = want;
+                else if (tval != want && atomicCAS(&s_err[0], 0, 2) == 0) { s_err[1] = s; s_err[2] = tval; s_err[3] = want; }
+              }
+              j++;
+              if (j < ie) fetch(j);
             }
-            if (tp >= 0) {
-              const int want = tp + (e2 < kTStage ? st_inc[wave][e2] : (il[in_arc[j]] != 0 ? 1 : 0));
-              if (tval == -1) tval = want;
-              else if (tval != want && atomicCAS(&s_err[0], 0, 2) == 0) { s_err[1] = s; s_err[2] = tval; s_err[3] = want; }
-            }
-            j++;
           }
           if (j >= ie) {
-            const int slot = s & (kWin - 1);
-            __hip_atomic_store(&w_tag[slot], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (to memory at the end of the block: see WinPublish)
-            __hip_atomic_store(&w_time[slot], tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&w_tag[slot], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&w_tt[s & wmask], (static_cast<unsigned long long>(static_cast<uint32_t>(s)) << 32) | static_cast<uint32_t>(tval),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (to memory at the end of the block: see WinPublish)
             my_maxt = tval > my_maxt ? tval : my_maxt;
             done = true;
           }
@@ -834,6 +847,7 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
   const int lv = 0, le = ns, lvb = sb + l;   // (no levels: n_levels = 0 tells the level-based kernels apart)
   atomicMax(&s_maxt, my_maxt);
   PrepSync();
+  LAT_STAMP(5);
   if (t < 4) err[4 * l + t] = s_err[t];
   if (t == 0) {
     LatDesc d;
@@ -863,12 +877,32 @@ namespace {
 // memory, where it was stored before it was published), and a state proceeds as soon as the operands it needs next are
 // there: no barrier, no level structure, the dependent chain runs at LDS latency.  Operand order per state = ascending
 // arc index, as in the reference's sequential sweep: results equal the level-based kernel's bit for bit.
-__device__ __forceinline__ bool WinRead(const int *w_tag, const double *w_val, const double *mem, int idx, bool forward, double *out) {
-  const int slot = idx & (kWin - 1);
-  const int tag1 = __hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// The window.  Two forms, chosen per workgroup: a lattice whose states all fit (n_states <= win_slots) uses the area as ONE
+// double per state, "not there yet" = a NaN bit pattern no sweep produces (kWinEmpty; a NaN result with exactly these bits is
+// published as the canonical quiet NaN): an operand is ONE 8-byte LDS read and a result one 8-byte LDS store, nothing is ever
+// evicted and nothing is read from memory.  A larger lattice uses half the area as values and the other half as tags
+// (which state a slot holds; -2 while it is rewritten): three dependent LDS operations per operand, and a value that has
+// left the window is read from memory, where it was stored before it was published.
+constexpr unsigned long long kWinEmpty = 0x7ff8dead00000001ull;
+struct Win {
+  double *val;
+  int *tag;
+  int mask;      // tagged form: slots - 1
+  bool direct;
+};
+template <bool kDirect>
+__device__ __forceinline__ bool WinRead(const Win &w, const double *mem, int idx, bool forward, double *out) {
+  if (kDirect) {
+    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&w.val[idx]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (b == kWinEmpty) return false;
+    *out = __longlong_as_double(static_cast<long long>(b));
+    return true;
+  }
+  const int slot = idx & w.mask;
+  const int tag1 = __hip_atomic_load(&w.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (tag1 == idx) {
-    const double v = __hip_atomic_load(&w_val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (__hip_atomic_load(&w_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == idx) { *out = v; return true; }
+    const double v = __hip_atomic_load(&w.val[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__hip_atomic_load(&w.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == idx) { *out = v; return true; }
     *out = __hip_atomic_load(&mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // evicted while we looked
     return true;
   }
@@ -881,16 +915,35 @@ __device__ __forceinline__ bool WinRead(const int *w_tag, const double *w_val, c
 // Publishes a value in the window (LDS only).  The value goes to memory when the wave has finished its block of states
 // (the callers), NOT here: on gfx9 `vmcnt` counts stores, and the compiler's s_waitcnt vmcnt(0) in front of the polling
 // loop's next load would put the store's round trip to device memory (~2 us) on every step of the dependent chain - that
-// was 3 ms per 256-lattice batch, more than the arithmetic.  In memory before anybody can find the slot evicted: a slot is
-// rewritten by the state kWin further on, which belongs to the SAME wave (kWin / 64 is a multiple of the waves), and the
-// wave stores and waits at the end of every block.
-__device__ __forceinline__ void WinPublish(int *w_tag, double *w_val, int idx, double v) {
-  const int slot = idx & (kWin - 1);
-  __hip_atomic_store(&w_tag[slot], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __hip_atomic_store(&w_val[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __hip_atomic_store(&w_tag[slot], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// was 3 ms per 256-lattice batch, more than the arithmetic.  (Tagged form) in memory before anybody can find the slot
+// evicted: a slot is rewritten by the state `slots` further on, which belongs to the SAME wave (slots / 64 is a multiple of
+// the waves), and the wave stores and waits at the end of every block.
+template <bool kDirect>
+__device__ __forceinline__ void WinPublish(const Win &w, int idx, double v) {
+  if (kDirect) {
+    unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    if (b == kWinEmpty) b = 0x7ff8000000000000ull;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&w.val[idx]), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+  const int slot = idx & w.mask;
+  __hip_atomic_store(&w.tag[slot], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_store(&w.val[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __hip_atomic_store(&w.tag[slot], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void WinReset(const Win &w, int ns) {
+  if (w.direct) {
+    for (int i = threadIdx.x; i < ns; i += kThreads) reinterpret_cast<unsigned long long *>(w.val)[i] = kWinEmpty;
+  } else {
+    for (int i = threadIdx.x; i <= w.mask; i += kThreads) w.tag[i] = -1;
+  }
 }
 
+// win_slots (a power of two >= 512) doubles of dynamic LDS: the window.  kStage: arcs of a 64-state block staged per wave.
+// A lane takes ONE operand per pass of its wave's loop (a lane with six operands ready used to hold the wave's other lanes -
+// among them the successors of states that had just been finished - for six LogAdds), and the staged words of its next
+// operand are requested before the LogAdd of the current one.
+template <bool kProf, int kStage>
 __global__ void __launch_bounds__(kThreads)
 ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off,
                         const int32_t *__restrict__ arc_next, const float *__restrict__ arc_g,
@@ -898,13 +951,21 @@ ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restr
                         const int64_t *__restrict__ in_off, const int64_t *__restrict__ in_arc,
                         const int32_t *__restrict__ in_src, const int32_t *__restrict__ final_list,
                         double *alpha, double *beta, float *__restrict__ arc_post, double *__restrict__ tot_like,
-                        double *__restrict__ ac_sum, double min_log_diff) {
+                        double *__restrict__ ac_sum, double min_log_diff, long long *__restrict__ prof, int win_slots) {
+  // kProf: wave 0 of every workgroup keeps, in registers, the shader cycles of [6] staging, [7] passes of its loop in which no
+  // lane had its operand (waiting for other waves), [8] passes in which some lane folded an operand (LDS read + LogAdd
+  // [+ posterior] + publish), [9] stores + wait at the end of a block; [10] / [11] the number of such passes, [12] blocks,
+  // [13] the whole kernel, [14] the forward sweep - written once at the end
+  long long t_prev_ = kProf ? clock64() : 0;
+  const long long t_begin_ = t_prev_;
+  long long pf_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FB_ADD(k, v) do { if (kProf) pf_[k] += (v); } while (0)
+#define FB_STAMP(k) do { if (kProf) { const long long now_ = clock64(); pf_[k] += now_ - t_prev_; t_prev_ = now_; } } while (0)
   // A block's arcs are staged in LDS before the block waits for anything (they do not depend on alpha / beta): inside the
   // polling loop ONE lane's load from device memory would stall the whole wave for a round trip on every step of the
   // dependent chain (SIMT) - that, not the arithmetic, was the 3 ms of the first version of this kernel.
-  constexpr int kStage = 384, kWaves = kThreads / 64;
-  __shared__ double w_val[kWin];
-  __shared__ int w_tag[kWin];
+  constexpr int kWaves = kThreads / 64;
+  extern __shared__ double dyn_win[];
   __shared__ double st_like[kWaves][kStage];
   __shared__ int st_idx[kWaves][kStage];     // forward: source state; backward: next state
   __shared__ float st_ac[kWaves][kStage];    // backward: acoustic cost, then the arc's posterior
@@ -915,7 +976,12 @@ ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restr
   const int ns = L.n_states, sb = L.state_b, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *al = alpha + sb, *be = beta + sb;
   const float *fin = state_final + sb;
-  for (int i = threadIdx.x; i < kWin; i += kThreads) w_tag[i] = -1;
+  Win w;
+  w.direct = ns <= win_slots;
+  w.val = dyn_win;
+  w.tag = reinterpret_cast<int *>(dyn_win + (win_slots >> 1));
+  w.mask = (win_slots >> 1) - 1;
+  WinReset(w, ns);
   __syncthreads();
   // ---- forward :300-316
   for (int blk = wave; blk * 64 < ns; blk += kWaves) {
@@ -931,30 +997,50 @@ ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restr
       st_idx[wave][e] = in_src[eb + e];
       st_like[wave][e] = -static_cast<double>(arc_g[arc] + arc_a[arc]);  // -ConvertToCost
     }
+    FB_STAMP(6);
+    FB_ADD(12, 1);
     double a = (active && s == 0) ? 0.0 : kLogZero;
-    int64_t j = ib;
-    bool done = !active;
-    while (__ballot(!done) != 0ull) {
-      if (!done) {
-        while (j < ie) {
-          int src;
-          double like;
-          const int64_t e = j - eb;
-          if (e < kStage) { src = st_idx[wave][e]; like = st_like[wave][e]; }
-          else { const int64_t arc = in_arc[j]; src = in_src[j]; like = -static_cast<double>(arc_g[arc] + arc_a[arc]); }
-          double av;
-          if (!WinRead(w_tag, w_val, al, src, true, &av)) break;
-          a = LogAddD(a, av + like, min_log_diff);
-          j++;
+    // (the loop in four forms - window form x "every arc of the block is staged" - so that the form that runs carries no
+    // test of the other ones: a pass of a lone wave is paid in instructions issued)
+    auto sweep = [&](auto direct_c, auto staged_c) {
+      constexpr bool kDirect = decltype(direct_c)::value, kStaged = decltype(staged_c)::value;
+      int64_t j = ib;
+      bool done = !active;
+      int src = 0;
+      double like = 0.0;
+      auto fetch = [&](int64_t jj) {
+        const int64_t e = jj - eb;
+        if (kStaged || e < kStage) { src = st_idx[wave][e]; like = st_like[wave][e]; }
+        else { const int64_t arc = in_arc[jj]; src = in_src[jj]; like = -static_cast<double>(arc_g[arc] + arc_a[arc]); }
+      };
+      if (!done && j < ie) fetch(j);
+      while (__ballot(!done) != 0ull) {
+        bool folded = false;
+        if (!done) {
+          if (j < ie) {
+            double av;
+            if (WinRead<kDirect>(w, al, src, true, &av)) {
+              const double term = av + like;
+              j++;
+              if (j < ie) fetch(j);
+              a = LogAddD(a, term, min_log_diff);
+              folded = true;
+            }
+          }
+          if (j >= ie) {
+            WinPublish<kDirect>(w, s, a);
+            done = true;
+          }
         }
-        if (j >= ie) {
-          WinPublish(w_tag, w_val, s, a);
-          done = true;
-        }
+        if (kProf) { if (__ballot(folded) != 0ull) { FB_STAMP(8); FB_ADD(10, 1); } else { FB_STAMP(7); FB_ADD(11, 1); } }
       }
-    }
+    };
+    const bool all_staged = ee - eb <= kStage;
+    if (w.direct) { if (all_staged) sweep(std::true_type{}, std::true_type{}); else sweep(std::true_type{}, std::false_type{}); }
+    else { if (all_staged) sweep(std::false_type{}, std::true_type{}); else sweep(std::false_type{}, std::false_type{}); }
     if (active) __hip_atomic_store(&al[s], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see WinPublish)
+    FB_STAMP(9);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -966,8 +1052,9 @@ ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restr
     }
     s_tot = tot;
   }
-  for (int i = threadIdx.x; i < kWin; i += kThreads) w_tag[i] = -1;
+  WinReset(w, ns);
   __syncthreads();
+  if (kProf) { t_prev_ = clock64(); pf_[14] = t_prev_ - t_begin_; }   // the forward sweep
   const double tot_forward = s_tot;
   // ---- backward :317-344 (blocks of states from the end; inside a block the highest state is the first to be ready)
   double my_ac = 0.0;
@@ -991,36 +1078,62 @@ ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restr
       st_ac[wave][e] = ac;
       st_like[wave][e] = -static_cast<double>(arc_g[eb + e] + ac);
     }
-    int64_t arc = ab;
-    bool done = !active;
-    while (__ballot(!done) != 0ull) {
-      if (!done) {
-        while (arc < ae) {
-          int nx;
-          double like;
-          float ac;
-          const int64_t e = arc - eb;
-          if (e < kStage) { nx = st_idx[wave][e]; like = st_like[wave][e]; ac = st_ac[wave][e]; }
-          else { nx = arc_next[arc]; ac = arc_a[arc]; like = -static_cast<double>(arc_g[arc] + ac); }
-          double bv;
-          if (!WinRead(w_tag, w_val, be, nx, false, &bv)) break;
-          const double arc_beta = bv + like;
-          this_beta = LogAddD(this_beta, arc_beta, min_log_diff);
-          const double posterior = exp(as + arc_beta - tot_forward);
-          if (e < kStage) st_ac[wave][e] = static_cast<float>(posterior);   // (written out when the block is done)
-          else arc_post[arc] = static_cast<float>(posterior);
-          my_ac -= posterior * static_cast<double>(ac);
-          arc++;
+    FB_STAMP(6);
+    FB_ADD(12, 1);
+    auto sweep = [&](auto direct_c, auto staged_c) {
+      constexpr bool kDirect = decltype(direct_c)::value, kStaged = decltype(staged_c)::value;
+      int64_t arc = ab;
+      bool done = !active;
+      int nx = 0;
+      double like = 0.0;
+      float ac = 0.f;
+      auto fetch = [&](int64_t aa) {
+        const int64_t e = aa - eb;
+        if (kStaged || e < kStage) { nx = st_idx[wave][e]; like = st_like[wave][e]; if (!kStaged) ac = st_ac[wave][e]; }
+        else { nx = arc_next[aa]; ac = arc_a[aa]; like = -static_cast<double>(arc_g[aa] + ac); }
+      };
+      if (!done && arc < ae) fetch(arc);
+      while (__ballot(!done) != 0ull) {
+        bool folded = false;
+        if (!done) {
+          if (arc < ae) {
+            double bv;
+            if (WinRead<kDirect>(w, be, nx, false, &bv)) {
+              const double arc_beta = bv + like;
+              const double acd = static_cast<double>(ac);
+              const int64_t e = arc - eb;
+              arc++;
+              if (arc < ae) fetch(arc);
+              this_beta = LogAddD(this_beta, arc_beta, min_log_diff);
+              if (kStaged || e < kStage) {
+                st_like[wave][e] = as + arc_beta;   // (the posterior's exp is not part of the chain: after the loop, every lane busy)
+              } else {
+                const double posterior = exp(as + arc_beta - tot_forward);
+                arc_post[eb + e] = static_cast<float>(posterior);
+                my_ac -= posterior * acd;
+              }
+              folded = true;
+            }
+          }
+          if (arc >= ae) {
+            WinPublish<kDirect>(w, s, this_beta);
+            done = true;
+          }
         }
-        if (arc >= ae) {
-          WinPublish(w_tag, w_val, s, this_beta);
-          done = true;
-        }
+        if (kProf) { if (__ballot(folded) != 0ull) { FB_STAMP(8); FB_ADD(10, 1); } else { FB_STAMP(7); FB_ADD(11, 1); } }
       }
-    }
+    };
+    const bool all_staged = ee - eb <= kStage;
+    if (w.direct) { if (all_staged) sweep(std::true_type{}, std::true_type{}); else sweep(std::true_type{}, std::false_type{}); }
+    else { if (all_staged) sweep(std::false_type{}, std::true_type{}); else sweep(std::false_type{}, std::false_type{}); }
     if (active) __hip_atomic_store(&be[s], this_beta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int e = lane; e < n_st; e += 64) arc_post[eb + e] = st_ac[wave][e];
+    for (int e = lane; e < n_st; e += 64) {   // arc posteriors :333-336 of the block's staged arcs
+      const double posterior = exp(st_like[wave][e] - tot_forward);
+      arc_post[eb + e] = static_cast<float>(posterior);
+      my_ac -= posterior * static_cast<double>(st_ac[wave][e]);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see WinPublish)
+    FB_STAMP(9);
   }
   my_ac = kh_wave_sum_d(my_ac);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = my_ac;
@@ -1031,6 +1144,12 @@ ForwardBackwardDFKernel(const LatDesc *__restrict__ lats, const int64_t *__restr
     ac_sum[blockIdx.x] = t;
     tot_like[blockIdx.x] = __hip_atomic_load(&be[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // tot_backward_prob :345
   }
+  if (kProf && threadIdx.x == 0) {
+    pf_[13] = clock64() - t_begin_;
+    for (int k = 0; k < kLatProf; k++) prof[blockIdx.x * kLatProf + k] = pf_[k];
+  }
+#undef FB_ADD
+#undef FB_STAMP
 }
 }  // namespace
 
@@ -1051,6 +1170,43 @@ struct LatTimer {
   }
 };
 static thread_local LatTimer g_lat_timer;
+
+// KH_LATTICE_PROFILE=1: the kProf instantiations of the dataflow kernels; prints where thread 0 / wave 0 of the workgroups
+// spent their shader cycles (means over the lattices of the call) to stderr.
+static bool LatProfile() {
+  static const bool on = getenv("KH_LATTICE_PROFILE") != nullptr && atoi(getenv("KH_LATTICE_PROFILE")) != 0;
+  return on;
+}
+static void LatProfilePrint(const char *what, const DevArr<long long> &d_prof, int n_lats, hipStream_t st) {
+  std::vector<long long> h(static_cast<size_t>(n_lats) * kLatProf);
+  if (hipMemcpyAsync(h.data(), d_prof.p, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return; }
+  double m[kLatProf] = {0};
+  for (int l = 0; l < n_lats; l++)
+    for (int k = 0; k < kLatProf; k++) m[k] += static_cast<double>(h[static_cast<size_t>(l) * kLatProf + k]) / n_lats;
+  {  // the slowest workgroup sets the kernel's duration
+    const bool prep = strcmp(what, "prep") == 0;
+    long long worst = -1;
+    int at = 0;
+    for (int l = 0; l < n_lats; l++) {
+      long long tot = 0;
+      if (prep) for (int k = 0; k < 6; k++) tot += h[static_cast<size_t>(l) * kLatProf + k];
+      else tot = h[static_cast<size_t>(l) * kLatProf + 13];
+      if (tot > worst) { worst = tot; at = l; }
+    }
+    fprintf(stderr, "[kh_lattice profile] %s: slowest workgroup = lattice %d, %lld cycles [", what, at, worst);
+    for (int k = 0; k < kLatProf; k++) fprintf(stderr, "%s%lld", k ? " " : "", h[static_cast<size_t>(at) * kLatProf + k]);
+    fprintf(stderr, "]\n");
+  }
+  if (strcmp(what, "prep") == 0)
+    fprintf(stderr, "[kh_lattice profile] PrepKernelDF, %d lattices, shader cycles of thread 0 (mean): init %.0f, in-degrees %.0f, "
+            "scans %.0f, incoming lists %.0f, sort of the lists %.0f, state times (dataflow) %.0f\n", n_lats, m[0], m[1], m[2], m[3], m[4], m[5]);
+  else
+    fprintf(stderr, "[kh_lattice profile] ForwardBackwardDFKernel, %d lattices, shader cycles of wave 0 (mean): kernel %.0f (forward "
+            "%.0f); staging %.0f, %.0f passes with no operand ready %.0f (%.0f each), %.0f passes that folded an operand %.0f (%.0f each: "
+            "LDS read + LogAdd [+ posterior] + publish), end of block (stores + wait) %.0f; %.0f blocks\n", n_lats, m[13], m[14], m[6],
+            m[11], m[7], m[11] > 0 ? m[7] / m[11] : 0.0, m[10], m[8], m[10] > 0 ? m[8] / m[10] : 0.0, m[9], m[12]);
+}
 
 struct LatBatch {
   int n_lats = 0, total_states = 0;
@@ -1094,10 +1250,44 @@ struct LatBatch {
       hipLaunchKernelGGL(PrepKernel, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
                          d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
                          d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p);
-    else
-      hipLaunchKernelGGL(PrepKernelDF, dim3(n_lats), dim3(kThreads), 0, st, d_lat_off.p, d_arc_off.p, d_ilabel.p, d_next.p,
-                         d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,
-                         d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p);
+    else {
+      // dynamic LDS: the state-time window + the per-state counters of the batch's largest lattice, as far as the workgroups
+      // that share a CU leave room (larger lattices count in device memory)
+      int max_ns = 1;
+      for (int l = 0; l < n_lats; l++) max_ns = std::max(max_ns, lat_state_offsets[l + 1] - lat_state_offsets[l]);
+      const int cus = std::max(1, NumCUs());
+      const int per_cu = std::min(4, (n_lats + cus - 1) / cus);
+      const int budget = (160 * 1024) / per_cu - 9 * 1024;   // (staging + the static words)
+      const int win = per_cu <= 2 ? 4096 : 1024;
+      const int lds_states = std::max(0, std::min(max_ns, (budget - win * 8) / 4));
+      const size_t dyn = static_cast<size_t>(win) * 8 + static_cast<size_t>(lds_states) * 4;
+      DevArr<long long> d_prof;
+      const bool prof = LatProfile();
+      if (prof) {
+        if (d_prof.Alloc(static_cast<size_t>(n_lats) * kLatProf)) return KH_ENOMEM;
+        KH_HIP(hipMemsetAsync(d_prof.p, 0, sizeof(long long) * n_lats * kLatProf, st));
+      }
+#define KH_PREP_LAUNCH(PROF)                                                                                                     \
+      do {                                                                                                                       \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&PrepKernelDF<PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, 151 * 1024); \
+          (void)hipGetLastError();                                                                                               \
+          attr_set = true;                                                                                                       \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(PrepKernelDF<PROF>, dim3(n_lats), dim3(kThreads), dyn, st, d_lat_off.p, d_arc_off.p, d_ilabel.p,      \
+                           d_next.p, d_fin.p, d_descs.p, d_times.p, d_level_off.p, d_level_states.p, d_in_off.p, d_in_arc.p,      \
+                           d_in_src.p, d_final_list.p, d_indeg.p, d_fill.p, d_err.p, d_prof.p, lds_states, win);                  \
+      } while (0)
+      if (prof) KH_PREP_LAUNCH(true); else KH_PREP_LAUNCH(false);
+#undef KH_PREP_LAUNCH
+      if (prof) {
+        KH_LAUNCH_CHECK();
+        fprintf(stderr, "[kh_lattice profile] prep: counters of up to %d states in LDS (largest lattice %d), window %d, %d workgroups per CU planned\n",
+                lds_states, max_ns, win, per_cu);
+        LatProfilePrint("prep", d_prof, n_lats, st);
+      }
+    }
     KH_LAUNCH_CHECK();
     descs.resize(n_lats);
     std::vector<int32_t> h_err(4 * static_cast<size_t>(n_lats));
@@ -1144,10 +1334,47 @@ static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_li
                        B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p,
                        B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p, d_alpha.p, d_beta.p,
                        d_post.p, d_tot.p, d_ac.p, min_log_diff);
-  else
-    hipLaunchKernelGGL(ForwardBackwardDFKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p,
-                       B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,
-                       B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff);
+  else {
+    // the window: as many states as the workgroups that share a CU leave room for (a lattice that fits it whole takes one LDS
+    // read per operand), 512 ... 16384 slots and no more than the batch's largest lattice needs; KH_LATTICE_WIN overrides
+    int max_ns = 1;
+    for (const LatDesc &d : B.descs) max_ns = std::max(max_ns, d.n_states);
+    const int cus = std::max(1, NumCUs());
+    const int per_cu = std::min(4, (n_lats + cus - 1) / cus);   // (more than four resident workgroups per CU: the window gets too small)
+    const bool small_stage = per_cu > 2;
+    const int stage_bytes = (small_stage ? 192 : 384) * 16 * (kThreads / 64) + 256;
+    int win = 512;
+    while (win < 16384 && win < max_ns && (2 * win) * 8 + stage_bytes <= (160 * 1024) / per_cu) win *= 2;
+    if (const char *e = getenv("KH_LATTICE_WIN")) { const int v = atoi(e); if (v >= 512 && v <= 16384 && (v & (v - 1)) == 0) win = v; }
+    const size_t dyn = static_cast<size_t>(win) * sizeof(double);
+    DevArr<long long> d_prof;
+    const bool prof = LatProfile();
+    if (prof) {
+      if (d_prof.Alloc(static_cast<size_t>(n_lats) * kLatProf)) return KH_ENOMEM;
+      KH_HIP(hipMemsetAsync(d_prof.p, 0, sizeof(long long) * n_lats * kLatProf, st));
+    }
+#define KH_FB_LAUNCH(PROF, STAGE)                                                                                              \
+    do {                                                                                                                       \
+      static bool attr_set = false;                                                                                            \
+      if (!attr_set) {                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ForwardBackwardDFKernel<PROF, STAGE>),                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);                                      \
+        (void)hipGetLastError();                                                                                               \
+        attr_set = true;                                                                                                       \
+      }                                                                                                                        \
+      hipLaunchKernelGGL((ForwardBackwardDFKernel<PROF, STAGE>), dim3(n_lats), dim3(kThreads), dyn, st, B.d_descs.p,           \
+                         B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,     \
+                         B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff, d_prof.p, win);       \
+    } while (0)
+    if (prof) { if (small_stage) KH_FB_LAUNCH(true, 192); else KH_FB_LAUNCH(true, 384); }
+    else { if (small_stage) KH_FB_LAUNCH(false, 192); else KH_FB_LAUNCH(false, 384); }
+#undef KH_FB_LAUNCH
+    if (prof) {
+      KH_LAUNCH_CHECK();
+      fprintf(stderr, "[kh_lattice profile] window %d slots (largest lattice %d states), %d workgroups per CU planned\n", win, max_ns, per_cu);
+      LatProfilePrint("sweeps", d_prof, n_lats, st);
+    }
+  }
   KH_LAUNCH_CHECK();
   g_lat_timer.Mark(3, st);
   if (arc_post && !post_dev)
