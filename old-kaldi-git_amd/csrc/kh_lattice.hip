@@ -761,29 +761,20 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
     }
   PrepSync();
   LAT_STAMP(3);
-  for (int s = t; s < ns; s += kThreads) {
-    const int64_t b0 = in_off[sb + s], e0 = in_off[sb + s + 1];
-    for (int64_t i = b0 + 1; i < e0; i++) {
-      const int64_t ka = in_arc[i];
-      const int32_t ks = in_src[i];
-      int64_t j = i - 1;
-      while (j >= b0 && in_arc[j] > ka) {
-        in_arc[j + 1] = in_arc[j];
-        in_src[j + 1] = in_src[j];
-        j--;
-      }
-      in_arc[j + 1] = ka;
-      in_src[j + 1] = ks;
-    }
-  }
   // ---- LatticeStateTimes (:36-67) without dependency levels: the states in INDEX order (the lattice is top-sorted), a
   // wave per block of 64 consecutive states, a state waits until the predecessor it reads next has published its time.
   // Sliding LDS window, ONE 8-byte word per slot = state << 32 | time (all ones: nothing yet): an operand is one LDS read, a
   // result one LDS store; a slot that holds a later state means the wanted one has left the window - its time is read
   // from memory, where it was stored before it was published (a slot is rewritten by the state win_slots further on, which
   // belongs to the same wave, and the wave stores and waits at the end of every block).  One operand per lane and pass.
+  // The incoming lists were filled in arrival order; the sweeps fold a state's arcs in ascending arc order (the reference's
+  // sequential sweep), so every list is sorted by arc index - in the block's LDS staging area (the block's lists are
+  // contiguous: coalesced loads, a lane sorts its own state's few entries at LDS latency, coalesced stores; one thread per
+  // state sorting in device memory took 3.7 M of the 6.4 M cycles of a 16 k-state lattice's preparation).
   constexpr int kTStage = 384;
   __shared__ int st_src[kThreads / 64][kTStage];
+  __shared__ int st_arc[kThreads / 64][kTStage];   // arc index - the lattice's first arc
+  __shared__ int st_seg[kThreads / 64][kTStage];   // the entry's list: first entry | length << 16
   __shared__ signed char st_inc[kThreads / 64][kTStage];
   for (int i = t; i < win_slots; i += kThreads) w_tt[i] = ~0ull;
   PrepSync();
@@ -802,9 +793,63 @@ PrepKernelDF(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ ar
       // (the block's entries staged in LDS before anything is waited for: see ForwardBackwardDFKernel)
       const int64_t jb = in_off[sb + blk * 64], je = in_off[sb + min(ns, blk * 64 + 64)];
       const int n_st = static_cast<int>(min<int64_t>(je - jb, kTStage));
-      for (int e2 = lane; e2 < n_st; e2 += 64) {
-        st_src[wave][e2] = in_src[jb + e2];
-        st_inc[wave][e2] = il[in_arc[jb + e2]] != 0 ? 1 : 0;
+      if (je - jb <= kTStage) {
+        for (int e2 = lane; e2 < n_st; e2 += 64) {
+          st_src[wave][e2] = in_src[jb + e2];
+          st_arc[wave][e2] = static_cast<int>(in_arc[jb + e2] - arc_b);
+        }
+        // every ENTRY finds its place in its state's list by counting the smaller arc indices of that list (a lane per
+        // entry: the longest list of the block costs its length in LDS reads, not its square in dependent round trips)
+        if (active) {
+          const int b0 = static_cast<int>(j - jb), len = static_cast<int>(ie - j);
+          for (int k = 0; k < len; k++) st_seg[wave][b0 + k] = b0 | (len << 16);
+        }
+        constexpr int kPer = kTStage / 64;
+        int pos[kPer], ksrc[kPer], karc[kPer];
+#pragma unroll
+        for (int r = 0; r < kPer; r++) {
+          const int e2 = lane + 64 * r;
+          pos[r] = -1;
+          ksrc[r] = 0;
+          karc[r] = 0;
+          if (e2 < n_st) {
+            const int seg = st_seg[wave][e2], b0 = seg & 0xffff, len = seg >> 16;
+            karc[r] = st_arc[wave][e2];
+            ksrc[r] = st_src[wave][e2];
+            int rank = 0;
+            for (int k = 0; k < len; k++) rank += st_arc[wave][b0 + k] < karc[r] ? 1 : 0;
+            pos[r] = b0 + rank;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kPer; r++) {
+          if (pos[r] < 0) continue;
+          const int64_t arc = arc_b + karc[r];
+          st_src[wave][pos[r]] = ksrc[r];
+          in_arc[jb + pos[r]] = arc;
+          in_src[jb + pos[r]] = ksrc[r];
+          st_inc[wave][pos[r]] = il[arc] != 0 ? 1 : 0;
+        }
+      } else {   // more entries than the staging area holds: every lane sorts its state's list in memory
+        if (active) {
+          for (int64_t i = j + 1; i < ie; i++) {
+            const int64_t ka = in_arc[i];
+            const int32_t ks = in_src[i];
+            int64_t q = i - 1;
+            while (q >= j && in_arc[q] > ka) {
+              in_arc[q + 1] = in_arc[q];
+              in_src[q + 1] = in_src[q];
+              q--;
+            }
+            in_arc[q + 1] = ka;
+            in_src[q + 1] = ks;
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int e2 = lane; e2 < n_st; e2 += 64) {
+          st_src[wave][e2] = in_src[jb + e2];
+          st_inc[wave][e2] = il[in_arc[jb + e2]] != 0 ? 1 : 0;
+        }
       }
       int src = 0, inc = 0;
       auto fetch = [&](int64_t jj) {
@@ -1200,7 +1245,7 @@ static void LatProfilePrint(const char *what, const DevArr<long long> &d_prof, i
   }
   if (strcmp(what, "prep") == 0)
     fprintf(stderr, "[kh_lattice profile] PrepKernelDF, %d lattices, shader cycles of thread 0 (mean): init %.0f, in-degrees %.0f, "
-            "scans %.0f, incoming lists %.0f, sort of the lists %.0f, state times (dataflow) %.0f\n", n_lats, m[0], m[1], m[2], m[3], m[4], m[5]);
+            "scans %.0f, incoming lists %.0f, window reset %.0f, sort of the lists + state times (dataflow) %.0f\n", n_lats, m[0], m[1], m[2], m[3], m[4], m[5]);
   else
     fprintf(stderr, "[kh_lattice profile] ForwardBackwardDFKernel, %d lattices, shader cycles of wave 0 (mean): kernel %.0f (forward "
             "%.0f); staging %.0f, %.0f passes with no operand ready %.0f (%.0f each), %.0f passes that folded an operand %.0f (%.0f each: "
@@ -1257,7 +1302,7 @@ struct LatBatch {
       for (int l = 0; l < n_lats; l++) max_ns = std::max(max_ns, lat_state_offsets[l + 1] - lat_state_offsets[l]);
       const int cus = std::max(1, NumCUs());
       const int per_cu = std::min(4, (n_lats + cus - 1) / cus);
-      const int budget = (160 * 1024) / per_cu - 9 * 1024;   // (staging + the static words)
+      const int budget = (160 * 1024) / per_cu - 21 * 1024;   // (staging + the static words)
       const int win = per_cu <= 2 ? 4096 : 1024;
       const int lds_states = std::max(0, std::min(max_ns, (budget - win * 8) / 4));
       const size_t dyn = static_cast<size_t>(win) * 8 + static_cast<size_t>(lds_states) * 4;
