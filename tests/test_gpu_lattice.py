@@ -238,3 +238,45 @@ def test_resident_batch_shares_one_upload(api):
     api.lattice_forward_backward(lats)
     t = api.lattice_last_timings()
     assert t["upload_ms"] > 0.0 and t["prep_ms"] > 0.0 and t["sweeps_ms"] > 0.0
+
+
+def test_window_forms_and_staging_overflow(api, monkeypatch):
+    """The dataflow sweeps' two window forms (one word per state when the lattice fits the window; tags + values otherwise)
+    and a block whose arcs do not fit the staging area (width-24 frames, ~17 incoming arcs per state: more than 384 per 64
+    states) against the oracle - and bit-identical to one another: the forms differ in where an operand is read, not in the
+    order it is folded in."""
+    rng = np.random.default_rng(41)
+    lats = [random_lattice(rng, n_frames=150, width=7), random_lattice(rng, n_frames=40, width=24, eps_frac=0.05),
+            random_lattice(rng, n_frames=3, width=2), random_lattice(rng, n_frames=260, width=5)]
+    assert max(L["n_states"] for L in lats) > 512
+    got = api.lattice_forward_backward(lats)
+    for L, r in zip(lats, got):
+        want = B.lattice_forward_backward(L)
+        assert abs(r["tot_like"] - want["tot_like"]) < 1e-9 * max(1.0, abs(want["tot_like"]))
+        assert np.abs(r["arc_post"] - want["arc_post"]).max() < 1e-6
+        assert np.array_equal(r["state_times"], want["state_times"])
+    monkeypatch.setenv("KH_LATTICE_WIN", "512")   # 256 tagged slots for every lattice of more than 512 states
+    tagged = api.lattice_forward_backward(lats)
+    for a, b in zip(got, tagged):
+        assert a["tot_like"] == b["tot_like"] and a["acoustic_like_sum"] == b["acoustic_like_sum"]
+        assert np.array_equal(a["arc_post"], b["arc_post"])
+    monkeypatch.delenv("KH_LATTICE_WIN")
+    # many lattices per CU (the small staging area, four workgroups per CU): the same numbers
+    many = api.lattice_forward_backward(lats * 300)
+    for i, r in enumerate(many):
+        assert r["tot_like"] == got[i % 4]["tot_like"] and np.array_equal(r["arc_post"], got[i % 4]["arc_post"])
+
+
+def test_nan_cost_does_not_stall_the_sweeps(api):
+    """A NaN arc cost makes NaN alphas; the window's "not there yet" word is a NaN bit pattern: a state whose value is NaN
+    must still count as published (the call returns; the other lattices of the batch are untouched)."""
+    rng = np.random.default_rng(42)
+    lats = [random_lattice(rng, n_frames=30, width=5) for _ in range(3)]
+    clean = api.lattice_forward_backward(lats)
+    bad = dict(lats[1])
+    g = bad["arc_graph"].copy()
+    g[len(g) // 2] = np.nan
+    bad["arc_graph"] = g
+    out = api.lattice_forward_backward([lats[0], bad, lats[2]])
+    assert out[0]["tot_like"] == clean[0]["tot_like"] and out[2]["tot_like"] == clean[2]["tot_like"]
+    assert np.array_equal(out[0]["arc_post"], clean[0]["arc_post"])
