@@ -1360,6 +1360,55 @@ struct LatBatch {
   }
 };
 
+// The dataflow sweeps on a batch prepared without levels (PrepKernelDF): window sizing + launch.
+static int LaunchForwardBackwardDF(const LatBatch &B, double *alpha, double *beta, float *post, double *tot, double *ac,
+                                   double min_log_diff, hipStream_t st) {
+  const int n_lats = B.n_lats;
+  struct { double *p; } d_alpha{alpha}, d_beta{beta}, d_tot{tot}, d_ac{ac};
+  struct { float *p; } d_post{post};
+  // the window: as many states as the workgroups that share a CU leave room for (a lattice that fits it whole takes one LDS
+  // read per operand), 512 ... 16384 slots and no more than the batch's largest lattice needs; KH_LATTICE_WIN overrides
+  int max_ns = 1;
+  for (const LatDesc &d : B.descs) max_ns = std::max(max_ns, d.n_states);
+  const int cus = std::max(1, NumCUs());
+  const int per_cu = std::min(4, (n_lats + cus - 1) / cus);   // (more than four resident workgroups per CU: the window gets too small)
+  const bool small_stage = per_cu > 2;
+  const int stage_bytes = (small_stage ? 192 : 384) * 16 * (kThreads / 64) + 256;
+  int win = 512;
+  while (win < 16384 && win < max_ns && (2 * win) * 8 + stage_bytes <= (160 * 1024) / per_cu) win *= 2;
+  if (const char *e = getenv("KH_LATTICE_WIN")) { const int v = atoi(e); if (v >= 512 && v <= 16384 && (v & (v - 1)) == 0) win = v; }
+  const size_t dyn = static_cast<size_t>(win) * sizeof(double);
+  DevArr<long long> d_prof;
+  const bool prof = LatProfile();
+  if (prof) {
+    if (d_prof.Alloc(static_cast<size_t>(n_lats) * kLatProf)) return KH_ENOMEM;
+    KH_HIP(hipMemsetAsync(d_prof.p, 0, sizeof(long long) * n_lats * kLatProf, st));
+  }
+#define KH_FB_LAUNCH(PROF, STAGE)                                                                                              \
+  do {                                                                                                                       \
+    static bool attr_set = false;                                                                                            \
+    if (!attr_set) {                                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ForwardBackwardDFKernel<PROF, STAGE>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);                                      \
+      (void)hipGetLastError();                                                                                               \
+      attr_set = true;                                                                                                       \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((ForwardBackwardDFKernel<PROF, STAGE>), dim3(n_lats), dim3(kThreads), dyn, st, B.d_descs.p,           \
+                       B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,     \
+                       B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff, d_prof.p, win);       \
+  } while (0)
+  if (prof) { if (small_stage) KH_FB_LAUNCH(true, 192); else KH_FB_LAUNCH(true, 384); }
+  else { if (small_stage) KH_FB_LAUNCH(false, 192); else KH_FB_LAUNCH(false, 384); }
+#undef KH_FB_LAUNCH
+  if (prof) {
+    KH_LAUNCH_CHECK();
+    fprintf(stderr, "[kh_lattice profile] window %d slots (largest lattice %d states), %d workgroups per CU planned\n", win, max_ns, per_cu);
+    LatProfilePrint("sweeps", d_prof, n_lats, st);
+  }
+  KH_LAUNCH_CHECK();
+  return KH_OK;
+}
+
 // LatticeForwardBackward :272-354 on a batch that is resident on the device: sweeps + download.
 // post_dev != NULL: the posteriors stay on the device, in the caller's buffer (arc_post is then ignored)
 static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_like, double *acoustic_like_sum, hipStream_t st,
@@ -1379,47 +1428,8 @@ static int RunForwardBackward(const LatBatch &B, float *arc_post, double *tot_li
                        B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p,
                        B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p, d_alpha.p, d_beta.p,
                        d_post.p, d_tot.p, d_ac.p, min_log_diff);
-  else {
-    // the window: as many states as the workgroups that share a CU leave room for (a lattice that fits it whole takes one LDS
-    // read per operand), 512 ... 16384 slots and no more than the batch's largest lattice needs; KH_LATTICE_WIN overrides
-    int max_ns = 1;
-    for (const LatDesc &d : B.descs) max_ns = std::max(max_ns, d.n_states);
-    const int cus = std::max(1, NumCUs());
-    const int per_cu = std::min(4, (n_lats + cus - 1) / cus);   // (more than four resident workgroups per CU: the window gets too small)
-    const bool small_stage = per_cu > 2;
-    const int stage_bytes = (small_stage ? 192 : 384) * 16 * (kThreads / 64) + 256;
-    int win = 512;
-    while (win < 16384 && win < max_ns && (2 * win) * 8 + stage_bytes <= (160 * 1024) / per_cu) win *= 2;
-    if (const char *e = getenv("KH_LATTICE_WIN")) { const int v = atoi(e); if (v >= 512 && v <= 16384 && (v & (v - 1)) == 0) win = v; }
-    const size_t dyn = static_cast<size_t>(win) * sizeof(double);
-    DevArr<long long> d_prof;
-    const bool prof = LatProfile();
-    if (prof) {
-      if (d_prof.Alloc(static_cast<size_t>(n_lats) * kLatProf)) return KH_ENOMEM;
-      KH_HIP(hipMemsetAsync(d_prof.p, 0, sizeof(long long) * n_lats * kLatProf, st));
-    }
-#define KH_FB_LAUNCH(PROF, STAGE)                                                                                              \
-    do {                                                                                                                       \
-      static bool attr_set = false;                                                                                            \
-      if (!attr_set) {                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ForwardBackwardDFKernel<PROF, STAGE>),                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);                                      \
-        (void)hipGetLastError();                                                                                               \
-        attr_set = true;                                                                                                       \
-      }                                                                                                                        \
-      hipLaunchKernelGGL((ForwardBackwardDFKernel<PROF, STAGE>), dim3(n_lats), dim3(kThreads), dyn, st, B.d_descs.p,           \
-                         B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p, B.d_fin.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,     \
-                         B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff, d_prof.p, win);       \
-    } while (0)
-    if (prof) { if (small_stage) KH_FB_LAUNCH(true, 192); else KH_FB_LAUNCH(true, 384); }
-    else { if (small_stage) KH_FB_LAUNCH(false, 192); else KH_FB_LAUNCH(false, 384); }
-#undef KH_FB_LAUNCH
-    if (prof) {
-      KH_LAUNCH_CHECK();
-      fprintf(stderr, "[kh_lattice profile] window %d slots (largest lattice %d states), %d workgroups per CU planned\n", win, max_ns, per_cu);
-      LatProfilePrint("sweeps", d_prof, n_lats, st);
-    }
-  }
+  else if (int rc_df = LaunchForwardBackwardDF(B, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, min_log_diff, st))
+    return rc_df;
   KH_LAUNCH_CHECK();
   g_lat_timer.Mark(3, st);
   if (arc_post && !post_dev)
@@ -2029,7 +2039,9 @@ extern "C" int kh_discriminative_lattice_computations(
   for (int i = 0; i < total_rows; i++) KH_CHECK_ARG(num_ali[i] > 0 && num_ali[i] <= num_tids);
   hipStream_t st = Stream();
   LatBatch B;
-  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st);
+  // (MMI needs LatticeForwardBackward only: the dataflow preparation and sweeps; the MPE / sMBR kernels sweep by level)
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st,
+               !is_mmi || getenv("KH_LATTICE_LEVELS") != nullptr);
   if (rc) return rc;
   for (int64_t a = 0; a < B.total_arcs; a++) KH_CHECK_ARG(arc_ilabel[a] >= 0 && arc_ilabel[a] <= num_tids);
   for (int l = 0; l < n_lats; l++)
@@ -2071,10 +2083,14 @@ extern "C" int kh_discriminative_lattice_computations(
     hipLaunchKernelGGL(NumLikeKernel, dim3(n_lats), dim3(kThreads), 0, st, d_row_off.p, d_ali.p, d_t2pdf.p, posteriors,
                        d_posteriors.stride, d_pri.p, acoustic_scale, d_num.p);
     if (d_alpha.Alloc(B.total_states) || d_beta.Alloc(B.total_states)) return KH_ENOMEM;
-    hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_next.p,
-                       B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,
-                       B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON));
-    KH_LAUNCH_CHECK();
+    if (B.has_levels) {
+      hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_next.p,
+                         B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,
+                         B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON));
+      KH_LAUNCH_CHECK();
+    } else if ((rc = LaunchForwardBackwardDF(B, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON), st))) {
+      return rc;
+    }
     KH_HIP(hipMemcpyAsync(h_num.data(), d_num.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
     KH_HIP(hipMemcpyAsync(h_tot.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
   } else {
