@@ -529,6 +529,71 @@ __device__ __forceinline__ int PrepScan(int v, int *total, int *s_w) {
   return before + inc - v;
 }
 
+// The incoming lists (filled in arrival order) sorted by arc index, a wave per block of 64 consecutive states: the block's
+// lists are contiguous - staged in LDS with coalesced loads, every ENTRY finds its place by counting the smaller arc indices
+// of its list, coalesced-ish stores (PrepKernelDF does the same inside its state-time pass).  A block with more entries than
+// the staging area holds: one lane per state, insertion sort in memory.
+constexpr int kSortStage = 384;
+__device__ __forceinline__ void SortIncomingLists(const int64_t *__restrict__ in_off, int64_t *__restrict__ in_arc, int32_t *__restrict__ in_src,
+                                                  int sb, int ns, int64_t arc_b, int (*st_src)[kSortStage], int (*st_arc)[kSortStage],
+                                                  int (*st_seg)[kSortStage]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int blk = wave; blk * 64 < ns; blk += kThreads / 64) {
+    const int s = blk * 64 + lane;
+    const bool active = s < ns;
+    int64_t j = 0, ie = 0;
+    if (active) { j = in_off[sb + s]; ie = in_off[sb + s + 1]; }
+    const int64_t jb = in_off[sb + blk * 64], je = in_off[sb + min(ns, blk * 64 + 64)];
+    if (je - jb <= kSortStage) {
+      const int n_st = static_cast<int>(je - jb);
+      for (int e2 = lane; e2 < n_st; e2 += 64) {
+        st_src[wave][e2] = in_src[jb + e2];
+        st_arc[wave][e2] = static_cast<int>(in_arc[jb + e2] - arc_b);
+      }
+      if (active) {
+        const int b0 = static_cast<int>(j - jb), len = static_cast<int>(ie - j);
+        for (int k = 0; k < len; k++) st_seg[wave][b0 + k] = b0 | (len << 16);
+      }
+      constexpr int kPer = kSortStage / 64;
+      int pos[kPer], ksrc[kPer], karc[kPer];
+#pragma unroll
+      for (int r = 0; r < kPer; r++) {
+        const int e2 = lane + 64 * r;
+        pos[r] = -1;
+        ksrc[r] = 0;
+        karc[r] = 0;
+        if (e2 < n_st) {
+          const int seg = st_seg[wave][e2], b0 = seg & 0xffff, len = seg >> 16;
+          karc[r] = st_arc[wave][e2];
+          ksrc[r] = st_src[wave][e2];
+          int rank = 0;
+          for (int k = 0; k < len; k++) rank += st_arc[wave][b0 + k] < karc[r] ? 1 : 0;
+          pos[r] = b0 + rank;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kPer; r++) {
+        if (pos[r] < 0) continue;
+        in_arc[jb + pos[r]] = arc_b + karc[r];
+        in_src[jb + pos[r]] = ksrc[r];
+      }
+    } else if (active) {
+      for (int64_t i = j + 1; i < ie; i++) {
+        const int64_t ka = in_arc[i];
+        const int32_t ks = in_src[i];
+        int64_t q = i - 1;
+        while (q >= j && in_arc[q] > ka) {
+          in_arc[q + 1] = in_arc[q];
+          in_src[q + 1] = in_src[q];
+          q--;
+        }
+        in_arc[q + 1] = ka;
+        in_src[q + 1] = ks;
+      }
+    }
+  }
+}
+
 constexpr int kPrepLdsStates = 5120;   // 60 KB of LDS for the three work arrays
 __global__ void __launch_bounds__(kThreads)
 PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ il,
@@ -603,20 +668,9 @@ PrepKernel(const int32_t *__restrict__ lat_off, const int64_t *__restrict__ arc_
       in_src[pos] = s;
     }
   PrepSync();
-  for (int s = t; s < ns; s += kThreads) {
-    const int64_t b0 = in_off[sb + s], e0 = in_off[sb + s + 1];
-    for (int64_t i = b0 + 1; i < e0; i++) {
-      const int64_t ka = in_arc[i];
-      const int32_t ks = in_src[i];
-      int64_t j = i - 1;
-      while (j >= b0 && in_arc[j] > ka) {
-        in_arc[j + 1] = in_arc[j];
-        in_src[j + 1] = in_src[j];
-        j--;
-      }
-      in_arc[j + 1] = ka;
-      in_src[j + 1] = ks;
-    }
+  {
+    __shared__ int so_src[kThreads / 64][kSortStage], so_arc[kThreads / 64][kSortStage], so_seg[kThreads / 64][kSortStage];
+    SortIncomingLists(in_off, in_arc, in_src, sb, ns, arc_b, so_src, so_arc, so_seg);
   }
   // ---- levels (Kahn) + LatticeStateTimes
   const int lvb = sb + l;  // level_off has n_states + 1 entries per lattice
