@@ -81,8 +81,14 @@ __device__ __forceinline__ void Prio() {
 }
 
 // ---- the production tiling (kh_gemm.hip GemmKernel): [k][row + 4] image, 2 x 2 waves of 2 x 2 MFMA tiles
+__device__ long long g_clk[4];   // shader clock / 100 MHz wall clock over the life of one workgroup in the middle of the grid
+__device__ long long g_life[2 * 65536];   // wall clock (100 MHz) at the start and the end of every workgroup of the base kernel
 __global__ void __launch_bounds__(256, 4) GemmBase(GemmArgs g) {
   constexpr int BM = 128, BN = 128, NT = 256, LA = BM + 4;
+  const bool probe = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  long long c0 = 0, w0 = 0;
+  if (probe) { c0 = clock64(); w0 = wall_clock64(); }
+  if (threadIdx.x == 0 && blockIdx.x < 65536) g_life[2 * blockIdx.x] = wall_clock64();
   __shared__ float As[2][BK][LA];
   __shared__ float Bs[2][BK][LA];
   Prio();
@@ -164,6 +170,8 @@ __global__ void __launch_bounds__(256, 4) GemmBase(GemmArgs g) {
         cp[voff] = acc[i][0][r] + bv0;
         cp[voff + 32] = acc[i][1][r] + bv1;
       }
+    if (probe) { g_clk[0] = clock64() - c0; g_clk[1] = wall_clock64() - w0; }
+    if (threadIdx.x == 0 && blockIdx.x < 65536) g_life[2 * blockIdx.x + 1] = wall_clock64();
     return;
   }
 #pragma unroll
@@ -180,6 +188,7 @@ __global__ void __launch_bounds__(256, 4) GemmBase(GemmArgs g) {
         g.C[static_cast<size_t>(row) * g.c_stride + col] = acc[i][j][r] + bv;
       }
     }
+  if (threadIdx.x == 0 && blockIdx.x < 65536) g_life[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 // ---- [row][16 k] image, b128 operand reads.  WM x WN waves, each TM x TN MFMA tiles of 32 x 32.
@@ -415,6 +424,36 @@ int main(int argc, char **argv) {
       CK(hipEventElapsedTime(&ms, e0, e1));
       ms /= reps;
       printf("%-48s %8.3f ms  %6.1f TFLOP/s  %s\n", v.name, ms, flop / ms / 1e9, same ? "bits ok" : "BITS DIFFER");
+      if (v.fn == LaunchBase) {
+        long long hc[4] = {0, 0, 0, 0};
+        CK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc)));
+        {
+          const int nwg = ((M + 127) / 128) * ((N + 127) / 128);
+          std::vector<long long> life(2 * static_cast<size_t>(std::min(nwg, 65536)));
+          CK(hipMemcpyFromSymbol(life.data(), HIP_SYMBOL(g_life), life.size() * 8));
+          long long t0 = life[0], t1 = life[1];
+          double sum = 0, mx = 0;
+          for (size_t i = 0; i < life.size() / 2; i++) {
+            t0 = std::min(t0, life[2 * i]); t1 = std::max(t1, life[2 * i + 1]);
+            const double d = static_cast<double>(life[2 * i + 1] - life[2 * i]);
+            sum += d; mx = std::max(mx, d);
+          }
+          const double span = static_cast<double>(t1 - t0);
+          // occupancy over time in 20 slices
+          std::vector<double> occ(20, 0.0);
+          for (size_t i = 0; i < life.size() / 2; i++)
+            for (int k = 0; k < 20; k++) {
+              const double a = t0 + span * k / 20, b = t0 + span * (k + 1) / 20;
+              const double lo = std::max<double>(a, life[2 * i]), hi = std::min<double>(b, life[2 * i + 1]);
+              if (hi > lo) occ[k] += (hi - lo) / (b - a);
+            }
+          printf("    %d workgroups: first start to last end %.1f us; lifetime mean %.1f us, max %.1f us; workgroups alive, by twentieth of the span:",
+                 nwg, span / 100.0, sum / (life.size() / 2) / 100.0, mx / 100.0);
+          for (int k = 0; k < 20; k++) printf(" %.0f", occ[k]);
+          printf("\n");
+        }
+        if (hc[1] > 0) printf("    shader clock under this load: %.0f MHz (%lld cycles in %.1f us, one workgroup)\n", hc[0] / (hc[1] / 100.0), hc[0], hc[1] / 100.0);
+      }
     }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dbias));
   }
