@@ -2,7 +2,9 @@
 graph, beam 15 / max-active 7000, real forward pass) decoded in one launch with more utterances
 than slots, and a sample of utterances — the longest, first and last in their slot's queue,
 a median one — compared bit-exactly with the canonical oracle on the SAME log-likelihood rows.
-    python tools/validate_bench_scale.py [n_utts=700]"""
+    python tools/validate_bench_scale.py [n_utts=700] [reference]
+"reference": the kernel in LatticeFasterDecoder's own iteration order (kh_decoder_set_reference_order) against the line-by-line
+restatement (oracle mode 0)."""
 import importlib
 import sys
 import time
@@ -19,6 +21,7 @@ from test_gpu_decoder import assert_same_best_path, assert_same_lattice
 api = importlib.import_module("old-kaldi-git_amd.api")
 api.select_gpu(0)
 n_utts = int(sys.argv[1]) if len(sys.argv) > 1 else 700
+MODE = "reference" if len(sys.argv) > 2 and sys.argv[2] == "reference" else "canonical"
 t0 = time.time()
 net, priors, g, protos = bench.build_model_and_graph(3456, 10_000_000, False)
 feats, off = bench.build_utterances(3456, 0, n_utts, net, g, protos, False)
@@ -26,7 +29,8 @@ print("workload built in %.0f s: %d utterances, %d frames" % (time.time() - t0, 
 nnet = api.Nnet(net, priors)
 fst = api.Fst(g)
 cfg = api.decoder_config(**bench.DECODE_CFG)
-dec = api.LatticeFasterDecoder(fst, cfg, max_batch=n_utts, max_frames=int(np.diff(off).max()))
+dec = api.LatticeFasterDecoder(fst, cfg, max_batch=n_utts, max_frames=int(np.diff(off).max()), exact_reference_order=MODE == "reference")
+print("decoding order:", MODE)
 n_pdf = net[-1]["output_dim"]
 ll = torch.empty((int(off[-1]), n_pdf), dtype=torch.float32, device="cuda")
 bench.forward_all(nnet, torch.from_numpy(feats).cuda(), off, ll, max_rows=60000)
@@ -41,7 +45,7 @@ sample = [0, 3, n_utts // 2, n_utts - 2, n_utts - 1, int(np.argmin(np.abs(lens -
 for u in sample:
     x = ll[off[u]:off[u + 1]].cpu().numpy()
     t1 = time.time()
-    oc = B.DecoderOracle(g, cfg, "canonical")
+    oc = B.DecoderOracle(g, cfg, MODE)
     assert oc.decode(x)
     assert_same_lattice(dec.get_raw_lattice(u), oc.raw_lattice())
     assert_same_best_path(dec.get_best_path(u), oc.best_path())
