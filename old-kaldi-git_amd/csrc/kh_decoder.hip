@@ -154,6 +154,24 @@ __device__ __forceinline__ void Store4I(const Arr<T> &a, int i, KhInt4 v) {
   static_assert(sizeof(T) == 4, "4-byte elements");
   *(__attribute__((address_space(1))) KhInt4U *)((__attribute__((address_space(1))) char *)a.p + static_cast<uint32_t>(i) * 4u) = v;
 }
+// Non-temporal forms (the nt cache policy: the line is not kept in L2 for this access): for the arrays a frame writes once
+// and nobody reads before the next pruning visit - far behind in the stream - and for that visit's reads.  What they no
+// longer displace is the part of the arc table the next frames re-read (the active states of consecutive frames overlap).
+template <class T>
+__device__ __forceinline__ KhInt4 Load4I_NT(const Arr<T> &a, int i) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  return __builtin_nontemporal_load((__attribute__((address_space(1))) const KhInt4U *)((__attribute__((address_space(1))) const char *)a.p + static_cast<uint32_t>(i) * 4u));
+}
+template <class T>
+__device__ __forceinline__ KhFloat4 Load4F_NT(const Arr<T> &a, int i) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  return __builtin_nontemporal_load((__attribute__((address_space(1))) const KhFloat4U *)((__attribute__((address_space(1))) const char *)a.p + static_cast<uint32_t>(i) * 4u));
+}
+template <class T>
+__device__ __forceinline__ void Store4I_NT(const Arr<T> &a, int i, KhInt4 v) {
+  static_assert(sizeof(T) == 4, "4-byte elements");
+  __builtin_nontemporal_store(v, (__attribute__((address_space(1))) KhInt4U *)((__attribute__((address_space(1))) char *)a.p + static_cast<uint32_t>(i) * 4u));
+}
 template <class T>
 __device__ __forceinline__ void Store4F(const Arr<T> &a, int i, KhFloat4 v) {
   static_assert(sizeof(T) == 4, "4-byte elements");
@@ -1924,7 +1942,11 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       e_state[idx] = ns & kStateMask;
       const uint32_t cost_enc = vals[i];
       e_cost[idx] = cost_enc;
+#ifndef KH_NO_NT
+      __builtin_nontemporal_store(0.0f, &e_extra[idx]);  // "tokens on the currently final frame have zero extra_cost" :241
+#else
       e_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
+#endif
       vals[i] = static_cast<uint32_t>(idx);
       // these tokens are the closure's first work list (every one has a finite cost)
       if ((ns & kHasEps) != 0) {
@@ -1987,7 +2009,11 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       if (full && wrote) {   // the lane owns the four slots: one 16-byte store
         KhInt4 o4;
         o4.x = nsv[0]; o4.y = nsv[1]; o4.z = nsv[2]; o4.w = nsv[3];
+#ifndef KH_NO_NT
+        if (k + 1 == parts) Store4I_NT(e_dst, base, o4); else Store4I(e_dst, base, o4);   // (the last part: nobody reads the links before pruning)
+#else
         Store4I(e_dst, base, o4);
+#endif
       }
       if (more) {
 #pragma unroll
@@ -2109,9 +2135,18 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
       },
       [&](int k, int l) {
         x_dst[l] = -2 - c_arc[k].w;  // <= -2: the HCLG next state (+ flags), unresolved; token index after pass 2
+#ifndef KH_NO_NT
+        // (source, arc and acoustic cost of a link are not read again before the next pruning visit: non-temporal stores -
+        // same-box A/B 546 -> 535 ms, with the other nt accesses of the file 531: the lines they no longer displace in L2
+        // are arc records the next frames re-read)
+        __builtin_nontemporal_store(c_src[k], &x_src[l]);
+        __builtin_nontemporal_store(c_ai[k], &x_arc[l]);
+        if (x_keep_ac) __builtin_nontemporal_store(c_ac[k], &x_a[l]);
+#else
         x_src[l] = c_src[k];
         x_arc[l] = c_ai[k];
         if (x_keep_ac) x_a[l] = c_ac[k];
+#endif
         x_k[l] = c_tot[k];
       });
   if (link_frame_e < 0) return false;
@@ -3847,7 +3882,11 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           x_dst[l] = -2 - arc.w;
           x_src[l] = base + lo;
           x_arc[l] = ai;
+#ifndef KH_NO_NT
+          if (x_keep_ac) __builtin_nontemporal_store(ac, &x_a[l]);   // (not read before the next pruning visit)
+#else
           if (x_keep_ac) x_a[l] = ac;
+#endif
           x_k[l] = tot;
           xp_csid[l - link_frame_b] = arc.y;   // the caller's id of the destination state (ArcPdfKernel)
         }
@@ -4486,8 +4525,13 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
     float kk[kBU];
     const bool full = l0 + kBU <= me;
     if (full) {
+#ifndef KH_NO_NT
+      const KhInt4 d4 = Load4I_NT(u.link_dst, l0), s4 = Load4I_NT(u.link_src, l0);
+      const KhFloat4 k4 = Load4F_NT(u.link_k, l0);
+#else
       const KhInt4 d4 = Load4I(u.link_dst, l0), s4 = Load4I(u.link_src, l0);
       const KhFloat4 k4 = Load4F(u.link_k, l0);
+#endif
       dst[0] = d4.x; dst[1] = d4.y; dst[2] = d4.z; dst[3] = d4.w;
       src[0] = s4.x; src[1] = s4.y; src[2] = s4.z; src[3] = s4.w;
       kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
