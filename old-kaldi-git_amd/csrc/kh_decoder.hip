@@ -1840,10 +1840,16 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     // candidates per lane are loaded before any is used (independent loads in flight).
     constexpr int kMU = 4;
     // a lane's kMU = 4 consecutive candidates: one 16-byte load per array (element by element, clamped, in the frame's last group)
+    bool last_read = false;   // (D) of the last part is the last read of the candidates' cost and state before pruning
     auto load_group = [&](int base, float (&tc)[kMU], int32_t (&nsv)[kMU]) {
       if (base + kMU <= link_frame_e) {
+#ifndef KH_NO_NT
+        const KhFloat4 t4 = last_read ? Load4F_NT(e_k, base) : Load4F(e_k, base);
+        const KhInt4 n4 = last_read ? Load4I_NT(e_dst, base) : Load4I(e_dst, base);
+#else
         const KhFloat4 t4 = Load4F(e_k, base);
         const KhInt4 n4 = Load4I(e_dst, base);
+#endif
         tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
         nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
       } else {
@@ -1969,6 +1975,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     if (threadIdx.x == 0) sh->tok_end = tok_base + total;
     KhSync();
     // (D) the part's links get their token index; rejected candidates become dead links
+    last_read = k + 1 == parts;
     {
       const int base0 = link_frame_b + threadIdx.x * kMU;
       if (base0 < link_frame_e) load_group(base0, tc, nsv);
@@ -2034,7 +2041,11 @@ __device__ __forceinline__ void StageScoreRow(const Utt &u, const Params &p, Blk
   for (int c0 = threadIdx.x; c0 < p.ll_cols; c0 += NT * kU) {
     float v[kU];
 #pragma unroll
+#ifndef KH_NO_NT
+    for (int k = 0; k < kU; k++) v[k] = c0 + k * NT < p.ll_cols ? __builtin_nontemporal_load(&src[c0 + k * NT]) : 0.0f;
+#else
     for (int k = 0; k < kU; k++) v[k] = c0 + k * NT < p.ll_cols ? src[c0 + k * NT] : 0.0f;
+#endif
 #pragma unroll
     for (int k = 0; k < kU; k++)
       if (c0 + k * NT < p.ll_cols) sh.ll_row[c0 + k * NT] = v[k];
@@ -4777,8 +4788,13 @@ __device__ void FinalBackward(const Utt &u_in, const Params &p, int last, int fb
       int dst[kBU], src[kBU];
       float kk[kBU];
       if (l0 + kBU <= me) {
+#ifndef KH_NO_NT
+        const KhInt4 d4 = Load4I_NT(u.link_dst, l0), s4 = Load4I_NT(u.link_src, l0);   // (the utterance's last pass over its links)
+        const KhFloat4 k4 = Load4F_NT(u.link_k, l0);
+#else
         const KhInt4 d4 = Load4I(u.link_dst, l0), s4 = Load4I(u.link_src, l0);
         const KhFloat4 k4 = Load4F(u.link_k, l0);
+#endif
         dst[0] = d4.x; dst[1] = d4.y; dst[2] = d4.z; dst[3] = d4.w;
         src[0] = s4.x; src[1] = s4.y; src[2] = s4.z; src[3] = s4.w;
         kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
