@@ -60,6 +60,7 @@ using namespace kh;
 struct KhFst {
   int32_t num_states = 0, start = 0, start_state = 0;  // start: unit id; start_state: the caller's id
   int64_t num_arcs = 0, num_emit = 0, num_eps = 0, num_units = 0;
+  int32_t max_emit = 0;            // the largest number of emitting arcs of one state
   int4 *rec = nullptr;             // [num_units] header {n_emit, eps_base, n_eps, final bits} | arc {ilabel, olabel, weight bits, nextstate unit | flags}
   int32_t *unit_ilabel = nullptr;  // [num_units] ilabel (> 0) of an arc unit (the decoder's copy of rec holds the pdf there); -1 - the caller's state id for a header
   int4 *n_arcs = nullptr;          // {0, olabel, weight bits, nextstate unit | flags}
@@ -282,6 +283,7 @@ struct Params {
   Arr<const KhInt4> n_arcs;
   Arr<const int32_t> unit_ilabel;
   int32_t start, num_units, num_eps, start_has_eps;
+  int32_t max_emit;           // largest emitting fan-out of a state (reference order: 16-bit arc counts in LDS when it fits)
   int32_t ll_cols;  // > 0: columns of the log-likelihood matrix, staged per frame in LDS
   int32_t keep_ac;  // 1: links store their acoustic cost (online decoding: a chunk's scores are gone when the lattice is
                     // exported); 0: it is recomputed at export from the score matrix, cost_offset[f] - loglike(f, pdf of the
@@ -465,6 +467,7 @@ struct Shared {
   // exact reference order
   uint32_t x_hsize;     // HashList::hash_size_ (:219-225: grows to hash_ratio x the frame's token count, never shrinks)
   uint32_t x_qbase;     // first insertion key of the epsilon closure's insertions (> every emitting candidate's ordinal)
+  int x_nbp;            // reference order, frames of 8 k - 16 k tokens: steps of the running cutoff found by the scan
   int x_ne_emit;        // end of the tokens the emitting pass created (the closure's follow)
   int x_eps_emit;       // entries of tmp_epslist the emitting pass made
   int x_n_new;          // closure replay: insertions counted
@@ -3773,9 +3776,28 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   // by position.  Larger frames: (M, count) by token through memory, the scan in chunks of 8192 positions.
   constexpr int kScanLds = kLdsSlots - kLdsSlots / 32;
   const bool lds_scan = n <= kScanLds;
+  // Frames of up to 2 * kLdsSlots tokens (nearly all of the rest; half of the kernel's work): the arc counts at their list
+  // positions as 16-BIT words (the key area holds 16384 of them; a state's emitting fan-out fits - Params::max_emit), the
+  // bitmap of the positions with a finite M in the top of the value area (above the score row, which the sweep is reading);
+  // the scan then writes the ordinal of every position's first arc over BOTH areas (the score row is not read again) and
+  // leaves the running cutoff as what it is - a step function with a handful of steps: the positions where it drops and
+  // the values it drops to, as a short list in memory.  A candidate at or under the frame's FINAL cutoff is accepted
+  // without looking (it is under every earlier value); the others - under one in a hundred - walk the list.
+#ifndef KH_X_NO_MID_TIER
+  constexpr int kMidBits = 2 * kLdsSlots / 32, kMidBitBase = kLdsSlots - kMidBits;
+  const bool mid_scan = !lds_scan && n <= 2 * kLdsSlots && x_ll_cols <= kMidBitBase && p.max_emit < 65536;
+#else
+  constexpr int kMidBits = 0, kMidBitBase = 0;
+  const bool mid_scan = false;
+#endif
   const LdsU32 sK = (LdsU32)LdsKeys(sh);
+  const LdsU32 sV = (LdsU32)LdsVals(sh);
   if (lds_scan)
     for (int w = n + static_cast<int>(threadIdx.x); w < n + ((n + 31) >> 5); w += NT) sK[w] = 0u;
+  if (mid_scan) {
+    for (int w = threadIdx.x; w < kMidBits; w += NT) sV[kMidBitBase + w] = 0u;
+    if (threadIdx.x == 0) sh->x_nbp = 0;
+  }
   LdsSync();
   const int lane = threadIdx.x & 63;
   long long my_arcs = 0;
@@ -3911,6 +3933,12 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           xp_m[pos] = me;
           (void)__hip_atomic_fetch_or(&sK[n + (pos >> 5)], 1u << (pos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+      } else if (mid_scan) {
+        ((LdsU16)sK)[pos] = static_cast<uint16_t>(cnt);
+        if (me < kEncInf) {
+          xp_m[pos] = me;
+          (void)__hip_atomic_fetch_or(&sV[kMidBitBase + (pos >> 5)], 1u << (pos & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       } else {
         xp_m[i - b] = me;
         xp_c[i - b] = cnt;
@@ -3977,6 +4005,52 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     run_min = run_min < tot_min ? run_min : tot_min;
     run_sum = tot_sum;
     LdsSync();
+  } else if (mid_scan) {
+    // a lane owns sixteen consecutive positions: eight words of counts, sixteen bits of the bitmap
+    const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);
+    constexpr int kPer = 2 * kLdsSlots / NT;
+    static_assert(kPer == 16, "a lane's positions are half a word of the bitmap");
+    const int w0 = tid * kPer;
+    uint32_t mm[kPer], lane_min = 0xFFFFFFFFu;
+    int cc[kPer], lane_sum = 0;
+    const uint32_t bits = w0 < n ? (V[kMidBitBase + (w0 >> 5)] >> (w0 & 31)) & 0xffffu : 0u;
+#pragma unroll
+    for (int j = 0; j < kPer / 2; j++) {
+      const uint32_t kv = K[(w0 >> 1) + j];   // (unguarded: inside the area)
+      cc[2 * j] = w0 + 2 * j < n ? static_cast<int>(kv & 0xffffu) : 0;
+      cc[2 * j + 1] = w0 + 2 * j + 1 < n ? static_cast<int>(kv >> 16) : 0;
+      lane_sum += cc[2 * j] + cc[2 * j + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; j++) mm[j] = 0xFFFFFFFFu;
+    if (bits != 0u) {   // (rare: a token with arcs under the bound of its run)
+#pragma unroll
+      for (int j = 0; j < kPer; j++)
+        if (((bits >> j) & 1u) != 0u) {
+          mm[j] = xp_m[w0 + j];
+          lane_min = mm[j] < lane_min ? mm[j] : lane_min;
+        }
+    }
+    int ex_sum, tot_sum;
+    uint32_t ex_min, tot_min;
+    BlockExScanSumMin(lane_sum, lane_min, &ex_sum, &ex_min, &tot_sum, &tot_min, sh);   // (its barrier: every lane has read its counts and bits)
+    uint32_t rm = run_min < ex_min ? run_min : ex_min;
+    int rs = ex_sum;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int w = w0 + j;
+      if (w < n) { if (w < kLdsSlots) K[w] = static_cast<uint32_t>(rs); else V[w - kLdsSlots] = static_cast<uint32_t>(rs); }
+      if (mm[j] < rm) {   // the running cutoff drops behind this position
+        rm = mm[j];
+        const int at = __hip_atomic_fetch_add(&sh->x_nbp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        xp_c[at] = w + 1;                               // (first position the new value holds for)
+        UX(x_h)[at] = static_cast<int32_t>(rm);
+      }
+      rs += cc[j];
+    }
+    run_min = run_min < tot_min ? run_min : tot_min;
+    run_sum = tot_sum;
+    KhSync();   // (the steps of the running cutoff are in memory)
   } else {
     const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);   // (the score row is not read again in this frame)
     constexpr int kTU = 4, kPer = kLdsSlots / NT;
@@ -4057,6 +4131,8 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     sh->front_b = nb;
   }
   if (lds_scan) LdsSync(); else KhSync();   // (the scan through memory: its results by token have landed)
+  const int n_bp = mid_scan ? Uni(sh->x_nbp) : 0;
+  const uint32_t r_final = run_min, r_start = Enc(est0);
   // ---- the candidates against the running cutoff in front of their source token (:731); ordinals
   int n_acc = 0;
   {
@@ -4084,6 +4160,28 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         for (int k = 0; k < kOU; k++) {
           rs[k] = V[ps[k]];
           as[k] = static_cast<int>(K[ps[k]]) - (sts[k] + 1);
+        }
+      } else if (mid_scan) {   // the ordinal of the token's first arc by list position, over both areas; the running cutoff from its steps
+        const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);
+        int ps[kOU], sts[kOU];
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          ps[k] = xp_pos[srcs[k] - b];
+          sts[k] = x_state[srcs[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          const uint32_t base = ps[k] < kLdsSlots ? K[ps[k]] : V[ps[k] - kLdsSlots];
+          as[k] = static_cast<int>(base) - (sts[k] + 1);
+          rs[k] = r_final;
+          if (ks[k] > Dec(r_final)) {   // (rare) above the final cutoff: the value that held in front of its source token
+            uint32_t r = r_start;
+            for (int q = 0; q < n_bp; q++) {
+              const uint32_t v = static_cast<uint32_t>(UX(x_h)[q]);
+              if (xp_c[q] <= ps[k] && v < r) r = v;
+            }
+            rs[k] = r;
+          }
         }
       } else {
 #pragma unroll
@@ -6862,6 +6960,8 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.num_units = static_cast<int32_t>(d->fst->num_units);
   p.num_eps = static_cast<int32_t>(d->fst->num_eps);
   p.start_has_eps = d->fst->start_has_eps;
+  p.max_emit = d->fst->max_emit;
+  if (const char *e = getenv("KH_DECODER_NO_MID_SCAN")) { if (atoi(e) != 0) p.max_emit = 1 << 16; }   // (tests: the scan through memory for every frame beyond the LDS tier)
   // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
   // the score row shares the workgroup's 64 KB of LDS with the static block (Shared)
   p.ll_cols = (sizeof(float) * static_cast<size_t>(ll_stride) + sizeof(Shared) + 256 <= 78 * 1024) ? ll_stride : 0;
@@ -7077,7 +7177,7 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
   std::vector<int4> rec(static_cast<size_t>(units)), n_arcs;
   std::vector<int32_t> unit_ilabel(static_cast<size_t>(units), 0);   // (every unit is written below)
   n_arcs.reserve(static_cast<size_t>(n_eps_total));
-  int32_t max_il = 0;
+  int32_t max_il = 0, max_emit = 0;
   for (int32_t s = 0; s < num_states; s++) {
     const int32_t base = unit_of_state[s], eps_base = static_cast<int32_t>(n_arcs.size());
     int32_t ne = 0;
@@ -7098,6 +7198,7 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
     memcpy(&fbits, &final_cost[s], 4);
     rec[base] = make_int4(ne, eps_base, static_cast<int32_t>(n_arcs.size()) - eps_base, fbits);
     unit_ilabel[base] = -1 - s;
+    max_emit = std::max(max_emit, ne);
   }
   KhFst *f = new KhFst();
   f->num_states = num_states;
@@ -7108,6 +7209,7 @@ KhFst *kh_fst_create(int32_t num_states, int32_t start, const int64_t *arc_offse
   f->num_emit = units - num_states;
   f->num_eps = static_cast<int64_t>(n_arcs.size());
   f->max_ilabel = max_il;
+  f->max_emit = max_emit;
   f->final_host.assign(final_cost, final_cost + num_states);
   f->start_has_eps = has_eps[start];
   auto up = [&](void **dst, const void *src, size_t bytes) -> bool {

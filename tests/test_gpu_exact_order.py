@@ -120,15 +120,25 @@ def test_list_order_by_the_sort(api, monkeypatch):
     run_exact(api, g, [workloads.make_loglikes(rng, 64, 80)], api.decoder_config(beam=11.0, max_active=1500, lattice_beam=7.0))
 
 
-def test_frames_beyond_the_lds_construction(api):
-    """Frames of more than 8160 tokens (the LDS construction's capacity) inside an utterance whose other frames fit:
-    both list-order paths in one decode, hash sizes growing on the way."""
+@pytest.mark.parametrize("scan", ["lds_and_mid", "through_memory"])
+def test_frames_beyond_the_lds_construction(api, scan, monkeypatch):
+    """Frames of more than 8160 tokens (the LDS construction's capacity) and of more than 16384 (the capacity of the 16-bit
+    counts of the running-cutoff scan) inside an utterance whose other frames fit: every list-order path and every scan
+    tier in one decode, hash sizes growing on the way; "through_memory": the frames beyond the first tier take the scan
+    through memory (KH_DECODER_NO_MID_SCAN)."""
+    if scan == "through_memory":
+        monkeypatch.setenv("KH_DECODER_NO_MID_SCAN", "1")
     rng = np.random.default_rng(11)
     g = graph_like_hclg(rng, 300000, 1000, mean_degree=3.0)
     lls = [workloads.make_loglikes(rng, T, 1000) for T in (40, 25)]
     cfg = api.decoder_config(beam=16.0, max_active=30000, min_active=200, lattice_beam=6.0)
     dec = run_exact(api, g, lls, cfg)
-    assert max(dec.stats(u)["max_tokens_frame"] for u in range(2)) > 8160
+    mx = max(dec.stats(u)["max_tokens_frame"] for u in range(2))
+    assert mx > 8160
+    # ... and frames beyond the second tier
+    cfg = api.decoder_config(beam=19.0, max_active=60000, min_active=200, lattice_beam=5.0)
+    dec = run_exact(api, g, [lls[1][:12]], cfg)
+    assert dec.stats(0)["max_tokens_frame"] > 16384, dec.stats(0)["max_tokens_frame"]
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KH_FUZZ_SEEDS", "100"))))
