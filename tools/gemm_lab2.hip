@@ -191,6 +191,125 @@ __global__ void __launch_bounds__(256, 4) GemmBase(GemmArgs g) {
   if (threadIdx.x == 0 && blockIdx.x < 65536) g_life[2 * blockIdx.x + 1] = wall_clock64();
 }
 
+__device__ int g_tile_counter;
+__global__ void __launch_bounds__(256, 4) GemmPersist(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, NT = 256, LA = BM + 4;
+  __shared__ float As[2][BK][LA];
+  __shared__ float Bs[2][BK][LA];
+  Prio();
+  __shared__ int s_tile;
+  const int nwg_ = g.tiles_m * g.tiles_n;
+  for (;;) {
+  __syncthreads();   // (the previous tile's readers of the operand buffers and of s_tile are done)
+  if (threadIdx.x == 0) s_tile = atomicAdd(&g_tile_counter, 1);
+  __syncthreads();
+  const int tile_ = s_tile;
+  if (tile_ >= nwg_) break;
+  int tm, tn;
+  {
+    const int per = g.group_m * g.tiles_n;
+    const int gid = tile_ / per, in = tile_ - gid * per;
+    const int first_m = gid * g.group_m;
+    const int gsz = min(g.tiles_m - first_m, g.group_m);
+    tn = in / gsz;
+    tm = first_m + (in - tn * gsz);
+  }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int lrow = t >> 2, lk = (t & 3) << 2, kk = lane >> 5, l31 = lane & 31;
+  const int nk = (g.K + BK - 1) / BK;
+  const int m0 = tm * BM, n0 = tn * BN, rowsA = g.M - m0, rowsB = g.N - n0;
+  const float *Ab = g.A + static_cast<long>(m0) * g.a_si, *Bb = g.B + static_cast<long>(n0) * g.b_sj;
+  const bool full = rowsA >= BM && rowsB >= BN;
+  float4 ra[2], rb[2];
+  unsigned offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    offa[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.a_si) + lk) * 4u;
+    offb[i] = (static_cast<unsigned>(lrow + NT / 4 * i) * static_cast<unsigned>(g.b_sj) + lk) * 4u;
+  }
+  auto load_tile = [&](int k0) {
+    if (full && k0 + BK <= g.K) {
+      const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+      for (int i = 0; i < 2; i++) { ra[i] = *reinterpret_cast<const float4 *>(pa + offa[i]); rb[i] = *reinterpret_cast<const float4 *>(pb + offb[i]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        ra[i] = LoadRow4(Ab, g.a_si, lrow + NT / 4 * i, k0 + lk, rowsA, g.K);
+        rb[i] = LoadRow4(Bb, g.b_sj, lrow + NT / 4 * i, k0 + lk, rowsB, g.K);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int m = lrow + NT / 4 * i;
+      As[buf][lk + 0][m] = ra[i].x; As[buf][lk + 1][m] = ra[i].y; As[buf][lk + 2][m] = ra[i].z; As[buf][lk + 3][m] = ra[i].w;
+      Bs[buf][lk + 0][m] = rb[i].x; Bs[buf][lk + 1][m] = rb[i].y; Bs[buf][lk + 2][m] = rb[i].z; Bs[buf][lk + 3][m] = rb[i].w;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      const int k = 2 * s + kk;
+      float a0 = As[buf][k][wm * 64 + l31], a1 = As[buf][k][wm * 64 + 32 + l31];
+      float b0 = Bs[buf][k][wn * 64 + l31], b1 = Bs[buf][k][wn * 64 + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int col = n0 + (wu & 1) * 64 + l31;
+    const float bv0 = g.bias[col], bv1 = g.bias[col + 32];
+    float *cb = g.C + static_cast<size_t>(m0 + (wu >> 1) * 64) * g.c_stride + n0 + (wu & 1) * 64;
+    const unsigned voff = static_cast<unsigned>(4 * kk) * g.c_stride + l31;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *cp = cb + static_cast<size_t>(i * 32 + (r & 3) + 8 * (r >> 2)) * g.c_stride;
+        cp[voff] = acc[i][0][r] + bv0;
+        cp[voff + 32] = acc[i][1][r] + bv1;
+      }
+    continue;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row >= g.M) continue;
+        g.C[static_cast<size_t>(row) * g.c_stride + col] = acc[i][j][r] + bv;
+      }
+    }
+  }
+}
+
+
 // ---- [row][16 k] image, b128 operand reads.  WM x WN waves, each TM x TN MFMA tiles of 32 x 32.
 template <int WM, int WN, int TM, int TN, int OCC, bool PRIO>
 __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
@@ -332,6 +451,13 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
     }
 }
 
+void LaunchPersist(GemmArgs g) {
+  g.tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.N + 127) / 128;
+  int zero = 0;
+  CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tile_counter), &zero, sizeof(int), 0, hipMemcpyHostToDevice, 0));
+  hipLaunchKernelGGL(GemmPersist, dim3(1024), dim3(256), 0, 0, g);
+}
 void LaunchBase(GemmArgs g) {
   g.tiles_m = (g.M + 127) / 128;
   g.tiles_n = (g.N + 127) / 128;
@@ -358,6 +484,7 @@ int main(int argc, char **argv) {
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
   const Var vars[] = {
       {"production tiling 128x128 [k][row]", LaunchBase},
+      {"the same, 1024 persistent workgroups + tile counter", LaunchPersist},
       {"b128 128x128, 2x2 waves of 2x2, occ 4, prio", LaunchV<2, 2, 2, 2, 4, true>},
       {"b128 128x128, 2x2 waves of 2x2, occ 4", LaunchV<2, 2, 2, 2, 4, false>},
       {"b128 128x128, 2x2 waves of 2x2, occ 3", LaunchV<2, 2, 2, 2, 3, true>},
