@@ -1772,9 +1772,14 @@ __device__ void ClearHash(const Utt &u, int fb, int fe, Blk &sh) {
 // consecutive token indices from one scan (a deterministic order), the tokens are written
 // with plain stores and a second sweep gives the part's links their token index.  Only the
 // tokens the epsilon closure may look up (kEpsDst states) also enter the global hash.
+// kLocal + fuse_ord (reference order): phase (D) also gives every new token its INSERTION KEY - the smallest ordinal among
+// its candidates (x_ord, from the acceptance sweep) - and the caller's id of its state (x_csid): the token's table value
+// holds (smallest ordinal so far << 13 | the token's index within the part) from (C) on, a candidate folds its ordinal in
+// with one LDS minimum, the first one to arrive stores the state id, and a sweep over the table's slots writes the keys out
+// in token order.  (Until round 5 a separate sweep over the candidates did this after pass 2: 8 % of the kernel.)
 template <bool kLocal>
 __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok_limit, int link_frame_b, int link_frame_e,
-                                          float next_cutoff, int n_acc_known = 0) {
+                                          float next_cutoff, int n_acc_known = 0, bool fuse_ord = false) {
   static_assert(kLdsSlots % NT == 0, "slots per lane");
   // the pass's own copies of the pointers it uses (see ProcessEmitting) - in the reference-order kernel only:
   // same-box A/B, canonical kernel 691 ms with them / 676 ms without, reference-order kernel 2208 / 2246 ms
@@ -1956,7 +1961,8 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
 #else
       e_extra[idx] = 0.0f;  // "tokens on the currently final frame have zero extra_cost" :241
 #endif
-      vals[i] = static_cast<uint32_t>(idx);
+      if (kLocal && fuse_ord) vals[i] = (0x7FFFFu << 13) | static_cast<uint32_t>(off[j]);
+      else vals[i] = static_cast<uint32_t>(idx);
       // these tokens are the closure's first work list (every one has a finite cost)
       if ((ns & kHasEps) != 0) {
         const int je = __hip_atomic_fetch_add(&sh->eps_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2012,7 +2018,15 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         const uint32_t step = ((h >> 9) | 1u) << kLocBits;
 #pragma nounroll
         while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
-        nsv[j] = static_cast<int32_t>(vals[slot]);
+        if (kLocal && fuse_ord) {
+          const uint32_t ord = static_cast<uint32_t>(UX(x_ord)[l - link_frame_b]);
+          const uint32_t lidx = vals[slot] & 8191u;
+          const uint32_t old = __hip_atomic_fetch_min(&vals[slot], (ord << 13) | lidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          nsv[j] = tok_base + static_cast<int32_t>(lidx);
+          if ((old >> 13) == 0x7FFFFu) UX(x_bkt)[nsv[j] - nb] = UX(x_csid)[l - link_frame_b];   // (the first candidate of the token to get here)
+        } else {
+          nsv[j] = static_cast<int32_t>(vals[slot]);
+        }
         wrote = true;
         if (!full) e_dst[l] = nsv[j];
       }
@@ -2031,6 +2045,16 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       }
     }
     KhSync();
+    if (kLocal && fuse_ord) {   // the part's insertion keys, in token order
+#pragma unroll
+      for (int j = 0; j < kLdsSlots / NT; j++) {
+        const int i = threadIdx.x + j * NT;
+        if (keys[i] == 0u) continue;
+        const uint32_t v = vals[i];
+        UX(x_q)[tok_base + static_cast<int>(v & 8191u) - nb] = v >> 13;
+      }
+      KhSync();
+    }
   }
   return true;
 }
@@ -3785,7 +3809,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   // without looking (it is under every earlier value); the others - under one in a hundred - walk the list.
 #ifndef KH_X_NO_MID_TIER
   constexpr int kMidBits = 2 * kLdsSlots / 32, kMidBitBase = kLdsSlots - kMidBits;
-  const bool mid_scan = !lds_scan && n <= 2 * kLdsSlots && x_ll_cols <= kMidBitBase && p.max_emit < 65536;
+  const bool mid_scan = !lds_scan && n <= 2 * kLdsSlots && x_ll_cols <= kMidBitBase && p.max_emit < 65536 && p.exact_order == 1;
 #else
   constexpr int kMidBits = 0, kMidBitBase = 0;
   const bool mid_scan = false;
@@ -4206,11 +4230,17 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   Stamp(u, sh, 1);
   // ---- pass 2: FindOrAddToken + minimum cost in the LDS token table, as in the canonical sweep (every live candidate
   // has been accepted: no cutoff test)
-  if (!EmitPass2<true>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf, n_acc)) return false;
+  // (the insertion keys inside pass 2 when the ordinals fit its 19 bits - every frame of the benchmark; else the sweep below)
+#ifndef KH_X_NO_FUSED_KEYS
+  const bool fuse_ord = run_sum <= 0x7FFFF && p.exact_order == 1;   // (exact_order 2, KH_DECODER_ORDER_SORT: round 4's constructions throughout - the tests)
+#else
+  const bool fuse_ord = false;
+#endif
+  if (!EmitPass2<true>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, inf, n_acc, fuse_ord)) return false;
   XS(63);
   // ---- the insertion key of a new token = the smallest ordinal among its candidates (the arc that made the reference
   // call HashList::Insert for it); its cost before the closure
-  {
+  if (!fuse_ord) {
     const int n_new = Uni(sh->tok_end) - nb;
     auto qtab = LdsKeys(sh);
     const bool in_lds = n_new <= kLdsSlots;
