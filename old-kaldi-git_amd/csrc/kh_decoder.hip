@@ -7948,7 +7948,17 @@ int kh_decoder_prepare(KhDecoder *d, int num_threads) {
   KH_CHECK_ARG(d);
   const int n = d->n_utts;
   if (n <= 0) return KH_OK;
-  int nt = num_threads > 0 ? num_threads : static_cast<int>(std::thread::hardware_concurrency());
+  // (0: the CPUs the container may use - never the 256 visible cores of a box whose cgroup grants 16: beyond the quota the
+  // kernel throttles the whole group, the thread that launches the next forward pass included - shared by the node's ranks)
+  int nt = num_threads;
+  if (nt <= 0) {
+    nt = std::min(64, HostCpuQuota());
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) {
+      const int ranks = atoi(e);
+      if (ranks > 1) nt = std::max(2, nt / ranks);
+    }
+    if (const char *e = getenv("KH_DECODER_HOST_THREADS")) nt = std::max(1, atoi(e));
+  }
   nt = std::max(1, std::min(std::min(nt, 128), n));
   // every lattice not built yet gets its slice of the batch store
   {
