@@ -16,11 +16,12 @@ feats, off = bench.build_utterances(3456, 0, 2620, net, g, protos, False)
 nnet = api.Nnet(net, priors)
 x = torch.from_numpy(feats).cuda()
 ll = torch.empty((int(off[-1]), net[-1]["output_dim"]), dtype=torch.float32, device="cuda")
-ts = []
-for rep in range(5):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    bench.forward_all(nnet, x, off, ll, 60000)
-    api.synchronize()
-    ts.append((time.perf_counter() - t0) * 1e3)
-print("forward pass: %s ms; checksum %.10f" % (" ".join("%.1f" % t for t in ts), float(ll.double().sum().item() / ll.numel())))
+for max_rows in [int(v) for v in (sys.argv[1:] or ["60000"])]:
+    ts = []
+    for rep in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bench.forward_all(nnet, x, off, ll, max_rows)
+        api.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print("forward pass in groups of <= %d rows: %s ms; checksum %.10f" % (max_rows, " ".join("%.1f" % t for t in ts), float(ll.double().sum().item() / ll.numel())))
