@@ -1552,12 +1552,25 @@ def _read_compact_lattice(h):
         return out
 
 
+def host_cpus():
+    """CPUs this process may use: the affinity mask, capped by the cgroup's CPU quota (cpu.max; a container that sees 256
+    cores and is granted 16 runs 16 threads well and 256 badly - beyond the quota the kernel throttles the whole group)."""
+    import os as _os
+    n = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def determinize_lattices(lats, beam, delta=2.0 ** -10, max_mem=50000000, num_threads=0, **kw):
     """determinize_lattice_pruned for a batch on host threads (the library call releases the
     GIL; utterances are independent, as the reference's $nj jobs / TaskSequencer threads)."""
     import concurrent.futures
-    import os as _os
-    nt = num_threads if num_threads > 0 else min(len(lats), len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else 8)
+    nt = num_threads if num_threads > 0 else min(len(lats), host_cpus())
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, nt)) as ex:
         return list(ex.map(lambda L: determinize_lattice_pruned(L, beam, delta, max_mem, **kw), lats))
 
