@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (config 2 / 5) legs")
     ap.add_argument("--secondary-timeout", type=int, default=300,
                     help="seconds the secondary legs may take before the line is printed without the one that hangs")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the unpipelined and the reference-order repeats of the step")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the unpipelined and the canonical-rule repeats of the step")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the value_end_to_end leg (the same steps with determinization timed)")
     ap.add_argument("--no-gpu-dryrun", action="store_true",
                     help="launcher / sharding / reduction only (gloo, no GPU, nothing decoded): CPU test of the multi-rank path")
@@ -206,7 +206,7 @@ def _cpu_secondary(binding, fwd):
     g5 = workloads.make_hclg_structured(rng, 60_000, P)
     seqs = workloads.sample_paths(rng, g5, [T] * N)
     dec = binding.DecoderOracle(g5, binding.decoder_config(beam=13.0, max_active=7000, min_active=200, lattice_beam=8.0),
-                                mode="canonical")
+                                mode="reference")
     csrs, alis = [], []
     for q in seqs:
         ll = (rng.standard_normal((T, P)) * 0.28 - 0.37).astype(np.float32)
@@ -361,7 +361,7 @@ def finish_cpu_baseline(handle):
 
 
 # ---------------------------------------------------------------- profiles
-def measured_traffic(args, world, kernel_ms):
+def measured_traffic(args, world, kernel_ms, ref_order=True):
     """HBM bytes per DecodeKernel launch from the PMC record committed under profiles/
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, tools/collect_profiles.sh ->
     tools/pmc_record.py): counters cannot be read inside this process, so this is a RECORDED figure,
@@ -372,7 +372,8 @@ def measured_traffic(args, world, kernel_ms):
     although a read request moves a 128-byte line (MI355X guide, HBM section: "double it"): calibrated for
     THIS kernel's access shapes by tools/pmc_calibrate.hip (profiles/r02_pmc_calibration.txt) and confirmed
     on DecodeKernel itself by the request-size and DRAM-side tallies.  WRITE_SIZE is exact.
-    traffic = 2 x FETCH_SIZE + WRITE_SIZE."""
+    traffic = 2 x FETCH_SIZE + WRITE_SIZE.  The record names the search it was taken for ("search":
+    "reference-order" = DecodeKernel<.., true>, the default since round 6); a record of the other kernel is not quoted."""
     if args.small or args.utts != 2620 or args.graph_states != 10_000_000 or world != 1:
         return None, "not the recorded workload"
     import glob
@@ -390,6 +391,9 @@ def measured_traffic(args, world, kernel_ms):
         if rec.get("kernel_src_sha16") != sha:
             return None, "%s was recorded for another build of the kernel (source hash %s, running %s): not quoted" % (
                 name, rec.get("kernel_src_sha16"), sha)
+        want = "reference-order" if ref_order else "canonical"
+        if rec.get("search", "canonical") != want:     # (records of rounds 2-5 carry no "search": they are the canonical kernel's)
+            return None, "%s was recorded for the %s search, this run timed the %s one: not quoted" % (name, rec.get("search", "canonical"), want)
         ref_ms = float(rec["kernel_trace_avg_ms"])
         if not (abs(kernel_ms - ref_ms) <= 0.05 * ref_ms):
             return None, "%s: recorded kernel duration %.1f ms differs from this run's %.1f ms by more than 5 %%: not quoted" % (
@@ -605,7 +609,7 @@ def main():
                 stats["host_tail_ms"] = dec.last_host_tail_ms()
                 t.append(time.perf_counter())
             stats.update(tot_like=tot_like, n_ok=n_ok, arcs=arcs, toks=toks, cand=cand, lat_arcs=lat_arcs, lat_states=lat_states,
-                         kernel_ms=dec.last_kernel_ms())
+                         kernel_ms=dec.last_kernel_ms(), ref_order=bool(dec.search_counters(-1)["reference_order"]))
             if verbose and rank == 0:
                 d = np.diff(t) * 1e3
                 print("[bench] forward %.0f ms, decode() %.0f ms (kernel %.0f), prepare %.0f ms, fetch %.0f ms"
@@ -636,7 +640,8 @@ def main():
         pipelined = pipelined and not pipe["disabled"]   # (a failed background forward pass: the rest ran one after the other)
         main_stats = dict(stats)
         # ---- the same step strictly one after the other (round-to-round comparison with the unpipelined headline of
-        # rounds 1-2), and in the reference's own iteration order (kh_decoder_set_reference_order): min(K, 3) steps each
+        # rounds 1-2), and with the opt-in order-independent acceptance rule (kh_decoder_set_reference_order(dec, 0), the
+        # headline of rounds 1-5): min(K, 3) steps each
         extra = {}
         if end_to_end and not args.no_extra_legs:
             k2 = max(1, min(steps, 3))
@@ -646,8 +651,8 @@ def main():
             sync()
             extra["unpipelined"] = dict(elapsed=time.perf_counter() - t1, steps=k2, kernel_ms=stats["kernel_ms"])
             try:
-                dec.set_reference_order(True)
-                step()        # (the slot arenas are carved again with the order's temporaries)
+                dec.set_reference_order(False)   # the opt-in order-independent rule E ("canonical"): a comparison leg
+                step()        # (the slot arenas are carved again without the order's temporaries)
                 sync()
                 t1 = time.perf_counter()
                 kms_x = []
@@ -655,13 +660,13 @@ def main():
                     step()
                     kms_x.append(stats["kernel_ms"])
                 sync()
-                extra["exact_order"] = dict(elapsed=time.perf_counter() - t1, steps=k2, kernel_ms=float(np.mean(kms_x)),
-                                            tot_like=stats["tot_like"], arcs=stats["arcs"], toks=stats["toks"], cand=stats["cand"],
-                                            lat_arcs=stats["lat_arcs"], lat_states=stats["lat_states"])
+                extra["canonical"] = dict(elapsed=time.perf_counter() - t1, steps=k2, kernel_ms=float(np.mean(kms_x)),
+                                          tot_like=stats["tot_like"], arcs=stats["arcs"], toks=stats["toks"], cand=stats["cand"],
+                                          lat_arcs=stats["lat_arcs"], lat_states=stats["lat_states"])
             except Exception as e:   # noqa: BLE001 - an extra leg never costs the headline
-                extra["exact_order"] = {"error": repr(e)}
+                extra["canonical"] = {"error": repr(e)}
             finally:
-                dec.set_reference_order(False)
+                dec.set_reference_order(True)
             step()            # back to the default arenas before the end-to-end loops
             sync()
         stats.clear()
@@ -714,7 +719,7 @@ def main():
             dec.set_after_launch(None)
         red = torch.tensor([elapsed, e2e["elapsed"] if e2e else 0.0, e2e.get("wave_elapsed", 0.0) if e2e else 0.0,
                             0.0 if pipelined else 1.0, 0.0 if (e2e and e2e["pipelined"]) else 1.0,
-                            extra.get("unpipelined", {}).get("elapsed", 0.0), extra.get("exact_order", {}).get("elapsed", 0.0)],
+                            extra.get("unpipelined", {}).get("elapsed", 0.0), extra.get("canonical", {}).get("elapsed", 0.0)],
                            dtype=torch.float64, device="cuda")
         tot = torch.tensor([float(frames), stats["tot_like"], float(stats["n_ok"])], dtype=torch.float64, device="cuda")
         kms = torch.zeros(world, dtype=torch.float64, device="cuda")
@@ -731,8 +736,8 @@ def main():
                 e2e["wave_elapsed"] = float(red[2].item())
         if "unpipelined" in extra:
             extra["unpipelined"]["elapsed"] = float(red[5].item())
-        if "exact_order" in extra and "elapsed" in extra["exact_order"]:
-            extra["exact_order"]["elapsed"] = float(red[6].item())
+        if "canonical" in extra and "elapsed" in extra["canonical"]:
+            extra["canonical"]["elapsed"] = float(red[6].item())
         return dict(elapsed=float(red[0].item()), e2e=e2e, extra=extra, pipelined=float(red[3].item()) == 0.0,
                     total_frames=float(tot[0].item()), tot_like=float(tot[1].item()),
                     n_ok=int(tot[2].item()), stats=dict(stats), kernel_ms=float(np.mean(kernel_ms)),
@@ -751,16 +756,21 @@ def main():
         tight_bytes = (st["arcs"] - st["cand"]) * 28.0 + st["cand"] * 60.0 + st["toks"] * 16.0
         k_ms = weak["kernel_ms"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(args, world, k_ms)
+        ref_order = bool(st.get("ref_order", True))
+        search = "reference-order" if ref_order else "canonical-rule-E"
+        traffic, traffic_src = measured_traffic(args, world, k_ms, ref_order)
         out = {
             # BASELINE.json's metric; value = frames/s of nnet2 forward + LatticeFasterDecoder, "rtf" = the
-            # real-time factor per GPU (10 ms frames: rtf = 100 / frames-per-second-per-GPU)
+            # real-time factor per GPU (10 ms frames: rtf = 100 / frames-per-second-per-GPU).  Since round 6 the decoder
+            # of `value` is the library's default: the reference's OWN iteration order (bit-exact against the line-by-line
+            # oracle of LatticeFasterDecoder, tests/test_gpu_exact_order.py); `search` says which one was timed
             "metric": "frames/sec decoded + real-time factor, LibriSpeech nnet2 decode @1/2/4/8 MI355X",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": weak["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "search": search,
             "rtf": weak["elapsed"] * 100.0 / (weak["total_frames"] * args.steps) * world,
             "config": {"workload": "librispeech_nnet_a_structured" + ("_small" if args.small else ""),
+                       "search": search,
                        "utts_per_gpu": weak["n_utts"], "frames_per_gpu": weak["frames"], "graph_states": int(g["num_states"]),
                        "graph_arcs": int(g["arc_offsets"][-1]), "graph": "HCLG-structured (prefix trees x 3-state HMM chains, "
                        "pushed LM costs, back-off epsilons); %d words, %d LM states" % (g["num_words"], g["num_hubs"]),
@@ -768,21 +778,22 @@ def main():
                        "decoder": DECODE_CFG, "acwt": ACWT, "parallelism": "utterance-shard x%d" % world,
                        "rccl_world_size": world, "workload_build_s": t_build,
                        "steps_pipelined": bool(weak["pipelined"]),
-                       "step": "forward pass + decode + best paths and lattice sizes of the whole shard; K steps run as a binary's "
+                       "step": "forward pass + decode (%s) + best paths and lattice sizes of the whole shard, K steps pipelined" % search,
+                       "step_detail": "K steps run as a binary's "
                                "main loop would: when step i's decode kernel has finished, a second host thread starts step "
                                "i + 1's forward pass (kh_decoder_set_after_launch) while the host finishes step i (lattices, best "
                                "paths) - K forward passes and K decodes inside the timed region; steps_pipelined = false "
                                "(KH_BENCH_NO_PIPELINE=1, or a background pass failed on some rank): strictly one after the other; "
-                               "value_unpipelined is that figure in every run.  `value` decodes with the ORDER-INDEPENDENT "
-                               "acceptance rule E (an arc is accepted against the frame's final next_cutoff; bit-exact against oracle "
-                               "mode 3); the search that is bit-exact to LatticeFasterDecoder's own iteration order (oracle mode 0) is "
-                               "roofline.reference_order / value_exact_order"},
-            "search": {"arcs_expanded_per_frame": st["arcs"] / weak["frames"], "tokens_per_frame": st["toks"] / weak["frames"],
-                       "lattice_arcs_per_frame": st["lat_arcs"] / weak["frames"],
-                       "lattice_states_per_frame": st["lat_states"] / weak["frames"]},
+                               "value_unpipelined is that figure in every run.  search = reference-order: LatticeFasterDecoder's own "
+                               "iteration order (HashList order, running next_cutoff; bit-exact against oracle mode 0), the library's "
+                               "default; value_canonical / roofline.canonical_* = the opt-in order-independent rule E (oracle mode 3)"},
+            "search_stats": {"arcs_expanded_per_frame": st["arcs"] / weak["frames"], "tokens_per_frame": st["toks"] / weak["frames"],
+                             "lattice_arcs_per_frame": st["lat_arcs"] / weak["frames"],
+                             "lattice_states_per_frame": st["lat_states"] / weak["frames"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "DecodeKernel", "kernel_ms": k_ms,
+                         "kernel": "DecodeKernel<reference order>" if ref_order else "DecodeKernel<canonical>", "kernel_ms": k_ms,
+                         "search": search,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "arcs_expanded_per_launch": st["arcs"], "tokens_created_per_launch": st["toks"],
                          # the same kernel against a TIGHT byte count: an arc that is read and rejected costs its 16-byte
@@ -800,35 +811,30 @@ def main():
         if "unpipelined" in ex:
             u_ = ex["unpipelined"]
             out["value_unpipelined"] = weak["total_frames"] * u_["steps"] / u_["elapsed"]
-        if "exact_order" in ex:
-            x_ = ex["exact_order"]
+        if "canonical" in ex:
+            x_ = ex["canonical"]
             if "error" in x_:
-                out["exact_order"] = x_
+                out["canonical"] = x_
             else:
-                # the same step with the decoder in the reference's OWN iteration order (running next_cutoff in HashList
-                # order, first-minimum ties, LIFO closure insertions): bit-exact against the line-by-line oracle
-                # (tests/test_gpu_exact_order.py); measured one step after the other, to be held against value_unpipelined
-                out["value_exact_order"] = weak["total_frames"] * x_["steps"] / x_["elapsed"]
-                # ... and inside `roofline`, where the driver's record keeps it: the SAME accounting for the kernel that is
-                # bit-exact to the reference (its own arcs / tokens / candidates, its own kernel time)
+                # the same step with the opt-in order-independent acceptance rule E (kh_decoder_set_reference_order(dec, 0);
+                # the headline of rounds 1-5; bit-exact against oracle mode 3, NOT the reference's lattices in general);
+                # measured one step after the other, to be held against value_unpipelined.  Flat scalars: the driver's
+                # record keeps neither nested dictionaries nor long strings
+                out["value_canonical"] = weak["total_frames"] * x_["steps"] / x_["elapsed"]
                 x_alg = 60.0 * x_["arcs"] + 16.0 * x_["toks"]
                 x_tight = 28.0 * (x_["arcs"] - x_["cand"]) + 60.0 * x_["cand"] + 16.0 * x_["toks"]
-                out["roofline"]["reference_order"] = {
-                    "kernel": "DecodeKernel<reference order>", "kernel_ms": x_["kernel_ms"],
-                    "achieved": x_alg / (x_["kernel_ms"] * 1e-3) / 1e9, "frac": x_alg / (x_["kernel_ms"] * 1e-3) / 1e9 / 8000.0,
-                    "frac_tight": x_tight / (x_["kernel_ms"] * 1e-3) / 1e9 / 8000.0,
-                    "kernel_ms_over_canonical": x_["kernel_ms"] / k_ms,
-                    "value": out["value_exact_order"], "unit": "frames/s (one step after the other: forward + decode + best paths)"}
-                out["exact_order"] = {
+                out["roofline"]["canonical_kernel_ms"] = x_["kernel_ms"]
+                out["roofline"]["canonical_frac"] = x_alg / (x_["kernel_ms"] * 1e-3) / 1e9 / 8000.0
+                out["roofline"]["canonical_frac_tight"] = x_tight / (x_["kernel_ms"] * 1e-3) / 1e9 / 8000.0
+                out["roofline"]["kernel_ms_over_canonical"] = k_ms / x_["kernel_ms"]
+                out["canonical"] = {
                     "unit": "frames/s", "steps": x_["steps"], "ms_per_step": x_["elapsed"] / x_["steps"] * 1e3,
-                    "kernel_ms": x_["kernel_ms"], "kernel_ms_canonical": k_ms,
-                    "kernel_cost_vs_canonical": x_["kernel_ms"] / k_ms - 1.0,
+                    "kernel_ms": x_["kernel_ms"],
                     "arcs_expanded_per_frame": x_["arcs"] / weak["frames"], "tokens_per_frame": x_["toks"] / weak["frames"],
                     "candidates_materialised_per_frame": x_["cand"] / weak["frames"],
                     "lattice_arcs_per_frame": x_["lat_arcs"] / weak["frames"],
                     "loglike_per_frame": x_["tot_like"] / weak["frames"],
-                    "note": "kh_decoder_set_reference_order(1): what LatticeFasterDecoder itself computes; the default "
-                            "(order-independent) rule is kept for the headline because it is cheaper"}
+                    "note": "kh_decoder_set_reference_order(dec, 0): the order-independent rule, an opt-in since round 6"}
         if weak["e2e"] is not None:
             e = weak["e2e"]
             # DecodeUtteranceLatticeFaster in full: what the reference binary's timer brackets per utterance

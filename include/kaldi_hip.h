@@ -344,15 +344,16 @@ int kh_decoder_get_counters(const KhDecoder *dec, int utt, KhDecodeStats *stats)
  * next visit through memory.  All zero under KH_DECODER_PRUNE_SCHEDULE=interval (PruneActiveTokens every
  * prune_interval frames, lattice-faster-decoder.cc:88-89); the lattice is the same either way. */
 int kh_decoder_get_schedule_counters(const KhDecoder *dec, int utt, int32_t *counters);
-/* enable != 0: kh_decoder_decode reproduces the reference's own ITERATION ORDER, so that tokens and forward links are the
- * ones LatticeFasterDecoder itself creates: ProcessEmitting prunes against the running next_cutoff
+/* enable != 0 (THE DEFAULT since round 6): kh_decoder_decode reproduces the reference's own ITERATION ORDER, so that tokens and
+ * forward links are the ones LatticeFasterDecoder itself creates: ProcessEmitting prunes against the running next_cutoff
  * (lattice-faster-decoder.cc:728-733) with the tokens in HashList order (util/hash-list-inl.h:118-147: buckets
  * state % hash_size in order of first occupation, insertion order inside a bucket; hash_size as :37, :219-225), the best
  * token of GetCutoff is the first minimum in that order (:599, :611), and the epsilon closure inserts in the order of its
  * LIFO queue (:766-811).  Each utterance is decoded as by a freshly constructed decoder (hash_size 1000 at its start).
- * enable == 0 (default): the order-independent resolution of those three places (DESIGN.md "Decoder parity": accept against
- * the FINAL next_cutoff, ties to the smallest state id), which is what the reference computes whenever no token lies
- * between the final and the running cutoff.  The environment variable KH_DECODER_ORDER=reference|canonical overrides. */
+ * enable == 0 (opt-in, "canonical"): the order-independent resolution of those three places (DESIGN.md "Decoder parity":
+ * accept against the FINAL next_cutoff, ties to the smallest state id), which is what the reference computes whenever no
+ * token lies between the final and the running cutoff - a cheaper kernel, NOT the reference's lattices in general.
+ * The environment variable KH_DECODER_ORDER=reference|canonical overrides both. */
 int kh_decoder_set_reference_order(KhDecoder *dec, int enable);
 /* Search counters of utterance `utt` (-1: summed over the batch) in the last kh_decoder_decode call (measurement aid): counters[0] = emitting
  * candidates that were materialised (given a link slot: the rest of arcs_expanded were read and rejected),
@@ -473,7 +474,8 @@ int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *dec, int enable);
  * the launch-per-job calls (kh_online_decoder_init_decoding / _advance / _finalize) and the persistent serving kernel
  * (kh_online_decoder_serve_*, started afterwards) reproduce it: chunked decoding, the offline kernel in reference order and
  * the line-by-line oracle (mode 0) give the same lattices bit for bit.  Between utterances only (KH_ESTATE while a stream is
- * in a decoding run or the serving kernel is running).  KH_DECODER_ORDER=reference in the environment sets it at creation. */
+ * in a decoding run or the serving kernel is running).  On by default (as kh_decoder_set_reference_order); KH_DECODER_ORDER=
+ * reference|canonical in the environment overrides at creation. */
 int kh_online_decoder_set_reference_order(KhOnlineDecoder *dec, int enable);
 /* The same three calls without a kernel launch per chunk: a PERSISTENT serving kernel, one resident workgroup per stream
  * (num_streams <= 2 x the CU count), which waits on a control block in pinned host memory (online2-wav-nnet2-latgen-faster's

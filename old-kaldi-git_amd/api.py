@@ -750,7 +750,7 @@ class LatticeFasterDecoder:
     DecodableMatrixScaledMapped-style decodable (decoder/decodable-matrix.h:33-84):
     loglikes[t, tid2pdf[ilabel]] already scaled."""
 
-    def __init__(self, fst, config=None, max_batch=256, max_frames=4096, exact_reference_order=False):
+    def __init__(self, fst, config=None, max_batch=256, max_frames=4096, exact_reference_order=True):
         self.fst = fst
         cfg = decoder_config() if config is None else config
         self.cfg = KhDecoderConfig(**cfg)
@@ -759,13 +759,14 @@ class LatticeFasterDecoder:
             raise KhError(lib().kh_last_error().decode())
         self._h = C.c_void_p(h)
         self.n_utts = 0
-        if exact_reference_order:
-            self.set_reference_order(True)
+        if not exact_reference_order:      # (the library's default is the reference's order)
+            self.set_reference_order(False)
 
     def set_reference_order(self, enable):
         """True: the reference's own iteration order (running next_cutoff in HashList order, first-minimum ties, LIFO
         closure insertions: include/kaldi_hip.h kh_decoder_set_reference_order) - tokens and links are the ones
-        LatticeFasterDecoder itself creates.  False (default): the order-independent rule."""
+        LatticeFasterDecoder itself creates; the default.  False: the order-independent ("canonical") rule, a cheaper
+        kernel whose lattices are the reference's only where no token lies between the final and the running cutoff."""
         check(lib().kh_decoder_set_reference_order(self._h, int(bool(enable))))
 
     def search_counters(self, utt=0):
@@ -938,7 +939,7 @@ class LatticeFasterOnlineDecoder:
     log-likelihood chunks are what DecodableNnet2Online would serve for the next
     frames (rows [t, t + n) of the utterance's matrix)."""
 
-    def __init__(self, fst, config=None, num_streams=1, max_frames=4096, exact_reference_order=False):
+    def __init__(self, fst, config=None, num_streams=1, max_frames=4096, exact_reference_order=True):
         self.fst = fst
         cfg = decoder_config() if config is None else config
         self.cfg = KhDecoderConfig(**cfg)
@@ -947,8 +948,8 @@ class LatticeFasterOnlineDecoder:
         if not h:
             raise KhError(lib().kh_last_error().decode())
         self._h = C.c_void_p(h)
-        if exact_reference_order:
-            self.set_reference_order(True)
+        if not exact_reference_order:      # (the library's default is the reference's order)
+            self.set_reference_order(False)
 
     def __del__(self):
         try:
@@ -991,8 +992,9 @@ class LatticeFasterOnlineDecoder:
 
     def set_reference_order(self, enable=True):
         """The reference's own iteration order for the streams (kh_online_decoder_set_reference_order;
-        lattice-faster-online-decoder.cc:864-951): the lattices LatticeFasterOnlineDecoder itself would build.  Every
-        stream must be idle; the persistent serving kernel does not run in this mode."""
+        lattice-faster-online-decoder.cc:864-951): the lattices LatticeFasterOnlineDecoder itself would build; the default.
+        Every stream must be idle and the persistent serving kernel stopped while switching; a serving kernel started
+        afterwards decodes in the same order (ServeKernel<kExact>)."""
         check(lib().kh_online_decoder_set_reference_order(self._h, int(bool(enable))))
 
     def num_frames_decoded(self, stream=0):

@@ -5967,8 +5967,28 @@ enum { kCmdInit = 1, kCmdFinalize = 2, kCmdInitCleared = 3 };
 
 template <class T>
 __device__ __forceinline__ int32_t SysLoad(T p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// ... and the polling side: the four words of a poll are fetched with relaxed loads (in flight together: one round trip to
+// the host's memory instead of four, and no cache invalidation per word), followed by ONE acquire fence only when the poll
+// found something to do (the scores the host published are read after it).
+template <class T>
+__device__ __forceinline__ int32_t SysLoadRelaxed(T p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// The host -> device words of a control block {avail, cmd_seq, cmd_op, pad} as ONE 16-byte read at system scope: one read
+// request = one snapshot of the host's cache line, so a new cmd_seq is never seen with the operation or frame count of an
+// earlier command (the host stores avail, cmd_op, cmd_seq in that order; separate relaxed reads may be reordered on the bus).
+typedef int KhI4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ KhI4 SysLoad16(const void *p) {
+  KhI4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 template <class T>
 __device__ __forceinline__ void SysStore(T p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// A store to the host's control block that orders nothing: diagnostics and fields the host reads only after the one
+// RELEASE store that ends an action.  A system-scope release is a write-back of the XCD's whole L2 (buffer_wbl2 sc0 sc1) -
+// with 32 streams decoding per XCD that is everybody's dirty lines; round 5 had grown from three to ten of them per chunk
+// (the heart-beat fields), round 6 issues exactly one.
+template <class T>
+__device__ __forceinline__ void SysStoreRelaxed(T p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // kExact: the streams decode in the reference's own iteration order (OnlineKernel<true>'s routines; the slots' temporaries in slotsx).
 template <bool kExact>
@@ -6019,10 +6039,9 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   for (;;) {
     if (threadIdx.x == 0) {
       int act = 0, arg = 0;
-      const int q = SysLoad(quit);
-      const int seq = SysLoad(&c->cmd_seq);
-      const int op = SysLoad(&c->cmd_op);
-      const int av = SysLoad(&c->avail);
+      const KhI4 w = SysLoad16(c);      // {avail, cmd_seq, cmd_op, pad0}
+      const int av = w.x, seq = w.y, op = w.z;
+      const int q = SysLoadRelaxed(quit);
       if (seq != acked && (op == kCmdInit || op == kCmdInitCleared)) { act = 1; arg = op == kCmdInitCleared ? 1 : 0; }
       else if (!fin && ok && av > run.t) { act = 2; arg = av; }
       else if (seq != acked && op == kCmdFinalize) act = 3;
@@ -6041,13 +6060,14 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
           if (all_idle) SysStore(quit, 2);
         }
       }
+      if (act != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: what the host wrote before it published
       sh->bcast_i[0] = act;
       sh->bcast_i[1] = arg;
       sh->bcast_i[2] = seq;
       if (act != 0 && act != 4) {
-        SysStore(&c->hb_arg, arg);
-        SysStore(&c->hb_clock, static_cast<int32_t>(wall_clock64()));
-        SysStore(&c->hb_phase, act);
+        SysStoreRelaxed(&c->hb_arg, arg);
+        SysStoreRelaxed(&c->hb_clock, static_cast<int32_t>(wall_clock64()));
+        SysStoreRelaxed(&c->hb_phase, act);
       }
     }
     KhSync();
@@ -6091,13 +6111,19 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
     t_idle = wall_clock64();
     if (threadIdx.x == 0) {
       __hip_atomic_store(&act_clock[s], t_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      SysStore(&c->ok, ok ? 1 : 0);
-      SysStore(&c->decoded, run.t);
-      SysStore(&c->hw, sh->tok_hw);
-      SysStore(&c->hb_actions, n_actions);
-      SysStore(&c->hb_clock, static_cast<int32_t>(t_idle));
-      SysStore(&c->hb_phase, 0);
-      if (act != 2) SysStore(&c->ack_seq, seq);
+      // (the __threadfence + barrier above have put the slot's arenas and SlotState in memory: of the stores below only the
+      // LAST one - what the host waits for - needs to order the others)
+      SysStoreRelaxed(&c->ok, ok ? 1 : 0);
+      SysStoreRelaxed(&c->hw, sh->tok_hw);
+      SysStoreRelaxed(&c->hb_actions, n_actions);
+      SysStoreRelaxed(&c->hb_clock, static_cast<int32_t>(t_idle));
+      SysStoreRelaxed(&c->hb_phase, 0);
+      if (act != 2) {
+        SysStoreRelaxed(&c->decoded, run.t);
+        SysStore(&c->ack_seq, seq);
+      } else {
+        SysStore(&c->decoded, run.t);
+      }
     }
     if (act != 2) acked = seq;
   }
@@ -6130,7 +6156,7 @@ struct KhDecoder {
   int slab_slots = 0, slab_T = 0, slab_scale = 1;
   int lazy = 0, alloc_link_a = 1;         // Params::lazy_prune / keep_ac of the calls this decoder serves (kh_decoder_decode sets them)
   int slab_lazy = 0, slab_link_a = 1;     // ... and what the slab was carved for
-  int exact = 0, slab_exact = 0;          // kh_decoder_set_reference_order; whether the slab holds the exact-order temporaries
+  int exact = 1, slab_exact = 0;          // kh_decoder_set_reference_order (default since round 6: the reference's own order); whether the slab holds the exact-order temporaries
   int rec_order_ids = -1;            // what the second word of the arcs in `rec` holds: 0 output labels, 1 state ids (ArcPdfKernel), -1 not built
   std::vector<Utt> h_slots;
   Utt *d_slots = nullptr;
@@ -8015,7 +8041,8 @@ KhOnlineDecoder *kh_online_decoder_create(const KhFst *fst, const KhDecoderConfi
                                           int max_frames) {
   KhDecoder *b = kh_decoder_create(fst, cfg, num_streams, max_frames);
   if (!b) return nullptr;
-  if (const char *e = getenv("KH_DECODER_ORDER")) b->exact = strcmp(e, "reference") == 0;   // (as kh_decoder_decode reads it)
+  if (const char *e = getenv("KH_DECODER_ORDER"))   // (as kh_decoder_decode reads it)
+    b->exact = strcmp(e, "reference") == 0 ? 1 : (strcmp(e, "canonical") == 0 ? 0 : b->exact);
   KhOnlineDecoder *o = new KhOnlineDecoder();
   o->base = b;
   o->num_streams = num_streams;
@@ -8402,6 +8429,13 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   }
   p.rec = (GP(const KhInt4))b->rec;
   KH_HIP(hipStreamSynchronize(st));   // whatever launch-per-job work is queued has written its SlotStates
+  // no serving kernel is running here: what the PREVIOUS grid left in the residency fields (alive 0, phase 9 = "has left")
+  // must not be read as the new grid's before its workgroups have started - kh_online_decoder_serve_poll would take the
+  // freshly launched grid for one that lost a workgroup, tell it to quit and launch it a second time
+  for (int s = 0; s < o->num_streams; s++) {
+    __atomic_store_n(&o->serve_ctl[s].alive, 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&o->serve_ctl[s].hb_phase, 0, __ATOMIC_RELAXED);
+  }
   __atomic_store_n(o->serve_quit, 0, __ATOMIC_RELEASE);
   void *ctl_dev = nullptr, *quit_dev = nullptr;
   KH_HIP(hipHostGetDevicePointer(&ctl_dev, o->serve_ctl, 0));
@@ -8409,13 +8443,28 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   long long idle_ticks = 200000000ll;   // 2 s of the 100 MHz wall clock
   if (const char *e = getenv("KH_SERVE_IDLE_MS")) idle_ticks = std::max(1ll, static_cast<long long>(atof(e) * 1e5));
   p.exact_order = b->exact ? 1 : 0;
+  // One resident workgroup per CU while the streams fit that way.  A CU takes two of these workgroups (64 VGPRs, 73 KB of
+  // LDS each) and nothing tells the dispatcher to spread 256 of them over 256 CUs: when it doubled up on ONE CU (the CUs
+  // it finds busy at launch time - a fill kernel, a forward pass - get none, others get two), those two streams ran at
+  // half speed for the kernel's lifetime and, the host waiting for every stream per chunk, so did the service: round 5's
+  // two regimes (350 k / 200 k frames/s, chunk p50 4.7 / 9 ms, chosen per launch).  LDS is the lever: a workgroup that
+  // asks for more than half of the CU's 160 KB cannot get a neighbour.  KH_SERVE_SHARE_CU=1: the round-5 launch.
+  size_t dyn_lds = DynLdsBytes(p.ll_cols);
+  if (o->num_streams <= NumCUs() && !(getenv("KH_SERVE_SHARE_CU") && atoi(getenv("KH_SERVE_SHARE_CU")) != 0)) {
+    hipFuncAttributes fa;
+    const void *fn = b->exact ? reinterpret_cast<const void *>(&ServeKernel<true>) : reinterpret_cast<const void *>(&ServeKernel<false>);
+    KH_HIP(hipFuncGetAttributes(&fa, fn));
+    const size_t want_total = 88 * 1024;
+    if (fa.sharedSizeBytes + dyn_lds < want_total) dyn_lds = want_total - fa.sharedSizeBytes;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn_lds));
+  }
   if (b->exact) {
     if (getenv("KH_DECODER_ORDER_SORT") != nullptr && atoi(getenv("KH_DECODER_ORDER_SORT")) != 0) p.exact_order = 2;
-    hipLaunchKernelGGL(ServeKernel<true>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
+    hipLaunchKernelGGL(ServeKernel<true>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), dyn_lds, o->serve_stream,
                        b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<int32_t *>(quit_dev), o->serve_ll,
                        o->serve_rows, o->serve_stride, p, idle_ticks, o->d_serve_act, (const UttX *)b->d_slotsx);
   } else {
-    hipLaunchKernelGGL(ServeKernel<false>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), DynLdsBytes(p.ll_cols), o->serve_stream,
+    hipLaunchKernelGGL(ServeKernel<false>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), dyn_lds, o->serve_stream,
                        b->d_slots, o->d_states, static_cast<ServeCtl *>(ctl_dev), static_cast<int32_t *>(quit_dev), o->serve_ll,
                        o->serve_rows, o->serve_stride, p, idle_ticks, o->d_serve_act, (const UttX *)nullptr);
   }
@@ -8452,6 +8501,11 @@ int kh_online_decoder_serve_start(KhOnlineDecoder *o, const float *loglikes, int
     o->serve_ctl[s].avail = o->frames[s];
     o->serve_ctl[s].decoded = o->frames[s];
     o->serve_ctl[s].ok = 1;
+    // the arena's high-water mark as the LAST serving kernel reported it is stale once launch-per-job calls have decoded
+    // on the stream in between (they raise SlotState::tok_hw, not this copy): 0 = the next InitDecoding is a plain kCmdInit,
+    // the device clears [0, its own tok_hw) and reports the mark afresh (a host-side fill of the stale range
+    // + kCmdInitCleared left finite costs behind)
+    o->serve_ctl[s].hw = 0;
   }
   o->serve_ll = loglikes;
   o->serve_stride = ll_stride;
@@ -8573,10 +8627,12 @@ int kh_online_decoder_serve_poll(KhOnlineDecoder *o, const int32_t *streams, int
     o->frames[s] = (pending && (c.cmd_op == kCmdInit || c.cmd_op == kCmdInitCleared)) ? 0 : dec;
     if (decoded) decoded[i] = o->frames[s];
     if (in_flight) in_flight[i] = pending ? 1 : 0;
-    work |= pending || (!o->finalized[s] && __atomic_load_n(&c.avail, __ATOMIC_ACQUIRE) > dec);
+    const bool has_work = pending || (!o->finalized[s] && __atomic_load_n(&c.avail, __ATOMIC_ACQUIRE) > dec);
+    work |= has_work;
     // a stream with work whose workgroup has left while the kernel is neither leaving nor gone: the protocol's invariant
     // (workgroups leave only together) is broken - stop the grid and start it again rather than wait for ever
-    lost |= work && o->serve_launched && __atomic_load_n(&c.alive, __ATOMIC_ACQUIRE) == 0 && __atomic_load_n(o->serve_quit, __ATOMIC_ACQUIRE) == 0 &&
+    // (phase 9 is written by a workgroup of THIS launch only: ServeEnsureRunning resets the field before it launches)
+    lost |= has_work && o->serve_launched && __atomic_load_n(&c.alive, __ATOMIC_ACQUIRE) == 0 && __atomic_load_n(o->serve_quit, __ATOMIC_ACQUIRE) == 0 &&
             __atomic_load_n(&c.hb_phase, __ATOMIC_ACQUIRE) == 9;
   }
   if (lost) {

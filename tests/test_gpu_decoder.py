@@ -1,8 +1,9 @@
-"""GPU parity for LatticeFasterDecoder: the HIP decoder (through the C-ABI) against
-the CPU oracle in canonical mode — bit-exact raw lattice (states keyed by
-(frame, HCLG state), sorted arcs with float-exact graph/acoustic costs) and
-best path — and against the reference-order oracle (best path; lattice where the
-order-dependence of the reference cannot show, i.e. when max_active is not binding)."""
+"""GPU parity for LatticeFasterDecoder: the HIP decoder (through the C-ABI) as it runs by default — the
+reference's own iteration order — against the line-by-line CPU oracle (mode 0): bit-exact raw lattice (states
+keyed by (frame, HCLG state), sorted arcs with float-exact graph/acoustic costs), best path and counters; and the
+opt-in order-independent rule (exact_reference_order=False) bit-exact against oracle mode 3, plus its distance
+to the reference-order result (best path; lattice where the order-dependence of the reference cannot show, i.e.
+when max_active is not binding)."""
 import importlib
 import os
 
@@ -42,43 +43,63 @@ def arc_set(L):
                    L["arc_il"].tolist(), L["arc_ol"].tolist(), L["arc_g"].tolist(), L["arc_a"].tolist()))
 
 
-def run_case(api, graph, lls, cfg, check_reference_lattice=False, check_reference_best_path=True, max_lattice_diff=0.10):
+def run_case(api, graph, lls, cfg, check_reference_lattice=False, check_reference_best_path=True, max_lattice_diff=0.10,
+             rules=("reference", "canonical")):
+    """Decodes `lls` with the DEFAULT decoder (round 6: the reference's own iteration order) and holds every lattice state,
+    arc, cost, best path and counter bit-exact to the line-by-line oracle (mode 0), then does the same with the opt-in
+    order-independent rule (exact_reference_order=False) against oracle mode 3, plus that rule's distance to the
+    reference's result.  Returns the default decoder."""
     fst = api.Fst(graph)
-    dec = api.LatticeFasterDecoder(fst, cfg, max_batch=max(1, len(lls)), max_frames=max(len(x) for x in lls))
     off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
     ll = torch.from_numpy(np.concatenate(lls, 0)).cuda()
-    dec.decode(ll, off)
-    # before any raw lattice is asked for, the best paths come straight from the exported pool (ComputeBestPathLean);
-    # the route over the canonical lattice is held to the oracle in test_gpu_structured.py (decode_and_compare asks for
-    # the raw lattice first) and to this one in its check_pool_best_paths
-    pool_bp = dec.get_best_paths()
-    for u, x in enumerate(lls):
-        oc = B.DecoderOracle(graph, cfg, "canonical")
-        assert oc.decode(x)
-        a0, a1, w0, w1 = pool_bp["ali_off"][u], pool_bp["ali_off"][u + 1], pool_bp["words_off"][u], pool_bp["words_off"][u + 1]
-        assert_same_best_path(dict(alignment=pool_bp["alignment"][a0:a1], words=pool_bp["words"][w0:w1],
-                                   graph_cost=float(pool_bp["graph_cost"][u]), acoustic_cost=float(pool_bp["acoustic_cost"][u])),
-                              oc.best_path())
-        want, got = oc.raw_lattice(), dec.get_raw_lattice(u)
-        assert_same_lattice(got, want)
-        assert_same_best_path(dec.get_best_path(u), oc.best_path())
-        so, sg = oc.stats(), dec.stats(u)
-        for k in ("num_frames", "reached_final", "num_tokens", "num_links", "tokens_created", "max_tokens_frame"):
-            assert so[k] == sg[k], (k, so[k], sg[k])
-        assert np.float32(so["final_relative_cost"]).tobytes() == np.float32(sg["final_relative_cost"]).tobytes()
+    ref_oracles = []
+    for x in lls:
         orf = B.DecoderOracle(graph, cfg, "reference")
-        assert orf.decode(x)
-        if check_reference_best_path:
-            assert_same_best_path(dec.get_best_path(u), orf.best_path())
-        # Against the reference-ORDER oracle the lattice can differ by the tokens that
-        # only the reference's running cutoff lets through (DESIGN.md "Decoder
-        # parity"); the reference's own decoder cross-check accepts 2 %
-        # (egs/rm/s5/local/test_decoders.sh, lattice-equivalent
-        # --max-error-proportion=0.02).  Here: arc-set symmetric difference.
-        ref_arcs, got_arcs = arc_set(orf.raw_lattice()), arc_set(got)
-        diff = len(ref_arcs ^ got_arcs) / max(1, len(ref_arcs))
-        assert diff <= (0.0 if check_reference_lattice else max_lattice_diff), diff
-    return dec
+        ref_oracles.append((orf, orf.decode(x)))
+    ret = None
+    for rule in rules:
+        kw = {} if rule == "reference" else dict(exact_reference_order=False)      # (no argument: the library's default)
+        dec = api.LatticeFasterDecoder(fst, cfg, max_batch=max(1, len(lls)), max_frames=max(len(x) for x in lls), **kw)
+        dec.decode(ll, off)
+        assert dec.search_counters(0)["reference_order"] == (rule == "reference")
+        # before any raw lattice is asked for, the best paths come straight from the exported pool (ComputeBestPathLean);
+        # the route over the canonical lattice is held to the oracle in test_gpu_structured.py (decode_and_compare asks for
+        # the raw lattice first) and to this one in its check_pool_best_paths
+        pool_bp = dec.get_best_paths()
+        for u, x in enumerate(lls):
+            if rule == "reference":
+                oc, ok = ref_oracles[u]
+            else:
+                oc = B.DecoderOracle(graph, cfg, "canonical")
+                ok = oc.decode(x)
+            so, sg = oc.stats(), dec.stats(u)
+            for k in ("num_frames", "reached_final", "num_tokens", "num_links", "tokens_created", "max_tokens_frame"):
+                assert so[k] == sg[k], (rule, u, k, so[k], sg[k])
+            assert np.float32(so["final_relative_cost"]).tobytes() == np.float32(sg["final_relative_cost"]).tobytes()
+            if not ok:
+                continue
+            a0, a1, w0, w1 = pool_bp["ali_off"][u], pool_bp["ali_off"][u + 1], pool_bp["words_off"][u], pool_bp["words_off"][u + 1]
+            assert_same_best_path(dict(alignment=pool_bp["alignment"][a0:a1], words=pool_bp["words"][w0:w1],
+                                       graph_cost=float(pool_bp["graph_cost"][u]), acoustic_cost=float(pool_bp["acoustic_cost"][u])),
+                                  oc.best_path())
+            want, got = oc.raw_lattice(), dec.get_raw_lattice(u)
+            assert_same_lattice(got, want)
+            assert_same_best_path(dec.get_best_path(u), oc.best_path())
+            if rule == "reference":
+                continue
+            orf = ref_oracles[u][0]
+            if check_reference_best_path:
+                assert_same_best_path(dec.get_best_path(u), orf.best_path())
+            # Against the reference-ORDER oracle the canonical rule's lattice can differ by the tokens that
+            # only the reference's running cutoff lets through (DESIGN.md "Decoder
+            # parity"); the reference's own decoder cross-check accepts 2 %
+            # (egs/rm/s5/local/test_decoders.sh, lattice-equivalent
+            # --max-error-proportion=0.02).  Here: arc-set symmetric difference.
+            ref_arcs, got_arcs = arc_set(orf.raw_lattice()), arc_set(got)
+            diff = len(ref_arcs ^ got_arcs) / max(1, len(ref_arcs))
+            assert diff <= (0.0 if check_reference_lattice else max_lattice_diff), diff
+        ret = ret or dec
+    return ret
 
 
 def test_tiny_graph_default_config(api):
@@ -163,7 +184,7 @@ def test_repeated_decodes_are_deterministic(api):
     cfg = api.decoder_config(beam=9.0, lattice_beam=6.0)
     want = []
     for x in lls:
-        oc = B.DecoderOracle(g, cfg, "canonical")
+        oc = B.DecoderOracle(g, cfg, "reference")
         assert oc.decode(x)
         want.append(oc.raw_lattice())
     fst = api.Fst(g)
@@ -417,14 +438,15 @@ def test_random_configurations(api, seed, monkeypatch):
     sane = max_active >= 800 and cfg["beam"] >= 6.0   # (beam 2: the running cutoff admits tokens that change the 1-best)
     # (the arc-set distance to the reference-ORDER lattice is not asserted here: on the tiny
     # lattices of these cases a handful of marginal arcs is a large fraction)
-    run_case(api, g, lls, cfg, check_reference_best_path=False, max_lattice_diff=10.0)
-    if sane:  # same 1-best as the reference-order search (costs to float rounding of its own cost offsets)
+    # (the default decoder - reference order - has its own fuzz over the same generator: test_gpu_exact_order.py)
+    run_case(api, g, lls, cfg, check_reference_best_path=False, max_lattice_diff=10.0, rules=("canonical",))
+    if sane:  # the canonical rule: same 1-best as the reference-order search (costs to float rounding of its own cost offsets)
         for u, x in enumerate(lls):
             orf = B.DecoderOracle(g, cfg, "reference")
             assert orf.decode(x)
             want = orf.best_path()
             fst = api.Fst(g)
-            dec = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=len(x))
+            dec = api.LatticeFasterDecoder(fst, cfg, max_batch=1, max_frames=len(x), exact_reference_order=False)
             dec.decode(torch.from_numpy(x).cuda())
             got = dec.get_best_path(0)
             c_got, c_want = got["graph_cost"] + got["acoustic_cost"], want["graph_cost"] + want["acoustic_cost"]
@@ -450,12 +472,12 @@ def test_capacity_overflow_is_retried_then_reported(api, monkeypatch):
     tiny = workloads.make_loglikes(rng, 1, 200)          # one frame: a handful of tokens
     cfg = api.decoder_config(beam=9.0, lattice_beam=6.0)
     fst = api.Fst(g)
-    oc = B.DecoderOracle(g, cfg, "canonical")
+    oc = B.DecoderOracle(g, cfg, "reference")
     assert oc.decode(x)
     want_x = oc.raw_lattice()
     need = oc.stats()["max_tokens_frame"]
     assert need > 16 * 8
-    oc1 = B.DecoderOracle(g, cfg, "canonical")
+    oc1 = B.DecoderOracle(g, cfg, "reference")
     assert oc1.decode(tiny)
     want_tiny = oc1.raw_lattice()
     # (a) first launch too small, a retry with larger arenas succeeds
@@ -553,7 +575,7 @@ def test_score_matrix_wider_than_16_bit_pdf_ids(api):
     wide[:, :60] = x
     dec = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=1, max_frames=40)
     dec.decode(torch.from_numpy(wide).cuda())
-    oc = B.DecoderOracle(g, cfg, "canonical")
+    oc = B.DecoderOracle(g, cfg, "reference")
     assert oc.decode(x)
     assert_same_lattice(dec.get_raw_lattice(0), oc.raw_lattice())
     assert_same_best_path(dec.get_best_path(0), oc.best_path())
@@ -573,7 +595,7 @@ def test_decoder_object_reused_across_batches(api):
         dec.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
         dec.prepare(2)
         for u, x in enumerate(lls):
-            oc = B.DecoderOracle(g, cfg, "canonical")
+            oc = B.DecoderOracle(g, cfg, "reference")
             assert oc.decode(x)
             assert_same_lattice(dec.get_raw_lattice(u), oc.raw_lattice())
             assert_same_best_path(dec.get_best_path(u), oc.best_path())

@@ -1,8 +1,8 @@
-"""The decoder in the reference's OWN iteration order (kh_decoder_set_reference_order): bit-exact raw lattice
+"""The decoder in the reference's OWN iteration order (kh_decoder_set_reference_order; the library's default since round 6): bit-exact raw lattice
 (every state, arc, cost), best path and counters against oracle mode 0 = the line-by-line restatement of
 LatticeFasterDecoder with its HashList order (hash-list-inl.h:118-147), running next_cutoff
 (lattice-faster-decoder.cc:728-733), first-minimum tie (:599, :611), LIFO closure (:766-811) and
-delta-tolerant prune sweeps (:296-343) — not against the order-independent rule the default mode implements.
+delta-tolerant prune sweeps (:296-343) — not against the order-independent rule of the opt-in canonical mode.
 
 Covered: the hand-picked configurations of test_gpu_decoder.py (max-active binding, min-active, tiny prune
 intervals, no final state, epsilon-heavy), random graphs / options (KH_FUZZ_SEEDS, default 100; the round's
@@ -62,7 +62,7 @@ def test_max_active_binding(api):
     cfg = api.decoder_config(beam=15.0, max_active=2000, min_active=200, lattice_beam=8.0)
     dec = run_exact(api, g, lls, cfg)
     # ... and the canonical mode really is a different search here (else this test would prove nothing)
-    can = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=3, max_frames=101)
+    can = api.LatticeFasterDecoder(api.Fst(g), cfg, max_batch=3, max_frames=101, exact_reference_order=False)
     off = np.concatenate([[0], np.cumsum([len(x) for x in lls])]).astype(np.int32)
     can.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
     assert any(can.stats(u)["tokens_created"] != dec.stats(u)["tokens_created"] for u in range(3))
@@ -302,7 +302,7 @@ def test_online_streams_in_reference_order(api):
     # max-active binds: the regime in which the reference order is a different search from the canonical rule
     cfg = api.decoder_config(beam=12.0, max_active=700, min_active=100, lattice_beam=6.0, prune_interval=10)
     dec = _online_reference_order(api, g, lls, cfg, rng)
-    can = api.LatticeFasterOnlineDecoder(api.Fst(g), cfg, num_streams=1, max_frames=211)
+    can = api.LatticeFasterOnlineDecoder(api.Fst(g), cfg, num_streams=1, max_frames=211, exact_reference_order=False)
     can.init_decoding([0])
     can.advance_decoding([0], [torch.from_numpy(lls[3]).cuda()])
     can.finalize_decoding([0])

@@ -18,7 +18,7 @@ GOLD = os.path.join(ROOT, "tests", "golden", "kaldi_io")
 
 @pytest.mark.parametrize("rule", ["canonical", "reference"])
 def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch, rule):
-    """rule = reference: --reference-order=true, the lattices of LatticeFasterDecoder's own iteration order (oracle mode 0) -
+    """rule = reference: the tool's default, the lattices of LatticeFasterDecoder's own iteration order (oracle mode 0) -
     what nnet2bin/nnet-latgen-faster.cc:139-160 itself writes; max-active binds in this test, so the two orders are
     different searches."""
     from oracle import binding
@@ -51,8 +51,8 @@ def test_nnet_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatc
             w.write(k, m)
         w.write("empty", np.zeros((0, 6), np.float32))
     det_opts = ["--beam=9", "--max-active=300", "--lattice-beam=5", "--acoustic-scale=%g" % acwt, "--allow-partial=true"]
-    if rule == "reference":
-        det_opts.append("--reference-order=true")
+    if rule == "canonical":      # (the tool's default is the reference's own order)
+        det_opts.append("--canonical-order=true")
     opts = det_opts + ["--determinize-lattice=false"]
     assert tool.main(opts + ["final.mdl", "HCLG.fst", "ark:feats.ark", "ark:lat.ark", "ark:words.ark", "ark,t:ali.txt"]) == 0
     # the binaries' default: determinized CompactLattices (binary and text)
@@ -181,7 +181,7 @@ def test_nnet_latgen_faster_with_the_recipe_command_line(api, oracle, tmp_path, 
     assert np.array_equal(tp[1:], np.ravel(np.stack([np.zeros(n_pdf, np.int32), np.arange(1, n_pdf + 1)], 1)))
     for k, x in utts.items():
         ll = oracle.decodable_am_nnet(net, priors, acwt, x)
-        oc = binding.DecoderOracle(g, cfg, "canonical")
+        oc = binding.DecoderOracle(g, cfg, "reference")
         oc.decode(ll)
         assert np.array_equal(words[k], oc.best_path()["words"])
         assert "%s %s\n" % (k, "".join("W%d " % w for w in words[k])) in err     # utt W3 W17 ... (decoder-wrappers.cc:247-256)
@@ -297,7 +297,7 @@ def test_gmm_latgen_faster_files_in_files_out(api, oracle, tmp_path, monkeypatch
     cfg = binding.decoder_config(beam=10.0, max_active=200, lattice_beam=6.0)
     for k, x in utts.items():
         ll = (oracle.am_gmm_loglikes(x, gconsts, mi, iv, am["pdf_offsets"], -1.0) * np.float32(acwt)).astype(np.float32)
-        oc = binding.DecoderOracle(g, cfg, "canonical")
+        oc = binding.DecoderOracle(g, cfg, "reference")
         oc.decode(ll)
         want, best = oc.raw_lattice(), oc.best_path()
         got = lats[k]
@@ -361,7 +361,7 @@ def test_cfg1_yesno_mono_gmm_at_its_stated_shape(api, oracle, tmp_path, monkeypa
     n_words = 0
     for k, x in utts.items():
         ll = (oracle.am_gmm_loglikes(x, gconsts, mi, iv, am["pdf_offsets"], -1.0) * np.float32(acwt)).astype(np.float32)
-        oc = binding.DecoderOracle(g, cfg, "canonical")
+        oc = binding.DecoderOracle(g, cfg, "reference")
         assert oc.decode(ll)
         best = oc.best_path()
         assert np.array_equal(words[k], best["words"]) and np.array_equal(alis[k], best["alignment"]), k
@@ -381,7 +381,7 @@ def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_pat
     """tools/online2_wav_nnet2_latgen_faster.py --online=false: wave files + the online2 configuration
     files in, CompactLattices out; checked against the chain of oracles (MFCC, iVector in the
     use_most_recent + greedy mode with the adaptation state carried from a speaker's utterance to the
-    next and LimitFrames in between, network, canonical decoder) on the same waveforms."""
+    next and LimitFrames in between, network, reference-order decoder) on the same waveforms."""
     from oracle import binding
     from oracle import ivector_oracle as IO
     from test_feature_oracle import wave
@@ -456,7 +456,7 @@ def test_online2_wav_nnet2_latgen_faster_files_in_files_out(api, oracle, tmp_pat
             different = np.abs(iv - IO.extract(m, ie)).max()
         x = np.concatenate([m, iv], 1)
         ll = oracle.decodable_am_nnet(net, priors, acwt, x)
-        oc = binding.DecoderOracle(g, cfg, "canonical")
+        oc = binding.DecoderOracle(g, cfg, "reference")
         assert oc.decode(ll)
         best = oc.best_path()
         C = clats[k]
@@ -585,7 +585,7 @@ def test_online2_wav_nnet2_latgen_faster_online_true_with_endpointing(api, oracl
             m_full = ko.mfcc_compute(w.astype(np.float32), **S["mfcc_kw"])
             iv_full, _ = IO.extract(m_full, ie, spk_state[spk], True)
             ll_full = oracle.decodable_am_nnet(S["net"], S["priors"], acwt, np.concatenate([m_full, iv_full], 1))
-            od = binding.DecoderOracle(g, cfg, "canonical")
+            od = binding.DecoderOracle(g, cfg, "reference")
             od.begin(ll_full)
             decoded, stop_at = 0, None
             for ci, o in enumerate(offs):
@@ -690,7 +690,7 @@ def test_online2_silence_weighting_of_the_ivector_statistics(api, oracle, tmp_pa
         rows = np.zeros((T, m_full.shape[1] + 2), np.float32)
         rows[:, :m_full.shape[1]] = m_full
         ll = np.zeros((T, S["n_pdf"]), np.float32)
-        od = binding.DecoderOracle(g, cfg, "canonical")
+        od = binding.DecoderOracle(g, cfg, "reference")
         od.begin(ll)
         ll = od._ll                                    # the rows the decoder reads: filled as they are computed
         decoded, filled, stop_at, base_used = 0, 0, None, T
@@ -822,7 +822,7 @@ def test_reference_named_executables_on_path_and_a_table_of_graphs(api, oracle, 
     for k, m in utts.items():
         gg = dict(graphs[k], tid2pdf=tid2pdf)
         ll = nnet_oracle.decodable_am_nnet(net, priors, acwt, m)
-        od = binding.DecoderOracle(gg, cfg, "canonical")
+        od = binding.DecoderOracle(gg, cfg, "reference")
         assert od.decode(ll)
         want = od.best_path()
         assert np.array_equal(ali[k], want["alignment"]), k

@@ -40,7 +40,7 @@ def test_decoder_lattice_end_to_end(api):
     dec.decode(torch.from_numpy(ll).cuda())
     csr = B.lattice_csr(dec.get_raw_lattice(0))
     got = api.lattice_forward_backward([csr])[0]
-    od = B.DecoderOracle(g, cfg, "canonical")
+    od = B.DecoderOracle(g, cfg, "reference")
     od.decode(ll)
     want = B.lattice_forward_backward(B.lattice_csr(od.raw_lattice()))
     assert abs(got["tot_like"] - want["tot_like"]) < 1e-8

@@ -85,7 +85,7 @@ def test_wave_to_determinized_lattice(oracle):
     dec.decode(ll, np.asarray(ll_off, np.int32))
     for u in range(2):
         x = np.ascontiguousarray(ll_h[ll_off[u]:ll_off[u + 1]])
-        oc = B.DecoderOracle(g, cfg, "canonical")
+        oc = B.DecoderOracle(g, cfg, "reference")
         assert oc.decode(x)
         raw = dec.get_raw_lattice(u)
         assert_same_lattice(raw, oc.raw_lattice())

@@ -35,23 +35,31 @@ LL_TOL = 1e-4
 
 
 def decode_and_compare(api, g, ll_dev, off, cfg, sample, max_ref_diff=0.02, max_utt_diff=0.06, max_inequivalent=0):
+    """The decoder as created (the reference's own iteration order) bit-exact against the line-by-line oracle (mode 0) on the
+    sampled utterances; then the opt-in canonical rule (exact_reference_order=False) bit-exact against oracle mode 3 and its
+    distance to the reference's result (raw arcs, 1-best, determinized lattices).  Returns the DEFAULT decoder."""
     fst = api.Fst(g)
     n = len(off) - 1
     dec = api.LatticeFasterDecoder(fst, cfg, max_batch=n, max_frames=int(np.diff(off).max()))
     dec.decode(ll_dev, off)
+    assert dec.search_counters(0)["reference_order"]
+    can = api.LatticeFasterDecoder(fst, cfg, max_batch=n, max_frames=int(np.diff(off).max()), exact_reference_order=False)
+    can.decode(ll_dev, off)
     ll = ll_dev.cpu().numpy()
     dens, diffs, det = [], [], []
     n_diff = n_ref = 0
     for u in sample:
         x = np.ascontiguousarray(ll[off[u]:off[u + 1]])
-        oc = B.DecoderOracle(g, cfg, "canonical")
-        assert oc.decode(x)
-        got = dec.get_raw_lattice(u)
-        assert_same_lattice(got, oc.raw_lattice())
-        assert_same_best_path(dec.get_best_path(u), oc.best_path())
         orf = B.DecoderOracle(g, cfg, "reference")
         assert orf.decode(x)
+        assert_same_lattice(dec.get_raw_lattice(u), orf.raw_lattice())
         assert_same_best_path(dec.get_best_path(u), orf.best_path())
+        oc = B.DecoderOracle(g, cfg, "canonical")
+        assert oc.decode(x)
+        got = can.get_raw_lattice(u)
+        assert_same_lattice(got, oc.raw_lattice())
+        assert_same_best_path(can.get_best_path(u), oc.best_path())
+        assert_same_best_path(can.get_best_path(u), orf.best_path())
         ref_arcs, got_arcs = arc_set(orf.raw_lattice()), arc_set(got)
         diff = len(ref_arcs ^ got_arcs) / max(1, len(ref_arcs))
         assert diff <= max_utt_diff, (u, diff)
@@ -64,8 +72,8 @@ def decode_and_compare(api, g, ll_dev, off, cfg, sample, max_ref_diff=0.02, max_
         # recipe's beam, compared by the reference's own criterion (latbin/lattice-equivalent.cc: RandEquivalent,
         # delta 0.1; 50 paths instead of its 20) AND exactly (every word sequence, its cost and alignment).
         det.append(det_equivalence(api, got, orf.raw_lattice(), cfg["lattice_beam"], u))
-    print("arc difference vs reference order per utterance: %s; pooled %.4f" % (["%.4f" % d for d in diffs], n_diff / max(1, n_ref)))
-    print("determinized CompactLattice, GPU vs reference order: %d utterances, %d inequivalent (lattice-equivalent criterion), "
+    print("canonical rule, arc difference vs reference order per utterance: %s; pooled %.4f" % (["%.4f" % d for d in diffs], n_diff / max(1, n_ref)))
+    print("determinized CompactLattice, canonical rule vs reference order: %d utterances, %d inequivalent (lattice-equivalent criterion), "
           "%d with any exact difference; raw arcs differing %d, determinized arcs %d vs %d" %
           (len(det), sum(not d["equivalent"] for d in det), sum(not d["exact"] for d in det), n_diff,
            sum(d["arcs_gpu"] for d in det), sum(d["arcs_ref"] for d in det)))
@@ -153,8 +161,9 @@ def test_cfg3_wsj_forward_and_structured_decode(api, oracle):
 
 def test_bench_workload_slice(api):
     """A bounded slice of bench.py's own workload (its model, its 10 M-state graph, its
-    features, its options; 48 utterances instead of 2620): sampled utterances bit-exact
-    against the canonical oracle, same 1-best and <= 2 % arcs against the reference order."""
+    features, its options; 48 utterances instead of 2620): sampled utterances bit-exact against the
+    reference-order oracle (the default decoder) and the canonical oracle (the opt-in rule); the canonical rule
+    within the same 1-best and <= 2 % arcs of the reference order."""
     sys.path.insert(0, ROOT)
     import bench
     net, priors, g, protos = bench.build_model_and_graph(3456, 10_000_000, False)

@@ -19,7 +19,7 @@ cfg = api.decoder_config(beam=float(rng.choice([2.0, 6.0, 11.0, 15.0])), max_act
                          prune_scale=float(rng.choice([0.05, 0.1, 0.5])))
 print("states", n_states, "pdf", n_pdf, "Ts", Ts, cfg)
 fst = api.Fst(g)
-dec = api.LatticeFasterDecoder(fst, cfg, max_batch=len(lls), max_frames=int(max(Ts)))
+dec = api.LatticeFasterDecoder(fst, cfg, max_batch=len(lls), max_frames=int(max(Ts)), exact_reference_order=False)
 off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
 dec.decode(torch.from_numpy(np.concatenate(lls, 0)).cuda(), off)
 for u, x in enumerate(lls):

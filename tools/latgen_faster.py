@@ -165,10 +165,11 @@ def run(cli, argv, kind, prog):
     po.register("allow-partial", False, "If true, produce output even if end state was not reached.")
     # not options of the reference binary:
     po.register("batch-frames", 200000, "[MI355X] frames per forward pass / decoder launch", int)
-    po.register("reference-order", False, "[MI355X] decode in LatticeFasterDecoder's own iteration order (HashList order, running next_cutoff): the lattices the reference "
-                "binary itself writes, bit for bit, at about twice the decoder time; false: the order-independent rule (same 1-best on every "
+    po.register("reference-order", True, "[MI355X] decode in LatticeFasterDecoder's own iteration order (HashList order, running next_cutoff): the lattices the "
+                "reference binary itself writes, bit for bit (the default since round 6)")
+    po.register("canonical-order", False, "[MI355X] opt out of --reference-order: the order-independent acceptance rule (a cheaper kernel; same 1-best on every "
                 "recipe-like case measured, 0-6 % different raw-lattice arcs; DESIGN.md).  KH_DECODER_ORDER=reference|canonical in the "
-                "environment overrides")
+                "environment overrides both")
     po.register("gpu", -1, "[MI355X] device ordinal (CuDevice::SelectGpuId); -1: LOCAL_RANK, else 0", int)
     po.register("world", 0, "[MI355X] number of ranks sharing the job (default: WORLD_SIZE, else 1).  Rank r is the recipe's JOB "
                 "r + 1: every JOB in the arguments becomes r + 1 (run.pl JOB=1:$nj); a feature table without JOB is taken "
@@ -293,7 +294,7 @@ def run(cli, argv, kind, prog):
             off = np.array([0, m.shape[0]], np.int32)
             loglikes = score(torch.from_numpy(np.ascontiguousarray(m, np.float32)).cuda(), off)
             dec = api.LatticeFasterDecoder(api.Fst(check_graph(g, "the graph of " + utt)), cfg, max_batch=1, max_frames=int(m.shape[0]),
-                                           exact_reference_order=bool(po["reference-order"]))
+                                           exact_reference_order=bool(po["reference-order"]) and not bool(po["canonical-order"]))
             dec.set_determinize(determinize, **det_opts)
             dec.decode(loglikes, off)
             dec.prepare()
@@ -314,7 +315,7 @@ def run(cli, argv, kind, prog):
         if state["dec"] is None or len(batch) > state["max_batch"] or max_T > state["max_frames"]:
             state["max_batch"], state["max_frames"] = max(len(batch), 64), max(max_T, 1024)
             state["dec"] = api.LatticeFasterDecoder(fst, cfg, max_batch=state["max_batch"], max_frames=state["max_frames"],
-                                                        exact_reference_order=bool(po["reference-order"]))
+                                                        exact_reference_order=bool(po["reference-order"]) and not bool(po["canonical-order"]))
             state["dec"].set_determinize(determinize, **det_opts)
         dec = state["dec"]
         dec.decode(loglikes, off)

@@ -163,10 +163,11 @@ def run(cli, argv, prog):
                 "constrained by currently available frames (this will rarely make a difference)", int)
     endpoint = online2.OnlineEndpointConfig()
     endpoint.register(po)
-    po.register("reference-order", False, "[MI355X] decode in LatticeFasterDecoder's own iteration order (HashList order, running next_cutoff): the lattices the reference "
-                "binary itself writes, bit for bit, at about twice the decoder time; false: the order-independent rule (same 1-best on every "
+    po.register("reference-order", True, "[MI355X] decode in LatticeFasterDecoder's own iteration order (HashList order, running next_cutoff): the lattices the "
+                "reference binary itself writes, bit for bit (the default since round 6)")
+    po.register("canonical-order", False, "[MI355X] opt out of --reference-order: the order-independent acceptance rule (a cheaper kernel; same 1-best on every "
                 "recipe-like case measured, 0-6 % different raw-lattice arcs; DESIGN.md).  KH_DECODER_ORDER=reference|canonical in the "
-                "environment overrides")
+                "environment overrides both")
     po.register("gpu", -1, "[MI355X] device ordinal (CuDevice::SelectGpuId); -1: LOCAL_RANK, else 0", int)
     po.register("world", 0, "[MI355X] number of ranks sharing the job (default: WORLD_SIZE, else 1): the SPEAKERS of the spk2utt "
                 "table are dealt to the ranks longest-first (a speaker's adaptation state chains its utterances); every JOB in the "
@@ -288,7 +289,7 @@ def run(cli, argv, prog):
         if wround is not None:
             # the iVector rows depend on the decoder's traceback: features, network and decoder advance chunk by chunk
             odec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=len(keep), max_frames=int(np.diff(off_k).max()),
-                                                  exact_reference_order=bool(po["reference-order"]))
+                                                  exact_reference_order=bool(po["reference-order"]) and not bool(po["canonical-order"]))
             wround.begin(keep, odec)
             decoded, stopped = online2.simulate(odec, None, off_k, [sched[u] for u in keep], endpoint if do_endpointing else None,
                                                 tm["tid2phone"], frame_shift, before_advance=wround.before_advance, rows_of=wround.rows_of)
@@ -302,12 +303,12 @@ def run(cli, argv, prog):
             pass
         elif do_endpointing:
             odec = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=len(keep), max_frames=int(np.diff(ll_off).max()),
-                                                  exact_reference_order=bool(po["reference-order"]))
+                                                  exact_reference_order=bool(po["reference-order"]) and not bool(po["canonical-order"]))
             decoded, stopped = online2.simulate(odec, ll, ll_off, [sched[u] for u in keep], endpoint, tm["tid2phone"], frame_shift)
             get = lambda j: (odec.stats(j), odec.get_raw_lattice(j), odec.get_best_path(j))
         else:
             dec = api.LatticeFasterDecoder(fst, cfg, max_batch=len(keep), max_frames=int(np.diff(ll_off).max()),
-                                           exact_reference_order=bool(po["reference-order"]))
+                                           exact_reference_order=bool(po["reference-order"]) and not bool(po["canonical-order"]))
             dec.set_determinize(True, **det_opts)
             dec.decode(ll, ll_off)
             dec.prepare()
