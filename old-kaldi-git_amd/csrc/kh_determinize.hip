@@ -610,28 +610,61 @@ struct Pass {
 };
 
 // ---------------------------------------------------------------- building / converting lattices
-// arcs with arbitrary state numbering, start = state `start`.  Produces the CSR form: states in topological order (the
-// start state first), arcs sorted by label within a state.  Returns false on a cycle.
+// arcs with arbitrary state numbering, start = state `start`.  Produces the CSR form: states in the topological order the
+// reference's wrapper would work on (below; the start state first), arcs sorted by label within a state.  Returns false on a cycle.
 struct RawArc { int32_t src, label, tid, next; LW w; };
-bool BuildLat(int32_t n, int32_t start, const std::vector<RawArc> &arcs, const std::vector<LW> &fin, Lat *L) {
-  std::vector<int32_t> indeg(n, 0), order, id(n, -1);
+bool BuildLat(int32_t n, int32_t start, const std::vector<RawArc> &arcs, const std::vector<LW> &fin, Lat *L, bool always_renumber = false) {
+  std::vector<int32_t> order, id(n, -1);
   std::vector<int64_t> off(n + 1, 0);
-  for (const RawArc &a : arcs) { indeg[a.next]++; off[a.src + 1]++; }
+  for (const RawArc &a : arcs) off[a.src + 1]++;
   for (int32_t s = 0; s < n; s++) off[s + 1] += off[s];
   std::vector<int32_t> by_src(arcs.size());
   {
     std::vector<int64_t> fill(off.begin(), off.end() - 1);
     for (size_t j = 0; j < arcs.size(); j++) by_src[fill[arcs[j].src]++] = static_cast<int32_t>(j);
   }
-  order.reserve(n);
-  if (start >= 0 && start < n && indeg[start] == 0) order.push_back(start);
-  for (int32_t s = 0; s < n; s++) if (indeg[s] == 0 && s != start) order.push_back(s);
-  for (size_t h = 0; h < order.size(); h++) {
-    const int32_t s = order[h];
-    for (int64_t k = off[s]; k < off[s + 1]; k++)
-      if (--indeg[arcs[by_src[k]].next] == 0) order.push_back(arcs[by_src[k]].next);
+  // The numbering DeterminizeLatticePhonePrunedWrapper works on (:1503-1512).  It asks ifst->Properties(kTopSorted) first:
+  // a lattice whose every arc leads to a higher state number (a raw lattice without backward epsilon arcs) keeps its
+  // numbering.  Otherwise fst/topsort.h: the REVERSE FINISHING order of a depth-first search from the start state, then
+  // from every state not yet visited in state order, a state's arcs taken in the order they were given.  Any topological
+  // order gives the same determinized lattice; this one also gives the reference's string repository - the epsilon
+  // closure settles states in increasing number, and how many strings it interns for candidates that are improved on
+  // later depends on that order - hence the same point at which max_mem stops a pass.  (Round 6: rounds 3-5 used Kahn's
+  // order; tests/test_gpu_determinize.py found it stopping 50 output states away from the oracle at the memory limit.)
+  // always_renumber: the two TopSort calls of DeterminizeLatticePhonePrunedFirstPass (:1410, :1417) do not ask first.
+  order.assign(n, -1);
+  bool sorted_already = start == 0 && !always_renumber;
+  for (size_t j = 0; j < arcs.size() && sorted_already; j++) sorted_already = arcs[j].next > arcs[j].src;
+  if (sorted_already) {
+    for (int32_t s = 0; s < n; s++) order[s] = s;
+  } else {
+    std::vector<char> color(n, 0);   // 0 white, 1 grey, 2 black
+    std::vector<std::pair<int32_t, int64_t>> stack;
+    int32_t n_fin = 0;
+    bool acyclic = true;
+    auto visit = [&](int32_t root) {
+      if (color[root]) return;
+      color[root] = 1;
+      stack.emplace_back(root, off[root]);
+      while (!stack.empty()) {
+        const int32_t s = stack.back().first;
+        const int64_t k = stack.back().second;
+        if (k < off[s + 1]) {
+          stack.back().second++;
+          const int32_t t = arcs[by_src[k]].next;
+          if (color[t] == 0) { color[t] = 1; stack.emplace_back(t, off[t]); }
+          else if (color[t] == 1) acyclic = false;
+        } else {
+          color[s] = 2;
+          order[n - 1 - n_fin++] = s;
+          stack.pop_back();
+        }
+      }
+    };
+    if (start >= 0 && start < n) visit(start);
+    for (int32_t s = 0; s < n; s++) visit(s);
+    if (!acyclic) return false;
   }
-  if (static_cast<int32_t>(order.size()) != n) return false;
   for (int32_t i = 0; i < n; i++) id[order[i]] = i;
   L->Clear();
   L->n = n;
@@ -1043,6 +1076,9 @@ KhCompactLattice *kh_determinize_lattice_phone_pruned(int n_states, int n_arcs, 
     int32_t highest = 0;
     for (const RawArc &a : arcs) highest = std::max(highest, a.label);
     const int32_t first_phone_label = highest + 1;
+    // (the wrapper has ArcSorted on the word by now, :1513-1514, and the phones go into the arcs in place: the depth-first
+    // numbering of the first pass's TopSort follows a state's arcs in THAT order)
+    std::stable_sort(arcs.begin(), arcs.end(), [](const RawArc &x, const RawArc &y) { return x.label < y.label; });
     const size_t m0 = arcs.size();
     for (size_t j = 0; j < m0; j++) {
       RawArc a = arcs[j];
@@ -1059,7 +1095,7 @@ KhCompactLattice *kh_determinize_lattice_phone_pruned(int n_states, int n_arcs, 
       arcs[j] = a;
     }
     lap(0);
-    if (!BuildLat(n_cur, 0, arcs, fin, &ws.lat)) { SetError("%s", cycle); delete K; return nullptr; }
+    if (!BuildLat(n_cur, 0, arcs, fin, &ws.lat, true)) { SetError("%s", cycle); delete K; return nullptr; }   // TopSort :1410
     lap(1);
     // first pass -> state-level lattice, phones deleted (:1386-1404)
     std::vector<RawArc> arcs2;
@@ -1073,7 +1109,8 @@ KhCompactLattice *kh_determinize_lattice_phone_pruned(int n_states, int n_arcs, 
     n_cur = n2;
   }
   lap(0);
-  if (n_cur > 0 && !BuildLat(n_cur, 0, arcs, fin, &ws.lat)) { SetError("%s", cycle); delete K; return nullptr; }
+  // (after a first pass: TopSort :1417, unconditional; else the wrapper's own, which keeps a sorted lattice's numbering)
+  if (n_cur > 0 && !BuildLat(n_cur, 0, arcs, fin, &ws.lat, phone_determinize != 0)) { SetError("%s", cycle); delete K; return nullptr; }
   lap(3);
   if (n_cur == 0) {
     // (an empty first pass)
