@@ -71,6 +71,26 @@ struct KhFst {
 
 namespace {
 
+// Every use of the lane's index in this file goes through an OPAQUE copy (round 6).  The decode kernels are one loop over
+// frames around everything; what the optimizer derives from a plain threadIdx.x - `tid * 8 + j`, `tid < 16`, `~tid`, LDS
+// addresses - is loop-invariant, gets computed once at the kernel's entry and stays live for the whole launch; the 64
+// registers of a 1024-thread workgroup at two per CU cannot hold these values, they are spilled, and every USE becomes a
+// scratch_load (a trip to memory: the scratch of 512 workgroups is 160 MB, no cache holds it) - ten such values accounted
+// for 230 of the reference-order kernel's 329 static scratch loads, about 1 MB of reads per frame.  Behind an empty
+// `asm volatile` the derived values are recomputed where they are used (a VALU instruction each).  Same-box A/B:
+// scratch 308 -> 128 B per lane and 981 -> 903 ms (reference order), 84 -> 0 B and 526 -> 507 ms (canonical), serving
+// kernel 416 -> 172 B and chunk latency p50 3.9 -> 2.8 ms.  (Round 5 had done this for the list-order routines only: OpaqueTid.)
+__device__ __forceinline__ unsigned KhOpaqueTidX() {
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#ifndef KH_PLAIN_TID
+#define KH_TIDX (KhOpaqueTidX())
+#else
+#define KH_TIDX (threadIdx.x)
+#endif
+
 #ifndef KH_NT
 #define KH_NT 1024
 #endif
@@ -387,7 +407,7 @@ __device__ __forceinline__ void Launder(Params &p) {
 // reached L2 before another wave's L2 read after it: s_waitcnt vmcnt(0) first.
 #ifdef KH_BOUNDS_CHECK
 __device__ int g_oob[8];
-#define KH_BOUND(code, v, lo, hi) do { if ((v) < (lo) || (v) >= (hi)) { if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = (code); g_oob[2] = (int)(v); g_oob[3] = (int)(lo); g_oob[4] = (int)(hi); g_oob[5] = threadIdx.x; } (v) = (lo); } } while (0)
+#define KH_BOUND(code, v, lo, hi) do { if ((v) < (lo) || (v) >= (hi)) { if (atomicAdd(&g_oob[0], 1) == 0) { g_oob[1] = (code); g_oob[2] = (int)(v); g_oob[3] = (int)(lo); g_oob[4] = (int)(hi); g_oob[5] = KH_TIDX; } (v) = (lo); } } while (0)
 #else
 #define KH_BOUND(code, v, lo, hi) do {} while (0)
 #endif
@@ -397,9 +417,9 @@ __device__ int g_bar_misaligned[4];
 #endif
 __device__ __forceinline__ void KhSync() {
 #ifdef KH_BARRIER_CHECK
-  const int w_ = threadIdx.x >> 6;
+  const int w_ = KH_TIDX >> 6;
   int *bc_ = g_bar_cnt + blockIdx.x * 16;
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&bc_[w_], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((KH_TIDX & 63) == 0) __hip_atomic_fetch_add(&bc_[w_], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -515,7 +535,7 @@ inline size_t DynLdsBytes(int ll_cols) { return std::max(sizeof(float) * static_
 // Diagnostic phase timer: thread 0 charges the shader cycles since the previous
 // stamp to `ph`.  Only active when the host passed a phase_cycles buffer.
 __device__ __forceinline__ void Stamp(const Utt &u, Blk &sh, int ph) {
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) {
     const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->phase[ph] += now - sh->t_last;
     sh->t_last = now;
@@ -550,7 +570,7 @@ __device__ __forceinline__ int WaveIncSum(int v) {
 #ifndef KH_NO_DPP
   KH_DPP_SCAN(v, 0, OpAddI);
 #else
-  const int lane = threadIdx.x & 63;
+  const int lane = KH_TIDX & 63;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v += n; }
 #endif
@@ -560,7 +580,7 @@ __device__ __forceinline__ int WaveIncMax(int v) {   // (values >= 0)
 #ifndef KH_NO_DPP
   KH_DPP_SCAN(v, 0, OpMaxI);
 #else
-  const int lane = threadIdx.x & 63;
+  const int lane = KH_TIDX & 63;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v = OpMaxI(v, n); }
 #endif
@@ -571,7 +591,7 @@ __device__ __forceinline__ uint32_t WaveIncMinU(uint32_t u) {
 #ifndef KH_NO_DPP
   KH_DPP_SCAN(v, -1, OpMinUBits);
 #else
-  const int lane = threadIdx.x & 63;
+  const int lane = KH_TIDX & 63;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v = OpMinUBits(v, n); }
 #endif
@@ -582,7 +602,7 @@ __device__ __forceinline__ float WaveIncMinF(float f) {
 #ifndef KH_NO_DPP
   KH_DPP_SCAN(v, 0x7f800000, OpMinFBits);
 #else
-  const int lane = threadIdx.x & 63;
+  const int lane = KH_TIDX & 63;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v = OpMinFBits(v, n); }
 #endif
@@ -643,7 +663,7 @@ __device__ __forceinline__ long long WaveSumLLToLast(long long x) {
 // calls later, i.e. behind at least one more barrier than its last read.
 template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = KH_TIDX & 63, w = KH_TIDX >> 6;
   const int inc = WaveIncSum(v);
   const int buf = (sh.k_scan++) & 1;
   if (lane == 63) sh->wsum[buf][w] = inc;
@@ -663,7 +683,7 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
 // thread t): one barrier for all slices.
 template <int K, bool kLdsOnly = false>
 __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], int *total, Blk &sh) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = KH_TIDX & 63, w = KH_TIDX >> 6;
   const int buf = (sh.k_scan++) & 1;
   int inc[K];
 #pragma unroll
@@ -691,7 +711,7 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], i
 __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, Blk &sh) {
   const int buf = (sh.k_red++) & 1;
   v = WaveMinU64ToLast(v);
-  if ((threadIdx.x & 63) == 63) sh->wred[buf][threadIdx.x >> 6] = v;
+  if ((KH_TIDX & 63) == 63) sh->wred[buf][KH_TIDX >> 6] = v;
   KhSync();
   unsigned long long r = sh->wred[buf][0];
 #pragma unroll
@@ -702,7 +722,7 @@ __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, 
 __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
   const int buf = (sh.k_red++) & 1;
   v = WaveIncMinF(v);
-  if ((threadIdx.x & 63) == 63) sh->wred[buf][threadIdx.x >> 6] = __float_as_uint(v);
+  if ((KH_TIDX & 63) == 63) sh->wred[buf][KH_TIDX >> 6] = __float_as_uint(v);
   KhSync();
   float r = __uint_as_float(static_cast<uint32_t>(sh->wred[buf][0]));
 #pragma unroll
@@ -713,7 +733,7 @@ __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
 __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
   const int buf = (sh.k_red++) & 1;
   v = WaveSumLLToLast(v);
-  if ((threadIdx.x & 63) == 63) sh->wred[buf][threadIdx.x >> 6] = static_cast<unsigned long long>(v);
+  if ((KH_TIDX & 63) == 63) sh->wred[buf][KH_TIDX >> 6] = static_cast<unsigned long long>(v);
   KhSync();
   long long r = 0;
 #pragma unroll
@@ -727,7 +747,7 @@ __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
 template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockOr(int bits, Blk &sh) {
   const int k = (sh.k_or++) & 3;
-  if (threadIdx.x == 0) sh->orbuf[(k + 2) & 3] = 0;
+  if (KH_TIDX == 0) sh->orbuf[(k + 2) & 3] = 0;
   if (bits) __hip_atomic_fetch_or(&sh->orbuf[k], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (kLdsOnly) LdsSync(); else KhSync();
   return Uni(sh->orbuf[k]);
@@ -756,10 +776,10 @@ __device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k, u
     const int w = (remaining + passes - 1) / passes, shift = remaining - w;
     const uint32_t dmask = (1u << w) - 1u;
     const int bins = 1 << w;
-    for (int i = threadIdx.x; i < bins; i += NT) sh->hist[i] = 0;
+    for (int i = KH_TIDX; i < bins; i += NT) sh->hist[i] = 0;
     KhSync();
     constexpr int kRU = 8;
-    for (int i0 = b + threadIdx.x; i0 < e; i0 += NT * kRU) {
+    for (int i0 = b + KH_TIDX; i0 < e; i0 += NT * kRU) {
       uint32_t ks[kRU];
 #pragma unroll
       for (int k = 0; k < kRU; k++) ks[k] = LoadCostEnc(&keys[min(i0 + k * NT, e - 1)]);
@@ -773,7 +793,7 @@ __device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k, u
     int cnt[kPerLane], mine = 0;
 #pragma unroll
     for (int j = 0; j < kPerLane; j++) {
-      const int bin = threadIdx.x * kPerLane + j;
+      const int bin = KH_TIDX * kPerLane + j;
       cnt[j] = bin < bins ? static_cast<int>(sh->hist[bin]) : 0;
       mine += cnt[j];
     }
@@ -783,7 +803,7 @@ __device__ uint32_t RadixSelect(Arr<const uint32_t> keys, int b, int e, int k, u
 #pragma unroll
       for (int j = 0; j < kPerLane; j++) {
         if (before <= k && k < before + cnt[j]) {
-          sh->bcast_i[1] = threadIdx.x * kPerLane + j;
+          sh->bcast_i[1] = KH_TIDX * kPerLane + j;
           sh->bcast_i[2] = k - before;
         }
         before += cnt[j];
@@ -890,7 +910,7 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const KhInt4> rec, 
     bool in_range[EU];
 #pragma unroll
     for (int k = 0; k < EU; k++) {
-      i[k] = base + k * NT + threadIdx.x;
+      i[k] = base + k * NT + KH_TIDX;
       in_range[k] = i[k] < e;
       int ic = min(i[k], e - 1);
       if (kEps) { ic = u.tmp_epslist[ic]; i[k] = ic; }  // [b, e) indexes the list of tokens with epsilon arcs
@@ -914,18 +934,18 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const KhInt4> rec, 
     // (this barrier also orders the previous group's LDS reads before the writes below)
     BlockExScanK<EU>(cnt, loff, &total, sh);
     if (lrun + total > u.link_cap || lrun + total - lrun0 > frame_cap) {
-      if (threadIdx.x == 0) sh->status = (lrun + total > u.link_cap) ? 2 : 3;
+      if (KH_TIDX == 0) sh->status = (lrun + total > u.link_cap) ? 2 : 3;
       KhSync();
       return -1;
     }
 #pragma unroll
     for (int k = 0; k < EU; k++) {  // slice-major item order = the scan's order: ex_off is non-decreasing
-      sh->ex_off[k * NT + threadIdx.x] = loff[k];
-      sh->ex_ab[k * NT + threadIdx.x] = ab[k];
-      sh->ex_tok[k * NT + threadIdx.x] = i[k];
+      sh->ex_off[k * NT + KH_TIDX] = loff[k];
+      sh->ex_ab[k * NT + KH_TIDX] = ab[k];
+      sh->ex_tok[k * NT + KH_TIDX] = i[k];
     }
     KhSync();
-    for (int q = threadIdx.x; q < total; q += NT) {
+    for (int q = KH_TIDX; q < total; q += NT) {
       // owner = the LAST item whose first slot is <= q (items without arcs share their
       // successor's first slot and are skipped by "last")
       int lo = 0, hi = EU * NT - 1;
@@ -935,7 +955,7 @@ __device__ __forceinline__ int ExpandSweep(const Utt &u, Arr<const KhInt4> rec, 
       }
       body(lrun + q, sh->ex_tok[lo], sh->ex_ab[lo] + (q - sh->ex_off[lo]));
     }
-    if (threadIdx.x == 0) *arcs += total;
+    if (KH_TIDX == 0) *arcs += total;
     lrun += total;
   }
   KhSync();  // the links are visible to the next phase
@@ -967,7 +987,7 @@ __device__ __forceinline__ int WaveLdsFetchAdd(__attribute__((address_space(3)))
   return __builtin_amdgcn_readfirstlane(r);
 #else
   int r = 0;
-  if ((threadIdx.x & 63) == 0) r = __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((KH_TIDX & 63) == 0) r = __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return __builtin_amdgcn_readfirstlane(r);
 #endif
 }
@@ -989,8 +1009,8 @@ struct OwnerScan {
 };
 __device__ __forceinline__ OwnerScan OwnerScanInit(Blk &sh) {   // (a workgroup barrier must follow before the first batch: none needed, the row is the wave's own)
   OwnerScan os;
-  os.row = &sh->own[Uni(static_cast<int>(threadIdx.x >> 6))][0];
-  os.row[threadIdx.x & 63] = 0;
+  os.row = &sh->own[Uni(static_cast<int>(KH_TIDX >> 6))][0];
+  os.row[KH_TIDX & 63] = 0;
   os.seq = 0;
   os.carry = -1;
   return os;
@@ -1028,8 +1048,8 @@ __device__ __forceinline__ int ExpandWavesFiltered(const Utt &u, Arr<const KhInt
                                                    int frame_cap, long long *arcs, Blk &sh, float *est, float *bound, Load load,
                                                    Finish finish, Store store) {
   const int limit = min(u.link_cap, lrun + frame_cap);
-  const int lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) {
+  const int lane = KH_TIDX & 63;
+  if (KH_TIDX == 0) {
     sh->link_cursor = lrun;
     sh->work_cursor = b;
     sh->bound_enc = Enc(*bound);
@@ -1208,7 +1228,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   uint32_t kmax = 0;
   // (kGU tokens of a lane in flight together: a plain loop waits for every trip's loads before it issues the next ones)
   constexpr int kGU = 4;
-  for (int i0 = b + threadIdx.x; i0 < e; i0 += NT * kGU) {
+  for (int i0 = b + KH_TIDX; i0 < e; i0 += NT * kGU) {
     uint32_t encs[kGU], lows[kGU];
 #pragma unroll
     for (int k = 0; k < kGU; k++) {
@@ -1265,7 +1285,7 @@ __device__ Cutoff GetCutoff(const Utt &u, const Params &p, int b, int e, Blk &sh
   {
     const uint32_t bc = Enc(beam_cutoff);
     constexpr int kWU = 8;
-    for (int i0 = b + threadIdx.x; i0 < e; i0 += NT * kWU) {
+    for (int i0 = b + KH_TIDX; i0 < e; i0 += NT * kWU) {
       uint32_t encs[kWU];
 #pragma unroll
       for (int k = 0; k < kWU; k++) encs[k] = LoadCostEnc(&g_cost[min(i0 + k * NT, e - 1)]);
@@ -1371,11 +1391,11 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
   const ClTab t = ClLayout(sh);
   const int fb = Uni(sh->front_b), tok_end0 = Uni(sh->tok_end);
   const int tok_limit = min(u.tok_cap, fb + u.tok_frame_cap);
-  for (int i = threadIdx.x; i < kClSlots; i += NT) { t.key[i] = 0u; t.cost[i] = kEncInf; t.idx[i] = 0u; }   // (rng: set by whoever inserts)
-  if (threadIdx.x == 0) { sh->cl_n = n_list; sh->flag = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
+  for (int i = KH_TIDX; i < kClSlots; i += NT) { t.key[i] = 0u; t.cost[i] = kEncInf; t.idx[i] = 0u; }   // (rng: set by whoever inserts)
+  if (KH_TIDX == 0) { sh->cl_n = n_list; sh->flag = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
   LdsSync();
   // ---- the table from the list; the tokens with epsilon arcs are the first work list (:766-767)
-  for (int k = threadIdx.x; k < n_list; k += NT) {
+  for (int k = KH_TIDX; k < n_list; k += NT) {
     const int32_t ns = u.tmp_work0[k];
     const int idx = u.tmp_work1[k];
     const uint32_t enc = __float_as_uint(u.tmp_f0[k]);
@@ -1397,11 +1417,11 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
   long long my_arcs = 0;
   for (int r = 0;; r++) {
     const int n = Uni(sh->wl_n[r % 3]);
-    if (threadIdx.x == 0) sh->wl_n[(r + 2) % 3] = 0;
+    if (KH_TIDX == 0) sh->wl_n[(r + 2) % 3] = 0;
     if (n == 0) break;
     const LdsU16 cur = (r & 1) ? t.l1 : t.l0, nxt = (r & 1) ? t.l0 : t.l1;
     auto nxt_n = &sh->wl_n[(r + 1) % 3];
-    for (int q = threadIdx.x; q < n; q += NT) {
+    for (int q = KH_TIDX; q < n; q += NT) {
       const int s = cur[q];
       // leave the queue BEFORE reading the cost (a later improvement queues the token again; the LDS unit executes the
       // workgroup's operations one after the other, so "clear, then read" cannot miss an update that found the flag set)
@@ -1446,13 +1466,13 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
         }
       }
     }
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[13] += 1;
     LdsSync();
     if (Uni(sh->flag) != 0 && Uni(sh->status) == 0) {
       // the table (or a work list) filled up: nothing has reached memory - undo the token reservations and let the
       // general routine do the frame
       LdsSync();
-      if (threadIdx.x == 0) { sh->tok_end = tok_end0; sh->flag = 0; sh->wl_n[0] = sh->eps_n; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
+      if (KH_TIDX == 0) { sh->tok_end = tok_end0; sh->flag = 0; sh->wl_n[0] = sh->eps_n; sh->wl_n[1] = 0; sh->wl_n[2] = 0; }
       LdsSync();
       return 0;
     }
@@ -1460,7 +1480,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
   }
   LdsSync();
   // ---- write back: final costs; the tokens the closure created (those with epsilon arcs join tmp_epslist)
-  for (int s = threadIdx.x; s < kClSlots; s += NT) {
+  for (int s = KH_TIDX; s < kClSlots; s += NT) {
     const uint32_t key = t.key[s];
     if (key == 0u) continue;
     const int32_t ns = static_cast<int32_t>(key - 1u);
@@ -1477,10 +1497,10 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
   // token's slots consecutive and in arc order; the slots whose tot_cost is not under the cutoff stay dead (dst = -1)
   const int blk_b = Uni(sh->link_end);
   const int limit = min(u.link_cap, blk_b + u.link_frame_cap);
-  if (threadIdx.x == 0) sh->link_cursor = blk_b;
+  if (KH_TIDX == 0) sh->link_cursor = blk_b;
   LdsSync();
   for (int s0 = 0; s0 < kClSlots; s0 += NT) {   // (uniform: the wave scan involves every lane)
-    const int s = s0 + threadIdx.x;
+    const int s = s0 + KH_TIDX;
     const uint32_t key = t.key[s];
     const float cost = Dec(t.cost[s]);
     int ab = 0, cnt = 0;
@@ -1500,7 +1520,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
     if (total == 0) continue;   // (uniform over the wave)
     const int base = WaveLdsFetchAdd(&sh->link_cursor, total);
     if (base + total > limit) {
-      if ((threadIdx.x & 63) == 0) sh->status = (base + total > u.link_cap) ? 2 : 3;
+      if ((KH_TIDX & 63) == 0) sh->status = (base + total > u.link_cap) ? 2 : 3;
       continue;
     }
     const int src = fb + static_cast<int>(t.idx[s] & ~kClQueued);
@@ -1528,12 +1548,12 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
 #ifndef KH_CL_BLOCKSUM
   {  // the arcs visited, for the utterance's counter: one LDS add per wave (no barrier of its own)
     const long long wave_arcs = WaveSumLLToLast(my_arcs);
-    if ((threadIdx.x & 63) == 63 && wave_arcs != 0)
+    if ((KH_TIDX & 63) == 63 && wave_arcs != 0)
       __hip_atomic_fetch_add(&sh->arcs_expanded, wave_arcs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   KhSync();
   if (Uni(sh->status) != 0) return -1;
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->link_end = sh->link_cursor;
     u.feps_b[frame] = blk_b;
     u.feps_e[frame] = sh->link_end;
@@ -1542,7 +1562,7 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
   KhSync();
   if (Uni(sh->status) != 0) return -1;
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->link_end = sh->link_cursor;
     sh->arcs_expanded += tot_arcs;
     u.feps_b[frame] = blk_b;
@@ -1559,10 +1579,10 @@ __device__ int ClosureLds(const Utt &u, const Params &p, int frame, float cutoff
 // and the tokens with epsilon arcs are marked queued.
 __device__ void ClosureGeneralPrep(const Utt &u, Blk &sh) {
   const int fb = Uni(sh->front_b), fe = Uni(sh->tok_end), n_list = Uni(sh->erel_n);
-  for (int i = fb + threadIdx.x; i < fe; i += NT) u.tmp_slot[i - fb] = -1;
-  if (threadIdx.x == 0) sh->hash_dirty = 1;
+  for (int i = fb + KH_TIDX; i < fe; i += NT) u.tmp_slot[i - fb] = -1;
+  if (KH_TIDX == 0) sh->hash_dirty = 1;
   KhSync();
-  for (int k = threadIdx.x; k < n_list; k += NT) {
+  for (int k = KH_TIDX; k < n_list; k += NT) {
     const int32_t ns = u.tmp_work0[k];
     const int idx = u.tmp_work1[k];
     if ((ns & kHasEps) != 0) u.tmp_dirty[idx - fb] = 1;
@@ -1599,7 +1619,7 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
   if (from_list) {   // (false: frame 0, whose start token DecodeInit entered in the global hash itself)
 #ifndef KH_NO_LDS_CLOSURE
     const int rc = ClosureLds(u, p, frame, cutoff, sh);
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[rc != 0 ? 38 : 39] += 1;
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[rc != 0 ? 38 : 39] += 1;
     if (rc != 0) return rc > 0;
 #endif
     ClosureGeneralPrep(u, sh);
@@ -1613,19 +1633,19 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
   long long my_arcs = 0;
   for (int r = 0;; r++) {
     const int n = Uni(sh->wl_n[r % 3]);
-    if (threadIdx.x == 0) sh->wl_n[(r + 2) % 3] = 0;  // last read one barrier ago, next pushed to one barrier ahead
+    if (KH_TIDX == 0) sh->wl_n[(r + 2) % 3] = 0;  // last read one barrier ago, next pushed to one barrier ahead
     if (n == 0) break;
     const Arr<const int32_t> cur = r == 0 ? u.tmp_epslist : ((r & 1) ? u.tmp_work1 : u.tmp_work0);
     const Arr<int32_t> nxt = (r & 1) ? u.tmp_work0 : u.tmp_work1;
     auto nxt_n = &sh->wl_n[(r + 1) % 3];
-    const int lane = threadIdx.x & 63;
+    const int lane = KH_TIDX & 63;
     long long tcl = 0;
-    const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0;
+    const bool prof = u.phase_cycles != nullptr && KH_TIDX == 0;
     if (prof) tcl = static_cast<long long>(__builtin_amdgcn_s_memtime());
 #define KH_CL_STAMP(k) do { if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tcl; tcl = now_; } } while (0)
     if (prof) sh->phase[33] += n;
     for (int q0 = 0; q0 < n; q0 += NT) {  // uniform trip count: the wave-level combine below involves every lane
-      const int q = q0 + threadIdx.x;
+      const int q = q0 + KH_TIDX;
       float cur_cost = INFINITY;
       int ab = 0, ae = 0;
       if (q < n) {
@@ -1697,7 +1717,7 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
         KH_CL_STAMP(29);
       }
     }
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[13] += 1;
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[13] += 1;
     KhSync();
     KH_CL_STAMP(30);
 #undef KH_CL_STAMP
@@ -1733,9 +1753,9 @@ __device__ bool ProcessNonemitting(const Utt &u_in, const Params &p_in, int fram
       });
   if (blk_e < 0) return false;
   KhSync();
-  if (threadIdx.x == 0) sh->link_end = blk_e;
+  if (KH_TIDX == 0) sh->link_end = blk_e;
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->arcs_expanded += tot_arcs;
     u.feps_b[frame] = blk_b;
     u.feps_e[frame] = sh->link_end;
@@ -1750,15 +1770,15 @@ __device__ void ClearHash(const Utt &u, int fb, int fe, Blk &sh) {
   if (Uni(sh->hash_dirty) == 0) return;   // (the frame's closure ran in LDS: the global hash was not touched)
   if (2 * (fe - fb) > static_cast<int>(u.hash_mask >> 2)) {
     // many entries: stream over the whole table (coalesced) instead of one scattered store per token
-    for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+    for (uint32_t i = KH_TIDX; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
   } else {
-    for (int i = fb + threadIdx.x; i < fe; i += NT) {
+    for (int i = fb + KH_TIDX; i < fe; i += NT) {
       const int32_t sl = u.tmp_slot[i - fb];  // -1: the token was never entered (emitting pass, no epsilon arc leads to its state)
       if (sl >= 0) u.hash[sl] = kEmpty;
     }
   }
   KhSync();
-  if (threadIdx.x == 0) sh->hash_dirty = 0;
+  if (KH_TIDX == 0) sh->hash_dirty = 0;
 }
 
 // ---- pass 2 of ProcessEmitting (shared by the canonical and the reference-order sweep): accept `tot_cost <= next_cutoff`
@@ -1826,7 +1846,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     int n_acc_mine = 0;
     {
       constexpr int kCU = 8;   // loads of a lane in flight together (a frame of this size took 11+ dependent round trips here)
-      for (int l0 = link_frame_b + threadIdx.x; l0 < link_frame_e; l0 += NT * kCU) {
+      for (int l0 = link_frame_b + KH_TIDX; l0 < link_frame_e; l0 += NT * kCU) {
         float ks[kCU];
 #pragma unroll
         for (int k = 0; k < kCU; k++) ks[k] = e_k[min(l0 + k * NT, link_frame_e - 1)];
@@ -1836,12 +1856,12 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     }
     const int n_acc = static_cast<int>(BlockSumLL(n_acc_mine, sh));
     while (parts * KH_PART_CAND < n_acc) parts *= 2;
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[32] += n_acc;
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[32] += n_acc;
   }
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[31] += link_frame_e - link_frame_b; sh->phase[13] += 0; }
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) { sh->phase[31] += link_frame_e - link_frame_b; sh->phase[13] += 0; }
   for (int k = 0; k < parts; k++) {
-    for (int i = threadIdx.x; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
-    if (threadIdx.x == 0) sh->flag = 0;
+    for (int i = KH_TIDX; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
+    if (KH_TIDX == 0) sh->flag = 0;
     KhSync();
     // (B) insert.  A link that an earlier part resolved holds its token index (>= 0), a rejected one -1,
     // an unresolved one -2 - (next state + flags).  kMU
@@ -1849,8 +1869,13 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     constexpr int kMU = 4;
     // a lane's kMU = 4 consecutive candidates: one 16-byte load per array (element by element, clamped, in the frame's last group)
     bool last_read = false;   // (D) of the last part is the last read of the candidates' cost and state before pruning
+    bool dst_only = false;    // (D) in reference order: the costs are not looked at again (every live candidate has been accepted; NaNs never got here)
     auto load_group = [&](int base, float (&tc)[kMU], int32_t (&nsv)[kMU]) {
-      if (base + kMU <= link_frame_e) {
+      if (kLocal && dst_only && base + kMU <= link_frame_e) {
+        const KhInt4 n4 = last_read ? Load4I_NT(e_dst, base) : Load4I(e_dst, base);
+        tc[0] = 0.0f; tc[1] = 0.0f; tc[2] = 0.0f; tc[3] = 0.0f;
+        nsv[0] = n4.x; nsv[1] = n4.y; nsv[2] = n4.z; nsv[3] = n4.w;
+      } else if (base + kMU <= link_frame_e) {
 #ifndef KH_NO_NT
         const KhFloat4 t4 = last_read ? Load4F_NT(e_k, base) : Load4F(e_k, base);
         const KhInt4 n4 = last_read ? Load4I_NT(e_dst, base) : Load4I(e_dst, base);
@@ -1878,15 +1903,15 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     float tc[kMU], tc_next[kMU];
     int32_t nsv[kMU], nsv_next[kMU];
     {
-      const int base0 = link_frame_b + threadIdx.x * kMU;
+      const int base0 = link_frame_b + KH_TIDX * kMU;
       if (base0 < link_frame_e) load_group(base0, tc, nsv);
     }
-    for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
+    for (int base = link_frame_b + KH_TIDX * kMU; base < link_frame_e; base += NT * kMU) {
 #ifdef KH_P2_PREFETCH
       const bool more = base + NT * kMU < link_frame_e;
 #else
       const bool more = false;
-      if (base != link_frame_b + static_cast<int>(threadIdx.x) * kMU) load_group(base, tc, nsv);
+      if (base != link_frame_b + static_cast<int>(KH_TIDX) * kMU) load_group(base, tc, nsv);
 #endif
       if (more) load_group(base + NT * kMU, tc_next, nsv_next);
 #pragma unroll
@@ -1928,7 +1953,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     if (Uni(sh->flag) != 0) {  // redo from this part on with twice as many parts (nothing was written yet)
       KhSync();                // (every lane has read the flag before it is reset)
       if (parts >= (1 << 20)) {
-        if (threadIdx.x == 0) sh->status = 5;
+        if (KH_TIDX == 0) sh->status = 5;
         KhSync();
         return false;
       }
@@ -1940,17 +1965,17 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     const int tok_base = Uni(sh->tok_end);
     int occ[kLdsSlots / NT], off[kLdsSlots / NT], total;
 #pragma unroll
-    for (int j = 0; j < kLdsSlots / NT; j++) occ[j] = keys[threadIdx.x + j * NT] != 0u ? 1 : 0;
+    for (int j = 0; j < kLdsSlots / NT; j++) occ[j] = keys[KH_TIDX + j * NT] != 0u ? 1 : 0;
     BlockExScanK<kLdsSlots / NT>(occ, off, &total, sh);
     if (tok_base + total > tok_limit) {
-      if (threadIdx.x == 0) sh->status = 1;
+      if (KH_TIDX == 0) sh->status = 1;
       KhSync();
       return false;
     }
 #pragma unroll
     for (int j = 0; j < kLdsSlots / NT; j++) {
       if (!occ[j]) continue;
-      const int i = threadIdx.x + j * NT;
+      const int i = KH_TIDX + j * NT;
       const int32_t ns = static_cast<int32_t>(keys[i] - 1u);
       const int idx = tok_base + off[j];
       e_state[idx] = ns & kStateMask;
@@ -1981,23 +2006,44 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
         e_f0[k] = __uint_as_float(cost_enc);   // (the cost image, bit for bit: saves the closure a dependent gather)
       }
     }
-    if (threadIdx.x == 0) sh->tok_end = tok_base + total;
+    if (KH_TIDX == 0) sh->tok_end = tok_base + total;
     KhSync();
     // (D) the part's links get their token index; rejected candidates become dead links
     last_read = k + 1 == parts;
+    dst_only = kLocal;
     {
-      const int base0 = link_frame_b + threadIdx.x * kMU;
+      const int base0 = link_frame_b + KH_TIDX * kMU;
       if (base0 < link_frame_e) load_group(base0, tc, nsv);
     }
-    for (int base = link_frame_b + threadIdx.x * kMU; base < link_frame_e; base += NT * kMU) {
+    for (int base = link_frame_b + KH_TIDX * kMU; base < link_frame_e; base += NT * kMU) {
       const bool full = base + kMU <= link_frame_e;
 #ifdef KH_P2_PREFETCH
       const bool more = base + NT * kMU < link_frame_e;
 #else
       const bool more = false;
-      if (base != link_frame_b + static_cast<int>(threadIdx.x) * kMU) load_group(base, tc, nsv);
+      if (base != link_frame_b + static_cast<int>(KH_TIDX) * kMU) load_group(base, tc, nsv);
 #endif
       if (more) load_group(base + NT * kMU, tc_next, nsv_next);   // (as in (B): the next group's loads under this group's work)
+      // reference order: the group's ordinals and state ids requested WITH its costs and destinations (one 16-byte load
+      // per array) - read where they are used, inside the loop below, each was a dependent round trip behind the stores of
+      // the candidate before it (the compiler cannot move a load over a store that may alias): round 6's fine stamps
+      // had this pass at 166 k cycles per frame against the canonical kernel's 100 k
+      uint32_t ordv[kMU] = {0u, 0u, 0u, 0u};
+      int32_t csidv[kMU] = {0, 0, 0, 0};
+      if (kLocal && fuse_ord) {
+        if (full) {
+          const KhInt4 o4 = Load4I_NT(UX(x_ord), base - link_frame_b), c4 = Load4I_NT(UX(x_csid), base - link_frame_b);
+          ordv[0] = static_cast<uint32_t>(o4.x); ordv[1] = static_cast<uint32_t>(o4.y); ordv[2] = static_cast<uint32_t>(o4.z); ordv[3] = static_cast<uint32_t>(o4.w);
+          csidv[0] = c4.x; csidv[1] = c4.y; csidv[2] = c4.z; csidv[3] = c4.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < kMU; j++) {
+            const int lc = min(base + j, link_frame_e - 1) - link_frame_b;
+            ordv[j] = static_cast<uint32_t>(UX(x_ord)[lc]);
+            csidv[j] = UX(x_csid)[lc];
+          }
+        }
+      }
       bool wrote = false;
 #pragma unroll
       for (int j = 0; j < kMU; j++) {
@@ -2019,11 +2065,11 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
 #pragma nounroll
         while (keys[slot] != key) slot = (slot + step) & (kLdsSlots - 1);
         if (kLocal && fuse_ord) {
-          const uint32_t ord = static_cast<uint32_t>(UX(x_ord)[l - link_frame_b]);
+          const uint32_t ord = ordv[j];
           const uint32_t lidx = vals[slot] & 8191u;
           const uint32_t old = __hip_atomic_fetch_min(&vals[slot], (ord << 13) | lidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           nsv[j] = tok_base + static_cast<int32_t>(lidx);
-          if ((old >> 13) == 0x7FFFFu) UX(x_bkt)[nsv[j] - nb] = UX(x_csid)[l - link_frame_b];   // (the first candidate of the token to get here)
+          if ((old >> 13) == 0x7FFFFu) UX(x_bkt)[nsv[j] - nb] = csidv[j];   // (the first candidate of the token to get here)
         } else {
           nsv[j] = static_cast<int32_t>(vals[slot]);
         }
@@ -2048,7 +2094,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     if (kLocal && fuse_ord) {   // the part's insertion keys, in token order
 #pragma unroll
       for (int j = 0; j < kLdsSlots / NT; j++) {
-        const int i = threadIdx.x + j * NT;
+        const int i = KH_TIDX + j * NT;
         if (keys[i] == 0u) continue;
         const uint32_t v = vals[i];
         UX(x_q)[tok_base + static_cast<int>(v & 8191u) - nb] = v >> 13;
@@ -2065,7 +2111,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
 __device__ __forceinline__ void StageScoreRow(const Utt &u, const Params &p, Blk &sh, int frame) {
   constexpr int kU = 8;
   GP(const float) src = u.ll + static_cast<size_t>(frame) * u.ll_stride;
-  for (int c0 = threadIdx.x; c0 < p.ll_cols; c0 += NT * kU) {
+  for (int c0 = KH_TIDX; c0 < p.ll_cols; c0 += NT * kU) {
     float v[kU];
 #pragma unroll
 #ifndef KH_NO_NT
@@ -2086,14 +2132,14 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
                                 float *next_cutoff_out, int *cand_out, Blk &sh) {
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
+  if (KH_TIDX == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }  // pass 2 fills tmp_epslist (barriers in between)
   // stage the frame's acoustic scores in LDS (the barriers of GetCutoff order it
   // against the last readers of the previous row and the first readers of this one)
   StageScoreRow(u, p, sh, frame);
   Stamp(u, sh, 15);
   const Cutoff c = GetCutoff(u, p, b, e, sh);
   Stamp(u, sh, 0);
-  if (threadIdx.x == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
+  if (KH_TIDX == 0 && c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
   const float inf = INFINITY;
   float cost_offset = 0.0f;
   float est = inf;
@@ -2107,24 +2153,24 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
     // behind the header before it knows how many of them are arcs of this state (they are units of the same table;
     // the index is clamped to it) - one round trip instead of two dependent ones in front of the frame's expansion.
     const int ab = s + 1;
-    const int a0 = ab + threadIdx.x;
+    const int a0 = ab + KH_TIDX;
     KhInt4 arc0;
     arc0.x = 0; arc0.y = 0; arc0.z = 0; arc0.w = 0;
-    if (threadIdx.x < 64) arc0 = p.rec[min(a0, p.num_units - 1)];
+    if (KH_TIDX < 64) arc0 = p.rec[min(a0, p.num_units - 1)];
     const int ae = ab + p.rec[s].x;
-    if (threadIdx.x < 64 && a0 < ae) {
+    if (KH_TIDX < 64 && a0 < ae) {
       const float w = __int_as_float(arc0.z) + (cost_offset - LogLike(u, p, sh, frame, arc0.x));   // {pdf, olabel, weight, nextstate}
       const float new_weight = w + tot;
       est = fminf(est, new_weight + c.adaptive_beam);
     }
-    for (int a = a0 + (threadIdx.x < 64 ? NT : 0); a < ae; a += NT) {
+    for (int a = a0 + (KH_TIDX < 64 ? NT : 0); a < ae; a += NT) {
       const KhInt4 arc = p.rec[a];
       const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
       const float new_weight = w + tot;
       est = fminf(est, new_weight + c.adaptive_beam);
     }
   }
-  if (threadIdx.x == 0) u.cost_offset[frame] = cost_offset;  // :710-711
+  if (KH_TIDX == 0) u.cost_offset[frame] = cost_offset;  // :710-711
 
   // ---- pass 1: the emitting arcs of every token under cur_cutoff (token sweep + scan, then
   // one lane per arc): fetches the arc and the acoustic score, reduces
@@ -2191,7 +2237,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   // final next_cutoff: the value the reference's running cutoff converges to
   const float next_cutoff = BlockMinF(est, sh);
   Stamp(u, sh, 1);
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     u.femit_b[frame] = link_frame_b;
     u.femit_e[frame] = link_frame_e;
     sh->link_end = link_frame_e;
@@ -2202,7 +2248,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
   if (!EmitPass2<false>(u, sh, nb, tok_limit, link_frame_b, link_frame_e, next_cutoff)) return false;
   KhSync();
   const long long tot_arcs = BlockSumLL(my_arcs, sh);
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->arcs_expanded += tot_arcs;
     sh->wl_n[0] = sh->eps_n;  // the closure's first work list = the new tokens with epsilon arcs
   }
@@ -2242,7 +2288,7 @@ __device__ bool ProcessEmitting(const Utt &u, const Params &p, int frame, int b,
 
 // Workgroup exclusive scan of (sum, min) pairs: ONE barrier.
 __device__ __forceinline__ void BlockExScanSumMin(int v, uint32_t m, int *ex_sum, uint32_t *ex_min, int *tot_sum, uint32_t *tot_min, Blk &sh) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = KH_TIDX & 63, w = KH_TIDX >> 6;
   const int inc = WaveIncSum(v);
   const uint32_t im = WaveIncMinU(m);
   const int b1 = (sh.k_scan++) & 1, b2 = (sh.k_red++) & 1;
@@ -2287,7 +2333,7 @@ static_assert(NW * (1 << kSortBits) <= kLdsSlots, "per-wave digit histograms fit
 __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
   auto hist = LdsKeys(sh);   // [NW][1 << kSortBits]
   constexpr int kBins = 1 << kSortBits;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = KH_TIDX >> 6, lane = KH_TIDX & 63;
   const int seg = ((n + NW - 1) / NW + 63) & ~63;
   const int s0 = min(n, w * seg), s1 = min(n, s0 + seg);
   int cur = 0;
@@ -2298,7 +2344,7 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
       const Arr<const int32_t> vin = cur ? UX(x_val1) : UX(x_val0);
       const Arr<unsigned long long> kout = cur ? UX(x_key0) : UX(x_key1);
       const Arr<int32_t> vout = cur ? UX(x_val0) : UX(x_val1);
-      for (int i = threadIdx.x; i < NW * kBins; i += NT) hist[i] = 0u;
+      for (int i = KH_TIDX; i < NW * kBins; i += NT) hist[i] = 0u;
       LdsSync();
       constexpr int kTU = 4;   // tiles of a wave's segment whose loads are in flight together (the passes are latency-bound)
       for (int base = s0; base < s1; base += 64 * kTU) {
@@ -2323,7 +2369,7 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
         int mine = 0;
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
-          const int idx = threadIdx.x * kPer + j;
+          const int idx = KH_TIDX * kPer + j;
           c[j] = hist[(idx % NW) * kBins + idx / NW];
           mine += static_cast<int>(c[j]);
         }
@@ -2331,7 +2377,7 @@ __device__ int BlockRadixSort(const Utt &u, int n, int bits, Blk &sh) {
         int run = BlockExScan<true>(mine, &total, sh);
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
-          const int idx = threadIdx.x * kPer + j;
+          const int idx = KH_TIDX * kPer + j;
           hist[(idx % NW) * kBins + idx / NW] = static_cast<uint32_t>(run);
           run += static_cast<int>(c[j]);
         }
@@ -2436,7 +2482,7 @@ typedef __attribute__((address_space(3))) float *LdsF;
 typedef __attribute__((address_space(3))) int *LdsI;
 __device__ int ReplayClosureWave(LdsF ncost, LdsI nlr, LdsI dstack, LdsI newq, LdsI lcode, LdsF lw, Arr<const int32_t> queue, int n_queue,
                                  float cutoff, int n_new, Blk &sh) {
-  const int lane = threadIdx.x & 63;
+  const int lane = KH_TIDX & 63;
   int cnt = 0;
 #ifdef KH_X_STAMPS
 #define RC(k, v) do { if (lane == 0) sh->phase[96 + 44 + (k)] += (v); } while (0)
@@ -2524,7 +2570,7 @@ __device__ int ReplayClosureWave(LdsF ncost, LdsI nlr, LdsI dstack, LdsI newq, L
 // Diagnostic: cycles since the previous SubStamp / Stamp of this workgroup into phase[ph] WITHOUT moving the phase timer
 // (sub-phases of a phase that Stamp charges as a whole).
 __device__ __forceinline__ void SubStamp(const Utt &u, Blk &sh, int ph) {
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) {
     const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->phase[ph] += now - sh->t_sub;
     sh->t_sub = now;
@@ -2548,7 +2594,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
   const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
   const int nl = le - lb;
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) {
     sh->t_sub = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->phase[47] += 1; sh->phase[52] += eps_emit; sh->phase[53] += eps_n; sh->phase[54] += nl; sh->phase[55] += fe - ne_emit; sh->phase[46] += n;
   }
@@ -2557,7 +2603,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
     // (kOU tokens of a lane in flight together: the plain loop paid two dependent round trips - state, then the caller's
     // id - per trip, five trips per frame)
     constexpr int kOU = 4;
-    for (int i0 = nb + threadIdx.x; i0 < fe; i0 += NT * kOU) {
+    for (int i0 = nb + KH_TIDX; i0 < fe; i0 += NT * kOU) {
       int32_t st[kOU], sid[kOU];
       uint32_t qv[kOU];
 #pragma unroll
@@ -2581,7 +2627,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
     }
   }
   KhSync();
-  for (int j = threadIdx.x; j < eps_n; j += NT) {
+  for (int j = KH_TIDX; j < eps_n; j += NT) {
     const int tok = u.tmp_epslist[j];
     UX(x_epsidx)[tok - nb] = j;
     UX(x_nl0)[j] = 0;
@@ -2594,7 +2640,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
     }
   }
   KhSync();
-  for (int l = lb + threadIdx.x; l < le; l += NT) {
+  for (int l = lb + KH_TIDX; l < le; l += NT) {
     const int src = u.link_src[l], dst = u.link_dst[l];
     const int j = UX(x_epsidx)[src - nb];
     if (l == lb || u.link_src[l - 1] != src) UX(x_nl0)[j] = l - lb;
@@ -2613,11 +2659,11 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   SubStamp(u, sh, 48);
   // ---- the queue's initial content in list order -> x_stack[0, eps_emit)
   if (eps_emit <= 1) {
-    if (threadIdx.x == 0 && eps_emit == 1) UX(x_stack)[0] = 0;
+    if (KH_TIDX == 0 && eps_emit == 1) UX(x_stack)[0] = 0;
   } else {   // (ranking a few hundred keys by counting over an LDS copy measured 4 x slower than these four passes)
     const int sb = BlockRadixSort(u, eps_emit, bits, sh);
     const Arr<const int32_t> sorted = sb ? UX(x_val1) : UX(x_val0);
-    for (int j = threadIdx.x; j < eps_emit; j += NT) UX(x_stack)[j] = sorted[j];
+    for (int j = KH_TIDX; j < eps_emit; j += NT) UX(x_stack)[j] = sorted[j];
   }
   KhSync();
   SubStamp(u, sh, 49);
@@ -2632,12 +2678,12 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   LdsI l_code = (LdsI)LdsVals(sh);
   LdsF l_lw = (LdsF)(LdsVals(sh) + kRpLinks);
   if (in_lds) {
-    for (int j = threadIdx.x; j < eps_n; j += NT) {
+    for (int j = KH_TIDX; j < eps_n; j += NT) {
       l_ncost[j] = UX(x_ncost)[j];
       l_nlr[j] = UX(x_nl0)[j] | (UX(x_nl1)[j] << 16);
     }
-    for (int k = threadIdx.x; k < n_new; k += NT) l_newq[k] = -1;
-    for (int l = threadIdx.x; l < nl; l += NT) {
+    for (int k = KH_TIDX; k < n_new; k += NT) l_newq[k] = -1;
+    for (int l = KH_TIDX; l < nl; l += NT) {
       int code = UX(x_ord)[l];
       if (code >= 0) {
         if ((code & 0x40000000) != 0) {
@@ -2651,15 +2697,15 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
       l_lw[l] = UX(x_lw)[l];
     }
     KhSync();
-    if (threadIdx.x < 64) {
+    if (KH_TIDX < 64) {
       const int cnt = ReplayClosureWave(l_ncost, l_nlr, l_dstack, l_newq, l_code, l_lw, UX(x_stack), eps_emit, cutoff, n_new, sh);
-      if (threadIdx.x == 0) sh->x_n_new = cnt;
+      if (KH_TIDX == 0) sh->x_n_new = cnt;
     }
     KhSync();
     in_lds = Uni(sh->x_n_new) >= 0;   // (-1: the depth-first stack outgrew LDS - from memory then)
     if (in_lds) {
       bool bad = false;
-      for (int k = threadIdx.x; k < n_new; k += NT) {
+      for (int k = KH_TIDX; k < n_new; k += NT) {
         const int q = l_newq[k];
         bad |= q < 0;
         UX(x_q)[ne_emit - nb + k] = qbase + static_cast<uint32_t>(q);
@@ -2670,7 +2716,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   }
   if (!in_lds) {
     KhSync();
-    if (threadIdx.x == 0) {
+    if (KH_TIDX == 0) {
       const int cnt = ReplayClosure((GP(float))UX(x_ncost).p, (GP(int32_t))UX(x_nl0).p, (GP(int32_t))UX(x_nl1).p, (GP(int32_t))UX(x_ord).p,
                                     (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, sh, eps_emit, cutoff, nb, qbase, n_new);
       if (cnt != n_new) sh->status = cnt < 0 ? 3 : 8;
@@ -2680,12 +2726,12 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   SubStamp(u, sh, 50);
   if (Uni(sh->status) != 0) return false;
   // ---- the closure's tokens enter their buckets; key = (first occupation of the bucket, insertion key); sort
-  for (int i = ne_emit + threadIdx.x; i < fe; i += NT)
+  for (int i = ne_emit + KH_TIDX; i < fe; i += NT)
     __hip_atomic_fetch_min(&UX(x_bmin)[UX(x_bkt)[i - nb]], UX(x_q)[i - nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   KhSync();
   {
     constexpr int kOU = 4;
-    for (int i0 = threadIdx.x; i0 < n; i0 += NT * kOU) {
+    for (int i0 = KH_TIDX; i0 < n; i0 += NT * kOU) {
       int32_t bk[kOU];
       uint32_t qv[kOU], bm[kOU];
 #pragma unroll
@@ -2708,7 +2754,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   KhSync();
   {
     constexpr int kOU = 4;
-    for (int i0 = threadIdx.x; i0 < n; i0 += NT * kOU) {   // the table's invariant between frames
+    for (int i0 = KH_TIDX; i0 < n; i0 += NT * kOU) {   // the table's invariant between frames
       int32_t bk[kOU];
 #pragma unroll
       for (int k = 0; k < kOU; k++) bk[k] = UX(x_bkt)[min(i0 + k * NT, n - 1)];
@@ -2722,7 +2768,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
   const Arr<const int32_t> order = fb2 ? UX(x_val1) : UX(x_val0);
   {
     constexpr int kOU = 8;
-    for (int r0 = threadIdx.x; r0 < n; r0 += NT * kOU) {
+    for (int r0 = KH_TIDX; r0 < n; r0 += NT * kOU) {
       int32_t o[kOU];
 #pragma unroll
       for (int k = 0; k < kOU; k++) o[k] = order[min(r0 + k * NT, n - 1)];
@@ -2756,7 +2802,7 @@ __device__ bool OrderFrontierSort(const Utt &u, const Params &p, int nb, int fe,
 constexpr int kFastN = 65535, kFastNew = 1024, kFastMulti = 2 * kLdsSlots;
 
 // The lane's index in the workgroup as a value the optimizer cannot see through.  The persistent kernel is one loop over
-// frames around everything; with plain threadIdx.x the loop-invariant code motion hoists every `tid * 8 + j`, `w < W`
+// frames around everything; with plain KH_TIDX the loop-invariant code motion hoists every `tid * 8 + j`, `w < W`
 // and LDS address out of that loop, the 64-register budget cannot hold them, and each USE becomes a scratch_load with its
 // own s_waitcnt vmcnt(0) - the round-5 listing of the 8-word LDS scans below had sixteen of those in a row (24 k cycles
 // for a scan whose arithmetic takes a few hundred).  An opaque copy makes the address arithmetic a per-call VALU
@@ -2821,16 +2867,16 @@ __device__ __forceinline__ int BitRank(LdsU32 bits, LdsU32 pre, uint32_t q) {   
 // stack outgrew it) and the replay by one lane.  x_epsidx must hold -1 for every token of the frame.
 __device__ void ReplayFromMemory(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, uint32_t qbase, Blk &sh) {
   const int ne_emit = Uni(sh->x_ne_emit), eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n), n_new = fe - ne_emit;
-  for (int j = threadIdx.x; j < eps_n; j += NT) {
+  for (int j = KH_TIDX; j < eps_n; j += NT) {
     const int tok = u.tmp_epslist[j];
     UX(x_epsidx)[tok - nb] = j;
     UX(x_nl0)[j] = 0;
     UX(x_nl1)[j] = 0;
     UX(x_ncost)[j] = j < eps_emit ? Dec(UX(x_c0e)[j]) : INFINITY;
   }
-  for (int i = ne_emit + threadIdx.x; i < fe; i += NT) UX(x_q)[i - nb] = 0xFFFFFFFFu;
+  for (int i = ne_emit + KH_TIDX; i < fe; i += NT) UX(x_q)[i - nb] = 0xFFFFFFFFu;
   KhSync();
-  for (int l = lb + threadIdx.x; l < le; l += NT) {
+  for (int l = lb + KH_TIDX; l < le; l += NT) {
     const int src = u.link_src[l], dst = u.link_dst[l];
     const int j = UX(x_epsidx)[src - nb];
     if (l == lb || u.link_src[l - 1] != src) UX(x_nl0)[j] = l - lb;
@@ -2845,7 +2891,7 @@ __device__ void ReplayFromMemory(const Utt &u, const Params &p, int nb, int fe, 
     UX(x_lw)[l - lb] = __int_as_float(p.n_arcs[-1 - u.link_arc[l]].z);
   }
   KhSync();
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     const int cnt = ReplayClosure((GP(float))UX(x_ncost).p, (GP(int32_t))UX(x_nl0).p, (GP(int32_t))UX(x_nl1).p, (GP(int32_t))UX(x_ord).p,
                                   (GP(float))UX(x_lw).p, (GP(int32_t))UX(x_stack).p, 0, u, sh, eps_emit, cutoff, nb, qbase, n_new);
     if (cnt != n_new) sh->status = cnt < 0 ? 3 : 8;
@@ -3687,7 +3733,7 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
   const bool fast = p.exact_order == 1 && n >= 1 && n <= kFastN && 2u * ((H + 31u) >> 5) <= static_cast<uint32_t>(kLdsSlots) && n_new <= kFastNew &&
                     Uni(sh->x_qbase) < 0x7fffffffu;
   long long t0 = 0;
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) {
     t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->phase[n <= 8160 ? 61 : (n <= 16384 ? 62 : 63)] += 1;
   }
@@ -3696,19 +3742,19 @@ __device__ bool OrderFrontier(const Utt &u, const Params &p, int nb, int fe, int
   if (fast) rc = OrderFrontierLds(u, p, nb, fe, lb, le, cutoff, sh);
 #endif
   if (fast && rc == 2) rc = OrderFrontierFast(u, p, nb, fe, lb, le, cutoff, sh);
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) {
     const long long t1 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (rc == 1) sh->phase[59] += t1 - t0;
     t0 = t1;
   }
   if (rc == 2) {
 #ifdef KH_X_NO_SORT
-    if (threadIdx.x == 0) sh->status = 9;
+    if (KH_TIDX == 0) sh->status = 9;
     rc = 0;
 #else
     rc = OrderFrontierSort(u, p, nb, fe, lb, le, cutoff, sh) ? 1 : 0;
 #endif
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) {
       sh->phase[60] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - t0;
       sh->phase[57] += 1;
     }
@@ -3736,7 +3782,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   const int nb = Uni(sh->tok_end);  // first token of frame + 1
   const int tok_limit = min(u.tok_cap, nb + u.tok_frame_cap);
   const int n = e - b;
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }
+  if (KH_TIDX == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->eps_n = 0; sh->erel_n = 0; }
   XS(27);
   StageScoreRow(u, p, sh, frame);
   Stamp(u, sh, 15);
@@ -3745,7 +3791,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   Stamp(u, sh, 0);
   XS(25);
   const int link_frame_b = Uni(sh->link_end);
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     if (c.count > sh->max_tokens_frame) sh->max_tokens_frame = c.count;
     // PossiblyResizeHash(tok_cnt) :219-225
     const uint32_t new_sz = static_cast<uint32_t>(static_cast<float>(c.count) * p.hash_ratio);
@@ -3759,14 +3805,14 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const int32_t s = u.tok_state[c.best_tok];
     const float tot = c.best_cost;
     const int ab = s + 1, ae = ab + p.rec[s].x;
-    for (int a = ab + threadIdx.x; a < ae; a += NT) {   // :692-704
+    for (int a = ab + KH_TIDX; a < ae; a += NT) {   // :692-704
       const KhInt4 arc = p.rec[a];
       const float w = __int_as_float(arc.z) + (cost_offset - LogLike(u, p, sh, frame, arc.x));
       const float new_weight = w + tot;
       est = fminf(est, new_weight + c.adaptive_beam);
     }
   }
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     u.cost_offset[frame] = cost_offset;  // :710-711
     sh->work_cursor = b;
     sh->link_cursor = link_frame_b;
@@ -3790,7 +3836,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   const float est0 = BlockMinF(est, sh);   // (its barrier publishes the cursors)
   XS(59);
   constexpr int kCB = 16;
-  if (threadIdx.x < kCB) sh->x_cb[threadIdx.x] = Enc(est0);
+  if (KH_TIDX < kCB) sh->x_cb[KH_TIDX] = Enc(est0);
   // run of positions a token belongs to: pos >> bshift, at most kCB runs
   const int bshift = n > kCB ? 32 - __clz(n - 1) - 4 : 0;
   const int limit = min(u.link_cap, link_frame_b + u.link_frame_cap);
@@ -3814,16 +3860,26 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   constexpr int kMidBits = 0, kMidBitBase = 0;
   const bool mid_scan = false;
 #endif
+  // Round 6: in the two LDS tiers the sweep leaves every candidate's place in the walk as (list position of its source
+  // token) << 16 | (index of the arc among the token's arcs) in x_ord; the acceptance sweep turns it into the ordinal with
+  // the scan's results alone - it used to read the candidate's source and arc and GATHER the source's position and state
+  // (two gathers per candidate), and the candidates' source / arc words, not read again before pruning, go out with
+  // non-temporal stores as in the canonical sweep.
+#ifndef KH_X_NO_KEY_ORD
+  const bool key_ord = (lds_scan || mid_scan) && p.max_emit < 65536;
+#else
+  const bool key_ord = false;
+#endif
   const LdsU32 sK = (LdsU32)LdsKeys(sh);
   const LdsU32 sV = (LdsU32)LdsVals(sh);
   if (lds_scan)
-    for (int w = n + static_cast<int>(threadIdx.x); w < n + ((n + 31) >> 5); w += NT) sK[w] = 0u;
+    for (int w = n + static_cast<int>(KH_TIDX); w < n + ((n + 31) >> 5); w += NT) sK[w] = 0u;
   if (mid_scan) {
-    for (int w = threadIdx.x; w < kMidBits; w += NT) sV[kMidBitBase + w] = 0u;
-    if (threadIdx.x == 0) sh->x_nbp = 0;
+    for (int w = KH_TIDX; w < kMidBits; w += NT) sV[kMidBitBase + w] = 0u;
+    if (KH_TIDX == 0) sh->x_nbp = 0;
   }
   LdsSync();
-  const int lane = threadIdx.x & 63;
+  const int lane = KH_TIDX & 63;
   long long my_arcs = 0;
   // inclusive minimum over the lanes that have the same owner (the lanes of a token are consecutive and `lo` is
   // non-decreasing): the wave scan with a segment test, on DPP
@@ -3851,11 +3907,17 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   int base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
   uint32_t co_next = 0u;
   int st_next = 0, pos_next = 0;
+  // (round 6) hc_next: the emitting-arc count in the header of the next claim's states, requested while the current claim's
+  // batches are in flight - the count used to be the first of a claim's dependent round trips (state -> header -> arcs)
+  int hc_next = 0;
   if (base_next < e) {
     const int icn = min(base_next + lane, e - 1);
     co_next = LoadCostEnc(&x_cost[icn]);
     st_next = x_state[icn];
     pos_next = xp_pos[icn - b];
+#ifndef KH_X_NO_CNT_PREFETCH
+    hc_next = x_rec[st_next].x;
+#endif
   }
   for (;;) {
     const int base = base_next;
@@ -3865,6 +3927,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     const uint32_t co = co_next;
     int st = st_next;
     const int pos = pos_next;
+    const int hc = hc_next;
     const int blk = pos >> bshift;
     base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
     if (base_next < e) {
@@ -3873,18 +3936,24 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       st_next = x_state[icn];
       pos_next = xp_pos[icn - b];
     }
+    bool hc_asked = false;
     KH_BOUND(1, st, 0, 0x7ffffff0);
     const bool need = in_range && Dec(co) <= c.cur_cutoff;
     int ab = 0, cnt = 0;
     if (need) {
       ab = st + 1;
+#ifndef KH_X_NO_CNT_PREFETCH
+      cnt = hc;
+#else
       cnt = x_rec[st].x;
+#endif
     }
     const float bnd = Dec(__hip_atomic_load(&sh->x_cb[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     const int inc = WaveIncSum(cnt);
     const int loff = inc - cnt;
     const int total = WaveLast(inc);
     const int rel = ab - loff;   // arc index = rel(owner) + slot
+    const int pk = (pos << 16) - loff;   // (position << 16 | arc's index within the token) = pk(owner) + slot
     const float cof = Dec(co);
     os.carry = -1;
     float acc = inf;   // min(tot_cost + adaptive_beam) over this token's arcs under the bound, in the batches before the current one
@@ -3934,21 +4003,46 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
         const int at = WaveLdsFetchAdd(&sh->link_cursor, n_keep);
         if (at + n_keep > limit) {
           if (lane == 0) sh->status = (at + n_keep > u.link_cap) ? 2 : 3;
-        } else if (keep) {
-          const int l = at + LanePrefixCount(kb);
-          x_dst[l] = -2 - arc.w;
-          x_src[l] = base + lo;
-          x_arc[l] = ai;
+        } else {
+          const int o_pk = key_ord ? ShflI(pk, lo) : 0;
+          if (keep) {
+            const int l = at + LanePrefixCount(kb);
+            x_dst[l] = -2 - arc.w;
 #ifndef KH_NO_NT
-          if (x_keep_ac) __builtin_nontemporal_store(ac, &x_a[l]);   // (not read before the next pruning visit)
+            if (key_ord) {
+              __builtin_nontemporal_store(base + lo, &x_src[l]);
+              __builtin_nontemporal_store(ai, &x_arc[l]);
+              xp_ord[l - link_frame_b] = o_pk + q;
+            } else {
+              x_src[l] = base + lo;
+              x_arc[l] = ai;
+            }
+            if (x_keep_ac) __builtin_nontemporal_store(ac, &x_a[l]);   // (not read before the next pruning visit)
 #else
-          if (x_keep_ac) x_a[l] = ac;
+            x_src[l] = base + lo;
+            x_arc[l] = ai;
+            if (key_ord) xp_ord[l - link_frame_b] = o_pk + q;
+            if (x_keep_ac) x_a[l] = ac;
 #endif
-          x_k[l] = tot;
-          xp_csid[l - link_frame_b] = arc.y;   // the caller's id of the destination state (ArcPdfKernel)
+            x_k[l] = tot;
+#if !defined(KH_NO_NT) && !defined(KH_X_NO_NT_AUX)
+            __builtin_nontemporal_store(arc.y, &xp_csid[l - link_frame_b]);   // the caller's id of the destination state (ArcPdfKernel); read once, by pass 2
+#else
+            xp_csid[l - link_frame_b] = arc.y;   // the caller's id of the destination state (ArcPdfKernel)
+#endif
+          }
         }
       }
+#ifndef KH_X_NO_CNT_PREFETCH
+      if (!hc_asked) {   // behind the claim's FIRST batch: the next claim's states have landed (they were asked for before this batch's arcs)
+        hc_asked = true;
+        if (base_next < e) hc_next = x_rec[st_next].x;
+      }
+#endif
     }
+#ifndef KH_X_NO_CNT_PREFETCH
+    if (!hc_asked && base_next < e) hc_next = x_rec[st_next].x;   // (a claim without arcs)
+#endif
     if (in_range) {
       const uint32_t me = Enc(acc);   // (+inf for a token none of whose arcs came under the bound)
       if (lds_scan) {
@@ -4165,6 +4259,35 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
       float ks[kOU];
       int srcs[kOU], ords[kOU], as[kOU];
       uint32_t rs[kOU];
+      if (key_ord) {   // the candidate's (position, arc index) as the sweep left it: no gather
+        const LdsU32 K = (LdsU32)LdsKeys(sh), V = (LdsU32)LdsVals(sh);
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          const int l = min(l0 + k * NT, link_frame_e - 1);
+          ks[k] = x_k[l];
+          ords[k] = xp_ord[l - link_frame_b];
+        }
+#pragma unroll
+        for (int k = 0; k < kOU; k++) {
+          const int ps = static_cast<int>(static_cast<uint32_t>(ords[k]) >> 16);
+          ords[k] &= 0xffff;
+          if (lds_scan) {
+            rs[k] = V[ps];
+            as[k] = static_cast<int>(K[ps]);
+          } else {
+            as[k] = static_cast<int>(ps < kLdsSlots ? K[ps] : V[ps - kLdsSlots]);
+            rs[k] = r_final;
+            if (ks[k] > Dec(r_final)) {   // (rare) above the final cutoff: the value that held in front of its source token
+              uint32_t r = r_start;
+              for (int q = 0; q < n_bp; q++) {
+                const uint32_t v = static_cast<uint32_t>(UX(x_h)[q]);
+                if (xp_c[q] <= ps && v < r) r = v;
+              }
+              rs[k] = r;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < kOU; k++) {
         const int l = min(l0 + k * NT, link_frame_e - 1);
@@ -4214,13 +4337,18 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           as[k] = xp_c[srcs[k] - b];
         }
       }
+      }
 #pragma unroll
       for (int k = 0; k < kOU; k++) {
         const int l = l0 + k * NT;
         if (l >= link_frame_e) continue;
         if (ks[k] > Dec(rs[k])) x_dst[l] = -1;   // the reference's `continue`: nothing was made of this arc
         else n_acc++;
+#if !defined(KH_NO_NT) && !defined(KH_X_NO_NT_AUX)
+        __builtin_nontemporal_store(ords[k] + as[k], &xp_ord[l - link_frame_b]);   // (read once, by pass 2)
+#else
         xp_ord[l - link_frame_b] = ords[k] + as[k];
+#endif
       }
     }
   }
@@ -4332,7 +4460,7 @@ template <bool kEps, bool kAccum, bool kExcise, bool kList = false>
 __device__ __forceinline__ int PruneLinkPass(const Utt &u, int lo, int hi, int b, float lb, const Acc &acc, bool fresh,
                                              __attribute__((address_space(3))) int *list_n = nullptr) {
   int flags = 0;
-  for (int base = lo + threadIdx.x; base < hi; base += NT * PU) {
+  for (int base = lo + KH_TIDX; base < hi; base += NT * PU) {
     int l[PU], dst[PU], src[PU];
     float kk[PU];
 #pragma unroll
@@ -4387,14 +4515,14 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
                                   int tb, int te, bool fresh, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY;
   const float lb = p.lattice_beam;
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; }
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) { sh->phase[10] += 1; sh->phase[11] += e - b; }
   long long tp = 0;
-  const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0 && e - b > NT;
+  const bool prof = u.phase_cycles != nullptr && KH_TIDX == 0 && e - b > NT;
   if (prof) tp = static_cast<long long>(__builtin_amdgcn_s_memtime());
 #define KH_PRUNE_STAMP(k) do { if (prof) { const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tp; tp = now_; } } while (0)
   // P0 (tokens): start the accumulator of the emitting links.  (tmp_acc1, the one of
   // the epsilon links, is +inf for every token outside this function.)
-  if (threadIdx.x == 0) { sh->wl_n[0] = 0; sh->pr_moved = 0; }
+  if (KH_TIDX == 0) { sh->wl_n[0] = 0; sh->pr_moved = 0; }
   Acc acc0, acc1;
   acc0.lds = e - b <= kLdsSlots;  // (uniform) the LDS of the emitting pass's token table is idle here
   acc0.l = LdsVals(sh);
@@ -4402,7 +4530,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   acc1.lds = false;
   acc1.l = nullptr;
   acc1.g = u.tmp_acc1;
-  for (int base = b + threadIdx.x; base < e; base += NT * PU) {
+  for (int base = b + KH_TIDX; base < e; base += NT * PU) {
     int i[PU], st[PU];
     uint32_t co[PU];
 #pragma unroll
@@ -4423,7 +4551,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     }
   }
   // PruneTokensForFrame(f + 1): its extra_costs are final, nothing below reads its states
-  for (int i = tb + threadIdx.x; i < te; i += NT)
+  for (int i = tb + KH_TIDX; i < te; i += NT)
     if (u.tok_state[i] >= 0 && LoadExtra(&u.tok_extra[i]) == inf) u.tok_state[i] = -1;
   KhSync();
   KH_PRUNE_STAMP(20);
@@ -4453,7 +4581,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     n_moved += (fabsf(v - entry) > delta ? 1 : 0) - (fabsf(old - entry) > delta ? 1 : 0);
     if (a1 != kEncInf) u.tmp_acc1[i - b] = kEncInf;
   };
-  for (int i = b + threadIdx.x; i < e; i += NT) {  // T0 (tmp_acc1 is +inf for every token here)
+  for (int i = b + KH_TIDX; i < e; i += NT) {  // T0 (tmp_acc1 is +inf for every token here)
     const uint32_t a0 = acc0.Get(i - b);
     const int st = u.tok_state[i];
     const float old = LoadExtra(&u.tok_extra[i]);
@@ -4461,7 +4589,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
     bool changed = false;
     settle(i, a0, kEncInf, st, old, old, changed);
   }
-  if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
+  if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[14] += 1;
   if (ne > nb) {
     for (int iter = 0;; iter++) {
       KhSync();  // the extra_costs of the previous token sweep are in place
@@ -4470,7 +4598,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
       KhSync();
       bool again = false;
       const int n_list = Uni(sh->wl_n[0]);
-      for (int q = threadIdx.x; q < n_list; q += NT) {
+      for (int q = KH_TIDX; q < n_list; q += NT) {
         const int i = u.tmp_work0[q];
         const uint32_t a1 = LoadCostEnc(&u.tmp_acc1[i - b]), a0 = acc0.Get(i - b);
         const int st = u.tok_state[i];
@@ -4480,12 +4608,12 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
         // (L2 read: the marks were set by atomics, which do not refresh this CU's L1)
         if (changed && (__hip_atomic_load(&u.tmp_dirty[i - b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0) again = true;
       }
-      if (u.phase_cycles != nullptr && threadIdx.x == 0) sh->phase[14] += 1;
+      if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[14] += 1;
       if (!BlockAny(again, sh)) break;
     }
     // bit 0 of the listed owners (bit 1 of the destinations is cleared by the excise pass below)
     const int n_list = Uni(sh->wl_n[0]);
-    for (int q = threadIdx.x; q < n_list; q += NT) u.tmp_dirty[u.tmp_work0[q] - b] = 0;
+    for (int q = KH_TIDX; q < n_list; q += NT) u.tmp_dirty[u.tmp_work0[q] - b] = 0;
   }
   if (n_moved != 0) __hip_atomic_fetch_add(&sh->pr_moved, n_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   KH_PRUNE_STAMP(22);
@@ -4511,7 +4639,7 @@ constexpr int kPruneLdsTok = kLdsSlots / 2;  // 4096
 __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
                               bool prune_toks_f1, bool fresh, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY, lb = p.lattice_beam;
-  const int t = threadIdx.x;
+  const int t = KH_TIDX;
   auto ra = LdsKeys(sh);  // 8192 words
   auto rb = LdsVals(sh);  // 8192 words
   auto s_acc0 = ra + kPruneLdsTok;                                                                  // Enc(min) over emitting links
@@ -4645,7 +4773,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
 __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
                                  bool prune_toks_f1, bool fresh, float delta, bool *extra_costs_changed, bool *links_pruned, Blk &sh) {
   const float inf = INFINITY, lb = p.lattice_beam;
-  const int t = threadIdx.x;
+  const int t = KH_TIDX;
   // 2 * kLdsSlots words in two pieces (the value and the key array of the emitting pass's table): Enc(extra_cost) of f's tokens
   auto x_lo = LdsVals(sh);
   auto x_hi = LdsKeys(sh);
@@ -4757,7 +4885,7 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
 
 // PruneTokensForFrame :450-469
 __device__ void PruneTokensForFrame(const Utt &u, int b, int e) {
-  for (int i = b + threadIdx.x; i < e; i += NT)
+  for (int i = b + KH_TIDX; i < e; i += NT)
     if (u.tok_state[i] >= 0 && LoadExtra(&u.tok_extra[i]) == INFINITY) u.tok_state[i] = -1;
   KhSync();
 }
@@ -4787,7 +4915,7 @@ __device__ __forceinline__ void StoreFlag(P p, uint8_t v) {
 // final_pass: the backward loop of FinalizeDecoding :581-586 instead - every frame below `cur`, PruneForwardLinks(f, delta = 0)
 // + PruneTokensForFrame(f + 1), whatever the flags say.
 __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Blk &sh, bool final_pass = false) {
-  if (u.phase_cycles != nullptr && threadIdx.x == 0 && !final_pass) sh->phase[12] += 1;
+  if (u.phase_cycles != nullptr && KH_TIDX == 0 && !final_pass) sh->phase[12] += 1;
   // every frame below conv_upto has been visited (a new frame has must_prune_forward_links set, and the
   // loop below cannot stop above it)
   const int conv_upto = Uni(sh->conv_upto);
@@ -4804,13 +4932,13 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     // has nothing to do the reference's remaining iterations are no-ops.
     if (!ml && !mt) break;
     long long t0 = 0;
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     if (ml) {
       bool ec, lp;
       const bool fresh = f >= conv_upto;  // the frame's first visit: its emitting links still carry tot_cost in link_k
       const int b = Uni(vb), e = Uni(ve), mb = Uni(vmb), me = Uni(vme), nb = Uni(vnb), ne = Uni(vne), b1 = Uni(vb1), e1 = Uni(ve1);
       PruneVisit(u, p, b, e, mb, me, nb, ne, b1, e1, mt, fresh, delta, &ec, &lp, sh);
-      if (threadIdx.x == 0) {
+      if (KH_TIDX == 0) {
         if (ec && f > 0) StoreFlag(&u.must_links[f - 1], 1);
         if (lp) StoreFlag(&u.must_toks[f], 1);
         StoreFlag(&u.must_links[f], 0);
@@ -4818,16 +4946,16 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
       }
     } else {  // mt
       PruneTokensForFrame(u, Uni(vb1), Uni(ve1));
-      if (threadIdx.x == 0) StoreFlag(&u.must_toks[f + 1], 0);
+      if (KH_TIDX == 0) StoreFlag(&u.must_toks[f + 1], 0);
     }
     KhSync();
-    if (u.phase_cycles != nullptr && threadIdx.x == 0) {
+    if (u.phase_cycles != nullptr && KH_TIDX == 0) {
       const int thick = (Uni(u.frame_e[f]) - Uni(u.frame_b[f]) > NT) ? 1 : 0;
       sh->phase[16 + thick] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - t0;
       sh->phase[18 + thick] += 1;
     }
   }
-  if (threadIdx.x == 0) sh->conv_upto = cur;
+  if (KH_TIDX == 0) sh->conv_upto = cur;
   KhSync();
 }
 
@@ -4864,7 +4992,7 @@ __device__ void FinalBackward(const Utt &u_in, const Params &p, int last, int fb
   KH_LAUNDER_FB(u.tok_cost.p); KH_LAUNDER_FB(u.surv_tok.p); KH_LAUNDER_FB(u.surv_link.p);
   KH_LAUNDER_FB(u.feps_b.p); KH_LAUNDER_FB(u.feps_e.p); KH_LAUNDER_FB(u.femit_b.p); KH_LAUNDER_FB(u.femit_e.p); KH_LAUNDER_FB(u.frame_b.p); KH_LAUNDER_FB(u.frame_e.p);
   const float inf = INFINITY, lb = p.lattice_beam;
-  const int t = threadIdx.x;
+  const int t = KH_TIDX;
   auto x_lo = LdsVals(sh);
   auto x_hi = LdsKeys(sh);
   auto x = [&](int i) -> __attribute__((address_space(3))) uint32_t * { return i < kLdsSlots ? &x_lo[i] : &x_hi[i - kLdsSlots]; };
@@ -5066,13 +5194,13 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
   const int old_tok_end = Uni(sh->tok_end);
   const int old_link_b = Uni(u.feps_b[w_lo]);
   if (old_tok_end - win_b > u.window_cap) {
-    if (threadIdx.x == 0) sh->status = 4;
+    if (KH_TIDX == 0) sh->status = 4;
     KhSync();
     return false;
   }
   KhSync();  // every thread has read the old ends
   long long tc = 0;
-  const bool prof = u.phase_cycles != nullptr && threadIdx.x == 0;
+  const bool prof = u.phase_cycles != nullptr && KH_TIDX == 0;
   if (prof) tc = static_cast<long long>(__builtin_amdgcn_s_memtime());
 #define KH_COMPACT_STAMP(k) do { if (prof) { const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); sh->phase[k] += now_ - tc; tc = now_; } } while (0)
   // Both slides run over the window's whole RANGE, not block by block: a frame that is one or
@@ -5089,7 +5217,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
     int base = win_b;
     for (int f0 = w_lo; f0 <= cur; f0 += kFB) {
       const int f1 = min(cur, f0 + kFB - 1), nb = f1 - f0 + 1;
-      for (int j = threadIdx.x; j < nb; j += NT) bnd[j] = u.frame_b[f0 + j];
+      for (int j = KH_TIDX; j < nb; j += NT) bnd[j] = u.frame_b[f0 + j];
       const int chunk_e = f1 == cur ? old_tok_end : Uni(u.frame_b[f1 + 1]);
       KhSync();
       int bj = 0;
@@ -5104,7 +5232,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
           int st[KC], alive[KC];
 #pragma unroll
           for (int k = 0; k < KC; k++) {
-            const int i = base + k * NT + threadIdx.x;
+            const int i = base + k * NT + KH_TIDX;
             st[k] = (k < kk && i < chunk_e) ? u.tok_state[i] : -1;
           }
 #pragma unroll
@@ -5112,7 +5240,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
           BlockExScanK<KC, true>(alive, off, &total, sh);
 #pragma unroll
           for (int k = 0; k < KC; k++) {
-            const int i = base + k * NT + threadIdx.x;
+            const int i = base + k * NT + KH_TIDX;
             if (k >= kk || i >= chunk_e) continue;
             int ni = -1;
             if (alive[k]) {
@@ -5125,7 +5253,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
           }
         } else {
           span = min(NT, chunk_e - base);
-          const int i = base + threadIdx.x;
+          const int i = base + KH_TIDX;
           int st = -1;
           uint32_t co = kEncInf;
           float ex = 0.f;
@@ -5146,7 +5274,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
         while (bj < nb) {   // the bounds inside this group
           const int q = Uni(bnd[bj]) - base;
           if (q >= span) break;
-          if (threadIdx.x == (q & (NT - 1))) {
+          if (KH_TIDX == (q & (NT - 1))) {
             int o = off[0];
 #pragma unroll
             for (int k = 1; k < KC; k++) o = (q / NT) == k ? off[k] : o;
@@ -5158,9 +5286,9 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
         base += span;
       }
       for (; bj < nb; bj++)
-        if (threadIdx.x == 0) nbn[bj] = tend;   // empty frames at the end of the batch
+        if (KH_TIDX == 0) nbn[bj] = tend;   // empty frames at the end of the batch
       KhSync();
-      for (int j = threadIdx.x; j < nb; j += NT) {
+      for (int j = KH_TIDX; j < nb; j += NT) {
         u.frame_b[f0 + j] = nbn[j];
         u.frame_e[f0 + j] = j + 1 < nb ? nbn[j + 1] : tend;
       }
@@ -5170,10 +5298,10 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
   KhSync();
   KH_COMPACT_STAMP(24);
   // arena invariant: free slots hold +inf
-  for (int i = tend + threadIdx.x; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
+  for (int i = tend + KH_TIDX; i < old_tok_end; i += NT) u.tok_cost[i] = kEncInf;
   // (b) emitting links of frame w_lo - 1 point into the window: rewrite in place
   if (w_lo > 0) {
-    for (int l = Uni(u.femit_b[w_lo - 1]) + threadIdx.x; l < Uni(u.femit_e[w_lo - 1]); l += NT) {
+    for (int l = Uni(u.femit_b[w_lo - 1]) + KH_TIDX; l < Uni(u.femit_e[w_lo - 1]); l += NT) {
       const int dst = u.link_dst[l];
       if (dst >= win_b) u.link_dst[l] = u.tmp_remap[dst - win_b];
     }
@@ -5186,7 +5314,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
     int base = old_link_b;
     for (int f0 = w_lo; f0 <= cur; f0 += kFB) {
       const int f1 = min(cur, f0 + kFB - 1), nb = 2 * (f1 - f0 + 1);
-      for (int j = threadIdx.x; j < nb; j += NT) {
+      for (int j = KH_TIDX; j < nb; j += NT) {
         const int f = f0 + (j >> 1);
         // (the emitting block of `cur` is not created yet: empty, at the end of the range)
         bnd[j] = (j & 1) ? (f == cur ? range_e : u.femit_b[f]) : u.feps_b[f];
@@ -5202,7 +5330,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
           int dst[KC], alive[KC];
 #pragma unroll
           for (int k = 0; k < KC; k++) {
-            const int l = base + k * NT + threadIdx.x;
+            const int l = base + k * NT + KH_TIDX;
             dst[k] = (k < kk && l < chunk_e) ? u.link_dst[l] : -1;
           }
 #pragma unroll
@@ -5216,7 +5344,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
 #pragma unroll
           for (int k = 0; k < KC; k++) {
             if (!alive[k]) continue;
-            const int l = base + k * NT + threadIdx.x;
+            const int l = base + k * NT + KH_TIDX;
             src[k] = u.link_src[l]; arc[k] = u.link_arc[l];
             g[k] = u.link_k[l]; a[k] = keep_ac ? u.link_a[l] : 0.0f;
           }
@@ -5236,7 +5364,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
           }
         } else {
           span = min(NT, chunk_e - base);
-          const int l = base + threadIdx.x;
+          const int l = base + KH_TIDX;
           int dst = -1, src = 0, arc = 0;
           float g = 0.f, a = 0.f;
           if (l < chunk_e) {
@@ -5259,7 +5387,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
         while (bj < nb) {   // the block bounds inside this group
           const int q = Uni(bnd[bj]) - base;
           if (q >= span) break;
-          if (threadIdx.x == (q & (NT - 1))) {
+          if (KH_TIDX == (q & (NT - 1))) {
             int o = off[0];
 #pragma unroll
             for (int k = 1; k < KC; k++) o = (q / NT) == k ? off[k] : o;
@@ -5271,9 +5399,9 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
         base += span;
       }
       for (; bj < nb; bj++)
-        if (threadIdx.x == 0) nbn[bj] = lend;   // empty blocks at the end of the batch
+        if (KH_TIDX == 0) nbn[bj] = lend;   // empty blocks at the end of the batch
       KhSync();
-      for (int j = threadIdx.x; j < nb; j += NT) {
+      for (int j = KH_TIDX; j < nb; j += NT) {
         const int f = f0 + (j >> 1);
         const int nbeg = nbn[j], nend = j + 1 < nb ? nbn[j + 1] : lend;
         if (j & 1) {
@@ -5285,7 +5413,7 @@ __device__ bool Compact(const Utt &u, int w_lo, int cur, bool keep_ac, Blk &sh) 
       KhSync();
     }
   }
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->tok_end = tend;
     sh->link_end = lend;
     sh->front_b = Uni(u.frame_b[cur]);
@@ -5315,7 +5443,7 @@ __device__ __forceinline__ int WindowFrames(const Params &p) { return (KH_COMPAC
 // InitDecoding :55-72 on a slot whose arenas hold their invariants.
 template <bool kExact = false>
 __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->tok_end = 0;
     sh->link_end = 0;
     sh->front_b = 0;
@@ -5330,12 +5458,12 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
     sh->surv_nl = 0;
     for (int i = 0; i < 4; i++) sh->sched[i] = 0;
   }
-  for (int f = threadIdx.x; f < u.T + 2; f += NT) {
+  for (int f = KH_TIDX; f < u.T + 2; f += NT) {
     u.must_links[f] = 1;  // TokenList(): must_prune_forward_links(true), must_prune_tokens(true)
     u.must_toks[f] = 1;
   }
   KhSync();
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->eps_n = 0;
     sh->erel_n = 0;
     sh->hash_dirty = 1;
@@ -5361,7 +5489,7 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   run->cand = 0;
   run->fb = 0;  // token range of the frontier frame
   run->fe = Uni(sh->tok_end);
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     u.frame_e[0] = run->fe;
     sh->tokens_created += run->fe - run->fb;
     if (run->fe > sh->tok_hw) sh->tok_hw = run->fe;
@@ -5392,12 +5520,12 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
         PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
         Stamp(u, sh, 6);
         ok = Compact(u, 0, t, p.keep_ac != 0, sh);
-        if (threadIdx.x == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; }
+        if (KH_TIDX == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; }
         KhSync();
         Stamp(u, sh, 7);
         if (!ok) break;
         last_gc = t;
-        if (threadIdx.x == 0) sh->sched[0] += 1;
+        if (KH_TIDX == 0) sh->sched[0] += 1;
         fb = Uni(u.frame_b[t]);
         fe = Uni(u.frame_e[t]);
       }
@@ -5412,7 +5540,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       // of a long utterance; a full sweep costs about a dozen frames of decoding).
       if (ok && (Uni(sh->tok_end) - Uni(sh->gc_tok) > u.tok_cap / 3 || Uni(sh->link_end) - Uni(sh->gc_link) > u.link_cap / 3)) {
         ok = Compact(u, 0, t, p.keep_ac != 0, sh);
-        if (threadIdx.x == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; }
+        if (KH_TIDX == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; }
         KhSync();
       }
       Stamp(u, sh, 7);
@@ -5436,7 +5564,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       XS(28);
       if (!ok) break;
     }
-    if (threadIdx.x == 0) {
+    if (KH_TIDX == 0) {
       u.frame_b[t + 1] = fb;
       u.frame_e[t + 1] = fe;
       sh->tokens_created += fe - fb;
@@ -5471,7 +5599,7 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
   if (ok) {
     const int last = run.t;
     float best_cost = inf, best_with_final = inf;
-    for (int i = fb + threadIdx.x; i < fe; i += NT) {
+    for (int i = fb + KH_TIDX; i < fe; i += NT) {
       const float cost = Dec(LoadCostEnc(&u.tok_cost[i]));
       const float final_cost = __int_as_float(p.rec[u.tok_state[i]].w);
       best_cost = fminf(best_cost, cost);
@@ -5495,14 +5623,14 @@ __device__ bool DecodeFinalize(const Utt &u, const Params &p, Blk &sh, const Run
       FinalBackward(u, p, last, fb, fe, sh);
     } else {
       PruneActiveTokens(u, p, last, 0.0f, sh, true);
-      if (threadIdx.x == 0) sh->conv_upto = last;
+      if (KH_TIDX == 0) sh->conv_upto = last;
       PruneTokensForFrame(u, Uni(u.frame_b[0]), Uni(u.frame_e[0]));
       // final compaction of the window so the export below copies little
       ok = Compact(u, last - WindowFrames(p), last, p.keep_ac != 0, sh);
     }
     Stamp(u, sh, 8);
   }
-  if (threadIdx.x == 0) sh->cand_mat = run.cand;
+  if (KH_TIDX == 0) sh->cand_mat = run.cand;
   KhSync();
   st.arcs_expanded = sh->arcs_expanded;
   st.tokens_created = sh->tokens_created;
@@ -5563,7 +5691,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
   // pass A: alive tokens -> dense indices (tmp_remap)
   int n_tok = 0;
   for (int base = 0; base < tok_end; base += NT) {
-    const int i = base + threadIdx.x;
+    const int i = base + KH_TIDX;
     const int alive = (i < tok_end && u.tok_state[i] >= 0) ? 1 : 0;
     int total;
     const int off = BlockExScan(alive, &total, sh);
@@ -5574,11 +5702,11 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
   int n_link = 0;
   {
     int mine = 0;
-    for (int l = threadIdx.x; l < link_end; l += NT) mine += u.link_dst[l] >= 0 ? 1 : 0;
+    for (int l = KH_TIDX; l < link_end; l += NT) mine += u.link_dst[l] >= 0 ? 1 : 0;
     n_link = static_cast<int>(BlockSumLL(mine, sh));
   }
   // allocate in the pool
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     const unsigned long long tb = __hip_atomic_fetch_add(&pool.used[0], static_cast<unsigned long long>(n_tok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long lb = __hip_atomic_fetch_add(&pool.used[1], static_cast<unsigned long long>(n_link), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out->tok_off = static_cast<long long>(tb);
@@ -5598,7 +5726,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
   KhSync();
   if (!fits) return;
   // pass C: tokens
-  for (int i = threadIdx.x; i < tok_end; i += NT) {
+  for (int i = KH_TIDX; i < tok_end; i += NT) {
     const int st = u.tok_state[i];
     if (st < 0) continue;
     const int ni = u.tmp_remap[i];
@@ -5608,7 +5736,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
   // pass D: links, in arena order
   int lrun = 0;
   for (int base = 0; base < link_end; base += NT) {
-    const int l = base + threadIdx.x;
+    const int l = base + KH_TIDX;
     const int dst = l < link_end ? u.link_dst[l] : -1;
     const int alive = dst >= 0 ? 1 : 0;
     int total;
@@ -5643,7 +5771,7 @@ __device__ void ExportLattice(const Utt &u, const Params &p, const Pool &pool, U
 // GetRawLattice :109-191 device half from the survivor lists of FinalBackward (lazy schedule): the arenas are not scanned.
 __device__ void ExportSurvivors(const Utt &u, const Params &p, const Pool &pool, UttOut *out, Blk &sh) {
   const int n_tok = Uni(sh->surv_nt), n_link = Uni(sh->surv_nl), T = u.T;
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     const unsigned long long tb = __hip_atomic_fetch_add(&pool.used[0], static_cast<unsigned long long>(n_tok), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long lb = __hip_atomic_fetch_add(&pool.used[1], static_cast<unsigned long long>(n_link), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out->tok_off = static_cast<long long>(tb);
@@ -5662,14 +5790,14 @@ __device__ void ExportSurvivors(const Utt &u, const Params &p, const Pool &pool,
   const bool fits = sh->flag != 0;
   KhSync();
   if (!fits) return;
-  for (int j = threadIdx.x; j < n_tok; j += NT) {
+  for (int j = KH_TIDX; j < n_tok; j += NT) {
     const int i = u.surv_tok[2 * j], f = u.surv_tok[2 * j + 1];
     u.tmp_remap[i] = j;
     pool.t_frame[tb + j] = f;
     pool.t_state[tb + j] = -1 - p.unit_ilabel[u.tok_state[i]];   // the caller's state id (kept in the header's slot of the label table)
   }
   KhSync();
-  for (int j = threadIdx.x; j < n_link; j += NT) {
+  for (int j = KH_TIDX; j < n_link; j += NT) {
     const int l = u.surv_link[2 * j], f = u.surv_link[2 * j + 1];
     const long long d = lbase + j;
     const int src = u.link_src[l], dst = u.link_dst[l], arc = u.link_arc[l];
@@ -5718,7 +5846,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
   Launder(u);
   Launder(p);
   u.phase_cycles = phase_cycles ? phase_cycles + NPH * blockIdx.x : (GP(long long))nullptr;
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
     sh->t_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
     sh->tok_hw = 0;
@@ -5734,7 +5862,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
 #endif
   KhSync();
   for (;;) {
-    if (threadIdx.x == 0) sh->bcast_i[3] = static_cast<int>(__hip_atomic_fetch_add(&pool.used[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (KH_TIDX == 0) sh->bcast_i[3] = static_cast<int>(__hip_atomic_fetch_add(&pool.used[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     KhSync();
     const int ui = Uni(sh->bcast_i[3]);
     KhSync();
@@ -5743,16 +5871,16 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     u.T = in[ui].T;
     // restore the arena invariants left dirty by the previous utterance of this slot
     const int hw = sh->tok_hw;
-    for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
-    for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+    for (int i = KH_TIDX; i < hw; i += NT) u.tok_cost[i] = kEncInf;
+    for (uint32_t i = KH_TIDX; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
     // (a capacity overflow aborts a frame with work-list flags still set: clear them too)
-    for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
+    for (int i = KH_TIDX; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
     if (kExact)   // (an aborted frame may have left bucket minima behind)
-      for (int i = threadIdx.x; i < sh.x->x_hcap; i += NT) UX(x_bmin)[i] = 0xFFFFFFFFu;
+      for (int i = KH_TIDX; i < sh.x->x_hcap; i += NT) UX(x_bmin)[i] = 0xFFFFFFFFu;
     KhSync();
     KhDecodeStats st;
     DecodeOne<kLazy, kExact>(u, p, sh, &st);
-    if (threadIdx.x == 0) {
+    if (KH_TIDX == 0) {
       out[ui].stats = st;
       for (int i = 0; i < 4; i++) out[ui].sched[i] = sh->sched[i];
       out[ui].cand_mat = sh->cand_mat;
@@ -5767,14 +5895,14 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
     // next ones.  Every wave's stores are complete behind KhSync(); thread 0 then releases
     // at system scope and appends the utterance to the list the host threads poll.
     KhSync();
-    if (done_list != nullptr && threadIdx.x == 0) {
+    if (done_list != nullptr && KH_TIDX == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
       const unsigned long long pos = __hip_atomic_fetch_add(&pool.used[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&done_list[pos], static_cast<int32_t>(ui), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     Stamp(u, sh, 9);
   }
-  if (threadIdx.x == 0 && u.phase_cycles != nullptr)
+  if (KH_TIDX == 0 && u.phase_cycles != nullptr)
     for (int i = 0; i < NPH; i++) u.phase_cycles[i] = sh->phase[i];
 }
 
@@ -5802,7 +5930,7 @@ struct Job {
 };
 
 __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     sh->tok_end = S.tok_end; sh->link_end = S.link_end; sh->front_b = S.front_b; sh->status = S.status;
     sh->max_tokens_frame = S.max_tokens_frame; sh->tok_hw = S.tok_hw; sh->gc_tok = S.gc_tok; sh->gc_link = S.gc_link;
     sh->arcs_expanded = S.arcs_expanded; sh->tokens_created = S.tokens_created; sh->conv_upto = S.conv_upto;
@@ -5815,7 +5943,7 @@ __device__ void LoadState(const SlotState &S, Blk &sh, Run *run) {
 }
 __device__ void SaveState(SlotState *S, Blk &sh, const Run &run, bool ok) {
   KhSync();
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     S->tok_end = sh->tok_end; S->link_end = sh->link_end; S->front_b = sh->front_b; S->status = sh->status;
     S->max_tokens_frame = sh->max_tokens_frame; S->tok_hw = sh->tok_hw; S->gc_tok = sh->gc_tok; S->gc_link = sh->gc_link;
     S->arcs_expanded = sh->arcs_expanded; S->tokens_created = sh->tokens_created; S->conv_upto = sh->conv_upto;
@@ -5850,7 +5978,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
   Launder(p);
   SlotState *S = &states[job.slot];
   u.phase_cycles = (GP(long long))nullptr;
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
     for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
     sh->hash_dirty = 0;
@@ -5861,14 +5989,14 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
     // arena invariants (a previous utterance of this stream may have left them dirty)
     const int hw = S->tok_hw;
     KhSync();
-    for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
-    for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
-    for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
-    if (threadIdx.x == 0) sh->tok_hw = 0;
+    for (int i = KH_TIDX; i < hw; i += NT) u.tok_cost[i] = kEncInf;
+    for (uint32_t i = KH_TIDX; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+    for (int i = KH_TIDX; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
+    if (KH_TIDX == 0) sh->tok_hw = 0;
     KhSync();
     const bool ok = DecodeInit<kExact>(u, p, sh, &run);
     SaveState(S, sh, run, ok);
-    if (threadIdx.x == 0) S->finalized = 0;
+    if (KH_TIDX == 0) S->finalized = 0;
   } else if (job.op == kJobAdvance) {
     LoadState(*S, sh, &run);
     u.ll = job.ll;
@@ -5881,7 +6009,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
     KhDecodeStats st;
     const bool ok = p.lazy_prune ? DecodeFinalize<true>(u, p, sh, run, S->ok != 0, &st) : DecodeFinalize<false>(u, p, sh, run, S->ok != 0, &st);
     SaveState(S, sh, run, ok);
-    if (threadIdx.x == 0) { S->finalized = 1; S->stats = st; }
+    if (KH_TIDX == 0) { S->finalized = 1; S->stats = st; }
   } else {  // kJobExport: snapshot of the current lattice
     LoadState(*S, sh, &run);
     u.T = run.t;
@@ -5892,7 +6020,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
       // prune_interval; best paths and the final lattice do not depend on it (Params::lazy_prune).
       PruneActiveTokens(u, p, run.t, p.lattice_beam * p.prune_scale, sh);
       const bool okc = Compact(u, 0, run.t, p.keep_ac != 0, sh);
-      if (threadIdx.x == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; sh->sched[0] += 1; }
+      if (KH_TIDX == 0) { sh->gc_tok = sh->tok_end; sh->gc_link = sh->link_end; sh->sched[0] += 1; }
       KhSync();
       run.fb = Uni(u.frame_b[run.t]);
       run.fe = Uni(u.frame_e[run.t]);
@@ -5905,7 +6033,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
     float frc = INFINITY, fbest = INFINITY;
     if (!S->finalized) {
       float best_cost = INFINITY, best_with_final = INFINITY;
-      for (int i = run.fb + threadIdx.x; i < run.fe; i += NT) {
+      for (int i = run.fb + KH_TIDX; i < run.fe; i += NT) {
         const float cost = Dec(LoadCostEnc(&u.tok_cost[i]));
         const float final_cost = __int_as_float(p.rec[u.tok_state[i]].w);
         best_cost = fminf(best_cost, cost);
@@ -5916,7 +6044,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
       frc = (best_cost == INFINITY && best_with_final == INFINITY) ? INFINITY : best_with_final - best_cost;
       fbest = best_with_final != INFINITY ? best_with_final : best_cost;
     }
-    if (threadIdx.x == 0) {
+    if (KH_TIDX == 0) {
       KhDecodeStats st = S->stats;
       if (!S->finalized) {
         st.num_frames = run.t; st.reached_final = 0; st.final_relative_cost = frc; st.final_best_cost = fbest;
@@ -6017,7 +6145,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   u.phase_cycles = (GP(long long))nullptr;
   u.ll = (GP(const float))(ll_base + static_cast<size_t>(s) * ll_rows_per_stream * ll_stride);
   u.ll_stride = ll_stride;
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     for (int i = 0; i < NPH; i++) sh->phase[i] = 0;
     for (int i = 0; i < 4; i++) sh->orbuf[i] = 0;
     sh->hash_dirty = 0;
@@ -6029,15 +6157,15 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   bool fin = S->finalized != 0;
   int acked = c->ack_seq;   // (the host set cmd_seq = ack_seq before the launch)
   long long t_idle = wall_clock64(), t_scan = t_idle;
-  int n_actions = 0;
-  if (threadIdx.x == 0) {
+  int n_actions = 0, idle_polls = 0;
+  if (KH_TIDX == 0) {
     __hip_atomic_store(&act_clock[s], t_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SysStore(&c->hb_phase, 0);
     SysStore(&c->hb_clock, static_cast<int32_t>(t_idle));
     SysStore(&c->alive, 1);
   }
   for (;;) {
-    if (threadIdx.x == 0) {
+    if (KH_TIDX == 0) {
       int act = 0, arg = 0;
       const KhI4 w = SysLoad16(c);      // {avail, cmd_seq, cmd_op, pad0}
       const int av = w.x, seq = w.y, op = w.z;
@@ -6074,21 +6202,32 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
     const int act = Uni(sh->bcast_i[0]), arg = Uni(sh->bcast_i[1]), seq = Uni(sh->bcast_i[2]);
     KhSync();
     if (act == 0) {
-      __builtin_amdgcn_s_sleep(127);
+      // Back off while nothing happens: every poll is a read of the host's memory across the bus, 256 resident workgroups
+      // polling every 3.4 us are 75 M reads a second in front of the packets the command processor fetches for the host's
+      // own kernels (the forward pass of the next chunk): a stream that has polled in vain a few times waits 14, then 27 us
+      // between polls (a chunk is 1.5 - 4 ms of work away; the first polls after an action stay at full rate).
+#ifndef KH_SERVE_NO_BACKOFF
+      idle_polls++;
+      const int reps = idle_polls < 8 ? 1 : (idle_polls < 32 ? 4 : 8);
+#else
+      const int reps = 1;
+#endif
+      for (int r = 0; r < reps; r++) __builtin_amdgcn_s_sleep(127);
       continue;
     }
+    idle_polls = 0;
     if (act == 4) break;
     if (act == 1) {          // InitDecoding (the body of OnlineKernel's kJobInit)
       const int hw = arg != 0 ? 0 : S->tok_hw;   // (arg: the host has reset the token arena)
       KhSync();
-      for (int i = threadIdx.x; i < hw; i += NT) u.tok_cost[i] = kEncInf;
-      for (uint32_t i = threadIdx.x; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
-      for (int i = threadIdx.x; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
-      if (threadIdx.x == 0) sh->tok_hw = 0;
+      for (int i = KH_TIDX; i < hw; i += NT) u.tok_cost[i] = kEncInf;
+      for (uint32_t i = KH_TIDX; i <= u.hash_mask; i += NT) u.hash[i] = kEmpty;
+      for (int i = KH_TIDX; i < u.tok_frame_cap; i += NT) { u.tmp_acc1[i] = kEncInf; u.tmp_dirty[i] = 0; }
+      if (KH_TIDX == 0) sh->tok_hw = 0;
       KhSync();
       ok = DecodeInit<kExact>(u, p, sh, &run);
       SaveState(S, sh, run, ok);
-      if (threadIdx.x == 0) S->finalized = 0;
+      if (KH_TIDX == 0) S->finalized = 0;
       fin = false;
       ok = ok && Uni(sh->status) == 0;
     } else if (act == 2) {   // AdvanceDecoding up to the frames the host has published
@@ -6102,14 +6241,14 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
       LoadState(*S, sh, &run);
       ok = p.lazy_prune ? DecodeFinalize<true>(u, p, sh, run, ok, &st) : DecodeFinalize<false>(u, p, sh, run, ok, &st);
       SaveState(S, sh, run, ok);
-      if (threadIdx.x == 0) { S->finalized = 1; S->stats = st; }
+      if (KH_TIDX == 0) { S->finalized = 1; S->stats = st; }
       fin = true;
     }
     __threadfence();   // the slot's arenas and SlotState are in memory before the acknowledgement
     KhSync();
     n_actions++;
     t_idle = wall_clock64();
-    if (threadIdx.x == 0) {
+    if (KH_TIDX == 0) {
       __hip_atomic_store(&act_clock[s], t_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (the __threadfence + barrier above have put the slot's arenas and SlotState in memory: of the stores below only the
       // LAST one - what the host waits for - needs to order the others)
@@ -6128,14 +6267,14 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
     if (act != 2) acked = seq;
   }
   KhSync();
-  if (threadIdx.x == 0) {
+  if (KH_TIDX == 0) {
     SysStore(&c->hb_phase, 9);
     SysStore(&c->alive, 0);
   }
 }
 
 __global__ void FillU32(uint32_t *p, size_t n, uint32_t v) {
-  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + KH_TIDX; i < n;
        i += static_cast<size_t>(gridDim.x) * blockDim.x)
     p[i] = v;
 }
@@ -6957,7 +7096,7 @@ int EnsureSlots(KhDecoder *d, int n_want, int T_max, hipStream_t st, int *n_slot
 // 1.2 TB of the reference-order kernel's 4.4 TB of reads.  The export reads output labels from the graph's own records then.
 __global__ void ArcPdfKernel(const int32_t *__restrict__ unit_ilabel, long long n, const int32_t *__restrict__ tid2pdf, int4 *__restrict__ rec,
                              int num_cols, int *__restrict__ bad, const int4 *__restrict__ rec0, int order_ids) {
-  for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x) {
+  for (long long a = blockIdx.x * static_cast<long long>(blockDim.x) + KH_TIDX; a < n; a += static_cast<long long>(gridDim.x) * blockDim.x) {
     const int32_t il = unit_ilabel[a];
     if (il > 0) {
       rec[a].y = order_ids ? -1 - unit_ilabel[rec0[a].w & kStateMask] : rec0[a].y;

@@ -30,11 +30,14 @@ def test_decode_kernel_spill_budget():
     # end of round 4: 19 758 instructions, 1 876 readlanes, 132 bytes of scratch, 2 ds_bpermute (the sweeps' data fetches are
     # counted per call site), 306 DPP instructions.  Generous bounds: this is a tripwire, not a benchmark.
     # round 5: 84 bytes with the machine-level loop-invariant code motion off for this file (build.py EXTRA); 132 with it on
-    assert scr_bytes <= 112, "DecodeKernel<1,0> scratch %d B per lane (84 in round 5, 132 at the end of round 4; +8..24 B cost 4-12 %%)" % scr_bytes
-    assert readlane <= 2600, "DecodeKernel<1,0> has %d v_readlane_b32 (1 804 in round 5, 1 876 at the end of round 4; 5 719 before Launder)" % readlane
+    # round 6: NO scratch - every threadIdx.x of the file behind an opaque copy (KH_TIDX in csrc/kh_decoder.hip: what the optimizer
+    # derived from the plain one was hoisted to the kernel's entry, kept live for the launch and spilled; same-box 526 -> 507 ms)
+    assert scr_bytes <= 24, "DecodeKernel<1,0> scratch %d B per lane (0 in round 6, 84 in round 5, 132 at the end of round 4; +8..24 B cost 4-12 %%)" % scr_bytes
+    assert readlane <= 1800, "DecodeKernel<1,0> has %d v_readlane_b32 (1 243 in round 6, 1 804 in round 5; 5 719 before Launder)" % readlane
     # the reference-order kernel (round 5: 204 bytes, 288 scratch loads; 304 / 683 before the opaque lane ids and with the pass on;
     # 284 bytes / 308 loads with the 16-bit scan tier - sixteen positions per lane, once per frame of 8 k - 16 k tokens - which
     # made the kernel 3.5 % faster all the same)
     key_x = next(k for k in rows if "DecodeKernel<true, true>" in k)
-    assert rows[key_x][5] <= 320 and rows[key_x][3] <= 400, "DecodeKernel<1,1> scratch %d B, %d scratch loads" % (rows[key_x][5], rows[key_x][3])
+    # round 6: 128 bytes / 90 loads with the opaque lane index (308 / 329 without it: 981 -> 903 ms on one box)
+    assert rows[key_x][5] <= 176 and rows[key_x][3] <= 140, "DecodeKernel<1,1> scratch %d B, %d scratch loads" % (rows[key_x][5], rows[key_x][3])
     assert dpp >= 200 and bpermute <= 40, "the wave scans are expected on DPP, not on ds_bpermute (%d DPP, %d bpermute)" % (dpp, bpermute)

@@ -451,6 +451,336 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) GemmV(GemmArgs g) {
     }
 }
 
+
+// ---- round 6: LDS-DMA.  The operand slabs go from global memory STRAIGHT into LDS (global_load_lds_dwordx4: gfx950 moves
+// 16 bytes per lane, the wave's 64 chunks land side by side at M0) - no VGPR staging, no ds_write, the loads are not on the
+// VALU path at all.  Image [row][4 chunks of 4 k], the chunk at position p of row r holds k-chunk p ^ ((r >> 2) & 3) (the
+// swizzle is applied to the GLOBAL address of the lane whose chunk lands there); a lane reads chunk c of its row with one
+// ds_read_b128 and uses elements kk, 2 + kk for the MFMA steps 2c, 2c + 1 (lanes 0-31: even k, lanes 32-63: odd k - the
+// production kernel's k order, the same fmaf chain per element).  Two slabs in flight (even / odd buffers are separate
+// objects so that the compiler's LDS-DMA alias tracking does not wait for the slab in flight before reading the other).
+// The last slab of a K that is not a multiple of 16 goes through registers (a chunk cannot be masked by element).
+typedef __attribute__((address_space(3))) void *LdsPtr;
+typedef const __attribute__((address_space(1))) void *GlbPtr;
+template <int OCC, bool PRIO>
+__global__ void __launch_bounds__(256, OCC) GemmD(GemmArgs g) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) float As0[BM][BK];
+  __shared__ __attribute__((aligned(16))) float As1[BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs0[BN][BK];
+  __shared__ __attribute__((aligned(16))) float Bs1[BN][BK];
+  if (PRIO) Prio();
+  int tm, tn;
+  TileOf(g, &tm, &tn);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kk = lane >> 5, l31 = lane & 31;
+  const int m0 = tm * BM, n0 = tn * BN, rowsA = g.M - m0, rowsB = g.N - n0;
+  const float *Ab = g.A + static_cast<long>(m0) * g.a_si, *Bb = g.B + static_cast<long>(n0) * g.b_sj;
+  // the wave's two DMA instructions per operand and slab: rows wave * 32 + 16 i + (lane >> 2), position lane & 3
+  unsigned offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int r = wave * 32 + 16 * i + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+    offa[i] = (static_cast<unsigned>(min(r, rowsA - 1)) * static_cast<unsigned>(g.a_si) + 4 * c) * 4u;   // (rows past the edge: the last valid row, never stored)
+    offb[i] = (static_cast<unsigned>(min(r, rowsB - 1)) * static_cast<unsigned>(g.b_sj) + 4 * c) * 4u;
+  }
+  auto dma = [&](float (*As)[BK], float (*Bs)[BK], int k0) {
+    const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pa + offa[i]), (LdsPtr)&As[wave * 32 + 16 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pb + offb[i]), (LdsPtr)&Bs[wave * 32 + 16 * i][0], 16, 0, 0);
+    }
+  };
+  // The last slab of a K that is not a multiple of 16: its chunks are fetched like any other (a chunk that would start
+  // beyond the row's stride is taken from the row's last whole chunk instead - any valid address), then the elements
+  // k >= K are ZEROED in LDS before the barrier that publishes the slab (the production kernel feeds zeros there too: the
+  // same fmaf chain).  Thread t owns row t of the 256 rows of the two operand slabs.
+  const int k_tail = g.K & (BK - 1);
+  unsigned offa_t[2], offb_t[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int r = wave * 32 + 16 * i + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+    const int k0 = g.K - k_tail;
+    const int ca = min(c, (static_cast<int>(g.a_si) - k0) / 4 - 1), cb = min(c, (static_cast<int>(g.b_sj) - k0) / 4 - 1);
+    offa_t[i] = (static_cast<unsigned>(min(r, rowsA - 1)) * static_cast<unsigned>(g.a_si) + 4 * ca) * 4u;
+    offb_t[i] = (static_cast<unsigned>(min(r, rowsB - 1)) * static_cast<unsigned>(g.b_sj) + 4 * cb) * 4u;
+  }
+  auto dma_tail = [&](float (*As)[BK], float (*Bs)[BK], int k0) {
+    const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pa + offa_t[i]), (LdsPtr)&As[wave * 32 + 16 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pb + offb_t[i]), (LdsPtr)&Bs[wave * 32 + 16 * i][0], 16, 0, 0);
+    }
+  };
+  // (a wave zeroes the rows its OWN two DMA instructions per operand wrote - the vmcnt it has just waited for covers no
+  // other wave's transfers: the first version had thread t zero row t, and a slab landing AFTER the zeroing gave wrong
+  // tiles now and then - "BITS DIFFER" in two of three runs of round 6's first lab pass)
+  auto zero_tail = [&](float (*As)[BK], float (*Bs)[BK]) {
+    float (*X)[BK] = lane < 32 ? As : Bs;
+    const int r = wave * 32 + (lane & 31), sw = (r >> 2) & 3;
+    for (int k = k_tail; k < BK; k++) X[r][(((k >> 2) ^ sw) << 2) | (k & 3)] = 0.f;
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int swl = (l31 >> 2) & 3;
+  auto mma = [&](const float (*As)[BK], const float (*Bs)[BK]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int ch = (c ^ swl) * 4;
+      float4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const float4 *>(&As[(wm * 2 + i) * 32 + l31][ch]);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bf[j] = *reinterpret_cast<const float4 *>(&Bs[(wn * 2 + j) * 32 + l31][ch]);
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const float a = s == 0 ? (kk ? af[i].y : af[i].x) : (kk ? af[i].w : af[i].z);
+            const float b = s == 0 ? (kk ? bf[j].y : bf[j].x) : (kk ? bf[j].w : bf[j].z);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+    }
+  };
+  const int nfull = g.K / BK, nk = (g.K + BK - 1) / BK;   // whole slabs, all slabs (nk - nfull = 0 or 1)
+  // slab kt -> the buffers; returns after the loads are ISSUED
+#define KH_ISSUE(AS, BS, KT) do { if ((KT) < nfull) dma(AS, BS, (KT) * BK); else dma_tail(AS, BS, (KT) * BK); } while (0)
+  // ... the slab is complete and visible to every wave
+#define KH_PUBLISH(AS, BS, KT) do { __builtin_amdgcn_s_waitcnt(0x0f70); if ((KT) >= nfull) zero_tail(AS, BS); __syncthreads(); } while (0)
+  KH_ISSUE(As0, Bs0, 0);
+  KH_PUBLISH(As0, Bs0, 0);
+  for (int kt = 0;; kt += 2) {
+    const bool more1 = kt + 1 < nk;
+    if (more1) KH_ISSUE(As1, Bs1, kt + 1);
+    mma(As0, Bs0);
+    if (!more1) break;
+    KH_PUBLISH(As1, Bs1, kt + 1);
+    const bool more2 = kt + 2 < nk;
+    if (more2) KH_ISSUE(As0, Bs0, kt + 2);
+    mma(As1, Bs1);
+    if (!more2) break;
+    KH_PUBLISH(As0, Bs0, kt + 2);
+  }
+#undef KH_ISSUE
+#undef KH_PUBLISH
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) bv[j] = g.bias[n0 + (wn * 2 + j) * 32 + l31];
+    float *cb = g.C + static_cast<size_t>(m0 + wm * 64) * g.c_stride + n0 + wn * 64;
+    const unsigned voff = static_cast<unsigned>(4 * kk) * g.c_stride + l31;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *cp = cb + static_cast<size_t>(i * 32 + (r & 3) + 8 * (r >> 2)) * g.c_stride;
+#pragma unroll
+        for (int j = 0; j < 2; j++) cp[voff + 32 * j] = acc[i][j][r] + bv[j];
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + (wn * 2 + j) * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row >= g.M) continue;
+        g.C[static_cast<size_t>(row) * g.c_stride + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+// ---- the same with a ring of three slabs
+template <int OCC, bool PRIO>
+__global__ void __launch_bounds__(256, OCC) GemmD3(GemmArgs g) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ __attribute__((aligned(16))) float As0[BM][BK];
+  __shared__ __attribute__((aligned(16))) float As1[BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs0[BN][BK];
+  __shared__ __attribute__((aligned(16))) float Bs1[BN][BK];
+  __shared__ __attribute__((aligned(16))) float As2[BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs2[BN][BK];
+  if (PRIO) Prio();
+  int tm, tn;
+  TileOf(g, &tm, &tn);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kk = lane >> 5, l31 = lane & 31;
+  const int m0 = tm * BM, n0 = tn * BN, rowsA = g.M - m0, rowsB = g.N - n0;
+  const float *Ab = g.A + static_cast<long>(m0) * g.a_si, *Bb = g.B + static_cast<long>(n0) * g.b_sj;
+  // the wave's two DMA instructions per operand and slab: rows wave * 32 + 16 i + (lane >> 2), position lane & 3
+  unsigned offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int r = wave * 32 + 16 * i + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+    offa[i] = (static_cast<unsigned>(min(r, rowsA - 1)) * static_cast<unsigned>(g.a_si) + 4 * c) * 4u;   // (rows past the edge: the last valid row, never stored)
+    offb[i] = (static_cast<unsigned>(min(r, rowsB - 1)) * static_cast<unsigned>(g.b_sj) + 4 * c) * 4u;
+  }
+  auto dma = [&](float (*As)[BK], float (*Bs)[BK], int k0) {
+    const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pa + offa[i]), (LdsPtr)&As[wave * 32 + 16 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pb + offb[i]), (LdsPtr)&Bs[wave * 32 + 16 * i][0], 16, 0, 0);
+    }
+  };
+  // The last slab of a K that is not a multiple of 16: its chunks are fetched like any other (a chunk that would start
+  // beyond the row's stride is taken from the row's last whole chunk instead - any valid address), then the elements
+  // k >= K are ZEROED in LDS before the barrier that publishes the slab (the production kernel feeds zeros there too: the
+  // same fmaf chain).  Thread t owns row t of the 256 rows of the two operand slabs.
+  const int k_tail = g.K & (BK - 1);
+  unsigned offa_t[2], offb_t[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int r = wave * 32 + 16 * i + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+    const int k0 = g.K - k_tail;
+    const int ca = min(c, (static_cast<int>(g.a_si) - k0) / 4 - 1), cb = min(c, (static_cast<int>(g.b_sj) - k0) / 4 - 1);
+    offa_t[i] = (static_cast<unsigned>(min(r, rowsA - 1)) * static_cast<unsigned>(g.a_si) + 4 * ca) * 4u;
+    offb_t[i] = (static_cast<unsigned>(min(r, rowsB - 1)) * static_cast<unsigned>(g.b_sj) + 4 * cb) * 4u;
+  }
+  auto dma_tail = [&](float (*As)[BK], float (*Bs)[BK], int k0) {
+    const char *pa = reinterpret_cast<const char *>(Ab + k0), *pb = reinterpret_cast<const char *>(Bb + k0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pa + offa_t[i]), (LdsPtr)&As[wave * 32 + 16 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GlbPtr)(pb + offb_t[i]), (LdsPtr)&Bs[wave * 32 + 16 * i][0], 16, 0, 0);
+    }
+  };
+  // (a wave zeroes the rows its OWN two DMA instructions per operand wrote - the vmcnt it has just waited for covers no
+  // other wave's transfers: the first version had thread t zero row t, and a slab landing AFTER the zeroing gave wrong
+  // tiles now and then - "BITS DIFFER" in two of three runs of round 6's first lab pass)
+  auto zero_tail = [&](float (*As)[BK], float (*Bs)[BK]) {
+    float (*X)[BK] = lane < 32 ? As : Bs;
+    const int r = wave * 32 + (lane & 31), sw = (r >> 2) & 3;
+    for (int k = k_tail; k < BK; k++) X[r][(((k >> 2) ^ sw) << 2) | (k & 3)] = 0.f;
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int swl = (l31 >> 2) & 3;
+  auto mma = [&](const float (*As)[BK], const float (*Bs)[BK]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int ch = (c ^ swl) * 4;
+      float4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const float4 *>(&As[(wm * 2 + i) * 32 + l31][ch]);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bf[j] = *reinterpret_cast<const float4 *>(&Bs[(wn * 2 + j) * 32 + l31][ch]);
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const float a = s == 0 ? (kk ? af[i].y : af[i].x) : (kk ? af[i].w : af[i].z);
+            const float b = s == 0 ? (kk ? bf[j].y : bf[j].x) : (kk ? bf[j].w : bf[j].z);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+    }
+  };
+  const int nfull = g.K / BK, nk = (g.K + BK - 1) / BK;   // whole slabs, all slabs (nk - nfull = 0 or 1)
+  // Three slabs: the one being read, the one that must have landed by the next barrier, the one in flight across it.
+  // A slab is published by a COUNTED vmcnt (all of this wave's transfers but the youngest slab's four) + a raw s_barrier
+  // (__syncthreads would drain the slab in flight: cdna_hip_programming.md, "Pipelining across barriers"); slab kt + 2 is
+  // issued behind the barrier that publishes slab kt, i.e. when every wave has finished reading slab kt - 1 from its buffer.
+  // The steady loop issues unconditionally (a conditional issue makes hipcc put its own vmcnt(0) in front of the reads);
+  // the last two slabs are drained behind it through plain pointers.
+#define KH_ISSUE(AS, BS, KT) do { if ((KT) < nfull) dma(AS, BS, (KT) * BK); else dma_tail(AS, BS, (KT) * BK); } while (0)
+#define KH_PUB4() do { __builtin_amdgcn_s_waitcnt(0x0f74); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); } while (0)
+  if (nk >= 3) {
+    KH_ISSUE(As0, Bs0, 0);
+    KH_ISSUE(As1, Bs1, 1);
+    int first = 0;   // the drain's first buffer
+    for (int kt = 0;; kt += 3) {
+      KH_PUB4(); KH_ISSUE(As2, Bs2, kt + 2); mma(As0, Bs0); if (kt + 2 == nk - 1) { first = 1; break; }
+      KH_PUB4(); KH_ISSUE(As0, Bs0, kt + 3); mma(As1, Bs1); if (kt + 3 == nk - 1) { first = 2; break; }
+      KH_PUB4(); KH_ISSUE(As1, Bs1, kt + 4); mma(As2, Bs2); if (kt + 4 == nk - 1) { first = 0; break; }
+    }
+    float (*A1)[BK] = first == 0 ? As0 : first == 1 ? As1 : As2, (*B1)[BK] = first == 0 ? Bs0 : first == 1 ? Bs1 : Bs2;
+    float (*A2)[BK] = first == 0 ? As1 : first == 1 ? As2 : As0, (*B2)[BK] = first == 0 ? Bs1 : first == 1 ? Bs2 : Bs0;
+    KH_PUB4();
+    mma(A1, B1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (nk > nfull) zero_tail(A2, B2);
+    __syncthreads();
+    mma(A2, B2);
+  } else {
+    for (int kt = 0; kt < nk; kt++) {
+      KH_ISSUE(As0, Bs0, kt);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      if (kt >= nfull) zero_tail(As0, Bs0);
+      __syncthreads();
+      mma(As0, Bs0);
+      __syncthreads();
+    }
+  }
+#undef KH_ISSUE
+#undef KH_PUB4
+  if (m0 + BM <= g.M && n0 + BN <= g.N) {
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) bv[j] = g.bias[n0 + (wn * 2 + j) * 32 + l31];
+    float *cb = g.C + static_cast<size_t>(m0 + wm * 64) * g.c_stride + n0 + wn * 64;
+    const unsigned voff = static_cast<unsigned>(4 * kk) * g.c_stride + l31;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *cp = cb + static_cast<size_t>(i * 32 + (r & 3) + 8 * (r >> 2)) * g.c_stride;
+#pragma unroll
+        for (int j = 0; j < 2; j++) cp[voff + 32 * j] = acc[i][j][r] + bv[j];
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + (wn * 2 + j) * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row >= g.M) continue;
+        g.C[static_cast<size_t>(row) * g.c_stride + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+template <int OCC, bool PRIO>
+void LaunchD3(GemmArgs g) {
+  g.tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.N + 127) / 128;
+  hipLaunchKernelGGL((GemmD3<OCC, PRIO>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, 0, g);
+}
+template <int OCC, bool PRIO>
+void LaunchD(GemmArgs g) {
+  g.tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.N + 127) / 128;
+  hipLaunchKernelGGL((GemmD<OCC, PRIO>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, 0, g);
+}
+
 void LaunchPersist(GemmArgs g) {
   g.tiles_m = (g.M + 127) / 128;
   g.tiles_n = (g.N + 127) / 128;
@@ -485,6 +815,12 @@ int main(int argc, char **argv) {
   const Var vars[] = {
       {"production tiling 128x128 [k][row]", LaunchBase},
       {"the same, 1024 persistent workgroups + tile counter", LaunchPersist},
+      {"LDS-DMA 128x128, 2x2 waves of 2x2, occ 4, prio", LaunchD<4, true>},
+      {"LDS-DMA 128x128, 2x2 waves of 2x2, occ 4", LaunchD<4, false>},
+      {"LDS-DMA 128x128, 2x2 waves of 2x2, occ 3, prio", LaunchD<3, true>},
+      {"LDS-DMA ring of 3, counted vmcnt, occ 3, prio", LaunchD3<3, true>},
+      {"LDS-DMA ring of 3, counted vmcnt, occ 3", LaunchD3<3, false>},
+      {"LDS-DMA ring of 3, counted vmcnt, occ 2, prio", LaunchD3<2, true>},
       {"b128 128x128, 2x2 waves of 2x2, occ 4, prio", LaunchV<2, 2, 2, 2, 4, true>},
       {"b128 128x128, 2x2 waves of 2x2, occ 4", LaunchV<2, 2, 2, 2, 4, false>},
       {"b128 128x128, 2x2 waves of 2x2, occ 3", LaunchV<2, 2, 2, 2, 3, true>},

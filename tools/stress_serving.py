@@ -64,11 +64,12 @@ def main():
             clean += 1 if ok else 0
             worst = max(worst, a["chunk_latency_ms"]["max"], b["chunk_latency_ms"]["max"])
             print("run %3d: %s  %.1f s  served %d + %d  frames/s %.0f / %.0f  chunk latency ms p50 %.1f / %.1f  p95 %.1f / %.1f  max %.0f / %.0f  "
-                  "last chunk + FinalizeDecoding max %.0f / %.0f" % (
+                  "last chunk + FinalizeDecoding max %.0f / %.0f  host step call ms %.2f / %.2f  streams per call %.0f / %.0f" % (
                 r, "clean" if ok else "INCOMPLETE", time.perf_counter() - t1, a["utterances_served"], b["utterances_served"],
                 a["frames_per_s"] or 0, b["frames_per_s"] or 0, a["chunk_latency_ms"]["p50"], b["chunk_latency_ms"]["p50"],
                 a["chunk_latency_ms"]["p95"], b["chunk_latency_ms"]["p95"], a["chunk_latency_ms"]["max"], b["chunk_latency_ms"]["max"],
-                a["last_chunk_and_finalize_ms"]["max"], b["last_chunk_and_finalize_ms"]["max"]), flush=True)
+                a["last_chunk_and_finalize_ms"]["max"], b["last_chunk_and_finalize_ms"]["max"], a["step_call_ms"]["mean"], b["step_call_ms"]["mean"],
+                a["streams_per_step_call"], b["streams_per_step_call"]), flush=True)
         except Exception as e:   # noqa: BLE001 - the harness records, it does not stop
             print("run %3d: FAILED after %.1f s: %r" % (r, time.perf_counter() - t1, e), flush=True)
         sec.release_device_memory(api, torch)
