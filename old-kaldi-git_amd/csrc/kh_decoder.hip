@@ -318,6 +318,11 @@ struct Params {
   // token's extra_cost from scratch.  0: PruneActiveTokens every prune_interval frames as :88-89 (online decoding, whose
   // mid-utterance getters expose that state).
   int32_t lazy_prune;
+  // lazy schedule, online streams (round 6): a garbage collection also once this many frames have gone unpruned, not only
+  // when the arenas run low - the collection of a 2000-frame backlog in the middle of an utterance was a 100 - 500 ms
+  // stall of that stream's chunk (KH_SERVE_LAZY_SPAN, default 128 for kh_online_decoder_set_lazy_prune; 0 = arenas only,
+  // the offline kernel's rule).  The lattice does not depend on when the collections run.
+  int32_t lazy_span;
   // 1: the reference's iteration order is reproduced (HashList order, running next_cutoff, first-minimum tie, the LIFO
   // order of the epsilon closure's insertions) - see "exact reference order" below; the kernels are instantiated for it
   int32_t exact_order;
@@ -450,6 +455,7 @@ __device__ __forceinline__ long long Uni(long long v) { return static_cast<long 
 
 // ---------------------------------------------------------------- block helpers
 struct Shared {
+  int kcnt[3][NW];                 // (reference-order kernels) call counters of the block primitives, one per wave: Blk::lds_cnt
   int wsum[2][NW];                 // BlockExScan, double buffered
   int wsumk[2][8][NW];             // BlockExScanK (K <= 8), double buffered
   int wl_n[3];                     // nonemitting work-list lengths, rotating ([0] also: prune's epsilon-token list)
@@ -509,8 +515,36 @@ struct Blk {
   // kernel 5 % (scratch 168 -> 184 bytes per lane; same-box A/B against the round-3 build)
   __attribute__((address_space(4))) const struct UttX *x;
   int k_or, k_red, k_scan;
+  // The call counters that pick a primitive's buffer.  In registers they are three values that live for the whole launch;
+  // the reference-order kernels, already short of registers, kept them in scratch and paid a load + store (two trips to
+  // memory) per block primitive - half of the kernel's remaining scratch traffic in round 6 (67 of 138 static scratch
+  // instructions).  lds_cnt (a compile-time constant per kernel): one counter per WAVE in LDS instead, read by the wave and
+  // bumped by its lane 0 - the LDS unit executes a wave's operations in order, and every wave makes the same calls.
+  bool lds_cnt;
   __device__ __forceinline__ LdsShared *operator->() const { return p; }
 };
+
+// which: 0 = BlockOr's slot counter, 1 = the reductions', 2 = the scans'.  Returns the counter's value before this call.
+template <int kWhich>
+__device__ __forceinline__ int NextCall(Blk &sh) {
+  if (sh.lds_cnt) {
+    const int w = static_cast<int>(KH_TIDX >> 6);
+    const int v = sh->kcnt[kWhich][w];
+    if ((KH_TIDX & 63) == 0) sh->kcnt[kWhich][w] = v + 1;
+    return v;
+  }
+  if (kWhich == 0) return sh.k_or++;
+  if (kWhich == 1) return sh.k_red++;
+  return sh.k_scan++;
+}
+// (at the kernel's entry, in front of a barrier)
+__device__ __forceinline__ void InitCalls(Blk &sh, bool lds_cnt) {
+  sh.k_or = 0;
+  sh.k_red = 0;
+  sh.k_scan = 0;
+  sh.lds_cnt = lds_cnt;
+  if (lds_cnt && KH_TIDX < 3 * NW) (&sh->kcnt[0][0])[KH_TIDX] = 0;
+}
 
 // The emitting pass dedupes the frame's new tokens in an LDS table (state -> min cost ->
 // token index) of 8192 slots laid over LDS that is idle at that point of the frame: the
@@ -665,7 +699,7 @@ template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
   const int lane = KH_TIDX & 63, w = KH_TIDX >> 6;
   const int inc = WaveIncSum(v);
-  const int buf = (sh.k_scan++) & 1;
+  const int buf = NextCall<2>(sh) & 1;
   if (lane == 63) sh->wsum[buf][w] = inc;
   if (kLdsOnly) LdsSync(); else KhSync();
   int before = 0, all = 0;
@@ -684,7 +718,7 @@ __device__ __forceinline__ int BlockExScan(int v, int *total, Blk &sh) {
 template <int K, bool kLdsOnly = false>
 __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], int *total, Blk &sh) {
   const int lane = KH_TIDX & 63, w = KH_TIDX >> 6;
-  const int buf = (sh.k_scan++) & 1;
+  const int buf = NextCall<2>(sh) & 1;
   int inc[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
@@ -709,7 +743,7 @@ __device__ __forceinline__ void BlockExScanK(const int (&v)[K], int (&off)[K], i
 }
 
 __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, Blk &sh) {
-  const int buf = (sh.k_red++) & 1;
+  const int buf = NextCall<1>(sh) & 1;
   v = WaveMinU64ToLast(v);
   if ((KH_TIDX & 63) == 63) sh->wred[buf][KH_TIDX >> 6] = v;
   KhSync();
@@ -720,7 +754,7 @@ __device__ __forceinline__ unsigned long long BlockMinU64(unsigned long long v, 
 }
 
 __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
-  const int buf = (sh.k_red++) & 1;
+  const int buf = NextCall<1>(sh) & 1;
   v = WaveIncMinF(v);
   if ((KH_TIDX & 63) == 63) sh->wred[buf][KH_TIDX >> 6] = __float_as_uint(v);
   KhSync();
@@ -731,7 +765,7 @@ __device__ __forceinline__ float BlockMinF(float v, Blk &sh) {
 }
 
 __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
-  const int buf = (sh.k_red++) & 1;
+  const int buf = NextCall<1>(sh) & 1;
   v = WaveSumLLToLast(v);
   if ((KH_TIDX & 63) == 63) sh->wred[buf][KH_TIDX >> 6] = static_cast<unsigned long long>(v);
   KhSync();
@@ -746,7 +780,7 @@ __device__ __forceinline__ long long BlockSumLL(long long v, Blk &sh) {
 // was fully read before every thread reached the barrier of call n - 1.
 template <bool kLdsOnly = false>
 __device__ __forceinline__ int BlockOr(int bits, Blk &sh) {
-  const int k = (sh.k_or++) & 3;
+  const int k = NextCall<0>(sh) & 3;
   if (KH_TIDX == 0) sh->orbuf[(k + 2) & 3] = 0;
   if (bits) __hip_atomic_fetch_or(&sh->orbuf[k], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (kLdsOnly) LdsSync(); else KhSync();
@@ -2291,7 +2325,7 @@ __device__ __forceinline__ void BlockExScanSumMin(int v, uint32_t m, int *ex_sum
   const int lane = KH_TIDX & 63, w = KH_TIDX >> 6;
   const int inc = WaveIncSum(v);
   const uint32_t im = WaveIncMinU(m);
-  const int b1 = (sh.k_scan++) & 1, b2 = (sh.k_red++) & 1;
+  const int b1 = NextCall<2>(sh) & 1, b2 = NextCall<1>(sh) & 1;
   if (lane == 63) {
     sh->wsum[b1][w] = inc;
     sh->wred[b2][w] = im;
@@ -2812,11 +2846,17 @@ __device__ __forceinline__ int OpaqueTid() {
   asm volatile("" : "+v"(t));
   return t;
 }
+// `const TidRef tid;` - a lane index that is re-made at every use (one v_mov) instead of living in a register from the top of
+// a routine that spans a dozen barriers: as a plain `const int tid = OpaqueTid()` it was the most reloaded spill slot of the
+// reference-order kernel after round 6's first pass (22 of its 90 static scratch loads).
+struct TidRef {
+  __device__ __forceinline__ operator int() const { return OpaqueTid(); }
+};
 
 // exclusive prefix of the set-bit counts of bits[0, W) -> pre[0, W), W <= kLdsSlots; returns the number of set bits.
 // One barrier inside; the caller syncs before it reads pre.
 __device__ __forceinline__ int BitmapPrefix(LdsU32 bits, LdsU32 pre, int W, Blk &sh) {
-  const int tid = OpaqueTid();
+  const TidRef tid;
   constexpr int kPer = kLdsSlots / NT;
   int c[kPer], mine = 0;
 #pragma unroll
@@ -2838,7 +2878,7 @@ __device__ __forceinline__ int BitmapPrefix(LdsU32 bits, LdsU32 pre, int W, Blk 
 }
 // a[0, W) -> its exclusive prefix sums, in place (a lane owns kLdsSlots / NT consecutive words); returns the total
 __device__ __forceinline__ int LdsExScanInPlace(LdsU32 a, int W, Blk &sh) {
-  const int tid = OpaqueTid();
+  const TidRef tid;
   constexpr int kPer = kLdsSlots / NT;
   int c[kPer], mine = 0;
 #pragma unroll
@@ -2902,7 +2942,7 @@ __device__ void ReplayFromMemory(const Utt &u, const Params &p, int nb, int fe, 
 // pos(t) = #{t': h(t') < h(t)} + inb(t) for the tokens [0, cnt) of the frame under construction -> x_pos.  One count per
 // first-of-bucket rank and one scan over the rank space, 8192 ranks at a time.
 __device__ void PositionsFromHeads(const Utt &u, int cnt, Blk &sh, int xs0) {
-  const int tid = OpaqueTid();
+  const TidRef tid;
   const LdsU32 K = (LdsU32)LdsKeys(sh);
   constexpr int kU = 8;   // (a lane's loads of eight trips in flight together: a loop that waits per trip pays a memory round trip per trip)
   int pbase = 0;
@@ -2949,7 +2989,7 @@ __device__ void PositionsFromHeads(const Utt &u, int cnt, Blk &sh, int xs0) {
 // Returns 1 = done, 0 = failed (sh->status), 2 = not applicable after all (more than kFastMulti tokens share their
 // bucket with another one: nothing the sort needs has been touched - it takes the frame).
 __device__ int OrderFrontierFast(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
-  const int tid = OpaqueTid();
+  const TidRef tid;
   const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, n_emit = ne_emit - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
   const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
   const int nl = le - lb, n_new = fe - ne_emit;
@@ -3391,7 +3431,7 @@ __device__ int OrderFrontierFast(const Utt &u, const Params &p, int nb, int fe, 
 //   bits) | rank inside the bucket (8 bits) << 13 | (entry of tmp_epslist + 1) << 21.
 constexpr int kT1Nodes = 1024, kT1Links = 1024, kT1New = 511;
 __device__ int OrderFrontierLds(const Utt &u, const Params &p, int nb, int fe, int lb, int le, float cutoff, Blk &sh) {
-  const int tid = OpaqueTid();
+  const TidRef tid;
   const int ne_emit = Uni(sh->x_ne_emit), n = fe - nb, n_emit = ne_emit - nb, eps_emit = Uni(sh->x_eps_emit), eps_n = Uni(sh->eps_n);
   const uint32_t H = Uni(sh->x_hsize), qbase = Uni(sh->x_qbase);
   const int nl = le - lb, n_new = fe - ne_emit;
@@ -3907,15 +3947,17 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   int base_next = WaveLdsFetchAdd(&sh->work_cursor, 64);
   uint32_t co_next = 0u;
   int st_next = 0, pos_next = 0;
-  // (round 6) hc_next: the emitting-arc count in the header of the next claim's states, requested while the current claim's
-  // batches are in flight - the count used to be the first of a claim's dependent round trips (state -> header -> arcs)
+  // (round 6, -DKH_X_CNT_PREFETCH: measured and NOT kept) hc_next: the emitting-arc count in the header of the next claim's
+  // states, requested while the current claim's batches are in flight - the count is the first of a claim's dependent round
+  // trips (state -> header -> arcs).  Same-box A/B 902 ms with it, 892 without: the extra register and the header reads of
+  // tokens above the cutoff cost more than the round trip they hide next to 31 other waves.
   int hc_next = 0;
   if (base_next < e) {
     const int icn = min(base_next + lane, e - 1);
     co_next = LoadCostEnc(&x_cost[icn]);
     st_next = x_state[icn];
     pos_next = xp_pos[icn - b];
-#ifndef KH_X_NO_CNT_PREFETCH
+#ifdef KH_X_CNT_PREFETCH
     hc_next = x_rec[st_next].x;
 #endif
   }
@@ -3942,7 +3984,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
     int ab = 0, cnt = 0;
     if (need) {
       ab = st + 1;
-#ifndef KH_X_NO_CNT_PREFETCH
+#ifdef KH_X_CNT_PREFETCH
       cnt = hc;
 #else
       cnt = x_rec[st].x;
@@ -4033,14 +4075,14 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
           }
         }
       }
-#ifndef KH_X_NO_CNT_PREFETCH
+#ifdef KH_X_CNT_PREFETCH
       if (!hc_asked) {   // behind the claim's FIRST batch: the next claim's states have landed (they were asked for before this batch's arcs)
         hc_asked = true;
         if (base_next < e) hc_next = x_rec[st_next].x;
       }
 #endif
     }
-#ifndef KH_X_NO_CNT_PREFETCH
+#ifdef KH_X_CNT_PREFETCH
     if (!hc_asked && base_next < e) hc_next = x_rec[st_next].x;   // (a claim without arcs)
 #endif
     if (in_range) {
@@ -4077,7 +4119,7 @@ __device__ bool ProcessEmittingExact(const Utt &u, const Params &p, int frame, i
   XS(60);
   if (Uni(sh->status) != 0) return false;
   const int link_frame_e = Uni(sh->link_cursor);
-  const int tid = OpaqueTid();
+  const TidRef tid;
   // ---- the scan in list order, in LDS over the POSITION space: every token puts (M, arc count) at its position, one
   // exclusive (min, sum) scan over the positions gives the running next_cutoff in front of every token (it starts at the
   // estimate) and the ordinal of its first arc, and the token takes them back: x_m = that cutoff, x_c = the ordinal of
@@ -5515,7 +5557,8 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       // compaction slides the survivors down.  Not more often than every prune_interval frames: an arena that is full of
       // LIVE data reports its overflow instead (the utterance is decoded again with larger arenas).
       const bool low = u.tok_cap - Uni(sh->tok_end) < u.tok_frame_cap || u.link_cap - Uni(sh->link_end) < 2 * u.link_frame_cap;
-      if (low && t > 0 && t - last_gc >= p.prune_interval) {
+      const bool span = p.lazy_span > 0 && t - Uni(sh->conv_upto) >= p.lazy_span;   // (conv_upto: the frame of the last collection)
+      if ((span && t > 0) || (low && t > 0 && t - last_gc >= p.prune_interval)) {
         Stamp(u, sh, 15);
         PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
         Stamp(u, sh, 6);
@@ -5838,9 +5881,7 @@ DecodeKernel(const Utt *__restrict__ slots, const UttIn *__restrict__ in, UttOut
   Blk sh;
   sh.p = (LdsShared *)&shm;
   sh.ll_row = (__attribute__((address_space(3))) float *)dyn_ll_row;
-  sh.k_or = 0;
-  sh.k_red = 0;
-  sh.k_scan = 0;
+  InitCalls(sh, kExact);
   sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + blockIdx.x) : nullptr;
   Utt u = slots[blockIdx.x];
   Launder(u);
@@ -5968,9 +6009,7 @@ OnlineKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, cons
   Blk sh;
   sh.p = (LdsShared *)&shm;
   sh.ll_row = (__attribute__((address_space(3))) float *)dyn_ll_row;
-  sh.k_or = 0;
-  sh.k_red = 0;
-  sh.k_scan = 0;
+  InitCalls(sh, kExact);
   const Job job = jobs[blockIdx.x];
   sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + job.slot) : nullptr;
   Utt u = slots[job.slot];
@@ -6132,9 +6171,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
   Blk sh;
   sh.p = (LdsShared *)&shm;
   sh.ll_row = (__attribute__((address_space(3))) float *)dyn_ll_row;
-  sh.k_or = 0;
-  sh.k_red = 0;
-  sh.k_scan = 0;
+  InitCalls(sh, kExact);
   const int s = blockIdx.x;
   sh.x = kExact ? (__attribute__((address_space(4))) const UttX *)(slotsx + s) : nullptr;
   Utt u = slots[s];
@@ -7145,6 +7182,11 @@ int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, int ll_stride, 
   return KH_OK;
 }
 
+static int OnlineLazySpan() {
+  if (const char *e = getenv("KH_SERVE_LAZY_SPAN")) return std::max(0, atoi(e));
+  return 128;
+}
+
 void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *tid2pdf) {
   Params &p = *pp;
   (void)tid2pdf;
@@ -7156,6 +7198,7 @@ void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *ti
   p.num_eps = static_cast<int32_t>(d->fst->num_eps);
   p.start_has_eps = d->fst->start_has_eps;
   p.max_emit = d->fst->max_emit;
+  p.lazy_span = 0;
   if (const char *e = getenv("KH_DECODER_NO_MID_SCAN")) { if (atoi(e) != 0) p.max_emit = 1 << 16; }   // (tests: the scan through memory for every frame beyond the LDS tier)
   // the frame's score row fits in LDS (two workgroups per CU share 160 KB): stage it
   // the score row shares the workgroup's 64 KB of LDS with the static block (Shared)
@@ -8238,6 +8281,7 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   Params p;
   FillParams(b, &p, ll_stride > 0 ? ll_stride : 1 << 30, tid2pdf);
   p.lazy_prune = b->lazy;   // kh_online_decoder_set_lazy_prune
+  p.lazy_span = b->lazy ? OnlineLazySpan() : 0;
   if (ll_stride <= 0) p.ll_cols = 0;
   if (b->rec != nullptr && b->rec_order_ids == (b->exact ? 1 : 0) &&
       (ll_stride <= 0 || (o->pinned && tid2pdf == o->pinned_map && ll_stride == o->pinned_cols))) {
@@ -8561,6 +8605,7 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   Params p;
   FillParams(b, &p, o->serve_stride, o->serve_map);
   p.lazy_prune = b->lazy;
+  p.lazy_span = b->lazy ? OnlineLazySpan() : 0;
   if (!(o->pinned && o->serve_map == o->pinned_map && o->serve_stride == o->pinned_cols && b->rec != nullptr &&
         b->rec_order_ids == (b->exact ? 1 : 0))) {
     const int rc = kh_online_decoder_set_pdf_map(o, o->serve_map, o->serve_stride);
