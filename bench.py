@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (config 2 / 5) legs")
     ap.add_argument("--secondary-timeout", type=int, default=300,
                     help="seconds the secondary legs may take before the line is printed without the one that hangs")
+    ap.add_argument("--secondary-only", action="store_true",
+                    help="(internal) run the secondary legs alone and print {\"secondary\": ...}: bench.py starts itself with this "
+                         "in a CHILD process, so that a leg that takes the GPU down costs its own figures, not the headline line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the unpipelined and the canonical-rule repeats of the step")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the value_end_to_end leg (the same steps with determinization timed)")
     ap.add_argument("--no-gpu-dryrun", action="store_true",
@@ -432,6 +435,57 @@ def dryrun(args, rank, world):
         dist.destroy_process_group()
 
 
+def secondary_only(args):
+    """The secondary legs (BASELINE.json configs 2, 3, 5, iVectors, config 4 as a serving loop: tools/bench_secondary.py) in a
+    process of their own; bench.py's main run starts it and takes {"secondary": {...}} from the last line of its stdout.
+    Under a watchdog: a leg that does not come back within --secondary-timeout costs its own figures - what is there is
+    printed, the leg is named, the process leaves with status 3."""
+    import threading
+    net, priors, g, protos = build_model_and_graph(3456, args.graph_states, False)
+    feats, off = build_utterances(3456, 0, args.utts, net, g, protos, False)
+    import torch
+    api = importlib.import_module(PKG + ".api")
+    api.select_gpu(0)
+    secondary = {}
+    state = {"leg": None, "printed": False}
+    lock = threading.Lock()
+
+    def emit_and_leave():
+        with lock:
+            if state["printed"]:
+                return
+            state["printed"] = True
+            try:   # where every thread stands, for whoever reads the run's stderr
+                import faulthandler
+                print("[bench] watchdog: the secondary leg %r has not returned within %d s; Python stacks of all threads:"
+                      % (state["leg"], args.secondary_timeout), file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            except Exception:   # noqa: BLE001
+                pass
+            sec_out = dict(secondary)
+            if state["leg"] is not None and state["leg"] not in sec_out:
+                sec_out[state["leg"]] = {"error": "no result within %d s (watchdog): the leg was abandoned" % args.secondary_timeout}
+            print(json.dumps({"secondary": sec_out}))
+            sys.stdout.flush()
+        os._exit(3)
+
+    timer = threading.Timer(float(args.secondary_timeout), emit_and_leave)
+    timer.daemon = True
+    timer.start()
+    try:
+        sec = importlib.import_module("tools.bench_secondary")
+        sec.run_all(api, torch, (net, priors, g, feats, off, DECODE_CFG, ACWT), out=secondary, state=state)
+    except Exception as e:  # noqa: BLE001
+        secondary["error"] = repr(e)
+    timer.cancel()
+    with lock:
+        if state["printed"]:      # (the watchdog is printing / has printed: it also leaves)
+            time.sleep(3600)
+        state["printed"] = True
+    print(json.dumps({"secondary": secondary}))
+    sys.stdout.flush()
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -444,6 +498,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.no_gpu_dryrun:
         return dryrun(args, rank, world)
+    if args.secondary_only:
+        return secondary_only(args)
 
     # ---- workload (numpy only: no GPU has been touched yet)
     if args.small:
@@ -881,51 +937,38 @@ def main():
                                        "secondary": res.get("secondary")}
                 out["speedup_vs_cpu_1thread_per_gpu"] = fps / world / res["value"]
         # The secondary legs (configs 2, 3, 5, iVectors, config 4 as a serving loop) run LAST, when the headline and its
-        # baselines are final, and under a watchdog: a leg that does not come back (round 4 saw the serving legs of a
-        # full run stop once in a while, inside a blocking library call) costs its own figures, not the line - the
-        # watchdog prints what is there, names the leg, and leaves.
+        # baselines are final, and in a CHILD process (round 6): this process keeps the line, whatever a leg does - a leg that
+        # does not come back (the child's own watchdog prints what it has and names the leg) or one that faults on the GPU
+        # and takes its process with it (round 6 saw ONE memory-access fault in ~60 runs of the serving legs: the headline of a
+        # driver run must not depend on that).
         if world == 1 and not args.no_secondary and not args.small:   # (at N > 1 the other ranks would wait at the final barrier)
-            import threading
-            secondary = {}
-            out["secondary"] = secondary
-            state = {"leg": None, "printed": False}
-            lock = threading.Lock()
-
-            def emit_and_leave():
-                with lock:
-                    if state["printed"]:
-                        return
-                    state["printed"] = True
-                    try:   # where every thread stands, for whoever reads the run's stderr
-                        import faulthandler
-                        print("[bench] watchdog: the secondary leg %r has not returned within %d s; Python stacks of all threads:"
-                              % (state["leg"], args.secondary_timeout), file=sys.stderr, flush=True)
-                        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
-                    except Exception:   # noqa: BLE001
-                        pass
-                    sec_out = dict(secondary)
-                    if state["leg"] is not None and state["leg"] not in sec_out:
-                        sec_out[state["leg"]] = {"error": "no result within %d s (watchdog): the leg was abandoned" % args.secondary_timeout}
-                    out["secondary"] = sec_out
-                    print(json.dumps(out))
-                    sys.stdout.flush()
-                # a leg that did not come back is a FAILED run: non-zero, so that nobody reads the line as green (every wait of
-                # the serving path has a deadline since round 5 - KH_ETIMEOUT - so this is not expected to fire any more)
-                os._exit(3)
-
-            timer = threading.Timer(float(args.secondary_timeout), emit_and_leave)
-            timer.daemon = True
-            timer.start()
+            import subprocess
             try:
                 sec = importlib.import_module("tools.bench_secondary")
-                sec.run_all(api, torch, (net, priors, g, feats, off, DECODE_CFG, ACWT), out=secondary, state=state)
-            except Exception as e:  # the secondary legs never fail the headline run
-                secondary["error"] = repr(e)
-            timer.cancel()
-            with lock:
-                if state["printed"]:      # (the watchdog is printing / has printed: it also leaves)
-                    time.sleep(3600)
-                state["printed"] = True
+                sec.release_device_memory(api, torch)   # (the child sizes its arenas from what is free)
+            except Exception:   # noqa: BLE001
+                pass
+            cmd = [sys.executable, os.path.abspath(__file__), "--secondary-only", "--utts", str(args.utts),
+                   "--graph-states", str(args.graph_states), "--secondary-timeout", str(args.secondary_timeout)]
+            secondary = None
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=args.secondary_timeout + 240, env=env)
+                lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+                if lines:
+                    secondary = json.loads(lines[-1]).get("secondary")
+                if secondary is None:
+                    secondary = {"error": "the secondary legs' process printed no result (exit status %d)" % p.returncode}
+                if p.returncode != 0:
+                    secondary["child_exit_status"] = p.returncode
+                    out["secondary_failed"] = True
+            except subprocess.TimeoutExpired:
+                secondary = {"error": "the secondary legs' process did not end within %d s" % (args.secondary_timeout + 240)}
+                out["secondary_failed"] = True
+            except Exception as e:   # noqa: BLE001 - the secondary legs never fail the headline run
+                secondary = {"error": repr(e)}
+                out["secondary_failed"] = True
+            out["secondary"] = secondary
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -468,9 +468,10 @@ int kh_online_decoder_num_frames_decoded(const KhOnlineDecoder *dec, int stream,
  * arenas run low, FinalizeDecoding prunes every frame once.  The final lattice, every best path and the endpointing
  * quantities are unchanged; a raw lattice asked for BEFORE FinalizeDecoding is pruned as of the current frame, not as of
  * the last multiple of prune_interval.  Re-carves the arenas (as much memory as is free, less 48 GB): every stream must be idle.
- * Round 6: a stream also collects its garbage (PruneActiveTokens + compaction) once KH_SERVE_LAZY_SPAN frames (default 128;
- * 0 = only when its arenas run low, the offline kernel's rule) have gone unpruned, so that no chunk of a long utterance
- * waits for the collection of a backlog of thousands of frames; the lattice does not depend on when collections run. */
+ * Round 6, experimental: with KH_SERVE_LAZY_SPAN=n (default 0 = only when its arenas run low, the offline kernel's rule) a
+ * stream also collects its garbage (PruneActiveTokens + compaction) once n frames have gone unpruned, so that no chunk of a
+ * long utterance waits for the collection of a backlog of thousands of frames (chunk latency max 113 -> 28 ms at n = 128);
+ * off by default: the serving stress harness saw rare GPU faults with it on (csrc/kh_decoder.hip OnlineLazySpan). */
 int kh_online_decoder_set_lazy_prune(KhOnlineDecoder *dec, int enable);
 /* kh_decoder_set_reference_order for the streams: LatticeFasterOnlineDecoder::ProcessEmitting (decoder/lattice-faster-online-
  * decoder.cc:864-951) walks the same HashList against the same running next_cutoff as the offline decoder, and with this set

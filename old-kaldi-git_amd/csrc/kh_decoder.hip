@@ -320,8 +320,8 @@ struct Params {
   int32_t lazy_prune;
   // lazy schedule, online streams (round 6): a garbage collection also once this many frames have gone unpruned, not only
   // when the arenas run low - the collection of a 2000-frame backlog in the middle of an utterance was a 100 - 500 ms
-  // stall of that stream's chunk (KH_SERVE_LAZY_SPAN, default 128 for kh_online_decoder_set_lazy_prune; 0 = arenas only,
-  // the offline kernel's rule).  The lattice does not depend on when the collections run.
+  // stall of that stream's chunk (KH_SERVE_LAZY_SPAN frames; 0 = arenas only, the offline kernel's rule and the DEFAULT:
+  // see OnlineLazySpan).  The lattice does not depend on when the collections run.
   int32_t lazy_span;
   // 1: the reference's iteration order is reproduced (HashList order, running next_cutoff, first-minimum tie, the LIFO
   // order of the epsilon closure's insertions) - see "exact reference order" below; the kernels are instantiated for it
@@ -519,7 +519,7 @@ struct Blk {
   // the reference-order kernels, already short of registers, kept them in scratch and paid a load + store (two trips to
   // memory) per block primitive - half of the kernel's remaining scratch traffic in round 6 (67 of 138 static scratch
   // instructions).  lds_cnt (a compile-time constant per kernel): one counter per WAVE in LDS instead, read by the wave and
-  // bumped by its lane 0 - the LDS unit executes a wave's operations in order, and every wave makes the same calls.
+  // bumped by its active lanes (all write the same value) - the LDS unit executes a wave's operations in order, and every wave makes the same calls.
   bool lds_cnt;
   __device__ __forceinline__ LdsShared *operator->() const { return p; }
 };
@@ -530,7 +530,7 @@ __device__ __forceinline__ int NextCall(Blk &sh) {
   if (sh.lds_cnt) {
     const int w = static_cast<int>(KH_TIDX >> 6);
     const int v = sh->kcnt[kWhich][w];
-    if ((KH_TIDX & 63) == 0) sh->kcnt[kWhich][w] = v + 1;
+    sh->kcnt[kWhich][w] = v + 1;   // (every ACTIVE lane, the same value: a call with lane 0 masked off still counts)
     return v;
   }
   if (kWhich == 0) return sh.k_or++;
@@ -7182,9 +7182,14 @@ int BuildArcPdf(KhDecoder *d, Params *p, const int32_t *tid2pdf, int ll_stride, 
   return KH_OK;
 }
 
+// OFF by default (0).  With the span on, the serving stress harness saw what it never saw without it: two memory-access
+// faults and one workgroup that never left its action in ~45 runs of the two serving legs (15 of 15 clean with the span off
+// on the same box, 116 of 116 in round 5) - about one bad collection in several hundred thousand.  The collections
+// themselves are the offline kernel's (PruneActiveTokens + full compaction), only far more frequent; the defect has not been
+// found, so the switch stays an experiment: KH_SERVE_LAZY_SPAN=128 gives chunk latency max 113 -> 28 ms at 256 streams.
 static int OnlineLazySpan() {
   if (const char *e = getenv("KH_SERVE_LAZY_SPAN")) return std::max(0, atoi(e));
-  return 128;
+  return 0;
 }
 
 void FillParams(const KhDecoder *d, Params *pp, int ll_stride, const int32_t *tid2pdf) {

@@ -112,10 +112,15 @@ def test_call_sequence_errors_and_stream_reuse(api):
     assert_same_lattice(first, oc.raw_lattice())
 
 
-def test_lazy_prune_schedule_same_results(api):
+@pytest.mark.parametrize("span", ["0", "64"])
+def test_lazy_prune_schedule_same_results(api, monkeypatch, span):
     """kh_online_decoder_set_lazy_prune: streams advanced in random chunks without any pruning on the way (an arena small
     enough to force garbage collections in one case), partial best paths and FinalRelativeCost mid-utterance, then
     FinalizeDecoding: lattice, best path and statistics of the interval schedule / the offline decoder, bit for bit."""
+    # KH_SERVE_LAZY_SPAN (round 6, experimental, off by default): a lazy stream also collects its garbage once that many frames
+    # have gone unpruned - 64: a collection (PruneActiveTokens + full compaction) or two per stream in the middle of a chunk;
+    # 0 (the default): only when the arenas run low
+    monkeypatch.setenv("KH_SERVE_LAZY_SPAN", span)
     rng = np.random.default_rng(77)
     g = workloads.make_hclg_like(rng, 8000, 60)
     cfg = api.decoder_config(beam=11.0, max_active=1500, min_active=100, lattice_beam=6.0, prune_interval=9)
