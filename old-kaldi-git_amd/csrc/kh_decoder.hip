@@ -91,6 +91,16 @@ __device__ __forceinline__ unsigned KhOpaqueTidX() {
 #define KH_TIDX (threadIdx.x)
 #endif
 
+// -DKH_SERVE_MARKERS (debug builds): thread 0 of a serving workgroup leaves (place << 24 | detail) in its stream's control
+// block in host memory as it goes; a KH_ETIMEOUT dump then says WHERE a workgroup that never came back is (round 6: one
+// reference-order stream in ~3 % of the stress harness's runs hangs inside AdvanceDecoding).
+#ifdef KH_SERVE_MARKERS
+__device__ int32_t *g_serve_mark = nullptr;   // the ServeCtl array (64-byte blocks; word 13 = pad1[0])
+#define KM(k, aux) do { if (KH_TIDX == 0 && g_serve_mark != nullptr) __hip_atomic_store(g_serve_mark + blockIdx.x * 16 + 13, ((k) << 24) | (static_cast<int32_t>(aux) & 0xffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define KM(k, aux) do {} while (0)
+#endif
+
 #ifndef KH_NT
 #define KH_NT 1024
 #endif
@@ -1897,6 +1907,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     for (int i = KH_TIDX; i < kLdsSlots; i += NT) { keys[i] = 0u; vals[i] = 0xFFFFFFFFu; }
     if (KH_TIDX == 0) sh->flag = 0;
     KhSync();
+    KM(40, k);
     // (B) insert.  A link that an earlier part resolved holds its token index (>= 0), a rejected one -1,
     // an unresolved one -2 - (next state + flags).  kMU
     // candidates per lane are loaded before any is used (independent loads in flight).
@@ -1995,6 +2006,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
       k = 2 * k - 1;
       continue;
     }
+    KM(41, k);
     // (C) occupied slots -> consecutive token indices; tokens written with plain stores
     const int tok_base = Uni(sh->tok_end);
     int occ[kLdsSlots / NT], off[kLdsSlots / NT], total;
@@ -2042,6 +2054,7 @@ __device__ __forceinline__ bool EmitPass2(const Utt &u, Blk &sh, int nb, int tok
     }
     if (KH_TIDX == 0) sh->tok_end = tok_base + total;
     KhSync();
+    KM(42, k);
     // (D) the part's links get their token index; rejected candidates become dead links
     last_read = k + 1 == parts;
     dst_only = kLocal;
@@ -2617,6 +2630,8 @@ __device__ __forceinline__ void SubStamp(const Utt &u, Blk &sh, int ph) {
 #define XS(k) do { KhSync(); SubStamp(u, sh, 96 + (k)); } while (0)
 #elif defined(KH_X_STAMPS)
 #define XS(k) SubStamp(u, sh, 96 + (k))
+#elif defined(KH_SERVE_MARKERS)
+#define XS(k) KM(32 + (k), 0)
 #else
 #define XS(k) do {} while (0)
 #endif
@@ -4975,6 +4990,7 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     if (!ml && !mt) break;
     long long t0 = 0;
     if (u.phase_cycles != nullptr && KH_TIDX == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    KM(20, f);
     if (ml) {
       bool ec, lp;
       const bool fresh = f >= conv_upto;  // the frame's first visit: its emitting links still carry tot_cost in link_k
@@ -5550,6 +5566,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
   long long cand = run->cand;
   int last_gc = 0;  // (lazy schedule) frame of the last garbage collection
   for (; ok && t < t_end; t++) {
+    KM(1, t);
     if (kLazy) {
       // Garbage collection on demand: the next frame may take up to tok_frame_cap tokens and link_frame_cap emitting +
       // link_frame_cap epsilon link slots.  PruneActiveTokens visits every frame since the last collection for the first
@@ -5574,7 +5591,9 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       }
     } else if (t % p.prune_interval == 0 && t > 0) {
       Stamp(u, sh, 15);
+      KM(2, t);
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
+      KM(3, t);
       Stamp(u, sh, 6);
       if ((t / p.prune_interval) % KH_COMPACT_EVERY == 0) ok = Compact(u, t - win_frames, t, p.keep_ac != 0, sh);
       // Frames older than the window keep the slots of what was pruned after they left it
@@ -5587,6 +5606,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
         KhSync();
       }
       Stamp(u, sh, 7);
+      KM(4, t);
       if (!ok) break;
       fb = Uni(u.frame_b[t]);
       fe = Uni(u.frame_e[t]);
@@ -5594,9 +5614,11 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
     float next_cutoff;
     int n_cand = 0;
     ok = kExact ? ProcessEmittingExact(u, p, t, fb, fe, &next_cutoff, &n_cand, sh) : ProcessEmitting(u, p, t, fb, fe, &next_cutoff, &n_cand, sh);
+    KM(5, t);
     if (!ok) break;
     cand += n_cand;
     ok = ProcessNonemitting(u, p, t + 1, next_cutoff, sh);
+    KM(6, t);
     if (!ok) break;
     fb = Uni(sh->front_b);
     fe = Uni(sh->tok_end);
@@ -5605,6 +5627,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       ok = OrderFrontier(u, p, fb, fe, Uni(u.feps_b[t + 1]), Uni(u.feps_e[t + 1]), next_cutoff, sh);
       Stamp(u, sh, 45);
       XS(28);
+      KM(7, t);
       if (!ok) break;
     }
     if (KH_TIDX == 0) {
@@ -8542,14 +8565,28 @@ static std::string ServeDump(const KhOnlineDecoder *o, const int32_t *streams, i
   std::string out;
   char buf[256];
   int shown = 0;
+  // two passes: the streams whose workgroup is still there or that have something pending first (what a time-out is about:
+  // round 6 had a dump whose eight entries were all workgroups that had left), then the others
+  int n_alive = 0, n_pending = 0;
+  for (int s = 0; s < o->num_streams; s++) {
+    const ServeCtl &c = o->serve_ctl[s];
+    n_alive += __atomic_load_n(&c.alive, __ATOMIC_ACQUIRE) != 0 ? 1 : 0;
+    n_pending += __atomic_load_n(&c.ack_seq, __ATOMIC_ACQUIRE) != o->serve_seq[s] ? 1 : 0;
+  }
+  snprintf(buf, sizeof buf, " %d of %d workgroups resident, %d streams with a command in flight;", n_alive, o->num_streams, n_pending);
+  out += buf;
+  for (int pass = 0; pass < 2; pass++)
   for (int i = 0; i < (streams ? n : o->num_streams) && shown < 8; i++) {
     const int s = streams ? streams[i] : i;
     const ServeCtl &c = o->serve_ctl[s];
     const int ack = __atomic_load_n(&c.ack_seq, __ATOMIC_ACQUIRE), dec = __atomic_load_n(&c.decoded, __ATOMIC_ACQUIRE);
     const bool pending = ack != o->serve_seq[s] || (!o->finalized[s] && __atomic_load_n(&c.avail, __ATOMIC_ACQUIRE) > dec);
+    const bool hot = pending || __atomic_load_n(&c.alive, __ATOMIC_ACQUIRE) != 0;
+    if (hot != (pass == 0)) continue;
     if (streams == nullptr && !pending && __atomic_load_n(&c.hb_phase, __ATOMIC_ACQUIRE) == 0) continue;
-    snprintf(buf, sizeof buf, "%s stream %d: avail %d decoded %d cmd %d/%d ack %d alive %d phase %d (to frame %d) actions %d clock %u", shown ? ";" : "",
-             s, c.avail, dec, c.cmd_op, o->serve_seq[s], ack, c.alive, c.hb_phase, c.hb_arg, c.hb_actions, static_cast<unsigned>(c.hb_clock));
+    snprintf(buf, sizeof buf, "%s stream %d: avail %d decoded %d cmd %d/%d ack %d alive %d phase %d (to frame %d) actions %d clock %u mark %d/%d", shown ? ";" : "",
+             s, c.avail, dec, c.cmd_op, o->serve_seq[s], ack, c.alive, c.hb_phase, c.hb_arg, c.hb_actions, static_cast<unsigned>(c.hb_clock),
+             static_cast<int>(static_cast<uint32_t>(c.pad1[0]) >> 24), c.pad1[0] & 0xffffff);
     out += buf;
     shown++;
   }
@@ -8647,6 +8684,12 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
     if (fa.sharedSizeBytes + dyn_lds < want_total) dyn_lds = want_total - fa.sharedSizeBytes;
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn_lds));
   }
+#ifdef KH_SERVE_MARKERS
+  {
+    int32_t *mark = static_cast<int32_t *>(ctl_dev);
+    KH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_serve_mark), &mark, sizeof(mark)));
+  }
+#endif
   if (b->exact) {
     if (getenv("KH_DECODER_ORDER_SORT") != nullptr && atoi(getenv("KH_DECODER_ORDER_SORT")) != 0) p.exact_order = 2;
     hipLaunchKernelGGL(ServeKernel<true>, dim3(static_cast<unsigned>(o->num_streams)), dim3(NT), dyn_lds, o->serve_stream,

@@ -394,6 +394,22 @@ def test_lazy_schedule_collects_garbage_when_the_arenas_fill_up(api, monkeypatch
     assert dec.schedule_counters(0)["garbage_collections"] >= 2, dec.schedule_counters(0)
 
 
+def test_lazy_schedule_collects_garbage_beyond_1024_frames(api, monkeypatch):
+    """The compaction stages the frames' bounds in LDS 1024 frames at a time: an utterance that collects its garbage after
+    its 1024th frame takes the multi-chunk form of both slides.  (Round 6: the serving stress harness, whose utterances are up
+    to 3500 frames long, saw rare GPU faults with frequent collections; no test decoded that far with small arenas.)"""
+    monkeypatch.setenv("KH_DECODER_ARENA_GB", "0")
+    monkeypatch.setenv("KH_DECODER_SLOTS", "1")
+    monkeypatch.setenv("KH_DECODER_TOKENS_PER_FRAME", "8192")
+    monkeypatch.setenv("KH_DECODER_WINDOW_TOKENS_PER_FRAME", "256")
+    monkeypatch.setenv("KH_DECODER_STABLE_TOKENS_PER_FRAME", "16")
+    rng = np.random.default_rng(781)
+    g = graph_like_hclg(rng, 50000, 400)
+    lls = [workloads.make_loglikes(rng, 2600, 400), workloads.make_loglikes(rng, 1300, 400)]
+    dec = run_case(api, g, lls, api.decoder_config(beam=11.0, max_active=900, min_active=100, lattice_beam=5.0))
+    assert dec.schedule_counters(0)["garbage_collections"] >= 4, dec.schedule_counters(0)
+
+
 def test_lazy_schedule_large_frames_and_many_survivors(api):
     """Frames beyond the 12288 tokens FinalizeDecoding keeps in LDS go through the general routines, and a frame
     with more survivors than the hand-off map holds passes its extra_costs through memory: a wide beam without

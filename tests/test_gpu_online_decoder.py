@@ -162,3 +162,37 @@ def test_lazy_prune_schedule_same_results(api, monkeypatch, span):
     lazy.advance_decoding([1], [dev[1]])
     lazy.finalize_decoding([1])
     assert_same_lattice(lazy.get_raw_lattice(1), ref.get_raw_lattice(1))
+
+
+def test_lazy_stream_with_span_collections_beyond_1024_frames(api, monkeypatch):
+    """KH_SERVE_LAZY_SPAN (experimental): a long utterance (2300 frames) as a lazy online stream that collects its garbage
+    every 64 frames - three dozen collections, two dozen of them behind the 1024th frame, where the compaction stages the
+    frames' bounds in more than one LDS chunk - against the offline decoder on the same scores."""
+    monkeypatch.setenv("KH_SERVE_LAZY_SPAN", "64")
+    rng = np.random.default_rng(782)
+    g = workloads.make_hclg_like(rng, 50000, 400)
+    cfg = api.decoder_config(beam=11.0, max_active=900, min_active=100, lattice_beam=5.0)
+    fst = api.Fst(g)
+    Ts = [2300, 1100]
+    lls = [workloads.make_loglikes(rng, T, 400) for T in Ts]
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int32)
+    ref = api.LatticeFasterDecoder(fst, cfg, max_batch=2, max_frames=max(Ts))
+    ref.decode(torch.from_numpy(np.concatenate(lls)).cuda(), off)
+    lazy = api.LatticeFasterOnlineDecoder(fst, cfg, num_streams=2, max_frames=max(Ts))
+    lazy.set_lazy_prune(True)
+    dev = [torch.from_numpy(x).cuda() for x in lls]
+    lazy.init_decoding([0, 1])
+    fed = [0, 0]
+    while any(f < T for f, T in zip(fed, Ts)):
+        act, chunks = [], []
+        for s in range(2):
+            if fed[s] < Ts[s]:
+                k = int(min(Ts[s] - fed[s], rng.integers(60, 140)))
+                act.append(s)
+                chunks.append(dev[s][fed[s]:fed[s] + k])
+                fed[s] += k
+        lazy.advance_decoding(act, chunks)
+    lazy.finalize_decoding([0, 1])
+    for s in range(2):
+        assert_same_lattice(lazy.get_raw_lattice(s), ref.get_raw_lattice(s))
+        assert_same_best_path(lazy.get_best_path(s), ref.get_best_path(s))

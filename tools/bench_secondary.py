@@ -458,11 +458,12 @@ def online2_cfg4(api, torch, workload=None, streams=256, chunks=(5, 50), only_pe
         serve_leg(c, "", "")
     # ... and with the offline kernel's lazy pruning schedule for the streams (kh_online_decoder_set_lazy_prune: nothing is
     # pruned while a stream advances, FinalizeDecoding prunes every frame once; same final lattices and best paths)
-    dec.set_lazy_prune(True)
-    for c in chunks:
-        serve_leg(c, "_lazy", "; lazy pruning schedule (no PruneActiveTokens every prune_interval frames: "
-                              "FinalizeDecoding prunes every frame once)")
-    dec.set_lazy_prune(False)
+    if not os.environ.get("KH_STRESS_SKIP_LAZY"):   # (tools/stress_serving.py --interval-only: the reference schedule's leg alone)
+        dec.set_lazy_prune(True)
+        for c in chunks:
+            serve_leg(c, "_lazy", "; lazy pruning schedule (no PruneActiveTokens every prune_interval frames: "
+                                  "FinalizeDecoding prunes every frame once)")
+        dec.set_lazy_prune(False)
     for c in (() if only_persistent else chunks[:1]):
         # ... and the same loop through the Python-side DecodableNnet2Online + advance_decoding (round 3's leg)
         dn = api.DecodableNnet2Online(nnet, n, max_t, acoustic_scale=acwt, pad_input=True, max_nnet_batch_size=max(256, c))

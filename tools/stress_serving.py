@@ -26,12 +26,15 @@ def main():
     ap.add_argument("--graph-states", type=int, default=2_000_000)
     ap.add_argument("--idle-ms", type=float, default=None)
     ap.add_argument("--closure-cap", type=int, default=None)
+    ap.add_argument("--interval-only", action="store_true", help="only the leg with the reference pruning schedule (skip the lazy one)")
     args = ap.parse_args()
     if args.idle_ms is not None:
         os.environ["KH_SERVE_IDLE_MS"] = str(args.idle_ms)
     if args.closure_cap is not None:
         os.environ["KH_DECODER_CLOSURE_CAP"] = str(args.closure_cap)
     os.environ.setdefault("KH_SERVE_TIMEOUT_MS", "20000")
+    if args.interval_only:
+        os.environ["KH_STRESS_SKIP_LAZY"] = "1"
     # the CPU baseline's stand-in: a child forked before the GPU is initialised, alive and blocked on its pipe throughout
     rfd, wfd = os.pipe()
     pid = os.fork()
@@ -59,7 +62,8 @@ def main():
         t1 = time.perf_counter()
         try:
             res = sec.online2_cfg4(api, torch, workload=wl, streams=args.streams, chunks=(5,), only_persistent=True)
-            a, b = res["chunk_5_frames_persistent"], res["chunk_5_frames_persistent_lazy"]
+            a = res["chunk_5_frames_persistent"]
+            b = res.get("chunk_5_frames_persistent_lazy", a)
             ok = a["utterances_served"] > 0 and b["utterances_served"] > 0
             clean += 1 if ok else 0
             worst = max(worst, a["chunk_latency_ms"]["max"], b["chunk_latency_ms"]["max"])
