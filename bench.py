@@ -952,19 +952,39 @@ def main():
                    "--graph-states", str(args.graph_states), "--secondary-timeout", str(args.secondary_timeout)]
             secondary = None
             try:
+                import tempfile
                 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=args.secondary_timeout + 240, env=env)
-                lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+                # The child's stdout goes to a FILE and the child is never waited for beyond its deadline: a process whose
+                # kernel hangs on the GPU may not even die when killed (its exit waits for the queue's teardown) - the
+                # line it printed before is in the file either way.
+                with tempfile.NamedTemporaryFile(prefix="bench_secondary_", suffix=".json", delete=False) as tf:
+                    tf_name = tf.name
+                with open(tf_name, "wb") as child_out:
+                    proc = subprocess.Popen(cmd, stdout=child_out, env=env)
+                deadline = time.perf_counter() + args.secondary_timeout + 150
+                while proc.poll() is None and time.perf_counter() < deadline:
+                    time.sleep(0.5)
+                rc = proc.poll()
+                if rc is None:
+                    proc.kill()
+                    for _ in range(20):      # (bounded: 10 s)
+                        if proc.poll() is not None:
+                            break
+                        time.sleep(0.5)
+                    rc = proc.poll()
+                with open(tf_name, "rb") as f:
+                    lines = [l for l in f.read().decode(errors="replace").splitlines() if l.startswith("{")]
+                try:
+                    os.unlink(tf_name)
+                except OSError:
+                    pass
                 if lines:
                     secondary = json.loads(lines[-1]).get("secondary")
                 if secondary is None:
-                    secondary = {"error": "the secondary legs' process printed no result (exit status %d)" % p.returncode}
-                if p.returncode != 0:
-                    secondary["child_exit_status"] = p.returncode
+                    secondary = {"error": "the secondary legs' process printed no result (exit status %r)" % (rc,)}
+                if rc != 0:
+                    secondary["child_exit_status"] = rc if rc is not None else "still running when bench.py left (killed, not reaped)"
                     out["secondary_failed"] = True
-            except subprocess.TimeoutExpired:
-                secondary = {"error": "the secondary legs' process did not end within %d s" % (args.secondary_timeout + 240)}
-                out["secondary_failed"] = True
             except Exception as e:   # noqa: BLE001 - the secondary legs never fail the headline run
                 secondary = {"error": repr(e)}
                 out["secondary_failed"] = True

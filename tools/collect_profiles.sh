@@ -58,7 +58,7 @@ python3 tools/phases_extract.py "$out/canon.err" > "$out/${tag}_decoder_phases_c
 python3 tools/pmc_record.py "$out/${tag}_pmc_FETCH_SIZE.txt" "$out/${tag}_pmc_WRITE_SIZE.txt" "$out/${tag}_bench_kernel_stats.csv" "$out/${tag}_pmc_traffic.json" reference-order || { echo "collect_profiles: PMC record incomplete" >&2; exit 1; }
 cp "$out/${tag}_pmc_FETCH_SIZE.txt" "$out/${tag}_pmc_WRITE_SIZE.txt" "$out/${tag}_pmc_traffic.json" profiles/ || exit 1
 # (every leg of the line, the CPU baselines included: 5-8 minutes depending on the box - its own, longer limit)
-KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout ${PROFILE_BENCH_TIMEOUT:-900} python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/bench.err"
+KH_DECODER_PROFILE=1 BENCH_VERBOSE=1 timeout ${PROFILE_BENCH_TIMEOUT:-1200} python3 bench.py --steps 3 --warmup 1 > "$out/${tag}_bench.json" 2> "$out/bench.err"
 [ -s "$out/${tag}_bench.json" ] || { echo "collect_profiles: the bench line is empty (timeout?)" >&2; exit 1; }
 python3 tools/phases_extract.py "$out/bench.err" > "$out/${tag}_decoder_phases.txt"
 rm -rf "$out/kt" "$out"/pmc_FETCH_SIZE "$out"/pmc_WRITE_SIZE
