@@ -464,6 +464,7 @@ SortScatterKernel(const unsigned long long *__restrict__ kin, const int32_t *__r
 // in (k1, v1) (returned through *in_second = 1) or back in (k0, v0).  work: kSortBins * n_blocks + kSortBins words.
 int SortPairs64(unsigned long long *k0, int32_t *v0, unsigned long long *k1, int32_t *v1, int64_t n, int lo_bits, int hi_bits,
                 uint32_t *work, hipStream_t st, int *in_second) {
+  if (n <= 0) { *in_second = 0; return KH_OK; }   // nothing to sort: a 0-block launch is an error on HIP
   const int n_blocks = static_cast<int>((n + kSortTile - 1) / kSortTile);
   uint32_t *hist = work, *totals = work + static_cast<size_t>(kSortBins) * n_blocks;
   int cur = 0;

@@ -476,6 +476,10 @@ class _PipeHelper:
                 if rc is None:
                     rc = self._RUNNING
                 os.write(rep, struct.pack("<Ii", ident, rc))
+            elif op == b"f":      # the requester has the exit status: drop the entry (a scp of pipes opens thousands of them)
+                p = children.pop(ident, None)
+                if p is not None and p.poll() is None:
+                    children[ident] = p     # still running (forgotten before it was waited for): reaped at the end
             elif op == b"q":
                 break
         for p in children.values():
@@ -545,8 +549,17 @@ class _PipeHelper:
             # (a reader whose command exited with status 0 before the open returned has simply produced its output already:
             # the shell held the FIFO open while it ran)
             f.close()
+            self._forget(ident)
             raise KaldiError("pipe %s: the command exited with status %d before its pipe was connected" % (cmd, state["dead"]))
         return ident, f
+
+    def _forget(self, ident):
+        """No reply: the helper drops the table entry of a child whose status has been delivered."""
+        with self.lock:
+            try:
+                os.write(self.req, struct.pack("<cII", b"f", ident, 0))
+            except OSError:
+                pass
 
     def wait(self, ident):
         """pclose(): the child's exit status.  Polls, so that one slow child does not hold the helper (and with it every
@@ -557,6 +570,7 @@ class _PipeHelper:
             if rc is None:
                 return -1
             if rc != self._RUNNING:
+                self._forget(ident)
                 return rc
             time.sleep(delay)
             delay = min(0.05, delay * 1.5)

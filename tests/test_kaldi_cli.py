@@ -225,6 +225,7 @@ def test_pipe_helper_is_not_stalled_by_a_slow_child_and_reports_its_own_death(tm
         quick = cli._PipeFile("printf abc", reading=True)
         assert quick.f.read() == b"abc" and quick.close() == 0
         assert time.perf_counter() - t0 < 1.0, "a second pipe had to wait for the first one's child"
+        assert h._poll(quick.ident) == -1, "the helper kept the table entry of a child whose status was delivered"
         th.join()
         assert box["rc"] == 0
         # the helper process gone: an error, not a blocked open()
