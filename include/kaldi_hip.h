@@ -241,6 +241,14 @@ int kh_nnet_compute(KhNnet *nnet, const float *feats, int feat_stride,
                     const int32_t *utt_row_offsets_host, int n_utts,
                     int pad_input, int epilogue, float prob_scale, float *out,
                     int out_stride, int32_t *out_row_offsets_host);
+/* The same call returning as soon as its work is QUEUED on the library's stream: `out` is valid for work queued on that
+ * stream behind it (or after a synchronisation), the handle keeps the call's activation buffers until its next call or its
+ * destruction.  What lets a caller prepare the consumer of the output while the forward pass runs
+ * (kh_discriminative_lattice_computations_parts; a binary that reads the next archive entry while the GPU works). */
+int kh_nnet_compute_async(KhNnet *nnet, const float *feats, int feat_stride,
+                    const int32_t *utt_row_offsets_host, int n_utts,
+                    int pad_input, int epilogue, float prob_scale, float *out,
+                    int out_stride, int32_t *out_row_offsets_host);
 
 /* ------------------------------------------------------------------ a9
  * DiagGmm (gmm/diag-gmm.h:83-135). */
@@ -726,6 +734,21 @@ int kh_discriminative_lattice_computations(
     const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic, const float *state_final,
     const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights, const int32_t *tid2pdf,
     const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
+    float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
+    KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, double *stats);
+
+/* The same call with the denominator lattices as they sit in the examples - one set of host arrays per lattice
+ * (NnetDiscriminativeUpdater::Propagate gets its examples one by one, nnet2/nnet-compute-discriminative.cc:150-175):
+ * n_states[l], arc_offsets[l][n_states[l] + 1] (starting at 0), and per arc arc_ilabel[l], arc_nextstate[l] (state
+ * numbers within the lattice), arc_graph[l], arc_acoustic[l]; state_final[l][n_states[l]].  The library assembles the
+ * batch in pinned memory with a few host threads and uploads / prepares it on a stream of its own, beside the forward
+ * pass the caller has launched on the library's stream and not waited for; only the steps that read `posteriors` are
+ * ordered behind it.  Everything else as kh_discriminative_lattice_computations. */
+int kh_discriminative_lattice_computations_parts(
+    int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
+    const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
+    const float *const *state_final, const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights,
+    const int32_t *tid2pdf, const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
     float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
     KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, double *stats);
 

@@ -9,6 +9,9 @@ the HIP stream; no computation is done by torch and there is no fallback: every
 function raises KhError (the KALDI_ERR equivalent) if the library call fails.
 """
 import ctypes as C
+import os
+import sys
+import time
 
 import numpy as np
 import torch
@@ -274,9 +277,10 @@ class Nnet:
     def right_context(self):
         return lib().kh_nnet_right_context(self._h)
 
-    def compute(self, feats, utt_row_offsets=None, pad_input=True, epilogue=False, prob_scale=1.0, out=None):
+    def compute(self, feats, utt_row_offsets=None, pad_input=True, epilogue=False, prob_scale=1.0, out=None, wait=True):
         """NnetComputation (nnet-compute.cc:159-166) for a batch stacked by rows;
-        epilogue=True adds DecodableAmNnet's floor/log/-logprior/scale."""
+        epilogue=True adds DecodableAmNnet's floor/log/-logprior/scale.
+        wait=False: kh_nnet_compute_async - the call returns when the work is queued on the library's stream."""
         T = feats.shape[0]
         if utt_row_offsets is None:
             utt_row_offsets = [0, T]
@@ -291,7 +295,7 @@ class Nnet:
             stride = (od + 3) // 4 * 4
             out = torch.empty((rows, stride), dtype=torch.float32, device=feats.device)[:, :od]
         out_off = np.zeros(n_utts + 1, np.int32)
-        check(lib().kh_nnet_compute(self._h, _p(feats), _dim(feats).stride,
+        check((lib().kh_nnet_compute if wait else lib().kh_nnet_compute_async)(self._h, _p(feats), _dim(feats).stride,
                                     off.ctypes.data_as(capi.c_int32_p), n_utts, int(pad_input),
                                     int(epilogue), float(prob_scale), _p(out), _dim(out).stride,
                                     out_off.ctypes.data_as(capi.c_int32_p)))
@@ -1423,6 +1427,8 @@ def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="s
     if criterion not in ("mmi", "smbr", "mpfe"):
         raise KhError('criterion must be "mmi", "mpfe" or "smbr"')
     n = len(egs)
+    timing = os.environ.get("KH_LATTICE_TIMING") is not None   # host-side split of the call on stderr (tools/time_cfg5.py)
+    t_in = time.perf_counter()
     t2p = np.ascontiguousarray(tid2pdf, np.int32)
     pri = np.ascontiguousarray(priors, np.float32)
     Ts = np.array([len(e["num_ali"]) for e in egs], np.int64)
@@ -1431,16 +1437,14 @@ def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="s
     feat_rows = np.array([e["feats"].shape[0] for e in egs], np.int64)
     foff = np.concatenate([[0], np.cumsum(feat_rows)]).astype(np.int32)
     feats = torch.cat([e["feats"] for e in egs], 0) if n > 1 else egs[0]["feats"]
-    out, out_off = nnet.compute(feats, foff, pad_input=False)
+    out, out_off = nnet.compute(feats, foff, pad_input=False, wait=False)   # (the lattice call below ends with a wait for the stream)
+    t_fwd = time.perf_counter()
     if not np.array_equal(np.diff(np.asarray(out_off)), Ts):
         raise KhError("KALDI_ASSERT(posteriors.NumRows() == num_frames) nnet-compute-discriminative.cc:194")
     if out.shape[1] != len(pri):
         raise KhError("KALDI_ASSERT(num_pdfs == priors.Dim()) :196")
     if criterion != "mmi" and tid2phone is None:
         raise KhError("sMBR / MPFE need the transition-id -> phone map")
-    nl, soff, aoff, il, ns, g, a, fin = den_lats if den_lats is not None else _cat_lattices([e["den_lat"] for e in egs])
-    if nl != n:
-        raise KhError("one denominator lattice per example")
     ali = np.ascontiguousarray(np.concatenate([np.asarray(e["num_ali"], np.int32) for e in egs]), np.int32)
     weights = np.array([float(e.get("weight", 1.0)) for e in egs], np.float32)
     t2ph = np.ascontiguousarray(tid2phone, np.int32) if tid2phone is not None else None
@@ -1448,13 +1452,42 @@ def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="s
     deriv = torch.empty_like(out)
     st = np.zeros(5)
     ip, fp = capi.c_int32_p, capi.c_float_p
-    check(lib().kh_discriminative_lattice_computations(
-        nl, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
-        g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp), ali.ctypes.data_as(ip), row_off.ctypes.data_as(ip),
-        weights.ctypes.data_as(fp), t2p.ctypes.data_as(ip), t2ph.ctypes.data_as(ip) if t2ph is not None else None, len(t2p) - 1,
-        sil.ctypes.data_as(ip), len(sil), {"mmi": 0, "smbr": 1, "mpfe": 2}[criterion], float(acoustic_scale), int(bool(drop_frames)),
-        int(bool(one_silence_class)), pri.ctypes.data_as(fp), _p(out), _dim(out), _p(deriv), _dim(deriv),
-        st.ctypes.data_as(capi.c_double_p)))
+    tail = (ali.ctypes.data_as(ip), row_off.ctypes.data_as(ip),
+            weights.ctypes.data_as(fp), t2p.ctypes.data_as(ip), t2ph.ctypes.data_as(ip) if t2ph is not None else None, len(t2p) - 1,
+            sil.ctypes.data_as(ip), len(sil), {"mmi": 0, "smbr": 1, "mpfe": 2}[criterion], float(acoustic_scale), int(bool(drop_frames)),
+            int(bool(one_silence_class)), pri.ctypes.data_as(fp), _p(out), _dim(out), _p(deriv), _dim(deriv),
+            st.ctypes.data_as(capi.c_double_p))
+    if den_lats is None:
+        # the lattices as the examples hold them: the library assembles the batch (host threads, pinned memory) and prepares
+        # it on the device beside the forward pass launched above, which nobody has waited for yet
+        keep, cols = [], []
+        for key, dt in (("arc_offsets", np.int64), ("arc_ilabel", np.int32), ("arc_nextstate", np.int32), ("arc_graph", np.float32),
+                        ("arc_acoustic", np.float32), ("state_final", np.float32)):
+            arrs = [np.ascontiguousarray(e["den_lat"][key], dt) for e in egs]
+            keep.append(arrs)
+            cols.append(np.fromiter((x.__array_interface__["data"][0] for x in arrs), np.uint64, n))
+        nst = np.fromiter((e["den_lat"]["n_states"] for e in egs), np.int32, n)
+        lens = [np.fromiter((x.size if x.ndim == 1 else -1 for x in arrs), np.int64, n) for arrs in keep]
+        na = np.fromiter((int(x[-1]) if x.size else -1 for x in keep[0]), np.int64, n)
+        good = (lens[0] == nst + 1) & (lens[5] == nst)
+        for k in range(1, 5):
+            good &= lens[k] == na
+        if not good.all():
+            raise KhError("example %d: the arrays of den_lat do not have the lengths n_states / arc_offsets give" % int(np.argmin(good)))
+        vp = C.c_void_p
+        if timing:
+            sys.stderr.write("[api timing] forward launched after %.2f ms, lattice arrays listed after %.2f ms\n"
+                             % ((t_fwd - t_in) * 1e3, (time.perf_counter() - t_in) * 1e3))
+        check(lib().kh_discriminative_lattice_computations_parts(
+            n, nst.ctypes.data_as(ip), *[c.ctypes.data_as(vp) for c in cols], *tail))
+        del keep
+    else:
+        nl, soff, aoff, il, ns, g, a, fin = den_lats
+        if nl != n:
+            raise KhError("one denominator lattice per example")
+        check(lib().kh_discriminative_lattice_computations(
+            nl, soff.ctypes.data_as(ip), aoff.ctypes.data_as(capi.c_int64_p), il.ctypes.data_as(ip), ns.ctypes.data_as(ip),
+            g.ctypes.data_as(fp), a.ctypes.data_as(fp), fin.ctypes.data_as(fp), *tail))
     stats = dict(tot_t=float(Ts.sum()), tot_t_weighted=float((Ts * weights).sum()), tot_num_count=float(st[0]),
                  tot_num_objf=float(st[1]), tot_den_objf=float(st[2]))
     return dict(stats=stats, deriv=deriv, output=out, objf=float(st[3]), weight=float(st[4]))

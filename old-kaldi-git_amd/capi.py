@@ -115,6 +115,7 @@ SIGNATURES = {
     "kh_nnet_left_context": (C.c_int, [vp]),
     "kh_nnet_right_context": (C.c_int, [vp]),
     "kh_nnet_compute": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, C.c_int, C.c_int, f, vp, C.c_int, c_int32_p]),
+    "kh_nnet_compute_async": (C.c_int, [vp, vp, C.c_int, c_int32_p, C.c_int, C.c_int, C.c_int, f, vp, C.c_int, c_int32_p]),
     "kh_gmm_compute_gconsts": (C.c_int, [c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]),
     "kh_diag_gmm_loglikes": (C.c_int, [vp, D, vp, vp, vp, C.c_int, vp, C.c_int]),
     "kh_am_gmm_loglikes": (C.c_int, [vp, D, vp, vp, vp, vp, C.c_int, C.c_int, f, vp, C.c_int]),
@@ -226,6 +227,9 @@ SIGNATURES = {
     "kh_discriminative_lattice_computations": (C.c_int, [C.c_int, c_int32_p, c_int64_p, c_int32_p, c_int32_p, c_float_p, c_float_p, c_float_p,
                                                         c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, C.c_int, c_int32_p, C.c_int,
                                                         C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, c_double_p]),
+    "kh_discriminative_lattice_computations_parts": (C.c_int, [C.c_int, c_int32_p, vp, vp, vp, vp, vp, vp,
+                                                              c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, C.c_int, c_int32_p, C.c_int,
+                                                              C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, c_double_p]),
     "kh_comp_objf_and_deriv": (C.c_int, [C.c_int, c_int32_p, c_int32_p, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, c_float_p, c_float_p]),
 }
 

@@ -97,8 +97,15 @@ __device__ __forceinline__ unsigned KhOpaqueTidX() {
 #ifdef KH_SERVE_MARKERS
 __device__ int32_t *g_serve_mark = nullptr;   // the ServeCtl array (64-byte blocks; word 13 = pad1[0])
 #define KM(k, aux) do { if (KH_TIDX == 0 && g_serve_mark != nullptr) __hip_atomic_store(g_serve_mark + blockIdx.x * 16 + 13, ((k) << 24) | (static_cast<int32_t>(aux) & 0xffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+// WM: the same per WAVE (lane 0 of each wave, 16 words per stream in a second host buffer): whether a stuck workgroup loops
+// or waits at a barrier some of its waves never reach.  WM_ANY(c): a condition met by a lane of the wave (or-ed into bit 20).
+__device__ int32_t *g_wave_mark = nullptr;
+#define WM(k, aux) do { if ((KH_TIDX & 63) == 0 && g_wave_mark != nullptr) __hip_atomic_store(g_wave_mark + blockIdx.x * 64 + (KH_TIDX >> 6), ((k) << 24) | (static_cast<int32_t>(aux) & 0xffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#define WM_ANY(c) (__any(c) ? (1 << 20) : 0)
 #else
 #define KM(k, aux) do {} while (0)
+#define WM(k, aux) do {} while (0)
+#define WM_ANY(c) ((void)(c), 0)
 #endif
 
 #ifndef KH_NT
@@ -4649,6 +4656,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
   if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[14] += 1;
   if (ne > nb) {
     for (int iter = 0;; iter++) {
+      WM(42, iter);
       KhSync();  // the extra_costs of the previous token sweep are in place
       if (iter == 0) PruneLinkPass<true, true, false, true>(u, nb, ne, b, lb, acc1, false, &sh->wl_n[0]);
       else PruneLinkPass<true, true, false>(u, nb, ne, b, lb, acc1, false);
@@ -4667,6 +4675,7 @@ __device__ void PruneForwardLinks(const Utt &u, const Params &p, int b, int e, i
       }
       if (u.phase_cycles != nullptr && KH_TIDX == 0) sh->phase[14] += 1;
       if (!BlockAny(again, sh)) break;
+      if (iter > e - b + 8) { if (KH_TIDX == 0) sh->status = 10; break; }   // (not a DAG: see PruneFrameLds)
     }
     // bit 0 of the listed owners (bit 1 of the destinations is cleared by the excise pass below)
     const int n_list = Uni(sh->wl_n[0]);
@@ -4722,7 +4731,9 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
   int m_dst = -1, m_src = 0;
   float m_k = 0.0f;
   if (mb + t < me) { m_dst = u.link_dst[mb + t]; m_src = u.link_src[mb + t]; m_k = u.link_k[mb + t]; }
+  WM(24, ne - nb);
   KhSync();
+  WM(25, me - mb);
   // ---- emitting links (to frame f + 1, whose extra_costs are final): :309-323
   int flags = 0;
   for (int l = mb + t; l < me; l += NT) {
@@ -4753,6 +4764,7 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
     old_st[k] = -1;
     if (i < e - b) { old_x[k] = LoadExtra(&u.tok_extra[b + i]); old_st[k] = u.tok_state[b + i]; }
   }
+  WM(26, 0);
   LdsSync();  // (s_nc / s_nx are dead from here on: their LDS becomes s_acc1 / s_x)
   for (int i = t; i < e - b; i += NT) {
     s_x[i] = Dec(s_acc0[i]);
@@ -4760,7 +4772,58 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
   }
   // ---- epsilon links (inside the frame): iterate to the fixed point
   if (ne > nb) {
-    for (;;) {
+    for (int round_no = 0;; round_no++) {
+      WM(27, round_no);
+#ifdef KH_SERVE_MARKERS
+      if (round_no == 5000 && g_wave_mark != nullptr) {   // (a frame's links form a DAG of depth <= its tokens: this round is never reached)
+        // what is wrong with the frame's epsilon links?  words 16.. of the stream's debug block
+        int32_t *dbg = g_wave_mark + blockIdx.x * 64 + 16;
+        if (t == 0) { for (int k = 0; k < 8; k++) sh->phase[k] = 0; }
+        KhSync();
+        for (int l = nb + t; l < ne; l += NT) {
+          const int dst = u.link_dst[l], src = u.link_src[l];
+          const float kv = u.link_k[l];
+          if (dst < 0) { __hip_atomic_fetch_add(&sh->phase[4], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+          int cat = -1;
+          if (dst < b || dst >= e) cat = 0;
+          else if (src < b || src >= e) cat = 1;
+          else if (!(kv >= 0.0f)) cat = 2;            // negative or not a number
+          else if (!(kv < INFINITY)) cat = 3;
+          if (cat >= 0) {
+            __hip_atomic_fetch_add(&sh->phase[cat], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int32_t *r = dbg + 8 + 4 * cat;
+            __hip_atomic_store(r + 0, l - nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(r + 1, dst - b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(r + 2, src - b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(r + 3, __float_as_int(kv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          if (dst >= b && dst < e && dst == src) __hip_atomic_fetch_add(&sh->phase[5], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // a link that leads to a token created before its source: the closure appends a token when it first reaches its
+          // state, so such a link exists in a DAG too - counted, with one sample
+          if (dst >= b && dst < e && dst < src) {
+            __hip_atomic_fetch_add(&sh->phase[6], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int32_t *r = dbg + 24;
+            __hip_atomic_store(r + 0, l - nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(r + 1, dst - b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(r + 2, src - b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(r + 3, __float_as_int(kv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        // which tokens keep changing?  (their count this round, one sample with its values)
+        KhSync();
+        if (t == 0) {
+          __hip_atomic_store(dbg + 0, e - b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 1, ne - nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 2, e1 - b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 3, me - mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          for (int k = 0; k < 4; k++) __hip_atomic_store(dbg + 4 + k, static_cast<int32_t>(sh->phase[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 28, static_cast<int32_t>(sh->phase[4]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 29, static_cast<int32_t>(sh->phase[5]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 30, static_cast<int32_t>(sh->phase[6]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dbg + 31, fresh ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+#endif
       LdsSync();
       if (n_dst >= 0) {
         float lec = s_x[n_dst - b] + n_a;  // the parenthesis of :309-311 was evaluated when the link was created
@@ -4780,16 +4843,33 @@ __device__ void PruneFrameLds(const Utt &u, const Params &p, int b, int e, int m
       }
       LdsSync();
       bool changed = false;
+      bool wm_nan = false;
       for (int i = t; i < e - b; i += NT) {
         const uint32_t a0 = s_acc0[i], a1 = s_acc1[i];
         const float v = Dec(a1 < a0 ? a1 : a0);
         changed |= !(v == s_x[i]);
         s_x[i] = v;
         s_acc1[i] = kEncInf;
+        wm_nan |= v != v;
+#ifdef KH_SERVE_MARKERS
+        if (round_no == 5001 && changed && g_wave_mark != nullptr) {
+          int32_t *r = g_wave_mark + blockIdx.x * 64 + 48;
+          __hip_atomic_store(r + 0, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(r + 1, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(r + 2, static_cast<int32_t>(a0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(r + 3, static_cast<int32_t>(a1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#endif
       }
+      WM(28, (round_no & 0xfffff) | WM_ANY(wm_nan));
       if (u.phase_cycles != nullptr && t == 0) sh->phase[14] += 1;
       if (!BlockAny(changed, sh)) break;
+      // The frame's epsilon links form a DAG no deeper than its tokens: a round beyond that means the links are not what
+      // the closure wrote (round 6: one serving stream in ~3 % of the stress harness's runs spun here for ever and took the
+      // whole grid's time-out with it).  The utterance fails (status 10) instead of the service.
+      if (round_no > e - b + 8) { if (t == 0) sh->status = 10; break; }
     }
+    WM(29, 0);
     // excise :315
     if (n_dst >= 0 && s_x[n_dst - b] + n_a > lb) {
       u.link_dst[nb + t] = -1;
@@ -4900,7 +4980,8 @@ __device__ void PruneFrameLdsBig(const Utt &u, const Params &p, int b, int e, in
   }
   // ---- epsilon links (inside the frame): relax in place to the fixed point
   if (ne > nb) {
-    for (;;) {
+    for (int round_no = 0;; round_no++) {
+      WM(32, round_no);
       LdsSync();
       bool changed = false;
       for (int l = nb + t; l < ne; l += NT) {
@@ -4951,6 +5032,7 @@ __device__ void PruneTokensForFrame(const Utt &u, int b, int e) {
 // dispatched by the frame's size to the LDS routines above.
 __device__ __forceinline__ void PruneVisit(const Utt &u, const Params &p, int b, int e, int mb, int me, int nb, int ne, int b1, int e1,
                                            bool prune_toks_f1, bool fresh, float delta, bool *ec, bool *lp, Blk &sh) {
+  WM(e - b <= kPruneLdsTok && e1 - b1 <= kPruneLdsTok ? 21 : (e - b <= 2 * kLdsSlots ? 22 : 23), e - b);
   if (e - b <= kPruneLdsTok && e1 - b1 <= kPruneLdsTok)
     PruneFrameLds(u, p, b, e, mb, me, nb, ne, b1, e1, prune_toks_f1, fresh, delta, ec, lp, sh);
   else if (e - b <= 2 * kLdsSlots)
@@ -4991,11 +5073,13 @@ __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float 
     long long t0 = 0;
     if (u.phase_cycles != nullptr && KH_TIDX == 0) t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
     KM(20, f);
+    WM(20, f);
     if (ml) {
       bool ec, lp;
       const bool fresh = f >= conv_upto;  // the frame's first visit: its emitting links still carry tot_cost in link_k
       const int b = Uni(vb), e = Uni(ve), mb = Uni(vmb), me = Uni(vme), nb = Uni(vnb), ne = Uni(vne), b1 = Uni(vb1), e1 = Uni(ve1);
       PruneVisit(u, p, b, e, mb, me, nb, ne, b1, e1, mt, fresh, delta, &ec, &lp, sh);
+      WM(50, f);
       if (KH_TIDX == 0) {
         if (ec && f > 0) StoreFlag(&u.must_links[f - 1], 1);
         if (lp) StoreFlag(&u.must_toks[f], 1);
@@ -5556,6 +5640,54 @@ __device__ bool DecodeInit(const Utt &u, const Params &p, Blk &sh, Run *run) {
   return ok;
 }
 
+#ifdef KH_SERVE_MARKERS
+// (debug build) the links and tokens a frame has just created, checked where they are created: a violation is written to
+// the stream's debug block (words 16..) and the workgroup STAYS here - the host's time-out dump then shows it.
+__device__ void DbgCheckFrame(const Utt &u, const Params &p, Blk &sh, int t, int t_start, int pfb, int pfe, int fb, int fe) {
+  if (g_wave_mark == nullptr) return;
+  int32_t *dbg = g_wave_mark + blockIdx.x * 64 + 16;
+  const int mb = Uni(u.femit_b[t]), me = Uni(u.femit_e[t]), nb = Uni(u.feps_b[t + 1]), ne = Uni(u.feps_e[t + 1]);
+  int cat = -1, wl = 0, wd = 0, ws = 0, wk = 0;
+  for (int l = mb + KH_TIDX; l < me; l += NT) {
+    const int dst = u.link_dst[l], src = u.link_src[l];
+    const float kv = u.link_k[l];
+    if (dst < 0) continue;
+    int c = -1;
+    if (dst < fb || dst >= fe) c = 10; else if (src < pfb || src >= pfe) c = 11; else if (!(kv == kv) || !(fabsf(kv) < INFINITY)) c = 12;
+    if (c >= 0) { cat = c; wl = l - mb; wd = dst; ws = src; wk = __float_as_int(kv); }
+  }
+  for (int l = nb + KH_TIDX; l < ne; l += NT) {
+    const int dst = u.link_dst[l], src = u.link_src[l];
+    const float kv = u.link_k[l];
+    if (dst < 0) continue;
+    int c = -1;
+    if (dst < fb || dst >= fe) c = 20; else if (src < fb || src >= fe) c = 21; else if (!(kv >= -1.0e-3f) || !(kv < INFINITY)) c = 22;
+    if (c >= 0) { cat = c; wl = l - nb; wd = dst; ws = src; wk = __float_as_int(kv); }
+  }
+  for (int i = fb + KH_TIDX; i < fe; i += NT) {
+    const float cv = Dec(LoadCostEnc(&u.tok_cost[i]));
+    const int st = u.tok_state[i];
+    int c = -1;
+    if (!(cv == cv) || !(fabsf(cv) < INFINITY)) c = 30; else if (st < 0 || st >= p.num_units) c = 31;
+    if (c >= 0) { cat = c; wl = i - fb; wd = st; ws = 0; wk = __float_as_int(cv); }
+  }
+  if (cat >= 0) {
+    __hip_atomic_store(dbg + 1, wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 2, wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 3, ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 4, wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dbg + 0, 7000 + cat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (BlockAny(cat >= 0, sh)) {
+    if (KH_TIDX == 0) {
+      const int vals[11] = {t, t_start, pfb, pfe, fb, fe, mb, me, nb, ne, static_cast<int>(Uni(sh->hash_dirty))};
+      for (int k = 0; k < 11; k++) __hip_atomic_store(dbg + 5 + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (;;) __builtin_amdgcn_s_sleep(127);
+  }
+}
+#endif
+
 // Decode :77-95 / AdvanceDecoding (lattice-faster-online-decoder.cc:747-769): frames
 // [run->t, t_end).  u.ll is addressed by absolute frame.
 template <bool kLazy, bool kExact = false>
@@ -5595,6 +5727,7 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
       PruneActiveTokens(u, p, t, p.lattice_beam * p.prune_scale, sh);
       KM(3, t);
       Stamp(u, sh, 6);
+      if (Uni(sh->status) != 0) { ok = false; break; }   // (status 10: a frame whose links are inconsistent)
       if ((t / p.prune_interval) % KH_COMPACT_EVERY == 0) ok = Compact(u, t - win_frames, t, p.keep_ac != 0, sh);
       // Frames older than the window keep the slots of what was pruned after they left it
       // (the backward pruning keeps thinning frames ~200 frames behind the frontier): once that
@@ -5613,6 +5746,9 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
     }
     float next_cutoff;
     int n_cand = 0;
+#ifdef KH_SERVE_MARKERS
+    const int dbg_pfb = fb, dbg_pfe = fe;
+#endif
     ok = kExact ? ProcessEmittingExact(u, p, t, fb, fe, &next_cutoff, &n_cand, sh) : ProcessEmitting(u, p, t, fb, fe, &next_cutoff, &n_cand, sh);
     KM(5, t);
     if (!ok) break;
@@ -5640,6 +5776,10 @@ __device__ bool DecodeFrames(const Utt &u, const Params &p, Blk &sh, Run *run, i
     ClearHash(u, fb, fe, sh);
     Stamp(u, sh, 5);
     XS(29);
+#ifdef KH_SERVE_MARKERS
+    KhSync();
+    DbgCheckFrame(u, p, sh, t, run->t, dbg_pfb, dbg_pfe, fb, fe);
+#endif
   }
   run->t = t;
   run->fb = fb;
@@ -6507,6 +6647,18 @@ struct KhOnlineDecoder {
 
 namespace {
 
+// KhDecodeStats::status / the codes the kernels leave in Shared::status
+const char *StatusText(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case 6: return "the lattice did not fit the pool";
+    case 7: return "the survivor lists are full";
+    case 8: case 9: return "reference order: the list order could not be built";
+    case 10: return "a frame's epsilon links are not a DAG - internal inconsistency";
+    default: return "capacity: a token / link arena or a per-frame cap overflowed";
+  }
+}
+
 // CPUs this process may use: the cgroup's cpu.max quota / period (v2; cpu.cfs_quota_us / cpu.cfs_period_us in v1), else
 // the hardware concurrency.  A container with 256 visible cores and a 16-CPU quota runs 16 threads well and 160 badly.
 int HostCpuQuota() {
@@ -6668,7 +6820,7 @@ int BuildLattice(KhDecoder *d, int ui) {
   const UttOut &o = d->h_out[ui];
   const KhDecodeStats &st = o.stats;
   if (st.status != 0) {
-    SetError("utterance %d: decoder capacity overflow (code %d)", ui, st.status);
+    SetError("utterance %d: decoder failed (code %d: %s)", ui, st.status, StatusText(st.status));
     return KH_ECAPACITY;
   }
   const int T = d->h_T[ui];
@@ -6826,7 +6978,7 @@ int ComputeBestPathLean(KhDecoder *d, int utt) {
   KhDecoder::Lat &L = d->lats[utt];
   const UttOut &o = d->h_out[utt];
   if (o.stats.status != 0) {
-    SetError("utterance %d: decoder capacity overflow (code %d)", utt, o.stats.status);
+    SetError("utterance %d: decoder failed (code %d: %s)", utt, o.stats.status, StatusText(o.stats.status));
     return KH_ECAPACITY;
   }
   if (d->h_round[utt] >= 0) return 1;   // (online snapshots arrive built)
@@ -8072,7 +8224,7 @@ int kh_decoder_get_stats(const KhDecoder *dc, int utt, KhDecodeStats *stats) {
   KH_CHECK_ARG(d && stats && utt >= 0 && utt < d->n_utts);
   // the raw lattice's sizes are those of the export (the canonical lattice keeps every exported token and link)
   if (d->h_out[utt].stats.status != 0) {
-    SetError("utterance %d: decoder capacity overflow (code %d)", utt, d->h_out[utt].stats.status);
+    SetError("utterance %d: decoder failed (code %d: %s)", utt, d->h_out[utt].stats.status, StatusText(d->h_out[utt].stats.status));
     return KH_ECAPACITY;
   }
   *stats = d->h_out[utt].stats;
@@ -8561,6 +8713,9 @@ static double ServeTimeoutMs() {
   if (const char *e = getenv("KH_SERVE_TIMEOUT_MS")) return std::max(1.0, atof(e));
   return 30000.0;
 }
+#ifdef KH_SERVE_MARKERS
+static int32_t *g_wave_mark_host = nullptr;
+#endif
 static std::string ServeDump(const KhOnlineDecoder *o, const int32_t *streams, int n) {
   std::string out;
   char buf[256];
@@ -8588,6 +8743,21 @@ static std::string ServeDump(const KhOnlineDecoder *o, const int32_t *streams, i
              s, c.avail, dec, c.cmd_op, o->serve_seq[s], ack, c.alive, c.hb_phase, c.hb_arg, c.hb_actions, static_cast<unsigned>(c.hb_clock),
              static_cast<int>(static_cast<uint32_t>(c.pad1[0]) >> 24), c.pad1[0] & 0xffffff);
     out += buf;
+#ifdef KH_SERVE_MARKERS
+    if (pass == 0 && g_wave_mark_host != nullptr && s < 1024) {
+      out += " waves";
+      for (int w = 0; w < 16; w++) {
+        const int32_t m = __atomic_load_n(&g_wave_mark_host[64 * s + w], __ATOMIC_ACQUIRE);
+        snprintf(buf, sizeof buf, " %d/%d", static_cast<int>(static_cast<uint32_t>(m) >> 24), m & 0xffffff);
+        out += buf;
+      }
+      out += " dbg";
+      for (int w = 16; w < 52; w++) {
+        snprintf(buf, sizeof buf, " %d", __atomic_load_n(&g_wave_mark_host[64 * s + w], __ATOMIC_ACQUIRE));
+        out += buf;
+      }
+    }
+#endif
     shown++;
   }
   snprintf(buf, sizeof buf, "%s quit %d, launched %d, relaunches %lld", shown ? ";" : "", o->serve_quit ? *o->serve_quit : -1,
@@ -8688,6 +8858,14 @@ static int ServeEnsureRunning(KhOnlineDecoder *o) {
   {
     int32_t *mark = static_cast<int32_t *>(ctl_dev);
     KH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_serve_mark), &mark, sizeof(mark)));
+    if (g_wave_mark_host == nullptr) {
+      KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_wave_mark_host), sizeof(int32_t) * 64 * 1024, hipHostMallocMapped));
+      memset(g_wave_mark_host, 0, sizeof(int32_t) * 64 * 1024);
+    }
+    int32_t *wm_dev = nullptr;
+    KH_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&wm_dev), g_wave_mark_host, 0));
+    if (o->num_streams > 1024) wm_dev = nullptr;
+    KH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_mark), &wm_dev, sizeof(wm_dev)));
   }
 #endif
   if (b->exact) {
@@ -8948,7 +9126,7 @@ static int SnapshotLattice(KhOnlineDecoder *o, int stream, int use_final_probs) 
       continue;
     }
     if (q.stats.status != 0) {
-      SetError("stream %d: decoder capacity overflow (code %d)", stream, q.stats.status);
+      SetError("stream %d: decoder failed (code %d: %s)", stream, q.stats.status, StatusText(q.stats.status));
       return KH_ECAPACITY;
     }
     b->rounds.clear();

@@ -15,9 +15,12 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <mutex>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1918,7 +1921,8 @@ __global__ void __launch_bounds__(kThreads)
 PseudoLikeKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ arc_off, const int32_t *__restrict__ ilabel,
                  const int32_t *__restrict__ times, const int32_t *__restrict__ row_off, const int32_t *__restrict__ tid2pdf,
                  const float *__restrict__ post, int post_stride, const float *__restrict__ priors, float acoustic_scale,
-                 int total_rows, float *__restrict__ arc_a, unsigned long long *__restrict__ keys, int32_t *__restrict__ vals) {
+                 int total_rows, float *__restrict__ arc_a, unsigned long long *__restrict__ keys, int32_t *__restrict__ vals,
+                 int what /* 1: the keys (they depend on the lattice alone); 2: the pseudo log-likelihoods; 3: both */) {
   const LatDesc L = lats[blockIdx.x];
   const int row0 = row_off[blockIdx.x];
   const unsigned long long none = static_cast<unsigned long long>(total_rows) << 32;   // sorts behind every row
@@ -1926,14 +1930,15 @@ PseudoLikeKernel(const LatDesc *__restrict__ lats, const int64_t *__restrict__ a
     const int t = times[L.state_b + s];
     for (int64_t a = arc_off[L.state_b + s]; a < arc_off[L.state_b + s + 1]; a++) {
       const int il = ilabel[a];
-      vals[a] = static_cast<int32_t>(a);
-      if (il == 0 || t < 0) { keys[a] = none; continue; }
+      if (what & 1) vals[a] = static_cast<int32_t>(a);
+      if (il == 0 || t < 0) { if (what & 1) keys[a] = none; continue; }
       const int pdf = tid2pdf[il], row = row0 + t;
+      if (what & 1) keys[a] = (static_cast<unsigned long long>(row) << 32) | static_cast<unsigned>(pdf);
+      if (!(what & 2)) continue;
       float p = post[static_cast<size_t>(row) * post_stride + pdf];
       if (p < 1.0e-20f) p = 1.0e-20f;                                   // ApplyFloor(1e-20) :233
       const float pseudo = logf(p / priors[pdf]) * acoustic_scale;       // :241-247
       arc_a[a] = -pseudo;                                                // SetValue2(-log_like) :270
-      keys[a] = (static_cast<unsigned long long>(row) << 32) | static_cast<unsigned>(pdf);
     }
   }
 }
@@ -2066,13 +2071,40 @@ __global__ void AliPdfKernel(int n, const int32_t *__restrict__ ali, const int32
 
 }  // namespace
 
-extern "C" int kh_discriminative_lattice_computations(
+namespace {
+// What does not depend on the network output - the upload and preparation of the lattices, the (row, pdf) keys of their arcs
+// and the sort of those keys - runs on a stream of its own, beside the forward pass that is still on the library's stream
+// when the call arrives (the caller launches the forward pass and does not wait for it): of the call's device work only the
+// pseudo log-likelihoods, the sweeps and the two kernels of the posterior algebra are left behind the forward pass.
+hipStream_t SideStream() {
+  static hipStream_t side = [] {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s = nullptr; }
+    return s;
+  }();
+  return side;
+}
+hipEvent_t SideEvent() {
+  static hipEvent_t ev = [] {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    return e;
+  }();
+  return ev;
+}
+// (last declared = first destroyed: no device array of the call is freed while either stream may still use it)
+struct TwoStreamSync {
+  hipStream_t a, b;
+  ~TwoStreamSync() { (void)hipStreamSynchronize(a); if (b != a) (void)hipStreamSynchronize(b); (void)hipGetLastError(); }
+};
+
+int DiscriminativeImpl(
     int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
     const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic, const float *state_final,
     const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights, const int32_t *tid2pdf,
     const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion, float acoustic_scale,
     int drop_frames, int one_silence_class, const float *priors, const float *posteriors, KhMatrixDim d_posteriors,
-    float *deriv, KhMatrixDim d_deriv, double *stats) {
+    float *deriv, KhMatrixDim d_deriv, double *stats, bool labels_checked) {
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_graph && arc_acoustic &&
@@ -2092,13 +2124,23 @@ extern "C" int kh_discriminative_lattice_computations(
       return KH_EINVAL;
     }
   for (int i = 0; i < total_rows; i++) KH_CHECK_ARG(num_ali[i] > 0 && num_ali[i] <= num_tids);
+  // KH_LATTICE_TIMING: the host's view of the call on stderr (ms since its entry)
+  const bool timing = getenv("KH_LATTICE_TIMING") != nullptr;
+  const auto t_in = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
+  double tm_build = 0, tm_side = 0, tm_launched = 0;
   hipStream_t st = Stream();
+  hipStream_t side = SideStream();
+  hipEvent_t side_ev = SideEvent();
+  if (side == nullptr || side_ev == nullptr || getenv("KH_LATTICE_ONE_STREAM") != nullptr) side = st;
   LatBatch B;
   // (MMI needs LatticeForwardBackward only: the dataflow preparation and sweeps; the MPE / sMBR kernels sweep by level)
-  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, st,
+  rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, side,
                !is_mmi || getenv("KH_LATTICE_LEVELS") != nullptr);
   if (rc) return rc;
-  for (int64_t a = 0; a < B.total_arcs; a++) KH_CHECK_ARG(arc_ilabel[a] >= 0 && arc_ilabel[a] <= num_tids);
+  tm_build = since();
+  if (!labels_checked)
+    for (int64_t a = 0; a < B.total_arcs; a++) KH_CHECK_ARG(arc_ilabel[a] >= 0 && arc_ilabel[a] <= num_tids);
   for (int l = 0; l < n_lats; l++)
     if (B.descs[l].max_time != num_ali_offsets[l + 1] - num_ali_offsets[l]) {
       SetError("example %d: lattice of %d frames, alignment of %d (KALDI_ASSERT(T == num_frames) nnet-compute-discriminative.cc:220)",
@@ -2114,24 +2156,50 @@ extern "C" int kh_discriminative_lattice_computations(
   std::vector<int32_t> h_ali(num_ali, num_ali + total_rows), h_row_off(num_ali_offsets, num_ali_offsets + n_lats + 1),
       h_t2pdf(tid2pdf, tid2pdf + num_tids + 1);
   std::vector<float> h_w(eg_weights, eg_weights + n_lats), h_pri(priors, priors + P);
-  if ((rc = d_ali.Upload(h_ali, st)) || (rc = d_row_off.Upload(h_row_off, st)) || (rc = d_t2pdf.Upload(h_t2pdf, st)) ||
-      (rc = d_w.Upload(h_w, st)) || (rc = d_pri.Upload(h_pri, st)))
+  DevArr<uint32_t> d_sort;
+  TwoStreamSync sync_before_free{side, st};
+  if ((rc = d_ali.Upload(h_ali, side)) || (rc = d_row_off.Upload(h_row_off, side)) || (rc = d_t2pdf.Upload(h_t2pdf, side)) ||
+      (rc = d_w.Upload(h_w, side)) || (rc = d_pri.Upload(h_pri, side)))
     return rc;
+  if (!is_mmi) {
+    std::vector<int32_t> h_t2ph(tid2phone, tid2phone + num_tids + 1), h_sil(silence_phones, silence_phones + n_sil);
+    if ((rc = d_t2ph.Upload(h_t2ph, side)) || (rc = d_sil.Upload(h_sil, side))) return rc;
+    KH_HIP(hipStreamSynchronize(side));   // (the vectors go out of scope)
+  }
   constexpr int kEmitBlocks = 256;
   if (d_ali_pdf.Alloc(total_rows) || d_has_num.Alloc(total_rows) || d_vals.Alloc(A) || d_vals2.Alloc(A) || d_keys.Alloc(A) ||
       d_keys2.Alloc(A) || d_post.Alloc(A) || d_seg.Alloc(A) || d_tot.Alloc(n_lats) || d_ac.Alloc(n_lats) || d_num.Alloc(n_lats) ||
-      d_part.Alloc(3 * kEmitBlocks))
+      d_part.Alloc(3 * kEmitBlocks) ||
+      d_sort.Alloc(static_cast<size_t>(kSortBins) * ((A + kSortTile - 1) / kSortTile + 1) + kSortBins))
     return KH_ENOMEM;
-  KH_HIP(hipMemsetAsync(d_has_num.p, 0, sizeof(int32_t) * (total_rows ? total_rows : 1), st));
+  // ---- beside the forward pass (side stream): the numerator's pdfs, the arcs' (row, pdf) keys and their stable sort;
+  // arcs without a transition-id carry row = total_rows and end up last.  Only the bits that can be set take part: the
+  // pdf's (the low word) and the row's (the high word).
+  KH_HIP(hipMemsetAsync(d_has_num.p, 0, sizeof(int32_t) * (total_rows ? total_rows : 1), side));
+  hipLaunchKernelGGL(AliPdfKernel, dim3(std::max(1, std::min(1024, (total_rows + 255) / 256))), dim3(256), 0, side, total_rows,
+                     d_ali.p, d_t2pdf.p, d_ali_pdf.p);
+  hipLaunchKernelGGL(PseudoLikeKernel, dim3(n_lats), dim3(kThreads), 0, side, B.d_descs.p, B.d_arc_off.p, B.d_ilabel.p, B.d_times.p,
+                     d_row_off.p, d_t2pdf.p, posteriors, d_posteriors.stride, d_pri.p, acoustic_scale, total_rows, B.d_a.p,
+                     d_keys.p, d_vals.p, 1);
+  KH_LAUNCH_CHECK();
+  int hi_bits = 1, lo_bits = 1;
+  while (hi_bits < 31 && (static_cast<unsigned long long>(total_rows) >> hi_bits) != 0) hi_bits++;
+  while (lo_bits < 31 && (static_cast<unsigned long long>(std::max(1, d_posteriors.cols - 1)) >> lo_bits) != 0) lo_bits++;
+  int in_second = 0;
+  if ((rc = SortPairs64(d_keys.p, d_vals.p, d_keys2.p, d_vals2.p, A, lo_bits, hi_bits, d_sort.p, side, &in_second))) return rc;
+  if (side != st) {
+    KH_HIP(hipEventRecord(side_ev, side));
+    KH_HIP(hipStreamWaitEvent(st, side_ev, 0));
+  }
+  tm_side = since();
+  // ---- behind the forward pass (the library's stream)
   for (int r = 0; r < d_deriv.rows && d_deriv.stride != d_deriv.cols; r++)
     KH_HIP(hipMemsetAsync(deriv + static_cast<size_t>(r) * d_deriv.stride, 0, sizeof(float) * d_deriv.cols, st));
   if (d_deriv.stride == d_deriv.cols)
     KH_HIP(hipMemsetAsync(deriv, 0, sizeof(float) * static_cast<size_t>(d_deriv.rows) * d_deriv.cols, st));
-  hipLaunchKernelGGL(AliPdfKernel, dim3(std::max(1, std::min(1024, (total_rows + 255) / 256))), dim3(256), 0, st, total_rows,
-                     d_ali.p, d_t2pdf.p, d_ali_pdf.p);
   hipLaunchKernelGGL(PseudoLikeKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_ilabel.p, B.d_times.p,
                      d_row_off.p, d_t2pdf.p, posteriors, d_posteriors.stride, d_pri.p, acoustic_scale, total_rows, B.d_a.p,
-                     d_keys.p, d_vals.p);
+                     d_keys.p, d_vals.p, 2);
   KH_LAUNCH_CHECK();
   std::vector<double> h_num(n_lats, 0.0), h_tot(n_lats, 0.0);
   if (is_mmi) {
@@ -2146,11 +2214,7 @@ extern "C" int kh_discriminative_lattice_computations(
     } else if ((rc = LaunchForwardBackwardDF(B, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON), st))) {
       return rc;
     }
-    KH_HIP(hipMemcpyAsync(h_num.data(), d_num.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-    KH_HIP(hipMemcpyAsync(h_tot.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
   } else {
-    std::vector<int32_t> h_t2ph(tid2phone, tid2phone + num_tids + 1), h_sil(silence_phones, silence_phones + n_sil);
-    if ((rc = d_t2ph.Upload(h_t2ph, st)) || (rc = d_sil.Upload(h_sil, st))) return rc;
     if ((rc = RunAlphaBeta(B, d_alpha, d_beta, d_tot, 0, st))) return rc;
     if (d_as.Alloc(B.total_states) || d_bs.Alloc(B.total_states) || d_score.Alloc(n_lats) || d_bscore.Alloc(n_lats)) return KH_ENOMEM;
     MpeArgs m;
@@ -2160,17 +2224,7 @@ extern "C" int kh_discriminative_lattice_computations(
                        B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p,
                        d_alpha.p, d_beta.p, d_tot.p, d_as.p, d_bs.p, m, d_post.p, d_score.p, d_bscore.p);
     KH_LAUNCH_CHECK();
-    KH_HIP(hipMemcpyAsync(h_tot.data(), d_score.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
   }
-  // stable sort of the arcs by (row, pdf); arcs without a transition-id carry row = total_rows and end up last.  Only the
-  // bits that can be set take part: the pdf's (the low word) and the row's (the high word).
-  int hi_bits = 1, lo_bits = 1;
-  while (hi_bits < 31 && (static_cast<unsigned long long>(total_rows) >> hi_bits) != 0) hi_bits++;
-  while (lo_bits < 31 && (static_cast<unsigned long long>(std::max(1, d_posteriors.cols - 1)) >> lo_bits) != 0) lo_bits++;
-  DevArr<uint32_t> d_sort;
-  if (d_sort.Alloc(static_cast<size_t>(kSortBins) * ((A + kSortTile - 1) / kSortTile + 1) + kSortBins)) return KH_ENOMEM;
-  int in_second = 0;
-  if ((rc = SortPairs64(d_keys.p, d_vals.p, d_keys2.p, d_vals2.p, A, lo_bits, hi_bits, d_sort.p, st, &in_second))) return rc;
   const unsigned long long *s_keys = in_second ? d_keys2.p : d_keys.p;
   const int32_t *s_vals = in_second ? d_vals2.p : d_vals.p;
   const int seg_blocks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(4096, (A + 255) / 256)));
@@ -2181,8 +2235,16 @@ extern "C" int kh_discriminative_lattice_computations(
                      d_ali_pdf.p, d_has_num.p, d_row_off.p, n_lats, d_w.p, posteriors, d_posteriors.stride, deriv, d_deriv.stride,
                      d_part.p);
   KH_LAUNCH_CHECK();
+  tm_launched = since();
+  // (the copies to the host wait for the device: issued behind the last launch)
   std::vector<double> h_part(3 * kEmitBlocks);
   KH_HIP(hipMemcpyAsync(h_part.data(), d_part.p, sizeof(double) * h_part.size(), hipMemcpyDeviceToHost, st));
+  if (is_mmi) {
+    KH_HIP(hipMemcpyAsync(h_num.data(), d_num.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+    KH_HIP(hipMemcpyAsync(h_tot.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  } else {
+    KH_HIP(hipMemcpyAsync(h_tot.data(), d_score.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+  }
   std::vector<double> h_beta0, h_fwd, h_bscore;
   if (!is_mmi) {   // the reference's forward / backward agreement checks (lattice-functions.cc:808, :909)
     h_beta0.resize(n_lats); h_fwd.resize(n_lats); h_bscore.resize(n_lats);
@@ -2192,6 +2254,9 @@ extern "C" int kh_discriminative_lattice_computations(
       KH_HIP(hipMemcpyAsync(&h_beta0[l], d_beta.p + lat_state_offsets[l], sizeof(double), hipMemcpyDeviceToHost, st));
   }
   KH_HIP(hipStreamSynchronize(st));
+  if (timing)
+    fprintf(stderr, "[kh_lattice timing] lattices prepared %.2f, side stream loaded %.2f, everything launched %.2f, device done %.2f ms\n",
+            tm_build, tm_side, tm_launched, since());
   if (!is_mmi)
     for (int l = 0; l < n_lats; l++) {
       if (!ApproxEqualD(h_fwd[l], h_beta0[l], 1e-6)) {
@@ -2215,4 +2280,109 @@ extern "C" int kh_discriminative_lattice_computations(
   stats[3] = objf;       // CompObjfAndDeriv's tot_objf
   stats[4] = wsum;       // ... tot_weight
   return KH_OK;
+}
+
+// pinned staging of kh_discriminative_lattice_computations_parts (kept across calls, grown on demand)
+struct PinnedStage {
+  std::mutex mu;
+  char *p = nullptr;
+  size_t bytes = 0;
+  int Reserve(size_t want) {
+    if (want <= bytes) return KH_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    want += want / 4;
+    KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault));
+    bytes = want;
+    return KH_OK;
+  }
+};
+PinnedStage g_stage;
+
+}  // namespace
+
+extern "C" int kh_discriminative_lattice_computations(
+    int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
+    const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic, const float *state_final,
+    const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights, const int32_t *tid2pdf,
+    const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion, float acoustic_scale,
+    int drop_frames, int one_silence_class, const float *priors, const float *posteriors, KhMatrixDim d_posteriors,
+    float *deriv, KhMatrixDim d_deriv, double *stats) {
+  return DiscriminativeImpl(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final,
+                            num_ali, num_ali_offsets, eg_weights, tid2pdf, tid2phone, num_tids, silence_phones, n_sil, criterion,
+                            acoustic_scale, drop_frames, one_silence_class, priors, posteriors, d_posteriors, deriv, d_deriv, stats,
+                            false);
+}
+
+// The same with the lattices as they sit in the examples, one set of arrays per lattice (NnetDiscriminativeUpdater gets its
+// examples one by one, nnet-compute-discriminative.cc:150-175): the batch arrays are assembled here - a few host threads,
+// straight into pinned memory, while the forward pass the caller has launched runs - instead of by the caller (round 5: 6 ms
+// of numpy concatenation per 256 lattices, between a 10 ms forward pass and 3.5 ms of lattice work).
+extern "C" int kh_discriminative_lattice_computations_parts(
+    int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
+    const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
+    const float *const *state_final, const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights,
+    const int32_t *tid2pdf, const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
+    float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
+    KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, double *stats) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  const auto t_parts = std::chrono::steady_clock::now();
+  KH_CHECK_ARG(n_lats > 0 && n_states && arc_offsets && arc_ilabel && arc_nextstate && arc_graph && arc_acoustic && state_final);
+  std::vector<int64_t> sbase(n_lats + 1, 0), abase(n_lats + 1, 0);
+  for (int l = 0; l < n_lats; l++) {
+    KH_CHECK_ARG(n_states[l] > 0 && arc_offsets[l] && arc_ilabel[l] && arc_nextstate[l] && arc_graph[l] && arc_acoustic[l] &&
+                 state_final[l] && arc_offsets[l][0] == 0 && arc_offsets[l][n_states[l]] >= 0);
+    sbase[l + 1] = sbase[l] + n_states[l];
+    abase[l + 1] = abase[l] + arc_offsets[l][n_states[l]];
+  }
+  const int64_t S = sbase[n_lats], A = abase[n_lats];
+  KH_CHECK_ARG(S < (1ll << 31));
+  std::lock_guard<std::mutex> lock(g_stage.mu);
+  auto up = [](size_t b) { return (b + 63) & ~static_cast<size_t>(63); };
+  const size_t o_soff = 0, o_aoff = o_soff + up(sizeof(int32_t) * (n_lats + 1)), o_il = o_aoff + up(sizeof(int64_t) * (S + 1)),
+               o_ns = o_il + up(sizeof(int32_t) * A), o_g = o_ns + up(sizeof(int32_t) * A), o_a = o_g + up(sizeof(float) * A),
+               o_fin = o_a + up(sizeof(float) * A), total = o_fin + up(sizeof(float) * S);
+  if ((rc = g_stage.Reserve(total))) return rc;
+  int32_t *soff = reinterpret_cast<int32_t *>(g_stage.p + o_soff), *il = reinterpret_cast<int32_t *>(g_stage.p + o_il),
+          *ns = reinterpret_cast<int32_t *>(g_stage.p + o_ns);
+  int64_t *aoff = reinterpret_cast<int64_t *>(g_stage.p + o_aoff);
+  float *g = reinterpret_cast<float *>(g_stage.p + o_g), *a = reinterpret_cast<float *>(g_stage.p + o_a),
+        *fin = reinterpret_cast<float *>(g_stage.p + o_fin);
+  for (int l = 0; l <= n_lats; l++) soff[l] = static_cast<int32_t>(sbase[l]);
+  aoff[0] = 0;
+  std::atomic<int> next{0}, bad{-1};
+  auto work = [&]() {
+    for (;;) {
+      const int l = next.fetch_add(1);
+      if (l >= n_lats) break;
+      const int64_t s0 = sbase[l], a0 = abase[l], na = abase[l + 1] - abase[l];
+      const int nsl = n_states[l];
+      const int64_t *o = arc_offsets[l];
+      bool ok = true;
+      for (int i = 1; i <= nsl; i++) { aoff[s0 + i] = a0 + o[i]; ok &= o[i] >= o[i - 1] && o[i] <= na; }
+      const int32_t *li = arc_ilabel[l];
+      for (int64_t k = 0; k < na; k++) { const int32_t v = li[k]; il[a0 + k] = v; ok &= v >= 0 && v <= num_tids; }
+      memcpy(ns + a0, arc_nextstate[l], sizeof(int32_t) * na);
+      memcpy(g + a0, arc_graph[l], sizeof(float) * na);
+      memcpy(a + a0, arc_acoustic[l], sizeof(float) * na);
+      memcpy(fin + s0, state_final[l], sizeof(float) * nsl);
+      if (!ok) bad.store(l);
+    }
+  };
+  const int n_threads = std::max(1, std::min({4, n_lats, static_cast<int>(std::thread::hardware_concurrency())}));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < n_threads; t++) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+  if (bad.load() >= 0) {
+    SetError("kh_discriminative_lattice_computations_parts: lattice %d: arc offsets not ascending, or an input label outside [0, %d]",
+             bad.load(), num_tids);
+    return KH_EINVAL;
+  }
+  if (getenv("KH_LATTICE_TIMING") != nullptr)
+    fprintf(stderr, "[kh_lattice timing] batch assembled in pinned memory: %.2f ms (%d threads)\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parts).count(), n_threads);
+  return DiscriminativeImpl(n_lats, soff, aoff, il, ns, g, a, fin, num_ali, num_ali_offsets, eg_weights, tid2pdf, tid2phone, num_tids,
+                            silence_phones, n_sil, criterion, acoustic_scale, drop_frames, one_silence_class, priors, posteriors,
+                            d_posteriors, deriv, d_deriv, stats, true);
 }

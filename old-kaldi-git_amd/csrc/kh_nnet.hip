@@ -36,6 +36,9 @@ struct KhNnet {
   std::vector<Comp> comps;
   float *log_priors = nullptr;
   int n_priors = 0;
+  // kh_nnet_compute_async: the descriptors and activation buffers of a call that returned before its work had finished -
+  // released at the start of the next call on this handle (behind a wait for the stream) or with the handle
+  std::vector<void *> held;
 };
 
 namespace {
@@ -182,6 +185,10 @@ void kh_nnet_destroy(KhNnet *n) {
     PoolFree(c.context_dev);
   }
   PoolFree(n->log_priors);
+  if (!n->held.empty()) {
+    (void)hipStreamSynchronize(Stream());
+    for (void *p : n->held) PoolFree(p);
+  }
   delete n;
 }
 
@@ -298,13 +305,22 @@ int kh_nnet_right_context(const KhNnet *n) {
   return a;
 }
 
-int kh_nnet_compute(KhNnet *n, const float *feats, int feat_stride,
+}  // extern "C"
+
+namespace {
+// wait: kh_nnet_compute (the buffers of the call go back to the pool when it returns); !wait: kh_nnet_compute_async
+int NnetComputeImpl(KhNnet *n, const float *feats, int feat_stride,
                     const int32_t *utt_off, int n_utts, int pad_input,
                     int epilogue, float prob_scale, float *out, int out_stride,
-                    int32_t *out_row_offsets_host) {
+                    int32_t *out_row_offsets_host, bool wait) {
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(n && feats && utt_off && out && n_utts > 0 && !n->comps.empty());
+  if (!n->held.empty()) {   // what an asynchronous call left in use
+    KH_HIP(hipStreamSynchronize(Stream()));
+    for (void *p : n->held) PoolFree(p);
+    n->held.clear();
+  }
   const int nc = (int)n->comps.size();
   const int in_dim = n->comps.front().in, out_dim = n->comps.back().out;
   KH_CHECK_ARG(feat_stride >= in_dim && out_stride >= out_dim);
@@ -451,6 +467,17 @@ int kh_nnet_compute(KhNnet *n, const float *feats, int feat_stride,
   }
 
   DevBuf d_index;  // non-contiguous splice indexes
+  // wait: the descriptors / buffers are released to the pool on return, so the work must have finished; else the handle
+  // keeps them until its next call
+  auto finish = [&]() -> int {
+    if (wait) {
+      KH_HIP(hipStreamSynchronize(st));
+      return KH_OK;
+    }
+    for (DevBuf *b : {&d_descs, &buf[0], &buf[1], &d_index})
+      if (b->p) { n->held.push_back(b->p); b->p = nullptr; }
+    return KH_OK;
+  };
   for (int i = 0; i < nc; i++) {
     const KhNnet::Comp &c = n->comps[i];
     const int in_rows = offs[i][n_utts], o_rows = offs[i + 1][n_utts];
@@ -528,8 +555,7 @@ int kh_nnet_compute(KhNnet *n, const float *feats, int feat_stride,
           rc = FusedSoftmaxSumGroup(out, KhMatrixDim{offs[nc][n_utts], sg.out, out_stride}, cur, din, sg.ranges,
                                     epilogue ? n->log_priors : nullptr, prob_scale);
           if (rc) return rc;
-          KH_HIP(hipStreamSynchronize(st));
-          return KH_OK;
+          return finish();
         }
         rc = kh_softmax_per_row(dst, cur, dout, cur_stride);
         if (!rc) rc = kh_apply_floor(dst, dout, 1.0e-20f);  // :942
@@ -559,9 +585,26 @@ int kh_nnet_compute(KhNnet *n, const float *feats, int feat_stride,
                             n->log_priors, prob_scale);
     if (rc) return rc;
   }
-  // descriptors / buffers are released to the pool on return: wait for the work.
-  KH_HIP(hipStreamSynchronize(st));
-  return KH_OK;
+  return finish();
+}
+}  // namespace
+
+extern "C" {
+
+int kh_nnet_compute(KhNnet *n, const float *feats, int feat_stride,
+                    const int32_t *utt_off, int n_utts, int pad_input,
+                    int epilogue, float prob_scale, float *out, int out_stride,
+                    int32_t *out_row_offsets_host) {
+  return NnetComputeImpl(n, feats, feat_stride, utt_off, n_utts, pad_input, epilogue, prob_scale, out, out_stride,
+                         out_row_offsets_host, true);
+}
+
+int kh_nnet_compute_async(KhNnet *n, const float *feats, int feat_stride,
+                          const int32_t *utt_off, int n_utts, int pad_input,
+                          int epilogue, float prob_scale, float *out, int out_stride,
+                          int32_t *out_row_offsets_host) {
+  return NnetComputeImpl(n, feats, feat_stride, utt_off, n_utts, pad_input, epilogue, prob_scale, out, out_stride,
+                         out_row_offsets_host, false);
 }
 
 }  // extern "C"

@@ -86,3 +86,43 @@ def test_context_mismatch_is_an_error(api):
     egs[0]["num_ali"] = egs[0]["num_ali"][:-1]
     with pytest.raises(api.KhError):
         api.discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="mmi")
+
+
+def test_lattices_by_example_and_as_one_batch_give_the_same_derivative(api):
+    """kh_discriminative_lattice_computations_parts (the lattices as the examples hold them, assembled by the library beside
+    the forward pass) against kh_discriminative_lattice_computations on the caller's concatenation: the same bits."""
+    rng = np.random.default_rng(57)
+    nnet, priors, tid2pdf, tid2phone, egs = make_examples(api, rng)
+    for criterion in ("mmi", "smbr"):
+        kw = dict(criterion=criterion, acoustic_scale=0.1, drop_frames=True, tid2phone=tid2phone, silence_phones=[1, 2])
+        a = api.discriminative_lattice_computations(nnet, priors, tid2pdf, egs, **kw)
+        b = api.discriminative_lattice_computations(nnet, priors, tid2pdf, egs, den_lats=api.cat_lattices([e["den_lat"] for e in egs]), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a["deriv"], b["deriv"]) and torch.equal(a["output"], b["output"])
+        assert a["stats"] == b["stats"] and a["objf"] == b["objf"]
+    bad = [dict(e) for e in egs]
+    bad[1]["den_lat"] = dict(bad[1]["den_lat"])
+    bad[1]["den_lat"]["arc_graph"] = bad[1]["den_lat"]["arc_graph"][:-1]
+    with pytest.raises(api.KhError):
+        api.discriminative_lattice_computations(nnet, priors, tid2pdf, bad, criterion="mmi")
+    bad[1]["den_lat"] = dict(egs[1]["den_lat"])
+    il = bad[1]["den_lat"]["arc_ilabel"].copy()
+    il[3] = len(tid2pdf) + 5      # an input label without a transition-id
+    bad[1]["den_lat"]["arc_ilabel"] = il
+    with pytest.raises(api.KhError):
+        api.discriminative_lattice_computations(nnet, priors, tid2pdf, bad, criterion="mmi")
+
+
+def test_forward_pass_queued_without_waiting_gives_the_same_output(api):
+    """kh_nnet_compute_async: the call returns with its work queued; after a synchronisation the output is kh_nnet_compute's,
+    also when the next call on the handle follows at once (the handle keeps the first call's buffers until then)."""
+    rng = np.random.default_rng(58)
+    nnet, priors, tid2pdf, tid2phone, egs = make_examples(api, rng, lens=(33, 41))
+    feats = torch.cat([e["feats"] for e in egs], 0)
+    foff = np.concatenate([[0], np.cumsum([e["feats"].shape[0] for e in egs])]).astype(np.int32)
+    want, off_w = nnet.compute(feats, foff, pad_input=False)
+    got1, off_1 = nnet.compute(feats, foff, pad_input=False, wait=False)
+    got2, off_2 = nnet.compute(feats, foff, pad_input=False, wait=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(off_w, off_1) and np.array_equal(off_w, off_2)
+    assert torch.equal(want, got1) and torch.equal(want, got2)
