@@ -6287,7 +6287,7 @@ struct ServeCtl {
   // (100 MHz) when it last started or finished one - what kh_online_decoder_serve_wait / _stop report when they time out
   int32_t hb_phase, hb_arg, hb_actions, hb_clock;
   int32_t hw;                               // device -> host: token slots of the stream's arena that hold something (InitDecoding resets them)
-  int32_t pad1[3];
+  int32_t pad1[3];                          // [0]: -DKH_SERVE_MARKERS progress word; [1]: device -> host, the kernel's status code behind ok == 0
 };
 static_assert(sizeof(ServeCtl) == 64, "one control block per 64-byte line");
 // kCmdInitCleared: InitDecoding whose reset of the token arena the HOST has done (a fill kernel over the whole chip: the
@@ -6452,6 +6452,7 @@ ServeKernel(const Utt *__restrict__ slots, SlotState *__restrict__ states, Serve
       __hip_atomic_store(&act_clock[s], t_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (the __threadfence + barrier above have put the slot's arenas and SlotState in memory: of the stores below only the
       // LAST one - what the host waits for - needs to order the others)
+      SysStoreRelaxed(&c->pad1[1], sh->status);   // (the code behind ok == 0)
       SysStoreRelaxed(&c->ok, ok ? 1 : 0);
       SysStoreRelaxed(&c->hw, sh->tok_hw);
       SysStoreRelaxed(&c->hb_actions, n_actions);
@@ -8488,6 +8489,17 @@ static int LaunchJobs(KhOnlineDecoder *o, const std::vector<Job> &jobs, int ll_s
   return KH_OK;
 }
 
+// a stream whose kernel status is not 0 -> the error the caller sees (KH_ECAPACITY: the message says which kind)
+static int StreamFailed(const char *what, int stream, int code, int frame) {
+  if (code == 10)
+    SetError("%s: stream %d failed at frame %d (code 10: %s); the stream's utterance is lost, the other streams are not affected",
+             what, stream, frame, StatusText(10));
+  else
+    SetError("%s: stream %d overflowed a decoder arena (code %d) at frame %d; see KH_DECODER_TOKENS_PER_FRAME / "
+             "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME", what, stream, code, frame);
+  return KH_ECAPACITY;
+}
+
 // kernel status of the listed streams -> error
 static int CheckStreams(KhOnlineDecoder *o, const int32_t *streams, int n, const char *what) {
   hipStream_t st = Stream();
@@ -8496,11 +8508,7 @@ static int CheckStreams(KhOnlineDecoder *o, const int32_t *streams, int n, const
   KH_HIP(hipStreamSynchronize(st));
   for (int i = 0; i < n; i++) {
     const SlotState &S = hs[streams[i]];
-    if (!S.ok) {
-      SetError("%s: stream %d overflowed a decoder arena (code %d) at frame %d; see KH_DECODER_TOKENS_PER_FRAME / "
-               "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME", what, streams[i], S.status, S.t);
-      return KH_ECAPACITY;
-    }
+    if (!S.ok) return StreamFailed(what, streams[i], S.status, S.t);
     o->frames[streams[i]] = S.t;
   }
   return KH_OK;
@@ -9027,11 +9035,8 @@ int kh_online_decoder_serve_poll(KhOnlineDecoder *o, const int32_t *streams, int
     const ServeCtl &c = o->serve_ctl[s];
     const int ack = __atomic_load_n(&c.ack_seq, __ATOMIC_ACQUIRE);
     const int dec = __atomic_load_n(&c.decoded, __ATOMIC_ACQUIRE);
-    if (!__atomic_load_n(&c.ok, __ATOMIC_ACQUIRE)) {
-      SetError("serving kernel: stream %d overflowed a decoder arena at frame %d; see KH_DECODER_TOKENS_PER_FRAME / "
-               "KH_DECODER_LINKS_PER_FRAME / KH_DECODER_STABLE_TOKENS_PER_FRAME", s, dec);
-      return KH_ECAPACITY;
-    }
+    if (!__atomic_load_n(&c.ok, __ATOMIC_ACQUIRE))
+      return StreamFailed("serving kernel", s, __atomic_load_n(&c.pad1[1], __ATOMIC_ACQUIRE), dec);
     const bool pending = ack != o->serve_seq[s];
     // (between an InitDecoding command and its acknowledgement `decoded` still belongs to the previous utterance)
     o->frames[s] = (pending && (c.cmd_op == kCmdInit || c.cmd_op == kCmdInitCleared)) ? 0 : dec;
