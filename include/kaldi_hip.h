@@ -752,6 +752,22 @@ int kh_discriminative_lattice_computations_parts(
     float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
     KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, double *stats);
 
+/* ... and in two halves, so that the NEXT batch's forward pass runs beside this batch's lattice work (a trainer's loop:
+ * forward(i) queued; begin(i); forward(i + 1) queued; end(i); begin(i + 1); ...).  _begin assembles, uploads and prepares
+ * the batch and queues every device step of the call on a stream of the call's own - the steps that read `posteriors`
+ * behind an event recorded on the library's stream at the moment of the call, i.e. behind the forward pass queued just
+ * before it - and returns without waiting.  _end waits for them, fills stats[5] and destroys the call (also when it
+ * returns an error).  posteriors / deriv must stay valid until _end; two calls may be in flight. */
+typedef struct KhDiscCall KhDiscCall;
+int kh_discriminative_lattice_computations_begin(
+    int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
+    const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
+    const float *const *state_final, const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights,
+    const int32_t *tid2pdf, const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
+    float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
+    KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, KhDiscCall **call);
+int kh_discriminative_lattice_computations_end(KhDiscCall *call, double *stats);
+
 /* CuMatrix::CompObjfAndDeriv (cudamatrix/cu-matrix.cc:1198-1248): the supervision
  * labels (row, column, weight) as three host arrays, output / deriv DEVICE matrices of
  * equal size: *tot_objf = sum w log output(r, c), *tot_weight = sum w,

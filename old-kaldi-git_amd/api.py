@@ -1404,9 +1404,35 @@ def _merge_keyed(rows, cols, weights, n_rows=None):
     return orow[:m].astype(np.int64), ocol[:m].astype(np.int64), ow[:m]
 
 
+class DiscriminativeCall:
+    """A discriminative_lattice_computations(..., begin=True) in flight: its device work is queued on a stream of its own
+    (kh_discriminative_lattice_computations_begin); end() waits for it and returns what the plain call returns."""
+
+    def __init__(self, handle, out, deriv, Ts, weights):
+        self._h, self.output, self.deriv, self._Ts, self._w = handle, out, deriv, Ts, weights
+
+    def end(self):
+        if self._h is None:
+            raise KhError("DiscriminativeCall.end() called twice")
+        st = np.zeros(5)
+        h, self._h = self._h, None
+        check(lib().kh_discriminative_lattice_computations_end(h, st.ctypes.data_as(capi.c_double_p)))
+        stats = dict(tot_t=float(self._Ts.sum()), tot_t_weighted=float((self._Ts * self._w).sum()), tot_num_count=float(st[0]),
+                     tot_num_objf=float(st[1]), tot_den_objf=float(st[2]))
+        return dict(stats=stats, deriv=self.deriv, output=self.output, objf=float(st[3]), weight=float(st[4]))
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().kh_discriminative_lattice_computations_end(self._h, np.zeros(5).ctypes.data_as(capi.c_double_p))
+                self._h = None
+        except Exception:
+            pass
+
+
 def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="smbr", acoustic_scale=0.1,
                                         drop_frames=False, one_silence_class=False, tid2phone=None,
-                                        silence_phones=(), den_lats=None):
+                                        silence_phones=(), den_lats=None, begin=False):
     """NnetDiscriminativeUpdater::Propagate + LatticeComputations
     (nnet2/nnet-compute-discriminative.cc:150-321) for a BATCH of examples, as one pipeline
     on the device: network forward -> CuMatrix::Lookup of the posteriors the numerator
@@ -1423,7 +1449,9 @@ def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="s
     den_lats: optionally the examples' lattices already concatenated (cat_lattices(...)), e.g. by the
     data loader's worker - the egs' den_lat entries are then not read.
     Returns dict(stats = NnetDiscriminativeStats fields, deriv = device matrix [sum T, num_pdfs]:
-    the derivative at the network output, output = the posteriors)."""
+    the derivative at the network output, output = the posteriors).
+    begin=True: returns a DiscriminativeCall as soon as the work is queued (the lattice steps on a stream of the call's
+    own); launch the NEXT batch's call - its forward pass runs beside this batch's sweeps - then .end() this one."""
     if criterion not in ("mmi", "smbr", "mpfe"):
         raise KhError('criterion must be "mmi", "mpfe" or "smbr"')
     n = len(egs)
@@ -1478,10 +1506,17 @@ def discriminative_lattice_computations(nnet, priors, tid2pdf, egs, criterion="s
         if timing:
             sys.stderr.write("[api timing] forward launched after %.2f ms, lattice arrays listed after %.2f ms\n"
                              % ((t_fwd - t_in) * 1e3, (time.perf_counter() - t_in) * 1e3))
+        if begin:
+            h = vp()
+            check(lib().kh_discriminative_lattice_computations_begin(
+                n, nst.ctypes.data_as(ip), *[c.ctypes.data_as(vp) for c in cols], *tail[:-1], C.byref(h)))
+            return DiscriminativeCall(h, out, deriv, Ts, weights)   # (the host arrays have been copied or uploaded)
         check(lib().kh_discriminative_lattice_computations_parts(
             n, nst.ctypes.data_as(ip), *[c.ctypes.data_as(vp) for c in cols], *tail))
         del keep
     else:
+        if begin:
+            raise KhError("begin=True takes the lattices by example (den_lats=None)")
         nl, soff, aoff, il, ns, g, a, fin = den_lats
         if nl != n:
             raise KhError("one denominator lattice per example")

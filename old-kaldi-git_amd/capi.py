@@ -230,6 +230,10 @@ SIGNATURES = {
     "kh_discriminative_lattice_computations_parts": (C.c_int, [C.c_int, c_int32_p, vp, vp, vp, vp, vp, vp,
                                                               c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, C.c_int, c_int32_p, C.c_int,
                                                               C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, c_double_p]),
+    "kh_discriminative_lattice_computations_begin": (C.c_int, [C.c_int, c_int32_p, vp, vp, vp, vp, vp, vp,
+                                                              c_int32_p, c_int32_p, c_float_p, c_int32_p, c_int32_p, C.c_int, c_int32_p, C.c_int,
+                                                              C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, C.POINTER(vp)]),
+    "kh_discriminative_lattice_computations_end": (C.c_int, [vp, c_double_p]),
     "kh_comp_objf_and_deriv": (C.c_int, [C.c_int, c_int32_p, c_int32_p, c_float_p, vp, KhMatrixDim, vp, KhMatrixDim, c_float_p, c_float_p]),
 }
 

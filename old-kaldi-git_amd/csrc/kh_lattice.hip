@@ -2076,13 +2076,14 @@ namespace {
 // and the sort of those keys - runs on a stream of its own, beside the forward pass that is still on the library's stream
 // when the call arrives (the caller launches the forward pass and does not wait for it): of the call's device work only the
 // pseudo log-likelihoods, the sweeps and the two kernels of the posterior algebra are left behind the forward pass.
-hipStream_t SideStream() {
-  static hipStream_t side = [] {
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s = nullptr; }
-    return s;
-  }();
-  return side;
+hipStream_t SideStream(int k = 0) {   // two of them: calls in flight together (begin / end) alternate
+  static hipStream_t side[2] = {nullptr, nullptr};
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (int i = 0; i < 2; i++)
+      if (hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side[i] = nullptr; }
+  });
+  return side[k & 1];
 }
 hipEvent_t SideEvent() {
   static hipEvent_t ev = [] {
@@ -2092,24 +2093,53 @@ hipEvent_t SideEvent() {
   }();
   return ev;
 }
-// (last declared = first destroyed: no device array of the call is freed while either stream may still use it)
-struct TwoStreamSync {
-  hipStream_t a, b;
-  ~TwoStreamSync() { (void)hipStreamSynchronize(a); if (b != a) (void)hipStreamSynchronize(b); (void)hipGetLastError(); }
+}  // namespace
+
+// One call of the discriminative lattice computations: what it holds on the device and on the host until its results
+// have been read.  (kh_discriminative_lattice_computations_begin / _end keep it between the two calls.)
+struct KhDiscCall {
+  LatBatch B;
+  DevArr<int32_t> d_ali, d_row_off, d_t2pdf, d_t2ph, d_sil, d_ali_pdf, d_has_num, d_vals, d_vals2;
+  DevArr<float> d_w, d_pri, d_post, d_seg;
+  DevArr<double> d_alpha, d_beta, d_tot, d_ac, d_num, d_as, d_bs, d_score, d_bscore, d_part;
+  DevArr<unsigned long long> d_keys, d_keys2;
+  DevArr<uint32_t> d_sort;
+  std::vector<float> w;              // the examples' weights (the statistics are weighted sums over the lattices)
+  double *pinned = nullptr;          // results of the device: 3 x 256 partial sums + five values per lattice
+  hipEvent_t ev_fwd = nullptr;       // (overlapped) everything queued on the library's stream when the call began
+  hipStream_t side = nullptr, tail = nullptr;   // preparation; the steps behind the network's output
+  int n_lats = 0, is_mmi = 0;
+  bool timing = false;
+  std::chrono::steady_clock::time_point t_in;
+  double tm_build = 0, tm_side = 0, tm_launched = 0;
+  // no device array of the call is freed while either stream may still use it
+  ~KhDiscCall() {
+    if (side) (void)hipStreamSynchronize(side);
+    if (tail && tail != side) (void)hipStreamSynchronize(tail);
+    if (ev_fwd) (void)hipEventDestroy(ev_fwd);
+    if (pinned) (void)hipHostFree(pinned);
+    (void)hipGetLastError();
+  }
 };
 
-int DiscriminativeImpl(
+namespace {
+constexpr int kEmitBlocks = 256;
+
+// Everything up to the copies of the results.  overlap: the steps behind the network's output run on the call's side stream
+// too, behind an event recorded on the library's stream NOW - what the caller queues there afterwards (the next batch's
+// forward pass) runs beside them.
+int DiscBegin(KhDiscCall &C,
     int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
     const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic, const float *state_final,
     const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights, const int32_t *tid2pdf,
     const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion, float acoustic_scale,
     int drop_frames, int one_silence_class, const float *priors, const float *posteriors, KhMatrixDim d_posteriors,
-    float *deriv, KhMatrixDim d_deriv, double *stats, bool labels_checked) {
+    float *deriv, KhMatrixDim d_deriv, bool labels_checked, bool overlap) {
   int rc = EnsureDevice();
   if (rc) return rc;
   KH_CHECK_ARG(n_lats > 0 && lat_state_offsets && arc_offsets && arc_ilabel && arc_nextstate && arc_graph && arc_acoustic &&
                state_final && num_ali && num_ali_offsets && eg_weights && tid2pdf && num_tids > 0 && priors && posteriors &&
-               deriv && stats && criterion >= 0 && criterion <= 2 && (criterion == 0 || tid2phone) && n_sil >= 0 &&
+               deriv && criterion >= 0 && criterion <= 2 && (criterion == 0 || tid2phone) && n_sil >= 0 &&
                (n_sil == 0 || silence_phones) && d_posteriors.rows == d_deriv.rows && d_posteriors.cols == d_deriv.cols);
   const int is_mmi = criterion == 0;
   const int total_rows = num_ali_offsets[n_lats], P = d_posteriors.cols;
@@ -2125,15 +2155,28 @@ int DiscriminativeImpl(
     }
   for (int i = 0; i < total_rows; i++) KH_CHECK_ARG(num_ali[i] > 0 && num_ali[i] <= num_tids);
   // KH_LATTICE_TIMING: the host's view of the call on stderr (ms since its entry)
-  const bool timing = getenv("KH_LATTICE_TIMING") != nullptr;
-  const auto t_in = std::chrono::steady_clock::now();
-  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
-  double tm_build = 0, tm_side = 0, tm_launched = 0;
+  C.timing = getenv("KH_LATTICE_TIMING") != nullptr;
+  C.t_in = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C.t_in).count(); };
+  double &tm_build = C.tm_build, &tm_side = C.tm_side, &tm_launched = C.tm_launched;
   hipStream_t st = Stream();
-  hipStream_t side = SideStream();
+  static std::atomic<int> n_calls{0};
+  hipStream_t side = SideStream(overlap ? n_calls.fetch_add(1) : 0);
   hipEvent_t side_ev = SideEvent();
-  if (side == nullptr || side_ev == nullptr || getenv("KH_LATTICE_ONE_STREAM") != nullptr) side = st;
-  LatBatch B;
+  if (side == nullptr || side_ev == nullptr || getenv("KH_LATTICE_ONE_STREAM") != nullptr) {
+    if (overlap) { SetError("kh_discriminative_lattice_computations_begin: no second stream"); return KH_EDEVICE; }
+    side = st;
+  }
+  hipStream_t ts = overlap ? side : st;   // where the steps behind the network's output run
+  C.side = side; C.tail = ts; C.n_lats = n_lats; C.is_mmi = is_mmi;
+  if (overlap) {
+    KH_HIP(hipEventCreateWithFlags(&C.ev_fwd, hipEventDisableTiming));
+    KH_HIP(hipEventRecord(C.ev_fwd, st));
+  }
+  KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&C.pinned), sizeof(double) * (3 * kEmitBlocks + 5 * static_cast<size_t>(n_lats)), hipHostMallocDefault));
+  memset(C.pinned, 0, sizeof(double) * (3 * kEmitBlocks + 5 * static_cast<size_t>(n_lats)));
+  C.w.assign(eg_weights, eg_weights + n_lats);
+  LatBatch &B = C.B;
   // (MMI needs LatticeForwardBackward only: the dataflow preparation and sweeps; the MPE / sMBR kernels sweep by level)
   rc = B.Build(n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, side,
                !is_mmi || getenv("KH_LATTICE_LEVELS") != nullptr);
@@ -2149,15 +2192,15 @@ int DiscriminativeImpl(
     }
   const int64_t A = B.total_arcs;
   if (A >= (1ll << 31)) { SetError("kh_discriminative_lattice_computations: %lld arcs in one batch (the sort takes < 2^31)", static_cast<long long>(A)); return KH_EINVAL; }
-  DevArr<int32_t> d_ali, d_row_off, d_t2pdf, d_t2ph, d_sil, d_ali_pdf, d_has_num, d_vals, d_vals2;
-  DevArr<float> d_w, d_pri, d_post, d_seg;
-  DevArr<double> d_alpha, d_beta, d_tot, d_ac, d_num, d_as, d_bs, d_score, d_bscore, d_part;
-  DevArr<unsigned long long> d_keys, d_keys2;
+  auto &d_ali = C.d_ali; auto &d_row_off = C.d_row_off; auto &d_t2pdf = C.d_t2pdf; auto &d_t2ph = C.d_t2ph; auto &d_sil = C.d_sil;
+  auto &d_ali_pdf = C.d_ali_pdf; auto &d_has_num = C.d_has_num; auto &d_vals = C.d_vals; auto &d_vals2 = C.d_vals2;
+  auto &d_w = C.d_w; auto &d_pri = C.d_pri; auto &d_post = C.d_post; auto &d_seg = C.d_seg;
+  auto &d_alpha = C.d_alpha; auto &d_beta = C.d_beta; auto &d_tot = C.d_tot; auto &d_ac = C.d_ac; auto &d_num = C.d_num;
+  auto &d_as = C.d_as; auto &d_bs = C.d_bs; auto &d_score = C.d_score; auto &d_bscore = C.d_bscore; auto &d_part = C.d_part;
+  auto &d_keys = C.d_keys; auto &d_keys2 = C.d_keys2; auto &d_sort = C.d_sort;
   std::vector<int32_t> h_ali(num_ali, num_ali + total_rows), h_row_off(num_ali_offsets, num_ali_offsets + n_lats + 1),
       h_t2pdf(tid2pdf, tid2pdf + num_tids + 1);
   std::vector<float> h_w(eg_weights, eg_weights + n_lats), h_pri(priors, priors + P);
-  DevArr<uint32_t> d_sort;
-  TwoStreamSync sync_before_free{side, st};
   if ((rc = d_ali.Upload(h_ali, side)) || (rc = d_row_off.Upload(h_row_off, side)) || (rc = d_t2pdf.Upload(h_t2pdf, side)) ||
       (rc = d_w.Upload(h_w, side)) || (rc = d_pri.Upload(h_pri, side)))
     return rc;
@@ -2166,7 +2209,6 @@ int DiscriminativeImpl(
     if ((rc = d_t2ph.Upload(h_t2ph, side)) || (rc = d_sil.Upload(h_sil, side))) return rc;
     KH_HIP(hipStreamSynchronize(side));   // (the vectors go out of scope)
   }
-  constexpr int kEmitBlocks = 256;
   if (d_ali_pdf.Alloc(total_rows) || d_has_num.Alloc(total_rows) || d_vals.Alloc(A) || d_vals2.Alloc(A) || d_keys.Alloc(A) ||
       d_keys2.Alloc(A) || d_post.Alloc(A) || d_seg.Alloc(A) || d_tot.Alloc(n_lats) || d_ac.Alloc(n_lats) || d_num.Alloc(n_lats) ||
       d_part.Alloc(3 * kEmitBlocks) ||
@@ -2187,40 +2229,41 @@ int DiscriminativeImpl(
   while (lo_bits < 31 && (static_cast<unsigned long long>(std::max(1, d_posteriors.cols - 1)) >> lo_bits) != 0) lo_bits++;
   int in_second = 0;
   if ((rc = SortPairs64(d_keys.p, d_vals.p, d_keys2.p, d_vals2.p, A, lo_bits, hi_bits, d_sort.p, side, &in_second))) return rc;
-  if (side != st) {
+  if (overlap) {
+    KH_HIP(hipStreamWaitEvent(side, C.ev_fwd, 0));
+  } else if (side != st) {
     KH_HIP(hipEventRecord(side_ev, side));
     KH_HIP(hipStreamWaitEvent(st, side_ev, 0));
   }
   tm_side = since();
-  // ---- behind the forward pass (the library's stream)
+  // ---- behind the forward pass (the library's stream; overlapped: the side stream, behind the event)
   for (int r = 0; r < d_deriv.rows && d_deriv.stride != d_deriv.cols; r++)
-    KH_HIP(hipMemsetAsync(deriv + static_cast<size_t>(r) * d_deriv.stride, 0, sizeof(float) * d_deriv.cols, st));
+    KH_HIP(hipMemsetAsync(deriv + static_cast<size_t>(r) * d_deriv.stride, 0, sizeof(float) * d_deriv.cols, ts));
   if (d_deriv.stride == d_deriv.cols)
-    KH_HIP(hipMemsetAsync(deriv, 0, sizeof(float) * static_cast<size_t>(d_deriv.rows) * d_deriv.cols, st));
-  hipLaunchKernelGGL(PseudoLikeKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_ilabel.p, B.d_times.p,
+    KH_HIP(hipMemsetAsync(deriv, 0, sizeof(float) * static_cast<size_t>(d_deriv.rows) * d_deriv.cols, ts));
+  hipLaunchKernelGGL(PseudoLikeKernel, dim3(n_lats), dim3(kThreads), 0, ts, B.d_descs.p, B.d_arc_off.p, B.d_ilabel.p, B.d_times.p,
                      d_row_off.p, d_t2pdf.p, posteriors, d_posteriors.stride, d_pri.p, acoustic_scale, total_rows, B.d_a.p,
                      d_keys.p, d_vals.p, 2);
   KH_LAUNCH_CHECK();
-  std::vector<double> h_num(n_lats, 0.0), h_tot(n_lats, 0.0);
   if (is_mmi) {
-    hipLaunchKernelGGL(NumLikeKernel, dim3(n_lats), dim3(kThreads), 0, st, d_row_off.p, d_ali.p, d_t2pdf.p, posteriors,
+    hipLaunchKernelGGL(NumLikeKernel, dim3(n_lats), dim3(kThreads), 0, ts, d_row_off.p, d_ali.p, d_t2pdf.p, posteriors,
                        d_posteriors.stride, d_pri.p, acoustic_scale, d_num.p);
     if (d_alpha.Alloc(B.total_states) || d_beta.Alloc(B.total_states)) return KH_ENOMEM;
     if (B.has_levels) {
-      hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_next.p,
+      hipLaunchKernelGGL(ForwardBackwardKernel, dim3(n_lats), dim3(kThreads), 0, ts, B.d_descs.p, B.d_arc_off.p, B.d_next.p,
                          B.d_g.p, B.d_a.p, B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p,
                          B.d_final_list.p, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON));
       KH_LAUNCH_CHECK();
-    } else if ((rc = LaunchForwardBackwardDF(B, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON), st))) {
+    } else if ((rc = LaunchForwardBackwardDF(B, d_alpha.p, d_beta.p, d_post.p, d_tot.p, d_ac.p, log(DBL_EPSILON), ts))) {
       return rc;
     }
   } else {
-    if ((rc = RunAlphaBeta(B, d_alpha, d_beta, d_tot, 0, st))) return rc;
+    if ((rc = RunAlphaBeta(B, d_alpha, d_beta, d_tot, 0, ts))) return rc;
     if (d_as.Alloc(B.total_states) || d_bs.Alloc(B.total_states) || d_score.Alloc(n_lats) || d_bscore.Alloc(n_lats)) return KH_ENOMEM;
     MpeArgs m;
     m.tid2phone = d_t2ph.p; m.tid2pdf = d_t2pdf.p; m.sil = d_sil.p; m.num_ali = d_ali.p; m.ali_off = d_row_off.p;
     m.times = B.d_times.p; m.ilabel = B.d_ilabel.p; m.n_sil = n_sil; m.is_mpfe = criterion == 2; m.one_silence_class = one_silence_class;
-    hipLaunchKernelGGL(MpeKernel, dim3(n_lats), dim3(kThreads), 0, st, B.d_descs.p, B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p,
+    hipLaunchKernelGGL(MpeKernel, dim3(n_lats), dim3(kThreads), 0, ts, B.d_descs.p, B.d_arc_off.p, B.d_next.p, B.d_g.p, B.d_a.p,
                        B.d_fin.p, B.d_level_off.p, B.d_level_states.p, B.d_in_off.p, B.d_in_arc.p, B.d_in_src.p, B.d_final_list.p,
                        d_alpha.p, d_beta.p, d_tot.p, d_as.p, d_bs.p, m, d_post.p, d_score.p, d_bscore.p);
     KH_LAUNCH_CHECK();
@@ -2228,36 +2271,42 @@ int DiscriminativeImpl(
   const unsigned long long *s_keys = in_second ? d_keys2.p : d_keys.p;
   const int32_t *s_vals = in_second ? d_vals2.p : d_vals.p;
   const int seg_blocks = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(4096, (A + 255) / 256)));
-  hipLaunchKernelGGL(SegmentKernel, dim3(seg_blocks), dim3(256), 0, st, A, s_keys, s_vals, B.d_ilabel.p, d_post.p, total_rows,
+  hipLaunchKernelGGL(SegmentKernel, dim3(seg_blocks), dim3(256), 0, ts, A, s_keys, s_vals, B.d_ilabel.p, d_post.p, total_rows,
                      is_mmi ? -1.0f : 1.0f, is_mmi ? d_ali_pdf.p : nullptr, d_seg.p, d_has_num.p);
   KH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(EmitKernel, dim3(kEmitBlocks), dim3(kThreads), 0, st, A, s_keys, d_seg.p, total_rows, is_mmi, drop_frames,
+  hipLaunchKernelGGL(EmitKernel, dim3(kEmitBlocks), dim3(kThreads), 0, ts, A, s_keys, d_seg.p, total_rows, is_mmi, drop_frames,
                      d_ali_pdf.p, d_has_num.p, d_row_off.p, n_lats, d_w.p, posteriors, d_posteriors.stride, deriv, d_deriv.stride,
                      d_part.p);
   KH_LAUNCH_CHECK();
   tm_launched = since();
-  // (the copies to the host wait for the device: issued behind the last launch)
-  std::vector<double> h_part(3 * kEmitBlocks);
-  KH_HIP(hipMemcpyAsync(h_part.data(), d_part.p, sizeof(double) * h_part.size(), hipMemcpyDeviceToHost, st));
+  // (the copies to the host wait for the device: issued behind the last launch, into pinned memory - the call does not)
+  double *h_part = C.pinned, *h_num = h_part + 3 * kEmitBlocks, *h_tot = h_num + n_lats, *h_beta0 = h_tot + n_lats,
+         *h_fwd = h_beta0 + n_lats, *h_bscore = h_fwd + n_lats;
+  KH_HIP(hipMemcpyAsync(h_part, d_part.p, sizeof(double) * 3 * kEmitBlocks, hipMemcpyDeviceToHost, ts));
   if (is_mmi) {
-    KH_HIP(hipMemcpyAsync(h_num.data(), d_num.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-    KH_HIP(hipMemcpyAsync(h_tot.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-  } else {
-    KH_HIP(hipMemcpyAsync(h_tot.data(), d_score.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-  }
-  std::vector<double> h_beta0, h_fwd, h_bscore;
-  if (!is_mmi) {   // the reference's forward / backward agreement checks (lattice-functions.cc:808, :909)
-    h_beta0.resize(n_lats); h_fwd.resize(n_lats); h_bscore.resize(n_lats);
-    KH_HIP(hipMemcpyAsync(h_fwd.data(), d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
-    KH_HIP(hipMemcpyAsync(h_bscore.data(), d_bscore.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, st));
+    KH_HIP(hipMemcpyAsync(h_num, d_num.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, ts));
+    KH_HIP(hipMemcpyAsync(h_tot, d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, ts));
+  } else {   // + the reference's forward / backward agreement checks (lattice-functions.cc:808, :909)
+    KH_HIP(hipMemcpyAsync(h_tot, d_score.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, ts));
+    KH_HIP(hipMemcpyAsync(h_fwd, d_tot.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, ts));
+    KH_HIP(hipMemcpyAsync(h_bscore, d_bscore.p, sizeof(double) * n_lats, hipMemcpyDeviceToHost, ts));
     for (int l = 0; l < n_lats; l++)
-      KH_HIP(hipMemcpyAsync(&h_beta0[l], d_beta.p + lat_state_offsets[l], sizeof(double), hipMemcpyDeviceToHost, st));
+      KH_HIP(hipMemcpyAsync(&h_beta0[l], d_beta.p + lat_state_offsets[l], sizeof(double), hipMemcpyDeviceToHost, ts));
   }
-  KH_HIP(hipStreamSynchronize(st));
-  if (timing)
+  return KH_OK;
+}
+
+// Waits for the call's device work and turns its results into the five statistics.
+int DiscEnd(KhDiscCall &C, double *stats) {
+  const int n_lats = C.n_lats;
+  const double *h_part = C.pinned, *h_num = h_part + 3 * kEmitBlocks, *h_tot = h_num + n_lats, *h_beta0 = h_tot + n_lats,
+               *h_fwd = h_beta0 + n_lats, *h_bscore = h_fwd + n_lats;
+  KH_HIP(hipStreamSynchronize(C.tail));
+  if (C.timing)
     fprintf(stderr, "[kh_lattice timing] lattices prepared %.2f, side stream loaded %.2f, everything launched %.2f, device done %.2f ms\n",
-            tm_build, tm_side, tm_launched, since());
-  if (!is_mmi)
+            C.tm_build, C.tm_side, C.tm_launched,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - C.t_in).count());
+  if (!C.is_mmi)
     for (int l = 0; l < n_lats; l++) {
       if (!ApproxEqualD(h_fwd[l], h_beta0[l], 1e-6)) {
         SetError("lattice %d: Total forward probability over lattice = %g, while total backward probability = %g", l, h_fwd[l], h_beta0[l]);
@@ -2271,8 +2320,8 @@ int DiscriminativeImpl(
   double objf = 0.0, wsum = 0.0, pos = 0.0, num_objf = 0.0, den_objf = 0.0;
   for (int b = 0; b < kEmitBlocks; b++) { objf += h_part[3 * b]; wsum += h_part[3 * b + 1]; pos += h_part[3 * b + 2]; }
   for (int l = 0; l < n_lats; l++) {
-    num_objf += static_cast<double>(eg_weights[l]) * h_num[l];     // :255
-    den_objf += static_cast<double>(eg_weights[l]) * h_tot[l];     // :285
+    num_objf += static_cast<double>(C.w[l]) * h_num[l];     // :255
+    den_objf += static_cast<double>(C.w[l]) * h_tot[l];     // :285
   }
   stats[0] = pos;        // tot_num_count :291-299
   stats[1] = num_objf;   // tot_num_objf (MMI)
@@ -2280,6 +2329,22 @@ int DiscriminativeImpl(
   stats[3] = objf;       // CompObjfAndDeriv's tot_objf
   stats[4] = wsum;       // ... tot_weight
   return KH_OK;
+}
+
+int DiscriminativeImpl(
+    int n_lats, const int32_t *lat_state_offsets, const int64_t *arc_offsets, const int32_t *arc_ilabel,
+    const int32_t *arc_nextstate, const float *arc_graph, const float *arc_acoustic, const float *state_final,
+    const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights, const int32_t *tid2pdf,
+    const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion, float acoustic_scale,
+    int drop_frames, int one_silence_class, const float *priors, const float *posteriors, KhMatrixDim d_posteriors,
+    float *deriv, KhMatrixDim d_deriv, double *stats, bool labels_checked) {
+  KH_CHECK_ARG(stats);
+  KhDiscCall C;
+  int rc = DiscBegin(C, n_lats, lat_state_offsets, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, num_ali,
+                     num_ali_offsets, eg_weights, tid2pdf, tid2phone, num_tids, silence_phones, n_sil, criterion, acoustic_scale,
+                     drop_frames, one_silence_class, priors, posteriors, d_posteriors, deriv, d_deriv, labels_checked, false);
+  if (!rc) rc = DiscEnd(C, stats);
+  return rc;
 }
 
 // pinned staging of kh_discriminative_lattice_computations_parts (kept across calls, grown on demand)
@@ -2313,19 +2378,19 @@ extern "C" int kh_discriminative_lattice_computations(
                             false);
 }
 
-// The same with the lattices as they sit in the examples, one set of arrays per lattice (NnetDiscriminativeUpdater gets its
-// examples one by one, nnet-compute-discriminative.cc:150-175): the batch arrays are assembled here - a few host threads,
-// straight into pinned memory, while the forward pass the caller has launched runs - instead of by the caller (round 5: 6 ms
-// of numpy concatenation per 256 lattices, between a 10 ms forward pass and 3.5 ms of lattice work).
-extern "C" int kh_discriminative_lattice_computations_parts(
-    int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
-    const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
-    const float *const *state_final, const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights,
-    const int32_t *tid2pdf, const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
-    float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
-    KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, double *stats) {
-  int rc = EnsureDevice();
-  if (rc) return rc;
+// The lattices as they sit in the examples, one set of arrays per lattice (NnetDiscriminativeUpdater gets its examples one by
+// one, nnet-compute-discriminative.cc:150-175) -> the batch arrays, assembled by a few host threads straight into pinned
+// memory while the forward pass the caller has launched runs (round 5: 6 ms of numpy concatenation per 256 lattices,
+// between a 10 ms forward pass and 3.5 ms of lattice work).  The caller holds g_stage.mu until the uploads have completed.
+namespace {
+struct BatchArrays {
+  int32_t *soff, *il, *ns;
+  int64_t *aoff;
+  float *g, *a, *fin;
+};
+int AssembleParts(int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
+                  const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
+                  const float *const *state_final, int num_tids, BatchArrays *out) {
   const auto t_parts = std::chrono::steady_clock::now();
   KH_CHECK_ARG(n_lats > 0 && n_states && arc_offsets && arc_ilabel && arc_nextstate && arc_graph && arc_acoustic && state_final);
   std::vector<int64_t> sbase(n_lats + 1, 0), abase(n_lats + 1, 0);
@@ -2337,12 +2402,12 @@ extern "C" int kh_discriminative_lattice_computations_parts(
   }
   const int64_t S = sbase[n_lats], A = abase[n_lats];
   KH_CHECK_ARG(S < (1ll << 31));
-  std::lock_guard<std::mutex> lock(g_stage.mu);
   auto up = [](size_t b) { return (b + 63) & ~static_cast<size_t>(63); };
   const size_t o_soff = 0, o_aoff = o_soff + up(sizeof(int32_t) * (n_lats + 1)), o_il = o_aoff + up(sizeof(int64_t) * (S + 1)),
                o_ns = o_il + up(sizeof(int32_t) * A), o_g = o_ns + up(sizeof(int32_t) * A), o_a = o_g + up(sizeof(float) * A),
                o_fin = o_a + up(sizeof(float) * A), total = o_fin + up(sizeof(float) * S);
-  if ((rc = g_stage.Reserve(total))) return rc;
+  int rc = g_stage.Reserve(total);
+  if (rc) return rc;
   int32_t *soff = reinterpret_cast<int32_t *>(g_stage.p + o_soff), *il = reinterpret_cast<int32_t *>(g_stage.p + o_il),
           *ns = reinterpret_cast<int32_t *>(g_stage.p + o_ns);
   int64_t *aoff = reinterpret_cast<int64_t *>(g_stage.p + o_aoff);
@@ -2382,7 +2447,62 @@ extern "C" int kh_discriminative_lattice_computations_parts(
   if (getenv("KH_LATTICE_TIMING") != nullptr)
     fprintf(stderr, "[kh_lattice timing] batch assembled in pinned memory: %.2f ms (%d threads)\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parts).count(), n_threads);
-  return DiscriminativeImpl(n_lats, soff, aoff, il, ns, g, a, fin, num_ali, num_ali_offsets, eg_weights, tid2pdf, tid2phone, num_tids,
-                            silence_phones, n_sil, criterion, acoustic_scale, drop_frames, one_silence_class, priors, posteriors,
-                            d_posteriors, deriv, d_deriv, stats, true);
+  *out = BatchArrays{soff, il, ns, aoff, g, a, fin};
+  return KH_OK;
+}
+}  // namespace
+
+extern "C" int kh_discriminative_lattice_computations_parts(
+    int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
+    const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
+    const float *const *state_final, const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights,
+    const int32_t *tid2pdf, const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
+    float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
+    KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, double *stats) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_stage.mu);
+  BatchArrays b;
+  if ((rc = AssembleParts(n_lats, n_states, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, num_tids, &b)))
+    return rc;
+  return DiscriminativeImpl(n_lats, b.soff, b.aoff, b.il, b.ns, b.g, b.a, b.fin, num_ali, num_ali_offsets, eg_weights, tid2pdf, tid2phone,
+                            num_tids, silence_phones, n_sil, criterion, acoustic_scale, drop_frames, one_silence_class, priors,
+                            posteriors, d_posteriors, deriv, d_deriv, stats, true);
+}
+
+// The same in two halves.  _begin: the batch is assembled, uploaded and prepared, and EVERY device step of the call is queued
+// on a stream of the call's own - the steps that read `posteriors` behind an event recorded on the library's stream at the
+// moment of the call (so: behind the forward pass the caller queued just before); the call returns without waiting.  What
+// the caller queues on the library's stream afterwards - the NEXT batch's forward pass - runs beside this batch's sweeps.
+// _end waits for the call's stream, fills stats[5] and destroys the call (also when it returns an error).  posteriors and
+// deriv must stay valid until then; at most two calls should be in flight (they alternate between two streams).
+extern "C" int kh_discriminative_lattice_computations_begin(
+    int n_lats, const int32_t *n_states, const int64_t *const *arc_offsets, const int32_t *const *arc_ilabel,
+    const int32_t *const *arc_nextstate, const float *const *arc_graph, const float *const *arc_acoustic,
+    const float *const *state_final, const int32_t *num_ali, const int32_t *num_ali_offsets, const float *eg_weights,
+    const int32_t *tid2pdf, const int32_t *tid2phone, int num_tids, const int32_t *silence_phones, int n_sil, int criterion,
+    float acoustic_scale, int drop_frames, int one_silence_class, const float *priors, const float *posteriors,
+    KhMatrixDim d_posteriors, float *deriv, KhMatrixDim d_deriv, KhDiscCall **call) {
+  int rc = EnsureDevice();
+  if (rc) return rc;
+  KH_CHECK_ARG(call);
+  *call = nullptr;
+  std::lock_guard<std::mutex> lock(g_stage.mu);
+  BatchArrays b;
+  if ((rc = AssembleParts(n_lats, n_states, arc_offsets, arc_ilabel, arc_nextstate, arc_graph, arc_acoustic, state_final, num_tids, &b)))
+    return rc;
+  KhDiscCall *C = new KhDiscCall();
+  rc = DiscBegin(*C, n_lats, b.soff, b.aoff, b.il, b.ns, b.g, b.a, b.fin, num_ali, num_ali_offsets, eg_weights, tid2pdf, tid2phone,
+                 num_tids, silence_phones, n_sil, criterion, acoustic_scale, drop_frames, one_silence_class, priors, posteriors,
+                 d_posteriors, deriv, d_deriv, true, true);
+  if (rc) { delete C; return rc; }
+  *call = C;
+  return KH_OK;
+}
+
+extern "C" int kh_discriminative_lattice_computations_end(KhDiscCall *call, double *stats) {
+  KH_CHECK_ARG(call && stats);
+  const int rc = DiscEnd(*call, stats);
+  delete call;
+  return rc;
 }

@@ -126,3 +126,28 @@ def test_forward_pass_queued_without_waiting_gives_the_same_output(api):
     torch.cuda.synchronize()
     assert np.array_equal(off_w, off_1) and np.array_equal(off_w, off_2)
     assert torch.equal(want, got1) and torch.equal(want, got2)
+
+
+def test_two_calls_in_flight_give_the_results_of_one_after_the_other(api):
+    """kh_discriminative_lattice_computations_begin / _end: batch A begun, batch B begun (its forward pass queued while A's
+    lattice steps run on A's own stream), then both ended - derivative and statistics are the plain call's, bit for bit."""
+    rng = np.random.default_rng(59)
+    nnet, priors, tid2pdf, tid2phone, egs = make_examples(api, rng)
+    batches = [egs, [egs[2], egs[0]], egs[:1]]
+    for criterion in ("mmi", "smbr"):
+        kw = dict(criterion=criterion, acoustic_scale=0.1, drop_frames=True, tid2phone=tid2phone, silence_phones=[1, 2])
+        want = [api.discriminative_lattice_computations(nnet, priors, tid2pdf, b, **kw) for b in batches]
+        calls = [api.discriminative_lattice_computations(nnet, priors, tid2pdf, b, begin=True, **kw) for b in batches[:2]]
+        got = [calls[0].end()]
+        calls.append(api.discriminative_lattice_computations(nnet, priors, tid2pdf, batches[2], begin=True, **kw))
+        got += [calls[1].end(), calls[2].end()]
+        torch.cuda.synchronize()
+        for w, g in zip(want, got):
+            assert torch.equal(w["deriv"], g["deriv"]) and torch.equal(w["output"], g["output"])
+            assert w["stats"] == g["stats"] and w["objf"] == g["objf"] and w["weight"] == g["weight"]
+        with pytest.raises(api.KhError):
+            calls[0].end()
+    # a call that is dropped without end() releases what it holds
+    c = api.discriminative_lattice_computations(nnet, priors, tid2pdf, egs, begin=True, criterion="mmi")
+    del c
+    torch.cuda.synchronize()

@@ -231,6 +231,19 @@ def lattice_fb_cfg5(api, torch, N=256, T=400):
                                                              drop_frames=True, tid2phone=t2ph, silence_phones=[1, 2])
         dt = _timeit(fn, lambda: torch.cuda.synchronize(), reps=2)
         res["pipeline_" + crit] = {"ms_per_batch": dt * 1e3, "frames_per_s": N * T / dt, "arcs_per_s": arcs / dt}
+    # a trainer's loop: batch i + 1 begun (its forward pass queued) before batch i is ended - the forward pass runs beside the
+    # previous batch's lattice steps (kh_discriminative_lattice_computations_begin / _end)
+    def piped(k=6):
+        prev = None
+        for _ in range(k):
+            c = api.discriminative_lattice_computations(nnet, priors, g["tid2pdf"], egs, criterion="mmi", acoustic_scale=0.1,
+                                                        drop_frames=True, tid2phone=t2ph, silence_phones=[1, 2], begin=True)
+            if prev is not None:
+                prev.end()
+            prev = c
+        prev.end()
+    dt = _timeit(piped, lambda: torch.cuda.synchronize(), reps=2) / 6
+    res["pipeline_mmi_two_in_flight"] = {"ms_per_batch": dt * 1e3, "frames_per_s": N * T / dt, "arcs_per_s": arcs / dt}
     # the same with the lattices of the batch concatenated ahead (a data loader's job), and its parts
     cat = api.cat_lattices(lats)
     fn = lambda: api.discriminative_lattice_computations(nnet, priors, g["tid2pdf"], egs, criterion="mmi", acoustic_scale=0.1,
