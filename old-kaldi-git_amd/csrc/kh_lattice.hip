@@ -2093,6 +2093,28 @@ hipEvent_t SideEvent() {
   }();
   return ev;
 }
+// Small pinned blocks for the results of the discriminative calls, kept for reuse: hipHostFree waits for the whole device -
+// freed per call it made _end(i) wait for the forward pass of batch i + 1.
+struct PinnedResults {
+  std::mutex mu;
+  struct Slab { double *p; size_t n; bool used; };
+  std::vector<Slab> slabs;
+  double *Take(size_t n) {
+    std::lock_guard<std::mutex> l(mu);
+    for (Slab &s : slabs)
+      if (!s.used && s.n >= n) { s.used = true; return s.p; }
+    double *p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&p), sizeof(double) * n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    slabs.push_back(Slab{p, n, true});
+    return p;
+  }
+  void Give(double *p) {
+    std::lock_guard<std::mutex> l(mu);
+    for (Slab &s : slabs)
+      if (s.p == p) s.used = false;
+  }
+};
+PinnedResults g_results;
 }  // namespace
 
 // One call of the discriminative lattice computations: what it holds on the device and on the host until its results
@@ -2117,7 +2139,7 @@ struct KhDiscCall {
     if (side) (void)hipStreamSynchronize(side);
     if (tail && tail != side) (void)hipStreamSynchronize(tail);
     if (ev_fwd) (void)hipEventDestroy(ev_fwd);
-    if (pinned) (void)hipHostFree(pinned);
+    if (pinned) g_results.Give(pinned);
     (void)hipGetLastError();
   }
 };
@@ -2173,7 +2195,8 @@ int DiscBegin(KhDiscCall &C,
     KH_HIP(hipEventCreateWithFlags(&C.ev_fwd, hipEventDisableTiming));
     KH_HIP(hipEventRecord(C.ev_fwd, st));
   }
-  KH_HIP(hipHostMalloc(reinterpret_cast<void **>(&C.pinned), sizeof(double) * (3 * kEmitBlocks + 5 * static_cast<size_t>(n_lats)), hipHostMallocDefault));
+  C.pinned = g_results.Take(3 * kEmitBlocks + 5 * static_cast<size_t>(n_lats));
+  if (C.pinned == nullptr) { SetError("kh_discriminative_lattice_computations: cannot allocate pinned host memory"); return KH_ENOMEM; }
   memset(C.pinned, 0, sizeof(double) * (3 * kEmitBlocks + 5 * static_cast<size_t>(n_lats)));
   C.w.assign(eg_weights, eg_weights + n_lats);
   LatBatch &B = C.B;
