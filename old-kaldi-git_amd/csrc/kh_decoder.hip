@@ -5054,6 +5054,14 @@ __device__ __forceinline__ void StoreFlag(P p, uint8_t v) {
 // final_pass: the backward loop of FinalizeDecoding :581-586 instead - every frame below `cur`, PruneForwardLinks(f, delta = 0)
 // + PruneTokensForFrame(f + 1), whatever the flags say.
 __device__ void PruneActiveTokens(const Utt &u, const Params &p, int cur, float delta, Blk &sh, bool final_pass = false) {
+  // The bounds of frame `cur` were stored by thread 0 at the end of the previous frame's iteration, and when that frame's
+  // closure ran in LDS (ClearHash returns at once) NO barrier lies between that store and this function's first visit,
+  // which reads them (frame_b / frame_e[f + 1]) with one load per lane: a wave ahead of wave 0 read the words a previous
+  // utterance had left there, took another routine or indexed LDS and memory with them.  That was round 6's serving
+  // defect (one stream in ~3 % of the stress harness's runs spinning in PruneFrameLds, or a memory-access fault; always
+  // the first visit; 77 runs of a debug build that happened to put a barrier here were clean, 4 of the last 20 without it
+  // were not).
+  KhSync();
   if (u.phase_cycles != nullptr && KH_TIDX == 0 && !final_pass) sh->phase[12] += 1;
   // every frame below conv_upto has been visited (a new frame has must_prune_forward_links set, and the
   // loop below cannot stop above it)
