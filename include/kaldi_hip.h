@@ -338,7 +338,10 @@ typedef struct KhDecodeStats {
   int32_t num_links;          /* surviving forward links (lattice arcs) */
   int64_t arcs_expanded;      /* emitting+epsilon arcs visited (roofline unit) */
   int64_t tokens_created;
-  int32_t status;             /* 0 ok; KH_ECAPACITY if an arena overflowed */
+  int32_t status;             /* 0 ok; else the kernel's code: 1-5 a token / link arena or a per-frame cap overflowed, 6 the lattice
+                               * did not fit the pool (retried with the exact size), 7 survivor lists full, 8-9 the reference order's
+                               * list could not be built, 10 internal inconsistency (a frame's epsilon links are not a DAG: the
+                               * backward pruning's fixed point did not stop) - the getters return KH_ECAPACITY with the text */
   int32_t max_tokens_frame;
 } KhDecodeStats;
 int kh_decoder_get_stats(const KhDecoder *dec, int utt, KhDecodeStats *stats);
