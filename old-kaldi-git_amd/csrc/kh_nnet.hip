@@ -39,6 +39,7 @@ struct KhNnet {
   // kh_nnet_compute_async: the descriptors and activation buffers of a call that returned before its work had finished -
   // released at the start of the next call on this handle (behind a wait for the stream) or with the handle
   std::vector<void *> held;
+  hipStream_t held_stream = nullptr;   // the stream that call's work was queued on (kh_set_stream may have changed since)
 };
 
 namespace {
@@ -186,7 +187,7 @@ void kh_nnet_destroy(KhNnet *n) {
   }
   PoolFree(n->log_priors);
   if (!n->held.empty()) {
-    (void)hipStreamSynchronize(Stream());
+    (void)hipStreamSynchronize(n->held_stream);
     for (void *p : n->held) PoolFree(p);
   }
   delete n;
@@ -317,7 +318,7 @@ int NnetComputeImpl(KhNnet *n, const float *feats, int feat_stride,
   if (rc) return rc;
   KH_CHECK_ARG(n && feats && utt_off && out && n_utts > 0 && !n->comps.empty());
   if (!n->held.empty()) {   // what an asynchronous call left in use
-    KH_HIP(hipStreamSynchronize(Stream()));
+    KH_HIP(hipStreamSynchronize(n->held_stream));
     for (void *p : n->held) PoolFree(p);
     n->held.clear();
   }
@@ -476,6 +477,7 @@ int NnetComputeImpl(KhNnet *n, const float *feats, int feat_stride,
     }
     for (DevBuf *b : {&d_descs, &buf[0], &buf[1], &d_index})
       if (b->p) { n->held.push_back(b->p); b->p = nullptr; }
+    n->held_stream = st;
     return KH_OK;
   };
   for (int i = 0; i < nc; i++) {
